@@ -1,0 +1,337 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by RUNNING THE REFERENCE (read-only, /root/reference) in this container.
+
+Test infrastructure only.  The reference cannot travel to the GPU box, so its behaviour on the hot
+path (VectorPhysEnv.vector_step -> ActionDecoder.map -> phys.apply, reference env.py:482-510,
+env.py:225-269, phys.py:184-197) is pinned here as data: inputs (config, seed, action tensors) and
+the outputs the reference produced for them under NumPy 2.2.6 (vectors G1-G5,
+anchors S1/S2).  Re-run with:   python oracle/gen_golden.py      (needs /root/reference)
+
+Every fixture stores:  config_json, seed, actions (T,N,A) float64, and per-tick arrays
+  obs (T,N,6) f64 | reward (T,N) f32 | done (T,N) bool | zero_start (T,N) bool
+  vel (T,N,3) f32 | z_pos (T,N) f64 | on_ground (T,N) bool | jump_released (T,N) bool
+  yaw (T,N) f64 | time_remaining (T,N) f64
+  last_key_press_time (T,N,K) f64 | last_keys (T,N,K) u8      (decoder state after the tick)
+  smove (T,N) i64 | fmove (T,N) i64 | jump (T,N) bool          (decoder outputs of the tick)
+  obs0 (N,6)  observation returned by vector_reset()
+  reset_tick / reset_env / reset_obs : every reset_at(i) the harness issued (RLlib style, after a
+                                       tick on which done[i] was set) and the obs it returned
+  + the state arrays right after reset (state0_*), so the first tick's inputs are pinned too.
+"""
+import dataclasses
+import json
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+from _refshim import import_reference  # noqa: E402
+
+ref_env, ref_phys = import_reference()
+OUT = os.path.join(os.path.dirname(HERE), "tests", "golden")
+
+
+# ----------------------------------------------------------------------------- action generators
+def persistent_actions(rng, T, N, num_keys, yaw_kind, action_range, yaw_steps, p_flip=0.05):
+    """Keys flip with prob p_flip per tick; yaw ~ U(-r, r) rounded to f32 (what an
+    RLlib Box(float32) sample is) or integer steps for a discrete yaw space."""
+    keys = np.zeros((T, N, num_keys), dtype=np.float64)
+    cur = rng.random((N, num_keys)) < 0.5
+    for t in range(T):
+        flip = rng.random((N, num_keys)) < p_flip
+        cur = cur ^ flip
+        keys[t] = cur
+    if yaw_kind == "none":
+        return keys
+    if yaw_kind == "continuous":
+        yaw = rng.uniform(-action_range, action_range, size=(T, N)).astype(np.float32).astype(np.float64)
+    else:
+        yaw = rng.integers(0, 2 * yaw_steps + 1, size=(T, N)).astype(np.float64)
+    return np.concatenate([keys, yaw[:, :, None]], axis=2)
+
+
+def iid_actions(rng, T, N, num_keys, action_range):
+    keys = (rng.random((T, N, num_keys)) < 0.5).astype(np.float64)
+    yaw = rng.uniform(-action_range, action_range, size=(T, N)).astype(np.float32).astype(np.float64)
+    return np.concatenate([keys, yaw[:, :, None]], axis=2)
+
+
+# ----------------------------------------------------------------------------- trace recorder
+def run_trace(cfg_kwargs, actions, seed, reset_on_done=True, second_reset=True, list_actions=False):
+    """Drive the reference exactly as RLlib's sampler does and record everything."""
+    cfg = ref_env.Config(**cfg_kwargs)
+    np.random.seed(seed)
+    e = ref_env.VectorPhysEnv(cfg)            # __init__ itself calls vector_reset (env.py:426)
+    obs0 = e.vector_reset() if second_reset else e._get_obs()
+    N = cfg.num_envs
+    dec = e._action_decoder
+
+    captured = {}
+    orig_map = dec.map
+
+    def spy_map(a, z_vel, t_rem):
+        out = orig_map(a, z_vel, t_rem)
+        captured["smove"], captured["fmove"], captured["jump"] = out[1], out[2], out[3]
+        return out
+
+    dec.map = spy_map
+
+    rec = {k: [] for k in ("obs", "reward", "done", "zero_start", "vel", "z_pos", "on_ground",
+                           "jump_released", "yaw", "time_remaining", "last_key_press_time",
+                           "last_keys", "smove", "fmove", "jump")}
+    resets = {"tick": [], "env": [], "obs": []}
+    state0 = {
+        "state0_vel": e.player_state.vel.copy(),
+        "state0_z_pos": np.asarray(e.player_state.z_pos, dtype=np.float64).copy(),
+        "state0_yaw": np.asarray(e._yaw, dtype=np.float64).copy(),
+        "state0_time_remaining": np.asarray(e._time_remaining, dtype=np.float64).copy(),
+        "state0_zero_start": e._zero_start.copy(),
+    }
+    T = actions.shape[0]
+    for t in range(T):
+        a = actions[t]
+        if list_actions:   # RLlib style: list of tuples whose components are scalars or (1,) arrays
+            a = [tuple([int(x) for x in row[:-1]] + [np.array([row[-1]], dtype=np.float32)]) for row in a]
+        obs, rew, done, infos = e.vector_step(a)
+        assert obs.dtype == np.float64 and rew.dtype == np.float32, (obs.dtype, rew.dtype)
+        rec["obs"].append(obs)
+        rec["reward"].append(rew)
+        rec["done"].append(done)
+        rec["zero_start"].append(np.array([i["zero_start"] for i in infos]))
+        ps = e.player_state
+        rec["vel"].append(ps.vel.copy())
+        rec["z_pos"].append(np.asarray(ps.z_pos, dtype=np.float64).copy())
+        rec["on_ground"].append(ps.on_ground.copy())
+        rec["jump_released"].append(ps.jump_released.copy())
+        rec["yaw"].append(np.asarray(e._yaw, dtype=np.float64).copy())
+        rec["time_remaining"].append(e._time_remaining.copy())
+        rec["last_key_press_time"].append(dec._last_key_press_time.copy())
+        rec["last_keys"].append(np.asarray(dec._last_keys).astype(np.uint8))
+        rec["smove"].append(np.asarray(captured["smove"], dtype=np.int64))
+        rec["fmove"].append(np.asarray(captured["fmove"], dtype=np.int64))
+        rec["jump"].append(np.asarray(captured["jump"], dtype=bool))
+        if reset_on_done:
+            for i in np.nonzero(done)[0]:
+                o = e.reset_at(int(i))
+                resets["tick"].append(t)
+                resets["env"].append(int(i))
+                resets["obs"].append(np.asarray(o, dtype=np.float64))
+    out = {k: np.stack(v) for k, v in rec.items()}
+    out.update(state0)
+    out["obs0"] = obs0
+    out["actions"] = np.asarray(actions, dtype=np.float64)
+    out["seed"] = np.int64(seed)
+    out["second_reset"] = np.bool_(second_reset)
+    out["reset_tick"] = np.asarray(resets["tick"], dtype=np.int64)
+    out["reset_env"] = np.asarray(resets["env"], dtype=np.int64)
+    out["reset_obs"] = (np.stack(resets["obs"]) if resets["obs"] else np.zeros((0, 6)))
+    # final post-reset state, so masked/injected resets can be checked as well
+    out["final_vel"] = e.player_state.vel.copy()
+    out["final_yaw"] = np.asarray(e._yaw, dtype=np.float64).copy()
+    out["final_time_remaining"] = e._time_remaining.copy()
+    cfg_json = {k: (list(v) if isinstance(v, tuple) else (float(v) if isinstance(v, np.floating) else v))
+                for k, v in dataclasses.asdict(cfg).items()}
+    out["config_json"] = np.array(json.dumps(cfg_json))
+    return out
+
+
+def save(name, data):
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **data)
+    print(f"{name:28s} {os.path.getsize(path) / 1024:8.1f} KiB")
+
+
+def default_kwargs(**over):
+    d = dataclasses.asdict(ref_env.Config.get_default())
+    d.update(over)
+    return d
+
+
+PARAMS_YML_ENV_CONFIG = dict(   # /root/reference/data/params.yml:16-33 (values, not text)
+    action_range=10, allow_jump=True, allow_yaw=True, auto_jump=False, discrete_yaw_steps=-1,
+    fmove_max=800, smove_max=1060, hover=False, initial_yaw_range=[0, 360], key_press_delay=0.3,
+    max_initial_speed=700, num_envs=100, smooth_keys=True, speed_reward=False,
+    time_delta=0.013888888888888, time_limit=10, zero_start_prob=0.01)
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    rng = np.random.default_rng(20260928)
+    ar_default = float(ref_env.Config.get_default().action_range)   # f32(720)*f32(0.014) = 10.0799999237...
+
+    # ---- G1: plumbing.  PhysEnv(get_default), gym-style step/reset loop, 1000 steps.
+    np.random.seed(0)
+    pe = ref_env.PhysEnv(ref_env.Config.get_default())
+    a1 = iid_actions(rng, 1000, 1, 4, ar_default)[:, 0, :]
+    g1 = {"obs": [], "reward": [], "done": [], "zero_start": [], "reset_obs": [], "reset_step": []}
+    o = pe.reset()
+    g1["reset_obs"].append(o); g1["reset_step"].append(-1)
+    for t in range(1000):
+        # mid-run: make the episode short by construction?  No - keep verbatim: episodes end when
+        # time_remaining < 0; random starts draw time in (1, 10] so several resets happen.
+        o, r, d, info = pe.step([int(a1[t, 0]), int(a1[t, 1]), int(a1[t, 2]), int(a1[t, 3]),
+                                 np.array([a1[t, 4]], dtype=np.float32)])
+        g1["obs"].append(o); g1["reward"].append(r); g1["done"].append(d)
+        g1["zero_start"].append(info["zero_start"])
+        if d:
+            o = pe.reset()
+            g1["reset_obs"].append(o); g1["reset_step"].append(t)
+    save("g1_physenv_default", {
+        "actions": a1, "seed": np.int64(0), "obs": np.stack(g1["obs"]),
+        "reward": np.asarray(g1["reward"], dtype=np.float32), "done": np.asarray(g1["done"]),
+        "zero_start": np.asarray(g1["zero_start"]), "reset_obs": np.stack(g1["reset_obs"]),
+        "reset_step": np.asarray(g1["reset_step"], dtype=np.int64),
+        "config_json": np.array(json.dumps({"get_default": True}))})
+
+    # ---- G2: zero-start lock-step, 720 ticks (10 s at dt = 1/72), N = 16, everything recorded.
+    kw = default_kwargs(num_envs=16, zero_start_prob=1.0)
+    acts = persistent_actions(rng, 720, 16, 4, "continuous", ar_default, -1)
+    save("g2_zero_start_720", run_trace(kw, acts, seed=2, reset_on_done=False))
+
+    # ---- G2b: same config, iid Bernoulli(0.5) keys (throughput-variant action statistics), N = 16
+    acts = iid_actions(rng, 720, 16, 4, ar_default)
+    save("g2b_zero_start_iid_720", run_trace(kw, acts, seed=3, reset_on_done=False))
+
+    # ---- G3: full Config with random starts and RLlib-style reset_at on done.
+    kw = dict(PARAMS_YML_ENV_CONFIG); kw["num_envs"] = 16
+    acts = persistent_actions(rng, 1500, 16, 4, "continuous", 10.0, -1)
+    save("g3_params_yml_1500", run_trace(kw, acts, seed=4))
+    kw = default_kwargs(num_envs=16)
+    acts = persistent_actions(rng, 1500, 16, 4, "continuous", ar_default, -1)
+    save("g3_get_default_1500", run_trace(kw, acts, seed=5))
+    # a high zero-start mix so both reset branches (and their different RNG consumption) are hit
+    kw = default_kwargs(num_envs=16, zero_start_prob=0.5, time_limit=2.0)
+    acts = persistent_actions(rng, 800, 16, 4, "continuous", ar_default, -1)
+    save("g3_mixed_zero_start_800", run_trace(kw, acts, seed=6))
+    # RLlib list-of-tuples action format (env.py:221-223) on a short run
+    kw = default_kwargs(num_envs=4, zero_start_prob=0.3, time_limit=1.0)
+    acts = persistent_actions(rng, 200, 4, 4, "continuous", ar_default, -1)
+    save("g3_list_actions_200", run_trace(kw, acts, seed=7, list_actions=True))
+
+    # ---- G4: Config variants, 100 ticks each, N = 8.
+    variants = {
+        "discrete_yaw5": (dict(discrete_yaw_steps=5), "discrete", 4),
+        "no_yaw": (dict(allow_yaw=False), "none", 4),
+        "auto_jump": (dict(auto_jump=True), "continuous", 3),
+        "no_jump": (dict(allow_jump=False), "continuous", 3),
+        "hover": (dict(hover=True), "continuous", 4),
+        "speed_reward": (dict(speed_reward=True), "continuous", 4),
+        "no_smooth": (dict(smooth_keys=False), "continuous", 4),
+        "delay0": (dict(key_press_delay=0.0), "continuous", 4),
+        "dataclass_defaults": (None, "continuous", 4),
+        "short_episodes": (dict(time_limit=0.5, zero_start_prob=0.2), "continuous", 4),
+        "fmove_small": (dict(fmove_max=200., smove_max=150.), "continuous", 4),
+    }
+    for i, (name, (over, yaw_kind, nk)) in enumerate(variants.items()):
+        if over is None:   # field defaults of the dataclass (env.py:136-148): dt=0.014, limit 5, smove 700, no smoothing
+            kw = dict(num_envs=8, zero_start_prob=0.1, initial_yaw_range=(0, 360), max_initial_speed=700.)
+            ar = ar_default
+        else:
+            kw = default_kwargs(num_envs=8, **over)
+            ar = ar_default
+        T = 400 if name in ("short_episodes", "dataclass_defaults") else 100
+        acts = persistent_actions(rng, T, 8, nk, yaw_kind, ar, kw.get("discrete_yaw_steps", -1), p_flip=0.15)
+        save("g4_" + name, run_trace(kw, acts, seed=100 + i))
+
+    # ---- S1: the reference's own test scenario (tests/test_integration.py:50-65,76-84), sim side.
+    kw = dict(num_envs=1, auto_jump=True, time_limit=5, key_press_delay=0.3,
+              initial_yaw_range=(90, 90), max_initial_speed=0., zero_start_prob=1.)
+    T = 400
+    acts = np.zeros((T, 1, 4))
+    acts[:100, 0, int(ref_env.Key.FORWARD)] = 1
+    acts[100:, 0, int(ref_env.Key.STRAFE_LEFT)] = 1
+    acts[100:, 0, 3] = -2
+    s1 = run_trace(kw, acts, seed=11, reset_on_done=False, second_reset=True)
+    n_done = int(np.argmax(s1["done"][:, 0])) + 1
+    print("S1 steps to done:", n_done, "sum reward:", float(np.sum(s1["reward"][:n_done, 0].astype(np.float64))))
+    s1["steps_to_done"] = np.int64(n_done)
+    save("s1_reference_test_scenario", s1)
+
+    # ---- S2: get_default + zero start, constant action [0,1,1,1,[1.0]], 720 steps.
+    kw = default_kwargs(num_envs=1, zero_start_prob=1.0)
+    acts = np.tile(np.array([0, 1, 1, 1, 1.0]), (720, 1, 1))
+    s2 = run_trace(kw, acts, seed=12, reset_on_done=False)
+    print("S2 sum reward:", float(np.sum(s2["reward"][:, 0].astype(np.float64))), "final yaw", s2["yaw"][-1, 0])
+    save("s2_constant_action_720", s2)
+
+    # ---- G5: micro-vectors per function on edge inputs.
+    g5 = {}
+    yaw = np.concatenate([np.array([0., 90., 180., 270., 360., -90., 45., 1e-12, 720.5, -1234.5678, 36000.25, 1e6]),
+                          rng.uniform(-4000, 4000, 52)])
+    g5["av_yaw"] = yaw
+    g5["av_out"] = ref_phys._angle_vectors(yaw, np.zeros_like(yaw, dtype=np.float32), np.zeros_like(yaw, dtype=np.float32))
+    hv = np.concatenate([np.array([[0, 0], [1e-3, 0], [30, 40], [100, 0], [0, -100], [99.99, 0], [320, 0], [500, 500]], dtype=np.float32),
+                         rng.uniform(-700, 700, (56, 2)).astype(np.float32)])
+    dt = np.full((hv.shape[0],), 1. / 72)
+    g5["fr_h_vel"], g5["fr_dt"] = hv, dt
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        g5["fr_out"] = ref_phys._user_friction(hv, dt)
+        # _air_move on mixed ground/air with every (fmove, smove) the decoder can emit (+ zero move)
+        M = 96
+        am_yaw = rng.uniform(-720, 720, M)
+        am_f = rng.choice(np.array([0, 400, 800]), M).astype(np.int64)
+        am_s = rng.choice(np.array([0, -530, 530, -1060, 1060]), M).astype(np.int64)
+        am_f[:4] = 0; am_s[:4] = 0
+        am_g = rng.random(M) < 0.5
+        am_v = rng.uniform(-700, 700, (M, 2)).astype(np.float32)
+        am_v[4:8] = 0
+        am_dt = np.full((M,), 1. / 72)
+        z32 = np.zeros((M,), dtype=np.float32)
+        g5["am_yaw"], g5["am_fmove"], g5["am_smove"], g5["am_on_ground"], g5["am_h_vel"], g5["am_dt"] = \
+            am_yaw, am_f, am_s, am_g, am_v, am_dt
+        g5["am_out"] = ref_phys._air_move(am_yaw, z32, z32, am_f, am_s, am_g, am_dt, am_v)
+    # _do_z_physics: exactly-on-floor, just above, landing, jumping
+    zp = np.array([24.03125, 24.03125, 24.2, 24.0312500001, 32.843201, 100., 24.03125, 24.5], dtype=np.float64)
+    zv = np.array([0., 0., -12., -1e-9, -12., 0., 0., -300.], dtype=np.float32)
+    og = np.array([True, True, False, False, False, False, True, False])
+    jp = np.array([True, False, True, True, False, True, True, True])
+    jr = np.array([True, True, True, True, True, True, False, True])
+    zdt = np.full((8,), 1. / 72)
+    out = ref_phys._do_z_physics(jp, zdt, zp, zv, og, jr)
+    g5["z_in_pos"], g5["z_in_vel"], g5["z_in_on_ground"], g5["z_in_jump"], g5["z_in_jump_released"], g5["z_dt"] = zp, zv, og, jp, jr, zdt
+    g5["z_out_pos"], g5["z_out_vel"], g5["z_out_on_ground"], g5["z_out_jump_released"] = out
+    # full phys.apply on random states
+    M = 128
+    ap_in = ref_phys.Inputs(yaw=rng.uniform(-720, 720, M), pitch=np.zeros(M, np.float32), roll=np.zeros(M, np.float32),
+                            fmove=rng.choice(np.array([0, 400, 800]), M).astype(np.int64),
+                            smove=rng.choice(np.array([0, -530, 530, -1060, 1060]), M).astype(np.int64),
+                            button2=rng.random(M) < 0.5, time_delta=np.full((M,), 1. / 72))
+    ap_og = rng.random(M) < 0.5
+    ap_z = np.where(ap_og, 24.03125, rng.uniform(24.04, 80, M))
+    ap_v = rng.uniform(-700, 700, (M, 3)).astype(np.float32)
+    ap_v[ap_og, 2] = 0
+    ap_ps = ref_phys.PlayerState(z_pos=ap_z, vel=ap_v, on_ground=ap_og, jump_released=np.ones(M, dtype=bool))
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        ap_out = ref_phys.apply(ap_in, ap_ps)
+    for f in dataclasses.fields(ap_in):
+        g5["ap_in_" + f.name] = getattr(ap_in, f.name)
+    for f in dataclasses.fields(ap_ps):
+        g5["ap_ps_" + f.name] = getattr(ap_ps, f.name)
+        g5["ap_out_" + f.name] = getattr(ap_out, f.name)
+    # ActionDecoder.map on its own (mkdemo-style use, mkdemo.py:47-55): time exactly at the delay boundary etc.
+    cfg = ref_env.Config(**default_kwargs(num_envs=6))
+    dec = ref_env.ActionDecoder(cfg)
+    dec.vector_reset(np.array([90., 0., -45., 720., 10., 33.]))
+    t_rems = [10.0, 10.0 - 1. / 72, 9.9, 9.7, 9.7 - 1e-12, 9.4, 9.0, 9.0]
+    dacts = np.array([[[1, 0, 1, 0, 2.5]] * 6, [[0, 0, 1, 1, -2.5]] * 6, [[1, 1, 1, 1, 0.]] * 6, [[1, 0, 0, 0, 10.]] * 6,
+                      [[1, 0, 0, 1, -10.]] * 6, [[0, 1, 0, 1, 1.]] * 6, [[0, 1, 1, 0, 1.]] * 6, [[0, 0, 0, 0, 0.]] * 6], dtype=np.float64)
+    douts = {"yaw": [], "smove": [], "fmove": [], "jump": [], "lkpt": [], "lk": []}
+    for t_rem, a in zip(t_rems, dacts):
+        y, s, f, j = dec.map(a, np.zeros(6, np.float32), np.full((6,), t_rem))
+        douts["yaw"].append(y.copy()); douts["smove"].append(s); douts["fmove"].append(f); douts["jump"].append(j)
+        douts["lkpt"].append(dec._last_key_press_time.copy()); douts["lk"].append(np.asarray(dec._last_keys).astype(np.uint8))
+    g5["dec_yaw0"] = np.array([90., 0., -45., 720., 10., 33.])
+    g5["dec_time_remaining"] = np.array(t_rems)
+    g5["dec_actions"] = dacts
+    for k, v in douts.items():
+        g5["dec_out_" + k] = np.stack(v)
+    save("g5_micro", g5)
+
+
+if __name__ == "__main__":
+    main()
