@@ -1,0 +1,189 @@
+/* q1env.h - C ABI of libq1env.so: the MI355X (gfx950) implementation of the q1physrl env hot path.
+ *
+ * This is the drop-in boundary.  Everything the reference computes per tick in pure NumPy
+ *     VectorPhysEnv.vector_step   q1physrl_env/q1physrl_env/env.py:482-510
+ *     ActionDecoder.map           q1physrl_env/q1physrl_env/env.py:225-269
+ *     phys.apply                  q1physrl_env/q1physrl_env/phys.py:184-197
+ *     _get_obs                    q1physrl_env/q1physrl_env/env.py:392-400
+ *     vector_reset / reset_at     q1physrl_env/q1physrl_env/env.py:428-480
+ * is behind these entry points as hand-written HIP kernels over an SoA env state resident in HBM.
+ * The reference has no FFI of its own (it is pure Python); the binding a maintainer adds is the
+ * ctypes stub shown in INTEGRATION.md (shipped as q1physrl_amd/_lib.py).
+ *
+ * Conventions
+ *   - plain C types only; no torch / HIP types in signatures (a hipStream_t travels as void*).
+ *   - every function returns 0 on success or a negative q1env_status; q1env_last_error() gives the
+ *     thread-local message.  No exceptions or aborts cross the ABI.
+ *   - "dev" pointers are device (HBM) pointers, e.g. torch_tensor.data_ptr(); "host" are host pointers.
+ *   - a handle is bound to one device and one stream; it is not thread-safe; distinct handles are
+ *     independent (one handle per process per GPU is the multi-GPU model - no collectives).
+ *   - all launches are asynchronous on the handle's stream; only *_host functions and q1env_sync block.
+ */
+#ifndef Q1ENV_H
+#define Q1ENV_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define Q1ENV_ABI_VERSION 1
+
+typedef enum q1env_status {
+    Q1ENV_OK = 0,
+    Q1ENV_ERR_INVALID_ARG = -1,
+    Q1ENV_ERR_HIP = -2,          /* a HIP runtime call failed (message has hipGetErrorString) */
+    Q1ENV_ERR_NO_DEVICE = -3,    /* no gfx950 device visible: the library has NO CPU fallback */
+    Q1ENV_ERR_ALLOC = -4
+} q1env_status;
+
+/* POD mirror of reference `Config` (env.py:94-148).  Doubles carry python floats unchanged; the
+ * library applies the reference's own float32 casts (fmove_max/smove_max env.py:260-261,
+ * max_yaw_delta env.py:230) internally. */
+typedef struct q1env_config {
+    int32_t num_envs;             /* envs owned by THIS handle (this shard)                     */
+    int32_t allow_yaw;            /* env.py:107                                                  */
+    int32_t discrete_yaw_steps;   /* -1 = continuous mouse dimension (env.py:109)                */
+    int32_t speed_reward;         /* env.py:111                                                  */
+    int32_t hover;                /* env.py:116                                                  */
+    int32_t smooth_keys;          /* env.py:122                                                  */
+    int32_t auto_jump;            /* env.py:124                                                  */
+    int32_t allow_jump;           /* env.py:126                                                  */
+    double zero_start_prob;       /* env.py:100                                                  */
+    double initial_yaw_lo;        /* env.py:102 initial_yaw_range[0]                             */
+    double initial_yaw_hi;
+    double max_initial_speed;     /* env.py:104                                                  */
+    double time_delta;            /* env.py:105                                                  */
+    double time_limit;            /* env.py:106                                                  */
+    double action_range;          /* env.py:108                                                  */
+    double fmove_max;             /* env.py:112                                                  */
+    double smove_max;             /* env.py:114                                                  */
+    double key_press_delay;       /* env.py:118                                                  */
+    int64_t env_index_base;       /* global index of this shard's env 0; keys the counter RNG so
+                                     results do not depend on how the batch is split over GPUs  */
+} q1env_config;
+
+/* Action layouts accepted by step/rollout/decode.  A = num_keys + (allow_yaw ? 1 : 0),
+ * num_keys = 4, or 3 when auto_jump or !allow_jump (env.py:206-207). */
+enum {
+    Q1ENV_ACT_F64_ROWS = 0,   /* act_a = double[N][A]: exactly what _fix_actions returns (env.py:221-223) */
+    Q1ENV_ACT_F32_ROWS = 1,   /* act_a = float[N][A]:  a torch policy's output                            */
+    Q1ENV_ACT_PACKED   = 2,   /* act_a = uint8[N] key bitmask (bit k = Key k, env.py:61-73), act_b = float[N] mouse action: 5 B/env */
+    Q1ENV_ACT_RANDOM   = 3    /* rollout only: iid Bernoulli(1/2) keys + U(-action_range, action_range) mouse from the counter RNG */
+};
+
+enum {
+    Q1ENV_OBS_F64 = 0,        /* double[N][6]: what the reference returns (env.py:399-400, Obs order env.py:76-86) */
+    Q1ENV_OBS_F32 = 1         /* float[N][6]: the same values rounded to float32 (what observation_space declares, env.py:416-417) */
+};
+
+/* bits of the per-env flag byte (SoA `flags`) */
+enum {
+    Q1ENV_FLAG_ON_GROUND     = 1u << 0,   /* PlayerState.on_ground     phys.py:160 */
+    Q1ENV_FLAG_JUMP_RELEASED = 1u << 1,   /* PlayerState.jump_released phys.py:161 */
+    Q1ENV_FLAG_ZERO_START    = 1u << 2,   /* VectorPhysEnv._zero_start env.py:379  */
+    Q1ENV_FLAG_LAST_KEY0     = 1u << 3    /* ActionDecoder._last_keys[k] = bit 3+k, env.py:201 */
+};
+
+/* Host-side view of the SoA env state for get/set (any pointer may be NULL = skip that array).
+ * Each array has num_envs elements; last_key_press_time has 4*num_envs, key-major: [k*num_envs + i]. */
+typedef struct q1env_state {
+    float*   vel_x;  float* vel_y;  float* vel_z;     /* PlayerState.vel[:,0..2] float32, phys.py:159 */
+    double*  pos_x;  double* pos_y;                   /* extension: sum of dt*vel_x / dt*vel_y in float64 (the "100 m" distance) */
+    double*  z_pos;                                   /* PlayerState.z_pos, phys.py:158 */
+    double*  yaw;                                     /* VectorPhysEnv._yaw, env.py:376 (unwrapped degrees) */
+    double*  time_remaining;                          /* VectorPhysEnv._time_remaining, env.py:377 */
+    double*  last_key_press_time;                     /* ActionDecoder._last_key_press_time, env.py:200 */
+    uint8_t* flags;                                   /* see Q1ENV_FLAG_* */
+} q1env_state;
+
+typedef struct q1env q1env_t;
+
+int         q1env_abi_version(void);
+const char* q1env_last_error(void);
+/* number of gfx950 devices visible; negative status on HIP failure */
+int         q1env_device_count(void);
+
+/* Lifetime.  `stream` = a hipStream_t to launch on (e.g. torch.cuda.current_stream().cuda_stream),
+ * or NULL to let the handle create and own a non-blocking stream.  State after create equals a
+ * zero-start reset (env.py:54-58) of every env. */
+int q1env_create(const q1env_config* cfg, int device, void* stream, q1env_t** out);
+int q1env_destroy(q1env_t* env);
+int q1env_sync(q1env_t* env);
+int q1env_num_keys(const q1env_t* env);
+int q1env_action_width(const q1env_t* env);
+
+/* ---- resets (env.py:428-480; decoder env.py:271-291) ------------------------------------------
+ * reset_draws: the caller supplies the raw random draws (the reference's RNG is the GLOBAL NumPy
+ * MT19937, env.py:432-446/461-471, which only the Python host can reproduce) and the device turns
+ * them into state: yaw / time / speed selection on zero_start, hover override, vel = speed*(cos,sin)(angle)
+ * rounded to float32, decoder state cleared.  idx == NULL resets envs 0..n-1.  All pointers HOST.
+ * obs (n x 6, obs_format) may be NULL. Synchronous. */
+int q1env_reset_draws_host(q1env_t* env, int64_t n, const int32_t* idx, const uint8_t* zero_start,
+                           const double* yaw, const double* time_remaining, const double* speed,
+                           const double* angle, int obs_format, void* obs);
+/* reset_philox: device-side counter RNG (Philox4x32-10 keyed by (seed, global env index, episode
+ * counter)) drawing the reference's distributions, including the one-argument uniform(x) quirk
+ * (= uniform(low=x, high=1), env.py:439-446).  mask_dev: NULL = all envs; else uint8[N], non-zero = reset.
+ * done_only != 0 additionally restricts to envs whose time_remaining < 0 (env.py:506). Asynchronous. */
+int q1env_reset_philox(q1env_t* env, uint64_t seed, const uint8_t* mask_dev, int done_only,
+                       int obs_format, void* obs_dev);
+
+/* ---- the hot path: one tick of every env (env.py:482-510) ------------------------------------
+ * Any of obs / reward / done / zero_start may be NULL (not written).  reward float[N] (env.py:500-503),
+ * done uint8[N] (env.py:506), zero_start uint8[N] (the info dict's only field, env.py:510). */
+int q1env_step(q1env_t* env, int action_format, const void* act_a_dev, const void* act_b_dev,
+               int obs_format, void* obs_dev, float* reward_dev, uint8_t* done_dev, uint8_t* zero_start_dev);
+/* Same with HOST pointers: stages H2D, steps, copies back, synchronises (the NumPy-compatible path). */
+int q1env_step_host(q1env_t* env, int action_format, const void* act_a, const void* act_b,
+                    int obs_format, void* obs, float* reward, uint8_t* done, uint8_t* zero_start);
+/* `ticks` consecutive single-tick launches with tick-major inputs/outputs ([ticks][N]... ; outputs may be
+ * NULL).  use_graph != 0 replays them from a cached hipGraph (launch-bound regime).  out_stride_ticks = 0
+ * makes every tick overwrite the same output slab (ring of 1), 1 = tick-major slabs. */
+int q1env_step_many(q1env_t* env, int ticks, int action_format, const void* act_a_dev, const void* act_b_dev,
+                    int obs_format, void* obs_dev, float* reward_dev, uint8_t* done_dev,
+                    int out_stride_ticks, int use_graph);
+/* Fused multi-tick kernel: state stays in registers for `ticks` ticks (one launch).  Actions are
+ * tick-major device arrays in `action_format`, or Q1ENV_ACT_RANDOM (then rng_seed keys the counter RNG).
+ * Per-tick outputs are tick-major and optional (NULL).  auto_reset != 0: an env whose tick set `done`
+ * is reset in-kernel with the Philox reset (as q1env_reset_philox) before its next tick.
+ * return_sum_dev (optional, double[N]) accumulates reward over the launch in float64. */
+int q1env_rollout(q1env_t* env, int ticks, int action_format, const void* act_a_dev, const void* act_b_dev,
+                  uint64_t rng_seed, int obs_format, void* obs_dev, float* reward_dev, uint8_t* done_dev,
+                  int auto_reset, double* return_sum_dev);
+
+/* current observation without stepping (env.py:392-400) */
+int q1env_observe(q1env_t* env, int obs_format, void* obs_dev);
+int q1env_observe_host(q1env_t* env, int obs_format, void* obs);
+
+/* SoA state exchange with HOST arrays (checkpoint / golden-state injection / player_state snapshots) */
+int q1env_get_state_host(q1env_t* env, const q1env_state* dst);
+int q1env_set_state_host(q1env_t* env, const q1env_state* src);
+/* device pointers of the live SoA arrays (zero-copy views for torch); valid until destroy */
+int q1env_state_device_ptrs(q1env_t* env, q1env_state* out);
+
+/* ---- stand-alone pieces of the reference's public surface -----------------------------------
+ * ActionDecoder.map (env.py:225-269) as used on its own by mkdemo.py:47-55 / analyse.py:199-207: the
+ * decoder state (last_key_press_time, last_keys, yaw) is this handle's; z_vel / time_remaining come
+ * from the caller.  Outputs HOST: yaw double[N], smove/fmove int64[N], jump uint8[N]. Synchronous. */
+int q1env_decode_host(q1env_t* env, int action_format, const void* act_a, const void* act_b,
+                      const float* z_vel, const double* time_remaining,
+                      double* yaw, int64_t* smove, int64_t* fmove, uint8_t* jump);
+/* ActionDecoder.vector_reset / reset_at (env.py:271-291): idx NULL = envs 0..n-1. */
+int q1env_decoder_reset_host(q1env_t* env, int64_t n, const int32_t* idx, const double* yaw);
+/* phys.apply (phys.py:184-197), stateless, HOST arrays of n elements (vel: float[n][3]).  pitch/roll may
+ * be NULL (= 0, what the env passes, env.py:490-491).  fmove/smove are doubles (integers convert exactly). */
+int q1phys_apply_host(int device, int64_t n, const double* yaw, const double* pitch, const double* roll,
+                      const double* fmove, const double* smove, const uint8_t* button2, const double* time_delta,
+                      const double* z_pos, const float* vel, const uint8_t* on_ground, const uint8_t* jump_released,
+                      double* out_z_pos, float* out_vel, uint8_t* out_on_ground, uint8_t* out_jump_released);
+
+/* ---- measurement: HIP events recorded on the handle's stream --------------------------------- */
+int q1env_timer_start(q1env_t* env);
+int q1env_timer_stop(q1env_t* env, float* elapsed_ms);   /* synchronises on the stop event */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* Q1ENV_H */

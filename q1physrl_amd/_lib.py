@@ -1,0 +1,106 @@
+"""ctypes binding of libq1env.so (include/q1env.h).  This is the whole Python <-> HIP boundary.
+
+There is deliberately NO fallback: if the library is missing or no MI355X is visible the calls raise.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "libq1env.so")
+
+ABI_VERSION = 1
+ACT_F64_ROWS, ACT_F32_ROWS, ACT_PACKED, ACT_RANDOM = 0, 1, 2, 3
+OBS_F64, OBS_F32 = 0, 1
+FLAG_ON_GROUND, FLAG_JUMP_RELEASED, FLAG_ZERO_START, FLAG_LAST_KEY0 = 1, 2, 4, 8
+
+
+class Q1EnvError(RuntimeError):
+    """A libq1env call returned a negative status (message from q1env_last_error)."""
+
+
+class Q1Config(C.Structure):          # q1env_config
+    _fields_ = [("num_envs", C.c_int32), ("allow_yaw", C.c_int32), ("discrete_yaw_steps", C.c_int32),
+                ("speed_reward", C.c_int32), ("hover", C.c_int32), ("smooth_keys", C.c_int32),
+                ("auto_jump", C.c_int32), ("allow_jump", C.c_int32),
+                ("zero_start_prob", C.c_double), ("initial_yaw_lo", C.c_double), ("initial_yaw_hi", C.c_double),
+                ("max_initial_speed", C.c_double), ("time_delta", C.c_double), ("time_limit", C.c_double),
+                ("action_range", C.c_double), ("fmove_max", C.c_double), ("smove_max", C.c_double),
+                ("key_press_delay", C.c_double), ("env_index_base", C.c_int64)]
+
+
+class Q1State(C.Structure):           # q1env_state
+    _fields_ = [("vel_x", C.c_void_p), ("vel_y", C.c_void_p), ("vel_z", C.c_void_p),
+                ("pos_x", C.c_void_p), ("pos_y", C.c_void_p), ("z_pos", C.c_void_p),
+                ("yaw", C.c_void_p), ("time_remaining", C.c_void_p),
+                ("last_key_press_time", C.c_void_p), ("flags", C.c_void_p)]
+
+
+STATE_FIELDS = (("vel_x", np.float32, 1), ("vel_y", np.float32, 1), ("vel_z", np.float32, 1),
+                ("pos_x", np.float64, 1), ("pos_y", np.float64, 1), ("z_pos", np.float64, 1),
+                ("yaw", np.float64, 1), ("time_remaining", np.float64, 1),
+                ("last_key_press_time", np.float64, 4), ("flags", np.uint8, 1))
+
+_P = C.c_void_p
+_SIGNATURES = {
+    "q1env_abi_version": (C.c_int, []),
+    "q1env_last_error": (C.c_char_p, []),
+    "q1env_device_count": (C.c_int, []),
+    "q1env_create": (C.c_int, [C.POINTER(Q1Config), C.c_int, _P, C.POINTER(_P)]),
+    "q1env_destroy": (C.c_int, [_P]),
+    "q1env_sync": (C.c_int, [_P]),
+    "q1env_num_keys": (C.c_int, [_P]),
+    "q1env_action_width": (C.c_int, [_P]),
+    "q1env_reset_draws_host": (C.c_int, [_P, C.c_int64, _P, _P, _P, _P, _P, _P, C.c_int, _P]),
+    "q1env_reset_philox": (C.c_int, [_P, C.c_uint64, _P, C.c_int, C.c_int, _P]),
+    "q1env_step": (C.c_int, [_P, C.c_int, _P, _P, C.c_int, _P, _P, _P, _P]),
+    "q1env_step_host": (C.c_int, [_P, C.c_int, _P, _P, C.c_int, _P, _P, _P, _P]),
+    "q1env_step_many": (C.c_int, [_P, C.c_int, C.c_int, _P, _P, C.c_int, _P, _P, _P, C.c_int, C.c_int]),
+    "q1env_rollout": (C.c_int, [_P, C.c_int, C.c_int, _P, _P, C.c_uint64, C.c_int, _P, _P, _P, C.c_int, _P]),
+    "q1env_observe": (C.c_int, [_P, C.c_int, _P]),
+    "q1env_observe_host": (C.c_int, [_P, C.c_int, _P]),
+    "q1env_get_state_host": (C.c_int, [_P, C.POINTER(Q1State)]),
+    "q1env_set_state_host": (C.c_int, [_P, C.POINTER(Q1State)]),
+    "q1env_state_device_ptrs": (C.c_int, [_P, C.POINTER(Q1State)]),
+    "q1env_decode_host": (C.c_int, [_P, C.c_int, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "q1env_decoder_reset_host": (C.c_int, [_P, C.c_int64, _P, _P]),
+    "q1phys_apply_host": (C.c_int, [C.c_int, C.c_int64] + [_P] * 15),
+    "q1env_timer_start": (C.c_int, [_P]),
+    "q1env_timer_stop": (C.c_int, [_P, C.POINTER(C.c_float)]),
+}
+EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+
+_lib = None
+
+
+def load():
+    """dlopen libq1env.so (built by q1physrl_amd.build / __graft_entry__.build()) and type its symbols."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise Q1EnvError(f"{LIB_PATH} is missing: build it with `python -m q1physrl_amd.build` "
+                         "(hipcc, gfx950).  q1physrl_amd has no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in _SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError here = the .so does not match include/q1env.h
+        fn.restype, fn.argtypes = res, args
+    if lib.q1env_abi_version() != ABI_VERSION:
+        raise Q1EnvError(f"libq1env ABI {lib.q1env_abi_version()} != binding ABI {ABI_VERSION}")
+    _lib = lib
+    return lib
+
+
+def check(rc):
+    if rc < 0:
+        raise Q1EnvError(f"libq1env error {rc}: {load().q1env_last_error().decode(errors='replace')}")
+    return rc
+
+
+def ptr(a):
+    """Host pointer of a C-contiguous NumPy array (None -> NULL)."""
+    if a is None:
+        return None
+    assert a.flags["C_CONTIGUOUS"], "array must be C-contiguous"
+    return a.ctypes.data_as(C.c_void_p)

@@ -1,0 +1,707 @@
+// q1env.hip - kernels, handle and C ABI of libq1env.so (gfx950 only; see include/q1env.h).
+//
+// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -shared q1env.hip -o libq1env.so
+// (-ffp-contract=off is part of the numerics contract: the reference never fuses multiply-add.)
+#include "q1env_device.hpp"
+#include "../../include/q1env.h"
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+using namespace q1;
+
+// =========================================================================================== kernels
+// One tick of every env (reference VectorPhysEnv.vector_step, env.py:482-510), one lane per env.
+// Loads: 85 B of SoA state + the action; stores: the state + obs/reward/done.  No LDS: nothing is shared
+// between envs and the per-tick constants already sit in SGPRs.
+template <typename OBS_T>
+__global__ void __launch_bounds__(256)
+step_kernel(Params p, StatePtrs s, int fmt, const void* act_a, const void* act_b,
+            OBS_T* obs, float* reward, uint8_t* done, uint8_t* zero_start) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= p.n) return;
+    Env e;
+    load_env(s, p.n, i, e);
+    double yaw_act;
+    const uint32_t keys = fetch_action(p, fmt, act_a, act_b, (size_t)i, &yaw_act);
+    TickOut o;
+    tick(p, e, keys, yaw_act, o);
+    store_env(s, p.n, i, e);
+    if (obs) write_obs<OBS_T>(obs, (size_t)i, o.obs);
+    if (reward) reward[i] = o.reward;
+    if (done) done[i] = o.done ? 1 : 0;
+    if (zero_start) zero_start[i] = (e.flags & FLAG_ZERO_START) ? 1 : 0;
+}
+
+// `ticks` ticks in one launch: the env state lives in registers between ticks, only actions stream in and
+// (optional) per-tick outputs stream out.  Tick-major layouts keep every access of a wave contiguous.
+template <typename OBS_T>
+__global__ void __launch_bounds__(256)
+rollout_kernel(Params p, StatePtrs s, int ticks, int fmt, const void* act_a, const void* act_b,
+               uint64_t seed, uint64_t tick0, OBS_T* obs, float* reward, uint8_t* done,
+               int auto_reset, double* return_sum) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= p.n) return;
+    Env e;
+    load_env(s, p.n, i, e);
+    const uint64_t genv = (uint64_t)p.env_index_base + (uint64_t)i;
+    const size_t n = (size_t)p.n;
+    double ret = 0.0;
+    for (int t = 0; t < ticks; ++t) {
+        double yaw_act;
+        uint32_t keys;
+        if (fmt == 3) keys = random_action(p, seed, genv, tick0 + (uint64_t)t, &yaw_act);
+        else keys = fetch_action(p, fmt, act_a, act_b, (size_t)t * n + (size_t)i, &yaw_act);
+        TickOut o;
+        tick(p, e, keys, yaw_act, o);
+        const size_t oi = (size_t)t * n + (size_t)i;
+        if (obs) write_obs<OBS_T>(obs, oi, o.obs);
+        if (reward) reward[oi] = o.reward;
+        if (done) done[oi] = o.done ? 1 : 0;
+        ret += (double)o.reward;
+        if (auto_reset && o.done) reset_philox(p, e, seed, genv, tick0 + (uint64_t)t + 1);
+    }
+    store_env(s, p.n, i, e);
+    if (return_sum) return_sum[i] += ret;
+}
+
+template <typename OBS_T>
+__global__ void __launch_bounds__(256) observe_kernel(Params p, StatePtrs s, OBS_T* obs) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= p.n) return;
+    Env e;
+    load_env(s, p.n, i, e);
+    double o[6];
+    observe(p, e, o);
+    write_obs<OBS_T>(obs, (size_t)i, o);
+}
+
+// Reset from host-supplied raw draws (NumPy-compatible RNG stays on the host, the arithmetic is here).
+template <typename OBS_T>
+__global__ void __launch_bounds__(256)
+reset_draws_kernel(Params p, StatePtrs s, int count, const int32_t* idx, const uint8_t* zero_start,
+                   const double* yaw, const double* tm, const double* speed, const double* angle, OBS_T* obs) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= count) return;
+    const int i = idx ? idx[j] : j;
+    Env e;
+    reset_from_draws(p, e, zero_start[j] != 0, yaw[j], tm[j], speed[j], angle[j]);
+    store_env(s, p.n, i, e);
+    if (obs) {
+        double o[6];
+        observe(p, e, o);
+        write_obs<OBS_T>(obs, (size_t)j, o);
+    }
+}
+
+template <typename OBS_T>
+__global__ void __launch_bounds__(256)
+reset_philox_kernel(Params p, StatePtrs s, uint64_t seed, uint64_t counter, const uint8_t* mask, int done_only, OBS_T* obs) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= p.n) return;
+    Env e;
+    load_env(s, p.n, i, e);
+    bool go = mask ? (mask[i] != 0) : true;
+    if (done_only) go = go && (e.trem < 0.0);
+    if (go) {
+        reset_philox(p, e, seed, (uint64_t)p.env_index_base + (uint64_t)i, counter);
+        store_env(s, p.n, i, e);
+    }
+    if (obs) {
+        double o[6];
+        observe(p, e, o);
+        write_obs<OBS_T>(obs, (size_t)i, o);
+    }
+}
+
+// Stand-alone ActionDecoder.map (env.py:225-269): decoder state from the handle, z_vel / time from the caller.
+__global__ void __launch_bounds__(256)
+decode_kernel(Params p, StatePtrs s, int fmt, const void* act_a, const void* act_b, const float* z_vel,
+              const double* trem, double* yaw, int64_t* smove, int64_t* fmove, uint8_t* jump) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= p.n) return;
+    Env e;
+    load_env(s, p.n, i, e);
+    double yaw_act;
+    const uint32_t keys = fetch_action(p, fmt, act_a, act_b, (size_t)i, &yaw_act);
+    const Cmd c = decode(p, e, keys, yaw_act, z_vel[i], trem[i]);
+    s.yaw[i] = e.yaw;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) s.lk[(size_t)k * p.n + i] = e.lk[k];
+    s.flags[i] = (uint8_t)e.flags;
+    yaw[i] = e.yaw;
+    smove[i] = (int64_t)c.smove;
+    fmove[i] = (int64_t)c.fmove;
+    jump[i] = c.jump ? 1 : 0;
+}
+
+__global__ void __launch_bounds__(256)
+decoder_reset_kernel(Params p, StatePtrs s, int count, const int32_t* idx, const double* yaw) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= count) return;
+    const int i = idx ? idx[j] : j;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) s.lk[(size_t)k * p.n + i] = -p.key_press_delay;   // env.py:277-278 / 289
+    s.flags[i] = s.flags[i] & 0x7u;                                               // env.py:279 / 290
+    s.yaw[i] = yaw[j];                                                            // env.py:281 / 291
+}
+
+// Stateless phys.apply (phys.py:184-197) with general pitch / roll (phys.py:56-66), all float64 trig.
+__global__ void __launch_bounds__(256)
+phys_apply_kernel(int n, const double* yaw, const double* pitch, const double* roll, const double* fmove,
+                  const double* smove, const uint8_t* button2, const double* time_delta, const double* z_pos,
+                  const float* vel, const uint8_t* on_ground, const uint8_t* jump_released,
+                  double* out_z, float* out_vel, uint8_t* out_og, uint8_t* out_jr) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Env e{};
+    e.vx = vel[3 * (size_t)i]; e.vy = vel[3 * (size_t)i + 1]; e.vz = vel[3 * (size_t)i + 2];
+    e.z = z_pos[i];
+    e.flags = (on_ground[i] ? FLAG_ON_GROUND : 0u) | (jump_released[i] ? FLAG_JUMP_RELEASED : 0u);
+    Cmd c;
+    c.fmove = fmove[i]; c.smove = smove[i]; c.jump = button2[i] != 0;
+    const double k = 3.141592653589793;
+    double sy, cy, sp = 0.0, cp = 1.0, sr = 0.0, cr = 1.0;
+    sincos((yaw[i] * k) / 180.0, &sy, &cy);
+    if (pitch) sincos((pitch[i] * k) / 180.0, &sp, &cp);
+    if (roll) sincos((roll[i] * k) / 180.0, &sr, &cr);
+    const double m00 = cp * cy;
+    const double m01 = ((-1.0 * sr) * sp) * cy + (-1.0 * cr) * (-sy);
+    const double m10 = cp * sy;
+    const double m11 = ((-1.0 * sr) * sp) * sy + (-1.0 * cr) * cy;
+    const double dt = time_delta[i];
+    physics(e, c, m00, m01, m10, m11, dt, 10.0 * dt, 800.0 * dt);
+    out_z[i] = e.z;
+    out_vel[3 * (size_t)i] = e.vx; out_vel[3 * (size_t)i + 1] = e.vy; out_vel[3 * (size_t)i + 2] = e.vz;
+    out_og[i] = (e.flags & FLAG_ON_GROUND) ? 1 : 0;
+    out_jr[i] = (e.flags & FLAG_JUMP_RELEASED) ? 1 : 0;
+}
+
+// =========================================================================================== host side
+static thread_local std::string g_err;
+
+static int fail(int code, const std::string& msg) {
+    g_err = msg;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                         \
+    do {                                                                                      \
+        hipError_t _e = (expr);                                                               \
+        if (_e != hipSuccess)                                                                 \
+            return fail(Q1ENV_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e));    \
+    } while (0)
+
+struct q1env {
+    q1env_config cfg{};
+    Params p{};
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    void* arena = nullptr;            // one allocation holding the whole SoA state
+    StatePtrs st{};
+    // staging for the *_host entry points (grown on demand)
+    void* stage = nullptr;
+    size_t stage_bytes = 0;
+    uint64_t tick_count = 0;          // ticks since create: the counter of the counter-based RNG
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    // cached graph for step_many
+    hipGraphExec_t gexec = nullptr;
+    std::vector<uint64_t> gkey;
+};
+
+static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+static inline dim3 grid_for(int n, int block) { return dim3((unsigned)((n + block - 1) / block)); }
+
+// Small batches are latency bound: 64-lane workgroups spread 64 k envs over all 256 CUs (1024 waves).
+// Large batches are bandwidth bound: 256-lane workgroups cut dispatch overhead.
+static inline int block_for(int n) { return n >= (1 << 19) ? 256 : 64; }
+
+static int ensure_stage(q1env* h, size_t bytes) {
+    if (bytes <= h->stage_bytes) return 0;
+    if (h->stage) (void)hipFree(h->stage);
+    h->stage = nullptr;
+    h->stage_bytes = 0;
+    HIP_TRY(hipMalloc(&h->stage, bytes));
+    h->stage_bytes = bytes;
+    return 0;
+}
+
+static int make_params(const q1env_config& c, Params& p, std::string& why) {
+    if (c.num_envs <= 0) { why = "num_envs must be > 0"; return -1; }
+    if (!(c.time_delta > 0)) { why = "time_delta must be > 0"; return -1; }
+    if (c.allow_yaw && c.discrete_yaw_steps != -1 && c.discrete_yaw_steps <= 0) {
+        why = "discrete_yaw_steps must be -1 or > 0"; return -1;
+    }
+    p.n = c.num_envs;
+    const bool has_jump_action = !c.auto_jump && c.allow_jump;          // env.py:206
+    p.num_keys = has_jump_action ? 4 : 3;                               // env.py:207
+    p.yaw_mode = !c.allow_yaw ? 0 : (c.discrete_yaw_steps == -1 ? 1 : 2);
+    p.act_width = p.num_keys + (p.yaw_mode ? 1 : 0);
+    p.jump_mode = c.auto_jump ? 2 : (c.allow_jump ? 1 : 0);             // env.py:262-267
+    p.smooth_keys = c.smooth_keys ? 1 : 0;
+    p.hover = c.hover ? 1 : 0;
+    p.speed_reward = c.speed_reward ? 1 : 0;
+    p.dt = c.time_delta;
+    p.time_limit = c.time_limit;
+    p.key_press_delay = c.key_press_delay;
+    p.yaw_num = (double)(720.0f * (float)c.time_delta);                 // env.py:230: float32 product (NEP 50)
+    p.yaw_steps = (double)c.discrete_yaw_steps;
+    p.yaw_den = (p.yaw_mode == 2) ? p.yaw_steps : c.action_range;       // env.py:236 / 238
+    p.fmove_max = (double)(float)c.fmove_max;                           // env.py:261
+    p.smove_max = (double)(float)c.smove_max;                           // env.py:260
+    p.accel_dt = 10.0 * c.time_delta;                                   // phys.py:78
+    p.grav_dt = 800.0 * c.time_delta;                                   // phys.py:122
+    p.zero_start_prob = c.zero_start_prob;
+    p.yaw_lo = c.initial_yaw_lo;
+    p.yaw_hi = c.initial_yaw_hi;
+    p.max_initial_speed = c.max_initial_speed;
+    p.action_range = c.action_range;
+    p.dt_f32 = (float)c.time_delta;                                     // env.py:501/503
+    p.action_range_f32 = (float)c.action_range;
+    p.env_index_base = c.env_index_base;
+    return 0;
+}
+
+static void carve(q1env* h) {
+    const size_t n = (size_t)h->p.n;
+    char* base = (char*)h->arena;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { void* q = base + off; off += align_up(bytes, 256); return q; };
+    h->st.vx = (float*)take(n * 4); h->st.vy = (float*)take(n * 4); h->st.vz = (float*)take(n * 4);
+    h->st.px = (double*)take(n * 8); h->st.py = (double*)take(n * 8); h->st.z = (double*)take(n * 8);
+    h->st.yaw = (double*)take(n * 8); h->st.trem = (double*)take(n * 8);
+    h->st.lk = (double*)take(n * 8 * 4);
+    h->st.flags = (uint8_t*)take(n);
+}
+
+static size_t arena_bytes(size_t n) {
+    return 3 * align_up(n * 4, 256) + 5 * align_up(n * 8, 256) + align_up(n * 32, 256) + align_up(n, 256);
+}
+
+extern "C" {
+
+int q1env_abi_version(void) { return Q1ENV_ABI_VERSION; }
+
+const char* q1env_last_error(void) { return g_err.c_str(); }
+
+int q1env_device_count(void) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) return fail(Q1ENV_ERR_NO_DEVICE, std::string("hipGetDeviceCount: ") + hipGetErrorString(e));
+    return n;
+}
+
+int q1env_create(const q1env_config* cfg, int device, void* stream, q1env_t** out) {
+    if (!cfg || !out) return fail(Q1ENV_ERR_INVALID_ARG, "q1env_create: null argument");
+    *out = nullptr;
+    Params p{};
+    std::string why;
+    if (make_params(*cfg, p, why) != 0) return fail(Q1ENV_ERR_INVALID_ARG, "q1env_create: " + why);
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(Q1ENV_ERR_NO_DEVICE, "q1env_create: no HIP device visible (libq1env has no CPU fallback)");
+    if (device < 0 || device >= ndev) return fail(Q1ENV_ERR_INVALID_ARG, "q1env_create: bad device index");
+    HIP_TRY(hipSetDevice(device));
+    q1env* h = new (std::nothrow) q1env();
+    if (!h) return fail(Q1ENV_ERR_ALLOC, "q1env_create: out of host memory");
+    h->cfg = *cfg;
+    h->p = p;
+    h->device = device;
+    if (stream) { h->stream = (hipStream_t)stream; h->own_stream = false; }
+    else {
+        hipError_t e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
+        if (e != hipSuccess) { delete h; return fail(Q1ENV_ERR_HIP, std::string("hipStreamCreate: ") + hipGetErrorString(e)); }
+        h->own_stream = true;
+    }
+    hipError_t e = hipMalloc(&h->arena, arena_bytes((size_t)p.n));
+    if (e != hipSuccess) {
+        if (h->own_stream) (void)hipStreamDestroy(h->stream);
+        delete h;
+        return fail(Q1ENV_ERR_ALLOC, std::string("hipMalloc(state): ") + hipGetErrorString(e));
+    }
+    carve(h);
+    (void)hipEventCreate(&h->ev0);
+    (void)hipEventCreate(&h->ev1);
+    // zero-start reset of every env: mask NULL, zero_start_prob forced to 1 for this launch
+    Params p0 = p;
+    p0.zero_start_prob = 2.0;
+    const int b = block_for(p.n);
+    hipLaunchKernelGGL(reset_philox_kernel<float>, grid_for(p.n, b), dim3(b), 0, h->stream, p0, h->st,
+                       (uint64_t)0, (uint64_t)0, (const uint8_t*)nullptr, 0, (float*)nullptr);
+    e = hipStreamSynchronize(h->stream);
+    if (e != hipSuccess) { q1env_destroy(h); return fail(Q1ENV_ERR_HIP, std::string("initial reset: ") + hipGetErrorString(e)); }
+    *out = h;
+    return Q1ENV_OK;
+}
+
+int q1env_destroy(q1env_t* h) {
+    if (!h) return Q1ENV_OK;
+    (void)hipSetDevice(h->device);
+    (void)hipStreamSynchronize(h->stream);
+    if (h->gexec) (void)hipGraphExecDestroy(h->gexec);
+    if (h->ev0) (void)hipEventDestroy(h->ev0);
+    if (h->ev1) (void)hipEventDestroy(h->ev1);
+    if (h->stage) (void)hipFree(h->stage);
+    if (h->arena) (void)hipFree(h->arena);
+    if (h->own_stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+    return Q1ENV_OK;
+}
+
+int q1env_sync(q1env_t* h) {
+    if (!h) return fail(Q1ENV_ERR_INVALID_ARG, "q1env_sync: null handle");
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return Q1ENV_OK;
+}
+
+int q1env_num_keys(const q1env_t* h) { return h ? h->p.num_keys : fail(Q1ENV_ERR_INVALID_ARG, "null handle"); }
+int q1env_action_width(const q1env_t* h) { return h ? h->p.act_width : fail(Q1ENV_ERR_INVALID_ARG, "null handle"); }
+
+static int check_act(const q1env* h, int fmt, const void* a, const void* b, bool allow_random) {
+    if (fmt == Q1ENV_ACT_RANDOM) return allow_random ? 0 : fail(Q1ENV_ERR_INVALID_ARG, "Q1ENV_ACT_RANDOM is rollout-only");
+    if (fmt < 0 || fmt > 2) return fail(Q1ENV_ERR_INVALID_ARG, "unknown action_format");
+    if (!a) return fail(Q1ENV_ERR_INVALID_ARG, "act_a is NULL");
+    if (fmt == Q1ENV_ACT_PACKED && h->p.yaw_mode && !b) return fail(Q1ENV_ERR_INVALID_ARG, "packed actions need act_b (mouse)");
+    return 0;
+}
+
+static size_t act_bytes_a(const q1env* h, int fmt) {
+    const size_t n = (size_t)h->p.n;
+    if (fmt == Q1ENV_ACT_F64_ROWS) return n * h->p.act_width * 8;
+    if (fmt == Q1ENV_ACT_F32_ROWS) return n * h->p.act_width * 4;
+    return n;
+}
+
+static void launch_step(q1env* h, int fmt, const void* a, const void* b, int obs_format, void* obs,
+                        float* reward, uint8_t* done, uint8_t* zs) {
+    const int blk = block_for(h->p.n);
+    if (obs_format == Q1ENV_OBS_F32)
+        hipLaunchKernelGGL(step_kernel<float>, grid_for(h->p.n, blk), dim3(blk), 0, h->stream, h->p, h->st, fmt, a, b,
+                           (float*)obs, reward, done, zs);
+    else
+        hipLaunchKernelGGL(step_kernel<double>, grid_for(h->p.n, blk), dim3(blk), 0, h->stream, h->p, h->st, fmt, a, b,
+                           (double*)obs, reward, done, zs);
+}
+
+int q1env_step(q1env_t* h, int fmt, const void* a, const void* b, int obs_format, void* obs, float* reward,
+               uint8_t* done, uint8_t* zs) {
+    if (!h) return fail(Q1ENV_ERR_INVALID_ARG, "q1env_step: null handle");
+    if (int r = check_act(h, fmt, a, b, false)) return r;
+    if (obs_format != Q1ENV_OBS_F32 && obs_format != Q1ENV_OBS_F64) return fail(Q1ENV_ERR_INVALID_ARG, "bad obs_format");
+    launch_step(h, fmt, a, b, obs_format, obs, reward, done, zs);
+    HIP_TRY(hipGetLastError());
+    h->tick_count += 1;
+    return Q1ENV_OK;
+}
+
+int q1env_step_host(q1env_t* h, int fmt, const void* a, const void* b, int obs_format, void* obs, float* reward,
+                    uint8_t* done, uint8_t* zs) {
+    if (!h) return fail(Q1ENV_ERR_INVALID_ARG, "q1env_step_host: null handle");
+    if (int r = check_act(h, fmt, a, b, false)) return r;
+    if (obs_format != Q1ENV_OBS_F32 && obs_format != Q1ENV_OBS_F64) return fail(Q1ENV_ERR_INVALID_ARG, "bad obs_format");
+    HIP_TRY(hipSetDevice(h->device));
+    const size_t n = (size_t)h->p.n;
+    const size_t ba = align_up(act_bytes_a(h, fmt), 256), bb = align_up(n * 4, 256);
+    const size_t bo = align_up(n * 6 * (obs_format == Q1ENV_OBS_F32 ? 4 : 8), 256);
+    const size_t br = align_up(n * 4, 256), bd = align_up(n, 256);
+    if (int r = ensure_stage(h, ba + bb + bo + br + 2 * bd)) return r;
+    char* d = (char*)h->stage;
+    void* d_a = d; void* d_b = d + ba; void* d_o = d + ba + bb;
+    float* d_r = (float*)(d + ba + bb + bo); uint8_t* d_d = (uint8_t*)(d + ba + bb + bo + br); uint8_t* d_z = d_d + bd;
+    HIP_TRY(hipMemcpyAsync(d_a, a, act_bytes_a(h, fmt), hipMemcpyHostToDevice, h->stream));
+    if (fmt == Q1ENV_ACT_PACKED && h->p.yaw_mode) HIP_TRY(hipMemcpyAsync(d_b, b, n * 4, hipMemcpyHostToDevice, h->stream));
+    launch_step(h, fmt, d_a, d_b, obs_format, obs ? d_o : nullptr, reward ? d_r : nullptr, done ? d_d : nullptr, zs ? d_z : nullptr);
+    HIP_TRY(hipGetLastError());
+    h->tick_count += 1;
+    if (obs) HIP_TRY(hipMemcpyAsync(obs, d_o, n * 6 * (obs_format == Q1ENV_OBS_F32 ? 4 : 8), hipMemcpyDeviceToHost, h->stream));
+    if (reward) HIP_TRY(hipMemcpyAsync(reward, d_r, n * 4, hipMemcpyDeviceToHost, h->stream));
+    if (done) HIP_TRY(hipMemcpyAsync(done, d_d, n, hipMemcpyDeviceToHost, h->stream));
+    if (zs) HIP_TRY(hipMemcpyAsync(zs, d_z, n, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return Q1ENV_OK;
+}
+
+static void enqueue_many(q1env* h, int ticks, int fmt, const void* a, const void* b, int obs_format, void* obs,
+                         float* reward, uint8_t* done, int out_stride) {
+    const size_t n = (size_t)h->p.n;
+    const size_t sa = act_bytes_a(h, fmt), sb = n * 4;
+    const size_t so = n * 6 * (obs_format == Q1ENV_OBS_F32 ? 4 : 8);
+    for (int t = 0; t < ticks; ++t) {
+        const size_t ot = out_stride ? (size_t)t : 0;
+        launch_step(h, fmt, (const char*)a + sa * t, b ? (const char*)b + sb * t : nullptr, obs_format,
+                    obs ? (char*)obs + so * ot : nullptr, reward ? reward + n * ot : nullptr,
+                    done ? done + n * ot : nullptr, nullptr);
+    }
+}
+
+int q1env_step_many(q1env_t* h, int ticks, int fmt, const void* a, const void* b, int obs_format, void* obs,
+                    float* reward, uint8_t* done, int out_stride, int use_graph) {
+    if (!h) return fail(Q1ENV_ERR_INVALID_ARG, "q1env_step_many: null handle");
+    if (ticks <= 0) return fail(Q1ENV_ERR_INVALID_ARG, "ticks must be > 0");
+    if (int r = check_act(h, fmt, a, b, false)) return r;
+    if (obs_format != Q1ENV_OBS_F32 && obs_format != Q1ENV_OBS_F64) return fail(Q1ENV_ERR_INVALID_ARG, "bad obs_format");
+    if (!use_graph) {
+        enqueue_many(h, ticks, fmt, a, b, obs_format, obs, reward, done, out_stride);
+        HIP_TRY(hipGetLastError());
+    } else {
+        std::vector<uint64_t> key = {(uint64_t)ticks, (uint64_t)fmt, (uint64_t)(uintptr_t)a, (uint64_t)(uintptr_t)b,
+                                     (uint64_t)obs_format, (uint64_t)(uintptr_t)obs, (uint64_t)(uintptr_t)reward,
+                                     (uint64_t)(uintptr_t)done, (uint64_t)out_stride};
+        if (!h->gexec || key != h->gkey) {
+            if (h->gexec) { (void)hipGraphExecDestroy(h->gexec); h->gexec = nullptr; }
+            hipGraph_t g = nullptr;
+            HIP_TRY(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
+            enqueue_many(h, ticks, fmt, a, b, obs_format, obs, reward, done, out_stride);
+            HIP_TRY(hipStreamEndCapture(h->stream, &g));
+            hipError_t e = hipGraphInstantiate(&h->gexec, g, nullptr, nullptr, 0);
+            (void)hipGraphDestroy(g);
+            if (e != hipSuccess) { h->gexec = nullptr; return fail(Q1ENV_ERR_HIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(e)); }
+            h->gkey = key;
+        }
+        HIP_TRY(hipGraphLaunch(h->gexec, h->stream));
+    }
+    h->tick_count += (uint64_t)ticks;
+    return Q1ENV_OK;
+}
+
+int q1env_rollout(q1env_t* h, int ticks, int fmt, const void* a, const void* b, uint64_t seed, int obs_format,
+                  void* obs, float* reward, uint8_t* done, int auto_reset, double* return_sum) {
+    if (!h) return fail(Q1ENV_ERR_INVALID_ARG, "q1env_rollout: null handle");
+    if (ticks <= 0) return fail(Q1ENV_ERR_INVALID_ARG, "ticks must be > 0");
+    if (int r = check_act(h, fmt, a, b, true)) return r;
+    if (obs_format != Q1ENV_OBS_F32 && obs_format != Q1ENV_OBS_F64) return fail(Q1ENV_ERR_INVALID_ARG, "bad obs_format");
+    const int blk = block_for(h->p.n);
+    if (obs_format == Q1ENV_OBS_F32)
+        hipLaunchKernelGGL(rollout_kernel<float>, grid_for(h->p.n, blk), dim3(blk), 0, h->stream, h->p, h->st, ticks, fmt, a, b,
+                           seed, h->tick_count, (float*)obs, reward, done, auto_reset, return_sum);
+    else
+        hipLaunchKernelGGL(rollout_kernel<double>, grid_for(h->p.n, blk), dim3(blk), 0, h->stream, h->p, h->st, ticks, fmt, a, b,
+                           seed, h->tick_count, (double*)obs, reward, done, auto_reset, return_sum);
+    HIP_TRY(hipGetLastError());
+    h->tick_count += (uint64_t)ticks;
+    return Q1ENV_OK;
+}
+
+int q1env_observe(q1env_t* h, int obs_format, void* obs) {
+    if (!h || !obs) return fail(Q1ENV_ERR_INVALID_ARG, "q1env_observe: null argument");
+    const int blk = block_for(h->p.n);
+    if (obs_format == Q1ENV_OBS_F32)
+        hipLaunchKernelGGL(observe_kernel<float>, grid_for(h->p.n, blk), dim3(blk), 0, h->stream, h->p, h->st, (float*)obs);
+    else if (obs_format == Q1ENV_OBS_F64)
+        hipLaunchKernelGGL(observe_kernel<double>, grid_for(h->p.n, blk), dim3(blk), 0, h->stream, h->p, h->st, (double*)obs);
+    else return fail(Q1ENV_ERR_INVALID_ARG, "bad obs_format");
+    HIP_TRY(hipGetLastError());
+    return Q1ENV_OK;
+}
+
+int q1env_observe_host(q1env_t* h, int obs_format, void* obs) {
+    if (!h || !obs) return fail(Q1ENV_ERR_INVALID_ARG, "q1env_observe_host: null argument");
+    HIP_TRY(hipSetDevice(h->device));
+    const size_t bytes = (size_t)h->p.n * 6 * (obs_format == Q1ENV_OBS_F32 ? 4 : 8);
+    if (int r = ensure_stage(h, bytes)) return r;
+    if (int r = q1env_observe(h, obs_format, h->stage)) return r;
+    HIP_TRY(hipMemcpyAsync(obs, h->stage, bytes, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return Q1ENV_OK;
+}
+
+int q1env_reset_draws_host(q1env_t* h, int64_t count, const int32_t* idx, const uint8_t* zero_start, const double* yaw,
+                           const double* tm, const double* speed, const double* angle, int obs_format, void* obs) {
+    if (!h || !zero_start || !yaw || !tm || !speed || !angle) return fail(Q1ENV_ERR_INVALID_ARG, "q1env_reset_draws_host: null argument");
+    if (count <= 0 || (!idx && count > h->p.n)) return fail(Q1ENV_ERR_INVALID_ARG, "q1env_reset_draws_host: bad count");
+    if (obs_format != Q1ENV_OBS_F32 && obs_format != Q1ENV_OBS_F64) return fail(Q1ENV_ERR_INVALID_ARG, "bad obs_format");
+    if (idx) for (int64_t j = 0; j < count; ++j)
+        if (idx[j] < 0 || idx[j] >= h->p.n) return fail(Q1ENV_ERR_INVALID_ARG, "q1env_reset_draws_host: index out of range");
+    HIP_TRY(hipSetDevice(h->device));
+    const size_t c = (size_t)count;
+    const size_t bi = align_up(c * 4, 256), bz = align_up(c, 256), bd = align_up(c * 8, 256);
+    const size_t bo = align_up(c * 6 * (obs_format == Q1ENV_OBS_F32 ? 4 : 8), 256);
+    if (int r = ensure_stage(h, bi + bz + 4 * bd + bo)) return r;
+    char* d = (char*)h->stage;
+    int32_t* d_i = (int32_t*)d; uint8_t* d_z = (uint8_t*)(d + bi);
+    double* d_y = (double*)(d + bi + bz); double* d_t = (double*)(d + bi + bz + bd);
+    double* d_s = (double*)(d + bi + bz + 2 * bd); double* d_a = (double*)(d + bi + bz + 3 * bd);
+    void* d_o = d + bi + bz + 4 * bd;
+    if (idx) HIP_TRY(hipMemcpyAsync(d_i, idx, c * 4, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipMemcpyAsync(d_z, zero_start, c, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipMemcpyAsync(d_y, yaw, c * 8, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipMemcpyAsync(d_t, tm, c * 8, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipMemcpyAsync(d_s, speed, c * 8, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipMemcpyAsync(d_a, angle, c * 8, hipMemcpyHostToDevice, h->stream));
+    const int blk = 64;
+    if (obs_format == Q1ENV_OBS_F32)
+        hipLaunchKernelGGL(reset_draws_kernel<float>, grid_for((int)count, blk), dim3(blk), 0, h->stream, h->p, h->st, (int)count,
+                           idx ? d_i : nullptr, d_z, d_y, d_t, d_s, d_a, obs ? (float*)d_o : nullptr);
+    else
+        hipLaunchKernelGGL(reset_draws_kernel<double>, grid_for((int)count, blk), dim3(blk), 0, h->stream, h->p, h->st, (int)count,
+                           idx ? d_i : nullptr, d_z, d_y, d_t, d_s, d_a, obs ? (double*)d_o : nullptr);
+    HIP_TRY(hipGetLastError());
+    if (obs) HIP_TRY(hipMemcpyAsync(obs, d_o, c * 6 * (obs_format == Q1ENV_OBS_F32 ? 4 : 8), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return Q1ENV_OK;
+}
+
+int q1env_reset_philox(q1env_t* h, uint64_t seed, const uint8_t* mask, int done_only, int obs_format, void* obs) {
+    if (!h) return fail(Q1ENV_ERR_INVALID_ARG, "q1env_reset_philox: null handle");
+    const int blk = block_for(h->p.n);
+    if (obs_format == Q1ENV_OBS_F32)
+        hipLaunchKernelGGL(reset_philox_kernel<float>, grid_for(h->p.n, blk), dim3(blk), 0, h->stream, h->p, h->st, seed,
+                           h->tick_count, mask, done_only, (float*)obs);
+    else if (obs_format == Q1ENV_OBS_F64)
+        hipLaunchKernelGGL(reset_philox_kernel<double>, grid_for(h->p.n, blk), dim3(blk), 0, h->stream, h->p, h->st, seed,
+                           h->tick_count, mask, done_only, (double*)obs);
+    else return fail(Q1ENV_ERR_INVALID_ARG, "bad obs_format");
+    HIP_TRY(hipGetLastError());
+    return Q1ENV_OK;
+}
+
+static int copy_state(q1env* h, const q1env_state* s, bool to_host) {
+    HIP_TRY(hipSetDevice(h->device));
+    const size_t n = (size_t)h->p.n;
+    struct Item { void* host; void* dev; size_t bytes; };
+    const Item items[] = {
+        {s->vel_x, h->st.vx, n * 4}, {s->vel_y, h->st.vy, n * 4}, {s->vel_z, h->st.vz, n * 4},
+        {s->pos_x, h->st.px, n * 8}, {s->pos_y, h->st.py, n * 8}, {s->z_pos, h->st.z, n * 8},
+        {s->yaw, h->st.yaw, n * 8}, {s->time_remaining, h->st.trem, n * 8},
+        {s->last_key_press_time, h->st.lk, n * 32}, {s->flags, h->st.flags, n},
+    };
+    for (const Item& it : items) {
+        if (!it.host) continue;
+        if (to_host) HIP_TRY(hipMemcpyAsync(it.host, it.dev, it.bytes, hipMemcpyDeviceToHost, h->stream));
+        else HIP_TRY(hipMemcpyAsync(it.dev, it.host, it.bytes, hipMemcpyHostToDevice, h->stream));
+    }
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return Q1ENV_OK;
+}
+
+int q1env_get_state_host(q1env_t* h, const q1env_state* dst) {
+    if (!h || !dst) return fail(Q1ENV_ERR_INVALID_ARG, "q1env_get_state_host: null argument");
+    return copy_state(h, dst, true);
+}
+
+int q1env_set_state_host(q1env_t* h, const q1env_state* src) {
+    if (!h || !src) return fail(Q1ENV_ERR_INVALID_ARG, "q1env_set_state_host: null argument");
+    return copy_state(h, src, false);
+}
+
+int q1env_state_device_ptrs(q1env_t* h, q1env_state* out) {
+    if (!h || !out) return fail(Q1ENV_ERR_INVALID_ARG, "q1env_state_device_ptrs: null argument");
+    out->vel_x = h->st.vx; out->vel_y = h->st.vy; out->vel_z = h->st.vz;
+    out->pos_x = h->st.px; out->pos_y = h->st.py; out->z_pos = h->st.z;
+    out->yaw = h->st.yaw; out->time_remaining = h->st.trem;
+    out->last_key_press_time = h->st.lk; out->flags = h->st.flags;
+    return Q1ENV_OK;
+}
+
+int q1env_decode_host(q1env_t* h, int fmt, const void* a, const void* b, const float* z_vel, const double* trem,
+                      double* yaw, int64_t* smove, int64_t* fmove, uint8_t* jump) {
+    if (!h || !z_vel || !trem || !yaw || !smove || !fmove || !jump) return fail(Q1ENV_ERR_INVALID_ARG, "q1env_decode_host: null argument");
+    if (int r = check_act(h, fmt, a, b, false)) return r;
+    HIP_TRY(hipSetDevice(h->device));
+    const size_t n = (size_t)h->p.n;
+    const size_t ba = align_up(act_bytes_a(h, fmt), 256), b4 = align_up(n * 4, 256), b8 = align_up(n * 8, 256), b1 = align_up(n, 256);
+    if (int r = ensure_stage(h, ba + 2 * b4 + 4 * b8 + b1)) return r;
+    char* d = (char*)h->stage;
+    void* d_a = d; void* d_b = d + ba; float* d_zv = (float*)(d + ba + b4);
+    double* d_tr = (double*)(d + ba + 2 * b4); double* d_y = d_tr + b8 / 8;
+    int64_t* d_sm = (int64_t*)(d_y + b8 / 8); int64_t* d_fm = d_sm + b8 / 8; uint8_t* d_j = (uint8_t*)(d_fm + b8 / 8);
+    HIP_TRY(hipMemcpyAsync(d_a, a, act_bytes_a(h, fmt), hipMemcpyHostToDevice, h->stream));
+    if (fmt == Q1ENV_ACT_PACKED && h->p.yaw_mode) HIP_TRY(hipMemcpyAsync(d_b, b, n * 4, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipMemcpyAsync(d_zv, z_vel, n * 4, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipMemcpyAsync(d_tr, trem, n * 8, hipMemcpyHostToDevice, h->stream));
+    const int blk = block_for(h->p.n);
+    hipLaunchKernelGGL(decode_kernel, grid_for(h->p.n, blk), dim3(blk), 0, h->stream, h->p, h->st, fmt, (const void*)d_a,
+                       (const void*)d_b, (const float*)d_zv, (const double*)d_tr, d_y, d_sm, d_fm, d_j);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(yaw, d_y, n * 8, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipMemcpyAsync(smove, d_sm, n * 8, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipMemcpyAsync(fmove, d_fm, n * 8, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipMemcpyAsync(jump, d_j, n, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return Q1ENV_OK;
+}
+
+int q1env_decoder_reset_host(q1env_t* h, int64_t count, const int32_t* idx, const double* yaw) {
+    if (!h || !yaw) return fail(Q1ENV_ERR_INVALID_ARG, "q1env_decoder_reset_host: null argument");
+    if (count <= 0 || (!idx && count > h->p.n)) return fail(Q1ENV_ERR_INVALID_ARG, "q1env_decoder_reset_host: bad count");
+    if (idx) for (int64_t j = 0; j < count; ++j)
+        if (idx[j] < 0 || idx[j] >= h->p.n) return fail(Q1ENV_ERR_INVALID_ARG, "q1env_decoder_reset_host: index out of range");
+    HIP_TRY(hipSetDevice(h->device));
+    const size_t c = (size_t)count;
+    const size_t bi = align_up(c * 4, 256), bd = align_up(c * 8, 256);
+    if (int r = ensure_stage(h, bi + bd)) return r;
+    int32_t* d_i = (int32_t*)h->stage; double* d_y = (double*)((char*)h->stage + bi);
+    if (idx) HIP_TRY(hipMemcpyAsync(d_i, idx, c * 4, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipMemcpyAsync(d_y, yaw, c * 8, hipMemcpyHostToDevice, h->stream));
+    hipLaunchKernelGGL(decoder_reset_kernel, grid_for((int)count, 64), dim3(64), 0, h->stream, h->p, h->st, (int)count,
+                       idx ? (const int32_t*)d_i : (const int32_t*)nullptr, (const double*)d_y);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return Q1ENV_OK;
+}
+
+int q1phys_apply_host(int device, int64_t n64, const double* yaw, const double* pitch, const double* roll, const double* fmove,
+                      const double* smove, const uint8_t* button2, const double* time_delta, const double* z_pos,
+                      const float* vel, const uint8_t* on_ground, const uint8_t* jump_released, double* out_z, float* out_vel,
+                      uint8_t* out_og, uint8_t* out_jr) {
+    if (!yaw || !fmove || !smove || !button2 || !time_delta || !z_pos || !vel || !on_ground || !jump_released || !out_z ||
+        !out_vel || !out_og || !out_jr)
+        return fail(Q1ENV_ERR_INVALID_ARG, "q1phys_apply_host: null argument");
+    if (n64 <= 0 || n64 > (int64_t)1 << 30) return fail(Q1ENV_ERR_INVALID_ARG, "q1phys_apply_host: bad n");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(Q1ENV_ERR_NO_DEVICE, "q1phys_apply_host: no HIP device visible (libq1env has no CPU fallback)");
+    HIP_TRY(hipSetDevice(device));
+    const size_t n = (size_t)n64;
+    const size_t b8 = align_up(n * 8, 256), b1 = align_up(n, 256), b12 = align_up(n * 12, 256);
+    char* d = nullptr;
+    const size_t total = 8 * b8 + 5 * b1 + 2 * b12;
+    HIP_TRY(hipMalloc((void**)&d, total));
+    double* d_yaw = (double*)d; double* d_pitch = d_yaw + b8 / 8; double* d_roll = d_pitch + b8 / 8;
+    double* d_f = d_roll + b8 / 8; double* d_s = d_f + b8 / 8; double* d_dt = d_s + b8 / 8; double* d_z = d_dt + b8 / 8;
+    double* d_oz = d_z + b8 / 8;
+    char* q = (char*)(d_oz + b8 / 8);
+    uint8_t* d_b2 = (uint8_t*)q; uint8_t* d_og = d_b2 + b1; uint8_t* d_jr = d_og + b1; uint8_t* d_oog = d_jr + b1; uint8_t* d_ojr = d_oog + b1;
+    float* d_v = (float*)(d_ojr + b1); float* d_ov = (float*)((char*)d_v + b12);
+    int rc = Q1ENV_OK;
+    auto up = [&](void* dst, const void* src, size_t bytes) {
+        if (rc == Q1ENV_OK && hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice) != hipSuccess) rc = fail(Q1ENV_ERR_HIP, "q1phys_apply_host: H2D failed");
+    };
+    up(d_yaw, yaw, n * 8); if (pitch) up(d_pitch, pitch, n * 8); if (roll) up(d_roll, roll, n * 8);
+    up(d_f, fmove, n * 8); up(d_s, smove, n * 8); up(d_dt, time_delta, n * 8); up(d_z, z_pos, n * 8);
+    up(d_b2, button2, n); up(d_og, on_ground, n); up(d_jr, jump_released, n); up(d_v, vel, n * 12);
+    if (rc == Q1ENV_OK) {
+        hipLaunchKernelGGL(phys_apply_kernel, grid_for((int)n, 256), dim3(256), 0, 0, (int)n, (const double*)d_yaw,
+                           pitch ? (const double*)d_pitch : (const double*)nullptr, roll ? (const double*)d_roll : (const double*)nullptr,
+                           (const double*)d_f, (const double*)d_s, (const uint8_t*)d_b2, (const double*)d_dt, (const double*)d_z,
+                           (const float*)d_v, (const uint8_t*)d_og, (const uint8_t*)d_jr, d_oz, d_ov, d_oog, d_ojr);
+        auto down = [&](void* dst, const void* src, size_t bytes) {
+            if (rc == Q1ENV_OK && hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost) != hipSuccess) rc = fail(Q1ENV_ERR_HIP, "q1phys_apply_host: D2H failed");
+        };
+        down(out_z, d_oz, n * 8); down(out_vel, d_ov, n * 12); down(out_og, d_oog, n); down(out_jr, d_ojr, n);
+    }
+    (void)hipFree(d);
+    return rc;
+}
+
+int q1env_timer_start(q1env_t* h) {
+    if (!h) return fail(Q1ENV_ERR_INVALID_ARG, "q1env_timer_start: null handle");
+    HIP_TRY(hipEventRecord(h->ev0, h->stream));
+    return Q1ENV_OK;
+}
+
+int q1env_timer_stop(q1env_t* h, float* ms) {
+    if (!h || !ms) return fail(Q1ENV_ERR_INVALID_ARG, "q1env_timer_stop: null argument");
+    HIP_TRY(hipEventRecord(h->ev1, h->stream));
+    HIP_TRY(hipEventSynchronize(h->ev1));
+    HIP_TRY(hipEventElapsedTime(ms, h->ev0, h->ev1));
+    return Q1ENV_OK;
+}
+
+}  // extern "C"

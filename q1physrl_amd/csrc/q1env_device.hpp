@@ -1,0 +1,334 @@
+// q1env_device.hpp - per-env arithmetic of the q1physrl hot path, written for gfx950 (CDNA4).
+//
+// One env = one lane.  All per-tick constants live in a `Params` struct passed BY VALUE as a kernel
+// argument, so they arrive through the scalar data path (s_load -> SGPRs) and cost no VGPRs, no LDS
+// and no per-lane loads.  Every branch on `Params` is wave-uniform.
+//
+// Numerics contract (restated from the reference as executed by NumPy 2.2.6):
+//   * yaw, time_remaining, last_key_press_time, z_pos and all horizontal intermediates: float64
+//   * vel: float32 storage, round-to-nearest-even on store (phys.py:190)
+//   * float32 islands: friction speed/control (phys.py:85-86), the +270 jump add (phys.py:119),
+//     the reward multiply (env.py:500-503)
+//   * no FMA contraction (this file MUST be compiled with -ffp-contract=off), true division,
+//     correctly rounded sqrt; einsum sums start from +0.0 (sign of zero results)
+//   * sin/cos: float64 ocml sincos (<= 2 ulp; the float32 rounding of vel absorbs it)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace q1 {
+
+constexpr uint32_t FLAG_ON_GROUND = 1u << 0;
+constexpr uint32_t FLAG_JUMP_RELEASED = 1u << 1;
+constexpr uint32_t FLAG_ZERO_START = 1u << 2;
+constexpr int FLAG_KEYS_SHIFT = 3;
+
+constexpr uint32_t STREAM_ACTION = 1;   // Philox stream tags
+constexpr uint32_t STREAM_RESET = 2;
+
+struct Params {
+    int32_t n;
+    int32_t num_keys;       // 4, or 3 when auto_jump || !allow_jump (env.py:206-207)
+    int32_t act_width;      // num_keys + (yaw_mode != 0)
+    int32_t yaw_mode;       // 0 none, 1 continuous, 2 discrete (env.py:233-238)
+    int32_t jump_mode;      // 0 never, 1 jump key, 2 auto-jump (env.py:262-267)
+    int32_t smooth_keys;
+    int32_t hover;
+    int32_t speed_reward;
+    double dt;              // time_delta
+    double time_limit;
+    double key_press_delay;
+    double yaw_num;         // double(float32(720) * float32(dt))        env.py:230 under NEP 50
+    double yaw_den;         // double(action_range) or discrete_yaw_steps env.py:236/238
+    double yaw_steps;
+    double fmove_max;       // double(float32(fmove_max))                 env.py:261
+    double smove_max;       // double(float32(smove_max))                 env.py:260
+    double accel_dt;        // double(float32(10)) * dt                   phys.py:78
+    double grav_dt;         // double(float32(800)) * dt                  phys.py:122
+    double zero_start_prob;
+    double yaw_lo, yaw_hi;
+    double max_initial_speed;
+    double action_range;
+    float dt_f32;           // float32(dt)                                env.py:501/503
+    float action_range_f32;
+    int64_t env_index_base;
+};
+
+// SoA state in HBM.  Every array is num_envs long and 256-B aligned; lane i of a wave touches element
+// base+i of each array, so every load/store instruction of a wave is one contiguous, aligned segment.
+struct StatePtrs {
+    float* vx; float* vy; float* vz;
+    double* px; double* py; double* z;
+    double* yaw; double* trem;
+    double* lk;            // [4][n] key-major
+    uint8_t* flags;
+};
+
+struct Env {               // one env's state in registers
+    float vx, vy, vz;
+    double px, py, z, yaw, trem;
+    double lk[4];
+    uint32_t flags;
+};
+
+struct Cmd {               // ActionDecoder.map's outputs for one env (env.py:269)
+    double fmove, smove;
+    bool jump;
+};
+
+struct TickOut {
+    double obs[6];
+    float reward;
+    bool done;
+};
+
+__device__ __forceinline__ void load_env(const StatePtrs& s, int n, int i, Env& e) {
+    e.vx = s.vx[i]; e.vy = s.vy[i]; e.vz = s.vz[i];
+    e.px = s.px[i]; e.py = s.py[i]; e.z = s.z[i];
+    e.yaw = s.yaw[i]; e.trem = s.trem[i];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) e.lk[k] = s.lk[(size_t)k * n + i];
+    e.flags = s.flags[i];
+}
+
+__device__ __forceinline__ void store_env(const StatePtrs& s, int n, int i, const Env& e) {
+    s.vx[i] = e.vx; s.vy[i] = e.vy; s.vz[i] = e.vz;
+    s.px[i] = e.px; s.py[i] = e.py; s.z[i] = e.z;
+    s.yaw[i] = e.yaw; s.trem[i] = e.trem;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) s.lk[(size_t)k * n + i] = e.lk[k];
+    s.flags[i] = (uint8_t)e.flags;
+}
+
+// ---------------------------------------------------------------------------------------- Philox
+__host__ __device__ __forceinline__ void philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        uint64_t p0 = (uint64_t)0xD2511F53u * c[0];
+        uint64_t p1 = (uint64_t)0xCD9E8D57u * c[2];
+        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0;
+        uint32_t n1 = (uint32_t)p1;
+        uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1;
+        uint32_t n3 = (uint32_t)p0;
+        c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+}
+
+__host__ __device__ __forceinline__ void philox_draw(uint64_t seed, uint64_t genv, uint64_t counter,
+                                                     uint32_t stream, uint32_t sub, uint32_t out[4]) {
+    out[0] = (uint32_t)genv; out[1] = (uint32_t)(genv >> 32);
+    out[2] = (uint32_t)counter;
+    out[3] = (stream << 28) | ((sub & 0xFu) << 24) | ((uint32_t)(counter >> 32) & 0xFFFFFFu);
+    philox4x32_10(out, (uint32_t)seed, (uint32_t)(seed >> 32));
+}
+
+__host__ __device__ __forceinline__ double u53(uint32_t a, uint32_t b) {   // [0,1) with 53 random bits
+    return ((double)(a >> 5) * 67108864.0 + (double)(b >> 6)) / 9007199254740992.0;
+}
+
+// iid random action for (seed, global env, tick): Bernoulli(1/2) keys, mouse ~ U(-range, range) in float32
+// (or a uniform discrete step).  Returns key bits; *yaw_act is what a policy would have emitted.
+__device__ __forceinline__ uint32_t random_action(const Params& p, uint64_t seed, uint64_t genv, uint64_t tick,
+                                                  double* yaw_act) {
+    uint32_t r[4];
+    philox_draw(seed, genv, tick, STREAM_ACTION, 0, r);
+    uint32_t keys = r[0] & ((1u << p.num_keys) - 1u);
+    if (p.yaw_mode == 1) {
+        float u = (float)(r[1] >> 8) * (1.0f / 16777216.0f);
+        float a = (u * 2.0f - 1.0f) * p.action_range_f32;
+        *yaw_act = (double)a;
+    } else if (p.yaw_mode == 2) {
+        uint32_t m = 2u * (uint32_t)p.yaw_steps + 1u;
+        *yaw_act = (double)(r[1] % m);
+    } else {
+        *yaw_act = 0.0;
+    }
+    return keys;
+}
+
+// ---------------------------------------------------------------------------------------- actions
+// Fetch env i's action from any of the device layouts (include/q1env.h Q1ENV_ACT_*): key bits (bit k =
+// trunc(a_k) & 1, the reference's `key_actions & (...)` on astype(int), env.py:228,243) and the mouse value.
+__device__ __forceinline__ uint32_t fetch_action(const Params& p, int fmt, const void* a, const void* b,
+                                                 size_t i, double* yaw_act) {
+    uint32_t keys = 0;
+    *yaw_act = 0.0;
+    if (fmt == 2) {                                   // packed: 1 B keys + 4 B mouse
+        keys = ((const uint8_t*)a)[i] & ((1u << p.num_keys) - 1u);
+        if (p.yaw_mode) *yaw_act = (double)((const float*)b)[i];
+    } else if (fmt == 0) {                            // float64 rows
+        const double* row = (const double*)a + i * (size_t)p.act_width;
+        for (int k = 0; k < p.num_keys; ++k) keys |= (uint32_t)((long long)row[k] & 1) << k;
+        if (p.yaw_mode) *yaw_act = row[p.num_keys];
+    } else {                                          // float32 rows
+        const float* row = (const float*)a + i * (size_t)p.act_width;
+        for (int k = 0; k < p.num_keys; ++k) keys |= (uint32_t)((long long)row[k] & 1) << k;
+        if (p.yaw_mode) *yaw_act = (double)row[p.num_keys];
+    }
+    return keys;
+}
+
+// ---------------------------------------------------------------------------------------- decode
+// ActionDecoder.map for one env (env.py:225-269).  z_vel / trem are passed separately because the
+// stand-alone decoder takes them from the caller (mkdemo.py:47-55).
+__device__ __forceinline__ Cmd decode(const Params& p, Env& e, uint32_t keybits, double yaw_act,
+                                      float z_vel, double trem) {
+    const double now = p.time_limit - trem;                             // env.py:241,246
+    const uint32_t prev = (e.flags >> FLAG_KEYS_SHIFT) & 0xFu;
+    uint32_t keys = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        if (k < p.num_keys) {
+            const bool may_press = now >= e.lk[k] + p.key_press_delay;  // float64 compare (env.py:241-242)
+            const uint32_t pk = (prev >> k) & 1u;
+            const uint32_t key = ((keybits >> k) & 1u) & ((may_press ? 1u : 0u) | pk);   // env.py:243
+            if (key & ~pk & 1u) e.lk[k] = now;                          // rising edge (env.py:244-248)
+            keys |= key << k;
+        }
+    }
+    double lvl[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const double kk = (double)((keys >> k) & 1u);
+        lvl[k] = p.smooth_keys ? (kk + (double)((prev >> k) & 1u)) * 0.5 : kk;   // env.py:251-254
+    }
+    e.flags = (e.flags & 0x7u) | (keys << FLAG_KEYS_SHIFT);             // env.py:256
+
+    double dyaw = 0.0;
+    if (p.yaw_mode == 1) dyaw = (yaw_act * p.yaw_num) / p.yaw_den;      // env.py:236
+    else if (p.yaw_mode == 2) dyaw = ((yaw_act - p.yaw_steps) * p.yaw_num) / p.yaw_den;   // env.py:238
+    e.yaw = e.yaw + dyaw;                                               // env.py:258
+
+    Cmd c;
+    c.smove = trunc(p.smove_max * (lvl[1] - lvl[0])) + 0.0;             // astype(int): toward zero, +0 (env.py:259-260,269)
+    c.fmove = trunc(p.fmove_max * lvl[2]) + 0.0;                        // env.py:261,269
+    if (p.jump_mode == 2) c.jump = z_vel <= 16.0f;                      // env.py:263
+    else if (p.jump_mode == 1) c.jump = (keys >> 3) & 1u;               // env.py:265
+    else c.jump = false;                                                // env.py:267
+    return c;
+}
+
+// ---------------------------------------------------------------------------------------- physics
+// phys.apply for one env (phys.py:184-197).  The 2x2 basis (forward | right, phys.py:65-66) is passed in:
+// the env always has pitch = roll = 0, i.e. m = [[cos, sin], [sin, -cos]].
+// The wave-level ballot of the PREVIOUS tick's on_ground lets airborne waves skip the whole friction
+// block (float32 sqrt + float64 divide) through a wave-uniform branch.
+__device__ __forceinline__ void physics(Env& e, const Cmd& c, double m00, double m01, double m10, double m11,
+                                        double dt, double accel_dt, double grav_dt) {
+    const bool og = e.flags & FLAG_ON_GROUND;
+    // einsum('ijk,ik->ij') accumulates from +0.0 (phys.py:97)
+    const double wx = (0.0 + m00 * c.fmove) + m01 * c.smove;
+    const double wy = (0.0 + m10 * c.fmove) + m11 * c.smove;
+    const double wlen = sqrt(wx * wx + wy * wy);                        // phys.py:98
+    double dx = wx, dy = wy;
+    if (wlen > 0.0) { dx = wx / wlen; dy = wy / wlen; }                 // phys.py:99-101
+    const double wish_speed = fmin(320.0, wlen);                        // phys.py:103
+
+    double hx = (double)e.vx, hy = (double)e.vy;
+    if (__ballot(og)) {                                                 // wave-uniform skip
+        const float speed = sqrtf(e.vx * e.vx + e.vy * e.vy);           // float32 norm (phys.py:85)
+        if (og && speed > 0.0f) {
+            const float control = fmaxf(speed, 100.0f);                 // phys.py:86
+            const double drop = (dt * (double)control) * 4.0;           // phys.py:87
+            const double ns = fmax(0.0, (double)speed - drop);          // phys.py:88
+            const double k = ns / (double)speed;                        // phys.py:90
+            hx = (double)e.vx * k; hy = (double)e.vy * k;
+        }
+    }
+    const double cur = (0.0 + hx * dx) + hy * dy;                       // phys.py:71
+    const double capped = (wish_speed > 30.0 && !og) ? 30.0 : wish_speed;   // phys.py:73-75
+    const double add = fmax(0.0, capped - cur);                         // phys.py:77
+    const double acc = fmin(accel_dt * wish_speed, add);                // phys.py:78 (unclipped wish_speed)
+    e.vx = (float)(hx + acc * dx);                                      // phys.py:80, RNE to float32 at phys.py:190
+    e.vy = (float)(hy + acc * dy);
+
+    // z (phys.py:112-132)
+    uint32_t fl = e.flags;
+    if (!c.jump) fl |= FLAG_JUMP_RELEASED;                              // phys.py:117
+    const bool do_jump = og && c.jump && (fl & FLAG_JUMP_RELEASED);     // phys.py:118
+    float vz = e.vz + (do_jump ? 270.0f : 0.0f);                        // float32 add (phys.py:119)
+    vz = (float)((double)vz - grav_dt);                                 // float64 subtract, RNE (phys.py:122)
+    double z = e.z + dt * (double)vz;                                   // phys.py:127
+    const bool landed = z < 24.03125;                                   // phys.py:128
+    if (landed) { z = 24.03125; vz = 0.0f; }                            // phys.py:129-130
+    e.z = z; e.vz = vz;
+    e.flags = (fl & ~FLAG_ON_GROUND) | (landed ? FLAG_ON_GROUND : 0u);
+}
+
+// yaw -> basis with pitch = roll = 0 (phys.py:56-66): radians = yaw*pi/180 (mul THEN div), float64 sincos
+__device__ __forceinline__ void physics_yaw_only(const Params& p, Env& e, const Cmd& c) {
+    const double rad = (e.yaw * 3.141592653589793) / 180.0;
+    double sn, cs;
+    sincos(rad, &sn, &cs);
+    physics(e, c, cs, sn, sn, -cs, p.dt, p.accel_dt, p.grav_dt);
+}
+
+// env.py:392-400 with _round_origin (385-390), _round_vel (381-383), get_obs_scale (294-296)
+__device__ __forceinline__ void observe(const Params& p, const Env& e, double o[6]) {
+    o[0] = e.trem / p.time_limit;
+    o[1] = e.yaw / 90.0;
+    o[2] = (rint(e.z * 8.0) / 8.0) / 100.0;
+    o[3] = (trunc((double)(e.vx / 16.0f)) * 16.0 + 0.0) / 200.0;
+    o[4] = (trunc((double)(e.vy / 16.0f)) * 16.0 + 0.0) / 200.0;
+    o[5] = (trunc((double)(e.vz / 16.0f)) * 16.0 + 0.0) / 200.0;
+}
+
+// VectorPhysEnv.vector_step for one env (env.py:482-510)
+__device__ __forceinline__ void tick(const Params& p, Env& e, uint32_t keybits, double yaw_act, TickOut& out) {
+    if (p.hover) { e.vz = 0.0f; e.z = 100.0; }                          // env.py:483-485
+    const Cmd c = decode(p, e, keybits, yaw_act, e.vz, e.trem);
+    physics_yaw_only(p, e, c);
+    if (p.speed_reward) out.reward = p.dt_f32 * sqrtf(e.vx * e.vx + e.vy * e.vy);   // env.py:501 (float32)
+    else out.reward = p.dt_f32 * e.vy;                                  // env.py:503 (float32)
+    e.px = e.px + p.dt * (double)e.vx;                                  // extension: distance integrals
+    e.py = e.py + p.dt * (double)e.vy;
+    e.trem = e.trem - p.dt;                                             // env.py:505
+    out.done = e.trem < 0.0;                                            // env.py:506
+    observe(p, e, out.obs);
+}
+
+// ---------------------------------------------------------------------------------------- resets
+// Initial player state on the 100 m map (env.py:54-58) + decoder reset (env.py:277-281 / 289-291)
+// from raw draws (env.py:432-451 / 461-476).
+__device__ __forceinline__ void reset_from_draws(const Params& p, Env& e, bool zero_start, double yaw_draw,
+                                                 double time_draw, double speed_draw, double angle_draw) {
+    double speed = zero_start ? 0.0 : speed_draw;
+    double angle = angle_draw;
+    if (p.hover) { speed = 320.0; angle = 1.5707963267948966; }         // env.py:443-448
+    double sn, cs;
+    sincos(angle, &sn, &cs);
+    e.vx = (float)(speed * cs);                                         // env.py:450
+    e.vy = (float)(speed * sn);                                         // env.py:451
+    e.vz = -12.0f;
+    e.z = (double)32.843201f;
+    e.px = 0.0; e.py = 0.0;
+    e.yaw = zero_start ? 90.0 : yaw_draw;                               // env.py:434-436
+    e.trem = zero_start ? p.time_limit : time_draw;                     // env.py:437-439
+#pragma unroll
+    for (int k = 0; k < 4; ++k) e.lk[k] = -p.key_press_delay;           // env.py:277-278
+    e.flags = FLAG_JUMP_RELEASED | (zero_start ? FLAG_ZERO_START : 0u); // on_ground False, last_keys False
+}
+
+// Device RNG reset: the reference's distributions, including uniform(x) == uniform(low=x, high=1.0)
+// (env.py:439,442,446): value = low + (high - low) * u.
+__device__ __forceinline__ void reset_philox(const Params& p, Env& e, uint64_t seed, uint64_t genv, uint64_t counter) {
+    uint32_t r0[4], r1[4], r2[4];
+    philox_draw(seed, genv, counter, STREAM_RESET, 0, r0);
+    philox_draw(seed, genv, counter, STREAM_RESET, 1, r1);
+    philox_draw(seed, genv, counter, STREAM_RESET, 2, r2);
+    const bool zs = u53(r0[0], r0[1]) < p.zero_start_prob;              // env.py:432
+    const double yaw = p.yaw_lo + (p.yaw_hi - p.yaw_lo) * u53(r0[2], r0[3]);               // env.py:436
+    const double tm = p.time_limit + (1.0 - p.time_limit) * u53(r1[0], r1[1]);             // env.py:439
+    const double sp = p.max_initial_speed + (1.0 - p.max_initial_speed) * u53(r1[2], r1[3]);   // env.py:442
+    const double an = 6.283185307179586 + (1.0 - 6.283185307179586) * u53(r2[0], r2[1]);   // env.py:446
+    reset_from_draws(p, e, zs, yaw, tm, sp, an);
+}
+
+template <typename T>
+__device__ __forceinline__ void write_obs(T* obs, size_t i, const double o[6]) {
+#pragma unroll
+    for (int j = 0; j < 6; ++j) obs[i * 6 + j] = (T)o[j];
+}
+
+}  // namespace q1

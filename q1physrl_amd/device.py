@@ -1,0 +1,172 @@
+"""DeviceEnv: thin object wrapper over one q1env_t handle (one shard of envs on one MI355X).
+
+Everything numerical happens in libq1env.so; this file only marshals NumPy arrays / raw device
+pointers across the C ABI (include/q1env.h).
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+
+
+def make_c_config(config, num_envs=None, env_index_base=0):
+    """reference Config (env.py:94-148) -> q1env_config POD."""
+    c = _lib.Q1Config()
+    c.num_envs = int(config.num_envs if num_envs is None else num_envs)
+    c.allow_yaw = int(bool(config.allow_yaw))
+    c.discrete_yaw_steps = int(config.discrete_yaw_steps)
+    c.speed_reward = int(bool(config.speed_reward))
+    c.hover = int(bool(config.hover))
+    c.smooth_keys = int(bool(config.smooth_keys))
+    c.auto_jump = int(bool(config.auto_jump))
+    c.allow_jump = int(bool(config.allow_jump))
+    c.zero_start_prob = float(config.zero_start_prob)
+    c.initial_yaw_lo = float(config.initial_yaw_range[0])
+    c.initial_yaw_hi = float(config.initial_yaw_range[1])
+    c.max_initial_speed = float(config.max_initial_speed)
+    c.time_delta = float(config.time_delta)
+    c.time_limit = float(config.time_limit)
+    c.action_range = float(config.action_range)
+    c.fmove_max = float(config.fmove_max)
+    c.smove_max = float(config.smove_max)
+    c.key_press_delay = float(config.key_press_delay)
+    c.env_index_base = int(env_index_base)
+    return c
+
+
+class DeviceEnv:
+    def __init__(self, config, num_envs=None, device=0, stream=None, env_index_base=0):
+        self._lib = _lib.load()
+        self._h = C.c_void_p()
+        cc = make_c_config(config, num_envs, env_index_base)
+        self.n = cc.num_envs
+        self.device = device
+        _lib.check(self._lib.q1env_create(C.byref(cc), int(device), C.c_void_p(stream or 0), C.byref(self._h)))
+        self.num_keys = _lib.check(self._lib.q1env_num_keys(self._h))
+        self.action_width = _lib.check(self._lib.q1env_action_width(self._h))
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self._lib.q1env_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:   # noqa: BLE001 - interpreter shutdown
+            pass
+
+    # ---- host (NumPy) paths -----------------------------------------------------------------
+    def step_host(self, actions_f64, obs_format=_lib.OBS_F64, want_zero_start=True):
+        n = self.n
+        a = np.ascontiguousarray(actions_f64, dtype=np.float64)
+        if a.shape != (n, self.action_width):
+            raise ValueError(f"actions must have shape ({n}, {self.action_width}), got {a.shape}")
+        obs = np.empty((n, 6), dtype=np.float64 if obs_format == _lib.OBS_F64 else np.float32)
+        reward = np.empty((n,), dtype=np.float32)
+        done = np.empty((n,), dtype=np.uint8)
+        zs = np.empty((n,), dtype=np.uint8) if want_zero_start else None
+        _lib.check(self._lib.q1env_step_host(self._h, _lib.ACT_F64_ROWS, _lib.ptr(a), None, obs_format,
+                                             _lib.ptr(obs), _lib.ptr(reward), _lib.ptr(done), _lib.ptr(zs)))
+        return obs, reward, done.view(np.bool_), (zs.view(np.bool_) if zs is not None else None)
+
+    def reset_draws(self, zero_start, yaw, time_remaining, speed, angle, idx=None, obs_format=_lib.OBS_F64):
+        zs = np.ascontiguousarray(zero_start, dtype=np.uint8)
+        cnt = zs.shape[0]
+        arrs = [np.ascontiguousarray(x, dtype=np.float64) for x in (yaw, time_remaining, speed, angle)]
+        assert all(x.shape == (cnt,) for x in arrs)
+        ix = None if idx is None else np.ascontiguousarray(idx, dtype=np.int32)
+        obs = np.empty((cnt, 6), dtype=np.float64 if obs_format == _lib.OBS_F64 else np.float32)
+        _lib.check(self._lib.q1env_reset_draws_host(self._h, cnt, _lib.ptr(ix), _lib.ptr(zs), *[_lib.ptr(x) for x in arrs],
+                                                    obs_format, _lib.ptr(obs)))
+        return obs
+
+    def observe_host(self, obs_format=_lib.OBS_F64):
+        obs = np.empty((self.n, 6), dtype=np.float64 if obs_format == _lib.OBS_F64 else np.float32)
+        _lib.check(self._lib.q1env_observe_host(self._h, obs_format, _lib.ptr(obs)))
+        return obs
+
+    def get_state(self, fields=None):
+        """dict of fresh host arrays; last_key_press_time comes back as (N, 4) like the reference's."""
+        out, st = {}, _lib.Q1State()
+        for name, dt, mult in _lib.STATE_FIELDS:
+            if fields is not None and name not in fields:
+                continue
+            out[name] = np.empty((mult * self.n,), dtype=dt)
+            setattr(st, name, out[name].ctypes.data)
+        _lib.check(self._lib.q1env_get_state_host(self._h, C.byref(st)))
+        if "last_key_press_time" in out:
+            out["last_key_press_time"] = np.ascontiguousarray(out["last_key_press_time"].reshape(4, self.n).T)
+        return out
+
+    def set_state(self, **arrays):
+        st, keep = _lib.Q1State(), []
+        for name, dt, mult in _lib.STATE_FIELDS:
+            if name not in arrays:
+                continue
+            a = np.asarray(arrays[name], dtype=dt)
+            if name == "last_key_press_time":
+                a = a.reshape(self.n, 4).T
+            a = np.ascontiguousarray(a).reshape(-1)
+            assert a.shape == (mult * self.n,), (name, a.shape)
+            keep.append(a)
+            setattr(st, name, a.ctypes.data)
+        _lib.check(self._lib.q1env_set_state_host(self._h, C.byref(st)))
+
+    def device_ptrs(self):
+        st = _lib.Q1State()
+        _lib.check(self._lib.q1env_state_device_ptrs(self._h, C.byref(st)))
+        return {name: getattr(st, name) for name, _, _ in _lib.STATE_FIELDS}
+
+    def decode_host(self, actions_f64, z_vel, time_remaining):
+        n = self.n
+        a = np.ascontiguousarray(actions_f64, dtype=np.float64)
+        if a.shape != (n, self.action_width):
+            raise ValueError(f"actions must have shape ({n}, {self.action_width}), got {a.shape}")
+        zv = np.ascontiguousarray(np.broadcast_to(np.asarray(z_vel, dtype=np.float32), (n,)))
+        tr = np.ascontiguousarray(np.broadcast_to(np.asarray(time_remaining, dtype=np.float64), (n,)))
+        yaw = np.empty((n,), np.float64)
+        smove = np.empty((n,), np.int64)
+        fmove = np.empty((n,), np.int64)
+        jump = np.empty((n,), np.uint8)
+        _lib.check(self._lib.q1env_decode_host(self._h, _lib.ACT_F64_ROWS, _lib.ptr(a), None, _lib.ptr(zv), _lib.ptr(tr),
+                                               _lib.ptr(yaw), _lib.ptr(smove), _lib.ptr(fmove), _lib.ptr(jump)))
+        return yaw, smove, fmove, jump.view(np.bool_)
+
+    def decoder_reset(self, yaw, idx=None):
+        y = np.ascontiguousarray(np.atleast_1d(np.asarray(yaw, dtype=np.float64)))
+        ix = None if idx is None else np.ascontiguousarray(np.atleast_1d(idx), dtype=np.int32)
+        _lib.check(self._lib.q1env_decoder_reset_host(self._h, y.shape[0], _lib.ptr(ix), _lib.ptr(y)))
+
+    # ---- device-pointer paths (zero copy; pointers are ints, e.g. tensor.data_ptr()) ----------
+    def step_dev(self, action_format, act_a, act_b=0, obs_format=_lib.OBS_F32, obs=0, reward=0, done=0, zero_start=0):
+        _lib.check(self._lib.q1env_step(self._h, action_format, act_a or None, act_b or None, obs_format,
+                                        obs or None, reward or None, done or None, zero_start or None))
+
+    def step_many_dev(self, ticks, action_format, act_a, act_b=0, obs_format=_lib.OBS_F32, obs=0, reward=0, done=0,
+                      out_stride_ticks=0, use_graph=True):
+        _lib.check(self._lib.q1env_step_many(self._h, ticks, action_format, act_a or None, act_b or None, obs_format,
+                                             obs or None, reward or None, done or None, int(out_stride_ticks), int(use_graph)))
+
+    def rollout_dev(self, ticks, action_format, act_a=0, act_b=0, rng_seed=0, obs_format=_lib.OBS_F32, obs=0, reward=0,
+                    done=0, auto_reset=False, return_sum=0):
+        _lib.check(self._lib.q1env_rollout(self._h, ticks, action_format, act_a or None, act_b or None, rng_seed, obs_format,
+                                           obs or None, reward or None, done or None, int(auto_reset), return_sum or None))
+
+    def reset_philox_dev(self, seed, mask=0, done_only=False, obs_format=_lib.OBS_F32, obs=0):
+        _lib.check(self._lib.q1env_reset_philox(self._h, seed, mask or None, int(done_only), obs_format, obs or None))
+
+    def observe_dev(self, obs, obs_format=_lib.OBS_F32):
+        _lib.check(self._lib.q1env_observe(self._h, obs_format, obs))
+
+    def sync(self):
+        _lib.check(self._lib.q1env_sync(self._h))
+
+    def timer_start(self):
+        _lib.check(self._lib.q1env_timer_start(self._h))
+
+    def timer_stop(self):
+        ms = C.c_float()
+        _lib.check(self._lib.q1env_timer_stop(self._h, C.byref(ms)))
+        return ms.value

@@ -1,0 +1,383 @@
+"""Host-side mirror of the reference env module (q1physrl_env/q1physrl_env/env.py) over libq1env.so.
+
+Same names, argument meaning, return types and error behaviour as the reference:
+
+    Config (+get_default, conforms_to_rules)        env.py:94-180
+    Key / Obs                                        env.py:61-86
+    ActionDecoder (action_space, map, vector_reset, reset_at)   env.py:183-291
+    get_obs_scale, INITIAL_YAW_ZERO                  env.py:294-296, 58
+    PhysEnv (gym.Env protocol: step / reset)         env.py:299-358
+    VectorPhysEnv (RLlib VectorEnv protocol)         env.py:369-513
+    registration of 'Q1PhysEnv-v0'                   env.py:516-521
+
+but every tick is ONE fused HIP kernel launch on an MI355X (include/q1env.h) instead of a few dozen
+NumPy temporaries.  The only arithmetic left on the host is what the reference contract pins to the
+host: drawing reset randomness from the GLOBAL NumPy MT19937 stream in the reference's order
+(env.py:432-446, 461-471), so that `np.random.seed(s)` reproduces the reference's episodes.
+
+There is no CPU fallback.  Without libq1env.so / without a GPU, constructing an env raises.
+"""
+import dataclasses
+import enum
+from typing import Optional, Tuple, Union
+
+import numpy as np
+
+from . import _lib, phys, spaces
+from .device import DeviceEnv
+
+__all__ = (
+    'ActionDecoder',
+    'Config',
+    'get_obs_scale',
+    'INITIAL_YAW_ZERO',
+    'Key',
+    'Obs',
+    'PhysEnv',
+    'VectorPhysEnv',
+)
+
+INITIAL_YAW_ZERO = np.float32(90)                       # env.py:58
+
+# only used for the default of Config.action_range (env.py:89-91, 139): float32(720) * float32(0.014)
+_DEFAULT_TIME_DELTA = np.float32(0.014)
+_MAX_YAW_SPEED = np.float32(2 * 360)
+
+
+class Key(enum.IntEnum):
+    """Action-vector index of each key (env.py:61-73).  The mouse dimension follows the keys."""
+    STRAFE_LEFT = 0
+    STRAFE_RIGHT = 1
+    FORWARD = 2
+    JUMP = 3            # absent from the action vector when auto_jump or not allow_jump
+
+
+class Obs(enum.IntEnum):
+    """Column order of an observation row (env.py:76-86)."""
+    TIME_LEFT = 0
+    YAW = 1
+    Z_POS = 2
+    X_VEL = 3
+    Y_VEL = 4
+    Z_VEL = 5
+
+
+@dataclasses.dataclass(frozen=True)
+class Config:
+    """Configuration of a PhysEnv / VectorPhysEnv; field-for-field the reference's (env.py:94-148).
+
+    num_envs must be None iff used with `PhysEnv`.  The field defaults are the reference's
+    "backwards compatibility" defaults; `get_default()` returns what `gym.make` uses.
+    Unknown keys raise TypeError (dataclass constructor), as in the reference.
+    """
+    num_envs: Optional[int]
+    zero_start_prob: float
+    initial_yaw_range: Tuple[float, float]
+    max_initial_speed: float
+    time_delta: float = 0.014
+    time_limit: float = 5
+    allow_yaw: bool = True
+    action_range: float = _MAX_YAW_SPEED * _DEFAULT_TIME_DELTA
+    discrete_yaw_steps: int = -1
+    speed_reward: bool = False
+    fmove_max: float = 800.
+    smove_max: float = 700.
+    hover: bool = False
+    key_press_delay: float = 0.3
+    smooth_keys: bool = False
+    auto_jump: bool = False
+    allow_jump: bool = True
+
+    @classmethod
+    def get_default(cls):
+        """Defaults used when the env is made through `gym.make` (env.py:150-170)."""
+        return cls(num_envs=None, zero_start_prob=0.01, initial_yaw_range=(0, 360), max_initial_speed=700,
+                   time_delta=1. / 72, time_limit=10., allow_yaw=True, discrete_yaw_steps=-1, speed_reward=False,
+                   fmove_max=800, smove_max=1060, hover=False, key_press_delay=0.3, smooth_keys=True,
+                   auto_jump=False, allow_jump=True)
+
+    def conforms_to_rules(self):
+        """Would these settings be legal under speed-running rules (env.py:172-180)."""
+        return self.time_delta == 1. / 72 and not self.hover
+
+
+def _num_keys(config) -> int:
+    return len(Key) if (config.allow_jump and not config.auto_jump) else len(Key) - 1     # env.py:206-207
+
+
+def get_obs_scale(config):
+    """Observations are divided by these before being returned (env.py:294-296)."""
+    return [config.time_limit, 90., 100, 200, 200, 200]
+
+
+def _action_rows(actions, width):
+    """The job of ActionDecoder._fix_actions (env.py:221-223) without its per-element Python loop.
+
+    Accepts (a) an (N, A) array, (b) RLlib's list of N tuples whose members are scalars or arrays of
+    length >= 1 (first element taken, like np.ravel(x)[0]).  Returns float64 (N, A), C-contiguous.
+    """
+    if isinstance(actions, np.ndarray) and actions.ndim == 2 and actions.dtype != object:
+        return np.ascontiguousarray(actions, dtype=np.float64)
+    try:                                                   # homogeneous nested sequence of scalars
+        a = np.asarray(actions, dtype=np.float64)
+        if a.ndim == 2:
+            return np.ascontiguousarray(a)
+        if a.ndim == 3:                                    # every component a length-m array
+            return np.ascontiguousarray(a[:, :, 0])
+    except (ValueError, TypeError):
+        pass
+    try:                                                   # column-wise: A conversions instead of N*A
+        cols = list(zip(*actions))
+        out = np.empty((len(actions), len(cols)), dtype=np.float64)
+        for j, col in enumerate(cols):
+            c = np.asarray(col, dtype=np.float64)
+            out[:, j] = c.reshape(c.shape[0], -1)[:, 0]
+        return out
+    except (ValueError, TypeError):                        # ragged inside a column: the reference's way
+        return np.array([[np.ravel(x)[0] for x in a] for a in actions], dtype=np.float64)
+
+
+class ActionDecoder:
+    """Stateful action -> move-command decoder (env.py:183-291), state and arithmetic on the GPU.
+
+    Tasks (unchanged): scale the mouse action to a yaw delta, rate-limit key presses
+    (`key_press_delay`), smooth key transitions (`smooth_keys`), auto-jump.  The decoder must be reset
+    with the env it accompanies.  Usable stand-alone (mkdemo.py:47-55, analyse.py:199-207) or as the
+    view `VectorPhysEnv._action_decoder` onto the env's own fused decoder state.
+    """
+
+    def __init__(self, config: Config, *, device: int = 0, _shared: Optional[DeviceEnv] = None):
+        self._config = config
+        self._num_keys = _num_keys(config)
+        self._device = device
+        self._dev: Optional[DeviceEnv] = _shared
+
+    @property
+    def action_space(self):
+        c = self._config
+        if not c.allow_yaw:
+            mouse = []
+        elif c.discrete_yaw_steps == -1:
+            mouse = [spaces.Box(low=-c.action_range, high=c.action_range, shape=(1,), dtype=np.float32)]
+        else:
+            mouse = [spaces.Discrete(2 * c.discrete_yaw_steps + 1)]
+        return spaces.Tuple([*(spaces.Discrete(2) for _ in range(self._num_keys)), *mouse])
+
+    def _fix_actions(self, actions):
+        return _action_rows(actions, self._num_keys + (1 if self._config.allow_yaw else 0))
+
+    def _require(self) -> DeviceEnv:
+        if self._dev is None:
+            raise AttributeError("ActionDecoder used before vector_reset()")      # reference: missing attribute
+        return self._dev
+
+    def map(self, actions, z_vel, time_remaining):
+        """Action vector -> (yaw, smove, fmove, jump) (env.py:225-269): float64, int64, int64, bool arrays."""
+        dev = self._require()
+        return dev.decode_host(self._fix_actions(actions), z_vel, time_remaining)
+
+    def vector_reset(self, yaw):
+        """Reset every decoder element before new episodes (env.py:271-281)."""
+        yaw = np.array(yaw, dtype=np.float64).reshape(-1)
+        if self._dev is None:
+            n = self._config.num_envs if self._config.num_envs is not None else yaw.shape[0]
+            self._dev = DeviceEnv(self._config, num_envs=n, device=self._device)
+        self._dev.decoder_reset(yaw)
+
+    def reset_at(self, index, yaw):
+        """Reset one decoder element (env.py:283-291)."""
+        self._require().decoder_reset(np.float64(yaw), idx=int(index))
+
+    # read-only views of the decoder state (reference attributes, env.py:200-202)
+    @property
+    def _last_key_press_time(self):
+        return self._require().get_state(("last_key_press_time",))["last_key_press_time"][:, :self._num_keys]
+
+    @property
+    def _last_keys(self):
+        f = self._require().get_state(("flags",))["flags"]
+        return ((f[:, None] >> (3 + np.arange(self._num_keys))[None, :]) & 1).astype(np.int64)
+
+    @property
+    def _yaw(self):
+        return self._require().get_state(("yaw",))["yaw"]
+
+
+class _LazyInfos:
+    """The per-env info dicts of vector_step (env.py:510) built on demand: the reference's list
+    comprehension is a third of its vectorised tick at 64 k envs."""
+    __slots__ = ("_zs",)
+
+    def __init__(self, zero_start):
+        self._zs = zero_start
+
+    def __len__(self):
+        return self._zs.shape[0]
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return [{'zero_start': z} for z in self._zs[i]]
+        return {'zero_start': self._zs[i]}
+
+    def __iter__(self):
+        return ({'zero_start': z} for z in self._zs)
+
+    def __eq__(self, other):
+        return list(self) == list(other)
+
+    def __repr__(self):
+        return repr(list(self))
+
+
+class PhysEnv:
+    """Single-env gym facade (env.py:299-358): 4 discrete keys + one continuous mouse dimension in,
+    6-d observation (time left, yaw, z, velocity) out, reward = distance travelled along +Y this frame.
+    No auto-reset: call reset() after done."""
+    metadata = {}
+
+    def __init__(self, config: Union[Config, dict], **device_kwargs):
+        if isinstance(config, dict):
+            config = Config(**config)
+        if config.num_envs is not None:
+            assert config.num_envs is None, "num_envs must be None for PhysEnv"
+        config = dataclasses.replace(config, num_envs=1)
+        self._env = VectorPhysEnv(config, **device_kwargs)
+        self.observation_space = self._env.observation_space
+        self.action_space = self._env.action_space
+        self.reward_range = self._env.reward_range
+
+    def step(self, action):
+        (obs,), (reward,), (done,), (info,) = self._env.vector_step([action])
+        return obs, reward, done, info
+
+    def reset(self):
+        (obs,) = self._env.vector_reset()
+        return obs
+
+    def close(self):
+        self._env.close()
+
+
+try:                                              # RLlib's base class when ray is installed (env.py:363-366)
+    from ray.rllib.env import VectorEnv            # pragma: no cover
+except ImportError:
+    VectorEnv = object
+
+
+class VectorPhysEnv(VectorEnv):
+    """Vectorised Quake-1 movement env (env.py:369-513) whose state lives in HBM as SoA arrays.
+
+    vector_reset() -> obs (N,6) float64; reset_at(i) -> obs (6,); vector_step(actions) ->
+    (obs (N,6) float64, reward (N,) float32, done (N,) bool, infos) with infos[i] == {'zero_start': bool}.
+    Extra keyword arguments (not in the reference): device, stream (raw hipStream_t), env_index_base.
+    """
+
+    def __init__(self, config, *, device: int = 0, stream: Optional[int] = None, env_index_base: int = 0):
+        if isinstance(config, dict):
+            config = Config(**config)
+        self._config = config
+        self.num_envs = self._config.num_envs
+        self.observation_space = spaces.Box(low=-np.inf, high=np.inf, shape=(6,), dtype=np.float32)
+        self.reward_range = (-1000 * self._config.time_delta, 1000 * self._config.time_delta)
+        self.metadata = {}
+        self._obs_scale = get_obs_scale(self._config)
+        self._dev = DeviceEnv(self._config, device=device, stream=stream, env_index_base=env_index_base)
+        self._action_decoder = ActionDecoder(self._config, device=device, _shared=self._dev)
+        self.action_space = self._action_decoder.action_space
+        self._step_num = 0
+        self._cache = {}
+        self.vector_reset()
+
+    # ---- resets: randomness from the global NumPy stream in the reference's order ---------------
+    def vector_reset(self):
+        c, n = self._config, self.num_envs
+        zero_start = np.random.random(size=(n,)) < c.zero_start_prob                       # env.py:432
+        yaw = np.random.uniform(*c.initial_yaw_range, size=(n,))                            # env.py:436
+        time_remaining = np.random.uniform(c.time_limit, size=(n,))                         # env.py:439 (low=limit, high=1)
+        speed = np.random.uniform(c.max_initial_speed, size=(n,))                           # env.py:442
+        angle = np.random.uniform(2 * np.pi, size=(n,))                                     # env.py:446
+        self._cache = {}
+        return self._dev.reset_draws(zero_start, yaw, time_remaining, speed, angle)
+
+    def reset_at(self, index):
+        c = self._config
+        zero_start = bool(np.random.random() < c.zero_start_prob)                           # env.py:461
+        # a zero start consumes no yaw / time / speed draw (env.py:462-467); the angle is always drawn (471)
+        yaw = 0.0 if zero_start else np.random.uniform(*c.initial_yaw_range)
+        time_remaining = 0.0 if zero_start else np.random.uniform(c.time_limit)
+        speed = 0.0 if zero_start else np.random.uniform(c.max_initial_speed)
+        angle = np.random.uniform(2 * np.pi)
+        self._cache = {}
+        obs = self._dev.reset_draws([zero_start], [yaw], [time_remaining], [speed], [angle], idx=[int(index)])
+        return obs[0]
+
+    # ---- the tick ----------------------------------------------------------------------------
+    def vector_step(self, actions):
+        rows = _action_rows(actions, self._dev.action_width)
+        obs, reward, done, zero_start = self._dev.step_host(rows)
+        self._step_num += 1
+        self._cache = {}
+        return obs, reward, done, _LazyInfos(zero_start)
+
+    def get_unwrapped(self):
+        return []
+
+    def close(self):
+        self._dev.close()
+
+    # ---- state the reference exposes as attributes (read by analyse.py:199-218) -----------------
+    def _state(self):
+        if "st" not in self._cache:
+            self._cache["st"] = self._dev.get_state()
+        return self._cache["st"]
+
+    @property
+    def player_state(self) -> phys.PlayerState:
+        """Immutable snapshot (fresh host arrays) of the reference's PlayerState (phys.py:156-161)."""
+        s = self._state()
+        return phys.PlayerState(z_pos=s["z_pos"].copy(),
+                                vel=np.stack([s["vel_x"], s["vel_y"], s["vel_z"]], axis=1),
+                                on_ground=(s["flags"] & _lib.FLAG_ON_GROUND) != 0,
+                                jump_released=(s["flags"] & _lib.FLAG_JUMP_RELEASED) != 0)
+
+    @property
+    def _yaw(self):
+        return self._state()["yaw"].copy()
+
+    @property
+    def _time_remaining(self):
+        return self._state()["time_remaining"].copy()
+
+    @property
+    def _zero_start(self):
+        return (self._state()["flags"] & _lib.FLAG_ZERO_START) != 0
+
+    @property
+    def distance(self):
+        """Extension: float64 integrals of dt*vel_x, dt*vel_y since the last reset, shape (N, 2)."""
+        s = self._state()
+        return np.stack([s["pos_x"], s["pos_y"]], axis=1)
+
+    def get_state(self):
+        """Checkpoint of the full env + decoder state (dict of host arrays); inverse: set_state()."""
+        return self._dev.get_state()
+
+    def set_state(self, **arrays):
+        self._cache = {}
+        self._dev.set_state(**arrays)
+
+
+def _register():
+    """env.py:516-521: importing the module registers 'Q1PhysEnv-v0' (when gym is installed) and always
+    fills q1physrl_amd.registry so `q1physrl_amd.make('Q1PhysEnv-v0')` works without gym."""
+    from . import registry
+    registry.register('Q1PhysEnv-v0', PhysEnv, {'config': Config.get_default()})
+    try:                                            # pragma: no cover - gym is not in this image
+        import gym.envs.registration as reg
+        reg.register(id='Q1PhysEnv-v0', entry_point=f'{__name__}:PhysEnv', nondeterministic=False,
+                     kwargs={'config': Config.get_default()})
+    except Exception:                               # noqa: BLE001 - no gym, or already registered
+        pass
+
+
+_register()

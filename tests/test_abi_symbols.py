@@ -1,0 +1,65 @@
+"""CPU: the C-ABI library builds for gfx950, loads without a GPU and exports every symbol that
+include/q1env.h declares; with no device the entry points fail loudly (no CPU fallback)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from q1physrl_amd import build, _lib
+    build.build_lib()
+    return _lib.load()
+
+
+def header_functions():
+    src = open(os.path.join(ROOT, "include", "q1env.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(q1(?:env|phys)_[a-z_0-9]+)\s*\(", src)))
+
+
+def test_header_and_binding_agree(lib):
+    from q1physrl_amd import _lib
+    names = header_functions()
+    assert len(names) >= 20
+    assert sorted(_lib.EXPORTED_SYMBOLS) == names
+    for n in names:
+        assert getattr(lib, n) is not None
+
+
+def test_abi_version(lib):
+    src = open(os.path.join(ROOT, "include", "q1env.h")).read()
+    assert int(re.search(r"#define Q1ENV_ABI_VERSION (\d+)", src).group(1)) == lib.q1env_abi_version()
+
+
+def test_struct_layout_matches_header():
+    from q1physrl_amd import _lib
+    assert ctypes.sizeof(_lib.Q1Config) == 8 * 4 + 10 * 8 + 8
+    assert ctypes.sizeof(_lib.Q1State) == 10 * ctypes.sizeof(ctypes.c_void_p)
+
+
+def test_code_object_is_gfx950_only():
+    from q1physrl_amd import build
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    if not os.path.exists(objdump):
+        pytest.skip("llvm-objdump not found")
+    import subprocess
+    out = subprocess.run([objdump, "--offloading", build.OUT], capture_output=True, text=True).stdout
+    archs = set(re.findall(r"gfx[0-9a-f]+", out))
+    assert archs == {"gfx950"}, archs
+
+
+def test_no_gpu_fails_loudly(lib):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from q1physrl_amd import env as E, phys as P, _lib
+    with pytest.raises(_lib.Q1EnvError, match="no HIP device|no ROCm"):
+        E.VectorPhysEnv(dict(E.Config.get_default().__dict__, num_envs=4))
+    with pytest.raises(_lib.Q1EnvError):
+        P.apply(P.Inputs(*[np.zeros(2)] * 7), P.PlayerState(np.zeros(2), np.zeros((2, 3), np.float32), np.zeros(2, bool), np.ones(2, bool)))

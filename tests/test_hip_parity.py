@@ -1,0 +1,212 @@
+"""GPU parity tests proper: the HIP path, called through the C ABI (ctypes -> libq1env.so), against
+  (1) golden vectors produced by the reference itself (tests/golden, made by oracle/gen_golden.py), and
+  (2) the oracle (oracle/np_oracle.py) on fresh seeded inputs.
+
+Bar: integer / boolean / index outputs (done, on_ground, zero_start, last_keys, smove, fmove, jump)
+BIT-EXACT; floating point within REL_TOL = 1e-5 relative to max(|ref|, 1) - the tolerance BASELINE.json's
+north_star states - over the whole 720-tick (10 s) rollout.  The float64 sincos of the device library may
+differ from NumPy's in the last ulp, which is why floats are not required to be bit-identical; the
+fraction of bit-identical elements is asserted separately (>= 99.9 %) so that a systematic deviation
+(wrong dtype, fused multiply-add, reordered arithmetic) cannot hide inside the tolerance.
+"""
+import numpy as np
+import pytest
+
+from oracle import np_oracle as O
+from tests import _replay as R
+
+pytestmark = pytest.mark.gpu
+
+REL_TOL = 1e-5
+INT_FIELDS = ("done", "zero_start", "on_ground", "jump_released", "last_keys")
+FLOAT_FIELDS = ("obs", "reward", "vel", "z_pos", "yaw", "time_remaining", "last_key_press_time")
+
+
+def hip_env(kw):
+    from q1physrl_amd import env as E
+    return E.VectorPhysEnv(kw)
+
+
+HIP_GETTERS = {
+    "vel": lambda e: e.player_state.vel, "z_pos": lambda e: e.player_state.z_pos,
+    "on_ground": lambda e: e.player_state.on_ground, "jump_released": lambda e: e.player_state.jump_released,
+    "yaw": lambda e: e._yaw, "time_remaining": lambda e: e._time_remaining,
+    "last_key_press_time": lambda e: e._action_decoder._last_key_press_time,
+    "last_keys": lambda e: e._action_decoder._last_keys.astype(np.uint8),
+}
+
+
+def rel_err(a, b):
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    return np.abs(a - b) / np.maximum(np.abs(b), 1.0)
+
+
+def bit_identical_fraction(a, b):
+    a = np.ascontiguousarray(a)
+    b = np.ascontiguousarray(b)
+    assert a.dtype == b.dtype and a.shape == b.shape, (a.dtype, b.dtype, a.shape, b.shape)
+    u = {4: np.uint32, 8: np.uint64}[a.dtype.itemsize]
+    return float(np.mean(a.view(u) == b.view(u)))
+
+
+def compare(res, ref, name, min_bit_frac=0.999):
+    for k in INT_FIELDS:
+        assert np.array_equal(np.asarray(res[k]).astype(np.int64), np.asarray(ref[k]).astype(np.int64)), f"{name}: {k} mismatch"
+    worst = {}
+    for k in FLOAT_FIELDS:
+        assert res[k].dtype == ref[k].dtype, (k, res[k].dtype, ref[k].dtype)
+        e = float(np.max(rel_err(res[k], ref[k]))) if res[k].size else 0.0
+        f = bit_identical_fraction(res[k], ref[k]) if res[k].size else 1.0
+        worst[k] = (e, f)
+        assert e <= REL_TOL, f"{name}: {k} max rel err {e:.3e} > {REL_TOL}"
+        assert f >= min_bit_frac, f"{name}: {k} only {f:.5f} of elements bit-identical"
+    return worst
+
+
+@pytest.mark.parametrize("name", R.TRACE_FIXTURES)
+def test_golden_trace(name):
+    """Every reference-generated trace: zero-start 720-tick rollouts (G2), full Config with RLlib-style
+    reset_at on done (G3), all Config variants (G4), the reference's own test scenario (S1), S2."""
+    fx = R.load(name)
+    res, env = R.replay(hip_env, fx, name, HIP_GETTERS)
+    assert res["obs0"].dtype == np.float64 and res["obs0"].shape == fx["obs0"].shape
+    assert np.max(rel_err(res["obs0"], fx["obs0"])) <= REL_TOL
+    worst = compare(res, fx, name)
+    assert res["reset_obs"].shape == fx["reset_obs"].shape
+    if fx["reset_obs"].size:
+        assert np.max(rel_err(res["reset_obs"], fx["reset_obs"])) <= REL_TOL
+    assert np.max(rel_err(env.player_state.vel, fx["final_vel"])) <= REL_TOL
+    print(name, {k: f"{e:.1e}/{f:.5f}" for k, (e, f) in worst.items()})
+    env.close()
+
+
+def test_position_parity_720_ticks():
+    """BASELINE metric: max |pos - ref| over the 10 s rollout.  pos_y of the reference = float64 running sum
+    of dt*vel_y over its per-tick float32 velocities (the reference never integrates x/y itself)."""
+    fx = R.load("g2_zero_start_720")
+    res, env = R.replay(hip_env, fx, "g2", {"dist": lambda e: e.distance, "z": lambda e: e.player_state.z_pos})
+    dt = 1.0 / 72
+    ref_xy = np.cumsum(dt * fx["vel"][:, :, :2].astype(np.float64), axis=0)
+    err_xy = np.abs(res["dist"] - ref_xy)
+    err_z = np.abs(res["z"] - fx["z_pos"])
+    scale = np.maximum(np.abs(ref_xy), 1.0)
+    print("max |pos_xy - ref| =", err_xy.max(), " max |z - ref| =", err_z.max(), " final |y| max =", np.abs(ref_xy[-1, :, 1]).max())
+    assert float(np.max(err_xy / scale)) < 1e-5 and float(err_z.max()) < 1e-5
+    env.close()
+
+
+def test_s1_known_answers_on_gpu():
+    fx = R.load("s1_reference_test_scenario")
+    res, env = R.replay(hip_env, fx, "s1", {"vel": HIP_GETTERS["vel"], "yaw": HIP_GETTERS["yaw"]})
+    n = int(np.argmax(res["done"][:, 0])) + 1
+    assert n == 358 and res["yaw"][n - 1, 0] == -426.0
+    assert abs(float(np.sum(res["reward"][:n, 0].astype(np.float64))) - 226.97054830007255) < 1e-5 * 226.97
+    env.close()
+
+
+def test_g1_physenv_gym_loop():
+    """BASELINE config 1 plumbing: PhysEnv(get_default) step/reset loop, RLlib-shaped single actions."""
+    from q1physrl_amd import env as E
+    import q1physrl_amd
+    fx = R.load("g1_physenv_default")
+    np.random.seed(int(fx["seed"]))
+    pe = q1physrl_amd.make('Q1PhysEnv-v0')
+    assert isinstance(pe, E.PhysEnv)
+    reset_obs = [pe.reset()]
+    for t in range(fx["actions"].shape[0]):
+        a = fx["actions"][t]
+        o, r, d, info = pe.step([int(a[0]), int(a[1]), int(a[2]), int(a[3]), np.array([a[4]], dtype=np.float32)])
+        assert o.shape == (6,) and o.dtype == np.float64 and isinstance(r, np.float32)
+        assert np.max(rel_err(o, fx["obs"][t])) <= REL_TOL and abs(float(r) - float(fx["reward"][t])) <= REL_TOL * max(1, abs(float(r)))
+        assert bool(d) == bool(fx["done"][t]) and bool(info["zero_start"]) == bool(fx["zero_start"][t])
+        if d:
+            reset_obs.append(pe.reset())
+    assert np.max(rel_err(np.stack(reset_obs), fx["reset_obs"])) <= REL_TOL
+    pe.close()
+
+
+def test_standalone_decoder_and_phys_apply_micro_vectors():
+    """G5: ActionDecoder.map on its own (mkdemo-style, incl. time exactly at the key_press_delay boundary)
+    and stateless phys.apply on random states."""
+    from q1physrl_amd import env as E, phys as P
+    fx = R.load("g5_micro")
+    cfg = E.Config(**{**E.Config.get_default().__dict__, "num_envs": 6})
+    dec = E.ActionDecoder(cfg)
+    dec.vector_reset(fx["dec_yaw0"])
+    for t in range(fx["dec_actions"].shape[0]):
+        y, sm, fm, j = dec.map(fx["dec_actions"][t], np.zeros(6, np.float32), np.full(6, fx["dec_time_remaining"][t]))
+        assert np.array_equal(sm, fx["dec_out_smove"][t]) and np.array_equal(fm, fx["dec_out_fmove"][t])
+        assert np.array_equal(j, fx["dec_out_jump"][t]) and sm.dtype == np.int64 and j.dtype == np.bool_
+        assert np.array_equal(y, fx["dec_out_yaw"][t])                     # pure float64 mul/div/add: exact
+        assert np.array_equal(dec._last_key_press_time, fx["dec_out_lkpt"][t])
+        assert np.array_equal(dec._last_keys.astype(np.uint8), fx["dec_out_lk"][t])
+    ins = P.Inputs(**{k: fx["ap_in_" + k] for k in ("yaw", "pitch", "roll", "fmove", "smove", "button2", "time_delta")})
+    ps = P.PlayerState(**{k: fx["ap_ps_" + k] for k in ("z_pos", "vel", "on_ground", "jump_released")})
+    out = P.apply(ins, ps)
+    assert out.vel.dtype == np.float32 and np.max(rel_err(out.vel, fx["ap_out_vel"])) <= REL_TOL
+    assert bit_identical_fraction(out.vel, fx["ap_out_vel"]) >= 0.99
+    assert np.array_equal(out.z_pos, fx["ap_out_z_pos"])                   # no transcendental on the z path: exact
+    assert np.array_equal(out.on_ground, fx["ap_out_on_ground"]) and np.array_equal(out.jump_released, fx["ap_out_jump_released"])
+    # z physics edge cases (exactly on the floor, landing, jump while released/not released)
+    n = fx["z_in_pos"].shape[0]
+    ins = P.Inputs(yaw=np.zeros(n), pitch=np.zeros(n), roll=np.zeros(n), fmove=np.zeros(n), smove=np.zeros(n),
+                   button2=fx["z_in_jump"], time_delta=fx["z_dt"])
+    vel = np.zeros((n, 3), np.float32)
+    vel[:, 2] = fx["z_in_vel"]
+    out = P.apply(ins, P.PlayerState(fx["z_in_pos"], vel, fx["z_in_on_ground"], fx["z_in_jump_released"]))
+    assert np.array_equal(out.z_pos, fx["z_out_pos"]) and np.array_equal(out.vel[:, 2], fx["z_out_vel"])
+    assert np.array_equal(out.on_ground, fx["z_out_on_ground"]) and np.array_equal(out.jump_released, fx["z_out_jump_released"])
+
+
+@pytest.mark.parametrize("n,ticks,seed", [(1, 50, 1), (63, 100, 2), (257, 200, 3), (4096, 720, 4)])
+def test_against_oracle_random(n, ticks, seed):
+    """Fresh seeded inputs (not in the fixtures), ragged sizes (1, 63, 257: partial waves / partial blocks),
+    full Config with random starts; the oracle runs beside the GPU on identical NumPy RNG state."""
+    from q1physrl_amd import env as E
+    kw = dict(O.OracleConfig.get_default(num_envs=n, zero_start_prob=0.25, time_limit=3.0).__dict__)
+    rng = np.random.default_rng(seed)
+    np.random.seed(seed)
+    ora = O.OracleVectorEnv(dict(kw))
+    np.random.seed(seed)
+    hip = E.VectorPhysEnv(dict(kw))
+    keys = rng.random((n, 4)) < 0.5
+    worst = 0.0
+    for t in range(ticks):
+        keys ^= rng.random((n, 4)) < 0.1
+        yaw = rng.uniform(-10.08, 10.08, n).astype(np.float32)
+        a = np.concatenate([keys.astype(np.float64), yaw[:, None].astype(np.float64)], axis=1)
+        o1, r1, d1, z1 = ora.vector_step(a)
+        o2, r2, d2, i2 = hip.vector_step(a)
+        assert np.array_equal(d1, d2) and np.array_equal(z1, np.array([i["zero_start"] for i in i2]) if n <= 64 else i2._zs)
+        worst = max(worst, float(np.max(rel_err(o2, o1))), float(np.max(rel_err(r2, r1))))
+        assert worst <= REL_TOL, (t, worst)
+        for i in np.nonzero(d1)[0]:
+            st = np.random.get_state()
+            a1 = ora.reset_at(int(i))
+            np.random.set_state(st)
+            a2 = hip.reset_at(int(i))
+            assert np.max(rel_err(a2, a1)) <= REL_TOL
+    ps = hip.player_state
+    assert np.array_equal(ps.on_ground, ora.st["on_ground"])
+    assert bit_identical_fraction(ps.vel, ora.st["vel"]) >= 0.999
+    hip.close()
+
+
+def test_state_roundtrip_and_error_behaviour():
+    from q1physrl_amd import env as E, _lib
+    cfg = dict(E.Config.get_default().__dict__, num_envs=8)
+    e = E.VectorPhysEnv(cfg)
+    st = e.get_state()
+    st["vel_x"][:] = np.arange(8, dtype=np.float32)
+    e.set_state(**st)
+    assert np.array_equal(e.get_state()["vel_x"], np.arange(8, dtype=np.float32))
+    with pytest.raises(ValueError):
+        e.vector_step(np.zeros((7, 5)))                 # wrong batch
+    with pytest.raises(TypeError):
+        E.VectorPhysEnv(dict(cfg, bogus=1))             # unknown Config key -> TypeError like the reference
+    with pytest.raises(AssertionError, match="num_envs must be None"):
+        E.PhysEnv(E.Config(**cfg))
+    with pytest.raises(_lib.Q1EnvError):
+        E.VectorPhysEnv(dict(cfg, num_envs=0))
+    e.close()
