@@ -179,7 +179,16 @@ int q1phys_apply_host(int device, int64_t n, const double* yaw, const double* pi
                       const double* z_pos, const float* vel, const uint8_t* on_ground, const uint8_t* jump_released,
                       double* out_z_pos, float* out_vel, uint8_t* out_on_ground, uint8_t* out_jump_released);
 
-/* ---- measurement: HIP events recorded on the handle's stream --------------------------------- */
+/* ---- measurement ------------------------------------------------------------------------------
+ * calibrate_traffic: `launches` launches of a pure copy kernel that reads the SoA state with step's own
+ * load pattern and writes it to scratch: exactly 85 B read + 85 B written per env, for calibrating the
+ * rocprofv3 FETCH_SIZE / WRITE_SIZE counters on a known byte count (MI355X_MICROARCH.md, HBM section).
+ * selftest_division: runs the kernels' exact-division shortcuts (Markstein constant division, shared-reciprocal
+ * division, float32 obs columns) against the hardware IEEE division on n random operands plus the constants
+ * 180, 90, 100, 200, c0, c1; writes 4 mismatch counts (all must be 0).
+ * timer_*: HIP events recorded on the handle's stream. */
+int q1env_selftest_division(int device, uint64_t n, uint64_t seed, double c0, double c1, uint64_t* mismatches4);
+int q1env_calibrate_traffic(q1env_t* env, int launches);
 int q1env_timer_start(q1env_t* env);
 int q1env_timer_stop(q1env_t* env, float* elapsed_ms);   /* synchronises on the stop event */
 

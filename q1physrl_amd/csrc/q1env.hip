@@ -28,8 +28,8 @@ step_kernel(Params p, StatePtrs s, int fmt, const void* act_a, const void* act_b
     load_env(s, p.n, i, e);
     double yaw_act;
     const uint32_t keys = fetch_action(p, fmt, act_a, act_b, (size_t)i, &yaw_act);
-    TickOut o;
-    tick(p, e, keys, yaw_act, o);
+    TickOut<OBS_T> o;
+    tick<OBS_T>(p, e, keys, yaw_act, o);
     store_env(s, p.n, i, e);
     if (obs) write_obs<OBS_T>(obs, (size_t)i, o.obs);
     if (reward) reward[i] = o.reward;
@@ -56,8 +56,8 @@ rollout_kernel(Params p, StatePtrs s, int ticks, int fmt, const void* act_a, con
         uint32_t keys;
         if (fmt == 3) keys = random_action(p, seed, genv, tick0 + (uint64_t)t, &yaw_act);
         else keys = fetch_action(p, fmt, act_a, act_b, (size_t)t * n + (size_t)i, &yaw_act);
-        TickOut o;
-        tick(p, e, keys, yaw_act, o);
+        TickOut<OBS_T> o;
+        tick<OBS_T>(p, e, keys, yaw_act, o);
         const size_t oi = (size_t)t * n + (size_t)i;
         if (obs) write_obs<OBS_T>(obs, oi, o.obs);
         if (reward) reward[oi] = o.reward;
@@ -75,8 +75,8 @@ __global__ void __launch_bounds__(256) observe_kernel(Params p, StatePtrs s, OBS
     if (i >= p.n) return;
     Env e;
     load_env(s, p.n, i, e);
-    double o[6];
-    observe(p, e, o);
+    OBS_T o[6];
+    observe<OBS_T>(p, e, o);
     write_obs<OBS_T>(obs, (size_t)i, o);
 }
 
@@ -92,8 +92,8 @@ reset_draws_kernel(Params p, StatePtrs s, int count, const int32_t* idx, const u
     reset_from_draws(p, e, zero_start[j] != 0, yaw[j], tm[j], speed[j], angle[j]);
     store_env(s, p.n, i, e);
     if (obs) {
-        double o[6];
-        observe(p, e, o);
+        OBS_T o[6];
+        observe<OBS_T>(p, e, o);
         write_obs<OBS_T>(obs, (size_t)j, o);
     }
 }
@@ -112,8 +112,8 @@ reset_philox_kernel(Params p, StatePtrs s, uint64_t seed, uint64_t counter, cons
         store_env(s, p.n, i, e);
     }
     if (obs) {
-        double o[6];
-        observe(p, e, o);
+        OBS_T o[6];
+        observe<OBS_T>(p, e, o);
         write_obs<OBS_T>(obs, (size_t)i, o);
     }
 }
@@ -148,6 +148,64 @@ decoder_reset_kernel(Params p, StatePtrs s, int count, const int32_t* idx, const
     for (int k = 0; k < 4; ++k) s.lk[(size_t)k * p.n + i] = -p.key_press_delay;   // env.py:277-278 / 289
     s.flags[i] = s.flags[i] & 0x7u;                                               // env.py:279 / 290
     s.yaw[i] = yaw[j];                                                            // env.py:281 / 291
+}
+
+// Traffic calibration for the PMC counters (MI355X_MICROARCH.md "HBM": FETCH_SIZE / WRITE_SIZE must be calibrated on
+// a known byte count in the kernel's own access pattern): reads every SoA state array with exactly the loads
+// step_kernel uses and writes the same bytes to a scratch arena: 85 B read + 85 B written per env, no arithmetic.
+__global__ void __launch_bounds__(256) calib_copy_kernel(Params p, StatePtrs src, StatePtrs dst) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= p.n) return;
+    Env e;
+    load_env(src, p.n, i, e);
+    store_env(dst, p.n, i, e);
+}
+
+// Self-test of the exact-division helpers against the hardware IEEE division on random operands drawn over the
+// ranges the hot path produces (and well beyond).  counts[0..3] = mismatches of: div_const<double>, div_shared,
+// the float32 vel-obs column, the float32 z-obs column.
+__global__ void __launch_bounds__(256)
+selftest_division_kernel(uint64_t n, uint64_t seed, double c_extra0, double c_extra1, unsigned long long* counts) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t r[4], r2[4];
+    philox_draw(seed, i, 0, 7, 0, r);
+    philox_draw(seed, i, 1, 7, 0, r2);
+    const double u = u53(r[0], r[1]), w = u53(r[2], r[3]);
+    // magnitude sweep 1e-12 .. 1e7, both signs
+    const double mag = exp(-27.6 + 43.7 * w);
+    const double x = (2.0 * u - 1.0) * mag;
+    const double cs[6] = {180.0, 90.0, 100.0, 200.0, c_extra0, c_extra1};
+    unsigned bad0 = 0, bad1 = 0, bad2 = 0, bad3 = 0;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        const double c = cs[k];
+        const double a = div_const<double>(x, c, 1.0 / c), b = x / c;
+        bad0 += (__double_as_longlong(a) != __double_as_longlong(b));
+    }
+    const double den = 0.5 + 4000.0 * u53(r2[0], r2[1]);
+    const double num = (2.0 * u53(r2[2], r2[3]) - 1.0) * den;
+    {
+        const double y = rcp_refined(den);
+        const double a = div_shared(num, den, y), b = num / den;
+        bad1 += (__double_as_longlong(a) != __double_as_longlong(b));
+        const double a2 = div_shared(x, den, y), b2 = x / den;
+        bad1 += (__double_as_longlong(a2) != __double_as_longlong(b2));
+    }
+    {   // vel column: v float32 -> trunc(v/16)*16 / 200, float64 reference vs float32 shortcut
+        const float v = (float)((2.0 * u - 1.0) * 40000.0);
+        const double ref = (trunc((double)(v / 16.0f)) * 16.0 + 0.0) / 200.0;
+        const float fast = div_const<float>(truncf(v * 0.0625f) * 16.0f + 0.0f, 200.0f, 1.0f / 200.0f);
+        bad2 += (__float_as_uint((float)ref) != __float_as_uint(fast));
+        const double z = 24.03125 + 3000.0 * w;
+        const double refz = (rint(z * 8.0) / 8.0) / 100.0;
+        const float fastz = div_const<float>((float)(rint(z * 8.0) * 0.125), 100.0f, 1.0f / 100.0f);
+        bad3 += (__float_as_uint((float)refz) != __float_as_uint(fastz));
+    }
+    if (bad0) atomicAdd(&counts[0], (unsigned long long)bad0);
+    if (bad1) atomicAdd(&counts[1], (unsigned long long)bad1);
+    if (bad2) atomicAdd(&counts[2], (unsigned long long)bad2);
+    if (bad3) atomicAdd(&counts[3], (unsigned long long)bad3);
 }
 
 // Stateless phys.apply (phys.py:184-197) with general pitch / roll (phys.py:56-66), all float64 trig.
@@ -253,6 +311,10 @@ static int make_params(const q1env_config& c, Params& p, std::string& why) {
     p.yaw_num = (double)(720.0f * (float)c.time_delta);                 // env.py:230: float32 product (NEP 50)
     p.yaw_steps = (double)c.discrete_yaw_steps;
     p.yaw_den = (p.yaw_mode == 2) ? p.yaw_steps : c.action_range;       // env.py:236 / 238
+    if (p.yaw_mode && !(p.yaw_den > 0)) { why = "action_range must be > 0"; return -1; }
+    if (!(c.time_limit > 0)) { why = "time_limit must be > 0"; return -1; }
+    p.yaw_den_rcp = p.yaw_mode ? 1.0 / p.yaw_den : 0.0;                 // correctly rounded reciprocals for div_const
+    p.time_limit_rcp = 1.0 / c.time_limit;
     p.fmove_max = (double)(float)c.fmove_max;                           // env.py:261
     p.smove_max = (double)(float)c.smove_max;                           // env.py:260
     p.accel_dt = 10.0 * c.time_delta;                                   // phys.py:78
@@ -268,17 +330,18 @@ static int make_params(const q1env_config& c, Params& p, std::string& why) {
     return 0;
 }
 
-static void carve(q1env* h) {
-    const size_t n = (size_t)h->p.n;
-    char* base = (char*)h->arena;
+static void carve_into(void* arena, size_t n, StatePtrs& st) {
+    char* base = (char*)arena;
     size_t off = 0;
     auto take = [&](size_t bytes) { void* q = base + off; off += align_up(bytes, 256); return q; };
-    h->st.vx = (float*)take(n * 4); h->st.vy = (float*)take(n * 4); h->st.vz = (float*)take(n * 4);
-    h->st.px = (double*)take(n * 8); h->st.py = (double*)take(n * 8); h->st.z = (double*)take(n * 8);
-    h->st.yaw = (double*)take(n * 8); h->st.trem = (double*)take(n * 8);
-    h->st.lk = (double*)take(n * 8 * 4);
-    h->st.flags = (uint8_t*)take(n);
+    st.vx = (float*)take(n * 4); st.vy = (float*)take(n * 4); st.vz = (float*)take(n * 4);
+    st.px = (double*)take(n * 8); st.py = (double*)take(n * 8); st.z = (double*)take(n * 8);
+    st.yaw = (double*)take(n * 8); st.trem = (double*)take(n * 8);
+    st.lk = (double*)take(n * 8 * 4);
+    st.flags = (uint8_t*)take(n);
 }
+
+static void carve(q1env* h) { carve_into(h->arena, (size_t)h->p.n, h->st); }
 
 static size_t arena_bytes(size_t n) {
     return 3 * align_up(n * 4, 256) + 5 * align_up(n * 8, 256) + align_up(n * 32, 256) + align_up(n, 256);
@@ -688,6 +751,38 @@ int q1phys_apply_host(int device, int64_t n64, const double* yaw, const double* 
     }
     (void)hipFree(d);
     return rc;
+}
+
+int q1env_selftest_division(int device, uint64_t n, uint64_t seed, double c0, double c1, uint64_t* mismatches4) {
+    if (!mismatches4 || n == 0 || !(c0 > 0) || !(c1 > 0)) return fail(Q1ENV_ERR_INVALID_ARG, "q1env_selftest_division: bad argument");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(Q1ENV_ERR_NO_DEVICE, "q1env_selftest_division: no HIP device visible");
+    HIP_TRY(hipSetDevice(device));
+    unsigned long long* d = nullptr;
+    HIP_TRY(hipMalloc((void**)&d, 4 * sizeof(unsigned long long)));
+    HIP_TRY(hipMemset(d, 0, 4 * sizeof(unsigned long long)));
+    hipLaunchKernelGGL(selftest_division_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, n, seed, c0, c1, d);
+    unsigned long long hcounts[4] = {0, 0, 0, 0};
+    hipError_t e = hipMemcpy(hcounts, d, sizeof(hcounts), hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    if (e != hipSuccess) return fail(Q1ENV_ERR_HIP, std::string("selftest: ") + hipGetErrorString(e));
+    for (int k = 0; k < 4; ++k) mismatches4[k] = hcounts[k];
+    return Q1ENV_OK;
+}
+
+int q1env_calibrate_traffic(q1env_t* h, int launches) {
+    if (!h || launches <= 0) return fail(Q1ENV_ERR_INVALID_ARG, "q1env_calibrate_traffic: bad argument");
+    HIP_TRY(hipSetDevice(h->device));
+    if (int r = ensure_stage(h, arena_bytes((size_t)h->p.n))) return r;
+    StatePtrs dst{};
+    carve_into(h->stage, (size_t)h->p.n, dst);
+    const int blk = block_for(h->p.n);
+    for (int l = 0; l < launches; ++l)
+        hipLaunchKernelGGL(calib_copy_kernel, grid_for(h->p.n, blk), dim3(blk), 0, h->stream, h->p, h->st, dst);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return Q1ENV_OK;
 }
 
 int q1env_timer_start(q1env_t* h) {

@@ -41,6 +41,8 @@ struct Params {
     double yaw_num;         // double(float32(720) * float32(dt))        env.py:230 under NEP 50
     double yaw_den;         // double(action_range) or discrete_yaw_steps env.py:236/238
     double yaw_steps;
+    double yaw_den_rcp;     // RN(1 / yaw_den), for the exact constant division below
+    double time_limit_rcp;  // RN(1 / time_limit)
     double fmove_max;       // double(float32(fmove_max))                 env.py:261
     double smove_max;       // double(float32(smove_max))                 env.py:260
     double accel_dt;        // double(float32(10)) * dt                   phys.py:78
@@ -76,11 +78,53 @@ struct Cmd {               // ActionDecoder.map's outputs for one env (env.py:26
     bool jump;
 };
 
+template <typename OBS_T>
 struct TickOut {
-    double obs[6];
+    OBS_T obs[6];
     float reward;
     bool done;
 };
+
+
+// ---------------------------------------------------------------------------------------- exact division
+// x / c for a run-time CONSTANT c > 0 whose correctly rounded reciprocal y = RN(1/c) was computed once on the
+// host.  q0 = RN(x*y) is within 1.5 ulp of x/c; one FMA correction step (r = x - q*c exactly, q' = RN(q + r*y))
+// makes it faithful, and by Markstein's theorem a second identical step yields RN(x/c) - bit-identical to the
+// IEEE division the reference performs, for 2^-960 < |x| < 2^960 (every quantity on this path), at 5 FMA-rate
+// instructions instead of the ~11-instruction v_div_scale/v_rcp/v_div_fmas/v_div_fixup sequence.
+// Zero keeps its sign (c > 0); NaN propagates.  Checked on-device against `/` by q1env_selftest_division.
+template <typename T> __device__ __forceinline__ T fma_t(T a, T b, T c);
+template <> __device__ __forceinline__ double fma_t<double>(double a, double b, double c) { return fma(a, b, c); }
+template <> __device__ __forceinline__ float fma_t<float>(float a, float b, float c) { return fmaf(a, b, c); }
+
+template <typename T>
+__device__ __forceinline__ T div_const(T x, T c, T y) {
+    T q = x * y;
+    T r = fma_t<T>(-q, c, x);
+    q = fma_t<T>(r, y, q);
+    r = fma_t<T>(-q, c, x);
+    q = fma_t<T>(r, y, q);
+    return x == T(0) ? x : q;
+}
+
+// a / b for two numerators sharing one denominator: the refined reciprocal (v_rcp_f64 + two Newton steps, the
+// same recurrence the compiler's own f64 division expands to) is computed once; each quotient is then
+// q = a*y, r = a - b*q, q + r*y.  With operands in the normal range (|wish_vel| <= ~2000, speeds <= ~1e4)
+// v_div_scale / v_div_fixup are identities, so the result equals the compiler's `/` bit for bit.
+__device__ __forceinline__ double rcp_refined(double b) {
+    double y = __builtin_amdgcn_rcp(b);
+    double e = fma(-b, y, 1.0);
+    y = fma(y, e, y);
+    e = fma(-b, y, 1.0);
+    y = fma(y, e, y);
+    return y;
+}
+__device__ __forceinline__ double div_shared(double a, double b, double y) {
+    const double q = a * y;
+    const double r = fma(-b, q, a);
+    const double res = fma(r, y, q);
+    return a == 0.0 ? a : res;
+}
 
 __device__ __forceinline__ void load_env(const StatePtrs& s, int n, int i, Env& e) {
     e.vx = s.vx[i]; e.vy = s.vy[i]; e.vz = s.vz[i];
@@ -196,8 +240,8 @@ __device__ __forceinline__ Cmd decode(const Params& p, Env& e, uint32_t keybits,
     e.flags = (e.flags & 0x7u) | (keys << FLAG_KEYS_SHIFT);             // env.py:256
 
     double dyaw = 0.0;
-    if (p.yaw_mode == 1) dyaw = (yaw_act * p.yaw_num) / p.yaw_den;      // env.py:236
-    else if (p.yaw_mode == 2) dyaw = ((yaw_act - p.yaw_steps) * p.yaw_num) / p.yaw_den;   // env.py:238
+    if (p.yaw_mode == 1) dyaw = div_const<double>(yaw_act * p.yaw_num, p.yaw_den, p.yaw_den_rcp);   // env.py:236
+    else if (p.yaw_mode == 2) dyaw = div_const<double>((yaw_act - p.yaw_steps) * p.yaw_num, p.yaw_den, p.yaw_den_rcp);   // env.py:238
     e.yaw = e.yaw + dyaw;                                               // env.py:258
 
     Cmd c;
@@ -222,7 +266,10 @@ __device__ __forceinline__ void physics(Env& e, const Cmd& c, double m00, double
     const double wy = (0.0 + m10 * c.fmove) + m11 * c.smove;
     const double wlen = sqrt(wx * wx + wy * wy);                        // phys.py:98
     double dx = wx, dy = wy;
-    if (wlen > 0.0) { dx = wx / wlen; dy = wy / wlen; }                 // phys.py:99-101
+    if (wlen > 0.0) {                                                   // phys.py:99-101
+        const double yw = rcp_refined(wlen);
+        dx = div_shared(wx, wlen, yw); dy = div_shared(wy, wlen, yw);
+    }
     const double wish_speed = fmin(320.0, wlen);                        // phys.py:103
 
     double hx = (double)e.vx, hy = (double)e.vy;
@@ -258,24 +305,37 @@ __device__ __forceinline__ void physics(Env& e, const Cmd& c, double m00, double
 
 // yaw -> basis with pitch = roll = 0 (phys.py:56-66): radians = yaw*pi/180 (mul THEN div), float64 sincos
 __device__ __forceinline__ void physics_yaw_only(const Params& p, Env& e, const Cmd& c) {
-    const double rad = (e.yaw * 3.141592653589793) / 180.0;
+    const double rad = div_const<double>(e.yaw * 3.141592653589793, 180.0, 1.0 / 180.0);
     double sn, cs;
     sincos(rad, &sn, &cs);
     physics(e, c, cs, sn, sn, -cs, p.dt, p.accel_dt, p.grav_dt);
 }
 
-// env.py:392-400 with _round_origin (385-390), _round_vel (381-383), get_obs_scale (294-296)
-__device__ __forceinline__ void observe(const Params& p, const Env& e, double o[6]) {
-    o[0] = e.trem / p.time_limit;
-    o[1] = e.yaw / 90.0;
-    o[2] = (rint(e.z * 8.0) / 8.0) / 100.0;
-    o[3] = (trunc((double)(e.vx / 16.0f)) * 16.0 + 0.0) / 200.0;
-    o[4] = (trunc((double)(e.vy / 16.0f)) * 16.0 + 0.0) / 200.0;
-    o[5] = (trunc((double)(e.vz / 16.0f)) * 16.0 + 0.0) / 200.0;
+// env.py:392-400 with _round_origin (385-390), _round_vel (381-383), get_obs_scale (294-296).
+// OBS_T = double reproduces the reference's float64 row.  OBS_T = float is DEFINED as that row rounded to float32;
+// for the z and vel columns the rounded-then-scaled numerators (j/8 and 16*m, |j|, |m| < 2^24) are exact in float32
+// and j/800, 2m/25 can never sit within 2^-53 of a float32 rounding boundary (distance >= 2^-29.6 relative), so the
+// float32 division gives RN32(RN64(.)) exactly and those four columns skip float64 entirely.
+template <typename OBS_T>
+__device__ __forceinline__ void observe(const Params& p, const Env& e, OBS_T o[6]) {
+    o[0] = (OBS_T)div_const<double>(e.trem, p.time_limit, p.time_limit_rcp);
+    o[1] = (OBS_T)div_const<double>(e.yaw, 90.0, 1.0 / 90.0);
+    if constexpr (sizeof(OBS_T) == 8) {
+        o[2] = div_const<double>(rint(e.z * 8.0) * 0.125, 100.0, 1.0 / 100.0);
+        o[3] = div_const<double>(trunc((double)(e.vx * 0.0625f)) * 16.0 + 0.0, 200.0, 1.0 / 200.0);
+        o[4] = div_const<double>(trunc((double)(e.vy * 0.0625f)) * 16.0 + 0.0, 200.0, 1.0 / 200.0);
+        o[5] = div_const<double>(trunc((double)(e.vz * 0.0625f)) * 16.0 + 0.0, 200.0, 1.0 / 200.0);
+    } else {
+        o[2] = div_const<float>((float)(rint(e.z * 8.0) * 0.125), 100.0f, 1.0f / 100.0f);
+        o[3] = div_const<float>(truncf(e.vx * 0.0625f) * 16.0f + 0.0f, 200.0f, 1.0f / 200.0f);
+        o[4] = div_const<float>(truncf(e.vy * 0.0625f) * 16.0f + 0.0f, 200.0f, 1.0f / 200.0f);
+        o[5] = div_const<float>(truncf(e.vz * 0.0625f) * 16.0f + 0.0f, 200.0f, 1.0f / 200.0f);
+    }
 }
 
 // VectorPhysEnv.vector_step for one env (env.py:482-510)
-__device__ __forceinline__ void tick(const Params& p, Env& e, uint32_t keybits, double yaw_act, TickOut& out) {
+template <typename OBS_T>
+__device__ __forceinline__ void tick(const Params& p, Env& e, uint32_t keybits, double yaw_act, TickOut<OBS_T>& out) {
     if (p.hover) { e.vz = 0.0f; e.z = 100.0; }                          // env.py:483-485
     const Cmd c = decode(p, e, keybits, yaw_act, e.vz, e.trem);
     physics_yaw_only(p, e, c);
@@ -285,7 +345,7 @@ __device__ __forceinline__ void tick(const Params& p, Env& e, uint32_t keybits, 
     e.py = e.py + p.dt * (double)e.vy;
     e.trem = e.trem - p.dt;                                             // env.py:505
     out.done = e.trem < 0.0;                                            // env.py:506
-    observe(p, e, out.obs);
+    observe<OBS_T>(p, e, out.obs);
 }
 
 // ---------------------------------------------------------------------------------------- resets
@@ -326,9 +386,9 @@ __device__ __forceinline__ void reset_philox(const Params& p, Env& e, uint64_t s
 }
 
 template <typename T>
-__device__ __forceinline__ void write_obs(T* obs, size_t i, const double o[6]) {
+__device__ __forceinline__ void write_obs(T* obs, size_t i, const T o[6]) {
 #pragma unroll
-    for (int j = 0; j < 6; ++j) obs[i * 6 + j] = (T)o[j];
+    for (int j = 0; j < 6; ++j) obs[i * 6 + j] = o[j];
 }
 
 }  // namespace q1

@@ -163,6 +163,9 @@ class DeviceEnv:
     def sync(self):
         _lib.check(self._lib.q1env_sync(self._h))
 
+    def calibrate_traffic(self, launches=10):
+        _lib.check(self._lib.q1env_calibrate_traffic(self._h, int(launches)))
+
     def timer_start(self):
         _lib.check(self._lib.q1env_timer_start(self._h))
 

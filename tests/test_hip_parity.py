@@ -210,3 +210,16 @@ def test_state_roundtrip_and_error_behaviour():
     with pytest.raises(_lib.Q1EnvError):
         E.VectorPhysEnv(dict(cfg, num_envs=0))
     e.close()
+
+
+def test_exact_division_shortcuts_selftest():
+    """The kernels replace IEEE divisions by exact FMA sequences (q1env_device.hpp div_const / div_shared and the
+    float32 obs columns).  On-device comparison with the hardware division on 2^24 random operands per seed and the
+    constants 180, 90, 100, 200, time_limit, action_range: zero mismatches allowed."""
+    import ctypes as C
+    from q1physrl_amd import _lib
+    lib = _lib.load()
+    for seed, c0, c1 in ((1, 10.0, 10.079999923706055), (2, 5.0, 10.0), (3, 0.5, 7.0), (4, 3.0, 5.0)):
+        out = (C.c_uint64 * 4)()
+        _lib.check(lib.q1env_selftest_division(0, 1 << 24, seed, c0, c1, out))
+        assert list(out) == [0, 0, 0, 0], (seed, list(out))
