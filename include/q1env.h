@@ -110,6 +110,9 @@ int         q1env_device_count(void);
  * zero-start reset (env.py:54-58) of every env. */
 int q1env_create(const q1env_config* cfg, int device, void* stream, q1env_t** out);
 int q1env_destroy(q1env_t* env);
+/* Rebind the handle to another stream (drains the old one first).  Here NULL means the device's default
+ * (null) stream - what torch.cuda.current_stream().cuda_stream is (0) unless a side stream is current. */
+int q1env_set_stream(q1env_t* env, void* stream);
 int q1env_sync(q1env_t* env);
 int q1env_num_keys(const q1env_t* env);
 int q1env_action_width(const q1env_t* env);

@@ -49,6 +49,7 @@ _SIGNATURES = {
     "q1env_device_count": (C.c_int, []),
     "q1env_create": (C.c_int, [C.POINTER(Q1Config), C.c_int, _P, C.POINTER(_P)]),
     "q1env_destroy": (C.c_int, [_P]),
+    "q1env_set_stream": (C.c_int, [_P, _P]),
     "q1env_sync": (C.c_int, [_P]),
     "q1env_num_keys": (C.c_int, [_P]),
     "q1env_action_width": (C.c_int, [_P]),

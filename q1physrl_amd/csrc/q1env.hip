@@ -269,6 +269,7 @@ struct q1env {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     // cached graph for step_many
     hipGraphExec_t gexec = nullptr;
+    hipStream_t cap_stream = nullptr;  // private stream used only to CAPTURE (the null stream cannot be captured)
     std::vector<uint64_t> gkey;
 };
 
@@ -408,12 +409,23 @@ int q1env_destroy(q1env_t* h) {
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
     if (h->gexec) (void)hipGraphExecDestroy(h->gexec);
+    if (h->cap_stream) (void)hipStreamDestroy(h->cap_stream);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->stage) (void)hipFree(h->stage);
     if (h->arena) (void)hipFree(h->arena);
     if (h->own_stream) (void)hipStreamDestroy(h->stream);
     delete h;
+    return Q1ENV_OK;
+}
+
+int q1env_set_stream(q1env_t* h, void* stream) {
+    if (!h) return fail(Q1ENV_ERR_INVALID_ARG, "q1env_set_stream: null handle");
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    if (h->gexec) { (void)hipGraphExecDestroy(h->gexec); h->gexec = nullptr; h->gkey.clear(); }
+    if (h->own_stream) { (void)hipStreamDestroy(h->stream); h->own_stream = false; }
+    h->stream = (hipStream_t)stream;          // NULL = the device's default (null) stream
     return Q1ENV_OK;
 }
 
@@ -519,9 +531,16 @@ int q1env_step_many(q1env_t* h, int ticks, int fmt, const void* a, const void* b
         if (!h->gexec || key != h->gkey) {
             if (h->gexec) { (void)hipGraphExecDestroy(h->gexec); h->gexec = nullptr; }
             hipGraph_t g = nullptr;
-            HIP_TRY(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
-            enqueue_many(h, ticks, fmt, a, b, obs_format, obs, reward, done, out_stride);
-            HIP_TRY(hipStreamEndCapture(h->stream, &g));
+            if (!h->cap_stream) HIP_TRY(hipStreamCreateWithFlags(&h->cap_stream, hipStreamNonBlocking));
+            hipStream_t launch_stream = h->stream;
+            h->stream = h->cap_stream;                      // record the launches on the capture stream ...
+            hipError_t ce = hipStreamBeginCapture(h->cap_stream, hipStreamCaptureModeThreadLocal);
+            if (ce == hipSuccess) {
+                enqueue_many(h, ticks, fmt, a, b, obs_format, obs, reward, done, out_stride);
+                ce = hipStreamEndCapture(h->cap_stream, &g);
+            }
+            h->stream = launch_stream;                      // ... and replay them on the handle's own stream
+            if (ce != hipSuccess) return fail(Q1ENV_ERR_HIP, std::string("graph capture: ") + hipGetErrorString(ce));
             hipError_t e = hipGraphInstantiate(&h->gexec, g, nullptr, nullptr, 0);
             (void)hipGraphDestroy(g);
             if (e != hipSuccess) { h->gexec = nullptr; return fail(Q1ENV_ERR_HIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(e)); }

@@ -160,6 +160,10 @@ class DeviceEnv:
     def observe_dev(self, obs, obs_format=_lib.OBS_F32):
         _lib.check(self._lib.q1env_observe(self._h, obs_format, obs))
 
+    def set_stream(self, stream):
+        """Rebind to a raw hipStream_t (int); 0 / None = the default (null) stream."""
+        _lib.check(self._lib.q1env_set_stream(self._h, C.c_void_p(stream or 0)))
+
     def sync(self):
         _lib.check(self._lib.q1env_sync(self._h))
 

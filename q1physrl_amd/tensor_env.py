@@ -1,0 +1,145 @@
+"""GPU-resident fast path: torch-ROCm tensors in and out of the env with zero copies.
+
+torch is plumbing here (device memory + the current stream); all arithmetic is the same HIP kernels the
+NumPy-compatible path uses (include/q1env.h: q1env_step / q1env_step_many / q1env_rollout / q1env_reset_philox).
+
+    env = TensorVectorEnv(config, device=0, seed=1)
+    obs = env.reset()                                   # (N, 6) float32 on the GPU
+    obs, reward, done = env.step_tensor(actions)        # actions: (N, A) float32 policy output, or (keys u8, mouse f32)
+    env.reset_done()                                    # masked device-RNG reset of finished episodes
+
+Outputs are views of env-owned buffers, valid until the next call (SURVEY.md section 8b ownership rule).
+"""
+from typing import Optional, Tuple, Union
+
+import numpy as np
+import torch
+
+from . import _lib
+from .device import DeviceEnv
+
+
+class _DevArray:
+    """__cuda_array_interface__ shim so torch.as_tensor can alias a raw device pointer of the SoA state."""
+
+    def __init__(self, ptr, shape, typestr):
+        self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": typestr, "data": (int(ptr), False), "version": 2}
+
+
+class TensorVectorEnv:
+    def __init__(self, config, device: int = 0, env_index_base: int = 0, seed: int = 0):
+        if isinstance(config, dict):
+            from .env import Config
+            config = Config(**config)
+        self.config = config
+        self.num_envs = int(config.num_envs)
+        self.device = torch.device("cuda", device)
+        self.seed = int(seed)
+        with torch.cuda.device(self.device):
+            self._dev = DeviceEnv(config, device=device, env_index_base=env_index_base)
+            self._dev.set_stream(torch.cuda.current_stream(self.device).cuda_stream)
+        n = self.num_envs
+        self.obs = torch.empty((n, 6), dtype=torch.float32, device=self.device)
+        self.reward = torch.empty((n,), dtype=torch.float32, device=self.device)
+        self.done = torch.empty((n,), dtype=torch.uint8, device=self.device)
+        self.zero_start = torch.empty((n,), dtype=torch.uint8, device=self.device)
+        self.num_keys = self._dev.num_keys
+        self.action_width = self._dev.action_width
+
+    # ---- stream plumbing -------------------------------------------------------------------
+    def use_current_stream(self):
+        """Re-bind to torch's current stream (call after entering a `torch.cuda.stream(...)` context)."""
+        self._dev.set_stream(torch.cuda.current_stream(self.device).cuda_stream)
+
+    # ---- API ---------------------------------------------------------------------------------
+    def reset(self, mask: Optional[torch.Tensor] = None) -> torch.Tensor:
+        m = 0
+        if mask is not None:
+            assert mask.dtype == torch.uint8 and mask.is_contiguous() and mask.numel() == self.num_envs
+            m = mask.data_ptr()
+        self._dev.reset_philox_dev(self.seed, mask=m, done_only=False, obs_format=_lib.OBS_F32, obs=self.obs.data_ptr())
+        return self.obs
+
+    def reset_done(self) -> torch.Tensor:
+        """Reset exactly the envs whose episode has ended (time_remaining < 0, env.py:506); returns fresh obs of all envs."""
+        self._dev.reset_philox_dev(self.seed, mask=0, done_only=True, obs_format=_lib.OBS_F32, obs=self.obs.data_ptr())
+        return self.obs
+
+    def _act_ptrs(self, actions, lead: Tuple[int, ...]):
+        if isinstance(actions, (tuple, list)):
+            keys, mouse = actions
+            assert keys.dtype == torch.uint8 and keys.is_contiguous() and tuple(keys.shape) == lead
+            if self.config.allow_yaw:
+                assert mouse.dtype == torch.float32 and mouse.is_contiguous() and tuple(mouse.shape) == lead
+            return _lib.ACT_PACKED, keys.data_ptr(), (mouse.data_ptr() if mouse is not None else 0)
+        a = actions
+        assert a.is_contiguous() and tuple(a.shape) == lead + (self.action_width,), (a.shape, lead, self.action_width)
+        if a.dtype == torch.float32:
+            return _lib.ACT_F32_ROWS, a.data_ptr(), 0
+        if a.dtype == torch.float64:
+            return _lib.ACT_F64_ROWS, a.data_ptr(), 0
+        raise TypeError(f"actions must be float32/float64 rows or (uint8 keys, float32 mouse); got {a.dtype}")
+
+    def step_tensor(self, actions) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+        fmt, a, b = self._act_ptrs(actions, (self.num_envs,))
+        self._dev.step_dev(fmt, a, b, _lib.OBS_F32, self.obs.data_ptr(), self.reward.data_ptr(), self.done.data_ptr(),
+                           self.zero_start.data_ptr())
+        return self.obs, self.reward, self.done
+
+    def step_many(self, actions, ticks: int, outputs: bool = False, use_graph: bool = True):
+        """`ticks` single-tick launches over tick-major actions; outputs=True returns tick-major (T,N,..) tensors."""
+        fmt, a, b = self._act_ptrs(actions, (ticks, self.num_envs))
+        if outputs:
+            n = self.num_envs
+            obs = torch.empty((ticks, n, 6), dtype=torch.float32, device=self.device)
+            rew = torch.empty((ticks, n), dtype=torch.float32, device=self.device)
+            done = torch.empty((ticks, n), dtype=torch.uint8, device=self.device)
+            self._dev.step_many_dev(ticks, fmt, a, b, _lib.OBS_F32, obs.data_ptr(), rew.data_ptr(), done.data_ptr(), 1, use_graph)
+            return obs, rew, done
+        self._dev.step_many_dev(ticks, fmt, a, b, _lib.OBS_F32, self.obs.data_ptr(), self.reward.data_ptr(), self.done.data_ptr(), 0, use_graph)
+        return self.obs, self.reward, self.done
+
+    def rollout(self, ticks: int, actions=None, outputs: bool = True, auto_reset: bool = False, obs_dtype=torch.float32,
+                return_sum: Optional[torch.Tensor] = None):
+        """Fused multi-tick kernel.  actions=None -> on-device iid random actions (Q1ENV_ACT_RANDOM, seed = self.seed)."""
+        n = self.num_envs
+        if actions is None:
+            fmt, a, b = _lib.ACT_RANDOM, 0, 0
+        else:
+            fmt, a, b = self._act_ptrs(actions, (ticks, n))
+        obs = rew = done = None
+        if outputs:
+            obs = torch.empty((ticks, n, 6), dtype=obs_dtype, device=self.device)
+            rew = torch.empty((ticks, n), dtype=torch.float32, device=self.device)
+            done = torch.empty((ticks, n), dtype=torch.uint8, device=self.device)
+        self._dev.rollout_dev(ticks, fmt, a, b, self.seed, _lib.OBS_F32 if obs_dtype == torch.float32 else _lib.OBS_F64,
+                              obs.data_ptr() if outputs else 0, rew.data_ptr() if outputs else 0,
+                              done.data_ptr() if outputs else 0, auto_reset,
+                              return_sum.data_ptr() if return_sum is not None else 0)
+        return obs, rew, done
+
+    def observe(self) -> torch.Tensor:
+        self._dev.observe_dev(self.obs.data_ptr(), _lib.OBS_F32)
+        return self.obs
+
+    def state_tensors(self):
+        """Zero-copy torch views of the live SoA state arrays (dict name -> tensor)."""
+        p = self._dev.device_ptrs()
+        n = self.num_envs
+        spec = {"vel_x": ("<f4", (n,)), "vel_y": ("<f4", (n,)), "vel_z": ("<f4", (n,)), "pos_x": ("<f8", (n,)), "pos_y": ("<f8", (n,)),
+                "z_pos": ("<f8", (n,)), "yaw": ("<f8", (n,)), "time_remaining": ("<f8", (n,)),
+                "last_key_press_time": ("<f8", (4, n)), "flags": ("|u1", (n,))}
+        return {k: torch.as_tensor(_DevArray(p[k], shape, ts), device=self.device) for k, (ts, shape) in spec.items()}
+
+    def get_state(self):
+        torch.cuda.current_stream(self.device).synchronize()
+        return self._dev.get_state()
+
+    def set_state(self, **arrays):
+        self._dev.set_state(**arrays)
+
+    def sync(self):
+        self._dev.sync()
+
+    def close(self):
+        self._dev.close()

@@ -1,0 +1,233 @@
+"""GPU parity of the device-pointer entry points (q1env_step with every action layout, q1env_step_many with and
+without hipGraph, the fused q1env_rollout kernel, the Philox device RNG for actions and resets, in-kernel
+auto-reset, shard-count invariance) against the oracle.  Same bar as test_hip_parity.py: integers bit-exact,
+floats <= 1e-5 relative and >= 99.9 % bit-identical (observed: bit-identical)."""
+import dataclasses
+
+import numpy as np
+import pytest
+
+from oracle import np_oracle as O
+from oracle import philox as PH
+
+pytestmark = pytest.mark.gpu
+REL_TOL = 1e-5
+
+
+def torch_mod():
+    import torch
+    return torch
+
+
+def inject(ora, tenv):
+    """Copy the oracle's state into the device env (golden-state injection through q1env_set_state_host)."""
+    k = ora.cfg.num_keys
+    n = ora.n
+    lk = np.full((n, 4), -np.float64(ora.cfg.key_press_delay))
+    lk[:, :k] = ora.dec["last_press"]
+    keys = np.zeros(n, dtype=np.uint8)
+    for j in range(k):
+        keys |= ora.dec["last_keys"][:, j].astype(np.uint8) << (3 + j)
+    flags = (ora.st["on_ground"].astype(np.uint8) | (ora.st["jump_released"].astype(np.uint8) << 1)
+             | (ora.zero_start.astype(np.uint8) << 2) | keys)
+    tenv.set_state(vel_x=ora.st["vel"][:, 0], vel_y=ora.st["vel"][:, 1], vel_z=ora.st["vel"][:, 2],
+                   pos_x=np.zeros(n), pos_y=np.zeros(n), z_pos=ora.st["z_pos"], yaw=ora.yaw, time_remaining=ora.t_rem,
+                   last_key_press_time=lk, flags=flags)
+
+
+def close(a, b, what=""):
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    e = np.abs(a - b) / np.maximum(np.abs(b), 1.0)
+    assert float(e.max()) <= REL_TOL, (what, float(e.max()))
+
+
+def same_bits_frac(a, b):
+    a, b = np.ascontiguousarray(a), np.ascontiguousarray(b)
+    assert a.dtype == b.dtype and a.shape == b.shape
+    u = {4: np.uint32, 8: np.uint64}[a.dtype.itemsize]
+    return float(np.mean(a.view(u) == b.view(u)))
+
+
+def make_pair(n, seed, **over):
+    from q1physrl_amd.tensor_env import TensorVectorEnv
+    from q1physrl_amd.env import Config
+    cfg = O.OracleConfig.get_default(num_envs=n, **over)
+    np.random.seed(seed)
+    ora = O.OracleVectorEnv(cfg)
+    tenv = TensorVectorEnv(Config(**cfg.__dict__), device=0, seed=seed)
+    inject(ora, tenv)
+    return cfg, ora, tenv
+
+
+def gen_actions(rng, ticks, n, cfg):
+    keys = rng.integers(0, 1 << cfg.num_keys, size=(ticks, n), dtype=np.uint8)
+    mouse = rng.uniform(-float(cfg.action_range), float(cfg.action_range), size=(ticks, n)).astype(np.float32)
+    rows = np.concatenate([((keys[:, :, None] >> np.arange(cfg.num_keys)[None, None, :]) & 1).astype(np.float64),
+                           mouse[:, :, None].astype(np.float64)], axis=2)
+    return keys, mouse, rows
+
+
+@pytest.mark.parametrize("fmt", ["packed", "f32rows", "f64rows"])
+def test_step_tensor_action_layouts(fmt):
+    torch = torch_mod()
+    n, ticks = 1000, 120
+    cfg, ora, tenv = make_pair(n, 11, zero_start_prob=0.3)
+    rng = np.random.default_rng(5)
+    keys, mouse, rows = gen_actions(rng, ticks, n, cfg)
+    for t in range(ticks):
+        o1, r1, d1, z1 = ora.vector_step(rows[t])
+        if fmt == "packed":
+            act = (torch.from_numpy(keys[t]).cuda(), torch.from_numpy(mouse[t]).cuda())
+        elif fmt == "f32rows":
+            act = torch.from_numpy(rows[t].astype(np.float32)).cuda()
+        else:
+            act = torch.from_numpy(rows[t]).cuda()
+        obs, rew, done = tenv.step_tensor(act)
+        assert obs.dtype == torch.float32 and obs.shape == (n, 6)
+        assert np.array_equal(obs.cpu().numpy(), o1.astype(np.float32)), t       # f32 obs IS the f64 obs rounded
+        assert np.array_equal(rew.cpu().numpy(), r1) and np.array_equal(done.cpu().numpy().astype(bool), d1)
+        assert np.array_equal(tenv.zero_start.cpu().numpy().astype(bool), z1)
+    st = tenv.get_state()
+    assert np.array_equal(st["vel_x"], ora.st["vel"][:, 0]) and np.array_equal(st["z_pos"], ora.st["z_pos"])
+    tenv.close()
+
+
+@pytest.mark.parametrize("mode", ["many_graph", "many_eager", "rollout_f32", "rollout_f64"])
+def test_multi_tick_entry_points(mode):
+    torch = torch_mod()
+    n, ticks = 777, 150            # ragged: 777 = 12 waves + 9 lanes
+    cfg, ora, tenv = make_pair(n, 21, zero_start_prob=0.2, time_limit=4.0)
+    rng = np.random.default_rng(8)
+    keys, mouse, rows = gen_actions(rng, ticks, n, cfg)
+    ref_obs, ref_rew, ref_done = [], [], []
+    for t in range(ticks):
+        o1, r1, d1, _ = ora.vector_step(rows[t])
+        ref_obs.append(o1); ref_rew.append(r1); ref_done.append(d1)
+    ref_obs, ref_rew, ref_done = np.stack(ref_obs), np.stack(ref_rew), np.stack(ref_done)
+    act = (torch.from_numpy(keys).cuda(), torch.from_numpy(mouse).cuda())
+    if mode.startswith("many"):
+        obs, rew, done = tenv.step_many(act, ticks, outputs=True, use_graph=(mode == "many_graph"))
+    else:
+        obs, rew, done = tenv.rollout(ticks, act, outputs=True, obs_dtype=torch.float32 if mode == "rollout_f32" else torch.float64)
+    torch.cuda.synchronize()
+    want_obs = ref_obs.astype(np.float32) if obs.dtype == torch.float32 else ref_obs
+    assert np.array_equal(obs.cpu().numpy(), want_obs)
+    assert np.array_equal(rew.cpu().numpy(), ref_rew) and np.array_equal(done.cpu().numpy().astype(bool), ref_done)
+    st = tenv.get_state()
+    assert np.array_equal(st["yaw"], ora.yaw) and np.array_equal(st["time_remaining"], ora.t_rem)
+    assert np.array_equal(st["last_key_press_time"][:, :4], ora.dec["last_press"])
+    tenv.close()
+
+
+def test_random_action_rollout_matches_philox_restatement():
+    torch = torch_mod()
+    n, ticks, seed = 512, 100, 1234
+    cfg, ora, tenv = make_pair(n, seed, zero_start_prob=1.0)
+    obs, rew, done = tenv.rollout(ticks, None, outputs=True, obs_dtype=torch.float64)
+    genv = np.arange(n, dtype=np.uint64)
+    for t in range(ticks):
+        a = PH.random_actions(cfg, seed, genv, t)          # handle's tick counter starts at 0
+        o1, r1, d1, _ = ora.vector_step(a)
+        assert np.array_equal(obs[t].cpu().numpy(), o1), t
+        assert np.array_equal(rew[t].cpu().numpy(), r1)
+    tenv.close()
+
+
+def test_reset_philox_matches_restatement_and_distribution():
+    from scipy import stats
+    from q1physrl_amd.tensor_env import TensorVectorEnv
+    from q1physrl_amd.env import Config
+    n, seed = 200_000, 77
+    cfg = O.OracleConfig.get_default(num_envs=n, zero_start_prob=0.25)
+    tenv = TensorVectorEnv(Config(**cfg.__dict__), device=0, seed=seed, env_index_base=5_000_000_000)   # > 2^32: 64-bit env index
+    tenv.reset()
+    st = tenv.get_state()
+    zs, yaw, tm, sp, an = PH.reset_draws(cfg, seed, np.arange(n, dtype=np.uint64) + np.uint64(5_000_000_000), 0)
+    flags = st["flags"]
+    assert np.array_equal((flags & 4) != 0, zs) and np.all((flags & 2) != 0) and not np.any(flags & 1)
+    assert np.array_equal(st["yaw"], np.where(zs, 90.0, yaw)) and np.array_equal(st["time_remaining"], np.where(zs, cfg.time_limit, tm))
+    speed = np.where(zs, 0.0, sp)
+    close(st["vel_x"], (speed * np.cos(an)).astype(np.float32), "vel_x")
+    assert same_bits_frac(st["vel_x"], (speed * np.cos(an)).astype(np.float32)) > 0.999
+    assert same_bits_frac(st["vel_y"], (speed * np.sin(an)).astype(np.float32)) > 0.999
+    assert np.all(st["vel_z"] == np.float32(-12)) and np.all(st["z_pos"] == np.float64(np.float32(32.843201)))
+    assert np.all(st["last_key_press_time"] == -cfg.key_press_delay)
+    # the reference's distributions: zero-start fraction, yaw ~ U(0,360), and the one-argument uniform quirk:
+    # time in (1, 10], speed in (1, 700], angle in (1, 2 pi]
+    nz = ~zs
+    assert abs(zs.mean() - 0.25) < 4 * np.sqrt(0.25 * 0.75 / n)
+    assert stats.kstest(st["yaw"][nz] / 360.0, "uniform").pvalue > 1e-4
+    assert stats.kstest((st["time_remaining"][nz] - 1.0) / 9.0, "uniform").pvalue > 1e-4
+    spd = np.hypot(st["vel_x"][nz].astype(np.float64), st["vel_y"][nz].astype(np.float64))
+    assert stats.kstest((spd - 1.0) / 699.0, "uniform").pvalue > 1e-4 and spd.min() > 0.999 and spd.max() <= 700.001
+    ang = np.mod(np.arctan2(st["vel_y"][nz].astype(np.float64), st["vel_x"][nz].astype(np.float64)), 2 * np.pi)
+    assert ang.min() > 0.999 and stats.kstest((ang - 1.0) / (2 * np.pi - 1.0), "uniform").pvalue > 1e-4
+    tenv.close()
+
+
+def test_auto_reset_rollout_equals_step_then_reset_done():
+    torch = torch_mod()
+    from q1physrl_amd.tensor_env import TensorVectorEnv
+    from q1physrl_amd.env import Config
+    n, ticks, seed = 300, 400, 5
+    cfg = Config(**O.OracleConfig.get_default(num_envs=n, zero_start_prob=0.3, time_limit=1.5).__dict__)
+    rng = np.random.default_rng(3)
+    keys = torch.from_numpy(rng.integers(0, 16, size=(ticks, n), dtype=np.uint8)).cuda()
+    mouse = torch.from_numpy(rng.uniform(-10, 10, size=(ticks, n)).astype(np.float32)).cuda()
+    a = TensorVectorEnv(cfg, seed=seed)
+    b = TensorVectorEnv(cfg, seed=seed)
+    a.reset(); b.reset()
+    ret = torch.zeros((n,), dtype=torch.float64, device="cuda")
+    obs_a, rew_a, done_a = a.rollout(ticks, (keys, mouse), outputs=True, auto_reset=True, return_sum=ret)
+    tot = np.zeros(n)
+    n_resets = 0
+    for t in range(ticks):
+        obs, rew, done = b.step_tensor((keys[t], mouse[t]))
+        assert torch.equal(obs, obs_a[t]) and torch.equal(rew, rew_a[t]) and torch.equal(done, done_a[t]), t
+        tot += rew.cpu().numpy().astype(np.float64)
+        n_resets += int(done.sum())
+        b.reset_done()
+    assert n_resets > n            # every env finished at least one episode
+    sa, sb = a.get_state(), b.get_state()
+    for k in sa:
+        assert np.array_equal(sa[k], sb[k]), k
+    assert np.allclose(ret.cpu().numpy(), tot, rtol=1e-12, atol=1e-9)
+    a.close(); b.close()
+
+
+def test_shard_count_invariance():
+    """Splitting the batch over 1, 2 or 3 handles (env_index_base = shard start) gives identical envs: the counter
+    RNG is keyed by the global env index, and no kernel has a cross-env term."""
+    torch = torch_mod()
+    from q1physrl_amd.tensor_env import TensorVectorEnv
+    from q1physrl_amd.env import Config
+    from q1physrl_amd.sharding import shard_plan
+    n, ticks, seed = 1000, 200, 9
+    base = O.OracleConfig.get_default(num_envs=n, zero_start_prob=0.2, time_limit=1.0)
+    full = TensorVectorEnv(Config(**base.__dict__), seed=seed)
+    full.reset()
+    full.rollout(ticks, None, outputs=False, auto_reset=True)
+    ref = full.get_state()
+    for world in (2, 3):
+        parts = []
+        for start, count in shard_plan(n, world):
+            e = TensorVectorEnv(Config(**dataclasses.replace(base, num_envs=count).__dict__), seed=seed, env_index_base=start)
+            e.reset()
+            e.rollout(ticks, None, outputs=False, auto_reset=True)
+            parts.append(e.get_state())
+            e.close()
+        for k in ref:
+            assert np.array_equal(np.concatenate([p[k] for p in parts], axis=0), ref[k]), (world, k)
+    full.close()
+
+
+def test_state_tensor_views_alias_device_state():
+    torch = torch_mod()
+    cfg, ora, tenv = make_pair(64, 2, zero_start_prob=1.0)
+    views = tenv.state_tensors()
+    assert views["yaw"].dtype == torch.float64 and views["last_key_press_time"].shape == (4, 64)
+    views["vel_x"].fill_(3.0)
+    torch.cuda.synchronize()
+    assert np.all(tenv.get_state()["vel_x"] == 3.0)
+    tenv.close()
