@@ -16,22 +16,34 @@ using namespace q1;
 
 // =========================================================================================== kernels
 // One tick of every env (reference VectorPhysEnv.vector_step, env.py:482-510), one lane per env.
-// Loads: 85 B of SoA state + the action; stores: the state + obs/reward/done.  No LDS: nothing is shared
-// between envs and the per-tick constants already sit in SGPRs.
-template <typename OBS_T>
+// Loads: 85 B of SoA state + the action; stores: the state + obs/reward/done.  The per-tick constants sit in SGPRs.
+// LDS is used for one thing only: transposing the wave's 64 float32 observation rows so they leave as 16-B-per-lane
+// coalesced stores (write_obs_wave_f32).
+//   SPEC: default Config structure baked in (straight-line tick);  FMT: action layout, or FMT_RUNTIME.
+template <typename OBS_T, bool SPEC, int FMT>
 __global__ void __launch_bounds__(256)
 step_kernel(Params p, StatePtrs s, int fmt, const void* act_a, const void* act_b,
             OBS_T* obs, float* reward, uint8_t* done, uint8_t* zero_start) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= p.n) return;
+    __shared__ float slab[4][384];
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t n = (uint32_t)p.n;
+    if (i >= n) return;
     Env e;
-    load_env(s, p.n, i, e);
+    load_env(s, n, i, e);
     double yaw_act;
-    const uint32_t keys = fetch_action(p, fmt, act_a, act_b, (size_t)i, &yaw_act);
+    const uint32_t keys = fetch_action<SPEC, FMT>(p, fmt, act_a, act_b, (size_t)i, &yaw_act);
     TickOut<OBS_T> o;
-    tick<OBS_T>(p, e, keys, yaw_act, o);
-    store_env(s, p.n, i, e);
-    if (obs) write_obs<OBS_T>(obs, (size_t)i, o.obs);
+    tick<OBS_T, SPEC>(p, e, keys, yaw_act, o);
+    store_env(s, n, i, e);
+    if (obs) {
+        if constexpr (sizeof(OBS_T) == 4) {
+            const uint32_t lane = threadIdx.x & 63u, wave_first = i - lane;
+            if (wave_first + 64u <= n) write_obs_wave_f32(obs, wave_first, lane, o.obs, slab[threadIdx.x >> 6]);
+            else write_obs<OBS_T>(obs, (size_t)i, o.obs);
+        } else {
+            write_obs<OBS_T>(obs, (size_t)i, o.obs);
+        }
+    }
     if (reward) reward[i] = o.reward;
     if (done) done[i] = o.done ? 1 : 0;
     if (zero_start) zero_start[i] = (e.flags & FLAG_ZERO_START) ? 1 : 0;
@@ -39,42 +51,95 @@ step_kernel(Params p, StatePtrs s, int fmt, const void* act_a, const void* act_b
 
 // `ticks` ticks in one launch: the env state lives in registers between ticks, only actions stream in and
 // (optional) per-tick outputs stream out.  Tick-major layouts keep every access of a wave contiguous.
-template <typename OBS_T>
+// The next tick's action is fetched before the current tick is computed, so its HBM latency hides under the
+// tick's float64 arithmetic instead of adding to it (a lone wave per SIMD has nothing else to hide it with).
+//   OUT_MODE: 1 = obs, reward and done are all written every tick (no null checks -> static store count),
+//             0 = no per-tick output at all, -1 = decided per pointer at run time.
+//   FULL:     every lane of the wave owns an env (the ragged tail wave runs its own copy of the loop, so that the
+//             number of stores per iteration is a compile-time constant in both).
+template <typename OBS_T, bool SPEC, int FMT, bool HAS_RESET, int OUT_MODE, bool FULL>
+__device__ __forceinline__ void rollout_loop(const Params& p, Env& e, uint32_t i, uint32_t n, int ticks, int fmt,
+                                             const void* act_a, const void* act_b, uint64_t seed, uint64_t tick0,
+                                             OBS_T* obs, float* reward, uint8_t* done, int auto_reset, double& ret,
+                                             float* slab) {
+    const uint64_t genv = (uint64_t)p.env_index_base + (uint64_t)i;
+    const bool random = (FMT >= 0 ? FMT : fmt) == FMT_RANDOM;
+    const uint32_t lane = threadIdx.x & 63u, wave_first = i - lane;
+    // Software prefetch for the packed layout: the RAW bytes of tick t+1's action are requested at the top of the
+    // body (unconditionally, index clamped on the last tick, so the loads stay in the body's first basic block),
+    // before tick t is computed, and are only decoded one iteration later; other layouts fetch in place.
+    constexpr bool PREFETCH = (FMT == FMT_PACKED);
+    uint32_t kraw_next = 0;
+    float mraw_next = 0.0f;
+    if constexpr (PREFETCH) {
+        kraw_next = ((const uint8_t*)act_a)[i];
+        mraw_next = ((const float*)act_b)[i];
+        // Drain every outstanding load (state + first action) once, here: the waitcnt scoreboard then enters the
+        // loop clean, so inside the loop the wait for a prefetched action is vmcnt(#younger ops) as seen along the
+        // back edge - it no longer has to cover the preheader's load order and does not drain the tick's stores.
+        __builtin_amdgcn_s_waitcnt(0x0F70);    // vmcnt(0), expcnt/lgkmcnt untouched
+    }
+    for (int t = 0; t < ticks; ++t) {
+        double yaw_act;
+        uint32_t keys;
+        if constexpr (PREFETCH) {
+            const uint32_t kraw = kraw_next;
+            const float mraw = mraw_next;
+            const size_t nxt = (size_t)(t + 1 < ticks ? t + 1 : t) * n + i;
+            kraw_next = ((const uint8_t*)act_a)[nxt];
+            mraw_next = ((const float*)act_b)[nxt];
+            keys = kraw & 0xFu;
+            yaw_act = (double)mraw;
+        } else if (random) {
+            keys = random_action<SPEC>(p, seed, genv, tick0 + (uint64_t)t, &yaw_act);
+        } else {
+            keys = fetch_action<SPEC, FMT>(p, fmt, act_a, act_b, (size_t)t * n + i, &yaw_act);
+        }
+        TickOut<OBS_T> o;
+        tick<OBS_T, SPEC>(p, e, keys, yaw_act, o);
+        const size_t base = (size_t)t * n;
+        if (OUT_MODE == 1 || (OUT_MODE < 0 && obs)) {
+            if constexpr (sizeof(OBS_T) == 4 && FULL) write_obs_wave_f32(obs, base + wave_first, lane, o.obs, slab);
+            else write_obs<OBS_T>(obs, base + i, o.obs);
+        }
+        if (OUT_MODE == 1 || (OUT_MODE < 0 && reward)) (reward + base)[i] = o.reward;
+        if (OUT_MODE == 1 || (OUT_MODE < 0 && done)) (done + base)[i] = o.done ? 1 : 0;
+        ret += (double)o.reward;
+        if constexpr (HAS_RESET) {
+            if (auto_reset && o.done) reset_philox(p, e, seed, genv, tick0 + (uint64_t)t + 1);
+        }
+    }
+}
+
+template <typename OBS_T, bool SPEC, int FMT, bool HAS_RESET, int OUT_MODE>
 __global__ void __launch_bounds__(256)
 rollout_kernel(Params p, StatePtrs s, int ticks, int fmt, const void* act_a, const void* act_b,
                uint64_t seed, uint64_t tick0, OBS_T* obs, float* reward, uint8_t* done,
                int auto_reset, double* return_sum) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= p.n) return;
+    __shared__ float slab[4][384];
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t n = (uint32_t)p.n;
+    if (i >= n) return;
     Env e;
-    load_env(s, p.n, i, e);
-    const uint64_t genv = (uint64_t)p.env_index_base + (uint64_t)i;
-    const size_t n = (size_t)p.n;
+    load_env(s, n, i, e);
     double ret = 0.0;
-    for (int t = 0; t < ticks; ++t) {
-        double yaw_act;
-        uint32_t keys;
-        if (fmt == 3) keys = random_action(p, seed, genv, tick0 + (uint64_t)t, &yaw_act);
-        else keys = fetch_action(p, fmt, act_a, act_b, (size_t)t * n + (size_t)i, &yaw_act);
-        TickOut<OBS_T> o;
-        tick<OBS_T>(p, e, keys, yaw_act, o);
-        const size_t oi = (size_t)t * n + (size_t)i;
-        if (obs) write_obs<OBS_T>(obs, oi, o.obs);
-        if (reward) reward[oi] = o.reward;
-        if (done) done[oi] = o.done ? 1 : 0;
-        ret += (double)o.reward;
-        if (auto_reset && o.done) reset_philox(p, e, seed, genv, tick0 + (uint64_t)t + 1);
-    }
-    store_env(s, p.n, i, e);
+    float* my_slab = slab[threadIdx.x >> 6];
+    if (i - (threadIdx.x & 63u) + 64u <= n)
+        rollout_loop<OBS_T, SPEC, FMT, HAS_RESET, OUT_MODE, true>(p, e, i, n, ticks, fmt, act_a, act_b, seed, tick0, obs, reward,
+                                                                   done, auto_reset, ret, my_slab);
+    else
+        rollout_loop<OBS_T, SPEC, FMT, HAS_RESET, OUT_MODE, false>(p, e, i, n, ticks, fmt, act_a, act_b, seed, tick0, obs, reward,
+                                                                    done, auto_reset, ret, my_slab);
+    store_env(s, n, i, e);
     if (return_sum) return_sum[i] += ret;
 }
 
 template <typename OBS_T>
 __global__ void __launch_bounds__(256) observe_kernel(Params p, StatePtrs s, OBS_T* obs) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= p.n) return;
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (uint32_t)p.n) return;
     Env e;
-    load_env(s, p.n, i, e);
+    load_env(s, (uint32_t)p.n, i, e);
     OBS_T o[6];
     observe<OBS_T>(p, e, o);
     write_obs<OBS_T>(obs, (size_t)i, o);
@@ -87,10 +152,10 @@ reset_draws_kernel(Params p, StatePtrs s, int count, const int32_t* idx, const u
                    const double* yaw, const double* tm, const double* speed, const double* angle, OBS_T* obs) {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= count) return;
-    const int i = idx ? idx[j] : j;
+    const uint32_t i = idx ? (uint32_t)idx[j] : (uint32_t)j;
     Env e;
     reset_from_draws(p, e, zero_start[j] != 0, yaw[j], tm[j], speed[j], angle[j]);
-    store_env(s, p.n, i, e);
+    store_env(s, (uint32_t)p.n, i, e);
     if (obs) {
         OBS_T o[6];
         observe<OBS_T>(p, e, o);
@@ -101,15 +166,15 @@ reset_draws_kernel(Params p, StatePtrs s, int count, const int32_t* idx, const u
 template <typename OBS_T>
 __global__ void __launch_bounds__(256)
 reset_philox_kernel(Params p, StatePtrs s, uint64_t seed, uint64_t counter, const uint8_t* mask, int done_only, OBS_T* obs) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= p.n) return;
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (uint32_t)p.n) return;
     Env e;
-    load_env(s, p.n, i, e);
+    load_env(s, (uint32_t)p.n, i, e);
     bool go = mask ? (mask[i] != 0) : true;
     if (done_only) go = go && (e.trem < 0.0);
     if (go) {
         reset_philox(p, e, seed, (uint64_t)p.env_index_base + (uint64_t)i, counter);
-        store_env(s, p.n, i, e);
+        store_env(s, (uint32_t)p.n, i, e);
     }
     if (obs) {
         OBS_T o[6];
@@ -122,13 +187,13 @@ reset_philox_kernel(Params p, StatePtrs s, uint64_t seed, uint64_t counter, cons
 __global__ void __launch_bounds__(256)
 decode_kernel(Params p, StatePtrs s, int fmt, const void* act_a, const void* act_b, const float* z_vel,
               const double* trem, double* yaw, int64_t* smove, int64_t* fmove, uint8_t* jump) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= p.n) return;
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (uint32_t)p.n) return;
     Env e;
-    load_env(s, p.n, i, e);
+    load_env(s, (uint32_t)p.n, i, e);
     double yaw_act;
-    const uint32_t keys = fetch_action(p, fmt, act_a, act_b, (size_t)i, &yaw_act);
-    const Cmd c = decode(p, e, keys, yaw_act, z_vel[i], trem[i]);
+    const uint32_t keys = fetch_action<false, FMT_RUNTIME>(p, fmt, act_a, act_b, (size_t)i, &yaw_act);
+    const Cmd c = decode<false>(p, e, keys, yaw_act, z_vel[i], trem[i]);
     s.yaw[i] = e.yaw;
 #pragma unroll
     for (int k = 0; k < 4; ++k) s.lk[(size_t)k * p.n + i] = e.lk[k];
@@ -154,11 +219,11 @@ decoder_reset_kernel(Params p, StatePtrs s, int count, const int32_t* idx, const
 // a known byte count in the kernel's own access pattern): reads every SoA state array with exactly the loads
 // step_kernel uses and writes the same bytes to a scratch arena: 85 B read + 85 B written per env, no arithmetic.
 __global__ void __launch_bounds__(256) calib_copy_kernel(Params p, StatePtrs src, StatePtrs dst) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= p.n) return;
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (uint32_t)p.n) return;
     Env e;
-    load_env(src, p.n, i, e);
-    store_env(dst, p.n, i, e);
+    load_env(src, (uint32_t)p.n, i, e);
+    store_env(dst, (uint32_t)p.n, i, e);
 }
 
 // Self-test of the exact-division helpers against the hardware IEEE division on random operands drawn over the
@@ -304,6 +369,8 @@ static int make_params(const q1env_config& c, Params& p, std::string& why) {
     p.act_width = p.num_keys + (p.yaw_mode ? 1 : 0);
     p.jump_mode = c.auto_jump ? 2 : (c.allow_jump ? 1 : 0);             // env.py:262-267
     p.smooth_keys = c.smooth_keys ? 1 : 0;
+    p.smooth_prev = c.smooth_keys ? 1.0 : 0.0;                          // env.py:251-254 as exact 0/1 arithmetic
+    p.smooth_scale = c.smooth_keys ? 0.5 : 1.0;
     p.hover = c.hover ? 1 : 0;
     p.speed_reward = c.speed_reward ? 1 : 0;
     p.dt = c.time_delta;
@@ -453,15 +520,27 @@ static size_t act_bytes_a(const q1env* h, int fmt) {
     return n;
 }
 
+// The default action/episode structure (4 keys, continuous mouse, jump key, no hover, y reward) runs the SPEC kernels.
+static bool is_spec(const Params& p) {
+    return p.num_keys == 4 && p.yaw_mode == 1 && p.jump_mode == 1 && !p.hover && !p.speed_reward;
+}
+
 static void launch_step(q1env* h, int fmt, const void* a, const void* b, int obs_format, void* obs,
                         float* reward, uint8_t* done, uint8_t* zs) {
     const int blk = block_for(h->p.n);
-    if (obs_format == Q1ENV_OBS_F32)
-        hipLaunchKernelGGL(step_kernel<float>, grid_for(h->p.n, blk), dim3(blk), 0, h->stream, h->p, h->st, fmt, a, b,
-                           (float*)obs, reward, done, zs);
-    else
-        hipLaunchKernelGGL(step_kernel<double>, grid_for(h->p.n, blk), dim3(blk), 0, h->stream, h->p, h->st, fmt, a, b,
-                           (double*)obs, reward, done, zs);
+    const dim3 g = grid_for(h->p.n, blk), bs(blk);
+    const bool spec = is_spec(h->p);
+#define Q1_LAUNCH_STEP(OT, SP, FM) \
+    hipLaunchKernelGGL((step_kernel<OT, SP, FM>), g, bs, 0, h->stream, h->p, h->st, fmt, a, b, (OT*)obs, reward, done, zs)
+    if (obs_format == Q1ENV_OBS_F32) {
+        if (spec && fmt == Q1ENV_ACT_PACKED) Q1_LAUNCH_STEP(float, true, FMT_PACKED);
+        else if (spec && fmt == Q1ENV_ACT_F32_ROWS) Q1_LAUNCH_STEP(float, true, FMT_F32_ROWS);
+        else Q1_LAUNCH_STEP(float, false, FMT_RUNTIME);
+    } else {
+        if (spec && fmt == Q1ENV_ACT_F64_ROWS) Q1_LAUNCH_STEP(double, true, FMT_F64_ROWS);
+        else Q1_LAUNCH_STEP(double, false, FMT_RUNTIME);
+    }
+#undef Q1_LAUNCH_STEP
 }
 
 int q1env_step(q1env_t* h, int fmt, const void* a, const void* b, int obs_format, void* obs, float* reward,
@@ -559,12 +638,32 @@ int q1env_rollout(q1env_t* h, int ticks, int fmt, const void* a, const void* b, 
     if (int r = check_act(h, fmt, a, b, true)) return r;
     if (obs_format != Q1ENV_OBS_F32 && obs_format != Q1ENV_OBS_F64) return fail(Q1ENV_ERR_INVALID_ARG, "bad obs_format");
     const int blk = block_for(h->p.n);
-    if (obs_format == Q1ENV_OBS_F32)
-        hipLaunchKernelGGL(rollout_kernel<float>, grid_for(h->p.n, blk), dim3(blk), 0, h->stream, h->p, h->st, ticks, fmt, a, b,
-                           seed, h->tick_count, (float*)obs, reward, done, auto_reset, return_sum);
-    else
-        hipLaunchKernelGGL(rollout_kernel<double>, grid_for(h->p.n, blk), dim3(blk), 0, h->stream, h->p, h->st, ticks, fmt, a, b,
-                           seed, h->tick_count, (double*)obs, reward, done, auto_reset, return_sum);
+    const dim3 g = grid_for(h->p.n, blk), bs(blk);
+    const bool spec = is_spec(h->p);
+#define Q1_LAUNCH_ROLL(OT, SP, FM, HR, OM)                                                                           \
+    hipLaunchKernelGGL((rollout_kernel<OT, SP, FM, HR, OM>), g, bs, 0, h->stream, h->p, h->st, ticks, fmt, a, b, seed, \
+                       h->tick_count, (OT*)obs, reward, done, auto_reset, return_sum)
+    const bool all_out = obs && reward && done, no_out = !obs && !reward && !done;
+    if (obs_format == Q1ENV_OBS_F32 && spec && (all_out || no_out) &&
+        (fmt == Q1ENV_ACT_PACKED || fmt == Q1ENV_ACT_RANDOM)) {
+        const int which = (fmt == Q1ENV_ACT_RANDOM ? 4 : 0) + (auto_reset ? 2 : 0) + (all_out ? 1 : 0);
+        switch (which) {
+            case 0: Q1_LAUNCH_ROLL(float, true, FMT_PACKED, false, 0); break;
+            case 1: Q1_LAUNCH_ROLL(float, true, FMT_PACKED, false, 1); break;
+            case 2: Q1_LAUNCH_ROLL(float, true, FMT_PACKED, true, 0); break;
+            case 3: Q1_LAUNCH_ROLL(float, true, FMT_PACKED, true, 1); break;
+            case 4: Q1_LAUNCH_ROLL(float, true, FMT_RANDOM, false, 0); break;
+            case 5: Q1_LAUNCH_ROLL(float, true, FMT_RANDOM, false, 1); break;
+            case 6: Q1_LAUNCH_ROLL(float, true, FMT_RANDOM, true, 0); break;
+            default: Q1_LAUNCH_ROLL(float, true, FMT_RANDOM, true, 1); break;
+        }
+    } else if (obs_format == Q1ENV_OBS_F32) {
+        if (spec && fmt == Q1ENV_ACT_F32_ROWS) Q1_LAUNCH_ROLL(float, true, FMT_F32_ROWS, true, -1);
+        else Q1_LAUNCH_ROLL(float, false, FMT_RUNTIME, true, -1);
+    } else {
+        Q1_LAUNCH_ROLL(double, false, FMT_RUNTIME, true, -1);
+    }
+#undef Q1_LAUNCH_ROLL
     HIP_TRY(hipGetLastError());
     h->tick_count += (uint64_t)ticks;
     return Q1ENV_OK;

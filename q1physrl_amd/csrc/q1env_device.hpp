@@ -4,6 +4,13 @@
 // argument, so they arrive through the scalar data path (s_load -> SGPRs) and cost no VGPRs, no LDS
 // and no per-lane loads.  Every branch on `Params` is wave-uniform.
 //
+// Two instantiations of everything below:
+//   SPEC = false  any Config (runtime num_keys / yaw mode / jump mode / hover / speed_reward), wave-uniform branches
+//   SPEC = true   the default action/episode structure baked in at compile time (4 keys, continuous mouse,
+//                 jump key, no hover, y-velocity reward: Config.get_default() and data/params.yml) -> one
+//                 straight-line basic block per tick, which is what lets the scheduler overlap the independent
+//                 float64 chains (decode | sincos | friction | z) of a lone wave on its SIMD.
+//
 // Numerics contract (restated from the reference as executed by NumPy 2.2.6):
 //   * yaw, time_remaining, last_key_press_time, z_pos and all horizontal intermediates: float64
 //   * vel: float32 storage, round-to-nearest-even on store (phys.py:190)
@@ -26,6 +33,9 @@ constexpr int FLAG_KEYS_SHIFT = 3;
 constexpr uint32_t STREAM_ACTION = 1;   // Philox stream tags
 constexpr uint32_t STREAM_RESET = 2;
 
+// action layouts (include/q1env.h Q1ENV_ACT_*); FMT_RUNTIME = decided by a kernel argument
+constexpr int FMT_RUNTIME = -1, FMT_F64_ROWS = 0, FMT_F32_ROWS = 1, FMT_PACKED = 2, FMT_RANDOM = 3;
+
 struct Params {
     int32_t n;
     int32_t num_keys;       // 4, or 3 when auto_jump || !allow_jump (env.py:206-207)
@@ -47,6 +57,8 @@ struct Params {
     double smove_max;       // double(float32(smove_max))                 env.py:260
     double accel_dt;        // double(float32(10)) * dt                   phys.py:78
     double grav_dt;         // double(float32(800)) * dt                  phys.py:122
+    double smooth_prev;     // 1.0 if smooth_keys else 0.0   } level = (key + smooth_prev*prev) * smooth_scale
+    double smooth_scale;    // 0.5 if smooth_keys else 1.0   } (exact: operands are 0/1)   env.py:251-254
     double zero_start_prob;
     double yaw_lo, yaw_hi;
     double max_initial_speed;
@@ -55,6 +67,13 @@ struct Params {
     float action_range_f32;
     int64_t env_index_base;
 };
+
+template <bool SPEC> __device__ __forceinline__ int cfg_num_keys(const Params& p) { if constexpr (SPEC) return 4; else return p.num_keys; }
+template <bool SPEC> __device__ __forceinline__ int cfg_act_width(const Params& p) { if constexpr (SPEC) return 5; else return p.act_width; }
+template <bool SPEC> __device__ __forceinline__ int cfg_yaw_mode(const Params& p) { if constexpr (SPEC) return 1; else return p.yaw_mode; }
+template <bool SPEC> __device__ __forceinline__ int cfg_jump_mode(const Params& p) { if constexpr (SPEC) return 1; else return p.jump_mode; }
+template <bool SPEC> __device__ __forceinline__ bool cfg_hover(const Params& p) { if constexpr (SPEC) return false; else return p.hover != 0; }
+template <bool SPEC> __device__ __forceinline__ bool cfg_speed_reward(const Params& p) { if constexpr (SPEC) return false; else return p.speed_reward != 0; }
 
 // SoA state in HBM.  Every array is num_envs long and 256-B aligned; lane i of a wave touches element
 // base+i of each array, so every load/store instruction of a wave is one contiguous, aligned segment.
@@ -84,7 +103,6 @@ struct TickOut {
     float reward;
     bool done;
 };
-
 
 // ---------------------------------------------------------------------------------------- exact division
 // x / c for a run-time CONSTANT c > 0 whose correctly rounded reciprocal y = RN(1/c) was computed once on the
@@ -126,21 +144,24 @@ __device__ __forceinline__ double div_shared(double a, double b, double y) {
     return a == 0.0 ? a : res;
 }
 
-__device__ __forceinline__ void load_env(const StatePtrs& s, int n, int i, Env& e) {
+// ---------------------------------------------------------------------------------------- state I/O
+// 32-bit unsigned lane index + SGPR base pointers: the loads/stores use the saddr addressing form instead of
+// per-array 64-bit VGPR address arithmetic.
+__device__ __forceinline__ void load_env(const StatePtrs& s, uint32_t n, uint32_t i, Env& e) {
     e.vx = s.vx[i]; e.vy = s.vy[i]; e.vz = s.vz[i];
     e.px = s.px[i]; e.py = s.py[i]; e.z = s.z[i];
     e.yaw = s.yaw[i]; e.trem = s.trem[i];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) e.lk[k] = s.lk[(size_t)k * n + i];
+    for (uint32_t k = 0; k < 4; ++k) e.lk[k] = (s.lk + (size_t)k * n)[i];
     e.flags = s.flags[i];
 }
 
-__device__ __forceinline__ void store_env(const StatePtrs& s, int n, int i, const Env& e) {
+__device__ __forceinline__ void store_env(const StatePtrs& s, uint32_t n, uint32_t i, const Env& e) {
     s.vx[i] = e.vx; s.vy[i] = e.vy; s.vz[i] = e.vz;
     s.px[i] = e.px; s.py[i] = e.py; s.z[i] = e.z;
     s.yaw[i] = e.yaw; s.trem[i] = e.trem;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) s.lk[(size_t)k * n + i] = e.lk[k];
+    for (uint32_t k = 0; k < 4; ++k) (s.lk + (size_t)k * n)[i] = e.lk[k];
     s.flags[i] = (uint8_t)e.flags;
 }
 
@@ -173,17 +194,18 @@ __host__ __device__ __forceinline__ double u53(uint32_t a, uint32_t b) {   // [0
 
 // iid random action for (seed, global env, tick): Bernoulli(1/2) keys, mouse ~ U(-range, range) in float32
 // (or a uniform discrete step).  Returns key bits; *yaw_act is what a policy would have emitted.
+template <bool SPEC>
 __device__ __forceinline__ uint32_t random_action(const Params& p, uint64_t seed, uint64_t genv, uint64_t tick,
                                                   double* yaw_act) {
     uint32_t r[4];
     philox_draw(seed, genv, tick, STREAM_ACTION, 0, r);
-    uint32_t keys = r[0] & ((1u << p.num_keys) - 1u);
-    if (p.yaw_mode == 1) {
-        float u = (float)(r[1] >> 8) * (1.0f / 16777216.0f);
-        float a = (u * 2.0f - 1.0f) * p.action_range_f32;
+    const uint32_t keys = r[0] & ((1u << cfg_num_keys<SPEC>(p)) - 1u);
+    if (cfg_yaw_mode<SPEC>(p) == 1) {
+        const float u = (float)(r[1] >> 8) * (1.0f / 16777216.0f);
+        const float a = (u * 2.0f - 1.0f) * p.action_range_f32;
         *yaw_act = (double)a;
-    } else if (p.yaw_mode == 2) {
-        uint32_t m = 2u * (uint32_t)p.yaw_steps + 1u;
+    } else if (cfg_yaw_mode<SPEC>(p) == 2) {
+        const uint32_t m = 2u * (uint32_t)p.yaw_steps + 1u;
         *yaw_act = (double)(r[1] % m);
     } else {
         *yaw_act = 0.0;
@@ -192,23 +214,28 @@ __device__ __forceinline__ uint32_t random_action(const Params& p, uint64_t seed
 }
 
 // ---------------------------------------------------------------------------------------- actions
-// Fetch env i's action from any of the device layouts (include/q1env.h Q1ENV_ACT_*): key bits (bit k =
-// trunc(a_k) & 1, the reference's `key_actions & (...)` on astype(int), env.py:228,243) and the mouse value.
-__device__ __forceinline__ uint32_t fetch_action(const Params& p, int fmt, const void* a, const void* b,
-                                                 size_t i, double* yaw_act) {
+// Fetch env idx's action from a device layout: key bits (bit k = trunc(a_k) & 1, the reference's
+// `key_actions & (...)` on astype(int), env.py:228,243) and the mouse value.
+template <bool SPEC, int FMT>
+__device__ __forceinline__ uint32_t fetch_action(const Params& p, int fmt_rt, const void* a, const void* b,
+                                                 size_t idx, double* yaw_act) {
+    const int fmt = FMT >= 0 ? FMT : fmt_rt;
+    const int nk = cfg_num_keys<SPEC>(p);
     uint32_t keys = 0;
     *yaw_act = 0.0;
-    if (fmt == 2) {                                   // packed: 1 B keys + 4 B mouse
-        keys = ((const uint8_t*)a)[i] & ((1u << p.num_keys) - 1u);
-        if (p.yaw_mode) *yaw_act = (double)((const float*)b)[i];
-    } else if (fmt == 0) {                            // float64 rows
-        const double* row = (const double*)a + i * (size_t)p.act_width;
-        for (int k = 0; k < p.num_keys; ++k) keys |= (uint32_t)((long long)row[k] & 1) << k;
-        if (p.yaw_mode) *yaw_act = row[p.num_keys];
+    if (fmt == FMT_PACKED) {                          // 1 B keys + 4 B mouse
+        keys = ((const uint8_t*)a)[idx] & ((1u << nk) - 1u);
+        if (cfg_yaw_mode<SPEC>(p)) *yaw_act = (double)((const float*)b)[idx];
+    } else if (fmt == FMT_F64_ROWS) {
+        const double* row = (const double*)a + idx * (size_t)cfg_act_width<SPEC>(p);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) if (k < nk) keys |= (uint32_t)((long long)row[k] & 1) << k;
+        if (cfg_yaw_mode<SPEC>(p)) *yaw_act = row[nk];
     } else {                                          // float32 rows
-        const float* row = (const float*)a + i * (size_t)p.act_width;
-        for (int k = 0; k < p.num_keys; ++k) keys |= (uint32_t)((long long)row[k] & 1) << k;
-        if (p.yaw_mode) *yaw_act = (double)row[p.num_keys];
+        const float* row = (const float*)a + idx * (size_t)cfg_act_width<SPEC>(p);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) if (k < nk) keys |= (uint32_t)((long long)row[k] & 1) << k;
+        if (cfg_yaw_mode<SPEC>(p)) *yaw_act = (double)row[nk];
     }
     return keys;
 }
@@ -216,39 +243,39 @@ __device__ __forceinline__ uint32_t fetch_action(const Params& p, int fmt, const
 // ---------------------------------------------------------------------------------------- decode
 // ActionDecoder.map for one env (env.py:225-269).  z_vel / trem are passed separately because the
 // stand-alone decoder takes them from the caller (mkdemo.py:47-55).
+template <bool SPEC>
 __device__ __forceinline__ Cmd decode(const Params& p, Env& e, uint32_t keybits, double yaw_act,
                                       float z_vel, double trem) {
     const double now = p.time_limit - trem;                             // env.py:241,246
     const uint32_t prev = (e.flags >> FLAG_KEYS_SHIFT) & 0xFu;
+    const int nk = cfg_num_keys<SPEC>(p);
     uint32_t keys = 0;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        if (k < p.num_keys) {
+        if (k < nk) {
             const bool may_press = now >= e.lk[k] + p.key_press_delay;  // float64 compare (env.py:241-242)
             const uint32_t pk = (prev >> k) & 1u;
             const uint32_t key = ((keybits >> k) & 1u) & ((may_press ? 1u : 0u) | pk);   // env.py:243
-            if (key & ~pk & 1u) e.lk[k] = now;                          // rising edge (env.py:244-248)
+            e.lk[k] = (key & ~pk & 1u) ? now : e.lk[k];                 // rising edge (env.py:244-248)
             keys |= key << k;
         }
     }
     double lvl[3];
 #pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        const double kk = (double)((keys >> k) & 1u);
-        lvl[k] = p.smooth_keys ? (kk + (double)((prev >> k) & 1u)) * 0.5 : kk;   // env.py:251-254
-    }
+    for (int k = 0; k < 3; ++k)                                         // env.py:251-254, branch-free and exact on 0/1
+        lvl[k] = ((double)((keys >> k) & 1u) + p.smooth_prev * (double)((prev >> k) & 1u)) * p.smooth_scale;
     e.flags = (e.flags & 0x7u) | (keys << FLAG_KEYS_SHIFT);             // env.py:256
 
     double dyaw = 0.0;
-    if (p.yaw_mode == 1) dyaw = div_const<double>(yaw_act * p.yaw_num, p.yaw_den, p.yaw_den_rcp);   // env.py:236
-    else if (p.yaw_mode == 2) dyaw = div_const<double>((yaw_act - p.yaw_steps) * p.yaw_num, p.yaw_den, p.yaw_den_rcp);   // env.py:238
+    if (cfg_yaw_mode<SPEC>(p) == 1) dyaw = div_const<double>(yaw_act * p.yaw_num, p.yaw_den, p.yaw_den_rcp);   // env.py:236
+    else if (cfg_yaw_mode<SPEC>(p) == 2) dyaw = div_const<double>((yaw_act - p.yaw_steps) * p.yaw_num, p.yaw_den, p.yaw_den_rcp);   // env.py:238
     e.yaw = e.yaw + dyaw;                                               // env.py:258
 
     Cmd c;
     c.smove = trunc(p.smove_max * (lvl[1] - lvl[0])) + 0.0;             // astype(int): toward zero, +0 (env.py:259-260,269)
     c.fmove = trunc(p.fmove_max * lvl[2]) + 0.0;                        // env.py:261,269
-    if (p.jump_mode == 2) c.jump = z_vel <= 16.0f;                      // env.py:263
-    else if (p.jump_mode == 1) c.jump = (keys >> 3) & 1u;               // env.py:265
+    if (cfg_jump_mode<SPEC>(p) == 2) c.jump = z_vel <= 16.0f;           // env.py:263
+    else if (cfg_jump_mode<SPEC>(p) == 1) c.jump = (keys >> 3) & 1u;    // env.py:265
     else c.jump = false;                                                // env.py:267
     return c;
 }
@@ -256,8 +283,9 @@ __device__ __forceinline__ Cmd decode(const Params& p, Env& e, uint32_t keybits,
 // ---------------------------------------------------------------------------------------- physics
 // phys.apply for one env (phys.py:184-197).  The 2x2 basis (forward | right, phys.py:65-66) is passed in:
 // the env always has pitch = roll = 0, i.e. m = [[cos, sin], [sin, -cos]].
-// The wave-level ballot of the PREVIOUS tick's on_ground lets airborne waves skip the whole friction
-// block (float32 sqrt + float64 divide) through a wave-uniform branch.
+// Per-lane conditions are selects, not branches, so the whole tick stays one basic block; the only branch is the
+// wave-level ballot of the PREVIOUS tick's on_ground: a wave with nobody on the ground skips the friction block
+// (float32 sqrt + float64 divide) through a wave-uniform s_cbranch.
 __device__ __forceinline__ void physics(Env& e, const Cmd& c, double m00, double m01, double m10, double m11,
                                         double dt, double accel_dt, double grav_dt) {
     const bool og = e.flags & FLAG_ON_GROUND;
@@ -265,23 +293,23 @@ __device__ __forceinline__ void physics(Env& e, const Cmd& c, double m00, double
     const double wx = (0.0 + m00 * c.fmove) + m01 * c.smove;
     const double wy = (0.0 + m10 * c.fmove) + m11 * c.smove;
     const double wlen = sqrt(wx * wx + wy * wy);                        // phys.py:98
-    double dx = wx, dy = wy;
-    if (wlen > 0.0) {                                                   // phys.py:99-101
-        const double yw = rcp_refined(wlen);
-        dx = div_shared(wx, wlen, yw); dy = div_shared(wy, wlen, yw);
-    }
+    const bool has_wish = wlen > 0.0;
+    const double wden = has_wish ? wlen : 1.0;                          // keep the unused quotient finite
+    const double yw = rcp_refined(wden);
+    const double dx = has_wish ? div_shared(wx, wden, yw) : wx;         // phys.py:99-101
+    const double dy = has_wish ? div_shared(wy, wden, yw) : wy;
     const double wish_speed = fmin(320.0, wlen);                        // phys.py:103
 
     double hx = (double)e.vx, hy = (double)e.vy;
     if (__ballot(og)) {                                                 // wave-uniform skip
         const float speed = sqrtf(e.vx * e.vx + e.vy * e.vy);           // float32 norm (phys.py:85)
-        if (og && speed > 0.0f) {
-            const float control = fmaxf(speed, 100.0f);                 // phys.py:86
-            const double drop = (dt * (double)control) * 4.0;           // phys.py:87
-            const double ns = fmax(0.0, (double)speed - drop);          // phys.py:88
-            const double k = ns / (double)speed;                        // phys.py:90
-            hx = (double)e.vx * k; hy = (double)e.vy * k;
-        }
+        const bool fr = og && speed > 0.0f;
+        const float control = fmaxf(speed, 100.0f);                     // phys.py:86
+        const double drop = (dt * (double)control) * 4.0;               // phys.py:87
+        const double ns = fmax(0.0, (double)speed - drop);              // phys.py:88
+        const double k = ns / (fr ? (double)speed : 1.0);               // phys.py:90
+        hx = fr ? (double)e.vx * k : hx;
+        hy = fr ? (double)e.vy * k : hy;
     }
     const double cur = (0.0 + hx * dx) + hy * dy;                       // phys.py:71
     const double capped = (wish_speed > 30.0 && !og) ? 30.0 : wish_speed;   // phys.py:73-75
@@ -291,15 +319,14 @@ __device__ __forceinline__ void physics(Env& e, const Cmd& c, double m00, double
     e.vy = (float)(hy + acc * dy);
 
     // z (phys.py:112-132)
-    uint32_t fl = e.flags;
-    if (!c.jump) fl |= FLAG_JUMP_RELEASED;                              // phys.py:117
+    const uint32_t fl = e.flags | (c.jump ? 0u : FLAG_JUMP_RELEASED);   // phys.py:117
     const bool do_jump = og && c.jump && (fl & FLAG_JUMP_RELEASED);     // phys.py:118
     float vz = e.vz + (do_jump ? 270.0f : 0.0f);                        // float32 add (phys.py:119)
     vz = (float)((double)vz - grav_dt);                                 // float64 subtract, RNE (phys.py:122)
-    double z = e.z + dt * (double)vz;                                   // phys.py:127
+    const double z = e.z + dt * (double)vz;                             // phys.py:127
     const bool landed = z < 24.03125;                                   // phys.py:128
-    if (landed) { z = 24.03125; vz = 0.0f; }                            // phys.py:129-130
-    e.z = z; e.vz = vz;
+    e.z = landed ? 24.03125 : z;                                        // phys.py:129
+    e.vz = landed ? 0.0f : vz;                                          // phys.py:130
     e.flags = (fl & ~FLAG_ON_GROUND) | (landed ? FLAG_ON_GROUND : 0u);
 }
 
@@ -334,12 +361,12 @@ __device__ __forceinline__ void observe(const Params& p, const Env& e, OBS_T o[6
 }
 
 // VectorPhysEnv.vector_step for one env (env.py:482-510)
-template <typename OBS_T>
+template <typename OBS_T, bool SPEC>
 __device__ __forceinline__ void tick(const Params& p, Env& e, uint32_t keybits, double yaw_act, TickOut<OBS_T>& out) {
-    if (p.hover) { e.vz = 0.0f; e.z = 100.0; }                          // env.py:483-485
-    const Cmd c = decode(p, e, keybits, yaw_act, e.vz, e.trem);
+    if (cfg_hover<SPEC>(p)) { e.vz = 0.0f; e.z = 100.0; }               // env.py:483-485
+    const Cmd c = decode<SPEC>(p, e, keybits, yaw_act, e.vz, e.trem);
     physics_yaw_only(p, e, c);
-    if (p.speed_reward) out.reward = p.dt_f32 * sqrtf(e.vx * e.vx + e.vy * e.vy);   // env.py:501 (float32)
+    if (cfg_speed_reward<SPEC>(p)) out.reward = p.dt_f32 * sqrtf(e.vx * e.vx + e.vy * e.vy);   // env.py:501 (float32)
     else out.reward = p.dt_f32 * e.vy;                                  // env.py:503 (float32)
     e.px = e.px + p.dt * (double)e.vx;                                  // extension: distance integrals
     e.py = e.py + p.dt * (double)e.vy;
@@ -385,10 +412,37 @@ __device__ __forceinline__ void reset_philox(const Params& p, Env& e, uint64_t s
     reset_from_draws(p, e, zs, yaw, tm, sp, an);
 }
 
+// ---------------------------------------------------------------------------------------- observation rows
 template <typename T>
 __device__ __forceinline__ void write_obs(T* obs, size_t i, const T o[6]) {
 #pragma unroll
     for (int j = 0; j < 6; ++j) obs[i * 6 + j] = o[j];
+}
+
+// Row-major (N,6) float32 observations are what a policy network consumes, but a lane owning one row means six
+// 4-byte stores at a 24-byte lane stride per wave.  Stage the wave's 64 rows (1536 contiguous bytes) through a
+// wave-private LDS slab instead and write them out as three all-lane 8-byte-per-lane stores (512 contiguous bytes
+// each): 3 fully coalesced VMEM instructions instead of 6 strided ones, and - because every lane takes part in each -
+// a STATIC number of stores per tick, which lets the compiler wait for a prefetched load with vmcnt(#stores) instead
+// of draining the stores (gfx9 counts loads and stores in one in-order vmcnt).  LDS ops of one wave execute in order,
+// so only a wave-scope fence + compiler-level wave barrier is needed between the write and the transposed read.
+// `slab` = this wave's 384 floats.  Only for waves whose 64 lanes are all active (the transposed store needs every
+// lane); the ragged tail wave writes its rows directly with write_obs.
+__device__ __forceinline__ void write_obs_wave_f32(float* obs, size_t wave_first, uint32_t lane, const float o[6],
+                                                   float* slab) {
+    float2* w = reinterpret_cast<float2*>(slab + lane * 6);
+    w[0] = make_float2(o[0], o[1]);
+    w[1] = make_float2(o[2], o[3]);
+    w[2] = make_float2(o[4], o[5]);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    float2* dst = reinterpret_cast<float2*>(obs + wave_first * 6);
+    const float2* src = reinterpret_cast<const float2*>(slab);
+#pragma unroll
+    for (uint32_t k = 0; k < 3; ++k) dst[k * 64u + lane] = src[k * 64u + lane];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
 }
 
 }  // namespace q1
