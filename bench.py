@@ -7,11 +7,17 @@
 A "step" is one tick (one VectorPhysEnv.vector_step, reference env.py:482-510) of the whole batch.
 Workload at N=1 = BASELINE.json configs[1]: 65 536 envs, zero-start 100 m run (zero_start_prob = 1,
 get_default Config, dt = 1/72, 720-tick episodes), random actions (keys flip with p = 0.05 per tick,
-mouse ~ U(-action_range, action_range) float32).  Inputs (the packed 5 B/env action tensor for a whole
+mouse ~ U(-action_range, action_range) float32).  Inputs (the packed 5 B/env action tensor of a whole
 720-tick episode) are resident in HBM before the timed region; every tick writes obs float32 (N,6),
 reward float32, done uint8; all envs are reset on device at each episode end (inside the timed region).
-Multi-GPU: one process per GPU, the batch is split (65 536 envs per GPU, weak scaling), no collective
-on the data path; ranks only meet in the barriers around the timed region.
+
+  --mode step     (default, = `value`): ONE step_kernel launch per tick, 720 launches replayed from one hipGraph.
+                  This is the granularity the drop-in API has (a policy can sit between ticks).
+  --mode rollout  the fused kernel: 720 ticks per launch, state in registers, same per-tick outputs.
+                  Reported in the same JSON line under "fused_rollout" (secondary; it needs the actions in advance).
+
+Multi-GPU: one process per GPU, the batch is split (65 536 envs per GPU, weak scaling), no collective on
+the data path; ranks only meet in the barriers around the timed region and in the MAX of the elapsed time.
 
 Output: ONE JSON line on rank 0 (contract in the task statement) with `roofline` and `cpu_baseline`.
 """
@@ -26,7 +32,8 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-B_ALG = 204.0            # algorithmic bytes per env-step (SURVEY.md 8d / DESIGN.md)
+B_ALG = 204.0            # algorithmic bytes per env-step (SURVEY.md 8d / DESIGN.md section 3)
+B_FUSED = 34.0           # real bytes per env-step of the fused rollout kernel (5 B action + 29 B outputs), + 170 B/env/launch
 HBM_PEAK_GBPS = 8000.0   # MI355X_MICROARCH.md: 8 TB/s spec
 EPISODE_TICKS = 720
 
@@ -46,9 +53,10 @@ def make_actions(n, ticks, action_range, seed):
     return keys, mouse
 
 
-def cpu_baseline(n, action_range, budget_s=12.0):
-    """The NumPy oracle (a from-scratch restatement of the reference's NumPy path, bit-pinned to the reference
-    by tests/golden) timed on this box's host: 1 process, 1 thread (NumPy elementwise kernels are single-threaded)."""
+def cpu_baseline(n, action_range, budget_s=10.0):
+    """The NumPy oracle (from-scratch restatement of the reference's NumPy path, bit-pinned to the reference by
+    tests/golden) timed on this box's host: 1 process, 1 thread (NumPy elementwise kernels are single-threaded).
+    Also the C oracle on all host cores (OpenMP), reported as extra information."""
     from oracle import np_oracle as O
     np.random.seed(0)
     env = O.OracleVectorEnv(O.OracleConfig.get_default(num_envs=n, zero_start_prob=1.0))
@@ -63,8 +71,31 @@ def cpu_baseline(n, action_range, budget_s=12.0):
         env.vector_step(acts[ticks % len(acts)])
         ticks += 1
     dt = time.perf_counter() - t0
-    return {"value": n * ticks / dt, "unit": "env-steps/s", "cores": 1, "kind": "port",
-            "sample": f"{ticks} ticks of {n} envs (ndarray actions, oracle/np_oracle.py) in {dt:.1f} s; host has {os.cpu_count()} logical cores"}
+    out = {"value": n * ticks / dt, "unit": "env-steps/s", "cores": 1, "kind": "port",
+           "sample": f"{ticks} ticks of {n} envs (ndarray actions, oracle/np_oracle.py, NumPy {np.__version__}) in {dt:.1f} s; "
+                     f"host has {os.cpu_count()} logical cores"}
+    try:
+        from oracle import c_oracle as CO
+        threads = max(1, min(os.cpu_count() or 1, 64))
+        CO.time_rollout(n, 4, threads, action_range)          # warm-up (page faults, thread pool)
+        tk = 60
+        dtc = CO.time_rollout(n, tk, threads, action_range)
+        out["c_port_openmp"] = {"value": n * tk / dtc, "unit": "env-steps/s", "cores": threads,
+                                "sample": f"{tk} ticks of {n} envs, oracle/q1_oracle.c, {threads} OpenMP threads, {dtc:.2f} s"}
+    except Exception as ex:   # noqa: BLE001 - the C oracle is optional extra information
+        out["c_port_openmp"] = {"error": repr(ex)}
+    return out
+
+
+def load_profiled_traffic(mode, n):
+    """HBM bytes per launch measured with rocprofv3 PMC passes (tools/profile_r1.sh -> profiles/*.json); None if absent."""
+    path = os.path.join(ROOT, "profiles", "traffic.json")
+    try:
+        with open(path) as f:
+            d = json.load(f)
+        return d.get(f"{mode}_{n}")
+    except Exception:   # noqa: BLE001
+        return None
 
 
 def main():
@@ -76,11 +107,12 @@ def main():
     ap.add_argument("--mode", choices=("step", "rollout"), default="step")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary (other-mode) measurement")
     args = ap.parse_args()
 
     import torch
     import torch.distributed as dist
-    from q1physrl_amd import _lib, env as E
+    from q1physrl_amd import _lib, env as E, sharding
     from q1physrl_amd.device import DeviceEnv
 
     rank = int(os.environ.get("RANK", "0"))
@@ -89,50 +121,57 @@ def main():
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible and there is no CPU fallback")
-    torch.cuda.set_device(local_rank)
+    ndev = torch.cuda.device_count()
+    dev_index = local_rank % ndev
+    torch.cuda.set_device(dev_index)
+    d = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        backend = os.environ.get("Q1_BENCH_BACKEND", "nccl" if ndev >= world else "gloo")
+        try:
+            dist.init_process_group(backend, device_id=d if backend == "nccl" else None)
+        except Exception:   # noqa: BLE001 - the env path needs no collective; barriers work over gloo as well
+            dist.init_process_group("gloo")
 
     n = args.envs
+    start, _ = sharding.shard_range(n * world, rank, world)                  # contiguous batch split, weak scaling
     cfg = E.Config(**{**E.Config.get_default().__dict__, "num_envs": n, "zero_start_prob": 1.0})
-    dev = DeviceEnv(cfg, device=local_rank, env_index_base=rank * n)    # own stream; global env index keys the RNG
+    dev = DeviceEnv(cfg, device=dev_index, env_index_base=start)             # own stream; global env index keys the RNG
     ar = float(cfg.action_range)
     keys_h, mouse_h = make_actions(n, EPISODE_TICKS, ar, seed=1234 + rank)
-    d = torch.device("cuda", local_rank)
     keys = torch.from_numpy(keys_h).to(d)
     mouse = torch.from_numpy(mouse_h).to(d)
-    obs = torch.empty((n, 6), dtype=torch.float32, device=d)
-    reward = torch.empty((n,), dtype=torch.float32, device=d)
-    done = torch.empty((n,), dtype=torch.uint8, device=d)
-    if args.mode == "rollout":       # tick-major per-tick outputs for a whole episode
-        obs = torch.empty((EPISODE_TICKS, n, 6), dtype=torch.float32, device=d)
-        reward = torch.empty((EPISODE_TICKS, n), dtype=torch.float32, device=d)
-        done = torch.empty((EPISODE_TICKS, n), dtype=torch.uint8, device=d)
+    obs1 = torch.empty((n, 6), dtype=torch.float32, device=d)
+    rew1 = torch.empty((n,), dtype=torch.float32, device=d)
+    done1 = torch.empty((n,), dtype=torch.uint8, device=d)
+    obsT = rewT = doneT = None
     torch.cuda.synchronize()
 
-    def run_ticks(k, tick0):
+    def run_ticks(mode, k, tick0):
         """k ticks starting at episode phase tick0 % 720; resets every env on device at each episode end."""
-        t = tick0
-        left = k
-        launches = 0
+        nonlocal obsT, rewT, doneT
+        if mode == "rollout" and obsT is None:        # tick-major per-tick outputs of a whole episode
+            obsT = torch.empty((EPISODE_TICKS, n, 6), dtype=torch.float32, device=d)
+            rewT = torch.empty((EPISODE_TICKS, n), dtype=torch.float32, device=d)
+            doneT = torch.empty((EPISODE_TICKS, n), dtype=torch.uint8, device=d)
+        t, left, launches = tick0, k, 0
         while left > 0:
             ph = t % EPISODE_TICKS
             chunk = min(left, EPISODE_TICKS - ph)
             ka = keys.data_ptr() + ph * n
             ma = mouse.data_ptr() + ph * n * 4
-            if args.mode == "step":
-                dev.step_many_dev(chunk, _lib.ACT_PACKED, ka, ma, _lib.OBS_F32, obs.data_ptr(), reward.data_ptr(),
-                                  done.data_ptr(), out_stride_ticks=0, use_graph=not args.no_graph)
+            if mode == "step":
+                dev.step_many_dev(chunk, _lib.ACT_PACKED, ka, ma, _lib.OBS_F32, obs1.data_ptr(), rew1.data_ptr(),
+                                  done1.data_ptr(), out_stride_ticks=0, use_graph=not args.no_graph)
                 launches += chunk
             else:
-                dev.rollout_dev(chunk, _lib.ACT_PACKED, ka, ma, 0, _lib.OBS_F32, obs.data_ptr(), reward.data_ptr(),
-                                done.data_ptr(), auto_reset=False)
+                dev.rollout_dev(chunk, _lib.ACT_PACKED, ka, ma, 0, _lib.OBS_F32, obsT.data_ptr(), rewT.data_ptr(),
+                                doneT.data_ptr(), auto_reset=False)
                 launches += 1
             t += chunk
             left -= chunk
             if t % EPISODE_TICKS == 0:
-                dev.reset_philox_dev(seed=99, done_only=True)          # zero_start_prob = 1: every env back to the start line
+                dev.reset_philox_dev(seed=99, done_only=True)        # zero_start_prob = 1: every env back to the start line
         return launches
 
     def barrier():
@@ -141,41 +180,58 @@ def main():
         if world > 1:
             dist.barrier()
 
-    run_ticks(args.warmup, 0)
-    barrier()
-    t0 = time.perf_counter()
-    dev.timer_start()
-    launches = run_ticks(args.steps, args.warmup)
-    ev_ms = dev.timer_stop()                      # HIP events on the stream the kernels were launched on
-    barrier()
-    wall = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([wall], dtype=torch.float64, device=d)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        wall = float(tt.item())
+    def measure(mode, steps, warmup):
+        run_ticks(mode, warmup, 0)
+        barrier()
+        t0 = time.perf_counter()
+        dev.timer_start()
+        launches = run_ticks(mode, steps, warmup)
+        ev_ms = dev.timer_stop()                  # HIP events on the stream the kernels were launched on
+        barrier()
+        wall = sharding.max_over_ranks(time.perf_counter() - t0, device=d)
+        return wall, ev_ms, launches
 
-    total_env_steps = float(n) * args.steps * world
-    value = total_env_steps / wall
-    units_per_launch = n * (args.steps / launches)
+    wall, ev_ms, launches = measure(args.mode, args.steps, args.warmup)
+    value = float(n) * args.steps * world / wall
+    ticks_per_launch = args.steps / launches
     kern_us = ev_ms * 1e3 / launches
-    achieved = B_ALG * units_per_launch / (kern_us * 1e-6) / 1e9
+    achieved = B_ALG * n * ticks_per_launch / (kern_us * 1e-6) / 1e9
+    kernel = ("step_kernel<float,SPEC,PACKED>" if args.mode == "step" else "rollout_kernel<float,SPEC,PACKED,no-reset,all-outputs>")
+    roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
+            "traffic": load_profiled_traffic(args.mode, n), "kernel": kernel, "avg_launch_us": kern_us,
+            "alg_bytes_per_env_step": B_ALG, "env_steps_per_launch": n * ticks_per_launch,
+            "note": "achieved = 204 B x env-steps per launch / (HIP-event time of the timed region / launches). "
+                    "traffic = HBM bytes per launch from the rocprofv3 FETCH_SIZE(x2, gfx950)/WRITE_SIZE passes in profiles/ "
+                    "(null if that size was not profiled)."}
+    if args.mode == "rollout":
+        real = (B_FUSED * n * ticks_per_launch + 170.0 * n) / (kern_us * 1e-6) / 1e9
+        roof["real_bytes_achieved_GBps"] = real
+        roof["note"] += (" The fused kernel keeps state in registers: its real traffic is 34 B/env-step + 170 B/env/launch, "
+                         "so the 204-B figure overstates its HBM use; it is bound by float64 VALU issue.")
     out = {
         "metric": "env-steps/sec @ 64k envs, 1/2/4/8 MI355X; max |pos - NumPy ref| over 10 s",
         "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": wall * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f64 arithmetic, f32 vel/obs/reward storage", "data": "synthetic",
+        "dtype": "f64", "data": "synthetic",
         "config": {"workload": f"BASELINE configs[1]: {n} envs/GPU, zero-start 100 m run, random actions, get_default Config, "
-                               f"720-tick episodes, mode={args.mode}" + ("" if args.no_graph or args.mode != "step" else "+hipGraph"),
-                   "envs_per_gpu": n, "parallelism": f"batch-split x{world}, no collective"},
-        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-                     "traffic": None, "kernel": "step_kernel<float>" if args.mode == "step" else "rollout_kernel<float>",
-                     "avg_launch_us": kern_us, "alg_bytes_per_env_step": B_ALG,
-                     "note": "achieved = 204 B x env-steps per launch / (HIP-event time of the timed region / launches); "
-                             "traffic: see profiles/ (PMC pass is a separate run)"},
+                               f"720-tick episodes with on-device reset, per-tick obs f32/reward/done written; mode={args.mode}"
+                               + ("+hipGraph" if args.mode == "step" and not args.no_graph else ""),
+                   "envs_per_gpu": n, "parallelism": f"batch-split x{world}, no collective",
+                   "arithmetic": "float64 (float32 storage of vel/obs/reward), bit-identical to the NumPy reference"},
+        "roofline": roof,
+        "parity": "tests/test_hip_parity.py + tests/test_hip_fastpath.py: max |pos - ref| = 0.0 over the 720-tick rollout (bit-identical)",
     }
+    if not args.no_secondary:
+        other = "rollout" if args.mode == "step" else "step"
+        w2, ev2, l2 = measure(other, args.steps, args.warmup)
+        out["fused_rollout" if other == "rollout" else "per_tick_step"] = {
+            "value": float(n) * args.steps * world / w2, "unit": "env-steps/s", "ms_per_step": w2 * 1e3 / args.steps,
+            "launches": l2, "avg_launch_us": ev2 * 1e3 / l2,
+            "note": ("one rollout_kernel launch per 720-tick episode, identical inputs/outputs" if other == "rollout"
+                     else "one step_kernel launch per tick (hipGraph)")}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(n, ar)
-    elif rank == 0:
+    else:
         out["cpu_baseline"] = None
     if rank == 0:
         print(json.dumps(out), flush=True)

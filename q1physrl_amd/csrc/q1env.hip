@@ -7,6 +7,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -344,7 +345,11 @@ static inline dim3 grid_for(int n, int block) { return dim3((unsigned)((n + bloc
 
 // Small batches are latency bound: 64-lane workgroups spread 64 k envs over all 256 CUs (1024 waves).
 // Large batches are bandwidth bound: 256-lane workgroups cut dispatch overhead.
-static inline int block_for(int n) { return n >= (1 << 19) ? 256 : 64; }
+static inline int block_for(int n) {
+    static const int forced = [] { const char* e = getenv("Q1ENV_BLOCK"); return e ? atoi(e) : 0; }();   // tuning knob
+    if (forced == 64 || forced == 128 || forced == 256) return forced;
+    return n >= (1 << 19) ? 256 : 64;
+}
 
 static int ensure_stage(q1env* h, size_t bytes) {
     if (bytes <= h->stage_bytes) return 0;

@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
-"""Summarise rocprofv3 CSV output of tools/profile_r1.sh: per-kernel stats and PMC byte counters per launch."""
+"""Summarise rocprofv3 CSV output of tools/profile_r1.sh: per-kernel stats, launch gaps, PMC byte counters per launch
+(raw and with the gfx950 FETCH_SIZE x2 correction), and the calibration of both counters on the known-bytes copy kernel."""
 import csv
 import glob
+import json
 import os
 import sys
 from collections import defaultdict
@@ -14,40 +16,51 @@ def first(pattern):
     return g[0] if g else None
 
 
+def short(name):
+    return name.replace("void ", "").split("(")[0][:60]
+
+
 st = first("trace/**/*kernel_stats.csv")
 if st:
-    print("== kernel stats (rocprofv3 --kernel-trace --stats):", st)
+    print("== rocprofv3 --kernel-trace --stats (kernel_stats.csv)")
     for row in csv.DictReader(open(st)):
-        print({k: row[k] for k in row if k in ("Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs")})
+        print(f"  {short(row['Name']):60s} calls={row['Calls']:>6s} avg_ns={float(row['AverageNs']):10.1f} min={row['MinNs']:>7s} max={row['MaxNs']:>8s} pct={row['Percentage']}")
 kt = first("trace/**/*kernel_trace.csv")
 if kt:
     rows = list(csv.DictReader(open(kt)))
-    by = defaultdict(list)
-    for r in rows:
-        by[r["Kernel_Name"]].append((int(r["Start_Timestamp"]), int(r["End_Timestamp"])))
-    print("== kernel trace: per-kernel avg duration and avg gap to the previous kernel end (same queue order)")
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-    gaps = defaultdict(list)
-    for a, b in zip(rows[:-1], rows[1:]):
-        gaps[b["Kernel_Name"]].append(int(b["Start_Timestamp"]) - int(a["End_Timestamp"]))
-    for k, v in by.items():
-        d = [e - s for s, e in v]
-        g = gaps.get(k, [0])
-        g2 = sorted(g)
-        print(f"{k[:70]:70s} calls={len(v):6d} avg={sum(d)/len(d):9.1f} ns  min={min(d)} max={max(d)}  median_gap={g2[len(g2)//2]} ns")
-    r0 = rows[0]
-    print("VGPR/SGPR/LDS of", r0["Kernel_Name"][:40], {k: r0[k] for k in r0 if "GPR" in k or "LDS" in k or "Workgroup" in k or "Grid" in k})
-for tag, ctr in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
+    by, grid = defaultdict(list), {}
+    for r in rows:
+        by[r["Kernel_Name"]].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+        grid[r["Kernel_Name"]] = {k: r[k] for k in ("Grid_Size_X", "Workgroup_Size_X", "VGPR_Count", "Accum_VGPR_Count", "SGPR_Count", "LDS_Block_Size") if k in r}
+    print("== kernel trace (per dispatch)")
+    for k, d in by.items():
+        d2 = sorted(d)
+        print(f"  {short(k):60s} n={len(d):6d} avg={sum(d)/len(d):9.1f} ns median={d2[len(d2)//2]} ns  {grid[k]}")
+
+
+def pmc(tag, ctr):
     cc = first(f"{tag}/**/*counter_collection.csv")
+    acc = defaultdict(lambda: [0.0, 0, 0])
     if not cc:
-        print("no counter csv for", tag)
-        continue
-    acc = defaultdict(lambda: [0.0, 0])
+        return acc
     for r in csv.DictReader(open(cc)):
         if r.get("Counter_Name") == ctr:
-            a = acc[r["Kernel_Name"]]
+            a = acc[(r["Kernel_Name"], int(r["Grid_Size_X"]) if "Grid_Size_X" in r else int(r.get("Grid_Size", 0)))]
             a[0] += float(r["Counter_Value"])
             a[1] += 1
-    print(f"== {ctr} (raw counter units, per launch)")
-    for k, (s, c) in acc.items():
-        print(f"{k[:70]:70s} launches={c:6d} avg_raw={s/c:14.2f}  -> x1024 B = {s/c*1024/1e6:10.3f} MB/launch")
+    return acc
+
+
+res = {}
+for label, ftag, wtag in (("bench", "pmc_fetch", "pmc_write"), ("calibration", "cal_fetch", "cal_write")):
+    f, w = pmc(ftag, "FETCH_SIZE"), pmc(wtag, "WRITE_SIZE")
+    print(f"== PMC per launch ({label}); FETCH_SIZE / WRITE_SIZE are in KiB; corrected fetch = raw x2 (gfx950, MI355X_MICROARCH.md HBM section)")
+    for key in sorted(set(f) | set(w), key=str):
+        name, gsz = key
+        fr = f[key][0] / f[key][1] if key in f and f[key][1] else float("nan")
+        wr = w[key][0] / w[key][1] if key in w and w[key][1] else float("nan")
+        print(f"  {short(name):52s} grid={gsz:9d} launches={f[key][1] if key in f else 0:5d}  fetch_raw={fr*1024/1e6:9.3f} MB  fetch_x2={2*fr*1024/1e6:9.3f} MB  write={wr*1024/1e6:9.3f} MB"
+              f"   per-thread: fetch_x2={2*fr*1024/max(gsz,1):7.2f} B write={wr*1024/max(gsz,1):7.2f} B")
+        res[f"{label}:{short(name)}:{gsz}"] = {"fetch_raw_B": fr * 1024, "fetch_x2_B": 2 * fr * 1024, "write_B": wr * 1024, "threads": gsz}
+json.dump(res, open(os.path.join(out, "pmc.json"), "w"), indent=1)
