@@ -77,8 +77,8 @@ def cpu_baseline(n, action_range, budget_s=10.0):
     try:
         from oracle import c_oracle as CO
         threads = max(1, min(os.cpu_count() or 1, 64))
-        CO.time_rollout(n, 4, threads, action_range)          # warm-up (page faults, thread pool)
-        tk = 60
+        dt1 = CO.time_rollout(n, 32, threads, action_range)   # warm-up (page faults, thread pool) + rate estimate
+        tk = int(min(max(32, 4.0 / max(dt1 / 32, 1e-6)), 20000))   # about 4 s of work
         dtc = CO.time_rollout(n, tk, threads, action_range)
         out["c_port_openmp"] = {"value": n * tk / dtc, "unit": "env-steps/s", "cores": threads,
                                 "sample": f"{tk} ticks of {n} envs, oracle/q1_oracle.c, {threads} OpenMP threads, {dtc:.2f} s"}

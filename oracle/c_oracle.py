@@ -93,21 +93,23 @@ class COracleVectorEnv(O.OracleVectorEnv):
         return obs, rew, done.astype(bool), self.zero_start.copy()
 
 
-def time_rollout(n, ticks, threads, action_range, seed=0):
-    """Throughput leg for bench.py: `ticks` ticks of n zero-start envs inside C (no Python per tick)."""
+def time_rollout(n, ticks, threads, action_range, seed=0, period=32):
+    """Throughput leg for bench.py: `ticks` ticks of n zero-start envs inside C (no Python per tick); the action
+    tensor holds `period` ticks and is cycled."""
     import time
     np.random.seed(seed)
     env = COracleVectorEnv(O.OracleConfig.get_default(num_envs=n, zero_start_prob=1.0), threads=threads)
     env._bind()
     rng = np.random.default_rng(seed)
-    a = np.concatenate([(rng.random((ticks, n, 4)) < 0.5).astype(np.float64),
-                        rng.uniform(-action_range, action_range, (ticks, n, 1)).astype(np.float32).astype(np.float64)], axis=2)
+    period = min(period, ticks)
+    a = np.concatenate([(rng.random((period, n, 4)) < 0.5).astype(np.float64),
+                        rng.uniform(-action_range, action_range, (period, n, 1)).astype(np.float32).astype(np.float64)], axis=2)
     a = np.ascontiguousarray(a)
     s = env._c_state()
     obs = np.empty((n, 6), np.float64)
     rew = np.empty((n,), np.float32)
     done = np.empty((n,), np.uint8)
     t0 = time.perf_counter()
-    env.lib.q1o_rollout(C.byref(env.p), C.byref(s), C.c_int64(n), C.c_int(ticks), a.ctypes.data_as(C.c_void_p),
+    env.lib.q1o_rollout(C.byref(env.p), C.byref(s), C.c_int64(n), C.c_int(ticks), C.c_int(period), a.ctypes.data_as(C.c_void_p),
                         obs.ctypes.data_as(C.c_void_p), rew.ctypes.data_as(C.c_void_p), done.ctypes.data_as(C.c_void_p), C.c_int(threads))
     return time.perf_counter() - t0
