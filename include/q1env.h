@@ -182,6 +182,16 @@ int q1phys_apply_host(int device, int64_t n, const double* yaw, const double* pi
                       const double* z_pos, const float* vel, const uint8_t* on_ground, const uint8_t* jump_released,
                       double* out_z_pos, float* out_vel, uint8_t* out_on_ground, uint8_t* out_jump_released);
 
+/* ---- policy-side glue for a GPU-resident sampler loop ------------------------------------------
+ * Counterpart of the reference's TF action distribution `Q1PhysActionDist` (q1physrl/action_dist.py:46-243):
+ * one row of policy-network outputs per env -> a sampled action in the PACKED layout q1env_step consumes, plus
+ * its log-probability.  logits: float[N][row_stride] device, row = num_keys x (logit0, logit1) then (mean, log_std)
+ * of the CDF-squashed Gaussian over (-action_range, action_range).  keys uint8[N], mouse float[N], logp float[N]
+ * (logp may be NULL).  deterministic != 0: arg-max keys and the squashed mean (action_dist.py:84-89).
+ * Randomness: Philox keyed by (seed, global env index, counter). Asynchronous on the handle's stream. */
+int q1env_policy_sample(q1env_t* env, const float* logits_dev, int row_stride, uint64_t seed, uint64_t counter,
+                        int deterministic, uint8_t* keys_dev, float* mouse_dev, float* logp_dev);
+
 /* ---- measurement ------------------------------------------------------------------------------
  * calibrate_traffic: `launches` launches of a pure copy kernel that reads the SoA state with step's own
  * load pattern and writes it to scratch: exactly 85 B read + 85 B written per env, for calibrating the

@@ -216,6 +216,71 @@ decoder_reset_kernel(Params p, StatePtrs s, int count, const int32_t* idx, const
     s.yaw[i] = yaw[j];                                                            // env.py:281 / 291
 }
 
+// Policy-side glue of the sampler loop (counterpart of reference q1physrl/action_dist.py:46-243, the TF
+// `Q1PhysActionDist`): turn one row of policy-network outputs into a sampled action, already in the packed layout
+// step_kernel consumes, plus its log-probability - one launch instead of ~20 elementwise torch ops per tick.
+// Row layout (action_dist.py:207-226 + RLlib's MultiActionDistribution): num_keys x [logit0, logit1] (Discrete(2)
+// categorical per key), then [mean, log_std] of the mouse Gaussian.  float32 arithmetic like the TF original.
+//   key k:   P(1) = softmax(logits)[1];  logp = log softmax[chosen]
+//   mouse:   mean clipped to +-3, log_std to [-20, 2] (action_dist.py:68-72); u = mean + std*eps;
+//            x = clip(NormalCDF(u / S), 1e-6, 1 - 1e-6) * (high - low) + low,  S = 0.5 * 1.8137  (action_dist.py:151,186-192)
+//            logp = N(mean,std).logpdf(u') - N(0,S).logpdf(u') - log(high - low), u' = S * ndtri((x - low)/(high - low))
+//            (action_dist.py:91-96,180-184,194-196)
+// Randomness: Philox stream 3 keyed by (seed, global env, counter): r[0] low bits -> one uniform per key, r[2],r[3] -> Box-Muller.
+constexpr uint32_t STREAM_POLICY = 3;
+
+__global__ void __launch_bounds__(256)
+policy_sample_kernel(Params p, const float* __restrict__ logits, int row_stride, uint64_t seed, uint64_t counter,
+                     int deterministic, uint8_t* keys_out, float* mouse_out, float* logp_out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (uint32_t)p.n) return;
+    const float* row = logits + (size_t)i * row_stride;
+    uint32_t r[4], r2[4];
+    philox_draw(seed, (uint64_t)p.env_index_base + i, counter, STREAM_POLICY, 0, r);
+    philox_draw(seed, (uint64_t)p.env_index_base + i, counter, STREAM_POLICY, 1, r2);
+    float logp = 0.0f;
+    uint32_t keys = 0;
+    const uint32_t ku[4] = {r[0], r[1], r2[0], r2[1]};
+    for (int k = 0; k < p.num_keys; ++k) {
+        const float l0 = row[2 * k], l1 = row[2 * k + 1];
+        const float d = l1 - l0;                                  // P(1) = sigmoid(d)
+        const float p1 = 1.0f / (1.0f + expf(-d));
+        const float u = (float)(ku[k] >> 8) * (1.0f / 16777216.0f);
+        const uint32_t bit = deterministic ? (d > 0.0f) : (u < p1);   // deterministic: argmax (RLlib Categorical)
+        keys |= bit << k;
+        const float z = bit ? -d : d;                             // log softmax[chosen] = -softplus(l_other - l_chosen)
+        logp -= (z > 0.0f ? z : 0.0f) + log1pf(expf(-fabsf(z)));
+    }
+    float mouse = 0.0f;
+    if (p.yaw_mode == 1) {
+        const float S = 0.5f * 1.8137f;
+        const float low = -p.action_range_f32, high = p.action_range_f32;
+        float mean = row[2 * p.num_keys], log_std = row[2 * p.num_keys + 1];
+        mean = fminf(fmaxf(mean, -3.0f), 3.0f);
+        log_std = fminf(fmaxf(log_std, -20.0f), 2.0f);
+        const float std = expf(log_std);
+        float eps = 0.0f;
+        if (!deterministic) {
+            const float u1 = ((float)(r[2] >> 8) + 1.0f) * (1.0f / 16777216.0f);      // (0, 1]
+            const float u2 = (float)(r[3] >> 8) * (1.0f / 16777216.0f);
+            eps = sqrtf(-2.0f * logf(u1)) * cosf(6.2831853071795865f * u2);
+        }
+        const float un = mean + std * eps;
+        float c = normcdff(un / S);
+        c = fminf(fmaxf(c, 1e-6f), 1.0f - 1e-6f);
+        mouse = c * (high - low) + low;
+        const float ub = S * normcdfinvf((mouse - low) / (high - low));
+        const float zs = (ub - mean) / std;
+        const float lp_pi = -0.5f * zs * zs - log_std - 0.9189385332046727f;            // N(mean, std).logpdf(ub)
+        const float zq = ub / S;
+        const float lp_sq = -0.5f * zq * zq - logf(S) - 0.9189385332046727f;            // N(0, S).logpdf(ub)
+        logp += lp_pi - (lp_sq + logf(high - low));
+    }
+    keys_out[i] = (uint8_t)keys;
+    if (mouse_out) mouse_out[i] = mouse;
+    if (logp_out) logp_out[i] = logp;
+}
+
 // Traffic calibration for the PMC counters (MI355X_MICROARCH.md "HBM": FETCH_SIZE / WRITE_SIZE must be calibrated on
 // a known byte count in the kernel's own access pattern): reads every SoA state array with exactly the loads
 // step_kernel uses and writes the same bytes to a scratch arena: 85 B read + 85 B written per env, no arithmetic.
@@ -874,6 +939,20 @@ int q1phys_apply_host(int device, int64_t n64, const double* yaw, const double* 
     }
     (void)hipFree(d);
     return rc;
+}
+
+int q1env_policy_sample(q1env_t* h, const float* logits, int row_stride, uint64_t seed, uint64_t counter, int deterministic,
+                        uint8_t* keys, float* mouse, float* logp) {
+    if (!h || !logits || !keys) return fail(Q1ENV_ERR_INVALID_ARG, "q1env_policy_sample: null argument");
+    const int need = 2 * h->p.num_keys + (h->p.yaw_mode == 1 ? 2 : 0);
+    if (h->p.yaw_mode == 2) return fail(Q1ENV_ERR_INVALID_ARG, "q1env_policy_sample: discrete yaw is not supported (continuous mouse or no mouse)");
+    if (row_stride < need) return fail(Q1ENV_ERR_INVALID_ARG, "q1env_policy_sample: row_stride smaller than 2*num_keys + 2");
+    if (h->p.yaw_mode == 1 && !mouse) return fail(Q1ENV_ERR_INVALID_ARG, "q1env_policy_sample: mouse output required");
+    const int blk = block_for(h->p.n);
+    hipLaunchKernelGGL(policy_sample_kernel, grid_for(h->p.n, blk), dim3(blk), 0, h->stream, h->p, logits, row_stride, seed, counter,
+                       deterministic, keys, mouse, logp);
+    HIP_TRY(hipGetLastError());
+    return Q1ENV_OK;
 }
 
 int q1env_selftest_division(int device, uint64_t n, uint64_t seed, double c0, double c1, uint64_t* mismatches4) {

@@ -157,6 +157,10 @@ class DeviceEnv:
     def reset_philox_dev(self, seed, mask=0, done_only=False, obs_format=_lib.OBS_F32, obs=0):
         _lib.check(self._lib.q1env_reset_philox(self._h, seed, mask or None, int(done_only), obs_format, obs or None))
 
+    def policy_sample_dev(self, logits, row_stride, seed, counter, keys, mouse, logp=0, deterministic=False):
+        _lib.check(self._lib.q1env_policy_sample(self._h, logits, int(row_stride), int(seed), int(counter), int(deterministic),
+                                                 keys, mouse or None, logp or None))
+
     def observe_dev(self, obs, obs_format=_lib.OBS_F32):
         _lib.check(self._lib.q1env_observe(self._h, obs_format, obs))
 

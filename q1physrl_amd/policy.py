@@ -1,0 +1,153 @@
+"""Policy-side counterpart of the env fast path ("next" row 1 of SURVEY.md section 8f).
+
+Torch restatement of the reference's TF action distribution (q1physrl/action_dist.py):
+  GaussianSquashedGaussian   action_dist.py:141-196 (base class 46-138): a diagonal Gaussian squashed through
+                             a Normal CDF into (low, high), with closed-form kl / entropy
+  Q1PhysActionDist           action_dist.py:199-243: a Discrete(2) categorical per key + the squashed Gaussian for the mouse
+and the network shape of the published WR checkpoint (data/checkpoints/wr: policy 6->256->256->10, separate value
+net 6->256->256->1, tanh).  torch here is the learner-side library (GEMMs via hipBLASLt);
+the per-tick sampling itself has a fused HIP kernel (q1env_policy_sample, used by q1physrl_amd.sampler).
+
+RLlib 0.8.4 constants (ray/rllib/utils): SMALL_NUMBER = 1e-6, MIN_LOG_NN_OUTPUT = -20, MAX_LOG_NN_OUTPUT = 2.
+"""
+import math
+
+import torch
+from torch import nn
+
+SMALL_NUMBER = 1e-6
+MIN_LOG_NN_OUTPUT = -20.0
+MAX_LOG_NN_OUTPUT = 2.0
+_HALF_LOG_2PI = 0.5 * math.log(2.0 * math.pi)
+
+
+def _normal_logpdf(x, mean, log_std):
+    z = (x - mean) * torch.exp(-log_std)
+    return -0.5 * z * z - log_std - _HALF_LOG_2PI
+
+
+class GaussianSquashedGaussian:
+    """Normal(mean, std) pushed through NormalCDF(. / _SCALE) and an affine map onto (low, high)."""
+    _SCALE = 0.5 * 1.8137            # action_dist.py:151: Var(N(0, 2*_SCALE)) = Var(Logistic(0, 1))
+
+    def __init__(self, inputs: torch.Tensor, low=-1.0, high=1.0):
+        mean, log_std = torch.chunk(inputs, 2, dim=-1)                       # action_dist.py:65
+        self.log_std = torch.clamp(log_std, MIN_LOG_NN_OUTPUT, MAX_LOG_NN_OUTPUT)   # :69-70
+        self.mean = torch.clamp(mean, -3.0, 3.0)                              # :72
+        self.std = torch.exp(self.log_std)
+        assert low < high
+        self.low, self.high = float(low), float(high)
+
+    # -- squash / unsquash (action_dist.py:186-196)
+    def _squash(self, raw):
+        v = torch.special.ndtr(raw / self._SCALE)
+        return torch.clamp(v, SMALL_NUMBER, 1.0 - SMALL_NUMBER) * (self.high - self.low) + self.low
+
+    def _unsquash(self, values):
+        return self._SCALE * torch.special.ndtri((values - self.low) / (self.high - self.low))
+
+    def _log_squash_grad(self, raw):                                          # :180-184
+        return _normal_logpdf(raw, torch.zeros_like(raw), torch.full_like(raw, math.log(self._SCALE))) + math.log(self.high - self.low)
+
+    def sample(self, generator=None):                                         # :98-101
+        eps = torch.randn(self.mean.shape, dtype=self.mean.dtype, device=self.mean.device, generator=generator)
+        return self._squash(self.mean + self.std * eps)
+
+    def deterministic_sample(self):                                           # :84-89
+        return self._squash(self.mean)
+
+    def logp(self, x):                                                        # :91-96
+        raw = self._unsquash(x)
+        return torch.sum(_normal_logpdf(raw, self.mean, self.log_std) - self._log_squash_grad(raw), dim=1)
+
+    def kl(self, other):                                                      # :153-165
+        return torch.sum(other.log_std - self.log_std
+                         + (self.std ** 2 + (self.mean - other.mean) ** 2) / (2.0 * other.std ** 2) - 0.5, dim=1)
+
+    def entropy(self):                                                        # :167-178
+        return torch.sum(math.log(self.high - self.low)
+                         - (math.log(self._SCALE) - self.log_std
+                            + (self.std ** 2 + self.mean ** 2) / (2.0 * self._SCALE ** 2) - 0.5), dim=1)
+
+
+class Categorical2:
+    """RLlib's TF Categorical on a Discrete(2) space: logits (B, 2)."""
+
+    def __init__(self, logits):
+        self.logits = logits
+        self.logprobs = torch.log_softmax(logits, dim=-1)
+
+    def sample(self, generator=None):
+        u = torch.rand(self.logits.shape[0], device=self.logits.device, generator=generator)
+        return (u < torch.exp(self.logprobs[:, 1])).long()
+
+    def deterministic_sample(self):
+        return torch.argmax(self.logits, dim=-1)
+
+    def logp(self, a):
+        return torch.gather(self.logprobs, 1, a.long().view(-1, 1)).squeeze(1)
+
+    def entropy(self):
+        return -torch.sum(torch.exp(self.logprobs) * self.logprobs, dim=1)
+
+    def kl(self, other):
+        return torch.sum(torch.exp(self.logprobs) * (self.logprobs - other.logprobs), dim=1)
+
+
+class Q1PhysActionDist:
+    """Tuple distribution over (key_0 .. key_{K-1}, mouse) (action_dist.py:199-243).
+
+    inputs: (B, 2K + 2) = K x (logit0, logit1), then (mean, log_std).  Actions are (keys (B,K) int64, mouse (B,1) float)."""
+
+    def __init__(self, inputs, action_range, num_keys=4):
+        self.num_keys = num_keys
+        self.keys = [Categorical2(inputs[:, 2 * k:2 * k + 2]) for k in range(num_keys)]
+        self.mouse = GaussianSquashedGaussian(inputs[:, 2 * num_keys:2 * num_keys + 2], low=-float(action_range), high=float(action_range))
+
+    @staticmethod
+    def required_model_output_shape(num_keys=4):                              # :236-241
+        return 2 * num_keys + 2
+
+    def sample(self, generator=None):
+        return torch.stack([c.sample(generator) for c in self.keys], dim=1), self.mouse.sample(generator)
+
+    def deterministic_sample(self):
+        return torch.stack([c.deterministic_sample() for c in self.keys], dim=1), self.mouse.deterministic_sample()
+
+    def logp(self, keys, mouse):
+        lp = self.mouse.logp(mouse)
+        for k, c in enumerate(self.keys):
+            lp = lp + c.logp(keys[:, k])
+        return lp
+
+    def entropy(self):
+        return sum(c.entropy() for c in self.keys) + self.mouse.entropy()
+
+    def kl(self, other):
+        return sum(a.kl(b) for a, b in zip(self.keys, other.keys)) + self.mouse.kl(other.mouse)
+
+
+def pack_keys(keys: torch.Tensor) -> torch.Tensor:
+    """(B, K) 0/1 -> uint8 bitmask (bit k = Key k), the packed action layout of q1env_step."""
+    w = (1 << torch.arange(keys.shape[1], device=keys.device, dtype=torch.int64))
+    return (keys.long() * w).sum(dim=1).to(torch.uint8)
+
+
+class Q1Policy(nn.Module):
+    """RLlib fcnet as used by the reference run (params.yml + PPO defaults): tanh MLP 6 -> 256 -> 256 -> 2K+2 and a
+    separate value MLP 6 -> 256 -> 256 -> 1 (the WR checkpoint has 70 154 + 67 841 = 137 995 parameters)."""
+
+    def __init__(self, num_keys=4, hidden=256, obs_dim=6):
+        super().__init__()
+        out = Q1PhysActionDist.required_model_output_shape(num_keys)
+        self.pi = nn.Sequential(nn.Linear(obs_dim, hidden), nn.Tanh(), nn.Linear(hidden, hidden), nn.Tanh(), nn.Linear(hidden, out))
+        self.vf = nn.Sequential(nn.Linear(obs_dim, hidden), nn.Tanh(), nn.Linear(hidden, hidden), nn.Tanh(), nn.Linear(hidden, 1))
+        with torch.no_grad():                      # RLlib: normc_initializer(0.01) on the logits layer -> near-uniform start
+            self.pi[-1].weight.mul_(0.01)
+            self.pi[-1].bias.zero_()
+
+    def forward(self, obs):
+        return self.pi(obs), self.vf(obs).squeeze(-1)
+
+    def num_parameters(self):
+        return sum(p.numel() for p in self.parameters())

@@ -1,0 +1,83 @@
+"""CPU: the torch restatement of the reference's action distribution (q1physrl_amd/policy.py) against the
+NumPy/SciPy oracle (oracle/dist_oracle.py) and against first principles.  float64 tensors: tolerance 1e-9."""
+import warnings
+
+import numpy as np
+import pytest
+import torch
+from scipy import integrate
+
+from oracle import dist_oracle as DO
+from q1physrl_amd import policy as P
+
+LOW, HIGH = -10.08, 10.08
+
+
+def rand_inputs(rng, b):
+    x = rng.normal(0, 1.5, (b, 10))
+    x[:, 8] = rng.uniform(-4, 4, b)        # mean, partly outside the +-3 clip
+    x[:, 9] = rng.uniform(-3, 2.5, b)      # log_std, partly above the clip at 2
+    return x
+
+
+def test_mouse_logp_entropy_kl_match_oracle():
+    rng = np.random.default_rng(0)
+    x = rand_inputs(rng, 500)
+    d = P.GaussianSquashedGaussian(torch.from_numpy(x[:, 8:10]), LOW, HIGH)
+    a = rng.uniform(LOW * 0.999, HIGH * 0.999, (500, 1))
+    assert np.allclose(d.logp(torch.from_numpy(a)).numpy(), DO.mouse_logp(a[:, 0], x[:, 8], x[:, 9], LOW, HIGH), rtol=1e-9, atol=1e-9)
+    assert np.allclose(d.entropy().numpy(), DO.mouse_entropy(x[:, 8], x[:, 9], LOW, HIGH), rtol=1e-12)
+    y = rand_inputs(rng, 500)
+    d2 = P.GaussianSquashedGaussian(torch.from_numpy(y[:, 8:10]), LOW, HIGH)
+    assert np.allclose(d.kl(d2).numpy(), DO.mouse_kl(x[:, 8], x[:, 9], y[:, 8], y[:, 9]), rtol=1e-12)
+    assert np.all(d.kl(d).numpy() == 0)
+
+
+def test_mouse_density_integrates_to_one_and_entropy_is_consistent():
+    for mean, log_std in ((0.0, 0.0), (1.2, -1.0), (-1.0, -0.3)):      # mass beyond the 1e-6 clip is negligible here
+        inp = torch.tensor([[mean, log_std]], dtype=torch.float64)
+        d = P.GaussianSquashedGaussian(inp, LOW, HIGH)
+        f = lambda a: float(torch.exp(d.logp(torch.tensor([[a]], dtype=torch.float64))))   # noqa: E731
+        warnings.simplefilter("ignore")
+        total, _ = integrate.quad(f, LOW, HIGH, limit=400, points=[0.0])
+        assert abs(total - 1.0) < 1e-4
+        h, _ = integrate.quad(lambda a: -f(a) * np.log(max(f(a), 1e-300)), LOW, HIGH, limit=400, points=[0.0])
+        assert abs(h - float(d.entropy())) < 1e-3          # closed form (action_dist.py:167-178) = differential entropy
+
+
+def test_squash_roundtrip_and_bounds():
+    d = P.GaussianSquashedGaussian(torch.zeros((1, 2), dtype=torch.float64), LOW, HIGH)
+    raw = torch.linspace(-3, 3, 101, dtype=torch.float64).view(-1, 1)
+    assert torch.allclose(d._unsquash(d._squash(raw)), raw, atol=1e-9)
+    big = d._squash(torch.tensor([[50.0], [-50.0]], dtype=torch.float64))
+    assert LOW < float(big[1]) < float(big[0]) < HIGH        # never exactly low / high (SMALL_NUMBER clip)
+    g = torch.Generator().manual_seed(0)
+    dd = P.GaussianSquashedGaussian(torch.tensor([[0.5, 0.3]], dtype=torch.float64).repeat(20000, 1), LOW, HIGH)
+    s = dd.sample(g)
+    assert s.shape == (20000, 1) and float(s.min()) > LOW and float(s.max()) < HIGH
+    mc_entropy = float(-dd.logp(s).mean())
+    assert abs(mc_entropy - float(dd.entropy()[0])) < 0.03
+
+
+def test_tuple_distribution_matches_oracle_and_policy_shapes():
+    rng = np.random.default_rng(3)
+    x = rand_inputs(rng, 64)
+    dist = P.Q1PhysActionDist(torch.from_numpy(x), 10.08, num_keys=4)
+    keys = torch.from_numpy(rng.integers(0, 2, (64, 4)))
+    mouse = torch.from_numpy(rng.uniform(-10, 10, (64, 1)))
+    want = DO.mouse_logp(mouse[:, 0].numpy(), x[:, 8], x[:, 9], -10.08, 10.08)
+    for k in range(4):
+        lp0, lp1 = DO.key_logprobs(x[:, 2 * k], x[:, 2 * k + 1])
+        want = want + np.where(keys[:, k].numpy() == 1, lp1, lp0)
+    assert np.allclose(dist.logp(keys, mouse).numpy(), want, rtol=1e-9, atol=1e-9)
+    ent = dist.entropy().numpy()
+    assert ent.shape == (64,) and np.all(np.isfinite(ent))
+    assert np.allclose(dist.kl(dist).numpy(), 0, atol=1e-12)
+    k, m = dist.sample(torch.Generator().manual_seed(1))
+    assert k.shape == (64, 4) and m.shape == (64, 1) and set(np.unique(k.numpy())) <= {0, 1}
+    assert P.pack_keys(torch.tensor([[1, 0, 1, 1], [0, 0, 0, 0], [1, 1, 1, 1]])).tolist() == [13, 0, 15]
+    net = P.Q1Policy()
+    assert net.num_parameters() == 137995                     # the WR checkpoint's parameter count
+    logits, value = net(torch.zeros(5, 6))
+    assert logits.shape == (5, 10) and value.shape == (5,)
+    assert P.Q1PhysActionDist.required_model_output_shape(4) == 10
