@@ -192,6 +192,11 @@ int q1phys_apply_host(int device, int64_t n, const double* yaw, const double* pi
 int q1env_policy_sample(q1env_t* env, const float* logits_dev, int row_stride, uint64_t seed, uint64_t counter,
                         int deterministic, uint8_t* keys_dev, float* mouse_dev, float* logp_dev);
 
+/* Generalised advantage estimation over tick-major device arrays of this handle's N envs (learner-side glue):
+ * reward float[T][N], value float[T+1][N] (bootstrap row last), done uint8[T][N] -> adv, vtarg float[T][N]. */
+int q1env_gae(q1env_t* env, int ticks, const float* reward_dev, const float* value_dev, const uint8_t* done_dev,
+              float gamma, float lam, float* adv_dev, float* vtarg_dev);
+
 /* ---- measurement ------------------------------------------------------------------------------
  * calibrate_traffic: `launches` launches of a pure copy kernel that reads the SoA state with step's own
  * load pattern and writes it to scratch: exactly 85 B read + 85 B written per env, for calibrating the

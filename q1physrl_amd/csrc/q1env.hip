@@ -281,6 +281,30 @@ policy_sample_kernel(Params p, const float* __restrict__ logits, int row_stride,
     if (logp_out) logp_out[i] = logp;
 }
 
+// Generalised advantage estimation over a tick-major trajectory (learner-side glue; RLlib's
+// compute_advantages with use_gae, lambda/gamma of reference data/params.yml:4-7).  One lane per env walks its T ticks
+// backwards; every access of a wave is a contiguous 256-B segment of the [T][N] arrays.
+//   delta_t = r_t + gamma * V_{t+1} * (1 - done_t) - V_t ;  A_t = delta_t + gamma * lambda * (1 - done_t) * A_{t+1}
+//   value has T+1 rows (bootstrap row last); vtarg_t = A_t + V_t.
+__global__ void __launch_bounds__(256)
+gae_kernel(int n, int ticks, const float* __restrict__ reward, const float* __restrict__ value,
+           const uint8_t* __restrict__ done, float gamma, float lam, float* __restrict__ adv, float* __restrict__ vtarg) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (uint32_t)n) return;
+    float a = 0.0f;
+    float v_next = value[(size_t)ticks * n + i];
+    for (int t = ticks - 1; t >= 0; --t) {
+        const size_t o = (size_t)t * n + i;
+        const float nd = done[o] ? 0.0f : 1.0f;
+        const float v = value[o];
+        const float delta = reward[o] + gamma * v_next * nd - v;
+        a = delta + gamma * lam * nd * a;
+        adv[o] = a;
+        vtarg[o] = a + v;
+        v_next = v;
+    }
+}
+
 // Traffic calibration for the PMC counters (MI355X_MICROARCH.md "HBM": FETCH_SIZE / WRITE_SIZE must be calibrated on
 // a known byte count in the kernel's own access pattern): reads every SoA state array with exactly the loads
 // step_kernel uses and writes the same bytes to a scratch arena: 85 B read + 85 B written per env, no arithmetic.
@@ -951,6 +975,14 @@ int q1env_policy_sample(q1env_t* h, const float* logits, int row_stride, uint64_
     const int blk = block_for(h->p.n);
     hipLaunchKernelGGL(policy_sample_kernel, grid_for(h->p.n, blk), dim3(blk), 0, h->stream, h->p, logits, row_stride, seed, counter,
                        deterministic, keys, mouse, logp);
+    HIP_TRY(hipGetLastError());
+    return Q1ENV_OK;
+}
+
+int q1env_gae(q1env_t* h, int ticks, const float* reward, const float* value, const uint8_t* done, float gamma, float lam,
+              float* adv, float* vtarg) {
+    if (!h || !reward || !value || !done || !adv || !vtarg || ticks <= 0) return fail(Q1ENV_ERR_INVALID_ARG, "q1env_gae: bad argument");
+    hipLaunchKernelGGL(gae_kernel, grid_for(h->p.n, 256), dim3(256), 0, h->stream, h->p.n, ticks, reward, value, done, gamma, lam, adv, vtarg);
     HIP_TRY(hipGetLastError());
     return Q1ENV_OK;
 }

@@ -161,6 +161,9 @@ class DeviceEnv:
         _lib.check(self._lib.q1env_policy_sample(self._h, logits, int(row_stride), int(seed), int(counter), int(deterministic),
                                                  keys, mouse or None, logp or None))
 
+    def gae_dev(self, ticks, reward, value, done, gamma, lam, adv, vtarg):
+        _lib.check(self._lib.q1env_gae(self._h, int(ticks), reward, value, done, float(gamma), float(lam), adv, vtarg))
+
     def observe_dev(self, obs, obs_format=_lib.OBS_F32):
         _lib.check(self._lib.q1env_observe(self._h, obs_format, obs))
 

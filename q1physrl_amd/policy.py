@@ -151,3 +151,19 @@ class Q1Policy(nn.Module):
 
     def num_parameters(self):
         return sum(p.numel() for p in self.parameters())
+
+
+def load_rllib_fcnet_weights(policy: Q1Policy, weights) -> Q1Policy:
+    """Load an RLlib 0.8.4 TF fcnet state (as exported by oracle/export_wr_weights.py from the reference's
+    data/checkpoints/wr: fc_1, fc_2, fc_out, fc_value_1, fc_value_2, value_out; TF kernels are (in, out)) into a Q1Policy."""
+    import numpy as np
+    pairs = [(policy.pi[0], "fc_1"), (policy.pi[2], "fc_2"), (policy.pi[4], "fc_out"),
+             (policy.vf[0], "fc_value_1"), (policy.vf[2], "fc_value_2"), (policy.vf[4], "value_out")]
+    with torch.no_grad():
+        for layer, name in pairs:
+            w = torch.from_numpy(np.ascontiguousarray(np.asarray(weights[name + ".kernel"], dtype=np.float32).T))
+            b = torch.from_numpy(np.asarray(weights[name + ".bias"], dtype=np.float32))
+            assert layer.weight.shape == w.shape and layer.bias.shape == b.shape, (name, layer.weight.shape, w.shape)
+            layer.weight.copy_(w)
+            layer.bias.copy_(b)
+    return policy

@@ -1,0 +1,122 @@
+"""PPO learner for the GPU-resident sampler ("next" row 3 of SURVEY.md section 8f): the counterpart of the RLlib
+PPOTrainer the reference configures in q1physrl/train.py:60-64 with data/params.yml:4-13 (gamma 0.99, lambda 0.95,
+kl_target 0.0036, entropy_coeff 0.01, vf_clip_param 100; RLlib 0.8.4 PPO defaults: clip_param 0.3, kl_coeff 0.2
+adaptive, vf_loss_coeff 1.0, advantages standardised per train batch).
+
+Loss (RLlib ppo_tf_policy.PPOLoss restated for torch):
+    ratio      = exp(logp_new - logp_old)
+    surrogate  = min(adv * ratio, adv * clip(ratio, 1 - clip, 1 + clip))
+    vf_loss    = max((v - vtarg)^2, (v_old + clip(v - v_old, +-vf_clip) - vtarg)^2)
+    total      = mean(-surrogate + kl_coeff * KL(old || new) + vf_loss_coeff * vf_loss - entropy_coeff * entropy)
+Multi-GPU: every rank samples its own env shard; the only collective of the whole system is the gradient
+all-reduce of the 138 k-parameter policy (one 552 KB flat bucket per SGD step; RCCL when the backend is nccl).
+"""
+import math
+
+import torch
+import torch.distributed as dist
+
+from .policy import Q1PhysActionDist
+
+
+def ppo_loss(policy, batch, action_range, clip_param, vf_clip_param, vf_loss_coeff, entropy_coeff, kl_coeff, num_keys=4):
+    logits, value = policy(batch["obs"])
+    new = Q1PhysActionDist(logits, action_range, num_keys)
+    old = Q1PhysActionDist(batch["old_logits"], action_range, num_keys)
+    logp = new.logp(batch["keys"], batch["mouse"])
+    ratio = torch.exp(logp - batch["logp"])
+    adv = batch["adv"]
+    surrogate = torch.minimum(adv * ratio, adv * torch.clamp(ratio, 1.0 - clip_param, 1.0 + clip_param))
+    v_clipped = batch["value"] + torch.clamp(value - batch["value"], -vf_clip_param, vf_clip_param)
+    vf_loss = torch.maximum((value - batch["vtarg"]) ** 2, (v_clipped - batch["vtarg"]) ** 2)
+    kl = old.kl(new)
+    entropy = new.entropy()
+    total = torch.mean(-surrogate + kl_coeff * kl + vf_loss_coeff * vf_loss - entropy_coeff * entropy)
+    stats = {"total_loss": total.detach(), "policy_loss": -surrogate.mean().detach(), "vf_loss": vf_loss.mean().detach(),
+             "kl": kl.mean().detach(), "entropy": entropy.mean().detach()}
+    return total, stats
+
+
+def allreduce_grads_(params, world):
+    """Average gradients over ranks with ONE collective on a flat bucket."""
+    grads = [p.grad for p in params if p.grad is not None]
+    flat = torch.cat([g.reshape(-1) for g in grads])
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+    flat /= world
+    off = 0
+    for g in grads:
+        g.copy_(flat[off:off + g.numel()].view_as(g))
+        off += g.numel()
+
+
+class PPOLearner:
+    def __init__(self, policy, action_range, lr=5e-6, gamma=0.99, lam=0.95, clip_param=0.3, vf_clip_param=100.0,
+                 vf_loss_coeff=1.0, entropy_coeff=0.01, kl_coeff=0.2, kl_target=0.0036, num_sgd_iter=30,
+                 minibatch_size=128, num_keys=4, seed=0):
+        self.policy = policy
+        self.action_range = float(action_range)
+        self.gamma, self.lam = gamma, lam
+        self.clip_param, self.vf_clip_param = clip_param, vf_clip_param
+        self.vf_loss_coeff, self.entropy_coeff = vf_loss_coeff, entropy_coeff
+        self.kl_coeff, self.kl_target = kl_coeff, kl_target
+        self.num_sgd_iter, self.minibatch_size, self.num_keys = num_sgd_iter, minibatch_size, num_keys
+        self.opt = torch.optim.Adam(policy.parameters(), lr=lr)
+        self.gen = None
+        self.seed = seed
+        self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+    def _flatten(self, traj, adv, vtarg, old_logits):
+        t, n = traj["reward"].shape
+        keys = ((traj["keys"].reshape(-1, 1).long() >> torch.arange(self.num_keys, device=adv.device)) & 1)
+        return {"obs": traj["obs"][:t].reshape(t * n, 6), "keys": keys, "mouse": traj["mouse"].reshape(-1, 1),
+                "logp": traj["logp"].reshape(-1), "value": traj["value"][:t].reshape(-1), "adv": adv.reshape(-1),
+                "vtarg": vtarg.reshape(-1), "old_logits": old_logits}
+
+    def update(self, traj, adv, vtarg):
+        """SGD epochs over one trajectory batch; adv/vtarg from q1env_gae.  Returns averaged stats (python floats)."""
+        dev = adv.device
+        t, n = traj["reward"].shape
+        with torch.no_grad():
+            old_logits, _ = self.policy(traj["obs"][:t].reshape(t * n, 6))
+        b = self._flatten(traj, adv, vtarg, old_logits)
+        a = b["adv"]
+        mean, sq = a.mean(), (a * a).mean()
+        if self.world > 1:                      # standardise over the GLOBAL batch
+            ms = torch.stack([mean, sq])
+            dist.all_reduce(ms, op=dist.ReduceOp.SUM)
+            mean, sq = ms[0] / self.world, ms[1] / self.world
+        b["adv"] = (a - mean) / torch.sqrt(torch.clamp(sq - mean * mean, min=1e-8))
+        total = t * n
+        mb = min(self.minibatch_size, total)
+        if self.gen is None:
+            self.gen = torch.Generator(device=dev).manual_seed(self.seed)
+        params = [p for p in self.policy.parameters()]
+        acc, steps = None, 0
+        for _ in range(self.num_sgd_iter):
+            perm = torch.randperm(total, device=dev, generator=self.gen)
+            for s in range(0, total - mb + 1, mb):
+                idx = perm[s:s + mb]
+                mbatch = {k: v[idx] for k, v in b.items()}
+                loss, st = ppo_loss(self.policy, mbatch, self.action_range, self.clip_param, self.vf_clip_param,
+                                    self.vf_loss_coeff, self.entropy_coeff, self.kl_coeff, self.num_keys)
+                self.opt.zero_grad(set_to_none=True)
+                loss.backward()
+                if self.world > 1:
+                    allreduce_grads_(params, self.world)
+                self.opt.step()
+                vals = torch.stack([st[k] for k in sorted(st)])
+                acc = vals if acc is None else acc + vals
+                steps += 1
+        acc = acc / steps
+        if self.world > 1:
+            dist.all_reduce(acc, op=dist.ReduceOp.SUM)
+            acc /= self.world
+        out = dict(zip(sorted(st), acc.tolist()))
+        # adaptive KL coefficient (RLlib KLCoeffMixin.update_kl)
+        if out["kl"] > 2.0 * self.kl_target:
+            self.kl_coeff *= 1.5
+        elif out["kl"] < 0.5 * self.kl_target:
+            self.kl_coeff *= 0.5
+        out["kl_coeff"] = self.kl_coeff
+        out["sgd_steps"] = steps
+        return out

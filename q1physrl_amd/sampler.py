@@ -78,3 +78,11 @@ class GpuSampler:
     def zero_start_total_reward_mean(self):
         z = self.stats["zero_start_episodes"]
         return self.stats["zero_start_return_sum"] / z if z else float("nan")
+
+    def advantages(self, traj, gamma, lam):
+        """GAE over the last collected trajectory on the device (q1env_gae): returns (adv, vtarg), each (T, N) float32."""
+        adv = torch.empty_like(traj["reward"])
+        vtarg = torch.empty_like(traj["reward"])
+        self.env._dev.gae_dev(self.T, traj["reward"].data_ptr(), traj["value"].data_ptr(), traj["done"].data_ptr(), gamma, lam,
+                              adv.data_ptr(), vtarg.data_ptr())
+        return adv, vtarg

@@ -77,3 +77,65 @@ def test_sampler_loop_end_to_end():
         o, r, d = env2.step_tensor((traj["keys"][t], traj["mouse"][t]))
         assert torch.equal(r, traj["reward"][t]) and torch.equal(d, traj["done"][t])
     env.close(); env2.close()
+
+
+def test_gae_kernel_matches_numpy():
+    import torch
+    from oracle import ppo_oracle as PO
+    from q1physrl_amd.sampler import GpuSampler
+    from q1physrl_amd import policy as P
+    cfg, env = make_env(3000, seed=2)
+    rng = np.random.default_rng(0)
+    t, n = 50, 3000
+    s = GpuSampler(env, P.Q1Policy().cuda(), horizon=t)
+    traj = {"reward": torch.from_numpy(rng.normal(0, 1, (t, n)).astype(np.float32)).cuda(),
+            "value": torch.from_numpy(rng.normal(0, 1, (t + 1, n)).astype(np.float32)).cuda(),
+            "done": torch.from_numpy((rng.random((t, n)) < 0.05).astype(np.uint8)).cuda()}
+    adv, vtarg = s.advantages(traj, 0.99, 0.95)
+    torch.cuda.synchronize()
+    a2, v2 = PO.gae(traj["reward"].cpu().numpy(), traj["value"].cpu().numpy(), traj["done"].cpu().numpy(), 0.99, 0.95)
+    assert np.allclose(adv.cpu().numpy(), a2, rtol=1e-5, atol=1e-5) and np.allclose(vtarg.cpu().numpy(), v2, rtol=1e-5, atol=1e-5)
+    env.close()
+
+
+def test_wr_policy_reproduces_published_reward_and_oracle_trajectory():
+    """Known answer from the reference's published artefacts: its world-record policy (weights fixture
+    tests/golden/wr_policy.npz, exported from data/checkpoints/wr by oracle/export_wr_weights.py) trained to
+    zero_start_total_reward_mean ~ 5700 (README.md:54, stochastic policy).  Played in the HIP env under the run's own
+    env_config it must score that, and the expert trajectory it produces (strafe-jumping, key rate-limiting in play)
+    must be bit-identical to the oracle driven with the same actions."""
+    import json
+    import os
+    import torch
+    from q1physrl_amd import policy as P
+    from q1physrl_amd.env import Config
+    from q1physrl_amd.sampler import GpuSampler
+    from q1physrl_amd.tensor_env import TensorVectorEnv
+    w = dict(np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "wr_policy.npz")))
+    ec = json.loads(str(w["env_config_json"]))
+    ec["initial_yaw_range"] = tuple(ec["initial_yaw_range"])
+    pol = P.load_rllib_fcnet_weights(P.Q1Policy(), w).cuda()
+    assert pol.num_parameters() == 137995
+    cfg = Config(**{**ec, "num_envs": 2048, "zero_start_prob": 1.0})
+    env = TensorVectorEnv(cfg, seed=7)
+    tr = GpuSampler(env, pol, horizon=720).collect()
+    total = tr["reward"].double().sum(0)
+    assert bool(tr["done"][-1].all()) and not bool(tr["done"][:-1].any())
+    assert 5600.0 < float(total.mean()) < 5800.0, float(total.mean())          # README: ~5700
+    # oracle replay of the first 32 envs' expert trajectories
+    k = 32
+    keys = tr["keys"][:, :k].cpu().numpy()
+    mouse = tr["mouse"][:, :k].cpu().numpy()
+    ocfg = O.OracleConfig(**{**ec, "num_envs": k, "zero_start_prob": 1.0})
+    np.random.seed(0)
+    ora = O.OracleVectorEnv(ocfg)
+    obs_gpu = tr["obs"][1:, :k].cpu().numpy()
+    rew_gpu = tr["reward"][:, :k].cpu().numpy()
+    for t in range(720):
+        a = np.concatenate([((keys[t][:, None] >> np.arange(4)[None, :]) & 1).astype(np.float64), mouse[t][:, None].astype(np.float64)], axis=1)
+        o, r, d, _ = ora.vector_step(a)
+        assert np.array_equal(r, rew_gpu[t]), t
+        if t < 719:                      # after the last tick the sampler's obs row is the post-reset observation
+            assert np.array_equal(o.astype(np.float32), obs_gpu[t]), t
+    assert float(np.sum(rew_gpu.astype(np.float64), axis=0).mean()) > 5600
+    env.close()

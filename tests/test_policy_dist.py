@@ -81,3 +81,29 @@ def test_tuple_distribution_matches_oracle_and_policy_shapes():
     logits, value = net(torch.zeros(5, 6))
     assert logits.shape == (5, 10) and value.shape == (5,)
     assert P.Q1PhysActionDist.required_model_output_shape(4) == 10
+
+
+def test_wr_policy_scores_published_reward_in_the_oracle_env():
+    """CPU known-answer for the ORACLE: the reference's published world-record policy (weights fixture exported from
+    data/checkpoints/wr) reached zero_start_total_reward_mean ~ 5700 in the reference env (README.md:54).  Driving the
+    NumPy oracle with that policy (deterministic head: arg-max keys, squashed mean) must give a run of that quality -
+    a check of the oracle against the reference's published artefacts that is independent of the generated vectors."""
+    import json
+    import os
+    from oracle import np_oracle as O
+    w = dict(np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "wr_policy.npz")))
+    ec = json.loads(str(w["env_config_json"]))
+    ec["initial_yaw_range"] = tuple(ec["initial_yaw_range"])
+    pol = P.load_rllib_fcnet_weights(P.Q1Policy(), w)
+    np.random.seed(0)
+    env = O.OracleVectorEnv(O.OracleConfig(**{**ec, "num_envs": 1, "zero_start_prob": 1.0}))
+    obs = env.observation()
+    total, done, ticks = 0.0, False, 0
+    with torch.no_grad():
+        while not done:
+            logits, _ = pol(torch.from_numpy(obs.astype(np.float32)))
+            keys, mouse = P.Q1PhysActionDist(logits, float(ec["action_range"])).deterministic_sample()
+            a = np.concatenate([keys.numpy().astype(np.float64), mouse.numpy().astype(np.float64)], axis=1)
+            obs, r, d, _ = env.vector_step(a)
+            total += float(r[0]); done = bool(d[0]); ticks += 1
+    assert ticks == 720 and 5600.0 < total < 5900.0, (ticks, total)

@@ -1,0 +1,103 @@
+"""CPU: PPO loss (torch) vs the NumPy oracle on a synthetic batch, and the multi-GPU learner model - gradient
+all-reduce on one flat bucket - with world_size-2 gloo: both ranks must end with identical parameters, equal to a
+single process training on the concatenated batch."""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import ppo_oracle as PO
+from q1physrl_amd import policy as P, ppo
+
+AR = 10.0
+
+
+def synth(rng, t, n):
+    obs = rng.normal(0, 1, (t + 1, n, 6)).astype(np.float32)
+    traj = {"obs": torch.from_numpy(obs), "keys": torch.from_numpy(rng.integers(0, 16, (t, n), dtype=np.uint8)),
+            "mouse": torch.from_numpy(rng.uniform(-9.5, 9.5, (t, n)).astype(np.float32)),
+            "logp": torch.from_numpy(rng.normal(-5, 1, (t, n)).astype(np.float32)),
+            "value": torch.from_numpy(rng.normal(0, 1, (t + 1, n)).astype(np.float32)),
+            "reward": torch.from_numpy(rng.normal(0, 1, (t, n)).astype(np.float32)),
+            "done": torch.from_numpy((rng.random((t, n)) < 0.05).astype(np.uint8))}
+    adv, vtarg = PO.gae(traj["reward"].numpy(), traj["value"].numpy(), traj["done"].numpy(), 0.99, 0.95)
+    return traj, torch.from_numpy(adv), torch.from_numpy(vtarg)
+
+
+def test_ppo_loss_matches_numpy_oracle():
+    rng = np.random.default_rng(0)
+    torch.manual_seed(0)
+    pol = P.Q1Policy().double()
+    b = 256
+    batch = {"obs": torch.from_numpy(rng.normal(0, 1, (b, 6))), "keys": torch.from_numpy(rng.integers(0, 2, (b, 4))),
+             "mouse": torch.from_numpy(rng.uniform(-9.5, 9.5, (b, 1))), "logp": torch.from_numpy(rng.normal(-5, 1, b)),
+             "value": torch.from_numpy(rng.normal(0, 1, b)), "adv": torch.from_numpy(rng.normal(0, 1, b)),
+             "vtarg": torch.from_numpy(rng.normal(0, 1, b)), "old_logits": torch.from_numpy(rng.normal(0, 0.5, (b, 10)))}
+    loss, st = ppo.ppo_loss(pol, batch, AR, 0.3, 100.0, 1.0, 0.01, 0.2)
+    with torch.no_grad():
+        logits, value = pol(batch["obs"])
+    nb = {k: v.numpy() for k, v in batch.items()}
+    want, kl, ent = PO.ppo_loss(logits.numpy(), value.numpy(), nb, AR, 0.3, 100.0, 1.0, 0.01, 0.2)
+    assert abs(float(loss) - want) < 1e-9 * max(1, abs(want))
+    assert abs(float(st["kl"]) - kl) < 1e-9 and abs(float(st["entropy"]) - ent) < 1e-9
+    loss.backward()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in pol.parameters())
+
+
+def test_learner_update_reduces_loss_and_adapts_kl():
+    rng = np.random.default_rng(1)
+    torch.manual_seed(1)
+    pol = P.Q1Policy()
+    traj, adv, vtarg = synth(rng, 16, 64)
+    with torch.no_grad():        # make logp consistent with the current policy so ratio starts at 1
+        logits, value = pol(traj["obs"][:16].reshape(-1, 6))
+        d = P.Q1PhysActionDist(logits, AR)
+        keys = ((traj["keys"].reshape(-1, 1).long() >> torch.arange(4)) & 1)
+        traj["logp"] = d.logp(keys, traj["mouse"].reshape(-1, 1)).reshape(16, 64)
+    lrn = ppo.PPOLearner(pol, AR, lr=1e-3, num_sgd_iter=4, minibatch_size=256, kl_target=0.0036)
+    s1 = lrn.update(traj, adv, vtarg)
+    s2 = lrn.update(traj, adv, vtarg)
+    assert s2["total_loss"] < s1["total_loss"] and s1["sgd_steps"] == 16
+    assert lrn.kl_coeff != 0.2                                   # adapted one way or the other
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
+    return p
+
+
+def _worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    rng = np.random.default_rng(5)
+    traj, adv, vtarg = synth(rng, 8, 32)                         # the GLOBAL batch, identical on both ranks
+    torch.manual_seed(3)
+    pol = P.Q1Policy().double()
+    sl = slice(rank * 16, (rank + 1) * 16)                       # this rank's env shard
+    mine = {k: (v[:, sl].double() if v.dtype == torch.float32 else v[:, sl]) for k, v in traj.items()}
+    lrn = ppo.PPOLearner(pol, AR, lr=1e-3, num_sgd_iter=3, minibatch_size=10 ** 9, seed=0)   # full-batch SGD: deterministic
+    lrn.update(mine, adv[:, sl].double(), vtarg[:, sl].double())
+    flat = torch.cat([p.detach().reshape(-1) for p in pol.parameters()])
+    gathered = [torch.empty_like(flat) for _ in range(world)]
+    dist.all_gather(gathered, flat)
+    if rank == 0:
+        torch.manual_seed(3)
+        ref = P.Q1Policy().double()
+        dist_world = lrn.world
+        single = ppo.PPOLearner(ref, AR, lr=1e-3, num_sgd_iter=3, minibatch_size=10 ** 9, seed=0)
+        single.world = 1
+        full = {k: (v.double() if v.dtype == torch.float32 else v) for k, v in traj.items()}
+        single.update(full, adv.double(), vtarg.double())
+        ref_flat = torch.cat([p.detach().reshape(-1) for p in ref.parameters()])
+        np.save(out, np.array([float(torch.equal(gathered[0], gathered[1])), float((gathered[0] - ref_flat).abs().max()), dist_world]))
+    dist.destroy_process_group()
+
+
+def test_two_rank_gradient_allreduce_equals_single_process(tmp_path):
+    out = str(tmp_path / "r.npy")
+    mp.spawn(_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    same, err, world = np.load(out)
+    assert same == 1.0 and world == 2 and err < 1e-10

@@ -1,0 +1,22 @@
+"""Play the reference's published world-record policy (weights fixture tests/golden/wr_policy.npz) in this env:
+zero-start 10 s runs under the run's own env_config; prints the total reward (= distance along +Y)."""
+import json, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from q1physrl_amd import policy as P
+from q1physrl_amd.env import Config
+from q1physrl_amd.sampler import GpuSampler
+from q1physrl_amd.tensor_env import TensorVectorEnv
+w = dict(np.load(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "wr_policy.npz")))
+ec = json.loads(str(w["env_config_json"]))
+ec["initial_yaw_range"] = tuple(ec["initial_yaw_range"])
+for det in (False, True):
+    cfg = Config(**{**ec, "num_envs": 4096, "zero_start_prob": 1.0})
+    env = TensorVectorEnv(cfg, seed=7)
+    pol = P.load_rllib_fcnet_weights(P.Q1Policy(), w).cuda()
+    s = GpuSampler(env, pol, horizon=720)
+    tr = s.collect(deterministic=det)
+    total = tr["reward"].double().sum(0)
+    print(("deterministic" if det else "stochastic"), "zero-start total reward: mean %.1f min %.1f max %.1f std %.1f; done on last tick: %s; value[0] mean %.1f"
+          % (total.mean(), total.min(), total.max(), total.std(), bool(tr["done"][-1].all()), float(tr["value"][0].mean())))
+    env.close()

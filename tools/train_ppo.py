@@ -1,0 +1,78 @@
+#!/usr/bin/env python3
+"""End-to-end check of the env through learning: PPO on the GPU-resident sampler (one process per GPU; with
+torch.distributed.run the policy gradient is all-reduced, the envs are sharded).  Prints one line per iteration with the
+reference's headline training metric, zero_start_total_reward_mean (train.py:54-57; README: ~5700 after 150 M steps).
+
+    python tools/train_ppo.py --iters 150 --envs 8192 --horizon 128
+"""
+import argparse, json, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import torch.distributed as dist
+from q1physrl_amd import policy as P, ppo, sharding
+from q1physrl_amd.env import Config
+from q1physrl_amd.sampler import GpuSampler
+from q1physrl_amd.tensor_env import TensorVectorEnv
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--iters", type=int, default=100)
+ap.add_argument("--envs", type=int, default=8192, help="total envs over all ranks")
+ap.add_argument("--horizon", type=int, default=128)
+ap.add_argument("--lr", type=float, default=3e-4)
+ap.add_argument("--epochs", type=int, default=4)
+ap.add_argument("--minibatch", type=int, default=65536)
+ap.add_argument("--entropy", type=float, default=0.003)
+ap.add_argument("--kl-target", type=float, default=0.01)
+ap.add_argument("--zero-start-prob", type=float, default=0.1)
+ap.add_argument("--seed", type=int, default=0)
+ap.add_argument("--out", default="")
+args = ap.parse_args()
+
+rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
+local = int(os.environ.get("LOCAL_RANK", 0)) % max(torch.cuda.device_count(), 1)
+torch.cuda.set_device(local)
+if world > 1:
+    dist.init_process_group("nccl" if torch.cuda.device_count() >= world else "gloo")
+torch.manual_seed(args.seed)                                   # identical initial weights on every rank
+start, count = sharding.shard_range(args.envs, rank, world)
+cfg = Config(**{**Config.get_default().__dict__, "num_envs": count, "zero_start_prob": args.zero_start_prob})
+env = TensorVectorEnv(cfg, device=local, seed=args.seed + 1, env_index_base=start)
+pol = P.Q1Policy().cuda()
+smp = GpuSampler(env, pol, horizon=args.horizon)
+lrn = ppo.PPOLearner(pol, float(cfg.action_range), lr=args.lr, num_sgd_iter=args.epochs, minibatch_size=args.minibatch,
+                     entropy_coeff=args.entropy, kl_target=args.kl_target, seed=args.seed + rank)
+log = []
+t0 = time.time()
+prev = smp.stats
+for it in range(args.iters):
+    ts = time.time()
+    traj = smp.collect()
+    adv, vtarg = smp.advantages(traj, lrn.gamma, lrn.lam)
+    torch.cuda.synchronize(); t_sample = time.time() - ts
+    st = lrn.update(traj, adv, vtarg)
+    torch.cuda.synchronize(); t_iter = time.time() - ts
+    cur = smp.stats
+    dz = cur["zero_start_episodes"] - prev["zero_start_episodes"]
+    zmean = (cur["zero_start_return_sum"] - prev["zero_start_return_sum"]) / dz if dz else float("nan")
+    de = cur["episodes"] - prev["episodes"]
+    emean = (cur["return_sum"] - prev["return_sum"]) / de if de else float("nan")
+    prev = cur
+    row = {"iter": it, "steps": (it + 1) * args.envs * args.horizon, "zero_start_total_reward_mean": zmean, "episode_reward_mean": emean,
+           "kl": st["kl"], "entropy": st["entropy"], "vf_loss": st["vf_loss"], "kl_coeff": st["kl_coeff"],
+           "sample_s": t_sample, "iter_s": t_iter, "wall_s": time.time() - t0}
+    log.append(row)
+    if rank == 0 and (it % 5 == 0 or it == args.iters - 1):
+        print(json.dumps(row), flush=True)
+
+# deterministic evaluation: zero-start, 720 ticks, argmax keys / squashed mean (what mkdemo would play back)
+ecfg = Config(**{**Config.get_default().__dict__, "num_envs": 64, "zero_start_prob": 1.0})
+eenv = TensorVectorEnv(ecfg, device=local, seed=123)
+es = GpuSampler(eenv, pol, horizon=720)
+tr = es.collect(deterministic=True)
+dist_y = tr["reward"].double().sum(0)
+if rank == 0:
+    final = {"eval_zero_start_distance_mean": float(dist_y.mean()), "eval_min": float(dist_y.min()), "eval_max": float(dist_y.max()),
+             "total_steps": args.iters * args.envs * args.horizon, "wall_s": time.time() - t0}
+    print(json.dumps(final), flush=True)
+    if args.out:
+        json.dump({"args": vars(args), "log": log, "final": final}, open(args.out, "w"))
