@@ -110,7 +110,8 @@ int         q1env_device_count(void);
  * zero-start reset (env.py:54-58) of every env. */
 int q1env_create(const q1env_config* cfg, int device, void* stream, q1env_t** out);
 int q1env_destroy(q1env_t* env);
-/* Rebind the handle to another stream (drains the old one first).  Here NULL means the device's default
+/* Rebind the handle to another stream (no synchronisation: ordering between the old and the new stream is the caller's
+ * business, as with torch.cuda.stream()); legal while the new stream is being captured.  Here NULL means the device's default
  * (null) stream - what torch.cuda.current_stream().cuda_stream is (0) unless a side stream is current. */
 int q1env_set_stream(q1env_t* env, void* stream);
 int q1env_sync(q1env_t* env);
@@ -129,8 +130,10 @@ int q1env_reset_draws_host(q1env_t* env, int64_t n, const int32_t* idx, const ui
 /* reset_philox: device-side counter RNG (Philox4x32-10 keyed by (seed, global env index, episode
  * counter)) drawing the reference's distributions, including the one-argument uniform(x) quirk
  * (= uniform(low=x, high=1), env.py:439-446).  mask_dev: NULL = all envs; else uint8[N], non-zero = reset.
- * done_only != 0 additionally restricts to envs whose time_remaining < 0 (env.py:506). Asynchronous. */
-int q1env_reset_philox(q1env_t* env, uint64_t seed, const uint8_t* mask_dev, int done_only,
+ * done_only != 0 additionally restricts to envs whose time_remaining < 0 (env.py:506). Asynchronous.
+ * counter_dev: NULL = the RNG counter is the handle's host-side tick count; else a device uint64 the kernel reads at run time,
+ * so that a captured hipGraph of a sampler loop draws fresh numbers on every replay (the caller increments it on the device). */
+int q1env_reset_philox(q1env_t* env, uint64_t seed, const uint64_t* counter_dev, const uint8_t* mask_dev, int done_only,
                        int obs_format, void* obs_dev);
 
 /* ---- the hot path: one tick of every env (env.py:482-510) ------------------------------------
@@ -188,9 +191,9 @@ int q1phys_apply_host(int device, int64_t n, const double* yaw, const double* pi
  * its log-probability.  logits: float[N][row_stride] device, row = num_keys x (logit0, logit1) then (mean, log_std)
  * of the CDF-squashed Gaussian over (-action_range, action_range).  keys uint8[N], mouse float[N], logp float[N]
  * (logp may be NULL).  deterministic != 0: arg-max keys and the squashed mean (action_dist.py:84-89).
- * Randomness: Philox keyed by (seed, global env index, counter). Asynchronous on the handle's stream. */
+ * Randomness: Philox keyed by (seed, global env index, counter + (counter_dev ? *counter_dev : 0)). Asynchronous. */
 int q1env_policy_sample(q1env_t* env, const float* logits_dev, int row_stride, uint64_t seed, uint64_t counter,
-                        int deterministic, uint8_t* keys_dev, float* mouse_dev, float* logp_dev);
+                        const uint64_t* counter_dev, int deterministic, uint8_t* keys_dev, float* mouse_dev, float* logp_dev);
 
 /* Generalised advantage estimation over tick-major device arrays of this handle's N envs (learner-side glue):
  * reward float[T][N], value float[T+1][N] (bootstrap row last), done uint8[T][N] -> adv, vtarg float[T][N]. */

@@ -54,7 +54,7 @@ _SIGNATURES = {
     "q1env_num_keys": (C.c_int, [_P]),
     "q1env_action_width": (C.c_int, [_P]),
     "q1env_reset_draws_host": (C.c_int, [_P, C.c_int64, _P, _P, _P, _P, _P, _P, C.c_int, _P]),
-    "q1env_reset_philox": (C.c_int, [_P, C.c_uint64, _P, C.c_int, C.c_int, _P]),
+    "q1env_reset_philox": (C.c_int, [_P, C.c_uint64, _P, _P, C.c_int, C.c_int, _P]),
     "q1env_step": (C.c_int, [_P, C.c_int, _P, _P, C.c_int, _P, _P, _P, _P]),
     "q1env_step_host": (C.c_int, [_P, C.c_int, _P, _P, C.c_int, _P, _P, _P, _P]),
     "q1env_step_many": (C.c_int, [_P, C.c_int, C.c_int, _P, _P, C.c_int, _P, _P, _P, C.c_int, C.c_int]),
@@ -67,7 +67,7 @@ _SIGNATURES = {
     "q1env_decode_host": (C.c_int, [_P, C.c_int, _P, _P, _P, _P, _P, _P, _P, _P]),
     "q1env_decoder_reset_host": (C.c_int, [_P, C.c_int64, _P, _P]),
     "q1phys_apply_host": (C.c_int, [C.c_int, C.c_int64] + [_P] * 15),
-    "q1env_policy_sample": (C.c_int, [_P, _P, C.c_int, C.c_uint64, C.c_uint64, C.c_int, _P, _P, _P]),
+    "q1env_policy_sample": (C.c_int, [_P, _P, C.c_int, C.c_uint64, C.c_uint64, _P, C.c_int, _P, _P, _P]),
     "q1env_gae": (C.c_int, [_P, C.c_int, _P, _P, _P, C.c_float, C.c_float, _P, _P]),
     "q1env_selftest_division": (C.c_int, [C.c_int, C.c_uint64, C.c_uint64, C.c_double, C.c_double, C.POINTER(C.c_uint64)]),
     "q1env_calibrate_traffic": (C.c_int, [_P, C.c_int]),

@@ -166,9 +166,11 @@ reset_draws_kernel(Params p, StatePtrs s, int count, const int32_t* idx, const u
 
 template <typename OBS_T>
 __global__ void __launch_bounds__(256)
-reset_philox_kernel(Params p, StatePtrs s, uint64_t seed, uint64_t counter, const uint8_t* mask, int done_only, OBS_T* obs) {
+reset_philox_kernel(Params p, StatePtrs s, uint64_t seed, uint64_t counter, const uint64_t* counter_dev, const uint8_t* mask,
+                    int done_only, OBS_T* obs) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (uint32_t)p.n) return;
+    if (counter_dev) counter += *counter_dev;          // device-resident tick counter (hipGraph-replayable loops)
     Env e;
     load_env(s, (uint32_t)p.n, i, e);
     bool go = mask ? (mask[i] != 0) : true;
@@ -231,9 +233,10 @@ constexpr uint32_t STREAM_POLICY = 3;
 
 __global__ void __launch_bounds__(256)
 policy_sample_kernel(Params p, const float* __restrict__ logits, int row_stride, uint64_t seed, uint64_t counter,
-                     int deterministic, uint8_t* keys_out, float* mouse_out, float* logp_out) {
+                     const uint64_t* counter_dev, int deterministic, uint8_t* keys_out, float* mouse_out, float* logp_out) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (uint32_t)p.n) return;
+    if (counter_dev) counter += *counter_dev;
     const float* row = logits + (size_t)i * row_stride;
     uint32_t r[4], r2[4];
     philox_draw(seed, (uint64_t)p.env_index_base + i, counter, STREAM_POLICY, 0, r);
@@ -558,7 +561,7 @@ int q1env_create(const q1env_config* cfg, int device, void* stream, q1env_t** ou
     p0.zero_start_prob = 2.0;
     const int b = block_for(p.n);
     hipLaunchKernelGGL(reset_philox_kernel<float>, grid_for(p.n, b), dim3(b), 0, h->stream, p0, h->st,
-                       (uint64_t)0, (uint64_t)0, (const uint8_t*)nullptr, 0, (float*)nullptr);
+                       (uint64_t)0, (uint64_t)0, (const uint64_t*)nullptr, (const uint8_t*)nullptr, 0, (float*)nullptr);
     e = hipStreamSynchronize(h->stream);
     if (e != hipSuccess) { q1env_destroy(h); return fail(Q1ENV_ERR_HIP, std::string("initial reset: ") + hipGetErrorString(e)); }
     *out = h;
@@ -583,7 +586,6 @@ int q1env_destroy(q1env_t* h) {
 int q1env_set_stream(q1env_t* h, void* stream) {
     if (!h) return fail(Q1ENV_ERR_INVALID_ARG, "q1env_set_stream: null handle");
     HIP_TRY(hipSetDevice(h->device));
-    HIP_TRY(hipStreamSynchronize(h->stream));
     if (h->gexec) { (void)hipGraphExecDestroy(h->gexec); h->gexec = nullptr; h->gkey.clear(); }
     if (h->own_stream) { (void)hipStreamDestroy(h->stream); h->own_stream = false; }
     h->stream = (hipStream_t)stream;          // NULL = the device's default (null) stream
@@ -822,15 +824,17 @@ int q1env_reset_draws_host(q1env_t* h, int64_t count, const int32_t* idx, const 
     return Q1ENV_OK;
 }
 
-int q1env_reset_philox(q1env_t* h, uint64_t seed, const uint8_t* mask, int done_only, int obs_format, void* obs) {
+int q1env_reset_philox(q1env_t* h, uint64_t seed, const uint64_t* counter_dev, const uint8_t* mask, int done_only, int obs_format,
+                       void* obs) {
     if (!h) return fail(Q1ENV_ERR_INVALID_ARG, "q1env_reset_philox: null handle");
     const int blk = block_for(h->p.n);
+    const uint64_t counter = counter_dev ? 0 : h->tick_count;
     if (obs_format == Q1ENV_OBS_F32)
         hipLaunchKernelGGL(reset_philox_kernel<float>, grid_for(h->p.n, blk), dim3(blk), 0, h->stream, h->p, h->st, seed,
-                           h->tick_count, mask, done_only, (float*)obs);
+                           counter, counter_dev, mask, done_only, (float*)obs);
     else if (obs_format == Q1ENV_OBS_F64)
         hipLaunchKernelGGL(reset_philox_kernel<double>, grid_for(h->p.n, blk), dim3(blk), 0, h->stream, h->p, h->st, seed,
-                           h->tick_count, mask, done_only, (double*)obs);
+                           counter, counter_dev, mask, done_only, (double*)obs);
     else return fail(Q1ENV_ERR_INVALID_ARG, "bad obs_format");
     HIP_TRY(hipGetLastError());
     return Q1ENV_OK;
@@ -965,8 +969,8 @@ int q1phys_apply_host(int device, int64_t n64, const double* yaw, const double* 
     return rc;
 }
 
-int q1env_policy_sample(q1env_t* h, const float* logits, int row_stride, uint64_t seed, uint64_t counter, int deterministic,
-                        uint8_t* keys, float* mouse, float* logp) {
+int q1env_policy_sample(q1env_t* h, const float* logits, int row_stride, uint64_t seed, uint64_t counter,
+                        const uint64_t* counter_dev, int deterministic, uint8_t* keys, float* mouse, float* logp) {
     if (!h || !logits || !keys) return fail(Q1ENV_ERR_INVALID_ARG, "q1env_policy_sample: null argument");
     const int need = 2 * h->p.num_keys + (h->p.yaw_mode == 1 ? 2 : 0);
     if (h->p.yaw_mode == 2) return fail(Q1ENV_ERR_INVALID_ARG, "q1env_policy_sample: discrete yaw is not supported (continuous mouse or no mouse)");
@@ -974,7 +978,7 @@ int q1env_policy_sample(q1env_t* h, const float* logits, int row_stride, uint64_
     if (h->p.yaw_mode == 1 && !mouse) return fail(Q1ENV_ERR_INVALID_ARG, "q1env_policy_sample: mouse output required");
     const int blk = block_for(h->p.n);
     hipLaunchKernelGGL(policy_sample_kernel, grid_for(h->p.n, blk), dim3(blk), 0, h->stream, h->p, logits, row_stride, seed, counter,
-                       deterministic, keys, mouse, logp);
+                       counter_dev, deterministic, keys, mouse, logp);
     HIP_TRY(hipGetLastError());
     return Q1ENV_OK;
 }

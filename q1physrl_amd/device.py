@@ -154,12 +154,12 @@ class DeviceEnv:
         _lib.check(self._lib.q1env_rollout(self._h, ticks, action_format, act_a or None, act_b or None, rng_seed, obs_format,
                                            obs or None, reward or None, done or None, int(auto_reset), return_sum or None))
 
-    def reset_philox_dev(self, seed, mask=0, done_only=False, obs_format=_lib.OBS_F32, obs=0):
-        _lib.check(self._lib.q1env_reset_philox(self._h, seed, mask or None, int(done_only), obs_format, obs or None))
+    def reset_philox_dev(self, seed, mask=0, done_only=False, obs_format=_lib.OBS_F32, obs=0, counter_dev=0):
+        _lib.check(self._lib.q1env_reset_philox(self._h, seed, counter_dev or None, mask or None, int(done_only), obs_format, obs or None))
 
-    def policy_sample_dev(self, logits, row_stride, seed, counter, keys, mouse, logp=0, deterministic=False):
-        _lib.check(self._lib.q1env_policy_sample(self._h, logits, int(row_stride), int(seed), int(counter), int(deterministic),
-                                                 keys, mouse or None, logp or None))
+    def policy_sample_dev(self, logits, row_stride, seed, counter, keys, mouse, logp=0, deterministic=False, counter_dev=0):
+        _lib.check(self._lib.q1env_policy_sample(self._h, logits, int(row_stride), int(seed), int(counter), counter_dev or None,
+                                                 int(deterministic), keys, mouse or None, logp or None))
 
     def gae_dev(self, ticks, reward, value, done, gamma, lam, adv, vtarg):
         _lib.check(self._lib.q1env_gae(self._h, int(ticks), reward, value, done, float(gamma), float(lam), adv, vtarg))

@@ -2,10 +2,15 @@
 sampler with nothing leaving the device between ticks:
 
     obs (N,6) f32 --torch MLP--> logits (N,10) --q1env_policy_sample (HIP)--> packed action + logp
-        --q1env_step (HIP)--> obs', reward, done --q1env_reset_philox(done_only) (HIP)--> next obs
+        --q1env_step (HIP)--> reward, done --q1env_reset_philox(done_only) (HIP)--> next obs (fresh for reset envs)
 
 Trajectories are stored tick-major ([T][N]...) in preallocated device tensors; episode statistics follow the
-reference's metric hook (train.py:54-57: the return of zero-start episodes, `zero_start_total_reward`)."""
+reference's metric hook (train.py:54-57: the return of zero-start episodes, `zero_start_total_reward`).
+
+The loop has no host<->device synchronisation and no host-side state that changes per tick (the Philox counter lives
+in device memory), so with use_graph=True the whole horizon is captured once into a hipGraph (torch.cuda.CUDAGraph) and
+replayed: a tick then costs its GPU time, not ~40 Python-driven launches.
+"""
 import torch
 
 from . import _lib
@@ -13,7 +18,7 @@ from .tensor_env import TensorVectorEnv
 
 
 class GpuSampler:
-    def __init__(self, env: TensorVectorEnv, policy, horizon: int, autocast_dtype=None):
+    def __init__(self, env: TensorVectorEnv, policy, horizon: int, autocast_dtype=None, use_graph: bool = False):
         self.env, self.policy, self.T = env, policy, int(horizon)
         n, d, t = env.num_envs, env.device, self.T
         self.obs = torch.empty((t + 1, n, 6), dtype=torch.float32, device=d)
@@ -25,12 +30,14 @@ class GpuSampler:
         self.done = torch.empty((t, n), dtype=torch.uint8, device=d)
         self.ep_return = torch.zeros((n,), dtype=torch.float64, device=d)
         self.autocast_dtype = autocast_dtype
-        self.counter = 0
+        self.tick = torch.zeros((1,), dtype=torch.int64, device=d)      # Philox counter, advanced on the device
         # device-resident episode statistics: [episodes, zero_start_episodes, return_sum, zero_start_return_sum]
         self._stats = torch.zeros((4,), dtype=torch.float64, device=d)
+        self._zero = torch.zeros((), dtype=torch.float64, device=d)
+        self.use_graph = bool(use_graph)
+        self._graphs = {}
         self.obs[0].copy_(env.reset())
 
-    @torch.no_grad()
     def _forward(self, obs):
         if self.autocast_dtype is not None:
             with torch.autocast("cuda", dtype=self.autocast_dtype):
@@ -39,45 +46,73 @@ class GpuSampler:
         logits, value = self.policy(obs)
         return logits.contiguous(), value
 
-    @torch.no_grad()
-    def collect(self, deterministic=False):
-        """One horizon of T ticks for all envs, without a single host<->device synchronisation; returns the trajectory
-        buffers (views, valid until the next collect)."""
+    def _horizon(self, deterministic):
+        """T ticks for all envs: no host<->device synchronisation, no per-tick host state."""
         env, dev = self.env, self.env._dev
-        zero = torch.zeros((), dtype=torch.float64, device=env.device)
+        cnt = self.tick.data_ptr()
         for t in range(self.T):
             logits, value = self._forward(self.obs[t])
             self.value[t].copy_(value)
-            dev.policy_sample_dev(logits.data_ptr(), logits.shape[1], env.seed, self.counter, self.keys[t].data_ptr(),
-                                  self.mouse[t].data_ptr(), self.logp[t].data_ptr(), deterministic)
-            self.counter += 1
+            dev.policy_sample_dev(logits.data_ptr(), logits.shape[1], env.seed, 0, self.keys[t].data_ptr(),
+                                  self.mouse[t].data_ptr(), self.logp[t].data_ptr(), deterministic, counter_dev=cnt)
             # tick: reward / done / zero_start only - the observation comes from the reset kernel below, which writes
             # the row of EVERY env (fresh first observation for the envs it resets, current observation for the others)
             dev.step_dev(_lib.ACT_PACKED, self.keys[t].data_ptr(), self.mouse[t].data_ptr(), _lib.OBS_F32, 0,
                          self.reward[t].data_ptr(), self.done[t].data_ptr(), env.zero_start.data_ptr())
             # episode bookkeeping (train.py:54-57: return of finished episodes, split by zero_start), all on device
-            self.ep_return += self.reward[t]
+            self.ep_return.add_(self.reward[t])
             fin = self.done[t].bool()
             zs = fin & env.zero_start.bool()
-            finished_ret = torch.where(fin, self.ep_return, zero)
-            self._stats += torch.stack([fin.sum(), zs.sum(), finished_ret.sum(), torch.where(zs, self.ep_return, zero).sum()])
-            self.ep_return = torch.where(fin, zero, self.ep_return)
-            dev.reset_philox_dev(env.seed, 0, True, _lib.OBS_F32, self.obs[t + 1].data_ptr())   # masked: done envs only
+            self._stats.add_(torch.stack([fin.sum(), zs.sum(), torch.where(fin, self.ep_return, self._zero).sum(),
+                                          torch.where(zs, self.ep_return, self._zero).sum()]))
+            self.ep_return.masked_fill_(fin, 0.0)
+            self.tick.add_(1)
+            dev.reset_philox_dev(env.seed, 0, True, _lib.OBS_F32, self.obs[t + 1].data_ptr(), counter_dev=cnt)   # done envs only
         _, v_last = self._forward(self.obs[self.T])
         self.value[self.T].copy_(v_last)
-        out = {"obs": self.obs, "keys": self.keys, "mouse": self.mouse, "logp": self.logp, "value": self.value,
-               "reward": self.reward, "done": self.done}
-        self.obs[0].copy_(self.obs[self.T])
-        return out
 
-    @property
-    def stats(self):
-        e, z, r, zr = self._stats.tolist()          # the only synchronisation, on demand
-        return {"episodes": int(e), "zero_start_episodes": int(z), "return_sum": r, "zero_start_return_sum": zr}
+    @torch.no_grad()
+    def collect(self, deterministic=False):
+        """One horizon; returns the trajectory buffers (views, valid until the next collect).  obs[T] is carried over
+        to obs[0] at the START of the next collect, so the returned buffers are complete (T+1 observation rows)."""
+        if getattr(self, "_carry", False):
+            self.obs[0].copy_(self.obs[self.T])
+        self._carry = True
+        if not self.use_graph:
+            self._horizon(deterministic)
+        else:
+            key = bool(deterministic)
+            if key not in self._graphs:
+                self._capture(key)
+            else:
+                self._graphs[key].replay()
+        return {"obs": self.obs, "keys": self.keys, "mouse": self.mouse, "logp": self.logp, "value": self.value,
+                "reward": self.reward, "done": self.done}
 
-    def zero_start_total_reward_mean(self):
-        z = self.stats["zero_start_episodes"]
-        return self.stats["zero_start_return_sum"] / z if z else float("nan")
+    def _capture(self, deterministic):
+        """Capture the horizon into a hipGraph.  Capture only records: the state a replay starts from must be the state
+        the eager path would start from, so everything the horizon mutates (env state, counters, statistics) is saved
+        before a warm-up pass (hipBLASLt workspaces, autotuning) and restored, and the graph is replayed once for real."""
+        env = self.env
+        torch.cuda.synchronize(env.device)
+        saved_env = env.get_state()
+        saved = [x.clone() for x in (self.tick, self._stats, self.ep_return, self.obs[0])]
+        side = torch.cuda.Stream(device=env.device)
+        with torch.cuda.stream(side):
+            env.use_current_stream()
+            self._horizon(deterministic)                      # warm-up on the side stream
+        torch.cuda.synchronize(env.device)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=side, capture_error_mode="relaxed"):
+            env.use_current_stream()
+            self._horizon(deterministic)
+        env.use_current_stream()                              # back on the caller's stream for replays and later calls
+        torch.cuda.synchronize(env.device)
+        env.set_state(**saved_env)
+        for dst, src in zip((self.tick, self._stats, self.ep_return, self.obs[0]), saved):
+            dst.copy_(src)
+        self._graphs[deterministic] = g
+        g.replay()
 
     def advantages(self, traj, gamma, lam):
         """GAE over the last collected trajectory on the device (q1env_gae): returns (adv, vtarg), each (T, N) float32."""
@@ -86,3 +121,12 @@ class GpuSampler:
         self.env._dev.gae_dev(self.T, traj["reward"].data_ptr(), traj["value"].data_ptr(), traj["done"].data_ptr(), gamma, lam,
                               adv.data_ptr(), vtarg.data_ptr())
         return adv, vtarg
+
+    @property
+    def stats(self):
+        e, z, r, zr = self._stats.tolist()          # the only synchronisation, on demand
+        return {"episodes": int(e), "zero_start_episodes": int(z), "return_sum": r, "zero_start_return_sum": zr}
+
+    def zero_start_total_reward_mean(self):
+        s = self.stats
+        return s["zero_start_return_sum"] / s["zero_start_episodes"] if s["zero_start_episodes"] else float("nan")

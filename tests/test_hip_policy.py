@@ -139,3 +139,33 @@ def test_wr_policy_reproduces_published_reward_and_oracle_trajectory():
             assert np.array_equal(o.astype(np.float32), obs_gpu[t]), t
     assert float(np.sum(rew_gpu.astype(np.float64), axis=0).mean()) > 5600
     env.close()
+
+
+def test_graph_captured_sampler_equals_eager_sampler():
+    """The whole horizon captured into one hipGraph (device-resident Philox counter) must produce the same trajectories
+    as the eager loop, on the first horizon AND on replays (fresh random numbers each replay, resets included)."""
+    import torch
+    from q1physrl_amd import policy as P
+    from q1physrl_amd.sampler import GpuSampler
+    outs = []
+    for use_graph in (False, True):
+        torch.manual_seed(0)
+        cfg, env = make_env(2048, seed=9, zero_start_prob=0.5, time_limit=0.5)
+        pol = P.Q1Policy().cuda()
+        s = GpuSampler(env, pol, horizon=48, use_graph=use_graph)
+        runs = []
+        for _ in range(3):
+            tr = s.collect()
+            torch.cuda.synchronize()
+            runs.append({k: v.clone() for k, v in tr.items()})
+        outs.append((runs, s.stats, env.get_state()))
+        env.close()
+    (eager, st_e, env_e), (graph, st_g, env_g) = outs
+    for h in range(3):
+        for k in ("keys", "reward", "done", "obs", "mouse"):
+            same = (eager[h][k] == graph[h][k]).float().mean().item()
+            assert same == 1.0, (h, k, same)
+    assert st_e == st_g and st_e["episodes"] > 2048
+    assert not torch.equal(eager[0]["keys"], eager[1]["keys"])           # replays draw fresh numbers
+    for k in env_e:
+        assert np.array_equal(env_e[k], env_g[k]), k

@@ -13,11 +13,12 @@ PARAMS_YML = dict(action_range=10, allow_jump=True, allow_yaw=True, auto_jump=Fa
                   smooth_keys=True, speed_reward=False, time_delta=0.013888888888888, time_limit=10, zero_start_prob=0.01)
 
 for n in (32768, 262144):
+  for use_graph in (False, True):
     for ac in (None, torch.bfloat16):
         env = TensorVectorEnv(Config(num_envs=n, **PARAMS_YML), seed=1)
         pol = P.Q1Policy().cuda()
         T = 64
-        s = GpuSampler(env, pol, horizon=T, autocast_dtype=ac)
+        s = GpuSampler(env, pol, horizon=T, autocast_dtype=ac, use_graph=use_graph)
         s.collect(); torch.cuda.synchronize()
         t0 = time.perf_counter()
         reps = 3
@@ -33,6 +34,6 @@ for n in (32768, 262144):
                 env.step_tensor((keys[t], mouse[t])); env.reset_done()
         torch.cuda.synchronize()
         de = (time.perf_counter() - t1) / (reps * T)
-        print(f"n={n:7d} policy={'fp32' if ac is None else 'bf16-autocast'}: {dt*1e6:8.1f} us/tick = {n/dt/1e6:8.2f} M env-steps/s; "
+        print(f"n={n:7d} graph={int(use_graph)} policy={'fp32' if ac is None else 'bf16-autocast'}: {dt*1e6:8.1f} us/tick = {n/dt/1e6:8.2f} M env-steps/s; "
               f"env step+reset alone {de*1e6:7.1f} us/tick ({100*de/dt:4.1f} % of the tick)")
         env.close()

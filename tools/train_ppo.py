@@ -26,6 +26,7 @@ ap.add_argument("--kl-target", type=float, default=0.01)
 ap.add_argument("--zero-start-prob", type=float, default=0.1)
 ap.add_argument("--seed", type=int, default=0)
 ap.add_argument("--out", default="")
+ap.add_argument("--no-graph", action="store_true")
 args = ap.parse_args()
 
 rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
@@ -38,7 +39,7 @@ start, count = sharding.shard_range(args.envs, rank, world)
 cfg = Config(**{**Config.get_default().__dict__, "num_envs": count, "zero_start_prob": args.zero_start_prob})
 env = TensorVectorEnv(cfg, device=local, seed=args.seed + 1, env_index_base=start)
 pol = P.Q1Policy().cuda()
-smp = GpuSampler(env, pol, horizon=args.horizon)
+smp = GpuSampler(env, pol, horizon=args.horizon, use_graph=not args.no_graph)
 lrn = ppo.PPOLearner(pol, float(cfg.action_range), lr=args.lr, num_sgd_iter=args.epochs, minibatch_size=args.minibatch,
                      entropy_coeff=args.entropy, kl_target=args.kl_target, seed=args.seed + rank)
 log = []
