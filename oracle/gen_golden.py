@@ -156,7 +156,23 @@ PARAMS_YML_ENV_CONFIG = dict(   # /root/reference/data/params.yml:16-33 (values,
     time_delta=0.013888888888888, time_limit=10, zero_start_prob=0.01)
 
 
+def extra_fixtures():
+    """Fixtures added after the first generation (own RNG streams, so the earlier files stay byte-stable)."""
+    rng = np.random.default_rng(777)
+    ar = float(ref_env.Config.get_default().action_range)
+    # key components that are not 0/1: the reference takes astype(int) and then `& (elapsed | last_keys)`, i.e. bit 0 of the
+    # truncated value (2 -> released, 3 -> pressed, -1 -> pressed, 0.9 -> released, 1.7 -> pressed) - env.py:228,243
+    T, N = 120, 8
+    vals = np.array([0, 1, 2, 3, -1, 0.9, 1.7, -0.5, 5.0, -2.0])
+    keys = rng.choice(vals, size=(T, N, 4))
+    yaw = rng.uniform(-ar, ar, size=(T, N, 1)).astype(np.float32).astype(np.float64)
+    save("g4_weird_key_values", run_trace(default_kwargs(num_envs=N, zero_start_prob=0.5), np.concatenate([keys, yaw], axis=2), seed=901))
+
+
 def main():
+    if "--extra-only" in sys.argv:
+        extra_fixtures()
+        return
     os.makedirs(OUT, exist_ok=True)
     rng = np.random.default_rng(20260928)
     ar_default = float(ref_env.Config.get_default().action_range)   # f32(720)*f32(0.014) = 10.0799999237...
@@ -331,6 +347,7 @@ def main():
     for k, v in douts.items():
         g5["dec_out_" + k] = np.stack(v)
     save("g5_micro", g5)
+    extra_fixtures()
 
 
 if __name__ == "__main__":

@@ -107,7 +107,7 @@ def decode(cfg, dec, actions: np.ndarray, z_vel: np.ndarray, t_rem: np.ndarray):
     last_keys (N,K) bool, yaw (N) f64 and is updated in place.  Returns (yaw, smove, fmove, jump)."""
     K = cfg.num_keys
     a = fix_actions(actions)
-    pressed = a[:, :K].astype(np.int64) != 0
+    pressed = (a[:, :K].astype(np.int64) & 1) != 0        # astype(int) then `& (0/1 array)`: bit 0 of the truncated value (env.py:228,243)
     if not cfg.allow_yaw:
         dyaw = np.zeros(a.shape[0], dtype=F64)
     elif cfg.discrete_yaw_steps == -1:

@@ -11,7 +11,7 @@ TRACE_FIXTURES = [
     "g2_zero_start_720", "g2b_zero_start_iid_720", "g3_params_yml_1500", "g3_get_default_1500",
     "g3_mixed_zero_start_800", "g3_list_actions_200", "g4_discrete_yaw5", "g4_no_yaw", "g4_auto_jump",
     "g4_no_jump", "g4_hover", "g4_speed_reward", "g4_no_smooth", "g4_delay0", "g4_dataclass_defaults",
-    "g4_short_episodes", "g4_fmove_small", "s1_reference_test_scenario", "s2_constant_action_720",
+    "g4_short_episodes", "g4_fmove_small", "g4_weird_key_values", "s1_reference_test_scenario", "s2_constant_action_720",
 ]
 
 
