@@ -53,9 +53,11 @@ def make_actions(n, ticks, action_range, seed):
     return keys, mouse
 
 
-def cpu_baseline(n, action_range, budget_s=10.0):
+def cpu_baseline(n, action_range, budget_s=10.0, gpu_check=None):
     """The NumPy oracle (from-scratch restatement of the reference's NumPy path, bit-pinned to the reference by
     tests/golden) timed on this box's host: 1 process, 1 thread (NumPy elementwise kernels are single-threaded).
+    While it runs it also serves as the CHECKER of the metric's second half: after 720 ticks (10 s of game time) its
+    state is compared with the GPU env driven by the same actions (`gpu_check`) -> max |pos - NumPy ref|.
     Also the C oracle on all host cores (OpenMP), reported as extra information."""
     from oracle import np_oracle as O
     np.random.seed(0)
@@ -64,16 +66,33 @@ def cpu_baseline(n, action_range, budget_s=10.0):
     acts = [np.concatenate([(rng.random((n, 4)) < 0.5).astype(np.float64),
                             rng.uniform(-action_range, action_range, (n, 1)).astype(np.float32).astype(np.float64)], axis=1)
             for _ in range(8)]
-    env.vector_step(acts[0])                       # warm-up
-    t0 = time.perf_counter()
-    ticks = 0
-    while time.perf_counter() - t0 < budget_s:
-        env.vector_step(acts[ticks % len(acts)])
+    dist = np.zeros((n, 2))
+    snap = None
+    spent, ticks = 0.0, 0
+    while spent < budget_s or ticks < EPISODE_TICKS - 1:
+        t0 = time.perf_counter()
+        _, _, done, _ = env.vector_step(acts[ticks % len(acts)])
+        spent += time.perf_counter() - t0
         ticks += 1
-    dt = time.perf_counter() - t0
+        if ticks <= EPISODE_TICKS - 1:                 # stop integrating before the episode-ending tick
+            dist += env.cfg.time_delta * env.st["vel"][:, :2].astype(np.float64)
+        if ticks == EPISODE_TICKS - 1:
+            snap = {"dist": dist.copy(), "z": env.st["z_pos"].copy(), "vel": env.st["vel"].copy(), "yaw": env.yaw.copy()}
+    dt = spent
     out = {"value": n * ticks / dt, "unit": "env-steps/s", "cores": 1, "kind": "port",
-           "sample": f"{ticks} ticks of {n} envs (ndarray actions, oracle/np_oracle.py, NumPy {np.__version__}) in {dt:.1f} s; "
+           "sample": f"{ticks} ticks of {n} envs (ndarray actions, oracle/np_oracle.py, NumPy {np.__version__}) in {dt:.1f} s of oracle time; "
                      f"host has {os.cpu_count()} logical cores"}
+    if gpu_check is not None and snap is not None:
+        g = gpu_check(acts, EPISODE_TICKS - 1)
+        out["parity_vs_gpu_after_719_ticks"] = {
+            "envs": n,
+            "max_abs_pos_xy_diff": float(max(np.abs(g["pos_x"] - snap["dist"][:, 0]).max(), np.abs(g["pos_y"] - snap["dist"][:, 1]).max())),
+            "max_abs_z_diff": float(np.abs(g["z_pos"] - snap["z"]).max()),
+            "max_abs_vel_diff": float(max(np.abs(g["vel_x"] - snap["vel"][:, 0]).max(), np.abs(g["vel_y"] - snap["vel"][:, 1]).max(),
+                                          np.abs(g["vel_z"] - snap["vel"][:, 2]).max())),
+            "max_abs_yaw_diff": float(np.abs(g["yaw"] - snap["yaw"]).max()),
+            "vel_bit_identical_fraction": float(np.mean(np.stack([g["vel_x"], g["vel_y"], g["vel_z"]], 1).view(np.uint32) == snap["vel"].view(np.uint32))),
+            "max_abs_y_travelled": float(np.abs(snap["dist"][:, 1]).max())}
     try:
         from oracle import c_oracle as CO
         threads = max(1, min(os.cpu_count() or 1, 64))
@@ -219,7 +238,8 @@ def main():
                    "envs_per_gpu": n, "parallelism": f"batch-split x{world}, no collective",
                    "arithmetic": "float64 (float32 storage of vel/obs/reward), bit-identical to the NumPy reference"},
         "roofline": roof,
-        "parity": "tests/test_hip_parity.py + tests/test_hip_fastpath.py: max |pos - ref| = 0.0 over the 720-tick rollout (bit-identical)",
+        "parity": "max |pos - NumPy ref| over the 10 s rollout: measured live in cpu_baseline.parity_vs_gpu_after_719_ticks (N=1 runs); "
+                  "tests/test_hip_fastpath.py::test_full_size_rollout_parity_65536_envs_720_ticks checks all 65 536 x 720 env-steps bit-exactly",
     }
     if not args.no_secondary:
         other = "rollout" if args.mode == "step" else "step"
@@ -230,7 +250,17 @@ def main():
             "note": ("one rollout_kernel launch per 720-tick episode, identical inputs/outputs" if other == "rollout"
                      else "one step_kernel launch per tick (hipGraph)")}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(n, ar)
+        def gpu_check(acts, k):
+            """The GPU env on the oracle's own actions (float64 rows) for k ticks from a fresh zero start."""
+            chk = DeviceEnv(cfg, device=dev_index)
+            rows = [torch.from_numpy(a).to(d) for a in acts]
+            for t in range(k):
+                chk.step_dev(_lib.ACT_F64_ROWS, rows[t % len(rows)].data_ptr(), 0, _lib.OBS_F32, 0, 0, 0, 0)
+            chk.sync()
+            st = chk.get_state()
+            chk.close()
+            return st
+        out["cpu_baseline"] = cpu_baseline(n, ar, gpu_check=gpu_check)
     else:
         out["cpu_baseline"] = None
     if rank == 0:
