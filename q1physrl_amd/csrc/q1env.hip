@@ -412,6 +412,21 @@ static int fail(int code, const std::string& msg) {
             return fail(Q1ENV_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e));    \
     } while (0)
 
+// Makes the handle's device current for the duration of an entry point and restores the caller's device afterwards
+// (a host framework such as torch tracks the thread's current device itself; the library must not change it under it).
+struct DeviceGuard {
+    int prev = -1;
+    bool switched = false;
+    explicit DeviceGuard(int dev) {
+        if (hipGetDevice(&prev) == hipSuccess && prev != dev) switched = (hipSetDevice(dev) == hipSuccess);
+    }
+    ~DeviceGuard() {
+        if (switched) (void)hipSetDevice(prev);
+    }
+    DeviceGuard(const DeviceGuard&) = delete;
+    DeviceGuard& operator=(const DeviceGuard&) = delete;
+};
+
 struct q1env {
     q1env_config cfg{};
     Params p{};
@@ -535,7 +550,7 @@ int q1env_create(const q1env_config* cfg, int device, void* stream, q1env_t** ou
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
         return fail(Q1ENV_ERR_NO_DEVICE, "q1env_create: no HIP device visible (libq1env has no CPU fallback)");
     if (device < 0 || device >= ndev) return fail(Q1ENV_ERR_INVALID_ARG, "q1env_create: bad device index");
-    HIP_TRY(hipSetDevice(device));
+    DeviceGuard guard(device);
     q1env* h = new (std::nothrow) q1env();
     if (!h) return fail(Q1ENV_ERR_ALLOC, "q1env_create: out of host memory");
     h->cfg = *cfg;
@@ -570,7 +585,7 @@ int q1env_create(const q1env_config* cfg, int device, void* stream, q1env_t** ou
 
 int q1env_destroy(q1env_t* h) {
     if (!h) return Q1ENV_OK;
-    (void)hipSetDevice(h->device);
+    DeviceGuard guard(h->device);
     (void)hipStreamSynchronize(h->stream);
     if (h->gexec) (void)hipGraphExecDestroy(h->gexec);
     if (h->cap_stream) (void)hipStreamDestroy(h->cap_stream);
@@ -585,7 +600,7 @@ int q1env_destroy(q1env_t* h) {
 
 int q1env_set_stream(q1env_t* h, void* stream) {
     if (!h) return fail(Q1ENV_ERR_INVALID_ARG, "q1env_set_stream: null handle");
-    HIP_TRY(hipSetDevice(h->device));
+    DeviceGuard guard(h->device);
     if (h->gexec) { (void)hipGraphExecDestroy(h->gexec); h->gexec = nullptr; h->gkey.clear(); }
     if (h->own_stream) { (void)hipStreamDestroy(h->stream); h->own_stream = false; }
     h->stream = (hipStream_t)stream;          // NULL = the device's default (null) stream
@@ -594,6 +609,7 @@ int q1env_set_stream(q1env_t* h, void* stream) {
 
 int q1env_sync(q1env_t* h) {
     if (!h) return fail(Q1ENV_ERR_INVALID_ARG, "q1env_sync: null handle");
+    DeviceGuard guard(h->device);
     HIP_TRY(hipStreamSynchronize(h->stream));
     return Q1ENV_OK;
 }
@@ -642,6 +658,7 @@ static void launch_step(q1env* h, int fmt, const void* a, const void* b, int obs
 int q1env_step(q1env_t* h, int fmt, const void* a, const void* b, int obs_format, void* obs, float* reward,
                uint8_t* done, uint8_t* zs) {
     if (!h) return fail(Q1ENV_ERR_INVALID_ARG, "q1env_step: null handle");
+    DeviceGuard guard(h->device);
     if (int r = check_act(h, fmt, a, b, false)) return r;
     if (obs_format != Q1ENV_OBS_F32 && obs_format != Q1ENV_OBS_F64) return fail(Q1ENV_ERR_INVALID_ARG, "bad obs_format");
     launch_step(h, fmt, a, b, obs_format, obs, reward, done, zs);
@@ -655,7 +672,7 @@ int q1env_step_host(q1env_t* h, int fmt, const void* a, const void* b, int obs_f
     if (!h) return fail(Q1ENV_ERR_INVALID_ARG, "q1env_step_host: null handle");
     if (int r = check_act(h, fmt, a, b, false)) return r;
     if (obs_format != Q1ENV_OBS_F32 && obs_format != Q1ENV_OBS_F64) return fail(Q1ENV_ERR_INVALID_ARG, "bad obs_format");
-    HIP_TRY(hipSetDevice(h->device));
+    DeviceGuard guard(h->device);
     const size_t n = (size_t)h->p.n;
     const size_t ba = align_up(act_bytes_a(h, fmt), 256), bb = align_up(n * 4, 256);
     const size_t bo = align_up(n * 6 * (obs_format == Q1ENV_OBS_F32 ? 4 : 8), 256);
@@ -693,6 +710,7 @@ static void enqueue_many(q1env* h, int ticks, int fmt, const void* a, const void
 int q1env_step_many(q1env_t* h, int ticks, int fmt, const void* a, const void* b, int obs_format, void* obs,
                     float* reward, uint8_t* done, int out_stride, int use_graph) {
     if (!h) return fail(Q1ENV_ERR_INVALID_ARG, "q1env_step_many: null handle");
+    DeviceGuard guard(h->device);
     if (ticks <= 0) return fail(Q1ENV_ERR_INVALID_ARG, "ticks must be > 0");
     if (int r = check_act(h, fmt, a, b, false)) return r;
     if (obs_format != Q1ENV_OBS_F32 && obs_format != Q1ENV_OBS_F64) return fail(Q1ENV_ERR_INVALID_ARG, "bad obs_format");
@@ -730,6 +748,7 @@ int q1env_step_many(q1env_t* h, int ticks, int fmt, const void* a, const void* b
 int q1env_rollout(q1env_t* h, int ticks, int fmt, const void* a, const void* b, uint64_t seed, int obs_format,
                   void* obs, float* reward, uint8_t* done, int auto_reset, double* return_sum) {
     if (!h) return fail(Q1ENV_ERR_INVALID_ARG, "q1env_rollout: null handle");
+    DeviceGuard guard(h->device);
     if (ticks <= 0) return fail(Q1ENV_ERR_INVALID_ARG, "ticks must be > 0");
     if (int r = check_act(h, fmt, a, b, true)) return r;
     if (obs_format != Q1ENV_OBS_F32 && obs_format != Q1ENV_OBS_F64) return fail(Q1ENV_ERR_INVALID_ARG, "bad obs_format");
@@ -767,6 +786,7 @@ int q1env_rollout(q1env_t* h, int ticks, int fmt, const void* a, const void* b, 
 
 int q1env_observe(q1env_t* h, int obs_format, void* obs) {
     if (!h || !obs) return fail(Q1ENV_ERR_INVALID_ARG, "q1env_observe: null argument");
+    DeviceGuard guard(h->device);
     const int blk = block_for(h->p.n);
     if (obs_format == Q1ENV_OBS_F32)
         hipLaunchKernelGGL(observe_kernel<float>, grid_for(h->p.n, blk), dim3(blk), 0, h->stream, h->p, h->st, (float*)obs);
@@ -779,7 +799,7 @@ int q1env_observe(q1env_t* h, int obs_format, void* obs) {
 
 int q1env_observe_host(q1env_t* h, int obs_format, void* obs) {
     if (!h || !obs) return fail(Q1ENV_ERR_INVALID_ARG, "q1env_observe_host: null argument");
-    HIP_TRY(hipSetDevice(h->device));
+    DeviceGuard guard(h->device);
     const size_t bytes = (size_t)h->p.n * 6 * (obs_format == Q1ENV_OBS_F32 ? 4 : 8);
     if (int r = ensure_stage(h, bytes)) return r;
     if (int r = q1env_observe(h, obs_format, h->stage)) return r;
@@ -795,7 +815,7 @@ int q1env_reset_draws_host(q1env_t* h, int64_t count, const int32_t* idx, const 
     if (obs_format != Q1ENV_OBS_F32 && obs_format != Q1ENV_OBS_F64) return fail(Q1ENV_ERR_INVALID_ARG, "bad obs_format");
     if (idx) for (int64_t j = 0; j < count; ++j)
         if (idx[j] < 0 || idx[j] >= h->p.n) return fail(Q1ENV_ERR_INVALID_ARG, "q1env_reset_draws_host: index out of range");
-    HIP_TRY(hipSetDevice(h->device));
+    DeviceGuard guard(h->device);
     const size_t c = (size_t)count;
     const size_t bi = align_up(c * 4, 256), bz = align_up(c, 256), bd = align_up(c * 8, 256);
     const size_t bo = align_up(c * 6 * (obs_format == Q1ENV_OBS_F32 ? 4 : 8), 256);
@@ -827,6 +847,7 @@ int q1env_reset_draws_host(q1env_t* h, int64_t count, const int32_t* idx, const 
 int q1env_reset_philox(q1env_t* h, uint64_t seed, const uint64_t* counter_dev, const uint8_t* mask, int done_only, int obs_format,
                        void* obs) {
     if (!h) return fail(Q1ENV_ERR_INVALID_ARG, "q1env_reset_philox: null handle");
+    DeviceGuard guard(h->device);
     const int blk = block_for(h->p.n);
     const uint64_t counter = counter_dev ? 0 : h->tick_count;
     if (obs_format == Q1ENV_OBS_F32)
@@ -841,7 +862,7 @@ int q1env_reset_philox(q1env_t* h, uint64_t seed, const uint64_t* counter_dev, c
 }
 
 static int copy_state(q1env* h, const q1env_state* s, bool to_host) {
-    HIP_TRY(hipSetDevice(h->device));
+    DeviceGuard guard(h->device);
     const size_t n = (size_t)h->p.n;
     struct Item { void* host; void* dev; size_t bytes; };
     const Item items[] = {
@@ -882,7 +903,7 @@ int q1env_decode_host(q1env_t* h, int fmt, const void* a, const void* b, const f
                       double* yaw, int64_t* smove, int64_t* fmove, uint8_t* jump) {
     if (!h || !z_vel || !trem || !yaw || !smove || !fmove || !jump) return fail(Q1ENV_ERR_INVALID_ARG, "q1env_decode_host: null argument");
     if (int r = check_act(h, fmt, a, b, false)) return r;
-    HIP_TRY(hipSetDevice(h->device));
+    DeviceGuard guard(h->device);
     const size_t n = (size_t)h->p.n;
     const size_t ba = align_up(act_bytes_a(h, fmt), 256), b4 = align_up(n * 4, 256), b8 = align_up(n * 8, 256), b1 = align_up(n, 256);
     if (int r = ensure_stage(h, ba + 2 * b4 + 4 * b8 + b1)) return r;
@@ -911,7 +932,7 @@ int q1env_decoder_reset_host(q1env_t* h, int64_t count, const int32_t* idx, cons
     if (count <= 0 || (!idx && count > h->p.n)) return fail(Q1ENV_ERR_INVALID_ARG, "q1env_decoder_reset_host: bad count");
     if (idx) for (int64_t j = 0; j < count; ++j)
         if (idx[j] < 0 || idx[j] >= h->p.n) return fail(Q1ENV_ERR_INVALID_ARG, "q1env_decoder_reset_host: index out of range");
-    HIP_TRY(hipSetDevice(h->device));
+    DeviceGuard guard(h->device);
     const size_t c = (size_t)count;
     const size_t bi = align_up(c * 4, 256), bd = align_up(c * 8, 256);
     if (int r = ensure_stage(h, bi + bd)) return r;
@@ -936,7 +957,8 @@ int q1phys_apply_host(int device, int64_t n64, const double* yaw, const double* 
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
         return fail(Q1ENV_ERR_NO_DEVICE, "q1phys_apply_host: no HIP device visible (libq1env has no CPU fallback)");
-    HIP_TRY(hipSetDevice(device));
+    if (device < 0 || device >= ndev) return fail(Q1ENV_ERR_INVALID_ARG, "q1phys_apply_host: bad device index");
+    DeviceGuard guard(device);
     const size_t n = (size_t)n64;
     const size_t b8 = align_up(n * 8, 256), b1 = align_up(n, 256), b12 = align_up(n * 12, 256);
     char* d = nullptr;
@@ -972,6 +994,7 @@ int q1phys_apply_host(int device, int64_t n64, const double* yaw, const double* 
 int q1env_policy_sample(q1env_t* h, const float* logits, int row_stride, uint64_t seed, uint64_t counter,
                         const uint64_t* counter_dev, int deterministic, uint8_t* keys, float* mouse, float* logp) {
     if (!h || !logits || !keys) return fail(Q1ENV_ERR_INVALID_ARG, "q1env_policy_sample: null argument");
+    DeviceGuard guard(h->device);
     const int need = 2 * h->p.num_keys + (h->p.yaw_mode == 1 ? 2 : 0);
     if (h->p.yaw_mode == 2) return fail(Q1ENV_ERR_INVALID_ARG, "q1env_policy_sample: discrete yaw is not supported (continuous mouse or no mouse)");
     if (row_stride < need) return fail(Q1ENV_ERR_INVALID_ARG, "q1env_policy_sample: row_stride smaller than 2*num_keys + 2");
@@ -986,6 +1009,7 @@ int q1env_policy_sample(q1env_t* h, const float* logits, int row_stride, uint64_
 int q1env_gae(q1env_t* h, int ticks, const float* reward, const float* value, const uint8_t* done, float gamma, float lam,
               float* adv, float* vtarg) {
     if (!h || !reward || !value || !done || !adv || !vtarg || ticks <= 0) return fail(Q1ENV_ERR_INVALID_ARG, "q1env_gae: bad argument");
+    DeviceGuard guard(h->device);
     hipLaunchKernelGGL(gae_kernel, grid_for(h->p.n, 256), dim3(256), 0, h->stream, h->p.n, ticks, reward, value, done, gamma, lam, adv, vtarg);
     HIP_TRY(hipGetLastError());
     return Q1ENV_OK;
@@ -996,7 +1020,8 @@ int q1env_selftest_division(int device, uint64_t n, uint64_t seed, double c0, do
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
         return fail(Q1ENV_ERR_NO_DEVICE, "q1env_selftest_division: no HIP device visible");
-    HIP_TRY(hipSetDevice(device));
+    if (device < 0 || device >= ndev) return fail(Q1ENV_ERR_INVALID_ARG, "q1env_selftest_division: bad device index");
+    DeviceGuard guard(device);
     unsigned long long* d = nullptr;
     HIP_TRY(hipMalloc((void**)&d, 4 * sizeof(unsigned long long)));
     HIP_TRY(hipMemset(d, 0, 4 * sizeof(unsigned long long)));
@@ -1011,7 +1036,7 @@ int q1env_selftest_division(int device, uint64_t n, uint64_t seed, double c0, do
 
 int q1env_calibrate_traffic(q1env_t* h, int launches) {
     if (!h || launches <= 0) return fail(Q1ENV_ERR_INVALID_ARG, "q1env_calibrate_traffic: bad argument");
-    HIP_TRY(hipSetDevice(h->device));
+    DeviceGuard guard(h->device);
     if (int r = ensure_stage(h, arena_bytes((size_t)h->p.n))) return r;
     StatePtrs dst{};
     carve_into(h->stage, (size_t)h->p.n, dst);
@@ -1025,12 +1050,14 @@ int q1env_calibrate_traffic(q1env_t* h, int launches) {
 
 int q1env_timer_start(q1env_t* h) {
     if (!h) return fail(Q1ENV_ERR_INVALID_ARG, "q1env_timer_start: null handle");
+    DeviceGuard guard(h->device);
     HIP_TRY(hipEventRecord(h->ev0, h->stream));
     return Q1ENV_OK;
 }
 
 int q1env_timer_stop(q1env_t* h, float* ms) {
     if (!h || !ms) return fail(Q1ENV_ERR_INVALID_ARG, "q1env_timer_stop: null argument");
+    DeviceGuard guard(h->device);
     HIP_TRY(hipEventRecord(h->ev1, h->stream));
     HIP_TRY(hipEventSynchronize(h->ev1));
     HIP_TRY(hipEventElapsedTime(ms, h->ev0, h->ev1));

@@ -137,6 +137,13 @@ def _action_rows(actions, width):
         return np.array([[np.ravel(x)[0] for x in a] for a in actions], dtype=np.float64)
 
 
+def _checked_rows(actions, width, n):
+    rows = _action_rows(actions, width)
+    if rows.shape != (n, width):
+        raise ValueError(f"expected {n} actions of {width} components, got an array of shape {rows.shape}")
+    return rows
+
+
 class ActionDecoder:
     """Stateful action -> move-command decoder (env.py:183-291), state and arithmetic on the GPU.
 
@@ -301,6 +308,9 @@ class VectorPhysEnv(VectorEnv):
 
     def reset_at(self, index):
         c = self._config
+        index = int(index)
+        if index < 0:                                   # the reference indexes NumPy arrays, so negatives wrap
+            index += self.num_envs
         zero_start = bool(np.random.random() < c.zero_start_prob)                           # env.py:461
         # a zero start consumes no yaw / time / speed draw (env.py:462-467); the angle is always drawn (471)
         yaw = 0.0 if zero_start else np.random.uniform(*c.initial_yaw_range)
@@ -313,7 +323,7 @@ class VectorPhysEnv(VectorEnv):
 
     # ---- the tick ----------------------------------------------------------------------------
     def vector_step(self, actions):
-        rows = _action_rows(actions, self._dev.action_width)
+        rows = _checked_rows(actions, self._dev.action_width, self.num_envs)
         obs, reward, done, zero_start = self._dev.step_host(rows)
         self._step_num += 1
         self._cache = {}

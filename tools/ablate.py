@@ -1,4 +1,5 @@
-"""Time the rollout kernel (720 ticks/launch, packed actions, f32 obs out) for ablated builds: which part of a tick costs what."""
+"""Time the fused rollout kernel and the per-tick step kernel (packed actions, f32 obs out) at 65 536 and 1 M envs for one or
+more builds of libq1env.so given on the command line (used for A/B comparisons of kernel variants)."""
 import sys, os, shutil, subprocess, json
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 code = r'''
