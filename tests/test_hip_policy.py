@@ -169,3 +169,36 @@ def test_graph_captured_sampler_equals_eager_sampler():
     assert not torch.equal(eager[0]["keys"], eager[1]["keys"])           # replays draw fresh numbers
     for k in env_e:
         assert np.array_equal(env_e[k], env_g[k]), k
+
+
+def test_eval_sim_with_wr_policy_through_the_compat_api():
+    """analyse.eval_sim's protocol (one-env VectorPhysEnv + a parallel stand-alone ActionDecoder + player_state snapshots)
+    over the NumPy-compatible surface, with the reference's WR policy: ~5750 units in 720 frames, and the move commands
+    (yaw, smove, fmove, jump) it would send to the real game equal the oracle's decoder outputs frame for frame."""
+    import json
+    import os
+    from q1physrl_amd import evaluate as EV, policy as P
+    from q1physrl_amd.env import Config
+    w = dict(np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "wr_policy.npz")))
+    ec = json.loads(str(w["env_config_json"]))
+    ec["initial_yaw_range"] = tuple(ec["initial_yaw_range"])
+    cfg = Config(**{**ec, "num_envs": 1, "zero_start_prob": 1.0})
+    pol = P.load_rllib_fcnet_weights(P.Q1Policy(), w)
+    res = EV.eval_sim(EV.TorchTrainer(pol, ec["action_range"]), cfg)
+    assert res.obs.shape == (720, 6) and res.player_state.vel.shape == (720, 3) and res.smove.dtype == np.int64
+    total = float(np.sum(res.reward.astype(np.float64)))
+    assert 5600 < total < 5900, total
+    # the oracle, driven with the recorded actions: same env trajectory AND same decoder outputs
+    np.random.seed(0)
+    ora = O.OracleVectorEnv(O.OracleConfig(**{**ec, "num_envs": 1, "zero_start_prob": 1.0}))
+    dec = {"last_press": np.full((1, 4), -cfg.key_press_delay), "last_keys": np.zeros((1, 4), bool), "yaw": ora.yaw.copy()}
+    for t in range(720):
+        o = ora.observation()
+        assert np.array_equal(o[0], res.obs[t]), t
+        y, sm, fm, j = O.decode(ora.cfg, dec, res.action[t][None, :], o[:, 5], ora.t_rem)
+        assert y[0] == res.yaw[t] and sm[0] == res.smove[t] and fm[0] == res.fmove[t] and bool(j[0]) == bool(res.jump[t]), t
+        _, r, _, _ = ora.vector_step(res.action[t][None, :])
+        assert r[0] == res.reward[t]
+    cmds = res.move_commands()
+    assert set(np.unique(cmds["buttons"])) <= {0, 2} and np.abs(cmds["side"]).max() <= 1060 and cmds["forward"].max() <= 800
+    assert np.isfinite(res.wish_angle).all() and res.move_angle.shape == (720,)

@@ -27,6 +27,7 @@ ap.add_argument("--zero-start-prob", type=float, default=0.1)
 ap.add_argument("--seed", type=int, default=0)
 ap.add_argument("--out", default="")
 ap.add_argument("--no-graph", action="store_true")
+ap.add_argument("--save", default="", help="write the final policy weights (npz, RLlib fcnet naming) here")
 args = ap.parse_args()
 
 rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
@@ -77,3 +78,8 @@ if rank == 0:
     print(json.dumps(final), flush=True)
     if args.out:
         json.dump({"args": vars(args), "log": log, "final": final}, open(args.out, "w"))
+    if args.save:
+        import numpy as np
+        names = [(pol.pi[0], "fc_1"), (pol.pi[2], "fc_2"), (pol.pi[4], "fc_out"), (pol.vf[0], "fc_value_1"), (pol.vf[2], "fc_value_2"), (pol.vf[4], "value_out")]
+        np.savez_compressed(args.save, **{f"{n}.kernel": l.weight.detach().cpu().numpy().T for l, n in names},
+                            **{f"{n}.bias": l.bias.detach().cpu().numpy() for l, n in names})
