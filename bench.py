@@ -93,6 +93,16 @@ def cpu_baseline(n, action_range, budget_s=10.0, gpu_check=None):
             "max_abs_yaw_diff": float(np.abs(g["yaw"] - snap["yaw"]).max()),
             "vel_bit_identical_fraction": float(np.mean(np.stack([g["vel_x"], g["vel_y"], g["vel_z"]], 1).view(np.uint32) == snap["vel"].view(np.uint32))),
             "max_abs_y_travelled": float(np.abs(snap["dist"][:, 1]).max())}
+    # the reference's verbatim call pattern: RLlib hands vector_step a list of N tuples (scalars + (1,) arrays), which
+    # _fix_actions (env.py:221-223) converts with a Python double loop - 86 % of the reference's wall time at this size
+    rows = acts[0]
+    as_list = [tuple([int(x) for x in r[:4]] + [np.array([r[4]], dtype=np.float32)]) for r in rows]
+    t0 = time.perf_counter()
+    k_list = 3
+    for _ in range(k_list):
+        env.vector_step(as_list)
+    out["numpy_port_rllib_list_actions"] = {"value": n * k_list / (time.perf_counter() - t0), "unit": "env-steps/s", "cores": 1,
+                                            "sample": f"{k_list} ticks of {n} envs with list-of-tuples actions (per-element Python conversion)"}
     try:
         from oracle import c_oracle as CO
         threads = max(1, min(os.cpu_count() or 1, 64))

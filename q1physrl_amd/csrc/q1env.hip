@@ -349,6 +349,11 @@ selftest_division_kernel(uint64_t n, uint64_t seed, double c_extra0, double c_ex
         bad1 += (__double_as_longlong(a) != __double_as_longlong(b));
         const double a2 = div_shared(x, den, y), b2 = x / den;
         bad1 += (__double_as_longlong(a2) != __double_as_longlong(b2));
+        // friction quotient (phys.py:88-90): new_speed / speed with a float32 speed and 0 <= new_speed <= speed
+        const float spf = (float)(0.001 + 3000.0 * u);
+        const double ns = fmax(0.0, (double)spf - w * 60.0);
+        const double a3 = div_shared(ns, (double)spf, rcp_refined((double)spf)), b3 = ns / (double)spf;
+        bad1 += (__double_as_longlong(a3) != __double_as_longlong(b3));
     }
     {   // vel column: v float32 -> trunc(v/16)*16 / 200, float64 reference vs float32 shortcut
         const float v = (float)((2.0 * u - 1.0) * 40000.0);

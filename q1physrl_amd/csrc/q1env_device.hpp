@@ -110,7 +110,9 @@ struct TickOut {
 // makes it faithful, and by Markstein's theorem a second identical step yields RN(x/c) - bit-identical to the
 // IEEE division the reference performs, for 2^-960 < |x| < 2^960 (every quantity on this path), at 5 FMA-rate
 // instructions instead of the ~11-instruction v_div_scale/v_rcp/v_div_fmas/v_div_fixup sequence.
-// Zero keeps its sign (c > 0); NaN propagates.  Checked on-device against `/` by q1env_selftest_division.
+// x = +0 gives +0 and NaN propagates; x = -0 would give +0 instead of -0, which cannot occur here: every dividend on
+// this path is a sum that starts from +0.0, a difference of distinct times, or an angle that is never -0 (initial yaw
+// is 90 or a uniform draw).  Checked on-device against `/` by q1env_selftest_division.
 template <typename T> __device__ __forceinline__ T fma_t(T a, T b, T c);
 template <> __device__ __forceinline__ double fma_t<double>(double a, double b, double c) { return fma(a, b, c); }
 template <> __device__ __forceinline__ float fma_t<float>(float a, float b, float c) { return fmaf(a, b, c); }
@@ -122,7 +124,7 @@ __device__ __forceinline__ T div_const(T x, T c, T y) {
     q = fma_t<T>(r, y, q);
     r = fma_t<T>(-q, c, x);
     q = fma_t<T>(r, y, q);
-    return x == T(0) ? x : q;
+    return q;
 }
 
 // a / b for two numerators sharing one denominator: the refined reciprocal (v_rcp_f64 + two Newton steps, the
@@ -140,8 +142,7 @@ __device__ __forceinline__ double rcp_refined(double b) {
 __device__ __forceinline__ double div_shared(double a, double b, double y) {
     const double q = a * y;
     const double r = fma(-b, q, a);
-    const double res = fma(r, y, q);
-    return a == 0.0 ? a : res;
+    return fma(r, y, q);          // a = +0 -> +0; a is never -0 here (einsum sums start from +0.0)
 }
 
 // ---------------------------------------------------------------------------------------- state I/O
@@ -307,7 +308,8 @@ __device__ __forceinline__ void physics(Env& e, const Cmd& c, double m00, double
         const float control = fmaxf(speed, 100.0f);                     // phys.py:86
         const double drop = (dt * (double)control) * 4.0;               // phys.py:87
         const double ns = fmax(0.0, (double)speed - drop);              // phys.py:88
-        const double k = ns / (fr ? (double)speed : 1.0);               // phys.py:90
+        const double sd = fr ? (double)speed : 1.0;
+        const double k = div_shared(ns, sd, rcp_refined(sd));           // phys.py:90 (exact: operands in the normal range)
         hx = fr ? (double)e.vx * k : hx;
         hy = fr ? (double)e.vy * k : hy;
     }

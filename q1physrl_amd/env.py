@@ -332,6 +332,14 @@ class VectorPhysEnv(VectorEnv):
     def get_unwrapped(self):
         return []
 
+    def _get_obs(self):
+        """Current observation of every env, (N, 6) float64 (env.py:392-400), without stepping."""
+        return self._dev.observe_host()
+
+    def _get_obs_at(self, index):
+        """Current observation of one env, (6,) float64 (env.py:402-408)."""
+        return self._dev.observe_host()[index]
+
     def close(self):
         self._dev.close()
 

@@ -201,6 +201,8 @@ def test_state_roundtrip_and_error_behaviour():
     st["vel_x"][:] = np.arange(8, dtype=np.float32)
     e.set_state(**st)
     assert np.array_equal(e.get_state()["vel_x"], np.arange(8, dtype=np.float32))
+    assert np.array_equal(e._get_obs(), e._dev.observe_host()) and e._get_obs_at(3).shape == (6,)
+    e.reset_at(-1)                                      # negative index wraps like the reference's NumPy indexing
     with pytest.raises(ValueError):
         e.vector_step(np.zeros((7, 5)))                 # wrong batch
     with pytest.raises(TypeError):
