@@ -116,6 +116,40 @@ def cpu_baseline(n, action_range, budget_s=10.0, gpu_check=None):
     return out
 
 
+def size_sweep(dev_index, sizes=(262144, 1048576, 4194304), ticks=72, reps=4):
+    """step_kernel at larger batches (same Config, packed random actions resident in HBM, hipGraph of `ticks` launches):
+    where the per-tick kernel stops being launch/latency-bound.  Extra information next to the contract fields."""
+    import torch
+    from q1physrl_amd import _lib, env as E
+    from q1physrl_amd.device import DeviceEnv
+    d = torch.device("cuda", dev_index)
+    rows = []
+    for n in sizes:
+        cfg = E.Config(**{**E.Config.get_default().__dict__, "num_envs": n, "zero_start_prob": 1.0})
+        dev = DeviceEnv(cfg, device=dev_index)
+        keys = torch.randint(0, 16, (ticks, n), dtype=torch.uint8, device=d)
+        mouse = torch.rand((ticks, n), device=d) * 20.0 - 10.0
+        obs = torch.empty((n, 6), dtype=torch.float32, device=d)
+        rew = torch.empty((n,), dtype=torch.float32, device=d)
+        done = torch.empty((n,), dtype=torch.uint8, device=d)
+        torch.cuda.synchronize()
+
+        def go():
+            dev.step_many_dev(ticks, _lib.ACT_PACKED, keys.data_ptr(), mouse.data_ptr(), _lib.OBS_F32, obs.data_ptr(), rew.data_ptr(),
+                              done.data_ptr(), out_stride_ticks=0, use_graph=True)
+        go()
+        dev.sync()
+        dev.timer_start()
+        for _ in range(reps):
+            go()
+        us = dev.timer_stop() * 1e3 / (reps * ticks)
+        gbps = B_ALG * n / (us * 1e-6) / 1e9
+        rows.append({"envs": n, "us_per_tick": us, "env_steps_per_s": n / (us * 1e-6), "achieved_GBps": gbps, "frac": gbps / HBM_PEAK_GBPS})
+        dev.close()
+        del keys, mouse, obs, rew, done
+    return rows
+
+
 def load_profiled_traffic(mode, n):
     """HBM bytes per launch measured with rocprofv3 PMC passes (tools/profile_r1.sh -> profiles/*.json); None if absent."""
     path = os.path.join(ROOT, "profiles", "traffic.json")
@@ -259,6 +293,8 @@ def main():
             "launches": l2, "avg_launch_us": ev2 * 1e3 / l2,
             "note": ("one rollout_kernel launch per 720-tick episode, identical inputs/outputs" if other == "rollout"
                      else "one step_kernel launch per tick (hipGraph)")}
+    if rank == 0 and world == 1 and not args.no_secondary:
+        out["step_kernel_size_sweep"] = size_sweep(dev_index)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         def gpu_check(acts, k):
             """The GPU env on the oracle's own actions (float64 rows) for k ticks from a fresh zero start."""
