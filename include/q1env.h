@@ -200,6 +200,13 @@ int q1env_policy_sample(q1env_t* env, const float* logits_dev, int row_stride, u
 int q1env_gae(q1env_t* env, int ticks, const float* reward_dev, const float* value_dev, const uint8_t* done_dev,
               float gamma, float lam, float* adv_dev, float* vtarg_dev);
 
+/* Episode bookkeeping of one sampler tick (the reference's on_episode_end metric hook, q1physrl/train.py:54-57):
+ * ep_return double[N] += reward; for envs with done != 0 the finished return is added to this wave's slot of
+ * partials (double[ceil(N/64)][4] = episodes, zero-start episodes, return sum, zero-start return sum) and ep_return is
+ * cleared.  No atomics: sums are bit-reproducible; add the slots up on the host. */
+int q1env_episode_stats(q1env_t* env, const float* reward_dev, const uint8_t* done_dev, const uint8_t* zero_start_dev,
+                        double* ep_return_dev, double* partials_dev);
+
 /* ---- measurement ------------------------------------------------------------------------------
  * calibrate_traffic: `launches` launches of a pure copy kernel that reads the SoA state with step's own
  * load pattern and writes it to scratch: exactly 85 B read + 85 B written per env, for calibrating the

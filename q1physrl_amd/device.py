@@ -164,6 +164,9 @@ class DeviceEnv:
     def gae_dev(self, ticks, reward, value, done, gamma, lam, adv, vtarg):
         _lib.check(self._lib.q1env_gae(self._h, int(ticks), reward, value, done, float(gamma), float(lam), adv, vtarg))
 
+    def episode_stats_dev(self, reward, done, zero_start, ep_return, partials):
+        _lib.check(self._lib.q1env_episode_stats(self._h, reward, done, zero_start, ep_return, partials))
+
     def observe_dev(self, obs, obs_format=_lib.OBS_F32):
         _lib.check(self._lib.q1env_observe(self._h, obs_format, obs))
 

@@ -31,9 +31,9 @@ class GpuSampler:
         self.ep_return = torch.zeros((n,), dtype=torch.float64, device=d)
         self.autocast_dtype = autocast_dtype
         self.tick = torch.zeros((1,), dtype=torch.int64, device=d)      # Philox counter, advanced on the device
-        # device-resident episode statistics: [episodes, zero_start_episodes, return_sum, zero_start_return_sum]
-        self._stats = torch.zeros((4,), dtype=torch.float64, device=d)
-        self._zero = torch.zeros((), dtype=torch.float64, device=d)
+        # device-resident episode statistics, one slot per wave of envs: [episodes, zero_start_episodes, return_sum,
+        # zero_start_return_sum] (q1env_episode_stats; summed on the host on demand)
+        self._stats = torch.zeros(((n + 63) // 64, 4), dtype=torch.float64, device=d)
         self.use_graph = bool(use_graph)
         self._graphs = {}
         self.obs[0].copy_(env.reset())
@@ -59,13 +59,9 @@ class GpuSampler:
             # the row of EVERY env (fresh first observation for the envs it resets, current observation for the others)
             dev.step_dev(_lib.ACT_PACKED, self.keys[t].data_ptr(), self.mouse[t].data_ptr(), _lib.OBS_F32, 0,
                          self.reward[t].data_ptr(), self.done[t].data_ptr(), env.zero_start.data_ptr())
-            # episode bookkeeping (train.py:54-57: return of finished episodes, split by zero_start), all on device
-            self.ep_return.add_(self.reward[t])
-            fin = self.done[t].bool()
-            zs = fin & env.zero_start.bool()
-            self._stats.add_(torch.stack([fin.sum(), zs.sum(), torch.where(fin, self.ep_return, self._zero).sum(),
-                                          torch.where(zs, self.ep_return, self._zero).sum()]))
-            self.ep_return.masked_fill_(fin, 0.0)
+            # episode bookkeeping (train.py:54-57: return of finished episodes, split by zero_start): one HIP kernel
+            dev.episode_stats_dev(self.reward[t].data_ptr(), self.done[t].data_ptr(), env.zero_start.data_ptr(),
+                                  self.ep_return.data_ptr(), self._stats.data_ptr())
             self.tick.add_(1)
             dev.reset_philox_dev(env.seed, 0, True, _lib.OBS_F32, self.obs[t + 1].data_ptr(), counter_dev=cnt)   # done envs only
         _, v_last = self._forward(self.obs[self.T])
@@ -124,7 +120,7 @@ class GpuSampler:
 
     @property
     def stats(self):
-        e, z, r, zr = self._stats.tolist()          # the only synchronisation, on demand
+        e, z, r, zr = self._stats.sum(dim=0).tolist()          # the only synchronisation, on demand
         return {"episodes": int(e), "zero_start_episodes": int(z), "return_sum": r, "zero_start_return_sum": zr}
 
     def zero_start_total_reward_mean(self):

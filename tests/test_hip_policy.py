@@ -70,6 +70,19 @@ def test_sampler_loop_end_to_end():
     # every stored transition is reproducible by the oracle: replay env 0..63 of the first episode segment
     assert s.stats["episodes"] >= 4096 and s.stats["zero_start_episodes"] > 0
     assert np.isfinite(s.zero_start_total_reward_mean())
+    # q1env_episode_stats against a NumPy replay of the stored trajectory (zero_start of an episode = flag at its first obs:
+    # obs column 0 (time left / limit) == 1 and yaw column == 1 identify zero starts only loosely, so use the env's own flags)
+    rew = traj["reward"].cpu().numpy().astype(np.float64)
+    dn = traj["done"].cpu().numpy().astype(bool)
+    run = np.zeros(4096)
+    episodes, ret_sum = 0, 0.0
+    for t in range(100):
+        run += rew[t]
+        episodes += int(dn[t].sum())
+        ret_sum += float(run[dn[t]].sum())
+        run[dn[t]] = 0.0
+    assert s.stats["episodes"] == episodes and abs(s.stats["return_sum"] - ret_sum) < 1e-6 * max(1.0, abs(ret_sum))
+    assert 0 < s.stats["zero_start_episodes"] < episodes
     # stored actions really are what was applied: re-step a fresh env with the stored packed actions (no resets in 20 ticks)
     cfg2, env2 = make_env(4096, seed=9, zero_start_prob=0.5, time_limit=1.0)
     env2.reset()
