@@ -3,6 +3,7 @@
 // Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -shared q1env.hip -o libq1env.so
 // (-ffp-contract=off is part of the numerics contract: the reference never fuses multiply-add.)
 #include "q1env_device.hpp"
+#include "q1policy.hpp"
 #include "../../include/q1env.h"
 
 #include <cmath>
@@ -1053,6 +1054,27 @@ int q1env_episode_stats(q1env_t* h, const float* reward, const uint8_t* done, co
     if (!h || !reward || !done || !zero_start || !ep_return || !partials) return fail(Q1ENV_ERR_INVALID_ARG, "q1env_episode_stats: null argument");
     DeviceGuard guard(h->device);
     hipLaunchKernelGGL(episode_stats_kernel, grid_for(h->p.n, 256), dim3(256), 0, h->stream, h->p.n, reward, done, zero_start, ep_return, partials);
+    HIP_TRY(hipGetLastError());
+    return Q1ENV_OK;
+}
+
+int q1env_policy_forward(q1env_t* h, const float* obs, const float* w1, const float* b1, const uint16_t* w2_bf16, const float* b2,
+                         const float* w3, const float* b3, int out_dim, float* out) {
+    if (!h || !obs || !w1 || !b1 || !w2_bf16 || !b2 || !w3 || !b3 || !out) return fail(Q1ENV_ERR_INVALID_ARG, "q1env_policy_forward: null argument");
+    if (out_dim != 10 && out_dim != 1) return fail(Q1ENV_ERR_INVALID_ARG, "q1env_policy_forward: out_dim must be 10 (policy) or 1 (value)");
+    DeviceGuard guard(h->device);
+    static thread_local bool attr_set = false;
+    if (!attr_set) {
+        HIP_TRY(hipFuncSetAttribute((const void*)q1pol::mlp_forward_kernel<10>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)q1pol::LDS_TOTAL));
+        HIP_TRY(hipFuncSetAttribute((const void*)q1pol::mlp_forward_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)q1pol::LDS_TOTAL));
+        attr_set = true;
+    }
+    const unsigned chunks = (unsigned)((h->p.n + 127) / 128);
+    const dim3 g(chunks < 256u ? chunks : 256u), b(256);
+    if (out_dim == 10)
+        hipLaunchKernelGGL(q1pol::mlp_forward_kernel<10>, g, b, q1pol::LDS_TOTAL, h->stream, h->p.n, obs, w1, b1, w2_bf16, b2, w3, b3, out);
+    else
+        hipLaunchKernelGGL(q1pol::mlp_forward_kernel<1>, g, b, q1pol::LDS_TOTAL, h->stream, h->p.n, obs, w1, b1, w2_bf16, b2, w3, b3, out);
     HIP_TRY(hipGetLastError());
     return Q1ENV_OK;
 }

@@ -167,3 +167,39 @@ def load_rllib_fcnet_weights(policy: Q1Policy, weights) -> Q1Policy:
             layer.weight.copy_(w)
             layer.bias.copy_(b)
     return policy
+
+
+class FusedPolicyForward:
+    """Inference-side twin of a Q1Policy for the sampler loop: both networks evaluated by the fused gfx950 kernel
+    (q1env_policy_forward: float32 first/last layers and tanh, the 256x256 layer on the matrix cores with bf16 inputs and
+    float32 accumulation).  The float32 torch modules stay the learner's master copy; call refresh() after an optimiser step.
+    Callable like the module: fused(obs) -> (logits (N,10) float32, value (N,) float32)."""
+
+    def __init__(self, policy: Q1Policy, env):
+        self.policy, self.env = policy, env
+        n = env.num_envs
+        dev = env.device
+        self.logits = torch.empty((n, policy.pi[-1].out_features), dtype=torch.float32, device=dev)
+        self.value = torch.empty((n, 1), dtype=torch.float32, device=dev)
+        self._w = {}
+        self.refresh()
+
+    @torch.no_grad()
+    def refresh(self):
+        for name, net in (("pi", self.policy.pi), ("vf", self.policy.vf)):
+            l1, l2, l3 = net[0], net[2], net[4]
+            self._w[name] = (l1.weight.detach().float().contiguous(), l1.bias.detach().float().contiguous(),
+                             l2.weight.detach().to(torch.bfloat16).contiguous(), l2.bias.detach().float().contiguous(),
+                             l3.weight.detach().float().contiguous(), l3.bias.detach().float().contiguous())
+
+    def __call__(self, obs):
+        assert obs.dtype == torch.float32 and obs.is_contiguous() and obs.shape == (self.env.num_envs, 6)
+        d = self.env._dev
+        for name, out in (("pi", self.logits), ("vf", self.value)):
+            w1, b1, w2, b2, w3, b3 = self._w[name]
+            d.policy_forward_dev(obs.data_ptr(), w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr(), w3.data_ptr(),
+                                 b3.data_ptr(), out.shape[1], out.data_ptr())
+        return self.logits, self.value[:, 0]
+
+    def parameters(self):
+        return self.policy.parameters()

@@ -215,3 +215,56 @@ def test_eval_sim_with_wr_policy_through_the_compat_api():
     cmds = res.move_commands()
     assert set(np.unique(cmds["buttons"])) <= {0, 2} and np.abs(cmds["side"]).max() <= 1060 and cmds["forward"].max() <= 800
     assert np.isfinite(res.wish_angle).all() and res.move_angle.shape == (720,)
+
+
+def _emulate_fused_forward(net, obs):
+    """torch restatement of q1env_policy_forward's arithmetic: float32 layer 1 + tanh -> bf16, bf16 W2, float32 accumulate."""
+    import torch
+    l1, l2, l3 = net[0], net[2], net[4]
+    h1 = torch.tanh(obs @ l1.weight.T + l1.bias).to(torch.bfloat16).float()
+    w2 = l2.weight.to(torch.bfloat16).float()
+    h2 = torch.tanh(h1 @ w2.T + l2.bias)
+    return h2 @ l3.weight.T + l3.bias
+
+
+@pytest.mark.parametrize("n", [32768, 1000, 37])
+def test_fused_mfma_policy_forward(n):
+    """The matrix-core forward pass against (a) a torch emulation of its own mixed precision - this pins the MFMA operand /
+    accumulator layout, any mistake there is an O(1) error - and (b) the float32 torch modules (bf16 rounding only)."""
+    import json
+    import os
+    import torch
+    from q1physrl_amd import policy as P
+    torch.manual_seed(n)
+    cfg, env = make_env(n, seed=3)
+    pol = P.Q1Policy().cuda()
+    with torch.no_grad():                                   # asymmetric, well-scaled random weights (default init is tiny on the head)
+        for net in (pol.pi, pol.vf):
+            for layer in (net[0], net[2], net[4]):
+                layer.weight.copy_(torch.randn_like(layer.weight) * (1.5 / layer.in_features ** 0.5))
+                layer.bias.copy_(torch.randn_like(layer.bias) * 0.3)
+    fused = P.FusedPolicyForward(pol, env)
+    obs = (torch.randn((n, 6), device="cuda") * torch.tensor([0.5, 3.0, 0.3, 2.0, 2.0, 1.0], device="cuda")).contiguous()
+    logits, value = fused(obs)
+    torch.cuda.synchronize()
+    with torch.no_grad():
+        emu_l, emu_v = _emulate_fused_forward(pol.pi, obs), _emulate_fused_forward(pol.vf, obs)[:, 0]
+        ref_l, ref_v = pol(obs)
+    assert torch.isfinite(logits).all() and logits.shape == (n, 10) and value.shape == (n,)
+    assert float((logits - emu_l).abs().max()) < 2e-3 and float((value - emu_v).abs().max()) < 2e-3
+    assert float((logits - ref_l).abs().max()) < 0.08 and float((value - ref_v).abs().max()) < 0.08
+    # the WR policy through the fused forward still plays at its published level
+    w = dict(np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "wr_policy.npz")))
+    env.close()
+    if n == 1000:
+        from q1physrl_amd.env import Config
+        from q1physrl_amd.sampler import GpuSampler
+        from q1physrl_amd.tensor_env import TensorVectorEnv
+        ec = json.loads(str(w["env_config_json"]))
+        ec["initial_yaw_range"] = tuple(ec["initial_yaw_range"])
+        env2 = TensorVectorEnv(Config(**{**ec, "num_envs": 1024, "zero_start_prob": 1.0}), seed=7)
+        wr = P.load_rllib_fcnet_weights(P.Q1Policy(), w).cuda()
+        tr = GpuSampler(env2, P.FusedPolicyForward(wr, env2), horizon=720).collect()
+        total = float(tr["reward"].double().sum(0).mean())
+        assert 5600.0 < total < 5800.0, total
+        env2.close()

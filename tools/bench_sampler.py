@@ -14,11 +14,12 @@ PARAMS_YML = dict(action_range=10, allow_jump=True, allow_yaw=True, auto_jump=Fa
 
 for n in (32768, 262144):
   for use_graph in (False, True):
-    for ac in (None, torch.bfloat16):
+    for ac in (None, torch.bfloat16, "fused"):
         env = TensorVectorEnv(Config(num_envs=n, **PARAMS_YML), seed=1)
         pol = P.Q1Policy().cuda()
         T = 64
-        s = GpuSampler(env, pol, horizon=T, autocast_dtype=ac, use_graph=use_graph)
+        s = GpuSampler(env, P.FusedPolicyForward(pol, env) if ac == "fused" else pol, horizon=T,
+                       autocast_dtype=None if ac == "fused" else ac, use_graph=use_graph)
         s.collect(); torch.cuda.synchronize()
         t0 = time.perf_counter()
         reps = 3
@@ -34,6 +35,6 @@ for n in (32768, 262144):
                 env.step_tensor((keys[t], mouse[t])); env.reset_done()
         torch.cuda.synchronize()
         de = (time.perf_counter() - t1) / (reps * T)
-        print(f"n={n:7d} graph={int(use_graph)} policy={'fp32' if ac is None else 'bf16-autocast'}: {dt*1e6:8.1f} us/tick = {n/dt/1e6:8.2f} M env-steps/s; "
+        print(f"n={n:7d} graph={int(use_graph)} policy={'torch-fp32' if ac is None else ('fused-mfma' if ac == 'fused' else 'torch-bf16-autocast')}: {dt*1e6:8.1f} us/tick = {n/dt/1e6:8.2f} M env-steps/s; "
               f"env step+reset alone {de*1e6:7.1f} us/tick ({100*de/dt:4.1f} % of the tick)")
         env.close()

@@ -27,6 +27,7 @@ ap.add_argument("--zero-start-prob", type=float, default=0.1)
 ap.add_argument("--seed", type=int, default=0)
 ap.add_argument("--out", default="")
 ap.add_argument("--no-graph", action="store_true")
+ap.add_argument("--fused-policy", action="store_true", help="sample with the fused MFMA forward kernel (bf16 hidden layer)")
 ap.add_argument("--save", default="", help="write the final policy weights (npz, RLlib fcnet naming) here")
 args = ap.parse_args()
 
@@ -40,7 +41,8 @@ start, count = sharding.shard_range(args.envs, rank, world)
 cfg = Config(**{**Config.get_default().__dict__, "num_envs": count, "zero_start_prob": args.zero_start_prob})
 env = TensorVectorEnv(cfg, device=local, seed=args.seed + 1, env_index_base=start)
 pol = P.Q1Policy().cuda()
-smp = GpuSampler(env, pol, horizon=args.horizon, use_graph=not args.no_graph)
+fused = P.FusedPolicyForward(pol, env) if args.fused_policy else None
+smp = GpuSampler(env, fused if fused is not None else pol, horizon=args.horizon, use_graph=not args.no_graph)
 lrn = ppo.PPOLearner(pol, float(cfg.action_range), lr=args.lr, num_sgd_iter=args.epochs, minibatch_size=args.minibatch,
                      entropy_coeff=args.entropy, kl_target=args.kl_target, seed=args.seed + rank)
 log = []
@@ -52,6 +54,8 @@ for it in range(args.iters):
     adv, vtarg = smp.advantages(traj, lrn.gamma, lrn.lam)
     torch.cuda.synchronize(); t_sample = time.time() - ts
     st = lrn.update(traj, adv, vtarg)
+    if fused is not None:
+        fused.refresh()
     torch.cuda.synchronize(); t_iter = time.time() - ts
     cur = smp.stats
     dz = cur["zero_start_episodes"] - prev["zero_start_episodes"]
