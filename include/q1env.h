@@ -203,10 +203,11 @@ int q1env_gae(q1env_t* env, int ticks, const float* reward_dev, const float* val
 /* Fused forward pass of one network of the reference policy's shape (RLlib fcnet of data/checkpoints/wr: 6 -> 256 tanh ->
  * 256 tanh -> out_dim, out_dim = 10 policy logits or 1 value) for this handle's N envs: obs float[N][6] -> out float[N][out_dim].
  * Weights in torch nn.Linear layout: w1 float[256][6], b1 float[256], w2 BF16 bits [256][256] (row = output unit), b2 float[256],
- * w3 float[out_dim][256], b3 float[out_dim].  The 256x256 layer runs on the matrix cores (bf16 inputs, float32 accumulate);
- * the two small layers and tanh are float32.  Inference only (sampler loop); the learner keeps its float32 torch modules. */
+ * w3 BF16 bits [32][256] (rows >= out_dim zero), b3 float[out_dim].  All three layers run on the matrix cores: layer 1 as exact
+ * float32 MFMA, layers 2 and 3 with bf16 inputs and float32 accumulation; biases and tanh are float32.
+ * Inference only (sampler loop); the learner keeps its float32 torch modules. */
 int q1env_policy_forward(q1env_t* env, const float* obs_dev, const float* w1_dev, const float* b1_dev, const uint16_t* w2_bf16_dev,
-                         const float* b2_dev, const float* w3_dev, const float* b3_dev, int out_dim, float* out_dev);
+                         const float* b2_dev, const uint16_t* w3_bf16_dev, const float* b3_dev, int out_dim, float* out_dev);
 
 /* Episode bookkeeping of one sampler tick (the reference's on_episode_end metric hook, q1physrl/train.py:54-57):
  * ep_return double[N] += reward; for envs with done != 0 the finished return is added to this wave's slot of

@@ -1059,7 +1059,7 @@ int q1env_episode_stats(q1env_t* h, const float* reward, const uint8_t* done, co
 }
 
 int q1env_policy_forward(q1env_t* h, const float* obs, const float* w1, const float* b1, const uint16_t* w2_bf16, const float* b2,
-                         const float* w3, const float* b3, int out_dim, float* out) {
+                         const uint16_t* w3, const float* b3, int out_dim, float* out) {
     if (!h || !obs || !w1 || !b1 || !w2_bf16 || !b2 || !w3 || !b3 || !out) return fail(Q1ENV_ERR_INVALID_ARG, "q1env_policy_forward: null argument");
     if (out_dim != 10 && out_dim != 1) return fail(Q1ENV_ERR_INVALID_ARG, "q1env_policy_forward: out_dim must be 10 (policy) or 1 (value)");
     DeviceGuard guard(h->device);

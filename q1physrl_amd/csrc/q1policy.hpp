@@ -2,17 +2,20 @@
 // checkpoint, SURVEY.md section 2: obs 6 -> 256 tanh -> 256 tanh -> OUT, OUT = 10 logits or 1 value) for gfx950.
 //
 // This is the GEMM-shaped neighbour of the env hot path (the sampler tick is: this, q1env_policy_sample, q1env_step,
-// q1env_reset_philox), so it is the one place matrix cores are used:
-//   layer 1 (K = 6)    float32 VALU, computed on the fly directly in the MFMA operand layout, tanh, rounded to bf16
-//   layer 2 (256x256)  v_mfma_f32_32x32x16_bf16, float32 accumulate; computed TRANSPOSED (H2^T = W2 . H1^T) so that after the
-//                      MFMAs each lane owns one env (column) and 128 of its 256 hidden units (rows)
-//   layer 3 (K = 256)  float32 VALU on the accumulator registers + one cross-half shuffle; no LDS round trip of H2
-// One workgroup (4 waves, one per SIMD) keeps the whole network in LDS - W2 as bf16 [n][k] with rows padded to 528 B so the
-// 16-byte operand reads are bank-conflict free, W1 / biases / W3 as float32: 156 KB of the CU's 160 KB - and walks
-// 128-env chunks grid-stride, so the weights are fetched once per CU, not once per chunk.
-//
-// MFMA operand layout used (v_mfma_f32_32x32x16_bf16): A: lane l holds A[row = l & 31][k = 8*(l >> 5) + j], j = 0..7;
-// B: lane l holds B[k = 8*(l >> 5) + j][col = l & 31]; C/D: col = l & 31, row = (r & 3) + 8*(r >> 2) + 4*(l >> 5), r = 0..15.
+// q1env_reset_philox), so it is the one place matrix cores are used - for all three layers, computed TRANSPOSED
+// (hidden units are MFMA rows, envs are MFMA columns), so that the output of one layer is already distributed the way the
+// next layer's B operand needs it and activations never leave registers:
+//   layer 1  H1^T = W1ext . Xext^T      v_mfma_f32_32x32x2_f32 (exact float32; K = 8: six inputs, a 1 for the bias, a 0);
+//                                       W1ext ([input][k], 8 KB) is read from LDS, 4 dwords per lane per 32-row tile
+//   layer 2  H2^T = W2 . tanh(H1)^T     v_mfma_f32_32x32x16_bf16, float32 accumulate, accumulators start at the bias b2
+//   layer 3  Y^T  = W3 . tanh(H2)^T     v_mfma_f32_32x32x16_bf16 (rows = outputs, padded to 32), + b3 in float32
+// The C/D register layout of a 32x32 tile gives lane (c, h) the rows (r&3) + 8(r>>2) + 4h, r = 0..15, of column c, while a
+// B operand wants 8 consecutive K indices per lane.  Instead of shuffling activations, the K index of the NEXT layer's
+// weights is permuted once, when they are staged into LDS: within every 16 hidden units the four groups of four are stored
+// in the order (0, 2, 1, 3).  Then lane (c, h)'s accumulator registers 8u..8u+7 ARE its B operand of K-step 2t + u.
+// One workgroup (4 waves, one per SIMD) keeps W2 / W3 (bf16, rows padded by 16 B so the 16-byte operand reads are
+// bank-conflict free), W1ext and b2 in LDS - 157.5 KB of the CU's 160 KB - and walks 128-env chunks grid-stride, so the weights
+// are fetched once per CU, not once per chunk.  tanh = 1 - 2/(2^(2x log2 e) + 1) on v_exp_f32 / v_rcp_f32.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -21,125 +24,176 @@ namespace q1pol {
 
 constexpr int HID = 256;
 constexpr int OBS = 6;
-constexpr int W2_ROW_BYTES = HID * 2 + 16;            // 528: padded row stride of the bf16 W2 copy in LDS
-constexpr int MAX_OUT = 12;                           // W3 rows are padded to 12 floats (3 x 16 B) in LDS
-constexpr size_t LDS_W2 = (size_t)HID * W2_ROW_BYTES;                // 135168
-constexpr size_t LDS_W1 = (size_t)HID * 8 * 4;                       // [k][8]: 6 weights + bias + pad = 8192
-constexpr size_t LDS_B2 = (size_t)HID * 4;                           // 1024
-constexpr size_t LDS_W3 = (size_t)HID * MAX_OUT * 4;                 // 12288
-constexpr size_t LDS_TOTAL = LDS_W2 + LDS_W1 + LDS_B2 + LDS_W3 + 64; // 156736 B <= 163840
+constexpr int ROW_BYTES = HID * 2 + 16;               // 528: padded row stride of the bf16 weight rows in LDS
+constexpr size_t LDS_W2 = (size_t)HID * ROW_BYTES;    // 135168
+constexpr size_t LDS_W3 = (size_t)32 * ROW_BYTES;     // 16896 (output rows padded to one 32-row tile)
+constexpr size_t LDS_B2 = (size_t)HID * 4;            // 1024
+constexpr size_t LDS_W1 = (size_t)8 * HID * 4;        // 8192: W1ext as [input i = 0..7][k]
+constexpr size_t LDS_TOTAL = LDS_W2 + LDS_W3 + LDS_B2 + LDS_W1;    // 161280 B <= 163840
 
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-__device__ __forceinline__ uint32_t f32_to_bf16_bits(float f) {      // round-to-nearest-even, finite inputs
-    const uint32_t u = __float_as_uint(f);
-    return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
-}
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ float fast_tanh(float x) {                // 1 - 2 / (e^{2x} + 1): exact limits at +-inf
     const float t = __builtin_amdgcn_exp2f(x * 2.8853900817779268f); // e^{2x} = 2^{2x log2 e}
     return 1.0f - 2.0f * __builtin_amdgcn_rcpf(t + 1.0f);
 }
 
+// tanh of accumulator registers 8u .. 8u+7 -> the lane's bf16 B operand of K-step 2t + u (v_cvt_pk_bf16_f32, RNE)
+__device__ __forceinline__ bf16x8 activate(const f32x16& acc, int u) {
+    union { bf16x8 v; bf16x2 p[4]; } o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const f32x2 pr = {fast_tanh(acc[8 * u + 2 * j]), fast_tanh(acc[8 * u + 2 * j + 1])};
+        o.p[j] = __builtin_convertvector(pr, bf16x2);
+    }
+    return o.v;
+}
+
+// One 32-row tile of layer 1 on the float32 matrix path: rows k = 32t + col, A operand of step s = W1ext[k][2s + half].
+__device__ __forceinline__ f32x16 layer1_tile(const float* l_w1, const float (&x1)[4], uint32_t t, uint32_t col, uint32_t half) {
+    f32x16 d1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) d1[r] = 0.0f;
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+        d1 = __builtin_amdgcn_mfma_f32_32x32x2f32(l_w1[(2u * s + half) * HID + t * 32u + col], x1[s], d1, 0, 0, 0);
+    return d1;
+}
+
+// Stage `rows` rows of a bf16 [rows][256] matrix into LDS with the (0,2,1,3) group permutation of every 16 columns.
+__device__ __forceinline__ void stage_permuted(unsigned char* dst, const uint16_t* __restrict__ src, uint32_t rows, uint32_t tid) {
+    for (uint32_t c = tid; c < rows * 64u; c += 256u) {              // 64 groups of 4 bf16 (8 B) per row
+        const uint32_t row = c >> 6, g = c & 63u;
+        const uint32_t gs = (g & ~3u) | (((g & 1u) << 1) | ((g >> 1) & 1u));   // dest group g <- source group (0,2,1,3)[g & 3]
+        const uint2 v = reinterpret_cast<const uint2*>(src)[row * 64u + gs];
+        *reinterpret_cast<uint2*>(dst + (size_t)row * ROW_BYTES + g * 8u) = v;
+    }
+}
+
 // w1: float[HID][OBS] (torch Linear(6,256).weight), b1: float[HID], w2: bf16 bits [HID n][HID k] (Linear(256,256).weight),
-// b2: float[HID], w3: float[out_dim][HID] (Linear(256,out).weight), b3: float[out_dim]; obs float[n][6]; out float[n][out_dim].
+// b2: float[HID], w3: bf16 bits [32][HID] (Linear(256,out).weight in rows 0..out-1, zero rows after), b3: float[out_dim];
+// obs float[n][6]; out float[n][out_dim].
 template <int OUT>
 __global__ void __launch_bounds__(256, 1)
 mlp_forward_kernel(int n, const float* __restrict__ obs, const float* __restrict__ w1, const float* __restrict__ b1,
-                   const uint16_t* __restrict__ w2, const float* __restrict__ b2, const float* __restrict__ w3,
+                   const uint16_t* __restrict__ w2, const float* __restrict__ b2, const uint16_t* __restrict__ w3,
                    const float* __restrict__ b3, float* __restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     unsigned char* l_w2 = lds;
-    float* l_w1 = reinterpret_cast<float*>(lds + LDS_W2);            // [k][8] = w1[k][0..5], b1[k], 0
-    float* l_b2 = reinterpret_cast<float*>(lds + LDS_W2 + LDS_W1);
-    float* l_w3 = reinterpret_cast<float*>(lds + LDS_W2 + LDS_W1 + LDS_B2);   // [n][MAX_OUT]
-    float* l_b3 = reinterpret_cast<float*>(lds + LDS_W2 + LDS_W1 + LDS_B2 + LDS_W3);
+    unsigned char* l_w3 = lds + LDS_W2;
+    float* l_b2 = reinterpret_cast<float*>(lds + LDS_W2 + LDS_W3);
+    float* l_w1 = reinterpret_cast<float*>(lds + LDS_W2 + LDS_W3 + LDS_B2);   // [i][k]: inputs 0..5, bias (input 6 == 1), 0
 
-    // ---- stage the network into LDS once per workgroup (16-byte global loads, coalesced)
     const uint32_t tid = threadIdx.x;
-    for (uint32_t c = tid; c < HID * (HID * 2 / 16); c += 256) {     // 256 rows x 32 chunks of 16 B
-        const uint32_t row = c >> 5, ch = c & 31u;
-        const uint4 v = reinterpret_cast<const uint4*>(w2)[c];
-        *reinterpret_cast<uint4*>(l_w2 + (size_t)row * W2_ROW_BYTES + ch * 16) = v;
-    }
-    {
-        const uint32_t k = tid;                                       // HID == blockDim.x == 256
-        float4 lo = make_float4(w1[k * OBS + 0], w1[k * OBS + 1], w1[k * OBS + 2], w1[k * OBS + 3]);
-        float4 hi = make_float4(w1[k * OBS + 4], w1[k * OBS + 5], b1[k], 0.0f);
-        reinterpret_cast<float4*>(l_w1)[k * 2] = lo;
-        reinterpret_cast<float4*>(l_w1)[k * 2 + 1] = hi;
-        l_b2[k] = b2[k];
+    stage_permuted(l_w2, w2, HID, tid);
+    stage_permuted(l_w3, w3, 32, tid);
+    l_b2[tid] = b2[tid];                                             // HID == blockDim.x
 #pragma unroll
-        for (int o = 0; o < MAX_OUT; ++o) l_w3[k * MAX_OUT + o] = (o < OUT) ? w3[(size_t)o * HID + k] : 0.0f;
-        if (k < MAX_OUT) l_b3[k] = (k < (uint32_t)OUT) ? b3[k] : 0.0f;
-    }
-    __syncthreads();
-
+    for (int i = 0; i < OBS; ++i) l_w1[i * HID + tid] = w1[tid * OBS + i];
+    l_w1[6 * HID + tid] = b1[tid];
+    l_w1[7 * HID + tid] = 0.0f;
     const uint32_t lane = tid & 63u, wave = tid >> 6;
     const uint32_t col = lane & 31u, half = lane >> 5;
+    __syncthreads();
+
     const uint32_t nchunks = ((uint32_t)n + 127u) / 128u;
+    // observations of the NEXT chunk are requested while the current one is computed (one wave per SIMD: a global load
+    // issued at the top of a chunk would otherwise expose its whole HBM latency once per chunk)
+    float xn[3];
+    {
+        const uint32_t e0 = blockIdx.x * 128u + wave * 32u + col;
+#pragma unroll
+        for (int s = 0; s < 3; ++s) xn[s] = (blockIdx.x < nchunks && e0 < (uint32_t)n) ? obs[(size_t)e0 * OBS + 2u * s + half] : 0.0f;
+    }
     for (uint32_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
         const uint32_t env = chunk * 128u + wave * 32u + col;
         const bool live = env < (uint32_t)n;
-        float x[OBS];
+        float x1[4];                                                 // B operands: Xext[env][2s + half]
 #pragma unroll
-        for (int i = 0; i < OBS; ++i) x[i] = live ? obs[(size_t)env * OBS + i] : 0.0f;
+        for (int s = 0; s < 3; ++s) x1[s] = xn[s];
+        x1[3] = half ? 0.0f : 1.0f;
+        {
+            const uint32_t en = env + gridDim.x * 128u;
+            const bool more = chunk + gridDim.x < nchunks && en < (uint32_t)n;
+#pragma unroll
+            for (int s = 0; s < 3; ++s) xn[s] = more ? obs[(size_t)en * OBS + 2u * s + half] : 0.0f;
+        }
 
-        f32x16 acc[8];
+        f32x16 acc[8];                                               // H2^T pre-activations, start at b2
 #pragma unroll
         for (int t = 0; t < 8; ++t)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+            for (int q = 0; q < 4; ++q) {
+                const float4 b = *reinterpret_cast<const float4*>(l_b2 + t * 32 + 8 * q + 4 * half);   // rows 8q + 4h + (0..3)
+                acc[t][4 * q + 0] = b.x; acc[t][4 * q + 1] = b.y; acc[t][4 * q + 2] = b.z; acc[t][4 * q + 3] = b.w;
+            }
 
-#pragma unroll 2
-        for (int kk = 0; kk < HID / 16; ++kk) {
-            // layer 1 for this lane's env and its 8 hidden units k = 16*kk + 8*half + j, straight into the B operand
-            bf16x8 bfrag;
+        // Software pipeline over the eight 32-row tiles of H1: while the sixteen bf16 MFMAs of tile t1 run on the matrix
+        // pipe, the VALU computes tanh of tile t1+1 (one wave per SIMD: nothing else could hide either behind the other).
+        bf16x8 cur0, cur1;
+        {
+            const f32x16 d1 = layer1_tile(l_w1, x1, 0u, col, half);
+            cur0 = activate(d1, 0); cur1 = activate(d1, 1);
+        }
+        // A operands (W2 rows) are fetched from LDS one K-step AHEAD of the MFMAs that consume them: with a single wave
+        // per SIMD an LDS read issued right before its MFMA exposes its full latency 144 times per tile (measured: 48 %
+        // of the wave's cycles in s_waitcnt).
+        const unsigned char* wrow = l_w2 + (size_t)col * ROW_BYTES + half * 16u;      // + t2 * 32 rows, + K-step * 32 B
+        bf16x8 a_even[8], a_odd[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const uint32_t k = (uint32_t)kk * 16u + half * 8u + (uint32_t)j;
-                const float4 lo = reinterpret_cast<const float4*>(l_w1)[k * 2];
-                const float4 hi = reinterpret_cast<const float4*>(l_w1)[k * 2 + 1];
-                float s = hi.z;
-                s = fmaf(x[0], lo.x, s); s = fmaf(x[1], lo.y, s); s = fmaf(x[2], lo.z, s); s = fmaf(x[3], lo.w, s);
-                s = fmaf(x[4], hi.x, s); s = fmaf(x[5], hi.y, s);
-                bfrag[j] = (short)f32_to_bf16_bits(fast_tanh(s));
-            }
-            // layer 2, transposed: acc[t] (+)= W2[n = 32t + row][k] . H1^T[k][env]
+        for (int t2 = 0; t2 < 8; ++t2) a_even[t2] = *reinterpret_cast<const bf16x8*>(wrow + (size_t)t2 * 32u * ROW_BYTES);
+#pragma unroll 1
+        for (int t1 = 0; t1 < 8; ++t1) {
+            const uint32_t q0 = 2u * (uint32_t)t1;
+            // phase A: request the odd K-step's operands      (sched_barrier: the compiler must not sink these reads
+#pragma unroll                                          //   back down next to their MFMAs)
+            for (int t2 = 0; t2 < 8; ++t2)
+                a_odd[t2] = *reinterpret_cast<const bf16x8*>(wrow + (size_t)t2 * 32u * ROW_BYTES + (q0 + 1u) * 32u);
+            __builtin_amdgcn_sched_barrier(0);
+            // phase B: even K-step on the matrix pipe; layer 1 + tanh of the NEXT tile on the VALU meanwhile
+            const f32x16 dn = layer1_tile(l_w1, x1, (uint32_t)(t1 + 1) & 7u, col, half);   // last pass recomputes tile 0, unused
 #pragma unroll
-            for (int t = 0; t < 8; ++t) {
-                const uint32_t nrow = (uint32_t)t * 32u + col;        // A operand: row = lane & 31
-                const bf16x8 afrag = *reinterpret_cast<const bf16x8*>(l_w2 + (size_t)nrow * W2_ROW_BYTES + ((uint32_t)kk * 16u + half * 8u) * 2u);
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag, bfrag, acc[t], 0, 0, 0);
-            }
+            for (int t2 = 0; t2 < 8; ++t2) acc[t2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_even[t2], cur0, acc[t2], 0, 0, 0);
+            const bf16x8 nxt0 = activate(dn, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            // phase C: request the next even K-step's operands
+#pragma unroll
+            for (int t2 = 0; t2 < 8; ++t2)
+                a_even[t2] = *reinterpret_cast<const bf16x8*>(wrow + (size_t)t2 * 32u * ROW_BYTES + ((q0 + 2u) & 15u) * 32u);
+            __builtin_amdgcn_sched_barrier(0);
+            // phase D: odd K-step; second half of the next tile's tanh
+#pragma unroll
+            for (int t2 = 0; t2 < 8; ++t2) acc[t2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_odd[t2], cur1, acc[t2], 0, 0, 0);
+            const bf16x8 nxt1 = activate(dn, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            cur0 = nxt0; cur1 = nxt1;
         }
 
-        // layer 3 on the accumulators: this lane owns env `col` and hidden units n = 32t + (r&3) + 8(r>>2) + 4*half
-        float o_acc[OUT];
+        f32x16 y, y2;                                                // two chains: consecutive MFMAs do not wait on each other
 #pragma unroll
-        for (int o = 0; o < OUT; ++o) o_acc[o] = 0.0f;
+        for (int r = 0; r < 16; ++r) { y[r] = 0.0f; y2[r] = 0.0f; }
 #pragma unroll
-        for (int t = 0; t < 8; ++t) {
+        for (int t2 = 0; t2 < 8; ++t2) {
+            const bf16x8 f0 = activate(acc[t2], 0), f1 = activate(acc[t2], 1);
+            const unsigned char* rowp = l_w3 + (size_t)col * ROW_BYTES + ((uint32_t)(2 * t2) * 16u + half * 8u) * 2u;
+            y = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(rowp), f0, y, 0, 0, 0);
+            y2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(rowp + 32), f1, y2, 0, 0, 0);
+            if (t2 & 1) __builtin_amdgcn_sched_barrier(0);           // bound the live ranges
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) y[r] += y2[r];
+        // y[r] = output row (r&3) + 8(r>>2) + 4*half of env `col`
+        if (live) {
+            float* dst = out + (size_t)env * OUT;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const uint32_t nn = (uint32_t)t * 32u + (uint32_t)(r & 3) + 8u * (uint32_t)(r >> 2) + 4u * half;
-                const float h2 = fast_tanh(acc[t][r] + l_b2[nn]);
-                const float4* wrow = reinterpret_cast<const float4*>(l_w3 + nn * MAX_OUT);
-                float w[MAX_OUT];
-                *reinterpret_cast<float4*>(w) = wrow[0];
-                if (OUT > 4) *reinterpret_cast<float4*>(w + 4) = wrow[1];
-                if (OUT > 8) *reinterpret_cast<float4*>(w + 8) = wrow[2];
-#pragma unroll
-                for (int o = 0; o < OUT; ++o) o_acc[o] = fmaf(h2, w[o], o_acc[o]);
-                if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // keep the LDS reads of later rows from being hoisted
-            }                                                          // (unbounded hoisting spilled the accumulators)
-        }
-#pragma unroll
-        for (int o = 0; o < OUT; ++o) o_acc[o] += __shfl_xor(o_acc[o], 32, 64);      // the two halves own disjoint hidden units
-        if (half == 0 && live) {
-#pragma unroll
-            for (int o = 0; o < OUT; ++o) out[(size_t)env * OUT + o] = o_acc[o] + l_b3[o];
+                const int o_lo = (r & 3) + 8 * (r >> 2);             // row for half = 0; half = 1 adds 4
+                if (o_lo < OUT && half == 0) dst[o_lo] = y[r] + b3[o_lo];
+                if (o_lo + 4 < OUT && half == 1) dst[o_lo + 4] = y[r] + b3[o_lo + 4];
+            }
         }
     }
 }

@@ -171,8 +171,8 @@ def load_rllib_fcnet_weights(policy: Q1Policy, weights) -> Q1Policy:
 
 class FusedPolicyForward:
     """Inference-side twin of a Q1Policy for the sampler loop: both networks evaluated by the fused gfx950 kernel
-    (q1env_policy_forward: float32 first/last layers and tanh, the 256x256 layer on the matrix cores with bf16 inputs and
-    float32 accumulation).  The float32 torch modules stay the learner's master copy; call refresh() after an optimiser step.
+    (q1env_policy_forward: all three layers on the matrix cores - layer 1 exact float32, layers 2 and 3 with bf16 inputs and
+    float32 accumulation; biases and tanh float32).  The float32 torch modules stay the learner's master copy; call refresh() after an optimiser step.
     Callable like the module: fused(obs) -> (logits (N,10) float32, value (N,) float32)."""
 
     def __init__(self, policy: Q1Policy, env):
@@ -188,9 +188,11 @@ class FusedPolicyForward:
     def refresh(self):
         for name, net in (("pi", self.policy.pi), ("vf", self.policy.vf)):
             l1, l2, l3 = net[0], net[2], net[4]
+            w3 = torch.zeros((32, l3.in_features), dtype=torch.bfloat16, device=l3.weight.device)
+            w3[:l3.out_features] = l3.weight.detach().to(torch.bfloat16)          # output rows padded to one 32-row MFMA tile
             self._w[name] = (l1.weight.detach().float().contiguous(), l1.bias.detach().float().contiguous(),
                              l2.weight.detach().to(torch.bfloat16).contiguous(), l2.bias.detach().float().contiguous(),
-                             l3.weight.detach().float().contiguous(), l3.bias.detach().float().contiguous())
+                             w3.contiguous(), l3.bias.detach().float().contiguous())
 
     def __call__(self, obs):
         assert obs.dtype == torch.float32 and obs.is_contiguous() and obs.shape == (self.env.num_envs, 6)

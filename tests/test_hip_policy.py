@@ -218,13 +218,12 @@ def test_eval_sim_with_wr_policy_through_the_compat_api():
 
 
 def _emulate_fused_forward(net, obs):
-    """torch restatement of q1env_policy_forward's arithmetic: float32 layer 1 + tanh -> bf16, bf16 W2, float32 accumulate."""
+    """torch restatement of q1env_policy_forward's arithmetic: float32 layer 1; tanh -> bf16; bf16 W2 / W3; float32 accumulate."""
     import torch
     l1, l2, l3 = net[0], net[2], net[4]
     h1 = torch.tanh(obs @ l1.weight.T + l1.bias).to(torch.bfloat16).float()
-    w2 = l2.weight.to(torch.bfloat16).float()
-    h2 = torch.tanh(h1 @ w2.T + l2.bias)
-    return h2 @ l3.weight.T + l3.bias
+    h2 = torch.tanh(h1 @ l2.weight.to(torch.bfloat16).float().T + l2.bias).to(torch.bfloat16).float()
+    return h2 @ l3.weight.to(torch.bfloat16).float().T + l3.bias
 
 
 @pytest.mark.parametrize("n", [32768, 1000, 37])
@@ -251,8 +250,10 @@ def test_fused_mfma_policy_forward(n):
         emu_l, emu_v = _emulate_fused_forward(pol.pi, obs), _emulate_fused_forward(pol.vf, obs)[:, 0]
         ref_l, ref_v = pol(obs)
     assert torch.isfinite(logits).all() and logits.shape == (n, 10) and value.shape == (n,)
-    assert float((logits - emu_l).abs().max()) < 2e-3 and float((value - emu_v).abs().max()) < 2e-3
-    assert float((logits - ref_l).abs().max()) < 0.08 and float((value - ref_v).abs().max()) < 0.08
+    # (two bf16 roundings: a float32-level difference in a pre-activation can flip one bf16 rounding -> up to ~1e-2)
+    assert float((logits - emu_l).abs().max()) < 1e-2 and float((value - emu_v).abs().max()) < 1e-2
+    assert float((logits - emu_l).abs().mean()) < 2e-4
+    assert float((logits - ref_l).abs().max()) < 0.12 and float((value - ref_v).abs().max()) < 0.12
     # the WR policy through the fused forward still plays at its published level
     w = dict(np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "wr_policy.npz")))
     env.close()
