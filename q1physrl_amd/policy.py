@@ -186,13 +186,19 @@ class FusedPolicyForward:
 
     @torch.no_grad()
     def refresh(self):
+        """Copy the master weights into the kernel's persistent device buffers IN PLACE: a captured hipGraph of the
+        sampler holds these addresses, so they must never be re-allocated."""
         for name, net in (("pi", self.policy.pi), ("vf", self.policy.vf)):
             l1, l2, l3 = net[0], net[2], net[4]
-            w3 = torch.zeros((32, l3.in_features), dtype=torch.bfloat16, device=l3.weight.device)
-            w3[:l3.out_features] = l3.weight.detach().to(torch.bfloat16)          # output rows padded to one 32-row MFMA tile
-            self._w[name] = (l1.weight.detach().float().contiguous(), l1.bias.detach().float().contiguous(),
-                             l2.weight.detach().to(torch.bfloat16).contiguous(), l2.bias.detach().float().contiguous(),
-                             w3.contiguous(), l3.bias.detach().float().contiguous())
+            if name not in self._w:
+                dev = l1.weight.device
+                self._w[name] = (torch.empty_like(l1.weight, dtype=torch.float32), torch.empty_like(l1.bias, dtype=torch.float32),
+                                 torch.empty_like(l2.weight, dtype=torch.bfloat16), torch.empty_like(l2.bias, dtype=torch.float32),
+                                 torch.zeros((32, l3.in_features), dtype=torch.bfloat16, device=dev),   # rows padded to one MFMA tile
+                                 torch.empty_like(l3.bias, dtype=torch.float32))
+            w1, b1, w2, b2, w3, b3 = self._w[name]
+            w1.copy_(l1.weight); b1.copy_(l1.bias); w2.copy_(l2.weight); b2.copy_(l2.bias)
+            w3[:l3.out_features].copy_(l3.weight); b3.copy_(l3.bias)
 
     def __call__(self, obs):
         assert obs.dtype == torch.float32 and obs.is_contiguous() and obs.shape == (self.env.num_envs, 6)

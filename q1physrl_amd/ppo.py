@@ -76,8 +76,11 @@ class PPOLearner:
         """SGD epochs over one trajectory batch; adv/vtarg from q1env_gae.  Returns averaged stats (python floats)."""
         dev = adv.device
         t, n = traj["reward"].shape
-        with torch.no_grad():
-            old_logits, _ = self.policy(traj["obs"][:t].reshape(t * n, 6))
+        if "logits" in traj:                    # the behaviour policy's own outputs (exact even when sampling ran in bf16)
+            old_logits = traj["logits"].reshape(t * n, -1)
+        else:
+            with torch.no_grad():
+                old_logits, _ = self.policy(traj["obs"][:t].reshape(t * n, 6))
         b = self._flatten(traj, adv, vtarg, old_logits)
         a = b["adv"]
         mean, sq = a.mean(), (a * a).mean()

@@ -25,6 +25,7 @@ class GpuSampler:
         self.keys = torch.empty((t, n), dtype=torch.uint8, device=d)
         self.mouse = torch.empty((t, n), dtype=torch.float32, device=d)
         self.logp = torch.empty((t, n), dtype=torch.float32, device=d)
+        self.logits = torch.empty((t, n, 2 * env.num_keys + 2), dtype=torch.float32, device=d)   # behaviour-policy outputs
         self.value = torch.empty((t + 1, n), dtype=torch.float32, device=d)
         self.reward = torch.empty((t, n), dtype=torch.float32, device=d)
         self.done = torch.empty((t, n), dtype=torch.uint8, device=d)
@@ -53,6 +54,8 @@ class GpuSampler:
         for t in range(self.T):
             logits, value = self._forward(self.obs[t])
             self.value[t].copy_(value)
+            self.logits[t].copy_(logits)          # what the actions were really sampled from (the learner's "old" policy)
+            logits = self.logits[t]
             dev.policy_sample_dev(logits.data_ptr(), logits.shape[1], env.seed, 0, self.keys[t].data_ptr(),
                                   self.mouse[t].data_ptr(), self.logp[t].data_ptr(), deterministic, counter_dev=cnt)
             # tick: reward / done / zero_start only - the observation comes from the reset kernel below, which writes
@@ -82,8 +85,8 @@ class GpuSampler:
                 self._capture(key)
             else:
                 self._graphs[key].replay()
-        return {"obs": self.obs, "keys": self.keys, "mouse": self.mouse, "logp": self.logp, "value": self.value,
-                "reward": self.reward, "done": self.done}
+        return {"obs": self.obs, "keys": self.keys, "mouse": self.mouse, "logp": self.logp, "logits": self.logits,
+                "value": self.value, "reward": self.reward, "done": self.done}
 
     def _capture(self, deterministic):
         """Capture the horizon into a hipGraph.  Capture only records: the state a replay starts from must be the state

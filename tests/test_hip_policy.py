@@ -269,3 +269,29 @@ def test_fused_mfma_policy_forward(n):
         total = float(tr["reward"].double().sum(0).mean())
         assert 5600.0 < total < 5800.0, total
         env2.close()
+
+
+def test_fused_policy_refresh_keeps_buffer_addresses():
+    """A captured sampler graph holds the kernel's weight-buffer addresses: refresh() after an optimiser step must update
+    them in place (re-allocating made graph replays read freed memory -> NaN logits)."""
+    import torch
+    from q1physrl_amd import policy as P
+    from q1physrl_amd.sampler import GpuSampler
+    cfg, env = make_env(2048, seed=4, zero_start_prob=0.5)
+    pol = P.Q1Policy().cuda()
+    fused = P.FusedPolicyForward(pol, env)
+    ptrs = [t.data_ptr() for w in fused._w.values() for t in w]
+    s = GpuSampler(env, fused, horizon=16, use_graph=True)
+    s.collect()
+    with torch.no_grad():
+        for p in pol.parameters():
+            p.add_(0.01 * torch.randn_like(p))
+    fused.refresh()
+    assert ptrs == [t.data_ptr() for w in fused._w.values() for t in w]
+    tr = s.collect()                                           # graph replay with the new weights
+    torch.cuda.synchronize()
+    assert torch.isfinite(tr["logits"]).all() and torch.isfinite(tr["logp"]).all()
+    with torch.no_grad():
+        ref, _ = pol(tr["obs"][3])
+    assert float((tr["logits"][3] - ref).abs().max()) < 0.05   # replay really used the refreshed weights
+    env.close()
