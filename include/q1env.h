@@ -141,6 +141,12 @@ int q1env_reset_philox(q1env_t* env, uint64_t seed, const uint64_t* counter_dev,
  * done uint8[N] (env.py:506), zero_start uint8[N] (the info dict's only field, env.py:510). */
 int q1env_step(q1env_t* env, int action_format, const void* act_a_dev, const void* act_b_dev,
                int obs_format, void* obs_dev, float* reward_dev, uint8_t* done_dev, uint8_t* zero_start_dev);
+/* One tick with in-kernel reset of the envs whose episode ended on it (auto-reset convention of GPU-resident RL loops):
+ * reward / done / zero_start describe the finished step, the observation row of a finished env is the first observation of
+ * its next episode.  Bit-identical to q1env_step followed by q1env_reset_philox(seed, counter_dev, NULL, done_only = 1).
+ * Observations are float32.  counter_dev as in q1env_reset_philox. */
+int q1env_step_autoreset(q1env_t* env, int action_format, const void* act_a_dev, const void* act_b_dev, uint64_t seed,
+                         const uint64_t* counter_dev, float* obs_dev, float* reward_dev, uint8_t* done_dev, uint8_t* zero_start_dev);
 /* Same with HOST pointers: stages H2D, steps, copies back, synchronises (the NumPy-compatible path). */
 int q1env_step_host(q1env_t* env, int action_format, const void* act_a, const void* act_b,
                     int obs_format, void* obs, float* reward, uint8_t* done, uint8_t* zero_start);

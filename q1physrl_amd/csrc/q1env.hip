@@ -51,6 +51,40 @@ step_kernel(Params p, StatePtrs s, int fmt, const void* act_a, const void* act_b
     if (zero_start) zero_start[i] = (e.flags & FLAG_ZERO_START) ? 1 : 0;
 }
 
+// One tick WITH in-kernel reset of the envs whose episode ended on it (the "auto-reset" vector-env convention of
+// GPU-resident RL loops): reward / done / zero_start describe the finished step; the observation row of a finished env is
+// the FIRST observation of its next episode (Philox reset exactly as q1env_reset_philox with counter + 1).  Saves the second
+// launch of the step + reset_philox(done_only) pair; bit-identical to that pair.
+template <bool SPEC, int FMT>
+__global__ void __launch_bounds__(256)
+step_autoreset_kernel(Params p, StatePtrs s, int fmt, const void* act_a, const void* act_b, uint64_t seed, uint64_t counter,
+                      const uint64_t* counter_dev, float* obs, float* reward, uint8_t* done, uint8_t* zero_start) {
+    __shared__ float slab[4][384];
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t n = (uint32_t)p.n;
+    if (i >= n) return;
+    if (counter_dev) counter += *counter_dev;
+    Env e;
+    load_env(s, n, i, e);
+    double yaw_act;
+    const uint32_t keys = fetch_action<SPEC, FMT>(p, fmt, act_a, act_b, (size_t)i, &yaw_act);
+    TickOut<float> o;
+    tick<float, SPEC>(p, e, keys, yaw_act, o);
+    if (zero_start) zero_start[i] = (e.flags & FLAG_ZERO_START) ? 1 : 0;      // of the episode the step belonged to
+    if (o.done) {
+        reset_philox(p, e, seed, (uint64_t)p.env_index_base + (uint64_t)i, counter + 1);
+        observe<float>(p, e, o.obs);
+    }
+    store_env(s, n, i, e);
+    if (obs) {
+        const uint32_t lane = threadIdx.x & 63u, wave_first = i - lane;
+        if (wave_first + 64u <= n) write_obs_wave_f32(obs, wave_first, lane, o.obs, slab[threadIdx.x >> 6]);
+        else write_obs<float>(obs, (size_t)i, o.obs);
+    }
+    if (reward) reward[i] = o.reward;
+    if (done) done[i] = o.done ? 1 : 0;
+}
+
 // `ticks` ticks in one launch: the env state lives in registers between ticks, only actions stream in and
 // (optional) per-tick outputs stream out.  Tick-major layouts keep every access of a wave contiguous.
 // The next tick's action is fetched before the current tick is computed, so its HBM latency hides under the
@@ -696,6 +730,24 @@ int q1env_step(q1env_t* h, int fmt, const void* a, const void* b, int obs_format
     if (int r = check_act(h, fmt, a, b, false)) return r;
     if (obs_format != Q1ENV_OBS_F32 && obs_format != Q1ENV_OBS_F64) return fail(Q1ENV_ERR_INVALID_ARG, "bad obs_format");
     launch_step(h, fmt, a, b, obs_format, obs, reward, done, zs);
+    HIP_TRY(hipGetLastError());
+    h->tick_count += 1;
+    return Q1ENV_OK;
+}
+
+int q1env_step_autoreset(q1env_t* h, int fmt, const void* a, const void* b, uint64_t seed, const uint64_t* counter_dev, float* obs,
+                         float* reward, uint8_t* done, uint8_t* zs) {
+    if (!h) return fail(Q1ENV_ERR_INVALID_ARG, "q1env_step_autoreset: null handle");
+    DeviceGuard guard(h->device);
+    if (int r = check_act(h, fmt, a, b, false)) return r;
+    const int blk = block_for(h->p.n);
+    const dim3 g = grid_for(h->p.n, blk), bs(blk);
+    const uint64_t counter = counter_dev ? 0 : h->tick_count;
+#define Q1_LAUNCH_AR(SP, FM) \
+    hipLaunchKernelGGL((step_autoreset_kernel<SP, FM>), g, bs, 0, h->stream, h->p, h->st, fmt, a, b, seed, counter, counter_dev, obs, reward, done, zs)
+    if (is_spec(h->p) && fmt == Q1ENV_ACT_PACKED) Q1_LAUNCH_AR(true, FMT_PACKED);
+    else Q1_LAUNCH_AR(false, FMT_RUNTIME);
+#undef Q1_LAUNCH_AR
     HIP_TRY(hipGetLastError());
     h->tick_count += 1;
     return Q1ENV_OK;

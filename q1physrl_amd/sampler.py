@@ -2,7 +2,7 @@
 sampler with nothing leaving the device between ticks:
 
     obs (N,6) f32 --torch MLP--> logits (N,10) --q1env_policy_sample (HIP)--> packed action + logp
-        --q1env_step (HIP)--> reward, done --q1env_reset_philox(done_only) (HIP)--> next obs (fresh for reset envs)
+        --q1env_step_autoreset (HIP)--> reward, done, next obs (fresh first observation for the envs it reset)
 
 Trajectories are stored tick-major ([T][N]...) in preallocated device tensors; episode statistics follow the
 reference's metric hook (train.py:54-57: the return of zero-start episodes, `zero_start_total_reward`).
@@ -58,15 +58,15 @@ class GpuSampler:
             logits = self.logits[t]
             dev.policy_sample_dev(logits.data_ptr(), logits.shape[1], env.seed, 0, self.keys[t].data_ptr(),
                                   self.mouse[t].data_ptr(), self.logp[t].data_ptr(), deterministic, counter_dev=cnt)
-            # tick: reward / done / zero_start only - the observation comes from the reset kernel below, which writes
-            # the row of EVERY env (fresh first observation for the envs it resets, current observation for the others)
-            dev.step_dev(_lib.ACT_PACKED, self.keys[t].data_ptr(), self.mouse[t].data_ptr(), _lib.OBS_F32, 0,
-                         self.reward[t].data_ptr(), self.done[t].data_ptr(), env.zero_start.data_ptr())
+            # tick with in-kernel reset of finished episodes: reward / done / zero_start of the step, next observation row
+            # (fresh first observation for the envs that were reset) straight into the trajectory buffer
+            dev.step_autoreset_dev(_lib.ACT_PACKED, self.keys[t].data_ptr(), self.mouse[t].data_ptr(), env.seed,
+                                   self.obs[t + 1].data_ptr(), self.reward[t].data_ptr(), self.done[t].data_ptr(),
+                                   env.zero_start.data_ptr(), counter_dev=cnt)
             # episode bookkeeping (train.py:54-57: return of finished episodes, split by zero_start): one HIP kernel
             dev.episode_stats_dev(self.reward[t].data_ptr(), self.done[t].data_ptr(), env.zero_start.data_ptr(),
                                   self.ep_return.data_ptr(), self._stats.data_ptr())
             self.tick.add_(1)
-            dev.reset_philox_dev(env.seed, 0, True, _lib.OBS_F32, self.obs[t + 1].data_ptr(), counter_dev=cnt)   # done envs only
         _, v_last = self._forward(self.obs[self.T])
         self.value[self.T].copy_(v_last)
 

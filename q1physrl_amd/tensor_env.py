@@ -86,6 +86,14 @@ class TensorVectorEnv:
                            self.zero_start.data_ptr())
         return self.obs, self.reward, self.done
 
+    def step_autoreset(self, actions) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+        """One tick with in-kernel reset of finished episodes (one launch instead of step_tensor + reset_done): reward /
+        done / zero_start describe the finished step, obs rows of finished envs are the new episodes' first observations."""
+        fmt, a, b = self._act_ptrs(actions, (self.num_envs,))
+        self._dev.step_autoreset_dev(fmt, a, b, self.seed, self.obs.data_ptr(), self.reward.data_ptr(), self.done.data_ptr(),
+                                     self.zero_start.data_ptr())
+        return self.obs, self.reward, self.done
+
     def step_many(self, actions, ticks: int, outputs: bool = False, use_graph: bool = True):
         """`ticks` single-tick launches over tick-major actions; outputs=True returns tick-major (T,N,..) tensors."""
         fmt, a, b = self._act_ptrs(actions, (ticks, self.num_envs))

@@ -327,3 +327,35 @@ def test_full_size_rollout_parity_65536_envs_720_ticks():
     assert np.array_equal(st["yaw"], ora.yaw) and np.array_equal((st["flags"] & 1) != 0, ora.st["on_ground"])
     assert done_g[-1].all() and not done_g[:-1].any()
     tenv.close()
+
+
+@pytest.mark.parametrize("variant", ["default", "auto_jump"])
+def test_step_autoreset_equals_step_then_reset_done(variant):
+    """q1env_step_autoreset (one launch) against q1env_step + q1env_reset_philox(done_only) (two launches): same rewards,
+    dones, zero_start flags, observations and final state, SPEC and generic instantiations."""
+    torch = torch_mod()
+    from q1physrl_amd.tensor_env import TensorVectorEnv
+    from q1physrl_amd.env import Config
+    n, ticks, seed = 777, 300, 5
+    over = dict(zero_start_prob=0.3, time_limit=1.0, **({"auto_jump": True} if variant == "auto_jump" else {}))
+    cfg = Config(**O.OracleConfig.get_default(num_envs=n, **over).__dict__)
+    rng = np.random.default_rng(3)
+    nk = 3 if variant == "auto_jump" else 4
+    keys = torch.from_numpy(rng.integers(0, 1 << nk, size=(ticks, n), dtype=np.uint8)).cuda()
+    mouse = torch.from_numpy(rng.uniform(-10, 10, size=(ticks, n)).astype(np.float32)).cuda()
+    a, b = TensorVectorEnv(cfg, seed=seed), TensorVectorEnv(cfg, seed=seed)
+    a.reset(); b.reset()
+    resets = 0
+    for t in range(ticks):
+        oa, ra, da = a.step_autoreset((keys[t], mouse[t]))
+        za = a.zero_start.clone()
+        ob, rb, db = b.step_tensor((keys[t], mouse[t]))
+        zb = b.zero_start.clone()
+        ob = b.reset_done()
+        assert torch.equal(ra, rb) and torch.equal(da, db) and torch.equal(za, zb) and torch.equal(oa, ob), t
+        resets += int(da.sum())
+    assert resets > n
+    sa, sb = a.get_state(), b.get_state()
+    for k in sa:
+        assert np.array_equal(sa[k], sb[k]), k
+    a.close(); b.close()
