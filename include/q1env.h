@@ -208,12 +208,14 @@ int q1env_gae(q1env_t* env, int ticks, const float* reward_dev, const float* val
 
 /* Fused forward pass of one network of the reference policy's shape (RLlib fcnet of data/checkpoints/wr: 6 -> 256 tanh ->
  * 256 tanh -> out_dim, out_dim = 10 policy logits or 1 value) for this handle's N envs: obs float[N][6] -> out float[N][out_dim].
- * Weights in torch nn.Linear layout: w1 float[256][6], b1 float[256], w2 BF16 bits [256][256] (row = output unit), b2 float[256],
- * w3 BF16 bits [32][256] (rows >= out_dim zero), b3 float[out_dim].  All three layers run on the matrix cores: layer 1 as exact
- * float32 MFMA, layers 2 and 3 with bf16 inputs and float32 accumulation; biases and tanh are float32.
- * Inference only (sampler loop); the learner keeps its float32 torch modules. */
-int q1env_policy_forward(q1env_t* env, const float* obs_dev, const float* w1_dev, const float* b1_dev, const uint16_t* w2_bf16_dev,
-                         const float* b2_dev, const uint16_t* w3_bf16_dev, const float* b3_dev, int out_dim, float* out_dev);
+ * w1 float[256][6], b1 float[256], b2 float[256], b3 float[out_dim] in torch nn.Linear layout.  w23_image: W2 (nn.Linear(256,256)
+ * weight, row = output unit) followed by W3 (nn.Linear(256,out_dim) weight in rows 0..out_dim-1 of a 32-row tile) as ONE bf16
+ * array of 288 rows x 264 elements: 256 weights + 8 zero pad per row, the columns of every row permuted so that within each
+ * group of 16 the four groups of four are stored in the order 0,2,1,3 (q1physrl_amd.policy.FusedPolicyForward builds it).
+ * All three layers run on the matrix cores: layer 1 as exact float32 MFMA, layers 2 and 3 with bf16 inputs and float32
+ * accumulation; biases and tanh are float32.  Inference only (sampler loop); the learner keeps its float32 torch modules. */
+int q1env_policy_forward(q1env_t* env, const float* obs_dev, const float* w1_dev, const float* b1_dev, const uint16_t* w23_image_dev,
+                         const float* b2_dev, const float* b3_dev, int out_dim, float* out_dev);
 
 /* Episode bookkeeping of one sampler tick (the reference's on_episode_end metric hook, q1physrl/train.py:54-57):
  * ep_return double[N] += reward; for envs with done != 0 the finished return is added to this wave's slot of

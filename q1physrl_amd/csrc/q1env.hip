@@ -1110,9 +1110,9 @@ int q1env_episode_stats(q1env_t* h, const float* reward, const uint8_t* done, co
     return Q1ENV_OK;
 }
 
-int q1env_policy_forward(q1env_t* h, const float* obs, const float* w1, const float* b1, const uint16_t* w2_bf16, const float* b2,
-                         const uint16_t* w3, const float* b3, int out_dim, float* out) {
-    if (!h || !obs || !w1 || !b1 || !w2_bf16 || !b2 || !w3 || !b3 || !out) return fail(Q1ENV_ERR_INVALID_ARG, "q1env_policy_forward: null argument");
+int q1env_policy_forward(q1env_t* h, const float* obs, const float* w1, const float* b1, const uint16_t* w23_image, const float* b2,
+                         const float* b3, int out_dim, float* out) {
+    if (!h || !obs || !w1 || !b1 || !w23_image || !b2 || !b3 || !out) return fail(Q1ENV_ERR_INVALID_ARG, "q1env_policy_forward: null argument");
     if (out_dim != 10 && out_dim != 1) return fail(Q1ENV_ERR_INVALID_ARG, "q1env_policy_forward: out_dim must be 10 (policy) or 1 (value)");
     DeviceGuard guard(h->device);
     static thread_local bool attr_set = false;
@@ -1124,9 +1124,9 @@ int q1env_policy_forward(q1env_t* h, const float* obs, const float* w1, const fl
     const unsigned chunks = (unsigned)((h->p.n + 127) / 128);
     const dim3 g(chunks < 256u ? chunks : 256u), b(256);
     if (out_dim == 10)
-        hipLaunchKernelGGL(q1pol::mlp_forward_kernel<10>, g, b, q1pol::LDS_TOTAL, h->stream, h->p.n, obs, w1, b1, w2_bf16, b2, w3, b3, out);
+        hipLaunchKernelGGL(q1pol::mlp_forward_kernel<10>, g, b, q1pol::LDS_TOTAL, h->stream, h->p.n, obs, w1, b1, w23_image, b2, b3, out);
     else
-        hipLaunchKernelGGL(q1pol::mlp_forward_kernel<1>, g, b, q1pol::LDS_TOTAL, h->stream, h->p.n, obs, w1, b1, w2_bf16, b2, w3, b3, out);
+        hipLaunchKernelGGL(q1pol::mlp_forward_kernel<1>, g, b, q1pol::LDS_TOTAL, h->stream, h->p.n, obs, w1, b1, w23_image, b2, b3, out);
     HIP_TRY(hipGetLastError());
     return Q1ENV_OK;
 }

@@ -41,46 +41,67 @@ __device__ __forceinline__ float fast_tanh(float x) {                // 1 - 2 / 
     return 1.0f - 2.0f * __builtin_amdgcn_rcpf(t + 1.0f);
 }
 
-// tanh of accumulator registers 8u .. 8u+7 -> the lane's bf16 B operand of K-step 2t + u (v_cvt_pk_bf16_f32, RNE)
+// tanh of accumulator registers 8u .. 8u+7 -> the lane's bf16 B operand of K-step 2t + u.  Two values at a time: the
+// multiply, the +1 and the final 1 - 2r are packed float32 instructions (v_pk_mul/add/fma_f32), only v_exp_f32 and
+// v_rcp_f32 are per element; the pair is converted with one v_cvt_pk_bf16_f32 (RNE).
 __device__ __forceinline__ bf16x8 activate(const f32x16& acc, int u) {
     union { bf16x8 v; bf16x2 p[4]; } o;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        const f32x2 pr = {fast_tanh(acc[8 * u + 2 * j]), fast_tanh(acc[8 * u + 2 * j + 1])};
-        o.p[j] = __builtin_convertvector(pr, bf16x2);
+        f32x2 x = {acc[8 * u + 2 * j], acc[8 * u + 2 * j + 1]};
+        x = x * 2.8853900817779268f;                                  // 2 log2(e)
+        f32x2 t = {__builtin_amdgcn_exp2f(x[0]), __builtin_amdgcn_exp2f(x[1])};
+        t = t + 1.0f;
+        const f32x2 r = {__builtin_amdgcn_rcpf(t[0]), __builtin_amdgcn_rcpf(t[1])};
+        const f32x2 y = 1.0f - 2.0f * r;
+        o.p[j] = __builtin_convertvector(y, bf16x2);
     }
     return o.v;
 }
 
 // One 32-row tile of layer 1 on the float32 matrix path: rows k = 32t + col, A operand of step s = W1ext[k][2s + half].
-__device__ __forceinline__ f32x16 layer1_tile(const float* l_w1, const float (&x1)[4], uint32_t t, uint32_t col, uint32_t half) {
+__device__ __forceinline__ void layer1_operands(const float* l_w1, uint32_t t, uint32_t col, uint32_t half, float (&a)[4]) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s) a[s] = l_w1[(2u * s + half) * HID + t * 32u + col];
+}
+__device__ __forceinline__ f32x16 layer1_tile(const float (&a)[4], const float (&x1)[4]) {
     f32x16 d1;
 #pragma unroll
     for (int r = 0; r < 16; ++r) d1[r] = 0.0f;
 #pragma unroll
-    for (int s = 0; s < 4; ++s)
-        d1 = __builtin_amdgcn_mfma_f32_32x32x2f32(l_w1[(2u * s + half) * HID + t * 32u + col], x1[s], d1, 0, 0, 0);
+    for (int s = 0; s < 4; ++s) d1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], x1[s], d1, 0, 0, 0);
     return d1;
 }
 
-// Stage `rows` rows of a bf16 [rows][256] matrix into LDS with the (0,2,1,3) group permutation of every 16 columns.
-__device__ __forceinline__ void stage_permuted(unsigned char* dst, const uint16_t* __restrict__ src, uint32_t rows, uint32_t tid) {
-    for (uint32_t c = tid; c < rows * 64u; c += 256u) {              // 64 groups of 4 bf16 (8 B) per row
-        const uint32_t row = c >> 6, g = c & 63u;
-        const uint32_t gs = (g & ~3u) | (((g & 1u) << 1) | ((g >> 1) & 1u));   // dest group g <- source group (0,2,1,3)[g & 3]
-        const uint2 v = reinterpret_cast<const uint2*>(src)[row * 64u + gs];
-        *reinterpret_cast<uint2*>(dst + (size_t)row * ROW_BYTES + g * 8u) = v;
+// The host hands W2 and W3 over as ONE bf16 image that is already in LDS layout: (256 + 32) rows of 264 elements (528 B:
+// 256 weights + 8 pad), columns of every row permuted (groups of four within each 16: 0,2,1,3).  Staging is then a straight
+// 16-byte-per-lane copy of 152 064 bytes with all of a thread's loads in flight at once.
+constexpr uint32_t IMG_VEC16 = (uint32_t)((LDS_W2 + LDS_W3) / 16);   // 9504 uint4
+__device__ __forceinline__ void stage_image(unsigned char* dst, const uint16_t* __restrict__ img, uint32_t tid) {
+    const uint4* src = reinterpret_cast<const uint4*>(img);
+    uint4* d = reinterpret_cast<uint4*>(dst);
+    constexpr uint32_t PER = (IMG_VEC16 + 255u) / 256u;              // 38 vectors per thread
+    uint4 v[PER];
+#pragma unroll
+    for (uint32_t k = 0; k < PER; ++k) {
+        const uint32_t c = k * 256u + tid;
+        v[k] = c < IMG_VEC16 ? src[c] : make_uint4(0, 0, 0, 0);
+    }
+#pragma unroll
+    for (uint32_t k = 0; k < PER; ++k) {
+        const uint32_t c = k * 256u + tid;
+        if (c < IMG_VEC16) d[c] = v[k];
     }
 }
 
-// w1: float[HID][OBS] (torch Linear(6,256).weight), b1: float[HID], w2: bf16 bits [HID n][HID k] (Linear(256,256).weight),
-// b2: float[HID], w3: bf16 bits [32][HID] (Linear(256,out).weight in rows 0..out-1, zero rows after), b3: float[out_dim];
+// w1: float[HID][OBS] (torch Linear(6,256).weight), b1: float[HID], w23: the bf16 LDS image of W2 (Linear(256,256).weight) and W3
+// (Linear(256,out).weight in rows 0..out-1 of a 32-row tile) described above, b2: float[HID], b3: float[out_dim];
 // obs float[n][6]; out float[n][out_dim].
 template <int OUT>
 __global__ void __launch_bounds__(256, 1)
 mlp_forward_kernel(int n, const float* __restrict__ obs, const float* __restrict__ w1, const float* __restrict__ b1,
-                   const uint16_t* __restrict__ w2, const float* __restrict__ b2, const uint16_t* __restrict__ w3,
-                   const float* __restrict__ b3, float* __restrict__ out) {
+                   const uint16_t* __restrict__ w23, const float* __restrict__ b2, const float* __restrict__ b3,
+                   float* __restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     unsigned char* l_w2 = lds;
     unsigned char* l_w3 = lds + LDS_W2;
@@ -88,8 +109,7 @@ mlp_forward_kernel(int n, const float* __restrict__ obs, const float* __restrict
     float* l_w1 = reinterpret_cast<float*>(lds + LDS_W2 + LDS_W3 + LDS_B2);   // [i][k]: inputs 0..5, bias (input 6 == 1), 0
 
     const uint32_t tid = threadIdx.x;
-    stage_permuted(l_w2, w2, HID, tid);
-    stage_permuted(l_w3, w3, 32, tid);
+    stage_image(lds, w23, tid);                                      // W2 rows then W3 rows, contiguous in LDS
     l_b2[tid] = b2[tid];                                             // HID == blockDim.x
 #pragma unroll
     for (int i = 0; i < OBS; ++i) l_w1[i * HID + tid] = w1[tid * OBS + i];
@@ -134,8 +154,12 @@ mlp_forward_kernel(int n, const float* __restrict__ obs, const float* __restrict
         // Software pipeline over the eight 32-row tiles of H1: while the sixteen bf16 MFMAs of tile t1 run on the matrix
         // pipe, the VALU computes tanh of tile t1+1 (one wave per SIMD: nothing else could hide either behind the other).
         bf16x8 cur0, cur1;
+        float a1n[4];                                                // layer-1 A operands, fetched one tile ahead as well
         {
-            const f32x16 d1 = layer1_tile(l_w1, x1, 0u, col, half);
+            float a1[4];
+            layer1_operands(l_w1, 0u, col, half, a1);
+            layer1_operands(l_w1, 1u, col, half, a1n);
+            const f32x16 d1 = layer1_tile(a1, x1);
             cur0 = activate(d1, 0); cur1 = activate(d1, 1);
         }
         // A operands (W2 rows) are fetched from LDS one K-step AHEAD of the MFMAs that consume them: with a single wave
@@ -152,9 +176,11 @@ mlp_forward_kernel(int n, const float* __restrict__ obs, const float* __restrict
 #pragma unroll                                          //   back down next to their MFMAs)
             for (int t2 = 0; t2 < 8; ++t2)
                 a_odd[t2] = *reinterpret_cast<const bf16x8*>(wrow + (size_t)t2 * 32u * ROW_BYTES + (q0 + 1u) * 32u);
+            float a1f[4];                                            // operands of tile t1 + 2, for the next iteration
+            layer1_operands(l_w1, (uint32_t)(t1 + 2) & 7u, col, half, a1f);
             __builtin_amdgcn_sched_barrier(0);
             // phase B: even K-step on the matrix pipe; layer 1 + tanh of the NEXT tile on the VALU meanwhile
-            const f32x16 dn = layer1_tile(l_w1, x1, (uint32_t)(t1 + 1) & 7u, col, half);   // last pass recomputes tile 0, unused
+            const f32x16 dn = layer1_tile(a1n, x1);                  // tile t1 + 1 (the last pass recomputes tile 0, unused)
 #pragma unroll
             for (int t2 = 0; t2 < 8; ++t2) acc[t2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_even[t2], cur0, acc[t2], 0, 0, 0);
             const bf16x8 nxt0 = activate(dn, 0);
@@ -170,29 +196,39 @@ mlp_forward_kernel(int n, const float* __restrict__ obs, const float* __restrict
             const bf16x8 nxt1 = activate(dn, 1);
             __builtin_amdgcn_sched_barrier(0);
             cur0 = nxt0; cur1 = nxt1;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) a1n[q] = a1f[q];
         }
 
+        // layer 3: all sixteen W3 operands are requested up front (64 VGPRs; the file has room with one wave per SIMD)
+        bf16x8 w3f[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) w3f[q] = *reinterpret_cast<const bf16x8*>(l_w3 + (size_t)col * ROW_BYTES + ((uint32_t)q * 16u + half * 8u) * 2u);
         f32x16 y, y2;                                                // two chains: consecutive MFMAs do not wait on each other
 #pragma unroll
         for (int r = 0; r < 16; ++r) { y[r] = 0.0f; y2[r] = 0.0f; }
 #pragma unroll
         for (int t2 = 0; t2 < 8; ++t2) {
             const bf16x8 f0 = activate(acc[t2], 0), f1 = activate(acc[t2], 1);
-            const unsigned char* rowp = l_w3 + (size_t)col * ROW_BYTES + ((uint32_t)(2 * t2) * 16u + half * 8u) * 2u;
-            y = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(rowp), f0, y, 0, 0, 0);
-            y2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(rowp + 32), f1, y2, 0, 0, 0);
-            if (t2 & 1) __builtin_amdgcn_sched_barrier(0);           // bound the live ranges
+            y = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w3f[2 * t2], f0, y, 0, 0, 0);
+            y2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w3f[2 * t2 + 1], f1, y2, 0, 0, 0);
         }
 #pragma unroll
         for (int r = 0; r < 16; ++r) y[r] += y2[r];
-        // y[r] = output row (r&3) + 8(r>>2) + 4*half of env `col`
+        // y[r] = output row (r&3) + 8(r>>2) + 4*half of env `col`: rows 0..7 come from registers 0..3 of the two halves,
+        // rows 8..9 from registers 4..5 of half 0
         if (live) {
             float* dst = out + (size_t)env * OUT;
+            if (OUT >= 8) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int o_lo = (r & 3) + 8 * (r >> 2);             // row for half = 0; half = 1 adds 4
-                if (o_lo < OUT && half == 0) dst[o_lo] = y[r] + b3[o_lo];
-                if (o_lo + 4 < OUT && half == 1) dst[o_lo + 4] = y[r] + b3[o_lo + 4];
+                for (int r = 0; r < 4; ++r) dst[r + 4 * half] = y[r] + b3[r + 4 * half];
+                if (half == 0) {
+#pragma unroll
+                    for (int r = 4; r < 4 + (OUT - 8); ++r) dst[r + 4] = y[r] + b3[r + 4];
+                }
+            } else if (half == 0) {
+#pragma unroll
+                for (int r = 0; r < OUT; ++r) dst[r] = y[r] + b3[r];
             }
         }
     }

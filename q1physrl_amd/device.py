@@ -168,8 +168,8 @@ class DeviceEnv:
     def gae_dev(self, ticks, reward, value, done, gamma, lam, adv, vtarg):
         _lib.check(self._lib.q1env_gae(self._h, int(ticks), reward, value, done, float(gamma), float(lam), adv, vtarg))
 
-    def policy_forward_dev(self, obs, w1, b1, w2_bf16, b2, w3, b3, out_dim, out):
-        _lib.check(self._lib.q1env_policy_forward(self._h, obs, w1, b1, w2_bf16, b2, w3, b3, int(out_dim), out))
+    def policy_forward_dev(self, obs, w1, b1, w23_image, b2, b3, out_dim, out):
+        _lib.check(self._lib.q1env_policy_forward(self._h, obs, w1, b1, w23_image, b2, b3, int(out_dim), out))
 
     def episode_stats_dev(self, reward, done, zero_start, ep_return, partials):
         _lib.check(self._lib.q1env_episode_stats(self._h, reward, done, zero_start, ep_return, partials))

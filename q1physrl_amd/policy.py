@@ -187,26 +187,30 @@ class FusedPolicyForward:
     @torch.no_grad()
     def refresh(self):
         """Copy the master weights into the kernel's persistent device buffers IN PLACE: a captured hipGraph of the
-        sampler holds these addresses, so they must never be re-allocated."""
+        sampler holds these addresses, so they must never be re-allocated.  W2 / W3 go into the bf16 LDS image the kernel
+        copies verbatim: 288 rows x 264 (256 weights + 8 pad), columns permuted (0,2,1,3 groups of four within each 16)."""
         for name, net in (("pi", self.policy.pi), ("vf", self.policy.vf)):
             l1, l2, l3 = net[0], net[2], net[4]
+            dev = l1.weight.device
             if name not in self._w:
-                dev = l1.weight.device
                 self._w[name] = (torch.empty_like(l1.weight, dtype=torch.float32), torch.empty_like(l1.bias, dtype=torch.float32),
-                                 torch.empty_like(l2.weight, dtype=torch.bfloat16), torch.empty_like(l2.bias, dtype=torch.float32),
-                                 torch.zeros((32, l3.in_features), dtype=torch.bfloat16, device=dev),   # rows padded to one MFMA tile
-                                 torch.empty_like(l3.bias, dtype=torch.float32))
-            w1, b1, w2, b2, w3, b3 = self._w[name]
-            w1.copy_(l1.weight); b1.copy_(l1.bias); w2.copy_(l2.weight); b2.copy_(l2.bias)
-            w3[:l3.out_features].copy_(l3.weight); b3.copy_(l3.bias)
+                                 torch.zeros((288, 264), dtype=torch.bfloat16, device=dev),
+                                 torch.empty_like(l2.bias, dtype=torch.float32), torch.empty_like(l3.bias, dtype=torch.float32))
+                g = torch.arange(256, device=dev)
+                grp = (g >> 2) & 3
+                self._perm = (g & ~0xC) | ((((grp & 1) << 1) | (grp >> 1)) << 2)      # dest column -> source column
+            w1, b1, img, b2, b3 = self._w[name]
+            w1.copy_(l1.weight); b1.copy_(l1.bias); b2.copy_(l2.bias); b3.copy_(l3.bias)
+            img[:256, :256].copy_(l2.weight[:, self._perm])
+            img[256:256 + l3.out_features, :256].copy_(l3.weight[:, self._perm])
 
     def __call__(self, obs):
         assert obs.dtype == torch.float32 and obs.is_contiguous() and obs.shape == (self.env.num_envs, 6)
         d = self.env._dev
         for name, out in (("pi", self.logits), ("vf", self.value)):
-            w1, b1, w2, b2, w3, b3 = self._w[name]
-            d.policy_forward_dev(obs.data_ptr(), w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr(), w3.data_ptr(),
-                                 b3.data_ptr(), out.shape[1], out.data_ptr())
+            w1, b1, img, b2, b3 = self._w[name]
+            d.policy_forward_dev(obs.data_ptr(), w1.data_ptr(), b1.data_ptr(), img.data_ptr(), b2.data_ptr(), b3.data_ptr(),
+                                 out.shape[1], out.data_ptr())
         return self.logits, self.value[:, 0]
 
     def parameters(self):
