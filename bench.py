@@ -210,8 +210,10 @@ def main():
     obsT = rewT = doneT = None
     torch.cuda.synchronize()
 
-    def run_ticks(mode, k, tick0):
-        """k ticks starting at episode phase tick0 % 720; resets every env on device at each episode end."""
+    def run_ticks(mode, k, tick0, prepare=False):
+        """k ticks starting at episode phase tick0 % 720; resets every env on device at each episode end.
+        prepare=True only builds the hipGraphs this sequence will replay (no launch), so that the timed region never
+        pays a graph instantiation whatever --steps / --warmup are."""
         nonlocal obsT, rewT, doneT
         if mode == "rollout" and obsT is None:        # tick-major per-tick outputs of a whole episode
             obsT = torch.empty((EPISODE_TICKS, n, 6), dtype=torch.float32, device=d)
@@ -224,16 +226,23 @@ def main():
             ka = keys.data_ptr() + ph * n
             ma = mouse.data_ptr() + ph * n * 4
             if mode == "step":
-                dev.step_many_dev(chunk, _lib.ACT_PACKED, ka, ma, _lib.OBS_F32, obs1.data_ptr(), rew1.data_ptr(),
-                                  done1.data_ptr(), out_stride_ticks=0, use_graph=not args.no_graph)
+                if prepare:
+                    if not args.no_graph:
+                        dev.step_many_dev(chunk, _lib.ACT_PACKED, ka, ma, _lib.OBS_F32, obs1.data_ptr(), rew1.data_ptr(),
+                                          done1.data_ptr(), out_stride_ticks=0, use_graph=2)
+                else:
+                    dev.step_many_dev(chunk, _lib.ACT_PACKED, ka, ma, _lib.OBS_F32, obs1.data_ptr(), rew1.data_ptr(),
+                                      done1.data_ptr(), out_stride_ticks=0, use_graph=not args.no_graph)
                 launches += chunk
+            elif prepare:
+                launches += 1
             else:
                 dev.rollout_dev(chunk, _lib.ACT_PACKED, ka, ma, 0, _lib.OBS_F32, obsT.data_ptr(), rewT.data_ptr(),
                                 doneT.data_ptr(), auto_reset=False)
                 launches += 1
             t += chunk
             left -= chunk
-            if t % EPISODE_TICKS == 0:
+            if t % EPISODE_TICKS == 0 and not prepare:
                 dev.reset_philox_dev(seed=99, done_only=True)        # zero_start_prob = 1: every env back to the start line
         return launches
 
@@ -244,6 +253,8 @@ def main():
             dist.barrier()
 
     def measure(mode, steps, warmup):
+        run_ticks(mode, warmup, 0, prepare=True)
+        run_ticks(mode, steps, warmup, prepare=True)
         run_ticks(mode, warmup, 0)
         barrier()
         t0 = time.perf_counter()

@@ -151,7 +151,9 @@ int q1env_step_autoreset(q1env_t* env, int action_format, const void* act_a_dev,
 int q1env_step_host(q1env_t* env, int action_format, const void* act_a, const void* act_b,
                     int obs_format, void* obs, float* reward, uint8_t* done, uint8_t* zero_start);
 /* `ticks` consecutive single-tick launches with tick-major inputs/outputs ([ticks][N]... ; outputs may be
- * NULL).  use_graph != 0 replays them from a cached hipGraph (launch-bound regime).  out_stride_ticks = 0
+ * NULL).  use_graph = 1 replays them from a cached hipGraph (launch-bound regime; up to 8 graphs are cached per handle,
+ * keyed by every argument); use_graph = 2 only captures and instantiates that graph (no launch, state untouched) so that a
+ * later use_graph = 1 call with the same arguments pays no instantiation.  out_stride_ticks = 0
  * makes every tick overwrite the same output slab (ring of 1), 1 = tick-major slabs. */
 int q1env_step_many(q1env_t* env, int ticks, int action_format, const void* act_a_dev, const void* act_b_dev,
                     int obs_format, void* obs_dev, float* reward_dev, uint8_t* done_dev,

@@ -509,9 +509,10 @@ struct q1env {
     uint64_t tick_count = 0;          // ticks since create: the counter of the counter-based RNG
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     // cached graph for step_many
-    hipGraphExec_t gexec = nullptr;
+    // cached hipGraphs of step_many, keyed by (ticks, formats, pointers); a handful of entries, oldest evicted
+    struct GraphEntry { std::vector<uint64_t> key; hipGraphExec_t exec; };
+    std::vector<GraphEntry> graphs;
     hipStream_t cap_stream = nullptr;  // private stream used only to CAPTURE (the null stream cannot be captured)
-    std::vector<uint64_t> gkey;
 };
 
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
@@ -655,7 +656,8 @@ int q1env_destroy(q1env_t* h) {
     if (!h) return Q1ENV_OK;
     DeviceGuard guard(h->device);
     (void)hipStreamSynchronize(h->stream);
-    if (h->gexec) (void)hipGraphExecDestroy(h->gexec);
+    for (auto& ge : h->graphs) (void)hipGraphExecDestroy(ge.exec);
+    h->graphs.clear();
     if (h->cap_stream) (void)hipStreamDestroy(h->cap_stream);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
@@ -669,7 +671,8 @@ int q1env_destroy(q1env_t* h) {
 int q1env_set_stream(q1env_t* h, void* stream) {
     if (!h) return fail(Q1ENV_ERR_INVALID_ARG, "q1env_set_stream: null handle");
     DeviceGuard guard(h->device);
-    if (h->gexec) { (void)hipGraphExecDestroy(h->gexec); h->gexec = nullptr; h->gkey.clear(); }
+    for (auto& ge : h->graphs) (void)hipGraphExecDestroy(ge.exec);
+    h->graphs.clear();
     if (h->own_stream) { (void)hipStreamDestroy(h->stream); h->own_stream = false; }
     h->stream = (hipStream_t)stream;          // NULL = the device's default (null) stream
     return Q1ENV_OK;
@@ -807,8 +810,10 @@ int q1env_step_many(q1env_t* h, int ticks, int fmt, const void* a, const void* b
         std::vector<uint64_t> key = {(uint64_t)ticks, (uint64_t)fmt, (uint64_t)(uintptr_t)a, (uint64_t)(uintptr_t)b,
                                      (uint64_t)obs_format, (uint64_t)(uintptr_t)obs, (uint64_t)(uintptr_t)reward,
                                      (uint64_t)(uintptr_t)done, (uint64_t)out_stride};
-        if (!h->gexec || key != h->gkey) {
-            if (h->gexec) { (void)hipGraphExecDestroy(h->gexec); h->gexec = nullptr; }
+        hipGraphExec_t exec = nullptr;
+        for (auto& ge : h->graphs)
+            if (ge.key == key) { exec = ge.exec; break; }
+        if (!exec) {
             hipGraph_t g = nullptr;
             if (!h->cap_stream) HIP_TRY(hipStreamCreateWithFlags(&h->cap_stream, hipStreamNonBlocking));
             hipStream_t launch_stream = h->stream;
@@ -820,12 +825,17 @@ int q1env_step_many(q1env_t* h, int ticks, int fmt, const void* a, const void* b
             }
             h->stream = launch_stream;                      // ... and replay them on the handle's own stream
             if (ce != hipSuccess) return fail(Q1ENV_ERR_HIP, std::string("graph capture: ") + hipGetErrorString(ce));
-            hipError_t e = hipGraphInstantiate(&h->gexec, g, nullptr, nullptr, 0);
+            hipError_t e = hipGraphInstantiate(&exec, g, nullptr, nullptr, 0);
             (void)hipGraphDestroy(g);
-            if (e != hipSuccess) { h->gexec = nullptr; return fail(Q1ENV_ERR_HIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(e)); }
-            h->gkey = key;
+            if (e != hipSuccess) return fail(Q1ENV_ERR_HIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(e));
+            if (h->graphs.size() >= 8) {                    // small cache: evict the oldest entry
+                (void)hipGraphExecDestroy(h->graphs.front().exec);
+                h->graphs.erase(h->graphs.begin());
+            }
+            h->graphs.push_back({key, exec});
         }
-        HIP_TRY(hipGraphLaunch(h->gexec, h->stream));
+        if (use_graph == 2) return Q1ENV_OK;                // prepare only: capture + instantiate, no launch, no tick
+        HIP_TRY(hipGraphLaunch(exec, h->stream));
     }
     h->tick_count += (uint64_t)ticks;
     return Q1ENV_OK;

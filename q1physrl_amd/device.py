@@ -151,7 +151,7 @@ class DeviceEnv:
     def step_many_dev(self, ticks, action_format, act_a, act_b=0, obs_format=_lib.OBS_F32, obs=0, reward=0, done=0,
                       out_stride_ticks=0, use_graph=True):
         _lib.check(self._lib.q1env_step_many(self._h, ticks, action_format, act_a or None, act_b or None, obs_format,
-                                             obs or None, reward or None, done or None, int(out_stride_ticks), int(use_graph)))
+                                             obs or None, reward or None, done or None, int(out_stride_ticks), int(use_graph)))   # use_graph: 0 eager, 1 replay, 2 prepare only
 
     def rollout_dev(self, ticks, action_format, act_a=0, act_b=0, rng_seed=0, obs_format=_lib.OBS_F32, obs=0, reward=0,
                     done=0, auto_reset=False, return_sum=0):
