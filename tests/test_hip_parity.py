@@ -225,3 +225,31 @@ def test_exact_division_shortcuts_selftest():
         out = (C.c_uint64 * 4)()
         _lib.check(lib.q1env_selftest_division(0, 1 << 24, seed, c0, c1, out))
         assert list(out) == [0, 0, 0, 0], (seed, list(out))
+
+
+def test_extreme_yaw_and_speed_states_match_oracle():
+    """States far outside what an episode reaches (yaw up to 1e9 degrees: the large-argument path of the device sincos;
+    speeds of 1e4; tiny and negative-zero-free velocities) injected through set_state: 50 ticks against the oracle."""
+    from q1physrl_amd import env as E
+    n = 512
+    kw = dict(O.OracleConfig.get_default(num_envs=n, zero_start_prob=1.0).__dict__)
+    np.random.seed(0)
+    ora = O.OracleVectorEnv(dict(kw))
+    np.random.seed(0)
+    hip = E.VectorPhysEnv(dict(kw))
+    rng = np.random.default_rng(9)
+    yaw = rng.uniform(-1, 1, n) * 10.0 ** rng.uniform(0, 9, n)
+    vel = (rng.uniform(-1, 1, (n, 3)) * 10.0 ** rng.uniform(-6, 4, (n, 1))).astype(np.float32)
+    vel[:, 2] = rng.uniform(-300, 300, n).astype(np.float32)
+    ora.yaw = yaw.copy(); ora.dec["yaw"] = yaw.copy(); ora.st["vel"] = vel.copy()
+    hip.set_state(yaw=yaw, vel_x=vel[:, 0], vel_y=vel[:, 1], vel_z=vel[:, 2])
+    worst, same = 0.0, []
+    for t in range(50):
+        a = np.concatenate([(rng.random((n, 4)) < 0.5).astype(np.float64), rng.uniform(-10, 10, (n, 1)).astype(np.float32).astype(np.float64)], axis=1)
+        o1, r1, d1, _ = ora.vector_step(a)
+        o2, r2, d2, _ = hip.vector_step(a)
+        worst = max(worst, float(np.max(rel_err(o2, o1))), float(np.max(rel_err(r2, r1))))
+        same.append(bit_identical_fraction(np.ascontiguousarray(o2), np.ascontiguousarray(o1)))
+    print("extreme states: worst rel err", worst, "min bit-identical fraction", min(same))
+    assert worst <= REL_TOL and min(same) >= 0.999
+    hip.close()
