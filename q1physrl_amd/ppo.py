@@ -37,6 +37,9 @@ def ppo_loss(policy, batch, action_range, clip_param, vf_clip_param, vf_loss_coe
     return total, stats
 
 
+STAT_KEYS = ("entropy", "kl", "policy_loss", "total_loss", "vf_loss")      # sorted: the order of the stats vector
+
+
 def allreduce_grads_(params, world):
     """Average gradients over ranks with ONE collective on a flat bucket."""
     grads = [p.grad for p in params if p.grad is not None]
@@ -52,7 +55,7 @@ def allreduce_grads_(params, world):
 class PPOLearner:
     def __init__(self, policy, action_range, lr=5e-6, gamma=0.99, lam=0.95, clip_param=0.3, vf_clip_param=100.0,
                  vf_loss_coeff=1.0, entropy_coeff=0.01, kl_coeff=0.2, kl_target=0.0036, num_sgd_iter=30,
-                 minibatch_size=128, num_keys=4, seed=0):
+                 minibatch_size=128, num_keys=4, seed=0, use_graph=False):
         self.policy = policy
         self.action_range = float(action_range)
         self.gamma, self.lam = gamma, lam
@@ -60,7 +63,11 @@ class PPOLearner:
         self.vf_loss_coeff, self.entropy_coeff = vf_loss_coeff, entropy_coeff
         self.kl_coeff, self.kl_target = kl_coeff, kl_target
         self.num_sgd_iter, self.minibatch_size, self.num_keys = num_sgd_iter, minibatch_size, num_keys
-        self.opt = torch.optim.Adam(policy.parameters(), lr=lr)
+        # use_graph: one SGD step (loss, backward, Adam) captured once into a hipGraph and replayed per minibatch - the step
+        # is ~100 small launches on a 138 k-parameter model, i.e. launch-bound.  Single-process only.
+        self.use_graph = bool(use_graph) and not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1)
+        self.opt = torch.optim.Adam(policy.parameters(), lr=lr, capturable=self.use_graph)
+        self._graph = None
         self.gen = None
         self.seed = seed
         self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
@@ -71,6 +78,55 @@ class PPOLearner:
         return {"obs": traj["obs"][:t].reshape(t * n, 6), "keys": keys, "mouse": traj["mouse"].reshape(-1, 1),
                 "logp": traj["logp"].reshape(-1), "value": traj["value"][:t].reshape(-1), "adv": adv.reshape(-1),
                 "vtarg": vtarg.reshape(-1), "old_logits": old_logits}
+
+    def _graph_epochs(self, b, total, mb, dev):
+        """All SGD steps of one update through a captured hipGraph of a single step on static minibatch buffers."""
+        if self._graph is None or self._mb["adv"].shape[0] != mb:
+            self._mb = {k: torch.empty((mb,) + tuple(v.shape[1:]), dtype=v.dtype, device=dev) for k, v in b.items()}
+            self._klc = torch.tensor(float(self.kl_coeff), dtype=torch.float32, device=dev)
+            self._acc = torch.zeros((len(STAT_KEYS),), dtype=torch.float32, device=dev)
+
+            def one_step():
+                loss, st = ppo_loss(self.policy, self._mb, self.action_range, self.clip_param, self.vf_clip_param,
+                                    self.vf_loss_coeff, self.entropy_coeff, self._klc, self.num_keys)
+                self.opt.zero_grad(set_to_none=True)
+                loss.backward()
+                self.opt.step()
+                self._acc += torch.stack([st[k].float() for k in STAT_KEYS])
+
+            for k, v in b.items():
+                self._mb[k].copy_(v[:mb])
+            snapshot = [p.detach().clone() for p in self.policy.parameters()]
+            side = torch.cuda.Stream(device=dev)
+            side.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(side):
+                for _ in range(3):                     # warm-up (allocator, Adam state) on a side stream
+                    one_step()
+            torch.cuda.current_stream(dev).wait_stream(side)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                one_step()
+            # the warm-up / capture steps trained on the first minibatch: undo them (parameters and Adam moments)
+            with torch.no_grad():
+                for p, q in zip(self.policy.parameters(), snapshot):
+                    p.copy_(q)
+                for st_ in self.opt.state.values():
+                    for k_, v_ in st_.items():
+                        if torch.is_tensor(v_):
+                            v_.zero_()
+            self._graph = g
+        self._klc.fill_(float(self.kl_coeff))
+        self._acc.zero_()
+        steps = 0
+        for _ in range(self.num_sgd_iter):
+            perm = torch.randperm(total, device=dev, generator=self.gen)
+            for s in range(0, total - mb + 1, mb):
+                idx = perm[s:s + mb]
+                for k, v in b.items():
+                    torch.index_select(v, 0, idx, out=self._mb[k])
+                self._graph.replay()
+                steps += 1
+        return self._acc.clone(), steps
 
     def update(self, traj, adv, vtarg):
         """SGD epochs over one trajectory batch; adv/vtarg from q1env_gae.  Returns averaged stats (python floats)."""
@@ -95,26 +151,29 @@ class PPOLearner:
             self.gen = torch.Generator(device=dev).manual_seed(self.seed)
         params = [p for p in self.policy.parameters()]
         acc, steps = None, 0
-        for _ in range(self.num_sgd_iter):
-            perm = torch.randperm(total, device=dev, generator=self.gen)
-            for s in range(0, total - mb + 1, mb):
-                idx = perm[s:s + mb]
-                mbatch = {k: v[idx] for k, v in b.items()}
-                loss, st = ppo_loss(self.policy, mbatch, self.action_range, self.clip_param, self.vf_clip_param,
-                                    self.vf_loss_coeff, self.entropy_coeff, self.kl_coeff, self.num_keys)
-                self.opt.zero_grad(set_to_none=True)
-                loss.backward()
-                if self.world > 1:
-                    allreduce_grads_(params, self.world)
-                self.opt.step()
-                vals = torch.stack([st[k] for k in sorted(st)])
-                acc = vals if acc is None else acc + vals
-                steps += 1
+        if self.use_graph:
+            acc, steps = self._graph_epochs(b, total, mb, dev)
+        else:
+            for _ in range(self.num_sgd_iter):
+                perm = torch.randperm(total, device=dev, generator=self.gen)
+                for s in range(0, total - mb + 1, mb):
+                    idx = perm[s:s + mb]
+                    mbatch = {k: v[idx] for k, v in b.items()}
+                    loss, st = ppo_loss(self.policy, mbatch, self.action_range, self.clip_param, self.vf_clip_param,
+                                        self.vf_loss_coeff, self.entropy_coeff, self.kl_coeff, self.num_keys)
+                    self.opt.zero_grad(set_to_none=True)
+                    loss.backward()
+                    if self.world > 1:
+                        allreduce_grads_(params, self.world)
+                    self.opt.step()
+                    vals = torch.stack([st[k] for k in sorted(st)])
+                    acc = vals if acc is None else acc + vals
+                    steps += 1
         acc = acc / steps
         if self.world > 1:
             dist.all_reduce(acc, op=dist.ReduceOp.SUM)
             acc /= self.world
-        out = dict(zip(sorted(st), acc.tolist()))
+        out = dict(zip(STAT_KEYS, acc.tolist()))
         # adaptive KL coefficient (RLlib KLCoeffMixin.update_kl)
         if out["kl"] > 2.0 * self.kl_target:
             self.kl_coeff *= 1.5

@@ -295,3 +295,38 @@ def test_fused_policy_refresh_keeps_buffer_addresses():
         ref, _ = pol(tr["obs"][3])
     assert float((tr["logits"][3] - ref).abs().max()) < 0.05   # replay really used the refreshed weights
     env.close()
+
+
+def test_graph_captured_sgd_step_matches_eager_learner():
+    """PPOLearner(use_graph=True) replays one captured SGD step (loss, backward, Adam) per minibatch: after two updates on
+    the same trajectories the parameters agree with the eager learner's (same minibatch permutation, same Adam arithmetic;
+    the capture's warm-up steps are rolled back)."""
+    import copy
+    import torch
+    from q1physrl_amd import policy as P, ppo, sampler as S
+    torch.manual_seed(3)
+    base = P.Q1Policy().cuda()
+    cfg, env = make_env(512, time_limit=1.0)
+    smp = S.GpuSampler(env, base, horizon=32)
+    trajs = []
+    for _ in range(2):
+        tr = {k: v.clone() for k, v in smp.collect().items()}
+        adv, vt = smp.advantages(tr, 0.99, 0.95)
+        trajs.append((tr, adv.clone(), vt.clone()))
+    env.close()
+    res = []
+    for use_graph in (False, True):
+        pol = copy.deepcopy(base)
+        lr = ppo.PPOLearner(pol, cfg.action_range, lr=1e-3, num_sgd_iter=3, minibatch_size=2048, seed=11, use_graph=use_graph)
+        assert lr.use_graph == use_graph
+        stats = [lr.update(*t) for t in trajs]
+        res.append(([p.detach().clone() for p in pol.parameters()], stats))
+    (pe, se), (pg, sg) = res
+    moved = max((a - b).abs().max().item() for a, b in zip(pe, base.parameters()))
+    assert moved > 1e-3                                   # the updates did something
+    for a, b in zip(pe, pg):
+        assert torch.allclose(a, b, rtol=0, atol=2e-5), (a - b).abs().max().item()
+    for a, b in zip(se, sg):
+        assert a["sgd_steps"] == b["sgd_steps"] == 3 * (512 * 32 // 2048) and a["kl_coeff"] == b["kl_coeff"]
+        for k in ppo.STAT_KEYS:
+            assert abs(a[k] - b[k]) <= 1e-3 * max(1.0, abs(a[k])), (k, a[k], b[k])

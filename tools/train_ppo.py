@@ -44,7 +44,7 @@ pol = P.Q1Policy().cuda()
 fused = P.FusedPolicyForward(pol, env) if args.fused_policy else None
 smp = GpuSampler(env, fused if fused is not None else pol, horizon=args.horizon, use_graph=not args.no_graph)
 lrn = ppo.PPOLearner(pol, float(cfg.action_range), lr=args.lr, num_sgd_iter=args.epochs, minibatch_size=args.minibatch,
-                     entropy_coeff=args.entropy, kl_target=args.kl_target, seed=args.seed + rank)
+                     entropy_coeff=args.entropy, kl_target=args.kl_target, seed=args.seed + rank, use_graph=not args.no_graph)
 log = []
 t0 = time.time()
 prev = smp.stats
