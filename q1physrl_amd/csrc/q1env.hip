@@ -508,7 +508,7 @@ struct q1env {
     size_t stage_bytes = 0;
     uint64_t tick_count = 0;          // ticks since create: the counter of the counter-based RNG
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    // cached graph for step_many
+    bool mlp_attr_set = false;        // dynamic-LDS attribute of the policy kernels (a per-device setting: kept per handle)
     // cached hipGraphs of step_many, keyed by (ticks, formats, pointers); a handful of entries, oldest evicted
     struct GraphEntry { std::vector<uint64_t> key; hipGraphExec_t exec; };
     std::vector<GraphEntry> graphs;
@@ -907,7 +907,7 @@ int q1env_observe_host(q1env_t* h, int obs_format, void* obs) {
 int q1env_reset_draws_host(q1env_t* h, int64_t count, const int32_t* idx, const uint8_t* zero_start, const double* yaw,
                            const double* tm, const double* speed, const double* angle, int obs_format, void* obs) {
     if (!h || !zero_start || !yaw || !tm || !speed || !angle) return fail(Q1ENV_ERR_INVALID_ARG, "q1env_reset_draws_host: null argument");
-    if (count <= 0 || (!idx && count > h->p.n)) return fail(Q1ENV_ERR_INVALID_ARG, "q1env_reset_draws_host: bad count");
+    if (count <= 0 || count > h->p.n) return fail(Q1ENV_ERR_INVALID_ARG, "q1env_reset_draws_host: count must be in 1..num_envs");
     if (obs_format != Q1ENV_OBS_F32 && obs_format != Q1ENV_OBS_F64) return fail(Q1ENV_ERR_INVALID_ARG, "bad obs_format");
     if (idx) for (int64_t j = 0; j < count; ++j)
         if (idx[j] < 0 || idx[j] >= h->p.n) return fail(Q1ENV_ERR_INVALID_ARG, "q1env_reset_draws_host: index out of range");
@@ -1025,7 +1025,7 @@ int q1env_decode_host(q1env_t* h, int fmt, const void* a, const void* b, const f
 
 int q1env_decoder_reset_host(q1env_t* h, int64_t count, const int32_t* idx, const double* yaw) {
     if (!h || !yaw) return fail(Q1ENV_ERR_INVALID_ARG, "q1env_decoder_reset_host: null argument");
-    if (count <= 0 || (!idx && count > h->p.n)) return fail(Q1ENV_ERR_INVALID_ARG, "q1env_decoder_reset_host: bad count");
+    if (count <= 0 || count > h->p.n) return fail(Q1ENV_ERR_INVALID_ARG, "q1env_decoder_reset_host: count must be in 1..num_envs");
     if (idx) for (int64_t j = 0; j < count; ++j)
         if (idx[j] < 0 || idx[j] >= h->p.n) return fail(Q1ENV_ERR_INVALID_ARG, "q1env_decoder_reset_host: index out of range");
     DeviceGuard guard(h->device);
@@ -1125,11 +1125,10 @@ int q1env_policy_forward(q1env_t* h, const float* obs, const float* w1, const fl
     if (!h || !obs || !w1 || !b1 || !w23_image || !b2 || !b3 || !out) return fail(Q1ENV_ERR_INVALID_ARG, "q1env_policy_forward: null argument");
     if (out_dim != 10 && out_dim != 1) return fail(Q1ENV_ERR_INVALID_ARG, "q1env_policy_forward: out_dim must be 10 (policy) or 1 (value)");
     DeviceGuard guard(h->device);
-    static thread_local bool attr_set = false;
-    if (!attr_set) {
+    if (!h->mlp_attr_set) {
         HIP_TRY(hipFuncSetAttribute((const void*)q1pol::mlp_forward_kernel<10>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)q1pol::LDS_TOTAL));
         HIP_TRY(hipFuncSetAttribute((const void*)q1pol::mlp_forward_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)q1pol::LDS_TOTAL));
-        attr_set = true;
+        h->mlp_attr_set = true;
     }
     const unsigned chunks = (unsigned)((h->p.n + 127) / 128);
     const dim3 g(chunks < 256u ? chunks : 256u), b(256);

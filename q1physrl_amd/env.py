@@ -321,6 +321,31 @@ class VectorPhysEnv(VectorEnv):
         obs = self._dev.reset_draws([zero_start], [yaw], [time_remaining], [speed], [angle], idx=[int(index)])
         return obs[0]
 
+    def reset_many(self, indices):
+        """Extension (not in the reference): `[reset_at(i) for i in indices]` as ONE device call - the same draws from the
+        global NumPy stream in the same order, the same states and observations, returned as a (len(indices), 6) array.
+        RLlib resets finished envs one `reset_at` (one launch + one synchronising copy, ~70 us) at a time; a caller that
+        knows the done set up front (`np.flatnonzero(done)`) saves that per-env round trip."""
+        c, n = self._config, self.num_envs
+        idx = np.asarray(indices, dtype=np.int64).reshape(-1)
+        idx = np.where(idx < 0, idx + n, idx)
+        if idx.size == 0:
+            return np.empty((0, 6), dtype=np.float64)
+        if np.unique(idx).size != idx.size:            # a repeated index: later resets overwrite earlier ones, keep it sequential
+            return np.stack([self.reset_at(int(i)) for i in idx])
+        k = idx.size
+        zs, yaw, tm, sp, an = np.zeros(k, bool), np.zeros(k), np.zeros(k), np.zeros(k), np.zeros(k)
+        rnd, uni, tau = np.random.random, np.random.uniform, 2 * np.pi
+        for j in range(k):                             # per-env draw order of reset_at (env.py:461-471)
+            z = zs[j] = rnd() < c.zero_start_prob
+            if not z:
+                yaw[j] = uni(*c.initial_yaw_range)
+                tm[j] = uni(c.time_limit)
+                sp[j] = uni(c.max_initial_speed)
+            an[j] = uni(tau)
+        self._cache = {}
+        return self._dev.reset_draws(zs, yaw, tm, sp, an, idx=idx)
+
     # ---- the tick ----------------------------------------------------------------------------
     def vector_step(self, actions):
         rows = _checked_rows(actions, self._dev.action_width, self.num_envs)

@@ -253,3 +253,32 @@ def test_extreme_yaw_and_speed_states_match_oracle():
     print("extreme states: worst rel err", worst, "min bit-identical fraction", min(same))
     assert worst <= REL_TOL and min(same) >= 0.999
     hip.close()
+
+
+def test_reset_many_equals_sequential_reset_at():
+    """reset_many(indices) == [reset_at(i) for i in indices]: same NumPy-stream consumption, same observations, same state
+    (including the repeated-index and negative-index cases), checked against the oracle's reset_at as well."""
+    from q1physrl_amd import env as E
+    n = 300
+    kw = dict(O.OracleConfig.get_default(num_envs=n, zero_start_prob=0.4, time_limit=3.0).__dict__)
+    envs = []
+    for make in (E.VectorPhysEnv, E.VectorPhysEnv, O.OracleVectorEnv):
+        np.random.seed(21)                              # identical initial episodes
+        envs.append(make(dict(kw)))
+    a, b, ora = envs
+    for idx in ([5, 299, 0, 17, 64, 63, 128], list(range(0, 300, 3)), [7, 7, 9], [-1, 3], []):
+        np.random.seed(33)
+        oa = np.stack([a.reset_at(i) for i in idx]) if idx else np.empty((0, 6))
+        end_a = np.random.get_state()[1].copy(), np.random.get_state()[2]
+        np.random.seed(33)
+        ob = b.reset_many(idx)
+        end_b = np.random.get_state()[1].copy(), np.random.get_state()[2]
+        np.random.seed(33)
+        oo = np.stack([ora.reset_at(i) for i in idx]) if idx else np.empty((0, 6))
+        assert ob.shape == (len(idx), 6) and np.array_equal(oa, ob)
+        assert np.array_equal(end_a[0], end_b[0]) and end_a[1] == end_b[1]          # the global stream advanced identically
+        assert np.max(rel_err(ob, oo), initial=0.0) <= REL_TOL
+    sa, sb = a.get_state(), b.get_state()
+    for k in sa:
+        assert np.array_equal(sa[k], sb[k]), k
+    a.close(); b.close()
