@@ -214,10 +214,25 @@ int q1env_gae(q1env_t* env, int ticks, const float* reward_dev, const float* val
  * weight, row = output unit) followed by W3 (nn.Linear(256,out_dim) weight in rows 0..out_dim-1 of a 32-row tile) as ONE bf16
  * array of 288 rows x 264 elements: 256 weights + 8 zero pad per row, the columns of every row permuted so that within each
  * group of 16 the four groups of four are stored in the order 0,2,1,3 (q1physrl_amd.policy.FusedPolicyForward builds it).
- * All three layers run on the matrix cores: layer 1 as exact float32 MFMA, layers 2 and 3 with bf16 inputs and float32
- * accumulation; biases and tanh are float32.  Inference only (sampler loop); the learner keeps its float32 torch modules. */
+ * All three layers run on the matrix cores with bf16 weights and float32 accumulation; layer 1 takes the observations and its
+ * bias split into two bf16 each (hi + lo, 16 mantissa bits), b2 / b3 and tanh are float32, hidden activations are rounded to
+ * bf16.  1 <= out_dim <= 10.  Inference only (sampler loop); the learner keeps its float32 torch modules. */
 int q1env_policy_forward(q1env_t* env, const float* obs_dev, const float* w1_dev, const float* b1_dev, const uint16_t* w23_image_dev,
                          const float* b2_dev, const float* b3_dev, int out_dim, float* out_dev);
+
+/* The policy and the value network of one sampler tick (train.py:60-64: RLlib's fcnet with vf_share_layers = False is two
+ * such networks over the same observation) in ONE launch: half of the CUs evaluate *pi, the other half *vf.  Same arithmetic
+ * as two q1env_policy_forward calls, bit for bit. */
+typedef struct q1env_mlp {
+    const float* w1;              /* float[256][6]   device */
+    const float* b1;              /* float[256]      device */
+    const uint16_t* w23_image;    /* bf16[288][264]  device, layout as above */
+    const float* b2;              /* float[256]      device */
+    const float* b3;              /* float[out_dim]  device */
+    float* out;                   /* float[N][out_dim] device */
+    int out_dim;
+} q1env_mlp;
+int q1env_policy_value_forward(q1env_t* env, const float* obs_dev, const q1env_mlp* pi, const q1env_mlp* vf);
 
 /* Episode bookkeeping of one sampler tick (the reference's on_episode_end metric hook, q1physrl/train.py:54-57):
  * ep_return double[N] += reward; for envs with done != 0 the finished return is added to this wave's slot of

@@ -37,6 +37,11 @@ class Q1State(C.Structure):           # q1env_state
                 ("last_key_press_time", C.c_void_p), ("flags", C.c_void_p)]
 
 
+class Q1Mlp(C.Structure):             # q1env_mlp
+    _fields_ = [("w1", C.c_void_p), ("b1", C.c_void_p), ("w23_image", C.c_void_p), ("b2", C.c_void_p), ("b3", C.c_void_p),
+                ("out", C.c_void_p), ("out_dim", C.c_int)]
+
+
 STATE_FIELDS = (("vel_x", np.float32, 1), ("vel_y", np.float32, 1), ("vel_z", np.float32, 1),
                 ("pos_x", np.float64, 1), ("pos_y", np.float64, 1), ("z_pos", np.float64, 1),
                 ("yaw", np.float64, 1), ("time_remaining", np.float64, 1),
@@ -71,6 +76,7 @@ _SIGNATURES = {
     "q1env_policy_sample": (C.c_int, [_P, _P, C.c_int, C.c_uint64, C.c_uint64, _P, C.c_int, _P, _P, _P]),
     "q1env_gae": (C.c_int, [_P, C.c_int, _P, _P, _P, C.c_float, C.c_float, _P, _P]),
     "q1env_policy_forward": (C.c_int, [_P] * 7 + [C.c_int, _P]),
+    "q1env_policy_value_forward": (C.c_int, [_P, _P, _P, _P]),
     "q1env_episode_stats": (C.c_int, [_P, _P, _P, _P, _P, _P]),
     "q1env_selftest_division": (C.c_int, [C.c_int, C.c_uint64, C.c_uint64, C.c_double, C.c_double, C.POINTER(C.c_uint64)]),
     "q1env_calibrate_traffic": (C.c_int, [_P, C.c_int]),

@@ -1120,24 +1120,48 @@ int q1env_episode_stats(q1env_t* h, const float* reward, const uint8_t* done, co
     return Q1ENV_OK;
 }
 
+static int launch_mlp(q1env* h, const float* obs, const q1pol::Net& na, const q1pol::Net& nb, int nets) {
+    if (!h->mlp_attr_set) {
+        HIP_TRY(hipFuncSetAttribute((const void*)q1pol::mlp_forward_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)q1pol::LDS_TOTAL));
+        HIP_TRY(hipFuncSetAttribute((const void*)q1pol::mlp_forward_kernel<512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)q1pol::LDS_TOTAL));
+        h->mlp_attr_set = true;
+    }
+    // One workgroup per CU (LDS holds one network's weights).  Up to one 32-env tile per SIMD of a network's share of the CUs:
+    // one wave per SIMD; beyond that two waves per SIMD.  Q1ENV_MLP_THREADS overrides (measurement only).
+    static const int forced = [] { const char* e = getenv("Q1ENV_MLP_THREADS"); return e ? atoi(e) : 0; }();
+    const unsigned cus = nets == 2 ? 128u : 256u;                               // CUs per network
+    const int threads = forced == 256 || forced == 512 ? forced : ((unsigned)h->p.n <= cus * 4u * 32u ? 256 : 512);
+    const unsigned per_block = 32u * (unsigned)(threads / 64);                   // envs one workgroup covers per grid-stride pass
+    unsigned blocks = ((unsigned)h->p.n + per_block - 1u) / per_block;
+    if (blocks > cus) blocks = cus;
+    const dim3 g(blocks * (unsigned)nets), b(threads);
+    if (threads == 256)
+        hipLaunchKernelGGL(q1pol::mlp_forward_kernel<256>, g, b, q1pol::LDS_TOTAL, h->stream, h->p.n, obs, na, nb, nets);
+    else
+        hipLaunchKernelGGL(q1pol::mlp_forward_kernel<512>, g, b, q1pol::LDS_TOTAL, h->stream, h->p.n, obs, na, nb, nets);
+    HIP_TRY(hipGetLastError());
+    return Q1ENV_OK;
+}
+
 int q1env_policy_forward(q1env_t* h, const float* obs, const float* w1, const float* b1, const uint16_t* w23_image, const float* b2,
                          const float* b3, int out_dim, float* out) {
     if (!h || !obs || !w1 || !b1 || !w23_image || !b2 || !b3 || !out) return fail(Q1ENV_ERR_INVALID_ARG, "q1env_policy_forward: null argument");
-    if (out_dim != 10 && out_dim != 1) return fail(Q1ENV_ERR_INVALID_ARG, "q1env_policy_forward: out_dim must be 10 (policy) or 1 (value)");
+    if (out_dim < 1 || out_dim > 10) return fail(Q1ENV_ERR_INVALID_ARG, "q1env_policy_forward: out_dim must be in 1..10");
     DeviceGuard guard(h->device);
-    if (!h->mlp_attr_set) {
-        HIP_TRY(hipFuncSetAttribute((const void*)q1pol::mlp_forward_kernel<10>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)q1pol::LDS_TOTAL));
-        HIP_TRY(hipFuncSetAttribute((const void*)q1pol::mlp_forward_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)q1pol::LDS_TOTAL));
-        h->mlp_attr_set = true;
+    const q1pol::Net net{w1, b1, w23_image, b2, b3, out, out_dim};
+    return launch_mlp(h, obs, net, net, 1);
+}
+
+int q1env_policy_value_forward(q1env_t* h, const float* obs, const q1env_mlp* pi, const q1env_mlp* vf) {
+    if (!h || !obs || !pi || !vf) return fail(Q1ENV_ERR_INVALID_ARG, "q1env_policy_value_forward: null argument");
+    for (const q1env_mlp* m : {pi, vf}) {
+        if (!m->w1 || !m->b1 || !m->w23_image || !m->b2 || !m->b3 || !m->out) return fail(Q1ENV_ERR_INVALID_ARG, "q1env_policy_value_forward: null pointer in q1env_mlp");
+        if (m->out_dim < 1 || m->out_dim > 10) return fail(Q1ENV_ERR_INVALID_ARG, "q1env_policy_value_forward: out_dim must be in 1..10");
     }
-    const unsigned chunks = (unsigned)((h->p.n + 127) / 128);
-    const dim3 g(chunks < 256u ? chunks : 256u), b(256);
-    if (out_dim == 10)
-        hipLaunchKernelGGL(q1pol::mlp_forward_kernel<10>, g, b, q1pol::LDS_TOTAL, h->stream, h->p.n, obs, w1, b1, w23_image, b2, b3, out);
-    else
-        hipLaunchKernelGGL(q1pol::mlp_forward_kernel<1>, g, b, q1pol::LDS_TOTAL, h->stream, h->p.n, obs, w1, b1, w23_image, b2, b3, out);
-    HIP_TRY(hipGetLastError());
-    return Q1ENV_OK;
+    DeviceGuard guard(h->device);
+    const q1pol::Net na{pi->w1, pi->b1, pi->w23_image, pi->b2, pi->b3, pi->out, pi->out_dim};
+    const q1pol::Net nb{vf->w1, vf->b1, vf->w23_image, vf->b2, vf->b3, vf->out, vf->out_dim};
+    return launch_mlp(h, obs, na, nb, 2);
 }
 
 int q1env_selftest_division(int device, uint64_t n, uint64_t seed, double c0, double c1, uint64_t* mismatches4) {

@@ -5,8 +5,8 @@
 // q1env_reset_philox), so it is the one place matrix cores are used - for all three layers, computed TRANSPOSED
 // (hidden units are MFMA rows, envs are MFMA columns), so that the output of one layer is already distributed the way the
 // next layer's B operand needs it and activations never leave registers:
-//   layer 1  H1^T = W1ext . Xext^T      v_mfma_f32_32x32x2_f32 (exact float32; K = 8: six inputs, a 1 for the bias, a 0);
-//                                       W1ext ([input][k], 8 KB) is read from LDS, 4 dwords per lane per 32-row tile
+//   layer 1  H1^T = W1b . (Xhi + Xlo)^T  ONE v_mfma_f32_32x32x16_bf16 per 32-row tile: bf16 weights, inputs and bias split into
+//                                       two bf16 each (hi + lo = 16 mantissa bits), K = 16 = 2 x (6 inputs + bias hi/lo)
 //   layer 2  H2^T = W2 . tanh(H1)^T     v_mfma_f32_32x32x16_bf16, float32 accumulate, accumulators start at the bias b2
 //   layer 3  Y^T  = W3 . tanh(H2)^T     v_mfma_f32_32x32x16_bf16 (rows = outputs, padded to 32), + b3 in float32
 // The C/D register layout of a 32x32 tile gives lane (c, h) the rows (r&3) + 8(r>>2) + 4h, r = 0..15, of column c, while a
@@ -28,7 +28,7 @@ constexpr int ROW_BYTES = HID * 2 + 16;               // 528: padded row stride 
 constexpr size_t LDS_W2 = (size_t)HID * ROW_BYTES;    // 135168
 constexpr size_t LDS_W3 = (size_t)32 * ROW_BYTES;     // 16896 (output rows padded to one 32-row tile)
 constexpr size_t LDS_B2 = (size_t)HID * 4;            // 1024
-constexpr size_t LDS_W1 = (size_t)8 * HID * 4;        // 8192: W1ext as [input i = 0..7][k]
+constexpr size_t LDS_W1 = (size_t)HID * 32;           // 8192: layer-1 operand image, [k][half][8 K slots] bf16
 constexpr size_t LDS_TOTAL = LDS_W2 + LDS_W3 + LDS_B2 + LDS_W1;    // 161280 B <= 163840
 
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
@@ -59,37 +59,69 @@ __device__ __forceinline__ bf16x8 activate(const f32x16& acc, int u) {
     return o.v;
 }
 
-// One 32-row tile of layer 1 on the float32 matrix path: rows k = 32t + col, A operand of step s = W1ext[k][2s + half].
-__device__ __forceinline__ void layer1_operands(const float* l_w1, uint32_t t, uint32_t col, uint32_t half, float (&a)[4]) {
-#pragma unroll
-    for (int s = 0; s < 4; ++s) a[s] = l_w1[(2u * s + half) * HID + t * 32u + col];
+// Layer 1 on the bf16 matrix path with SPLIT inputs: x = hi + lo (two bf16, 16 mantissa bits together), so ONE
+// v_mfma_f32_32x32x16_bf16 computes W1b . (x_hi + x_lo) + (b1_hi + b1_lo) for a 32-row tile (the float32 32x32x2 path it replaces
+// needed four dependent 16-pass MFMAs per tile).  K layout of half h: slots 0..3 = hi of inputs h, 2+h, 4+h, 6+h, slots 4..7 = lo
+// of the same inputs; inputs 6 and 7 are the constant 1 carrying bf16(b1) and bf16(b1 - bf16(b1)).
+__device__ __forceinline__ uint16_t bf16_bits(float x) {              // RNE, like v_cvt_pk_bf16_f32
+    const f32x2 v = {x, 0.0f};
+    union { bf16x2 b; uint16_t u[2]; } o;
+    o.b = __builtin_convertvector(v, bf16x2);
+    return o.u[0];
 }
-__device__ __forceinline__ f32x16 layer1_tile(const float (&a)[4], const float (&x1)[4]) {
-    f32x16 d1;
+__device__ __forceinline__ float bf16_value(uint16_t b) { return __uint_as_float((uint32_t)b << 16); }
+
+__device__ __forceinline__ bf16x8 split_inputs(const float (&x)[3], uint32_t half) {
+    (void)half;
+    union { bf16x8 v; uint16_t u[8]; } o;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) d1[r] = 0.0f;
+    for (int s = 0; s < 3; ++s) {
+        const uint16_t hi = bf16_bits(x[s]);
+        o.u[s] = hi;
+        o.u[4 + s] = bf16_bits(x[s] - bf16_value(hi));
+    }
+    o.u[3] = 0x3F80;                                                  // 1.0: bias slot (hi part for half 0, lo part for half 1)
+    o.u[7] = 0;
+    return o.v;
+}
+
+// row k of the layer-1 operand image: 16 bf16 = [half][8 K slots] (32 B), built from float w1[k][0..5], b1[k]
+__device__ __forceinline__ void stage_w1_row(unsigned char* l_w1, uint32_t k, const float* __restrict__ w1, const float* __restrict__ b1) {
+    union { uint4 q[2]; uint16_t u[16]; } r;
+    const uint16_t bhi = bf16_bits(b1[k]);
+    const uint16_t blo = bf16_bits(b1[k] - bf16_value(bhi));
 #pragma unroll
-    for (int s = 0; s < 4; ++s) d1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], x1[s], d1, 0, 0, 0);
-    return d1;
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int i = 2 * j + h;                                  // input index of slot j in half h
+            const uint16_t w = i < OBS ? bf16_bits(w1[k * OBS + i]) : (i == 6 ? bhi : blo);
+            r.u[8 * h + j] = w;
+            r.u[8 * h + 4 + j] = i < OBS ? w : (uint16_t)0;           // lo parts of the inputs meet the same weight; lo(1) = 0
+        }
+    uint4* dst = reinterpret_cast<uint4*>(l_w1 + (size_t)k * 32u);
+    dst[0] = r.q[0]; dst[1] = r.q[1];
 }
 
 // The host hands W2 and W3 over as ONE bf16 image that is already in LDS layout: (256 + 32) rows of 264 elements (528 B:
 // 256 weights + 8 pad), columns of every row permuted (groups of four within each 16: 0,2,1,3).  Staging is then a straight
 // 16-byte-per-lane copy of 152 064 bytes with all of a thread's loads in flight at once.
 constexpr uint32_t IMG_VEC16 = (uint32_t)((LDS_W2 + LDS_W3) / 16);   // 9504 uint4
+template <int THREADS>
 __device__ __forceinline__ void stage_image(unsigned char* dst, const uint16_t* __restrict__ img, uint32_t tid) {
     const uint4* src = reinterpret_cast<const uint4*>(img);
     uint4* d = reinterpret_cast<uint4*>(dst);
-    constexpr uint32_t PER = (IMG_VEC16 + 255u) / 256u;              // 38 vectors per thread
+    constexpr uint32_t NT = (uint32_t)THREADS;
+    constexpr uint32_t PER = (IMG_VEC16 + NT - 1u) / NT;               // 19 (512 threads) or 38 vectors per thread
     uint4 v[PER];
 #pragma unroll
     for (uint32_t k = 0; k < PER; ++k) {
-        const uint32_t c = k * 256u + tid;
+        const uint32_t c = k * NT + tid;
         v[k] = c < IMG_VEC16 ? src[c] : make_uint4(0, 0, 0, 0);
     }
 #pragma unroll
     for (uint32_t k = 0; k < PER; ++k) {
-        const uint32_t c = k * 256u + tid;
+        const uint32_t c = k * NT + tid;
         if (c < IMG_VEC16) d[c] = v[k];
     }
 }
@@ -97,47 +129,75 @@ __device__ __forceinline__ void stage_image(unsigned char* dst, const uint16_t* 
 // w1: float[HID][OBS] (torch Linear(6,256).weight), b1: float[HID], w23: the bf16 LDS image of W2 (Linear(256,256).weight) and W3
 // (Linear(256,out).weight in rows 0..out-1 of a 32-row tile) described above, b2: float[HID], b3: float[out_dim];
 // obs float[n][6]; out float[n][out_dim].
-template <int OUT>
-__global__ void __launch_bounds__(256, 1)
-mlp_forward_kernel(int n, const float* __restrict__ obs, const float* __restrict__ w1, const float* __restrict__ b1,
-                   const uint16_t* __restrict__ w23, const float* __restrict__ b2, const float* __restrict__ b3,
-                   float* __restrict__ out) {
+// THREADS = 512: 8 waves, TWO per SIMD, each walking its own 32-env tiles (large batches); THREADS = 256: one wave per SIMD
+// (batches with at most one tile per SIMD, where a second wave would have nothing to do and the register budget is better spent).
+struct Net {                                         // one network: device pointers (see q1env_policy_forward)
+    const float* w1; const float* b1; const uint16_t* w23; const float* b2; const float* b3;
+    float* out; int out_dim;
+};
+
+template <int THREADS>
+// (register budget of 256 per lane in both variants - 512 threads x 1 block or 256 threads x "2" blocks: with more the compiler
+// parks the accumulators in AGPRs and every tanh input costs a v_accvgpr_read; LDS admits one block per CU either way)
+__global__ void __launch_bounds__(THREADS, 512 / THREADS)
+mlp_forward_kernel(int n, const float* __restrict__ obs, Net net_a, Net net_b, int nets) {
+    // nets == 2: the first half of the grid evaluates net_a, the second half net_b, over the same observations - the policy
+    // and the value network of one sampler tick in ONE launch (weight staging of both overlaps, half the launches).
+    const uint32_t bgrid = nets == 2 ? gridDim.x / 2u : gridDim.x;
+    const bool second = nets == 2 && blockIdx.x >= bgrid;
+    const uint32_t bid = second ? blockIdx.x - bgrid : blockIdx.x;
+    const Net net = second ? net_b : net_a;
+    const float* __restrict__ w1 = net.w1; const float* __restrict__ b1 = net.b1; const uint16_t* __restrict__ w23 = net.w23;
+    const float* __restrict__ b2 = net.b2; const float* __restrict__ b3 = net.b3; float* __restrict__ out = net.out;
+    const int OUT = net.out_dim;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     unsigned char* l_w2 = lds;
     unsigned char* l_w3 = lds + LDS_W2;
     float* l_b2 = reinterpret_cast<float*>(lds + LDS_W2 + LDS_W3);
-    float* l_w1 = reinterpret_cast<float*>(lds + LDS_W2 + LDS_W3 + LDS_B2);   // [i][k]: inputs 0..5, bias (input 6 == 1), 0
+    unsigned char* l_w1 = lds + LDS_W2 + LDS_W3 + LDS_B2;           // layer-1 operand image: [k][half][8] bf16
 
     const uint32_t tid = threadIdx.x;
-    stage_image(lds, w23, tid);                                      // W2 rows then W3 rows, contiguous in LDS
-    l_b2[tid] = b2[tid];                                             // HID == blockDim.x
-#pragma unroll
-    for (int i = 0; i < OBS; ++i) l_w1[i * HID + tid] = w1[tid * OBS + i];
-    l_w1[6 * HID + tid] = b1[tid];
-    l_w1[7 * HID + tid] = 0.0f;
+    stage_image<THREADS>(lds, w23, tid);                             // W2 rows then W3 rows, contiguous in LDS
+    if (tid < (uint32_t)HID) {
+        l_b2[tid] = b2[tid];
+        stage_w1_row(l_w1, tid, w1, b1);
+    }
     const uint32_t lane = tid & 63u, wave = tid >> 6;
     const uint32_t col = lane & 31u, half = lane >> 5;
     __syncthreads();
 
-    const uint32_t nchunks = ((uint32_t)n + 127u) / 128u;
-    // observations of the NEXT chunk are requested while the current one is computed (one wave per SIMD: a global load
-    // issued at the top of a chunk would otherwise expose its whole HBM latency once per chunk)
+    // Every wave owns whole 32-env tiles (tile = 32 consecutive envs), grid-stride.  Two waves share a SIMD: while one is in
+    // a VALU stretch (tanh) or waits for LDS, the other one's MFMAs keep the matrix pipe busy - with a single wave per SIMD
+    // the in-order issue serialises the two pipes unless the instruction stream alternates perfectly.
+    const uint32_t ntiles = ((uint32_t)n + 31u) / 32u;
+    const uint32_t tstride = bgrid * (uint32_t)(THREADS / 64);
+    uint32_t tile = bid * (uint32_t)(THREADS / 64) + wave;
+    // observations of the NEXT tile are requested while the current one is computed
     float xn[3];
     {
-        const uint32_t e0 = blockIdx.x * 128u + wave * 32u + col;
+        const uint32_t e0 = tile * 32u + col;
 #pragma unroll
-        for (int s = 0; s < 3; ++s) xn[s] = (blockIdx.x < nchunks && e0 < (uint32_t)n) ? obs[(size_t)e0 * OBS + 2u * s + half] : 0.0f;
+        for (int s = 0; s < 3; ++s) xn[s] = (tile < ntiles && e0 < (uint32_t)n) ? obs[(size_t)e0 * OBS + 2u * s + half] : 0.0f;
     }
-    for (uint32_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
-        const uint32_t env = chunk * 128u + wave * 32u + col;
+    const unsigned char* w1row = l_w1 + (size_t)col * 32u + half * 16u;               // + tile * 1024
+    const unsigned char* wrow = l_w2 + (size_t)col * ROW_BYTES + half * 16u;          // + t2 * 32 rows, + K-step * 32 B
+    const unsigned char* w3row = l_w3 + (size_t)col * ROW_BYTES + half * 16u;         // + K-step * 32 B
+    const f32x16 zero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#ifdef Q1POL_TRACE                                                   // diagnostic build (tools/trace_mlp.py): phase times of wave 0
+    uint64_t tr_pro = 0, tr_loop = 0, tr_l3 = 0, tr_chunks = 0;
+    const uint64_t tr_real0 = wall_clock64(), tr_mem0 = __builtin_amdgcn_s_memtime();   // 100 MHz reference vs s_memtime
+#define Q1POL_STAMP(var) const uint64_t var = __builtin_amdgcn_s_memtime()
+#else
+#define Q1POL_STAMP(var)
+#endif
+    for (; tile < ntiles; tile += tstride) {
+        const uint32_t env = tile * 32u + col;
         const bool live = env < (uint32_t)n;
-        float x1[4];                                                 // B operands: Xext[env][2s + half]
-#pragma unroll
-        for (int s = 0; s < 3; ++s) x1[s] = xn[s];
-        x1[3] = half ? 0.0f : 1.0f;
+        Q1POL_STAMP(ts0);
+        const bf16x8 xb = split_inputs(xn, half);                    // B operand of layer 1
         {
-            const uint32_t en = env + gridDim.x * 128u;
-            const bool more = chunk + gridDim.x < nchunks && en < (uint32_t)n;
+            const uint32_t en = env + tstride * 32u;
+            const bool more = tile + tstride < ntiles && en < (uint32_t)n;
 #pragma unroll
             for (int s = 0; s < 3; ++s) xn[s] = more ? obs[(size_t)en * OBS + 2u * s + half] : 0.0f;
         }
@@ -151,87 +211,98 @@ mlp_forward_kernel(int n, const float* __restrict__ obs, const float* __restrict
                 acc[t][4 * q + 0] = b.x; acc[t][4 * q + 1] = b.y; acc[t][4 * q + 2] = b.z; acc[t][4 * q + 3] = b.w;
             }
 
-        // Software pipeline over the eight 32-row tiles of H1: while the sixteen bf16 MFMAs of tile t1 run on the matrix
-        // pipe, the VALU computes tanh of tile t1+1 (one wave per SIMD: nothing else could hide either behind the other).
-        bf16x8 cur0, cur1;
-        float a1n[4];                                                // layer-1 A operands, fetched one tile ahead as well
+        // Software pipeline over the eight 32-row tiles of H1: tanh of tile t1+1 is interleaved (sched_group_barrier) with the
+        // sixteen MFMAs of tile t1; every W2 operand register is re-requested from LDS for the next K-step right after the
+        // MFMA that consumed it has been issued (operands are read at issue), i.e. eight MFMAs ahead of its next use.
+        bf16x8 cur0, cur1, a_l1, a[8];
+        f32x16 dn;
         {
-            float a1[4];
-            layer1_operands(l_w1, 0u, col, half, a1);
-            layer1_operands(l_w1, 1u, col, half, a1n);
-            const f32x16 d1 = layer1_tile(a1, x1);
-            cur0 = activate(d1, 0); cur1 = activate(d1, 1);
-        }
-        // A operands (W2 rows) are fetched from LDS one K-step AHEAD of the MFMAs that consume them: with a single wave
-        // per SIMD an LDS read issued right before its MFMA exposes its full latency 144 times per tile (measured: 48 %
-        // of the wave's cycles in s_waitcnt).
-        const unsigned char* wrow = l_w2 + (size_t)col * ROW_BYTES + half * 16u;      // + t2 * 32 rows, + K-step * 32 B
-        bf16x8 a_even[8], a_odd[8];
+            const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(w1row);
+            const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(w1row + 1024u);
+            a_l1 = *reinterpret_cast<const bf16x8*>(w1row + 2048u);
+            const f32x16 d0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, xb, zero16, 0, 0, 0);
+            dn = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, xb, zero16, 0, 0, 0);
 #pragma unroll
-        for (int t2 = 0; t2 < 8; ++t2) a_even[t2] = *reinterpret_cast<const bf16x8*>(wrow + (size_t)t2 * 32u * ROW_BYTES);
+            for (int t2 = 0; t2 < 8; ++t2) a[t2] = *reinterpret_cast<const bf16x8*>(wrow + (size_t)t2 * 32u * ROW_BYTES);
+            cur0 = activate(d0, 0); cur1 = activate(d0, 1);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        Q1POL_STAMP(ts1);
 #pragma unroll 1
         for (int t1 = 0; t1 < 8; ++t1) {
             const uint32_t q0 = 2u * (uint32_t)t1;
-            // phase A: request the odd K-step's operands      (sched_barrier: the compiler must not sink these reads
-#pragma unroll                                          //   back down next to their MFMAs)
-            for (int t2 = 0; t2 < 8; ++t2)
-                a_odd[t2] = *reinterpret_cast<const bf16x8*>(wrow + (size_t)t2 * 32u * ROW_BYTES + (q0 + 1u) * 32u);
-            float a1f[4];                                            // operands of tile t1 + 2, for the next iteration
-            layer1_operands(l_w1, (uint32_t)(t1 + 2) & 7u, col, half, a1f);
-            __builtin_amdgcn_sched_barrier(0);
-            // phase B: even K-step on the matrix pipe; layer 1 + tanh of the NEXT tile on the VALU meanwhile
-            const f32x16 dn = layer1_tile(a1n, x1);                  // tile t1 + 1 (the last pass recomputes tile 0, unused)
+            // phase 1: even K-step, first half of tanh(tile t1+1)
 #pragma unroll
-            for (int t2 = 0; t2 < 8; ++t2) acc[t2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_even[t2], cur0, acc[t2], 0, 0, 0);
+            for (int t2 = 0; t2 < 8; ++t2) {
+                acc[t2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[t2], cur0, acc[t2], 0, 0, 0);
+                a[t2] = *reinterpret_cast<const bf16x8*>(wrow + (size_t)t2 * 32u * ROW_BYTES + (q0 + 1u) * 32u);
+            }
             const bf16x8 nxt0 = activate(dn, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            // phase C: request the next even K-step's operands
 #pragma unroll
-            for (int t2 = 0; t2 < 8; ++t2)
-                a_even[t2] = *reinterpret_cast<const bf16x8*>(wrow + (size_t)t2 * 32u * ROW_BYTES + ((q0 + 2u) & 15u) * 32u);
+            for (int i = 0; i < 8; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
+            }
             __builtin_amdgcn_sched_barrier(0);
-            // phase D: odd K-step; second half of the next tile's tanh
+            // phase 2: odd K-step, second half of the tanh, then layer 1 of tile t1+2 (one MFMA)
+            const bf16x8 a_l1n = *reinterpret_cast<const bf16x8*>(w1row + (((uint32_t)t1 + 3u) & 7u) * 1024u);
 #pragma unroll
-            for (int t2 = 0; t2 < 8; ++t2) acc[t2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_odd[t2], cur1, acc[t2], 0, 0, 0);
+            for (int t2 = 0; t2 < 8; ++t2) {
+                acc[t2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[t2], cur1, acc[t2], 0, 0, 0);
+                a[t2] = *reinterpret_cast<const bf16x8*>(wrow + (size_t)t2 * 32u * ROW_BYTES + ((q0 + 2u) & 15u) * 32u);
+            }
             const bf16x8 nxt1 = activate(dn, 1);
+            dn = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_l1, xb, zero16, 0, 0, 0);   // tile t1 + 2 (the last two passes wrap around, unused)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
+            }
             __builtin_amdgcn_sched_barrier(0);
-            cur0 = nxt0; cur1 = nxt1;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) a1n[q] = a1f[q];
+            cur0 = nxt0; cur1 = nxt1; a_l1 = a_l1n;
         }
+        Q1POL_STAMP(ts2);
 
-        // layer 3: all sixteen W3 operands are requested up front (64 VGPRs; the file has room with one wave per SIMD)
-        bf16x8 w3f[16];
-#pragma unroll
-        for (int q = 0; q < 16; ++q) w3f[q] = *reinterpret_cast<const bf16x8*>(l_w3 + (size_t)col * ROW_BYTES + ((uint32_t)q * 16u + half * 8u) * 2u);
-        f32x16 y, y2;                                                // two chains: consecutive MFMAs do not wait on each other
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { y[r] = 0.0f; y2[r] = 0.0f; }
+        // layer 3: tanh(H2 tile) and its two K-steps, W3 operands requested two tiles ahead
+        f32x16 y = zero16;
+        bf16x8 w3a = *reinterpret_cast<const bf16x8*>(w3row), w3b = *reinterpret_cast<const bf16x8*>(w3row + 32u);
 #pragma unroll
         for (int t2 = 0; t2 < 8; ++t2) {
             const bf16x8 f0 = activate(acc[t2], 0), f1 = activate(acc[t2], 1);
-            y = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w3f[2 * t2], f0, y, 0, 0, 0);
-            y2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w3f[2 * t2 + 1], f1, y2, 0, 0, 0);
+            y = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w3a, f0, y, 0, 0, 0);
+            y = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w3b, f1, y, 0, 0, 0);
+            if (t2 < 7) {
+                w3a = *reinterpret_cast<const bf16x8*>(w3row + (uint32_t)(2 * t2 + 2) * 32u);
+                w3b = *reinterpret_cast<const bf16x8*>(w3row + (uint32_t)(2 * t2 + 3) * 32u);
+            }
         }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) y[r] += y2[r];
         // y[r] = output row (r&3) + 8(r>>2) + 4*half of env `col`: rows 0..7 come from registers 0..3 of the two halves,
         // rows 8..9 from registers 4..5 of half 0
         if (live) {
-            float* dst = out + (size_t)env * OUT;
-            if (OUT >= 8) {
+            float* dst = out + (size_t)env * (uint32_t)OUT;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) dst[r + 4 * half] = y[r] + b3[r + 4 * half];
-                if (half == 0) {
+            for (int r = 0; r < 4; ++r)
+                if ((int)(r + 4 * half) < OUT) dst[r + 4 * half] = y[r] + b3[r + 4 * half];
+            if (half == 0) {
 #pragma unroll
-                    for (int r = 4; r < 4 + (OUT - 8); ++r) dst[r + 4] = y[r] + b3[r + 4];
-                }
-            } else if (half == 0) {
-#pragma unroll
-                for (int r = 0; r < OUT; ++r) dst[r] = y[r] + b3[r];
+                for (int r = 4; r < 6; ++r)
+                    if (r + 4 < OUT) dst[r + 4] = y[r] + b3[r + 4];
             }
         }
+#ifdef Q1POL_TRACE
+        __builtin_amdgcn_sched_barrier(0);
+        const uint64_t ts3 = __builtin_amdgcn_s_memtime();
+        tr_pro += ts1 - ts0; tr_loop += ts2 - ts1; tr_l3 += ts3 - ts2; tr_chunks += 1;
+#endif
     }
+#ifdef Q1POL_TRACE
+    if (blockIdx.x == 0 && tid == 0) {                  // s_memtime ticks summed over this wave's tiles
+        out[0] = (float)tr_pro; out[1] = (float)tr_loop; out[2] = (float)tr_l3; out[3] = (float)tr_chunks;
+        out[4] = (float)(wall_clock64() - tr_real0); out[5] = (float)(__builtin_amdgcn_s_memtime() - tr_mem0);
+    }
+#endif
 }
 
 }  // namespace q1pol

@@ -171,6 +171,10 @@ class DeviceEnv:
     def policy_forward_dev(self, obs, w1, b1, w23_image, b2, b3, out_dim, out):
         _lib.check(self._lib.q1env_policy_forward(self._h, obs, w1, b1, w23_image, b2, b3, int(out_dim), out))
 
+    def policy_value_forward_dev(self, obs, pi: "_lib.Q1Mlp", vf: "_lib.Q1Mlp"):
+        """Both networks of a sampler tick in one launch (q1env_policy_value_forward); pi / vf are _lib.Q1Mlp structs."""
+        _lib.check(self._lib.q1env_policy_value_forward(self._h, obs, C.byref(pi), C.byref(vf)))
+
     def episode_stats_dev(self, reward, done, zero_start, ep_return, partials):
         _lib.check(self._lib.q1env_episode_stats(self._h, reward, done, zero_start, ep_return, partials))
 

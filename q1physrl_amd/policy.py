@@ -204,13 +204,21 @@ class FusedPolicyForward:
             img[:256, :256].copy_(l2.weight[:, self._perm])
             img[256:256 + l3.out_features, :256].copy_(l3.weight[:, self._perm])
 
-    def __call__(self, obs):
+    def _mlp(self, name, out):
+        from . import _lib
+        w1, b1, img, b2, b3 = self._w[name]
+        return _lib.Q1Mlp(w1.data_ptr(), b1.data_ptr(), img.data_ptr(), b2.data_ptr(), b3.data_ptr(), out.data_ptr(), out.shape[1])
+
+    def __call__(self, obs, separate_launches=False):
         assert obs.dtype == torch.float32 and obs.is_contiguous() and obs.shape == (self.env.num_envs, 6)
         d = self.env._dev
-        for name, out in (("pi", self.logits), ("vf", self.value)):
-            w1, b1, img, b2, b3 = self._w[name]
-            d.policy_forward_dev(obs.data_ptr(), w1.data_ptr(), b1.data_ptr(), img.data_ptr(), b2.data_ptr(), b3.data_ptr(),
-                                 out.shape[1], out.data_ptr())
+        if separate_launches:                  # one q1env_policy_forward per network (same bits; kept for tests / measurement)
+            for name, out in (("pi", self.logits), ("vf", self.value)):
+                w1, b1, img, b2, b3 = self._w[name]
+                d.policy_forward_dev(obs.data_ptr(), w1.data_ptr(), b1.data_ptr(), img.data_ptr(), b2.data_ptr(), b3.data_ptr(),
+                                     out.shape[1], out.data_ptr())
+        else:                                  # both networks in one launch, half of the CUs each
+            d.policy_value_forward_dev(obs.data_ptr(), self._mlp("pi", self.logits), self._mlp("vf", self.value))
         return self.logits, self.value[:, 0]
 
     def parameters(self):

@@ -218,15 +218,20 @@ def test_eval_sim_with_wr_policy_through_the_compat_api():
 
 
 def _emulate_fused_forward(net, obs):
-    """torch restatement of q1env_policy_forward's arithmetic: float32 layer 1; tanh -> bf16; bf16 W2 / W3; float32 accumulate."""
+    """torch restatement of q1env_policy_forward's arithmetic: layer 1 with bf16 W1 and the inputs / bias split into two bf16
+    (hi + lo); tanh -> bf16; bf16 W2 / W3; float32 accumulation everywhere."""
     import torch
     l1, l2, l3 = net[0], net[2], net[4]
-    h1 = torch.tanh(obs @ l1.weight.T + l1.bias).to(torch.bfloat16).float()
+
+    def split(x):
+        hi = x.to(torch.bfloat16).float()
+        return hi + (x - hi).to(torch.bfloat16).float()
+    h1 = torch.tanh(split(obs) @ l1.weight.to(torch.bfloat16).float().T + split(l1.bias)).to(torch.bfloat16).float()
     h2 = torch.tanh(h1 @ l2.weight.to(torch.bfloat16).float().T + l2.bias).to(torch.bfloat16).float()
     return h2 @ l3.weight.to(torch.bfloat16).float().T + l3.bias
 
 
-@pytest.mark.parametrize("n", [32768, 1000, 37])
+@pytest.mark.parametrize("n", [32768, 1000, 37, 70001])
 def test_fused_mfma_policy_forward(n):
     """The matrix-core forward pass against (a) a torch emulation of its own mixed precision - this pins the MFMA operand /
     accumulator layout, any mistake there is an O(1) error - and (b) the float32 torch modules (bf16 rounding only)."""
@@ -244,8 +249,10 @@ def test_fused_mfma_policy_forward(n):
                 layer.bias.copy_(torch.randn_like(layer.bias) * 0.3)
     fused = P.FusedPolicyForward(pol, env)
     obs = (torch.randn((n, 6), device="cuda") * torch.tensor([0.5, 3.0, 0.3, 2.0, 2.0, 1.0], device="cuda")).contiguous()
-    logits, value = fused(obs)
+    l2, v2 = (t.clone() for t in fused(obs, separate_launches=True))   # one q1env_policy_forward per network
+    logits, value = fused(obs)                                         # q1env_policy_value_forward: both in one launch
     torch.cuda.synchronize()
+    assert torch.equal(l2, logits) and torch.equal(v2, value)
     with torch.no_grad():
         emu_l, emu_v = _emulate_fused_forward(pol.pi, obs), _emulate_fused_forward(pol.vf, obs)[:, 0]
         ref_l, ref_v = pol(obs)
