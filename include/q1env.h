@@ -208,6 +208,18 @@ int q1env_policy_sample(q1env_t* env, const float* logits_dev, int row_stride, u
 int q1env_gae(q1env_t* env, int ticks, const float* reward_dev, const float* value_dev, const uint8_t* done_dev,
               float gamma, float lam, float* adv_dev, float* vtarg_dev);
 
+/* One sampler tick after the policy forward in ONE launch: q1env_policy_sample (counter) -> q1env_step_autoreset with the
+ * sampled packed action -> q1env_episode_stats; bit-identical to that sequence of three calls.  Writes the sampled action
+ * and its log-probability (keys uint8[N], mouse float[N], logp float[N]: the trajectory the learner needs), the step's reward /
+ * done / zero_start and the next observation row (float[N][6], fresh first observation for envs that were reset), and updates
+ * ep_return / partials as q1env_episode_stats does.  RNG counter = counter_offset + (*counter_dev if counter_dev else the
+ * handle's host-side tick count): a captured horizon passes the tick index as counter_offset and advances *counter_dev once
+ * per horizon. */
+int q1env_sample_step(q1env_t* env, const float* logits_dev, int row_stride, uint64_t seed, const uint64_t* counter_dev,
+                      uint64_t counter_offset, int deterministic, uint8_t* keys_dev, float* mouse_dev, float* logp_dev,
+                      float* obs_dev, float* reward_dev, uint8_t* done_dev, uint8_t* zero_start_dev, double* ep_return_dev,
+                      double* partials_dev);
+
 /* Fused forward pass of one network of the reference policy's shape (RLlib fcnet of data/checkpoints/wr: 6 -> 256 tanh ->
  * 256 tanh -> out_dim, out_dim = 10 policy logits or 1 value) for this handle's N envs: obs float[N][6] -> out float[N][out_dim].
  * w1 float[256][6], b1 float[256], b2 float[256], b3 float[out_dim] in torch nn.Linear layout.  w23_image: W2 (nn.Linear(256,256)

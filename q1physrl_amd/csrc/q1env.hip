@@ -266,18 +266,13 @@ decoder_reset_kernel(Params p, StatePtrs s, int count, const int32_t* idx, const
 // Randomness: Philox stream 3 keyed by (seed, global env, counter): r[0] low bits -> one uniform per key, r[2],r[3] -> Box-Muller.
 constexpr uint32_t STREAM_POLICY = 3;
 
-__global__ void __launch_bounds__(256)
-policy_sample_kernel(Params p, const float* __restrict__ logits, int row_stride, uint64_t seed, uint64_t counter,
-                     const uint64_t* counter_dev, int deterministic, uint8_t* keys_out, float* mouse_out, float* logp_out) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (uint32_t)p.n) return;
-    if (counter_dev) counter += *counter_dev;
-    const float* row = logits + (size_t)i * row_stride;
+__device__ __forceinline__ void sample_action(const Params& p, const float* __restrict__ row, uint64_t seed, uint64_t genv,
+                                              uint64_t counter, int deterministic, uint32_t& keys, float& mouse, float& logp) {
     uint32_t r[4], r2[4];
-    philox_draw(seed, (uint64_t)p.env_index_base + i, counter, STREAM_POLICY, 0, r);
-    philox_draw(seed, (uint64_t)p.env_index_base + i, counter, STREAM_POLICY, 1, r2);
-    float logp = 0.0f;
-    uint32_t keys = 0;
+    philox_draw(seed, genv, counter, STREAM_POLICY, 0, r);
+    philox_draw(seed, genv, counter, STREAM_POLICY, 1, r2);
+    logp = 0.0f;
+    keys = 0;
     const uint32_t ku[4] = {r[0], r[1], r2[0], r2[1]};
     for (int k = 0; k < p.num_keys; ++k) {
         const float l0 = row[2 * k], l1 = row[2 * k + 1];
@@ -289,7 +284,7 @@ policy_sample_kernel(Params p, const float* __restrict__ logits, int row_stride,
         const float z = bit ? -d : d;                             // log softmax[chosen] = -softplus(l_other - l_chosen)
         logp -= (z > 0.0f ? z : 0.0f) + log1pf(expf(-fabsf(z)));
     }
-    float mouse = 0.0f;
+    mouse = 0.0f;
     if (p.yaw_mode == 1) {
         const float S = 0.5f * 1.8137f;
         const float low = -p.action_range_f32, high = p.action_range_f32;
@@ -314,6 +309,17 @@ policy_sample_kernel(Params p, const float* __restrict__ logits, int row_stride,
         const float lp_sq = -0.5f * zq * zq - logf(S) - 0.9189385332046727f;            // N(0, S).logpdf(ub)
         logp += lp_pi - (lp_sq + logf(high - low));
     }
+}
+
+__global__ void __launch_bounds__(256)
+policy_sample_kernel(Params p, const float* __restrict__ logits, int row_stride, uint64_t seed, uint64_t counter,
+                     const uint64_t* counter_dev, int deterministic, uint8_t* keys_out, float* mouse_out, float* logp_out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (uint32_t)p.n) return;
+    if (counter_dev) counter += *counter_dev;
+    uint32_t keys;
+    float mouse, logp;
+    sample_action(p, logits + (size_t)i * row_stride, seed, (uint64_t)p.env_index_base + i, counter, deterministic, keys, mouse, logp);
     keys_out[i] = (uint8_t)keys;
     if (mouse_out) mouse_out[i] = mouse;
     if (logp_out) logp_out[i] = logp;
@@ -348,15 +354,13 @@ gae_kernel(int n, int ticks, const float* __restrict__ reward, const float* __re
 // reduces its 64 envs with cross-lane shuffles and adds into ITS OWN slot of `partials` ([ceil(n/64)][4] doubles:
 // episodes, zero-start episodes, return sum, zero-start return sum): no atomics, bit-reproducible; the host sums the slots
 // when statistics are asked for.  Replaces ~10 elementwise/reduction launches of the torch formulation.
-__global__ void __launch_bounds__(256)
-episode_stats_kernel(int n, const float* __restrict__ reward, const uint8_t* __restrict__ done,
-                     const uint8_t* __restrict__ zero_start, double* __restrict__ ep_return, double* __restrict__ partials) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+// (all 64 lanes of the wave must call this: `live` masks the lanes without an env)
+__device__ __forceinline__ void episode_stats_lane(bool live, uint32_t i, float reward, bool fin, bool zero_start,
+                                                   double* __restrict__ ep_return, double* __restrict__ partials) {
     double v[4] = {0.0, 0.0, 0.0, 0.0};
-    if (i < (uint32_t)n) {
-        const double ret = ep_return[i] + (double)reward[i];
-        const bool fin = done[i] != 0;
-        const bool zs = fin && zero_start[i] != 0;
+    if (live) {
+        const double ret = ep_return[i] + (double)reward;
+        const bool zs = fin && zero_start;
         ep_return[i] = fin ? 0.0 : ret;
         v[0] = fin ? 1.0 : 0.0; v[1] = zs ? 1.0 : 0.0; v[2] = fin ? ret : 0.0; v[3] = zs ? ret : 0.0;
     }
@@ -364,11 +368,65 @@ episode_stats_kernel(int n, const float* __restrict__ reward, const uint8_t* __r
     for (int k = 0; k < 4; ++k)
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) v[k] += __shfl_down(v[k], off, 64);
-    if ((threadIdx.x & 63u) == 0 && i < (uint32_t)n) {
+    if ((threadIdx.x & 63u) == 0 && live) {
         double* slot = partials + (size_t)(i >> 6) * 4;
 #pragma unroll
         for (int k = 0; k < 4; ++k) slot[k] += v[k];
     }
+}
+
+__global__ void __launch_bounds__(256)
+episode_stats_kernel(int n, const float* __restrict__ reward, const uint8_t* __restrict__ done,
+                     const uint8_t* __restrict__ zero_start, double* __restrict__ ep_return, double* __restrict__ partials) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool live = i < (uint32_t)n;
+    episode_stats_lane(live, i, live ? reward[i] : 0.0f, live && done[i] != 0, live && zero_start[i] != 0, ep_return, partials);
+}
+
+// One sampler tick after the policy forward, in ONE launch: q1env_policy_sample -> q1env_step_autoreset (packed action) ->
+// q1env_episode_stats, bit-identical to that sequence.  The sampled action goes from registers straight into the decoder (and
+// to the trajectory arrays); reward / done / zero_start of the step feed the episode statistics without a round trip.
+// counter = counter_offset + *counter_dev: a captured horizon bakes the tick index into counter_offset and advances the
+// device counter once per horizon, so the tick needs no separate "counter += 1" launch either.
+template <bool SPEC>
+__global__ void __launch_bounds__(256)
+sample_step_kernel(Params p, StatePtrs s, const float* __restrict__ logits, int row_stride, uint64_t seed, uint64_t counter,
+                   const uint64_t* counter_dev, int deterministic, uint8_t* keys_out, float* mouse_out, float* logp_out,
+                   float* obs, float* reward, uint8_t* done, uint8_t* zero_start, double* ep_return, double* partials) {
+    __shared__ float slab[4][384];
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t n = (uint32_t)p.n;
+    const bool live = i < n;
+    if (counter_dev) counter += *counter_dev;
+    TickOut<float> o;
+    o.reward = 0.0f; o.done = false;
+    bool zs = false;
+    if (live) {
+        const uint64_t genv = (uint64_t)p.env_index_base + (uint64_t)i;
+        uint32_t keys;
+        float mouse, logp;
+        sample_action(p, logits + (size_t)i * row_stride, seed, genv, counter, deterministic, keys, mouse, logp);
+        keys_out[i] = (uint8_t)keys;
+        if (mouse_out) mouse_out[i] = mouse;
+        if (logp_out) logp_out[i] = logp;
+        Env e;
+        load_env(s, n, i, e);
+        const double yaw_act = cfg_yaw_mode<SPEC>(p) ? (double)mouse : 0.0;        // the packed action layout: float32 mouse
+        tick<float, SPEC>(p, e, keys & ((1u << cfg_num_keys<SPEC>(p)) - 1u), yaw_act, o);
+        zs = (e.flags & FLAG_ZERO_START) != 0;                                      // of the episode the step belonged to
+        if (zero_start) zero_start[i] = zs ? 1 : 0;
+        if (o.done) {
+            reset_philox(p, e, seed, genv, counter + 1);
+            observe<float>(p, e, o.obs);
+        }
+        store_env(s, n, i, e);
+        const uint32_t lane = threadIdx.x & 63u, wave_first = i - lane;
+        if (wave_first + 64u <= n) write_obs_wave_f32(obs, wave_first, lane, o.obs, slab[threadIdx.x >> 6]);
+        else write_obs<float>(obs, (size_t)i, o.obs);
+        reward[i] = o.reward;
+        done[i] = o.done ? 1 : 0;
+    }
+    episode_stats_lane(live, i, o.reward, o.done, zs, ep_return, partials);
 }
 
 // Traffic calibration for the PMC counters (MI355X_MICROARCH.md "HBM": FETCH_SIZE / WRITE_SIZE must be calibrated on
@@ -1117,6 +1175,30 @@ int q1env_episode_stats(q1env_t* h, const float* reward, const uint8_t* done, co
     DeviceGuard guard(h->device);
     hipLaunchKernelGGL(episode_stats_kernel, grid_for(h->p.n, 256), dim3(256), 0, h->stream, h->p.n, reward, done, zero_start, ep_return, partials);
     HIP_TRY(hipGetLastError());
+    return Q1ENV_OK;
+}
+
+int q1env_sample_step(q1env_t* h, const float* logits, int row_stride, uint64_t seed, const uint64_t* counter_dev,
+                      uint64_t counter_offset, int deterministic, uint8_t* keys, float* mouse, float* logp, float* obs, float* reward,
+                      uint8_t* done, uint8_t* zero_start, double* ep_return, double* partials) {
+    if (!h || !logits || !keys || !obs || !reward || !done || !ep_return || !partials)
+        return fail(Q1ENV_ERR_INVALID_ARG, "q1env_sample_step: null argument");
+    DeviceGuard guard(h->device);
+    const int need = 2 * h->p.num_keys + (h->p.yaw_mode == 1 ? 2 : 0);
+    if (h->p.yaw_mode == 2) return fail(Q1ENV_ERR_INVALID_ARG, "q1env_sample_step: discrete yaw is not supported (continuous mouse or no mouse)");
+    if (row_stride < need) return fail(Q1ENV_ERR_INVALID_ARG, "q1env_sample_step: row_stride smaller than 2*num_keys + 2");
+    if (h->p.yaw_mode == 1 && !mouse) return fail(Q1ENV_ERR_INVALID_ARG, "q1env_sample_step: mouse output required");
+    const int blk = block_for(h->p.n);
+    const dim3 g = grid_for(h->p.n, blk), bs(blk);
+    const uint64_t counter = counter_offset + (counter_dev ? 0 : h->tick_count);
+#define Q1_LAUNCH_SS(SP) \
+    hipLaunchKernelGGL((sample_step_kernel<SP>), g, bs, 0, h->stream, h->p, h->st, logits, row_stride, seed, counter, counter_dev, \
+                       deterministic, keys, mouse, logp, obs, reward, done, zero_start, ep_return, partials)
+    if (is_spec(h->p)) Q1_LAUNCH_SS(true);
+    else Q1_LAUNCH_SS(false);
+#undef Q1_LAUNCH_SS
+    HIP_TRY(hipGetLastError());
+    h->tick_count += 1;
     return Q1ENV_OK;
 }
 

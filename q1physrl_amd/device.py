@@ -171,6 +171,13 @@ class DeviceEnv:
     def policy_forward_dev(self, obs, w1, b1, w23_image, b2, b3, out_dim, out):
         _lib.check(self._lib.q1env_policy_forward(self._h, obs, w1, b1, w23_image, b2, b3, int(out_dim), out))
 
+    def sample_step_dev(self, logits, row_stride, seed, counter_dev, counter_offset, deterministic, keys, mouse, logp, obs, reward,
+                        done, zero_start, ep_return, partials):
+        """policy_sample + step_autoreset + episode_stats of one sampler tick in one launch (q1env_sample_step)."""
+        _lib.check(self._lib.q1env_sample_step(self._h, logits, int(row_stride), int(seed) & (2 ** 64 - 1), counter_dev,
+                                               int(counter_offset), int(bool(deterministic)), keys, mouse, logp, obs, reward, done,
+                                               zero_start, ep_return, partials))
+
     def policy_value_forward_dev(self, obs, pi: "_lib.Q1Mlp", vf: "_lib.Q1Mlp"):
         """Both networks of a sampler tick in one launch (q1env_policy_value_forward); pi / vf are _lib.Q1Mlp structs."""
         _lib.check(self._lib.q1env_policy_value_forward(self._h, obs, C.byref(pi), C.byref(vf)))

@@ -209,6 +209,15 @@ class FusedPolicyForward:
         w1, b1, img, b2, b3 = self._w[name]
         return _lib.Q1Mlp(w1.data_ptr(), b1.data_ptr(), img.data_ptr(), b2.data_ptr(), b3.data_ptr(), out.data_ptr(), out.shape[1])
 
+    def forward_into(self, obs, logits_out, value_out):
+        """Both networks in one launch, written straight into caller-owned buffers (the sampler's trajectory rows):
+        logits_out (N, 10) float32, value_out (N,) float32, both contiguous."""
+        n = self.env.num_envs
+        assert obs.dtype == torch.float32 and obs.is_contiguous() and obs.shape == (n, 6)
+        assert logits_out.dtype == torch.float32 and logits_out.is_contiguous() and logits_out.shape == self.logits.shape
+        assert value_out.dtype == torch.float32 and value_out.is_contiguous() and value_out.numel() == n
+        self.env._dev.policy_value_forward_dev(obs.data_ptr(), self._mlp("pi", logits_out), self._mlp("vf", value_out.view(n, 1)))
+
     def __call__(self, obs, separate_launches=False):
         assert obs.dtype == torch.float32 and obs.is_contiguous() and obs.shape == (self.env.num_envs, 6)
         d = self.env._dev

@@ -1,8 +1,12 @@
 """GPU-resident sampler loop ("next" row 1 of SURVEY.md section 8f): the counterpart of RLlib's per-worker
 sampler with nothing leaving the device between ticks:
 
-    obs (N,6) f32 --torch MLP--> logits (N,10) --q1env_policy_sample (HIP)--> packed action + logp
-        --q1env_step_autoreset (HIP)--> reward, done, next obs (fresh first observation for the envs it reset)
+    obs (N,6) f32 --policy forward (torch modules, or the fused MFMA kernel writing straight into the trajectory rows)-->
+    logits (N,10), value --q1env_sample_step (HIP, ONE launch: sample the action + log-prob, step, reset finished episodes,
+    episode statistics)--> packed action, logp, reward, done, next obs (fresh first observation for the envs it reset)
+
+A tick is two launches with the fused policy (q1env_policy_value_forward + q1env_sample_step); fused_tick=False keeps the
+three separate kernels (q1env_policy_sample, q1env_step_autoreset, q1env_episode_stats) - same bits, for tests.
 
 Trajectories are stored tick-major ([T][N]...) in preallocated device tensors; episode statistics follow the
 reference's metric hook (train.py:54-57: the return of zero-start episodes, `zero_start_total_reward`).
@@ -18,8 +22,10 @@ from .tensor_env import TensorVectorEnv
 
 
 class GpuSampler:
-    def __init__(self, env: TensorVectorEnv, policy, horizon: int, autocast_dtype=None, use_graph: bool = False):
+    def __init__(self, env: TensorVectorEnv, policy, horizon: int, autocast_dtype=None, use_graph: bool = False,
+                 fused_tick: bool = True):
         self.env, self.policy, self.T = env, policy, int(horizon)
+        self.fused_tick = bool(fused_tick)
         n, d, t = env.num_envs, env.device, self.T
         self.obs = torch.empty((t + 1, n, 6), dtype=torch.float32, device=d)
         self.keys = torch.empty((t, n), dtype=torch.uint8, device=d)
@@ -48,27 +54,46 @@ class GpuSampler:
         return logits.contiguous(), value
 
     def _horizon(self, deterministic):
-        """T ticks for all envs: no host<->device synchronisation, no per-tick host state."""
+        """T ticks for all envs: no host<->device synchronisation, no per-tick host state (the RNG counter of tick t is
+        the device-resident tick count + t; the count advances once per horizon)."""
         env, dev = self.env, self.env._dev
         cnt = self.tick.data_ptr()
+        into = getattr(self.policy, "forward_into", None)
         for t in range(self.T):
-            logits, value = self._forward(self.obs[t])
-            self.value[t].copy_(value)
-            self.logits[t].copy_(logits)          # what the actions were really sampled from (the learner's "old" policy)
-            logits = self.logits[t]
-            dev.policy_sample_dev(logits.data_ptr(), logits.shape[1], env.seed, 0, self.keys[t].data_ptr(),
-                                  self.mouse[t].data_ptr(), self.logp[t].data_ptr(), deterministic, counter_dev=cnt)
-            # tick with in-kernel reset of finished episodes: reward / done / zero_start of the step, next observation row
-            # (fresh first observation for the envs that were reset) straight into the trajectory buffer
-            dev.step_autoreset_dev(_lib.ACT_PACKED, self.keys[t].data_ptr(), self.mouse[t].data_ptr(), env.seed,
-                                   self.obs[t + 1].data_ptr(), self.reward[t].data_ptr(), self.done[t].data_ptr(),
-                                   env.zero_start.data_ptr(), counter_dev=cnt)
-            # episode bookkeeping (train.py:54-57: return of finished episodes, split by zero_start): one HIP kernel
-            dev.episode_stats_dev(self.reward[t].data_ptr(), self.done[t].data_ptr(), env.zero_start.data_ptr(),
-                                  self.ep_return.data_ptr(), self._stats.data_ptr())
-            self.tick.add_(1)
-        _, v_last = self._forward(self.obs[self.T])
-        self.value[self.T].copy_(v_last)
+            logits = self.logits[t]                   # what the actions are really sampled from (the learner's "old" policy)
+            if into is not None:
+                into(self.obs[t], logits, self.value[t])
+            else:
+                lg, value = self._forward(self.obs[t])
+                self.value[t].copy_(value)
+                logits.copy_(lg)
+            if self.fused_tick:
+                # sample + tick with in-kernel reset of finished episodes + episode bookkeeping (train.py:54-57): one kernel
+                dev.sample_step_dev(logits.data_ptr(), logits.shape[1], env.seed, cnt, t, deterministic, self.keys[t].data_ptr(),
+                                    self.mouse[t].data_ptr(), self.logp[t].data_ptr(), self.obs[t + 1].data_ptr(),
+                                    self.reward[t].data_ptr(), self.done[t].data_ptr(), env.zero_start.data_ptr(),
+                                    self.ep_return.data_ptr(), self._stats.data_ptr())
+            else:
+                dev.policy_sample_dev(logits.data_ptr(), logits.shape[1], env.seed, 0, self.keys[t].data_ptr(),
+                                      self.mouse[t].data_ptr(), self.logp[t].data_ptr(), deterministic, counter_dev=cnt)
+                dev.step_autoreset_dev(_lib.ACT_PACKED, self.keys[t].data_ptr(), self.mouse[t].data_ptr(), env.seed,
+                                       self.obs[t + 1].data_ptr(), self.reward[t].data_ptr(), self.done[t].data_ptr(),
+                                       env.zero_start.data_ptr(), counter_dev=cnt)
+                dev.episode_stats_dev(self.reward[t].data_ptr(), self.done[t].data_ptr(), env.zero_start.data_ptr(),
+                                      self.ep_return.data_ptr(), self._stats.data_ptr())
+                self.tick.add_(1)
+        if self.fused_tick:
+            self.tick.add_(self.T)
+        if into is not None:
+            into(self.obs[self.T], self._scratch_logits(), self.value[self.T])
+        else:
+            _, v_last = self._forward(self.obs[self.T])
+            self.value[self.T].copy_(v_last)
+
+    def _scratch_logits(self):
+        if not hasattr(self, "_scratch"):
+            self._scratch = torch.empty_like(self.logits[0])
+        return self._scratch
 
     @torch.no_grad()
     def collect(self, deterministic=False):

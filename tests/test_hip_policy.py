@@ -337,3 +337,29 @@ def test_graph_captured_sgd_step_matches_eager_learner():
         assert a["sgd_steps"] == b["sgd_steps"] == 3 * (512 * 32 // 2048) and a["kl_coeff"] == b["kl_coeff"]
         for k in ppo.STAT_KEYS:
             assert abs(a[k] - b[k]) <= 1e-3 * max(1.0, abs(a[k])), (k, a[k], b[k])
+
+
+@pytest.mark.parametrize("n,fused_policy", [(4096, False), (1000, True)])
+def test_fused_sampler_tick_equals_three_kernels(n, fused_policy):
+    """q1env_sample_step (sample + step + autoreset + episode statistics in one launch, RNG counter = device tick count + tick
+    index) against the q1env_policy_sample / q1env_step_autoreset / q1env_episode_stats sequence: identical trajectories, env
+    state and statistics over three horizons with episode ends and resets (ragged tail wave included for n = 1000)."""
+    import torch
+    from q1physrl_amd import policy as P
+    from q1physrl_amd.sampler import GpuSampler
+    res = []
+    for fused_tick in (False, True):
+        torch.manual_seed(1)
+        cfg, env = make_env(n, seed=9, time_limit=0.5, zero_start_prob=0.3)
+        pol = P.Q1Policy().cuda()
+        s = GpuSampler(env, P.FusedPolicyForward(pol, env) if fused_policy else pol, horizon=48, fused_tick=fused_tick)
+        trajs = [{k: v.clone() for k, v in s.collect().items()} for _ in range(3)]
+        res.append((trajs, s.stats, env.get_state(), int(s.tick.item())))
+        env.close()
+    (ta, sa, ea, ca), (tb, sb, eb, cb) = res
+    assert ca == cb == 3 * 48 and sa == sb and sa["episodes"] > n
+    for h in range(3):
+        for k in ta[h]:
+            assert torch.equal(ta[h][k], tb[h][k]), (h, k)
+    for k in ea:
+        assert np.array_equal(ea[k], eb[k]), k
