@@ -1,8 +1,9 @@
 // q1policy.hpp - fused forward pass of one policy / value network of the reference's shape (RLlib fcnet of the published
-// checkpoint, SURVEY.md section 2: obs 6 -> 256 tanh -> 256 tanh -> OUT, OUT = 10 logits or 1 value) for gfx950.
+// checkpoint, SURVEY.md section 2: obs 6 -> 256 tanh -> 256 tanh -> OUT, OUT = 10 logits or 1 value) for gfx950; one launch
+// evaluates one network or the policy AND the value network (half of the CUs each).
 //
-// This is the GEMM-shaped neighbour of the env hot path (the sampler tick is: this, q1env_policy_sample, q1env_step,
-// q1env_reset_philox), so it is the one place matrix cores are used - for all three layers, computed TRANSPOSED
+// This is the GEMM-shaped neighbour of the env hot path (the sampler tick is: this, then q1env_sample_step), so it is the
+// one place matrix cores are used - for all three layers, computed TRANSPOSED
 // (hidden units are MFMA rows, envs are MFMA columns), so that the output of one layer is already distributed the way the
 // next layer's B operand needs it and activations never leave registers:
 //   layer 1  H1^T = W1b . (Xhi + Xlo)^T  ONE v_mfma_f32_32x32x16_bf16 per 32-row tile: bf16 weights, inputs and bias split into
@@ -13,9 +14,15 @@
 // B operand wants 8 consecutive K indices per lane.  Instead of shuffling activations, the K index of the NEXT layer's
 // weights is permuted once, when they are staged into LDS: within every 16 hidden units the four groups of four are stored
 // in the order (0, 2, 1, 3).  Then lane (c, h)'s accumulator registers 8u..8u+7 ARE its B operand of K-step 2t + u.
-// One workgroup (4 waves, one per SIMD) keeps W2 / W3 (bf16, rows padded by 16 B so the 16-byte operand reads are
-// bank-conflict free), W1ext and b2 in LDS - 157.5 KB of the CU's 160 KB - and walks 128-env chunks grid-stride, so the weights
-// are fetched once per CU, not once per chunk.  tanh = 1 - 2/(2^(2x log2 e) + 1) on v_exp_f32 / v_rcp_f32.
+// One workgroup per CU keeps W2 / W3 (bf16, rows padded by 16 B so the 16-byte operand reads are bank-conflict free), the
+// layer-1 operand image and b2 in LDS - 157.5 KB of the CU's 160 KB; every wave walks its own 32-env tiles grid-stride, so the
+// weights are fetched once per CU, not once per tile.  tanh = 1 - 2/(2^(2x log2 e) + 1) on v_exp_f32 / v_rcp_f32.
+// Measured on MI355X (tools/trace_mlp.py, gpurun_scratch micro-benchmarks): under this load the shader
+// clock settles at ~1.6 GHz; a tile costs ~7 600 cycles per SIMD against a VALU floor of ~6 500 (512 tanh per lane: 4 250 cycles
+// of v_exp/v_rcp at 8.3 cycles each, the rest packed float32 and bf16 converts) and an MFMA floor of 4 864 (152 x 32 cycles).
+// What mattered, in order: accumulators in VGPRs (a 256-register budget; with 512 the compiler parks them in AGPRs and pays a
+// v_accvgpr_read per tanh input), layer 1 as one bf16 MFMA instead of four dependent float32 ones, MFMA / VALU alternation in the
+// instruction stream (one wave issues in order), both networks in one launch (weight staging overlaps).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
