@@ -208,6 +208,20 @@ int q1env_policy_sample(q1env_t* env, const float* logits_dev, int row_stride, u
 int q1env_gae(q1env_t* env, int ticks, const float* reward_dev, const float* value_dev, const uint8_t* done_dev,
               float gamma, float lam, float* adv_dev, float* vtarg_dev);
 
+/* PPO loss of one minibatch and its gradient with respect to the policy outputs, in one kernel (learner side; the closed forms
+ * of RLlib 0.8.4's PPOLoss, as configured by q1physrl/train.py:60-64 + data/params.yml:4-13, over the reference's Q1PhysActionDist,
+ * q1physrl/action_dist.py:46-243, differentiated by hand).  Per sample b of `batch`: logits / old_logits float[batch][row_stride]
+ * (current and behaviour policy outputs), keys uint8 bit mask + mouse float (the action taken), logp_old, adv (already
+ * standardised), value (current), value_old, vtarg.  Outputs: dlogits float[batch][row_stride] and dvalue float[batch] =
+ * d mean(total loss) / d(logits, value) - feed them to autograd.backward of the networks; partials float[ceil(batch/256)][5] =
+ * per-block sums of (entropy, kl, policy loss, total loss, vf loss).  kl_coeff_dev: device scalar (it changes between updates
+ * while a captured graph replays this launch).  The handle supplies num_keys / action_range and the stream. */
+int q1env_ppo_loss_grad(q1env_t* env, int64_t batch, const float* logits_dev, const float* old_logits_dev, int row_stride,
+                        const uint8_t* keys_dev, const float* mouse_dev, const float* logp_old_dev, const float* adv_dev,
+                        const float* value_dev, const float* value_old_dev, const float* vtarg_dev, float clip_param,
+                        float vf_clip_param, float vf_loss_coeff, float entropy_coeff, const float* kl_coeff_dev,
+                        float* dlogits_dev, float* dvalue_dev, float* partials_dev);
+
 /* One sampler tick after the policy forward in ONE launch: q1env_policy_sample (counter) -> q1env_step_autoreset with the
  * sampled packed action -> q1env_episode_stats; bit-identical to that sequence of three calls.  Writes the sampled action
  * and its log-probability (keys uint8[N], mouse float[N], logp float[N]: the trajectory the learner needs), the step's reward /

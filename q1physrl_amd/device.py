@@ -171,6 +171,12 @@ class DeviceEnv:
     def policy_forward_dev(self, obs, w1, b1, w23_image, b2, b3, out_dim, out):
         _lib.check(self._lib.q1env_policy_forward(self._h, obs, w1, b1, w23_image, b2, b3, int(out_dim), out))
 
+    def ppo_loss_grad_dev(self, batch, logits, old_logits, row_stride, keys, mouse, logp_old, adv, value, value_old, vtarg, clip_param,
+                          vf_clip_param, vf_loss_coeff, entropy_coeff, kl_coeff_dev, dlogits, dvalue, partials):
+        _lib.check(self._lib.q1env_ppo_loss_grad(self._h, int(batch), logits, old_logits, int(row_stride), keys, mouse or None, logp_old,
+                                                 adv, value, value_old, vtarg, float(clip_param), float(vf_clip_param),
+                                                 float(vf_loss_coeff), float(entropy_coeff), kl_coeff_dev, dlogits, dvalue, partials))
+
     def sample_step_dev(self, logits, row_stride, seed, counter_dev, counter_offset, deterministic, keys, mouse, logp, obs, reward,
                         done, zero_start, ep_return, partials):
         """policy_sample + step_autoreset + episode_stats of one sampler tick in one launch (q1env_sample_step)."""

@@ -53,9 +53,18 @@ def allreduce_grads_(params, world):
 
 
 class PPOLearner:
+    """SGD epochs over trajectory batches.
+
+    use_graph:   one SGD step (forward, loss, backward, Adam) captured once into a hipGraph and replayed per minibatch (single
+                 process only).
+    fused_loss:  the loss and its gradient w.r.t. (logits, value) come from ONE HIP kernel (q1env_ppo_loss_grad, closed-form
+                 derivatives) instead of ~100 elementwise torch launches and their autograd twins; torch autograd only runs the
+                 two MLPs.  Needs `env` (a TensorVectorEnv: its handle supplies num_keys / action_range and the stream).
+    """
+
     def __init__(self, policy, action_range, lr=5e-6, gamma=0.99, lam=0.95, clip_param=0.3, vf_clip_param=100.0,
                  vf_loss_coeff=1.0, entropy_coeff=0.01, kl_coeff=0.2, kl_target=0.0036, num_sgd_iter=30,
-                 minibatch_size=128, num_keys=4, seed=0, use_graph=False):
+                 minibatch_size=128, num_keys=4, seed=0, use_graph=False, fused_loss=False, env=None):
         self.policy = policy
         self.action_range = float(action_range)
         self.gamma, self.lam = gamma, lam
@@ -63,70 +72,91 @@ class PPOLearner:
         self.vf_loss_coeff, self.entropy_coeff = vf_loss_coeff, entropy_coeff
         self.kl_coeff, self.kl_target = kl_coeff, kl_target
         self.num_sgd_iter, self.minibatch_size, self.num_keys = num_sgd_iter, minibatch_size, num_keys
-        # use_graph: one SGD step (loss, backward, Adam) captured once into a hipGraph and replayed per minibatch - the step
-        # is ~100 small launches on a 138 k-parameter model, i.e. launch-bound.  Single-process only.
-        self.use_graph = bool(use_graph) and not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1)
+        self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        self.use_graph = bool(use_graph) and self.world == 1
+        self.fused_loss, self.env = bool(fused_loss), env
+        if self.fused_loss and env is None:
+            raise ValueError("fused_loss=True needs env= (the TensorVectorEnv whose handle runs q1env_ppo_loss_grad)")
         self.opt = torch.optim.Adam(policy.parameters(), lr=lr, capturable=self.use_graph)
         self._graph = None
+        self._klc = None                        # device scalar: the KL coefficient as the captured graph / the kernel reads it
+        self._work = None
         self.gen = None
         self.seed = seed
-        self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
 
     def _flatten(self, traj, adv, vtarg, old_logits):
         t, n = traj["reward"].shape
         keys = ((traj["keys"].reshape(-1, 1).long() >> torch.arange(self.num_keys, device=adv.device)) & 1)
-        return {"obs": traj["obs"][:t].reshape(t * n, 6), "keys": keys, "mouse": traj["mouse"].reshape(-1, 1),
-                "logp": traj["logp"].reshape(-1), "value": traj["value"][:t].reshape(-1), "adv": adv.reshape(-1),
-                "vtarg": vtarg.reshape(-1), "old_logits": old_logits}
+        return {"obs": traj["obs"][:t].reshape(t * n, 6), "keys": keys, "keys_packed": traj["keys"].reshape(-1),
+                "mouse": traj["mouse"].reshape(-1, 1), "logp": traj["logp"].reshape(-1), "value": traj["value"][:t].reshape(-1),
+                "adv": adv.reshape(-1), "vtarg": vtarg.reshape(-1), "old_logits": old_logits}
 
-    def _graph_epochs(self, b, total, mb, dev):
-        """All SGD steps of one update through a captured hipGraph of a single step on static minibatch buffers."""
-        if self._graph is None or self._mb["adv"].shape[0] != mb:
-            self._mb = {k: torch.empty((mb,) + tuple(v.shape[1:]), dtype=v.dtype, device=dev) for k, v in b.items()}
-            self._klc = torch.tensor(float(self.kl_coeff), dtype=torch.float32, device=dev)
-            self._acc = torch.zeros((len(STAT_KEYS),), dtype=torch.float32, device=dev)
+    def _sgd_step(self, mb):
+        """One minibatch: forward, loss, backward, (gradient all-reduce,) Adam.  Returns the stats vector (STAT_KEYS order)."""
+        if self.fused_loss:
+            logits, value = self.policy(mb["obs"])
+            bsz, width = logits.shape
+            if self._work is None or self._work[0].shape != logits.shape:
+                dev = logits.device
+                self._work = (torch.empty_like(logits), torch.empty_like(value),
+                              torch.zeros(((bsz + 255) // 256, len(STAT_KEYS)), dtype=torch.float32, device=dev))
+            dlogits, dvalue, partials = self._work
+            assert logits.is_contiguous() and value.is_contiguous() and mb["old_logits"].is_contiguous()
+            self.env._dev.ppo_loss_grad_dev(bsz, logits.data_ptr(), mb["old_logits"].data_ptr(), width, mb["keys_packed"].data_ptr(),
+                                            mb["mouse"].data_ptr(), mb["logp"].data_ptr(), mb["adv"].data_ptr(), value.data_ptr(),
+                                            mb["value"].data_ptr(), mb["vtarg"].data_ptr(), self.clip_param, self.vf_clip_param,
+                                            self.vf_loss_coeff, self.entropy_coeff, self._klc.data_ptr(), dlogits.data_ptr(),
+                                            dvalue.data_ptr(), partials.data_ptr())
+            self.opt.zero_grad(set_to_none=True)
+            torch.autograd.backward([logits, value], [dlogits, dvalue])
+            stats = partials.sum(dim=0) / bsz
+        else:
+            loss, st = ppo_loss(self.policy, mb, self.action_range, self.clip_param, self.vf_clip_param, self.vf_loss_coeff,
+                                self.entropy_coeff, self._klc, self.num_keys)
+            self.opt.zero_grad(set_to_none=True)
+            loss.backward()
+            stats = torch.stack([st[k].float() for k in STAT_KEYS])
+        if self.world > 1:
+            allreduce_grads_([p for p in self.policy.parameters()], self.world)
+        self.opt.step()
+        return stats
 
-            def one_step():
-                loss, st = ppo_loss(self.policy, self._mb, self.action_range, self.clip_param, self.vf_clip_param,
-                                    self.vf_loss_coeff, self.entropy_coeff, self._klc, self.num_keys)
-                self.opt.zero_grad(set_to_none=True)
-                loss.backward()
-                self.opt.step()
-                self._acc += torch.stack([st[k].float() for k in STAT_KEYS])
+    def _capture(self, b, mb, dev):
+        """Capture one SGD step on static minibatch buffers into a hipGraph (warm-up on a side stream first; the warm-up and
+        capture steps trained on the first minibatch, so parameters and Adam moments are rolled back afterwards)."""
+        self._mb = {k: torch.empty((mb,) + tuple(v.shape[1:]), dtype=v.dtype, device=dev) for k, v in b.items()}
+        self._acc = torch.zeros((len(STAT_KEYS),), dtype=torch.float32, device=dev)
+        for k, v in b.items():
+            self._mb[k].copy_(v[:mb])
+        snapshot = [p.detach().clone() for p in self.policy.parameters()]
 
-            for k, v in b.items():
-                self._mb[k].copy_(v[:mb])
-            snapshot = [p.detach().clone() for p in self.policy.parameters()]
-            side = torch.cuda.Stream(device=dev)
-            side.wait_stream(torch.cuda.current_stream(dev))
-            with torch.cuda.stream(side):
-                for _ in range(3):                     # warm-up (allocator, Adam state) on a side stream
-                    one_step()
-            torch.cuda.current_stream(dev).wait_stream(side)
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+        def one_step():
+            self._acc += self._sgd_step(self._mb)
+
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            if self.env is not None:
+                self.env.use_current_stream()
+            for _ in range(3):
                 one_step()
-            # the warm-up / capture steps trained on the first minibatch: undo them (parameters and Adam moments)
-            with torch.no_grad():
-                for p, q in zip(self.policy.parameters(), snapshot):
-                    p.copy_(q)
-                for st_ in self.opt.state.values():
-                    for k_, v_ in st_.items():
-                        if torch.is_tensor(v_):
-                            v_.zero_()
-            self._graph = g
-        self._klc.fill_(float(self.kl_coeff))
-        self._acc.zero_()
-        steps = 0
-        for _ in range(self.num_sgd_iter):
-            perm = torch.randperm(total, device=dev, generator=self.gen)
-            for s in range(0, total - mb + 1, mb):
-                idx = perm[s:s + mb]
-                for k, v in b.items():
-                    torch.index_select(v, 0, idx, out=self._mb[k])
-                self._graph.replay()
-                steps += 1
-        return self._acc.clone(), steps
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            if self.env is not None:
+                self.env.use_current_stream()          # the kernel launch must land on the capturing stream
+            one_step()
+        if self.env is not None:
+            self.env.use_current_stream()              # back on the caller's stream
+        with torch.no_grad():
+            for p, q in zip(self.policy.parameters(), snapshot):
+                p.copy_(q)
+            for st_ in self.opt.state.values():
+                for v_ in st_.values():
+                    if torch.is_tensor(v_):
+                        v_.zero_()
+        self._graph = g
 
     def update(self, traj, adv, vtarg):
         """SGD epochs over one trajectory batch; adv/vtarg from q1env_gae.  Returns averaged stats (python floats)."""
@@ -149,26 +179,27 @@ class PPOLearner:
         mb = min(self.minibatch_size, total)
         if self.gen is None:
             self.gen = torch.Generator(device=dev).manual_seed(self.seed)
-        params = [p for p in self.policy.parameters()]
-        acc, steps = None, 0
+        if self._klc is None:
+            self._klc = torch.zeros((), dtype=torch.float32, device=dev)
+        self._klc.fill_(float(self.kl_coeff))
+        if self.use_graph and (self._graph is None or self._mb["adv"].shape[0] != mb):
+            self._capture(b, mb, dev)
+        acc, steps = torch.zeros((len(STAT_KEYS),), dtype=torch.float32, device=dev), 0
         if self.use_graph:
-            acc, steps = self._graph_epochs(b, total, mb, dev)
-        else:
-            for _ in range(self.num_sgd_iter):
-                perm = torch.randperm(total, device=dev, generator=self.gen)
-                for s in range(0, total - mb + 1, mb):
-                    idx = perm[s:s + mb]
-                    mbatch = {k: v[idx] for k, v in b.items()}
-                    loss, st = ppo_loss(self.policy, mbatch, self.action_range, self.clip_param, self.vf_clip_param,
-                                        self.vf_loss_coeff, self.entropy_coeff, self.kl_coeff, self.num_keys)
-                    self.opt.zero_grad(set_to_none=True)
-                    loss.backward()
-                    if self.world > 1:
-                        allreduce_grads_(params, self.world)
-                    self.opt.step()
-                    vals = torch.stack([st[k] for k in sorted(st)])
-                    acc = vals if acc is None else acc + vals
-                    steps += 1
+            self._acc.zero_()
+        for _ in range(self.num_sgd_iter):
+            perm = torch.randperm(total, device=dev, generator=self.gen)
+            for s in range(0, total - mb + 1, mb):
+                idx = perm[s:s + mb]
+                if self.use_graph:
+                    for k, v in b.items():
+                        torch.index_select(v, 0, idx, out=self._mb[k])
+                    self._graph.replay()
+                else:
+                    acc = acc + self._sgd_step({k: v[idx] for k, v in b.items()})
+                steps += 1
+        if self.use_graph:
+            acc = self._acc.clone()
         acc = acc / steps
         if self.world > 1:
             dist.all_reduce(acc, op=dist.ReduceOp.SUM)

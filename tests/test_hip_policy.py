@@ -363,3 +363,88 @@ def test_fused_sampler_tick_equals_three_kernels(n, fused_policy):
             assert torch.equal(ta[h][k], tb[h][k]), (h, k)
     for k in ea:
         assert np.array_equal(ea[k], eb[k]), k
+
+
+def test_ppo_loss_grad_kernel_matches_autograd():
+    """q1env_ppo_loss_grad (closed-form derivatives, one kernel) against torch autograd of q1physrl_amd.ppo.ppo_loss on the same
+    minibatch: statistics and d loss / d(logits, value), including clamped mean / log_std rows, ratios outside the clip range
+    and clipped value errors."""
+    import torch
+    from q1physrl_amd import ppo
+    from q1physrl_amd.policy import Q1PhysActionDist
+    torch.manual_seed(5)
+    bsz = 5000                                               # ragged last block
+    cfg, env = make_env(64)
+    g = torch.Generator(device="cuda").manual_seed(2)
+    rnd = lambda *sh, **kw: torch.randn(*sh, device="cuda", generator=g, **kw)
+    old_logits = rnd(bsz, 10) * torch.tensor([1, 1, 1, 1, 1, 1, 1, 1, 1.5, 0.7], device="cuda")
+    logits = (old_logits + 0.3 * rnd(bsz, 10)).requires_grad_(True)
+    with torch.no_grad():
+        logits[:200, 8] = 3.5                                 # mean outside +-3 -> clamp gates the gradient
+        logits[200:300, 9] = 2.5                             # log_std above its clamp
+        logits[300:400, 9] = -21.0
+        dist_old = Q1PhysActionDist(old_logits, cfg.action_range)
+        keys, mouse = dist_old.sample(generator=g)
+        logp_old = dist_old.logp(keys, mouse) + 0.4 * rnd(bsz)           # ratios spread well beyond 1 +- 0.3
+    value_old = 50.0 * rnd(bsz)
+    value = (value_old + 60.0 * rnd(bsz) * (torch.rand(bsz, device="cuda", generator=g) < 0.5)).requires_grad_(True)
+    vtarg = value_old + 80.0 * rnd(bsz)
+    adv = rnd(bsz)
+    klc = 0.37
+
+    class Fixed(torch.nn.Module):                            # ppo_loss calls policy(obs): hand it the leaf tensors
+        def forward(self, obs):
+            return logits, value
+    mb = {"obs": None, "old_logits": old_logits, "keys": keys, "mouse": mouse, "logp": logp_old, "adv": adv, "value": value_old,
+          "vtarg": vtarg}
+    loss, st = ppo.ppo_loss(Fixed(), mb, cfg.action_range, 0.3, 100.0, 1.0, 0.01, klc)
+    loss.backward()
+    packed = (keys.long() << torch.arange(4, device="cuda")).sum(1).to(torch.uint8)
+    dl, dv = torch.empty_like(logits), torch.empty_like(value)
+    partials = torch.zeros(((bsz + 255) // 256, 5), device="cuda")
+    klc_dev = torch.tensor(klc, device="cuda")
+    env._dev.ppo_loss_grad_dev(bsz, logits.data_ptr(), old_logits.data_ptr(), 10, packed.data_ptr(), mouse.data_ptr(), logp_old.data_ptr(),
+                               adv.data_ptr(), value.data_ptr(), value_old.data_ptr(), vtarg.data_ptr(), 0.3, 100.0, 1.0, 0.01,
+                               klc_dev.data_ptr(), dl.data_ptr(), dv.data_ptr(), partials.data_ptr())
+    torch.cuda.synchronize()
+    stats = dict(zip(ppo.STAT_KEYS, (partials.double().sum(0) / bsz).tolist()))
+    for k in ppo.STAT_KEYS:
+        assert abs(stats[k] - float(st[k])) <= 2e-5 * max(1.0, abs(float(st[k]))), (k, stats[k], float(st[k]))
+    scale = float(logits.grad.abs().max())
+    assert float((dl - logits.grad).abs().max()) <= 2e-5 * scale, (float((dl - logits.grad).abs().max()), scale)
+    assert float((dv - value.grad).abs().max()) <= 1e-6 * float(value.grad.abs().max())
+    assert float(logits.grad[:200, 8].abs().max()) == 0.0 and float(dl[:200, 8].abs().max()) == 0.0      # gated by the clamp
+    assert float(dl[200:400, 9].abs().max()) == 0.0
+    env.close()
+
+
+def test_fused_loss_learner_matches_torch_loss_learner():
+    """PPOLearner(fused_loss=True) (eager and graph-captured) against the torch-loss learner on the same trajectories."""
+    import copy
+    import torch
+    from q1physrl_amd import policy as P, ppo, sampler as S
+    torch.manual_seed(3)
+    base = P.Q1Policy().cuda()
+    cfg, env = make_env(512, time_limit=1.0)
+    smp = S.GpuSampler(env, base, horizon=32)
+    trajs = []
+    for _ in range(2):
+        tr = {k: v.clone() for k, v in smp.collect().items()}
+        adv, vt = smp.advantages(tr, 0.99, 0.95)
+        trajs.append((tr, adv.clone(), vt.clone()))
+    res = []
+    for fused, graph in ((False, False), (True, False), (True, True)):
+        pol = copy.deepcopy(base)
+        lr = ppo.PPOLearner(pol, cfg.action_range, lr=1e-3, num_sgd_iter=3, minibatch_size=2048, seed=11, use_graph=graph,
+                            fused_loss=fused, env=env)
+        stats = [lr.update(*t) for t in trajs]
+        res.append(([p.detach().clone() for p in pol.parameters()], stats))
+    env.close()
+    (p0, s0) = res[0]
+    for pk, sk in res[1:]:
+        for a, b in zip(p0, pk):              # 18 Adam steps of lr 1e-3: float32-level gradient differences move a weight by << lr
+            assert float((a - b).abs().max()) < 5e-4 and float((a - b).abs().mean()) < 1e-5, float((a - b).abs().max())
+        for a, b in zip(s0, sk):
+            assert a["kl_coeff"] == b["kl_coeff"] and a["sgd_steps"] == b["sgd_steps"]
+            for k in ppo.STAT_KEYS:
+                assert abs(a[k] - b[k]) <= 1e-3 * max(1.0, abs(a[k])), (k, a[k], b[k])

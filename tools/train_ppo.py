@@ -28,6 +28,7 @@ ap.add_argument("--seed", type=int, default=0)
 ap.add_argument("--out", default="")
 ap.add_argument("--no-graph", action="store_true")
 ap.add_argument("--fused-policy", action="store_true", help="sample with the fused MFMA forward kernel (bf16 hidden layer)")
+ap.add_argument("--fused-loss", action="store_true", help="PPO loss + gradient from the q1env_ppo_loss_grad kernel")
 ap.add_argument("--save", default="", help="write the final policy weights (npz, RLlib fcnet naming) here")
 args = ap.parse_args()
 
@@ -44,7 +45,7 @@ pol = P.Q1Policy().cuda()
 fused = P.FusedPolicyForward(pol, env) if args.fused_policy else None
 smp = GpuSampler(env, fused if fused is not None else pol, horizon=args.horizon, use_graph=not args.no_graph)
 lrn = ppo.PPOLearner(pol, float(cfg.action_range), lr=args.lr, num_sgd_iter=args.epochs, minibatch_size=args.minibatch,
-                     entropy_coeff=args.entropy, kl_target=args.kl_target, seed=args.seed + rank, use_graph=not args.no_graph)
+                     entropy_coeff=args.entropy, kl_target=args.kl_target, seed=args.seed + rank, use_graph=not args.no_graph, fused_loss=args.fused_loss, env=env)
 log = []
 t0 = time.time()
 prev = smp.stats
