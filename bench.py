@@ -77,7 +77,8 @@ def cpu_baseline(n, action_range, budget_s=10.0, gpu_check=None):
         if ticks <= EPISODE_TICKS - 1:                 # stop integrating before the episode-ending tick
             dist += env.cfg.time_delta * env.st["vel"][:, :2].astype(np.float64)
         if ticks == EPISODE_TICKS - 1:
-            snap = {"dist": dist.copy(), "z": env.st["z_pos"].copy(), "vel": env.st["vel"].copy(), "yaw": env.yaw.copy()}
+            snap = {"dist": dist.copy(), "z": env.st["z_pos"].copy(), "vel": env.st["vel"].copy(), "yaw": env.yaw.copy(),
+                    "on_ground": env.st["on_ground"].copy(), "t_rem": env.t_rem.copy()}
     dt = spent
     out = {"value": n * ticks / dt, "unit": "env-steps/s", "cores": 1, "kind": "port",
            "sample": f"{ticks} ticks of {n} envs (ndarray actions, oracle/np_oracle.py, NumPy {np.__version__}) in {dt:.1f} s of oracle time; "
@@ -92,6 +93,8 @@ def cpu_baseline(n, action_range, budget_s=10.0, gpu_check=None):
                                           np.abs(g["vel_z"] - snap["vel"][:, 2]).max())),
             "max_abs_yaw_diff": float(np.abs(g["yaw"] - snap["yaw"]).max()),
             "vel_bit_identical_fraction": float(np.mean(np.stack([g["vel_x"], g["vel_y"], g["vel_z"]], 1).view(np.uint32) == snap["vel"].view(np.uint32))),
+            "on_ground_mismatches": int(np.count_nonzero(((g["flags"] & 1) != 0) != snap["on_ground"])),
+            "max_abs_time_remaining_diff": float(np.abs(g["time_remaining"] - snap["t_rem"]).max()),
             "max_abs_y_travelled": float(np.abs(snap["dist"][:, 1]).max())}
     # the reference's verbatim call pattern: RLlib hands vector_step a list of N tuples (scalars + (1,) arrays), which
     # _fix_actions (env.py:221-223) converts with a Python double loop - 86 % of the reference's wall time at this size
@@ -144,7 +147,14 @@ def size_sweep(dev_index, sizes=(262144, 1048576, 4194304), ticks=72, reps=4):
             go()
         us = dev.timer_stop() * 1e3 / (reps * ticks)
         gbps = B_ALG * n / (us * 1e-6) / 1e9
-        rows.append({"envs": n, "us_per_tick": us, "env_steps_per_s": n / (us * 1e-6), "achieved_GBps": gbps, "frac": gbps / HBM_PEAK_GBPS})
+        # on-box copy ceiling in the kernel's own access pattern: calib_copy_kernel reads and writes the 85-B state
+        dev.calibrate_traffic(4)
+        dev.timer_start()
+        dev.calibrate_traffic(32)
+        copy_us = dev.timer_stop() * 1e3 / 32
+        copy_gbps = 170.0 * n / (copy_us * 1e-6) / 1e9
+        rows.append({"envs": n, "us_per_tick": us, "env_steps_per_s": n / (us * 1e-6), "achieved_GBps": gbps, "frac": gbps / HBM_PEAK_GBPS,
+                     "state_copy_kernel_GBps": copy_gbps, "frac_of_copy_kernel": gbps / copy_gbps})
         dev.close()
         del keys, mouse, obs, rew, done
     return rows
