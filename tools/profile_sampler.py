@@ -9,7 +9,9 @@ from q1physrl_amd.tensor_env import TensorVectorEnv
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 32768
 cfg = Config(**{**Config.get_default().__dict__, "num_envs": n})
 env = TensorVectorEnv(cfg, seed=1)
-s = GpuSampler(env, P.Q1Policy().cuda(), horizon=32, use_graph=False)
+pol = P.Q1Policy().cuda()
+fused = len(sys.argv) > 2 and sys.argv[2] == "fused"      # the two-launch tick: fused MFMA policy+value forward + q1env_sample_step
+s = GpuSampler(env, P.FusedPolicyForward(pol, env) if fused else pol, horizon=32, use_graph=False)
 for _ in range(4):
     s.collect()
 torch.cuda.synchronize()
