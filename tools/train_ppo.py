@@ -7,6 +7,12 @@ reference's headline training metric, zero_start_total_reward_mean (train.py:54-
 """
 import argparse, json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+# The learner's float32 GEMMs are tall-skinny (weight gradients reduce over a 32 768-row minibatch); hipBLASLt's default
+# heuristic picks poor tiles for them.  PyTorch's TunableOp times the candidate rocBLAS / hipBLASLt solutions once per shape
+# (during the learner's warm-up steps) - measured 0.67 -> 0.47 s per iteration.  Q1_TUNABLEOP=0 turns it off.
+if os.environ.get("Q1_TUNABLEOP", "1") != "0":
+    os.environ.setdefault("PYTORCH_TUNABLEOP_ENABLED", "1")
+    os.environ.setdefault("PYTORCH_TUNABLEOP_FILENAME", "/tmp/q1physrl_tunableop_%d.csv")
 import torch
 import torch.distributed as dist
 from q1physrl_amd import policy as P, ppo, sharding
