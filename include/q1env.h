@@ -239,7 +239,9 @@ int q1env_sample_step(q1env_t* env, const float* logits_dev, int row_stride, uin
  * w1 float[256][6], b1 float[256], b2 float[256], b3 float[out_dim] in torch nn.Linear layout.  w23_image: W2 (nn.Linear(256,256)
  * weight, row = output unit) followed by W3 (nn.Linear(256,out_dim) weight in rows 0..out_dim-1 of a 32-row tile) as ONE bf16
  * array of 288 rows x 264 elements: 256 weights + 8 zero pad per row, the columns of every row permuted so that within each
- * group of 16 the four groups of four are stored in the order 0,2,1,3 (q1physrl_amd.policy.FusedPolicyForward builds it).
+ * group of 16 the four groups of four are stored in the order 0,2,1,3, and the W2 rows (not W3) pre-multiplied by 2*log2(e)
+ * before the bf16 rounding - the kernel's tanh takes its exp2 argument straight from the accumulator
+ * (q1physrl_amd.policy.FusedPolicyForward builds the image).
  * All three layers run on the matrix cores with bf16 weights and float32 accumulation; layer 1 takes the observations and its
  * bias split into two bf16 each (hi + lo, 16 mantissa bits), b2 / b3 and tanh are float32, hidden activations are rounded to
  * bf16.  1 <= out_dim <= 10.  Inference only (sampler loop); the learner keeps its float32 torch modules. */

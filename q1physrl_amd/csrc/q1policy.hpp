@@ -16,7 +16,8 @@
 // in the order (0, 2, 1, 3).  Then lane (c, h)'s accumulator registers 8u..8u+7 ARE its B operand of K-step 2t + u.
 // One workgroup per CU keeps W2 / W3 (bf16, rows padded by 16 B so the 16-byte operand reads are bank-conflict free), the
 // layer-1 operand image and b2 in LDS - 157.5 KB of the CU's 160 KB; every wave walks its own 32-env tiles grid-stride, so the
-// weights are fetched once per CU, not once per tile.  tanh = 1 - 2/(2^(2x log2 e) + 1) on v_exp_f32 / v_rcp_f32.
+// weights are fetched once per CU, not once per tile.  tanh = 1 - 2/(2^(2x log2 e) + 1) on v_exp_f32 / v_rcp_f32, the factor
+// 2 log2 e folded into the producing layer's weights.
 // Measured on MI355X (tools/trace_mlp.py, gpurun_scratch micro-benchmarks): under this load the shader
 // clock settles at ~1.6 GHz; a tile costs ~7 600 cycles per SIMD against a VALU floor of ~6 500 (512 tanh per lane: 4 250 cycles
 // of v_exp/v_rcp at 8.3 cycles each, the rest packed float32 and bf16 converts) and an MFMA floor of 4 864 (152 x 32 cycles).
@@ -43,21 +44,20 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 
-__device__ __forceinline__ float fast_tanh(float x) {                // 1 - 2 / (e^{2x} + 1): exact limits at +-inf
-    const float t = __builtin_amdgcn_exp2f(x * 2.8853900817779268f); // e^{2x} = 2^{2x log2 e}
-    return 1.0f - 2.0f * __builtin_amdgcn_rcpf(t + 1.0f);
-}
+// tanh(z) = 1 - 2 / (2^(c z) + 1) with c = 2 log2(e).  The factor c is folded into the weights and biases of the layer that
+// PRODUCES z (W1, b1 here at staging; the W2 block of the host-built image; b2 at staging), so the accumulators already hold c z
+// and an activation is v_exp_f32, +1, v_rcp_f32, 1 - 2r: one packed multiply less per pair of values on the VALU that bounds
+// this kernel.
+constexpr float TANH_PRESCALE = 2.8853900817779268f;                 // 2 log2(e)
 
-// tanh of accumulator registers 8u .. 8u+7 -> the lane's bf16 B operand of K-step 2t + u.  Two values at a time: the
-// multiply, the +1 and the final 1 - 2r are packed float32 instructions (v_pk_mul/add/fma_f32), only v_exp_f32 and
-// v_rcp_f32 are per element; the pair is converted with one v_cvt_pk_bf16_f32 (RNE).
+// tanh of accumulator registers 8u .. 8u+7 (holding c z) -> the lane's bf16 B operand of K-step 2t + u.  Two values at a time:
+// the +1 and the final 1 - 2r are packed float32 instructions (v_pk_add/fma_f32), only v_exp_f32 and v_rcp_f32 are per
+// element; the pair is converted with one v_cvt_pk_bf16_f32 (RNE).
 __device__ __forceinline__ bf16x8 activate(const f32x16& acc, int u) {
     union { bf16x8 v; bf16x2 p[4]; } o;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        f32x2 x = {acc[8 * u + 2 * j], acc[8 * u + 2 * j + 1]};
-        x = x * 2.8853900817779268f;                                  // 2 log2(e)
-        f32x2 t = {__builtin_amdgcn_exp2f(x[0]), __builtin_amdgcn_exp2f(x[1])};
+        f32x2 t = {__builtin_amdgcn_exp2f(acc[8 * u + 2 * j]), __builtin_amdgcn_exp2f(acc[8 * u + 2 * j + 1])};
         t = t + 1.0f;
         const f32x2 r = {__builtin_amdgcn_rcpf(t[0]), __builtin_amdgcn_rcpf(t[1])};
         const f32x2 y = 1.0f - 2.0f * r;
@@ -92,17 +92,18 @@ __device__ __forceinline__ bf16x8 split_inputs(const float (&x)[3], uint32_t hal
     return o.v;
 }
 
-// row k of the layer-1 operand image: 16 bf16 = [half][8 K slots] (32 B), built from float w1[k][0..5], b1[k]
+// row k of the layer-1 operand image: 16 bf16 = [half][8 K slots] (32 B), built from float w1[k][0..5], b1[k], pre-scaled by c
 __device__ __forceinline__ void stage_w1_row(unsigned char* l_w1, uint32_t k, const float* __restrict__ w1, const float* __restrict__ b1) {
     union { uint4 q[2]; uint16_t u[16]; } r;
-    const uint16_t bhi = bf16_bits(b1[k]);
-    const uint16_t blo = bf16_bits(b1[k] - bf16_value(bhi));
+    const float bs = TANH_PRESCALE * b1[k];
+    const uint16_t bhi = bf16_bits(bs);
+    const uint16_t blo = bf16_bits(bs - bf16_value(bhi));
 #pragma unroll
     for (int h = 0; h < 2; ++h)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int i = 2 * j + h;                                  // input index of slot j in half h
-            const uint16_t w = i < OBS ? bf16_bits(w1[k * OBS + i]) : (i == 6 ? bhi : blo);
+            const uint16_t w = i < OBS ? bf16_bits(TANH_PRESCALE * w1[k * OBS + i]) : (i == 6 ? bhi : blo);
             r.u[8 * h + j] = w;
             r.u[8 * h + 4 + j] = i < OBS ? w : (uint16_t)0;           // lo parts of the inputs meet the same weight; lo(1) = 0
         }
@@ -110,7 +111,7 @@ __device__ __forceinline__ void stage_w1_row(unsigned char* l_w1, uint32_t k, co
     dst[0] = r.q[0]; dst[1] = r.q[1];
 }
 
-// The host hands W2 and W3 over as ONE bf16 image that is already in LDS layout: (256 + 32) rows of 264 elements (528 B:
+// The host hands W2 (times 2 log2 e, see TANH_PRESCALE) and W3 over as ONE bf16 image that is already in LDS layout: (256 + 32) rows of 264 elements (528 B:
 // 256 weights + 8 pad), columns of every row permuted (groups of four within each 16: 0,2,1,3).  Staging is then a straight
 // 16-byte-per-lane copy of 152 064 bytes with all of a thread's loads in flight at once.
 constexpr uint32_t IMG_VEC16 = (uint32_t)((LDS_W2 + LDS_W3) / 16);   // 9504 uint4
@@ -166,7 +167,7 @@ mlp_forward_kernel(int n, const float* __restrict__ obs, Net net_a, Net net_b, i
     const uint32_t tid = threadIdx.x;
     stage_image<THREADS>(lds, w23, tid);                             // W2 rows then W3 rows, contiguous in LDS
     if (tid < (uint32_t)HID) {
-        l_b2[tid] = b2[tid];
+        l_b2[tid] = TANH_PRESCALE * b2[tid];
         stage_w1_row(l_w1, tid, w1, b1);
     }
     const uint32_t lane = tid & 63u, wave = tid >> 6;

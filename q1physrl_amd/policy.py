@@ -16,6 +16,7 @@ import torch
 from torch import nn
 
 SMALL_NUMBER = 1e-6
+TANH_PRESCALE = 2.8853900817779268        # 2 log2(e): folded into the W2 block of the fused kernel's weight image (q1policy.hpp)
 MIN_LOG_NN_OUTPUT = -20.0
 MAX_LOG_NN_OUTPUT = 2.0
 _HALF_LOG_2PI = 0.5 * math.log(2.0 * math.pi)
@@ -188,7 +189,8 @@ class FusedPolicyForward:
     def refresh(self):
         """Copy the master weights into the kernel's persistent device buffers IN PLACE: a captured hipGraph of the
         sampler holds these addresses, so they must never be re-allocated.  W2 / W3 go into the bf16 LDS image the kernel
-        copies verbatim: 288 rows x 264 (256 weights + 8 pad), columns permuted (0,2,1,3 groups of four within each 16)."""
+        copies verbatim: 288 rows x 264 (256 weights + 8 pad), columns permuted (0,2,1,3 groups of four within each 16), the
+        W2 rows multiplied by 2 log2(e) before the bf16 rounding (tanh's exp2 argument is then the accumulator itself)."""
         for name, net in (("pi", self.policy.pi), ("vf", self.policy.vf)):
             l1, l2, l3 = net[0], net[2], net[4]
             dev = l1.weight.device
@@ -201,7 +203,7 @@ class FusedPolicyForward:
                 self._perm = (g & ~0xC) | ((((grp & 1) << 1) | (grp >> 1)) << 2)      # dest column -> source column
             w1, b1, img, b2, b3 = self._w[name]
             w1.copy_(l1.weight); b1.copy_(l1.bias); b2.copy_(l2.bias); b3.copy_(l3.bias)
-            img[:256, :256].copy_(l2.weight[:, self._perm])
+            img[:256, :256].copy_(l2.weight[:, self._perm] * TANH_PRESCALE)     # the kernel's exp2 argument is the accumulator itself
             img[256:256 + l3.out_features, :256].copy_(l3.weight[:, self._perm])
 
     def _mlp(self, name, out):

@@ -218,17 +218,23 @@ def test_eval_sim_with_wr_policy_through_the_compat_api():
 
 
 def _emulate_fused_forward(net, obs):
-    """torch restatement of q1env_policy_forward's arithmetic: layer 1 with bf16 W1 and the inputs / bias split into two bf16
-    (hi + lo); tanh -> bf16; bf16 W2 / W3; float32 accumulation everywhere."""
+    """torch restatement of q1env_policy_forward's arithmetic: bf16 weights with float32 accumulation; layer 1 takes the inputs
+    and its bias split into two bf16 (hi + lo); tanh(z) = 1 - 2 / (2^(c z) + 1) with c = 2 log2(e) folded into W1, b1, W2, b2
+    BEFORE their bf16 rounding; hidden activations rounded to bf16."""
     import torch
+    from q1physrl_amd.policy import TANH_PRESCALE as C
     l1, l2, l3 = net[0], net[2], net[4]
+    bf = lambda w: w.to(torch.bfloat16).float()
 
     def split(x):
-        hi = x.to(torch.bfloat16).float()
-        return hi + (x - hi).to(torch.bfloat16).float()
-    h1 = torch.tanh(split(obs) @ l1.weight.to(torch.bfloat16).float().T + split(l1.bias)).to(torch.bfloat16).float()
-    h2 = torch.tanh(h1 @ l2.weight.to(torch.bfloat16).float().T + l2.bias).to(torch.bfloat16).float()
-    return h2 @ l3.weight.to(torch.bfloat16).float().T + l3.bias
+        hi = bf(x)
+        return hi + bf(x - hi)
+
+    def act(a):                                            # a = c z
+        return bf(1.0 - 2.0 / (torch.exp2(a) + 1.0))
+    h1 = act(split(obs) @ bf(C * l1.weight).T + split(C * l1.bias))
+    h2 = act(h1 @ bf(C * l2.weight).T + C * l2.bias)
+    return h2 @ bf(l3.weight).T + l3.bias
 
 
 @pytest.mark.parametrize("n", [32768, 1000, 37, 70001])
