@@ -101,3 +101,12 @@ def test_two_rank_gradient_allreduce_equals_single_process(tmp_path):
     mp.spawn(_worker, args=(2, _free_port(), out), nprocs=2, join=True)
     same, err, world = np.load(out)
     assert same == 1.0 and world == 2 and err < 1e-10
+
+
+def test_fused_loss_needs_an_env_handle():
+    """fused_loss=True runs q1env_ppo_loss_grad on an env handle's stream: constructing the learner without one fails loudly."""
+    import pytest
+    import torch
+    from q1physrl_amd import policy as P, ppo
+    with pytest.raises(ValueError, match="fused_loss=True needs env"):
+        ppo.PPOLearner(P.Q1Policy(), 10.0, fused_loss=True)
