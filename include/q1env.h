@@ -237,14 +237,14 @@ int q1env_sample_step(q1env_t* env, const float* logits_dev, int row_stride, uin
 /* Fused forward pass of one network of the reference policy's shape (RLlib fcnet of data/checkpoints/wr: 6 -> 256 tanh ->
  * 256 tanh -> out_dim, out_dim = 10 policy logits or 1 value) for this handle's N envs: obs float[N][6] -> out float[N][out_dim].
  * w1 float[256][6], b1 float[256], b2 float[256], b3 float[out_dim] in torch nn.Linear layout.  w23_image: W2 (nn.Linear(256,256)
- * weight, row = output unit) followed by W3 (nn.Linear(256,out_dim) weight in rows 0..out_dim-1 of a 32-row tile) as ONE bf16
+ * weight, row = output unit) followed by W3 (nn.Linear(256,out_dim) weight in rows 0..out_dim-1 of a 32-row tile) as ONE float16 (IEEE binary16)
  * array of 288 rows x 264 elements: 256 weights + 8 zero pad per row, the columns of every row permuted so that within each
  * group of 16 the four groups of four are stored in the order 0,2,1,3, and the W2 rows (not W3) pre-multiplied by 2*log2(e)
- * before the bf16 rounding - the kernel's tanh takes its exp2 argument straight from the accumulator
+ * before the float16 rounding - the kernel's tanh takes its exp2 argument straight from the accumulator
  * (q1physrl_amd.policy.FusedPolicyForward builds the image).
- * All three layers run on the matrix cores with bf16 weights and float32 accumulation; layer 1 takes the observations and its
- * bias split into two bf16 each (hi + lo, 16 mantissa bits), b2 / b3 and tanh are float32, hidden activations are rounded to
- * bf16.  1 <= out_dim <= 10.  Inference only (sampler loop); the learner keeps its float32 torch modules. */
+ * All three layers run on the matrix cores with float16 weights and float32 accumulation; layer 1 takes the observations and its
+ * bias split into two float16 each (hi + lo, 22 mantissa bits), b2 / b3 and tanh are float32, hidden activations are rounded to
+ * float16.  1 <= out_dim <= 10.  Inference only (sampler loop); the learner keeps its float32 torch modules. */
 int q1env_policy_forward(q1env_t* env, const float* obs_dev, const float* w1_dev, const float* b1_dev, const uint16_t* w23_image_dev,
                          const float* b2_dev, const float* b3_dev, int out_dim, float* out_dev);
 
@@ -254,7 +254,7 @@ int q1env_policy_forward(q1env_t* env, const float* obs_dev, const float* w1_dev
 typedef struct q1env_mlp {
     const float* w1;              /* float[256][6]   device */
     const float* b1;              /* float[256]      device */
-    const uint16_t* w23_image;    /* bf16[288][264]  device, layout as above */
+    const uint16_t* w23_image;    /* float16[288][264] bits, device, layout as above */
     const float* b2;              /* float[256]      device */
     const float* b3;              /* float[out_dim]  device */
     float* out;                   /* float[N][out_dim] device */

@@ -2,27 +2,31 @@
 // checkpoint, SURVEY.md section 2: obs 6 -> 256 tanh -> 256 tanh -> OUT, OUT = 10 logits or 1 value) for gfx950; one launch
 // evaluates one network or the policy AND the value network (half of the CUs each).
 //
+// Operand precision: float16, not bfloat16 - activations live in [-1, 1] and the weights of such a policy are O(1), so f16's
+// 11-bit significand costs nothing in range, runs at the same MFMA rate and packs with the same single convert instruction,
+// and it makes the behaviour policy 8x closer to the float32 learner policy (matters for PPO: DESIGN.md section 8).
+//
 // This is the GEMM-shaped neighbour of the env hot path (the sampler tick is: this, then q1env_sample_step), so it is the
 // one place matrix cores are used - for all three layers, computed TRANSPOSED
 // (hidden units are MFMA rows, envs are MFMA columns), so that the output of one layer is already distributed the way the
 // next layer's B operand needs it and activations never leave registers:
-//   layer 1  H1^T = W1b . (Xhi + Xlo)^T  ONE v_mfma_f32_32x32x16_bf16 per 32-row tile: bf16 weights, inputs and bias split into
-//                                       two bf16 each (hi + lo = 16 mantissa bits), K = 16 = 2 x (6 inputs + bias hi/lo)
-//   layer 2  H2^T = W2 . tanh(H1)^T     v_mfma_f32_32x32x16_bf16, float32 accumulate, accumulators start at the bias b2
-//   layer 3  Y^T  = W3 . tanh(H2)^T     v_mfma_f32_32x32x16_bf16 (rows = outputs, padded to 32), + b3 in float32
+//   layer 1  H1^T = W1b . (Xhi + Xlo)^T  ONE v_mfma_f32_32x32x16_f16 per 32-row tile: f16 weights, inputs and bias split into
+//                                       two f16 each (hi + lo = 22 mantissa bits), K = 16 = 2 x (6 inputs + bias hi/lo)
+//   layer 2  H2^T = W2 . tanh(H1)^T     v_mfma_f32_32x32x16_f16, float32 accumulate, accumulators start at the bias b2
+//   layer 3  Y^T  = W3 . tanh(H2)^T     v_mfma_f32_32x32x16_f16 (rows = outputs, padded to 32), + b3 in float32
 // The C/D register layout of a 32x32 tile gives lane (c, h) the rows (r&3) + 8(r>>2) + 4h, r = 0..15, of column c, while a
 // B operand wants 8 consecutive K indices per lane.  Instead of shuffling activations, the K index of the NEXT layer's
 // weights is permuted once, when they are staged into LDS: within every 16 hidden units the four groups of four are stored
 // in the order (0, 2, 1, 3).  Then lane (c, h)'s accumulator registers 8u..8u+7 ARE its B operand of K-step 2t + u.
-// One workgroup per CU keeps W2 / W3 (bf16, rows padded by 16 B so the 16-byte operand reads are bank-conflict free), the
+// One workgroup per CU keeps W2 / W3 (f16, rows padded by 16 B so the 16-byte operand reads are bank-conflict free), the
 // layer-1 operand image and b2 in LDS - 157.5 KB of the CU's 160 KB; every wave walks its own 32-env tiles grid-stride, so the
 // weights are fetched once per CU, not once per tile.  tanh = 1 - 2/(2^(2x log2 e) + 1) on v_exp_f32 / v_rcp_f32, the factor
 // 2 log2 e folded into the producing layer's weights.
 // Measured on MI355X (tools/trace_mlp.py, gpurun_scratch micro-benchmarks): under this load the shader
 // clock settles at ~1.6 GHz; a tile costs ~7 600 cycles per SIMD against a VALU floor of ~6 500 (512 tanh per lane: 4 250 cycles
-// of v_exp/v_rcp at 8.3 cycles each, the rest packed float32 and bf16 converts) and an MFMA floor of 4 864 (152 x 32 cycles).
+// of v_exp/v_rcp at 8.3 cycles each, the rest packed float32 and f16 converts) and an MFMA floor of 4 864 (152 x 32 cycles).
 // What mattered, in order: accumulators in VGPRs (a 256-register budget; with 512 the compiler parks them in AGPRs and pays a
-// v_accvgpr_read per tanh input), layer 1 as one bf16 MFMA instead of four dependent float32 ones, MFMA / VALU alternation in the
+// v_accvgpr_read per tanh input), layer 1 as one f16 MFMA instead of four dependent float32 ones, MFMA / VALU alternation in the
 // instruction stream (one wave issues in order), both networks in one launch (weight staging overlaps).
 #pragma once
 #include <hip/hip_runtime.h>
@@ -32,17 +36,17 @@ namespace q1pol {
 
 constexpr int HID = 256;
 constexpr int OBS = 6;
-constexpr int ROW_BYTES = HID * 2 + 16;               // 528: padded row stride of the bf16 weight rows in LDS
+constexpr int ROW_BYTES = HID * 2 + 16;               // 528: padded row stride of the f16 weight rows in LDS
 constexpr size_t LDS_W2 = (size_t)HID * ROW_BYTES;    // 135168
 constexpr size_t LDS_W3 = (size_t)32 * ROW_BYTES;     // 16896 (output rows padded to one 32-row tile)
 constexpr size_t LDS_B2 = (size_t)HID * 4;            // 1024
-constexpr size_t LDS_W1 = (size_t)HID * 32;           // 8192: layer-1 operand image, [k][half][8 K slots] bf16
+constexpr size_t LDS_W1 = (size_t)HID * 32;           // 8192: layer-1 operand image, [k][half][8 K slots] f16
 constexpr size_t LDS_TOTAL = LDS_W2 + LDS_W3 + LDS_B2 + LDS_W1;    // 161280 B <= 163840
 
-typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 
 // tanh(z) = 1 - 2 / (2^(c z) + 1) with c = 2 log2(e).  The factor c is folded into the weights and biases of the layer that
 // PRODUCES z (W1, b1 here at staging; the W2 block of the host-built image; b2 at staging), so the accumulators already hold c z
@@ -50,60 +54,63 @@ typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 // this kernel.
 constexpr float TANH_PRESCALE = 2.8853900817779268f;                 // 2 log2(e)
 
-// tanh of accumulator registers 8u .. 8u+7 (holding c z) -> the lane's bf16 B operand of K-step 2t + u.  Two values at a time:
+// tanh of accumulator registers 8u .. 8u+7 (holding c z) -> the lane's f16 B operand of K-step 2t + u.  Two values at a time:
 // the +1 and the final 1 - 2r are packed float32 instructions (v_pk_add/fma_f32), only v_exp_f32 and v_rcp_f32 are per
-// element; the pair is converted with one v_cvt_pk_bf16_f32 (RNE).
-__device__ __forceinline__ bf16x8 activate(const f32x16& acc, int u) {
-    union { bf16x8 v; bf16x2 p[4]; } o;
+// element; the pair is converted with one v_cvt_pk_f16_f32 (RNE).
+__device__ __forceinline__ f16x8 activate(const f32x16& acc, int u) {
+    union { f16x8 v; f16x2 p[4]; } o;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         f32x2 t = {__builtin_amdgcn_exp2f(acc[8 * u + 2 * j]), __builtin_amdgcn_exp2f(acc[8 * u + 2 * j + 1])};
         t = t + 1.0f;
         const f32x2 r = {__builtin_amdgcn_rcpf(t[0]), __builtin_amdgcn_rcpf(t[1])};
         const f32x2 y = 1.0f - 2.0f * r;
-        o.p[j] = __builtin_convertvector(y, bf16x2);
+        o.p[j] = __builtin_convertvector(y, f16x2);
     }
     return o.v;
 }
 
-// Layer 1 on the bf16 matrix path with SPLIT inputs: x = hi + lo (two bf16, 16 mantissa bits together), so ONE
-// v_mfma_f32_32x32x16_bf16 computes W1b . (x_hi + x_lo) + (b1_hi + b1_lo) for a 32-row tile (the float32 32x32x2 path it replaces
+// Layer 1 on the f16 matrix path with SPLIT inputs: x = hi + lo (two f16, 22 mantissa bits together), so ONE
+// v_mfma_f32_32x32x16_f16 computes W1b . (x_hi + x_lo) + (b1_hi + b1_lo) for a 32-row tile (the float32 32x32x2 path it replaces
 // needed four dependent 16-pass MFMAs per tile).  K layout of half h: slots 0..3 = hi of inputs h, 2+h, 4+h, 6+h, slots 4..7 = lo
-// of the same inputs; inputs 6 and 7 are the constant 1 carrying bf16(b1) and bf16(b1 - bf16(b1)).
-__device__ __forceinline__ uint16_t bf16_bits(float x) {              // RNE, like v_cvt_pk_bf16_f32
-    const f32x2 v = {x, 0.0f};
-    union { bf16x2 b; uint16_t u[2]; } o;
-    o.b = __builtin_convertvector(v, bf16x2);
-    return o.u[0];
+// of the same inputs; inputs 6 and 7 are the constant 1 carrying f16(b1) and f16(b1 - f16(b1)).
+__device__ __forceinline__ uint16_t f16_bits(float x) {               // RNE, like v_cvt_pk_f16_f32
+    union { _Float16 h; uint16_t u; } o;
+    o.h = (_Float16)x;
+    return o.u;
 }
-__device__ __forceinline__ float bf16_value(uint16_t b) { return __uint_as_float((uint32_t)b << 16); }
+__device__ __forceinline__ float f16_value(uint16_t b) {
+    union { _Float16 h; uint16_t u; } o;
+    o.u = b;
+    return (float)o.h;
+}
 
-__device__ __forceinline__ bf16x8 split_inputs(const float (&x)[3], uint32_t half) {
+__device__ __forceinline__ f16x8 split_inputs(const float (&x)[3], uint32_t half) {
     (void)half;
-    union { bf16x8 v; uint16_t u[8]; } o;
+    union { f16x8 v; uint16_t u[8]; } o;
 #pragma unroll
     for (int s = 0; s < 3; ++s) {
-        const uint16_t hi = bf16_bits(x[s]);
+        const uint16_t hi = f16_bits(x[s]);
         o.u[s] = hi;
-        o.u[4 + s] = bf16_bits(x[s] - bf16_value(hi));
+        o.u[4 + s] = f16_bits(x[s] - f16_value(hi));
     }
-    o.u[3] = 0x3F80;                                                  // 1.0: bias slot (hi part for half 0, lo part for half 1)
+    o.u[3] = 0x3C00;                                                  // 1.0: bias slot (hi part for half 0, lo part for half 1)
     o.u[7] = 0;
     return o.v;
 }
 
-// row k of the layer-1 operand image: 16 bf16 = [half][8 K slots] (32 B), built from float w1[k][0..5], b1[k], pre-scaled by c
+// row k of the layer-1 operand image: 16 f16 = [half][8 K slots] (32 B), built from float w1[k][0..5], b1[k], pre-scaled by c
 __device__ __forceinline__ void stage_w1_row(unsigned char* l_w1, uint32_t k, const float* __restrict__ w1, const float* __restrict__ b1) {
     union { uint4 q[2]; uint16_t u[16]; } r;
     const float bs = TANH_PRESCALE * b1[k];
-    const uint16_t bhi = bf16_bits(bs);
-    const uint16_t blo = bf16_bits(bs - bf16_value(bhi));
+    const uint16_t bhi = f16_bits(bs);
+    const uint16_t blo = f16_bits(bs - f16_value(bhi));
 #pragma unroll
     for (int h = 0; h < 2; ++h)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int i = 2 * j + h;                                  // input index of slot j in half h
-            const uint16_t w = i < OBS ? bf16_bits(TANH_PRESCALE * w1[k * OBS + i]) : (i == 6 ? bhi : blo);
+            const uint16_t w = i < OBS ? f16_bits(TANH_PRESCALE * w1[k * OBS + i]) : (i == 6 ? bhi : blo);
             r.u[8 * h + j] = w;
             r.u[8 * h + 4 + j] = i < OBS ? w : (uint16_t)0;           // lo parts of the inputs meet the same weight; lo(1) = 0
         }
@@ -111,7 +118,7 @@ __device__ __forceinline__ void stage_w1_row(unsigned char* l_w1, uint32_t k, co
     dst[0] = r.q[0]; dst[1] = r.q[1];
 }
 
-// The host hands W2 (times 2 log2 e, see TANH_PRESCALE) and W3 over as ONE bf16 image that is already in LDS layout: (256 + 32) rows of 264 elements (528 B:
+// The host hands W2 (times 2 log2 e, see TANH_PRESCALE) and W3 over as ONE f16 image that is already in LDS layout: (256 + 32) rows of 264 elements (528 B:
 // 256 weights + 8 pad), columns of every row permuted (groups of four within each 16: 0,2,1,3).  Staging is then a straight
 // 16-byte-per-lane copy of 152 064 bytes with all of a thread's loads in flight at once.
 constexpr uint32_t IMG_VEC16 = (uint32_t)((LDS_W2 + LDS_W3) / 16);   // 9504 uint4
@@ -134,7 +141,7 @@ __device__ __forceinline__ void stage_image(unsigned char* dst, const uint16_t* 
     }
 }
 
-// w1: float[HID][OBS] (torch Linear(6,256).weight), b1: float[HID], w23: the bf16 LDS image of W2 (Linear(256,256).weight) and W3
+// w1: float[HID][OBS] (torch Linear(6,256).weight), b1: float[HID], w23: the f16 LDS image of W2 (Linear(256,256).weight) and W3
 // (Linear(256,out).weight in rows 0..out-1 of a 32-row tile) described above, b2: float[HID], b3: float[out_dim];
 // obs float[n][6]; out float[n][out_dim].
 // THREADS = 512: 8 waves, TWO per SIMD, each walking its own 32-env tiles (large batches); THREADS = 256: one wave per SIMD
@@ -162,7 +169,7 @@ mlp_forward_kernel(int n, const float* __restrict__ obs, Net net_a, Net net_b, i
     unsigned char* l_w2 = lds;
     unsigned char* l_w3 = lds + LDS_W2;
     float* l_b2 = reinterpret_cast<float*>(lds + LDS_W2 + LDS_W3);
-    unsigned char* l_w1 = lds + LDS_W2 + LDS_W3 + LDS_B2;           // layer-1 operand image: [k][half][8] bf16
+    unsigned char* l_w1 = lds + LDS_W2 + LDS_W3 + LDS_B2;           // layer-1 operand image: [k][half][8] f16
 
     const uint32_t tid = threadIdx.x;
     stage_image<THREADS>(lds, w23, tid);                             // W2 rows then W3 rows, contiguous in LDS
@@ -202,7 +209,7 @@ mlp_forward_kernel(int n, const float* __restrict__ obs, Net net_a, Net net_b, i
         const uint32_t env = tile * 32u + col;
         const bool live = env < (uint32_t)n;
         Q1POL_STAMP(ts0);
-        const bf16x8 xb = split_inputs(xn, half);                    // B operand of layer 1
+        const f16x8 xb = split_inputs(xn, half);                    // B operand of layer 1
         {
             const uint32_t en = env + tstride * 32u;
             const bool more = tile + tstride < ntiles && en < (uint32_t)n;
@@ -222,16 +229,16 @@ mlp_forward_kernel(int n, const float* __restrict__ obs, Net net_a, Net net_b, i
         // Software pipeline over the eight 32-row tiles of H1: tanh of tile t1+1 is interleaved (sched_group_barrier) with the
         // sixteen MFMAs of tile t1; every W2 operand register is re-requested from LDS for the next K-step right after the
         // MFMA that consumed it has been issued (operands are read at issue), i.e. eight MFMAs ahead of its next use.
-        bf16x8 cur0, cur1, a_l1, a[8];
+        f16x8 cur0, cur1, a_l1, a[8];
         f32x16 dn;
         {
-            const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(w1row);
-            const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(w1row + 1024u);
-            a_l1 = *reinterpret_cast<const bf16x8*>(w1row + 2048u);
-            const f32x16 d0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, xb, zero16, 0, 0, 0);
-            dn = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, xb, zero16, 0, 0, 0);
+            const f16x8 a0 = *reinterpret_cast<const f16x8*>(w1row);
+            const f16x8 a1 = *reinterpret_cast<const f16x8*>(w1row + 1024u);
+            a_l1 = *reinterpret_cast<const f16x8*>(w1row + 2048u);
+            const f32x16 d0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, xb, zero16, 0, 0, 0);
+            dn = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, xb, zero16, 0, 0, 0);
 #pragma unroll
-            for (int t2 = 0; t2 < 8; ++t2) a[t2] = *reinterpret_cast<const bf16x8*>(wrow + (size_t)t2 * 32u * ROW_BYTES);
+            for (int t2 = 0; t2 < 8; ++t2) a[t2] = *reinterpret_cast<const f16x8*>(wrow + (size_t)t2 * 32u * ROW_BYTES);
             cur0 = activate(d0, 0); cur1 = activate(d0, 1);
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -242,10 +249,10 @@ mlp_forward_kernel(int n, const float* __restrict__ obs, Net net_a, Net net_b, i
             // phase 1: even K-step, first half of tanh(tile t1+1)
 #pragma unroll
             for (int t2 = 0; t2 < 8; ++t2) {
-                acc[t2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[t2], cur0, acc[t2], 0, 0, 0);
-                a[t2] = *reinterpret_cast<const bf16x8*>(wrow + (size_t)t2 * 32u * ROW_BYTES + (q0 + 1u) * 32u);
+                acc[t2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[t2], cur0, acc[t2], 0, 0, 0);
+                a[t2] = *reinterpret_cast<const f16x8*>(wrow + (size_t)t2 * 32u * ROW_BYTES + (q0 + 1u) * 32u);
             }
-            const bf16x8 nxt0 = activate(dn, 0);
+            const f16x8 nxt0 = activate(dn, 0);
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
@@ -254,14 +261,14 @@ mlp_forward_kernel(int n, const float* __restrict__ obs, Net net_a, Net net_b, i
             }
             __builtin_amdgcn_sched_barrier(0);
             // phase 2: odd K-step, second half of the tanh, then layer 1 of tile t1+2 (one MFMA)
-            const bf16x8 a_l1n = *reinterpret_cast<const bf16x8*>(w1row + (((uint32_t)t1 + 3u) & 7u) * 1024u);
+            const f16x8 a_l1n = *reinterpret_cast<const f16x8*>(w1row + (((uint32_t)t1 + 3u) & 7u) * 1024u);
 #pragma unroll
             for (int t2 = 0; t2 < 8; ++t2) {
-                acc[t2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[t2], cur1, acc[t2], 0, 0, 0);
-                a[t2] = *reinterpret_cast<const bf16x8*>(wrow + (size_t)t2 * 32u * ROW_BYTES + ((q0 + 2u) & 15u) * 32u);
+                acc[t2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[t2], cur1, acc[t2], 0, 0, 0);
+                a[t2] = *reinterpret_cast<const f16x8*>(wrow + (size_t)t2 * 32u * ROW_BYTES + ((q0 + 2u) & 15u) * 32u);
             }
-            const bf16x8 nxt1 = activate(dn, 1);
-            dn = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_l1, xb, zero16, 0, 0, 0);   // tile t1 + 2 (the last two passes wrap around, unused)
+            const f16x8 nxt1 = activate(dn, 1);
+            dn = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_l1, xb, zero16, 0, 0, 0);   // tile t1 + 2 (the last two passes wrap around, unused)
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
@@ -275,15 +282,15 @@ mlp_forward_kernel(int n, const float* __restrict__ obs, Net net_a, Net net_b, i
 
         // layer 3: tanh(H2 tile) and its two K-steps, W3 operands requested two tiles ahead
         f32x16 y = zero16;
-        bf16x8 w3a = *reinterpret_cast<const bf16x8*>(w3row), w3b = *reinterpret_cast<const bf16x8*>(w3row + 32u);
+        f16x8 w3a = *reinterpret_cast<const f16x8*>(w3row), w3b = *reinterpret_cast<const f16x8*>(w3row + 32u);
 #pragma unroll
         for (int t2 = 0; t2 < 8; ++t2) {
-            const bf16x8 f0 = activate(acc[t2], 0), f1 = activate(acc[t2], 1);
-            y = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w3a, f0, y, 0, 0, 0);
-            y = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w3b, f1, y, 0, 0, 0);
+            const f16x8 f0 = activate(acc[t2], 0), f1 = activate(acc[t2], 1);
+            y = __builtin_amdgcn_mfma_f32_32x32x16_f16(w3a, f0, y, 0, 0, 0);
+            y = __builtin_amdgcn_mfma_f32_32x32x16_f16(w3b, f1, y, 0, 0, 0);
             if (t2 < 7) {
-                w3a = *reinterpret_cast<const bf16x8*>(w3row + (uint32_t)(2 * t2 + 2) * 32u);
-                w3b = *reinterpret_cast<const bf16x8*>(w3row + (uint32_t)(2 * t2 + 3) * 32u);
+                w3a = *reinterpret_cast<const f16x8*>(w3row + (uint32_t)(2 * t2 + 2) * 32u);
+                w3b = *reinterpret_cast<const f16x8*>(w3row + (uint32_t)(2 * t2 + 3) * 32u);
             }
         }
         // y[r] = output row (r&3) + 8(r>>2) + 4*half of env `col`: rows 0..7 come from registers 0..3 of the two halves,

@@ -172,7 +172,7 @@ def load_rllib_fcnet_weights(policy: Q1Policy, weights) -> Q1Policy:
 
 class FusedPolicyForward:
     """Inference-side twin of a Q1Policy for the sampler loop: both networks evaluated by the fused gfx950 kernel
-    (q1env_policy_forward: all three layers on the matrix cores - layer 1 exact float32, layers 2 and 3 with bf16 inputs and
+    (q1env_policy_forward: all three layers on the matrix cores with float16 operands and
     float32 accumulation; biases and tanh float32).  The float32 torch modules stay the learner's master copy; call refresh() after an optimiser step.
     Callable like the module: fused(obs) -> (logits (N,10) float32, value (N,) float32)."""
 
@@ -188,15 +188,15 @@ class FusedPolicyForward:
     @torch.no_grad()
     def refresh(self):
         """Copy the master weights into the kernel's persistent device buffers IN PLACE: a captured hipGraph of the
-        sampler holds these addresses, so they must never be re-allocated.  W2 / W3 go into the bf16 LDS image the kernel
+        sampler holds these addresses, so they must never be re-allocated.  W2 / W3 go into the float16 LDS image the kernel
         copies verbatim: 288 rows x 264 (256 weights + 8 pad), columns permuted (0,2,1,3 groups of four within each 16), the
-        W2 rows multiplied by 2 log2(e) before the bf16 rounding (tanh's exp2 argument is then the accumulator itself)."""
+        W2 rows multiplied by 2 log2(e) before the float16 rounding (tanh's exp2 argument is then the accumulator itself)."""
         for name, net in (("pi", self.policy.pi), ("vf", self.policy.vf)):
             l1, l2, l3 = net[0], net[2], net[4]
             dev = l1.weight.device
             if name not in self._w:
                 self._w[name] = (torch.empty_like(l1.weight, dtype=torch.float32), torch.empty_like(l1.bias, dtype=torch.float32),
-                                 torch.zeros((288, 264), dtype=torch.bfloat16, device=dev),
+                                 torch.zeros((288, 264), dtype=torch.float16, device=dev),
                                  torch.empty_like(l2.bias, dtype=torch.float32), torch.empty_like(l3.bias, dtype=torch.float32))
                 g = torch.arange(256, device=dev)
                 grp = (g >> 2) & 3

@@ -218,13 +218,13 @@ def test_eval_sim_with_wr_policy_through_the_compat_api():
 
 
 def _emulate_fused_forward(net, obs):
-    """torch restatement of q1env_policy_forward's arithmetic: bf16 weights with float32 accumulation; layer 1 takes the inputs
-    and its bias split into two bf16 (hi + lo); tanh(z) = 1 - 2 / (2^(c z) + 1) with c = 2 log2(e) folded into W1, b1, W2, b2
-    BEFORE their bf16 rounding; hidden activations rounded to bf16."""
+    """torch restatement of q1env_policy_forward's arithmetic: float16 weights with float32 accumulation; layer 1 takes the inputs
+    and its bias split into two float16 (hi + lo); tanh(z) = 1 - 2 / (2^(c z) + 1) with c = 2 log2(e) folded into W1, b1, W2, b2
+    BEFORE their float16 rounding; hidden activations rounded to float16."""
     import torch
     from q1physrl_amd.policy import TANH_PRESCALE as C
     l1, l2, l3 = net[0], net[2], net[4]
-    bf = lambda w: w.to(torch.bfloat16).float()
+    bf = lambda w: w.to(torch.float16).float()
 
     def split(x):
         hi = bf(x)
@@ -263,10 +263,11 @@ def test_fused_mfma_policy_forward(n):
         emu_l, emu_v = _emulate_fused_forward(pol.pi, obs), _emulate_fused_forward(pol.vf, obs)[:, 0]
         ref_l, ref_v = pol(obs)
     assert torch.isfinite(logits).all() and logits.shape == (n, 10) and value.shape == (n,)
-    # (two bf16 roundings: a float32-level difference in a pre-activation can flip one bf16 rounding -> up to ~1e-2)
-    assert float((logits - emu_l).abs().max()) < 1e-2 and float((value - emu_v).abs().max()) < 1e-2
-    assert float((logits - emu_l).abs().mean()) < 2e-4
-    assert float((logits - ref_l).abs().max()) < 0.12 and float((value - ref_v).abs().max()) < 0.12
+    # (two float16 roundings: a float32-level difference in a pre-activation can flip one rounding -> up to ~1e-3)
+    assert float((logits - emu_l).abs().max()) < 2e-3 and float((value - emu_v).abs().max()) < 2e-3
+    assert float((logits - emu_l).abs().mean()) < 5e-5
+    # float16 operands: the behaviour policy stays within ~2e-3 of the float32 learner policy (bfloat16 operands: ~1e-1)
+    assert float((logits - ref_l).abs().max()) < 6e-3 and float((value - ref_v).abs().max()) < 6e-3
     # the WR policy through the fused forward still plays at its published level
     w = dict(np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "wr_policy.npz")))
     env.close()
