@@ -1,5 +1,9 @@
 """Play the reference's published world-record policy (weights fixture tests/golden/wr_policy.npz) in this env:
-zero-start 10 s runs under the run's own env_config; prints the total reward (= distance along +Y)."""
+zero-start 10 s runs under the run's own env_config; prints the total reward (= distance along +Y).
+
+    python tools/eval_wr.py                                  # the WR checkpoint
+    python tools/eval_wr.py profiles/r1_policy_i.npz [fused]   # any npz in RLlib fcnet naming (tools/train_ppo.py --save);
+                                                             # "fused": evaluate through the f16 matrix-core forward"""
 import json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -10,11 +14,15 @@ from q1physrl_amd.tensor_env import TensorVectorEnv
 w = dict(np.load(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "wr_policy.npz")))
 ec = json.loads(str(w["env_config_json"]))
 ec["initial_yaw_range"] = tuple(ec["initial_yaw_range"])
+if len(sys.argv) > 1:                     # a policy trained by tools/train_ppo.py: its env_config is Config.get_default()
+    w = dict(np.load(sys.argv[1]))
+    ec = {k: v for k, v in Config.get_default().__dict__.items() if k != "num_envs"}
+fused = len(sys.argv) > 2 and sys.argv[2] == "fused"
 for det in (False, True):
     cfg = Config(**{**ec, "num_envs": 4096, "zero_start_prob": 1.0})
     env = TensorVectorEnv(cfg, seed=7)
     pol = P.load_rllib_fcnet_weights(P.Q1Policy(), w).cuda()
-    s = GpuSampler(env, pol, horizon=720)
+    s = GpuSampler(env, P.FusedPolicyForward(pol, env) if fused else pol, horizon=720)
     tr = s.collect(deterministic=det)
     total = tr["reward"].double().sum(0)
     print(("deterministic" if det else "stochastic"), "zero-start total reward: mean %.1f min %.1f max %.1f std %.1f; done on last tick: %s; value[0] mean %.1f"
