@@ -110,3 +110,39 @@ def test_fused_loss_needs_an_env_handle():
     from q1physrl_amd import policy as P, ppo
     with pytest.raises(ValueError, match="fused_loss=True needs env"):
         ppo.PPOLearner(P.Q1Policy(), 10.0, fused_loss=True)
+
+
+def test_closed_form_loss_gradient_matches_autograd():
+    """oracle/ppo_oracle.ppo_loss_grad (the float64 restatement of what the q1env_ppo_loss_grad kernel computes) against float64
+    torch autograd of ppo.ppo_loss: gradients with respect to the policy outputs and the five statistics, on a batch that
+    exercises the clamps, ratios outside the clip range and clipped value errors."""
+    import torch
+    from q1physrl_amd import ppo
+    rng = np.random.default_rng(4)
+    bsz = 3000
+    old = rng.normal(0, 1, (bsz, 10)) * np.array([1, 1, 1, 1, 1, 1, 1, 1, 1.5, 0.7])
+    new = old + 0.3 * rng.normal(0, 1, (bsz, 10))
+    new[:150, 8] = 3.4; new[150:300, 8] = -3.7; new[300:400, 9] = 2.5; new[400:500, 9] = -21.0
+    keys = rng.integers(0, 2, (bsz, 4))
+    mouse = rng.uniform(-9.9, 9.9, (bsz, 1))
+    lp_old = PO.dist_terms(old, keys, mouse, AR)[0] + 0.4 * rng.normal(0, 1, bsz)
+    v_old = 50 * rng.normal(0, 1, bsz)
+    v_new = v_old + 60 * rng.normal(0, 1, bsz) * (rng.random(bsz) < 0.5)
+    b = {"keys": keys, "mouse": mouse, "logp": lp_old, "adv": rng.normal(0, 1, bsz), "value": v_old, "vtarg": v_old + 80 * rng.normal(0, 1, bsz),
+         "old_logits": old}
+    dl, dv, st = PO.ppo_loss_grad(new, v_new, b, AR, 0.3, 100.0, 1.0, 0.01, 0.37)
+    lt, vt = torch.tensor(new, requires_grad=True), torch.tensor(v_new, requires_grad=True)
+
+    class Fixed(torch.nn.Module):
+        def forward(self, obs):
+            return lt, vt
+    loss, tst = ppo.ppo_loss(Fixed(), {k: (None if v is None else torch.as_tensor(v)) for k, v in {**b, "obs": None}.items()}, AR, 0.3, 100.0,
+                             1.0, 0.01, 0.37)
+    loss.backward()
+    # (relative: the rows with log_std clamped at -20 have std = 2e-9 and astronomically large - but equal - KL gradients)
+    rel = lambda a, r: np.max(np.abs(a - r) / np.maximum(np.abs(r), 1e-9))
+    assert rel(dl, lt.grad.numpy()) <= 1e-9 and rel(dv, vt.grad.numpy()) <= 1e-12
+    assert np.abs(lt.grad.numpy()[:300, 8]).max() == 0.0 and np.abs(dl[300:500, 9]).max() == 0.0      # gated by the clamps
+    for k in ppo.STAT_KEYS:
+        assert abs(st[k] - float(tst[k])) <= 1e-10 * max(1.0, abs(float(tst[k]))), k
+    assert abs(st["total_loss"] - PO.ppo_loss(new, v_new, b, AR, 0.3, 100.0, 1.0, 0.01, 0.37)[0]) <= 1e-10
