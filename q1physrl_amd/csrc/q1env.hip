@@ -667,6 +667,7 @@ struct q1env {
     size_t stage_bytes = 0;
     uint64_t tick_count = 0;          // ticks since create: the counter of the counter-based RNG
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    int num_cus = 256;                // compute units of the device (MI355X in SPX mode: 256)
     bool mlp_attr_set = false;        // dynamic-LDS attribute of the policy kernels (a per-device setting: kept per handle)
     // cached hipGraphs of step_many, keyed by (ticks, formats, pointers); a handful of entries, oldest evicted
     struct GraphEntry { std::vector<uint64_t> key; hipGraphExec_t exec; };
@@ -797,6 +798,10 @@ int q1env_create(const q1env_config* cfg, int device, void* stream, q1env_t** ou
         return fail(Q1ENV_ERR_ALLOC, std::string("hipMalloc(state): ") + hipGetErrorString(e));
     }
     carve(h);
+    {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) h->num_cus = cus;
+    }
     (void)hipEventCreate(&h->ev0);
     (void)hipEventCreate(&h->ev1);
     // zero-start reset of every env: mask NULL, zero_start_prob forced to 1 for this launch
@@ -1331,7 +1336,7 @@ static int launch_mlp(q1env* h, const float* obs, const q1pol::Net& na, const q1
     // One workgroup per CU (LDS holds one network's weights).  Up to one 32-env tile per SIMD of a network's share of the CUs:
     // one wave per SIMD; beyond that two waves per SIMD.  Q1ENV_MLP_THREADS overrides (measurement only).
     static const int forced = [] { const char* e = getenv("Q1ENV_MLP_THREADS"); return e ? atoi(e) : 0; }();
-    const unsigned cus = nets == 2 ? 128u : 256u;                               // CUs per network
+    const unsigned cus = (unsigned)(nets == 2 ? (h->num_cus > 1 ? h->num_cus / 2 : 1) : h->num_cus);   // CUs per network
     const int threads = forced == 256 || forced == 512 ? forced : ((unsigned)h->p.n <= cus * 4u * 32u ? 256 : 512);
     const unsigned per_block = 32u * (unsigned)(threads / 64);                   // envs one workgroup covers per grid-stride pass
     unsigned blocks = ((unsigned)h->p.n + per_block - 1u) / per_block;
