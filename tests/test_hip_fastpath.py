@@ -329,6 +329,63 @@ def test_full_size_rollout_parity_65536_envs_720_ticks():
     tenv.close()
 
 
+def test_one_million_envs_replication_and_kernel_agreement():
+    """BASELINE.json configs[3] size (1 048 576 envs, 720 ticks, zero start) through size-independent properties: the action
+    tensor is a 4 096-env pattern tiled 256 times, so (a) every replica must end bit-identical to the first 4 096 envs,
+    (b) those equal the C oracle driven with the same 4 096 action columns, and (c) the per-tick step kernels (hipGraph)
+    and the fused rollout kernel must agree on all 1 048 576 final states.  Also a checksum of checksums of the state."""
+    torch = torch_mod()
+    from oracle import c_oracle as CO
+    from q1physrl_amd.tensor_env import TensorVectorEnv
+    from q1physrl_amd.env import Config
+    import os
+    n, base, ticks = 1 << 20, 4096, 720
+    cfg = O.OracleConfig.get_default(num_envs=n, zero_start_prob=1.0)
+    rng = np.random.default_rng(7)
+    keys_b = rng.integers(0, 16, (ticks, base), dtype=np.uint8)
+    keys_b[1:] = np.where(rng.random((ticks - 1, base)) < 0.8, keys_b[:-1], keys_b[1:])       # some persistence
+    mouse_b = rng.uniform(-10.08, 10.08, (ticks, base)).astype(np.float32)
+    keys = torch.from_numpy(keys_b).cuda().repeat(1, n // base).contiguous()
+    mouse = torch.from_numpy(mouse_b).cuda().repeat(1, n // base).contiguous()
+    finals = []
+    for mode in ("rollout", "step_many"):
+        tenv = TensorVectorEnv(Config(**cfg.__dict__), device=0, seed=1)
+        tenv.reset()                                            # zero_start_prob = 1: identical start line for every env
+        if mode == "rollout":
+            tenv.rollout(ticks, (keys, mouse), outputs=False)
+        else:
+            tenv.step_many((keys, mouse), ticks, outputs=False, use_graph=True)
+        torch.cuda.synchronize()
+        finals.append(tenv.get_state())
+        tenv.close()
+    a, b = finals
+    for k in a:
+        assert np.array_equal(a[k], b[k]), k                    # (c) both kernels, every env
+    for k in ("vel_x", "vel_y", "vel_z", "pos_x", "pos_y", "z_pos", "yaw", "time_remaining", "flags"):
+        tiles = a[k].reshape(n // base, base)
+        assert np.array_equal(tiles, np.broadcast_to(tiles[0], tiles.shape)), k              # (a) replicas
+    lk = a["last_key_press_time"].reshape(n // base, base, 4)
+    assert np.array_equal(lk, np.broadcast_to(lk[0], lk.shape))
+    # (b) the first 4 096 envs against the C oracle
+    ocfg = O.OracleConfig.get_default(num_envs=base, zero_start_prob=1.0)
+    np.random.seed(1)
+    ora = CO.COracleVectorEnv(ocfg, threads=min(16, os.cpu_count() or 1))
+    bits = np.arange(4)[None, :]
+    dist = np.zeros((base, 2))
+    for t in range(ticks):
+        act = np.concatenate([((keys_b[t][:, None] >> bits) & 1).astype(np.float64), mouse_b[t][:, None].astype(np.float64)], axis=1)
+        ora.vector_step(act)
+        dist += ocfg.time_delta * ora.st["vel"][:, :2].astype(np.float64)
+    assert np.array_equal(a["vel_x"][:base], ora.st["vel"][:, 0]) and np.array_equal(a["vel_y"][:base], ora.st["vel"][:, 1])
+    assert np.array_equal(a["vel_z"][:base], ora.st["vel"][:, 2]) and np.array_equal(a["z_pos"][:base], ora.st["z_pos"])
+    assert np.array_equal(a["yaw"][:base], ora.yaw) and np.array_equal((a["flags"][:base] & 1) != 0, ora.st["on_ground"])
+    assert max(np.abs(a["pos_x"][:base] - dist[:, 0]).max(), np.abs(a["pos_y"][:base] - dist[:, 1]).max()) < 1e-5
+    # checksum of checksums: per-tile uint64 sums of the raw state words are all equal, and their total is 256 x the first
+    words = np.concatenate([a[k].view(np.uint32).reshape(n // base, -1).astype(np.uint64).sum(1, keepdims=True)
+                            for k in ("vel_x", "vel_y", "vel_z", "pos_y", "z_pos", "yaw")], axis=1)
+    assert (words == words[0]).all() and int(words.sum()) == int(words[0].sum()) * (n // base)
+
+
 @pytest.mark.parametrize("variant", ["default", "auto_jump"])
 def test_step_autoreset_equals_step_then_reset_done(variant):
     """q1env_step_autoreset (one launch) against q1env_step + q1env_reset_philox(done_only) (two launches): same rewards,
