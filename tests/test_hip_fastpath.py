@@ -222,6 +222,38 @@ def test_shard_count_invariance():
     full.close()
 
 
+def test_config3_full_size_shard_invariance_262144_envs_2000_ticks():
+    """BASELINE.json configs[2] at FULL size (262 144 envs, the reference run's params.yml env_config with random starts,
+    2 000 ticks with resets on done, on-device random actions): the whole batch on one handle equals 8 shards of 32 768 envs
+    with env_index_base = shard start (the multi-GPU partition), env for env, including the accumulated episode returns."""
+    torch = torch_mod()
+    from q1physrl_amd.tensor_env import TensorVectorEnv
+    from q1physrl_amd.env import Config
+    from q1physrl_amd.sharding import shard_plan
+    n, ticks, seed = 262144, 2000, 3
+    params_yml = dict(action_range=10, allow_jump=True, allow_yaw=True, auto_jump=False, discrete_yaw_steps=-1, fmove_max=800,
+                      smove_max=1060, hover=False, initial_yaw_range=(0, 360), key_press_delay=0.3, max_initial_speed=700,
+                      smooth_keys=True, speed_reward=False, time_delta=0.013888888888888, time_limit=10, zero_start_prob=0.01)
+
+    def run(count, start):
+        e = TensorVectorEnv(Config(num_envs=count, **params_yml), seed=seed, env_index_base=start)
+        e.reset()
+        ret = torch.zeros((count,), dtype=torch.float64, device="cuda")
+        e.rollout(ticks, None, outputs=False, auto_reset=True, return_sum=ret)
+        torch.cuda.synchronize()
+        st = e.get_state()
+        e.close()
+        return st, ret.cpu().numpy()
+    ref, ref_ret = run(n, 0)
+    parts = [run(count, start) for start, count in shard_plan(n, 8)]
+    for k in ref:
+        assert np.array_equal(np.concatenate([p[0][k] for p in parts], axis=0), ref[k]), k
+    assert np.array_equal(np.concatenate([p[1] for p in parts]), ref_ret)
+    assert ref["time_remaining"].min() >= -0.02 and ref["time_remaining"].max() <= 10.0          # every env kept being reset
+    assert np.isfinite(ref_ret).all() and np.abs(ref_ret).max() > 100.0
+    assert len(np.unique(ref["time_remaining"])) > 1000                                            # random starts: episodes out of phase
+
+
 def test_state_tensor_views_alias_device_state():
     torch = torch_mod()
     cfg, ora, tenv = make_pair(64, 2, zero_start_prob=1.0)
