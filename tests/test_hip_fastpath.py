@@ -254,6 +254,36 @@ def test_config3_full_size_shard_invariance_262144_envs_2000_ticks():
     assert len(np.unique(ref["time_remaining"])) > 1000                                            # random starts: episodes out of phase
 
 
+def test_large_batch_16m_envs_indexing():
+    """16 777 216 envs on one handle (1.4 GB of state; 32-bit indexing, 65 536-block grids): 40 ticks of a 4 096-env action
+    pattern tiled 4 096 times - every replica must equal the first tile (checked on the device through the zero-copy state
+    views) and the first tile must equal a 4 096-env handle driven with the same actions."""
+    torch = torch_mod()
+    from q1physrl_amd.tensor_env import TensorVectorEnv
+    from q1physrl_amd.env import Config
+    n, base, ticks = 1 << 24, 4096, 40
+    cfg = O.OracleConfig.get_default(num_envs=n, zero_start_prob=1.0)
+    g = torch.Generator(device="cuda").manual_seed(5)
+    keys_b = torch.randint(0, 16, (ticks, base), dtype=torch.uint8, device="cuda", generator=g)
+    mouse_b = (torch.rand((ticks, base), device="cuda", generator=g) * 20.16 - 10.08).contiguous()
+    big = TensorVectorEnv(Config(**cfg.__dict__), device=0, seed=1)
+    big.reset()
+    for t in range(ticks):                                      # per-tick kernel: one (n,) action row at a time
+        big.step_tensor((keys_b[t].repeat(n // base), mouse_b[t].repeat(n // base)))
+    small = TensorVectorEnv(Config(**dataclasses.replace(cfg, num_envs=base).__dict__), device=0, seed=1)
+    small.reset()
+    small.step_many((keys_b, mouse_b), ticks, outputs=False, use_graph=False)
+    torch.cuda.synchronize()
+    sb, ss = big.state_tensors(), small.state_tensors()
+    for k in ("vel_x", "vel_y", "vel_z", "pos_x", "pos_y", "z_pos", "yaw", "time_remaining", "flags"):
+        tiles = sb[k].view(n // base, base)
+        assert bool((tiles == ss[k].view(1, base)).all()), k
+    lk = sb["last_key_press_time"].view(4, n // base, base)
+    assert bool((lk == ss["last_key_press_time"].view(4, 1, base)).all())
+    assert float(sb["vel_y"].abs().max()) > 10.0                 # the envs really moved
+    big.close(); small.close()
+
+
 def test_state_tensor_views_alias_device_state():
     torch = torch_mod()
     cfg, ora, tenv = make_pair(64, 2, zero_start_prob=1.0)
