@@ -11,8 +11,6 @@ Loss (RLlib ppo_tf_policy.PPOLoss restated for torch):
 Multi-GPU: every rank samples its own env shard; the only collective of the whole system is the gradient
 all-reduce of the 138 k-parameter policy (one 552 KB flat bucket per SGD step; RCCL when the backend is nccl).
 """
-import math
-
 import torch
 import torch.distributed as dist
 

@@ -10,9 +10,8 @@ NumPy-compatible path uses (include/q1env.h: q1env_step / q1env_step_many / q1en
 
 Outputs are views of env-owned buffers, valid until the next call (SURVEY.md section 8b ownership rule).
 """
-from typing import Optional, Tuple, Union
+from typing import Optional, Tuple
 
-import numpy as np
 import torch
 
 from . import _lib

@@ -1,5 +1,5 @@
 """Error of the fused policy forward against the float32 torch modules (random well-scaled weights and the WR policy)."""
-import os, sys, json
+import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from q1physrl_amd import policy as P

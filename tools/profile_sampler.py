@@ -1,5 +1,5 @@
 """One sampler configuration under rocprofv3 (kernel trace): which kernels make up a tick of the GPU-resident sampler."""
-import os, sys, time
+import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from q1physrl_amd import policy as P
