@@ -41,7 +41,7 @@ def test_ppo_loss_matches_numpy_oracle():
         logits, value = pol(batch["obs"])
     nb = {k: v.numpy() for k, v in batch.items()}
     want, kl, ent = PO.ppo_loss(logits.numpy(), value.numpy(), nb, AR, 0.3, 100.0, 1.0, 0.01, 0.2)
-    assert abs(float(loss) - want) < 1e-9 * max(1, abs(want))
+    assert abs(float(loss.detach()) - want) < 1e-9 * max(1, abs(want))
     assert abs(float(st["kl"]) - kl) < 1e-9 and abs(float(st["entropy"]) - ent) < 1e-9
     loss.backward()
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in pol.parameters())
