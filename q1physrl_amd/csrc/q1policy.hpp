@@ -90,9 +90,11 @@ __device__ __forceinline__ f16x8 split_inputs(const float (&x)[3], uint32_t half
     union { f16x8 v; uint16_t u[8]; } o;
 #pragma unroll
     for (int s = 0; s < 3; ++s) {
-        const uint16_t hi = f16_bits(x[s]);
+        // (observations are O(1..1e3); the clamp keeps an out-of-range input finite - f16 saturates at 65504 - instead of inf/NaN)
+        const float xs = fminf(fmaxf(x[s], -65504.0f), 65504.0f);
+        const uint16_t hi = f16_bits(xs);
         o.u[s] = hi;
-        o.u[4 + s] = f16_bits(x[s] - f16_value(hi));
+        o.u[4 + s] = f16_bits(xs - f16_value(hi));
     }
     o.u[3] = 0x3C00;                                                  // 1.0: bias slot (hi part for half 0, lo part for half 1)
     o.u[7] = 0;

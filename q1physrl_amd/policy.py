@@ -193,6 +193,10 @@ class FusedPolicyForward:
         W2 rows multiplied by 2 log2(e) before the float16 rounding (tanh's exp2 argument is then the accumulator itself)."""
         for name, net in (("pi", self.policy.pi), ("vf", self.policy.vf)):
             l1, l2, l3 = net[0], net[2], net[4]
+            # float16 operands: fine for weights of O(1..10) (the WR checkpoint's largest is 7.4); refuse silently wrong results
+            wmax = max(float(l.weight.abs().max()) for l in (l1, l2, l3)) * TANH_PRESCALE
+            if not wmax < 6.0e4:
+                raise ValueError(f"FusedPolicyForward: |weight| * 2log2(e) = {wmax:.3g} does not fit float16; use the float32 modules")
             dev = l1.weight.device
             if name not in self._w:
                 self._w[name] = (torch.empty_like(l1.weight, dtype=torch.float32), torch.empty_like(l1.bias, dtype=torch.float32),
