@@ -22,3 +22,25 @@ for n, style in ((100, "rllib"), (4096, "rllib"), (65536, "rllib"), (4096, "ndar
     dr = (time.perf_counter() - t0) / 50
     print(f"n={n:8d} {style:8s} vector_step {dt*1e3:9.3f} ms = {n/dt/1e6:9.3f} M env-steps/s   reset_at {dr*1e6:8.1f} us")
     e.close()
+
+# BASELINE configs[0]: the gym single-env loop (PhysEnv.step / reset on done), 1000 steps
+np.random.seed(0)
+g = E.PhysEnv(E.Config.get_default())
+g.reset()
+rng = np.random.default_rng(1)
+acts = [tuple(int(x) for x in rng.integers(0, 2, 4)) + (np.array([rng.uniform(-10, 10)], dtype=np.float32),) for _ in range(1000)]
+g.step(acts[0])
+t0 = time.perf_counter()
+for a in acts:
+    _, _, d, _ = g.step(a)
+    if d:
+        g.reset()
+dt = (time.perf_counter() - t0) / len(acts)
+print(f"PhysEnv (gym, 1 env): {dt*1e6:.1f} us per step incl. resets = {1/dt/1e3:.1f} k env-steps/s")
+g.close()
+# reset_many vs reset_at
+e = E.VectorPhysEnv(dict(E.Config.get_default().__dict__, num_envs=65536))
+idx = np.arange(0, 65536, 720)
+t0 = time.perf_counter(); [e.reset_at(int(i)) for i in idx]; t1 = time.perf_counter(); e.reset_many(idx); t2 = time.perf_counter()
+print(f"{len(idx)} resets at 65536 envs: reset_at loop {1e3*(t1-t0):.2f} ms, reset_many {1e3*(t2-t1):.2f} ms")
+e.close()
