@@ -268,14 +268,25 @@ constexpr uint32_t STREAM_POLICY = 3;
 
 __device__ __forceinline__ void sample_action(const Params& p, const float* __restrict__ row, uint64_t seed, uint64_t genv,
                                               uint64_t counter, int deterministic, uint32_t& keys, float& mouse, float& logp) {
+    // all (up to ten) policy outputs of the row are requested before anything is computed: inside the per-key loop each pair
+    // would expose its own HBM round trip (one wave per SIMD at sampler batch sizes has nothing to hide it with)
+    float lg[10];
+    const int pairs = p.num_keys + (p.yaw_mode == 1 ? 1 : 0);
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+        lg[2 * j] = j < pairs ? row[2 * j] : 0.0f;
+        lg[2 * j + 1] = j < pairs ? row[2 * j + 1] : 0.0f;
+    }
     uint32_t r[4], r2[4];
     philox_draw(seed, genv, counter, STREAM_POLICY, 0, r);
     philox_draw(seed, genv, counter, STREAM_POLICY, 1, r2);
     logp = 0.0f;
     keys = 0;
     const uint32_t ku[4] = {r[0], r[1], r2[0], r2[1]};
-    for (int k = 0; k < p.num_keys; ++k) {
-        const float l0 = row[2 * k], l1 = row[2 * k + 1];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        if (k >= p.num_keys) break;
+        const float l0 = lg[2 * k], l1 = lg[2 * k + 1];
         const float d = l1 - l0;                                  // P(1) = sigmoid(d)
         const float p1 = 1.0f / (1.0f + expf(-d));
         const float u = (float)(ku[k] >> 8) * (1.0f / 16777216.0f);
@@ -288,7 +299,10 @@ __device__ __forceinline__ void sample_action(const Params& p, const float* __re
     if (p.yaw_mode == 1) {
         const float S = 0.5f * 1.8137f;
         const float low = -p.action_range_f32, high = p.action_range_f32;
-        float mean = row[2 * p.num_keys], log_std = row[2 * p.num_keys + 1];
+        float mean = 0.0f, log_std = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 5; ++j)
+            if (j == p.num_keys) { mean = lg[2 * j]; log_std = lg[2 * j + 1]; }
         mean = fminf(fmaxf(mean, -3.0f), 3.0f);
         log_std = fminf(fmaxf(log_std, -20.0f), 2.0f);
         const float std = expf(log_std);
@@ -504,14 +518,14 @@ sample_step_kernel(Params p, StatePtrs s, const float* __restrict__ logits, int 
     bool zs = false;
     if (live) {
         const uint64_t genv = (uint64_t)p.env_index_base + (uint64_t)i;
+        Env e;
+        load_env(s, n, i, e);                     // requested first: the state's HBM latency hides under the sampling arithmetic
         uint32_t keys;
         float mouse, logp;
         sample_action(p, logits + (size_t)i * row_stride, seed, genv, counter, deterministic, keys, mouse, logp);
         keys_out[i] = (uint8_t)keys;
         if (mouse_out) mouse_out[i] = mouse;
         if (logp_out) logp_out[i] = logp;
-        Env e;
-        load_env(s, n, i, e);
         const double yaw_act = cfg_yaw_mode<SPEC>(p) ? (double)mouse : 0.0;        // the packed action layout: float32 mouse
         tick<float, SPEC>(p, e, keys & ((1u << cfg_num_keys<SPEC>(p)) - 1u), yaw_act, o);
         zs = (e.flags & FLAG_ZERO_START) != 0;                                      // of the episode the step belonged to
