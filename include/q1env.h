@@ -174,6 +174,13 @@ int q1env_observe_host(q1env_t* env, int obs_format, void* obs);
 /* SoA state exchange with HOST arrays (checkpoint / golden-state injection / player_state snapshots) */
 int q1env_get_state_host(q1env_t* env, const q1env_state* dst);
 int q1env_set_state_host(q1env_t* env, const q1env_state* src);
+/* Device-side copy of the whole env state (all SoA arrays, one device-to-device copy on the handle's stream) and its
+ * restoration.  No reference counterpart: the host mirror uses it to undo speculative work (q1physrl_amd.env.VectorPhysEnv with
+ * speculative_resets=True resets every env that finished on a tick at the first reset_at call and rolls back what the caller
+ * did not claim). */
+int q1env_snapshot_state(q1env_t* env);
+int q1env_restore_state(q1env_t* env);
+
 /* device pointers of the live SoA arrays (zero-copy views for torch); valid until destroy */
 int q1env_state_device_ptrs(q1env_t* env, q1env_state* out);
 

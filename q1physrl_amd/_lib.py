@@ -75,6 +75,8 @@ _SIGNATURES = {
     "q1phys_apply_host": (C.c_int, [C.c_int, C.c_int64] + [_P] * 15),
     "q1env_policy_sample": (C.c_int, [_P, _P, C.c_int, C.c_uint64, C.c_uint64, _P, C.c_int, _P, _P, _P]),
     "q1env_gae": (C.c_int, [_P, C.c_int, _P, _P, _P, C.c_float, C.c_float, _P, _P]),
+    "q1env_snapshot_state": (C.c_int, [_P]),
+    "q1env_restore_state": (C.c_int, [_P]),
     "q1env_policy_forward": (C.c_int, [_P] * 7 + [C.c_int, _P]),
     "q1env_policy_value_forward": (C.c_int, [_P, _P, _P, _P]),
     "q1env_ppo_loss_grad": (C.c_int, [_P, C.c_int64, _P, _P, C.c_int] + [_P] * 7 + [C.c_float] * 4 + [_P] * 4),

@@ -677,6 +677,7 @@ struct q1env {
     void* arena = nullptr;            // one allocation holding the whole SoA state
     StatePtrs st{};
     // staging for the *_host entry points (grown on demand)
+    void* snap = nullptr;             // q1env_snapshot_state: a second arena holding a copy of the whole SoA state
     void* stage = nullptr;
     size_t stage_bytes = 0;
     uint64_t tick_count = 0;          // ticks since create: the counter of the counter-based RNG
@@ -840,6 +841,7 @@ int q1env_destroy(q1env_t* h) {
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->stage) (void)hipFree(h->stage);
+    if (h->snap) (void)hipFree(h->snap);
     if (h->arena) (void)hipFree(h->arena);
     if (h->own_stream) (void)hipStreamDestroy(h->stream);
     delete h;
@@ -1162,6 +1164,23 @@ int q1env_get_state_host(q1env_t* h, const q1env_state* dst) {
 int q1env_set_state_host(q1env_t* h, const q1env_state* src) {
     if (!h || !src) return fail(Q1ENV_ERR_INVALID_ARG, "q1env_set_state_host: null argument");
     return copy_state(h, src, false);
+}
+
+int q1env_snapshot_state(q1env_t* h) {
+    if (!h) return fail(Q1ENV_ERR_INVALID_ARG, "q1env_snapshot_state: null handle");
+    DeviceGuard guard(h->device);
+    const size_t bytes = arena_bytes((size_t)h->p.n);
+    if (!h->snap) HIP_TRY(hipMalloc(&h->snap, bytes));
+    HIP_TRY(hipMemcpyAsync(h->snap, h->arena, bytes, hipMemcpyDeviceToDevice, h->stream));
+    return Q1ENV_OK;
+}
+
+int q1env_restore_state(q1env_t* h) {
+    if (!h) return fail(Q1ENV_ERR_INVALID_ARG, "q1env_restore_state: null handle");
+    if (!h->snap) return fail(Q1ENV_ERR_INVALID_ARG, "q1env_restore_state: no snapshot taken");
+    DeviceGuard guard(h->device);
+    HIP_TRY(hipMemcpyAsync(h->arena, h->snap, arena_bytes((size_t)h->p.n), hipMemcpyDeviceToDevice, h->stream));
+    return Q1ENV_OK;
 }
 
 int q1env_state_device_ptrs(q1env_t* h, q1env_state* out) {

@@ -82,6 +82,12 @@ class DeviceEnv:
                                                     obs_format, _lib.ptr(obs)))
         return obs
 
+    def snapshot_state(self):
+        _lib.check(self._lib.q1env_snapshot_state(self._h))
+
+    def restore_state(self):
+        _lib.check(self._lib.q1env_restore_state(self._h))
+
     def observe_host(self, obs_format=_lib.OBS_F64):
         obs = np.empty((self.n, 6), dtype=np.float64 if obs_format == _lib.OBS_F64 else np.float32)
         _lib.check(self._lib.q1env_observe_host(self._h, obs_format, _lib.ptr(obs)))

@@ -276,10 +276,17 @@ class VectorPhysEnv(VectorEnv):
 
     vector_reset() -> obs (N,6) float64; reset_at(i) -> obs (6,); vector_step(actions) ->
     (obs (N,6) float64, reward (N,) float32, done (N,) bool, infos) with infos[i] == {'zero_start': bool}.
-    Extra keyword arguments (not in the reference): device, stream (raw hipStream_t), env_index_base.
+    Extra keyword arguments (not in the reference): device, stream (raw hipStream_t), env_index_base, speculative_resets.
+
+    speculative_resets=True batches RLlib's per-env reset protocol: the first `reset_at(i)` after a `vector_step` resets EVERY env
+    that finished on that tick (one device call, draws taken from the global NumPy stream in ascending index order - the order
+    RLlib's sampler calls reset_at in) and the following `reset_at` calls are answered from that batch.  Whatever the caller
+    does not claim, or claims out of order, is rolled back (device state snapshot + NumPy RNG state), so results and the RNG
+    stream equal the plain protocol's - provided nothing else draws from np.random between the reset_at calls of one tick.
     """
 
-    def __init__(self, config, *, device: int = 0, stream: Optional[int] = None, env_index_base: int = 0):
+    def __init__(self, config, *, device: int = 0, stream: Optional[int] = None, env_index_base: int = 0,
+                 speculative_resets: bool = False):
         if isinstance(config, dict):
             config = Config(**config)
         self._config = config
@@ -293,10 +300,15 @@ class VectorPhysEnv(VectorEnv):
         self.action_space = self._action_decoder.action_space
         self._step_num = 0
         self._cache = {}
+        self._speculative = bool(speculative_resets)
+        self._pending_done = None            # indices that finished on the last vector_step (speculative mode only)
+        self._spec = None                    # the speculative batch in flight
+        self.speculation_stats = {"batches": 0, "claimed": 0, "rolled_back": 0}
         self.vector_reset()
 
     # ---- resets: randomness from the global NumPy stream in the reference's order ---------------
     def vector_reset(self):
+        self._settle_speculation()
         c, n = self._config, self.num_envs
         zero_start = np.random.random(size=(n,)) < c.zero_start_prob                       # env.py:432
         yaw = np.random.uniform(*c.initial_yaw_range, size=(n,))                            # env.py:436
@@ -306,20 +318,62 @@ class VectorPhysEnv(VectorEnv):
         self._cache = {}
         return self._dev.reset_draws(zero_start, yaw, time_remaining, speed, angle)
 
-    def reset_at(self, index):
+    def _draw_reset_rows(self, k):
+        """The draws of k consecutive `reset_at` calls from the global NumPy stream (env.py:461-471: a zero start consumes no
+        yaw / time / speed draw, the angle is always drawn)."""
         c = self._config
+        zs, yaw, tm, sp, an = np.zeros(k, bool), np.zeros(k), np.zeros(k), np.zeros(k), np.zeros(k)
+        rnd, uni, tau = np.random.random, np.random.uniform, 2 * np.pi
+        for j in range(k):
+            z = zs[j] = rnd() < c.zero_start_prob
+            if not z:
+                yaw[j] = uni(*c.initial_yaw_range)
+                tm[j] = uni(c.time_limit)
+                sp[j] = uni(c.max_initial_speed)
+            an[j] = uni(tau)
+        return zs, yaw, tm, sp, an
+
+    def _settle_speculation(self):
+        """Undo the part of a speculative reset batch the caller did not claim: device state back to the snapshot, NumPy RNG back
+        to where the claimed prefix left it, the claimed resets re-applied."""
+        sp, self._spec, self._pending_done = self._spec, None, None
+        if sp is not None:
+            self.speculation_stats["claimed"] += sp["claimed"]
+        if sp is None or sp["claimed"] == len(sp["order"]):
+            return
+        k = sp["claimed"]
+        self.speculation_stats["rolled_back"] += len(sp["order"]) - k
+        self._dev.restore_state()
+        np.random.set_state(sp["rng"])
+        if k:
+            rows = self._draw_reset_rows(k)            # replays exactly the draws of the claimed prefix
+            self._dev.reset_draws(*rows, idx=sp["order"][:k])
+        self._cache = {}
+
+    def reset_at(self, index):
         index = int(index)
         if index < 0:                                   # the reference indexes NumPy arrays, so negatives wrap
             index += self.num_envs
-        zero_start = bool(np.random.random() < c.zero_start_prob)                           # env.py:461
-        # a zero start consumes no yaw / time / speed draw (env.py:462-467); the angle is always drawn (471)
-        yaw = 0.0 if zero_start else np.random.uniform(*c.initial_yaw_range)
-        time_remaining = 0.0 if zero_start else np.random.uniform(c.time_limit)
-        speed = 0.0 if zero_start else np.random.uniform(c.max_initial_speed)
-        angle = np.random.uniform(2 * np.pi)
+        sp = self._spec
+        if sp is not None:
+            if sp["claimed"] < len(sp["order"]) and int(sp["order"][sp["claimed"]]) == index:
+                sp["claimed"] += 1
+                return sp["obs"][sp["claimed"] - 1].copy()
+            self._settle_speculation()                  # out-of-order / unexpected index: fall back to the plain protocol
+        elif self._pending_done is not None and self._pending_done.size > 1 and int(self._pending_done[0]) == index:
+            order, self._pending_done = self._pending_done, None
+            rng = np.random.get_state()
+            rows = self._draw_reset_rows(order.size)
+            self._dev.snapshot_state()
+            obs = self._dev.reset_draws(*rows, idx=order)
+            self._spec = {"order": order, "obs": obs, "claimed": 1, "rng": rng}
+            self.speculation_stats["batches"] += 1
+            self._cache = {}
+            return obs[0].copy()
+        self._pending_done = None
+        rows = self._draw_reset_rows(1)
         self._cache = {}
-        obs = self._dev.reset_draws([zero_start], [yaw], [time_remaining], [speed], [angle], idx=[int(index)])
-        return obs[0]
+        return self._dev.reset_draws(*rows, idx=[index])[0]
 
     def reset_many(self, indices):
         """Extension (not in the reference): `[reset_at(i) for i in indices]` as ONE device call - the same draws from the
@@ -333,25 +387,19 @@ class VectorPhysEnv(VectorEnv):
             return np.empty((0, 6), dtype=np.float64)
         if np.unique(idx).size != idx.size:            # a repeated index: later resets overwrite earlier ones, keep it sequential
             return np.stack([self.reset_at(int(i)) for i in idx])
-        k = idx.size
-        zs, yaw, tm, sp, an = np.zeros(k, bool), np.zeros(k), np.zeros(k), np.zeros(k), np.zeros(k)
-        rnd, uni, tau = np.random.random, np.random.uniform, 2 * np.pi
-        for j in range(k):                             # per-env draw order of reset_at (env.py:461-471)
-            z = zs[j] = rnd() < c.zero_start_prob
-            if not z:
-                yaw[j] = uni(*c.initial_yaw_range)
-                tm[j] = uni(c.time_limit)
-                sp[j] = uni(c.max_initial_speed)
-            an[j] = uni(tau)
+        self._settle_speculation()
         self._cache = {}
-        return self._dev.reset_draws(zs, yaw, tm, sp, an, idx=idx)
+        return self._dev.reset_draws(*self._draw_reset_rows(idx.size), idx=idx)
 
     # ---- the tick ----------------------------------------------------------------------------
     def vector_step(self, actions):
         rows = _checked_rows(actions, self._dev.action_width, self.num_envs)
+        self._settle_speculation()
         obs, reward, done, zero_start = self._dev.step_host(rows)
         self._step_num += 1
         self._cache = {}
+        if self._speculative:
+            self._pending_done = np.flatnonzero(done)
         return obs, reward, done, _LazyInfos(zero_start)
 
     def get_unwrapped(self):
@@ -359,10 +407,12 @@ class VectorPhysEnv(VectorEnv):
 
     def _get_obs(self):
         """Current observation of every env, (N, 6) float64 (env.py:392-400), without stepping."""
+        self._settle_speculation()
         return self._dev.observe_host()
 
     def _get_obs_at(self, index):
         """Current observation of one env, (6,) float64 (env.py:402-408)."""
+        self._settle_speculation()
         return self._dev.observe_host()[index]
 
     def close(self):
@@ -370,6 +420,7 @@ class VectorPhysEnv(VectorEnv):
 
     # ---- state the reference exposes as attributes (read by analyse.py:199-218) -----------------
     def _state(self):
+        self._settle_speculation()
         if "st" not in self._cache:
             self._cache["st"] = self._dev.get_state()
         return self._cache["st"]
@@ -403,9 +454,11 @@ class VectorPhysEnv(VectorEnv):
 
     def get_state(self):
         """Checkpoint of the full env + decoder state (dict of host arrays); inverse: set_state()."""
+        self._settle_speculation()
         return self._dev.get_state()
 
     def set_state(self, **arrays):
+        self._settle_speculation()
         self._cache = {}
         self._dev.set_state(**arrays)
 

@@ -282,3 +282,60 @@ def test_reset_many_equals_sequential_reset_at():
     for k in sa:
         assert np.array_equal(sa[k], sb[k]), k
     a.close(); b.close()
+
+
+@pytest.mark.parametrize("behaviour", ["rllib", "skip_last", "descending", "peek", "foreign_index"])
+def test_speculative_resets_equal_the_plain_protocol(behaviour):
+    """VectorPhysEnv(speculative_resets=True) resets the whole done set at the first reset_at of a tick and answers the later
+    calls from that batch.  Whatever the caller does - RLlib's ascending sweep, leaving a finished env un-reset, descending
+    order, reading state between the calls, resetting an env that was not done - observations, rewards, dones, the final state
+    and the position of the global NumPy stream must equal the plain one-call-per-env protocol."""
+    from q1physrl_amd import env as E
+    n, ticks = 257, 160
+    kw = dict(O.OracleConfig.get_default(num_envs=n, zero_start_prob=0.3, time_limit=0.25).__dict__)
+    envs = []
+    for spec in (False, True):
+        np.random.seed(5)
+        envs.append(E.VectorPhysEnv(dict(kw), speculative_resets=spec))
+    plain, fast = envs
+    rng = np.random.default_rng(1)
+    states = []
+    for e in envs:
+        np.random.seed(6)
+        rng = np.random.default_rng(1)
+        log = []
+        for t in range(ticks):
+            a = np.concatenate([(rng.random((n, 4)) < 0.5).astype(np.float64), rng.uniform(-10, 10, (n, 1))], axis=1)
+            obs, rew, done, _ = e.vector_step(a)
+            idx = np.flatnonzero(done)
+            if behaviour == "skip_last":
+                idx = idx[:-1]
+            elif behaviour == "descending":
+                idx = idx[::-1]
+            elif behaviour == "foreign_index" and idx.size > 2:
+                idx = np.concatenate([idx[:1], [(int(idx[0]) + 1) % n if (int(idx[0]) + 1) % n not in idx else int(idx[0])], idx[1:]])
+            fresh = []
+            for j, i in enumerate(idx):
+                fresh.append(e.reset_at(int(i)))
+                if behaviour == "peek" and j == 0:
+                    log.append(e._time_remaining.copy())
+            log.append((obs.copy(), rew.copy(), done.copy(), np.array(fresh)))
+        states.append((log, e.get_state(), np.random.get_state()[1].copy(), np.random.get_state()[2], dict(e.speculation_stats)))
+        e.close()
+    (la, sa, ra, pa, st_a), (lb, sb, rb, pb, st_b) = states
+    assert st_a["batches"] == 0
+    if behaviour == "descending":                 # the first call is not the smallest finished index: speculation never starts
+        assert st_b["batches"] == 0
+    else:                                         # the fast path really ran (and rolled back whenever the caller deviated)
+        assert st_b["batches"] > 20 and st_b["claimed"] > 100
+        assert (st_b["rolled_back"] > 0) == (behaviour != "rllib")
+    assert len(la) == len(lb)
+    for x, y in zip(la, lb):
+        if isinstance(x, tuple):
+            for u, v in zip(x, y):
+                assert np.array_equal(u, v)
+        else:
+            assert np.array_equal(x, y)
+    for k in sa:
+        assert np.array_equal(sa[k], sb[k]), k
+    assert np.array_equal(ra, rb) and pa == pb
