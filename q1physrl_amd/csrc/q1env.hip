@@ -32,11 +32,12 @@ step_kernel(Params p, StatePtrs s, int fmt, const void* act_a, const void* act_b
     if (i >= n) return;
     Env e;
     load_env(s, n, i, e);
+    const Env loaded = e;
     double yaw_act;
     const uint32_t keys = fetch_action<SPEC, FMT>(p, fmt, act_a, act_b, (size_t)i, &yaw_act);
     TickOut<OBS_T> o;
     tick<OBS_T, SPEC>(p, e, keys, yaw_act, o);
-    store_env(s, n, i, e);
+    store_env_delta(s, n, i, e, loaded);
     if (obs) {
         if constexpr (sizeof(OBS_T) == 4) {
             const uint32_t lane = threadIdx.x & 63u, wave_first = i - lane;
@@ -66,6 +67,7 @@ step_autoreset_kernel(Params p, StatePtrs s, int fmt, const void* act_a, const v
     if (counter_dev) counter += *counter_dev;
     Env e;
     load_env(s, n, i, e);
+    const Env loaded = e;
     double yaw_act;
     const uint32_t keys = fetch_action<SPEC, FMT>(p, fmt, act_a, act_b, (size_t)i, &yaw_act);
     TickOut<float> o;
@@ -75,7 +77,7 @@ step_autoreset_kernel(Params p, StatePtrs s, int fmt, const void* act_a, const v
         reset_philox(p, e, seed, (uint64_t)p.env_index_base + (uint64_t)i, counter + 1);
         observe<float>(p, e, o.obs);
     }
-    store_env(s, n, i, e);
+    store_env_delta(s, n, i, e, loaded);
     if (obs) {
         const uint32_t lane = threadIdx.x & 63u, wave_first = i - lane;
         if (wave_first + 64u <= n) write_obs_wave_f32(obs, wave_first, lane, o.obs, slab[threadIdx.x >> 6]);
@@ -520,6 +522,7 @@ sample_step_kernel(Params p, StatePtrs s, const float* __restrict__ logits, int 
         const uint64_t genv = (uint64_t)p.env_index_base + (uint64_t)i;
         Env e;
         load_env(s, n, i, e);                     // requested first: the state's HBM latency hides under the sampling arithmetic
+        const Env loaded = e;
         uint32_t keys;
         float mouse, logp;
         sample_action(p, logits + (size_t)i * row_stride, seed, genv, counter, deterministic, keys, mouse, logp);
@@ -534,7 +537,7 @@ sample_step_kernel(Params p, StatePtrs s, const float* __restrict__ logits, int 
             reset_philox(p, e, seed, genv, counter + 1);
             observe<float>(p, e, o.obs);
         }
-        store_env(s, n, i, e);
+        store_env_delta(s, n, i, e, loaded);
         const uint32_t lane = threadIdx.x & 63u, wave_first = i - lane;
         if (wave_first + 64u <= n) write_obs_wave_f32(obs, wave_first, lane, o.obs, slab[threadIdx.x >> 6]);
         else write_obs<float>(obs, (size_t)i, o.obs);
