@@ -41,14 +41,14 @@ step_kernel(Params p, StatePtrs s, int fmt, const void* act_a, const void* act_b
     if (obs) {
         if constexpr (sizeof(OBS_T) == 4) {
             const uint32_t lane = threadIdx.x & 63u, wave_first = i - lane;
-            if (wave_first + 64u <= n) write_obs_wave_f32(obs, wave_first, lane, o.obs, slab[threadIdx.x >> 6]);
+            if (wave_first + 64u <= n) write_obs_wave_f32_nt(obs, wave_first, lane, o.obs, slab[threadIdx.x >> 6]);
             else write_obs<OBS_T>(obs, (size_t)i, o.obs);
         } else {
             write_obs<OBS_T>(obs, (size_t)i, o.obs);
         }
     }
-    if (reward) reward[i] = o.reward;
-    if (done) done[i] = o.done ? 1 : 0;
+    if (reward) __builtin_nontemporal_store(o.reward, reward + i);
+    if (done) __builtin_nontemporal_store((uint8_t)(o.done ? 1 : 0), done + i);
     if (zero_start) zero_start[i] = (e.flags & FLAG_ZERO_START) ? 1 : 0;
 }
 

@@ -462,4 +462,23 @@ __device__ __forceinline__ void write_obs_wave_f32(float* obs, size_t wave_first
     __builtin_amdgcn_wave_barrier();
 }
 
+// Same, with non-temporal stores (outputs are written once and read by a later kernel / the host: no reason to keep them in L2).
+__device__ __forceinline__ void write_obs_wave_f32_nt(float* obs, size_t wave_first, uint32_t lane, const float o[6],
+                                                      float* slab) {
+    float2* w = reinterpret_cast<float2*>(slab + lane * 6);
+    w[0] = make_float2(o[0], o[1]);
+    w[1] = make_float2(o[2], o[3]);
+    w[2] = make_float2(o[4], o[5]);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    f2* dst = reinterpret_cast<f2*>(obs + wave_first * 6);
+    const f2* src = reinterpret_cast<const f2*>(slab);
+#pragma unroll
+    for (uint32_t k = 0; k < 3; ++k) __builtin_nontemporal_store(src[k * 64u + lane], dst + k * 64u + lane);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
 }  // namespace q1
