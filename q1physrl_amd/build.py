@@ -18,7 +18,8 @@ DEPS = [SRC, os.path.join(PKG, "csrc", "q1env_device.hpp"), os.path.join(PKG, "c
 OUT = os.path.join(PKG, "libq1env.so")
 
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
-               "-Wall", "-Wno-unused-function"]
+               "-Wall", "-Wno-unused-function",
+               "-mllvm", "-amdgpu-kernarg-preload-count=16"]   # leading scalar kernel arguments arrive in SGPRs (step_kernel's state pointers)
 
 
 def hipcc_path():

@@ -24,12 +24,16 @@ using namespace q1;
 //   SPEC: default Config structure baked in (straight-line tick);  FMT: action layout, or FMT_RUNTIME.
 template <typename OBS_T, bool SPEC, int FMT>
 __global__ void __launch_bounds__(256)
-step_kernel(Params p, StatePtrs s, int fmt, const void* act_a, const void* act_b,
+step_kernel(float* pvx, float* pvy, float* pvz, double* ppx, double* ppy, double* pz, double* pyaw, double* ptrem,   // preloaded into SGPRs
+            Params p, StatePtrs s, int fmt, const void* act_a, const void* act_b,
             OBS_T* obs, float* reward, uint8_t* done, uint8_t* zero_start) {
+    // The eight leading pointers repeat s.vx .. s.trem: leading scalar kernel arguments are preloaded into SGPRs by the command
+    // processor (-mllvm -amdgpu-kernarg-preload-count), so the first state loads do not wait for an s_load of the kernarg segment.
     __shared__ float slab[4][384];
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t n = (uint32_t)p.n;
     if (i >= n) return;
+    s.vx = pvx; s.vy = pvy; s.vz = pvz; s.px = ppx; s.py = ppy; s.z = pz; s.yaw = pyaw; s.trem = ptrem;
     Env e;
     load_env(s, n, i, e);
     const Env loaded = e;
@@ -897,7 +901,8 @@ static void launch_step(q1env* h, int fmt, const void* a, const void* b, int obs
     const dim3 g = grid_for(h->p.n, blk), bs(blk);
     const bool spec = is_spec(h->p);
 #define Q1_LAUNCH_STEP(OT, SP, FM) \
-    hipLaunchKernelGGL((step_kernel<OT, SP, FM>), g, bs, 0, h->stream, h->p, h->st, fmt, a, b, (OT*)obs, reward, done, zs)
+    hipLaunchKernelGGL((step_kernel<OT, SP, FM>), g, bs, 0, h->stream, h->st.vx, h->st.vy, h->st.vz, h->st.px, h->st.py, h->st.z, h->st.yaw, \
+                       h->st.trem, h->p, h->st, fmt, a, b, (OT*)obs, reward, done, zs)
     if (obs_format == Q1ENV_OBS_F32) {
         if (spec && fmt == Q1ENV_ACT_PACKED) Q1_LAUNCH_STEP(float, true, FMT_PACKED);
         else if (spec && fmt == Q1ENV_ACT_F32_ROWS) Q1_LAUNCH_STEP(float, true, FMT_F32_ROWS);
