@@ -20,7 +20,8 @@ def test_action_generator_and_traffic_lookup():
     flips = np.mean((keys[1:] ^ keys[:-1]) != 0)
     assert 0.1 < flips < 0.3                       # ~1 - 0.95^4 of the envs flip at least one key per tick
     t = bench.load_profiled_traffic("step", 65536)
-    assert t is None or 12e6 < t < 16e6            # profiles/traffic.json: ~13.6 MB per launch at 65 536 envs
+    assert t is None or 9e6 < t < 16e6             # profiles/traffic.json: ~11.7 MB per launch at 65 536 envs (13.4 MB algorithmic;
+                                                   # the write-back skips unchanged state words)
     assert bench.B_ALG == 204.0 and bench.EPISODE_TICKS == 720
 
 
