@@ -4,6 +4,10 @@
     python bench.py [--gpus N] [--steps K] [--warmup W] [--envs E] [--mode step|rollout]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
+`python bench.py --gpus N` with N > 1 and no RANK / WORLD_SIZE in the environment launches its own N workers (one process
+per GPU, LOCAL_RANK = device index, rendezvous on 127.0.0.1) and rank 0 prints the JSON line; under torch.distributed.run the
+launcher's environment is used as is.  BASELINE configs[3] (1 048 576 envs on 8 GPUs) is `--gpus 8 --envs 131072`.
+
 A "step" is one tick (one VectorPhysEnv.vector_step, reference env.py:482-510) of the whole batch.
 Workload at N=1 = BASELINE.json configs[1]: 65 536 envs, zero-start 100 m run (zero_start_prob = 1,
 get_default Config, dt = 1/72, 720-tick episodes), random actions (keys flip with p = 0.05 per tick,
@@ -19,11 +23,18 @@ reward float32, done uint8; all envs are reset on device at each episode end (in
 Multi-GPU: one process per GPU, the batch is split (65 536 envs per GPU, weak scaling), no collective on
 the data path; ranks only meet in the barriers around the timed region and in the MAX of the elapsed time.
 
+Timed region (every rank): graphs instantiated and uploaded, warm-up ticks, barrier + torch.cuda.synchronize();
+t0; start event; EXACTLY K ticks enqueued; stop event; ONE torch.cuda.synchronize(); t1; barrier.  `value` uses the MAX over
+ranks of t1 - t0 (host wall clock); `roofline` uses the HIP-event time between the two events on the launch stream.
+
 Output: ONE JSON line on rank 0 (contract in the task statement) with `roofline` and `cpu_baseline`.
 """
 import argparse
+import importlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -171,39 +182,109 @@ def load_profiled_traffic(mode, n):
         return None
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=7200)
     ap.add_argument("--warmup", type=int, default=720)
-    ap.add_argument("--envs", type=int, default=65536, help="envs per GPU")
+    ap.add_argument("--envs", type=int, default=65536, help="envs per GPU (131072 = BASELINE configs[3]'s shard)")
     ap.add_argument("--mode", choices=("step", "rollout"), default="step")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary (other-mode) measurement")
-    args = ap.parse_args()
+    return ap.parse_args(argv)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch_workers(args, argv):
+    """`python bench.py --gpus N` outside a distributed launcher: start N copies of this script, one per GPU, with the
+    environment torch.distributed.run would have given them.  Rank 0's stdout (the JSON line) is this process's stdout; the other
+    ranks' stdout goes to stderr.  Exit status: the first non-zero worker status."""
+    port = _free_port()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), Q1_BENCH_SELF_LAUNCHED="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=None if r == 0 else sys.stderr))
+    rc = 0
+    deadline = None
+    alive = list(procs)
+    while alive:
+        for p in list(alive):
+            st = p.poll()
+            if st is None:
+                continue
+            alive.remove(p)
+            if st != 0 and rc == 0:
+                rc = st
+                deadline = time.time() + 30.0          # a rank died: the others would wait in a barrier forever
+        if deadline is not None and time.time() > deadline:
+            for p in alive:
+                p.kill()
+        time.sleep(0.05)
+    return rc
+
+
+def load_env_class():
+    """The per-GPU env handle.  Q1_BENCH_ENV_FACTORY = "module:attr" exists for tests/test_bench_launcher.py only: this
+    container has no GPU, so the world-size-2 launcher test substitutes an oracle-backed stand-in with DeviceEnv's methods and
+    runs every other line of this file (launcher, rendezvous, timed region, rank reduction, JSON) on CPU over gloo."""
+    spec = os.environ.get("Q1_BENCH_ENV_FACTORY")
+    if spec:
+        mod, attr = spec.split(":")
+        return getattr(importlib.import_module(mod), attr), True
+    from q1physrl_amd.device import DeviceEnv
+    return DeviceEnv, False
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    args = parse_args(argv)
+    if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(launch_workers(args, argv))
 
     import torch
     import torch.distributed as dist
     from q1physrl_amd import _lib, env as E, sharding
-    from q1physrl_amd.device import DeviceEnv
+    DeviceEnv, injected = load_env_class()
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: no HIP device visible and there is no CPU fallback")
-    ndev = torch.cuda.device_count()
-    dev_index = local_rank % ndev
-    torch.cuda.set_device(dev_index)
-    d = torch.device("cuda", dev_index)
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world} (launch with --nproc-per-node {args.gpus}, "
+                         f"or run plain `python bench.py --gpus {args.gpus}` and let it start its own workers)")
+    if injected:
+        dev_index, ndev = 0, 0
+        d = torch.device("cpu")
+        dsync = lambda: None                                         # noqa: E731
+    else:
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs an MI355X: no HIP device visible and there is no CPU fallback")
+        ndev = torch.cuda.device_count()
+        if world > ndev and not os.environ.get("Q1_BENCH_OVERSUBSCRIBE"):
+            raise SystemExit(f"bench.py: --gpus {world} but only {ndev} HIP device(s) visible")
+        dev_index = local_rank % ndev
+        torch.cuda.set_device(dev_index)
+        d = torch.device("cuda", dev_index)
+        dsync = torch.cuda.synchronize
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        backend = os.environ.get("Q1_BENCH_BACKEND", "nccl" if ndev >= world else "gloo")
-        try:
-            dist.init_process_group(backend, device_id=d if backend == "nccl" else None)
-        except Exception:   # noqa: BLE001 - the env path needs no collective; barriers work over gloo as well
+        # the env path has no collective: ranks only meet in barriers and one MAX of a scalar, which gloo serves from the host
+        # (no GPU all-reduce latency inside the timed region's brackets); Q1_BENCH_BACKEND=nccl selects RCCL instead
+        backend = os.environ.get("Q1_BENCH_BACKEND", "gloo")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=d)
+        else:
             dist.init_process_group("gloo")
 
     n = args.envs
@@ -218,7 +299,7 @@ def main():
     rew1 = torch.empty((n,), dtype=torch.float32, device=d)
     done1 = torch.empty((n,), dtype=torch.uint8, device=d)
     obsT = rewT = doneT = None
-    torch.cuda.synchronize()
+    dsync()
 
     def run_ticks(mode, k, tick0, prepare=False):
         """k ticks starting at episode phase tick0 % 720; resets every env on device at each episode end.
@@ -258,24 +339,38 @@ def main():
 
     def barrier():
         dev.sync()
-        torch.cuda.synchronize()
+        dsync()
         if world > 1:
             dist.barrier()
 
     def measure(mode, steps, warmup):
-        run_ticks(mode, warmup, 0, prepare=True)
+        run_ticks(mode, warmup, 0, prepare=True)           # instantiate + upload every graph the two sequences replay
         run_ticks(mode, steps, warmup, prepare=True)
         run_ticks(mode, warmup, 0)
         barrier()
         t0 = time.perf_counter()
-        dev.timer_start()
+        dev.timer_start()                         # HIP events on the stream the kernels are launched on
         launches = run_ticks(mode, steps, warmup)
-        ev_ms = dev.timer_stop()                  # HIP events on the stream the kernels were launched on
-        barrier()
-        wall = sharding.max_over_ranks(time.perf_counter() - t0, device=d)
-        return wall, ev_ms, launches
+        dev.timer_mark()
+        dsync()                                   # the ONE synchronisation that ends the timed region (device-wide: covers the handle's stream)
+        own = time.perf_counter() - t0
+        ev_ms = dev.timer_elapsed()               # both events have completed: no further wait
+        if world > 1:
+            dist.barrier()
+        wall = sharding.max_over_ranks(own, device=d)
+        return wall, ev_ms, launches, own
 
-    wall, ev_ms, launches = measure(args.mode, args.steps, args.warmup)
+    def per_rank(own, ev_ms):
+        """Every rank's own wall / event time of the region it timed, gathered on all ranks (host objects, after the timing)."""
+        mine = {"rank": rank, "wall_ms": own * 1e3, "event_ms": ev_ms, "env_steps_per_s": float(n) * args.steps / own}
+        if world == 1:
+            return [mine]
+        rows = [None] * world
+        dist.all_gather_object(rows, mine)
+        return rows
+
+    wall, ev_ms, launches, own = measure(args.mode, args.steps, args.warmup)
+    ranks = per_rank(own, ev_ms)
     value = float(n) * args.steps * world / wall
     ticks_per_launch = args.steps / launches
     kern_us = ev_ms * 1e3 / launches
@@ -283,6 +378,7 @@ def main():
     kernel = ("step_kernel<float,SPEC,PACKED>" if args.mode == "step" else "rollout_kernel<float,SPEC,PACKED,no-reset,all-outputs>")
     roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
             "traffic": load_profiled_traffic(args.mode, n), "kernel": kernel, "avg_launch_us": kern_us,
+            "event_ms_per_step": ev_ms / args.steps, "wall_over_event": wall * 1e3 / ev_ms if ev_ms > 0 else None,
             "alg_bytes_per_env_step": B_ALG, "env_steps_per_launch": n * ticks_per_launch,
             "note": "achieved = 204 B x env-steps per launch / (HIP-event time of the timed region / launches). "
                     "traffic = HBM bytes per launch from the rocprofv3 FETCH_SIZE(x2, gfx950)/WRITE_SIZE passes in profiles/ "
@@ -297,18 +393,22 @@ def main():
         "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": wall * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
-        "config": {"workload": f"BASELINE configs[1]: {n} envs/GPU, zero-start 100 m run, random actions, get_default Config, "
+        "config": {"workload": (f"BASELINE configs[1]: {n} envs/GPU" if n != 131072 else
+                                f"BASELINE configs[3] shard: 131072 envs/GPU ({131072 * world} envs on {world} GPU(s))")
+                               + ", zero-start 100 m run, random actions, get_default Config, "
                                f"720-tick episodes with on-device reset, per-tick obs f32/reward/done written; mode={args.mode}"
                                + ("+hipGraph" if args.mode == "step" and not args.no_graph else ""),
+                   "total_envs": n * world,
                    "envs_per_gpu": n, "parallelism": f"batch-split x{world}, no collective",
                    "arithmetic": "float64 (float32 storage of vel/obs/reward), bit-identical to the NumPy reference"},
         "roofline": roof,
+        "per_rank": ranks,
         "parity": "max |pos - NumPy ref| over the 10 s rollout: measured live in cpu_baseline.parity_vs_gpu_after_719_ticks (N=1 runs); "
                   "tests/test_hip_fastpath.py::test_full_size_rollout_parity_65536_envs_720_ticks checks all 65 536 x 720 env-steps bit-exactly",
     }
     if not args.no_secondary:
         other = "rollout" if args.mode == "step" else "step"
-        w2, ev2, l2 = measure(other, args.steps, args.warmup)
+        w2, ev2, l2, _own2 = measure(other, args.steps, args.warmup)
         out["fused_rollout" if other == "rollout" else "per_tick_step"] = {
             "value": float(n) * args.steps * world / w2, "unit": "env-steps/s", "ms_per_step": w2 * 1e3 / args.steps,
             "launches": l2, "avg_launch_us": ev2 * 1e3 / l2,

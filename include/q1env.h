@@ -287,7 +287,11 @@ int q1env_episode_stats(q1env_t* env, const float* reward_dev, const uint8_t* do
 int q1env_selftest_division(int device, uint64_t n, uint64_t seed, double c0, double c1, uint64_t* mismatches4);
 int q1env_calibrate_traffic(q1env_t* env, int launches);
 int q1env_timer_start(q1env_t* env);
-int q1env_timer_stop(q1env_t* env, float* elapsed_ms);   /* synchronises on the stop event */
+int q1env_timer_stop(q1env_t* env, float* elapsed_ms);   /* = timer_mark + timer_elapsed: synchronises on the stop event */
+/* The two halves of timer_stop, for a timed region that ends in ONE synchronisation of the caller's own: mark records the
+ * stop event (asynchronous); elapsed waits for it (immediate once the stream has drained) and returns start -> mark. */
+int q1env_timer_mark(q1env_t* env);
+int q1env_timer_elapsed(q1env_t* env, float* elapsed_ms);
 
 #ifdef __cplusplus
 }

@@ -86,6 +86,8 @@ _SIGNATURES = {
     "q1env_calibrate_traffic": (C.c_int, [_P, C.c_int]),
     "q1env_timer_start": (C.c_int, [_P]),
     "q1env_timer_stop": (C.c_int, [_P, C.POINTER(C.c_float)]),
+    "q1env_timer_mark": (C.c_int, [_P]),
+    "q1env_timer_elapsed": (C.c_int, [_P, C.POINTER(C.c_float)]),
 }
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 

@@ -1022,7 +1022,10 @@ int q1env_step_many(q1env_t* h, int ticks, int fmt, const void* a, const void* b
             }
             h->graphs.push_back({key, exec});
         }
-        if (use_graph == 2) return Q1ENV_OK;                // prepare only: capture + instantiate, no launch, no tick
+        if (use_graph == 2) {                               // prepare only: capture + instantiate + upload, no launch, no tick
+            (void)hipGraphUpload(exec, h->stream);          // the executable graph's packets are resident before the first replay
+            return Q1ENV_OK;
+        }
         HIP_TRY(hipGraphLaunch(exec, h->stream));
     }
     h->tick_count += (uint64_t)ticks;
@@ -1449,6 +1452,21 @@ int q1env_timer_start(q1env_t* h) {
     if (!h) return fail(Q1ENV_ERR_INVALID_ARG, "q1env_timer_start: null handle");
     DeviceGuard guard(h->device);
     HIP_TRY(hipEventRecord(h->ev0, h->stream));
+    return Q1ENV_OK;
+}
+
+int q1env_timer_mark(q1env_t* h) {
+    if (!h) return fail(Q1ENV_ERR_INVALID_ARG, "q1env_timer_mark: null handle");
+    DeviceGuard guard(h->device);
+    HIP_TRY(hipEventRecord(h->ev1, h->stream));
+    return Q1ENV_OK;
+}
+
+int q1env_timer_elapsed(q1env_t* h, float* ms) {
+    if (!h || !ms) return fail(Q1ENV_ERR_INVALID_ARG, "q1env_timer_elapsed: null argument");
+    DeviceGuard guard(h->device);
+    HIP_TRY(hipEventSynchronize(h->ev1));
+    HIP_TRY(hipEventElapsedTime(ms, h->ev0, h->ev1));
     return Q1ENV_OK;
 }
 

@@ -213,6 +213,15 @@ class DeviceEnv:
     def timer_start(self):
         _lib.check(self._lib.q1env_timer_start(self._h))
 
+    def timer_mark(self):
+        """Record the stop event without waiting for it (read it later with timer_elapsed)."""
+        _lib.check(self._lib.q1env_timer_mark(self._h))
+
+    def timer_elapsed(self):
+        ms = C.c_float()
+        _lib.check(self._lib.q1env_timer_elapsed(self._h, C.byref(ms)))
+        return ms.value
+
     def timer_stop(self):
         ms = C.c_float()
         _lib.check(self._lib.q1env_timer_stop(self._h, C.byref(ms)))
