@@ -301,29 +301,42 @@ def main(argv=None):
     obsT = rewT = doneT = None
     dsync()
 
-    def run_ticks(mode, k, tick0, prepare=False):
+    def run_ticks(mode, k, tick0, prepare=False, timed=False):
         """k ticks starting at episode phase tick0 % 720; resets every env on device at each episode end.
-        prepare=True only builds the hipGraphs this sequence will replay (no launch), so that the timed region never
-        pays a graph instantiation whatever --steps / --warmup are."""
+        prepare=True only builds (instantiates + uploads) the hipGraphs this sequence will replay, no launch.
+        timed=True brackets the sequence with the handle's timer events (HIP events on the launch stream); in step mode they
+        are recorded inside the q1env_step_many call of the first / last chunk, next to the launch itself."""
         nonlocal obsT, rewT, doneT
         if mode == "rollout" and obsT is None:        # tick-major per-tick outputs of a whole episode
             obsT = torch.empty((EPISODE_TICKS, n, 6), dtype=torch.float32, device=d)
             rewT = torch.empty((EPISODE_TICKS, n), dtype=torch.float32, device=d)
             doneT = torch.empty((EPISODE_TICKS, n), dtype=torch.uint8, device=d)
         t, left, launches = tick0, k, 0
+        started = stopped = False
+        if timed and mode != "step":
+            dev.timer_start()
+            started = True
         while left > 0:
             ph = t % EPISODE_TICKS
             chunk = min(left, EPISODE_TICKS - ph)
             ka = keys.data_ptr() + ph * n
             ma = mouse.data_ptr() + ph * n * 4
+            ends_episode = (t + chunk) % EPISODE_TICKS == 0
             if mode == "step":
                 if prepare:
                     if not args.no_graph:
                         dev.step_many_dev(chunk, _lib.ACT_PACKED, ka, ma, _lib.OBS_F32, obs1.data_ptr(), rew1.data_ptr(),
                                           done1.data_ptr(), out_stride_ticks=0, use_graph=2)
                 else:
+                    flags = 0 if args.no_graph else 1
+                    if timed and not started:
+                        flags |= _lib.TIMER_START
+                        started = True
+                    if timed and left == chunk and not ends_episode:
+                        flags |= _lib.TIMER_STOP
+                        stopped = True
                     dev.step_many_dev(chunk, _lib.ACT_PACKED, ka, ma, _lib.OBS_F32, obs1.data_ptr(), rew1.data_ptr(),
-                                      done1.data_ptr(), out_stride_ticks=0, use_graph=not args.no_graph)
+                                      done1.data_ptr(), out_stride_ticks=0, use_graph=flags)
                 launches += chunk
             elif prepare:
                 launches += 1
@@ -333,8 +346,10 @@ def main(argv=None):
                 launches += 1
             t += chunk
             left -= chunk
-            if t % EPISODE_TICKS == 0 and not prepare:
+            if ends_episode and not prepare:
                 dev.reset_philox_dev(seed=99, done_only=True)        # zero_start_prob = 1: every env back to the start line
+        if timed and not stopped:
+            dev.timer_mark()
         return launches
 
     def barrier():
@@ -344,14 +359,20 @@ def main(argv=None):
             dist.barrier()
 
     def measure(mode, steps, warmup):
-        run_ticks(mode, warmup, 0, prepare=True)           # instantiate + upload every graph the two sequences replay
+        # Preparation (untimed): instantiate + upload every graph the two sequences replay, and replay them ONCE with the env
+        # state saved and restored around it, so that neither the warm-up nor the timed region pays a first-replay cost (kernel
+        # code objects, the graph's packets, the TLB entries of the action slabs) - in production a graph is replayed thousands
+        # of times.  The env state the W warm-up ticks start from is the state before this preparation.
+        run_ticks(mode, warmup, 0, prepare=True)
         run_ticks(mode, steps, warmup, prepare=True)
+        dev.snapshot_state()
         run_ticks(mode, warmup, 0)
+        run_ticks(mode, steps, warmup)
+        dev.restore_state()
+        run_ticks(mode, warmup, 0)                # the W untimed warm-up ticks
         barrier()
         t0 = time.perf_counter()
-        dev.timer_start()                         # HIP events on the stream the kernels are launched on
-        launches = run_ticks(mode, steps, warmup)
-        dev.timer_mark()
+        launches = run_ticks(mode, steps, warmup, timed=True)   # EXACTLY `steps` ticks; HIP events on the launch stream around them
         dsync()                                   # the ONE synchronisation that ends the timed region (device-wide: covers the handle's stream)
         own = time.perf_counter() - t0
         ev_ms = dev.timer_elapsed()               # both events have completed: no further wait

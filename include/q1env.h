@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define Q1ENV_ABI_VERSION 1
+#define Q1ENV_ABI_VERSION 2
 
 typedef enum q1env_status {
     Q1ENV_OK = 0,
@@ -62,6 +62,10 @@ typedef struct q1env_config {
     double key_press_delay;       /* env.py:118                                                  */
     int64_t env_index_base;       /* global index of this shard's env 0; keys the counter RNG so
                                      results do not depend on how the batch is split over GPUs  */
+    int32_t legacy_promotion;     /* env.py:230 `np.float32(720) * time_delta`: 0 = float32 product (NumPy >= 2, NEP 50: what
+                                     the golden fixtures pin), 1 = float64 product (the NumPy 1.18.2 of requirements.txt:33).
+                                     Identical for time_delta = 1/72; 7.6e-9 relative apart for 0.014, 6e-14 for params.yml's dt */
+    int32_t reserved0;            /* must be 0 */
 } q1env_config;
 
 /* Action layouts accepted by step/rollout/decode.  A = num_keys + (allow_yaw ? 1 : 0),
@@ -153,8 +157,12 @@ int q1env_step_host(q1env_t* env, int action_format, const void* act_a, const vo
 /* `ticks` consecutive single-tick launches with tick-major inputs/outputs ([ticks][N]... ; outputs may be
  * NULL).  use_graph = 1 replays them from a cached hipGraph (launch-bound regime; up to 8 graphs are cached per handle,
  * keyed by every argument); use_graph = 2 only captures and instantiates that graph (no launch, state untouched) so that a
- * later use_graph = 1 call with the same arguments pays no instantiation.  out_stride_ticks = 0
- * makes every tick overwrite the same output slab (ring of 1), 1 = tick-major slabs. */
+ * later use_graph = 1 call with the same arguments pays no instantiation.  Adding Q1ENV_TIMER_START (4) / Q1ENV_TIMER_STOP (8)
+ * to use_graph 0 or 1 records the handle's start / stop timer event immediately before / after the launches inside this call
+ * (read the time with q1env_timer_elapsed): the same bracket as q1env_timer_start / q1env_timer_mark without two more calls
+ * across the ABI.  out_stride_ticks = 0 makes every tick overwrite the same output slab (ring of 1), 1 = tick-major slabs. */
+#define Q1ENV_TIMER_START 4
+#define Q1ENV_TIMER_STOP 8
 int q1env_step_many(q1env_t* env, int ticks, int action_format, const void* act_a_dev, const void* act_b_dev,
                     int obs_format, void* obs_dev, float* reward_dev, uint8_t* done_dev,
                     int out_stride_ticks, int use_graph);
@@ -199,13 +207,30 @@ int q1phys_apply_host(int device, int64_t n, const double* yaw, const double* pi
                       const double* fmove, const double* smove, const uint8_t* button2, const double* time_delta,
                       const double* z_pos, const float* vel, const uint8_t* on_ground, const uint8_t* jump_released,
                       double* out_z_pos, float* out_vel, uint8_t* out_on_ground, uint8_t* out_jump_released);
+/* The same for a float64 velocity (vel: double[n][3]).  The reference's arithmetic follows the dtype of PlayerState.vel:
+ * the env stores float32 (friction speed, the +270 jump add and the store are float32), but PlayerState.from_df
+ * (phys.py:168-170, the demo-analysis path of analyse.py:102-118) yields float64 and then nothing is rounded to float32. */
+int q1phys_apply_host_f64(int device, int64_t n, const double* yaw, const double* pitch, const double* roll,
+                          const double* fmove, const double* smove, const uint8_t* button2, const double* time_delta,
+                          const double* z_pos, const double* vel, const uint8_t* on_ground, const uint8_t* jump_released,
+                          double* out_z_pos, double* out_vel, uint8_t* out_on_ground, uint8_t* out_jump_released);
+
+/* Page-locked host memory for arrays passed to the *_host entry points (any host pointer is accepted there; arrays from
+ * here are copied by direct DMA instead of the runtime's staged pageable path - at 1 M envs a tick moves 98 MB).  NULL on
+ * failure (q1env_last_error says why).  Batches of at most 16 384 envs are packed through the handle's own pinned staging
+ * instead (one copy each way), so small callers need not bother. */
+void* q1env_host_alloc(uint64_t bytes);
+int   q1env_host_free(void* p);
 
 /* ---- policy-side glue for a GPU-resident sampler loop ------------------------------------------
  * Counterpart of the reference's TF action distribution `Q1PhysActionDist` (q1physrl/action_dist.py:46-243):
  * one row of policy-network outputs per env -> a sampled action in the PACKED layout q1env_step consumes, plus
  * its log-probability.  logits: float[N][row_stride] device, row = num_keys x (logit0, logit1) then (mean, log_std)
- * of the CDF-squashed Gaussian over (-action_range, action_range).  keys uint8[N], mouse float[N], logp float[N]
- * (logp may be NULL).  deterministic != 0: arg-max keys and the squashed mean (action_dist.py:84-89).
+ * of the CDF-squashed Gaussian over (-action_range, action_range); with Config.discrete_yaw_steps = S > 0 the mouse child is
+ * Discrete(2S+1) (env.py:216-219; ModelCatalog's Categorical, action_dist.py:221-222) and the row ends with its 2S+1 logits
+ * instead - the sampled step index 0..2S is then what `mouse` holds (as a float: the packed layout's mouse slot).  With
+ * allow_yaw = False the row is the key pairs only.  keys uint8[N], mouse float[N], logp float[N]
+ * (logp may be NULL).  deterministic != 0: arg-max keys / arg-max step and the squashed mean (action_dist.py:84-89).
  * Randomness: Philox keyed by (seed, global env index, counter + (counter_dev ? *counter_dev : 0)). Asynchronous. */
 int q1env_policy_sample(q1env_t* env, const float* logits_dev, int row_stride, uint64_t seed, uint64_t counter,
                         const uint64_t* counter_dev, int deterministic, uint8_t* keys_dev, float* mouse_dev, float* logp_dev);
@@ -251,7 +276,7 @@ int q1env_sample_step(q1env_t* env, const float* logits_dev, int row_stride, uin
  * (q1physrl_amd.policy.FusedPolicyForward builds the image).
  * All three layers run on the matrix cores with float16 weights and float32 accumulation; layer 1 takes the observations and its
  * bias split into two float16 each (hi + lo, 22 mantissa bits), b2 / b3 and tanh are float32, hidden activations are rounded to
- * float16.  1 <= out_dim <= 10.  Inference only (sampler loop); the learner keeps its float32 torch modules. */
+ * float16.  1 <= out_dim <= 32 (one 32-row output tile: 10 = continuous-mouse policy, 2K + 2S+1 = discrete-mouse policy, 1 = value).  Inference only (sampler loop); the learner keeps its float32 torch modules. */
 int q1env_policy_forward(q1env_t* env, const float* obs_dev, const float* w1_dev, const float* b1_dev, const uint16_t* w23_image_dev,
                          const float* b2_dev, const float* b3_dev, int out_dim, float* out_dev);
 

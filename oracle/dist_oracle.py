@@ -56,6 +56,21 @@ def key_logprobs(l0, l1):
     return l0 - lse, l1 - lse
 
 
+def categorical_lse(lg):
+    m = lg.max(axis=1)
+    return m + np.log(np.exp(lg - m[:, None]).sum(axis=1))
+
+
+def categorical_terms(lg, lg_old=None):
+    """log-probabilities, entropy and (with lg_old) KL(old || new) of RLlib's Categorical over the rows of lg."""
+    lp = lg - categorical_lse(lg)[:, None]
+    ent = -(np.exp(lp) * lp).sum(axis=1)
+    if lg_old is None:
+        return lp, ent, None
+    lpo = lg_old - categorical_lse(lg_old)[:, None]
+    return lp, ent, (np.exp(lpo) * (lpo - lp)).sum(axis=1)
+
+
 def sample_from_philox(cfg, logits, seed, genv, counter, deterministic=False):
     """What q1env_policy_sample produces for these logits (float64 restatement of policy_sample_kernel)."""
     from . import philox as PH
@@ -76,6 +91,23 @@ def sample_from_philox(cfg, logits, seed, genv, counter, deterministic=False):
         keys |= bit.astype(np.uint8) << j
         lp0, lp1 = key_logprobs(l0, l1)
         logp += np.where(bit, lp1, lp0)
+    if not cfg.allow_yaw:
+        return keys, np.zeros(n), logp, margin
+    if cfg.discrete_yaw_steps != -1:              # Categorical over 2S+1 steps: inverse CDF on the uniform of word a[2]
+        m = 2 * cfg.discrete_yaw_steps + 1
+        lg = logits[:, 2 * k:2 * k + m].astype(np.float64)
+        lse = categorical_lse(lg)
+        prob = np.exp(lg - lse[:, None])
+        cdf = np.cumsum(prob, axis=1)
+        if deterministic:
+            choice = np.argmax(lg, axis=1)
+        else:
+            u = (a[2] >> np.uint64(8)).astype(np.float64) / 16777216.0
+            choice = np.minimum((cdf <= u[:, None]).sum(axis=1), m - 1)
+            edges = np.concatenate([np.zeros((n, 1)), cdf[:, :-1]], axis=1)
+            margin = np.minimum(margin, np.min(np.abs(edges[:, 1:] - u[:, None]), axis=1))
+        logp += lg[np.arange(n), choice] - lse
+        return keys, choice.astype(np.float64), logp, margin
     low, high = -float(np.float32(cfg.action_range)), float(np.float32(cfg.action_range))
     mean, log_std = clip_params(logits[:, 2 * k].astype(np.float64), logits[:, 2 * k + 1].astype(np.float64))
     if deterministic:

@@ -96,8 +96,13 @@ def fix_actions(actions) -> np.ndarray:
     return np.array([[np.ravel(c)[0] for c in row] for row in actions], dtype=F64)
 
 
-def max_yaw_delta(cfg) -> F32:
-    """env.py:230 under NumPy 2 (NEP 50): float32(720) * python-float -> float32 product."""
+def max_yaw_delta(cfg, legacy: bool = False):
+    """env.py:230 `_MAX_YAW_SPEED * time_delta`.  Under NumPy 2 (NEP 50) float32(720) * python-float is a float32 product (what
+    the G1-G5 fixtures pin); under the NumPy 1.18.2 the reference's requirements.txt pins it is a float64 product
+    (legacy=True; pinned by tests/golden/g3_legacy_promotion_*.npz, generated with the reference's module constant patched to
+    float64, which is what value-based promotion did)."""
+    if legacy:
+        return F64(720.0) * F64(cfg.time_delta)
     return MAX_YAW_SPEED * F32(cfg.time_delta)
 
 
@@ -111,10 +116,10 @@ def decode(cfg, dec, actions: np.ndarray, z_vel: np.ndarray, t_rem: np.ndarray):
     if not cfg.allow_yaw:
         dyaw = np.zeros(a.shape[0], dtype=F64)
     elif cfg.discrete_yaw_steps == -1:
-        dyaw = (a[:, K] * F64(max_yaw_delta(cfg))) / F64(cfg.action_range)
+        dyaw = (a[:, K] * F64(max_yaw_delta(cfg, dec.get("legacy", False)))) / F64(cfg.action_range)
     else:
         s = cfg.discrete_yaw_steps
-        dyaw = ((a[:, K] - s) * F64(max_yaw_delta(cfg))) / F64(s)
+        dyaw = ((a[:, K] - s) * F64(max_yaw_delta(cfg, dec.get("legacy", False)))) / F64(s)
 
     now = (F64(cfg.time_limit) - t_rem.astype(F64))[:, None]                     # env.py:241,246
     may_press = now >= (dec["last_press"] + F64(cfg.key_press_delay))
@@ -215,6 +220,54 @@ def phys_apply(yaw, fmove, smove, jump, dt: float, st: dict) -> dict:
     return {"z_pos": z, "vel": new_vel, "on_ground": og, "jump_released": jr}
 
 
+def phys_apply_general(yaw, pitch, roll, fmove, smove, jump, dt, z_pos, vel, on_ground, jump_released):
+    """phys.apply (phys.py:184-197) for ANY velocity dtype and general pitch / roll (phys.py:56-66), per-element time_delta:
+    float32 vel follows the env path above; float64 vel (PlayerState.from_df, phys.py:168-170) keeps every intermediate float64
+    (np.linalg.norm, the +270 add and the store are all float64 then)."""
+    vt = vel.dtype.type
+    dt = np.asarray(dt, dtype=F64)
+    k = np.pi
+    ry, rp, rr = (np.asarray(yaw, F64) * k) / 180., (np.asarray(pitch, F64) * k) / 180., (np.asarray(roll, F64) * k) / 180.
+    sy, cy, sp, cp, sr, cr = np.sin(ry), np.cos(ry), np.sin(rp), np.cos(rp), np.sin(rr), np.cos(rr)
+    m00, m01 = cp * cy, ((-1 * sr) * sp) * cy + (-1 * cr) * (-sy)
+    m10, m11 = cp * sy, ((-1 * sr) * sp) * sy + (-1 * cr) * cy
+    f, m = np.asarray(fmove).astype(F64), np.asarray(smove).astype(F64)
+    wx = (F64(0) + m00 * f) + m01 * m
+    wy = (F64(0) + m10 * f) + m11 * m
+    wlen = np.sqrt(wx * wx + wy * wy)
+    has_wish = wlen > 0
+    with np.errstate(invalid="ignore", divide="ignore"):
+        dx = np.where(has_wish, wx / wlen, wx)
+        dy = np.where(has_wish, wy / wlen, wy)
+        wish_speed = np.minimum(F64(MAX_SPEED), wlen)
+        vx, vy = vel[:, 0], vel[:, 1]
+        speed = np.sqrt(vx * vx + vy * vy)                          # in vel's dtype (np.linalg.norm)
+        control = np.maximum(speed, vt(100))
+        new_speed = np.maximum(F64(0), speed.astype(F64) - (dt * control.astype(F64)) * F64(FRICTION))
+        ratio = new_speed / speed.astype(F64)
+    moving = speed > 0
+    fx = np.where(moving, vx.astype(F64) * ratio, vx.astype(F64))
+    fy = np.where(moving, vy.astype(F64) * ratio, vy.astype(F64))
+    hx = np.where(on_ground, fx, vx.astype(F64))
+    hy = np.where(on_ground, fy, vy.astype(F64))
+    cur = (F64(0) + hx * dx) + hy * dy
+    capped = np.where((wish_speed > 30) & ~on_ground, F64(30), wish_speed)
+    add = np.maximum(F64(0), capped - cur)
+    acc = np.minimum((F64(ACCELERATE) * dt) * wish_speed, add)
+    out = np.empty_like(vel)
+    out[:, 0] = (hx + acc * dx).astype(vt)
+    out[:, 1] = (hy + acc * dy).astype(vt)
+    jump = np.asarray(jump, dtype=bool)
+    jr = np.asarray(jump_released, dtype=bool) | ~jump
+    do_jump = np.asarray(on_ground, dtype=bool) & jump & jr
+    vz = vel[:, 2] + np.where(do_jump, vt(270), vt(0))
+    vz = (vz.astype(F64) - F64(GRAVITY) * dt).astype(vt)
+    z = np.asarray(z_pos, F64) + dt * vz.astype(F64)
+    landed = z < F64(FLOOR_HEIGHT)
+    out[:, 2] = np.where(landed, vt(0), vz)
+    return np.where(landed, F64(FLOOR_HEIGHT), z), out, landed, jr
+
+
 # ------------------------------------------------------------------------------------------ observation
 def obs_scale(cfg):
     return np.array([cfg.time_limit, 90., 100, 200, 200, 200], dtype=F64)      # env.py:294-296
@@ -236,10 +289,11 @@ class OracleVectorEnv:
     including the one-argument uniform(x) == uniform(low=x, high=1.0) quirk.
     """
 
-    def __init__(self, cfg):
+    def __init__(self, cfg, legacy_promotion: bool = False):
         if isinstance(cfg, dict):
             cfg = OracleConfig(**{k: (tuple(v) if isinstance(v, list) else v) for k, v in cfg.items()})
         self.cfg = cfg
+        self.legacy_promotion = bool(legacy_promotion)
         self.n = cfg.num_envs
         self.step_num = 0
         self.vector_reset()
@@ -305,6 +359,7 @@ class OracleVectorEnv:
             self.st["vel"][:, 2] = 0
             self.st["z_pos"][:] = 100
         self.dec["yaw"] = self.yaw
+        self.dec["legacy"] = getattr(self, "legacy_promotion", False)
         yaw, smove, fmove, jump = decode(cfg, self.dec, actions, self.st["vel"][:, 2], self.t_rem)
         self.yaw = yaw
         self.last_cmd = (smove, fmove, jump)

@@ -52,6 +52,54 @@ def ppo_loss(new_logits, new_value, b, action_range, clip_param, vf_clip_param, 
     return float(np.mean(-sur + kl_coeff * kl + vf_loss_coeff * vf - entropy_coeff * ent)), float(kl.mean()), float(ent.mean())
 
 
+def ppo_loss_grad_discrete(new_logits, new_value, b, steps, clip_param, vf_clip_param, vf_loss_coeff, entropy_coeff, kl_coeff,
+                           num_keys=4):
+    """ppo_loss_grad for a DISCRETE mouse (Config.discrete_yaw_steps = steps): the row is num_keys x (logit0, logit1) then the
+    2*steps+1 logits of RLlib's Categorical; b["mouse"] holds the chosen step index.  Same closed forms as the kernel's
+    yaw_mode == 2 branch: d logp / d l_j = [j == a] - p_j, d H / d l_j = -p_j (log p_j + H), d KL / d l_j = p_j - po_j."""
+    L, O = new_logits.astype(np.float64), b["old_logits"].astype(np.float64)
+    n, k2, m = L.shape[0], 2 * num_keys, 2 * steps + 1
+    sig = lambda d: 1.0 / (1.0 + np.exp(-d))
+    softplus = lambda z: np.maximum(z, 0.0) + np.log1p(np.exp(-np.abs(z)))
+    logp, ent, kl = np.zeros(n), np.zeros(n), np.zeros(n)
+    dlp, dh, dk = np.zeros_like(L), np.zeros_like(L), np.zeros_like(L)
+    for k in range(num_keys):
+        d, d_o = L[:, 2 * k + 1] - L[:, 2 * k], O[:, 2 * k + 1] - O[:, 2 * k]
+        pn, po = sig(d), sig(d_o)
+        a = b["keys"][:, k].astype(np.float64)
+        logp -= np.where(a != 0, softplus(-d), softplus(d))
+        ent += softplus(d) - d * pn
+        kl += po * (softplus(-d) - softplus(-d_o)) + (1 - po) * (softplus(d) - softplus(d_o))
+        for arr, g in ((dlp, a - pn), (dh, -d * pn * (1 - pn)), (dk, pn - po)):
+            arr[:, 2 * k + 1], arr[:, 2 * k] = g, -g
+    lp, h_c, kl_c = DO.categorical_terms(L[:, k2:k2 + m], O[:, k2:k2 + m])
+    lpo = O[:, k2:k2 + m] - DO.categorical_lse(O[:, k2:k2 + m])[:, None]
+    act = b["mouse"].reshape(-1).astype(np.int64)
+    logp += lp[np.arange(n), act]
+    ent += h_c
+    kl += kl_c
+    onehot = np.zeros((n, m))
+    onehot[np.arange(n), act] = 1.0
+    dlp[:, k2:k2 + m] = onehot - np.exp(lp)
+    dh[:, k2:k2 + m] = -np.exp(lp) * (lp + h_c[:, None])
+    dk[:, k2:k2 + m] = np.exp(lp) - np.exp(lpo)
+    ratio = np.exp(logp - b["logp"])
+    s1, s2 = b["adv"] * ratio, b["adv"] * np.clip(ratio, 1 - clip_param, 1 + clip_param)
+    sur = np.minimum(s1, s2)
+    c_lp = np.where(s1 <= s2, -s1, 0.0)
+    v, vo, vt = new_value.astype(np.float64), b["value"].astype(np.float64), b["vtarg"].astype(np.float64)
+    dv = v - vo
+    vc = vo + np.clip(dv, -vf_clip_param, vf_clip_param)
+    e1, e2 = (v - vt) ** 2, (vc - vt) ** 2
+    vf = np.maximum(e1, e2)
+    dvf = np.where(e1 >= e2, 2 * (v - vt), np.where(np.abs(dv) <= vf_clip_param, 2 * (vc - vt), 0.0))
+    dlogits = (c_lp[:, None] * dlp + kl_coeff * dk - entropy_coeff * dh) / n
+    total = -sur + kl_coeff * kl + vf_loss_coeff * vf - entropy_coeff * ent
+    stats = {"entropy": ent.mean(), "kl": kl.mean(), "policy_loss": (-sur).mean(), "total_loss": total.mean(), "vf_loss": vf.mean(),
+             "logp": logp}
+    return dlogits, vf_loss_coeff * dvf / n, stats
+
+
 def ppo_loss_grad(new_logits, new_value, b, action_range, clip_param, vf_clip_param, vf_loss_coeff, entropy_coeff, kl_coeff):
     """float64 restatement of q1env_ppo_loss_grad (q1physrl_amd/csrc/q1env.hip::ppo_loss_grad_kernel): the closed-form derivatives
     of ppo_loss above with respect to (new_logits, new_value), and the five statistics.  b["keys"] is (B, 4) 0/1.

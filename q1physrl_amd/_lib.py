@@ -10,9 +10,10 @@ import numpy as np
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "libq1env.so")
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 ACT_F64_ROWS, ACT_F32_ROWS, ACT_PACKED, ACT_RANDOM = 0, 1, 2, 3
 OBS_F64, OBS_F32 = 0, 1
+TIMER_START, TIMER_STOP = 4, 8     # q1env_step_many use_graph flags: record the handle's start / stop timer event around the launches
 FLAG_ON_GROUND, FLAG_JUMP_RELEASED, FLAG_ZERO_START, FLAG_LAST_KEY0 = 1, 2, 4, 8
 
 
@@ -27,7 +28,8 @@ class Q1Config(C.Structure):          # q1env_config
                 ("zero_start_prob", C.c_double), ("initial_yaw_lo", C.c_double), ("initial_yaw_hi", C.c_double),
                 ("max_initial_speed", C.c_double), ("time_delta", C.c_double), ("time_limit", C.c_double),
                 ("action_range", C.c_double), ("fmove_max", C.c_double), ("smove_max", C.c_double),
-                ("key_press_delay", C.c_double), ("env_index_base", C.c_int64)]
+                ("key_press_delay", C.c_double), ("env_index_base", C.c_int64),
+                ("legacy_promotion", C.c_int32), ("reserved0", C.c_int32)]
 
 
 class Q1State(C.Structure):           # q1env_state
@@ -73,6 +75,9 @@ _SIGNATURES = {
     "q1env_decode_host": (C.c_int, [_P, C.c_int, _P, _P, _P, _P, _P, _P, _P, _P]),
     "q1env_decoder_reset_host": (C.c_int, [_P, C.c_int64, _P, _P]),
     "q1phys_apply_host": (C.c_int, [C.c_int, C.c_int64] + [_P] * 15),
+    "q1phys_apply_host_f64": (C.c_int, [C.c_int, C.c_int64] + [_P] * 15),
+    "q1env_host_alloc": (C.c_void_p, [C.c_uint64]),
+    "q1env_host_free": (C.c_int, [_P]),
     "q1env_policy_sample": (C.c_int, [_P, _P, C.c_int, C.c_uint64, C.c_uint64, _P, C.c_int, _P, _P, _P]),
     "q1env_gae": (C.c_int, [_P, C.c_int, _P, _P, _P, C.c_float, C.c_float, _P, _P]),
     "q1env_snapshot_state": (C.c_int, [_P]),
@@ -124,3 +129,78 @@ def ptr(a):
         return None
     assert a.flags["C_CONTIGUOUS"], "array must be C-contiguous"
     return a.ctypes.data_as(C.c_void_p)
+
+
+# ---- page-locked host arrays -------------------------------------------------------------------------------------------------
+PACK_MAX_ENVS = 16384      # q1env.hip: batches up to this size are packed through the handle's own pinned staging
+
+
+class _PinnedBlock:
+    """Owner of one q1env_host_alloc block; NumPy arrays made from it keep it alive through `.base`, and when the last of them is
+    garbage-collected the block returns to the pool (so callers still own what they were handed, as with np.empty)."""
+    __slots__ = ("ptr", "nbytes", "pool", "__array_interface__")
+
+    def __init__(self, pool, ptr, nbytes):
+        self.ptr, self.nbytes, self.pool = ptr, nbytes, pool
+        self.__array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (ptr, False), "version": 3}
+
+    def __del__(self):
+        try:
+            self.pool._release(self.ptr, self.nbytes)
+        except Exception:   # noqa: BLE001 - interpreter shutdown
+            pass
+
+
+class PinnedPool:
+    """np.empty for page-locked memory: size classes (powers of two >= 4 KiB), freed blocks are cached (up to `cache_bytes`) because
+    hipHostMalloc costs milliseconds for the 48 MB observation block of a million envs."""
+
+    def __init__(self, cache_bytes=2 << 30):
+        self._free, self._cached, self._cap = {}, 0, int(cache_bytes)
+
+    def empty(self, shape, dtype):
+        dtype = np.dtype(dtype)
+        need = max(int(np.prod(shape)) * dtype.itemsize, 1)
+        size = 4096
+        while size < need:
+            size *= 2
+        stack = self._free.get(size)
+        if stack:
+            ptr = stack.pop()
+            self._cached -= size
+        else:
+            ptr = load().q1env_host_alloc(size)
+            if not ptr:
+                raise Q1EnvError(f"q1env_host_alloc({size}) failed: {load().q1env_last_error().decode(errors='replace')}")
+        raw = np.asarray(_PinnedBlock(self, ptr, size))
+        return raw[:need].view(dtype).reshape(shape)
+
+    def _release(self, ptr, size):
+        if self._cached + size <= self._cap:
+            self._free.setdefault(size, []).append(ptr)
+            self._cached += size
+        elif _lib is not None:
+            _lib.q1env_host_free(C.c_void_p(ptr))
+
+    def trim(self):
+        for size, stack in self._free.items():
+            while stack:
+                load().q1env_host_free(C.c_void_p(stack.pop()))
+        self._cached = 0
+
+
+_pool = None
+
+
+def pinned_pool():
+    global _pool
+    if _pool is None:
+        _pool = PinnedPool()
+    return _pool
+
+
+def host_empty(shape, dtype, n_envs):
+    """An uninitialised host array for a *_host entry point: page-locked for batches the library does not pack itself."""
+    if n_envs > PACK_MAX_ENVS:
+        return pinned_pool().empty(shape, dtype)
+    return np.empty(shape, dtype=dtype)

@@ -10,6 +10,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <string>
 #include <vector>
@@ -269,8 +270,37 @@ decoder_reset_kernel(Params p, StatePtrs s, int count, const int32_t* idx, const
 //            x = clip(NormalCDF(u / S), 1e-6, 1 - 1e-6) * (high - low) + low,  S = 0.5 * 1.8137  (action_dist.py:151,186-192)
 //            logp = N(mean,std).logpdf(u') - N(0,S).logpdf(u') - log(high - low), u' = S * ndtri((x - low)/(high - low))
 //            (action_dist.py:91-96,180-184,194-196)
-// Randomness: Philox stream 3 keyed by (seed, global env, counter): r[0] low bits -> one uniform per key, r[2],r[3] -> Box-Muller.
+// Discrete mouse (Config.discrete_yaw_steps = S > 0, env.py:216-219): the Tuple's last child is Discrete(2S+1), which the reference
+// takes through ModelCatalog.get_action_dist (action_dist.py:221-222) -> RLlib's Categorical over M = 2S+1 logits that follow the
+// key pairs in the row.  Sampling: inverse CDF of softmax(logits) on one uniform; deterministic: first arg-max (tf.argmax);
+// logp = logit[choice] - logsumexp.  The action leaves as the step index in the packed layout's float mouse slot, which is what
+// the decoder's discrete branch consumes ((a - S) * max_yaw_delta / S, env.py:238).
+// Randomness: Philox stream 3 keyed by (seed, global env, counter): r[0] low bits -> one uniform per key, r[2],r[3] -> Box-Muller
+// (r[2] alone -> the categorical's uniform).
 constexpr uint32_t STREAM_POLICY = 3;
+
+__device__ __forceinline__ void sample_categorical(const float* __restrict__ lg, int m, uint32_t rnd, int deterministic,
+                                                   int& choice, float& logp) {
+    float mx = lg[0];
+    int arg = 0;
+    for (int j = 1; j < m; ++j) {
+        const float v = lg[j];
+        if (v > mx) { mx = v; arg = j; }
+    }
+    float sum = 0.0f;
+    for (int j = 0; j < m; ++j) sum += expf(lg[j] - mx);
+    choice = arg;
+    if (!deterministic) {
+        const float target = ((float)(rnd >> 8) * (1.0f / 16777216.0f)) * sum;     // u in [0, 1) scaled to the unnormalised mass
+        float acc = 0.0f;
+        choice = m - 1;
+        for (int j = 0; j < m; ++j) {
+            acc += expf(lg[j] - mx);
+            if (acc > target) { choice = j; break; }
+        }
+    }
+    logp = (lg[choice] - mx) - logf(sum);
+}
 
 __device__ __forceinline__ void sample_action(const Params& p, const float* __restrict__ row, uint64_t seed, uint64_t genv,
                                               uint64_t counter, int deterministic, uint32_t& keys, float& mouse, float& logp) {
@@ -328,6 +358,12 @@ __device__ __forceinline__ void sample_action(const Params& p, const float* __re
         const float zq = ub / S;
         const float lp_sq = -0.5f * zq * zq - logf(S) - 0.9189385332046727f;            // N(0, S).logpdf(ub)
         logp += lp_pi - (lp_sq + logf(high - low));
+    } else if (p.yaw_mode == 2) {
+        int choice;
+        float lpc;
+        sample_categorical(row + 2 * p.num_keys, 2 * (int)p.yaw_steps + 1, r[2], deterministic, choice, lpc);
+        mouse = (float)choice;
+        logp += lpc;
     }
 }
 
@@ -418,6 +454,32 @@ ppo_loss_grad_kernel(Params p, int batch, const float* __restrict__ logits, cons
         }
         float dlp_m = 0.0f, dlp_s = 0.0f, dh_m = 0.0f, dh_s = 0.0f, dk_m = 0.0f, dk_s = 0.0f;
         bool in_m = false, in_s = false;
+        // discrete mouse: Categorical over M = 2S+1 logits (see sample_categorical):
+        //   logp += l_a - lse;  H_c = -sum p_j log p_j;  KL_c = sum po_j (log po_j - log p_j)
+        //   d logp / d l_j = [j == a] - p_j;  d H_c / d l_j = -p_j (log p_j + H_c);  d KL_c / d l_j = p_j - po_j
+        const int cat_m = p.yaw_mode == 2 ? 2 * (int)p.yaw_steps + 1 : 0;
+        float cat_lse = 0.0f, cat_lse_o = 0.0f, cat_h = 0.0f;
+        int cat_a = 0;
+        if (p.yaw_mode == 2) {
+            const float* l = row + 2 * nk;
+            const float* lo = old + 2 * nk;
+            float mx = l[0], mxo = lo[0];
+            for (int j = 1; j < cat_m; ++j) { mx = fmaxf(mx, l[j]); mxo = fmaxf(mxo, lo[j]); }
+            float sn = 0.0f, so = 0.0f;
+            for (int j = 0; j < cat_m; ++j) { sn += expf(l[j] - mx); so += expf(lo[j] - mxo); }
+            cat_lse = mx + logf(sn);
+            cat_lse_o = mxo + logf(so);
+            cat_a = min(max((int)mouse[i], 0), cat_m - 1);
+            logp += l[cat_a] - cat_lse;
+            float kc = 0.0f;
+            for (int j = 0; j < cat_m; ++j) {
+                const float lpn = l[j] - cat_lse, lpo = lo[j] - cat_lse_o;
+                cat_h -= expf(lpn) * lpn;
+                kc += expf(lpo) * (lpo - lpn);
+            }
+            ent += cat_h;
+            kl += kc;
+        }
         if (p.yaw_mode == 1) {
             const float S = 0.5f * 1.8137f, low = -p.action_range_f32, high = p.action_range_f32;
             const float m_raw = row[2 * nk], s_raw = row[2 * nk + 1];
@@ -454,7 +516,16 @@ ppo_loss_grad_kernel(Params p, int batch, const float* __restrict__ logits, cons
             g[2 * nk] = in_m ? (c_lp * dlp_m + klc * dk_m - ent_coeff * dh_m) * inv_b : 0.0f;
             g[2 * nk + 1] = in_s ? (c_lp * dlp_s + klc * dk_s - ent_coeff * dh_s) * inv_b : 0.0f;
         }
-        for (int c = 2 * nk + (p.yaw_mode == 1 ? 2 : 0); c < row_stride; ++c) g[c] = 0.0f;
+        if (p.yaw_mode == 2) {
+            const float* l = row + 2 * nk;
+            const float* lo = old + 2 * nk;
+            for (int j = 0; j < cat_m; ++j) {
+                const float lpn = l[j] - cat_lse, pn = expf(lpn), po = expf(lo[j] - cat_lse_o);
+                const float dlp_j = (j == cat_a ? 1.0f : 0.0f) - pn, dh_j = -pn * (lpn + cat_h), dk_j = pn - po;
+                g[2 * nk + j] = (c_lp * dlp_j + klc * dk_j - ent_coeff * dh_j) * inv_b;
+            }
+        }
+        for (int c = 2 * nk + (p.yaw_mode == 1 ? 2 : cat_m); c < row_stride; ++c) g[c] = 0.0f;
         dvalue[i] = vf_coeff * dvf * inv_b;
         st[0] = ent; st[1] = kl; st[2] = -surr; st[3] = -surr + klc * kl + vf_coeff * vf - ent_coeff * ent; st[4] = vf;
     }
@@ -614,18 +685,19 @@ selftest_division_kernel(uint64_t n, uint64_t seed, double c_extra0, double c_ex
     if (bad3) atomicAdd(&counts[3], (unsigned long long)bad3);
 }
 
-// Stateless phys.apply (phys.py:184-197) with general pitch / roll (phys.py:56-66), all float64 trig.
+// Stateless phys.apply (phys.py:184-197) with general pitch / roll (phys.py:56-66), all float64 trig.  VT = dtype of vel:
+// float (the env's storage) or double (PlayerState.from_df, phys.py:168-170: nothing is rounded to float32 then).
+template <typename VT>
 __global__ void __launch_bounds__(256)
 phys_apply_kernel(int n, const double* yaw, const double* pitch, const double* roll, const double* fmove,
                   const double* smove, const uint8_t* button2, const double* time_delta, const double* z_pos,
-                  const float* vel, const uint8_t* on_ground, const uint8_t* jump_released,
-                  double* out_z, float* out_vel, uint8_t* out_og, uint8_t* out_jr) {
+                  const VT* vel, const uint8_t* on_ground, const uint8_t* jump_released,
+                  double* out_z, VT* out_vel, uint8_t* out_og, uint8_t* out_jr) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    Env e{};
-    e.vx = vel[3 * (size_t)i]; e.vy = vel[3 * (size_t)i + 1]; e.vz = vel[3 * (size_t)i + 2];
-    e.z = z_pos[i];
-    e.flags = (on_ground[i] ? FLAG_ON_GROUND : 0u) | (jump_released[i] ? FLAG_JUMP_RELEASED : 0u);
+    VT vx = vel[3 * (size_t)i], vy = vel[3 * (size_t)i + 1], vz = vel[3 * (size_t)i + 2];
+    double z = z_pos[i];
+    uint32_t flags = (on_ground[i] ? FLAG_ON_GROUND : 0u) | (jump_released[i] ? FLAG_JUMP_RELEASED : 0u);
     Cmd c;
     c.fmove = fmove[i]; c.smove = smove[i]; c.jump = button2[i] != 0;
     const double k = 3.141592653589793;
@@ -638,11 +710,11 @@ phys_apply_kernel(int n, const double* yaw, const double* pitch, const double* r
     const double m10 = cp * sy;
     const double m11 = ((-1.0 * sr) * sp) * sy + (-1.0 * cr) * cy;
     const double dt = time_delta[i];
-    physics(e, c, m00, m01, m10, m11, dt, 10.0 * dt, 800.0 * dt);
-    out_z[i] = e.z;
-    out_vel[3 * (size_t)i] = e.vx; out_vel[3 * (size_t)i + 1] = e.vy; out_vel[3 * (size_t)i + 2] = e.vz;
-    out_og[i] = (e.flags & FLAG_ON_GROUND) ? 1 : 0;
-    out_jr[i] = (e.flags & FLAG_JUMP_RELEASED) ? 1 : 0;
+    physics_core<VT>(vx, vy, vz, z, flags, c, m00, m01, m10, m11, dt, 10.0 * dt, 800.0 * dt);
+    out_z[i] = z;
+    out_vel[3 * (size_t)i] = vx; out_vel[3 * (size_t)i + 1] = vy; out_vel[3 * (size_t)i + 2] = vz;
+    out_og[i] = (flags & FLAG_ON_GROUND) ? 1 : 0;
+    out_jr[i] = (flags & FLAG_JUMP_RELEASED) ? 1 : 0;
 }
 
 // =========================================================================================== host side
@@ -687,6 +759,8 @@ struct q1env {
     void* snap = nullptr;             // q1env_snapshot_state: a second arena holding a copy of the whole SoA state
     void* stage = nullptr;
     size_t stage_bytes = 0;
+    void* pin = nullptr;              // pinned (page-locked) host staging of the *_host entry points: one DMA each way instead of
+    size_t pin_bytes = 0;             // one staged pageable copy per array
     uint64_t tick_count = 0;          // ticks since create: the counter of the counter-based RNG
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     int num_cus = 256;                // compute units of the device (MI355X in SPX mode: 256)
@@ -719,6 +793,20 @@ static int ensure_stage(q1env* h, size_t bytes) {
     return 0;
 }
 
+static int ensure_pin(q1env* h, size_t bytes) {
+    if (bytes <= h->pin_bytes) return 0;
+    if (h->pin) (void)hipHostFree(h->pin);
+    h->pin = nullptr;
+    h->pin_bytes = 0;
+    HIP_TRY(hipHostMalloc(&h->pin, bytes, hipHostMallocDefault));
+    h->pin_bytes = bytes;
+    return 0;
+}
+
+// Batches up to this many envs go through the handle's pinned staging as ONE block each way (the call count dominates there);
+// larger batches copy every array directly (fast when the caller's arrays are pinned - q1env_host_alloc - as the Python layer's are).
+constexpr size_t PACK_MAX_ENVS = 16384;
+
 static int make_params(const q1env_config& c, Params& p, std::string& why) {
     if (c.num_envs <= 0) { why = "num_envs must be > 0"; return -1; }
     if (!(c.time_delta > 0)) { why = "time_delta must be > 0"; return -1; }
@@ -739,7 +827,10 @@ static int make_params(const q1env_config& c, Params& p, std::string& why) {
     p.dt = c.time_delta;
     p.time_limit = c.time_limit;
     p.key_press_delay = c.key_press_delay;
-    p.yaw_num = (double)(720.0f * (float)c.time_delta);                 // env.py:230: float32 product (NEP 50)
+    // env.py:230 `_MAX_YAW_SPEED * time_delta` = np.float32(720) * python float: a float32 product under NumPy >= 2 (NEP 50, what
+    // the golden fixtures were generated with), a float64 product under the NumPy 1.18.2 the reference pins (requirements.txt:33).
+    // Equal for dt = 1/72 (10.0 either way); differs in the 9th digit for dt = 0.014 and the 14th for params.yml's truncated dt.
+    p.yaw_num = c.legacy_promotion ? 720.0 * c.time_delta : (double)(720.0f * (float)c.time_delta);
     p.yaw_steps = (double)c.discrete_yaw_steps;
     p.yaw_den = (p.yaw_mode == 2) ? p.yaw_steps : c.action_range;       // env.py:236 / 238
     if (p.yaw_mode && !(p.yaw_den > 0)) { why = "action_range must be > 0"; return -1; }
@@ -776,6 +867,74 @@ static void carve(q1env* h) { carve_into(h->arena, (size_t)h->p.n, h->st); }
 
 static size_t arena_bytes(size_t n) {
     return 3 * align_up(n * 4, 256) + 5 * align_up(n * 8, 256) + align_up(n * 32, 256) + align_up(n, 256);
+}
+
+// q1phys_apply_host keeps one scratch context per device (stream, device arena, pinned staging, grown on demand) instead of a
+// hipMalloc / 15 synchronous copies / hipFree per call: analyse.py-style callers invoke phys.apply hundreds of times
+// (hypothetical_delta_speeds, analyse.py:71-118).  Guarded by a mutex: the function is stateless for its callers.
+namespace {
+struct ApplyCtx { hipStream_t stream = nullptr; char* dev = nullptr; char* pin = nullptr; size_t bytes = 0; };
+std::mutex g_apply_mutex;
+ApplyCtx g_apply_ctx[64];
+}
+
+template <typename VT>
+static int phys_apply_host_impl(int device, int64_t n64, const double* yaw, const double* pitch, const double* roll, const double* fmove,
+                                const double* smove, const uint8_t* button2, const double* time_delta, const double* z_pos,
+                                const VT* vel, const uint8_t* on_ground, const uint8_t* jump_released, double* out_z, VT* out_vel,
+                                uint8_t* out_og, uint8_t* out_jr) {
+    if (!yaw || !fmove || !smove || !button2 || !time_delta || !z_pos || !vel || !on_ground || !jump_released || !out_z ||
+        !out_vel || !out_og || !out_jr)
+        return fail(Q1ENV_ERR_INVALID_ARG, "q1phys_apply_host: null argument");
+    if (n64 <= 0 || n64 > (int64_t)1 << 30) return fail(Q1ENV_ERR_INVALID_ARG, "q1phys_apply_host: bad n");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(Q1ENV_ERR_NO_DEVICE, "q1phys_apply_host: no HIP device visible (libq1env has no CPU fallback)");
+    if (device < 0 || device >= ndev || device >= 64) return fail(Q1ENV_ERR_INVALID_ARG, "q1phys_apply_host: bad device index");
+    DeviceGuard guard(device);
+    std::lock_guard<std::mutex> lock(g_apply_mutex);
+    ApplyCtx& cx = g_apply_ctx[device];
+    const size_t n = (size_t)n64;
+    const size_t b8 = align_up(n * 8, 256), b1 = align_up(n, 256), bv = align_up(n * 3 * sizeof(VT), 256);
+    // block layout, inputs then outputs: yaw pitch roll fmove smove dt z | button2 on_ground jump_released | vel || out_z out_vel out_og out_jr
+    const size_t in_bytes = 7 * b8 + 3 * b1 + bv, out_bytes = b8 + bv + 2 * b1, total = in_bytes + out_bytes;
+    if (!cx.stream) HIP_TRY(hipStreamCreateWithFlags(&cx.stream, hipStreamNonBlocking));
+    if (total > cx.bytes) {
+        if (cx.dev) (void)hipFree(cx.dev);
+        if (cx.pin) (void)hipHostFree(cx.pin);
+        cx.dev = nullptr; cx.pin = nullptr; cx.bytes = 0;
+        const size_t want = total + total / 2;
+        HIP_TRY(hipMalloc((void**)&cx.dev, want));
+        HIP_TRY(hipHostMalloc((void**)&cx.pin, want, hipHostMallocDefault));
+        cx.bytes = want;
+    }
+    char* pin = cx.pin;
+    char* d = cx.dev;
+    const size_t o_pitch = b8, o_roll = 2 * b8, o_f = 3 * b8, o_s = 4 * b8, o_dt = 5 * b8, o_z = 6 * b8;
+    const size_t o_b2 = 7 * b8, o_og = o_b2 + b1, o_jr = o_og + b1, o_v = o_jr + b1;
+    const size_t o_oz = in_bytes, o_ov = o_oz + b8, o_oog = o_ov + bv, o_ojr = o_oog + b1;
+    memcpy(pin, yaw, n * 8);
+    if (pitch) memcpy(pin + o_pitch, pitch, n * 8);
+    if (roll) memcpy(pin + o_roll, roll, n * 8);
+    memcpy(pin + o_f, fmove, n * 8); memcpy(pin + o_s, smove, n * 8); memcpy(pin + o_dt, time_delta, n * 8);
+    memcpy(pin + o_z, z_pos, n * 8);
+    memcpy(pin + o_b2, button2, n); memcpy(pin + o_og, on_ground, n); memcpy(pin + o_jr, jump_released, n);
+    memcpy(pin + o_v, vel, n * 3 * sizeof(VT));
+    HIP_TRY(hipMemcpyAsync(d, pin, in_bytes, hipMemcpyHostToDevice, cx.stream));
+    hipLaunchKernelGGL(phys_apply_kernel<VT>, grid_for((int)n, 256), dim3(256), 0, cx.stream, (int)n, (const double*)d,
+                       pitch ? (const double*)(d + o_pitch) : (const double*)nullptr,
+                       roll ? (const double*)(d + o_roll) : (const double*)nullptr, (const double*)(d + o_f),
+                       (const double*)(d + o_s), (const uint8_t*)(d + o_b2), (const double*)(d + o_dt), (const double*)(d + o_z),
+                       (const VT*)(d + o_v), (const uint8_t*)(d + o_og), (const uint8_t*)(d + o_jr), (double*)(d + o_oz),
+                       (VT*)(d + o_ov), (uint8_t*)(d + o_oog), (uint8_t*)(d + o_ojr));
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(pin + in_bytes, d + in_bytes, out_bytes, hipMemcpyDeviceToHost, cx.stream));
+    HIP_TRY(hipStreamSynchronize(cx.stream));
+    memcpy(out_z, pin + o_oz, n * 8);
+    memcpy(out_vel, pin + o_ov, n * 3 * sizeof(VT));
+    memcpy(out_og, pin + o_oog, n);
+    memcpy(out_jr, pin + o_ojr, n);
+    return Q1ENV_OK;
 }
 
 extern "C" {
@@ -848,6 +1007,7 @@ int q1env_destroy(q1env_t* h) {
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->stage) (void)hipFree(h->stage);
+    if (h->pin) (void)hipHostFree(h->pin);
     if (h->snap) (void)hipFree(h->snap);
     if (h->arena) (void)hipFree(h->arena);
     if (h->own_stream) (void)hipStreamDestroy(h->stream);
@@ -888,6 +1048,12 @@ static size_t act_bytes_a(const q1env* h, int fmt) {
     if (fmt == Q1ENV_ACT_F64_ROWS) return n * h->p.act_width * 8;
     if (fmt == Q1ENV_ACT_F32_ROWS) return n * h->p.act_width * 4;
     return n;
+}
+
+// Width of one row of policy-network outputs (Q1PhysActionDist.required_model_output_shape, action_dist.py:236-241): two logits per
+// key, then (mean, log_std) of the continuous mouse or the 2S+1 logits of the discrete one.
+static int policy_row_width(const Params& p) {
+    return 2 * p.num_keys + (p.yaw_mode == 1 ? 2 : (p.yaw_mode == 2 ? 2 * (int)p.yaw_steps + 1 : 0));
 }
 
 // The default action/episode structure (4 keys, continuous mouse, jump key, no hover, y reward) runs the SPEC kernels.
@@ -951,19 +1117,41 @@ int q1env_step_host(q1env_t* h, int fmt, const void* a, const void* b, int obs_f
     if (obs_format != Q1ENV_OBS_F32 && obs_format != Q1ENV_OBS_F64) return fail(Q1ENV_ERR_INVALID_ARG, "bad obs_format");
     DeviceGuard guard(h->device);
     const size_t n = (size_t)h->p.n;
-    const size_t ba = align_up(act_bytes_a(h, fmt), 256), bb = align_up(n * 4, 256);
-    const size_t bo = align_up(n * 6 * (obs_format == Q1ENV_OBS_F32 ? 4 : 8), 256);
+    const size_t na = act_bytes_a(h, fmt), nb = (fmt == Q1ENV_ACT_PACKED && h->p.yaw_mode) ? n * 4 : 0;
+    const size_t no = n * 6 * (obs_format == Q1ENV_OBS_F32 ? 4 : 8);
+    const size_t ba = align_up(na, 256), bb = align_up(n * 4, 256), bo = align_up(no, 256);
     const size_t br = align_up(n * 4, 256), bd = align_up(n, 256);
-    if (int r = ensure_stage(h, ba + bb + bo + br + 2 * bd)) return r;
+    const size_t in_bytes = ba + bb, out_bytes = bo + br + 2 * bd;
+    if (int r = ensure_stage(h, in_bytes + out_bytes)) return r;
     char* d = (char*)h->stage;
-    void* d_a = d; void* d_b = d + ba; void* d_o = d + ba + bb;
-    float* d_r = (float*)(d + ba + bb + bo); uint8_t* d_d = (uint8_t*)(d + ba + bb + bo + br); uint8_t* d_z = d_d + bd;
-    HIP_TRY(hipMemcpyAsync(d_a, a, act_bytes_a(h, fmt), hipMemcpyHostToDevice, h->stream));
-    if (fmt == Q1ENV_ACT_PACKED && h->p.yaw_mode) HIP_TRY(hipMemcpyAsync(d_b, b, n * 4, hipMemcpyHostToDevice, h->stream));
+    void* d_a = d; void* d_b = d + ba; void* d_o = d + in_bytes;
+    float* d_r = (float*)(d + in_bytes + bo); uint8_t* d_d = (uint8_t*)(d + in_bytes + bo + br); uint8_t* d_z = d_d + bd;
+    const bool pack = n <= PACK_MAX_ENVS;
+    char* pin = nullptr;
+    if (pack) {                                   // one H2D block, one D2H block through the handle's pinned staging
+        if (int r = ensure_pin(h, in_bytes + out_bytes)) return r;
+        pin = (char*)h->pin;
+        memcpy(pin, a, na);
+        if (nb) memcpy(pin + ba, b, nb);
+        HIP_TRY(hipMemcpyAsync(d, pin, nb ? ba + nb : na, hipMemcpyHostToDevice, h->stream));
+    } else {
+        HIP_TRY(hipMemcpyAsync(d_a, a, na, hipMemcpyHostToDevice, h->stream));
+        if (nb) HIP_TRY(hipMemcpyAsync(d_b, b, nb, hipMemcpyHostToDevice, h->stream));
+    }
     launch_step(h, fmt, d_a, d_b, obs_format, obs ? d_o : nullptr, reward ? d_r : nullptr, done ? d_d : nullptr, zs ? d_z : nullptr);
     HIP_TRY(hipGetLastError());
     h->tick_count += 1;
-    if (obs) HIP_TRY(hipMemcpyAsync(obs, d_o, n * 6 * (obs_format == Q1ENV_OBS_F32 ? 4 : 8), hipMemcpyDeviceToHost, h->stream));
+    if (pack) {
+        HIP_TRY(hipMemcpyAsync(pin + in_bytes, d + in_bytes, out_bytes, hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        const char* po = pin + in_bytes;
+        if (obs) memcpy(obs, po, no);
+        if (reward) memcpy(reward, po + bo, n * 4);
+        if (done) memcpy(done, po + bo + br, n);
+        if (zs) memcpy(zs, po + bo + br + bd, n);
+        return Q1ENV_OK;
+    }
+    if (obs) HIP_TRY(hipMemcpyAsync(obs, d_o, no, hipMemcpyDeviceToHost, h->stream));
     if (reward) HIP_TRY(hipMemcpyAsync(reward, d_r, n * 4, hipMemcpyDeviceToHost, h->stream));
     if (done) HIP_TRY(hipMemcpyAsync(done, d_d, n, hipMemcpyDeviceToHost, h->stream));
     if (zs) HIP_TRY(hipMemcpyAsync(zs, d_z, n, hipMemcpyDeviceToHost, h->stream));
@@ -991,9 +1179,15 @@ int q1env_step_many(q1env_t* h, int ticks, int fmt, const void* a, const void* b
     if (ticks <= 0) return fail(Q1ENV_ERR_INVALID_ARG, "ticks must be > 0");
     if (int r = check_act(h, fmt, a, b, false)) return r;
     if (obs_format != Q1ENV_OBS_F32 && obs_format != Q1ENV_OBS_F64) return fail(Q1ENV_ERR_INVALID_ARG, "bad obs_format");
+    const bool t_start = (use_graph & Q1ENV_TIMER_START) != 0;    // record the handle's timer events around the launches
+    const bool t_stop = (use_graph & Q1ENV_TIMER_STOP) != 0;
+    use_graph &= ~(Q1ENV_TIMER_START | Q1ENV_TIMER_STOP);
+    if (use_graph < 0 || use_graph > 2) return fail(Q1ENV_ERR_INVALID_ARG, "bad use_graph");
     if (!use_graph) {
+        if (t_start) HIP_TRY(hipEventRecord(h->ev0, h->stream));
         enqueue_many(h, ticks, fmt, a, b, obs_format, obs, reward, done, out_stride);
         HIP_TRY(hipGetLastError());
+        if (t_stop) HIP_TRY(hipEventRecord(h->ev1, h->stream));
     } else {
         std::vector<uint64_t> key = {(uint64_t)ticks, (uint64_t)fmt, (uint64_t)(uintptr_t)a, (uint64_t)(uintptr_t)b,
                                      (uint64_t)obs_format, (uint64_t)(uintptr_t)obs, (uint64_t)(uintptr_t)reward,
@@ -1026,7 +1220,9 @@ int q1env_step_many(q1env_t* h, int ticks, int fmt, const void* a, const void* b
             (void)hipGraphUpload(exec, h->stream);          // the executable graph's packets are resident before the first replay
             return Q1ENV_OK;
         }
+        if (t_start) HIP_TRY(hipEventRecord(h->ev0, h->stream));
         HIP_TRY(hipGraphLaunch(exec, h->stream));
+        if (t_stop) HIP_TRY(hipEventRecord(h->ev1, h->stream));
     }
     h->tick_count += (uint64_t)ticks;
     return Q1ENV_OK;
@@ -1105,19 +1301,24 @@ int q1env_reset_draws_host(q1env_t* h, int64_t count, const int32_t* idx, const 
     DeviceGuard guard(h->device);
     const size_t c = (size_t)count;
     const size_t bi = align_up(c * 4, 256), bz = align_up(c, 256), bd = align_up(c * 8, 256);
-    const size_t bo = align_up(c * 6 * (obs_format == Q1ENV_OBS_F32 ? 4 : 8), 256);
-    if (int r = ensure_stage(h, bi + bz + 4 * bd + bo)) return r;
+    const size_t no = c * 6 * (obs_format == Q1ENV_OBS_F32 ? 4 : 8), bo = align_up(no, 256);
+    const size_t in_bytes = bi + bz + 4 * bd;
+    if (int r = ensure_stage(h, in_bytes + bo)) return r;
+    if (int r = ensure_pin(h, in_bytes + (c <= PACK_MAX_ENVS ? bo : 0))) return r;
     char* d = (char*)h->stage;
+    char* pin = (char*)h->pin;
     int32_t* d_i = (int32_t*)d; uint8_t* d_z = (uint8_t*)(d + bi);
     double* d_y = (double*)(d + bi + bz); double* d_t = (double*)(d + bi + bz + bd);
     double* d_s = (double*)(d + bi + bz + 2 * bd); double* d_a = (double*)(d + bi + bz + 3 * bd);
-    void* d_o = d + bi + bz + 4 * bd;
-    if (idx) HIP_TRY(hipMemcpyAsync(d_i, idx, c * 4, hipMemcpyHostToDevice, h->stream));
-    HIP_TRY(hipMemcpyAsync(d_z, zero_start, c, hipMemcpyHostToDevice, h->stream));
-    HIP_TRY(hipMemcpyAsync(d_y, yaw, c * 8, hipMemcpyHostToDevice, h->stream));
-    HIP_TRY(hipMemcpyAsync(d_t, tm, c * 8, hipMemcpyHostToDevice, h->stream));
-    HIP_TRY(hipMemcpyAsync(d_s, speed, c * 8, hipMemcpyHostToDevice, h->stream));
-    HIP_TRY(hipMemcpyAsync(d_a, angle, c * 8, hipMemcpyHostToDevice, h->stream));
+    void* d_o = d + in_bytes;
+    // the six input arrays travel as ONE block through the pinned staging (a reset_at is 1 env: six tiny copies were six calls)
+    if (idx) memcpy(pin, idx, c * 4);
+    memcpy(pin + bi, zero_start, c);
+    memcpy(pin + bi + bz, yaw, c * 8);
+    memcpy(pin + bi + bz + bd, tm, c * 8);
+    memcpy(pin + bi + bz + 2 * bd, speed, c * 8);
+    memcpy(pin + bi + bz + 3 * bd, angle, c * 8);
+    HIP_TRY(hipMemcpyAsync(d, pin, in_bytes, hipMemcpyHostToDevice, h->stream));
     const int blk = 64;
     if (obs_format == Q1ENV_OBS_F32)
         hipLaunchKernelGGL(reset_draws_kernel<float>, grid_for((int)count, blk), dim3(blk), 0, h->stream, h->p, h->st, (int)count,
@@ -1126,7 +1327,13 @@ int q1env_reset_draws_host(q1env_t* h, int64_t count, const int32_t* idx, const 
         hipLaunchKernelGGL(reset_draws_kernel<double>, grid_for((int)count, blk), dim3(blk), 0, h->stream, h->p, h->st, (int)count,
                            idx ? d_i : nullptr, d_z, d_y, d_t, d_s, d_a, obs ? (double*)d_o : nullptr);
     HIP_TRY(hipGetLastError());
-    if (obs) HIP_TRY(hipMemcpyAsync(obs, d_o, c * 6 * (obs_format == Q1ENV_OBS_F32 ? 4 : 8), hipMemcpyDeviceToHost, h->stream));
+    if (obs && c <= PACK_MAX_ENVS) {
+        HIP_TRY(hipMemcpyAsync(pin + in_bytes, d_o, no, hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        memcpy(obs, pin + in_bytes, no);
+        return Q1ENV_OK;
+    }
+    if (obs) HIP_TRY(hipMemcpyAsync(obs, d_o, no, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
     return Q1ENV_OK;
 }
@@ -1254,55 +1461,43 @@ int q1phys_apply_host(int device, int64_t n64, const double* yaw, const double* 
                       const double* smove, const uint8_t* button2, const double* time_delta, const double* z_pos,
                       const float* vel, const uint8_t* on_ground, const uint8_t* jump_released, double* out_z, float* out_vel,
                       uint8_t* out_og, uint8_t* out_jr) {
-    if (!yaw || !fmove || !smove || !button2 || !time_delta || !z_pos || !vel || !on_ground || !jump_released || !out_z ||
-        !out_vel || !out_og || !out_jr)
-        return fail(Q1ENV_ERR_INVALID_ARG, "q1phys_apply_host: null argument");
-    if (n64 <= 0 || n64 > (int64_t)1 << 30) return fail(Q1ENV_ERR_INVALID_ARG, "q1phys_apply_host: bad n");
+    return phys_apply_host_impl<float>(device, n64, yaw, pitch, roll, fmove, smove, button2, time_delta, z_pos, vel, on_ground,
+                                       jump_released, out_z, out_vel, out_og, out_jr);
+}
+
+int q1phys_apply_host_f64(int device, int64_t n64, const double* yaw, const double* pitch, const double* roll, const double* fmove,
+                          const double* smove, const uint8_t* button2, const double* time_delta, const double* z_pos,
+                          const double* vel, const uint8_t* on_ground, const uint8_t* jump_released, double* out_z, double* out_vel,
+                          uint8_t* out_og, uint8_t* out_jr) {
+    return phys_apply_host_impl<double>(device, n64, yaw, pitch, roll, fmove, smove, button2, time_delta, z_pos, vel, on_ground,
+                                        jump_released, out_z, out_vel, out_og, out_jr);
+}
+
+// Page-locked host memory for the arrays handed to the *_host entry points: copies to and from it are direct DMA (hipMemcpyAsync
+// recognises the pointer), pageable arrays are staged by the runtime at a fraction of the rate (98 MB per tick at 1 M envs).
+void* q1env_host_alloc(uint64_t bytes) {
+    void* p = nullptr;
+    if (bytes == 0) { (void)fail(Q1ENV_ERR_INVALID_ARG, "q1env_host_alloc: zero bytes"); return nullptr; }
     int ndev = 0;
-    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
-        return fail(Q1ENV_ERR_NO_DEVICE, "q1phys_apply_host: no HIP device visible (libq1env has no CPU fallback)");
-    if (device < 0 || device >= ndev) return fail(Q1ENV_ERR_INVALID_ARG, "q1phys_apply_host: bad device index");
-    DeviceGuard guard(device);
-    const size_t n = (size_t)n64;
-    const size_t b8 = align_up(n * 8, 256), b1 = align_up(n, 256), b12 = align_up(n * 12, 256);
-    char* d = nullptr;
-    const size_t total = 8 * b8 + 5 * b1 + 2 * b12;
-    HIP_TRY(hipMalloc((void**)&d, total));
-    double* d_yaw = (double*)d; double* d_pitch = d_yaw + b8 / 8; double* d_roll = d_pitch + b8 / 8;
-    double* d_f = d_roll + b8 / 8; double* d_s = d_f + b8 / 8; double* d_dt = d_s + b8 / 8; double* d_z = d_dt + b8 / 8;
-    double* d_oz = d_z + b8 / 8;
-    char* q = (char*)(d_oz + b8 / 8);
-    uint8_t* d_b2 = (uint8_t*)q; uint8_t* d_og = d_b2 + b1; uint8_t* d_jr = d_og + b1; uint8_t* d_oog = d_jr + b1; uint8_t* d_ojr = d_oog + b1;
-    float* d_v = (float*)(d_ojr + b1); float* d_ov = (float*)((char*)d_v + b12);
-    int rc = Q1ENV_OK;
-    auto up = [&](void* dst, const void* src, size_t bytes) {
-        if (rc == Q1ENV_OK && hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice) != hipSuccess) rc = fail(Q1ENV_ERR_HIP, "q1phys_apply_host: H2D failed");
-    };
-    up(d_yaw, yaw, n * 8); if (pitch) up(d_pitch, pitch, n * 8); if (roll) up(d_roll, roll, n * 8);
-    up(d_f, fmove, n * 8); up(d_s, smove, n * 8); up(d_dt, time_delta, n * 8); up(d_z, z_pos, n * 8);
-    up(d_b2, button2, n); up(d_og, on_ground, n); up(d_jr, jump_released, n); up(d_v, vel, n * 12);
-    if (rc == Q1ENV_OK) {
-        hipLaunchKernelGGL(phys_apply_kernel, grid_for((int)n, 256), dim3(256), 0, 0, (int)n, (const double*)d_yaw,
-                           pitch ? (const double*)d_pitch : (const double*)nullptr, roll ? (const double*)d_roll : (const double*)nullptr,
-                           (const double*)d_f, (const double*)d_s, (const uint8_t*)d_b2, (const double*)d_dt, (const double*)d_z,
-                           (const float*)d_v, (const uint8_t*)d_og, (const uint8_t*)d_jr, d_oz, d_ov, d_oog, d_ojr);
-        auto down = [&](void* dst, const void* src, size_t bytes) {
-            if (rc == Q1ENV_OK && hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost) != hipSuccess) rc = fail(Q1ENV_ERR_HIP, "q1phys_apply_host: D2H failed");
-        };
-        down(out_z, d_oz, n * 8); down(out_vel, d_ov, n * 12); down(out_og, d_oog, n); down(out_jr, d_ojr, n);
-    }
-    (void)hipFree(d);
-    return rc;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { (void)fail(Q1ENV_ERR_NO_DEVICE, "q1env_host_alloc: no HIP device visible"); return nullptr; }
+    hipError_t e = hipHostMalloc(&p, (size_t)bytes, hipHostMallocPortable);
+    if (e != hipSuccess) { (void)fail(Q1ENV_ERR_ALLOC, std::string("hipHostMalloc: ") + hipGetErrorString(e)); return nullptr; }
+    return p;
+}
+
+int q1env_host_free(void* p) {
+    if (!p) return Q1ENV_OK;
+    HIP_TRY(hipHostFree(p));
+    return Q1ENV_OK;
 }
 
 int q1env_policy_sample(q1env_t* h, const float* logits, int row_stride, uint64_t seed, uint64_t counter,
                         const uint64_t* counter_dev, int deterministic, uint8_t* keys, float* mouse, float* logp) {
     if (!h || !logits || !keys) return fail(Q1ENV_ERR_INVALID_ARG, "q1env_policy_sample: null argument");
     DeviceGuard guard(h->device);
-    const int need = 2 * h->p.num_keys + (h->p.yaw_mode == 1 ? 2 : 0);
-    if (h->p.yaw_mode == 2) return fail(Q1ENV_ERR_INVALID_ARG, "q1env_policy_sample: discrete yaw is not supported (continuous mouse or no mouse)");
-    if (row_stride < need) return fail(Q1ENV_ERR_INVALID_ARG, "q1env_policy_sample: row_stride smaller than 2*num_keys + 2");
-    if (h->p.yaw_mode == 1 && !mouse) return fail(Q1ENV_ERR_INVALID_ARG, "q1env_policy_sample: mouse output required");
+    const int need = policy_row_width(h->p);
+    if (row_stride < need) return fail(Q1ENV_ERR_INVALID_ARG, "q1env_policy_sample: row_stride smaller than the policy row (2*num_keys + 2, or + 2*discrete_yaw_steps+1)");
+    if (h->p.yaw_mode != 0 && !mouse) return fail(Q1ENV_ERR_INVALID_ARG, "q1env_policy_sample: mouse output required");
     const int blk = block_for(h->p.n);
     hipLaunchKernelGGL(policy_sample_kernel, grid_for(h->p.n, blk), dim3(blk), 0, h->stream, h->p, logits, row_stride, seed, counter,
                        counter_dev, deterministic, keys, mouse, logp);
@@ -1327,9 +1522,8 @@ int q1env_ppo_loss_grad(q1env_t* h, int64_t batch, const float* logits, const fl
         !dvalue || !partials)
         return fail(Q1ENV_ERR_INVALID_ARG, "q1env_ppo_loss_grad: null argument");
     if (batch <= 0 || batch > (int64_t)1 << 30) return fail(Q1ENV_ERR_INVALID_ARG, "q1env_ppo_loss_grad: bad batch");
-    if (h->p.yaw_mode == 2) return fail(Q1ENV_ERR_INVALID_ARG, "q1env_ppo_loss_grad: discrete yaw is not supported");
-    if (h->p.yaw_mode == 1 && !mouse) return fail(Q1ENV_ERR_INVALID_ARG, "q1env_ppo_loss_grad: mouse actions required");
-    if (row_stride < 2 * h->p.num_keys + (h->p.yaw_mode == 1 ? 2 : 0)) return fail(Q1ENV_ERR_INVALID_ARG, "q1env_ppo_loss_grad: row_stride too small");
+    if (h->p.yaw_mode != 0 && !mouse) return fail(Q1ENV_ERR_INVALID_ARG, "q1env_ppo_loss_grad: mouse actions required");
+    if (row_stride < policy_row_width(h->p)) return fail(Q1ENV_ERR_INVALID_ARG, "q1env_ppo_loss_grad: row_stride too small");
     DeviceGuard guard(h->device);
     hipLaunchKernelGGL(ppo_loss_grad_kernel, grid_for((int)batch, 256), dim3(256), 0, h->stream, h->p, (int)batch, logits, old_logits,
                        row_stride, keys, mouse, logp_old, adv, value, value_old, vtarg, clip_param, vf_clip_param, vf_loss_coeff,
@@ -1353,10 +1547,9 @@ int q1env_sample_step(q1env_t* h, const float* logits, int row_stride, uint64_t 
     if (!h || !logits || !keys || !obs || !reward || !done || !ep_return || !partials)
         return fail(Q1ENV_ERR_INVALID_ARG, "q1env_sample_step: null argument");
     DeviceGuard guard(h->device);
-    const int need = 2 * h->p.num_keys + (h->p.yaw_mode == 1 ? 2 : 0);
-    if (h->p.yaw_mode == 2) return fail(Q1ENV_ERR_INVALID_ARG, "q1env_sample_step: discrete yaw is not supported (continuous mouse or no mouse)");
-    if (row_stride < need) return fail(Q1ENV_ERR_INVALID_ARG, "q1env_sample_step: row_stride smaller than 2*num_keys + 2");
-    if (h->p.yaw_mode == 1 && !mouse) return fail(Q1ENV_ERR_INVALID_ARG, "q1env_sample_step: mouse output required");
+    const int need = policy_row_width(h->p);
+    if (row_stride < need) return fail(Q1ENV_ERR_INVALID_ARG, "q1env_sample_step: row_stride smaller than the policy row (2*num_keys + 2, or + 2*discrete_yaw_steps+1)");
+    if (h->p.yaw_mode != 0 && !mouse) return fail(Q1ENV_ERR_INVALID_ARG, "q1env_sample_step: mouse output required");
     const int blk = block_for(h->p.n);
     const dim3 g = grid_for(h->p.n, blk), bs(blk);
     const uint64_t counter = counter_offset + (counter_dev ? 0 : h->tick_count);
@@ -1397,7 +1590,7 @@ static int launch_mlp(q1env* h, const float* obs, const q1pol::Net& na, const q1
 int q1env_policy_forward(q1env_t* h, const float* obs, const float* w1, const float* b1, const uint16_t* w23_image, const float* b2,
                          const float* b3, int out_dim, float* out) {
     if (!h || !obs || !w1 || !b1 || !w23_image || !b2 || !b3 || !out) return fail(Q1ENV_ERR_INVALID_ARG, "q1env_policy_forward: null argument");
-    if (out_dim < 1 || out_dim > 10) return fail(Q1ENV_ERR_INVALID_ARG, "q1env_policy_forward: out_dim must be in 1..10");
+    if (out_dim < 1 || out_dim > 32) return fail(Q1ENV_ERR_INVALID_ARG, "q1env_policy_forward: out_dim must be in 1..32");
     DeviceGuard guard(h->device);
     const q1pol::Net net{w1, b1, w23_image, b2, b3, out, out_dim};
     return launch_mlp(h, obs, net, net, 1);
@@ -1407,7 +1600,7 @@ int q1env_policy_value_forward(q1env_t* h, const float* obs, const q1env_mlp* pi
     if (!h || !obs || !pi || !vf) return fail(Q1ENV_ERR_INVALID_ARG, "q1env_policy_value_forward: null argument");
     for (const q1env_mlp* m : {pi, vf}) {
         if (!m->w1 || !m->b1 || !m->w23_image || !m->b2 || !m->b3 || !m->out) return fail(Q1ENV_ERR_INVALID_ARG, "q1env_policy_value_forward: null pointer in q1env_mlp");
-        if (m->out_dim < 1 || m->out_dim > 10) return fail(Q1ENV_ERR_INVALID_ARG, "q1env_policy_value_forward: out_dim must be in 1..10");
+        if (m->out_dim < 1 || m->out_dim > 32) return fail(Q1ENV_ERR_INVALID_ARG, "q1env_policy_value_forward: out_dim must be in 1..32");
     }
     DeviceGuard guard(h->device);
     const q1pol::Net na{pi->w1, pi->b1, pi->w23_image, pi->b2, pi->b3, pi->out, pi->out_dim};

@@ -302,9 +302,14 @@ __device__ __forceinline__ Cmd decode(const Params& p, Env& e, uint32_t keybits,
 // Per-lane conditions are selects, not branches, so the whole tick stays one basic block; the only branch is the
 // wave-level ballot of the PREVIOUS tick's on_ground: a wave with nobody on the ground skips the friction block
 // (float32 sqrt + float64 divide) through a wave-uniform s_cbranch.
-__device__ __forceinline__ void physics(Env& e, const Cmd& c, double m00, double m01, double m10, double m11,
-                                        double dt, double accel_dt, double grav_dt) {
-    const bool og = e.flags & FLAG_ON_GROUND;
+// VT = the dtype PlayerState.vel arrives in: float for the env (float32 storage: friction speed / control and the +270 add are
+// float32 islands, the result is rounded to float32 on store, phys.py:190), double for DataFrame-driven callers
+// (PlayerState.from_df yields a float64 vel, phys.py:168-170: then NOTHING on the path is float32).
+template <typename VT>
+__device__ __forceinline__ void physics_core(VT& vx, VT& vy, VT& vz, double& zpos, uint32_t& flags, const Cmd& c,
+                                             double m00, double m01, double m10, double m11,
+                                             double dt, double accel_dt, double grav_dt) {
+    const bool og = flags & FLAG_ON_GROUND;
     // einsum('ijk,ik->ij') accumulates from +0.0 (phys.py:97)
     const double wx = (0.0 + m00 * c.fmove) + m01 * c.smove;
     const double wy = (0.0 + m10 * c.fmove) + m11 * c.smove;
@@ -316,35 +321,41 @@ __device__ __forceinline__ void physics(Env& e, const Cmd& c, double m00, double
     const double dy = has_wish ? div_shared(wy, wden, yw) : wy;
     const double wish_speed = fmin(320.0, wlen);                        // phys.py:103
 
-    double hx = (double)e.vx, hy = (double)e.vy;
+    double hx = (double)vx, hy = (double)vy;
     if (__ballot(og)) {                                                 // wave-uniform skip
-        const float speed = sqrtf(e.vx * e.vx + e.vy * e.vy);           // float32 norm (phys.py:85)
-        const bool fr = og && speed > 0.0f;
-        const float control = fmaxf(speed, 100.0f);                     // phys.py:86
+        VT speed, control;                                              // norm / control in the velocity's own dtype (phys.py:85-86)
+        if constexpr (sizeof(VT) == 4) { speed = sqrtf(vx * vx + vy * vy); control = fmaxf(speed, 100.0f); }
+        else { speed = sqrt(vx * vx + vy * vy); control = fmax(speed, 100.0); }
+        const bool fr = og && speed > (VT)0;
         const double drop = (dt * (double)control) * 4.0;               // phys.py:87
         const double ns = fmax(0.0, (double)speed - drop);              // phys.py:88
         const double sd = fr ? (double)speed : 1.0;
         const double k = div_shared(ns, sd, rcp_refined(sd));           // phys.py:90 (exact: operands in the normal range)
-        hx = fr ? (double)e.vx * k : hx;
-        hy = fr ? (double)e.vy * k : hy;
+        hx = fr ? (double)vx * k : hx;
+        hy = fr ? (double)vy * k : hy;
     }
     const double cur = (0.0 + hx * dx) + hy * dy;                       // phys.py:71
     const double capped = (wish_speed > 30.0 && !og) ? 30.0 : wish_speed;   // phys.py:73-75
     const double add = fmax(0.0, capped - cur);                         // phys.py:77
     const double acc = fmin(accel_dt * wish_speed, add);                // phys.py:78 (unclipped wish_speed)
-    e.vx = (float)(hx + acc * dx);                                      // phys.py:80, RNE to float32 at phys.py:190
-    e.vy = (float)(hy + acc * dy);
+    vx = (VT)(hx + acc * dx);                                           // phys.py:80, RNE to float32 at phys.py:190
+    vy = (VT)(hy + acc * dy);
 
     // z (phys.py:112-132)
-    const uint32_t fl = e.flags | (c.jump ? 0u : FLAG_JUMP_RELEASED);   // phys.py:117
+    const uint32_t fl = flags | (c.jump ? 0u : FLAG_JUMP_RELEASED);     // phys.py:117
     const bool do_jump = og && c.jump && (fl & FLAG_JUMP_RELEASED);     // phys.py:118
-    float vz = e.vz + (do_jump ? 270.0f : 0.0f);                        // float32 add (phys.py:119)
-    vz = (float)((double)vz - grav_dt);                                 // float64 subtract, RNE (phys.py:122)
-    const double z = e.z + dt * (double)vz;                             // phys.py:127
+    VT z_vel = vz + (do_jump ? (VT)270 : (VT)0);                        // add in vel's dtype (phys.py:119)
+    z_vel = (VT)((double)z_vel - grav_dt);                              // float64 subtract, RNE (phys.py:122)
+    const double z = zpos + dt * (double)z_vel;                         // phys.py:127
     const bool landed = z < 24.03125;                                   // phys.py:128
-    e.z = landed ? 24.03125 : z;                                        // phys.py:129
-    e.vz = landed ? 0.0f : vz;                                          // phys.py:130
-    e.flags = (fl & ~FLAG_ON_GROUND) | (landed ? FLAG_ON_GROUND : 0u);
+    zpos = landed ? 24.03125 : z;                                       // phys.py:129
+    vz = landed ? (VT)0 : z_vel;                                        // phys.py:130
+    flags = (fl & ~FLAG_ON_GROUND) | (landed ? FLAG_ON_GROUND : 0u);
+}
+
+__device__ __forceinline__ void physics(Env& e, const Cmd& c, double m00, double m01, double m10, double m11,
+                                        double dt, double accel_dt, double grav_dt) {
+    physics_core<float>(e.vx, e.vy, e.vz, e.z, e.flags, c, m00, m01, m10, m11, dt, accel_dt, grav_dt);
 }
 
 // yaw -> basis with pitch = roll = 0 (phys.py:56-66): radians = yaw*pi/180 (mul THEN div), float64 sincos

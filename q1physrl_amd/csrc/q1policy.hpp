@@ -295,17 +295,19 @@ mlp_forward_kernel(int n, const float* __restrict__ obs, Net net_a, Net net_b, i
                 w3b = *reinterpret_cast<const f16x8*>(w3row + (uint32_t)(2 * t2 + 3) * 32u);
             }
         }
-        // y[r] = output row (r&3) + 8(r>>2) + 4*half of env `col`: rows 0..7 come from registers 0..3 of the two halves,
-        // rows 8..9 from registers 4..5 of half 0
+        // y[r] = output row (r&3) + 8(r>>2) + 4*half of env `col`; OUT <= 32 rows are real (10 policy logits with the continuous
+        // mouse, 2K + 2S+1 with a discrete one, 1 for the value net).  OUT is wave-uniform: the group test is a scalar branch.
         if (live) {
             float* dst = out + (size_t)env * (uint32_t)OUT;
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-                if ((int)(r + 4 * half) < OUT) dst[r + 4 * half] = y[r] + b3[r + 4 * half];
-            if (half == 0) {
+            for (int g = 0; g < 4; ++g) {
+                if (8 * g < OUT) {
 #pragma unroll
-                for (int r = 4; r < 6; ++r)
-                    if (r + 4 < OUT) dst[r + 4] = y[r] + b3[r + 4];
+                    for (int r = 0; r < 4; ++r) {
+                        const int row = r + 8 * g + 4 * (int)half;
+                        if (row < OUT) dst[row] = y[4 * g + r] + b3[row];
+                    }
+                }
             }
         }
 #ifdef Q1POL_TRACE

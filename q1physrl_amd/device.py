@@ -10,8 +10,19 @@ import numpy as np
 from . import _lib
 
 
-def make_c_config(config, num_envs=None, env_index_base=0):
-    """reference Config (env.py:94-148) -> q1env_config POD."""
+def legacy_promotion_default():
+    """NumPy < 2 multiplies np.float32(720) by a Python float in float64 (env.py:230); NumPy >= 2 (NEP 50) in float32.  The
+    default follows the NumPy the caller runs - i.e. what the reference itself would compute in this interpreter - and
+    Q1PHYSRL_NUMPY_PROMOTION=legacy|nep50 overrides it."""
+    import os
+    v = os.environ.get("Q1PHYSRL_NUMPY_PROMOTION", "").lower()
+    if v in ("legacy", "nep50"):
+        return v == "legacy"
+    return int(np.__version__.split(".")[0]) < 2
+
+
+def make_c_config(config, num_envs=None, env_index_base=0, numpy_promotion=None):
+    """reference Config (env.py:94-148) -> q1env_config POD.  numpy_promotion: None (follow the running NumPy), "nep50", "legacy"."""
     c = _lib.Q1Config()
     c.num_envs = int(config.num_envs if num_envs is None else num_envs)
     c.allow_yaw = int(bool(config.allow_yaw))
@@ -32,14 +43,20 @@ def make_c_config(config, num_envs=None, env_index_base=0):
     c.smove_max = float(config.smove_max)
     c.key_press_delay = float(config.key_press_delay)
     c.env_index_base = int(env_index_base)
+    if numpy_promotion not in (None, "nep50", "legacy"):
+        raise ValueError(f"numpy_promotion must be None, 'nep50' or 'legacy', got {numpy_promotion!r}")
+    c.legacy_promotion = int(legacy_promotion_default() if numpy_promotion is None else numpy_promotion == "legacy")
+    c.reserved0 = 0
     return c
 
 
 class DeviceEnv:
-    def __init__(self, config, num_envs=None, device=0, stream=None, env_index_base=0):
+    def __init__(self, config, num_envs=None, device=0, stream=None, env_index_base=0, numpy_promotion=None):
         self._lib = _lib.load()
         self._h = C.c_void_p()
-        cc = make_c_config(config, num_envs, env_index_base)
+        cc = make_c_config(config, num_envs, env_index_base, numpy_promotion)
+        self.legacy_promotion = bool(cc.legacy_promotion)
+        self._pin_in = None
         self.n = cc.num_envs
         self.device = device
         _lib.check(self._lib.q1env_create(C.byref(cc), int(device), C.c_void_p(stream or 0), C.byref(self._h)))
@@ -63,10 +80,17 @@ class DeviceEnv:
         a = np.ascontiguousarray(actions_f64, dtype=np.float64)
         if a.shape != (n, self.action_width):
             raise ValueError(f"actions must have shape ({n}, {self.action_width}), got {a.shape}")
-        obs = np.empty((n, 6), dtype=np.float64 if obs_format == _lib.OBS_F64 else np.float32)
-        reward = np.empty((n,), dtype=np.float32)
-        done = np.empty((n,), dtype=np.uint8)
-        zs = np.empty((n,), dtype=np.uint8) if want_zero_start else None
+        if n > _lib.PACK_MAX_ENVS:
+            # large batches: page-locked arrays, so every copy is one direct DMA instead of the runtime's staged pageable path
+            # (the returned arrays are the caller's, as always: their block goes back to the pool when they are collected)
+            if self._pin_in is None:
+                self._pin_in = _lib.pinned_pool().empty(a.shape, np.float64)
+            np.copyto(self._pin_in, a)
+            a = self._pin_in
+        obs = _lib.host_empty((n, 6), np.float64 if obs_format == _lib.OBS_F64 else np.float32, n)
+        reward = _lib.host_empty((n,), np.float32, n)
+        done = _lib.host_empty((n,), np.uint8, n)
+        zs = _lib.host_empty((n,), np.uint8, n) if want_zero_start else None
         _lib.check(self._lib.q1env_step_host(self._h, _lib.ACT_F64_ROWS, _lib.ptr(a), None, obs_format,
                                              _lib.ptr(obs), _lib.ptr(reward), _lib.ptr(done), _lib.ptr(zs)))
         return obs, reward, done.view(np.bool_), (zs.view(np.bool_) if zs is not None else None)
@@ -77,7 +101,7 @@ class DeviceEnv:
         arrs = [np.ascontiguousarray(x, dtype=np.float64) for x in (yaw, time_remaining, speed, angle)]
         assert all(x.shape == (cnt,) for x in arrs)
         ix = None if idx is None else np.ascontiguousarray(idx, dtype=np.int32)
-        obs = np.empty((cnt, 6), dtype=np.float64 if obs_format == _lib.OBS_F64 else np.float32)
+        obs = _lib.host_empty((cnt, 6), np.float64 if obs_format == _lib.OBS_F64 else np.float32, cnt)
         _lib.check(self._lib.q1env_reset_draws_host(self._h, cnt, _lib.ptr(ix), _lib.ptr(zs), *[_lib.ptr(x) for x in arrs],
                                                     obs_format, _lib.ptr(obs)))
         return obs
@@ -89,7 +113,7 @@ class DeviceEnv:
         _lib.check(self._lib.q1env_restore_state(self._h))
 
     def observe_host(self, obs_format=_lib.OBS_F64):
-        obs = np.empty((self.n, 6), dtype=np.float64 if obs_format == _lib.OBS_F64 else np.float32)
+        obs = _lib.host_empty((self.n, 6), np.float64 if obs_format == _lib.OBS_F64 else np.float32, self.n)
         _lib.check(self._lib.q1env_observe_host(self._h, obs_format, _lib.ptr(obs)))
         return obs
 
@@ -99,7 +123,7 @@ class DeviceEnv:
         for name, dt, mult in _lib.STATE_FIELDS:
             if fields is not None and name not in fields:
                 continue
-            out[name] = np.empty((mult * self.n,), dtype=dt)
+            out[name] = _lib.host_empty((mult * self.n,), dt, self.n)
             setattr(st, name, out[name].ctypes.data)
         _lib.check(self._lib.q1env_get_state_host(self._h, C.byref(st)))
         if "last_key_press_time" in out:

@@ -153,10 +153,12 @@ class ActionDecoder:
     view `VectorPhysEnv._action_decoder` onto the env's own fused decoder state.
     """
 
-    def __init__(self, config: Config, *, device: int = 0, _shared: Optional[DeviceEnv] = None):
+    def __init__(self, config: Config, *, device: int = 0, numpy_promotion: Optional[str] = None,
+                 _shared: Optional[DeviceEnv] = None):
         self._config = config
         self._num_keys = _num_keys(config)
         self._device = device
+        self._numpy_promotion = numpy_promotion
         self._dev: Optional[DeviceEnv] = _shared
 
     @property
@@ -188,7 +190,7 @@ class ActionDecoder:
         yaw = np.array(yaw, dtype=np.float64).reshape(-1)
         if self._dev is None:
             n = self._config.num_envs if self._config.num_envs is not None else yaw.shape[0]
-            self._dev = DeviceEnv(self._config, num_envs=n, device=self._device)
+            self._dev = DeviceEnv(self._config, num_envs=n, device=self._device, numpy_promotion=self._numpy_promotion)
         self._dev.decoder_reset(yaw)
 
     def reset_at(self, index, yaw):
@@ -236,10 +238,49 @@ class _LazyInfos:
         return repr(list(self))
 
 
-class PhysEnv:
+try:                                              # the reference's base class (env.py:299: `class PhysEnv(gym.Env)`) when gym is installed
+    import gym as _gym
+    _GymEnv = _gym.Env
+except ImportError:
+    _gym = None
+
+    class _GymEnv:
+        """What gym.Env (0.17, the reference's pin) gives a subclass, for images without gym: `gym.make` does
+        `env.unwrapped.spec = spec`, wrappers read `metadata` / `reward_range` / `spec`, RLlib calls `seed` / `close`."""
+        metadata = {'render.modes': []}
+        reward_range = (-float('inf'), float('inf'))
+        spec = None
+        action_space = None
+        observation_space = None
+
+        @property
+        def unwrapped(self):
+            return self
+
+        def seed(self, seed=None):
+            return
+
+        def render(self, mode='human'):
+            raise NotImplementedError
+
+        def close(self):
+            pass
+
+        def __enter__(self):
+            return self
+
+        def __exit__(self, *args):
+            self.close()
+            return False
+
+        def __str__(self):
+            return f'<{type(self).__name__} instance>' if self.spec is None else f'<{type(self).__name__}<{self.spec.id}>>'
+
+
+class PhysEnv(_GymEnv):
     """Single-env gym facade (env.py:299-358): 4 discrete keys + one continuous mouse dimension in,
     6-d observation (time left, yaw, z, velocity) out, reward = distance travelled along +Y this frame.
-    No auto-reset: call reset() after done."""
+    No auto-reset: call reset() after done.  A gym.Env subclass whenever gym is importable (as in the reference)."""
     metadata = {}
 
     def __init__(self, config: Union[Config, dict], **device_kwargs):
@@ -260,6 +301,10 @@ class PhysEnv:
     def reset(self):
         (obs,) = self._env.vector_reset()
         return obs
+
+    def seed(self, seed=None):
+        """The reference inherits gym.Env.seed (a no-op returning None): its randomness is the GLOBAL NumPy stream."""
+        return
 
     def close(self):
         self._env.close()
@@ -286,7 +331,7 @@ class VectorPhysEnv(VectorEnv):
     """
 
     def __init__(self, config, *, device: int = 0, stream: Optional[int] = None, env_index_base: int = 0,
-                 speculative_resets: bool = False):
+                 speculative_resets: bool = False, numpy_promotion: Optional[str] = None):
         if isinstance(config, dict):
             config = Config(**config)
         self._config = config
@@ -295,7 +340,10 @@ class VectorPhysEnv(VectorEnv):
         self.reward_range = (-1000 * self._config.time_delta, 1000 * self._config.time_delta)
         self.metadata = {}
         self._obs_scale = get_obs_scale(self._config)
-        self._dev = DeviceEnv(self._config, device=device, stream=stream, env_index_base=env_index_base)
+        # numpy_promotion: how env.py:230's np.float32(720) * time_delta is evaluated - None = like the NumPy running here
+        # ("nep50" for NumPy >= 2, "legacy" float64 product for the NumPy 1.18.2 the reference pins); see include/q1env.h
+        self._dev = DeviceEnv(self._config, device=device, stream=stream, env_index_base=env_index_base,
+                              numpy_promotion=numpy_promotion)
         self._action_decoder = ActionDecoder(self._config, device=device, _shared=self._dev)
         self.action_space = self._action_decoder.action_space
         self._step_num = 0
@@ -318,24 +366,60 @@ class VectorPhysEnv(VectorEnv):
         self._cache = {}
         return self._dev.reset_draws(zero_start, yaw, time_remaining, speed, angle)
 
-    def _draw_reset_rows(self, k):
+    def _draw_reset_rows(self, k, consumed=None):
         """The draws of k consecutive `reset_at` calls from the global NumPy stream (env.py:461-471: a zero start consumes no
-        yaw / time / speed draw, the angle is always drawn)."""
+        yaw / time / speed draw, the angle is always drawn), and the stream left exactly where those k calls leave it.
+
+        Every draw of the reference's reset_at is ONE double of the legacy MT19937 stream (random() is it; uniform(a, b) is
+        a + (b - a) * it; the one-argument uniform(x) is uniform(low=x, high=1)).  So instead of up to 5 k scalar np.random calls:
+        draw 5 k doubles as one block, follow the data-dependent consumption (2 doubles for a zero start, 5 otherwise) with an
+        integer walk over the block, gather the fields with array arithmetic, then rewind the stream and advance it by the
+        number of doubles really consumed.  `consumed`, if a list, receives the cumulative count after each reset."""
         c = self._config
-        zs, yaw, tm, sp, an = np.zeros(k, bool), np.zeros(k), np.zeros(k), np.zeros(k), np.zeros(k)
-        rnd, uni, tau = np.random.random, np.random.uniform, 2 * np.pi
-        for j in range(k):
-            z = zs[j] = rnd() < c.zero_start_prob
-            if not z:
-                yaw[j] = uni(*c.initial_yaw_range)
-                tm[j] = uni(c.time_limit)
-                sp[j] = uni(c.max_initial_speed)
-            an[j] = uni(tau)
+        p, (lo, hi), tl, ms, tau = c.zero_start_prob, c.initial_yaw_range, c.time_limit, c.max_initial_speed, 2 * np.pi
+        if k <= 2:                                       # one or two resets: the plain calls are cheaper than a state save
+            zs, yaw, tm, sp, an = np.zeros(k, bool), np.zeros(k), np.zeros(k), np.zeros(k), np.zeros(k)
+            rnd, uni, used = np.random.random, np.random.uniform, 0
+            for j in range(k):
+                z = zs[j] = rnd() < p
+                if not z:
+                    yaw[j] = uni(lo, hi)
+                    tm[j] = uni(tl)
+                    sp[j] = uni(ms)
+                an[j] = uni(tau)
+                used += 2 if z else 5
+                if consumed is not None:
+                    consumed.append(used)
+            return zs, yaw, tm, sp, an
+        state = np.random.get_state()
+        block = np.random.random(5 * k)
+        step = np.where(block < p, 2, 5)                 # doubles a reset consumes IF it starts at this position
+        hop = step.tolist()
+        pos, starts = 0, [0] * k
+        for j in range(k):                               # the only sequential part: integer hops
+            starts[j] = pos
+            pos += hop[pos]
+        at = np.asarray(starts, dtype=np.intp)
+        zs = block[at] < p
+        go = ~zs
+        yaw, tm, sp = np.zeros(k), np.zeros(k), np.zeros(k)
+        a3 = at[go]
+        yaw[go] = float(lo) + (float(hi) - float(lo)) * block[a3 + 1]
+        tm[go] = float(tl) + (1.0 - float(tl)) * block[a3 + 2]
+        sp[go] = float(ms) + (1.0 - float(ms)) * block[a3 + 3]
+        an = tau + (1.0 - tau) * block[at + step[at] - 1]
+        np.random.set_state(state)
+        np.random.random(pos)                            # the stream is now where k reset_at calls leave it
+        if consumed is not None:
+            consumed.extend((at + step[at]).tolist())
         return zs, yaw, tm, sp, an
 
     def _settle_speculation(self):
-        """Undo the part of a speculative reset batch the caller did not claim: device state back to the snapshot, NumPy RNG back
-        to where the claimed prefix left it, the claimed resets re-applied."""
+        """Undo the part of a speculative reset batch the caller did not claim: device state back to the snapshot, the claimed
+        resets re-applied from the rows drawn for them, NumPy RNG back to where the claimed prefix left it - but only if the
+        global stream is still where the speculative draws left it; if something else drew from np.random in between, rewinding
+        would replay those foreign draws, so the stream is left alone (RuntimeWarning: it is then ahead of the plain protocol's
+        by the unclaimed draws)."""
         sp, self._spec, self._pending_done = self._spec, None, None
         if sp is not None:
             self.speculation_stats["claimed"] += sp["claimed"]
@@ -344,10 +428,20 @@ class VectorPhysEnv(VectorEnv):
         k = sp["claimed"]
         self.speculation_stats["rolled_back"] += len(sp["order"]) - k
         self._dev.restore_state()
-        np.random.set_state(sp["rng"])
         if k:
-            rows = self._draw_reset_rows(k)            # replays exactly the draws of the claimed prefix
-            self._dev.reset_draws(*rows, idx=sp["order"][:k])
+            self._dev.reset_draws(*[r[:k] for r in sp["rows"]], idx=sp["order"][:k])
+        now = np.random.get_state()
+        after = sp["rng_after"]
+        if now[0] == after[0] and now[2:] == after[2:] and np.array_equal(now[1], after[1]):
+            np.random.set_state(sp["rng"])
+            if k:
+                np.random.random(sp["consumed"][k - 1])   # one double per draw: exactly the claimed prefix's consumption
+        else:
+            import warnings
+            warnings.warn("VectorPhysEnv(speculative_resets=True): the global NumPy RNG was used by other code between the "
+                          "reset_at calls of one tick; the unclaimed speculative draws are not rewound", RuntimeWarning,
+                          stacklevel=3)
+            self.speculation_stats["foreign_rng_use"] = self.speculation_stats.get("foreign_rng_use", 0) + 1
         self._cache = {}
 
     def reset_at(self, index):
@@ -363,10 +457,12 @@ class VectorPhysEnv(VectorEnv):
         elif self._pending_done is not None and self._pending_done.size > 1 and int(self._pending_done[0]) == index:
             order, self._pending_done = self._pending_done, None
             rng = np.random.get_state()
-            rows = self._draw_reset_rows(order.size)
+            consumed = []
+            rows = self._draw_reset_rows(order.size, consumed)
             self._dev.snapshot_state()
             obs = self._dev.reset_draws(*rows, idx=order)
-            self._spec = {"order": order, "obs": obs, "claimed": 1, "rng": rng}
+            self._spec = {"order": order, "obs": obs, "claimed": 1, "rng": rng, "rng_after": np.random.get_state(),
+                          "rows": rows, "consumed": consumed}
             self.speculation_stats["batches"] += 1
             self._cache = {}
             return obs[0].copy()
@@ -468,12 +564,15 @@ def _register():
     fills q1physrl_amd.registry so `q1physrl_amd.make('Q1PhysEnv-v0')` works without gym."""
     from . import registry
     registry.register('Q1PhysEnv-v0', PhysEnv, {'config': Config.get_default()})
-    try:                                            # pragma: no cover - gym is not in this image
-        import gym.envs.registration as reg
+    if _gym is None:
+        return
+    import gym.envs.registration as reg
+    try:
         reg.register(id='Q1PhysEnv-v0', entry_point=f'{__name__}:PhysEnv', nondeterministic=False,
                      kwargs={'config': Config.get_default()})
-    except Exception:                               # noqa: BLE001 - no gym, or already registered
-        pass
+    except Exception as ex:                          # noqa: BLE001 - gym.error.Error('Cannot re-register id: ...') only
+        if 're-register' not in str(ex) and 'already registered' not in str(ex).lower():
+            raise
 
 
 _register()

@@ -35,7 +35,7 @@ class Inputs:
 @dataclasses.dataclass
 class PlayerState:
     z_pos: np.ndarray
-    vel: np.ndarray             # (N, 3) float32
+    vel: np.ndarray             # (N, 3) float32 (env) or float64 (from_df)
     on_ground: np.ndarray
     jump_released: np.ndarray
 
@@ -66,11 +66,15 @@ def _u8(a, n):
 def apply(inputs: Inputs, player_state: PlayerState, *, device: int = 0) -> PlayerState:
     """One frame of Quake player physics for N players (phys.py:184-197): returns a NEW PlayerState.
 
-    Velocity is float32 (as the env stores it); all other arithmetic follows the reference's float64
-    path.  pitch / roll of all zeros take the yaw-only basis the env uses.
+    As in the reference, the arithmetic follows the dtype of `player_state.vel`: float32 (what the env stores: friction
+    speed, the +270 jump add and the stored result are float32) or float64 (what PlayerState.from_df yields, phys.py:168-170,
+    the demo-analysis path: nothing is rounded to float32) - the returned vel has the same dtype.  Other dtypes are treated as
+    float64, like NumPy's promotion would.  pitch / roll of all zeros take the yaw-only basis the env uses.
     """
     lib = _lib.load()
-    vel = np.ascontiguousarray(player_state.vel, dtype=np.float32)
+    v_in = np.asarray(player_state.vel)
+    vdt = np.float32 if v_in.dtype == np.float32 else np.float64
+    vel = np.ascontiguousarray(v_in, dtype=vdt)
     n = vel.shape[0]
     assert vel.shape == (n, 3)
     pitch = np.asarray(inputs.pitch)
@@ -78,11 +82,12 @@ def apply(inputs: Inputs, player_state: PlayerState, *, device: int = 0) -> Play
     pitch = _f64(pitch, n) if np.any(pitch != 0) else None
     roll = _f64(roll, n) if np.any(roll != 0) else None
     out_z = np.empty((n,), np.float64)
-    out_vel = np.empty((n, 3), np.float32)
+    out_vel = np.empty((n, 3), vdt)
     out_og = np.empty((n,), np.uint8)
     out_jr = np.empty((n,), np.uint8)
     args = [_f64(inputs.yaw, n), pitch, roll, _f64(inputs.fmove, n), _f64(inputs.smove, n), _u8(inputs.button2, n),
             _f64(inputs.time_delta, n), _f64(player_state.z_pos, n), vel, _u8(player_state.on_ground, n),
             _u8(player_state.jump_released, n), out_z, out_vel, out_og, out_jr]
-    _lib.check(lib.q1phys_apply_host(int(device), n, *[_lib.ptr(a) for a in args]))
+    fn = lib.q1phys_apply_host if vdt == np.float32 else lib.q1phys_apply_host_f64
+    _lib.check(fn(int(device), n, *[_lib.ptr(a) for a in args]))
     return PlayerState(out_z, out_vel, out_og.view(np.bool_), out_jr.view(np.bool_))

@@ -72,7 +72,9 @@ class GaussianSquashedGaussian:
 
 
 class Categorical2:
-    """RLlib's TF Categorical on a Discrete(2) space: logits (B, 2)."""
+    """RLlib's TF Categorical on a Discrete(M) space: logits (B, M) - M = 2 for a key, M = 2S+1 for a discrete mouse
+    (Config.discrete_yaw_steps = S, env.py:216-219; the reference obtains it from ModelCatalog.get_action_dist,
+    action_dist.py:221-222)."""
 
     def __init__(self, logits):
         self.logits = logits
@@ -80,7 +82,10 @@ class Categorical2:
 
     def sample(self, generator=None):
         u = torch.rand(self.logits.shape[0], device=self.logits.device, generator=generator)
-        return (u < torch.exp(self.logprobs[:, 1])).long()
+        if self.logits.shape[1] == 2:
+            return (u < torch.exp(self.logprobs[:, 1])).long()
+        cdf = torch.cumsum(torch.exp(self.logprobs), dim=1)                   # inverse CDF, like the sampling kernel
+        return torch.clamp((cdf <= u[:, None]).sum(dim=1), max=self.logits.shape[1] - 1)
 
     def deterministic_sample(self):
         return torch.argmax(self.logits, dim=-1)
@@ -95,37 +100,70 @@ class Categorical2:
         return torch.sum(torch.exp(self.logprobs) * (self.logprobs - other.logprobs), dim=1)
 
 
+CategoricalN = Categorical2
+
+
+def policy_row_width(num_keys=4, discrete_yaw_steps=-1, allow_yaw=True):
+    """Q1PhysActionDist.required_model_output_shape (action_dist.py:236-241): two logits per key, then (mean, log_std) of the
+    continuous mouse, or the 2S+1 logits of a discrete mouse, or nothing without a mouse dimension."""
+    if not allow_yaw:
+        return 2 * num_keys
+    return 2 * num_keys + (2 if discrete_yaw_steps == -1 else 2 * discrete_yaw_steps + 1)
+
+
 class Q1PhysActionDist:
     """Tuple distribution over (key_0 .. key_{K-1}, mouse) (action_dist.py:199-243).
 
-    inputs: (B, 2K + 2) = K x (logit0, logit1), then (mean, log_std).  Actions are (keys (B,K) int64, mouse (B,1) float)."""
+    inputs: (B, 2K + 2) = K x (logit0, logit1), then (mean, log_std); with discrete_yaw_steps = S > 0 the mouse child is a
+    Categorical over 2S+1 steps and the row is (B, 2K + 2S+1); without a mouse dimension (allow_yaw=False) it is (B, 2K).
+    Actions are (keys (B,K) int64, mouse (B,1) float - the step index for a discrete mouse)."""
 
-    def __init__(self, inputs, action_range, num_keys=4):
+    def __init__(self, inputs, action_range, num_keys=4, discrete_yaw_steps=-1, allow_yaw=True):
         self.num_keys = num_keys
+        self.discrete = allow_yaw and discrete_yaw_steps != -1
         self.keys = [Categorical2(inputs[:, 2 * k:2 * k + 2]) for k in range(num_keys)]
-        self.mouse = GaussianSquashedGaussian(inputs[:, 2 * num_keys:2 * num_keys + 2], low=-float(action_range), high=float(action_range))
+        if not allow_yaw:
+            self.mouse = None
+        elif self.discrete:
+            self.mouse = CategoricalN(inputs[:, 2 * num_keys:2 * num_keys + 2 * discrete_yaw_steps + 1])
+        else:
+            self.mouse = GaussianSquashedGaussian(inputs[:, 2 * num_keys:2 * num_keys + 2], low=-float(action_range), high=float(action_range))
 
     @staticmethod
-    def required_model_output_shape(num_keys=4):                              # :236-241
-        return 2 * num_keys + 2
+    def required_model_output_shape(num_keys=4, discrete_yaw_steps=-1, allow_yaw=True):   # :236-241
+        return policy_row_width(num_keys, discrete_yaw_steps, allow_yaw)
+
+    def _mouse_value(self, m):
+        return m.view(-1, 1).to(self.keys[0].logits.dtype) if self.discrete else m
 
     def sample(self, generator=None):
-        return torch.stack([c.sample(generator) for c in self.keys], dim=1), self.mouse.sample(generator)
+        keys = torch.stack([c.sample(generator) for c in self.keys], dim=1)
+        if self.mouse is None:
+            return keys, torch.zeros((keys.shape[0], 1), dtype=self.keys[0].logits.dtype, device=keys.device)
+        return keys, self._mouse_value(self.mouse.sample(generator))
 
     def deterministic_sample(self):
-        return torch.stack([c.deterministic_sample() for c in self.keys], dim=1), self.mouse.deterministic_sample()
+        keys = torch.stack([c.deterministic_sample() for c in self.keys], dim=1)
+        if self.mouse is None:
+            return keys, torch.zeros((keys.shape[0], 1), dtype=self.keys[0].logits.dtype, device=keys.device)
+        return keys, self._mouse_value(self.mouse.deterministic_sample())
 
     def logp(self, keys, mouse):
-        lp = self.mouse.logp(mouse)
+        if self.mouse is None:
+            lp = 0.0
+        elif self.discrete:
+            lp = self.mouse.logp(mouse.reshape(-1))
+        else:
+            lp = self.mouse.logp(mouse)
         for k, c in enumerate(self.keys):
             lp = lp + c.logp(keys[:, k])
         return lp
 
     def entropy(self):
-        return sum(c.entropy() for c in self.keys) + self.mouse.entropy()
+        return sum(c.entropy() for c in self.keys) + (self.mouse.entropy() if self.mouse is not None else 0.0)
 
     def kl(self, other):
-        return sum(a.kl(b) for a, b in zip(self.keys, other.keys)) + self.mouse.kl(other.mouse)
+        return sum(a.kl(b) for a, b in zip(self.keys, other.keys)) + (self.mouse.kl(other.mouse) if self.mouse is not None else 0.0)
 
 
 def pack_keys(keys: torch.Tensor) -> torch.Tensor:
@@ -138,9 +176,10 @@ class Q1Policy(nn.Module):
     """RLlib fcnet as used by the reference run (params.yml + PPO defaults): tanh MLP 6 -> 256 -> 256 -> 2K+2 and a
     separate value MLP 6 -> 256 -> 256 -> 1 (the WR checkpoint has 70 154 + 67 841 = 137 995 parameters)."""
 
-    def __init__(self, num_keys=4, hidden=256, obs_dim=6):
+    def __init__(self, num_keys=4, hidden=256, obs_dim=6, discrete_yaw_steps=-1, allow_yaw=True):
         super().__init__()
-        out = Q1PhysActionDist.required_model_output_shape(num_keys)
+        self.num_keys, self.discrete_yaw_steps, self.allow_yaw = num_keys, discrete_yaw_steps, allow_yaw
+        out = Q1PhysActionDist.required_model_output_shape(num_keys, discrete_yaw_steps, allow_yaw)
         self.pi = nn.Sequential(nn.Linear(obs_dim, hidden), nn.Tanh(), nn.Linear(hidden, hidden), nn.Tanh(), nn.Linear(hidden, out))
         self.vf = nn.Sequential(nn.Linear(obs_dim, hidden), nn.Tanh(), nn.Linear(hidden, hidden), nn.Tanh(), nn.Linear(hidden, 1))
         with torch.no_grad():                      # RLlib: normc_initializer(0.01) on the logits layer -> near-uniform start
@@ -174,7 +213,7 @@ class FusedPolicyForward:
     """Inference-side twin of a Q1Policy for the sampler loop: both networks evaluated by the fused gfx950 kernel
     (q1env_policy_forward: all three layers on the matrix cores with float16 operands and
     float32 accumulation; biases and tanh float32).  The float32 torch modules stay the learner's master copy; call refresh() after an optimiser step.
-    Callable like the module: fused(obs) -> (logits (N,10) float32, value (N,) float32)."""
+    Callable like the module: fused(obs) -> (logits (N, row width <= 32) float32, value (N,) float32)."""
 
     def __init__(self, policy: Q1Policy, env):
         self.policy, self.env = policy, env
@@ -193,6 +232,8 @@ class FusedPolicyForward:
         W2 rows multiplied by 2 log2(e) before the float16 rounding (tanh's exp2 argument is then the accumulator itself)."""
         for name, net in (("pi", self.policy.pi), ("vf", self.policy.vf)):
             l1, l2, l3 = net[0], net[2], net[4]
+            if l3.out_features > 32:
+                raise ValueError(f"FusedPolicyForward: {l3.out_features} outputs do not fit the kernel's one 32-row output tile")
             # float16 operands: fine for weights of O(1..10) (the WR checkpoint's largest is 7.4); refuse silently wrong results
             wmax = max(float(l.weight.abs().max()) for l in (l1, l2, l3)) * TANH_PRESCALE
             if not wmax < 6.0e4:

@@ -17,10 +17,11 @@ import torch.distributed as dist
 from .policy import Q1PhysActionDist
 
 
-def ppo_loss(policy, batch, action_range, clip_param, vf_clip_param, vf_loss_coeff, entropy_coeff, kl_coeff, num_keys=4):
+def ppo_loss(policy, batch, action_range, clip_param, vf_clip_param, vf_loss_coeff, entropy_coeff, kl_coeff, num_keys=4,
+             discrete_yaw_steps=-1, allow_yaw=True):
     logits, value = policy(batch["obs"])
-    new = Q1PhysActionDist(logits, action_range, num_keys)
-    old = Q1PhysActionDist(batch["old_logits"], action_range, num_keys)
+    new = Q1PhysActionDist(logits, action_range, num_keys, discrete_yaw_steps, allow_yaw)
+    old = Q1PhysActionDist(batch["old_logits"], action_range, num_keys, discrete_yaw_steps, allow_yaw)
     logp = new.logp(batch["keys"], batch["mouse"])
     ratio = torch.exp(logp - batch["logp"])
     adv = batch["adv"]
@@ -62,7 +63,8 @@ class PPOLearner:
 
     def __init__(self, policy, action_range, lr=5e-6, gamma=0.99, lam=0.95, clip_param=0.3, vf_clip_param=100.0,
                  vf_loss_coeff=1.0, entropy_coeff=0.01, kl_coeff=0.2, kl_target=0.0036, num_sgd_iter=30,
-                 minibatch_size=128, num_keys=4, seed=0, use_graph=False, fused_loss=False, env=None):
+                 minibatch_size=128, num_keys=4, seed=0, use_graph=False, fused_loss=False, env=None, discrete_yaw_steps=-1,
+                 allow_yaw=True):
         self.policy = policy
         self.action_range = float(action_range)
         self.gamma, self.lam = gamma, lam
@@ -70,6 +72,7 @@ class PPOLearner:
         self.vf_loss_coeff, self.entropy_coeff = vf_loss_coeff, entropy_coeff
         self.kl_coeff, self.kl_target = kl_coeff, kl_target
         self.num_sgd_iter, self.minibatch_size, self.num_keys = num_sgd_iter, minibatch_size, num_keys
+        self.discrete_yaw_steps, self.allow_yaw = discrete_yaw_steps, allow_yaw
         self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
         self.use_graph = bool(use_graph) and self.world == 1
         self.fused_loss, self.env = bool(fused_loss), env
@@ -110,7 +113,7 @@ class PPOLearner:
             stats = partials.sum(dim=0) / bsz
         else:
             loss, st = ppo_loss(self.policy, mb, self.action_range, self.clip_param, self.vf_clip_param, self.vf_loss_coeff,
-                                self.entropy_coeff, self._klc, self.num_keys)
+                                self.entropy_coeff, self._klc, self.num_keys, self.discrete_yaw_steps, self.allow_yaw)
             self.opt.zero_grad(set_to_none=True)
             loss.backward()
             stats = torch.stack([st[k].float() for k in STAT_KEYS])
@@ -127,6 +130,10 @@ class PPOLearner:
         for k, v in b.items():
             self._mb[k].copy_(v[:mb])
         snapshot = [p.detach().clone() for p in self.policy.parameters()]
+        # Adam's moments / step counts as they are NOW (empty before the very first step, accumulated on a re-capture after
+        # the minibatch size changed): the warm-up and capture steps below must not leave a trace in them either
+        opt_snapshot = {id(p): {k: (v.detach().clone() if torch.is_tensor(v) else v) for k, v in st.items()}
+                        for p, st in self.opt.state.items()}
 
         def one_step():
             self._acc += self._sgd_step(self._mb)
@@ -150,10 +157,14 @@ class PPOLearner:
         with torch.no_grad():
             for p, q in zip(self.policy.parameters(), snapshot):
                 p.copy_(q)
-            for st_ in self.opt.state.values():
-                for v_ in st_.values():
-                    if torch.is_tensor(v_):
-                        v_.zero_()
+            for p, st_ in self.opt.state.items():
+                saved = opt_snapshot.get(id(p))
+                for k_, v_ in st_.items():
+                    if torch.is_tensor(v_):          # in place: the captured graph holds these addresses
+                        if saved is not None and k_ in saved:
+                            v_.copy_(saved[k_])
+                        else:
+                            v_.zero_()
         self._graph = g
 
     def update(self, traj, adv, vtarg):

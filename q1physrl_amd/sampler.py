@@ -31,7 +31,9 @@ class GpuSampler:
         self.keys = torch.empty((t, n), dtype=torch.uint8, device=d)
         self.mouse = torch.empty((t, n), dtype=torch.float32, device=d)
         self.logp = torch.empty((t, n), dtype=torch.float32, device=d)
-        self.logits = torch.empty((t, n, 2 * env.num_keys + 2), dtype=torch.float32, device=d)   # behaviour-policy outputs
+        from .policy import policy_row_width
+        width = policy_row_width(env.num_keys, env.config.discrete_yaw_steps, env.config.allow_yaw)
+        self.logits = torch.empty((t, n, width), dtype=torch.float32, device=d)   # behaviour-policy outputs
         self.value = torch.empty((t + 1, n), dtype=torch.float32, device=d)
         self.reward = torch.empty((t, n), dtype=torch.float32, device=d)
         self.done = torch.empty((t, n), dtype=torch.uint8, device=d)

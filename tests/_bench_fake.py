@@ -41,8 +41,11 @@ class FakeDeviceEnv:
     def step_many_dev(self, ticks, action_format, act_a, act_b=0, obs_format=1, obs=0, reward=0, done=0, out_stride_ticks=0,
                       use_graph=True):
         self.calls.append(("step_many", ticks, int(use_graph)))
-        if int(use_graph) == 2:                      # prepare only
+        flags, use_graph = int(use_graph) & 12, int(use_graph) & 3
+        if use_graph == 2:                           # prepare only
             return
+        if flags & 4:
+            self.timer_start()
         n = self.n
         for t in range(ticks):
             ot = t if out_stride_ticks else 0
@@ -50,6 +53,16 @@ class FakeDeviceEnv:
                        _view(obs + 24 * ot * n, 6 * n, np.float32) if obs else None,
                        _view(reward + 4 * ot * n, n, np.float32) if reward else None,
                        _view(done + ot * n, n, np.uint8) if done else None)
+        if flags & 8:
+            self.timer_mark()
+
+    def snapshot_state(self):
+        import copy
+        self._snap = copy.deepcopy(self._env)
+
+    def restore_state(self):
+        import copy
+        self._env = copy.deepcopy(self._snap)
 
     def rollout_dev(self, ticks, action_format, act_a=0, act_b=0, rng_seed=0, obs_format=1, obs=0, reward=0, done=0,
                     auto_reset=False, return_sum=0):

@@ -39,7 +39,8 @@ def test_abi_version(lib):
 
 def test_struct_layout_matches_header():
     from q1physrl_amd import _lib
-    assert ctypes.sizeof(_lib.Q1Config) == 8 * 4 + 10 * 8 + 8
+    assert ctypes.sizeof(_lib.Q1Config) == 8 * 4 + 10 * 8 + 8 + 2 * 4      # + legacy_promotion, reserved0 (ABI v2)
+    assert _lib.Q1Config.legacy_promotion.offset == 120 and _lib.Q1Config.env_index_base.offset == 112
     assert ctypes.sizeof(_lib.Q1State) == 10 * ctypes.sizeof(ctypes.c_void_p)
 
 

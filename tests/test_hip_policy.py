@@ -455,3 +455,172 @@ def test_fused_loss_learner_matches_torch_loss_learner():
             assert a["kl_coeff"] == b["kl_coeff"] and a["sgd_steps"] == b["sgd_steps"]
             for k in ppo.STAT_KEYS:
                 assert abs(a[k] - b[k]) <= 1e-3 * max(1.0, abs(a[k])), (k, a[k], b[k])
+
+
+# ------------------------------------------------------------------------------------------------ discrete mouse (yaw_mode 2)
+DISCRETE = dict(discrete_yaw_steps=5, time_delta=0.013888888888888888)      # the Config of tests/golden/g4_discrete_yaw5.npz
+
+
+def test_policy_sample_discrete_mouse_matches_restatement():
+    """Config.discrete_yaw_steps = 5 (reference env.py:216-219: the mouse child is Discrete(11), a Categorical under RLlib's
+    ModelCatalog, action_dist.py:221-222): q1env_policy_sample's categorical branch against oracle/dist_oracle.py on the same
+    Philox draws, the torch Categorical's logp on the kernel's own samples, sample frequencies, and deterministic mode."""
+    import torch
+    from q1physrl_amd import policy as P
+    n, seed, counter, base = 40_000, 11, 5, 77_000_000_000
+    cfg, env = make_env(n, seed, base, **DISCRETE)
+    width = P.policy_row_width(4, 5)
+    rng = np.random.default_rng(3)
+    logits = rng.normal(0, 1.5, (n, width)).astype(np.float32)
+    logits[:2000, 8:] = np.float32(0.25)                     # exact ties: the arg-max must be the FIRST maximum
+    lt = torch.from_numpy(logits).cuda()
+    keys = torch.empty(n, dtype=torch.uint8, device="cuda")
+    mouse = torch.empty(n, dtype=torch.float32, device="cuda")
+    logp = torch.empty(n, dtype=torch.float32, device="cuda")
+    env._dev.policy_sample_dev(lt.data_ptr(), width, seed, counter, keys.data_ptr(), mouse.data_ptr(), logp.data_ptr())
+    torch.cuda.synchronize()
+    genv = np.arange(n, dtype=np.uint64) + np.uint64(base)
+    k2, m2, lp2, margin = DO.sample_from_philox(cfg, logits, seed, genv, counter)
+    sure = margin > 1e-5
+    assert sure.mean() > 0.995
+    mk = mouse.cpu().numpy()
+    assert np.array_equal(keys.cpu().numpy()[sure], k2[sure]) and np.array_equal(mk[sure], m2[sure])
+    assert mk.min() >= 0 and mk.max() <= 10 and np.array_equal(mk, np.round(mk))
+    lp = logp.cpu().numpy()
+    assert np.max(np.abs(lp[sure] - lp2[sure]) / np.maximum(np.abs(lp2[sure]), 1.0)) < 2e-5
+    dist = P.Q1PhysActionDist(lt.double(), float(np.float32(cfg.action_range)), 4, 5)
+    kbits = ((keys[:, None].long() >> torch.arange(4, device="cuda")) & 1)
+    lp_t = dist.logp(kbits, mouse.double().view(-1, 1)).cpu().numpy()
+    assert np.max(np.abs(lp - lp_t) / np.maximum(np.abs(lp_t), 1.0)) < 2e-5
+    # frequencies on the tied rows: uniform over 11 steps
+    freq = np.bincount(mk[:2000].astype(np.int64), minlength=11) / 2000.0
+    assert np.max(np.abs(freq - 1 / 11)) < 0.03
+    env._dev.policy_sample_dev(lt.data_ptr(), width, seed, counter, keys.data_ptr(), mouse.data_ptr(), logp.data_ptr(), True)
+    torch.cuda.synchronize()
+    kd, md, lpd, _ = DO.sample_from_philox(cfg, logits, seed, genv, counter, deterministic=True)
+    assert np.array_equal(keys.cpu().numpy(), kd) and np.array_equal(mouse.cpu().numpy(), md)
+    assert np.all(mouse.cpu().numpy()[:2000] == 0)            # first maximum of a tie
+    assert np.max(np.abs(logp.cpu().numpy() - lpd) / np.maximum(np.abs(lpd), 1.0)) < 2e-5
+    env.close()
+
+
+def test_discrete_mouse_sampler_tick_and_oracle_replay():
+    """The whole sampler tick with a discrete mouse: fused q1env_sample_step == the three separate kernels bit for bit, through
+    the torch policy AND the fused matrix-core forward (19 output rows); the stored actions replayed through the NumPy env oracle
+    (discrete decode branch, env.py:238) reproduce every stored reward and done flag of a 64-env slice until its first reset."""
+    import torch
+    from q1physrl_amd import policy as P
+    from q1physrl_amd.sampler import GpuSampler
+    n, T = 1000, 60
+    res = []
+    for fused_tick, fused_policy in ((False, False), (True, False), (True, True)):
+        torch.manual_seed(4)
+        cfg, env = make_env(n, seed=21, zero_start_prob=1.0, time_limit=0.6, **DISCRETE)
+        pol = P.Q1Policy(discrete_yaw_steps=5).cuda()
+        with torch.no_grad():
+            pol.pi[-1].weight.mul_(60.0)                       # spread the step distribution (normc 0.01 init is near-uniform)
+        s = GpuSampler(env, P.FusedPolicyForward(pol, env) if fused_policy else pol, horizon=T, fused_tick=fused_tick)
+        tr = {k: v.clone() for k, v in s.collect().items()}
+        res.append((tr, s.stats, env.get_state()))
+        env.close()
+    (ta, sa, ea), (tb, sb, eb), (tc, sc, ec) = res
+    assert sa == sb and sa["episodes"] >= n
+    for k in ta:
+        assert torch.equal(ta[k], tb[k]), k
+    for k in ea:
+        assert np.array_equal(ea[k], eb[k]), k
+    assert ta["logits"].shape == (T, n, 19) and tc["logits"].shape == (T, n, 19)
+    assert float((tc["logits"][0] - ta["logits"][0]).abs().max()) < 2e-2      # f16 matrix-core forward vs float32 modules, tick 0
+    mouse = ta["mouse"].cpu().numpy()
+    assert mouse.min() >= 0 and mouse.max() <= 10 and len(np.unique(mouse)) > 3
+    # oracle replay of envs 0..63 (zero starts: known initial state) over the first episode (43 ticks at time_limit 0.6)
+    m = 64
+    np.random.seed(0)
+    ora = O.OracleVectorEnv(O.OracleConfig(**{**cfg.__dict__, "num_envs": m}))
+    keys = ta["keys"].cpu().numpy()
+    rew, done = ta["reward"].cpu().numpy(), ta["done"].cpu().numpy()
+    first_done = int(np.argmax(done[:, 0]))
+    assert done[first_done, :m].all() and first_done > 30
+    for t in range(first_done + 1):
+        a = np.concatenate([((keys[t, :m, None] >> np.arange(4)) & 1).astype(np.float64), mouse[t, :m, None].astype(np.float64)], axis=1)
+        o, r, d, _ = ora.vector_step(a)
+        assert np.array_equal(r, rew[t, :m]) and np.array_equal(d, done[t, :m].astype(bool)), t
+        if t < first_done:
+            assert np.array_equal(o.astype(np.float32), ta["obs"][t + 1, :m].cpu().numpy()), t
+
+
+def test_ppo_loss_grad_kernel_discrete_mouse_matches_autograd_and_oracle():
+    import torch
+    from oracle import ppo_oracle as PO
+    from q1physrl_amd import ppo
+    from q1physrl_amd.policy import Q1PhysActionDist
+    torch.manual_seed(6)
+    bsz, steps, width = 3001, 5, 19
+    cfg, env = make_env(64, **DISCRETE)
+    g = torch.Generator(device="cuda").manual_seed(3)
+    rnd = lambda *sh, **kw: torch.randn(*sh, device="cuda", generator=g, **kw)
+    stride = 24                                                  # row stride wider than the row: the padding columns get zero gradient
+    old_full, new_full = 1.2 * rnd(bsz, stride), None
+    new_full = (old_full + 0.3 * rnd(bsz, stride)).contiguous()
+    old_logits = old_full[:, :width]
+    logits = new_full[:, :width].clone().requires_grad_(True)
+    with torch.no_grad():
+        dist_old = Q1PhysActionDist(old_logits, cfg.action_range, 4, steps)
+        keys, mouse = dist_old.sample(generator=g)
+        logp_old = dist_old.logp(keys, mouse) + 0.4 * rnd(bsz)
+    value_old = 50.0 * rnd(bsz)
+    value = (value_old + 60.0 * rnd(bsz) * (torch.rand(bsz, device="cuda", generator=g) < 0.5)).requires_grad_(True)
+    vtarg, adv, klc = value_old + 80.0 * rnd(bsz), rnd(bsz), 0.37
+
+    class Fixed(torch.nn.Module):
+        def forward(self, obs):
+            return logits, value
+    mb = {"obs": None, "old_logits": old_logits, "keys": keys, "mouse": mouse, "logp": logp_old, "adv": adv, "value": value_old, "vtarg": vtarg}
+    loss, st = ppo.ppo_loss(Fixed(), mb, cfg.action_range, 0.3, 100.0, 1.0, 0.01, klc, discrete_yaw_steps=steps)
+    loss.backward()
+    packed = (keys.long() << torch.arange(4, device="cuda")).sum(1).to(torch.uint8)
+    mouse_f = mouse.reshape(-1).float().contiguous()
+    dl = torch.full((bsz, stride), 7.0, device="cuda")
+    dv = torch.empty_like(value)
+    partials = torch.zeros(((bsz + 255) // 256, 5), device="cuda")
+    klc_dev = torch.tensor(klc, device="cuda")
+    env._dev.ppo_loss_grad_dev(bsz, new_full.data_ptr(), old_full.contiguous().data_ptr(), stride, packed.data_ptr(), mouse_f.data_ptr(),
+                               logp_old.data_ptr(), adv.data_ptr(), value.data_ptr(), value_old.data_ptr(), vtarg.data_ptr(), 0.3, 100.0,
+                               1.0, 0.01, klc_dev.data_ptr(), dl.data_ptr(), dv.data_ptr(), partials.data_ptr())
+    torch.cuda.synchronize()
+    stats = dict(zip(ppo.STAT_KEYS, (partials.double().sum(0) / bsz).tolist()))
+    for k in ppo.STAT_KEYS:
+        assert abs(stats[k] - float(st[k])) <= 3e-5 * max(1.0, abs(float(st[k]))), (k, stats[k], float(st[k]))
+    scale = float(logits.grad.abs().max())
+    assert float((dl[:, :width] - logits.grad).abs().max()) <= 3e-5 * scale
+    assert float(dl[:, width:].abs().max()) == 0.0
+    assert float((dv - value.grad).abs().max()) <= 1e-6 * float(value.grad.abs().max())
+    b = {"keys": keys.cpu().numpy(), "mouse": mouse.cpu().numpy(), "logp": logp_old.cpu().numpy().astype(np.float64),
+         "adv": adv.cpu().numpy().astype(np.float64), "value": value_old.cpu().numpy().astype(np.float64),
+         "vtarg": vtarg.cpu().numpy().astype(np.float64), "old_logits": old_logits.cpu().numpy()}
+    dlo, dvo, sto = PO.ppo_loss_grad_discrete(logits.detach().cpu().numpy(), value.detach().cpu().numpy(), b, steps, 0.3, 100.0, 1.0, 0.01, klc)
+    assert np.max(np.abs(dl[:, :width].cpu().numpy() - dlo)) <= 3e-5 * scale
+    for k in ppo.STAT_KEYS:
+        assert abs(stats[k] - sto[k]) <= 3e-5 * max(1.0, abs(sto[k])), k
+    env.close()
+
+
+def test_no_mouse_policy_row_and_rejected_widths():
+    """allow_yaw = False: the policy row is the key pairs only (8 columns) and the sampler tick runs; a row stride smaller than
+    the Config's row is refused loudly."""
+    import torch
+    from q1physrl_amd import _lib, policy as P
+    from q1physrl_amd.sampler import GpuSampler
+    cfg, env = make_env(512, seed=3, allow_yaw=False, time_limit=0.5)
+    pol = P.Q1Policy(allow_yaw=False).cuda()
+    s = GpuSampler(env, pol, horizon=40)
+    tr = s.collect()
+    torch.cuda.synchronize()
+    assert tr["logits"].shape == (40, 512, 8) and torch.isfinite(tr["logp"]).all() and s.stats["episodes"] >= 512
+    env.close()
+    cfg, env = make_env(64, **DISCRETE)
+    lt = torch.zeros((64, 19), device="cuda")
+    k, m = torch.empty(64, dtype=torch.uint8, device="cuda"), torch.empty(64, device="cuda")
+    with pytest.raises(_lib.Q1EnvError, match="row_stride"):
+        env._dev.policy_sample_dev(lt.data_ptr(), 18, 1, 0, k.data_ptr(), m.data_ptr())
+    env.close()

@@ -103,3 +103,143 @@ def test_player_state_helpers():
     df = ps.to_df()
     back = P.PlayerState.from_df(df)
     assert np.array_equal(back.vel, ps.vel) and np.array_equal(back.on_ground, ps.on_ground)
+
+
+# ---- vectorised reset draws (the RLlib reset_at sweep without 5 scalar np.random calls per env) ------------------------------
+class _DrawHost:
+    """Just enough of a VectorPhysEnv to call _draw_reset_rows without a device."""
+    _draw_reset_rows = E.VectorPhysEnv._draw_reset_rows
+
+    def __init__(self, config):
+        self._config = config
+
+
+def _plain_draws(c, k):
+    """The reference's reset_at draw order, one np.random call per draw (env.py:461-471)."""
+    zs, yaw, tm, sp, an = np.zeros(k, bool), np.zeros(k), np.zeros(k), np.zeros(k), np.zeros(k)
+    for j in range(k):
+        z = zs[j] = np.random.random() < c.zero_start_prob
+        yaw[j] = 0.0 if z else np.random.uniform(*c.initial_yaw_range)
+        tm[j] = 0.0 if z else np.random.uniform(c.time_limit)
+        sp[j] = 0.0 if z else np.random.uniform(c.max_initial_speed)
+        an[j] = np.random.uniform(2 * np.pi)
+    return zs, yaw, tm, sp, an
+
+
+@pytest.mark.parametrize("p,k", [(0.01, 1), (0.01, 2), (0.01, 3), (0.01, 1035), (0.5, 700), (1.0, 50), (0.0, 64), (0.3, 4097)])
+def test_vectorised_reset_draws_equal_the_scalar_protocol(p, k):
+    c = dataclasses.replace(E.Config.get_default(), num_envs=8, zero_start_prob=p, initial_yaw_range=(-30, 400), time_limit=7.5)
+    np.random.seed(1234 + k)
+    want = _plain_draws(c, k)
+    end_want = np.random.random(3)                       # where the global stream is afterwards
+    np.random.seed(1234 + k)
+    consumed = []
+    got = _DrawHost(c)._draw_reset_rows(k, consumed)
+    end_got = np.random.random(3)
+    for a, b in zip(want, got):
+        assert a.dtype == b.dtype and np.array_equal(a, b)
+    assert np.array_equal(end_want, end_got)
+    # cumulative consumption: 2 doubles per zero start, 5 otherwise - what a partial rollback rewinds to
+    assert consumed == np.cumsum(np.where(want[0], 2, 5)).tolist()
+    # rewinding to a claimed prefix lands exactly where the plain protocol would be after that many resets
+    j = k // 2
+    if j:
+        np.random.seed(1234 + k)
+        state = np.random.get_state()
+        _DrawHost(c)._draw_reset_rows(k)
+        np.random.set_state(state)
+        np.random.random(consumed[j - 1])
+        mine = np.random.random(2)
+        np.random.seed(1234 + k)
+        _plain_draws(c, j)
+        assert np.array_equal(mine, np.random.random(2))
+
+
+def test_numpy_promotion_default_follows_the_running_numpy(monkeypatch):
+    from q1physrl_amd import device
+    monkeypatch.delenv("Q1PHYSRL_NUMPY_PROMOTION", raising=False)
+    assert device.legacy_promotion_default() == (int(np.__version__.split(".")[0]) < 2)
+    cfg = dataclasses.replace(E.Config.get_default(), num_envs=4)
+    assert device.make_c_config(cfg).legacy_promotion == int(device.legacy_promotion_default())
+    assert device.make_c_config(cfg, numpy_promotion="legacy").legacy_promotion == 1
+    assert device.make_c_config(cfg, numpy_promotion="nep50").legacy_promotion == 0
+    monkeypatch.setenv("Q1PHYSRL_NUMPY_PROMOTION", "legacy")
+    assert device.make_c_config(cfg).legacy_promotion == 1
+    with pytest.raises(ValueError):
+        device.make_c_config(cfg, numpy_promotion="numpy1")
+
+
+# ---- gym integration (the reference is `class PhysEnv(gym.Env)`, registered at import: env.py:299, 516-521) -------------------
+_STUB_GYM = '''
+import sys, types
+gym = types.ModuleType("gym")
+class Env:
+    metadata = {"render.modes": []}
+    reward_range = (-float("inf"), float("inf"))
+    spec = None
+    @property
+    def unwrapped(self):
+        return self
+    def seed(self, seed=None):
+        return
+    def close(self):
+        pass
+class Error(Exception):
+    pass
+gym.Env = Env
+err = types.ModuleType("gym.error"); err.Error = Error
+envs = types.ModuleType("gym.envs")
+reg = types.ModuleType("gym.envs.registration")
+reg.calls = []
+def register(id, **kw):
+    if any(c[0] == id for c in reg.calls):
+        raise Error("Cannot re-register id: " + id)
+    reg.calls.append((id, kw))
+reg.register = register
+gym.error, gym.envs, envs.registration = err, envs, reg
+sys.modules.update({"gym": gym, "gym.error": err, "gym.envs": envs, "gym.envs.registration": reg})
+'''
+
+
+def test_physenv_is_a_gym_env_and_registers_when_gym_is_importable():
+    """With a gym on the path PhysEnv must BE a gym.Env (gym 0.17's EnvSpec.make does `env.unwrapped.spec = spec`; RLlib and
+    wrappers test isinstance) and importing the module must register Q1PhysEnv-v0 exactly as env.py:516-521 does; importing it
+    twice (the drop-in namespace re-exports it) must not fail, any other registration error must surface."""
+    import subprocess
+    import sys
+    code = _STUB_GYM + '''
+import importlib, dataclasses
+import q1physrl_amd.env as E
+import gym
+assert issubclass(E.PhysEnv, gym.Env)
+(i, kw), = gym.envs.registration.calls
+assert i == "Q1PhysEnv-v0" and kw["entry_point"] == "q1physrl_amd.env:PhysEnv" and kw["nondeterministic"] is False
+assert kw["kwargs"] == {"config": E.Config.get_default()}
+importlib.reload(E)                                   # "Cannot re-register id" is swallowed, nothing else
+e = E.PhysEnv.__new__(E.PhysEnv)                      # no device here: what gym.make does after constructing the env
+e.unwrapped.spec = "spec"
+assert e.spec == "spec" and e.seed(3) is None
+import q1physrl_env.env as D
+assert D.PhysEnv is E.PhysEnv or issubclass(D.PhysEnv, gym.Env)
+def boom(id, **kw):
+    raise RuntimeError("registry is broken")
+gym.envs.registration.register = boom
+try:
+    importlib.reload(E)
+except RuntimeError as ex:
+    assert "broken" in str(ex)
+else:
+    raise SystemExit("a failing registration was swallowed")
+print("OK")
+'''
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=root, timeout=120)
+    assert r.returncode == 0 and r.stdout.strip().endswith("OK"), r.stdout + r.stderr
+
+
+def test_physenv_without_gym_has_the_gym_env_attributes():
+    e = E.PhysEnv.__new__(E.PhysEnv)
+    assert e.unwrapped is e and e.spec is None and e.seed(1) is None and E.PhysEnv.metadata == {}
+    e.unwrapped.spec = 5
+    assert e.spec == 5

@@ -108,3 +108,59 @@ def test_g5_micro_vectors():
         assert np.array_equal(fm, fx["dec_out_fmove"][t]) and np.array_equal(j, fx["dec_out_jump"][t])
         assert bits_equal(dec["last_press"], fx["dec_out_lkpt"][t])
         assert np.array_equal(dec["last_keys"].astype(np.uint8), fx["dec_out_lk"][t])
+
+
+# ---- round-2 vectors (oracle/gen_golden_r2.py) -------------------------------------------------------------------------------
+LEGACY_FIXTURES = ["g3_legacy_promotion_params_yml_400", "g4_legacy_promotion_dt014_400"]
+
+
+@pytest.mark.parametrize("name", LEGACY_FIXTURES)
+def test_legacy_promotion_traces_bit_exact(name):
+    """env.py:230 as NumPy < 2 evaluates it (float64 product): traces generated from the reference with that promotion."""
+    fx = R.load(name)
+    res, env = R.replay(lambda kw: O.OracleVectorEnv(kw, legacy_promotion=True), fx, name.replace("g3_legacy", "g3_").replace("g4_legacy", "g4_"), GETTERS)
+    for k in ("obs", "reward", "done", "vel", "z_pos", "on_ground", "yaw", "time_remaining", "last_key_press_time", "last_keys",
+              "smove", "fmove", "jump"):
+        assert bits_equal(res[k], fx[k]), f"{name}: field {k} differs from the reference"
+    assert bits_equal(res["reset_obs"], fx["reset_obs"]) and bits_equal(env.yaw, fx["final_yaw"])
+    # ... and the fixture really pins the promotion: the NEP 50 product gives a different yaw track
+    res2, _ = R.replay(lambda kw: O.OracleVectorEnv(kw), fx, "g3_x", {"yaw": GETTERS["yaw"]})
+    assert not bits_equal(res2["yaw"], fx["yaw"])
+    rel = np.max(np.abs(res2["yaw"] - fx["yaw"]) / np.maximum(np.abs(fx["yaw"]), 1.0))
+    assert rel < (1e-6 if "dt014" in name else 1e-11)          # 7.6e-9 relative per tick for dt = 0.014, 6e-14 for params.yml's dt
+
+
+def test_g5b_apply_with_float64_velocity():
+    """phys.apply on PlayerState.from_df / Inputs.from_df data (float64 vel, per-frame dt, pitch / roll): no float32 anywhere."""
+    fx = R.load("g5b_apply_f64vel")
+    assert fx["ps_vel"].dtype == np.float64 and fx["out_vel"].dtype == np.float64
+    z, vel, og, jr = O.phys_apply_general(fx["in_yaw"], fx["in_pitch"], fx["in_roll"], fx["in_fmove"], fx["in_smove"], fx["in_button2"],
+                                          fx["in_time_delta"], fx["ps_z_pos"], fx["ps_vel"], fx["ps_on_ground"], fx["ps_jump_released"])
+    assert bits_equal(z, fx["out_z_pos"]) and bits_equal(vel, fx["out_vel"])
+    assert np.array_equal(og, fx["out_on_ground"]) and np.array_equal(jr, fx["out_jump_released"])
+    # the same function on the float32 micro-vector of G5 reproduces the env-path arithmetic
+    g5 = R.load("g5_micro")
+    z, vel, og, jr = O.phys_apply_general(g5["ap_in_yaw"], g5["ap_in_pitch"], g5["ap_in_roll"], g5["ap_in_fmove"], g5["ap_in_smove"],
+                                          g5["ap_in_button2"], g5["ap_in_time_delta"], g5["ap_ps_z_pos"], g5["ap_ps_vel"],
+                                          g5["ap_ps_on_ground"], g5["ap_ps_jump_released"])
+    assert bits_equal(vel, g5["ap_out_vel"]) and bits_equal(z, g5["ap_out_z_pos"]) and np.array_equal(og, g5["ap_out_on_ground"])
+
+
+def test_g6_reset_draws_fixture_matches_the_oracle_draw_order():
+    """G6: the reference's vector_reset state for 100 000 envs.  The oracle, seeded the same, reproduces it draw for
+    draw (pins env.py:432-451 incl. the one-argument uniform quirk); the fixture's ranges are the quirk's."""
+    import json
+    fx = R.load("g6_reset_draws")
+    kw = json.loads(str(fx["config_json"]))
+    kw["initial_yaw_range"] = tuple(kw["initial_yaw_range"])
+    np.random.seed(int(fx["seed"]))
+    env = O.OracleVectorEnv(O.OracleConfig(num_envs=fx["yaw"].shape[0], **kw))
+    assert np.array_equal(env.zero_start, fx["zero_start"])
+    assert np.array_equal(env.yaw.astype(np.float32), fx["yaw"]) and np.array_equal(env.t_rem.astype(np.float32), fx["time_remaining"])
+    v = env.st["vel"]
+    assert np.array_equal(np.hypot(v[:, 0].astype(np.float64), v[:, 1].astype(np.float64)).astype(np.float32), fx["speed"])
+    nz = ~fx["zero_start"]
+    assert fx["time_remaining"][nz].min() > 1.0 and fx["time_remaining"][nz].max() <= 10.0      # uniform(10) == uniform(10, 1)
+    assert fx["speed"][nz].min() > 0.999 and fx["speed"][nz].max() <= 700.0
+    assert fx["angle"][nz].min() > 0.999 and fx["angle"][nz].max() <= 2 * np.pi + 1e-6
+    assert abs(fx["zero_start"].mean() - 0.01) < 0.002

@@ -146,3 +146,48 @@ def test_closed_form_loss_gradient_matches_autograd():
     for k in ppo.STAT_KEYS:
         assert abs(st[k] - float(tst[k])) <= 1e-10 * max(1.0, abs(float(tst[k]))), k
     assert abs(st["total_loss"] - PO.ppo_loss(new, v_new, b, AR, 0.3, 100.0, 1.0, 0.01, 0.37)[0]) <= 1e-10
+
+
+def test_discrete_mouse_closed_form_gradient_matches_autograd():
+    """Discrete mouse (Config.discrete_yaw_steps = 5: the Tuple's last child is Discrete(11), reference env.py:216-219, taken
+    through ModelCatalog's Categorical, action_dist.py:221-222): oracle/ppo_oracle.ppo_loss_grad_discrete (float64 restatement of
+    the kernel's yaw_mode == 2 branch) against float64 torch autograd of ppo.ppo_loss over the torch Categorical."""
+    import torch
+    from q1physrl_amd import ppo
+    from q1physrl_amd.policy import Q1PhysActionDist, policy_row_width
+    rng = np.random.default_rng(8)
+    bsz, steps = 2000, 5
+    width = policy_row_width(4, steps)
+    assert width == 19
+    old = rng.normal(0, 1.2, (bsz, width))
+    new = old + 0.3 * rng.normal(0, 1, (bsz, width))
+    keys = rng.integers(0, 2, (bsz, 4))
+    mouse = rng.integers(0, 2 * steps + 1, (bsz, 1)).astype(np.float64)
+    d_old = Q1PhysActionDist(torch.tensor(old), AR, 4, steps)
+    lp_old = d_old.logp(torch.tensor(keys), torch.tensor(mouse)).numpy() + 0.4 * rng.normal(0, 1, bsz)
+    v_old = 50 * rng.normal(0, 1, bsz)
+    v_new = v_old + 60 * rng.normal(0, 1, bsz) * (rng.random(bsz) < 0.5)
+    b = {"keys": keys, "mouse": mouse, "logp": lp_old, "adv": rng.normal(0, 1, bsz), "value": v_old, "vtarg": v_old + 80 * rng.normal(0, 1, bsz),
+         "old_logits": old}
+    dl, dv, st = PO.ppo_loss_grad_discrete(new, v_new, b, steps, 0.3, 100.0, 1.0, 0.01, 0.37)
+    lt, vt = torch.tensor(new, requires_grad=True), torch.tensor(v_new, requires_grad=True)
+
+    class Fixed(torch.nn.Module):
+        def forward(self, obs):
+            return lt, vt
+    loss, tst = ppo.ppo_loss(Fixed(), {k: (None if v is None else torch.as_tensor(v)) for k, v in {**b, "obs": None}.items()}, AR, 0.3, 100.0,
+                             1.0, 0.01, 0.37, discrete_yaw_steps=steps)
+    loss.backward()
+    assert np.max(np.abs(dl - lt.grad.numpy())) <= 1e-12 * max(1.0, np.abs(dl).max()) + 1e-15
+    assert np.max(np.abs(dv - vt.grad.numpy())) <= 1e-12 * np.abs(dv).max()
+    for k in ppo.STAT_KEYS:
+        assert abs(st[k] - float(tst[k])) <= 1e-10 * max(1.0, abs(float(tst[k]))), k
+    # the sampled-step bookkeeping of the torch distribution: inverse-CDF sampling reproduces softmax frequencies
+    g = torch.Generator().manual_seed(0)
+    big = Q1PhysActionDist(torch.tensor(np.tile(new[:1], (200000, 1))), AR, 4, steps)
+    _, m = big.sample(generator=g)
+    freq = np.bincount(m.reshape(-1).long().numpy(), minlength=11) / 200000
+    p = np.exp(new[0, 8:] - new[0, 8:].max()); p /= p.sum()
+    assert np.max(np.abs(freq - p)) < 5e-3
+    kd, md = big.deterministic_sample()
+    assert int(md[0, 0]) == int(np.argmax(new[0, 8:]))
