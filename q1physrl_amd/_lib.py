@@ -8,7 +8,8 @@ import os
 import numpy as np
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, "libq1env.so")
+# Q1ENV_LIB_PATH selects another build of the SAME library (tools/asan_check.sh: the AddressSanitizer build of the host side)
+LIB_PATH = os.environ.get("Q1ENV_LIB_PATH") or os.path.join(_PKG, "libq1env.so")
 
 ABI_VERSION = 2
 ACT_F64_ROWS, ACT_F32_ROWS, ACT_PACKED, ACT_RANDOM = 0, 1, 2, 3

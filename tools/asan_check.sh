@@ -1,0 +1,32 @@
+#!/bin/bash
+# AddressSanitizer job for the HOST side of libq1env: builds the library with -fsanitize=address on the host
+# code only (-fno-gpu-sanitize: device code unchanged, same kernels), preloads the ASan runtime into python and runs
+#   (1) the CPU ABI tests (symbol table, struct layout, loud failure without a device),
+#   (2) when a GPU is present: __graft_entry__.smoke() + the staging-heavy compat calls (step_host small/large, reset_at,
+#       reset_many, decode_host, phys.apply float32/float64, get/set state) that exercise the pointer arithmetic of the *_host paths.
+# Output: gpurun_out/asan/{build.log,cpu.log,gpu.log}; exit status 0 = no ASan report.
+set -u
+ROOT=$(cd "$(dirname "$0")/.." && pwd)
+cd "$ROOT"
+OUT=gpurun_out/asan
+mkdir -p $OUT
+SO=q1physrl_amd/libq1env_asan.so
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O1 -g -std=c++17 -ffp-contract=off -fPIC -shared -Wall -Wno-unused-function \
+    -mllvm -amdgpu-kernarg-preload-count=16 -fsanitize=address -fno-gpu-sanitize -shared-libsan \
+    q1physrl_amd/csrc/q1env.hip -o $SO > $OUT/build.log 2>&1 || { echo "ASAN BUILD FAILED"; tail -20 $OUT/build.log; exit 2; }
+RT=$(/opt/rocm/lib/llvm/bin/clang -print-file-name=libclang_rt.asan-x86_64.so)
+[ -f "$RT" ] || RT=$(ls /opt/rocm/lib/llvm/lib/clang/*/lib/linux/libclang_rt.asan-x86_64.so | head -1)
+export Q1ENV_LIB_PATH=$ROOT/$SO
+export ASAN_OPTIONS=detect_leaks=0:protect_shadow_gap=0:abort_on_error=0:halt_on_error=1:log_path=$ROOT/$OUT/report
+rm -f $OUT/report.*
+LD_PRELOAD=$RT python -m pytest tests/test_abi_symbols.py -q -x -p no:cacheprovider > $OUT/cpu.log 2>&1
+rc1=$?
+rc2=0
+if python -c "import torch,sys; sys.exit(0 if torch.cuda.is_available() else 1)" 2>/dev/null; then
+    LD_PRELOAD=$RT timeout 600 python tools/asan_gpu_calls.py > $OUT/gpu.log 2>&1
+    rc2=$?
+fi
+n=$(ls $OUT/report.* 2>/dev/null | wc -l)
+echo "asan: cpu rc=$rc1 gpu rc=$rc2 reports=$n"
+tail -3 $OUT/cpu.log; [ -f $OUT/gpu.log ] && tail -5 $OUT/gpu.log
+[ "$rc1" = 0 ] && [ "$rc2" = 0 ] && [ "$n" = 0 ]

@@ -1,0 +1,41 @@
+"""The host-side staging paths of libq1env under AddressSanitizer (run by tools/asan_check.sh with the ASan build selected through
+Q1ENV_LIB_PATH): every *_host entry point at a size below and above the packed-staging threshold, odd sizes, index lists."""
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import __graft_entry__ as G  # noqa: E402
+from q1physrl_amd import _lib, env as E, phys as P  # noqa: E402
+
+assert _lib.LIB_PATH.endswith("libq1env_asan.so"), _lib.LIB_PATH
+G.smoke()
+rng = np.random.default_rng(0)
+for n in (1, 63, 4097, 16384, 16385, 70001):
+    cfg = dict(E.Config.get_default().__dict__, num_envs=n, time_limit=0.2)
+    e = E.VectorPhysEnv(cfg, speculative_resets=(n == 4097))
+    for t in range(20):
+        a = np.concatenate([(rng.random((n, 4)) < 0.5).astype(np.float64), rng.uniform(-10, 10, (n, 1))], axis=1)
+        obs, rew, done, infos = e.vector_step(a if t % 2 else [tuple(r) for r in a[: min(n, 50)]] + list(a[min(n, 50):]))
+        idx = np.flatnonzero(done)
+        if idx.size and t % 3 == 0:
+            e.reset_many(idx)
+        else:
+            for i in idx[:40]:
+                e.reset_at(int(i))
+    st = e.get_state()
+    e.set_state(**st)
+    _ = e.player_state, e._yaw, e._get_obs(), e._get_obs_at(n - 1)
+    y, s, f, j = e._action_decoder.map(a, np.zeros(n, np.float32), np.full(n, 5.0))
+    e.close()
+    m = max(n // 7, 1)
+    ins = P.Inputs(rng.uniform(-720, 720, m), np.zeros(m), rng.uniform(-5, 5, m), rng.choice([0., 400., 800.], m), rng.choice([0., 530., -1060.], m),
+                   rng.random(m) < 0.5, np.full(m, 1 / 72))
+    for dt in (np.float32, np.float64):
+        ps = P.PlayerState(rng.uniform(24.04, 60, m), rng.uniform(-500, 500, (m, 3)).astype(dt), rng.random(m) < 0.5, np.ones(m, bool))
+        out = P.apply(ins, ps)
+        assert out.vel.dtype == dt
+    print("ok", n, flush=True)
+_lib.pinned_pool().trim()
+print("ASAN_GPU_CALLS_OK")
