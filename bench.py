@@ -30,6 +30,7 @@ ranks of t1 - t0 (host wall clock); `roofline` uses the HIP-event time between t
 Output: ONE JSON line on rank 0 (contract in the task statement) with `roofline` and `cpu_baseline`.
 """
 import argparse
+import functools
 import importlib
 import json
 import os
@@ -301,21 +302,25 @@ def main(argv=None):
     obsT = rewT = doneT = None
     dsync()
 
-    def run_ticks(mode, k, tick0, prepare=False, timed=False):
-        """k ticks starting at episode phase tick0 % 720; resets every env on device at each episode end.
-        prepare=True only builds (instantiates + uploads) the hipGraphs this sequence will replay, no launch.
-        timed=True brackets the sequence with the handle's timer events (HIP events on the launch stream); in step mode they
-        are recorded inside the q1env_step_many call of the first / last chunk, next to the launch itself."""
+    def plan_ticks(mode, k, tick0, prepare=False, timed=False):
+        """The calls that run k ticks starting at episode phase tick0 % 720 (all envs are reset on device at each episode end),
+        as a list of zero-argument callables with every pointer and flag already resolved - so that the timed region is
+        nothing but the calls themselves - plus the number of kernel launches they make.
+        prepare=True: only build (instantiate + upload) the hipGraphs the sequence replays, no launch.
+        timed=True: bracket the sequence with the handle's timer events (HIP events on the launch stream); in step mode they are
+        recorded inside the q1env_step_many call of the first / last chunk, next to the launch itself."""
         nonlocal obsT, rewT, doneT
         if mode == "rollout" and obsT is None:        # tick-major per-tick outputs of a whole episode
             obsT = torch.empty((EPISODE_TICKS, n, 6), dtype=torch.float32, device=d)
             rewT = torch.empty((EPISODE_TICKS, n), dtype=torch.float32, device=d)
             doneT = torch.empty((EPISODE_TICKS, n), dtype=torch.uint8, device=d)
+        calls = []
         t, left, launches = tick0, k, 0
         started = stopped = False
         if timed and mode != "step":
-            dev.timer_start()
+            calls.append(dev.timer_start)
             started = True
+        o1, r1, d1 = obs1.data_ptr(), rew1.data_ptr(), done1.data_ptr()
         while left > 0:
             ph = t % EPISODE_TICKS
             chunk = min(left, EPISODE_TICKS - ph)
@@ -325,8 +330,7 @@ def main(argv=None):
             if mode == "step":
                 if prepare:
                     if not args.no_graph:
-                        dev.step_many_dev(chunk, _lib.ACT_PACKED, ka, ma, _lib.OBS_F32, obs1.data_ptr(), rew1.data_ptr(),
-                                          done1.data_ptr(), out_stride_ticks=0, use_graph=2)
+                        calls.append(functools.partial(dev.step_many_dev, chunk, _lib.ACT_PACKED, ka, ma, _lib.OBS_F32, o1, r1, d1, 0, 2))
                 else:
                     flags = 0 if args.no_graph else 1
                     if timed and not started:
@@ -335,22 +339,24 @@ def main(argv=None):
                     if timed and left == chunk and not ends_episode:
                         flags |= _lib.TIMER_STOP
                         stopped = True
-                    dev.step_many_dev(chunk, _lib.ACT_PACKED, ka, ma, _lib.OBS_F32, obs1.data_ptr(), rew1.data_ptr(),
-                                      done1.data_ptr(), out_stride_ticks=0, use_graph=flags)
+                    calls.append(functools.partial(dev.step_many_dev, chunk, _lib.ACT_PACKED, ka, ma, _lib.OBS_F32, o1, r1, d1, 0, flags))
                 launches += chunk
-            elif prepare:
-                launches += 1
             else:
-                dev.rollout_dev(chunk, _lib.ACT_PACKED, ka, ma, 0, _lib.OBS_F32, obsT.data_ptr(), rewT.data_ptr(),
-                                doneT.data_ptr(), auto_reset=False)
+                if not prepare:
+                    calls.append(functools.partial(dev.rollout_dev, chunk, _lib.ACT_PACKED, ka, ma, 0, _lib.OBS_F32, obsT.data_ptr(),
+                                                   rewT.data_ptr(), doneT.data_ptr(), False))
                 launches += 1
             t += chunk
             left -= chunk
             if ends_episode and not prepare:
-                dev.reset_philox_dev(seed=99, done_only=True)        # zero_start_prob = 1: every env back to the start line
+                calls.append(functools.partial(dev.reset_philox_dev, 99, 0, True))   # zero_start_prob = 1: every env back to the start line
         if timed and not stopped:
-            dev.timer_mark()
-        return launches
+            calls.append(dev.timer_mark)
+        return calls, launches
+
+    def run(calls):
+        for f in calls:
+            f()
 
     def barrier():
         dev.sync()
@@ -363,16 +369,19 @@ def main(argv=None):
         # state saved and restored around it, so that neither the warm-up nor the timed region pays a first-replay cost (kernel
         # code objects, the graph's packets, the TLB entries of the action slabs) - in production a graph is replayed thousands
         # of times.  The env state the W warm-up ticks start from is the state before this preparation.
-        run_ticks(mode, warmup, 0, prepare=True)
-        run_ticks(mode, steps, warmup, prepare=True)
+        run(plan_ticks(mode, warmup, 0, prepare=True)[0])
+        run(plan_ticks(mode, steps, warmup, prepare=True)[0])
+        warm_calls, _ = plan_ticks(mode, warmup, 0)
+        dry_calls, _ = plan_ticks(mode, steps, warmup)
+        timed_calls, launches = plan_ticks(mode, steps, warmup, timed=True)
         dev.snapshot_state()
-        run_ticks(mode, warmup, 0)
-        run_ticks(mode, steps, warmup)
+        run(warm_calls)
+        run(dry_calls)
         dev.restore_state()
-        run_ticks(mode, warmup, 0)                # the W untimed warm-up ticks
+        run(warm_calls)                           # the W untimed warm-up ticks
         barrier()
         t0 = time.perf_counter()
-        launches = run_ticks(mode, steps, warmup, timed=True)   # EXACTLY `steps` ticks; HIP events on the launch stream around them
+        run(timed_calls)                          # EXACTLY `steps` ticks; HIP events on the launch stream around them
         dsync()                                   # the ONE synchronisation that ends the timed region (device-wide: covers the handle's stream)
         own = time.perf_counter() - t0
         ev_ms = dev.timer_elapsed()               # both events have completed: no further wait

@@ -11,19 +11,28 @@ cd "$ROOT"
 OUT=gpurun_out/asan
 mkdir -p $OUT
 SO=q1physrl_amd/libq1env_asan.so
+# Runtime: GCC's libasan, not ROCm's compiler-rt build - the latter also intercepts hsa_amd_memory_pool_allocate for DEVICE-side
+# ASan and aborts every HIP allocation on a GPU that is not in xnack/ASan mode.  The host instrumentation clang emits needs three
+# newer helper symbols GCC 11's runtime lacks; tools/asan_shim.c (its own tiny preloaded library) forwards them to libc.
+gcc -O1 -fPIC -shared tools/asan_shim.c -o $OUT/libasan_shim.so > $OUT/build.log 2>&1 || { echo "ASAN SHIM BUILD FAILED"; exit 2; }
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O1 -g -std=c++17 -ffp-contract=off -fPIC -shared -Wall -Wno-unused-function \
-    -mllvm -amdgpu-kernarg-preload-count=16 -fsanitize=address -fno-gpu-sanitize -shared-libsan \
-    q1physrl_amd/csrc/q1env.hip -o $SO > $OUT/build.log 2>&1 || { echo "ASAN BUILD FAILED"; tail -20 $OUT/build.log; exit 2; }
-RT=$(/opt/rocm/lib/llvm/bin/clang -print-file-name=libclang_rt.asan-x86_64.so)
-[ -f "$RT" ] || RT=$(ls /opt/rocm/lib/llvm/lib/clang/*/lib/linux/libclang_rt.asan-x86_64.so | head -1)
+    -mllvm -amdgpu-kernarg-preload-count=16 -fsanitize=address -fno-gpu-sanitize \
+    q1physrl_amd/csrc/q1env.hip -o $SO >> $OUT/build.log 2>&1 || { echo "ASAN BUILD FAILED"; tail -5 $OUT/build.log | cut -c1-300; exit 2; }
+RT="$(readlink -f "$(gcc -print-file-name=libasan.so)") $ROOT/$OUT/libasan_shim.so"
+# canary: the same toolchain + runtime must catch a deliberate overflow
+/opt/rocm/lib/llvm/bin/clang -O1 -g -fPIC -shared -fsanitize=address tools/asan_canary.c -o $OUT/libcanary.so >> $OUT/build.log 2>&1
+rm -f $OUT/canary.*
+ASAN_OPTIONS=detect_leaks=0:halt_on_error=1:log_path=$ROOT/$OUT/canary LD_PRELOAD="$RT" python -c "import ctypes; ctypes.CDLL('$ROOT/$OUT/libcanary.so').q1_asan_canary(0)" > /dev/null 2>&1
+if ! grep -q "heap-buffer-overflow" $OUT/canary.* 2>/dev/null; then echo "asan: CANARY NOT DETECTED - the sanitizer setup is not live"; exit 3; fi
+echo "asan: canary overflow detected (setup is live)"
 export Q1ENV_LIB_PATH=$ROOT/$SO
 export ASAN_OPTIONS=detect_leaks=0:protect_shadow_gap=0:abort_on_error=0:halt_on_error=1:log_path=$ROOT/$OUT/report
 rm -f $OUT/report.*
-LD_PRELOAD=$RT python -m pytest tests/test_abi_symbols.py -q -x -p no:cacheprovider > $OUT/cpu.log 2>&1
+LD_PRELOAD="$RT" python -m pytest tests/test_abi_symbols.py -q -x -p no:cacheprovider > $OUT/cpu.log 2>&1
 rc1=$?
 rc2=0
 if python -c "import torch,sys; sys.exit(0 if torch.cuda.is_available() else 1)" 2>/dev/null; then
-    LD_PRELOAD=$RT timeout 600 python tools/asan_gpu_calls.py > $OUT/gpu.log 2>&1
+    LD_PRELOAD="$RT" timeout 600 python tools/asan_gpu_calls.py > $OUT/gpu.log 2>&1
     rc2=$?
 fi
 n=$(ls $OUT/report.* 2>/dev/null | wc -l)
