@@ -611,7 +611,7 @@ def test_no_mouse_policy_row_and_rejected_widths():
     import torch
     from q1physrl_amd import _lib, policy as P
     from q1physrl_amd.sampler import GpuSampler
-    cfg, env = make_env(512, seed=3, allow_yaw=False, time_limit=0.5)
+    cfg, env = make_env(512, seed=3, allow_yaw=False, time_limit=0.5, zero_start_prob=1.0)    # 37-tick episodes
     pol = P.Q1Policy(allow_yaw=False).cuda()
     s = GpuSampler(env, pol, horizon=40)
     tr = s.collect()
