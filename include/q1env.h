@@ -301,6 +301,29 @@ int q1env_policy_value_forward(q1env_t* env, const float* obs_dev, const q1env_m
 int q1env_episode_stats(q1env_t* env, const float* reward_dev, const uint8_t* done_dev, const uint8_t* zero_start_dev,
                         double* ep_return_dev, double* partials_dev);
 
+/* ---- persistent tick server (experimental) -----------------------------------------------------
+ * One resident grid serves `ticks` ticks without a kernel boundary per tick: the env state stays in registers and tick t's action is
+ * handed over by a producer that runs CONCURRENTLY on another stream.  Bit-identical to `ticks` q1env_step_autoreset (auto_reset
+ * != 0; Philox counter as there) or q1env_step calls with the packed action layout.  Hand-off = one 8-byte data-tagged granule per
+ * env, written by ONE agent-scope (sc1) store and polled with sc1 loads (MI355X_MICROARCH.md, persistent-kernel price list):
+ *   mailbox[i] = (tag << 40) | (key bits << 32) | float32 bits of the mouse action          producer -> server, uint64[N]
+ *   results[i] = (tag << 40) | (zero_start << 33) | (done << 32) | float32 bits of reward   server -> consumer, uint64[N]
+ *   obs[i][0..5] float32: complete BEFORE results[i] shows the tick's tag (read it with agent-scope loads)
+ *   tag of tick t (0-based) of the launch = (tag0 + t + 1) & 0xFFFFFF; zero the mailbox before the first launch.
+ * status uint32[5], written by the kernels: [0] server waves that served every tick, [1] != 0 = the server timed out waiting for
+ * an action, [2] ticks completed by every server wave, [3] != 0 = the driver timed out, [4] actions handed over by every driver
+ * wave.  Every wait is bounded by timeout_s (of no progress): a missing producer ends the launch with status[1] set and the state
+ * of the last completed tick stored - it never hangs the device.  num_envs <= CUs * 2048 (the grid must be resident at once).
+ * _start launches the server on the handle's stream (asynchronous; wait with q1env_sync).  _drive launches the reference
+ * producer on `producer_stream` (a hipStream_t other than the handle's): a DEPENDENT driver - what a policy is to the env - that
+ * hands tick t+1's action (from tick-major packed arrays keys uint8[T][N], mouse float[T][N]) over only after tick t's result
+ * granule of the same env arrived, and adds the rewards it received to checksum double[N] (optional). */
+int q1env_step_persistent_start(q1env_t* env, int ticks, uint32_t tag0, const uint64_t* mailbox_dev, float* obs_dev,
+                                uint64_t* results_dev, uint64_t seed, int auto_reset, uint32_t* status_dev, double timeout_s);
+int q1env_step_persistent_drive(q1env_t* env, void* producer_stream, int ticks, uint32_t tag0, const uint8_t* keys_dev,
+                                const float* mouse_dev, uint64_t* mailbox_dev, const uint64_t* results_dev, const float* obs_dev,
+                                double* checksum_dev, uint32_t* status_dev, double timeout_s);
+
 /* ---- measurement ------------------------------------------------------------------------------
  * calibrate_traffic: `launches` launches of a pure copy kernel that reads the SoA state with step's own
  * load pattern and writes it to scratch: exactly 85 B read + 85 B written per env, for calibrating the

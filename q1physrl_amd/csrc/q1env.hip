@@ -622,6 +622,151 @@ sample_step_kernel(Params p, StatePtrs s, const float* __restrict__ logits, int 
     episode_stats_lane(live, i, o.reward, o.done, zs, ep_return, partials);
 }
 
+// =========================================================================================== persistent tick server
+// q1env_step_persistent_*: ONE resident grid serves ticks for as long as actions keep arriving, the env state lives in registers
+// between ticks, and tick t's action is handed over by a producer running CONCURRENTLY on another stream - there is no kernel
+// boundary per tick (the ~1.8 us dependent-dispatch boundary + the write-back of the tick's dirty state lines that bound
+// q1env_step at 65 536 envs).  Hand-off protocol = the data-tagged granule of MI355X_MICROARCH.md (persistent-kernel price list,
+// "handoff-1to1"): one naturally aligned 8-byte word per env carries data AND tag and is written by ONE sc1 (agent-scope,
+// write-through) store and polled with sc1 loads, so no separate flag, fence or L2 write-back is needed in either direction:
+//     action granule   mailbox[i]  = (tag << 40) | (keys << 32) | float_bits(mouse)      producer -> server
+//     result granule   results[i]  = (tag << 40) | (zero_start << 33) | (done << 32) | float_bits(reward)   server -> consumer
+//     observation row  obs[i][0..5] float32, written (sc1) and drained BEFORE the result granule of the same tick
+// tag = (tag0 + t + 1) & 0xFFFFFF for tick t of the launch (never 0: a zeroed mailbox holds no valid action).
+// Every wait is bounded: a lane that sees no new tag for `timeout_ticks` of the 100 MHz wall clock gives up, the wave stores its
+// state as of the last completed tick and reports status[1] != 0 - a missing or stalled producer ends the launch, not the GPU.
+// Bit-identical to `ticks` q1env_step_autoreset / q1env_step calls with the packed action layout.
+__device__ __forceinline__ uint64_t granule_load(const uint64_t* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void granule_store(uint64_t* p, uint64_t v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+template <bool SPEC>
+__global__ void __launch_bounds__(64)
+tick_server_kernel(Params p, StatePtrs s, int ticks, uint32_t tag0, const uint64_t* mailbox, float* obs, uint64_t* results,
+                   uint64_t seed, uint64_t counter0, int auto_reset, uint32_t* status, uint64_t timeout_ticks) {
+    __shared__ float slab[384];
+    const uint32_t lane = threadIdx.x, i = blockIdx.x * 64u + lane, n = (uint32_t)p.n;
+    const bool live = i < n;
+    const uint32_t wave_first = i - lane;
+    const bool full = wave_first + 64u <= n;
+    const uint64_t genv = (uint64_t)p.env_index_base + (uint64_t)i;
+    Env e{};
+    if (live) load_env(s, n, i, e);
+    int completed = 0;
+    bool timed_out = false;
+    uint64_t t_last = wall_clock64();
+    for (int t = 0; t < ticks; ++t) {
+        const uint64_t tag = (uint64_t)((tag0 + (uint32_t)t + 1u) & 0xFFFFFFu);
+        uint64_t g = 0;
+        bool ok = !live;
+        for (;;) {                                    // every lane polls its own granule: one contiguous 512-B sc1 read per wave
+            if (!ok) {
+                g = granule_load(mailbox + i);
+                ok = (g >> 40) == tag;
+            }
+            if (__all(ok)) break;
+            __builtin_amdgcn_s_sleep(1);
+            if (wall_clock64() - t_last > timeout_ticks) { timed_out = true; break; }
+        }
+        if (timed_out) break;
+        TickOut<float> o;
+        o.reward = 0.0f; o.done = false;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) o.obs[j] = 0.0f;
+        bool zs = false;
+        if (live) {
+            const uint32_t keys = (uint32_t)(g >> 32) & ((1u << cfg_num_keys<SPEC>(p)) - 1u);
+            const double yaw_act = cfg_yaw_mode<SPEC>(p) ? (double)__uint_as_float((uint32_t)g) : 0.0;
+            tick<float, SPEC>(p, e, keys, yaw_act, o);
+            zs = (e.flags & FLAG_ZERO_START) != 0;                                  // of the episode the step belonged to
+            if (auto_reset && o.done) {
+                reset_philox(p, e, seed, genv, counter0 + (uint64_t)t + 1);
+                observe<float>(p, e, o.obs);
+            }
+        }
+        // observation rows: the wave's 64 rows are 1 536 contiguous bytes -> three 8-byte-per-lane sc1 stores (LDS transpose)
+        if (full) {
+            float2* w = reinterpret_cast<float2*>(slab + lane * 6);
+            w[0] = make_float2(o.obs[0], o.obs[1]); w[1] = make_float2(o.obs[2], o.obs[3]); w[2] = make_float2(o.obs[4], o.obs[5]);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const uint64_t* src = reinterpret_cast<const uint64_t*>(slab);
+            uint64_t* dst = reinterpret_cast<uint64_t*>(obs + (size_t)wave_first * 6);
+#pragma unroll
+            for (uint32_t k = 0; k < 3; ++k) granule_store(dst + k * 64u + lane, src[k * 64u + lane]);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        } else if (live) {
+#pragma unroll
+            for (int j = 0; j < 6; ++j) __hip_atomic_store(obs + (size_t)i * 6 + j, o.obs[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the rows have left before the granule that announces them
+        if (live)
+            granule_store(results + i, (tag << 40) | ((uint64_t)(zs ? 1u : 0u) << 33) | ((uint64_t)(o.done ? 1u : 0u) << 32) |
+                                           (uint64_t)__float_as_uint(o.reward));
+        completed = t + 1;
+        t_last = wall_clock64();
+    }
+    if (live) store_env(s, n, i, e);
+    if (lane == 0) {
+        if (completed == ticks) atomicAdd(&status[0], 1u);       // waves that served every tick
+        if (timed_out) atomicOr(&status[1], 1u);
+        atomicMin(&status[2], (uint32_t)completed);              // ticks every wave completed
+    }
+}
+
+// The reference driver of the tick server: a DEPENDENT producer, i.e. what a policy is to the env - it hands tick t+1's action
+// over only after tick t's result granule (and with it the observation row) of the same env has arrived.  Actions come from a
+// resident tick-major packed episode (keys uint8[T][N], mouse float[T][N]); checksum (optional, double[N]) accumulates the
+// rewards it received, so the data really makes the round trip.  One lane per env, resident next to the server.
+__global__ void __launch_bounds__(64)
+tick_driver_kernel(int n, int ticks, uint32_t tag0, const uint8_t* keys, const float* mouse, uint64_t* mailbox,
+                   const uint64_t* results, const float* obs, double* checksum, uint32_t* status, uint64_t timeout_ticks) {
+    const uint32_t lane = threadIdx.x, i = blockIdx.x * 64u + lane;
+    const bool live = i < (uint32_t)n;
+    double acc = 0.0;
+    bool timed_out = false;
+    int handed = 0;
+    uint64_t t_last = wall_clock64();
+    for (int t = 0; t < ticks; ++t) {
+        // tick t's action is fetched before the wait: its latency hides under the server's tick
+        const uint32_t k = live ? keys[(size_t)t * n + i] : 0u;
+        const float m = live ? mouse[(size_t)t * n + i] : 0.0f;
+        if (t > 0) {
+            const uint64_t want = (uint64_t)((tag0 + (uint32_t)t) & 0xFFFFFFu);      // result of tick t-1
+            uint64_t g = 0;
+            bool ok = !live;
+            for (;;) {
+                if (!ok) {
+                    g = granule_load(results + i);
+                    ok = (g >> 40) == want;
+                }
+                if (__all(ok)) break;
+                __builtin_amdgcn_s_sleep(1);
+                if (wall_clock64() - t_last > timeout_ticks) { timed_out = true; break; }
+            }
+            if (timed_out) break;
+            if (live) {
+                acc += (double)__uint_as_float((uint32_t)g);
+                if (obs) acc += 1e-9 * (double)__hip_atomic_load(obs + (size_t)i * 6, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // a consumer reads the row
+            }
+        }
+        const uint64_t tag = (uint64_t)((tag0 + (uint32_t)t + 1u) & 0xFFFFFFu);
+        if (live) granule_store(mailbox + i, (tag << 40) | ((uint64_t)(k & 0xFu) << 32) | (uint64_t)__float_as_uint(m));
+        handed = t + 1;
+        t_last = wall_clock64();
+    }
+    if (live && checksum) checksum[i] += acc;
+    if (lane == 0) {
+        if (timed_out) atomicOr(&status[3], 1u);
+        atomicMin(&status[4], (uint32_t)handed);
+    }
+}
+
 // Traffic calibration for the PMC counters (MI355X_MICROARCH.md "HBM": FETCH_SIZE / WRITE_SIZE must be calibrated on
 // a known byte count in the kernel's own access pattern): reads every SoA state array with exactly the loads
 // step_kernel uses and writes the same bytes to a scratch arena: 85 B read + 85 B written per env, no arithmetic.
@@ -1606,6 +1751,47 @@ int q1env_policy_value_forward(q1env_t* h, const float* obs, const q1env_mlp* pi
     const q1pol::Net na{pi->w1, pi->b1, pi->w23_image, pi->b2, pi->b3, pi->out, pi->out_dim};
     const q1pol::Net nb{vf->w1, vf->b1, vf->w23_image, vf->b2, vf->b3, vf->out, vf->out_dim};
     return launch_mlp(h, obs, na, nb, 2);
+}
+
+// ---- persistent tick server -----------------------------------------------------------------------------------------------
+int q1env_step_persistent_start(q1env_t* h, int ticks, uint32_t tag0, const uint64_t* mailbox_dev, float* obs_dev,
+                                uint64_t* results_dev, uint64_t seed, int auto_reset, uint32_t* status_dev, double timeout_s) {
+    if (!h || !mailbox_dev || !obs_dev || !results_dev || !status_dev) return fail(Q1ENV_ERR_INVALID_ARG, "q1env_step_persistent_start: null argument");
+    if (ticks <= 0) return fail(Q1ENV_ERR_INVALID_ARG, "q1env_step_persistent_start: ticks must be > 0");
+    if (!(timeout_s > 0.0) || timeout_s > 30.0) return fail(Q1ENV_ERR_INVALID_ARG, "q1env_step_persistent_start: timeout_s must be in (0, 30]");
+    // the whole grid must be resident at once (a wave that is not scheduled never polls): 8 waves per SIMD at most
+    const long max_envs = (long)h->num_cus * 4 * 8 * 64;
+    if ((long)h->p.n > max_envs) return fail(Q1ENV_ERR_INVALID_ARG, "q1env_step_persistent_start: too many envs for one resident grid");
+    if (h->p.yaw_mode == 2 && h->p.yaw_steps > 8388608.0) return fail(Q1ENV_ERR_INVALID_ARG, "q1env_step_persistent_start: step index does not fit the granule");
+    DeviceGuard guard(h->device);
+    const uint32_t init[5] = {0u, 0u, 0xFFFFFFFFu, 0u, 0xFFFFFFFFu};
+    HIP_TRY(hipMemcpyAsync(status_dev, init, sizeof(init), hipMemcpyHostToDevice, h->stream));
+    const dim3 g(((unsigned)h->p.n + 63u) / 64u), b(64);
+    const uint64_t timeout_ticks = (uint64_t)(timeout_s * 1.0e8);          // wall_clock64: 100 MHz
+    if (is_spec(h->p))
+        hipLaunchKernelGGL(tick_server_kernel<true>, g, b, 0, h->stream, h->p, h->st, ticks, tag0, mailbox_dev, obs_dev, results_dev, seed,
+                           h->tick_count, auto_reset, status_dev, timeout_ticks);
+    else
+        hipLaunchKernelGGL(tick_server_kernel<false>, g, b, 0, h->stream, h->p, h->st, ticks, tag0, mailbox_dev, obs_dev, results_dev, seed,
+                           h->tick_count, auto_reset, status_dev, timeout_ticks);
+    HIP_TRY(hipGetLastError());
+    h->tick_count += (uint64_t)ticks;
+    return Q1ENV_OK;
+}
+
+int q1env_step_persistent_drive(q1env_t* h, void* producer_stream, int ticks, uint32_t tag0, const uint8_t* keys_dev,
+                                const float* mouse_dev, uint64_t* mailbox_dev, const uint64_t* results_dev, const float* obs_dev,
+                                double* checksum_dev, uint32_t* status_dev, double timeout_s) {
+    if (!h || !producer_stream || !keys_dev || !mouse_dev || !mailbox_dev || !results_dev || !status_dev)
+        return fail(Q1ENV_ERR_INVALID_ARG, "q1env_step_persistent_drive: null argument (the producer needs its own stream)");
+    if ((hipStream_t)producer_stream == h->stream) return fail(Q1ENV_ERR_INVALID_ARG, "q1env_step_persistent_drive: the producer must run on another stream than the server");
+    if (ticks <= 0 || !(timeout_s > 0.0) || timeout_s > 30.0) return fail(Q1ENV_ERR_INVALID_ARG, "q1env_step_persistent_drive: bad ticks / timeout_s");
+    DeviceGuard guard(h->device);
+    const dim3 g(((unsigned)h->p.n + 63u) / 64u), b(64);
+    hipLaunchKernelGGL(tick_driver_kernel, g, b, 0, (hipStream_t)producer_stream, h->p.n, ticks, tag0, keys_dev, mouse_dev, mailbox_dev,
+                       results_dev, obs_dev, checksum_dev, status_dev, (uint64_t)(timeout_s * 1.0e8));
+    HIP_TRY(hipGetLastError());
+    return Q1ENV_OK;
 }
 
 int q1env_selftest_division(int device, uint64_t n, uint64_t seed, double c0, double c1, uint64_t* mismatches4) {

@@ -1,0 +1,126 @@
+"""GPU: the resident tick server (q1env_step_persistent_start / _drive) - bit-identical to per-tick q1env_step_autoreset calls and
+to the NumPy oracle, across launches, with ragged sizes and in-kernel resets; and its failure mode: without a producer the
+server times out, reports it, stores the state it had and the device stays usable (it must never hang)."""
+import time
+
+import numpy as np
+import pytest
+
+from oracle import np_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def make_env(n, seed, **over):
+    from q1physrl_amd.env import Config
+    from q1physrl_amd.tensor_env import TensorVectorEnv
+    cfg = O.OracleConfig.get_default(num_envs=n, **over)
+    return cfg, TensorVectorEnv(Config(**cfg.__dict__), device=0, seed=seed)
+
+
+def actions(n, ticks, seed):
+    import torch
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    keys = torch.randint(0, 16, (ticks, n), dtype=torch.uint8, device="cuda", generator=g)
+    mouse = (torch.rand((ticks, n), device="cuda", generator=g) * 2 - 1) * float(np.float32(720) * np.float32(0.014))
+    return keys, mouse.contiguous()
+
+
+@pytest.mark.parametrize("n,ticks,over", [(4096 + 37, 150, dict(time_limit=0.5, zero_start_prob=0.3)),
+                                          (65536, 100, dict(zero_start_prob=1.0)),
+                                          (1000, 90, dict(time_limit=0.4, zero_start_prob=0.5, smooth_keys=False, key_press_delay=0.0))])
+def test_tick_server_equals_per_tick_kernels(n, ticks, over):
+    import torch
+    cfg, a = make_env(n, 7, **over)
+    _, b = make_env(n, 7, **over)
+    a.reset(); b.reset()
+    keys, mouse = actions(n, ticks, 3)
+    rew_sum = torch.zeros((n,), dtype=torch.float64, device="cuda")
+    for t in range(ticks):
+        obs_b, rew_b, done_b = b.step_autoreset((keys[t], mouse[t]))
+        if t < ticks - 1:
+            rew_sum += rew_b.double()
+    half = ticks // 3                                    # two launches: the second continues where the first stopped (tags go on)
+    r1 = a.serve_ticks(keys[:half].contiguous(), mouse[:half].contiguous())
+    assert r1["status"][1] == 0 and r1["status"][3] == 0 and r1["status"][2] == half and r1["status"][4] == half
+    first = r1["checksum"].clone()
+    r2 = a.serve_ticks(keys[half:].contiguous(), mouse[half:].contiguous())
+    st = r2["status"]
+    assert st[1] == 0 and st[3] == 0 and st[0] == (n + 63) // 64 and st[2] == ticks - half and st[4] == ticks - half, st
+    torch.cuda.synchronize()
+    sa, sb = a.get_state(), b.get_state()
+    for k in sa:
+        assert np.array_equal(sa[k], sb[k]), k
+    assert torch.equal(r2["obs"], obs_b) and torch.equal(r2["reward"], rew_b) and torch.equal(r2["done"], done_b)
+    assert torch.equal(r2["zero_start"], b.zero_start)
+    # the dependent producer received every tick's reward but the last of each launch (float64 sums: exact in any order? no - same order per env)
+    b2_missing = torch.zeros_like(rew_sum)                # reward of tick half-1 was the last of launch 1: not received by the driver
+    _, c = make_env(n, 7, **over)
+    c.reset()
+    for t in range(half):
+        _, rew_c, _ = c.step_autoreset((keys[t], mouse[t]))
+    b2_missing += rew_c.double()
+    assert torch.allclose(first + r2["checksum"], rew_sum - b2_missing, rtol=0, atol=1e-9)
+    a.close(); b.close(); c.close()
+
+
+def test_tick_server_against_the_numpy_oracle():
+    """64 zero-start envs x 300 ticks (no episode end): every tick's state transition is the oracle's, bit for bit."""
+    import torch
+    n, ticks = 64, 300
+    cfg, env = make_env(n, 1, zero_start_prob=1.0)
+    env.reset()
+    np.random.seed(0)
+    ora = O.OracleVectorEnv(cfg)
+    keys, mouse = actions(n, ticks, 11)
+    res = env.serve_ticks(keys, mouse, auto_reset=False)
+    assert res["status"][1] == 0 and res["status"][2] == ticks
+    kh, mh = keys.cpu().numpy(), mouse.cpu().numpy()
+    total = np.zeros(n)
+    for t in range(ticks):
+        a = np.concatenate([((kh[t][:, None] >> np.arange(4)) & 1).astype(np.float64), mh[t][:, None].astype(np.float64)], axis=1)
+        o, r, d, _ = ora.vector_step(a)
+        if t < ticks - 1:
+            total += r.astype(np.float64)
+    assert np.array_equal(o.astype(np.float32), res["obs"].cpu().numpy()) and np.array_equal(r, res["reward"].cpu().numpy())
+    st = env.get_state()
+    assert np.array_equal(st["yaw"], ora.yaw) and np.array_equal(st["z_pos"], ora.st["z_pos"])
+    assert np.array_equal(np.stack([st["vel_x"], st["vel_y"], st["vel_z"]], 1), ora.st["vel"])
+    assert np.allclose(res["checksum"].cpu().numpy(), total, rtol=0, atol=1e-9)
+    env.close()
+
+
+def test_tick_server_without_a_producer_times_out_and_reports_it():
+    import torch
+    n = 2048
+    cfg, env = make_env(n, 5, zero_start_prob=0.5)
+    env.reset()
+    before = env.get_state()
+    mailbox = torch.zeros((n,), dtype=torch.int64, device="cuda")
+    results = torch.zeros((n,), dtype=torch.int64, device="cuda")
+    status = torch.zeros((5,), dtype=torch.int32, device="cuda")
+    t0 = time.perf_counter()
+    env._dev.persistent_start(50, 0, mailbox.data_ptr(), env.obs.data_ptr(), results.data_ptr(), 1, True, status.data_ptr(), timeout_s=0.05)
+    torch.cuda.synchronize()
+    took = time.perf_counter() - t0
+    st = status.cpu().numpy()
+    assert st[1] == 1 and st[0] == 0 and st[2] == 0 and took < 2.0, (st, took)
+    after = env.get_state()
+    for k in before:
+        assert np.array_equal(before[k], after[k]), k           # no tick was served: the state is what it was
+    # the device is fine: a normal tick still runs, and the server works when it does get a producer
+    keys, mouse = actions(n, 20, 2)
+    res = env.serve_ticks(keys, mouse)
+    assert res["status"][1] == 0 and res["status"][2] == 20
+    # a driver without a server times out on its side too
+    status.zero_()
+    side = torch.cuda.Stream()
+    env._dev.persistent_drive(side.cuda_stream, 10, 5000, keys.data_ptr(), mouse.data_ptr(), mailbox.data_ptr(), results.data_ptr(), 0, 0,
+                              status.data_ptr(), timeout_s=0.05)
+    torch.cuda.synchronize()
+    assert status.cpu().numpy()[3] == 1
+    from q1physrl_amd import _lib
+    with pytest.raises(_lib.Q1EnvError, match="another stream"):
+        env._dev.persistent_drive(torch.cuda.current_stream().cuda_stream, 10, 0, keys.data_ptr(), mouse.data_ptr(), mailbox.data_ptr(),
+                                  results.data_ptr(), 0, 0, status.data_ptr())
+    env.close()
