@@ -304,24 +304,27 @@ int q1env_episode_stats(q1env_t* env, const float* reward_dev, const uint8_t* do
 /* ---- persistent tick server (experimental) -----------------------------------------------------
  * One resident grid serves `ticks` ticks without a kernel boundary per tick: the env state stays in registers and tick t's action is
  * handed over by a producer that runs CONCURRENTLY on another stream.  Bit-identical to `ticks` q1env_step_autoreset (auto_reset
- * != 0; Philox counter as there) or q1env_step calls with the packed action layout.  Hand-off = one 8-byte data-tagged granule per
- * env, written by ONE agent-scope (sc1) store and polled with sc1 loads (MI355X_MICROARCH.md, persistent-kernel price list):
- *   mailbox[i] = (tag << 40) | (key bits << 32) | float32 bits of the mouse action          producer -> server, uint64[N]
- *   results[i] = (tag << 40) | (zero_start << 33) | (done << 32) | float32 bits of reward   server -> consumer, uint64[N]
- *   obs[i][0..5] float32: complete BEFORE results[i] shows the tick's tag (read it with agent-scope loads)
+ * != 0; Philox counter as there) or q1env_step calls with the packed action layout.  Everything that crosses is an 8-byte
+ * data-tagged granule, written by ONE agent-scope (sc1) store and polled with sc1 loads (MI355X_MICROARCH.md, persistent-kernel
+ * price list) - no flags, fences or drains, one hop per direction:
+ *   mailbox[i]    = (tag << 40) | (key bits << 32) | float32 bits of the mouse action          producer -> server, uint64[N]
+ *   results[k][i] = (tag << 40) | float32 bits of observation column k, k = 0..5              server -> consumer, uint64[7][N]
+ *   results[6][i] = (tag << 40) | (zero_start << 33) | (done << 32) | float32 bits of reward
  *   tag of tick t (0-based) of the launch = (tag0 + t + 1) & 0xFFFFFF; zero the mailbox before the first launch.
+ * obs_final (optional, float[N][6]): the last served tick's observation rows as plain stores at the end of the launch.
  * status uint32[5], written by the kernels: [0] server waves that served every tick, [1] != 0 = the server timed out waiting for
  * an action, [2] ticks completed by every server wave, [3] != 0 = the driver timed out, [4] actions handed over by every driver
  * wave.  Every wait is bounded by timeout_s (of no progress): a missing producer ends the launch with status[1] set and the state
  * of the last completed tick stored - it never hangs the device.  num_envs <= CUs * 2048 (the grid must be resident at once).
  * _start launches the server on the handle's stream (asynchronous; wait with q1env_sync).  _drive launches the reference
  * producer on `producer_stream` (a hipStream_t other than the handle's): a DEPENDENT driver - what a policy is to the env - that
- * hands tick t+1's action (from tick-major packed arrays keys uint8[T][N], mouse float[T][N]) over only after tick t's result
- * granule of the same env arrived, and adds the rewards it received to checksum double[N] (optional). */
-int q1env_step_persistent_start(q1env_t* env, int ticks, uint32_t tag0, const uint64_t* mailbox_dev, float* obs_dev,
-                                uint64_t* results_dev, uint64_t seed, int auto_reset, uint32_t* status_dev, double timeout_s);
+ * hands tick t+1's action (from tick-major packed arrays keys uint8[T][N], mouse float[T][N]) over only after all seven result
+ * granules of tick t of the same env arrived, and adds the rewards / first observation column it received to checksum
+ * double[2][N] (optional). */
+int q1env_step_persistent_start(q1env_t* env, int ticks, uint32_t tag0, const uint64_t* mailbox_dev, uint64_t* results_dev,
+                                float* obs_final_dev, uint64_t seed, int auto_reset, uint32_t* status_dev, double timeout_s);
 int q1env_step_persistent_drive(q1env_t* env, void* producer_stream, int ticks, uint32_t tag0, const uint8_t* keys_dev,
-                                const float* mouse_dev, uint64_t* mailbox_dev, const uint64_t* results_dev, const float* obs_dev,
+                                const float* mouse_dev, uint64_t* mailbox_dev, const uint64_t* results_dev,
                                 double* checksum_dev, uint32_t* status_dev, double timeout_s);
 
 /* ---- measurement ------------------------------------------------------------------------------

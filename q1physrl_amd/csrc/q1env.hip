@@ -627,15 +627,19 @@ sample_step_kernel(Params p, StatePtrs s, const float* __restrict__ logits, int 
 // between ticks, and tick t's action is handed over by a producer running CONCURRENTLY on another stream - there is no kernel
 // boundary per tick (the ~1.8 us dependent-dispatch boundary + the write-back of the tick's dirty state lines that bound
 // q1env_step at 65 536 envs).  Hand-off protocol = the data-tagged granule of MI355X_MICROARCH.md (persistent-kernel price list,
-// "handoff-1to1"): one naturally aligned 8-byte word per env carries data AND tag and is written by ONE sc1 (agent-scope,
-// write-through) store and polled with sc1 loads, so no separate flag, fence or L2 write-back is needed in either direction:
-//     action granule   mailbox[i]  = (tag << 40) | (keys << 32) | float_bits(mouse)      producer -> server
-//     result granule   results[i]  = (tag << 40) | (zero_start << 33) | (done << 32) | float_bits(reward)   server -> consumer
-//     observation row  obs[i][0..5] float32, written (sc1) and drained BEFORE the result granule of the same tick
+// "handoff-1to1"): every word that crosses is a naturally aligned 8-byte {data, tag} written by ONE sc1 (agent-scope,
+// write-through) store and polled with sc1 loads, so no separate flag, no fence, no L2 write-back and no store drain is needed in
+// either direction, and a consumer has a whole tick's outputs after ONE hop:
+//     action granule     mailbox[i]       = (tag << 40) | (keys << 32) | float_bits(mouse)                   producer -> server
+//     result granules    results[k][i]    = (tag << 40) | float_bits(obs[k]),  k = 0..5                       server -> consumer
+//                        results[6][i]    = (tag << 40) | (zero_start << 33) | (done << 32) | float_bits(reward)
+// (granule-index-major, so a wave's 64 granules of one index are one contiguous 512-byte store / load).
 // tag = (tag0 + t + 1) & 0xFFFFFF for tick t of the launch (never 0: a zeroed mailbox holds no valid action).
 // Every wait is bounded: a lane that sees no new tag for `timeout_ticks` of the 100 MHz wall clock gives up, the wave stores its
 // state as of the last completed tick and reports status[1] != 0 - a missing or stalled producer ends the launch, not the GPU.
 // Bit-identical to `ticks` q1env_step_autoreset / q1env_step calls with the packed action layout.
+constexpr int RESULT_GRANULES = 7;
+
 __device__ __forceinline__ uint64_t granule_load(const uint64_t* p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
@@ -645,18 +649,19 @@ __device__ __forceinline__ void granule_store(uint64_t* p, uint64_t v) {
 
 template <bool SPEC>
 __global__ void __launch_bounds__(64)
-tick_server_kernel(Params p, StatePtrs s, int ticks, uint32_t tag0, const uint64_t* mailbox, float* obs, uint64_t* results,
+tick_server_kernel(Params p, StatePtrs s, int ticks, uint32_t tag0, const uint64_t* mailbox, uint64_t* results, float* obs_final,
                    uint64_t seed, uint64_t counter0, int auto_reset, uint32_t* status, uint64_t timeout_ticks) {
-    __shared__ float slab[384];
     const uint32_t lane = threadIdx.x, i = blockIdx.x * 64u + lane, n = (uint32_t)p.n;
     const bool live = i < n;
-    const uint32_t wave_first = i - lane;
-    const bool full = wave_first + 64u <= n;
     const uint64_t genv = (uint64_t)p.env_index_base + (uint64_t)i;
     Env e{};
     if (live) load_env(s, n, i, e);
     int completed = 0;
     bool timed_out = false;
+    TickOut<float> o;
+    o.reward = 0.0f; o.done = false;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) o.obs[j] = 0.0f;
     uint64_t t_last = wall_clock64();
     for (int t = 0; t < ticks; ++t) {
         const uint64_t tag = (uint64_t)((tag0 + (uint32_t)t + 1u) & 0xFFFFFFu);
@@ -672,46 +677,28 @@ tick_server_kernel(Params p, StatePtrs s, int ticks, uint32_t tag0, const uint64
             if (wall_clock64() - t_last > timeout_ticks) { timed_out = true; break; }
         }
         if (timed_out) break;
-        TickOut<float> o;
-        o.reward = 0.0f; o.done = false;
-#pragma unroll
-        for (int j = 0; j < 6; ++j) o.obs[j] = 0.0f;
-        bool zs = false;
         if (live) {
             const uint32_t keys = (uint32_t)(g >> 32) & ((1u << cfg_num_keys<SPEC>(p)) - 1u);
             const double yaw_act = cfg_yaw_mode<SPEC>(p) ? (double)__uint_as_float((uint32_t)g) : 0.0;
             tick<float, SPEC>(p, e, keys, yaw_act, o);
-            zs = (e.flags & FLAG_ZERO_START) != 0;                                  // of the episode the step belonged to
+            const bool zs = (e.flags & FLAG_ZERO_START) != 0;                       // of the episode the step belonged to
             if (auto_reset && o.done) {
                 reset_philox(p, e, seed, genv, counter0 + (uint64_t)t + 1);
                 observe<float>(p, e, o.obs);
             }
-        }
-        // observation rows: the wave's 64 rows are 1 536 contiguous bytes -> three 8-byte-per-lane sc1 stores (LDS transpose)
-        if (full) {
-            float2* w = reinterpret_cast<float2*>(slab + lane * 6);
-            w[0] = make_float2(o.obs[0], o.obs[1]); w[1] = make_float2(o.obs[2], o.obs[3]); w[2] = make_float2(o.obs[4], o.obs[5]);
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            const uint64_t* src = reinterpret_cast<const uint64_t*>(slab);
-            uint64_t* dst = reinterpret_cast<uint64_t*>(obs + (size_t)wave_first * 6);
+            const uint64_t hi = tag << 40;
 #pragma unroll
-            for (uint32_t k = 0; k < 3; ++k) granule_store(dst + k * 64u + lane, src[k * 64u + lane]);
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-        } else if (live) {
-#pragma unroll
-            for (int j = 0; j < 6; ++j) __hip_atomic_store(obs + (size_t)i * 6 + j, o.obs[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int k = 0; k < 6; ++k) granule_store(results + (size_t)k * n + i, hi | (uint64_t)__float_as_uint(o.obs[k]));
+            granule_store(results + (size_t)6 * n + i, hi | ((uint64_t)(zs ? 1u : 0u) << 33) | ((uint64_t)(o.done ? 1u : 0u) << 32) |
+                                                           (uint64_t)__float_as_uint(o.reward));
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the rows have left before the granule that announces them
-        if (live)
-            granule_store(results + i, (tag << 40) | ((uint64_t)(zs ? 1u : 0u) << 33) | ((uint64_t)(o.done ? 1u : 0u) << 32) |
-                                           (uint64_t)__float_as_uint(o.reward));
         completed = t + 1;
         t_last = wall_clock64();
     }
-    if (live) store_env(s, n, i, e);
+    if (live) {
+        store_env(s, n, i, e);
+        if (obs_final && completed > 0) write_obs<float>(obs_final, (size_t)i, o.obs);    // plain row of the last served tick
+    }
     if (lane == 0) {
         if (completed == ticks) atomicAdd(&status[0], 1u);       // waves that served every tick
         if (timed_out) atomicOr(&status[1], 1u);
@@ -720,15 +707,16 @@ tick_server_kernel(Params p, StatePtrs s, int ticks, uint32_t tag0, const uint64
 }
 
 // The reference driver of the tick server: a DEPENDENT producer, i.e. what a policy is to the env - it hands tick t+1's action
-// over only after tick t's result granule (and with it the observation row) of the same env has arrived.  Actions come from a
-// resident tick-major packed episode (keys uint8[T][N], mouse float[T][N]); checksum (optional, double[N]) accumulates the
-// rewards it received, so the data really makes the round trip.  One lane per env, resident next to the server.
+// over only after ALL SEVEN result granules of tick t of the same env have arrived (one poll round: the seven loads of a lane are
+// in flight together).  Actions come from a resident tick-major packed episode (keys uint8[T][N], mouse float[T][N]); checksum
+// (optional, double[2][N]) accumulates the rewards and the first observation column it received, so the data really makes the
+// round trip.  One lane per env, resident next to the server.
 __global__ void __launch_bounds__(64)
 tick_driver_kernel(int n, int ticks, uint32_t tag0, const uint8_t* keys, const float* mouse, uint64_t* mailbox,
-                   const uint64_t* results, const float* obs, double* checksum, uint32_t* status, uint64_t timeout_ticks) {
+                   const uint64_t* results, double* checksum, uint32_t* status, uint64_t timeout_ticks) {
     const uint32_t lane = threadIdx.x, i = blockIdx.x * 64u + lane;
     const bool live = i < (uint32_t)n;
-    double acc = 0.0;
+    double acc_r = 0.0, acc_o = 0.0;
     bool timed_out = false;
     int handed = 0;
     uint64_t t_last = wall_clock64();
@@ -737,13 +725,16 @@ tick_driver_kernel(int n, int ticks, uint32_t tag0, const uint8_t* keys, const f
         const uint32_t k = live ? keys[(size_t)t * n + i] : 0u;
         const float m = live ? mouse[(size_t)t * n + i] : 0.0f;
         if (t > 0) {
-            const uint64_t want = (uint64_t)((tag0 + (uint32_t)t) & 0xFFFFFFu);      // result of tick t-1
-            uint64_t g = 0;
+            const uint64_t want = (uint64_t)((tag0 + (uint32_t)t) & 0xFFFFFFu);      // results of tick t-1
+            uint64_t g[RESULT_GRANULES];
             bool ok = !live;
             for (;;) {
                 if (!ok) {
-                    g = granule_load(results + i);
-                    ok = (g >> 40) == want;
+#pragma unroll
+                    for (int q = 0; q < RESULT_GRANULES; ++q) g[q] = granule_load(results + (size_t)q * n + i);
+                    ok = true;
+#pragma unroll
+                    for (int q = 0; q < RESULT_GRANULES; ++q) ok = ok && ((g[q] >> 40) == want);
                 }
                 if (__all(ok)) break;
                 __builtin_amdgcn_s_sleep(1);
@@ -751,8 +742,8 @@ tick_driver_kernel(int n, int ticks, uint32_t tag0, const uint8_t* keys, const f
             }
             if (timed_out) break;
             if (live) {
-                acc += (double)__uint_as_float((uint32_t)g);
-                if (obs) acc += 1e-9 * (double)__hip_atomic_load(obs + (size_t)i * 6, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // a consumer reads the row
+                acc_r += (double)__uint_as_float((uint32_t)g[6]);
+                acc_o += (double)__uint_as_float((uint32_t)g[0]);
             }
         }
         const uint64_t tag = (uint64_t)((tag0 + (uint32_t)t + 1u) & 0xFFFFFFu);
@@ -760,7 +751,7 @@ tick_driver_kernel(int n, int ticks, uint32_t tag0, const uint8_t* keys, const f
         handed = t + 1;
         t_last = wall_clock64();
     }
-    if (live && checksum) checksum[i] += acc;
+    if (live && checksum) { checksum[i] += acc_r; checksum[(size_t)n + i] += acc_o; }
     if (lane == 0) {
         if (timed_out) atomicOr(&status[3], 1u);
         atomicMin(&status[4], (uint32_t)handed);
@@ -1754,9 +1745,9 @@ int q1env_policy_value_forward(q1env_t* h, const float* obs, const q1env_mlp* pi
 }
 
 // ---- persistent tick server -----------------------------------------------------------------------------------------------
-int q1env_step_persistent_start(q1env_t* h, int ticks, uint32_t tag0, const uint64_t* mailbox_dev, float* obs_dev,
-                                uint64_t* results_dev, uint64_t seed, int auto_reset, uint32_t* status_dev, double timeout_s) {
-    if (!h || !mailbox_dev || !obs_dev || !results_dev || !status_dev) return fail(Q1ENV_ERR_INVALID_ARG, "q1env_step_persistent_start: null argument");
+int q1env_step_persistent_start(q1env_t* h, int ticks, uint32_t tag0, const uint64_t* mailbox_dev, uint64_t* results_dev,
+                                float* obs_final_dev, uint64_t seed, int auto_reset, uint32_t* status_dev, double timeout_s) {
+    if (!h || !mailbox_dev || !results_dev || !status_dev) return fail(Q1ENV_ERR_INVALID_ARG, "q1env_step_persistent_start: null argument");
     if (ticks <= 0) return fail(Q1ENV_ERR_INVALID_ARG, "q1env_step_persistent_start: ticks must be > 0");
     if (!(timeout_s > 0.0) || timeout_s > 30.0) return fail(Q1ENV_ERR_INVALID_ARG, "q1env_step_persistent_start: timeout_s must be in (0, 30]");
     // the whole grid must be resident at once (a wave that is not scheduled never polls): 8 waves per SIMD at most
@@ -1769,10 +1760,10 @@ int q1env_step_persistent_start(q1env_t* h, int ticks, uint32_t tag0, const uint
     const dim3 g(((unsigned)h->p.n + 63u) / 64u), b(64);
     const uint64_t timeout_ticks = (uint64_t)(timeout_s * 1.0e8);          // wall_clock64: 100 MHz
     if (is_spec(h->p))
-        hipLaunchKernelGGL(tick_server_kernel<true>, g, b, 0, h->stream, h->p, h->st, ticks, tag0, mailbox_dev, obs_dev, results_dev, seed,
+        hipLaunchKernelGGL(tick_server_kernel<true>, g, b, 0, h->stream, h->p, h->st, ticks, tag0, mailbox_dev, results_dev, obs_final_dev, seed,
                            h->tick_count, auto_reset, status_dev, timeout_ticks);
     else
-        hipLaunchKernelGGL(tick_server_kernel<false>, g, b, 0, h->stream, h->p, h->st, ticks, tag0, mailbox_dev, obs_dev, results_dev, seed,
+        hipLaunchKernelGGL(tick_server_kernel<false>, g, b, 0, h->stream, h->p, h->st, ticks, tag0, mailbox_dev, results_dev, obs_final_dev, seed,
                            h->tick_count, auto_reset, status_dev, timeout_ticks);
     HIP_TRY(hipGetLastError());
     h->tick_count += (uint64_t)ticks;
@@ -1780,7 +1771,7 @@ int q1env_step_persistent_start(q1env_t* h, int ticks, uint32_t tag0, const uint
 }
 
 int q1env_step_persistent_drive(q1env_t* h, void* producer_stream, int ticks, uint32_t tag0, const uint8_t* keys_dev,
-                                const float* mouse_dev, uint64_t* mailbox_dev, const uint64_t* results_dev, const float* obs_dev,
+                                const float* mouse_dev, uint64_t* mailbox_dev, const uint64_t* results_dev,
                                 double* checksum_dev, uint32_t* status_dev, double timeout_s) {
     if (!h || !producer_stream || !keys_dev || !mouse_dev || !mailbox_dev || !results_dev || !status_dev)
         return fail(Q1ENV_ERR_INVALID_ARG, "q1env_step_persistent_drive: null argument (the producer needs its own stream)");
@@ -1789,7 +1780,7 @@ int q1env_step_persistent_drive(q1env_t* h, void* producer_stream, int ticks, ui
     DeviceGuard guard(h->device);
     const dim3 g(((unsigned)h->p.n + 63u) / 64u), b(64);
     hipLaunchKernelGGL(tick_driver_kernel, g, b, 0, (hipStream_t)producer_stream, h->p.n, ticks, tag0, keys_dev, mouse_dev, mailbox_dev,
-                       results_dev, obs_dev, checksum_dev, status_dev, (uint64_t)(timeout_s * 1.0e8));
+                       results_dev, checksum_dev, status_dev, (uint64_t)(timeout_s * 1.0e8));
     HIP_TRY(hipGetLastError());
     return Q1ENV_OK;
 }

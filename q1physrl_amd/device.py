@@ -221,16 +221,15 @@ class DeviceEnv:
     def episode_stats_dev(self, reward, done, zero_start, ep_return, partials):
         _lib.check(self._lib.q1env_episode_stats(self._h, reward, done, zero_start, ep_return, partials))
 
-    def persistent_start(self, ticks, tag0, mailbox, obs, results, seed, auto_reset, status, timeout_s=2.0):
+    def persistent_start(self, ticks, tag0, mailbox, results, obs_final, seed, auto_reset, status, timeout_s=2.0):
         """Launch the resident tick server on the handle's stream (q1env_step_persistent_start); pointers are device ints."""
-        _lib.check(self._lib.q1env_step_persistent_start(self._h, int(ticks), int(tag0) & 0xFFFFFFFF, mailbox, obs, results,
+        _lib.check(self._lib.q1env_step_persistent_start(self._h, int(ticks), int(tag0) & 0xFFFFFFFF, mailbox, results, obs_final or None,
                                                          int(seed) & (2 ** 64 - 1), int(bool(auto_reset)), status, float(timeout_s)))
 
-    def persistent_drive(self, producer_stream, ticks, tag0, keys, mouse, mailbox, results, obs, checksum, status, timeout_s=2.0):
+    def persistent_drive(self, producer_stream, ticks, tag0, keys, mouse, mailbox, results, checksum, status, timeout_s=2.0):
         """Launch the reference dependent producer on `producer_stream` (raw hipStream_t int, not the handle's stream)."""
         _lib.check(self._lib.q1env_step_persistent_drive(self._h, C.c_void_p(int(producer_stream)), int(ticks), int(tag0) & 0xFFFFFFFF,
-                                                         keys, mouse, mailbox, results, obs or None, checksum or None, status,
-                                                         float(timeout_s)))
+                                                         keys, mouse, mailbox, results, checksum or None, status, float(timeout_s)))
 
     def observe_dev(self, obs, obs_format=_lib.OBS_F32):
         _lib.check(self._lib.q1env_observe(self._h, obs_format, obs))

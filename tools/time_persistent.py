@@ -30,14 +30,14 @@ def main():
         mouse = (torch.rand((T, n), device="cuda") * 20 - 10).contiguous()
         dev = env._dev
         row = {"envs": n, "ticks": T}
-        for label, read_obs in (("server_us_per_tick", True), ("server_no_obs_read_us_per_tick", False)):
-            env.serve_ticks(keys, mouse, read_obs=read_obs)                      # warm-up
+        for label in ("server_us_per_tick",):
+            env.serve_ticks(keys, mouse)                      # warm-up
             best = 1e30
             for _ in range(args.reps):
                 env.reset()
                 torch.cuda.synchronize()
                 dev.timer_start()
-                env.serve_ticks(keys, mouse, read_obs=read_obs, sync=False)
+                env.serve_ticks(keys, mouse, sync=False)
                 ms = dev.timer_stop()
                 st = env._srv["status"].cpu().numpy()
                 assert st[1] == 0 and st[3] == 0 and st[2] == T, st
