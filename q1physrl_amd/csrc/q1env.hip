@@ -662,19 +662,26 @@ tick_server_kernel(Params p, StatePtrs s, int ticks, uint32_t tag0, const uint64
     o.reward = 0.0f; o.done = false;
 #pragma unroll
     for (int j = 0; j < 6; ++j) o.obs[j] = 0.0f;
-    uint64_t t_last = wall_clock64();
     for (int t = 0; t < ticks; ++t) {
         const uint64_t tag = (uint64_t)((tag0 + (uint32_t)t + 1u) & 0xFFFFFFu);
         uint64_t g = 0;
         bool ok = !live;
+        uint32_t polls = 0;
+        uint64_t t_wait = 0;
         for (;;) {                                    // every lane polls its own granule: one contiguous 512-B sc1 read per wave
             if (!ok) {
                 g = granule_load(mailbox + i);
                 ok = (g >> 40) == tag;
             }
             if (__all(ok)) break;
-            __builtin_amdgcn_s_sleep(1);
-            if (wall_clock64() - t_last > timeout_ticks) { timed_out = true; break; }
+            // the load's own latency paces the loop; the 100 MHz clock is only consulted every 256 failed polls (no s_memrealtime
+            // on the path of a tick that is served promptly), the timeout counts from the first such look
+            if ((++polls & 255u) == 0u) {
+                const uint64_t now = wall_clock64();
+                if (t_wait == 0) t_wait = now;
+                else if (now - t_wait > timeout_ticks) { timed_out = true; break; }
+                __builtin_amdgcn_s_sleep(8);
+            }
         }
         if (timed_out) break;
         if (live) {
@@ -693,7 +700,6 @@ tick_server_kernel(Params p, StatePtrs s, int ticks, uint32_t tag0, const uint64
                                                            (uint64_t)__float_as_uint(o.reward));
         }
         completed = t + 1;
-        t_last = wall_clock64();
     }
     if (live) {
         store_env(s, n, i, e);
@@ -719,7 +725,6 @@ tick_driver_kernel(int n, int ticks, uint32_t tag0, const uint8_t* keys, const f
     double acc_r = 0.0, acc_o = 0.0;
     bool timed_out = false;
     int handed = 0;
-    uint64_t t_last = wall_clock64();
     for (int t = 0; t < ticks; ++t) {
         // tick t's action is fetched before the wait: its latency hides under the server's tick
         const uint32_t k = live ? keys[(size_t)t * n + i] : 0u;
@@ -728,6 +733,8 @@ tick_driver_kernel(int n, int ticks, uint32_t tag0, const uint8_t* keys, const f
             const uint64_t want = (uint64_t)((tag0 + (uint32_t)t) & 0xFFFFFFu);      // results of tick t-1
             uint64_t g[RESULT_GRANULES];
             bool ok = !live;
+            uint32_t polls = 0;
+            uint64_t t_wait = 0;
             for (;;) {
                 if (!ok) {
 #pragma unroll
@@ -737,8 +744,12 @@ tick_driver_kernel(int n, int ticks, uint32_t tag0, const uint8_t* keys, const f
                     for (int q = 0; q < RESULT_GRANULES; ++q) ok = ok && ((g[q] >> 40) == want);
                 }
                 if (__all(ok)) break;
-                __builtin_amdgcn_s_sleep(1);
-                if (wall_clock64() - t_last > timeout_ticks) { timed_out = true; break; }
+                if ((++polls & 255u) == 0u) {
+                    const uint64_t now = wall_clock64();
+                    if (t_wait == 0) t_wait = now;
+                    else if (now - t_wait > timeout_ticks) { timed_out = true; break; }
+                    __builtin_amdgcn_s_sleep(8);
+                }
             }
             if (timed_out) break;
             if (live) {
@@ -749,7 +760,6 @@ tick_driver_kernel(int n, int ticks, uint32_t tag0, const uint8_t* keys, const f
         const uint64_t tag = (uint64_t)((tag0 + (uint32_t)t + 1u) & 0xFFFFFFu);
         if (live) granule_store(mailbox + i, (tag << 40) | ((uint64_t)(k & 0xFu) << 32) | (uint64_t)__float_as_uint(m));
         handed = t + 1;
-        t_last = wall_clock64();
     }
     if (live && checksum) { checksum[i] += acc_r; checksum[(size_t)n + i] += acc_o; }
     if (lane == 0) {
@@ -1750,9 +1760,16 @@ int q1env_step_persistent_start(q1env_t* h, int ticks, uint32_t tag0, const uint
     if (!h || !mailbox_dev || !results_dev || !status_dev) return fail(Q1ENV_ERR_INVALID_ARG, "q1env_step_persistent_start: null argument");
     if (ticks <= 0) return fail(Q1ENV_ERR_INVALID_ARG, "q1env_step_persistent_start: ticks must be > 0");
     if (!(timeout_s > 0.0) || timeout_s > 30.0) return fail(Q1ENV_ERR_INVALID_ARG, "q1env_step_persistent_start: timeout_s must be in (0, 30]");
-    // the whole grid must be resident at once (a wave that is not scheduled never polls): 8 waves per SIMD at most
-    const long max_envs = (long)h->num_cus * 4 * 8 * 64;
-    if ((long)h->p.n > max_envs) return fail(Q1ENV_ERR_INVALID_ARG, "q1env_step_persistent_start: too many envs for one resident grid");
+    // The whole grid must be resident at once - a wave that is not scheduled never polls - AND leave room for the producer's waves
+    // on every SIMD (a server that fills the register file starves the producer it waits for: both would only time out).
+    DeviceGuard guard_occ(h->device);
+    int per_cu = 0;
+    const void* fn = is_spec(h->p) ? (const void*)tick_server_kernel<true> : (const void*)tick_server_kernel<false>;
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 64, 0));
+    const long max_envs = (long)h->num_cus * (per_cu > 4 ? per_cu - 4 : 0) * 64;
+    if ((long)h->p.n > max_envs)
+        return fail(Q1ENV_ERR_INVALID_ARG, "q1env_step_persistent_start: too many envs for one resident grid next to its producer (" +
+                                           std::to_string(max_envs) + " at most on this device)");
     if (h->p.yaw_mode == 2 && h->p.yaw_steps > 8388608.0) return fail(Q1ENV_ERR_INVALID_ARG, "q1env_step_persistent_start: step index does not fit the granule");
     DeviceGuard guard(h->device);
     const uint32_t init[5] = {0u, 0u, 0xFFFFFFFFu, 0u, 0xFFFFFFFFu};

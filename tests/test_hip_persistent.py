@@ -36,13 +36,13 @@ def test_tick_server_equals_per_tick_kernels(n, ticks, over):
     a.reset(); b.reset()
     keys, mouse = actions(n, ticks, 3)
     half = ticks // 3
-    rew_sum = torch.zeros((n,), dtype=torch.float64, device="cuda")      # what the dependent producer receives: every tick's result but
-    obs_sum = torch.zeros((n,), dtype=torch.float64, device="cuda")      # the last one of each of the two launches
+    # what the dependent producer receives: every tick's result but the last one of each launch, summed per launch in tick order
+    sums = torch.zeros((2, 2, n), dtype=torch.float64, device="cuda")
     for t in range(ticks):
         obs_b, rew_b, done_b = b.step_autoreset((keys[t], mouse[t]))
         if t not in (half - 1, ticks - 1):
-            rew_sum += rew_b.double()
-            obs_sum += obs_b[:, 0].double()
+            sums[int(t >= half), 0] += rew_b.double()
+            sums[int(t >= half), 1] += obs_b[:, 0].double()
     # two launches: the second continues where the first stopped (tags go on)
     r1 = a.serve_ticks(keys[:half].contiguous(), mouse[:half].contiguous())
     assert r1["status"][1] == 0 and r1["status"][3] == 0 and r1["status"][2] == half and r1["status"][4] == half
@@ -57,8 +57,7 @@ def test_tick_server_equals_per_tick_kernels(n, ticks, over):
     assert torch.equal(r2["obs"], obs_b) and torch.equal(r2["obs_from_granules"], obs_b)
     assert torch.equal(r2["reward"], rew_b) and torch.equal(r2["done"], done_b) and torch.equal(r2["zero_start"], b.zero_start)
     # the data really made the round trip: the producer's sums of what it received (same per-env order: exact in float64)
-    got = first + r2["checksum"]
-    assert torch.equal(got[0], rew_sum) and torch.equal(got[1], obs_sum)
+    assert torch.equal(first, sums[0]) and torch.equal(r2["checksum"], sums[1])
     a.close(); b.close()
 
 
@@ -123,3 +122,8 @@ def test_tick_server_without_a_producer_times_out_and_reports_it():
         env._dev.persistent_drive(torch.cuda.current_stream().cuda_stream, 10, 0, keys.data_ptr(), mouse.data_ptr(), mailbox.data_ptr(),
                                   results.data_ptr(), 0, status.data_ptr())
     env.close()
+    # a batch that cannot be resident next to its producer is refused up front (it could only time out)
+    cfg, big = make_env(1 << 20, 5)
+    with pytest.raises(_lib.Q1EnvError, match="too many envs"):
+        big._dev.persistent_start(5, 0, mailbox.data_ptr(), results.data_ptr(), 0, 1, True, status.data_ptr())
+    big.close()

@@ -13,7 +13,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--envs", type=int, nargs="+", default=[4096, 65536, 131072, 262144])
+    ap.add_argument("--envs", type=int, nargs="+", default=[4096, 65536, 131072, 196608, 262144])
     ap.add_argument("--ticks", type=int, default=720)
     ap.add_argument("--reps", type=int, default=5)
     args = ap.parse_args()
@@ -31,7 +31,11 @@ def main():
         dev = env._dev
         row = {"envs": n, "ticks": T}
         for label in ("server_us_per_tick",):
-            env.serve_ticks(keys, mouse)                      # warm-up
+            try:
+                env.serve_ticks(keys, mouse)                  # warm-up
+            except _lib.Q1EnvError as ex:
+                row["server_refused"] = str(ex)[-90:]
+                break
             best = 1e30
             for _ in range(args.reps):
                 env.reset()
@@ -55,7 +59,8 @@ def main():
         for _ in range(args.reps):
             dev.rollout_dev(T, _lib.ACT_PACKED, keys.data_ptr(), mouse.data_ptr(), 0, _lib.OBS_F32, 0, 0, 0, True)
         row["fused_rollout_no_outputs_us_per_tick"] = dev.timer_stop() * 1e3 / (T * args.reps)
-        row["server_frac_of_8TBps_at_204B"] = 204.0 * n / (row["server_us_per_tick"] * 1e-6) / 8e12
+        if "server_us_per_tick" in row:
+            row["server_frac_of_8TBps_at_204B"] = 204.0 * n / (row["server_us_per_tick"] * 1e-6) / 8e12
         row["step_frac_of_8TBps_at_204B"] = 204.0 * n / (row["step_graph_us_per_tick"] * 1e-6) / 8e12
         rows.append(row)
         print(json.dumps(row), flush=True)
