@@ -56,6 +56,9 @@ class FakeDeviceEnv:
         if flags & 8:
             self.timer_mark()
 
+    def persistent_start(self, *a):
+        raise RuntimeError("the oracle stand-in has no tick server")
+
     def snapshot_state(self):
         import copy
         self._snap = copy.deepcopy(self._env)
