@@ -501,7 +501,18 @@ def main(argv=None):
                                  "launches": l2, "avg_launch_us": ev2 * 1e3 / l2, "event_us_per_tick": ev2 * 1e3 / args.steps,
                                  "frac_of_8TBps_at_204B": B_ALG * n / (ev2 * 1e-3 / args.steps) / 1e9 / HBM_PEAK_GBPS,
                                  "note": notes[other]}
-    if rank == 0 and world == 1 and not args.no_secondary:
+    if rank == 0 and world == 1 and not args.no_secondary and not injected:
+        # steady state of the two "a policy can sit between ticks" modes: one whole 720-tick episode per measurement, HIP events
+        # only (what a --steps 20 region cannot show: launch / start-up latency amortised)
+        steady = {}
+        for m in ("step", "server"):
+            try:
+                _w, ev, _l, _o = measure(m, EPISODE_TICKS, 0)
+                steady[m] = {"us_per_tick": ev * 1e3 / EPISODE_TICKS, "env_steps_per_s": n / (ev * 1e-3 / EPISODE_TICKS),
+                             "frac_of_8TBps_at_204B": B_ALG * n / (ev * 1e-3 / EPISODE_TICKS) / 1e9 / HBM_PEAK_GBPS}
+            except Exception as ex:   # noqa: BLE001
+                steady[m] = {"error": repr(ex)}
+        out["steady_state_720_ticks"] = steady
         out["step_kernel_size_sweep"] = size_sweep(dev_index)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         def gpu_check(acts, k):

@@ -3,7 +3,7 @@
 # bench command and for the traffic-calibration kernel.  Outputs land in gpurun_out/prof_<tag>/ ; copy the summaries you
 # want judged into profiles/.
 set -u
-TAG=${1:-r1}
+TAG=${1:-r2}
 shift || true
 ARGS=${*:-"--no-cpu-baseline --no-secondary --steps 1440 --warmup 720"}
 cd /tmp && export TMPDIR=/tmp
@@ -15,6 +15,8 @@ rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch 
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -o write -- python bench.py $ARGS > $OUT/bench_write.json 2> $OUT/write.err
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/cal_fetch -o fetch -- python tools/calib_traffic.py > /dev/null 2> $OUT/cal_fetch.err
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/cal_write -o write -- python tools/calib_traffic.py > /dev/null 2> $OUT/cal_write.err
+# the resident tick server: kernel trace only (PMC collection serialises kernels; the server and its producer must run concurrently)
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_server -o trace -- python bench.py --mode server $ARGS > $OUT/bench_server_trace.json 2> $OUT/trace_server.err
 python tools/summarize_prof.py $OUT > $OUT/summary.txt 2>&1
 cat $OUT/summary.txt
 find $OUT -name '*.csv' -size +2M -delete

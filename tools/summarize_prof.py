@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Summarise rocprofv3 CSV output of tools/profile_r1.sh: per-kernel stats, launch gaps, PMC byte counters per launch
+"""Summarise rocprofv3 CSV output of tools/profile_round.sh: per-kernel stats, launch gaps, PMC byte counters per launch
 (raw and with the gfx950 FETCH_SIZE x2 correction), and the calibration of both counters on the known-bytes copy kernel."""
 import csv
 import glob
@@ -25,6 +25,12 @@ if st:
     print("== rocprofv3 --kernel-trace --stats (kernel_stats.csv)")
     for row in csv.DictReader(open(st)):
         print(f"  {short(row['Name']):60s} calls={row['Calls']:>6s} avg_ns={float(row['AverageNs']):10.1f} min={row['MinNs']:>7s} max={row['MaxNs']:>8s} pct={row['Percentage']}")
+sv = first("trace_server/**/*kernel_stats.csv")
+if sv:
+    print("== rocprofv3 --kernel-trace --stats, bench.py --mode server (resident tick server + dependent producer)")
+    for row in csv.DictReader(open(sv)):
+        if float(row["Percentage"]) > 0.05:
+            print(f"  {short(row['Name']):60s} calls={row['Calls']:>6s} avg_ns={float(row['AverageNs']):12.1f} min={row['MinNs']:>9s} max={row['MaxNs']:>9s} pct={row['Percentage']}")
 kt = first("trace/**/*kernel_trace.csv")
 if kt:
     rows = list(csv.DictReader(open(kt)))
