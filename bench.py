@@ -176,7 +176,7 @@ def size_sweep(dev_index, sizes=(262144, 1048576, 4194304), ticks=72, reps=4):
 
 
 def load_profiled_traffic(mode, n):
-    """HBM bytes per launch measured with rocprofv3 PMC passes (tools/profile_r1.sh -> profiles/*.json); None if absent."""
+    """HBM bytes per launch measured with rocprofv3 PMC passes (tools/profile_round.sh -> profiles/traffic.json); None if absent."""
     path = os.path.join(ROOT, "profiles", "traffic.json")
     try:
         with open(path) as f:
@@ -396,8 +396,8 @@ def main(argv=None):
             dist.barrier()
 
     def server_ok():
-        st = server_state()["status"].cpu().numpy()
-        return int(st[1]) == 0 and int(st[3]) == 0
+        st = server_state()["status"].cpu().numpy()          # accumulated since it was zeroed at set-up
+        return int(st[1]) == 0 and int(st[3]) == 0 and int(st[2]) == 0 and int(st[4]) == 0
 
     def measure(mode, steps, warmup):
         # Preparation (untimed): instantiate + upload every graph the two sequences replay, and replay them ONCE with the env

@@ -708,7 +708,7 @@ tick_server_kernel(Params p, StatePtrs s, int ticks, uint32_t tag0, const uint64
     if (lane == 0) {
         if (completed == ticks) atomicAdd(&status[0], 1u);       // waves that served every tick
         if (timed_out) atomicOr(&status[1], 1u);
-        atomicMin(&status[2], (uint32_t)completed);              // ticks every wave completed
+        atomicMax(&status[2], (uint32_t)(ticks - completed));    // ticks the slowest wave left unserved
     }
 }
 
@@ -764,7 +764,7 @@ tick_driver_kernel(int n, int ticks, uint32_t tag0, const uint8_t* keys, const f
     if (live && checksum) { checksum[i] += acc_r; checksum[(size_t)n + i] += acc_o; }
     if (lane == 0) {
         if (timed_out) atomicOr(&status[3], 1u);
-        atomicMin(&status[4], (uint32_t)handed);
+        atomicMax(&status[4], (uint32_t)(ticks - handed));       // actions the slowest wave did not hand over
     }
 }
 
@@ -910,6 +910,7 @@ struct q1env {
     uint64_t tick_count = 0;          // ticks since create: the counter of the counter-based RNG
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     int num_cus = 256;                // compute units of the device (MI355X in SPX mode: 256)
+    int server_blocks_per_cu = -1;    // occupancy of the resident tick server (queried once)
     bool mlp_attr_set = false;        // dynamic-LDS attribute of the policy kernels (a per-device setting: kept per handle)
     // cached hipGraphs of step_many, keyed by (ticks, formats, pointers); a handful of entries, oldest evicted
     struct GraphEntry { std::vector<uint64_t> key; hipGraphExec_t exec; };
@@ -1763,17 +1764,19 @@ int q1env_step_persistent_start(q1env_t* h, int ticks, uint32_t tag0, const uint
     // The whole grid must be resident at once - a wave that is not scheduled never polls - AND leave room for the producer's waves
     // on every SIMD (a server that fills the register file starves the producer it waits for: both would only time out).
     DeviceGuard guard_occ(h->device);
-    int per_cu = 0;
-    const void* fn = is_spec(h->p) ? (const void*)tick_server_kernel<true> : (const void*)tick_server_kernel<false>;
-    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 64, 0));
+    if (h->server_blocks_per_cu < 0) {
+        int per_cu = 0;
+        const void* fn = is_spec(h->p) ? (const void*)tick_server_kernel<true> : (const void*)tick_server_kernel<false>;
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 64, 0));
+        h->server_blocks_per_cu = per_cu;
+    }
+    const int per_cu = h->server_blocks_per_cu;
     const long max_envs = (long)h->num_cus * (per_cu > 4 ? per_cu - 4 : 0) * 64;
     if ((long)h->p.n > max_envs)
         return fail(Q1ENV_ERR_INVALID_ARG, "q1env_step_persistent_start: too many envs for one resident grid next to its producer (" +
                                            std::to_string(max_envs) + " at most on this device)");
     if (h->p.yaw_mode == 2 && h->p.yaw_steps > 8388608.0) return fail(Q1ENV_ERR_INVALID_ARG, "q1env_step_persistent_start: step index does not fit the granule");
     DeviceGuard guard(h->device);
-    const uint32_t init[5] = {0u, 0u, 0xFFFFFFFFu, 0u, 0xFFFFFFFFu};
-    HIP_TRY(hipMemcpyAsync(status_dev, init, sizeof(init), hipMemcpyHostToDevice, h->stream));
     const dim3 g(((unsigned)h->p.n + 63u) / 64u), b(64);
     const uint64_t timeout_ticks = (uint64_t)(timeout_s * 1.0e8);          // wall_clock64: 100 MHz
     if (is_spec(h->p))

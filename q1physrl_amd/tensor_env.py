@@ -131,7 +131,7 @@ class TensorVectorEnv:
         mouse float32 (T,N)) over only after tick t's results arrived.  Bit-identical to T step_autoreset calls.  Returns a dict:
         obs (N,6) / reward / done / zero_start of the LAST tick (decoded from the result granules), checksum (float64 (2,N): sums
         of the rewards / first observation column of ticks 0..T-2 as the producer received them) and status (the five uint32 of
-        include/q1env.h; status[1] / status[3] != 0 = a side timed out)."""
+        include/q1env.h for this launch pair; status[1] / status[3] != 0 = a side timed out, status[2] / status[4] = ticks left unserved)."""
         n, d = self.num_envs, self.device
         ticks = int(keys.shape[0])
         assert keys.dtype == torch.uint8 and keys.is_contiguous() and tuple(keys.shape) == (ticks, n)
@@ -142,6 +142,7 @@ class TensorVectorEnv:
                          "stream": torch.cuda.Stream(device=d), "tag": 0}
         sv = self._srv
         sv["checksum"].zero_()
+        sv["status"].zero_()
         cur = torch.cuda.current_stream(d)
         sv["stream"].wait_stream(cur)                       # the producer starts after the inputs exist
         self._dev.persistent_start(ticks, sv["tag"], sv["mailbox"].data_ptr(), sv["results"].data_ptr(), self.obs.data_ptr(), self.seed,
