@@ -21,14 +21,15 @@ def make_env(n, seed, **over):
 def actions(n, ticks, seed):
     import torch
     g = torch.Generator(device="cuda").manual_seed(seed)
-    keys = torch.randint(0, 16, (ticks, n), dtype=torch.uint8, device="cuda", generator=g)
+    keys = torch.randint(0, 16, (ticks, n), dtype=torch.uint8, device="cuda", generator=g)     # (a 3-key Config ignores bit 3)
     mouse = (torch.rand((ticks, n), device="cuda", generator=g) * 2 - 1) * float(np.float32(720) * np.float32(0.014))
     return keys, mouse.contiguous()
 
 
 @pytest.mark.parametrize("n,ticks,over", [(4096 + 37, 150, dict(time_limit=0.5, zero_start_prob=0.3)),
                                           (65536, 100, dict(zero_start_prob=1.0)),
-                                          (1000, 90, dict(time_limit=0.4, zero_start_prob=0.5, smooth_keys=False, key_press_delay=0.0))])
+                                          (1000, 90, dict(time_limit=0.4, zero_start_prob=0.5, smooth_keys=False, key_press_delay=0.0)),
+                                          (777, 80, dict(time_limit=0.4, zero_start_prob=0.5, auto_jump=True, speed_reward=True))])   # SPEC=false kernels
 def test_tick_server_equals_per_tick_kernels(n, ticks, over):
     import torch
     cfg, a = make_env(n, 7, **over)
