@@ -311,7 +311,7 @@ def main(argv=None):
         if srv is None:
             srv = {"mailbox": torch.zeros((n,), dtype=torch.int64, device=d), "results": torch.zeros((7, n), dtype=torch.int64, device=d),
                    "status": torch.zeros((5,), dtype=torch.int32, device=d), "tag": 0,
-                   "stream": None if injected else torch.cuda.Stream(device=d)}
+                   "stream": None if injected else torch.cuda.Stream(device=d, priority=-1)}
             dsync()
         return srv
 
@@ -349,10 +349,14 @@ def main(argv=None):
                     if timed and not started:
                         calls.append(dev.timer_start)
                         started = True
-                    calls.append(functools.partial(dev.persistent_start, chunk, sv["tag"], sv["mailbox"].data_ptr(), sv["results"].data_ptr(),
-                                                   o1, 99, True, sv["status"].data_ptr(), 2.0))
-                    calls.append(functools.partial(dev.persistent_drive, ps, chunk, sv["tag"], ka, ma, sv["mailbox"].data_ptr(),
-                                                   sv["results"].data_ptr(), 0, sv["status"].data_ptr(), 2.0))
+                    if os.environ.get("Q1_BENCH_SERVER_TWO_STREAMS"):      # producer on its own (high-priority) stream
+                        calls.append(functools.partial(dev.persistent_start, chunk, sv["tag"], sv["mailbox"].data_ptr(), sv["results"].data_ptr(),
+                                                       o1, 99, True, sv["status"].data_ptr(), 2.0))
+                        calls.append(functools.partial(dev.persistent_drive, ps, chunk, sv["tag"], ka, ma, sv["mailbox"].data_ptr(),
+                                                       sv["results"].data_ptr(), 0, sv["status"].data_ptr(), 2.0))
+                    else:                                                  # server + producer as one dispatch: co-resident by construction
+                        calls.append(functools.partial(dev.persistent_pair, chunk, sv["tag"], ka, ma, sv["mailbox"].data_ptr(),
+                                                       sv["results"].data_ptr(), o1, 99, True, 0, sv["status"].data_ptr(), 2.0))
                     sv["tag"] = (sv["tag"] + chunk) & 0xFFFFFF
                 launches += 1
                 t += chunk
@@ -445,7 +449,7 @@ def main(argv=None):
     kern_us = ev_ms * 1e3 / launches
     achieved = B_ALG * n * ticks_per_launch / (kern_us * 1e-6) / 1e9
     kernel = {"step": "step_kernel<float,SPEC,PACKED>", "rollout": "rollout_kernel<float,SPEC,PACKED,no-reset,all-outputs>",
-              "server": "tick_server_kernel<SPEC>"}[args.mode]
+              "server": "tick_pair_kernel<SPEC> (tick server + dependent producer)"}[args.mode]
     roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
             "traffic": load_profiled_traffic(args.mode, n), "kernel": kernel, "avg_launch_us": kern_us,
             "event_ms_per_step": ev_ms / args.steps, "wall_over_event": wall * 1e3 / ev_ms if ev_ms > 0 else None,

@@ -648,10 +648,10 @@ __device__ __forceinline__ void granule_store(uint64_t* p, uint64_t v) {
 }
 
 template <bool SPEC>
-__global__ void __launch_bounds__(64)
-tick_server_kernel(Params p, StatePtrs s, int ticks, uint32_t tag0, const uint64_t* mailbox, uint64_t* results, float* obs_final,
-                   uint64_t seed, uint64_t counter0, int auto_reset, uint32_t* status, uint64_t timeout_ticks) {
-    const uint32_t lane = threadIdx.x, i = blockIdx.x * 64u + lane, n = (uint32_t)p.n;
+__device__ __forceinline__ void tick_server_body(const Params& p, const StatePtrs& s, uint32_t block, int ticks, uint32_t tag0,
+                                                 const uint64_t* mailbox, uint64_t* results, float* obs_final, uint64_t seed,
+                                                 uint64_t counter0, int auto_reset, uint32_t* status, uint64_t timeout_ticks) {
+    const uint32_t lane = threadIdx.x, i = block * 64u + lane, n = (uint32_t)p.n;
     const bool live = i < n;
     const uint64_t genv = (uint64_t)p.env_index_base + (uint64_t)i;
     Env e{};
@@ -717,10 +717,10 @@ tick_server_kernel(Params p, StatePtrs s, int ticks, uint32_t tag0, const uint64
 // in flight together).  Actions come from a resident tick-major packed episode (keys uint8[T][N], mouse float[T][N]); checksum
 // (optional, double[2][N]) accumulates the rewards and the first observation column it received, so the data really makes the
 // round trip.  One lane per env, resident next to the server.
-__global__ void __launch_bounds__(64)
-tick_driver_kernel(int n, int ticks, uint32_t tag0, const uint8_t* keys, const float* mouse, uint64_t* mailbox,
-                   const uint64_t* results, double* checksum, uint32_t* status, uint64_t timeout_ticks) {
-    const uint32_t lane = threadIdx.x, i = blockIdx.x * 64u + lane;
+__device__ __forceinline__ void tick_driver_body(int n, uint32_t block, int ticks, uint32_t tag0, const uint8_t* keys, const float* mouse,
+                                                 uint64_t* mailbox, const uint64_t* results, double* checksum, uint32_t* status,
+                                                 uint64_t timeout_ticks) {
+    const uint32_t lane = threadIdx.x, i = block * 64u + lane;
     const bool live = i < (uint32_t)n;
     double acc_r = 0.0, acc_o = 0.0;
     bool timed_out = false;
@@ -766,6 +766,36 @@ tick_driver_kernel(int n, int ticks, uint32_t tag0, const uint8_t* keys, const f
         if (timed_out) atomicOr(&status[3], 1u);
         atomicMax(&status[4], (uint32_t)(ticks - handed));       // actions the slowest wave did not hand over
     }
+}
+
+template <bool SPEC>
+__global__ void __launch_bounds__(64)
+tick_server_kernel(Params p, StatePtrs s, int ticks, uint32_t tag0, const uint64_t* mailbox, uint64_t* results, float* obs_final,
+                   uint64_t seed, uint64_t counter0, int auto_reset, uint32_t* status, uint64_t timeout_ticks) {
+    tick_server_body<SPEC>(p, s, blockIdx.x, ticks, tag0, mailbox, results, obs_final, seed, counter0, auto_reset, status, timeout_ticks);
+}
+
+__global__ void __launch_bounds__(64)
+tick_driver_kernel(int n, int ticks, uint32_t tag0, const uint8_t* keys, const float* mouse, uint64_t* mailbox,
+                   const uint64_t* results, double* checksum, uint32_t* status, uint64_t timeout_ticks) {
+    tick_driver_body(n, blockIdx.x, ticks, tag0, keys, mouse, mailbox, results, checksum, status, timeout_ticks);
+}
+
+// Server and reference driver in ONE dispatch (q1env_step_persistent_pair): blocks [0, B) are the server's waves, blocks [B, 2B) the
+// driver's.  Two streams are only concurrent when the runtime maps them to different hardware queues, which HIP does not
+// promise (a process that has created many streams re-uses queues: the producer then queues BEHIND the server it feeds and both
+// sides can only time out).  One grid that fits the device is co-resident by construction - this is what the benchmark and most
+// tests use; the two-stream entry points remain for an external producer.
+template <bool SPEC>
+__global__ void __launch_bounds__(64)
+tick_pair_kernel(Params p, StatePtrs s, int ticks, uint32_t tag0, uint64_t* mailbox, uint64_t* results, float* obs_final,
+                 uint64_t seed, uint64_t counter0, int auto_reset, const uint8_t* keys, const float* mouse, double* checksum,
+                 uint32_t* status, uint64_t timeout_ticks) {
+    const uint32_t half = gridDim.x >> 1;
+    if (blockIdx.x < half)
+        tick_server_body<SPEC>(p, s, blockIdx.x, ticks, tag0, mailbox, results, obs_final, seed, counter0, auto_reset, status, timeout_ticks);
+    else
+        tick_driver_body(p.n, blockIdx.x - half, ticks, tag0, keys, mouse, mailbox, results, checksum, status, timeout_ticks);
 }
 
 // Traffic calibration for the PMC counters (MI355X_MICROARCH.md "HBM": FETCH_SIZE / WRITE_SIZE must be calibrated on
@@ -911,6 +941,7 @@ struct q1env {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     int num_cus = 256;                // compute units of the device (MI355X in SPX mode: 256)
     int server_blocks_per_cu = -1;    // occupancy of the resident tick server (queried once)
+    int pair_blocks_per_cu = -1;      // ... and of the server + driver pair kernel
     bool mlp_attr_set = false;        // dynamic-LDS attribute of the policy kernels (a per-device setting: kept per handle)
     // cached hipGraphs of step_many, keyed by (ticks, formats, pointers); a handful of entries, oldest evicted
     struct GraphEntry { std::vector<uint64_t> key; hipGraphExec_t exec; };
@@ -1802,6 +1833,37 @@ int q1env_step_persistent_drive(q1env_t* h, void* producer_stream, int ticks, ui
     hipLaunchKernelGGL(tick_driver_kernel, g, b, 0, (hipStream_t)producer_stream, h->p.n, ticks, tag0, keys_dev, mouse_dev, mailbox_dev,
                        results_dev, checksum_dev, status_dev, (uint64_t)(timeout_s * 1.0e8));
     HIP_TRY(hipGetLastError());
+    return Q1ENV_OK;
+}
+
+int q1env_step_persistent_pair(q1env_t* h, int ticks, uint32_t tag0, const uint8_t* keys_dev, const float* mouse_dev,
+                               uint64_t* mailbox_dev, uint64_t* results_dev, float* obs_final_dev, uint64_t seed, int auto_reset,
+                               double* checksum_dev, uint32_t* status_dev, double timeout_s) {
+    if (!h || !keys_dev || !mouse_dev || !mailbox_dev || !results_dev || !status_dev)
+        return fail(Q1ENV_ERR_INVALID_ARG, "q1env_step_persistent_pair: null argument");
+    if (ticks <= 0 || !(timeout_s > 0.0) || timeout_s > 30.0) return fail(Q1ENV_ERR_INVALID_ARG, "q1env_step_persistent_pair: bad ticks / timeout_s");
+    DeviceGuard guard(h->device);
+    if (h->pair_blocks_per_cu < 0) {
+        int per_cu = 0;
+        const void* fn = is_spec(h->p) ? (const void*)tick_pair_kernel<true> : (const void*)tick_pair_kernel<false>;
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 64, 0));
+        h->pair_blocks_per_cu = per_cu;
+    }
+    const unsigned blocks = ((unsigned)h->p.n + 63u) / 64u;
+    const long resident = (long)h->num_cus * h->pair_blocks_per_cu;
+    if (2L * blocks > resident)
+        return fail(Q1ENV_ERR_INVALID_ARG, "q1env_step_persistent_pair: too many envs for one resident grid (" +
+                                           std::to_string(resident / 2 * 64) + " at most on this device)");
+    const uint64_t timeout_ticks = (uint64_t)(timeout_s * 1.0e8);
+    const dim3 g(2u * blocks), b(64);
+    if (is_spec(h->p))
+        hipLaunchKernelGGL(tick_pair_kernel<true>, g, b, 0, h->stream, h->p, h->st, ticks, tag0, mailbox_dev, results_dev, obs_final_dev, seed,
+                           h->tick_count, auto_reset, keys_dev, mouse_dev, checksum_dev, status_dev, timeout_ticks);
+    else
+        hipLaunchKernelGGL(tick_pair_kernel<false>, g, b, 0, h->stream, h->p, h->st, ticks, tag0, mailbox_dev, results_dev, obs_final_dev, seed,
+                           h->tick_count, auto_reset, keys_dev, mouse_dev, checksum_dev, status_dev, timeout_ticks);
+    HIP_TRY(hipGetLastError());
+    h->tick_count += (uint64_t)ticks;
     return Q1ENV_OK;
 }
 

@@ -231,6 +231,12 @@ class DeviceEnv:
         _lib.check(self._lib.q1env_step_persistent_drive(self._h, C.c_void_p(int(producer_stream)), int(ticks), int(tag0) & 0xFFFFFFFF,
                                                          keys, mouse, mailbox, results, checksum or None, status, float(timeout_s)))
 
+    def persistent_pair(self, ticks, tag0, keys, mouse, mailbox, results, obs_final, seed, auto_reset, checksum, status, timeout_s=2.0):
+        """Server + reference driver as one dispatch on the handle's stream (q1env_step_persistent_pair)."""
+        _lib.check(self._lib.q1env_step_persistent_pair(self._h, int(ticks), int(tag0) & 0xFFFFFFFF, keys, mouse, mailbox, results,
+                                                        obs_final or None, int(seed) & (2 ** 64 - 1), int(bool(auto_reset)),
+                                                        checksum or None, status, float(timeout_s)))
+
     def observe_dev(self, obs, obs_format=_lib.OBS_F32):
         _lib.check(self._lib.q1env_observe(self._h, obs_format, obs))
 

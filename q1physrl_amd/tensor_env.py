@@ -125,13 +125,16 @@ class TensorVectorEnv:
                               return_sum.data_ptr() if return_sum is not None else 0)
         return obs, rew, done
 
-    def serve_ticks(self, keys: torch.Tensor, mouse: torch.Tensor, auto_reset: bool = True, timeout_s: float = 2.0, sync: bool = True):
+    def serve_ticks(self, keys: torch.Tensor, mouse: torch.Tensor, auto_reset: bool = True, timeout_s: float = 2.0, sync: bool = True,
+                    two_streams: bool = False):
         """Experimental: `ticks` ticks on the RESIDENT tick server (q1env_step_persistent_*: no kernel boundary per tick, state in
         registers) fed by the reference dependent producer on a side stream, which hands tick t+1's action (keys uint8 (T,N),
         mouse float32 (T,N)) over only after tick t's results arrived.  Bit-identical to T step_autoreset calls.  Returns a dict:
         obs (N,6) / reward / done / zero_start of the LAST tick (decoded from the result granules), checksum (float64 (2,N): sums
         of the rewards / first observation column of ticks 0..T-2 as the producer received them) and status (the five uint32 of
-        include/q1env.h for this launch pair; status[1] / status[3] != 0 = a side timed out, status[2] / status[4] = ticks left unserved)."""
+        include/q1env.h for this launch pair; status[1] / status[3] != 0 = a side timed out, status[2] / status[4] = ticks left unserved).
+        two_streams=False: server and producer are blocks of ONE dispatch (co-resident by construction); True: the producer runs on a
+        high-priority side stream (its own hardware-queue pool) - the arrangement an external producer has."""
         n, d = self.num_envs, self.device
         ticks = int(keys.shape[0])
         assert keys.dtype == torch.uint8 and keys.is_contiguous() and tuple(keys.shape) == (ticks, n)
@@ -139,18 +142,22 @@ class TensorVectorEnv:
         if not hasattr(self, "_srv"):
             self._srv = {"mailbox": torch.zeros((n,), dtype=torch.int64, device=d), "results": torch.zeros((7, n), dtype=torch.int64, device=d),
                          "status": torch.zeros((5,), dtype=torch.int32, device=d), "checksum": torch.zeros((2, n), dtype=torch.float64, device=d),
-                         "stream": torch.cuda.Stream(device=d), "tag": 0}
+                         "stream": torch.cuda.Stream(device=d, priority=-1), "tag": 0}
         sv = self._srv
         sv["checksum"].zero_()
         sv["status"].zero_()
         cur = torch.cuda.current_stream(d)
-        sv["stream"].wait_stream(cur)                       # the producer starts after the inputs exist
-        self._dev.persistent_start(ticks, sv["tag"], sv["mailbox"].data_ptr(), sv["results"].data_ptr(), self.obs.data_ptr(), self.seed,
-                                   auto_reset, sv["status"].data_ptr(), timeout_s)
-        self._dev.persistent_drive(sv["stream"].cuda_stream, ticks, sv["tag"], keys.data_ptr(), mouse.data_ptr(), sv["mailbox"].data_ptr(),
-                                   sv["results"].data_ptr(), sv["checksum"].data_ptr(), sv["status"].data_ptr(), timeout_s)
+        if two_streams:
+            sv["stream"].wait_stream(cur)                   # the producer starts after the inputs exist
+            self._dev.persistent_start(ticks, sv["tag"], sv["mailbox"].data_ptr(), sv["results"].data_ptr(), self.obs.data_ptr(), self.seed,
+                                       auto_reset, sv["status"].data_ptr(), timeout_s)
+            self._dev.persistent_drive(sv["stream"].cuda_stream, ticks, sv["tag"], keys.data_ptr(), mouse.data_ptr(), sv["mailbox"].data_ptr(),
+                                       sv["results"].data_ptr(), sv["checksum"].data_ptr(), sv["status"].data_ptr(), timeout_s)
+            cur.wait_stream(sv["stream"])
+        else:
+            self._dev.persistent_pair(ticks, sv["tag"], keys.data_ptr(), mouse.data_ptr(), sv["mailbox"].data_ptr(), sv["results"].data_ptr(),
+                                      self.obs.data_ptr(), self.seed, auto_reset, sv["checksum"].data_ptr(), sv["status"].data_ptr(), timeout_s)
         sv["tag"] = (sv["tag"] + ticks) & 0xFFFFFF
-        cur.wait_stream(sv["stream"])
         if not sync:
             return None
         torch.cuda.synchronize(d)

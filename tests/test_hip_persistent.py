@@ -30,7 +30,8 @@ def actions(n, ticks, seed):
                                           (65536, 100, dict(zero_start_prob=1.0)),
                                           (1000, 90, dict(time_limit=0.4, zero_start_prob=0.5, smooth_keys=False, key_press_delay=0.0)),
                                           (777, 80, dict(time_limit=0.4, zero_start_prob=0.5, auto_jump=True, speed_reward=True))])   # SPEC=false kernels
-def test_tick_server_equals_per_tick_kernels(n, ticks, over):
+@pytest.mark.parametrize("two_streams", [False, True])
+def test_tick_server_equals_per_tick_kernels(n, ticks, over, two_streams):
     import torch
     cfg, a = make_env(n, 7, **over)
     _, b = make_env(n, 7, **over)
@@ -45,10 +46,10 @@ def test_tick_server_equals_per_tick_kernels(n, ticks, over):
             sums[int(t >= half), 0] += rew_b.double()
             sums[int(t >= half), 1] += obs_b[:, 0].double()
     # two launches: the second continues where the first stopped (tags go on)
-    r1 = a.serve_ticks(keys[:half].contiguous(), mouse[:half].contiguous())
+    r1 = a.serve_ticks(keys[:half].contiguous(), mouse[:half].contiguous(), two_streams=two_streams)
     assert r1["status"][1] == 0 and r1["status"][3] == 0 and r1["status"][2] == 0 and r1["status"][4] == 0
     first = r1["checksum"].clone()
-    r2 = a.serve_ticks(keys[half:].contiguous(), mouse[half:].contiguous())
+    r2 = a.serve_ticks(keys[half:].contiguous(), mouse[half:].contiguous(), two_streams=two_streams)
     st = r2["status"]
     assert st[1] == 0 and st[3] == 0 and st[0] == (n + 63) // 64 and st[2] == 0 and st[4] == 0, st
     torch.cuda.synchronize()

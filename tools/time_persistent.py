@@ -30,18 +30,18 @@ def main():
         mouse = (torch.rand((T, n), device="cuda") * 20 - 10).contiguous()
         dev = env._dev
         row = {"envs": n, "ticks": T}
-        for label in ("server_us_per_tick",):
+        for label, two in (("server_us_per_tick", False), ("server_two_streams_us_per_tick", True)):
             try:
-                env.serve_ticks(keys, mouse)                  # warm-up
+                env.serve_ticks(keys, mouse, two_streams=two)                  # warm-up
             except _lib.Q1EnvError as ex:
-                row["server_refused"] = str(ex)[-90:]
-                break
+                row[label.replace("us_per_tick", "refused")] = str(ex)[-90:]
+                continue
             best = 1e30
             for _ in range(args.reps):
                 env.reset()
                 torch.cuda.synchronize()
                 dev.timer_start()
-                env.serve_ticks(keys, mouse, sync=False)
+                env.serve_ticks(keys, mouse, sync=False, two_streams=two)
                 ms = dev.timer_stop()
                 st = env._srv["status"].cpu().numpy()
                 assert st[1] == 0 and st[3] == 0 and st[2] == 0, st
