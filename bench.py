@@ -401,7 +401,7 @@ def main(argv=None):
 
     def server_ok():
         st = server_state()["status"].cpu().numpy()          # accumulated since it was zeroed at set-up
-        return int(st[1]) == 0 and int(st[3]) == 0 and int(st[2]) == 0 and int(st[4]) == 0
+        return not st.any()
 
     def measure(mode, steps, warmup):
         # Preparation (untimed): instantiate + upload every graph the two sequences replay, and replay them ONCE with the env

@@ -312,9 +312,10 @@ int q1env_episode_stats(q1env_t* env, const float* reward_dev, const uint8_t* do
  *   results[6][i] = (tag << 40) | (zero_start << 33) | (done << 32) | float32 bits of reward
  *   tag of tick t (0-based) of the launch = (tag0 + t + 1) & 0xFFFFFF; zero the mailbox before the first launch.
  * obs_final (optional, float[N][6]): the last served tick's observation rows as plain stores at the end of the launch.
- * status uint32[5], ACCUMULATED by the kernels (zero it before a launch pair to read that pair alone): [0] += server waves that
- * served every tick, [1] |= 1 when a server wave timed out waiting for an action, [2] = max ticks a server wave left unserved,
- * [3] |= 1 when a driver wave timed out, [4] = max actions a driver wave did not hand over.  Every wait is bounded by timeout_s (of no progress): a missing producer ends the launch with status[1] set and the state
+ * status uint32[5], ACCUMULATED by the kernels and written ONLY on failure (all zero = every wave served / handed over every tick;
+ * zero it before a launch to read that launch alone): [0] += server waves that did not serve every tick, [1] |= 1 when a server
+ * wave timed out waiting for an action, [2] = max ticks a server wave left unserved, [3] |= 1 when a driver wave timed out,
+ * [4] = max actions a driver wave did not hand over.  Every wait is bounded by timeout_s (of no progress): a missing producer ends the launch with status[1] set and the state
  * of the last completed tick stored - it never hangs the device.  num_envs <= CUs * 2048 (the grid must be resident at once).
  * _start launches the server on the handle's stream (asynchronous; wait with q1env_sync).  _drive launches the reference
  * producer on `producer_stream` (a hipStream_t other than the handle's): a DEPENDENT driver - what a policy is to the env - that

@@ -705,8 +705,8 @@ __device__ __forceinline__ void tick_server_body(const Params& p, const StatePtr
         store_env(s, n, i, e);
         if (obs_final && completed > 0) write_obs<float>(obs_final, (size_t)i, o.obs);    // plain row of the last served tick
     }
-    if (lane == 0) {
-        if (completed == ticks) atomicAdd(&status[0], 1u);       // waves that served every tick
+    if (lane == 0 && completed != ticks) {                       // nothing is written on the success path: thousands of waves ending
+        atomicAdd(&status[0], 1u);                               // together would serialise ~12 ns per atomic on these five words
         if (timed_out) atomicOr(&status[1], 1u);
         atomicMax(&status[2], (uint32_t)(ticks - completed));    // ticks the slowest wave left unserved
     }
@@ -762,7 +762,7 @@ __device__ __forceinline__ void tick_driver_body(int n, uint32_t block, int tick
         handed = t + 1;
     }
     if (live && checksum) { checksum[i] += acc_r; checksum[(size_t)n + i] += acc_o; }
-    if (lane == 0) {
+    if (lane == 0 && handed != ticks) {
         if (timed_out) atomicOr(&status[3], 1u);
         atomicMax(&status[4], (uint32_t)(ticks - handed));       // actions the slowest wave did not hand over
     }

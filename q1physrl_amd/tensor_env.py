@@ -132,7 +132,7 @@ class TensorVectorEnv:
         mouse float32 (T,N)) over only after tick t's results arrived.  Bit-identical to T step_autoreset calls.  Returns a dict:
         obs (N,6) / reward / done / zero_start of the LAST tick (decoded from the result granules), checksum (float64 (2,N): sums
         of the rewards / first observation column of ticks 0..T-2 as the producer received them) and status (the five uint32 of
-        include/q1env.h for this launch pair; status[1] / status[3] != 0 = a side timed out, status[2] / status[4] = ticks left unserved).
+        include/q1env.h for this launch: all zero = success; status[1] / status[3] != 0 = a side timed out, status[2] / status[4] = ticks left unserved).
         two_streams=False: server and producer are blocks of ONE dispatch (co-resident by construction); True: the producer runs on a
         high-priority side stream (its own hardware-queue pool) - the arrangement an external producer has."""
         n, d = self.num_envs, self.device

@@ -47,11 +47,11 @@ def test_tick_server_equals_per_tick_kernels(n, ticks, over, two_streams):
             sums[int(t >= half), 1] += obs_b[:, 0].double()
     # two launches: the second continues where the first stopped (tags go on)
     r1 = a.serve_ticks(keys[:half].contiguous(), mouse[:half].contiguous(), two_streams=two_streams)
-    assert r1["status"][1] == 0 and r1["status"][3] == 0 and r1["status"][2] == 0 and r1["status"][4] == 0
+    assert not r1["status"].any(), r1["status"]
     first = r1["checksum"].clone()
     r2 = a.serve_ticks(keys[half:].contiguous(), mouse[half:].contiguous(), two_streams=two_streams)
     st = r2["status"]
-    assert st[1] == 0 and st[3] == 0 and st[0] == (n + 63) // 64 and st[2] == 0 and st[4] == 0, st
+    assert not st.any(), st
     torch.cuda.synchronize()
     sa, sb = a.get_state(), b.get_state()
     for k in sa:
@@ -73,7 +73,7 @@ def test_tick_server_against_the_numpy_oracle():
     ora = O.OracleVectorEnv(cfg)
     keys, mouse = actions(n, ticks, 11)
     res = env.serve_ticks(keys, mouse, auto_reset=False)
-    assert res["status"][1] == 0 and res["status"][2] == 0 and res["status"][0] == 1
+    assert not res["status"].any()
     kh, mh = keys.cpu().numpy(), mouse.cpu().numpy()
     total = np.zeros(n)
     for t in range(ticks):
@@ -104,14 +104,14 @@ def test_tick_server_without_a_producer_times_out_and_reports_it():
     torch.cuda.synchronize()
     took = time.perf_counter() - t0
     st = status.cpu().numpy()
-    assert st[1] == 1 and st[0] == 0 and st[2] == 50 and took < 2.0, (st, took)
+    assert st[1] == 1 and st[0] == n // 64 and st[2] == 50 and took < 2.0, (st, took)
     after = env.get_state()
     for k in before:
         assert np.array_equal(before[k], after[k]), k           # no tick was served: the state is what it was
     # the device is fine: a normal tick still runs, and the server works when it does get a producer
     keys, mouse = actions(n, 20, 2)
     res = env.serve_ticks(keys, mouse)
-    assert res["status"][1] == 0 and res["status"][2] == 0 and res["status"][0] == n // 64
+    assert not res["status"].any()
     # a driver without a server times out on its side too
     status.zero_()
     side = torch.cuda.Stream()
