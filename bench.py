@@ -15,13 +15,16 @@ mouse ~ U(-action_range, action_range) float32).  Inputs (the packed 5 B/env act
 720-tick episode) are resident in HBM before the timed region; every tick writes obs float32 (N,6),
 reward float32, done uint8; all envs are reset on device at each episode end (inside the timed region).
 
-  --mode step     (default, = `value`): ONE step_kernel launch per tick, 720 launches replayed from one hipGraph.
-                  This is the granularity the drop-in API has (a policy can sit between ticks).
+  --mode auto     (default) = server, falling back to step (and saying so in "mode_fallback") if the server cannot run.
+  --mode step     ONE step_kernel launch per tick, 720 launches replayed from one hipGraph.  The granularity the drop-in API has
+                  (a policy can sit between ticks); reported as "per_tick_step" when it is not the primary mode.
   --mode rollout  the fused kernel: 720 ticks per launch, state in registers, same per-tick outputs.
                   Reported in the same JSON line under "fused_rollout" (secondary; it needs the actions in advance).
-  --mode server   the resident tick server (q1env_step_persistent_*): one launch serves all K ticks, state in registers, and a
-                  DEPENDENT producer kernel on a second stream hands tick t+1's action over only after tick t's results arrived
-                  (a policy's place).  Reported under "persistent_server" when it is not the primary mode.
+  --mode server   the resident tick server (q1env_step_persistent_pair): ONE dispatch serves all K ticks with the env state in
+                  registers; half of its waves are the server, the other half a DEPENDENT producer that hands tick t+1's action over
+                  only after all of tick t's results arrived (a policy's place) - every tick is a real round trip through 8-byte
+                  data-tagged words, no kernel boundary per tick.  Bit-identical to the per-tick kernels
+                  (tests/test_hip_persistent.py).  Q1_BENCH_SERVER_TWO_STREAMS=1 puts the producer on its own stream instead.
 
 Multi-GPU: one process per GPU, the batch is split (65 536 envs per GPU, weak scaling), no collective on
 the data path; ranks only meet in the barriers around the timed region and in the MAX of the elapsed time.
@@ -192,7 +195,8 @@ def parse_args(argv=None):
     ap.add_argument("--steps", type=int, default=7200)
     ap.add_argument("--warmup", type=int, default=720)
     ap.add_argument("--envs", type=int, default=65536, help="envs per GPU (131072 = BASELINE configs[3]'s shard)")
-    ap.add_argument("--mode", choices=("step", "rollout", "server"), default="step")
+    ap.add_argument("--mode", choices=("auto", "step", "rollout", "server"), default="auto",
+                    help="auto = server (the resident tick server), falling back to step - and saying so in the JSON - if it cannot run")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary (other-mode) measurement")
@@ -346,17 +350,25 @@ def main(argv=None):
                 if not prepare:
                     sv = server_state()
                     ps = 1 if sv["stream"] is None else sv["stream"].cuda_stream
+                    two = bool(os.environ.get("Q1_BENCH_SERVER_TWO_STREAMS"))
+                    ar = 1
                     if timed and not started:
-                        calls.append(dev.timer_start)
+                        if two:
+                            calls.append(dev.timer_start)
+                        else:
+                            ar |= _lib.TIMER_START
                         started = True
-                    if os.environ.get("Q1_BENCH_SERVER_TWO_STREAMS"):      # producer on its own (high-priority) stream
+                    if timed and left == chunk and not two:
+                        ar |= _lib.TIMER_STOP
+                        stopped = True
+                    if two:                                                # producer on its own (high-priority) stream
                         calls.append(functools.partial(dev.persistent_start, chunk, sv["tag"], sv["mailbox"].data_ptr(), sv["results"].data_ptr(),
                                                        o1, 99, True, sv["status"].data_ptr(), 2.0))
                         calls.append(functools.partial(dev.persistent_drive, ps, chunk, sv["tag"], ka, ma, sv["mailbox"].data_ptr(),
                                                        sv["results"].data_ptr(), 0, sv["status"].data_ptr(), 2.0))
                     else:                                                  # server + producer as one dispatch: co-resident by construction
                         calls.append(functools.partial(dev.persistent_pair, chunk, sv["tag"], ka, ma, sv["mailbox"].data_ptr(),
-                                                       sv["results"].data_ptr(), o1, 99, True, 0, sv["status"].data_ptr(), 2.0))
+                                                       sv["results"].data_ptr(), o1, 99, ar, 0, sv["status"].data_ptr(), 2.0))
                     sv["tag"] = (sv["tag"] + chunk) & 0xFFFFFF
                 launches += 1
                 t += chunk
@@ -442,7 +454,26 @@ def main(argv=None):
         dist.all_gather_object(rows, mine)
         return rows
 
-    wall, ev_ms, launches, own = measure(args.mode, args.steps, args.warmup)
+    fallback, measured = None, False
+    if args.mode == "auto":
+        args.mode = "step" if injected else "server"
+        if not injected:
+            try:
+                wall, ev_ms, launches, own = measure("server", args.steps, args.warmup)
+                measured = True
+            except Exception as ex:   # noqa: BLE001 - e.g. the pair grid is not resident on this device: measure the per-tick kernels instead
+                fallback = f"server mode failed ({ex!r}); measured with per-tick launches instead"
+                sys.stderr.write("bench.py: " + fallback + "\n")
+                args.mode = "step"
+        if world > 1:                             # every rank must time the same thing
+            modes = [None] * world
+            dist.all_gather_object(modes, args.mode)
+            if any(m != "server" for m in modes) and args.mode == "server":
+                fallback = "another rank fell back to step mode; measured with per-tick launches on every rank"
+                args.mode = "step"
+                measured = False
+    if not measured:
+        wall, ev_ms, launches, own = measure(args.mode, args.steps, args.warmup)
     ranks = per_rank(own, ev_ms)
     value = float(n) * args.steps * world / wall
     ticks_per_launch = args.steps / launches
@@ -483,6 +514,7 @@ def main(argv=None):
                    "envs_per_gpu": n, "parallelism": f"batch-split x{world}, no collective",
                    "arithmetic": "float64 (float32 storage of vel/obs/reward), bit-identical to the NumPy reference"},
         "roofline": roof,
+        "mode": args.mode, "mode_fallback": fallback,
         "per_rank": ranks,
         "parity": "max |pos - NumPy ref| over the 10 s rollout: measured live in cpu_baseline.parity_vs_gpu_after_719_ticks (N=1 runs); "
                   "tests/test_hip_fastpath.py::test_full_size_rollout_parity_65536_envs_720_ticks checks all 65 536 x 720 env-steps bit-exactly",

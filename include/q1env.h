@@ -330,7 +330,9 @@ int q1env_step_persistent_drive(q1env_t* env, void* producer_stream, int ticks, 
 /* _start + _drive as ONE dispatch on the handle's stream (server waves and driver waves are blocks of the same grid, same protocol,
  * same results): two streams are only concurrent when the runtime maps them to different hardware queues, which HIP does not
  * promise - a producer queued behind the server it feeds can only time out.  Give an external producer a stream of another
- * PRIORITY (hipStreamCreateWithPriority: separate queue pool) or use this entry point.  num_envs <= half the resident capacity. */
+ * PRIORITY (hipStreamCreateWithPriority: separate queue pool) or use this entry point.  num_envs <= half the resident capacity.
+ * auto_reset: bit 0 = in-kernel reset of finished episodes; Q1ENV_TIMER_START (4) / Q1ENV_TIMER_STOP (8) may be added to record the
+ * handle's timer events right around the launch, as in q1env_step_many. */
 int q1env_step_persistent_pair(q1env_t* env, int ticks, uint32_t tag0, const uint8_t* keys_dev, const float* mouse_dev,
                                uint64_t* mailbox_dev, uint64_t* results_dev, float* obs_final_dev, uint64_t seed, int auto_reset,
                                double* checksum_dev, uint32_t* status_dev, double timeout_s);

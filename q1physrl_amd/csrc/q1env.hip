@@ -1856,6 +1856,9 @@ int q1env_step_persistent_pair(q1env_t* h, int ticks, uint32_t tag0, const uint8
                                            std::to_string(resident / 2 * 64) + " at most on this device)");
     const uint64_t timeout_ticks = (uint64_t)(timeout_s * 1.0e8);
     const dim3 g(2u * blocks), b(64);
+    const bool t_start = (auto_reset & Q1ENV_TIMER_START) != 0, t_stop = (auto_reset & Q1ENV_TIMER_STOP) != 0;
+    auto_reset &= 1;
+    if (t_start) HIP_TRY(hipEventRecord(h->ev0, h->stream));
     if (is_spec(h->p))
         hipLaunchKernelGGL(tick_pair_kernel<true>, g, b, 0, h->stream, h->p, h->st, ticks, tag0, mailbox_dev, results_dev, obs_final_dev, seed,
                            h->tick_count, auto_reset, keys_dev, mouse_dev, checksum_dev, status_dev, timeout_ticks);
@@ -1863,6 +1866,7 @@ int q1env_step_persistent_pair(q1env_t* h, int ticks, uint32_t tag0, const uint8
         hipLaunchKernelGGL(tick_pair_kernel<false>, g, b, 0, h->stream, h->p, h->st, ticks, tag0, mailbox_dev, results_dev, obs_final_dev, seed,
                            h->tick_count, auto_reset, keys_dev, mouse_dev, checksum_dev, status_dev, timeout_ticks);
     HIP_TRY(hipGetLastError());
+    if (t_stop) HIP_TRY(hipEventRecord(h->ev1, h->stream));
     h->tick_count += (uint64_t)ticks;
     return Q1ENV_OK;
 }

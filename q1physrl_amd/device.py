@@ -234,7 +234,7 @@ class DeviceEnv:
     def persistent_pair(self, ticks, tag0, keys, mouse, mailbox, results, obs_final, seed, auto_reset, checksum, status, timeout_s=2.0):
         """Server + reference driver as one dispatch on the handle's stream (q1env_step_persistent_pair)."""
         _lib.check(self._lib.q1env_step_persistent_pair(self._h, int(ticks), int(tag0) & 0xFFFFFFFF, keys, mouse, mailbox, results,
-                                                        obs_final or None, int(seed) & (2 ** 64 - 1), int(bool(auto_reset)),
+                                                        obs_final or None, int(seed) & (2 ** 64 - 1), int(auto_reset),   # bit 0 + timer flags
                                                         checksum or None, status, float(timeout_s)))
 
     def observe_dev(self, obs, obs_format=_lib.OBS_F32):

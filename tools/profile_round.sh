@@ -15,8 +15,10 @@ rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch 
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -o write -- python bench.py $ARGS > $OUT/bench_write.json 2> $OUT/write.err
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/cal_fetch -o fetch -- python tools/calib_traffic.py > /dev/null 2> $OUT/cal_fetch.err
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/cal_write -o write -- python tools/calib_traffic.py > /dev/null 2> $OUT/cal_write.err
-# the resident tick server: kernel trace only (PMC collection serialises kernels; the server and its producer must run concurrently)
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_server -o trace -- python bench.py --mode server $ARGS > $OUT/bench_server_trace.json 2> $OUT/trace_server.err
+# the per-tick kernels (bench.py's default mode is the resident tick server)
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_step -o trace -- python bench.py --mode step $ARGS > $OUT/bench_step_trace.json 2> $OUT/trace_step.err
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch_step -o fetch -- python bench.py --mode step $ARGS > /dev/null 2> $OUT/fetch_step.err
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write_step -o write -- python bench.py --mode step $ARGS > /dev/null 2> $OUT/write_step.err
 python tools/summarize_prof.py $OUT > $OUT/summary.txt 2>&1
 cat $OUT/summary.txt
 find $OUT -name '*.csv' -size +2M -delete

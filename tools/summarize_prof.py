@@ -25,9 +25,9 @@ if st:
     print("== rocprofv3 --kernel-trace --stats (kernel_stats.csv)")
     for row in csv.DictReader(open(st)):
         print(f"  {short(row['Name']):60s} calls={row['Calls']:>6s} avg_ns={float(row['AverageNs']):10.1f} min={row['MinNs']:>7s} max={row['MaxNs']:>8s} pct={row['Percentage']}")
-sv = first("trace_server/**/*kernel_stats.csv")
+sv = first("trace_step/**/*kernel_stats.csv")
 if sv:
-    print("== rocprofv3 --kernel-trace --stats, bench.py --mode server (resident tick server + dependent producer)")
+    print("== rocprofv3 --kernel-trace --stats, bench.py --mode step (one step_kernel launch per tick)")
     for row in csv.DictReader(open(sv)):
         if float(row["Percentage"]) > 0.05:
             print(f"  {short(row['Name']):60s} calls={row['Calls']:>6s} avg_ns={float(row['AverageNs']):12.1f} min={row['MinNs']:>9s} max={row['MaxNs']:>9s} pct={row['Percentage']}")
@@ -59,7 +59,8 @@ def pmc(tag, ctr):
 
 
 res = {}
-for label, ftag, wtag in (("bench", "pmc_fetch", "pmc_write"), ("calibration", "cal_fetch", "cal_write")):
+for label, ftag, wtag in (("bench", "pmc_fetch", "pmc_write"), ("bench --mode step", "pmc_fetch_step", "pmc_write_step"),
+                          ("calibration", "cal_fetch", "cal_write")):
     f, w = pmc(ftag, "FETCH_SIZE"), pmc(wtag, "WRITE_SIZE")
     print(f"== PMC per launch ({label}); FETCH_SIZE / WRITE_SIZE are in KiB; corrected fetch = raw x2 (gfx950, MI355X_MICROARCH.md HBM section)")
     for key in sorted(set(f) | set(w), key=str):
