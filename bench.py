@@ -178,12 +178,16 @@ def size_sweep(dev_index, sizes=(262144, 1048576, 4194304), ticks=72, reps=4):
     return rows
 
 
-def load_profiled_traffic(mode, n):
-    """HBM bytes per launch measured with rocprofv3 PMC passes (tools/profile_round.sh -> profiles/traffic.json); None if absent."""
+def load_profiled_traffic(mode, n, env_steps_per_launch=None):
+    """HBM bytes per launch measured with rocprofv3 PMC passes (tools/profile_round.sh -> profiles/traffic.json); None if absent.
+    A tick-server launch serves as many ticks as it is asked to, so its entry is per env-step and scaled to the launch."""
     path = os.path.join(ROOT, "profiles", "traffic.json")
     try:
         with open(path) as f:
             d = json.load(f)
+        if mode == "server":
+            per = d.get(f"server_{n}_per_env_step")
+            return None if per is None or env_steps_per_launch is None else per * env_steps_per_launch
         return d.get(f"{mode}_{n}")
     except Exception:   # noqa: BLE001
         return None
@@ -290,10 +294,21 @@ def main(argv=None):
         # the env path has no collective: ranks only meet in barriers and one MAX of a scalar, which gloo serves from the host
         # (no GPU all-reduce latency inside the timed region's brackets); Q1_BENCH_BACKEND=nccl selects RCCL instead
         backend = os.environ.get("Q1_BENCH_BACKEND", "gloo")
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=d)
-        else:
-            dist.init_process_group("gloo")
+        # rank 0's stdout carries exactly ONE line, the JSON: the native libraries' connection banners ("[Gloo] Rank 0 is connected
+        # to ..." goes to the C++ stdout) are sent to stderr while the process group comes up
+        sys.stdout.flush()
+        saved_fd = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            if backend == "nccl":
+                dist.init_process_group("nccl", device_id=d)
+            else:
+                dist.init_process_group("gloo")
+            dist.barrier()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved_fd, 1)
+            os.close(saved_fd)
 
     n = args.envs
     start, _ = sharding.shard_range(n * world, rank, world)                  # contiguous batch split, weak scaling
@@ -482,7 +497,7 @@ def main(argv=None):
     kernel = {"step": "step_kernel<float,SPEC,PACKED>", "rollout": "rollout_kernel<float,SPEC,PACKED,no-reset,all-outputs>",
               "server": "tick_pair_kernel<SPEC> (tick server + dependent producer)"}[args.mode]
     roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-            "traffic": load_profiled_traffic(args.mode, n), "kernel": kernel, "avg_launch_us": kern_us,
+            "traffic": load_profiled_traffic(args.mode, n, n * ticks_per_launch), "kernel": kernel, "avg_launch_us": kern_us,
             "event_ms_per_step": ev_ms / args.steps, "wall_over_event": wall * 1e3 / ev_ms if ev_ms > 0 else None,
             "alg_bytes_per_env_step": B_ALG, "env_steps_per_launch": n * ticks_per_launch,
             "note": "achieved = 204 B x env-steps per launch / (HIP-event time of the timed region / launches). "
@@ -490,9 +505,10 @@ def main(argv=None):
                     "(null if that size was not profiled)."}
     if args.mode == "server":
         roof["note"] += (" The resident tick server keeps the env state in registers between ticks and exchanges 8-byte data-tagged "
-                         "granules with a dependent producer kernel on a second stream (8 B action in, 56 B results out per env-step): "
-                         "the 204-B figure is the per-tick kernel's algorithmic traffic, kept for comparability; this mode is bound by "
-                         "the two agent-scope hand-off hops per tick, not by HBM.")
+                         "granules with the dependent producer half of the same dispatch (8 B action in, 56 B results out per env-step, "
+                         "written through to memory: 134 B of measured HBM traffic per env-step incl. the other side's reads and poll "
+                         "re-reads): the 204-B figure is the per-tick formulation's algorithmic traffic (SURVEY 8d), kept as the common "
+                         "yardstick; this mode is bound by the two agent-scope hand-off hops per tick, not by HBM bandwidth.")
     if args.mode == "rollout":
         real = (B_FUSED * n * ticks_per_launch + 170.0 * n) / (kern_us * 1e-6) / 1e9
         roof["real_bytes_achieved_GBps"] = real

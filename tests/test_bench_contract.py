@@ -42,3 +42,10 @@ def test_bench_prints_one_contract_json_line():
     rf = d["roofline"]
     assert rf["bound"] in ("hbm", "mfma") and rf["unit"] == "GB/s" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9
     assert d["fused_rollout"]["value"] > d["value"]
+    # the default primary mode is the resident tick server (falling back to per-tick launches, loudly, if it cannot run); the
+    # per-tick kernels are then reported next to it, and the steady-state block carries both
+    assert d["mode"] in ("server", "step") and (d["mode"] == "server" or d["mode_fallback"])
+    if d["mode"] == "server":
+        assert d["mode_fallback"] is None and d["per_tick_step"]["value"] > 1e8 and "tick_pair_kernel" in rf["kernel"]
+    ss = d["steady_state_720_ticks"]
+    assert ss["step"]["us_per_tick"] > 0 and ss["server"]["us_per_tick"] > 0

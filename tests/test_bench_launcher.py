@@ -23,8 +23,8 @@ def _run(cmd, extra_env=None, timeout=300):
 
 
 def _one_json(stdout):
-    lines = [ln for ln in stdout.splitlines() if ln.strip().startswith("{")]
-    assert len(lines) == 1, stdout
+    lines = [ln for ln in stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1 and lines[0].startswith("{"), stdout          # rank 0's stdout is the JSON line and nothing else
     return json.loads(lines[0])
 
 
