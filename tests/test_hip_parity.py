@@ -415,3 +415,43 @@ def test_g6_device_rng_reset_against_reference_draws():
     # zero starts are exact states, not distributions
     assert np.all(st["yaw"][zs] == 90.0) and np.all(st["time_remaining"][zs] == 10.0) and np.all(speed[zs] == 0.0)
     assert np.all(st["vel_z"] == -12.0) and np.all(st["z_pos"] == np.float64(np.float32(32.843201)))
+
+
+def test_speculative_rollback_leaves_a_foreign_rng_user_alone():
+    """the speculative batch's rollback rewinds the GLOBAL NumPy stream.  If other code drew from np.random between the
+    reset_at calls of a tick, rewinding would replay its draws - so the rollback then keeps the stream where it is (RuntimeWarning,
+    counted in speculation_stats) while still restoring the device state and re-applying the claimed resets."""
+    import warnings
+    from q1physrl_amd import env as E
+    n = 257
+    kw = dict(O.OracleConfig.get_default(num_envs=n, zero_start_prob=0.3, time_limit=0.25).__dict__)
+    np.random.seed(5)
+    e = E.VectorPhysEnv(dict(kw), speculative_resets=True)
+    rng = np.random.default_rng(1)
+    hit = 0
+    for t in range(60):
+        a = np.concatenate([(rng.random((n, 4)) < 0.5).astype(np.float64), rng.uniform(-10, 10, (n, 1))], axis=1)
+        obs, rew, done, _ = e.vector_step(a)
+        idx = np.flatnonzero(done)
+        if idx.size < 3:
+            for i in idx:
+                e.reset_at(int(i))
+            continue
+        first = e.reset_at(int(idx[0]))                 # starts the speculative batch (draws for ALL finished envs)
+        foreign = np.random.random()                    # somebody else uses the global stream
+        after_foreign = np.random.get_state()
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            st = e.get_state()                          # a state read settles the batch: idx[1:] were not claimed -> rollback
+        assert any(issubclass(x.category, RuntimeWarning) and "global NumPy RNG" in str(x.message) for x in w)
+        now = np.random.get_state()
+        assert now[2] == after_foreign[2] and np.array_equal(now[1], after_foreign[1])      # the stream was NOT rewound
+        assert 0.0 <= foreign < 1.0
+        # device state: env idx[0] is reset (its obs is what reset_at returned), the unclaimed ones are still finished
+        assert st["time_remaining"][idx[0]] > 0 and np.all(st["time_remaining"][idx[1:]] < 0)
+        assert np.allclose(e._get_obs_at(int(idx[0])), first, rtol=0, atol=0)
+        for i in idx[1:]:
+            e.reset_at(int(i))
+        hit += 1
+    assert hit > 5 and e.speculation_stats.get("foreign_rng_use", 0) == hit
+    e.close()

@@ -624,3 +624,35 @@ def test_no_mouse_policy_row_and_rejected_widths():
     with pytest.raises(_lib.Q1EnvError, match="row_stride"):
         env._dev.policy_sample_dev(lt.data_ptr(), 18, 1, 0, k.data_ptr(), m.data_ptr())
     env.close()
+
+
+def test_graph_recapture_keeps_adam_state():
+    """A change of the minibatch size re-captures the SGD-step graph in the middle of training.  The capture's warm-up steps are
+    rolled back by restoring parameters AND optimiser state (moments, step counts) - not by zeroing the latter: after a second
+    update with another minibatch size the graph learner still agrees with the eager one."""
+    import copy
+    import torch
+    from q1physrl_amd import policy as P, ppo, sampler as S
+    torch.manual_seed(5)
+    base = P.Q1Policy().cuda()
+    cfg, env = make_env(512, time_limit=1.0)
+    smp = S.GpuSampler(env, base, horizon=32)
+    trajs = []
+    for _ in range(2):
+        tr = {k: v.clone() for k, v in smp.collect().items()}
+        adv, vt = smp.advantages(tr, 0.99, 0.95)
+        trajs.append((tr, adv.clone(), vt.clone()))
+    env.close()
+    res = []
+    for use_graph in (False, True):
+        pol = copy.deepcopy(base)
+        lr = ppo.PPOLearner(pol, cfg.action_range, lr=1e-3, num_sgd_iter=3, minibatch_size=2048, seed=11, use_graph=use_graph)
+        lr.update(*trajs[0])
+        lr.minibatch_size = 4096                          # -> re-capture on the next update (graph learner)
+        lr.update(*trajs[1])
+        steps = [int(st["step"].item()) if torch.is_tensor(st["step"]) else int(st["step"]) for st in lr.opt.state.values()]
+        res.append(([p.detach().clone() for p in pol.parameters()], steps))
+    (pe, se), (pg, sg) = res
+    assert se == sg and se[0] == 3 * (512 * 32 // 2048) + 3 * (512 * 32 // 4096)       # Adam's step count survived the re-capture
+    for a, b in zip(pe, pg):
+        assert torch.allclose(a, b, rtol=0, atol=5e-5), (a - b).abs().max().item()
