@@ -54,7 +54,6 @@ B_ALG = 204.0            # algorithmic bytes per env-step (SURVEY.md 8d / DESIGN
 B_FUSED = 34.0           # real bytes per env-step of the fused rollout kernel (5 B action + 29 B outputs), + 170 B/env/launch
 HBM_PEAK_GBPS = 8000.0   # MI355X_MICROARCH.md: 8 TB/s spec
 EPISODE_TICKS = 720
-DRY_RUN_TICKS = 3000     # untimed dry replays of the (warm-up + timed) sequence before the real warm-up, state restored afterwards
 
 
 def make_actions(n, ticks, action_range, seed):
@@ -436,15 +435,13 @@ def main(argv=None):
         # Preparation (untimed): instantiate + upload every graph the two sequences replay, and replay them ONCE with the env
         # state saved and restored around it, so that neither the warm-up nor the timed region pays a first-replay cost (kernel
         # code objects, the graph's packets, the TLB entries of the action slabs) - in production a graph is replayed thousands
-        # of times - and the dry replays go on for >= 3 000 ticks (~10 ms) so that the short driver-style region is not measured on a
-        # GPU that has just left its idle clocks.  The env state the W warm-up ticks start from is the state before this preparation.
+        # of times.  The env state the W warm-up ticks start from is the state before this preparation.
         # (server mode: the plans hold the hand-off tags, so each is made right before it runs, in execution order)
         run(plan_ticks(mode, warmup, 0, prepare=True)[0])
         run(plan_ticks(mode, steps, warmup, prepare=True)[0])
         dev.snapshot_state()
-        for _ in range(max(1, -(-DRY_RUN_TICKS // max(1, warmup + steps)))):      # >= DRY_RUN_TICKS ticks: also brings the clocks up
-            run(plan_ticks(mode, warmup, 0)[0])
-            run(plan_ticks(mode, steps, warmup)[0])
+        run(plan_ticks(mode, warmup, 0)[0])
+        run(plan_ticks(mode, steps, warmup)[0])
         barrier()
         if mode == "server" and not server_ok():
             raise RuntimeError("tick server / producer timed out in the dry run (the two kernels were not co-resident)")

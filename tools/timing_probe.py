@@ -63,6 +63,35 @@ def main():
         q = lambda x: {"min": float(np.min(x)), "p50": float(np.median(x)), "p90": float(np.percentile(x, 90))}   # noqa: E731
         out[label] = {"launch_call_us": q(launch), "wall_us": q(wall), "event_us": q(ev),
                       "wall_per_tick_p50": float(np.median(wall)) / T, "event_per_tick_p50": float(np.median(ev)) / T}
+    # the resident tick server (one dispatch): where its 20-tick region's wall time goes
+    mailbox = torch.zeros((n,), dtype=torch.int64, device=d)
+    results = torch.zeros((7, n), dtype=torch.int64, device=d)
+    status = torch.zeros((5,), dtype=torch.int32, device=d)
+    tag = 0
+    for label, flags, sync in (("pair+flags+torch_sync", 1 | _lib.TIMER_START | _lib.TIMER_STOP, torch.cuda.synchronize),
+                               ("pair+flags+stream_sync", 1 | _lib.TIMER_START | _lib.TIMER_STOP, dev.sync),
+                               ("pair+noevents+stream_sync", 1, dev.sync)):
+        launch, wall, ev = [], [], []
+        for rep in range(args.reps + 5):
+            dev.reset_philox_dev(seed=1, done_only=False)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            dev.persistent_pair(T, tag, keys.data_ptr(), mouse.data_ptr(), mailbox.data_ptr(), results.data_ptr(), obs.data_ptr(), 1, flags, 0,
+                                status.data_ptr(), 2.0)
+            t1 = time.perf_counter()
+            sync()
+            t2 = time.perf_counter()
+            tag = (tag + T) & 0xFFFFFF
+            if rep < 5:
+                continue
+            if flags & _lib.TIMER_STOP:
+                ev.append(dev.timer_elapsed() * 1e3)
+            launch.append((t1 - t0) * 1e6)
+            wall.append((t2 - t0) * 1e6)
+        assert not status.cpu().numpy().any()
+        q = lambda x: {"min": float(np.min(x)), "p50": float(np.median(x)), "p90": float(np.percentile(x, 90))}   # noqa: E731
+        out[label] = {"launch_call_us": q(launch), "wall_us": q(wall), "event_us": q(ev) if ev else None,
+                      "wall_per_tick_p50": float(np.median(wall)) / T}
     # long region for reference: per-tick event time when launch/sync latency is amortised
     T2 = 720
     keys2 = torch.randint(0, 16, (T2, n), dtype=torch.uint8, device=d)
