@@ -13,7 +13,7 @@ import sys
 
 PKG = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(PKG, "csrc", "q1env.hip")
-DEPS = [SRC, os.path.join(PKG, "csrc", "q1env_device.hpp"), os.path.join(PKG, "csrc", "q1policy.hpp"),
+DEPS = [SRC, os.path.join(PKG, "csrc", "q1env_device.hpp"), os.path.join(PKG, "csrc", "q1policy.hpp"), os.path.join(PKG, "csrc", "q1server.hpp"),
         os.path.join(os.path.dirname(PKG), "include", "q1env.h")]
 OUT = os.path.join(PKG, "libq1env.so")
 

@@ -1,0 +1,183 @@
+// q1server.hpp - the resident tick server of libq1env (q1env_step_persistent_start / _drive / _pair, include/q1env.h): device code.
+// Included by q1env.hip after q1env_device.hpp; uses tick<>, reset_philox, observe<>, load_env / store_env from there.
+#pragma once
+#include "q1env_device.hpp"
+
+using namespace q1;
+
+// =========================================================================================== persistent tick server
+// q1env_step_persistent_*: ONE resident grid serves ticks for as long as actions keep arriving, the env state lives in registers
+// between ticks, and tick t's action is handed over by a producer running CONCURRENTLY on another stream - there is no kernel
+// boundary per tick (the ~1.8 us dependent-dispatch boundary + the write-back of the tick's dirty state lines that bound
+// q1env_step at 65 536 envs).  Hand-off protocol = the data-tagged granule of MI355X_MICROARCH.md (persistent-kernel price list,
+// "handoff-1to1"): every word that crosses is a naturally aligned 8-byte {data, tag} written by ONE sc1 (agent-scope,
+// write-through) store and polled with sc1 loads, so no separate flag, no fence, no L2 write-back and no store drain is needed in
+// either direction, and a consumer has a whole tick's outputs after ONE hop:
+//     action granule     mailbox[i]       = (tag << 40) | (keys << 32) | float_bits(mouse)                   producer -> server
+//     result granules    results[k][i]    = (tag << 40) | float_bits(obs[k]),  k = 0..5                       server -> consumer
+//                        results[6][i]    = (tag << 40) | (zero_start << 33) | (done << 32) | float_bits(reward)
+// (granule-index-major, so a wave's 64 granules of one index are one contiguous 512-byte store / load).
+// tag = (tag0 + t + 1) & 0xFFFFFF for tick t of the launch (never 0: a zeroed mailbox holds no valid action).
+// Every wait is bounded: a lane that sees no new tag for `timeout_ticks` of the 100 MHz wall clock gives up, the wave stores its
+// state as of the last completed tick and reports status[1] != 0 - a missing or stalled producer ends the launch, not the GPU.
+// Bit-identical to `ticks` q1env_step_autoreset / q1env_step calls with the packed action layout.
+constexpr int RESULT_GRANULES = 7;
+
+__device__ __forceinline__ uint64_t granule_load(const uint64_t* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void granule_store(uint64_t* p, uint64_t v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+template <bool SPEC>
+__device__ __forceinline__ void tick_server_body(const Params& p, const StatePtrs& s, uint32_t block, int ticks, uint32_t tag0,
+                                                 const uint64_t* mailbox, uint64_t* results, float* obs_final, uint64_t seed,
+                                                 uint64_t counter0, int auto_reset, uint32_t* status, uint64_t timeout_ticks) {
+    const uint32_t lane = threadIdx.x, i = block * 64u + lane, n = (uint32_t)p.n;
+    const bool live = i < n;
+    const uint64_t genv = (uint64_t)p.env_index_base + (uint64_t)i;
+    Env e{};
+    if (live) load_env(s, n, i, e);
+    int completed = 0;
+    bool timed_out = false;
+    TickOut<float> o;
+    o.reward = 0.0f; o.done = false;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) o.obs[j] = 0.0f;
+    for (int t = 0; t < ticks; ++t) {
+        const uint64_t tag = (uint64_t)((tag0 + (uint32_t)t + 1u) & 0xFFFFFFu);
+        uint64_t g = 0;
+        bool ok = !live;
+        uint32_t polls = 0;
+        uint64_t t_wait = 0;
+        for (;;) {                                    // every lane polls its own granule: one contiguous 512-B sc1 read per wave
+            if (!ok) {
+                g = granule_load(mailbox + i);
+                ok = (g >> 40) == tag;
+            }
+            if (__all(ok)) break;
+            // the load's own latency paces the loop; the 100 MHz clock is only consulted every 256 failed polls (no s_memrealtime
+            // on the path of a tick that is served promptly), the timeout counts from the first such look
+            if ((++polls & 255u) == 0u) {
+                const uint64_t now = wall_clock64();
+                if (t_wait == 0) t_wait = now;
+                else if (now - t_wait > timeout_ticks) { timed_out = true; break; }
+                __builtin_amdgcn_s_sleep(8);
+            }
+        }
+        if (timed_out) break;
+        if (live) {
+            const uint32_t keys = (uint32_t)(g >> 32) & ((1u << cfg_num_keys<SPEC>(p)) - 1u);
+            const double yaw_act = cfg_yaw_mode<SPEC>(p) ? (double)__uint_as_float((uint32_t)g) : 0.0;
+            tick<float, SPEC>(p, e, keys, yaw_act, o);
+            const bool zs = (e.flags & FLAG_ZERO_START) != 0;                       // of the episode the step belonged to
+            if (auto_reset && o.done) {
+                reset_philox(p, e, seed, genv, counter0 + (uint64_t)t + 1);
+                observe<float>(p, e, o.obs);
+            }
+            const uint64_t hi = tag << 40;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) granule_store(results + (size_t)k * n + i, hi | (uint64_t)__float_as_uint(o.obs[k]));
+            granule_store(results + (size_t)6 * n + i, hi | ((uint64_t)(zs ? 1u : 0u) << 33) | ((uint64_t)(o.done ? 1u : 0u) << 32) |
+                                                           (uint64_t)__float_as_uint(o.reward));
+        }
+        completed = t + 1;
+    }
+    if (live) {
+        store_env(s, n, i, e);
+        if (obs_final && completed > 0) write_obs<float>(obs_final, (size_t)i, o.obs);    // plain row of the last served tick
+    }
+    if (lane == 0 && completed != ticks) {                       // nothing is written on the success path: thousands of waves ending
+        atomicAdd(&status[0], 1u);                               // together would serialise ~12 ns per atomic on these five words
+        if (timed_out) atomicOr(&status[1], 1u);
+        atomicMax(&status[2], (uint32_t)(ticks - completed));    // ticks the slowest wave left unserved
+    }
+}
+
+// The reference driver of the tick server: a DEPENDENT producer, i.e. what a policy is to the env - it hands tick t+1's action
+// over only after ALL SEVEN result granules of tick t of the same env have arrived (one poll round: the seven loads of a lane are
+// in flight together).  Actions come from a resident tick-major packed episode (keys uint8[T][N], mouse float[T][N]); checksum
+// (optional, double[2][N]) accumulates the rewards and the first observation column it received, so the data really makes the
+// round trip.  One lane per env, resident next to the server.
+__device__ __forceinline__ void tick_driver_body(int n, uint32_t block, int ticks, uint32_t tag0, const uint8_t* keys, const float* mouse,
+                                                 uint64_t* mailbox, const uint64_t* results, double* checksum, uint32_t* status,
+                                                 uint64_t timeout_ticks) {
+    const uint32_t lane = threadIdx.x, i = block * 64u + lane;
+    const bool live = i < (uint32_t)n;
+    double acc_r = 0.0, acc_o = 0.0;
+    bool timed_out = false;
+    int handed = 0;
+    for (int t = 0; t < ticks; ++t) {
+        // tick t's action is fetched before the wait: its latency hides under the server's tick
+        const uint32_t k = live ? keys[(size_t)t * n + i] : 0u;
+        const float m = live ? mouse[(size_t)t * n + i] : 0.0f;
+        if (t > 0) {
+            const uint64_t want = (uint64_t)((tag0 + (uint32_t)t) & 0xFFFFFFu);      // results of tick t-1
+            uint64_t g[RESULT_GRANULES];
+            bool ok = !live;
+            uint32_t polls = 0;
+            uint64_t t_wait = 0;
+            for (;;) {
+                if (!ok) {
+#pragma unroll
+                    for (int q = 0; q < RESULT_GRANULES; ++q) g[q] = granule_load(results + (size_t)q * n + i);
+                    ok = true;
+#pragma unroll
+                    for (int q = 0; q < RESULT_GRANULES; ++q) ok = ok && ((g[q] >> 40) == want);
+                }
+                if (__all(ok)) break;
+                if ((++polls & 255u) == 0u) {
+                    const uint64_t now = wall_clock64();
+                    if (t_wait == 0) t_wait = now;
+                    else if (now - t_wait > timeout_ticks) { timed_out = true; break; }
+                    __builtin_amdgcn_s_sleep(8);
+                }
+            }
+            if (timed_out) break;
+            if (live) {
+                acc_r += (double)__uint_as_float((uint32_t)g[6]);
+                acc_o += (double)__uint_as_float((uint32_t)g[0]);
+            }
+        }
+        const uint64_t tag = (uint64_t)((tag0 + (uint32_t)t + 1u) & 0xFFFFFFu);
+        if (live) granule_store(mailbox + i, (tag << 40) | ((uint64_t)(k & 0xFu) << 32) | (uint64_t)__float_as_uint(m));
+        handed = t + 1;
+    }
+    if (live && checksum) { checksum[i] += acc_r; checksum[(size_t)n + i] += acc_o; }
+    if (lane == 0 && handed != ticks) {
+        if (timed_out) atomicOr(&status[3], 1u);
+        atomicMax(&status[4], (uint32_t)(ticks - handed));       // actions the slowest wave did not hand over
+    }
+}
+
+template <bool SPEC>
+__global__ void __launch_bounds__(64)
+tick_server_kernel(Params p, StatePtrs s, int ticks, uint32_t tag0, const uint64_t* mailbox, uint64_t* results, float* obs_final,
+                   uint64_t seed, uint64_t counter0, int auto_reset, uint32_t* status, uint64_t timeout_ticks) {
+    tick_server_body<SPEC>(p, s, blockIdx.x, ticks, tag0, mailbox, results, obs_final, seed, counter0, auto_reset, status, timeout_ticks);
+}
+
+__global__ void __launch_bounds__(64)
+tick_driver_kernel(int n, int ticks, uint32_t tag0, const uint8_t* keys, const float* mouse, uint64_t* mailbox,
+                   const uint64_t* results, double* checksum, uint32_t* status, uint64_t timeout_ticks) {
+    tick_driver_body(n, blockIdx.x, ticks, tag0, keys, mouse, mailbox, results, checksum, status, timeout_ticks);
+}
+
+// Server and reference driver in ONE dispatch (q1env_step_persistent_pair): blocks [0, B) are the server's waves, blocks [B, 2B) the
+// driver's.  Two streams are only concurrent when the runtime maps them to different hardware queues, which HIP does not
+// promise (a process that has created many streams re-uses queues: the producer then queues BEHIND the server it feeds and both
+// sides can only time out).  One grid that fits the device is co-resident by construction - this is what the benchmark and most
+// tests use; the two-stream entry points remain for an external producer.
+template <bool SPEC>
+__global__ void __launch_bounds__(64)
+tick_pair_kernel(Params p, StatePtrs s, int ticks, uint32_t tag0, uint64_t* mailbox, uint64_t* results, float* obs_final,
+                 uint64_t seed, uint64_t counter0, int auto_reset, const uint8_t* keys, const float* mouse, double* checksum,
+                 uint32_t* status, uint64_t timeout_ticks) {
+    const uint32_t half = gridDim.x >> 1;
+    if (blockIdx.x < half)
+        tick_server_body<SPEC>(p, s, blockIdx.x, ticks, tag0, mailbox, results, obs_final, seed, counter0, auto_reset, status, timeout_ticks);
+    else
+        tick_driver_body(p.n, blockIdx.x - half, ticks, tag0, keys, mouse, mailbox, results, checksum, status, timeout_ticks);
+}
+

@@ -455,3 +455,43 @@ def test_speculative_rollback_leaves_a_foreign_rng_user_alone():
         hit += 1
     assert hit > 5 and e.speculation_stats.get("foreign_rng_use", 0) == hit
     e.close()
+
+
+def test_large_batch_host_arrays_are_page_locked_and_owned_by_the_caller():
+    """Above the packed-staging threshold (16 384 envs) the NumPy arrays vector_step / vector_reset / get_state return live in
+    page-locked blocks from a pool (direct DMA instead of staged pageable copies).  They must still behave like the reference's
+    fresh arrays: later calls never overwrite them, a block returns to the pool only when the last array viewing it is collected,
+    and the values equal the oracle's."""
+    import gc
+    from q1physrl_amd import _lib, env as E
+    n = 20_000
+    kw = dict(O.OracleConfig.get_default(num_envs=n, zero_start_prob=0.5).__dict__)
+    np.random.seed(3)
+    ora = O.OracleVectorEnv(dict(kw))
+    np.random.seed(3)
+    env = E.VectorPhysEnv(dict(kw))
+    rng = np.random.default_rng(0)
+    kept, want = [], []
+    for t in range(6):
+        a = np.concatenate([(rng.random((n, 4)) < 0.5).astype(np.float64), rng.uniform(-10, 10, (n, 1)).astype(np.float32).astype(np.float64)], axis=1)
+        o1, r1, d1, _ = ora.vector_step(a)
+        o2, r2, d2, _ = env.vector_step(a)
+        kept.append((o2, r2, d2))
+        want.append((o1.copy(), r1.copy(), d1.copy()))
+    for (o2, r2, d2), (o1, r1, d1) in zip(kept, want):              # every tick's arrays are still what they were when returned
+        assert np.array_equal(o2, o1) and np.array_equal(r2, r1) and np.array_equal(d2, d1)
+        assert o2.dtype == np.float64 and r2.dtype == np.float32 and d2.dtype == np.bool_ and o2.flags["C_CONTIGUOUS"]
+    base = kept[0][0]
+    while base.base is not None:
+        base = base.base
+    assert isinstance(base, _lib._PinnedBlock)                         # page-locked, pool-owned
+    view = kept[0][0][5:10]                                           # a view keeps its block alive after the array itself is gone
+    pool = _lib.pinned_pool()
+    cached_before = pool._cached
+    del kept, o2, r2, d2, base
+    gc.collect()
+    assert pool._cached > cached_before                               # the other blocks went back to the pool ...
+    assert np.array_equal(view, want[0][0][5:10])                     # ... the viewed one is intact
+    o3, _, _, _ = env.vector_step(a)                                  # and recycled blocks serve the next call
+    assert np.array_equal(view, want[0][0][5:10]) and o3.shape == (n, 6)
+    env.close()
