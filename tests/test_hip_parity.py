@@ -482,7 +482,7 @@ def test_large_batch_host_arrays_are_page_locked_and_owned_by_the_caller():
         assert np.array_equal(o2, o1) and np.array_equal(r2, r1) and np.array_equal(d2, d1)
         assert o2.dtype == np.float64 and r2.dtype == np.float32 and d2.dtype == np.bool_ and o2.flags["C_CONTIGUOUS"]
     base = kept[0][0]
-    while base.base is not None:
+    while isinstance(base, np.ndarray) and base.base is not None:
         base = base.base
     assert isinstance(base, _lib._PinnedBlock)                         # page-locked, pool-owned
     view = kept[0][0][5:10]                                           # a view keeps its block alive after the array itself is gone
