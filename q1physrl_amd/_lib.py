@@ -3,7 +3,9 @@
 There is deliberately NO fallback: if the library is missing or no MI355X is visible the calls raise.
 """
 import ctypes as C
+import importlib.util
 import os
+import sys
 
 import numpy as np
 
@@ -103,6 +105,27 @@ EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 _lib = None
 
 
+def _share_torch_hip_runtime():
+    """One HIP runtime per process.  PyTorch-ROCm wheels bundle their own libamdhip64.so and load it by path; libq1env.so finds
+    ROCm's copy through its RUNPATH.  If this library comes first, a later `import torch` brings a SECOND runtime into the process and
+    torch.cuda then reports "No HIP GPUs are available".  So when a torch with a bundled runtime is installed (looked up without
+    importing it) and not loaded yet, that copy is loaded first: same SONAME, so libq1env binds to it and torch re-uses it."""
+    if "torch" in sys.modules:
+        return                                            # torch's runtime is in the process already; the SONAME resolves to it
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        try:
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass                                          # fall back to the system runtime
+
+
 def load():
     """dlopen libq1env.so (built by q1physrl_amd.build / __graft_entry__.build()) and type its symbols."""
     global _lib
@@ -111,6 +134,7 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise Q1EnvError(f"{LIB_PATH} is missing: build it with `python -m q1physrl_amd.build` "
                          "(hipcc, gfx950).  q1physrl_amd has no CPU fallback.")
+    _share_torch_hip_runtime()
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in _SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError here = the .so does not match include/q1env.h

@@ -495,3 +495,35 @@ def test_large_batch_host_arrays_are_page_locked_and_owned_by_the_caller():
     o3, _, _, _ = env.vector_step(a)                                  # and recycled blocks serve the next call
     assert np.array_equal(view, want[0][0][5:10]) and o3.shape == (n, 6)
     env.close()
+
+
+def test_library_and_torch_share_one_hip_runtime_whatever_the_import_order():
+    """`import q1physrl_amd.env`, step an env, THEN `import torch`: PyTorch-ROCm bundles its own libamdhip64.so; two runtimes in one
+    process leave torch.cuda without devices.  The binding loads torch's copy first when there is one, so both orders work."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = '''
+import sys
+import numpy as np
+from q1physrl_amd import env as E
+assert "torch" not in sys.modules
+e = E.VectorPhysEnv(dict(E.Config.get_default().__dict__, num_envs=256))
+o, r, d, _ = e.vector_step(np.zeros((256, 5)))
+import torch
+assert torch.cuda.is_available() and torch.cuda.device_count() >= 1
+x = torch.arange(8, device="cuda").float().sum().item()
+assert x == 28.0
+from q1physrl_amd.tensor_env import TensorVectorEnv
+t = TensorVectorEnv(dict(E.Config.get_default().__dict__, num_envs=256))
+t.reset()
+o2, r2, d2 = t.step_tensor(torch.zeros((256, 5), device="cuda"))
+torch.cuda.synchronize()
+maps = open("/proc/self/maps").read()
+libs = sorted({ln.split()[-1] for ln in maps.splitlines() if "libamdhip64" in ln})
+assert len(libs) == 1, libs
+print("OK", libs[0])
+'''
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=root, timeout=600)
+    assert r.returncode == 0 and "OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
