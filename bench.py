@@ -385,7 +385,7 @@ def main(argv=None):
                     else:                                                  # server + producer as one dispatch: co-resident by construction
                         calls.append(functools.partial(dev.persistent_pair, chunk, sv["tag"], ka, ma, sv["mailbox"].data_ptr(),
                                                        sv["results"].data_ptr(), o1, 99, ar, 0, sv["status"].data_ptr(), 2.0))
-                    sv["tag"] = (sv["tag"] + chunk) & 0xFFFFFF
+                    sv["tag"] = (sv["tag"] + chunk) % 0xFFFFFF
                 launches += 1
                 t += chunk
                 left -= chunk

@@ -310,7 +310,8 @@ int q1env_episode_stats(q1env_t* env, const float* reward_dev, const uint8_t* do
  *   mailbox[i]    = (tag << 40) | (key bits << 32) | float32 bits of the mouse action          producer -> server, uint64[N]
  *   results[k][i] = (tag << 40) | float32 bits of observation column k, k = 0..5              server -> consumer, uint64[7][N]
  *   results[6][i] = (tag << 40) | (zero_start << 33) | (done << 32) | float32 bits of reward
- *   tag of tick t (0-based) of the launch = (tag0 + t + 1) & 0xFFFFFF; zero the mailbox before the first launch.
+ *   tag of tick t (0-based) of the launch = (tag0 + t) mod (2^24 - 1) + 1, i.e. 1 .. 0xFFFFFF and never 0: zero the mailbox before the
+ *   first launch; continue a run with tag0' = (tag0 + ticks) mod (2^24 - 1).
  * obs_final (optional, float[N][6]): the last served tick's observation rows as plain stores at the end of the launch.
  * status uint32[5], ACCUMULATED by the kernels and written ONLY on failure (all zero = every wave served / handed over every tick;
  * zero it before a launch to read that launch alone): [0] += server waves that did not serve every tick, [1] |= 1 when a server

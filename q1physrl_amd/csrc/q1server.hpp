@@ -17,11 +17,16 @@ using namespace q1;
 //     result granules    results[k][i]    = (tag << 40) | float_bits(obs[k]),  k = 0..5                       server -> consumer
 //                        results[6][i]    = (tag << 40) | (zero_start << 33) | (done << 32) | float_bits(reward)
 // (granule-index-major, so a wave's 64 granules of one index are one contiguous 512-byte store / load).
-// tag = (tag0 + t + 1) & 0xFFFFFF for tick t of the launch (never 0: a zeroed mailbox holds no valid action).
+// tag = (tag0 + t) mod (2^24 - 1) + 1 for tick t of the launch: 1 .. 0xFFFFFF, never 0 - a zeroed mailbox holds no valid action -
+// and consecutive ticks never share a tag across the wrap-around.
 // Every wait is bounded: a lane that sees no new tag for `timeout_ticks` of the 100 MHz wall clock gives up, the wave stores its
 // state as of the last completed tick and reports status[1] != 0 - a missing or stalled producer ends the launch, not the GPU.
 // Bit-identical to `ticks` q1env_step_autoreset / q1env_step calls with the packed action layout.
 constexpr int RESULT_GRANULES = 7;
+
+__device__ __forceinline__ uint64_t tick_tag(uint32_t tag0, uint32_t t) {          // 1 .. 0xFFFFFF
+    return (uint64_t)(((uint64_t)tag0 + (uint64_t)t) % 0xFFFFFFull) + 1ull;
+}
 
 __device__ __forceinline__ uint64_t granule_load(const uint64_t* p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -46,7 +51,7 @@ __device__ __forceinline__ void tick_server_body(const Params& p, const StatePtr
 #pragma unroll
     for (int j = 0; j < 6; ++j) o.obs[j] = 0.0f;
     for (int t = 0; t < ticks; ++t) {
-        const uint64_t tag = (uint64_t)((tag0 + (uint32_t)t + 1u) & 0xFFFFFFu);
+        const uint64_t tag = tick_tag(tag0, (uint32_t)t);
         uint64_t g = 0;
         bool ok = !live;
         uint32_t polls = 0;
@@ -113,7 +118,7 @@ __device__ __forceinline__ void tick_driver_body(int n, uint32_t block, int tick
         const uint32_t k = live ? keys[(size_t)t * n + i] : 0u;
         const float m = live ? mouse[(size_t)t * n + i] : 0.0f;
         if (t > 0) {
-            const uint64_t want = (uint64_t)((tag0 + (uint32_t)t) & 0xFFFFFFu);      // results of tick t-1
+            const uint64_t want = tick_tag(tag0, (uint32_t)t - 1u);      // results of tick t-1
             uint64_t g[RESULT_GRANULES];
             bool ok = !live;
             uint32_t polls = 0;
@@ -140,7 +145,7 @@ __device__ __forceinline__ void tick_driver_body(int n, uint32_t block, int tick
                 acc_o += (double)__uint_as_float((uint32_t)g[0]);
             }
         }
-        const uint64_t tag = (uint64_t)((tag0 + (uint32_t)t + 1u) & 0xFFFFFFu);
+        const uint64_t tag = tick_tag(tag0, (uint32_t)t);
         if (live) granule_store(mailbox + i, (tag << 40) | ((uint64_t)(k & 0xFu) << 32) | (uint64_t)__float_as_uint(m));
         handed = t + 1;
     }

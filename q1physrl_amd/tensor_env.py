@@ -157,7 +157,7 @@ class TensorVectorEnv:
         else:
             self._dev.persistent_pair(ticks, sv["tag"], keys.data_ptr(), mouse.data_ptr(), sv["mailbox"].data_ptr(), sv["results"].data_ptr(),
                                       self.obs.data_ptr(), self.seed, auto_reset, sv["checksum"].data_ptr(), sv["status"].data_ptr(), timeout_s)
-        sv["tag"] = (sv["tag"] + ticks) & 0xFFFFFF
+        sv["tag"] = (sv["tag"] + ticks) % 0xFFFFFF
         if not sync:
             return None
         torch.cuda.synchronize(d)

@@ -90,6 +90,36 @@ def test_tick_server_against_the_numpy_oracle():
     env.close()
 
 
+def test_tick_server_tags_wrap_around():
+    """The 24-bit hand-off tag wraps after 16.7 M ticks: tags run 1 .. 0xFFFFFF and skip 0 (a zeroed mailbox must never look like a
+    valid action), and a run that crosses the wrap - here forced by starting 20 ticks before it - stays bit-identical."""
+    import torch
+    n, ticks = 3000, 64
+    cfg, a = make_env(n, 9, time_limit=0.3, zero_start_prob=0.5)
+    _, c = make_env(n, 9, time_limit=0.3, zero_start_prob=0.5)
+    keys, mouse = actions(n, ticks, 4)
+    # same history on both handles: one tick, then a reset (the reset's Philox counter is the handle's tick count)
+    a.reset(); c.reset()
+    r0 = a.serve_ticks(keys[:1].contiguous(), mouse[:1].contiguous())     # creates the server buffers; uses tag 1
+    c.step_autoreset((keys[0], mouse[0]))
+    assert not r0["status"].any() and int((a._srv["results"][6] >> 40).max()) == 1
+    a.reset(); c.reset()
+    a._srv["tag"] = 0xFFFFFF - 20                                         # the next launch crosses the wrap-around
+    res = a.serve_ticks(keys, mouse)
+    assert not res["status"].any()
+    assert a._srv["tag"] == (0xFFFFFF - 20 + ticks) % 0xFFFFFF == ticks - 20
+    for t in range(ticks):
+        obs_c, rew_c, done_c = c.step_autoreset((keys[t], mouse[t]))
+    torch.cuda.synchronize()
+    sa, sc = a.get_state(), c.get_state()
+    for k in sa:
+        assert np.array_equal(sa[k], sc[k]), k
+    assert torch.equal(res["obs"], obs_c) and torch.equal(res["reward"], rew_c) and torch.equal(res["done"], done_c)
+    tags = (a._srv["results"] >> 40).unique()                             # every granule carries the last tick's tag, which is not 0
+    assert tags.numel() == 1 and int(tags[0]) == (0xFFFFFF - 20 + ticks - 1) % 0xFFFFFF + 1 == ticks - 20
+    a.close(); c.close()
+
+
 def test_tick_server_without_a_producer_times_out_and_reports_it():
     import torch
     n = 2048

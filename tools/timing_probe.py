@@ -81,7 +81,7 @@ def main():
             t1 = time.perf_counter()
             sync()
             t2 = time.perf_counter()
-            tag = (tag + T) & 0xFFFFFF
+            tag = (tag + T) % 0xFFFFFF
             if rep < 5:
                 continue
             if flags & _lib.TIMER_STOP:
