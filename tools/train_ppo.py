@@ -36,6 +36,7 @@ ap.add_argument("--no-graph", action="store_true")
 ap.add_argument("--fused-policy", action="store_true", help="sample with the fused MFMA forward kernel (bf16 hidden layer)")
 ap.add_argument("--fused-loss", action="store_true", help="PPO loss + gradient from the q1env_ppo_loss_grad kernel")
 ap.add_argument("--save", default="", help="write the final policy weights (npz, RLlib fcnet naming) here")
+ap.add_argument("--discrete-yaw-steps", type=int, default=-1, help="Config.discrete_yaw_steps: the mouse becomes Discrete(2S+1) (a Categorical policy head)")
 args = ap.parse_args()
 
 rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
@@ -45,13 +46,15 @@ if world > 1:
     dist.init_process_group("nccl" if torch.cuda.device_count() >= world else "gloo")
 torch.manual_seed(args.seed)                                   # identical initial weights on every rank
 start, count = sharding.shard_range(args.envs, rank, world)
-cfg = Config(**{**Config.get_default().__dict__, "num_envs": count, "zero_start_prob": args.zero_start_prob})
+cfg = Config(**{**Config.get_default().__dict__, "num_envs": count, "zero_start_prob": args.zero_start_prob,
+                "discrete_yaw_steps": args.discrete_yaw_steps})
 env = TensorVectorEnv(cfg, device=local, seed=args.seed + 1, env_index_base=start)
-pol = P.Q1Policy().cuda()
+pol = P.Q1Policy(discrete_yaw_steps=args.discrete_yaw_steps).cuda()
 fused = P.FusedPolicyForward(pol, env) if args.fused_policy else None
 smp = GpuSampler(env, fused if fused is not None else pol, horizon=args.horizon, use_graph=not args.no_graph)
 lrn = ppo.PPOLearner(pol, float(cfg.action_range), lr=args.lr, num_sgd_iter=args.epochs, minibatch_size=args.minibatch,
-                     entropy_coeff=args.entropy, kl_target=args.kl_target, seed=args.seed + rank, use_graph=not args.no_graph, fused_loss=args.fused_loss, env=env)
+                     entropy_coeff=args.entropy, kl_target=args.kl_target, seed=args.seed + rank, use_graph=not args.no_graph, fused_loss=args.fused_loss, env=env,
+                     discrete_yaw_steps=args.discrete_yaw_steps)
 log = []
 t0 = time.time()
 prev = smp.stats
@@ -78,7 +81,7 @@ for it in range(args.iters):
         print(json.dumps(row), flush=True)
 
 # deterministic evaluation: zero-start, 720 ticks, argmax keys / squashed mean (what mkdemo would play back)
-ecfg = Config(**{**Config.get_default().__dict__, "num_envs": 64, "zero_start_prob": 1.0})
+ecfg = Config(**{**Config.get_default().__dict__, "num_envs": 64, "zero_start_prob": 1.0, "discrete_yaw_steps": args.discrete_yaw_steps})
 eenv = TensorVectorEnv(ecfg, device=local, seed=123)
 es = GpuSampler(eenv, pol, horizon=720)
 tr = es.collect(deterministic=True)
