@@ -367,15 +367,15 @@ def main(argv=None):
                     sv = server_state()
                     ps = 1 if sv["stream"] is None else sv["stream"].cuda_stream
                     two = bool(os.environ.get("Q1_BENCH_SERVER_TWO_STREAMS"))
-                    ar = 1
+                    pair_flags = 1                                         # bit 0: in-kernel reset of finished episodes
                     if timed and not started:
                         if two:
                             calls.append(dev.timer_start)
                         else:
-                            ar |= _lib.TIMER_START
+                            pair_flags |= _lib.TIMER_START
                         started = True
                     if timed and left == chunk and not two:
-                        ar |= _lib.TIMER_STOP
+                        pair_flags |= _lib.TIMER_STOP
                         stopped = True
                     if two:                                                # producer on its own (high-priority) stream
                         calls.append(functools.partial(dev.persistent_start, chunk, sv["tag"], sv["mailbox"].data_ptr(), sv["results"].data_ptr(),
@@ -384,7 +384,7 @@ def main(argv=None):
                                                        sv["results"].data_ptr(), 0, sv["status"].data_ptr(), 2.0))
                     else:                                                  # server + producer as one dispatch: co-resident by construction
                         calls.append(functools.partial(dev.persistent_pair, chunk, sv["tag"], ka, ma, sv["mailbox"].data_ptr(),
-                                                       sv["results"].data_ptr(), o1, 99, ar, 0, sv["status"].data_ptr(), 2.0))
+                                                       sv["results"].data_ptr(), o1, 99, pair_flags, 0, sv["status"].data_ptr(), 2.0))
                     sv["tag"] = (sv["tag"] + chunk) % 0xFFFFFF
                 launches += 1
                 t += chunk
@@ -427,9 +427,17 @@ def main(argv=None):
         if world > 1:
             dist.barrier()
 
+    def agree(ok):
+        """Collective AND over the ranks: every rank reaches the same verdict at the same point, so a failure on one GPU can never
+        leave the others waiting in a barrier."""
+        if world == 1:
+            return bool(ok)
+        flags = [None] * world
+        dist.all_gather_object(flags, bool(ok))
+        return all(flags)
+
     def server_ok():
-        st = server_state()["status"].cpu().numpy()          # accumulated since it was zeroed at set-up
-        return not st.any()
+        return not server_state()["status"].cpu().numpy().any()      # accumulated since it was zeroed at set-up; written on failure only
 
     def measure(mode, steps, warmup):
         # Preparation (untimed): instantiate + upload every graph the two sequences replay, and replay them ONCE with the env
@@ -437,14 +445,19 @@ def main(argv=None):
         # code objects, the graph's packets, the TLB entries of the action slabs) - in production a graph is replayed thousands
         # of times.  The env state the W warm-up ticks start from is the state before this preparation.
         # (server mode: the plans hold the hand-off tags, so each is made right before it runs, in execution order)
-        run(plan_ticks(mode, warmup, 0, prepare=True)[0])
-        run(plan_ticks(mode, steps, warmup, prepare=True)[0])
-        dev.snapshot_state()
-        run(plan_ticks(mode, warmup, 0)[0])
-        run(plan_ticks(mode, steps, warmup)[0])
+        err = None
+        try:
+            run(plan_ticks(mode, warmup, 0, prepare=True)[0])
+            run(plan_ticks(mode, steps, warmup, prepare=True)[0])
+            dev.snapshot_state()
+            run(plan_ticks(mode, warmup, 0)[0])
+            run(plan_ticks(mode, steps, warmup)[0])
+        except Exception as ex:   # noqa: BLE001 - e.g. the tick-server pair does not fit this device: reported collectively below
+            err = ex
         barrier()
-        if mode == "server" and not server_ok():
-            raise RuntimeError("tick server / producer timed out in the dry run (the two kernels were not co-resident)")
+        if not agree(err is None and (mode != "server" or server_ok())):
+            raise RuntimeError(f"{mode} mode failed in the dry run on at least one rank" + (f": {err!r}" if err is not None else
+                               " (tick server / producer timed out)" if mode == "server" else ""))
         dev.restore_state()
         run(plan_ticks(mode, warmup, 0)[0])       # the W untimed warm-up ticks
         timed_calls, launches = plan_ticks(mode, steps, warmup, timed=True)
@@ -456,8 +469,8 @@ def main(argv=None):
         ev_ms = dev.timer_elapsed()               # both events have completed: no further wait
         if world > 1:
             dist.barrier()
-        if mode == "server" and not server_ok():
-            raise RuntimeError("tick server / producer timed out in the timed region")
+        if not agree(mode != "server" or server_ok()):
+            raise RuntimeError("tick server / producer timed out in the timed region on at least one rank")
         wall = sharding.max_over_ranks(own, device=d)
         return wall, ev_ms, launches, own
 
@@ -472,8 +485,9 @@ def main(argv=None):
 
     fallback, measured = None, False
     if args.mode == "auto":
-        args.mode = "step" if injected else "server"
-        if not injected:
+        try_server = not injected or bool(os.environ.get("Q1_BENCH_FORCE_AUTO_SERVER"))     # (the test stand-in has no tick server)
+        args.mode = "server" if try_server else "step"
+        if try_server:
             try:
                 wall, ev_ms, launches, own = measure("server", args.steps, args.warmup)
                 measured = True
@@ -481,13 +495,7 @@ def main(argv=None):
                 fallback = f"server mode failed ({ex!r}); measured with per-tick launches instead"
                 sys.stderr.write("bench.py: " + fallback + "\n")
                 args.mode = "step"
-        if world > 1:                             # every rank must time the same thing
-            modes = [None] * world
-            dist.all_gather_object(modes, args.mode)
-            if any(m != "server" for m in modes) and args.mode == "server":
-                fallback = "another rank fell back to step mode; measured with per-tick launches on every rank"
-                args.mode = "step"
-                measured = False
+        # (measure() reaches its verdict collectively, so every rank is in the same mode here)
     if not measured:
         wall, ev_ms, launches, own = measure(args.mode, args.steps, args.warmup)
     ranks = per_rank(own, ev_ms)

@@ -74,3 +74,18 @@ def test_failed_rank_fails_the_launch():
     r = _run([sys.executable, "bench.py", "--gpus", "2", "--steps", "4", "--warmup", "1", "--envs", "8"],
              extra_env={"Q1_BENCH_ENV_FACTORY": "tests._bench_fake:Missing"})
     assert r.returncode != 0
+
+
+def test_server_mode_failure_is_collective_and_auto_falls_back():
+    """The oracle stand-in has no tick server.  Explicit `--mode server` must fail on BOTH ranks at the same point (nobody is left
+    waiting in a barrier: the run ends in seconds, non-zero); the default `auto` mode must fall back to per-tick launches on every
+    rank and say so in the JSON line."""
+    r = _run([sys.executable, "bench.py", "--gpus", "2", "--steps", "6", "--warmup", "2", "--envs", "16", "--mode", "server", "--no-secondary"],
+             timeout=120)
+    assert r.returncode != 0 and "server mode failed in the dry run" in r.stderr
+    r = _run([sys.executable, "bench.py", "--gpus", "2", "--steps", "6", "--warmup", "2", "--envs", "16", "--no-secondary"],
+             extra_env={"Q1_BENCH_FORCE_AUTO_SERVER": "1"}, timeout=120)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = _one_json(r.stdout)
+    _check_line(d, 2, 16, 6, 2)
+    assert d["mode"] == "step" and "server mode failed" in d["mode_fallback"] and "step_kernel" in d["roofline"]["kernel"]
