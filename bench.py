@@ -427,6 +427,8 @@ def main(argv=None):
         if world > 1:
             dist.barrier()
 
+    host_split = {}                              # per mode: host time spent enqueueing the timed region / waiting in the synchronisation
+
     def agree(ok):
         """Collective AND over the ranks: every rank reaches the same verdict at the same point, so a failure on one GPU can never
         leave the others waiting in a barrier."""
@@ -464,8 +466,10 @@ def main(argv=None):
         barrier()
         t0 = time.perf_counter()
         run(timed_calls)                          # EXACTLY `steps` ticks; HIP events on the launch stream around them
+        t_enq = time.perf_counter()
         dsync()                                   # the ONE synchronisation that ends the timed region (device-wide: covers both streams)
         own = time.perf_counter() - t0
+        host_split[mode] = {"enqueue_us": (t_enq - t0) * 1e6, "enqueue_to_sync_return_us": (t0 + own - t_enq) * 1e6}
         ev_ms = dev.timer_elapsed()               # both events have completed: no further wait
         if world > 1:
             dist.barrier()
@@ -508,6 +512,7 @@ def main(argv=None):
     roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
             "traffic": load_profiled_traffic(args.mode, n, n * ticks_per_launch), "kernel": kernel, "avg_launch_us": kern_us,
             "event_ms_per_step": ev_ms / args.steps, "wall_over_event": wall * 1e3 / ev_ms if ev_ms > 0 else None,
+            "host_split_us": host_split.get(args.mode),
             "alg_bytes_per_env_step": B_ALG, "env_steps_per_launch": n * ticks_per_launch,
             "note": "achieved = 204 B x env-steps per launch / (HIP-event time of the timed region / launches). "
                     "traffic = HBM bytes per launch from the rocprofv3 FETCH_SIZE(x2, gfx950)/WRITE_SIZE passes in profiles/ "

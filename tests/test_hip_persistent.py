@@ -29,7 +29,9 @@ def actions(n, ticks, seed):
 @pytest.mark.parametrize("n,ticks,over", [(4096 + 37, 150, dict(time_limit=0.5, zero_start_prob=0.3)),
                                           (65536, 100, dict(zero_start_prob=1.0)),
                                           (1000, 90, dict(time_limit=0.4, zero_start_prob=0.5, smooth_keys=False, key_press_delay=0.0)),
-                                          (777, 80, dict(time_limit=0.4, zero_start_prob=0.5, auto_jump=True, speed_reward=True))])   # SPEC=false kernels
+                                          (777, 80, dict(time_limit=0.4, zero_start_prob=0.5, auto_jump=True, speed_reward=True)),   # SPEC=false kernels
+                                          (600, 70, dict(time_limit=0.4, zero_start_prob=0.2, discrete_yaw_steps=5, hover=True)),
+                                          (130, 60, dict(time_limit=0.3, allow_yaw=False, allow_jump=False))])
 @pytest.mark.parametrize("two_streams", [False, True])
 def test_tick_server_equals_per_tick_kernels(n, ticks, over, two_streams):
     import torch
