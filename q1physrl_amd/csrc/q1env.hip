@@ -302,17 +302,16 @@ __device__ __forceinline__ void sample_categorical(const float* __restrict__ lg,
     logp = (lg[choice] - mx) - logf(sum);
 }
 
-__device__ __forceinline__ void sample_action(const Params& p, const float* __restrict__ row, uint64_t seed, uint64_t genv,
-                                              uint64_t counter, int deterministic, uint32_t& keys, float& mouse, float& logp) {
-    // all (up to ten) policy outputs of the row are requested before anything is computed: inside the per-key loop each pair
-    // would expose its own HBM round trip (one wave per SIMD at sampler batch sizes has nothing to hide it with)
-    float lg[10];
-    const int pairs = p.num_keys + (p.yaw_mode == 1 ? 1 : 0);
-#pragma unroll
-    for (int j = 0; j < 5; ++j) {
-        lg[2 * j] = j < pairs ? row[2 * j] : 0.0f;
-        lg[2 * j + 1] = j < pairs ? row[2 * j + 1] : 0.0f;
-    }
+// log(S) of the squashing scale S = 0.5f * 1.8137f as float32 (shared by the sampling and the loss kernels, so that the constant
+// terms of a log-probability cancel exactly in a ratio)
+constexpr float SQUASH_SCALE = 0.5f * 1.8137f;
+constexpr float LOG_SQUASH_SCALE = -0.097778246f;     // float32(log(float32(0.90685)))
+
+// The arithmetic of one env's action from its (up to ten) policy outputs in registers; `row` is only read by the discrete-mouse
+// branch (2S+1 logits behind the key pairs).
+__device__ __forceinline__ void sample_action_regs(const Params& p, const float (&lg)[10], const float* __restrict__ row, uint64_t seed,
+                                                   uint64_t genv, uint64_t counter, int deterministic, uint32_t& keys, float& mouse,
+                                                   float& logp) {
     uint32_t r[4], r2[4];
     philox_draw(seed, genv, counter, STREAM_POLICY, 0, r);
     philox_draw(seed, genv, counter, STREAM_POLICY, 1, r2);
@@ -324,16 +323,20 @@ __device__ __forceinline__ void sample_action(const Params& p, const float* __re
         if (k >= p.num_keys) break;
         const float l0 = lg[2 * k], l1 = lg[2 * k + 1];
         const float d = l1 - l0;                                  // P(1) = sigmoid(d)
-        const float p1 = 1.0f / (1.0f + expf(-d));
+        // one exponential serves both the probability and the log-probability: e = exp(-|d|);
+        // sigmoid(d) = 1 / (1 + e) for d >= 0, e / (1 + e) otherwise; softplus(+-d) = max(+-d, 0) + log1p(e)
+        const float e = expf(-fabsf(d));
+        const float rc = 1.0f / (1.0f + e);
+        const float p1 = d >= 0.0f ? rc : e * rc;
         const float u = (float)(ku[k] >> 8) * (1.0f / 16777216.0f);
         const uint32_t bit = deterministic ? (d > 0.0f) : (u < p1);   // deterministic: argmax (RLlib Categorical)
         keys |= bit << k;
         const float z = bit ? -d : d;                             // log softmax[chosen] = -softplus(l_other - l_chosen)
-        logp -= (z > 0.0f ? z : 0.0f) + log1pf(expf(-fabsf(z)));
+        logp -= (z > 0.0f ? z : 0.0f) + log1pf(e);
     }
     mouse = 0.0f;
     if (p.yaw_mode == 1) {
-        const float S = 0.5f * 1.8137f;
+        const float S = SQUASH_SCALE;
         const float low = -p.action_range_f32, high = p.action_range_f32;
         float mean = 0.0f, log_std = 0.0f;
 #pragma unroll
@@ -356,8 +359,8 @@ __device__ __forceinline__ void sample_action(const Params& p, const float* __re
         const float zs = (ub - mean) / std;
         const float lp_pi = -0.5f * zs * zs - log_std - 0.9189385332046727f;            // N(mean, std).logpdf(ub)
         const float zq = ub / S;
-        const float lp_sq = -0.5f * zq * zq - logf(S) - 0.9189385332046727f;            // N(0, S).logpdf(ub)
-        logp += lp_pi - (lp_sq + logf(high - low));
+        const float lp_sq = -0.5f * zq * zq - LOG_SQUASH_SCALE - 0.9189385332046727f;   // N(0, S).logpdf(ub)
+        logp += lp_pi - (lp_sq + p.log_range_f32);
     } else if (p.yaw_mode == 2) {
         int choice;
         float lpc;
@@ -365,6 +368,20 @@ __device__ __forceinline__ void sample_action(const Params& p, const float* __re
         mouse = (float)choice;
         logp += lpc;
     }
+}
+
+__device__ __forceinline__ void sample_action(const Params& p, const float* __restrict__ row, uint64_t seed, uint64_t genv,
+                                              uint64_t counter, int deterministic, uint32_t& keys, float& mouse, float& logp) {
+    // all (up to ten) policy outputs of the row are requested before anything is computed: inside the per-key loop each pair
+    // would expose its own HBM round trip (one wave per SIMD at sampler batch sizes has nothing to hide it with)
+    float lg[10];
+    const int pairs = p.num_keys + (p.yaw_mode == 1 ? 1 : 0);
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+        lg[2 * j] = j < pairs ? row[2 * j] : 0.0f;
+        lg[2 * j + 1] = j < pairs ? row[2 * j + 1] : 0.0f;
+    }
+    sample_action_regs(p, lg, row, seed, genv, counter, deterministic, keys, mouse, logp);
 }
 
 __global__ void __launch_bounds__(256)
@@ -481,7 +498,7 @@ ppo_loss_grad_kernel(Params p, int batch, const float* __restrict__ logits, cons
             kl += kc;
         }
         if (p.yaw_mode == 1) {
-            const float S = 0.5f * 1.8137f, low = -p.action_range_f32, high = p.action_range_f32;
+            const float S = SQUASH_SCALE, low = -p.action_range_f32, high = p.action_range_f32;
             const float m_raw = row[2 * nk], s_raw = row[2 * nk + 1];
             in_m = m_raw >= -3.0f && m_raw <= 3.0f;
             in_s = s_raw >= -20.0f && s_raw <= 2.0f;
@@ -490,9 +507,9 @@ ppo_loss_grad_kernel(Params p, int batch, const float* __restrict__ logits, cons
             const float inv_std = expf(-ls), std = expf(ls), std_o = expf(ls_o);
             const float u = S * normcdfinvf((mouse[i] - low) / (high - low));
             const float z = (u - mean) * inv_std, zq = u / S;
-            logp += (-0.5f * z * z - ls - 0.9189385332046727f) - ((-0.5f * zq * zq - logf(S) - 0.9189385332046727f) + logf(high - low));
+            logp += (-0.5f * z * z - ls - 0.9189385332046727f) - ((-0.5f * zq * zq - LOG_SQUASH_SCALE - 0.9189385332046727f) + p.log_range_f32);
             dlp_m = z * inv_std; dlp_s = z * z - 1.0f;
-            ent += logf(high - low) - (logf(S) - ls + (std * std + mean * mean) / (2.0f * S * S) - 0.5f);
+            ent += p.log_range_f32 - (LOG_SQUASH_SCALE - ls + (std * std + mean * mean) / (2.0f * S * S) - 0.5f);
             dh_m = -mean / (S * S); dh_s = 1.0f - std * std / (S * S);
             const float dm = mean_o - mean, q = (std_o * std_o + dm * dm) * inv_std * inv_std;
             kl += ls - ls_o + 0.5f * q - 0.5f;
@@ -585,7 +602,7 @@ __global__ void __launch_bounds__(256)
 sample_step_kernel(Params p, StatePtrs s, const float* __restrict__ logits, int row_stride, uint64_t seed, uint64_t counter,
                    const uint64_t* counter_dev, int deterministic, uint8_t* keys_out, float* mouse_out, float* logp_out,
                    float* obs, float* reward, uint8_t* done, uint8_t* zero_start, double* ep_return, double* partials) {
-    __shared__ float slab[4][384];
+    __shared__ float slab[4][640];               // per wave: 64 logits rows of 10 (in), later 64 observation rows of 6 (out)
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t n = (uint32_t)p.n;
     const bool live = i < n;
@@ -595,12 +612,39 @@ sample_step_kernel(Params p, StatePtrs s, const float* __restrict__ logits, int 
     bool zs = false;
     if (live) {
         const uint64_t genv = (uint64_t)p.env_index_base + (uint64_t)i;
+        const uint32_t lane = threadIdx.x & 63u, wave_first = i - lane;
+        const bool full = wave_first + 64u <= n;
+        float* my_slab = slab[threadIdx.x >> 6];
         Env e;
         load_env(s, n, i, e);                     // requested first: the state's HBM latency hides under the sampling arithmetic
         const Env loaded = e;
         uint32_t keys;
         float mouse, logp;
-        sample_action(p, logits + (size_t)i * row_stride, seed, genv, counter, deterministic, keys, mouse, logp);
+        if (full && row_stride == 10 && p.yaw_mode != 2) {
+            // the wave's 64 rows are 2 560 contiguous bytes: ten all-lane 256-byte loads instead of ten loads at a 40-byte lane
+            // stride, transposed through the wave's LDS slab (same wave-synchronous pattern as write_obs_wave_f32)
+            const float* src = logits + (size_t)wave_first * 10u;
+            float v[10];
+#pragma unroll
+            for (uint32_t k = 0; k < 10u; ++k) v[k] = src[k * 64u + lane];
+#pragma unroll
+            for (uint32_t k = 0; k < 10u; ++k) my_slab[k * 64u + lane] = v[k];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            float lg[10];
+            const float2* rowp = reinterpret_cast<const float2*>(my_slab + lane * 10u);
+#pragma unroll
+            for (int j = 0; j < 5; ++j) { const float2 q = rowp[j]; lg[2 * j] = q.x; lg[2 * j + 1] = q.y; }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const int pairs = p.num_keys + (p.yaw_mode == 1 ? 1 : 0);
+#pragma unroll
+            for (int j = 0; j < 5; ++j) if (j >= pairs) { lg[2 * j] = 0.0f; lg[2 * j + 1] = 0.0f; }
+            sample_action_regs(p, lg, logits + (size_t)i * row_stride, seed, genv, counter, deterministic, keys, mouse, logp);
+        } else {
+            sample_action(p, logits + (size_t)i * row_stride, seed, genv, counter, deterministic, keys, mouse, logp);
+        }
         keys_out[i] = (uint8_t)keys;
         if (mouse_out) mouse_out[i] = mouse;
         if (logp_out) logp_out[i] = logp;
@@ -613,8 +657,7 @@ sample_step_kernel(Params p, StatePtrs s, const float* __restrict__ logits, int 
             observe<float>(p, e, o.obs);
         }
         store_env_delta(s, n, i, e, loaded);
-        const uint32_t lane = threadIdx.x & 63u, wave_first = i - lane;
-        if (wave_first + 64u <= n) write_obs_wave_f32(obs, wave_first, lane, o.obs, slab[threadIdx.x >> 6]);
+        if (full) write_obs_wave_f32(obs, wave_first, lane, o.obs, my_slab);
         else write_obs<float>(obs, (size_t)i, o.obs);
         reward[i] = o.reward;
         done[i] = o.done ? 1 : 0;
@@ -852,6 +895,7 @@ static int make_params(const q1env_config& c, Params& p, std::string& why) {
     p.action_range = c.action_range;
     p.dt_f32 = (float)c.time_delta;                                     // env.py:501/503
     p.action_range_f32 = (float)c.action_range;
+    p.log_range_f32 = logf(2.0f * (float)c.action_range);               // log(high - low) of the mouse Box, float32 like the kernels' terms
     p.env_index_base = c.env_index_base;
     return 0;
 }

@@ -65,6 +65,7 @@ struct Params {
     double action_range;
     float dt_f32;           // float32(dt)                                env.py:501/503
     float action_range_f32;
+    float log_range_f32;    // logf(2 * action_range_f32): log(high - low) of the mouse Box (policy-side kernels)
     int64_t env_index_base;
 };
 
