@@ -602,7 +602,7 @@ __global__ void __launch_bounds__(256)
 sample_step_kernel(Params p, StatePtrs s, const float* __restrict__ logits, int row_stride, uint64_t seed, uint64_t counter,
                    const uint64_t* counter_dev, int deterministic, uint8_t* keys_out, float* mouse_out, float* logp_out,
                    float* obs, float* reward, uint8_t* done, uint8_t* zero_start, double* ep_return, double* partials) {
-    __shared__ float slab[4][640];               // per wave: 64 logits rows of 10 (in), later 64 observation rows of 6 (out)
+    __shared__ float slab[4][384];
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t n = (uint32_t)p.n;
     const bool live = i < n;
@@ -620,31 +620,9 @@ sample_step_kernel(Params p, StatePtrs s, const float* __restrict__ logits, int 
         const Env loaded = e;
         uint32_t keys;
         float mouse, logp;
-        if (full && row_stride == 10 && p.yaw_mode != 2) {
-            // the wave's 64 rows are 2 560 contiguous bytes: ten all-lane 256-byte loads instead of ten loads at a 40-byte lane
-            // stride, transposed through the wave's LDS slab (same wave-synchronous pattern as write_obs_wave_f32)
-            const float* src = logits + (size_t)wave_first * 10u;
-            float v[10];
-#pragma unroll
-            for (uint32_t k = 0; k < 10u; ++k) v[k] = src[k * 64u + lane];
-#pragma unroll
-            for (uint32_t k = 0; k < 10u; ++k) my_slab[k * 64u + lane] = v[k];
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            float lg[10];
-            const float2* rowp = reinterpret_cast<const float2*>(my_slab + lane * 10u);
-#pragma unroll
-            for (int j = 0; j < 5; ++j) { const float2 q = rowp[j]; lg[2 * j] = q.x; lg[2 * j + 1] = q.y; }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            const int pairs = p.num_keys + (p.yaw_mode == 1 ? 1 : 0);
-#pragma unroll
-            for (int j = 0; j < 5; ++j) if (j >= pairs) { lg[2 * j] = 0.0f; lg[2 * j + 1] = 0.0f; }
-            sample_action_regs(p, lg, logits + (size_t)i * row_stride, seed, genv, counter, deterministic, keys, mouse, logp);
-        } else {
-            sample_action(p, logits + (size_t)i * row_stride, seed, genv, counter, deterministic, keys, mouse, logp);
-        }
+        // (an LDS-transposed, fully coalesced read of the wave's 64 logits rows was tried in round 2: 8.85 -> 8.73 us at 32 768 envs,
+        // 19.8 -> 19.7 us at 262 144 - the kernel is bound by its float32 / float64 arithmetic and latency chain, not by these loads)
+        sample_action(p, logits + (size_t)i * row_stride, seed, genv, counter, deterministic, keys, mouse, logp);
         keys_out[i] = (uint8_t)keys;
         if (mouse_out) mouse_out[i] = mouse;
         if (logp_out) logp_out[i] = logp;
