@@ -328,7 +328,7 @@ def main(argv=None):
     def server_state():
         nonlocal srv
         if srv is None:
-            srv = {"mailbox": torch.zeros((n,), dtype=torch.int64, device=d), "results": torch.zeros((7, n), dtype=torch.int64, device=d),
+            srv = {"mailbox": torch.zeros((n,), dtype=torch.int64, device=d), "results": torch.zeros((4, n, 2), dtype=torch.int64, device=d),
                    "status": torch.zeros((5,), dtype=torch.int32, device=d), "tag": 0,
                    # (a second stream only for the two-stream form: every extra stream is one more queue a device-wide sync visits)
                    "stream": torch.cuda.Stream(device=d, priority=-1) if os.environ.get("Q1_BENCH_SERVER_TWO_STREAMS") and not injected else None}

@@ -308,8 +308,10 @@ int q1env_episode_stats(q1env_t* env, const float* reward_dev, const uint8_t* do
  * data-tagged granule, written by ONE agent-scope (sc1) store and polled with sc1 loads (MI355X_MICROARCH.md, persistent-kernel
  * price list) - no flags, fences or drains, one hop per direction:
  *   mailbox[i]    = (tag << 40) | (key bits << 32) | float32 bits of the mouse action          producer -> server, uint64[N]
- *   results[k][i] = (tag << 40) | float32 bits of observation column k, k = 0..5              server -> consumer, uint64[7][N]
- *   results[6][i] = (tag << 40) | (zero_start << 33) | (done << 32) | float32 bits of reward
+ *   G[k][i], k = 0..5 = (tag << 40) | float32 bits of observation column k                   server -> consumer
+ *   G[6][i] = (tag << 40) | (zero_start << 33) | (done << 32) | float32 bits of reward;  G[7][i] = tag << 40 (padding)
+ *   results = uint64[4][N][2]: pair q of env i = {G[2q][i], G[2q+1][i]}, written as ONE 16-byte sc1 store (an sc1 store is one
+ *   fabric write per lane whatever its width); every 8-byte half carries its own tag and can be read and validated alone.
  *   tag of tick t (0-based) of the launch = (tag0 + t) mod (2^24 - 1) + 1, i.e. 1 .. 0xFFFFFF and never 0: zero the mailbox before the
  *   first launch; continue a run with tag0' = (tag0 + ticks) mod (2^24 - 1).
  * obs_final (optional, float[N][6]): the last served tick's observation rows as plain stores at the end of the launch.
@@ -320,7 +322,7 @@ int q1env_episode_stats(q1env_t* env, const float* reward_dev, const uint8_t* do
  * of the last completed tick stored - it never hangs the device.  num_envs <= CUs * 2048 (the grid must be resident at once).
  * _start launches the server on the handle's stream (asynchronous; wait with q1env_sync).  _drive launches the reference
  * producer on `producer_stream` (a hipStream_t other than the handle's): a DEPENDENT driver - what a policy is to the env - that
- * hands tick t+1's action (from tick-major packed arrays keys uint8[T][N], mouse float[T][N]) over only after all seven result
+ * hands tick t+1's action (from tick-major packed arrays keys uint8[T][N], mouse float[T][N]) over only after all result
  * granules of tick t of the same env arrived, and adds the rewards / first observation column it received to checksum
  * double[2][N] (optional). */
 int q1env_step_persistent_start(q1env_t* env, int ticks, uint32_t tag0, const uint64_t* mailbox_dev, uint64_t* results_dev,

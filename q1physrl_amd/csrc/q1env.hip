@@ -1635,6 +1635,19 @@ int q1env_policy_value_forward(q1env_t* h, const float* obs, const q1env_mlp* pi
 }
 
 // ---- persistent tick server -----------------------------------------------------------------------------------------------
+// Poll pacing of the tick server (see Backoff in q1server.hpp); Q1ENV_SERVER_BACKOFF="first_server,first_driver,between" overrides
+// the defaults (measurement knob).
+static Backoff server_backoff() {
+    static const Backoff bo = [] {
+        Backoff b{0, 0, 0};
+        if (const char* e = getenv("Q1ENV_SERVER_BACKOFF")) (void)sscanf(e, "%d,%d,%d", &b.first_server, &b.first_driver, &b.between);
+        auto clamp = [](int v) { return v < 0 ? 0 : (v > 4096 ? 4096 : v); };
+        b.first_server = clamp(b.first_server); b.first_driver = clamp(b.first_driver); b.between = clamp(b.between);
+        return b;
+    }();
+    return bo;
+}
+
 int q1env_step_persistent_start(q1env_t* h, int ticks, uint32_t tag0, const uint64_t* mailbox_dev, uint64_t* results_dev,
                                 float* obs_final_dev, uint64_t seed, int auto_reset, uint32_t* status_dev, double timeout_s) {
     if (!h || !mailbox_dev || !results_dev || !status_dev) return fail(Q1ENV_ERR_INVALID_ARG, "q1env_step_persistent_start: null argument");
@@ -1660,10 +1673,10 @@ int q1env_step_persistent_start(q1env_t* h, int ticks, uint32_t tag0, const uint
     const uint64_t timeout_ticks = (uint64_t)(timeout_s * 1.0e8);          // wall_clock64: 100 MHz
     if (is_spec(h->p))
         hipLaunchKernelGGL(tick_server_kernel<true>, g, b, 0, h->stream, h->p, h->st, ticks, tag0, mailbox_dev, results_dev, obs_final_dev, seed,
-                           h->tick_count, auto_reset, status_dev, timeout_ticks);
+                           h->tick_count, auto_reset, status_dev, timeout_ticks, server_backoff());
     else
         hipLaunchKernelGGL(tick_server_kernel<false>, g, b, 0, h->stream, h->p, h->st, ticks, tag0, mailbox_dev, results_dev, obs_final_dev, seed,
-                           h->tick_count, auto_reset, status_dev, timeout_ticks);
+                           h->tick_count, auto_reset, status_dev, timeout_ticks, server_backoff());
     HIP_TRY(hipGetLastError());
     h->tick_count += (uint64_t)ticks;
     return Q1ENV_OK;
@@ -1679,7 +1692,7 @@ int q1env_step_persistent_drive(q1env_t* h, void* producer_stream, int ticks, ui
     DeviceGuard guard(h->device);
     const dim3 g(((unsigned)h->p.n + 63u) / 64u), b(64);
     hipLaunchKernelGGL(tick_driver_kernel, g, b, 0, (hipStream_t)producer_stream, h->p.n, ticks, tag0, keys_dev, mouse_dev, mailbox_dev,
-                       results_dev, checksum_dev, status_dev, (uint64_t)(timeout_s * 1.0e8));
+                       results_dev, checksum_dev, status_dev, (uint64_t)(timeout_s * 1.0e8), server_backoff());
     HIP_TRY(hipGetLastError());
     return Q1ENV_OK;
 }
@@ -1709,10 +1722,10 @@ int q1env_step_persistent_pair(q1env_t* h, int ticks, uint32_t tag0, const uint8
     if (t_start) HIP_TRY(hipEventRecord(h->ev0, h->stream));
     if (is_spec(h->p))
         hipLaunchKernelGGL(tick_pair_kernel<true>, g, b, 0, h->stream, h->p, h->st, ticks, tag0, mailbox_dev, results_dev, obs_final_dev, seed,
-                           h->tick_count, auto_reset, keys_dev, mouse_dev, checksum_dev, status_dev, timeout_ticks);
+                           h->tick_count, auto_reset, keys_dev, mouse_dev, checksum_dev, status_dev, timeout_ticks, server_backoff());
     else
         hipLaunchKernelGGL(tick_pair_kernel<false>, g, b, 0, h->stream, h->p, h->st, ticks, tag0, mailbox_dev, results_dev, obs_final_dev, seed,
-                           h->tick_count, auto_reset, keys_dev, mouse_dev, checksum_dev, status_dev, timeout_ticks);
+                           h->tick_count, auto_reset, keys_dev, mouse_dev, checksum_dev, status_dev, timeout_ticks, server_backoff());
     HIP_TRY(hipGetLastError());
     if (t_stop) HIP_TRY(hipEventRecord(h->ev1, h->stream));
     h->tick_count += (uint64_t)ticks;

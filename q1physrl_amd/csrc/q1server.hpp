@@ -14,15 +14,25 @@ using namespace q1;
 // write-through) store and polled with sc1 loads, so no separate flag, no fence, no L2 write-back and no store drain is needed in
 // either direction, and a consumer has a whole tick's outputs after ONE hop:
 //     action granule     mailbox[i]       = (tag << 40) | (keys << 32) | float_bits(mouse)                   producer -> server
-//     result granules    results[k][i]    = (tag << 40) | float_bits(obs[k]),  k = 0..5                       server -> consumer
-//                        results[6][i]    = (tag << 40) | (zero_start << 33) | (done << 32) | float_bits(reward)
-// (granule-index-major, so a wave's 64 granules of one index are one contiguous 512-byte store / load).
+//     result granules    G[k][i], k = 0..5 = (tag << 40) | float_bits(obs[k])                                  server -> consumer
+//                        G[6][i]          = (tag << 40) | (zero_start << 33) | (done << 32) | float_bits(reward)
+//                        G[7][i]          = (tag << 40)                                              (padding)
+//     stored as PAIRS: results = uint64[4][N][2], pair q of env i = {G[2q][i], G[2q+1][i]} (16 bytes, one sc1 access).
 // tag = (tag0 + t) mod (2^24 - 1) + 1 for tick t of the launch: 1 .. 0xFFFFFF, never 0 - a zeroed mailbox holds no valid action -
 // and consecutive ticks never share a tag across the wrap-around.
 // Every wait is bounded: a lane that sees no new tag for `timeout_ticks` of the 100 MHz wall clock gives up, the wave stores its
 // state as of the last completed tick and reports status[1] != 0 - a missing or stalled producer ends the launch, not the GPU.
 // Bit-identical to `ticks` q1env_step_autoreset / q1env_step calls with the packed action layout.
 constexpr int RESULT_GRANULES = 7;
+
+// Poll pacing, in units of s_sleep(1) (64 clocks): `first_*` before the first poll of a tick - the other side needs at least a hop
+// plus its own work before anything new can be there, and thousands of waves polling early only load the fabric the hand-offs
+// travel through - and `between` after every failed poll.
+struct Backoff { int first_server, first_driver, between; };
+
+__device__ __forceinline__ void nap(int units) {
+    for (int k = 0; k < units; ++k) __builtin_amdgcn_s_sleep(1);
+}
 
 __device__ __forceinline__ uint64_t tick_tag(uint32_t tag0, uint32_t t) {          // 1 .. 0xFFFFFF
     return (uint64_t)(((uint64_t)tag0 + (uint64_t)t) % 0xFFFFFFull) + 1ull;
@@ -35,10 +45,46 @@ __device__ __forceinline__ void granule_store(uint64_t* p, uint64_t v) {
     __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// Two granules that are neighbours in memory leave / arrive as ONE 16-byte sc1 access: an sc1 store is one fabric write per lane
+// whatever its width (MI355X_MICROARCH.md: dwordx2 costs 2.7x the dwordx4 time per byte), so the seven result granules of a tick
+// cost four writes instead of seven.  Each 8-byte half still carries its own tag, so a consumer validates every granule by itself
+// and a 16-byte access torn at the 8-byte boundary (never observed on gfx950) would be detected, not consumed.
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void granule_pair_store(uint64_t* p, uint64_t a, uint64_t b) {
+    const u32x4 v = {(uint32_t)a, (uint32_t)(a >> 32), (uint32_t)b, (uint32_t)(b >> 32)};
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+}
+
+// four pairs (eight granules) with all four loads in flight together
+__device__ __forceinline__ void granule_pairs_load4(const uint64_t* p0, const uint64_t* p1, const uint64_t* p2, const uint64_t* p3,
+                                                    uint64_t (&g)[8]) {
+    u32x4 a, b, c, d;
+    asm volatile(
+        "global_load_dwordx4 %0, %4, off sc1\n\t"
+        "global_load_dwordx4 %1, %5, off sc1\n\t"
+        "global_load_dwordx4 %2, %6, off sc1\n\t"
+        "global_load_dwordx4 %3, %7, off sc1\n\t"
+        "s_waitcnt vmcnt(0)"
+        : "=&v"(a), "=&v"(b), "=&v"(c), "=&v"(d)
+        : "v"(p0), "v"(p1), "v"(p2), "v"(p3)
+        : "memory");
+    g[0] = (uint64_t)a[0] | ((uint64_t)a[1] << 32); g[1] = (uint64_t)a[2] | ((uint64_t)a[3] << 32);
+    g[2] = (uint64_t)b[0] | ((uint64_t)b[1] << 32); g[3] = (uint64_t)b[2] | ((uint64_t)b[3] << 32);
+    g[4] = (uint64_t)c[0] | ((uint64_t)c[1] << 32); g[5] = (uint64_t)c[2] | ((uint64_t)c[3] << 32);
+    g[6] = (uint64_t)d[0] | ((uint64_t)d[1] << 32); g[7] = (uint64_t)d[2] | ((uint64_t)d[3] << 32);
+}
+
+// address of granule pair q (granules 2q, 2q+1) of env i: pair-index-major, 16 bytes per env
+__device__ __forceinline__ uint64_t* pair_ptr(const uint64_t* results, uint32_t n, uint32_t q, uint32_t i) {
+    return const_cast<uint64_t*>(results) + ((size_t)q * n + i) * 2u;
+}
+
 template <bool SPEC>
 __device__ __forceinline__ void tick_server_body(const Params& p, const StatePtrs& s, uint32_t block, int ticks, uint32_t tag0,
                                                  const uint64_t* mailbox, uint64_t* results, float* obs_final, uint64_t seed,
-                                                 uint64_t counter0, int auto_reset, uint32_t* status, uint64_t timeout_ticks) {
+                                                 uint64_t counter0, int auto_reset, uint32_t* status, uint64_t timeout_ticks,
+                                                 Backoff bo) {
     const uint32_t lane = threadIdx.x, i = block * 64u + lane, n = (uint32_t)p.n;
     const bool live = i < n;
     const uint64_t genv = (uint64_t)p.env_index_base + (uint64_t)i;
@@ -56,12 +102,14 @@ __device__ __forceinline__ void tick_server_body(const Params& p, const StatePtr
         bool ok = !live;
         uint32_t polls = 0;
         uint64_t t_wait = 0;
+        if (t > 0) nap(bo.first_server);
         for (;;) {                                    // every lane polls its own granule: one contiguous 512-B sc1 read per wave
             if (!ok) {
                 g = granule_load(mailbox + i);
                 ok = (g >> 40) == tag;
             }
             if (__all(ok)) break;
+            nap(bo.between);
             // the load's own latency paces the loop; the 100 MHz clock is only consulted every 256 failed polls (no s_memrealtime
             // on the path of a tick that is served promptly), the timeout counts from the first such look
             if ((++polls & 255u) == 0u) {
@@ -82,10 +130,12 @@ __device__ __forceinline__ void tick_server_body(const Params& p, const StatePtr
                 observe<float>(p, e, o.obs);
             }
             const uint64_t hi = tag << 40;
+            const uint64_t last = hi | ((uint64_t)(zs ? 1u : 0u) << 33) | ((uint64_t)(o.done ? 1u : 0u) << 32) | (uint64_t)__float_as_uint(o.reward);
 #pragma unroll
-            for (int k = 0; k < 6; ++k) granule_store(results + (size_t)k * n + i, hi | (uint64_t)__float_as_uint(o.obs[k]));
-            granule_store(results + (size_t)6 * n + i, hi | ((uint64_t)(zs ? 1u : 0u) << 33) | ((uint64_t)(o.done ? 1u : 0u) << 32) |
-                                                           (uint64_t)__float_as_uint(o.reward));
+            for (uint32_t q = 0; q < 3u; ++q)
+                granule_pair_store(pair_ptr(results, n, q, i), hi | (uint64_t)__float_as_uint(o.obs[2 * q]),
+                                   hi | (uint64_t)__float_as_uint(o.obs[2 * q + 1]));
+            granule_pair_store(pair_ptr(results, n, 3u, i), last, hi);          // granule 7 is padding: tag only
         }
         completed = t + 1;
     }
@@ -107,7 +157,7 @@ __device__ __forceinline__ void tick_server_body(const Params& p, const StatePtr
 // round trip.  One lane per env, resident next to the server.
 __device__ __forceinline__ void tick_driver_body(int n, uint32_t block, int ticks, uint32_t tag0, const uint8_t* keys, const float* mouse,
                                                  uint64_t* mailbox, const uint64_t* results, double* checksum, uint32_t* status,
-                                                 uint64_t timeout_ticks) {
+                                                 uint64_t timeout_ticks, Backoff bo) {
     const uint32_t lane = threadIdx.x, i = block * 64u + lane;
     const bool live = i < (uint32_t)n;
     double acc_r = 0.0, acc_o = 0.0;
@@ -119,19 +169,21 @@ __device__ __forceinline__ void tick_driver_body(int n, uint32_t block, int tick
         const float m = live ? mouse[(size_t)t * n + i] : 0.0f;
         if (t > 0) {
             const uint64_t want = tick_tag(tag0, (uint32_t)t - 1u);      // results of tick t-1
-            uint64_t g[RESULT_GRANULES];
+            uint64_t g[8];
             bool ok = !live;
             uint32_t polls = 0;
             uint64_t t_wait = 0;
+            nap(bo.first_driver);
             for (;;) {
                 if (!ok) {
-#pragma unroll
-                    for (int q = 0; q < RESULT_GRANULES; ++q) g[q] = granule_load(results + (size_t)q * n + i);
+                    granule_pairs_load4(pair_ptr(results, (uint32_t)n, 0u, i), pair_ptr(results, (uint32_t)n, 1u, i),
+                                        pair_ptr(results, (uint32_t)n, 2u, i), pair_ptr(results, (uint32_t)n, 3u, i), g);
                     ok = true;
 #pragma unroll
                     for (int q = 0; q < RESULT_GRANULES; ++q) ok = ok && ((g[q] >> 40) == want);
                 }
                 if (__all(ok)) break;
+                nap(bo.between);
                 if ((++polls & 255u) == 0u) {
                     const uint64_t now = wall_clock64();
                     if (t_wait == 0) t_wait = now;
@@ -159,14 +211,14 @@ __device__ __forceinline__ void tick_driver_body(int n, uint32_t block, int tick
 template <bool SPEC>
 __global__ void __launch_bounds__(64)
 tick_server_kernel(Params p, StatePtrs s, int ticks, uint32_t tag0, const uint64_t* mailbox, uint64_t* results, float* obs_final,
-                   uint64_t seed, uint64_t counter0, int auto_reset, uint32_t* status, uint64_t timeout_ticks) {
-    tick_server_body<SPEC>(p, s, blockIdx.x, ticks, tag0, mailbox, results, obs_final, seed, counter0, auto_reset, status, timeout_ticks);
+                   uint64_t seed, uint64_t counter0, int auto_reset, uint32_t* status, uint64_t timeout_ticks, Backoff bo) {
+    tick_server_body<SPEC>(p, s, blockIdx.x, ticks, tag0, mailbox, results, obs_final, seed, counter0, auto_reset, status, timeout_ticks, bo);
 }
 
 __global__ void __launch_bounds__(64)
 tick_driver_kernel(int n, int ticks, uint32_t tag0, const uint8_t* keys, const float* mouse, uint64_t* mailbox,
-                   const uint64_t* results, double* checksum, uint32_t* status, uint64_t timeout_ticks) {
-    tick_driver_body(n, blockIdx.x, ticks, tag0, keys, mouse, mailbox, results, checksum, status, timeout_ticks);
+                   const uint64_t* results, double* checksum, uint32_t* status, uint64_t timeout_ticks, Backoff bo) {
+    tick_driver_body(n, blockIdx.x, ticks, tag0, keys, mouse, mailbox, results, checksum, status, timeout_ticks, bo);
 }
 
 // Server and reference driver in ONE dispatch (q1env_step_persistent_pair): blocks [0, B) are the server's waves, blocks [B, 2B) the
@@ -178,11 +230,11 @@ template <bool SPEC>
 __global__ void __launch_bounds__(64)
 tick_pair_kernel(Params p, StatePtrs s, int ticks, uint32_t tag0, uint64_t* mailbox, uint64_t* results, float* obs_final,
                  uint64_t seed, uint64_t counter0, int auto_reset, const uint8_t* keys, const float* mouse, double* checksum,
-                 uint32_t* status, uint64_t timeout_ticks) {
+                 uint32_t* status, uint64_t timeout_ticks, Backoff bo) {
     const uint32_t half = gridDim.x >> 1;
     if (blockIdx.x < half)
-        tick_server_body<SPEC>(p, s, blockIdx.x, ticks, tag0, mailbox, results, obs_final, seed, counter0, auto_reset, status, timeout_ticks);
+        tick_server_body<SPEC>(p, s, blockIdx.x, ticks, tag0, mailbox, results, obs_final, seed, counter0, auto_reset, status, timeout_ticks, bo);
     else
-        tick_driver_body(p.n, blockIdx.x - half, ticks, tag0, keys, mouse, mailbox, results, checksum, status, timeout_ticks);
+        tick_driver_body(p.n, blockIdx.x - half, ticks, tag0, keys, mouse, mailbox, results, checksum, status, timeout_ticks, bo);
 }
 

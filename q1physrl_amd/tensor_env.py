@@ -140,7 +140,7 @@ class TensorVectorEnv:
         assert keys.dtype == torch.uint8 and keys.is_contiguous() and tuple(keys.shape) == (ticks, n)
         assert mouse.dtype == torch.float32 and mouse.is_contiguous() and tuple(mouse.shape) == (ticks, n)
         if not hasattr(self, "_srv"):
-            self._srv = {"mailbox": torch.zeros((n,), dtype=torch.int64, device=d), "results": torch.zeros((7, n), dtype=torch.int64, device=d),
+            self._srv = {"mailbox": torch.zeros((n,), dtype=torch.int64, device=d), "results": torch.zeros((4, n, 2), dtype=torch.int64, device=d),
                          "status": torch.zeros((5,), dtype=torch.int32, device=d), "checksum": torch.zeros((2, n), dtype=torch.float64, device=d),
                          "stream": torch.cuda.Stream(device=d, priority=-1), "tag": 0}
         sv = self._srv
@@ -161,7 +161,7 @@ class TensorVectorEnv:
         if not sync:
             return None
         torch.cuda.synchronize(d)
-        res = sv["results"]
+        res = sv["results"].permute(0, 2, 1).reshape(8, n)      # granule k of env i (stored as pairs: uint64[4][N][2])
         low = (res & 0xFFFFFFFF).to(torch.int32).view(torch.float32)
         self.reward.copy_(low[6])
         self.done.copy_(((res[6] >> 32) & 1).to(torch.uint8))

@@ -104,7 +104,7 @@ def test_tick_server_tags_wrap_around():
     a.reset(); c.reset()
     r0 = a.serve_ticks(keys[:1].contiguous(), mouse[:1].contiguous())     # creates the server buffers; uses tag 1
     c.step_autoreset((keys[0], mouse[0]))
-    assert not r0["status"].any() and int((a._srv["results"][6] >> 40).max()) == 1
+    assert not r0["status"].any() and int((a._srv["results"][3, :, 0] >> 40).max()) == 1
     a.reset(); c.reset()
     a._srv["tag"] = 0xFFFFFF - 20                                         # the next launch crosses the wrap-around
     res = a.serve_ticks(keys, mouse)
@@ -129,7 +129,7 @@ def test_tick_server_without_a_producer_times_out_and_reports_it():
     env.reset()
     before = env.get_state()
     mailbox = torch.zeros((n,), dtype=torch.int64, device="cuda")
-    results = torch.zeros((7, n), dtype=torch.int64, device="cuda")
+    results = torch.zeros((4, n, 2), dtype=torch.int64, device="cuda")
     status = torch.zeros((5,), dtype=torch.int32, device="cuda")
     t0 = time.perf_counter()
     env._dev.persistent_start(50, 0, mailbox.data_ptr(), results.data_ptr(), env.obs.data_ptr(), 1, True, status.data_ptr(), timeout_s=0.05)

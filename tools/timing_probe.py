@@ -65,7 +65,7 @@ def main():
                       "wall_per_tick_p50": float(np.median(wall)) / T, "event_per_tick_p50": float(np.median(ev)) / T}
     # the resident tick server (one dispatch): where its 20-tick region's wall time goes
     mailbox = torch.zeros((n,), dtype=torch.int64, device=d)
-    results = torch.zeros((7, n), dtype=torch.int64, device=d)
+    results = torch.zeros((4, n, 2), dtype=torch.int64, device=d)
     status = torch.zeros((5,), dtype=torch.int32, device=d)
     tag = 0
     for label, flags, sync in (("pair+flags+torch_sync", 1 | _lib.TIMER_START | _lib.TIMER_STOP, torch.cuda.synchronize),
