@@ -53,7 +53,9 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ void granule_pair_store(uint64_t* p, uint64_t a, uint64_t b) {
     const u32x4 v = {(uint32_t)a, (uint32_t)(a >> 32), (uint32_t)b, (uint32_t)(b >> 32)};
-    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+    // (the s_nop covers the "VALU overwrites the data registers of a > 64-bit VMEM store" hazard: the compiler's hazard recognizer
+    // does not look inside inline assembly, and without it lanes 12-15 of every 16 stored the NEXT pair's first word)
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 2" ::"v"(p), "v"(v) : "memory");
 }
 
 // four pairs (eight granules) with all four loads in flight together
