@@ -1391,6 +1391,18 @@ static int copy_state(q1env* h, const q1env_state* s, bool to_host) {
         {s->yaw, h->st.yaw, n * 8}, {s->time_remaining, h->st.trem, n * 8},
         {s->last_key_press_time, h->st.lk, n * 32}, {s->flags, h->st.flags, n},
     };
+    int wanted = 0;
+    for (const Item& it : items) wanted += it.host != nullptr;
+    if (to_host && n <= PACK_MAX_ENVS && wanted > 2) {
+        // the SoA arrays are one contiguous arena: one copy of it through the pinned staging instead of one copy per array
+        const size_t bytes = arena_bytes(n);
+        if (int r = ensure_pin(h, bytes)) return r;
+        HIP_TRY(hipMemcpyAsync(h->pin, h->arena, bytes, hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        for (const Item& it : items)
+            if (it.host) memcpy(it.host, (const char*)h->pin + ((const char*)it.dev - (const char*)h->arena), it.bytes);
+        return Q1ENV_OK;
+    }
     for (const Item& it : items) {
         if (!it.host) continue;
         if (to_host) HIP_TRY(hipMemcpyAsync(it.host, it.dev, it.bytes, hipMemcpyDeviceToHost, h->stream));
@@ -1448,14 +1460,35 @@ int q1env_decode_host(q1env_t* h, int fmt, const void* a, const void* b, const f
     void* d_a = d; void* d_b = d + ba; float* d_zv = (float*)(d + ba + b4);
     double* d_tr = (double*)(d + ba + 2 * b4); double* d_y = d_tr + b8 / 8;
     int64_t* d_sm = (int64_t*)(d_y + b8 / 8); int64_t* d_fm = d_sm + b8 / 8; uint8_t* d_j = (uint8_t*)(d_fm + b8 / 8);
-    HIP_TRY(hipMemcpyAsync(d_a, a, act_bytes_a(h, fmt), hipMemcpyHostToDevice, h->stream));
-    if (fmt == Q1ENV_ACT_PACKED && h->p.yaw_mode) HIP_TRY(hipMemcpyAsync(d_b, b, n * 4, hipMemcpyHostToDevice, h->stream));
-    HIP_TRY(hipMemcpyAsync(d_zv, z_vel, n * 4, hipMemcpyHostToDevice, h->stream));
-    HIP_TRY(hipMemcpyAsync(d_tr, trem, n * 8, hipMemcpyHostToDevice, h->stream));
+    const bool pack = n <= PACK_MAX_ENVS;                  // mkdemo-style per-frame use is n = 1: one copy each way, not eight
+    const size_t in_bytes = ba + 2 * b4 + b8, total = ba + 2 * b4 + 4 * b8 + b1;
+    const bool has_b = fmt == Q1ENV_ACT_PACKED && h->p.yaw_mode;
+    char* pin = nullptr;
+    if (pack) {
+        if (int r = ensure_pin(h, total)) return r;
+        pin = (char*)h->pin;
+        memcpy(pin, a, act_bytes_a(h, fmt));
+        if (has_b) memcpy(pin + ba, b, n * 4);
+        memcpy(pin + ba + b4, z_vel, n * 4);
+        memcpy(pin + ba + 2 * b4, trem, n * 8);
+        HIP_TRY(hipMemcpyAsync(d, pin, in_bytes, hipMemcpyHostToDevice, h->stream));
+    } else {
+        HIP_TRY(hipMemcpyAsync(d_a, a, act_bytes_a(h, fmt), hipMemcpyHostToDevice, h->stream));
+        if (has_b) HIP_TRY(hipMemcpyAsync(d_b, b, n * 4, hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(hipMemcpyAsync(d_zv, z_vel, n * 4, hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(hipMemcpyAsync(d_tr, trem, n * 8, hipMemcpyHostToDevice, h->stream));
+    }
     const int blk = block_for(h->p.n);
     hipLaunchKernelGGL(decode_kernel, grid_for(h->p.n, blk), dim3(blk), 0, h->stream, h->p, h->st, fmt, (const void*)d_a,
                        (const void*)d_b, (const float*)d_zv, (const double*)d_tr, d_y, d_sm, d_fm, d_j);
     HIP_TRY(hipGetLastError());
+    if (pack) {
+        HIP_TRY(hipMemcpyAsync(pin + in_bytes, d + in_bytes, total - in_bytes, hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        const char* po = pin + in_bytes;
+        memcpy(yaw, po, n * 8); memcpy(smove, po + b8, n * 8); memcpy(fmove, po + 2 * b8, n * 8); memcpy(jump, po + 3 * b8, n);
+        return Q1ENV_OK;
+    }
     HIP_TRY(hipMemcpyAsync(yaw, d_y, n * 8, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipMemcpyAsync(smove, d_sm, n * 8, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipMemcpyAsync(fmove, d_fm, n * 8, hipMemcpyDeviceToHost, h->stream));
