@@ -118,14 +118,18 @@ def _action_rows(actions, width):
     """
     if isinstance(actions, np.ndarray) and actions.ndim == 2 and actions.dtype != object:
         return np.ascontiguousarray(actions, dtype=np.float64)
-    try:                                                   # homogeneous nested sequence of scalars
-        a = np.asarray(actions, dtype=np.float64)
-        if a.ndim == 2:
-            return np.ascontiguousarray(a)
-        if a.ndim == 3:                                    # every component a length-m array
-            return np.ascontiguousarray(a[:, :, 0])
-    except (ValueError, TypeError):
-        pass
+    first = actions[0] if len(actions) else ()
+    mixed = isinstance(first, (tuple, list)) and any(isinstance(c, np.ndarray) for c in first) and \
+        not all(isinstance(c, np.ndarray) for c in first)  # RLlib's rows: Python ints + a (1,) array - np.asarray can only fail on them
+    if not mixed:
+        try:                                               # homogeneous nested sequence of scalars
+            a = np.asarray(actions, dtype=np.float64)
+            if a.ndim == 2:
+                return np.ascontiguousarray(a)
+            if a.ndim == 3:                                # every component a length-m array
+                return np.ascontiguousarray(a[:, :, 0])
+        except (ValueError, TypeError):
+            pass
     try:                                                   # column-wise: A conversions instead of N*A
         cols = list(zip(*actions))
         out = np.empty((len(actions), len(cols)), dtype=np.float64)
