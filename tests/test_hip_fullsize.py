@@ -119,18 +119,18 @@ def test_config5_sampler_262144_envs_slice_replayed_by_the_oracles():
         assert np.array_equal(o.astype(np.float32), obs[t + 1]), t
         # (b) the distribution: same Philox draws (counter = tick index) through the float64 restatement
         k2, m2, lp2, margin = DO.sample_from_philox(cfg, logits[t], seed, genv, t)
-        sure = margin > 1e-5
+        sure = margin > 1e-6
         sure_total += int(sure.sum())
         assert np.array_equal(keys[t][sure], k2[sure]), t
-        assert np.max(np.abs(mouse[t] - m2)) < 2e-4, t
+        assert np.max(np.abs(mouse[t] - m2)) < 1e-4, t
         # (c) the stored log-probability re-derived for the STORED action from the stored logits (no sampling involved)
         lp3 = DO.mouse_logp(mouse[t].astype(np.float64), logits[t][:, 8].astype(np.float64), logits[t][:, 9].astype(np.float64), low, high)
         for j in range(4):
             lp0, lp1 = DO.key_logprobs(logits[t][:, 2 * j].astype(np.float64), logits[t][:, 2 * j + 1].astype(np.float64))
             lp3 = lp3 + np.where((keys[t] >> j) & 1, lp1, lp0)
         inner = np.abs(mouse[t]) < 0.99 * high               # away from the 1e-6 clip, where ndtri amplifies float32 rounding
-        assert np.max(np.abs(logp[t][inner] - lp3[inner]) / np.maximum(np.abs(lp3[inner]), 1.0)) < 2e-3, t
-    assert sure_total > 0.99 * T * m
+        assert np.max(np.abs(logp[t][inner] - lp3[inner]) / np.maximum(np.abs(lp3[inner]), 1.0)) < 1e-3, t
+    assert sure_total > 0.999 * T * m
     # (d) the fused matrix-core forward at this size against the float32 torch modules on the slice
     with torch.no_grad():
         lg32, v32 = pol(tr["obs"][0, pick])

@@ -31,19 +31,22 @@ def test_policy_sample_kernel_matches_restatement():
     env._dev.policy_sample_dev(lt.data_ptr(), 10, seed, counter, keys.data_ptr(), mouse.data_ptr(), logp.data_ptr())
     torch.cuda.synchronize()
     k2, m2, lp2, margin = DO.sample_from_philox(cfg, logits, seed, np.arange(n, dtype=np.uint64) + np.uint64(base), counter)
-    sure = margin > 1e-5                    # a uniform within 1e-5 of its float32 threshold may legitimately flip
-    assert sure.mean() > 0.999 and np.array_equal(keys.cpu().numpy()[sure], k2[sure])
+    sure = margin > 1e-6                    # a uniform within 1e-6 of its float32 threshold may legitimately flip
+    assert sure.mean() > 0.9999 and np.array_equal(keys.cpu().numpy()[sure], k2[sure])
     # float32 kernel vs float64 restatement: absolute tolerance on the action (range 20), relative on logp
-    assert np.max(np.abs(mouse.cpu().numpy() - m2)) < 2e-4
+    # (measured on MI355X, 200 000 rows: 0 key mismatches, |mouse diff| <= 5.3e-5, logp 2.9e-4 / 2.6e-5 relative)
+    assert np.max(np.abs(mouse.cpu().numpy() - m2)) < 1e-4
     lp = logp.cpu().numpy()
     same = sure & (np.abs(m2) < 10.0)       # away from the 1e-6 clip, where ndtri amplifies float32 rounding
-    assert np.max(np.abs(lp[same] - lp2[same]) / np.maximum(np.abs(lp2[same]), 1.0)) < 2e-3
+    assert np.max(np.abs(lp[same] - lp2[same]) / np.maximum(np.abs(lp2[same]), 1.0)) < 6e-4
+    inner = sure & (np.abs(m2) < 9.5)
+    assert np.max(np.abs(lp[inner] - lp2[inner]) / np.maximum(np.abs(lp2[inner]), 1.0)) < 1e-4
     # torch distribution agrees with the kernel's logp on the kernel's own samples
     from q1physrl_amd import policy as P
     dist = P.Q1PhysActionDist(lt.double(), float(np.float32(cfg.action_range)), 4)
     kbits = ((keys[:, None].long() >> torch.arange(4, device="cuda")) & 1)
     lp_t = dist.logp(kbits, mouse.double().view(-1, 1)).cpu().numpy()
-    assert np.max(np.abs(lp[same] - lp_t[same]) / np.maximum(np.abs(lp_t[same]), 1.0)) < 2e-3
+    assert np.max(np.abs(lp[same] - lp_t[same]) / np.maximum(np.abs(lp_t[same]), 1.0)) < 6e-4
     # statistics: empirical key frequency equals sigmoid(l1 - l0) on average
     p1 = 1 / (1 + np.exp(-(logits[:, 1].astype(np.float64) - logits[:, 0])))
     assert abs(((keys.cpu().numpy() & 1) != 0).mean() - p1.mean()) < 0.01
@@ -51,7 +54,7 @@ def test_policy_sample_kernel_matches_restatement():
     env._dev.policy_sample_dev(lt.data_ptr(), 10, seed, counter, keys.data_ptr(), mouse.data_ptr(), logp.data_ptr(), True)
     torch.cuda.synchronize()
     kd, md, _, _ = DO.sample_from_philox(cfg, logits, seed, np.arange(n, dtype=np.uint64), counter, deterministic=True)
-    assert np.array_equal(keys.cpu().numpy(), kd) and np.max(np.abs(mouse.cpu().numpy() - md)) < 2e-4
+    assert np.array_equal(keys.cpu().numpy(), kd) and np.max(np.abs(mouse.cpu().numpy() - md)) < 1e-4
     env.close()
 
 
