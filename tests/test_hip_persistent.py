@@ -161,3 +161,32 @@ def test_tick_server_without_a_producer_times_out_and_reports_it():
     with pytest.raises(_lib.Q1EnvError, match="too many envs"):
         big._dev.persistent_start(5, 0, mailbox.data_ptr(), results.data_ptr(), 0, 1, True, status.data_ptr())
     big.close()
+
+
+def test_tick_server_soak_5000_ticks_65536_envs():
+    """Soak: 65 536 envs x 5 040 ticks (seven 720-tick launches, in-kernel resets, cycling actions) = 330 M action hand-offs and
+    1.3 G result-granule pairs.  The final state equals the per-tick kernels' and the producer's float64 sums of every reward and
+    first observation column it received equal the per-tick path's - one stale, torn or skipped granule anywhere would show."""
+    import torch
+    n, T, launches = 65536, 720, 7
+    cfg, a = make_env(n, 3, zero_start_prob=0.3)
+    _, b = make_env(n, 3, zero_start_prob=0.3)
+    a.reset(); b.reset()
+    keys, mouse = actions(n, T, 8)
+    want = torch.zeros((launches, 2, n), dtype=torch.float64, device="cuda")
+    for l in range(launches):
+        for t in range(T):
+            obs_b, rew_b, done_b = b.step_autoreset((keys[t], mouse[t]))
+            if t != T - 1:
+                want[l, 0] += rew_b.double()
+                want[l, 1] += obs_b[:, 0].double()
+    for l in range(launches):
+        res = a.serve_ticks(keys, mouse, two_streams=(l == 3))             # one of the launches in the two-stream form
+        assert not res["status"].any(), (l, res["status"])
+        assert torch.equal(res["checksum"], want[l]), l
+    torch.cuda.synchronize()
+    sa, sb = a.get_state(), b.get_state()
+    for k in sa:
+        assert np.array_equal(sa[k], sb[k]), k
+    assert torch.equal(res["obs_from_granules"], obs_b) and torch.equal(res["reward"], rew_b) and torch.equal(res["done"], done_b)
+    a.close(); b.close()
