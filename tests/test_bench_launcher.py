@@ -89,3 +89,13 @@ def test_server_mode_failure_is_collective_and_auto_falls_back():
     d = _one_json(r.stdout)
     _check_line(d, 2, 16, 6, 2)
     assert d["mode"] == "step" and "server mode failed" in d["mode_fallback"] and "step_kernel" in d["roofline"]["kernel"]
+
+
+def test_self_launch_eight_ranks():
+    """The driver's largest invocation shape, `python bench.py --gpus 8`, on CPU: eight self-launched workers rendezvous, time their
+    regions, agree collectively and rank 0 prints the one line with eight per-rank rows (BASELINE configs[3] is 8 x 131 072 envs)."""
+    r = _run([sys.executable, "bench.py", "--gpus", "8", "--steps", "10", "--warmup", "3", "--envs", "16", "--no-secondary"], timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = _one_json(r.stdout)
+    _check_line(d, 8, 16, 10, 3)
+    assert len(d["per_rank"]) == 8 and d["config"]["total_envs"] == 128

@@ -243,3 +243,60 @@ def test_physenv_without_gym_has_the_gym_env_attributes():
     assert e.unwrapped is e and e.spec is None and e.seed(1) is None and E.PhysEnv.metadata == {}
     e.unwrapped.spec = 5
     assert e.spec == 5
+
+
+def test_pinned_pool_recycles_blocks_only_when_every_view_is_gone(monkeypatch):
+    """_lib.PinnedPool is np.empty for page-locked memory.  With the allocator stubbed (no GPU here): size classes, a block returns to
+    the pool when the LAST array viewing it is collected - not before - and recycled blocks are handed out again."""
+    import ctypes
+    import gc
+    from q1physrl_amd import _lib
+    libc = ctypes.CDLL(None)
+    libc.malloc.restype, libc.malloc.argtypes = ctypes.c_void_p, [ctypes.c_size_t]
+    libc.free.argtypes = [ctypes.c_void_p]
+    log = {"alloc": [], "free": []}
+
+    class FakeLib:
+        @staticmethod
+        def q1env_host_alloc(size):
+            p = libc.malloc(size)
+            log["alloc"].append((p, size))
+            return p
+
+        @staticmethod
+        def q1env_host_free(p):
+            log["free"].append(p.value)
+            libc.free(p)
+            return 0
+
+        @staticmethod
+        def q1env_last_error():
+            return b""
+    monkeypatch.setattr(_lib, "load", lambda: FakeLib)
+    monkeypatch.setattr(_lib, "_lib", FakeLib)
+    pool = _lib.PinnedPool(cache_bytes=1 << 20)
+    a = pool.empty((1000, 6), np.float64)                # 48 000 B -> 64 KiB class
+    assert a.shape == (1000, 6) and a.dtype == np.float64 and a.flags["C_CONTIGUOUS"] and log["alloc"][-1][1] == 65536
+    a[:] = 7.0
+    view = a[10:20, 2]
+    ptr_a = log["alloc"][-1][0]
+    del a
+    gc.collect()
+    assert pool._cached == 0 and not log["free"]          # the view keeps the block alive
+    assert float(view.sum()) == 70.0
+    del view
+    gc.collect()
+    assert pool._cached == 65536                          # ... now it is back in the pool
+    b = pool.empty((8192,), np.float64)                   # same class: recycled, no new allocation
+    assert len(log["alloc"]) == 1 and pool._cached == 0 and b.ctypes.data == ptr_a
+    c = pool.empty((3,), np.uint8)                        # smallest class: 4 KiB
+    assert log["alloc"][-1][1] == 4096
+    big = pool.empty((1 << 21,), np.uint8)                # 2 MiB: above the cache cap of this pool -> freed, not cached, on release
+    del big
+    gc.collect()
+    assert len(log["free"]) == 1 and pool._cached == 0
+    del b, c
+    gc.collect()
+    assert pool._cached == 65536 + 4096
+    pool.trim()
+    assert pool._cached == 0 and len(log["free"]) == 3
