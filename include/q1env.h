@@ -330,6 +330,16 @@ int q1env_step_persistent_start(q1env_t* env, int ticks, uint32_t tag0, const ui
 int q1env_step_persistent_drive(q1env_t* env, void* producer_stream, int ticks, uint32_t tag0, const uint8_t* keys_dev,
                                 const float* mouse_dev, uint64_t* mailbox_dev, const uint64_t* results_dev,
                                 double* checksum_dev, uint32_t* status_dev, double timeout_s);
+/* An EXTERNAL producer (a policy) talks to the server with two ordinary launches on its own stream: _publish hands tick `tick`
+ * (0-based within the launch that was started with the same tag0) of packed actions over; _collect waits - bounded by timeout_s,
+ * reporting a timeout in status[3] - for that tick's result granules and unpacks them into plain arrays (obs float[N][6]; reward
+ * float[N], done / zero_start uint8[N] optional) for the kernels that follow on that stream.  A sampler iteration is then
+ * collect(t-1) -> policy forward -> action sampling -> publish(t), with no launch at all on the env side. */
+int q1env_step_persistent_publish(q1env_t* env, void* producer_stream, uint32_t tag0, uint32_t tick, const uint8_t* keys_dev,
+                                  const float* mouse_dev, uint64_t* mailbox_dev);
+int q1env_step_persistent_collect(q1env_t* env, void* producer_stream, uint32_t tag0, uint32_t tick, const uint64_t* results_dev,
+                                  float* obs_dev, float* reward_dev, uint8_t* done_dev, uint8_t* zero_start_dev, uint32_t* status_dev,
+                                  double timeout_s);
 /* _start + _drive as ONE dispatch on the handle's stream (server waves and driver waves are blocks of the same grid, same protocol,
  * same results): two streams are only concurrent when the runtime maps them to different hardware queues, which HIP does not
  * promise - a producer queued behind the server it feeds can only time out.  Give an external producer a stream of another

@@ -92,6 +92,8 @@ _SIGNATURES = {
     "q1env_episode_stats": (C.c_int, [_P, _P, _P, _P, _P, _P]),
     "q1env_step_persistent_start": (C.c_int, [_P, C.c_int, C.c_uint32, _P, _P, _P, C.c_uint64, C.c_int, _P, C.c_double]),
     "q1env_step_persistent_drive": (C.c_int, [_P, _P, C.c_int, C.c_uint32, _P, _P, _P, _P, _P, _P, C.c_double]),
+    "q1env_step_persistent_publish": (C.c_int, [_P, _P, C.c_uint32, C.c_uint32, _P, _P, _P]),
+    "q1env_step_persistent_collect": (C.c_int, [_P, _P, C.c_uint32, C.c_uint32, _P, _P, _P, _P, _P, _P, C.c_double]),
     "q1env_step_persistent_pair": (C.c_int, [_P, C.c_int, C.c_uint32, _P, _P, _P, _P, _P, C.c_uint64, C.c_int, _P, _P, C.c_double]),
     "q1env_selftest_division": (C.c_int, [C.c_int, C.c_uint64, C.c_uint64, C.c_double, C.c_double, C.POINTER(C.c_uint64)]),
     "q1env_calibrate_traffic": (C.c_int, [_P, C.c_int]),

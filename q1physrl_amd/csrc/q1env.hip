@@ -1730,6 +1730,31 @@ int q1env_step_persistent_drive(q1env_t* h, void* producer_stream, int ticks, ui
     return Q1ENV_OK;
 }
 
+int q1env_step_persistent_publish(q1env_t* h, void* producer_stream, uint32_t tag0, uint32_t tick, const uint8_t* keys_dev,
+                                  const float* mouse_dev, uint64_t* mailbox_dev) {
+    if (!h || !producer_stream || !keys_dev || !mailbox_dev) return fail(Q1ENV_ERR_INVALID_ARG, "q1env_step_persistent_publish: null argument");
+    if (h->p.yaw_mode && !mouse_dev) return fail(Q1ENV_ERR_INVALID_ARG, "q1env_step_persistent_publish: mouse actions required");
+    if ((hipStream_t)producer_stream == h->stream) return fail(Q1ENV_ERR_INVALID_ARG, "q1env_step_persistent_publish: the producer must run on another stream than the server");
+    DeviceGuard guard(h->device);
+    hipLaunchKernelGGL(tick_publish_kernel, grid_for(h->p.n, 256), dim3(256), 0, (hipStream_t)producer_stream, h->p.n, tag0, tick, keys_dev,
+                       mouse_dev, mailbox_dev);
+    HIP_TRY(hipGetLastError());
+    return Q1ENV_OK;
+}
+
+int q1env_step_persistent_collect(q1env_t* h, void* producer_stream, uint32_t tag0, uint32_t tick, const uint64_t* results_dev,
+                                  float* obs_dev, float* reward_dev, uint8_t* done_dev, uint8_t* zero_start_dev, uint32_t* status_dev,
+                                  double timeout_s) {
+    if (!h || !producer_stream || !results_dev || !obs_dev || !status_dev) return fail(Q1ENV_ERR_INVALID_ARG, "q1env_step_persistent_collect: null argument");
+    if ((hipStream_t)producer_stream == h->stream) return fail(Q1ENV_ERR_INVALID_ARG, "q1env_step_persistent_collect: the producer must run on another stream than the server");
+    if (!(timeout_s > 0.0) || timeout_s > 30.0) return fail(Q1ENV_ERR_INVALID_ARG, "q1env_step_persistent_collect: timeout_s must be in (0, 30]");
+    DeviceGuard guard(h->device);
+    hipLaunchKernelGGL(tick_collect_kernel, dim3(((unsigned)h->p.n + 63u) / 64u), dim3(64), 0, (hipStream_t)producer_stream, h->p.n, tag0, tick,
+                       results_dev, obs_dev, reward_dev, done_dev, zero_start_dev, status_dev, (uint64_t)(timeout_s * 1.0e8));
+    HIP_TRY(hipGetLastError());
+    return Q1ENV_OK;
+}
+
 int q1env_step_persistent_pair(q1env_t* h, int ticks, uint32_t tag0, const uint8_t* keys_dev, const float* mouse_dev,
                                uint64_t* mailbox_dev, uint64_t* results_dev, float* obs_final_dev, uint64_t seed, int auto_reset,
                                double* checksum_dev, uint32_t* status_dev, double timeout_s) {

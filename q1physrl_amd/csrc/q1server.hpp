@@ -210,6 +210,57 @@ __device__ __forceinline__ void tick_driver_body(int n, uint32_t block, int tick
     }
 }
 
+// An EXTERNAL producer's two halves of the protocol, as ordinary launches on the producer's own stream (a torch policy sits
+// between them): publish hands one tick's packed actions over, collect waits - bounded - for one tick's result granules and unpacks
+// them into plain tensors (obs float[N][6], reward, done, zero_start) for the kernels that follow on that stream.
+__global__ void __launch_bounds__(256)
+tick_publish_kernel(int n, uint32_t tag0, uint32_t t, const uint8_t* keys, const float* mouse, uint64_t* mailbox) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (uint32_t)n) return;
+    const uint64_t tag = tick_tag(tag0, t);
+    const float m = mouse ? mouse[i] : 0.0f;
+    granule_store(mailbox + i, (tag << 40) | ((uint64_t)(keys[i] & 0xFu) << 32) | (uint64_t)__float_as_uint(m));
+}
+
+__global__ void __launch_bounds__(64)
+tick_collect_kernel(int n, uint32_t tag0, uint32_t t, const uint64_t* results, float* obs, float* reward, uint8_t* done,
+                    uint8_t* zero_start, uint32_t* status, uint64_t timeout_ticks) {
+    const uint32_t lane = threadIdx.x, i = blockIdx.x * 64u + lane;
+    const bool live = i < (uint32_t)n;
+    const uint64_t want = tick_tag(tag0, t);
+    uint64_t g[8];
+    bool ok = !live, timed_out = false;
+    uint32_t polls = 0;
+    uint64_t t_wait = 0;
+    for (;;) {
+        if (!ok) {
+            granule_pairs_load4(pair_ptr(results, (uint32_t)n, 0u, i), pair_ptr(results, (uint32_t)n, 1u, i),
+                                pair_ptr(results, (uint32_t)n, 2u, i), pair_ptr(results, (uint32_t)n, 3u, i), g);
+            ok = true;
+#pragma unroll
+            for (int q = 0; q < RESULT_GRANULES; ++q) ok = ok && ((g[q] >> 40) == want);
+        }
+        if (__all(ok)) break;
+        if ((++polls & 255u) == 0u) {
+            const uint64_t now = wall_clock64();
+            if (t_wait == 0) t_wait = now;
+            else if (now - t_wait > timeout_ticks) { timed_out = true; break; }
+            __builtin_amdgcn_s_sleep(8);
+        }
+    }
+    if (timed_out) {
+        if (lane == 0) { atomicOr(&status[3], 1u); atomicMax(&status[4], 1u); }
+        return;
+    }
+    if (live) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) obs[(size_t)i * 6 + k] = __uint_as_float((uint32_t)g[k]);
+        if (reward) reward[i] = __uint_as_float((uint32_t)g[6]);
+        if (done) done[i] = (uint8_t)((g[6] >> 32) & 1u);
+        if (zero_start) zero_start[i] = (uint8_t)((g[6] >> 33) & 1u);
+    }
+}
+
 template <bool SPEC>
 __global__ void __launch_bounds__(64)
 tick_server_kernel(Params p, StatePtrs s, int ticks, uint32_t tag0, const uint64_t* mailbox, uint64_t* results, float* obs_final,

@@ -231,6 +231,14 @@ class DeviceEnv:
         _lib.check(self._lib.q1env_step_persistent_drive(self._h, C.c_void_p(int(producer_stream)), int(ticks), int(tag0) & 0xFFFFFFFF,
                                                          keys, mouse, mailbox, results, checksum or None, status, float(timeout_s)))
 
+    def persistent_publish(self, producer_stream, tag0, tick, keys, mouse, mailbox):
+        _lib.check(self._lib.q1env_step_persistent_publish(self._h, C.c_void_p(int(producer_stream)), int(tag0) & 0xFFFFFFFF, int(tick), keys,
+                                                           mouse or None, mailbox))
+
+    def persistent_collect(self, producer_stream, tag0, tick, results, obs, reward, done, zero_start, status, timeout_s=2.0):
+        _lib.check(self._lib.q1env_step_persistent_collect(self._h, C.c_void_p(int(producer_stream)), int(tag0) & 0xFFFFFFFF, int(tick), results,
+                                                           obs, reward or None, done or None, zero_start or None, status, float(timeout_s)))
+
     def persistent_pair(self, ticks, tag0, keys, mouse, mailbox, results, obs_final, seed, auto_reset, checksum, status, timeout_s=2.0):
         """Server + reference driver as one dispatch on the handle's stream (q1env_step_persistent_pair)."""
         _lib.check(self._lib.q1env_step_persistent_pair(self._h, int(ticks), int(tag0) & 0xFFFFFFFF, keys, mouse, mailbox, results,

@@ -169,6 +169,42 @@ class TensorVectorEnv:
         return {"obs": self.obs, "obs_from_granules": low[:6].t().contiguous(), "reward": self.reward, "done": self.done,
                 "zero_start": self.zero_start, "checksum": sv["checksum"], "status": sv["status"].cpu().numpy().astype("uint32")}
 
+    def serve_with_policy(self, act_fn, ticks: int, auto_reset: bool = True, timeout_s: float = 2.0):
+        """Experimental: `ticks` ticks on the resident tick server with a TORCH producer in a policy's place.  act_fn(obs, t) ->
+        (keys uint8 (N,), mouse float32 (N,)) is ordinary torch code; it runs on a high-priority side stream between
+        q1env_step_persistent_collect (tick t-1's results -> obs / reward / done tensors) and q1env_step_persistent_publish (tick t's
+        action), while the env side is ONE launch for the whole run.  Bit-identical to `obs = observe(); for t: step_autoreset(act_fn(obs, t))`.
+        Returns (reward (T,N) float32, done (T,N) uint8, status uint32[5]); self.obs / reward / done hold the last tick."""
+        n, d = self.num_envs, self.device
+        if not hasattr(self, "_srv"):
+            self._srv = {"mailbox": torch.zeros((n,), dtype=torch.int64, device=d), "results": torch.zeros((4, n, 2), dtype=torch.int64, device=d),
+                         "status": torch.zeros((5,), dtype=torch.int32, device=d), "checksum": torch.zeros((2, n), dtype=torch.float64, device=d),
+                         "stream": torch.cuda.Stream(device=d, priority=-1), "tag": 0}
+        sv = self._srv
+        sv["status"].zero_()
+        obs = self.observe().clone()                           # the observation the first action is computed from
+        rew = torch.empty((ticks, n), dtype=torch.float32, device=d)
+        don = torch.empty((ticks, n), dtype=torch.uint8, device=d)
+        cur, side = torch.cuda.current_stream(d), sv["stream"]
+        side.wait_stream(cur)
+        tag0 = sv["tag"]
+        self._dev.persistent_start(ticks, tag0, sv["mailbox"].data_ptr(), sv["results"].data_ptr(), 0, self.seed, auto_reset,
+                                   sv["status"].data_ptr(), timeout_s)
+        with torch.cuda.stream(side):
+            for t in range(ticks):
+                keys, mouse = act_fn(obs, t)
+                assert keys.dtype == torch.uint8 and mouse.dtype == torch.float32 and keys.is_contiguous() and mouse.is_contiguous()
+                self._dev.persistent_publish(side.cuda_stream, tag0, t, keys.data_ptr(), mouse.data_ptr(), sv["mailbox"].data_ptr())
+                self._dev.persistent_collect(side.cuda_stream, tag0, t, sv["results"].data_ptr(), obs.data_ptr(), rew[t].data_ptr(),
+                                             don[t].data_ptr(), self.zero_start.data_ptr(), sv["status"].data_ptr(), timeout_s)
+        sv["tag"] = (tag0 + ticks) % 0xFFFFFF
+        cur.wait_stream(side)
+        torch.cuda.synchronize(d)
+        self.obs.copy_(obs)
+        self.reward.copy_(rew[-1])
+        self.done.copy_(don[-1])
+        return rew, don, sv["status"].cpu().numpy().astype("uint32")
+
     def observe(self) -> torch.Tensor:
         self._dev.observe_dev(self.obs.data_ptr(), _lib.OBS_F32)
         return self.obs

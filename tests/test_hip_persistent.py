@@ -190,3 +190,38 @@ def test_tick_server_soak_5000_ticks_65536_envs():
         assert np.array_equal(sa[k], sb[k]), k
     assert torch.equal(res["obs_from_granules"], obs_b) and torch.equal(res["reward"], rew_b) and torch.equal(res["done"], done_b)
     a.close(); b.close()
+
+
+def test_tick_server_with_a_torch_producer_in_the_policy_seat():
+    """The protocol's purpose: an EXTERNAL producer.  A torch function of the observation computes every tick's action on a side
+    stream between q1env_step_persistent_collect and _publish while the env side is ONE launch; results equal the per-tick loop
+    `obs = observe(); for t: obs, r, d = step_autoreset(policy(obs, t))` bit for bit (actions DEPEND on the observations, so any
+    stale or reordered hand-off would change the trajectory)."""
+    import torch
+    n, ticks = 5000, 120
+    over = dict(time_limit=0.7, zero_start_prob=0.4)
+    cfg, a = make_env(n, 13, **over)
+    _, b = make_env(n, 13, **over)
+    a.reset(); b.reset()
+    rng = float(np.float32(cfg.action_range))
+
+    def policy(obs, t):
+        h = (obs[:, 1] * 97.0 + obs[:, 3] * 31.0 + obs[:, 0] * 1009.0).abs()
+        keys = ((h.long() + t) & 15).to(torch.uint8)
+        mouse = torch.clamp(obs[:, 4] * 4.0 - obs[:, 3] * 2.0 + 0.01 * t, -rng, rng).float().contiguous()
+        return keys.contiguous(), mouse
+
+    rew_a, done_a, st = a.serve_with_policy(policy, ticks)
+    assert not st.any(), st
+    obs = b.observe().clone()
+    for t in range(ticks):
+        k, m = policy(obs, t)
+        o, r, d = b.step_autoreset((k, m))
+        obs = o.clone()
+        assert torch.equal(rew_a[t], r) and torch.equal(done_a[t], d), t
+    torch.cuda.synchronize()
+    assert torch.equal(a.obs, obs) and done_a.sum() > n          # episodes ended and were reset in-kernel on the way
+    sa, sb = a.get_state(), b.get_state()
+    for k_ in sa:
+        assert np.array_equal(sa[k_], sb[k_]), k_
+    a.close(); b.close()
