@@ -36,6 +36,28 @@ def main():
             env.reset_done()
     ms = timed(env, step_reset, 2)
     print(f"C3 {n} envs full Config: step + masked reset_done per tick (2 launches/tick): {ms*1e3/T:8.2f} us/tick  {n*T/ms/1e6:8.2f} G env-steps/s")
+    # the same ticks as ONE launch each (q1env_step_autoreset: in-kernel Philox reset of finished episodes, RNG counter in device
+    # memory), the T launches replayed from a captured graph
+    cnt = torch.zeros((1,), dtype=torch.int64, device="cuda")
+    side = torch.cuda.Stream()
+
+    def autoreset_ticks():
+        for t in range(T):
+            env._dev.step_autoreset_dev(_lib.ACT_PACKED, keys[t].data_ptr(), mouse[t].data_ptr(), 3, env.obs.data_ptr(), env.reward.data_ptr(),
+                                        env.done.data_ptr(), env.zero_start.data_ptr(), counter_dev=cnt.data_ptr())
+            cnt.add_(1)
+    with torch.cuda.stream(side):
+        env.use_current_stream()
+        autoreset_ticks()
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=side, capture_error_mode="relaxed"):
+        env.use_current_stream()
+        autoreset_ticks()
+    env.use_current_stream()
+    torch.cuda.synchronize()
+    ms = timed(env, g.replay, 3)
+    print(f"C3 {n} envs full Config: step with in-kernel reset, 1 launch/tick (+1 counter op), graph replay: {ms*1e3/T:8.2f} us/tick  {n*T/ms/1e6:8.2f} G env-steps/s")
     obs = torch.empty((T, n, 6), dtype=torch.float32, device="cuda"); rew = torch.empty((T, n), device="cuda"); done = torch.empty((T, n), dtype=torch.uint8, device="cuda")
     def fused():
         env._dev.rollout_dev(T, _lib.ACT_PACKED, keys.data_ptr(), mouse.data_ptr(), 3, _lib.OBS_F32, obs.data_ptr(), rew.data_ptr(), done.data_ptr(), True, 0)
