@@ -151,6 +151,14 @@ int q1env_step(q1env_t* env, int action_format, const void* act_a_dev, const voi
  * Observations are float32.  counter_dev as in q1env_reset_philox. */
 int q1env_step_autoreset(q1env_t* env, int action_format, const void* act_a_dev, const void* act_b_dev, uint64_t seed,
                          const uint64_t* counter_dev, float* obs_dev, float* reward_dev, uint8_t* done_dev, uint8_t* zero_start_dev);
+/* `ticks` consecutive q1env_step_autoreset launches over tick-major actions (outputs tick-major when out_stride_ticks = 1, a ring of
+ * one slab when 0; any may be NULL) - RLlib's "step, then reset what finished" loop at one launch per tick.  Tick t draws its
+ * reset randomness with the Philox counter *counter_dev + t, and one last node advances *counter_dev by `ticks`, so the cached
+ * hipGraph (use_graph as in q1env_step_many: 0 eager, 1 replay, 2 prepare only) draws fresh numbers on every replay.  counter_dev
+ * (device uint64, required) belongs to the caller; bit-identical to the same ticks issued one by one with that counter. */
+int q1env_step_autoreset_many(q1env_t* env, int ticks, int action_format, const void* act_a_dev, const void* act_b_dev, uint64_t seed,
+                              uint64_t* counter_dev, float* obs_dev, float* reward_dev, uint8_t* done_dev, uint8_t* zero_start_dev,
+                              int out_stride_ticks, int use_graph);
 /* Same with HOST pointers: stages H2D, steps, copies back, synchronises (the NumPy-compatible path). */
 int q1env_step_host(q1env_t* env, int action_format, const void* act_a, const void* act_b,
                     int obs_format, void* obs, float* reward, uint8_t* done, uint8_t* zero_start);

@@ -67,6 +67,7 @@ _SIGNATURES = {
     "q1env_reset_philox": (C.c_int, [_P, C.c_uint64, _P, _P, C.c_int, C.c_int, _P]),
     "q1env_step": (C.c_int, [_P, C.c_int, _P, _P, C.c_int, _P, _P, _P, _P]),
     "q1env_step_autoreset": (C.c_int, [_P, C.c_int, _P, _P, C.c_uint64, _P, _P, _P, _P, _P]),
+    "q1env_step_autoreset_many": (C.c_int, [_P, C.c_int, C.c_int, _P, _P, C.c_uint64, _P, _P, _P, _P, _P, C.c_int, C.c_int]),
     "q1env_step_host": (C.c_int, [_P, C.c_int, _P, _P, C.c_int, _P, _P, _P, _P]),
     "q1env_step_many": (C.c_int, [_P, C.c_int, C.c_int, _P, _P, C.c_int, _P, _P, _P, C.c_int, C.c_int]),
     "q1env_rollout": (C.c_int, [_P, C.c_int, C.c_int, _P, _P, C.c_uint64, C.c_int, _P, _P, _P, C.c_int, _P]),

@@ -643,6 +643,11 @@ sample_step_kernel(Params p, StatePtrs s, const float* __restrict__ logits, int 
     episode_stats_lane(live, i, o.reward, o.done, zs, ep_return, partials);
 }
 
+// *counter += by: the one extra node of a replayable run of auto-reset ticks (q1env_step_autoreset_many)
+__global__ void counter_add_kernel(uint64_t* counter, uint64_t by) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) *counter += by;
+}
+
 #include "q1server.hpp"       // tick_server_kernel / tick_driver_kernel / tick_pair_kernel (the resident tick server)
 
 // Traffic calibration for the PMC counters (MI355X_MICROARCH.md "HBM": FETCH_SIZE / WRITE_SIZE must be calibrated on
@@ -1118,21 +1123,88 @@ int q1env_step(q1env_t* h, int fmt, const void* a, const void* b, int obs_format
     return Q1ENV_OK;
 }
 
-int q1env_step_autoreset(q1env_t* h, int fmt, const void* a, const void* b, uint64_t seed, const uint64_t* counter_dev, float* obs,
-                         float* reward, uint8_t* done, uint8_t* zs) {
-    if (!h) return fail(Q1ENV_ERR_INVALID_ARG, "q1env_step_autoreset: null handle");
-    DeviceGuard guard(h->device);
-    if (int r = check_act(h, fmt, a, b, false)) return r;
+static void launch_step_autoreset(q1env* h, int fmt, const void* a, const void* b, uint64_t seed, uint64_t counter,
+                                  const uint64_t* counter_dev, float* obs, float* reward, uint8_t* done, uint8_t* zs) {
     const int blk = block_for(h->p.n);
     const dim3 g = grid_for(h->p.n, blk), bs(blk);
-    const uint64_t counter = counter_dev ? 0 : h->tick_count;
 #define Q1_LAUNCH_AR(SP, FM) \
     hipLaunchKernelGGL((step_autoreset_kernel<SP, FM>), g, bs, 0, h->stream, h->p, h->st, fmt, a, b, seed, counter, counter_dev, obs, reward, done, zs)
     if (is_spec(h->p) && fmt == Q1ENV_ACT_PACKED) Q1_LAUNCH_AR(true, FMT_PACKED);
     else Q1_LAUNCH_AR(false, FMT_RUNTIME);
 #undef Q1_LAUNCH_AR
+}
+
+int q1env_step_autoreset(q1env_t* h, int fmt, const void* a, const void* b, uint64_t seed, const uint64_t* counter_dev, float* obs,
+                         float* reward, uint8_t* done, uint8_t* zs) {
+    if (!h) return fail(Q1ENV_ERR_INVALID_ARG, "q1env_step_autoreset: null handle");
+    DeviceGuard guard(h->device);
+    if (int r = check_act(h, fmt, a, b, false)) return r;
+    launch_step_autoreset(h, fmt, a, b, seed, counter_dev ? 0 : h->tick_count, counter_dev, obs, reward, done, zs);
     HIP_TRY(hipGetLastError());
     h->tick_count += 1;
+    return Q1ENV_OK;
+}
+
+// `ticks` auto-reset ticks over tick-major actions as a replayable unit: tick t uses the Philox counter *counter_dev + t, and one
+// last node advances *counter_dev by `ticks` - so a cached graph draws fresh reset randomness on every replay.
+static void enqueue_many_autoreset(q1env* h, int ticks, int fmt, const void* a, const void* b, uint64_t seed, uint64_t* counter_dev,
+                                   float* obs, float* reward, uint8_t* done, uint8_t* zs, int out_stride) {
+    const size_t n = (size_t)h->p.n;
+    const size_t sa = act_bytes_a(h, fmt), sb = n * 4;
+    for (int t = 0; t < ticks; ++t) {
+        const size_t ot = out_stride ? (size_t)t : 0;
+        launch_step_autoreset(h, fmt, (const char*)a + sa * t, b ? (const char*)b + sb * t : nullptr, seed, (uint64_t)t, counter_dev,
+                              obs ? obs + n * 6 * ot : nullptr, reward ? reward + n * ot : nullptr, done ? done + n * ot : nullptr,
+                              zs ? zs + n * ot : nullptr);
+    }
+    hipLaunchKernelGGL(counter_add_kernel, dim3(1), dim3(64), 0, h->stream, counter_dev, (uint64_t)ticks);
+}
+
+int q1env_step_autoreset_many(q1env_t* h, int ticks, int fmt, const void* a, const void* b, uint64_t seed, uint64_t* counter_dev,
+                              float* obs, float* reward, uint8_t* done, uint8_t* zs, int out_stride, int use_graph) {
+    if (!h || !counter_dev) return fail(Q1ENV_ERR_INVALID_ARG, "q1env_step_autoreset_many: null argument (counter_dev is required)");
+    DeviceGuard guard(h->device);
+    if (ticks <= 0) return fail(Q1ENV_ERR_INVALID_ARG, "ticks must be > 0");
+    if (int r = check_act(h, fmt, a, b, false)) return r;
+    if (use_graph < 0 || use_graph > 2) return fail(Q1ENV_ERR_INVALID_ARG, "bad use_graph");
+    if (!use_graph) {
+        enqueue_many_autoreset(h, ticks, fmt, a, b, seed, counter_dev, obs, reward, done, zs, out_stride);
+        HIP_TRY(hipGetLastError());
+    } else {
+        std::vector<uint64_t> key = {0xA17053E7ull, (uint64_t)ticks, (uint64_t)fmt, (uint64_t)(uintptr_t)a, (uint64_t)(uintptr_t)b, seed,
+                                     (uint64_t)(uintptr_t)counter_dev, (uint64_t)(uintptr_t)obs, (uint64_t)(uintptr_t)reward,
+                                     (uint64_t)(uintptr_t)done, (uint64_t)(uintptr_t)zs, (uint64_t)out_stride};
+        hipGraphExec_t exec = nullptr;
+        for (auto& ge : h->graphs)
+            if (ge.key == key) { exec = ge.exec; break; }
+        if (!exec) {
+            hipGraph_t g = nullptr;
+            if (!h->cap_stream) HIP_TRY(hipStreamCreateWithFlags(&h->cap_stream, hipStreamNonBlocking));
+            hipStream_t launch_stream = h->stream;
+            h->stream = h->cap_stream;
+            hipError_t ce = hipStreamBeginCapture(h->cap_stream, hipStreamCaptureModeThreadLocal);
+            if (ce == hipSuccess) {
+                enqueue_many_autoreset(h, ticks, fmt, a, b, seed, counter_dev, obs, reward, done, zs, out_stride);
+                ce = hipStreamEndCapture(h->cap_stream, &g);
+            }
+            h->stream = launch_stream;
+            if (ce != hipSuccess) return fail(Q1ENV_ERR_HIP, std::string("graph capture: ") + hipGetErrorString(ce));
+            hipError_t e = hipGraphInstantiate(&exec, g, nullptr, nullptr, 0);
+            (void)hipGraphDestroy(g);
+            if (e != hipSuccess) return fail(Q1ENV_ERR_HIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(e));
+            if (h->graphs.size() >= 8) {
+                (void)hipGraphExecDestroy(h->graphs.front().exec);
+                h->graphs.erase(h->graphs.begin());
+            }
+            h->graphs.push_back({key, exec});
+        }
+        if (use_graph == 2) {
+            (void)hipGraphUpload(exec, h->stream);
+            return Q1ENV_OK;
+        }
+        HIP_TRY(hipGraphLaunch(exec, h->stream));
+    }
+    h->tick_count += (uint64_t)ticks;
     return Q1ENV_OK;
 }
 

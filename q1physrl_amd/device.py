@@ -178,6 +178,13 @@ class DeviceEnv:
         _lib.check(self._lib.q1env_step_autoreset(self._h, action_format, act_a or None, act_b or None, int(seed), counter_dev or None,
                                                   obs or None, reward or None, done or None, zero_start or None))
 
+    def step_autoreset_many_dev(self, ticks, action_format, act_a, act_b, seed, counter_dev, obs=0, reward=0, done=0, zero_start=0,
+                                out_stride_ticks=0, use_graph=True):
+        """`ticks` auto-reset ticks (one launch each + one counter node) from a cached hipGraph (q1env_step_autoreset_many)."""
+        _lib.check(self._lib.q1env_step_autoreset_many(self._h, int(ticks), action_format, act_a or None, act_b or None, int(seed), counter_dev,
+                                                       obs or None, reward or None, done or None, zero_start or None, int(out_stride_ticks),
+                                                       int(use_graph)))
+
     def step_many_dev(self, ticks, action_format, act_a, act_b=0, obs_format=_lib.OBS_F32, obs=0, reward=0, done=0,
                       out_stride_ticks=0, use_graph=True):
         _lib.check(self._lib.q1env_step_many(self._h, ticks, action_format, act_a or None, act_b or None, obs_format,

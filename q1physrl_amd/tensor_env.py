@@ -93,9 +93,24 @@ class TensorVectorEnv:
                                      self.zero_start.data_ptr())
         return self.obs, self.reward, self.done
 
-    def step_many(self, actions, ticks: int, outputs: bool = False, use_graph: bool = True):
-        """`ticks` single-tick launches over tick-major actions; outputs=True returns tick-major (T,N,..) tensors."""
+    def step_many(self, actions, ticks: int, outputs: bool = False, use_graph: bool = True, auto_reset: bool = False):
+        """`ticks` single-tick launches over tick-major actions; outputs=True returns tick-major (T,N,..) tensors.
+        auto_reset=True: every tick also resets, in-kernel, the envs it finished (q1env_step_autoreset_many; the Philox counter
+        lives in self.reset_counter, a device int64 advanced by the graph itself)."""
         fmt, a, b = self._act_ptrs(actions, (ticks, self.num_envs))
+        if auto_reset:
+            if not hasattr(self, "reset_counter"):
+                self.reset_counter = torch.zeros((1,), dtype=torch.int64, device=self.device)
+            n = self.num_envs
+            if outputs:
+                obs = torch.empty((ticks, n, 6), dtype=torch.float32, device=self.device)
+                rew = torch.empty((ticks, n), dtype=torch.float32, device=self.device)
+                done = torch.empty((ticks, n), dtype=torch.uint8, device=self.device)
+            else:
+                obs, rew, done = self.obs, self.reward, self.done
+            self._dev.step_autoreset_many_dev(ticks, fmt, a, b, self.seed, self.reset_counter.data_ptr(), obs.data_ptr(), rew.data_ptr(),
+                                              done.data_ptr(), self.zero_start.data_ptr() if not outputs else 0, int(outputs), use_graph)
+            return obs, rew, done
         if outputs:
             n = self.num_envs
             obs = torch.empty((ticks, n, 6), dtype=torch.float32, device=self.device)

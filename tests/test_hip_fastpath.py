@@ -478,3 +478,40 @@ def test_step_autoreset_equals_step_then_reset_done(variant):
     for k in sa:
         assert np.array_equal(sa[k], sb[k]), k
     a.close(); b.close()
+
+
+@pytest.mark.parametrize("n,use_graph", [(4096 + 19, True), (4096 + 19, False), (65536, True)])
+def test_step_autoreset_many_equals_single_launches(n, use_graph):
+    """q1env_step_autoreset_many: T auto-reset ticks + one counter node, replayed from a cached hipGraph.  Two replays (the second
+    draws fresh reset randomness: the Philox counter lives on the device and the graph advances it) equal 2 T single
+    q1env_step_autoreset launches driven with the same device counter, tick-major outputs included."""
+    torch = torch_mod()
+    from q1physrl_amd import _lib
+    from q1physrl_amd.tensor_env import TensorVectorEnv
+    from q1physrl_amd.env import Config
+    T = 150
+    cfg = O.OracleConfig.get_default(num_envs=n, zero_start_prob=0.3, time_limit=0.6)
+    a = TensorVectorEnv(Config(**cfg.__dict__), seed=11)
+    b = TensorVectorEnv(Config(**cfg.__dict__), seed=11)
+    a.reset(); b.reset()
+    g = torch.Generator(device="cuda").manual_seed(1)
+    keys = torch.randint(0, 16, (T, n), dtype=torch.uint8, device="cuda", generator=g)
+    mouse = ((torch.rand((T, n), device="cuda", generator=g) * 2 - 1) * 10).contiguous()
+    cnt_b = torch.zeros((1,), dtype=torch.int64, device="cuda")
+    outs = []
+    for rep in range(2):
+        obs, rew, done = a.step_many((keys, mouse), T, outputs=True, use_graph=use_graph, auto_reset=True)
+        outs.append((obs.clone(), rew.clone(), done.clone()))
+    assert int(a.reset_counter.item()) == 2 * T
+    for rep in range(2):
+        for t in range(T):
+            b._dev.step_autoreset_dev(_lib.ACT_PACKED, keys[t].data_ptr(), mouse[t].data_ptr(), 11, b.obs.data_ptr(), b.reward.data_ptr(),
+                                      b.done.data_ptr(), b.zero_start.data_ptr(), counter_dev=cnt_b.data_ptr())
+            cnt_b.add_(1)
+            assert torch.equal(outs[rep][0][t], b.obs) and torch.equal(outs[rep][1][t], b.reward) and torch.equal(outs[rep][2][t], b.done), (rep, t)
+    torch.cuda.synchronize()
+    sa, sb = a.get_state(), b.get_state()
+    for k in sa:
+        assert np.array_equal(sa[k], sb[k]), k
+    assert outs[0][2].sum() > n and not torch.equal(outs[0][0][-1], outs[1][0][-1])     # episodes ended; the replays differ
+    a.close(); b.close()

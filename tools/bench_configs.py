@@ -58,6 +58,8 @@ def main():
     torch.cuda.synchronize()
     ms = timed(env, g.replay, 3)
     print(f"C3 {n} envs full Config: step with in-kernel reset, 1 launch/tick (+1 counter op), graph replay: {ms*1e3/T:8.2f} us/tick  {n*T/ms/1e6:8.2f} G env-steps/s")
+    ms = timed(env, lambda: env.step_many((keys, mouse), T, auto_reset=True), 3)
+    print(f"C3 {n} envs full Config: q1env_step_autoreset_many (1 launch/tick, one counter node per {T} ticks), graph replay: {ms*1e3/T:8.2f} us/tick  {n*T/ms/1e6:8.2f} G env-steps/s")
     obs = torch.empty((T, n, 6), dtype=torch.float32, device="cuda"); rew = torch.empty((T, n), device="cuda"); done = torch.empty((T, n), dtype=torch.uint8, device="cuda")
     def fused():
         env._dev.rollout_dev(T, _lib.ACT_PACKED, keys.data_ptr(), mouse.data_ptr(), 3, _lib.OBS_F32, obs.data_ptr(), rew.data_ptr(), done.data_ptr(), True, 0)
