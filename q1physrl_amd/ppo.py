@@ -64,7 +64,7 @@ class PPOLearner:
     def __init__(self, policy, action_range, lr=5e-6, gamma=0.99, lam=0.95, clip_param=0.3, vf_clip_param=100.0,
                  vf_loss_coeff=1.0, entropy_coeff=0.01, kl_coeff=0.2, kl_target=0.0036, num_sgd_iter=30,
                  minibatch_size=128, num_keys=4, seed=0, use_graph=False, fused_loss=False, env=None, discrete_yaw_steps=-1,
-                 allow_yaw=True, gemm_dtype=None, grad_scale=4096.0):
+                 allow_yaw=True):
         self.policy = policy
         self.action_range = float(action_range)
         self.gamma, self.lam = gamma, lam
@@ -73,13 +73,6 @@ class PPOLearner:
         self.kl_coeff, self.kl_target = kl_coeff, kl_target
         self.num_sgd_iter, self.minibatch_size, self.num_keys = num_sgd_iter, minibatch_size, num_keys
         self.discrete_yaw_steps, self.allow_yaw = discrete_yaw_steps, allow_yaw
-        # gemm_dtype = torch.float16 / bfloat16: the two MLPs' GEMMs (forward, input- and weight-gradients) run with 16-bit operands
-        # and float32 accumulation (torch.autocast) on float32 master weights; the gradient leaving the loss is multiplied by
-        # grad_scale before it enters the 16-bit backward (a 1/batch-scaled PPO gradient underflows float16) and divided out of
-        # the float32 parameter gradients before Adam.  Needs fused_loss (the loss itself stays float32 in the kernel).
-        self.gemm_dtype, self.grad_scale = gemm_dtype, float(grad_scale)
-        if gemm_dtype is not None and not fused_loss:
-            raise ValueError("gemm_dtype needs fused_loss=True")
         self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
         self.use_graph = bool(use_graph) and self.world == 1
         self.fused_loss, self.env = bool(fused_loss), env
@@ -102,12 +95,7 @@ class PPOLearner:
     def _sgd_step(self, mb):
         """One minibatch: forward, loss, backward, (gradient all-reduce,) Adam.  Returns the stats vector (STAT_KEYS order)."""
         if self.fused_loss:
-            if self.gemm_dtype is not None:
-                with torch.autocast("cuda", dtype=self.gemm_dtype):
-                    lg16, v16 = self.policy(mb["obs"])
-                logits, value = lg16.float().contiguous(), v16.float().contiguous()     # the loss kernel reads float32 (casts are differentiable)
-            else:
-                logits, value = self.policy(mb["obs"])
+            logits, value = self.policy(mb["obs"])
             bsz, width = logits.shape
             if self._work is None or self._work[0].shape != logits.shape:
                 dev = logits.device
@@ -121,11 +109,7 @@ class PPOLearner:
                                             self.vf_loss_coeff, self.entropy_coeff, self._klc.data_ptr(), dlogits.data_ptr(),
                                             dvalue.data_ptr(), partials.data_ptr())
             self.opt.zero_grad(set_to_none=True)
-            if self.gemm_dtype is not None:
-                torch.autograd.backward([logits, value], [dlogits * self.grad_scale, dvalue * self.grad_scale])
-                torch._foreach_mul_([p.grad for p in self.policy.parameters()], 1.0 / self.grad_scale)
-            else:
-                torch.autograd.backward([logits, value], [dlogits, dvalue])
+            torch.autograd.backward([logits, value], [dlogits, dvalue])
             stats = partials.sum(dim=0) / bsz
         else:
             loss, st = ppo_loss(self.policy, mb, self.action_range, self.clip_param, self.vf_clip_param, self.vf_loss_coeff,

@@ -36,7 +36,6 @@ ap.add_argument("--no-graph", action="store_true")
 ap.add_argument("--fused-policy", action="store_true", help="sample with the fused MFMA forward kernel (bf16 hidden layer)")
 ap.add_argument("--fused-loss", action="store_true", help="PPO loss + gradient from the q1env_ppo_loss_grad kernel")
 ap.add_argument("--save", default="", help="write the final policy weights (npz, RLlib fcnet naming) here")
-ap.add_argument("--learner-gemm", choices=("f32", "f16", "bf16"), default="f32", help="operand dtype of the learner's MLP GEMMs (autocast on float32 master weights)")
 ap.add_argument("--discrete-yaw-steps", type=int, default=-1, help="Config.discrete_yaw_steps: the mouse becomes Discrete(2S+1) (a Categorical policy head)")
 args = ap.parse_args()
 
@@ -55,8 +54,7 @@ fused = P.FusedPolicyForward(pol, env) if args.fused_policy else None
 smp = GpuSampler(env, fused if fused is not None else pol, horizon=args.horizon, use_graph=not args.no_graph)
 lrn = ppo.PPOLearner(pol, float(cfg.action_range), lr=args.lr, num_sgd_iter=args.epochs, minibatch_size=args.minibatch,
                      entropy_coeff=args.entropy, kl_target=args.kl_target, seed=args.seed + rank, use_graph=not args.no_graph, fused_loss=args.fused_loss, env=env,
-                     discrete_yaw_steps=args.discrete_yaw_steps,
-                     gemm_dtype={"f32": None, "f16": torch.float16, "bf16": torch.bfloat16}[args.learner_gemm])
+                     discrete_yaw_steps=args.discrete_yaw_steps)
 log = []
 t0 = time.time()
 prev = smp.stats
