@@ -326,8 +326,10 @@ int q1env_episode_stats(q1env_t* env, const float* reward_dev, const uint8_t* do
  * status uint32[5], ACCUMULATED by the kernels and written ONLY on failure (all zero = every wave served / handed over every tick;
  * zero it before a launch to read that launch alone): [0] += server waves that did not serve every tick, [1] |= 1 when a server
  * wave timed out waiting for an action, [2] = max ticks a server wave left unserved, [3] |= 1 when a driver wave timed out,
- * [4] = max actions a driver wave did not hand over.  Every wait is bounded by timeout_s (of no progress): a missing producer ends the launch with status[1] set and the state
- * of the last completed tick stored - it never hangs the device.  num_envs <= CUs * 2048 (the grid must be resident at once).
+ * [4] = max actions a driver wave did not hand over.  Every wait is bounded by timeout_s (of no progress): a missing producer
+ * ends the launch with status[1] set and the state of the last completed tick stored - it never hangs the device.  The server's
+ * grid must be resident at once AND leave room for its producer's waves: num_envs is checked against the kernel's occupancy
+ * (131 072 envs for _start, 98 304 for _pair on an MI355X); larger batches are refused with Q1ENV_ERR_INVALID_ARG.
  * _start launches the server on the handle's stream (asynchronous; wait with q1env_sync).  _drive launches the reference
  * producer on `producer_stream` (a hipStream_t other than the handle's): a DEPENDENT driver - what a policy is to the env - that
  * hands tick t+1's action (from tick-major packed arrays keys uint8[T][N], mouse float[T][N]) over only after all result
