@@ -328,8 +328,9 @@ int q1env_episode_stats(q1env_t* env, const float* reward_dev, const uint8_t* do
  * wave timed out waiting for an action, [2] = max ticks a server wave left unserved, [3] |= 1 when a driver wave timed out,
  * [4] = max actions a driver wave did not hand over.  Every wait is bounded by timeout_s (of no progress): a missing producer
  * ends the launch with status[1] set and the state of the last completed tick stored - it never hangs the device.  The server's
- * grid must be resident at once AND leave room for its producer's waves: num_envs is checked against the kernel's occupancy
- * (131 072 envs for _start, 98 304 for _pair on an MI355X); larger batches are refused with Q1ENV_ERR_INVALID_ARG.
+ * grid must be resident at once AND leave room for its producer's waves: a wave serves 1, 2 or 4 sub-batches of 64 envs (the
+ * smallest count whose grid fits the kernel's occupancy; external producers never see it - mailbox and results are indexed by
+ * env); batches beyond that (262 144 envs on an MI355X) are refused with Q1ENV_ERR_INVALID_ARG.
  * _start launches the server on the handle's stream (asynchronous; wait with q1env_sync).  _drive launches the reference
  * producer on `producer_stream` (a hipStream_t other than the handle's): a DEPENDENT driver - what a policy is to the env - that
  * hands tick t+1's action (from tick-major packed arrays keys uint8[T][N], mouse float[T][N]) over only after all result

@@ -792,8 +792,8 @@ struct q1env {
     uint64_t tick_count = 0;          // ticks since create: the counter of the counter-based RNG
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     int num_cus = 256;                // compute units of the device (MI355X in SPX mode: 256)
-    int server_blocks_per_cu = -1;    // occupancy of the resident tick server (queried once)
-    int pair_blocks_per_cu = -1;      // ... and of the server + driver pair kernel
+    int server_blocks_per_cu[3] = {-1, -1, -1};   // occupancy of the resident tick server at 1/2/4 envs per lane (queried once)
+    int pair_blocks_per_cu[3] = {-1, -1, -1};     // ... and of the server + driver pair kernel
     bool mlp_attr_set = false;        // dynamic-LDS attribute of the policy kernels (a per-device setting: kept per handle)
     // cached hipGraphs of step_many, keyed by (ticks, formats, pointers); a handful of entries, oldest evicted
     struct GraphEntry { std::vector<uint64_t> key; hipGraphExec_t exec; };
@@ -1753,35 +1753,74 @@ static Backoff server_backoff() {
     return bo;
 }
 
+// Envs per lane of the resident grid (E in {1, 2, 4}, index e = log2 E): the smallest that makes the whole grid resident (at 8 the
+// server needs 416 VGPRs and spills: one wave per SIMD, no more envs resident than at 4).
+// A kernel instance per (SPEC, E); the switch keeps every launch a direct call.
+#define Q1_FOR_E(e_idx, CALL)          \
+    switch (e_idx) {                   \
+        case 0: { CALL(1); } break;    \
+        case 1: { CALL(2); } break;    \
+        default: { CALL(4); } break;   \
+    }
+
+extern "C++" {
+template <int E> static const void* server_fn(bool spec) { return spec ? (const void*)tick_server_kernel<true, E> : (const void*)tick_server_kernel<false, E>; }
+template <int E> static const void* pair_fn(bool spec) { return spec ? (const void*)tick_pair_kernel<true, E> : (const void*)tick_pair_kernel<false, E>; }
+}
+
+static int resident_blocks_per_cu(q1env_t* h, bool pair, int e_idx, int* out) {
+    int& slot = pair ? h->pair_blocks_per_cu[e_idx] : h->server_blocks_per_cu[e_idx];
+    if (slot < 0) {
+        const void* fn = nullptr;
+        const bool spec = is_spec(h->p);
+#define Q1_FN(E) fn = pair ? pair_fn<E>(spec) : server_fn<E>(spec)
+        Q1_FOR_E(e_idx, Q1_FN)
+#undef Q1_FN
+        int per_cu = 0;
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 64, 0));
+        slot = per_cu;
+    }
+    *out = slot;
+    return Q1ENV_OK;
+}
+
+// Server on its own stream (an external producer next to it): the whole grid must be resident at once - a wave that is not
+// scheduled never polls - AND leave room for the producer's waves on every SIMD (a server that fills the register file starves
+// the producer it waits for: both would only time out).  start and drive call this with the same handle, so they agree on E.
+static int server_envs_per_lane(q1env_t* h, const char* who, int* e_idx_out) {
+    long best = 0;
+    for (int e = 0; e < 3; ++e) {
+        int per_cu = 0;
+        if (int rc = resident_blocks_per_cu(h, false, e, &per_cu)) return rc;
+        const long max_envs = (long)h->num_cus * (per_cu > 4 ? per_cu - 4 : 0) * 64 * (1L << e);
+        if ((long)h->p.n <= max_envs) { *e_idx_out = e; return Q1ENV_OK; }
+        if (max_envs > best) best = max_envs;
+    }
+    return fail(Q1ENV_ERR_INVALID_ARG, std::string(who) + ": too many envs for one resident grid next to its producer (" +
+                                       std::to_string(best) + " at most on this device)");
+}
+
 int q1env_step_persistent_start(q1env_t* h, int ticks, uint32_t tag0, const uint64_t* mailbox_dev, uint64_t* results_dev,
                                 float* obs_final_dev, uint64_t seed, int auto_reset, uint32_t* status_dev, double timeout_s) {
     if (!h || !mailbox_dev || !results_dev || !status_dev) return fail(Q1ENV_ERR_INVALID_ARG, "q1env_step_persistent_start: null argument");
     if (ticks <= 0) return fail(Q1ENV_ERR_INVALID_ARG, "q1env_step_persistent_start: ticks must be > 0");
     if (!(timeout_s > 0.0) || timeout_s > 30.0) return fail(Q1ENV_ERR_INVALID_ARG, "q1env_step_persistent_start: timeout_s must be in (0, 30]");
-    // The whole grid must be resident at once - a wave that is not scheduled never polls - AND leave room for the producer's waves
-    // on every SIMD (a server that fills the register file starves the producer it waits for: both would only time out).
-    DeviceGuard guard_occ(h->device);
-    if (h->server_blocks_per_cu < 0) {
-        int per_cu = 0;
-        const void* fn = is_spec(h->p) ? (const void*)tick_server_kernel<true> : (const void*)tick_server_kernel<false>;
-        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 64, 0));
-        h->server_blocks_per_cu = per_cu;
-    }
-    const int per_cu = h->server_blocks_per_cu;
-    const long max_envs = (long)h->num_cus * (per_cu > 4 ? per_cu - 4 : 0) * 64;
-    if ((long)h->p.n > max_envs)
-        return fail(Q1ENV_ERR_INVALID_ARG, "q1env_step_persistent_start: too many envs for one resident grid next to its producer (" +
-                                           std::to_string(max_envs) + " at most on this device)");
     if (h->p.yaw_mode == 2 && h->p.yaw_steps > 8388608.0) return fail(Q1ENV_ERR_INVALID_ARG, "q1env_step_persistent_start: step index does not fit the granule");
     DeviceGuard guard(h->device);
-    const dim3 g(((unsigned)h->p.n + 63u) / 64u), b(64);
+    int e_idx = 0;
+    if (int rc = server_envs_per_lane(h, "q1env_step_persistent_start", &e_idx)) return rc;
+    const unsigned per_block = 64u << e_idx;
+    const dim3 g(((unsigned)h->p.n + per_block - 1u) / per_block), b(64);
     const uint64_t timeout_ticks = (uint64_t)(timeout_s * 1.0e8);          // wall_clock64: 100 MHz
-    if (is_spec(h->p))
-        hipLaunchKernelGGL(tick_server_kernel<true>, g, b, 0, h->stream, h->p, h->st, ticks, tag0, mailbox_dev, results_dev, obs_final_dev, seed,
-                           h->tick_count, auto_reset, status_dev, timeout_ticks, server_backoff());
-    else
-        hipLaunchKernelGGL(tick_server_kernel<false>, g, b, 0, h->stream, h->p, h->st, ticks, tag0, mailbox_dev, results_dev, obs_final_dev, seed,
-                           h->tick_count, auto_reset, status_dev, timeout_ticks, server_backoff());
+#define Q1_LAUNCH(E)                                                                                                                    \
+    if (is_spec(h->p))                                                                                                                  \
+        hipLaunchKernelGGL((tick_server_kernel<true, E>), g, b, 0, h->stream, h->p, h->st, ticks, tag0, mailbox_dev, results_dev,       \
+                           obs_final_dev, seed, h->tick_count, auto_reset, status_dev, timeout_ticks, server_backoff());                \
+    else                                                                                                                                \
+        hipLaunchKernelGGL((tick_server_kernel<false, E>), g, b, 0, h->stream, h->p, h->st, ticks, tag0, mailbox_dev, results_dev,      \
+                           obs_final_dev, seed, h->tick_count, auto_reset, status_dev, timeout_ticks, server_backoff())
+    Q1_FOR_E(e_idx, Q1_LAUNCH)
+#undef Q1_LAUNCH
     HIP_TRY(hipGetLastError());
     h->tick_count += (uint64_t)ticks;
     return Q1ENV_OK;
@@ -1795,9 +1834,15 @@ int q1env_step_persistent_drive(q1env_t* h, void* producer_stream, int ticks, ui
     if ((hipStream_t)producer_stream == h->stream) return fail(Q1ENV_ERR_INVALID_ARG, "q1env_step_persistent_drive: the producer must run on another stream than the server");
     if (ticks <= 0 || !(timeout_s > 0.0) || timeout_s > 30.0) return fail(Q1ENV_ERR_INVALID_ARG, "q1env_step_persistent_drive: bad ticks / timeout_s");
     DeviceGuard guard(h->device);
-    const dim3 g(((unsigned)h->p.n + 63u) / 64u), b(64);
-    hipLaunchKernelGGL(tick_driver_kernel, g, b, 0, (hipStream_t)producer_stream, h->p.n, ticks, tag0, keys_dev, mouse_dev, mailbox_dev,
-                       results_dev, checksum_dev, status_dev, (uint64_t)(timeout_s * 1.0e8), server_backoff());
+    int e_idx = 0;
+    if (int rc = server_envs_per_lane(h, "q1env_step_persistent_drive", &e_idx)) return rc;
+    const unsigned per_block = 64u << e_idx;
+    const dim3 g(((unsigned)h->p.n + per_block - 1u) / per_block), b(64);
+#define Q1_LAUNCH(E)                                                                                                                 \
+    hipLaunchKernelGGL((tick_driver_kernel<E>), g, b, 0, (hipStream_t)producer_stream, h->p.n, ticks, tag0, keys_dev, mouse_dev,     \
+                       mailbox_dev, results_dev, checksum_dev, status_dev, (uint64_t)(timeout_s * 1.0e8), server_backoff())
+    Q1_FOR_E(e_idx, Q1_LAUNCH)
+#undef Q1_LAUNCH
     HIP_TRY(hipGetLastError());
     return Q1ENV_OK;
 }
@@ -1834,28 +1879,37 @@ int q1env_step_persistent_pair(q1env_t* h, int ticks, uint32_t tag0, const uint8
         return fail(Q1ENV_ERR_INVALID_ARG, "q1env_step_persistent_pair: null argument");
     if (ticks <= 0 || !(timeout_s > 0.0) || timeout_s > 30.0) return fail(Q1ENV_ERR_INVALID_ARG, "q1env_step_persistent_pair: bad ticks / timeout_s");
     DeviceGuard guard(h->device);
-    if (h->pair_blocks_per_cu < 0) {
+    // one dispatch of server + driver waves: co-resident iff the grid fits the device (smallest envs-per-lane that does)
+    int e_idx = -1;
+    long best = 0;
+    for (int e = 0; e < 3 && e_idx < 0; ++e) {
         int per_cu = 0;
-        const void* fn = is_spec(h->p) ? (const void*)tick_pair_kernel<true> : (const void*)tick_pair_kernel<false>;
-        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 64, 0));
-        h->pair_blocks_per_cu = per_cu;
+        if (int rc = resident_blocks_per_cu(h, true, e, &per_cu)) return rc;
+        const long max_envs = (long)h->num_cus * per_cu / 2 * 64 * (1L << e);
+        if ((long)h->p.n <= max_envs) e_idx = e;
+        if (max_envs > best) best = max_envs;
     }
-    const unsigned blocks = ((unsigned)h->p.n + 63u) / 64u;
-    const long resident = (long)h->num_cus * h->pair_blocks_per_cu;
-    if (2L * blocks > resident)
-        return fail(Q1ENV_ERR_INVALID_ARG, "q1env_step_persistent_pair: too many envs for one resident grid (" +
-                                           std::to_string(resident / 2 * 64) + " at most on this device)");
+    if (e_idx < 0)
+        return fail(Q1ENV_ERR_INVALID_ARG, "q1env_step_persistent_pair: too many envs for one resident grid (" + std::to_string(best) +
+                                           " at most on this device)");
+    const unsigned per_block = 64u << e_idx;
+    const unsigned blocks = ((unsigned)h->p.n + per_block - 1u) / per_block;
     const uint64_t timeout_ticks = (uint64_t)(timeout_s * 1.0e8);
     const dim3 g(2u * blocks), b(64);
     const bool t_start = (auto_reset & Q1ENV_TIMER_START) != 0, t_stop = (auto_reset & Q1ENV_TIMER_STOP) != 0;
     auto_reset &= 1;
     if (t_start) HIP_TRY(hipEventRecord(h->ev0, h->stream));
-    if (is_spec(h->p))
-        hipLaunchKernelGGL(tick_pair_kernel<true>, g, b, 0, h->stream, h->p, h->st, ticks, tag0, mailbox_dev, results_dev, obs_final_dev, seed,
-                           h->tick_count, auto_reset, keys_dev, mouse_dev, checksum_dev, status_dev, timeout_ticks, server_backoff());
-    else
-        hipLaunchKernelGGL(tick_pair_kernel<false>, g, b, 0, h->stream, h->p, h->st, ticks, tag0, mailbox_dev, results_dev, obs_final_dev, seed,
-                           h->tick_count, auto_reset, keys_dev, mouse_dev, checksum_dev, status_dev, timeout_ticks, server_backoff());
+#define Q1_LAUNCH(E)                                                                                                                     \
+    if (is_spec(h->p))                                                                                                                   \
+        hipLaunchKernelGGL((tick_pair_kernel<true, E>), g, b, 0, h->stream, h->p, h->st, ticks, tag0, mailbox_dev, results_dev,          \
+                           obs_final_dev, seed, h->tick_count, auto_reset, keys_dev, mouse_dev, checksum_dev, status_dev, timeout_ticks, \
+                           server_backoff());                                                                                            \
+    else                                                                                                                                 \
+        hipLaunchKernelGGL((tick_pair_kernel<false, E>), g, b, 0, h->stream, h->p, h->st, ticks, tag0, mailbox_dev, results_dev,         \
+                           obs_final_dev, seed, h->tick_count, auto_reset, keys_dev, mouse_dev, checksum_dev, status_dev, timeout_ticks, \
+                           server_backoff())
+    Q1_FOR_E(e_idx, Q1_LAUNCH)
+#undef Q1_LAUNCH
     HIP_TRY(hipGetLastError());
     if (t_stop) HIP_TRY(hipEventRecord(h->ev1, h->stream));
     h->tick_count += (uint64_t)ticks;

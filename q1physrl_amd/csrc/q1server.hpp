@@ -82,69 +82,95 @@ __device__ __forceinline__ uint64_t* pair_ptr(const uint64_t* results, uint32_t 
     return const_cast<uint64_t*>(results) + ((size_t)q * n + i) * 2u;
 }
 
-template <bool SPEC>
+// One bounded wait of a wave on one granule set: `probe` loads and validates the lane's granules (returns true when its tag has
+// arrived); the load's own latency paces the loop, and the 100 MHz clock is only consulted every 256 failed polls (no
+// s_memrealtime on the path of a tick that is served promptly) - the timeout counts from the first such look.
+template <typename Probe>
+__device__ __forceinline__ bool wait_for(bool live, uint64_t timeout_ticks, const Backoff& bo, Probe probe) {
+    bool ok = !live;
+    uint32_t polls = 0;
+    uint64_t t_wait = 0;
+    for (;;) {
+        if (!ok) ok = probe();
+        if (__all(ok)) return true;
+        nap(bo.between);
+        if ((++polls & 255u) == 0u) {
+            const uint64_t now = wall_clock64();
+            if (t_wait == 0) t_wait = now;
+            else if (now - t_wait > timeout_ticks) return false;
+            __builtin_amdgcn_s_sleep(8);
+        }
+    }
+}
+
+// E = envs per lane.  A wave serves E sub-batches of 64 consecutive envs (env = (block * E + e) * 64 + lane), each an independent
+// hand-off stream served in order e = 0 .. E-1 within a tick: while the server computes sub-batch e, the producer's hand-off for
+// e + 1 is already in flight - so a batch that would not be resident at one env per lane (more than ~100 k envs next to a
+// producer) still runs as ONE resident grid, at E x the arithmetic per wave and the same two hops per tick.
+template <bool SPEC, int E>
 __device__ __forceinline__ void tick_server_body(const Params& p, const StatePtrs& s, uint32_t block, int ticks, uint32_t tag0,
                                                  const uint64_t* mailbox, uint64_t* results, float* obs_final, uint64_t seed,
                                                  uint64_t counter0, int auto_reset, uint32_t* status, uint64_t timeout_ticks,
                                                  Backoff bo) {
-    const uint32_t lane = threadIdx.x, i = block * 64u + lane, n = (uint32_t)p.n;
-    const bool live = i < n;
-    const uint64_t genv = (uint64_t)p.env_index_base + (uint64_t)i;
-    Env e{};
-    if (live) load_env(s, n, i, e);
+    const uint32_t lane = threadIdx.x, n = (uint32_t)p.n;
+    uint32_t idx[E];
+    bool live[E];
+    Env env[E];
+    float last_obs[E][6];
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        idx[e] = (block * (uint32_t)E + (uint32_t)e) * 64u + lane;
+        live[e] = idx[e] < n;
+        env[e] = Env{};
+        if (live[e]) load_env(s, n, idx[e], env[e]);
+#pragma unroll
+        for (int j = 0; j < 6; ++j) last_obs[e][j] = 0.0f;
+    }
     int completed = 0;
     bool timed_out = false;
-    TickOut<float> o;
-    o.reward = 0.0f; o.done = false;
-#pragma unroll
-    for (int j = 0; j < 6; ++j) o.obs[j] = 0.0f;
-    for (int t = 0; t < ticks; ++t) {
+    for (int t = 0; t < ticks && !timed_out; ++t) {
         const uint64_t tag = tick_tag(tag0, (uint32_t)t);
-        uint64_t g = 0;
-        bool ok = !live;
-        uint32_t polls = 0;
-        uint64_t t_wait = 0;
         if (t > 0) nap(bo.first_server);
-        for (;;) {                                    // every lane polls its own granule: one contiguous 512-B sc1 read per wave
-            if (!ok) {
-                g = granule_load(mailbox + i);
-                ok = (g >> 40) == tag;
-            }
-            if (__all(ok)) break;
-            nap(bo.between);
-            // the load's own latency paces the loop; the 100 MHz clock is only consulted every 256 failed polls (no s_memrealtime
-            // on the path of a tick that is served promptly), the timeout counts from the first such look
-            if ((++polls & 255u) == 0u) {
-                const uint64_t now = wall_clock64();
-                if (t_wait == 0) t_wait = now;
-                else if (now - t_wait > timeout_ticks) { timed_out = true; break; }
-                __builtin_amdgcn_s_sleep(8);
-            }
-        }
-        if (timed_out) break;
-        if (live) {
-            const uint32_t keys = (uint32_t)(g >> 32) & ((1u << cfg_num_keys<SPEC>(p)) - 1u);
-            const double yaw_act = cfg_yaw_mode<SPEC>(p) ? (double)__uint_as_float((uint32_t)g) : 0.0;
-            tick<float, SPEC>(p, e, keys, yaw_act, o);
-            const bool zs = (e.flags & FLAG_ZERO_START) != 0;                       // of the episode the step belonged to
-            if (auto_reset && o.done) {
-                reset_philox(p, e, seed, genv, counter0 + (uint64_t)t + 1);
-                observe<float>(p, e, o.obs);
-            }
-            const uint64_t hi = tag << 40;
-            const uint64_t last = hi | ((uint64_t)(zs ? 1u : 0u) << 33) | ((uint64_t)(o.done ? 1u : 0u) << 32) | (uint64_t)__float_as_uint(o.reward);
 #pragma unroll
-            for (uint32_t q = 0; q < 3u; ++q)
-                granule_pair_store(pair_ptr(results, n, q, i), hi | (uint64_t)__float_as_uint(o.obs[2 * q]),
-                                   hi | (uint64_t)__float_as_uint(o.obs[2 * q + 1]));
-            granule_pair_store(pair_ptr(results, n, 3u, i), last, hi);          // granule 7 is padding: tag only
+        for (int e = 0; e < E; ++e) {
+            const uint32_t i = idx[e];
+            uint64_t g = 0;
+            // every lane polls its own granule: one contiguous 512-B sc1 read per wave
+            if (!wait_for(live[e], timeout_ticks, bo, [&] { g = granule_load(mailbox + i); return (g >> 40) == tag; })) {
+                timed_out = true;
+                break;
+            }
+            if (live[e]) {
+                const uint32_t keys = (uint32_t)(g >> 32) & ((1u << cfg_num_keys<SPEC>(p)) - 1u);
+                const double yaw_act = cfg_yaw_mode<SPEC>(p) ? (double)__uint_as_float((uint32_t)g) : 0.0;
+                TickOut<float> o;
+                tick<float, SPEC>(p, env[e], keys, yaw_act, o);
+                const bool zs = (env[e].flags & FLAG_ZERO_START) != 0;                  // of the episode the step belonged to
+                if (auto_reset && o.done) {
+                    reset_philox(p, env[e], seed, (uint64_t)p.env_index_base + (uint64_t)i, counter0 + (uint64_t)t + 1);
+                    observe<float>(p, env[e], o.obs);
+                }
+                const uint64_t hi = tag << 40;
+                const uint64_t last = hi | ((uint64_t)(zs ? 1u : 0u) << 33) | ((uint64_t)(o.done ? 1u : 0u) << 32) | (uint64_t)__float_as_uint(o.reward);
+#pragma unroll
+                for (uint32_t q = 0; q < 3u; ++q)
+                    granule_pair_store(pair_ptr(results, n, q, i), hi | (uint64_t)__float_as_uint(o.obs[2 * q]),
+                                       hi | (uint64_t)__float_as_uint(o.obs[2 * q + 1]));
+                granule_pair_store(pair_ptr(results, n, 3u, i), last, hi);      // granule 7 is padding: tag only
+#pragma unroll
+                for (int j = 0; j < 6; ++j) last_obs[e][j] = o.obs[j];
+            }
         }
-        completed = t + 1;
+        if (!timed_out) completed = t + 1;
     }
-    if (live) {
-        store_env(s, n, i, e);
-        if (obs_final && completed > 0) write_obs<float>(obs_final, (size_t)i, o.obs);    // plain row of the last served tick
-    }
+    // (a wave that timed out in the middle of a tick has served that tick for its first sub-batches only: their state is one tick
+    // ahead of the others' - reported through status, like every incomplete launch)
+#pragma unroll
+    for (int e = 0; e < E; ++e)
+        if (live[e]) {
+            store_env(s, n, idx[e], env[e]);
+            if (obs_final && completed > 0) write_obs<float>(obs_final, (size_t)idx[e], last_obs[e]);   // plain row of the last served tick
+        }
     if (lane == 0 && completed != ticks) {                       // nothing is written on the success path: thousands of waves ending
         atomicAdd(&status[0], 1u);                               // together would serialise ~12 ns per atomic on these five words
         if (timed_out) atomicOr(&status[1], 1u);
@@ -153,57 +179,59 @@ __device__ __forceinline__ void tick_server_body(const Params& p, const StatePtr
 }
 
 // The reference driver of the tick server: a DEPENDENT producer, i.e. what a policy is to the env - it hands tick t+1's action
-// over only after ALL SEVEN result granules of tick t of the same env have arrived (one poll round: the seven loads of a lane are
-// in flight together).  Actions come from a resident tick-major packed episode (keys uint8[T][N], mouse float[T][N]); checksum
+// over only after ALL result granules of tick t of the same env have arrived (one poll round: the four pair loads of a lane are in
+// flight together).  Actions come from a resident tick-major packed episode (keys uint8[T][N], mouse float[T][N]); checksum
 // (optional, double[2][N]) accumulates the rewards and the first observation column it received, so the data really makes the
-// round trip.  One lane per env, resident next to the server.
-__device__ __forceinline__ void tick_driver_body(int n, uint32_t block, int ticks, uint32_t tag0, const uint8_t* keys, const float* mouse,
+// round trip.  E envs per lane, sub-batch by sub-batch like the server; resident next to it.
+template <int E>
+__device__ __forceinline__ void tick_driver_body(int n_, uint32_t block, int ticks, uint32_t tag0, const uint8_t* keys, const float* mouse,
                                                  uint64_t* mailbox, const uint64_t* results, double* checksum, uint32_t* status,
                                                  uint64_t timeout_ticks, Backoff bo) {
-    const uint32_t lane = threadIdx.x, i = block * 64u + lane;
-    const bool live = i < (uint32_t)n;
-    double acc_r = 0.0, acc_o = 0.0;
+    const uint32_t lane = threadIdx.x, n = (uint32_t)n_;
+    uint32_t idx[E];
+    bool live[E];
+    double acc_r[E], acc_o[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        idx[e] = (block * (uint32_t)E + (uint32_t)e) * 64u + lane;
+        live[e] = idx[e] < n;
+        acc_r[e] = 0.0; acc_o[e] = 0.0;
+    }
     bool timed_out = false;
     int handed = 0;
-    for (int t = 0; t < ticks; ++t) {
-        // tick t's action is fetched before the wait: its latency hides under the server's tick
-        const uint32_t k = live ? keys[(size_t)t * n + i] : 0u;
-        const float m = live ? mouse[(size_t)t * n + i] : 0.0f;
-        if (t > 0) {
-            const uint64_t want = tick_tag(tag0, (uint32_t)t - 1u);      // results of tick t-1
-            uint64_t g[8];
-            bool ok = !live;
-            uint32_t polls = 0;
-            uint64_t t_wait = 0;
-            nap(bo.first_driver);
-            for (;;) {
-                if (!ok) {
-                    granule_pairs_load4(pair_ptr(results, (uint32_t)n, 0u, i), pair_ptr(results, (uint32_t)n, 1u, i),
-                                        pair_ptr(results, (uint32_t)n, 2u, i), pair_ptr(results, (uint32_t)n, 3u, i), g);
-                    ok = true;
+    for (int t = 0; t < ticks && !timed_out; ++t) {
 #pragma unroll
-                    for (int q = 0; q < RESULT_GRANULES; ++q) ok = ok && ((g[q] >> 40) == want);
-                }
-                if (__all(ok)) break;
-                nap(bo.between);
-                if ((++polls & 255u) == 0u) {
-                    const uint64_t now = wall_clock64();
-                    if (t_wait == 0) t_wait = now;
-                    else if (now - t_wait > timeout_ticks) { timed_out = true; break; }
-                    __builtin_amdgcn_s_sleep(8);
+        for (int e = 0; e < E; ++e) {
+            const uint32_t i = idx[e];
+            // tick t's action is fetched before the wait: its latency hides under the server's tick
+            const uint32_t k = live[e] ? keys[(size_t)t * n + i] : 0u;
+            const float m = live[e] ? mouse[(size_t)t * n + i] : 0.0f;
+            if (t > 0) {
+                const uint64_t want = tick_tag(tag0, (uint32_t)t - 1u);          // results of tick t-1
+                uint64_t g[8];
+                if (e == 0) nap(bo.first_driver);
+                const bool got = wait_for(live[e], timeout_ticks, bo, [&] {
+                    granule_pairs_load4(pair_ptr(results, n, 0u, i), pair_ptr(results, n, 1u, i), pair_ptr(results, n, 2u, i),
+                                        pair_ptr(results, n, 3u, i), g);
+                    bool all = true;
+#pragma unroll
+                    for (int q = 0; q < RESULT_GRANULES; ++q) all = all && ((g[q] >> 40) == want);
+                    return all;
+                });
+                if (!got) { timed_out = true; break; }
+                if (live[e]) {
+                    acc_r[e] += (double)__uint_as_float((uint32_t)g[6]);
+                    acc_o[e] += (double)__uint_as_float((uint32_t)g[0]);
                 }
             }
-            if (timed_out) break;
-            if (live) {
-                acc_r += (double)__uint_as_float((uint32_t)g[6]);
-                acc_o += (double)__uint_as_float((uint32_t)g[0]);
-            }
+            const uint64_t tag = tick_tag(tag0, (uint32_t)t);
+            if (live[e]) granule_store(mailbox + i, (tag << 40) | ((uint64_t)(k & 0xFu) << 32) | (uint64_t)__float_as_uint(m));
         }
-        const uint64_t tag = tick_tag(tag0, (uint32_t)t);
-        if (live) granule_store(mailbox + i, (tag << 40) | ((uint64_t)(k & 0xFu) << 32) | (uint64_t)__float_as_uint(m));
-        handed = t + 1;
+        if (!timed_out) handed = t + 1;
     }
-    if (live && checksum) { checksum[i] += acc_r; checksum[(size_t)n + i] += acc_o; }
+#pragma unroll
+    for (int e = 0; e < E; ++e)
+        if (live[e] && checksum) { checksum[idx[e]] += acc_r[e]; checksum[(size_t)n + idx[e]] += acc_o[e]; }
     if (lane == 0 && handed != ticks) {
         if (timed_out) atomicOr(&status[3], 1u);
         atomicMax(&status[4], (uint32_t)(ticks - handed));       // actions the slowest wave did not hand over
@@ -261,17 +289,18 @@ tick_collect_kernel(int n, uint32_t tag0, uint32_t t, const uint64_t* results, f
     }
 }
 
-template <bool SPEC>
+template <bool SPEC, int E>
 __global__ void __launch_bounds__(64)
 tick_server_kernel(Params p, StatePtrs s, int ticks, uint32_t tag0, const uint64_t* mailbox, uint64_t* results, float* obs_final,
                    uint64_t seed, uint64_t counter0, int auto_reset, uint32_t* status, uint64_t timeout_ticks, Backoff bo) {
-    tick_server_body<SPEC>(p, s, blockIdx.x, ticks, tag0, mailbox, results, obs_final, seed, counter0, auto_reset, status, timeout_ticks, bo);
+    tick_server_body<SPEC, E>(p, s, blockIdx.x, ticks, tag0, mailbox, results, obs_final, seed, counter0, auto_reset, status, timeout_ticks, bo);
 }
 
+template <int E>
 __global__ void __launch_bounds__(64)
 tick_driver_kernel(int n, int ticks, uint32_t tag0, const uint8_t* keys, const float* mouse, uint64_t* mailbox,
                    const uint64_t* results, double* checksum, uint32_t* status, uint64_t timeout_ticks, Backoff bo) {
-    tick_driver_body(n, blockIdx.x, ticks, tag0, keys, mouse, mailbox, results, checksum, status, timeout_ticks, bo);
+    tick_driver_body<E>(n, blockIdx.x, ticks, tag0, keys, mouse, mailbox, results, checksum, status, timeout_ticks, bo);
 }
 
 // Server and reference driver in ONE dispatch (q1env_step_persistent_pair): blocks [0, B) are the server's waves, blocks [B, 2B) the
@@ -279,15 +308,15 @@ tick_driver_kernel(int n, int ticks, uint32_t tag0, const uint8_t* keys, const f
 // promise (a process that has created many streams re-uses queues: the producer then queues BEHIND the server it feeds and both
 // sides can only time out).  One grid that fits the device is co-resident by construction - this is what the benchmark and most
 // tests use; the two-stream entry points remain for an external producer.
-template <bool SPEC>
+template <bool SPEC, int E>
 __global__ void __launch_bounds__(64)
 tick_pair_kernel(Params p, StatePtrs s, int ticks, uint32_t tag0, uint64_t* mailbox, uint64_t* results, float* obs_final,
                  uint64_t seed, uint64_t counter0, int auto_reset, const uint8_t* keys, const float* mouse, double* checksum,
                  uint32_t* status, uint64_t timeout_ticks, Backoff bo) {
     const uint32_t half = gridDim.x >> 1;
     if (blockIdx.x < half)
-        tick_server_body<SPEC>(p, s, blockIdx.x, ticks, tag0, mailbox, results, obs_final, seed, counter0, auto_reset, status, timeout_ticks, bo);
+        tick_server_body<SPEC, E>(p, s, blockIdx.x, ticks, tag0, mailbox, results, obs_final, seed, counter0, auto_reset, status, timeout_ticks, bo);
     else
-        tick_driver_body(p.n, blockIdx.x - half, ticks, tag0, keys, mouse, mailbox, results, checksum, status, timeout_ticks, bo);
+        tick_driver_body<E>(p.n, blockIdx.x - half, ticks, tag0, keys, mouse, mailbox, results, checksum, status, timeout_ticks, bo);
 }
 

@@ -65,6 +65,39 @@ def test_tick_server_equals_per_tick_kernels(n, ticks, over, two_streams):
     a.close(); b.close()
 
 
+@pytest.mark.parametrize("n,two_streams", [(131072 + 77, False),        # 2 envs per lane (pair), ragged last wave
+                                           (131072 + 77, True),         # ... and on two streams
+                                           (200000, True),              # 4 envs per lane next to an external producer
+                                           (262144, False)])            # 4 envs per lane: BASELINE configs[2]'s batch as ONE resident grid
+def test_tick_server_several_envs_per_lane(n, two_streams):
+    """Batches above one env per lane of the resident grid: each wave serves 2 or 4 sub-batches of 64 envs in order.  Same bits as
+    the per-tick kernels (state, last results, the producer's float64 sums), with in-kernel resets on."""
+    import torch
+    ticks = 60
+    over = dict(time_limit=0.3, zero_start_prob=0.4)
+    cfg, a = make_env(n, 9, **over)
+    _, b = make_env(n, 9, **over)
+    a.reset(); b.reset()
+    keys, mouse = actions(n, ticks, 4)
+    sums = torch.zeros((2, n), dtype=torch.float64, device="cuda")
+    for t in range(ticks):
+        obs_b, rew_b, done_b = b.step_autoreset((keys[t], mouse[t]))
+        if t != ticks - 1:
+            sums[0] += rew_b.double()
+            sums[1] += obs_b[:, 0].double()
+    res = a.serve_ticks(keys, mouse, two_streams=two_streams)
+    assert not res["status"].any(), res["status"]
+    torch.cuda.synchronize()
+    sa, sb = a.get_state(), b.get_state()
+    for k in sa:
+        assert np.array_equal(sa[k], sb[k]), k
+    assert torch.equal(res["obs"], obs_b) and torch.equal(res["obs_from_granules"], obs_b)
+    assert torch.equal(res["reward"], rew_b) and torch.equal(res["done"], done_b) and torch.equal(res["zero_start"], b.zero_start)
+    assert torch.equal(res["checksum"], sums)
+    assert int(done_b.sum()) >= 0 and float(sums[0].abs().sum()) > 0
+    a.close(); b.close()
+
+
 def test_tick_server_against_the_numpy_oracle():
     """64 zero-start envs x 300 ticks (no episode end): every tick's state transition is the oracle's, bit for bit."""
     import torch
