@@ -193,7 +193,7 @@ def load_profiled_traffic(mode, n, env_steps_per_launch=None):
         return None
 
 
-SERVER_AUTO_MAX_ENVS = 196608      # auto mode: resident tick server up to here (1 or 2 envs per lane), per-tick kernels above
+SERVER_AUTO_MAX_ENVS = 262144      # auto mode: resident tick server up to its resident capacity on an MI355X, per-tick kernels above
 
 
 def parse_args(argv=None):
@@ -494,7 +494,6 @@ def main(argv=None):
     if args.mode == "auto":
         try_server = not injected or bool(os.environ.get("Q1_BENCH_FORCE_AUTO_SERVER"))     # (the test stand-in has no tick server)
         if try_server and n > SERVER_AUTO_MAX_ENVS:
-            # measured (profiles/r2_persistent_server_sizes_multi.txt): at 4 envs per lane the per-tick kernels are the faster path again
             try_server = False
             sys.stderr.write(f"bench.py: {n} envs per GPU > {SERVER_AUTO_MAX_ENVS}: auto mode = per-tick step kernels\n")
         args.mode = "server" if try_server else "step"

@@ -794,6 +794,9 @@ struct q1env {
     int num_cus = 256;                // compute units of the device (MI355X in SPX mode: 256)
     int server_blocks_per_cu[3] = {-1, -1, -1};   // occupancy of the resident tick server at 1/2/4 envs per lane (queried once)
     int pair_blocks_per_cu[3] = {-1, -1, -1};     // ... and of the server + driver pair kernel
+    uint64_t* near_buf = nullptr;     // XCD-local copies of the tick server's hand-off buffers (mailbox uint64[N] + results uint64[4][N][2])
+    uint32_t near_next_tag = 0;       // the tag0 that continues the last launch (the copies hold no tag a continuing launch could match)
+    bool near_stale = false;          // a launch ran without the copies: wipe them before the next use
     bool mlp_attr_set = false;        // dynamic-LDS attribute of the policy kernels (a per-device setting: kept per handle)
     // cached hipGraphs of step_many, keyed by (ticks, formats, pointers); a handful of entries, oldest evicted
     struct GraphEntry { std::vector<uint64_t> key; hipGraphExec_t exec; };
@@ -1040,6 +1043,7 @@ int q1env_destroy(q1env_t* h) {
     if (h->stage) (void)hipFree(h->stage);
     if (h->pin) (void)hipHostFree(h->pin);
     if (h->snap) (void)hipFree(h->snap);
+    if (h->near_buf) (void)hipFree(h->near_buf);
     if (h->arena) (void)hipFree(h->arena);
     if (h->own_stream) (void)hipStreamDestroy(h->stream);
     delete h;
@@ -1753,6 +1757,39 @@ static Backoff server_backoff() {
     return bo;
 }
 
+// The XCD-local copies of mailbox / results (q1server.hpp): owned by the handle, handed to the server and to the library's own driver
+// only.  They must never hold a tag the coming launch could match: fresh buffers are zeroed, and so are they whenever tag0 does not
+// continue the previous launch's sequence (a synchronising memset on that rare path; launches that continue pay nothing).
+// Measurement / test knobs, read at every launch: Q1ENV_SERVER_NEAR=0 turns the fast path off (everything travels agent-scope);
+// Q1ENV_SERVER_PAD=0 leaves the pair grid unpadded (an odd block count then puts every pair on two XCDs: the verified-far path).
+static bool knob_on(const char* name) { const char* e = getenv(name); return !(e && e[0] == '0'); }
+
+static int near_bufs(q1env_t* h, uint32_t tag0, int ticks, NearBufs* out) {
+    *out = NearBufs{nullptr, nullptr};
+    if (!knob_on("Q1ENV_SERVER_NEAR")) {
+        h->near_stale = true;                   // (no launch continues this one: the copies are wiped before they are used again)
+        return Q1ENV_OK;
+    }
+    const size_t n = (size_t)h->p.n, bytes = n * 9 * sizeof(uint64_t);
+    bool wipe = h->near_stale || tag0 != h->near_next_tag;
+    h->near_stale = false;
+    if (!h->near_buf) {
+        HIP_TRY(hipMalloc((void**)&h->near_buf, bytes));
+        wipe = true;
+    }
+    if (wipe) {
+        HIP_TRY(hipMemsetAsync(h->near_buf, 0, bytes, h->stream));
+        HIP_TRY(hipStreamSynchronize(h->stream));
+    }
+    h->near_next_tag = (uint32_t)(((uint64_t)tag0 + (uint64_t)ticks) % 0xFFFFFFull);
+    *out = NearBufs{h->near_buf, h->near_buf + n};
+    return Q1ENV_OK;
+}
+// (for the driver of the two-stream form: whatever q1env_step_persistent_start set up - call that first)
+static NearBufs near_bufs_of(const q1env_t* h) {
+    return h->near_buf && knob_on("Q1ENV_SERVER_NEAR") ? NearBufs{h->near_buf, h->near_buf + (size_t)h->p.n} : NearBufs{nullptr, nullptr};
+}
+
 // Envs per lane of the resident grid (E in {1, 2, 4}, index e = log2 E): the smallest that makes the whole grid resident (at 8 the
 // server needs 416 VGPRs and spills: one wave per SIMD, no more envs resident than at 4).
 // A kernel instance per (SPEC, E); the switch keeps every launch a direct call.
@@ -1812,12 +1849,14 @@ int q1env_step_persistent_start(q1env_t* h, int ticks, uint32_t tag0, const uint
     const unsigned per_block = 64u << e_idx;
     const dim3 g(((unsigned)h->p.n + per_block - 1u) / per_block), b(64);
     const uint64_t timeout_ticks = (uint64_t)(timeout_s * 1.0e8);          // wall_clock64: 100 MHz
+    NearBufs near;
+    if (int rc = near_bufs(h, tag0, ticks, &near)) return rc;
 #define Q1_LAUNCH(E)                                                                                                                    \
     if (is_spec(h->p))                                                                                                                  \
-        hipLaunchKernelGGL((tick_server_kernel<true, E>), g, b, 0, h->stream, h->p, h->st, ticks, tag0, mailbox_dev, results_dev,       \
+        hipLaunchKernelGGL((tick_server_kernel<true, E>), g, b, 0, h->stream, h->p, h->st, ticks, tag0, mailbox_dev, results_dev, near, \
                            obs_final_dev, seed, h->tick_count, auto_reset, status_dev, timeout_ticks, server_backoff());                \
     else                                                                                                                                \
-        hipLaunchKernelGGL((tick_server_kernel<false, E>), g, b, 0, h->stream, h->p, h->st, ticks, tag0, mailbox_dev, results_dev,      \
+        hipLaunchKernelGGL((tick_server_kernel<false, E>), g, b, 0, h->stream, h->p, h->st, ticks, tag0, mailbox_dev, results_dev, near,\
                            obs_final_dev, seed, h->tick_count, auto_reset, status_dev, timeout_ticks, server_backoff())
     Q1_FOR_E(e_idx, Q1_LAUNCH)
 #undef Q1_LAUNCH
@@ -1840,7 +1879,7 @@ int q1env_step_persistent_drive(q1env_t* h, void* producer_stream, int ticks, ui
     const dim3 g(((unsigned)h->p.n + per_block - 1u) / per_block), b(64);
 #define Q1_LAUNCH(E)                                                                                                                 \
     hipLaunchKernelGGL((tick_driver_kernel<E>), g, b, 0, (hipStream_t)producer_stream, h->p.n, ticks, tag0, keys_dev, mouse_dev,     \
-                       mailbox_dev, results_dev, checksum_dev, status_dev, (uint64_t)(timeout_s * 1.0e8), server_backoff())
+                       mailbox_dev, results_dev, near_bufs_of(h), checksum_dev, status_dev, (uint64_t)(timeout_s * 1.0e8), server_backoff())
     Q1_FOR_E(e_idx, Q1_LAUNCH)
 #undef Q1_LAUNCH
     HIP_TRY(hipGetLastError());
@@ -1893,19 +1932,27 @@ int q1env_step_persistent_pair(q1env_t* h, int ticks, uint32_t tag0, const uint8
         return fail(Q1ENV_ERR_INVALID_ARG, "q1env_step_persistent_pair: too many envs for one resident grid (" + std::to_string(best) +
                                            " at most on this device)");
     const unsigned per_block = 64u << e_idx;
-    const unsigned blocks = ((unsigned)h->p.n + per_block - 1u) / per_block;
+    unsigned blocks = ((unsigned)h->p.n + per_block - 1u) / per_block;
+    {   // speed only: with B a multiple of 8, block b and block B + b meet on one XCD under round-robin placement (q1server.hpp)
+        int per_cu = 0;
+        if (int rc = resident_blocks_per_cu(h, true, e_idx, &per_cu)) return rc;
+        const unsigned padded = (blocks + 7u) & ~7u;
+        if (2L * padded <= (long)h->num_cus * per_cu && knob_on("Q1ENV_SERVER_PAD")) blocks = padded;
+    }
     const uint64_t timeout_ticks = (uint64_t)(timeout_s * 1.0e8);
     const dim3 g(2u * blocks), b(64);
+    NearBufs near;
+    if (int rc = near_bufs(h, tag0, ticks, &near)) return rc;
     const bool t_start = (auto_reset & Q1ENV_TIMER_START) != 0, t_stop = (auto_reset & Q1ENV_TIMER_STOP) != 0;
     auto_reset &= 1;
     if (t_start) HIP_TRY(hipEventRecord(h->ev0, h->stream));
 #define Q1_LAUNCH(E)                                                                                                                     \
     if (is_spec(h->p))                                                                                                                   \
-        hipLaunchKernelGGL((tick_pair_kernel<true, E>), g, b, 0, h->stream, h->p, h->st, ticks, tag0, mailbox_dev, results_dev,          \
+        hipLaunchKernelGGL((tick_pair_kernel<true, E>), g, b, 0, h->stream, h->p, h->st, ticks, tag0, mailbox_dev, results_dev, near,    \
                            obs_final_dev, seed, h->tick_count, auto_reset, keys_dev, mouse_dev, checksum_dev, status_dev, timeout_ticks, \
                            server_backoff());                                                                                            \
     else                                                                                                                                 \
-        hipLaunchKernelGGL((tick_pair_kernel<false, E>), g, b, 0, h->stream, h->p, h->st, ticks, tag0, mailbox_dev, results_dev,         \
+        hipLaunchKernelGGL((tick_pair_kernel<false, E>), g, b, 0, h->stream, h->p, h->st, ticks, tag0, mailbox_dev, results_dev, near,   \
                            obs_final_dev, seed, h->tick_count, auto_reset, keys_dev, mouse_dev, checksum_dev, status_dev, timeout_ticks, \
                            server_backoff())
     Q1_FOR_E(e_idx, Q1_LAUNCH)

@@ -23,7 +23,26 @@ using namespace q1;
 // Every wait is bounded: a lane that sees no new tag for `timeout_ticks` of the 100 MHz wall clock gives up, the wave stores its
 // state as of the last completed tick and reports status[1] != 0 - a missing or stalled producer ends the launch, not the GPU.
 // Bit-identical to `ticks` q1env_step_autoreset / q1env_step calls with the packed action layout.
+//
+// XCD-local fast path (the library's own resident driver only).  An sc1 store DROPS its line from the writer's L2 and an sc1 load
+// of it is served over the fabric - ~0.9 us per hop wherever the two waves sit.  A PLAIN store stays in the XCD's L2, where an
+// L1-bypassing (sc1) load of ANOTHER CU OF THE SAME XCD finds it in ~0.4 us (tools/ubench_handoff.hip: round trip 1.78 -> 0.79 us);
+// a reader on another XCD never sees it.  So placement is not assumed but EXCHANGED: every wave reads HW_REG_XCC_ID and puts it
+// into its granules (action bits 36..39, result granule 7 bits 0..3: 8 | xcc; 0 = "unknown", what an external producer writes).
+// Tick 0 of a launch travels agent-scope (the driver stores both copies; it polls both for the results).  From then on a side
+// whose partner is verified on its own XCD stores the XCD-local copy ONLY (buffers owned by the handle, never seen by an
+// external producer) and polls it, looking at the agent-scope copy every eighth poll; every other pair keeps the sc1 protocol.
+// Nothing is assumed about block -> XCD placement (the pair grid is merely padded so that block b and block B + b meet on
+// one XCD when the dispatcher goes round-robin): a pair on two XCDs is slower, not wrong.  The last tick of a launch is also
+// stored agent-scope, so `results` always holds it.
 constexpr int RESULT_GRANULES = 7;
+constexpr uint32_t PEER_VALID = 8u;            // granule bit: "the low three bits are my XCC id"
+constexpr uint32_t NEAR_POLL_PERIOD = 8u;      // near-first polling: polls 0..6 of every 8 read the XCD-local copy, poll 7 the agent-scope copy
+
+struct NearBufs { uint64_t* mailbox; uint64_t* results; };      // XCD-local copies (uint64[N], uint64[4][N][2]); null = sc1 protocol only
+
+__device__ __forceinline__ uint32_t xcc_id() { return (uint32_t)__builtin_amdgcn_s_getreg(20 | (3 << 11)) & 7u; }      // HW_REG_XCC_ID[3:0]
+__device__ __forceinline__ bool peer_is_near(uint32_t bits, uint32_t my_xcc) { return (bits & PEER_VALID) != 0u && (bits & 7u) == my_xcc; }
 
 // Poll pacing, in units of s_sleep(1) (64 clocks): `first_*` before the first poll of a tick - the other side needs at least a hop
 // plus its own work before anything new can be there, and thousands of waves polling early only load the fabric the hand-offs
@@ -58,6 +77,15 @@ __device__ __forceinline__ void granule_pair_store(uint64_t* p, uint64_t a, uint
     asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 2" ::"v"(p), "v"(v) : "memory");
 }
 
+// the XCD-local flavours: plain stores (the line stays in this XCD's L2)
+__device__ __forceinline__ void granule_store_near(uint64_t* p, uint64_t v) {
+    asm volatile("global_store_dwordx2 %0, %1, off" ::"v"(p), "v"(v) : "memory");
+}
+__device__ __forceinline__ void granule_pair_store_near(uint64_t* p, uint64_t a, uint64_t b) {
+    const u32x4 v = {(uint32_t)a, (uint32_t)(a >> 32), (uint32_t)b, (uint32_t)(b >> 32)};
+    asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 2" ::"v"(p), "v"(v) : "memory");
+}
+
 // four pairs (eight granules) with all four loads in flight together
 __device__ __forceinline__ void granule_pairs_load4(const uint64_t* p0, const uint64_t* p1, const uint64_t* p2, const uint64_t* p3,
                                                     uint64_t (&g)[8]) {
@@ -82,8 +110,8 @@ __device__ __forceinline__ uint64_t* pair_ptr(const uint64_t* results, uint32_t 
     return const_cast<uint64_t*>(results) + ((size_t)q * n + i) * 2u;
 }
 
-// One bounded wait of a wave on one granule set: `probe` loads and validates the lane's granules (returns true when its tag has
-// arrived); the load's own latency paces the loop, and the 100 MHz clock is only consulted every 256 failed polls (no
+// One bounded wait of a wave on one granule set: `probe(poll number)` loads and validates the lane's granules (returns true when
+// its tag has arrived); the load's own latency paces the loop, and the 100 MHz clock is only consulted every 256 failed polls (no
 // s_memrealtime on the path of a tick that is served promptly) - the timeout counts from the first such look.
 template <typename Probe>
 __device__ __forceinline__ bool wait_for(bool live, uint64_t timeout_ticks, const Backoff& bo, Probe probe) {
@@ -91,7 +119,7 @@ __device__ __forceinline__ bool wait_for(bool live, uint64_t timeout_ticks, cons
     uint32_t polls = 0;
     uint64_t t_wait = 0;
     for (;;) {
-        if (!ok) ok = probe();
+        if (!ok) ok = probe(polls);
         if (__all(ok)) return true;
         nap(bo.between);
         if ((++polls & 255u) == 0u) {
@@ -109,22 +137,22 @@ __device__ __forceinline__ bool wait_for(bool live, uint64_t timeout_ticks, cons
 // producer) still runs as ONE resident grid, at E x the arithmetic per wave and the same two hops per tick.
 template <bool SPEC, int E>
 __device__ __forceinline__ void tick_server_body(const Params& p, const StatePtrs& s, uint32_t block, int ticks, uint32_t tag0,
-                                                 const uint64_t* mailbox, uint64_t* results, float* obs_final, uint64_t seed,
-                                                 uint64_t counter0, int auto_reset, uint32_t* status, uint64_t timeout_ticks,
-                                                 Backoff bo) {
+                                                 const uint64_t* mailbox, uint64_t* results, NearBufs near, float* obs_final,
+                                                 uint64_t seed, uint64_t counter0, int auto_reset, uint32_t* status,
+                                                 uint64_t timeout_ticks, Backoff bo) {
     const uint32_t lane = threadIdx.x, n = (uint32_t)p.n;
+    const uint32_t my_xcc = xcc_id();
     uint32_t idx[E];
     bool live[E];
+    bool near_peer[E];                   // the producer of this sub-batch said (last tick) that it sits on this XCD
     Env env[E];
-    float last_obs[E][6];
 #pragma unroll
     for (int e = 0; e < E; ++e) {
         idx[e] = (block * (uint32_t)E + (uint32_t)e) * 64u + lane;
         live[e] = idx[e] < n;
+        near_peer[e] = false;
         env[e] = Env{};
         if (live[e]) load_env(s, n, idx[e], env[e]);
-#pragma unroll
-        for (int j = 0; j < 6; ++j) last_obs[e][j] = 0.0f;
     }
     int completed = 0;
     bool timed_out = false;
@@ -135,11 +163,20 @@ __device__ __forceinline__ void tick_server_body(const Params& p, const StatePtr
         for (int e = 0; e < E; ++e) {
             const uint32_t i = idx[e];
             uint64_t g = 0;
-            // every lane polls its own granule: one contiguous 512-B sc1 read per wave
-            if (!wait_for(live[e], timeout_ticks, bo, [&] { g = granule_load(mailbox + i); return (g >> 40) == tag; })) {
+            // every lane polls its own granule: one contiguous 512-B sc1 read per wave (of the XCD-local copy while the producer is near)
+            const bool near_first = near_peer[e];
+            if (!wait_for(live[e], timeout_ticks, bo, [&](uint32_t polls) {
+                    const bool far = !near_first || (polls % NEAR_POLL_PERIOD) == NEAR_POLL_PERIOD - 1u;
+                    g = granule_load((far ? mailbox : near.mailbox) + i);
+                    return (g >> 40) == tag;
+                })) {
                 timed_out = true;
                 break;
             }
+            // where this tick's results go is decided by the action granule itself (wave-uniform: one producer wave per sub-batch)
+            const bool peer_near = near.results != nullptr && __all(!live[e] || peer_is_near((uint32_t)(g >> 36) & 0xFu, my_xcc));
+            near_peer[e] = peer_near;
+            const bool store_far = !peer_near || t == ticks - 1, store_near = peer_near;
             if (live[e]) {
                 const uint32_t keys = (uint32_t)(g >> 32) & ((1u << cfg_num_keys<SPEC>(p)) - 1u);
                 const double yaw_act = cfg_yaw_mode<SPEC>(p) ? (double)__uint_as_float((uint32_t)g) : 0.0;
@@ -152,13 +189,21 @@ __device__ __forceinline__ void tick_server_body(const Params& p, const StatePtr
                 }
                 const uint64_t hi = tag << 40;
                 const uint64_t last = hi | ((uint64_t)(zs ? 1u : 0u) << 33) | ((uint64_t)(o.done ? 1u : 0u) << 32) | (uint64_t)__float_as_uint(o.reward);
+                const uint64_t pad = hi | (uint64_t)(PEER_VALID | my_xcc);                // granule 7: tag + where the server wave sits
+                if (store_near) {
 #pragma unroll
-                for (uint32_t q = 0; q < 3u; ++q)
-                    granule_pair_store(pair_ptr(results, n, q, i), hi | (uint64_t)__float_as_uint(o.obs[2 * q]),
-                                       hi | (uint64_t)__float_as_uint(o.obs[2 * q + 1]));
-                granule_pair_store(pair_ptr(results, n, 3u, i), last, hi);      // granule 7 is padding: tag only
+                    for (uint32_t q = 0; q < 3u; ++q)
+                        granule_pair_store_near(pair_ptr(near.results, n, q, i), hi | (uint64_t)__float_as_uint(o.obs[2 * q]),
+                                                hi | (uint64_t)__float_as_uint(o.obs[2 * q + 1]));
+                    granule_pair_store_near(pair_ptr(near.results, n, 3u, i), last, pad);
+                }
+                if (store_far) {
 #pragma unroll
-                for (int j = 0; j < 6; ++j) last_obs[e][j] = o.obs[j];
+                    for (uint32_t q = 0; q < 3u; ++q)
+                        granule_pair_store(pair_ptr(results, n, q, i), hi | (uint64_t)__float_as_uint(o.obs[2 * q]),
+                                           hi | (uint64_t)__float_as_uint(o.obs[2 * q + 1]));
+                    granule_pair_store(pair_ptr(results, n, 3u, i), last, pad);
+                }
             }
         }
         if (!timed_out) completed = t + 1;
@@ -169,7 +214,11 @@ __device__ __forceinline__ void tick_server_body(const Params& p, const StatePtr
     for (int e = 0; e < E; ++e)
         if (live[e]) {
             store_env(s, n, idx[e], env[e]);
-            if (obs_final && completed > 0) write_obs<float>(obs_final, (size_t)idx[e], last_obs[e]);   // plain row of the last served tick
+            if (obs_final && completed > 0) {                    // plain row of the last served tick (a tick ends with observe() of the state it leaves)
+                float o[6];
+                observe<float>(p, env[e], o);
+                write_obs<float>(obs_final, (size_t)idx[e], o);
+            }
         }
     if (lane == 0 && completed != ticks) {                       // nothing is written on the success path: thousands of waves ending
         atomicAdd(&status[0], 1u);                               // together would serialise ~12 ns per atomic on these five words
@@ -185,16 +234,20 @@ __device__ __forceinline__ void tick_server_body(const Params& p, const StatePtr
 // round trip.  E envs per lane, sub-batch by sub-batch like the server; resident next to it.
 template <int E>
 __device__ __forceinline__ void tick_driver_body(int n_, uint32_t block, int ticks, uint32_t tag0, const uint8_t* keys, const float* mouse,
-                                                 uint64_t* mailbox, const uint64_t* results, double* checksum, uint32_t* status,
-                                                 uint64_t timeout_ticks, Backoff bo) {
+                                                 uint64_t* mailbox, const uint64_t* results, NearBufs near, double* checksum,
+                                                 uint32_t* status, uint64_t timeout_ticks, Backoff bo) {
     const uint32_t lane = threadIdx.x, n = (uint32_t)n_;
+    const uint32_t my_xcc = xcc_id();
+    const bool has_near = near.mailbox != nullptr;
     uint32_t idx[E];
     bool live[E];
+    bool near_peer[E];                   // the server wave of this sub-batch is known to sit on this XCD (from its last results)
     double acc_r[E], acc_o[E];
 #pragma unroll
     for (int e = 0; e < E; ++e) {
         idx[e] = (block * (uint32_t)E + (uint32_t)e) * 64u + lane;
         live[e] = idx[e] < n;
+        near_peer[e] = false;
         acc_r[e] = 0.0; acc_o[e] = 0.0;
     }
     bool timed_out = false;
@@ -210,22 +263,32 @@ __device__ __forceinline__ void tick_driver_body(int n_, uint32_t block, int tic
                 const uint64_t want = tick_tag(tag0, (uint32_t)t - 1u);          // results of tick t-1
                 uint64_t g[8];
                 if (e == 0) nap(bo.first_driver);
-                const bool got = wait_for(live[e], timeout_ticks, bo, [&] {
-                    granule_pairs_load4(pair_ptr(results, n, 0u, i), pair_ptr(results, n, 1u, i), pair_ptr(results, n, 2u, i),
-                                        pair_ptr(results, n, 3u, i), g);
+                // tick 0's results may be in either copy (the server knows by then where this wave sits, this wave does not know
+                // the server's place yet): near-first polling covers both; afterwards only a near server is polled near-first
+                const bool near_first = has_near && (t == 1 || near_peer[e]);
+                const bool got = wait_for(live[e], timeout_ticks, bo, [&](uint32_t polls) {
+                    const bool far = !near_first || (polls % NEAR_POLL_PERIOD) == NEAR_POLL_PERIOD - 1u;
+                    const uint64_t* r = far ? results : near.results;
+                    granule_pairs_load4(pair_ptr(r, n, 0u, i), pair_ptr(r, n, 1u, i), pair_ptr(r, n, 2u, i), pair_ptr(r, n, 3u, i), g);
                     bool all = true;
 #pragma unroll
-                    for (int q = 0; q < RESULT_GRANULES; ++q) all = all && ((g[q] >> 40) == want);
+                    for (int q = 0; q < RESULT_GRANULES + 1; ++q) all = all && ((g[q] >> 40) == want);
                     return all;
                 });
                 if (!got) { timed_out = true; break; }
+                near_peer[e] = has_near && __all(!live[e] || peer_is_near((uint32_t)g[7] & 0xFu, my_xcc));
                 if (live[e]) {
                     acc_r[e] += (double)__uint_as_float((uint32_t)g[6]);
                     acc_o[e] += (double)__uint_as_float((uint32_t)g[0]);
                 }
             }
             const uint64_t tag = tick_tag(tag0, (uint32_t)t);
-            if (live[e]) granule_store(mailbox + i, (tag << 40) | ((uint64_t)(k & 0xFu) << 32) | (uint64_t)__float_as_uint(m));
+            if (live[e]) {
+                const uint64_t a = (tag << 40) | ((uint64_t)(has_near ? (PEER_VALID | my_xcc) : 0u) << 36) | ((uint64_t)(k & 0xFu) << 32) |
+                                   (uint64_t)__float_as_uint(m);
+                if (has_near && (t == 0 || near_peer[e])) granule_store_near(near.mailbox + i, a);
+                if (t == 0 || !near_peer[e]) granule_store(mailbox + i, a);
+            }
         }
         if (!timed_out) handed = t + 1;
     }
@@ -291,32 +354,34 @@ tick_collect_kernel(int n, uint32_t tag0, uint32_t t, const uint64_t* results, f
 
 template <bool SPEC, int E>
 __global__ void __launch_bounds__(64)
-tick_server_kernel(Params p, StatePtrs s, int ticks, uint32_t tag0, const uint64_t* mailbox, uint64_t* results, float* obs_final,
+tick_server_kernel(Params p, StatePtrs s, int ticks, uint32_t tag0, const uint64_t* mailbox, uint64_t* results, NearBufs near, float* obs_final,
                    uint64_t seed, uint64_t counter0, int auto_reset, uint32_t* status, uint64_t timeout_ticks, Backoff bo) {
-    tick_server_body<SPEC, E>(p, s, blockIdx.x, ticks, tag0, mailbox, results, obs_final, seed, counter0, auto_reset, status, timeout_ticks, bo);
+    tick_server_body<SPEC, E>(p, s, blockIdx.x, ticks, tag0, mailbox, results, near, obs_final, seed, counter0, auto_reset, status, timeout_ticks, bo);
 }
 
 template <int E>
 __global__ void __launch_bounds__(64)
 tick_driver_kernel(int n, int ticks, uint32_t tag0, const uint8_t* keys, const float* mouse, uint64_t* mailbox,
-                   const uint64_t* results, double* checksum, uint32_t* status, uint64_t timeout_ticks, Backoff bo) {
-    tick_driver_body<E>(n, blockIdx.x, ticks, tag0, keys, mouse, mailbox, results, checksum, status, timeout_ticks, bo);
+                   const uint64_t* results, NearBufs near, double* checksum, uint32_t* status, uint64_t timeout_ticks, Backoff bo) {
+    tick_driver_body<E>(n, blockIdx.x, ticks, tag0, keys, mouse, mailbox, results, near, checksum, status, timeout_ticks, bo);
 }
 
 // Server and reference driver in ONE dispatch (q1env_step_persistent_pair): blocks [0, B) are the server's waves, blocks [B, 2B) the
 // driver's.  Two streams are only concurrent when the runtime maps them to different hardware queues, which HIP does not
 // promise (a process that has created many streams re-uses queues: the producer then queues BEHIND the server it feeds and both
 // sides can only time out).  One grid that fits the device is co-resident by construction - this is what the benchmark and most
-// tests use; the two-stream entry points remain for an external producer.
+// tests use; the two-stream entry points remain for an external producer.  The host pads B to a multiple of 8 (blocks whose envs are
+// all beyond n idle through the loop), so that with the round-robin block -> XCD placement the dispatcher is observed to use, server
+// block b and its driver block B + b share an XCD and take the XCD-local path (verified per wave pair at run time, never assumed).
 template <bool SPEC, int E>
 __global__ void __launch_bounds__(64)
-tick_pair_kernel(Params p, StatePtrs s, int ticks, uint32_t tag0, uint64_t* mailbox, uint64_t* results, float* obs_final,
+tick_pair_kernel(Params p, StatePtrs s, int ticks, uint32_t tag0, uint64_t* mailbox, uint64_t* results, NearBufs near, float* obs_final,
                  uint64_t seed, uint64_t counter0, int auto_reset, const uint8_t* keys, const float* mouse, double* checksum,
                  uint32_t* status, uint64_t timeout_ticks, Backoff bo) {
     const uint32_t half = gridDim.x >> 1;
     if (blockIdx.x < half)
-        tick_server_body<SPEC, E>(p, s, blockIdx.x, ticks, tag0, mailbox, results, obs_final, seed, counter0, auto_reset, status, timeout_ticks, bo);
+        tick_server_body<SPEC, E>(p, s, blockIdx.x, ticks, tag0, mailbox, results, near, obs_final, seed, counter0, auto_reset, status, timeout_ticks, bo);
     else
-        tick_driver_body<E>(p.n, blockIdx.x - half, ticks, tag0, keys, mouse, mailbox, results, checksum, status, timeout_ticks, bo);
+        tick_driver_body<E>(p.n, blockIdx.x - half, ticks, tag0, keys, mouse, mailbox, results, near, checksum, status, timeout_ticks, bo);
 }
 

@@ -98,6 +98,42 @@ def test_tick_server_several_envs_per_lane(n, two_streams):
     a.close(); b.close()
 
 
+@pytest.mark.parametrize("knobs", [{}, {"Q1ENV_SERVER_NEAR": "0"}, {"Q1ENV_SERVER_PAD": "0"}])
+@pytest.mark.parametrize("n", [4096 + 37, 65536 + 64])            # 65 and 1025 blocks: odd, so unpadded pairs sit on two XCDs
+def test_tick_server_hand_off_paths(n, knobs, monkeypatch):
+    """The hand-offs travel XCD-local (plain stores, found in the shared L2) between wave pairs that verified - by exchanging
+    their XCC ids - that they share an XCD, agent-scope (sc1) otherwise.  Same bits on every path: default (padded grid: pairs
+    meet on one XCD), fast path off, and an unpadded odd grid (every pair verified to sit on two XCDs); launches alternate
+    between the knobs' setting and the default, with continuing tags, so stale XCD-local copies would show."""
+    import torch
+    ticks = 90
+    over = dict(time_limit=0.4, zero_start_prob=0.3)
+    cfg, a = make_env(n, 5, **over)
+    _, b = make_env(n, 5, **over)
+    a.reset(); b.reset()
+    keys, mouse = actions(n, ticks, 6)
+    for launch in range(3):
+        sums = torch.zeros((2, n), dtype=torch.float64, device="cuda")
+        for t in range(ticks):
+            obs_b, rew_b, done_b = b.step_autoreset((keys[t], mouse[t]))
+            if t != ticks - 1:
+                sums[0] += rew_b.double()
+                sums[1] += obs_b[:, 0].double()
+        with monkeypatch.context() as m:
+            if launch != 1:
+                for k, v in knobs.items():
+                    m.setenv(k, v)
+            res = a.serve_ticks(keys, mouse)
+        assert not res["status"].any(), (launch, res["status"])
+        assert torch.equal(res["checksum"], sums), launch
+        assert torch.equal(res["obs"], obs_b) and torch.equal(res["obs_from_granules"], obs_b)
+        assert torch.equal(res["reward"], rew_b) and torch.equal(res["done"], done_b)
+    sa, sb = a.get_state(), b.get_state()
+    for k in sa:
+        assert np.array_equal(sa[k], sb[k]), k
+    a.close(); b.close()
+
+
 def test_tick_server_against_the_numpy_oracle():
     """64 zero-start envs x 300 ticks (no episode end): every tick's state transition is the oracle's, bit for bit."""
     import torch
