@@ -514,7 +514,7 @@ def main(argv=None):
     kern_us = ev_ms * 1e3 / launches
     achieved = B_ALG * n * ticks_per_launch / (kern_us * 1e-6) / 1e9
     kernel = {"step": "step_kernel<float,SPEC,PACKED>", "rollout": "rollout_kernel<float,SPEC,PACKED,no-reset,all-outputs>",
-              "server": "tick_pair_kernel<SPEC> (tick server + dependent producer)"}[args.mode]
+              "server": "tick_pair_kernel<SPEC, E> (tick server + dependent producer)"}[args.mode]
     roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
             "traffic": load_profiled_traffic(args.mode, n, n * ticks_per_launch), "kernel": kernel, "avg_launch_us": kern_us,
             "event_ms_per_step": ev_ms / args.steps, "wall_over_event": wall * 1e3 / ev_ms if ev_ms > 0 else None,
@@ -525,10 +525,12 @@ def main(argv=None):
                     "(null if that size was not profiled)."}
     if args.mode == "server":
         roof["note"] += (" The resident tick server keeps the env state in registers between ticks and exchanges 8-byte data-tagged "
-                         "granules with the dependent producer half of the same dispatch (8 B action in, 56 B results out per env-step, "
-                         "written through to memory: 134 B of measured HBM traffic per env-step incl. the other side's reads and poll "
-                         "re-reads): the 204-B figure is the per-tick formulation's algorithmic traffic (SURVEY 8d), kept as the common "
-                         "yardstick; this mode is bound by the two agent-scope hand-off hops per tick, not by HBM bandwidth.")
+                         "granules with the dependent producer half of the same dispatch (8 B action in, 64 B of result granule pairs out "
+                         "per env-step).  Wave pairs that verified - by exchanging their XCC ids - that they share an XCD hand over through "
+                         "that XCD's L2 (plain stores, L1-bypassing loads), all others agent-scope (sc1): measured HBM traffic is 6.6 B per "
+                         "env-step (the producer's packed actions; 150 B before the XCD-local path).  The 204-B figure is the per-tick "
+                         "formulation's algorithmic traffic (SURVEY 8d), kept as the common yardstick: this mode is bound by the latency of "
+                         "one tick's dependent float64 chain (~0.7 us) plus two L2 hand-off hops, not by HBM bandwidth.")
     if args.mode == "rollout":
         real = (B_FUSED * n * ticks_per_launch + 170.0 * n) / (kern_us * 1e-6) / 1e9
         roof["real_bytes_achieved_GBps"] = real

@@ -315,9 +315,14 @@ int q1env_episode_stats(q1env_t* env, const float* reward_dev, const uint8_t* do
  * != 0; Philox counter as there) or q1env_step calls with the packed action layout.  Everything that crosses is an 8-byte
  * data-tagged granule, written by ONE agent-scope (sc1) store and polled with sc1 loads (MI355X_MICROARCH.md, persistent-kernel
  * price list) - no flags, fences or drains, one hop per direction:
- *   mailbox[i]    = (tag << 40) | (key bits << 32) | float32 bits of the mouse action          producer -> server, uint64[N]
+ *   mailbox[i]    = (tag << 40) | (place << 36) | (key bits << 32) | float32 bits of the mouse action   producer -> server, uint64[N]
  *   G[k][i], k = 0..5 = (tag << 40) | float32 bits of observation column k                   server -> consumer
- *   G[6][i] = (tag << 40) | (zero_start << 33) | (done << 32) | float32 bits of reward;  G[7][i] = tag << 40 (padding)
+ *   G[6][i] = (tag << 40) | (zero_start << 33) | (done << 32) | float32 bits of reward;  G[7][i] = (tag << 40) | place (padding)
+ *   place (4 bits) = 0 ("unknown": what an external producer writes - keep bits 36..39 of an action granule zero) or 8 | XCC id of
+ *   the writing wave.  The library's own resident driver (_drive / _pair) sets it: a server wave and a driver wave that find each
+ *   other on ONE XCD hand over through that XCD's L2 (plain stores into copies owned by the handle) instead of these agent-scope
+ *   buffers, from tick 1 of a launch on; tick 0 and the last tick of every launch always travel through mailbox / results, and an
+ *   external producer sees nothing but them.  Placement is verified per wave pair at run time, never assumed.
  *   results = uint64[4][N][2]: pair q of env i = {G[2q][i], G[2q+1][i]}, written as ONE 16-byte sc1 store (an sc1 store is one
  *   fabric write per lane whatever its width); every 8-byte half carries its own tag and can be read and validated alone.
  *   tag of tick t (0-based) of the launch = (tag0 + t) mod (2^24 - 1) + 1, i.e. 1 .. 0xFFFFFF and never 0: zero the mailbox before the
