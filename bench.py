@@ -530,7 +530,10 @@ def main(argv=None):
                          "that XCD's L2 (plain stores, L1-bypassing loads), all others agent-scope (sc1): measured HBM traffic is 6.6 B per "
                          "env-step (the producer's packed actions; 150 B before the XCD-local path).  The 204-B figure is the per-tick "
                          "formulation's algorithmic traffic (SURVEY 8d), kept as the common yardstick: this mode is bound by the latency of "
-                         "one tick's dependent float64 chain (~0.7 us) plus two L2 hand-off hops, not by HBM bandwidth.")
+                         "one tick's dependent float64 chain (~0.7 us) plus two L2 hand-off hops, not by HBM bandwidth - so `frac` is a "
+                         "NOMINAL figure (it passes 1 at 131 072 envs per GPU); `traffic` is what the kernel really moves.")
+        roof["frac_is_nominal"] = True
+        roof["us_per_tick"] = ev_ms * 1e3 / args.steps
     if args.mode == "rollout":
         real = (B_FUSED * n * ticks_per_launch + 170.0 * n) / (kern_us * 1e-6) / 1e9
         roof["real_bytes_achieved_GBps"] = real
@@ -546,7 +549,9 @@ def main(argv=None):
                                + ", zero-start 100 m run, random actions, get_default Config, "
                                f"720-tick episodes with on-device reset, per-tick obs f32/reward/done written; mode={args.mode}"
                                + ("+hipGraph" if args.mode == "step" and not args.no_graph else "")
-                               + (" (resident tick server + dependent producer kernel on a second stream, results as 8-byte granules)"
+                               + (" (resident tick server + dependent producer as ONE dispatch, hand-offs as 8-byte tagged granules)"
+                                  if args.mode == "server" and not os.environ.get("Q1_BENCH_SERVER_TWO_STREAMS") else
+                                  " (resident tick server + dependent producer kernel on a second stream, hand-offs as 8-byte tagged granules)"
                                   if args.mode == "server" else ""),
                    "total_envs": n * world,
                    "envs_per_gpu": n, "parallelism": f"batch-split x{world}, no collective",

@@ -793,7 +793,7 @@ struct q1env {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     int num_cus = 256;                // compute units of the device (MI355X in SPX mode: 256)
     int server_blocks_per_cu[3] = {-1, -1, -1};   // occupancy of the resident tick server at 1/2/4 envs per lane (queried once)
-    int pair_blocks_per_cu[3] = {-1, -1, -1};     // ... and of the server + driver pair kernel
+    int pair_blocks_per_cu[3] = {-1, -1, -1};     // ... and of the server + driver pair kernel, per shape (PAIR_SHAPES)
     uint64_t* near_buf = nullptr;     // XCD-local copies of the tick server's hand-off buffers (mailbox uint64[N] + results uint64[4][N][2])
     uint32_t near_next_tag = 0;       // the tag0 that continues the last launch (the copies hold no tag a continuing launch could match)
     bool near_stale = false;          // a launch ran without the copies: wipe them before the next use
@@ -1748,10 +1748,11 @@ int q1env_policy_value_forward(q1env_t* h, const float* obs, const q1env_mlp* pi
 // the defaults (measurement knob).
 static Backoff server_backoff() {
     static const Backoff bo = [] {
-        Backoff b{0, 0, 0};
+        Backoff b{0, 0, 0, 0};
         if (const char* e = getenv("Q1ENV_SERVER_BACKOFF")) (void)sscanf(e, "%d,%d,%d", &b.first_server, &b.first_driver, &b.between);
         auto clamp = [](int v) { return v < 0 ? 0 : (v > 4096 ? 4096 : v); };
         b.first_server = clamp(b.first_server); b.first_driver = clamp(b.first_driver); b.between = clamp(b.between);
+        if (const char* d = getenv("Q1ENV_SERVER_DIAG")) b.diag = d[0] == '1';
         return b;
     }();
     return bo;
@@ -1802,16 +1803,46 @@ static NearBufs near_bufs_of(const q1env_t* h) {
 
 extern "C++" {
 template <int E> static const void* server_fn(bool spec) { return spec ? (const void*)tick_server_kernel<true, E> : (const void*)tick_server_kernel<false, E>; }
-template <int E> static const void* pair_fn(bool spec) { return spec ? (const void*)tick_pair_kernel<true, E> : (const void*)tick_pair_kernel<false, E>; }
 }
 
-static int resident_blocks_per_cu(q1env_t* h, bool pair, int e_idx, int* out) {
-    int& slot = pair ? h->pair_blocks_per_cu[e_idx] : h->server_blocks_per_cu[e_idx];
+// Shapes of the pair dispatch: a server / driver wave pair serves ES sub-batches of 64 envs; "dense" is the same code compiled for
+// four waves per SIMD (q1server.hpp).  Tried in this order; the first whose grid is resident wins (Q1ENV_SERVER_SHAPE="<index>"
+// forces one: measurement knob).  Measured on an MI355X (tools/time_persistent.py): dense ES = 1 up to 131 072 envs, ES = 2 up to
+// 196 608, ES = 4 up to 262 144; a dense ES = 2 spills (28 registers) and is slower than ES = 4.
+struct PairShape { int es; bool dense; };
+static constexpr int N_PAIR_SHAPES = 3;
+static constexpr PairShape PAIR_SHAPES[N_PAIR_SHAPES] = {{1, true}, {2, false}, {4, false}};
+
+#define Q1_FOR_SHAPE(idx, CALL)                              \
+    switch (idx) {                                           \
+        case 0: { CALL(tick_pair_kernel_dense, 1); } break;  \
+        case 1: { CALL(tick_pair_kernel, 2); } break;        \
+        default: { CALL(tick_pair_kernel, 4); } break;       \
+    }
+
+static int server_blocks_per_cu_of(q1env_t* h, int e_idx, int* out) {
+    int& slot = h->server_blocks_per_cu[e_idx];
     if (slot < 0) {
         const void* fn = nullptr;
         const bool spec = is_spec(h->p);
-#define Q1_FN(E) fn = pair ? pair_fn<E>(spec) : server_fn<E>(spec)
+#define Q1_FN(E) fn = server_fn<E>(spec)
         Q1_FOR_E(e_idx, Q1_FN)
+#undef Q1_FN
+        int per_cu = 0;
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 64, 0));
+        slot = per_cu;
+    }
+    *out = slot;
+    return Q1ENV_OK;
+}
+
+static int pair_blocks_per_cu_of(q1env_t* h, int shape, int* out) {
+    int& slot = h->pair_blocks_per_cu[shape];
+    if (slot < 0) {
+        const void* fn = nullptr;
+        const bool spec = is_spec(h->p);
+#define Q1_FN(K, ES) fn = spec ? (const void*)K<true, ES> : (const void*)K<false, ES>
+        Q1_FOR_SHAPE(shape, Q1_FN)
 #undef Q1_FN
         int per_cu = 0;
         HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 64, 0));
@@ -1828,7 +1859,7 @@ static int server_envs_per_lane(q1env_t* h, const char* who, int* e_idx_out) {
     long best = 0;
     for (int e = 0; e < 3; ++e) {
         int per_cu = 0;
-        if (int rc = resident_blocks_per_cu(h, false, e, &per_cu)) return rc;
+        if (int rc = server_blocks_per_cu_of(h, e, &per_cu)) return rc;
         const long max_envs = (long)h->num_cus * (per_cu > 4 ? per_cu - 4 : 0) * 64 * (1L << e);
         if ((long)h->p.n <= max_envs) { *e_idx_out = e; return Q1ENV_OK; }
         if (max_envs > best) best = max_envs;
@@ -1918,44 +1949,47 @@ int q1env_step_persistent_pair(q1env_t* h, int ticks, uint32_t tag0, const uint8
         return fail(Q1ENV_ERR_INVALID_ARG, "q1env_step_persistent_pair: null argument");
     if (ticks <= 0 || !(timeout_s > 0.0) || timeout_s > 30.0) return fail(Q1ENV_ERR_INVALID_ARG, "q1env_step_persistent_pair: bad ticks / timeout_s");
     DeviceGuard guard(h->device);
-    // one dispatch of server + driver waves: co-resident iff the grid fits the device (smallest envs-per-lane that does)
-    int e_idx = -1;
+    // one dispatch of server + driver waves: co-resident iff the grid fits the device (first shape that does)
+    int shape = -1;
+    unsigned server_blocks = 0, driver_blocks = 0;
     long best = 0;
-    for (int e = 0; e < 3 && e_idx < 0; ++e) {
+    const char* forced = getenv("Q1ENV_SERVER_SHAPE");
+    const bool pad = knob_on("Q1ENV_SERVER_PAD");
+    for (int k = 0; k < N_PAIR_SHAPES && shape < 0; ++k) {
+        if (forced && forced[0] >= '0' && forced[0] < '0' + N_PAIR_SHAPES && k != forced[0] - '0') continue;
+        const int es = PAIR_SHAPES[k].es;
         int per_cu = 0;
-        if (int rc = resident_blocks_per_cu(h, true, e, &per_cu)) return rc;
-        const long max_envs = (long)h->num_cus * per_cu / 2 * 64 * (1L << e);
-        if ((long)h->p.n <= max_envs) e_idx = e;
+        if (int rc = pair_blocks_per_cu_of(h, k, &per_cu)) return rc;
+        const long resident = (long)h->num_cus * per_cu;
+        const unsigned per_block = 64u * (unsigned)es;
+        // speed only: with B a multiple of 8, block b and block B + b meet on one XCD under round-robin placement (q1server.hpp)
+        unsigned bs = ((unsigned)h->p.n + per_block - 1u) / per_block;
+        const unsigned padded = (bs + 7u) & ~7u;
+        if (pad && 2L * padded <= resident) bs = padded;
+        const long max_envs = resident / 2 * per_block;
         if (max_envs > best) best = max_envs;
+        if (2L * bs <= resident) { shape = k; server_blocks = bs; driver_blocks = bs; }
     }
-    if (e_idx < 0)
+    if (shape < 0)
         return fail(Q1ENV_ERR_INVALID_ARG, "q1env_step_persistent_pair: too many envs for one resident grid (" + std::to_string(best) +
                                            " at most on this device)");
-    const unsigned per_block = 64u << e_idx;
-    unsigned blocks = ((unsigned)h->p.n + per_block - 1u) / per_block;
-    {   // speed only: with B a multiple of 8, block b and block B + b meet on one XCD under round-robin placement (q1server.hpp)
-        int per_cu = 0;
-        if (int rc = resident_blocks_per_cu(h, true, e_idx, &per_cu)) return rc;
-        const unsigned padded = (blocks + 7u) & ~7u;
-        if (2L * padded <= (long)h->num_cus * per_cu && knob_on("Q1ENV_SERVER_PAD")) blocks = padded;
-    }
     const uint64_t timeout_ticks = (uint64_t)(timeout_s * 1.0e8);
-    const dim3 g(2u * blocks), b(64);
+    const dim3 g(server_blocks + driver_blocks), b(64);
     NearBufs near;
     if (int rc = near_bufs(h, tag0, ticks, &near)) return rc;
     const bool t_start = (auto_reset & Q1ENV_TIMER_START) != 0, t_stop = (auto_reset & Q1ENV_TIMER_STOP) != 0;
     auto_reset &= 1;
     if (t_start) HIP_TRY(hipEventRecord(h->ev0, h->stream));
-#define Q1_LAUNCH(E)                                                                                                                     \
-    if (is_spec(h->p))                                                                                                                   \
-        hipLaunchKernelGGL((tick_pair_kernel<true, E>), g, b, 0, h->stream, h->p, h->st, ticks, tag0, mailbox_dev, results_dev, near,    \
-                           obs_final_dev, seed, h->tick_count, auto_reset, keys_dev, mouse_dev, checksum_dev, status_dev, timeout_ticks, \
-                           server_backoff());                                                                                            \
-    else                                                                                                                                 \
-        hipLaunchKernelGGL((tick_pair_kernel<false, E>), g, b, 0, h->stream, h->p, h->st, ticks, tag0, mailbox_dev, results_dev, near,   \
-                           obs_final_dev, seed, h->tick_count, auto_reset, keys_dev, mouse_dev, checksum_dev, status_dev, timeout_ticks, \
-                           server_backoff())
-    Q1_FOR_E(e_idx, Q1_LAUNCH)
+#define Q1_LAUNCH(K, ES)                                                                                                                   \
+    if (is_spec(h->p))                                                                                                                     \
+        hipLaunchKernelGGL((K<true, ES>), g, b, 0, h->stream, h->p, h->st, ticks, tag0, mailbox_dev, results_dev, near,                 \
+                           obs_final_dev, seed, h->tick_count, auto_reset, keys_dev, mouse_dev, checksum_dev, status_dev, timeout_ticks,   \
+                           server_backoff(), server_blocks);                                                                               \
+    else                                                                                                                                   \
+        hipLaunchKernelGGL((K<false, ES>), g, b, 0, h->stream, h->p, h->st, ticks, tag0, mailbox_dev, results_dev, near,                \
+                           obs_final_dev, seed, h->tick_count, auto_reset, keys_dev, mouse_dev, checksum_dev, status_dev, timeout_ticks,   \
+                           server_backoff(), server_blocks)
+    Q1_FOR_SHAPE(shape, Q1_LAUNCH)
 #undef Q1_LAUNCH
     HIP_TRY(hipGetLastError());
     if (t_stop) HIP_TRY(hipEventRecord(h->ev1, h->stream));

@@ -47,7 +47,7 @@ __device__ __forceinline__ bool peer_is_near(uint32_t bits, uint32_t my_xcc) { r
 // Poll pacing, in units of s_sleep(1) (64 clocks): `first_*` before the first poll of a tick - the other side needs at least a hop
 // plus its own work before anything new can be there, and thousands of waves polling early only load the fabric the hand-offs
 // travel through - and `between` after every failed poll.
-struct Backoff { int first_server, first_driver, between; };
+struct Backoff { int first_server, first_driver, between, diag; };     // diag != 0: driver waves count their XCD-local sub-batches into status[5..6] (status must then have 8 words)
 
 __device__ __forceinline__ void nap(int units) {
     for (int k = 0; k < units; ++k) __builtin_amdgcn_s_sleep(1);
@@ -228,24 +228,44 @@ __device__ __forceinline__ void tick_server_body(const Params& p, const StatePtr
 }
 
 // The reference driver of the tick server: a DEPENDENT producer, i.e. what a policy is to the env - it hands tick t+1's action
-// over only after ALL result granules of tick t of the same env have arrived (one poll round: the four pair loads of a lane are in
-// flight together).  Actions come from a resident tick-major packed episode (keys uint8[T][N], mouse float[T][N]); checksum
-// (optional, double[2][N]) accumulates the rewards and the first observation column it received, so the data really makes the
-// round trip.  E envs per lane, sub-batch by sub-batch like the server; resident next to it.
-template <int E>
-__device__ __forceinline__ void tick_driver_body(int n_, uint32_t block, int ticks, uint32_t tag0, const uint8_t* keys, const float* mouse,
+// over only after ALL result granules of tick t of the same env have arrived.  Actions come from a resident tick-major packed
+// episode (keys uint8[T][N], mouse float[T][N]); checksum (optional, double[2][N]) accumulates the rewards and the first
+// observation column it received, so the data really makes the round trip.
+// A driver wave feeds the server wave of the same block index (ED = ES sub-batches of 64 envs; block d and server block d meet on
+// one XCD when the dispatcher places blocks round-robin and the server half is a multiple of 8 blocks - speed only, verified per
+// pair).  The result polls of up to four sub-batches are in flight TOGETHER (a poll is an L2 round trip of ~0.4 us even when the
+// granule is there): each round requests the pending sub-batches of the group, then consumes those that have arrived and hands
+// their next action over at once.
+typedef uint32_t u32x4v __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t granule_rsrc(const uint64_t* base, uint32_t bytes) {
+    // (wave-uniform by construction: kernel arguments only)
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<uint64_t*>(base), 0, bytes, 0x00020000);
+}
+// 16-byte L1-bypassing (sc1) load the compiler can see: several stay in flight, its own s_waitcnt before the first use
+__device__ __forceinline__ u32x4v granule_pair_load_sc1(__amdgpu_buffer_rsrc_t r, uint32_t byte_offset) {
+    return __builtin_amdgcn_raw_buffer_load_b128(r, byte_offset, 0, 16);
+}
+
+template <int ED>
+__device__ __forceinline__ void tick_driver_body(int n_, uint32_t dblock, int ticks, uint32_t tag0, const uint8_t* keys, const float* mouse,
                                                  uint64_t* mailbox, const uint64_t* results, NearBufs near, double* checksum,
                                                  uint32_t* status, uint64_t timeout_ticks, Backoff bo) {
+    constexpr int GROUP = ED < 4 ? ED : 4;
+    static_assert(ED % GROUP == 0, "sub-batches are polled in full groups");
     const uint32_t lane = threadIdx.x, n = (uint32_t)n_;
     const uint32_t my_xcc = xcc_id();
     const bool has_near = near.mailbox != nullptr;
-    uint32_t idx[E];
-    bool live[E];
-    bool near_peer[E];                   // the server wave of this sub-batch is known to sit on this XCD (from its last results)
-    double acc_r[E], acc_o[E];
+    const uint32_t result_bytes = n * 64u;                                 // uint64[4][N][2]
+    const __amdgpu_buffer_rsrc_t far_rsrc = granule_rsrc(results, result_bytes);
+    const __amdgpu_buffer_rsrc_t near_rsrc = granule_rsrc(has_near ? near.results : results, result_bytes);
+    uint32_t idx[ED];
+    bool live[ED];
+    bool near_peer[ED];                  // the server wave of this sub-batch is known to sit on this XCD (from its last results)
+    double acc_r[ED], acc_o[ED];
 #pragma unroll
-    for (int e = 0; e < E; ++e) {
-        idx[e] = (block * (uint32_t)E + (uint32_t)e) * 64u + lane;
+    for (int e = 0; e < ED; ++e) {
+        idx[e] = (dblock * (uint32_t)ED + (uint32_t)e) * 64u + lane;
         live[e] = idx[e] < n;
         near_peer[e] = false;
         acc_r[e] = 0.0; acc_o[e] = 0.0;
@@ -253,48 +273,95 @@ __device__ __forceinline__ void tick_driver_body(int n_, uint32_t block, int tic
     bool timed_out = false;
     int handed = 0;
     for (int t = 0; t < ticks && !timed_out; ++t) {
+        const uint64_t tag = tick_tag(tag0, (uint32_t)t);
+        const uint64_t want = tick_tag(tag0, t > 0 ? (uint32_t)t - 1u : 0u);          // results of tick t-1
+        // tick t's actions are fetched before the waits: their latency hides under the server's tick
+        uint32_t k[ED];
+        float m[ED];
 #pragma unroll
-        for (int e = 0; e < E; ++e) {
-            const uint32_t i = idx[e];
-            // tick t's action is fetched before the wait: its latency hides under the server's tick
-            const uint32_t k = live[e] ? keys[(size_t)t * n + i] : 0u;
-            const float m = live[e] ? mouse[(size_t)t * n + i] : 0.0f;
-            if (t > 0) {
-                const uint64_t want = tick_tag(tag0, (uint32_t)t - 1u);          // results of tick t-1
-                uint64_t g[8];
-                if (e == 0) nap(bo.first_driver);
-                // tick 0's results may be in either copy (the server knows by then where this wave sits, this wave does not know
-                // the server's place yet): near-first polling covers both; afterwards only a near server is polled near-first
-                const bool near_first = has_near && (t == 1 || near_peer[e]);
-                const bool got = wait_for(live[e], timeout_ticks, bo, [&](uint32_t polls) {
-                    const bool far = !near_first || (polls % NEAR_POLL_PERIOD) == NEAR_POLL_PERIOD - 1u;
-                    const uint64_t* r = far ? results : near.results;
-                    granule_pairs_load4(pair_ptr(r, n, 0u, i), pair_ptr(r, n, 1u, i), pair_ptr(r, n, 2u, i), pair_ptr(r, n, 3u, i), g);
-                    bool all = true;
+        for (int e = 0; e < ED; ++e) {
+            k[e] = live[e] ? keys[(size_t)t * n + idx[e]] : 0u;
+            m[e] = live[e] ? mouse[(size_t)t * n + idx[e]] : 0.0f;
+        }
+        if (t > 0) nap(bo.first_driver);
 #pragma unroll
-                    for (int q = 0; q < RESULT_GRANULES + 1; ++q) all = all && ((g[q] >> 40) == want);
-                    return all;
-                });
-                if (!got) { timed_out = true; break; }
-                near_peer[e] = has_near && __all(!live[e] || peer_is_near((uint32_t)g[7] & 0xFu, my_xcc));
-                if (live[e]) {
-                    acc_r[e] += (double)__uint_as_float((uint32_t)g[6]);
-                    acc_o[e] += (double)__uint_as_float((uint32_t)g[0]);
+        for (int base = 0; base < ED; base += GROUP) {
+            uint32_t pending = t > 0 ? (1u << GROUP) - 1u : 0u;           // sub-batches of the group whose tick t-1 results are awaited
+            uint32_t polls = 0;
+            uint64_t t_wait = 0;
+            while (pending != 0u) {
+                // tick 0's results may be in either copy (the server knows by then where this wave sits, this wave does not know the
+                // server's place yet): near-first polling covers both; afterwards only a near server is polled near-first
+                const bool far_round = (polls % NEAR_POLL_PERIOD) == NEAR_POLL_PERIOD - 1u;
+                u32x4v v[GROUP][4];
+#pragma unroll
+                for (int q = 0; q < GROUP; ++q) {
+                    const int e = base + q;
+                    const bool near_first = has_near && (t == 1 || near_peer[e]);
+                    const __amdgpu_buffer_rsrc_t r = (!near_first || far_round) ? far_rsrc : near_rsrc;
+#pragma unroll
+                    for (uint32_t w = 0; w < 4u; ++w) v[q][w] = u32x4v{0u, 0u, 0u, 0u};
+                    if (((pending >> q) & 1u) != 0u && live[e]) {
+#pragma unroll
+                        for (uint32_t w = 0; w < 4u; ++w) v[q][w] = granule_pair_load_sc1(r, (w * n + idx[e]) * 16u);
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < GROUP; ++q) {
+                    const int e = base + q;
+                    if (((pending >> q) & 1u) == 0u) continue;
+                    bool ok = true;
+#pragma unroll
+                    for (uint32_t w = 0; w < 4u; ++w)
+                        ok = ok && ((uint64_t)(v[q][w][1] >> 8) == want) && ((uint64_t)(v[q][w][3] >> 8) == want);      // tag = bits 40..63 of each granule
+                    if (!__all(!live[e] || ok)) continue;
+                    pending &= ~(1u << q);
+                    near_peer[e] = has_near && __all(!live[e] || peer_is_near(v[q][3][2] & 0xFu, my_xcc));               // granule 7's payload
+                    if (live[e]) {
+                        acc_r[e] += (double)__uint_as_float(v[q][3][0]);                                                  // granule 6: reward
+                        acc_o[e] += (double)__uint_as_float(v[q][0][0]);                                                  // granule 0: obs[0]
+                        const uint64_t a = (tag << 40) | ((uint64_t)(has_near ? (PEER_VALID | my_xcc) : 0u) << 36) | ((uint64_t)(k[e] & 0xFu) << 32) |
+                                           (uint64_t)__float_as_uint(m[e]);
+                        if (near_peer[e]) granule_store_near(near.mailbox + idx[e], a);
+                        else granule_store(mailbox + idx[e], a);
+                    }
+                }
+                if (pending != 0u) {
+                    nap(bo.between);
+                    if ((++polls & 255u) == 0u) {                        // (the 100 MHz clock is only looked at every 256 failed rounds)
+                        const uint64_t now = wall_clock64();
+                        if (t_wait == 0) t_wait = now;
+                        else if (now - t_wait > timeout_ticks) { timed_out = true; break; }
+                        __builtin_amdgcn_s_sleep(8);
+                    }
                 }
             }
-            const uint64_t tag = tick_tag(tag0, (uint32_t)t);
-            if (live[e]) {
-                const uint64_t a = (tag << 40) | ((uint64_t)(has_near ? (PEER_VALID | my_xcc) : 0u) << 36) | ((uint64_t)(k & 0xFu) << 32) |
-                                   (uint64_t)__float_as_uint(m);
-                if (has_near && (t == 0 || near_peer[e])) granule_store_near(near.mailbox + i, a);
-                if (t == 0 || !near_peer[e]) granule_store(mailbox + i, a);
-            }
+            if (timed_out) break;
         }
-        if (!timed_out) handed = t + 1;
+        if (timed_out) break;
+        if (t == 0) {
+            // the first tick of a launch travels agent-scope AND XCD-local: neither side knows the other's place yet
+#pragma unroll
+            for (int e = 0; e < ED; ++e)
+                if (live[e]) {
+                    const uint64_t a = (tag << 40) | ((uint64_t)(has_near ? (PEER_VALID | my_xcc) : 0u) << 36) | ((uint64_t)(k[e] & 0xFu) << 32) |
+                                       (uint64_t)__float_as_uint(m[e]);
+                    if (has_near) granule_store_near(near.mailbox + idx[e], a);
+                    granule_store(mailbox + idx[e], a);
+                }
+        }
+        handed = t + 1;
     }
 #pragma unroll
-    for (int e = 0; e < E; ++e)
+    for (int e = 0; e < ED; ++e)
         if (live[e] && checksum) { checksum[idx[e]] += acc_r[e]; checksum[(size_t)n + idx[e]] += acc_o[e]; }
+    if (bo.diag != 0 && lane == 0) {                             // measurement knob (Q1ENV_SERVER_DIAG): how many sub-batches ended XCD-local
+        uint32_t near_count = 0, total = 0;
+#pragma unroll
+        for (int e = 0; e < ED; ++e) { near_count += near_peer[e] ? 1u : 0u; total += (idx[e] - lane) < n ? 1u : 0u; }
+        atomicAdd(&status[5], near_count);
+        atomicAdd(&status[6], total);
+    }
     if (lane == 0 && handed != ticks) {
         if (timed_out) atomicOr(&status[3], 1u);
         atomicMax(&status[4], (uint32_t)(ticks - handed));       // actions the slowest wave did not hand over
@@ -366,22 +433,38 @@ tick_driver_kernel(int n, int ticks, uint32_t tag0, const uint8_t* keys, const f
     tick_driver_body<E>(n, blockIdx.x, ticks, tag0, keys, mouse, mailbox, results, near, checksum, status, timeout_ticks, bo);
 }
 
-// Server and reference driver in ONE dispatch (q1env_step_persistent_pair): blocks [0, B) are the server's waves, blocks [B, 2B) the
-// driver's.  Two streams are only concurrent when the runtime maps them to different hardware queues, which HIP does not
-// promise (a process that has created many streams re-uses queues: the producer then queues BEHIND the server it feeds and both
-// sides can only time out).  One grid that fits the device is co-resident by construction - this is what the benchmark and most
-// tests use; the two-stream entry points remain for an external producer.  The host pads B to a multiple of 8 (blocks whose envs are
-// all beyond n idle through the loop), so that with the round-robin block -> XCD placement the dispatcher is observed to use, server
-// block b and its driver block B + b share an XCD and take the XCD-local path (verified per wave pair at run time, never assumed).
-template <bool SPEC, int E>
+// Server and reference driver in ONE dispatch (q1env_step_persistent_pair): blocks [0, B) are the server's waves (ES sub-batches of 64
+// envs each), blocks [B, 2B) the driver's.  Two streams are only concurrent when the runtime maps them to different hardware
+// queues, which HIP does not promise (a process that has created many streams re-uses queues: the producer then queues BEHIND the
+// server it feeds and both sides can only time out).  One grid that fits the device is co-resident by construction - this is what
+// the benchmark and most tests use; the two-stream entry points remain for an external producer.  The host pads B to a multiple of
+// 8 (blocks whose envs are all beyond n idle through the loop), so that with the round-robin block -> XCD placement the dispatcher
+// is observed to use, server block b and its driver block B + b share an XCD and take the XCD-local path (verified per wave pair at
+// run time, never assumed).
+#define Q1_PAIR_KERNEL_BODY                                                                                                                   \
+    if (blockIdx.x < server_blocks)                                                                                                           \
+        tick_server_body<SPEC, ES>(p, s, blockIdx.x, ticks, tag0, mailbox, results, near, obs_final, seed, counter0, auto_reset, status,     \
+                                   timeout_ticks, bo);                                                                                        \
+    else                                                                                                                                      \
+        tick_driver_body<ES>(p.n, blockIdx.x - server_blocks, ticks, tag0, keys, mouse, mailbox, results, near, checksum, status,            \
+                             timeout_ticks, bo)
+
+template <bool SPEC, int ES>
 __global__ void __launch_bounds__(64)
 tick_pair_kernel(Params p, StatePtrs s, int ticks, uint32_t tag0, uint64_t* mailbox, uint64_t* results, NearBufs near, float* obs_final,
                  uint64_t seed, uint64_t counter0, int auto_reset, const uint8_t* keys, const float* mouse, double* checksum,
-                 uint32_t* status, uint64_t timeout_ticks, Backoff bo) {
-    const uint32_t half = gridDim.x >> 1;
-    if (blockIdx.x < half)
-        tick_server_body<SPEC, E>(p, s, blockIdx.x, ticks, tag0, mailbox, results, near, obs_final, seed, counter0, auto_reset, status, timeout_ticks, bo);
-    else
-        tick_driver_body<E>(p.n, blockIdx.x - half, ticks, tag0, keys, mouse, mailbox, results, near, checksum, status, timeout_ticks, bo);
+                 uint32_t* status, uint64_t timeout_ticks, Backoff bo, uint32_t server_blocks) {
+    Q1_PAIR_KERNEL_BODY;
 }
 
+// The same dispatch compiled for FOUR waves per SIMD (at most 128 VGPRs; no spills at ES = 1): 131 072 envs are resident at one env
+// per lane, with two server waves per SIMD overlapping their float64 chains (3.3 -> 2.6 us per tick against two envs per lane), and
+// smaller batches are no slower than with the 142 registers the compiler takes when left alone.
+template <bool SPEC, int ES>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
+tick_pair_kernel_dense(Params p, StatePtrs s, int ticks, uint32_t tag0, uint64_t* mailbox, uint64_t* results, NearBufs near, float* obs_final,
+                       uint64_t seed, uint64_t counter0, int auto_reset, const uint8_t* keys, const float* mouse, double* checksum,
+                       uint32_t* status, uint64_t timeout_ticks, Backoff bo, uint32_t server_blocks) {
+    Q1_PAIR_KERNEL_BODY;
+}
+#undef Q1_PAIR_KERNEL_BODY
