@@ -18,7 +18,9 @@ gcc -O1 -fPIC -shared tools/asan_shim.c -o $OUT/libasan_shim.so > $OUT/build.log
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O1 -g -std=c++17 -ffp-contract=off -fPIC -shared -Wall -Wno-unused-function \
     -mllvm -amdgpu-kernarg-preload-count=16 -fsanitize=address -fno-gpu-sanitize \
     q1physrl_amd/csrc/q1env.hip -o $SO >> $OUT/build.log 2>&1 || { echo "ASAN BUILD FAILED"; tail -5 $OUT/build.log | cut -c1-300; exit 2; }
-RT="$(readlink -f "$(gcc -print-file-name=libasan.so)") $ROOT/$OUT/libasan_shim.so"
+# (libstdc++ rides along so that the runtime finds the real __cxa_throw when it initialises: torch's lazy device initialisation throws
+# and catches a C++ exception, and GCC's ASan aborts with a CHECK if it had no libstdc++ to resolve the interceptor's target in)
+RT="$(readlink -f "$(gcc -print-file-name=libasan.so)") $(readlink -f "$(gcc -print-file-name=libstdc++.so.6)") $ROOT/$OUT/libasan_shim.so"
 # canary: the same toolchain + runtime must catch a deliberate overflow
 /opt/rocm/lib/llvm/bin/clang -O1 -g -fPIC -shared -fsanitize=address tools/asan_canary.c -o $OUT/libcanary.so >> $OUT/build.log 2>&1
 rm -f $OUT/canary.*
@@ -32,7 +34,9 @@ LD_PRELOAD="$RT" python -m pytest tests/test_abi_symbols.py -q -x -p no:cachepro
 rc1=$?
 rc2=0
 if python -c "import torch,sys; sys.exit(0 if torch.cuda.is_available() else 1)" 2>/dev/null; then
-    LD_PRELOAD="$RT" timeout 600 python tools/asan_gpu_calls.py > $OUT/gpu.log 2>&1
+    # (dlopen goes through the sanitizer's interceptor, so libtorch's RPATH no longer finds its own lazily loaded libraries)
+    TORCH_LIB=$(python -c "import importlib.util, os; print(os.path.join(os.path.dirname(importlib.util.find_spec('torch').origin), 'lib'))")
+    LD_LIBRARY_PATH="$TORCH_LIB:${LD_LIBRARY_PATH:-}" LD_PRELOAD="$RT" timeout 600 python tools/asan_gpu_calls.py > $OUT/gpu.log 2>&1
     rc2=$?
 fi
 n=$(ls $OUT/report.* 2>/dev/null | wc -l)

@@ -37,5 +37,20 @@ for n in (1, 63, 4097, 16384, 16385, 70001):
         out = P.apply(ins, ps)
         assert out.vel.dtype == dt
     print("ok", n, flush=True)
+# the resident tick server's host side (shape selection, the handle-owned XCD-local copies and their wipes on non-continuing tags)
+import torch
+from q1physrl_amd.tensor_env import TensorVectorEnv
+for n in (130, 4096 + 37, 70001):
+    tv = TensorVectorEnv(E.Config(**dict(E.Config.get_default().__dict__, num_envs=n, time_limit=0.3)), device=0, seed=3)
+    tv.reset()
+    keys = torch.randint(0, 16, (40, n), dtype=torch.uint8, device="cuda")
+    mouse = (torch.rand((40, n), device="cuda") * 20 - 10).contiguous()
+    for two in (False, True, False):
+        r = tv.serve_ticks(keys, mouse, two_streams=two)
+        assert not r["status"].any()
+    tv._srv["tag"] = 12345                       # a launch that does not continue the tag sequence: the copies are wiped first
+    assert not tv.serve_ticks(keys, mouse)["status"].any()
+    tv.close()
+    print("ok server", n, flush=True)
 _lib.pinned_pool().trim()
 print("ASAN_GPU_CALLS_OK")
