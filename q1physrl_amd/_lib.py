@@ -47,6 +47,14 @@ class Q1Mlp(C.Structure):             # q1env_mlp
                 ("out", C.c_void_p), ("out_dim", C.c_int)]
 
 
+class Q1ResidentArgs(C.Structure):   # q1env_resident_args
+    _fields_ = [("ticks", C.c_int), ("tag0", C.c_uint32), ("pi", C.POINTER(Q1Mlp)), ("seed", C.c_uint64), ("counter_dev", C.c_void_p),
+                ("counter_offset", C.c_uint64), ("deterministic", C.c_int), ("keys_dev", C.c_void_p), ("mouse_dev", C.c_void_p),
+                ("logp_dev", C.c_void_p), ("obs_dev", C.c_void_p), ("reward_dev", C.c_void_p), ("done_dev", C.c_void_p),
+                ("zero_start_dev", C.c_void_p), ("ep_return_dev", C.c_void_p), ("partials_dev", C.c_void_p), ("mailbox_dev", C.c_void_p),
+                ("results_dev", C.c_void_p), ("status_dev", C.c_void_p), ("timeout_s", C.c_double)]
+
+
 STATE_FIELDS = (("vel_x", np.float32, 1), ("vel_y", np.float32, 1), ("vel_z", np.float32, 1),
                 ("pos_x", np.float64, 1), ("pos_y", np.float64, 1), ("z_pos", np.float64, 1),
                 ("yaw", np.float64, 1), ("time_remaining", np.float64, 1),
@@ -96,6 +104,8 @@ _SIGNATURES = {
     "q1env_step_persistent_publish": (C.c_int, [_P, _P, C.c_uint32, C.c_uint32, _P, _P, _P]),
     "q1env_step_persistent_collect": (C.c_int, [_P, _P, C.c_uint32, C.c_uint32, _P, _P, _P, _P, _P, _P, C.c_double]),
     "q1env_step_persistent_pair": (C.c_int, [_P, C.c_int, C.c_uint32, _P, _P, _P, _P, _P, C.c_uint64, C.c_int, _P, _P, C.c_double]),
+    "q1env_policy_forward_rows": (C.c_int, [_P, C.c_uint64, _P, _P]),
+    "q1env_sample_resident": (C.c_int, [_P, _P]),
     "q1env_selftest_division": (C.c_int, [C.c_int, C.c_uint64, C.c_uint64, C.c_double, C.c_double, C.POINTER(C.c_uint64)]),
     "q1env_calibrate_traffic": (C.c_int, [_P, C.c_int]),
     "q1env_timer_start": (C.c_int, [_P]),

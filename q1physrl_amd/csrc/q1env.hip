@@ -649,6 +649,7 @@ __global__ void counter_add_kernel(uint64_t* counter, uint64_t by) {
 }
 
 #include "q1server.hpp"       // tick_server_kernel / tick_driver_kernel / tick_pair_kernel (the resident tick server)
+#include "q1resident.hpp"     // sampler_resident_kernel (a sampling horizon as one dispatch)
 
 // Traffic calibration for the PMC counters (MI355X_MICROARCH.md "HBM": FETCH_SIZE / WRITE_SIZE must be calibrated on
 // a known byte count in the kernel's own access pattern): reads every SoA state array with exactly the loads
@@ -797,6 +798,7 @@ struct q1env {
     uint64_t* near_buf = nullptr;     // XCD-local copies of the tick server's hand-off buffers (mailbox uint64[N] + results uint64[4][N][2])
     uint32_t near_next_tag = 0;       // the tag0 that continues the last launch (the copies hold no tag a continuing launch could match)
     bool near_stale = false;          // a launch ran without the copies: wipe them before the next use
+    bool resident_attr_set = false;   // the resident sampler's dynamic-LDS attribute
     bool mlp_attr_set = false;        // dynamic-LDS attribute of the policy kernels (a per-device setting: kept per handle)
     // cached hipGraphs of step_many, keyed by (ticks, formats, pointers); a handful of entries, oldest evicted
     struct GraphEntry { std::vector<uint64_t> key; hipGraphExec_t exec; };
@@ -1699,7 +1701,8 @@ int q1env_sample_step(q1env_t* h, const float* logits, int row_stride, uint64_t 
     return Q1ENV_OK;
 }
 
-static int launch_mlp(q1env* h, const float* obs, const q1pol::Net& na, const q1pol::Net& nb, int nets) {
+static int launch_mlp(q1env* h, const float* obs, const q1pol::Net& na, const q1pol::Net& nb, int nets, unsigned rows = 0) {
+    const unsigned n = rows ? rows : (unsigned)h->p.n;
     if (!h->mlp_attr_set) {
         HIP_TRY(hipFuncSetAttribute((const void*)q1pol::mlp_forward_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)q1pol::LDS_TOTAL));
         HIP_TRY(hipFuncSetAttribute((const void*)q1pol::mlp_forward_kernel<512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)q1pol::LDS_TOTAL));
@@ -1709,15 +1712,15 @@ static int launch_mlp(q1env* h, const float* obs, const q1pol::Net& na, const q1
     // one wave per SIMD; beyond that two waves per SIMD.  Q1ENV_MLP_THREADS overrides (measurement only).
     static const int forced = [] { const char* e = getenv("Q1ENV_MLP_THREADS"); return e ? atoi(e) : 0; }();
     const unsigned cus = (unsigned)(nets == 2 ? (h->num_cus > 1 ? h->num_cus / 2 : 1) : h->num_cus);   // CUs per network
-    const int threads = forced == 256 || forced == 512 ? forced : ((unsigned)h->p.n <= cus * 4u * 32u ? 256 : 512);
+    const int threads = forced == 256 || forced == 512 ? forced : (n <= cus * 4u * 32u ? 256 : 512);
     const unsigned per_block = 32u * (unsigned)(threads / 64);                   // envs one workgroup covers per grid-stride pass
-    unsigned blocks = ((unsigned)h->p.n + per_block - 1u) / per_block;
+    unsigned blocks = (n + per_block - 1u) / per_block;
     if (blocks > cus) blocks = cus;
     const dim3 g(blocks * (unsigned)nets), b(threads);
     if (threads == 256)
-        hipLaunchKernelGGL(q1pol::mlp_forward_kernel<256>, g, b, q1pol::LDS_TOTAL, h->stream, h->p.n, obs, na, nb, nets);
+        hipLaunchKernelGGL(q1pol::mlp_forward_kernel<256>, g, b, q1pol::LDS_TOTAL, h->stream, (int)n, obs, na, nb, nets);
     else
-        hipLaunchKernelGGL(q1pol::mlp_forward_kernel<512>, g, b, q1pol::LDS_TOTAL, h->stream, h->p.n, obs, na, nb, nets);
+        hipLaunchKernelGGL(q1pol::mlp_forward_kernel<512>, g, b, q1pol::LDS_TOTAL, h->stream, (int)n, obs, na, nb, nets);
     HIP_TRY(hipGetLastError());
     return Q1ENV_OK;
 }
@@ -1741,6 +1744,16 @@ int q1env_policy_value_forward(q1env_t* h, const float* obs, const q1env_mlp* pi
     const q1pol::Net na{pi->w1, pi->b1, pi->w23_image, pi->b2, pi->b3, pi->out, pi->out_dim};
     const q1pol::Net nb{vf->w1, vf->b1, vf->w23_image, vf->b2, vf->b3, vf->out, vf->out_dim};
     return launch_mlp(h, obs, na, nb, 2);
+}
+
+int q1env_policy_forward_rows(q1env_t* h, uint64_t rows, const float* obs, const q1env_mlp* m) {
+    if (!h || !obs || !m || !m->w1 || !m->b1 || !m->w23_image || !m->b2 || !m->b3 || !m->out)
+        return fail(Q1ENV_ERR_INVALID_ARG, "q1env_policy_forward_rows: null argument");
+    if (m->out_dim < 1 || m->out_dim > 32) return fail(Q1ENV_ERR_INVALID_ARG, "q1env_policy_forward_rows: out_dim must be in 1..32");
+    if (rows == 0 || rows > 0x7FFFFFFFull / 32u) return fail(Q1ENV_ERR_INVALID_ARG, "q1env_policy_forward_rows: rows out of range");
+    DeviceGuard guard(h->device);
+    const q1pol::Net net{m->w1, m->b1, m->w23_image, m->b2, m->b3, m->out, m->out_dim};
+    return launch_mlp(h, obs, net, net, 1, (unsigned)rows);
 }
 
 // ---- persistent tick server -----------------------------------------------------------------------------------------------
@@ -1994,6 +2007,59 @@ int q1env_step_persistent_pair(q1env_t* h, int ticks, uint32_t tag0, const uint8
     HIP_TRY(hipGetLastError());
     if (t_stop) HIP_TRY(hipEventRecord(h->ev1, h->stream));
     h->tick_count += (uint64_t)ticks;
+    return Q1ENV_OK;
+}
+
+// ---- resident sampler ----------------------------------------------------------------------------------------------------
+int q1env_sample_resident(q1env_t* h, const q1env_resident_args* a) {
+    if (!h || !a || !a->pi) return fail(Q1ENV_ERR_INVALID_ARG, "q1env_sample_resident: null argument");
+    const q1env_mlp* m = a->pi;
+    if (!m->w1 || !m->b1 || !m->w23_image || !m->b2 || !m->b3) return fail(Q1ENV_ERR_INVALID_ARG, "q1env_sample_resident: null pointer in q1env_mlp");
+    if (!a->keys_dev || !a->logp_dev || !a->obs_dev || !a->reward_dev || !a->done_dev || !a->ep_return_dev || !a->partials_dev ||
+        !a->mailbox_dev || !a->results_dev || !a->status_dev)
+        return fail(Q1ENV_ERR_INVALID_ARG, "q1env_sample_resident: null trajectory / scratch pointer");
+    if (a->ticks <= 0 || !(a->timeout_s > 0.0) || a->timeout_s > 30.0) return fail(Q1ENV_ERR_INVALID_ARG, "q1env_sample_resident: bad ticks / timeout_s");
+    if (h->p.yaw_mode == 2) return fail(Q1ENV_ERR_INVALID_ARG, "q1env_sample_resident: discrete-mouse policies are not supported (use q1env_sample_step)");
+    const int width = 2 * (h->p.num_keys + (h->p.yaw_mode == 1 ? 1 : 0));
+    if (m->out_dim != width) return fail(Q1ENV_ERR_INVALID_ARG, "q1env_sample_resident: pi->out_dim must be " + std::to_string(width));
+    if (h->p.yaw_mode == 1 && !a->mouse_dev) return fail(Q1ENV_ERR_INVALID_ARG, "q1env_sample_resident: mouse trajectory required");
+    DeviceGuard guard(h->device);
+    if (!h->resident_attr_set) {
+        HIP_TRY(hipFuncSetAttribute((const void*)sampler_resident_kernel<true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)q1pol::LDS_TOTAL));
+        HIP_TRY(hipFuncSetAttribute((const void*)sampler_resident_kernel<true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)q1pol::LDS_TOTAL));
+        HIP_TRY(hipFuncSetAttribute((const void*)sampler_resident_kernel<false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)q1pol::LDS_TOTAL));
+        HIP_TRY(hipFuncSetAttribute((const void*)sampler_resident_kernel<false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)q1pol::LDS_TOTAL));
+        h->resident_attr_set = true;
+    }
+    // one workgroup per CU (LDS): Be env blocks (padded to a multiple of 8: XCD affinity of the block mapping, speed only) and
+    // Be * 2 / TP policy blocks must all be resident
+    const unsigned n = (unsigned)h->p.n;
+    const unsigned be = ((n + 511u) / 512u + 7u) & ~7u;
+    int tp = 0;
+    if (3u * be <= (unsigned)h->num_cus) tp = 1;
+    else if (2u * be <= (unsigned)h->num_cus) tp = 2;
+    if (const char* f = getenv("Q1ENV_RESIDENT_TP")) { if (f[0] == '2' && 2u * be <= (unsigned)h->num_cus) tp = 2; }      // measurement knob
+    if (!tp)
+        return fail(Q1ENV_ERR_INVALID_ARG, "q1env_sample_resident: too many envs for one resident grid (" +
+                                           std::to_string((unsigned)h->num_cus / 2u / 8u * 8u * 512u) + " at most on this device)");
+    NearBufs near;
+    if (int rc = near_bufs(h, a->tag0, a->ticks, &near)) return rc;
+    ResidentArgs k{};
+    k.ticks = a->ticks; k.tag0 = a->tag0; k.env_blocks = be;
+    k.pi = q1pol::Net{m->w1, m->b1, m->w23_image, m->b2, m->b3, m->out, m->out_dim};
+    k.seed = a->seed; k.counter_offset = a->counter_offset + (a->counter_dev ? 0 : h->tick_count); k.counter_dev = a->counter_dev;
+    k.deterministic = a->deterministic;
+    k.keys = a->keys_dev; k.mouse = a->mouse_dev; k.logp = a->logp_dev; k.obs = a->obs_dev; k.reward = a->reward_dev; k.done = a->done_dev;
+    k.zero_start = a->zero_start_dev; k.ep_return = a->ep_return_dev; k.partials = a->partials_dev;
+    k.mailbox = a->mailbox_dev; k.results = a->results_dev; k.near = near; k.status = a->status_dev;
+    k.timeout_ticks = (uint64_t)(a->timeout_s * 1.0e8);
+    const dim3 g(be + (tp == 1 ? 2u * be : be)), b(512);
+#define Q1_LAUNCH_RS(SP, TP) hipLaunchKernelGGL((sampler_resident_kernel<SP, TP>), g, b, q1pol::LDS_TOTAL, h->stream, h->p, h->st, k)
+    if (is_spec(h->p)) { if (tp == 1) Q1_LAUNCH_RS(true, 1); else Q1_LAUNCH_RS(true, 2); }
+    else { if (tp == 1) Q1_LAUNCH_RS(false, 1); else Q1_LAUNCH_RS(false, 2); }
+#undef Q1_LAUNCH_RS
+    HIP_TRY(hipGetLastError());
+    h->tick_count += (uint64_t)a->ticks;
     return Q1ENV_OK;
 }
 

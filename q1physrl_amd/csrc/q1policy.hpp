@@ -143,6 +143,111 @@ __device__ __forceinline__ void stage_image(unsigned char* dst, const uint16_t* 
     }
 }
 
+// LDS carve-up of one network (LDS_TOTAL bytes from `lds`) and the per-lane operand row pointers of a wave
+struct LdsNet {
+    unsigned char* w2; unsigned char* w3; float* b2; unsigned char* w1;
+};
+__device__ __forceinline__ LdsNet lds_net(unsigned char* lds) {
+    return LdsNet{lds, lds + LDS_W2, reinterpret_cast<float*>(lds + LDS_W2 + LDS_W3), lds + LDS_W2 + LDS_W3 + LDS_B2};
+}
+
+// stage one network's weights into LDS (all THREADS threads of the workgroup; the caller synchronises afterwards)
+template <int THREADS>
+__device__ __forceinline__ void stage_net(unsigned char* lds, const float* __restrict__ w1, const float* __restrict__ b1,
+                                          const uint16_t* __restrict__ w23, const float* __restrict__ b2, uint32_t tid) {
+    const LdsNet l = lds_net(lds);
+    stage_image<THREADS>(lds, w23, tid);                             // W2 rows then W3 rows, contiguous in LDS
+    if (tid < (uint32_t)HID) {
+        l.b2[tid] = TANH_PRESCALE * b2[tid];
+        stage_w1_row(l.w1, tid, w1, b1);
+    }
+}
+
+// One 32-env tile through all three layers: xb = the lane's layer-1 B operand (split_inputs of its env's observation), the three
+// row pointers = this lane's operand rows in the LDS images (see the callers).  Returns Y^T without b3: y[r] = output row
+// (r&3) + 8(r>>2) + 4*half of env `col`.  (stamps: diagnostic build only - s_memtime after the prologue and after the main loop.)
+__device__ __forceinline__ f32x16 mlp_tile(const f16x8 xb, const unsigned char* w1row, const unsigned char* wrow, const unsigned char* w3row,
+                                           const float* l_b2, uint32_t half, uint64_t* stamps) {
+    const f32x16 zero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    f32x16 acc[8];                                               // H2^T pre-activations, start at b2
+#pragma unroll
+    for (int t = 0; t < 8; ++t)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 b = *reinterpret_cast<const float4*>(l_b2 + t * 32 + 8 * q + 4 * half);   // rows 8q + 4h + (0..3)
+            acc[t][4 * q + 0] = b.x; acc[t][4 * q + 1] = b.y; acc[t][4 * q + 2] = b.z; acc[t][4 * q + 3] = b.w;
+        }
+
+    // Software pipeline over the eight 32-row tiles of H1: tanh of tile t1+1 is interleaved (sched_group_barrier) with the
+    // sixteen MFMAs of tile t1; every W2 operand register is re-requested from LDS for the next K-step right after the
+    // MFMA that consumed it has been issued (operands are read at issue), i.e. eight MFMAs ahead of its next use.
+    f16x8 cur0, cur1, a_l1, a[8];
+    f32x16 dn;
+    {
+        const f16x8 a0 = *reinterpret_cast<const f16x8*>(w1row);
+        const f16x8 a1 = *reinterpret_cast<const f16x8*>(w1row + 1024u);
+        a_l1 = *reinterpret_cast<const f16x8*>(w1row + 2048u);
+        const f32x16 d0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, xb, zero16, 0, 0, 0);
+        dn = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, xb, zero16, 0, 0, 0);
+#pragma unroll
+        for (int t2 = 0; t2 < 8; ++t2) a[t2] = *reinterpret_cast<const f16x8*>(wrow + (size_t)t2 * 32u * ROW_BYTES);
+        cur0 = activate(d0, 0); cur1 = activate(d0, 1);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (stamps) stamps[0] = __builtin_amdgcn_s_memtime();
+#pragma unroll 1
+    for (int t1 = 0; t1 < 8; ++t1) {
+        const uint32_t q0 = 2u * (uint32_t)t1;
+        // phase 1: even K-step, first half of tanh(tile t1+1)
+#pragma unroll
+        for (int t2 = 0; t2 < 8; ++t2) {
+            acc[t2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[t2], cur0, acc[t2], 0, 0, 0);
+            a[t2] = *reinterpret_cast<const f16x8*>(wrow + (size_t)t2 * 32u * ROW_BYTES + (q0 + 1u) * 32u);
+        }
+        const f16x8 nxt0 = activate(dn, 0);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // phase 2: odd K-step, second half of the tanh, then layer 1 of tile t1+2 (one MFMA)
+        const f16x8 a_l1n = *reinterpret_cast<const f16x8*>(w1row + (((uint32_t)t1 + 3u) & 7u) * 1024u);
+#pragma unroll
+        for (int t2 = 0; t2 < 8; ++t2) {
+            acc[t2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[t2], cur1, acc[t2], 0, 0, 0);
+            a[t2] = *reinterpret_cast<const f16x8*>(wrow + (size_t)t2 * 32u * ROW_BYTES + ((q0 + 2u) & 15u) * 32u);
+        }
+        const f16x8 nxt1 = activate(dn, 1);
+        dn = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_l1, xb, zero16, 0, 0, 0);   // tile t1 + 2 (the last two passes wrap around, unused)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        cur0 = nxt0; cur1 = nxt1; a_l1 = a_l1n;
+    }
+    if (stamps) stamps[1] = __builtin_amdgcn_s_memtime();
+
+    // layer 3: tanh(H2 tile) and its two K-steps, W3 operands requested two tiles ahead
+    f32x16 y = zero16;
+    f16x8 w3a = *reinterpret_cast<const f16x8*>(w3row), w3b = *reinterpret_cast<const f16x8*>(w3row + 32u);
+#pragma unroll
+    for (int t2 = 0; t2 < 8; ++t2) {
+        const f16x8 f0 = activate(acc[t2], 0), f1 = activate(acc[t2], 1);
+        y = __builtin_amdgcn_mfma_f32_32x32x16_f16(w3a, f0, y, 0, 0, 0);
+        y = __builtin_amdgcn_mfma_f32_32x32x16_f16(w3b, f1, y, 0, 0, 0);
+        if (t2 < 7) {
+            w3a = *reinterpret_cast<const f16x8*>(w3row + (uint32_t)(2 * t2 + 2) * 32u);
+            w3b = *reinterpret_cast<const f16x8*>(w3row + (uint32_t)(2 * t2 + 3) * 32u);
+        }
+    }
+    return y;
+}
+
 // w1: float[HID][OBS] (torch Linear(6,256).weight), b1: float[HID], w23: the f16 LDS image of W2 (Linear(256,256).weight) and W3
 // (Linear(256,out).weight in rows 0..out-1 of a 32-row tile) described above, b2: float[HID], b3: float[out_dim];
 // obs float[n][6]; out float[n][out_dim].
@@ -219,82 +324,13 @@ mlp_forward_kernel(int n, const float* __restrict__ obs, Net net_a, Net net_b, i
             for (int s = 0; s < 3; ++s) xn[s] = more ? obs[(size_t)en * OBS + 2u * s + half] : 0.0f;
         }
 
-        f32x16 acc[8];                                               // H2^T pre-activations, start at b2
-#pragma unroll
-        for (int t = 0; t < 8; ++t)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const float4 b = *reinterpret_cast<const float4*>(l_b2 + t * 32 + 8 * q + 4 * half);   // rows 8q + 4h + (0..3)
-                acc[t][4 * q + 0] = b.x; acc[t][4 * q + 1] = b.y; acc[t][4 * q + 2] = b.z; acc[t][4 * q + 3] = b.w;
-            }
-
-        // Software pipeline over the eight 32-row tiles of H1: tanh of tile t1+1 is interleaved (sched_group_barrier) with the
-        // sixteen MFMAs of tile t1; every W2 operand register is re-requested from LDS for the next K-step right after the
-        // MFMA that consumed it has been issued (operands are read at issue), i.e. eight MFMAs ahead of its next use.
-        f16x8 cur0, cur1, a_l1, a[8];
-        f32x16 dn;
-        {
-            const f16x8 a0 = *reinterpret_cast<const f16x8*>(w1row);
-            const f16x8 a1 = *reinterpret_cast<const f16x8*>(w1row + 1024u);
-            a_l1 = *reinterpret_cast<const f16x8*>(w1row + 2048u);
-            const f32x16 d0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, xb, zero16, 0, 0, 0);
-            dn = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, xb, zero16, 0, 0, 0);
-#pragma unroll
-            for (int t2 = 0; t2 < 8; ++t2) a[t2] = *reinterpret_cast<const f16x8*>(wrow + (size_t)t2 * 32u * ROW_BYTES);
-            cur0 = activate(d0, 0); cur1 = activate(d0, 1);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        Q1POL_STAMP(ts1);
-#pragma unroll 1
-        for (int t1 = 0; t1 < 8; ++t1) {
-            const uint32_t q0 = 2u * (uint32_t)t1;
-            // phase 1: even K-step, first half of tanh(tile t1+1)
-#pragma unroll
-            for (int t2 = 0; t2 < 8; ++t2) {
-                acc[t2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[t2], cur0, acc[t2], 0, 0, 0);
-                a[t2] = *reinterpret_cast<const f16x8*>(wrow + (size_t)t2 * 32u * ROW_BYTES + (q0 + 1u) * 32u);
-            }
-            const f16x8 nxt0 = activate(dn, 0);
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            // phase 2: odd K-step, second half of the tanh, then layer 1 of tile t1+2 (one MFMA)
-            const f16x8 a_l1n = *reinterpret_cast<const f16x8*>(w1row + (((uint32_t)t1 + 3u) & 7u) * 1024u);
-#pragma unroll
-            for (int t2 = 0; t2 < 8; ++t2) {
-                acc[t2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[t2], cur1, acc[t2], 0, 0, 0);
-                a[t2] = *reinterpret_cast<const f16x8*>(wrow + (size_t)t2 * 32u * ROW_BYTES + ((q0 + 2u) & 15u) * 32u);
-            }
-            const f16x8 nxt1 = activate(dn, 1);
-            dn = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_l1, xb, zero16, 0, 0, 0);   // tile t1 + 2 (the last two passes wrap around, unused)
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            cur0 = nxt0; cur1 = nxt1; a_l1 = a_l1n;
-        }
-        Q1POL_STAMP(ts2);
-
-        // layer 3: tanh(H2 tile) and its two K-steps, W3 operands requested two tiles ahead
-        f32x16 y = zero16;
-        f16x8 w3a = *reinterpret_cast<const f16x8*>(w3row), w3b = *reinterpret_cast<const f16x8*>(w3row + 32u);
-#pragma unroll
-        for (int t2 = 0; t2 < 8; ++t2) {
-            const f16x8 f0 = activate(acc[t2], 0), f1 = activate(acc[t2], 1);
-            y = __builtin_amdgcn_mfma_f32_32x32x16_f16(w3a, f0, y, 0, 0, 0);
-            y = __builtin_amdgcn_mfma_f32_32x32x16_f16(w3b, f1, y, 0, 0, 0);
-            if (t2 < 7) {
-                w3a = *reinterpret_cast<const f16x8*>(w3row + (uint32_t)(2 * t2 + 2) * 32u);
-                w3b = *reinterpret_cast<const f16x8*>(w3row + (uint32_t)(2 * t2 + 3) * 32u);
-            }
-        }
+#ifdef Q1POL_TRACE
+        uint64_t stamps[2];
+        const f32x16 y = mlp_tile(xb, w1row, wrow, w3row, l_b2, half, stamps);
+        const uint64_t ts1 = stamps[0], ts2 = stamps[1];
+#else
+        const f32x16 y = mlp_tile(xb, w1row, wrow, w3row, l_b2, half, nullptr);
+#endif
         // y[r] = output row (r&3) + 8(r>>2) + 4*half of env `col`; OUT <= 32 rows are real (10 policy logits with the continuous
         // mouse, 2K + 2S+1 with a discrete one, 1 for the value net).  OUT is wave-uniform: the group test is a scalar branch.
         if (live) {

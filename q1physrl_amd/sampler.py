@@ -23,9 +23,16 @@ from .tensor_env import TensorVectorEnv
 
 class GpuSampler:
     def __init__(self, env: TensorVectorEnv, policy, horizon: int, autocast_dtype=None, use_graph: bool = False,
-                 fused_tick: bool = True):
+                 fused_tick: bool = True, resident: bool = False):
+        """resident=True: the whole horizon is ONE dispatch (q1env_sample_resident: policy blocks with the network's weights in LDS
+        and env blocks with the state in registers, talking through tagged granules) followed by one batched value-network
+        forward over the stored observations - bit-identical trajectories, no per-tick launches.  Needs a FusedPolicyForward
+        policy, a continuous (or no) mouse and a batch whose grid is resident (q1env.h); use_graph is ignored."""
         self.env, self.policy, self.T = env, policy, int(horizon)
         self.fused_tick = bool(fused_tick)
+        self.resident = bool(resident)
+        if self.resident and not hasattr(policy, "_mlp"):
+            raise ValueError("GpuSampler(resident=True) needs a policy.FusedPolicyForward")
         n, d, t = env.num_envs, env.device, self.T
         self.obs = torch.empty((t + 1, n, 6), dtype=torch.float32, device=d)
         self.keys = torch.empty((t, n), dtype=torch.uint8, device=d)
@@ -43,8 +50,11 @@ class GpuSampler:
         # device-resident episode statistics, one slot per wave of envs: [episodes, zero_start_episodes, return_sum,
         # zero_start_return_sum] (q1env_episode_stats; summed on the host on demand)
         self._stats = torch.zeros(((n + 63) // 64, 4), dtype=torch.float64, device=d)
-        self.use_graph = bool(use_graph)
+        self.use_graph = bool(use_graph) and not self.resident
         self._graphs = {}
+        if self.resident:               # scratch of the hand-off protocol (tags continue from launch to launch)
+            self._srv = {"mailbox": torch.zeros((n,), dtype=torch.int64, device=d), "results": torch.zeros((4, n, 2), dtype=torch.int64, device=d),
+                         "status": torch.zeros((5,), dtype=torch.int32, device=d), "tag": 0}
         self.obs[0].copy_(env.reset())
 
     def _forward(self, obs):
@@ -92,6 +102,23 @@ class GpuSampler:
             _, v_last = self._forward(self.obs[self.T])
             self.value[self.T].copy_(v_last)
 
+    def _horizon_resident(self, deterministic, timeout_s=5.0):
+        """T ticks as one dispatch + the value network over the T + 1 stored observation rows as one batched launch."""
+        env, dev, sv = self.env, self.env._dev, self._srv
+        n, t = env.num_envs, self.T
+        pi = self.policy._mlp("pi", self.logits.view(t * n, -1))
+        dev.sample_resident_dev(t, sv["tag"], pi, env.seed, self.tick.data_ptr(), 0, deterministic, self.keys.data_ptr(),
+                                self.mouse.data_ptr(), self.logp.data_ptr(), self.obs.data_ptr(),
+                                self.reward.data_ptr(), self.done.data_ptr(), env.zero_start.data_ptr(), self.ep_return.data_ptr(),
+                                self._stats.data_ptr(), sv["mailbox"].data_ptr(), sv["results"].data_ptr(), sv["status"].data_ptr(), timeout_s)
+        sv["tag"] = (sv["tag"] + t) % 0xFFFFFF
+        self.tick.add_(t)
+        dev.policy_forward_rows_dev((t + 1) * n, self.obs.data_ptr(), self.policy._mlp("vf", self.value.view((t + 1) * n, 1)))
+
+    def resident_status(self):
+        """uint32[5] as q1env_step_persistent_*: all zero = every wave served / handed over every tick of every horizon so far."""
+        return self._srv["status"].cpu().numpy().astype("uint32")
+
     def _scratch_logits(self):
         if not hasattr(self, "_scratch"):
             self._scratch = torch.empty_like(self.logits[0])
@@ -104,7 +131,9 @@ class GpuSampler:
         if getattr(self, "_carry", False):
             self.obs[0].copy_(self.obs[self.T])
         self._carry = True
-        if not self.use_graph:
+        if self.resident:
+            self._horizon_resident(deterministic)
+        elif not self.use_graph:
             self._horizon(deterministic)
         else:
             key = bool(deterministic)

@@ -1,0 +1,88 @@
+"""GPU: the resident sampler (q1env_sample_resident + q1env_policy_forward_rows: a sampling horizon as ONE dispatch + one batched
+value forward) against the two-launch-per-tick sampler it replaces - every trajectory tensor, the env state, the episode statistics and
+the Philox counter must be identical, bit for bit, over several horizons (resets, ragged batches, 3-key / no-mouse / generic Configs,
+one and two tiles per policy wave, deterministic actions), and its failure mode must be a bounded time-out."""
+import numpy as np
+import pytest
+
+from oracle import np_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def make_env(n, seed, **over):
+    from q1physrl_amd.env import Config
+    from q1physrl_amd.tensor_env import TensorVectorEnv
+    cfg = O.OracleConfig.get_default(num_envs=n, **over)
+    return cfg, TensorVectorEnv(Config(**cfg.__dict__), device=0, seed=seed)
+
+
+def run_sampler(n, horizons, T, resident, over, deterministic=False, policy_seed=0):
+    import torch
+    from q1physrl_amd import policy as P
+    from q1physrl_amd.sampler import GpuSampler
+    torch.manual_seed(policy_seed)
+    cfg, env = make_env(n, seed=9, **over)
+    pol = P.Q1Policy(num_keys=env.num_keys, allow_yaw=cfg.allow_yaw).cuda() if (env.num_keys != 4 or not cfg.allow_yaw) else P.Q1Policy().cuda()
+    with torch.no_grad():                                          # (weights large enough for the actions to depend on the observation)
+        for p_ in pol.parameters():
+            p_.mul_(3.0)
+    fused = P.FusedPolicyForward(pol, env)
+    s = GpuSampler(env, fused, horizon=T, resident=resident)
+    runs = []
+    for _ in range(horizons):
+        tr = s.collect(deterministic=deterministic)
+        torch.cuda.synchronize()
+        runs.append({k: v.clone() for k, v in tr.items()})
+    out = (runs, s.stats, env.get_state(), s.tick.clone(), s.ep_return.clone(), env.zero_start.clone(),
+           s.resident_status() if resident else None)
+    env.close()
+    return out
+
+
+@pytest.mark.parametrize("n,T,over,det", [
+    (2048, 40, dict(zero_start_prob=0.5, time_limit=0.3), False),                       # one tile per policy wave, resets
+    (4096 + 37, 24, dict(zero_start_prob=0.3, time_limit=0.2), False),                  # ragged: dead lanes in env and policy waves
+    (32768, 16, dict(zero_start_prob=0.1, time_limit=0.15), False),                     # BASELINE configs[4]'s shard
+    (65536, 8, dict(zero_start_prob=1.0), False),                                       # two tiles per policy wave
+    (1000, 30, dict(time_limit=0.25, allow_jump=False), False),                         # three keys (8 logits + mouse)
+    (1500, 30, dict(time_limit=0.25, allow_yaw=False), False),                          # no mouse
+    (777, 30, dict(time_limit=0.25, auto_jump=True, speed_reward=True), False),         # generic (SPEC = false) kernels
+    (2048, 30, dict(zero_start_prob=0.5, time_limit=0.3), True),                        # deterministic actions
+])
+def test_resident_sampler_equals_the_two_launch_sampler(n, T, over, det):
+    import torch
+    ref = run_sampler(n, 3, T, False, over, det)
+    res = run_sampler(n, 3, T, True, over, det)
+    assert res[6] is not None and not res[6].any(), res[6]
+    for h in range(3):
+        for k in ("obs", "keys", "mouse", "logp", "logits", "value", "reward", "done"):
+            a, b = ref[0][h][k], res[0][h][k]
+            assert a.shape == b.shape and torch.equal(a, b), (h, k, float((a != b).float().mean()))
+    assert ref[1] == res[1]                                          # episode statistics
+    if not det:
+        assert not torch.equal(res[0][0]["keys"], res[0][1]["keys"])
+    for k in ref[2]:
+        assert np.array_equal(ref[2][k], res[2][k]), k              # env state
+    assert torch.equal(ref[3], res[3]) and torch.equal(ref[4], res[4]) and torch.equal(ref[5], res[5])
+    assert int(ref[0][0]["done"].sum()) > 0 or over.get("zero_start_prob") == 1.0
+
+
+def test_resident_sampler_refuses_what_it_cannot_run():
+    import torch
+    from q1physrl_amd import _lib, policy as P
+    from q1physrl_amd.sampler import GpuSampler
+    cfg, env = make_env(512, seed=1, discrete_yaw_steps=5)
+    pol = P.Q1Policy(discrete_yaw_steps=5).cuda()
+    s = GpuSampler(env, P.FusedPolicyForward(pol, env), horizon=4, resident=True)
+    with pytest.raises(_lib.Q1EnvError, match="discrete-mouse"):
+        s.collect()
+    env.close()
+    cfg, env = make_env(1 << 17, seed=1)
+    s = GpuSampler(env, P.FusedPolicyForward(P.Q1Policy().cuda(), env), horizon=4, resident=True)
+    with pytest.raises(_lib.Q1EnvError, match="too many envs"):
+        s.collect()
+    env.close()
+    with pytest.raises(ValueError, match="FusedPolicyForward"):
+        cfg, env = make_env(512, seed=1)
+        GpuSampler(env, P.Q1Policy().cuda(), horizon=4, resident=True)
