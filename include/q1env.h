@@ -317,26 +317,25 @@ int q1env_policy_forward_rows(q1env_t* env, uint64_t rows, const float* obs_dev,
  * A whole sampling horizon - `ticks` times { policy forward, sample the action, step, reset finished episodes, episode
  * statistics } - as ONE dispatch: the counterpart of `ticks` x (q1env_policy_value_forward + q1env_sample_step) without the
  * value network, which is evaluated afterwards over the stored observations (q1env_policy_forward_rows); trajectories are
- * bit-identical to that loop's.  ENV blocks (8 waves x 64 envs, state in registers) and POLICY blocks (the policy network's
- * weights staged ONCE into LDS; 32-env tiles on the matrix cores; the action sampled in the wave that computed its logits) are
- * co-resident and talk through the tick server's tagged granules (see below: mailbox uint64[N] and results uint64[4][N][2] are
- * scratch buffers of the caller, zeroed before the first launch, tags continued across launches exactly as for
- * q1env_step_persistent_*); every wait is bounded by timeout_s and reported in status uint32[5] (as there).
+ * bit-identical to that loop's.  Every workgroup is self-contained (one per CU): four POLICY waves - one per SIMD, the policy
+ * network's weights staged ONCE into LDS, 32-env tiles on the matrix cores, the action sampled in the wave that computed its
+ * logits - and two or four ENV waves (64 envs each, state in registers); observations and actions change hands through LDS
+ * (data, workgroup-scope release, one tag word per env wave / tile).  Every wait is bounded by timeout_s and reported in
+ * status uint32[5] as for q1env_step_persistent_* ([0..2] env side, [3..4] policy side; written on failure only).
  * Tick-major trajectory: pi->out = logits float[T][N][out_dim] (or NULL), keys uint8[T][N], mouse float[T][N] (NULL without a
  * mouse), logp float[T][N], obs float[T + 1][N][6] (row 0 = input: the current observations; rows 1..T written), reward
  * float[T][N], done uint8[T][N]; zero_start uint8[N], ep_return double[N], partials double[ceil(N/64)][4] as q1env_sample_step /
- * q1env_episode_stats.  RNG counter of tick t = counter_offset + *counter_dev (if given) + t.
- * Limits: continuous or no mouse (Config.discrete_yaw_steps < 0), out_dim = 2 (num_keys + mouse) <= 10, and a batch whose grid
- * is resident (one workgroup per CU: N / 512 env blocks + N / 256 or N / 512 policy blocks <= the device's CUs, i.e. 43 520 envs
- * at one tile per policy wave, 65 536 at two on an MI355X); anything else is refused with Q1ENV_ERR_INVALID_ARG. */
+ * q1env_episode_stats.  RNG counter of tick t = counter_offset + (*counter_dev if given, else the handle's tick count) + t.
+ * Limits: continuous or no mouse (Config.discrete_yaw_steps < 0), out_dim = 2 (num_keys + mouse) <= 10, and N <= 256 x the number
+ * of CUs (a workgroup serves 128 envs at one tile per policy wave and tick, 256 at two: 32 768 / 65 536 envs on an MI355X);
+ * anything else is refused with Q1ENV_ERR_INVALID_ARG - use the per-tick calls. */
 typedef struct q1env_resident_args {
     int ticks;
-    uint32_t tag0;
+    int deterministic;
     const q1env_mlp* pi;
     uint64_t seed;
     const uint64_t* counter_dev;
     uint64_t counter_offset;
-    int deterministic;
     uint8_t* keys_dev;
     float* mouse_dev;
     float* logp_dev;
@@ -346,8 +345,6 @@ typedef struct q1env_resident_args {
     uint8_t* zero_start_dev;
     double* ep_return_dev;
     double* partials_dev;
-    uint64_t* mailbox_dev;
-    uint64_t* results_dev;
     uint32_t* status_dev;
     double timeout_s;
 } q1env_resident_args;

@@ -48,11 +48,11 @@ class Q1Mlp(C.Structure):             # q1env_mlp
 
 
 class Q1ResidentArgs(C.Structure):   # q1env_resident_args
-    _fields_ = [("ticks", C.c_int), ("tag0", C.c_uint32), ("pi", C.POINTER(Q1Mlp)), ("seed", C.c_uint64), ("counter_dev", C.c_void_p),
-                ("counter_offset", C.c_uint64), ("deterministic", C.c_int), ("keys_dev", C.c_void_p), ("mouse_dev", C.c_void_p),
+    _fields_ = [("ticks", C.c_int), ("deterministic", C.c_int), ("pi", C.POINTER(Q1Mlp)), ("seed", C.c_uint64), ("counter_dev", C.c_void_p),
+                ("counter_offset", C.c_uint64), ("keys_dev", C.c_void_p), ("mouse_dev", C.c_void_p),
                 ("logp_dev", C.c_void_p), ("obs_dev", C.c_void_p), ("reward_dev", C.c_void_p), ("done_dev", C.c_void_p),
-                ("zero_start_dev", C.c_void_p), ("ep_return_dev", C.c_void_p), ("partials_dev", C.c_void_p), ("mailbox_dev", C.c_void_p),
-                ("results_dev", C.c_void_p), ("status_dev", C.c_void_p), ("timeout_s", C.c_double)]
+                ("zero_start_dev", C.c_void_p), ("ep_return_dev", C.c_void_p), ("partials_dev", C.c_void_p), ("status_dev", C.c_void_p),
+                ("timeout_s", C.c_double)]
 
 
 STATE_FIELDS = (("vel_x", np.float32, 1), ("vel_y", np.float32, 1), ("vel_z", np.float32, 1),

@@ -7,14 +7,14 @@ the repo snapshot.  -ffp-contract=off is part of the numerics contract (the refe
 multiply-add), not an optimisation knob.
 """
 import os
+import glob
 import shutil
 import subprocess
 import sys
 
 PKG = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(PKG, "csrc", "q1env.hip")
-DEPS = [SRC, os.path.join(PKG, "csrc", "q1env_device.hpp"), os.path.join(PKG, "csrc", "q1policy.hpp"), os.path.join(PKG, "csrc", "q1server.hpp"),
-        os.path.join(os.path.dirname(PKG), "include", "q1env.h")]
+DEPS = [SRC] + sorted(glob.glob(os.path.join(PKG, "csrc", "*.hpp"))) + [os.path.join(os.path.dirname(PKG), "include", "q1env.h")]
 OUT = os.path.join(PKG, "libq1env.so")
 
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",

@@ -2015,9 +2015,8 @@ int q1env_sample_resident(q1env_t* h, const q1env_resident_args* a) {
     if (!h || !a || !a->pi) return fail(Q1ENV_ERR_INVALID_ARG, "q1env_sample_resident: null argument");
     const q1env_mlp* m = a->pi;
     if (!m->w1 || !m->b1 || !m->w23_image || !m->b2 || !m->b3) return fail(Q1ENV_ERR_INVALID_ARG, "q1env_sample_resident: null pointer in q1env_mlp");
-    if (!a->keys_dev || !a->logp_dev || !a->obs_dev || !a->reward_dev || !a->done_dev || !a->ep_return_dev || !a->partials_dev ||
-        !a->mailbox_dev || !a->results_dev || !a->status_dev)
-        return fail(Q1ENV_ERR_INVALID_ARG, "q1env_sample_resident: null trajectory / scratch pointer");
+    if (!a->keys_dev || !a->logp_dev || !a->obs_dev || !a->reward_dev || !a->done_dev || !a->ep_return_dev || !a->partials_dev || !a->status_dev)
+        return fail(Q1ENV_ERR_INVALID_ARG, "q1env_sample_resident: null trajectory / status pointer");
     if (a->ticks <= 0 || !(a->timeout_s > 0.0) || a->timeout_s > 30.0) return fail(Q1ENV_ERR_INVALID_ARG, "q1env_sample_resident: bad ticks / timeout_s");
     if (h->p.yaw_mode == 2) return fail(Q1ENV_ERR_INVALID_ARG, "q1env_sample_resident: discrete-mouse policies are not supported (use q1env_sample_step)");
     const int width = 2 * (h->p.num_keys + (h->p.yaw_mode == 1 ? 1 : 0));
@@ -2025,36 +2024,31 @@ int q1env_sample_resident(q1env_t* h, const q1env_resident_args* a) {
     if (h->p.yaw_mode == 1 && !a->mouse_dev) return fail(Q1ENV_ERR_INVALID_ARG, "q1env_sample_resident: mouse trajectory required");
     DeviceGuard guard(h->device);
     if (!h->resident_attr_set) {
-        HIP_TRY(hipFuncSetAttribute((const void*)sampler_resident_kernel<true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)q1pol::LDS_TOTAL));
-        HIP_TRY(hipFuncSetAttribute((const void*)sampler_resident_kernel<true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)q1pol::LDS_TOTAL));
-        HIP_TRY(hipFuncSetAttribute((const void*)sampler_resident_kernel<false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)q1pol::LDS_TOTAL));
-        HIP_TRY(hipFuncSetAttribute((const void*)sampler_resident_kernel<false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)q1pol::LDS_TOTAL));
+        HIP_TRY(hipFuncSetAttribute((const void*)sampler_resident_kernel<true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)q1res::LDS_BYTES));
+        HIP_TRY(hipFuncSetAttribute((const void*)sampler_resident_kernel<true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)q1res::LDS_BYTES));
+        HIP_TRY(hipFuncSetAttribute((const void*)sampler_resident_kernel<false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)q1res::LDS_BYTES));
+        HIP_TRY(hipFuncSetAttribute((const void*)sampler_resident_kernel<false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)q1res::LDS_BYTES));
         h->resident_attr_set = true;
     }
-    // one workgroup per CU (LDS): Be env blocks (padded to a multiple of 8: XCD affinity of the block mapping, speed only) and
-    // Be * 2 / TP policy blocks must all be resident
-    const unsigned n = (unsigned)h->p.n;
-    const unsigned be = ((n + 511u) / 512u + 7u) & ~7u;
-    int tp = 0;
-    if (3u * be <= (unsigned)h->num_cus) tp = 1;
-    else if (2u * be <= (unsigned)h->num_cus) tp = 2;
-    if (const char* f = getenv("Q1ENV_RESIDENT_TP")) { if (f[0] == '2' && 2u * be <= (unsigned)h->num_cus) tp = 2; }      // measurement knob
+    // one workgroup per CU (its LDS holds the network): 128 envs per workgroup at one tile per policy wave, 256 at two
+    const unsigned n = (unsigned)h->p.n, cus = (unsigned)h->num_cus;
+    int tp = (n + 127u) / 128u <= cus ? 1 : ((n + 255u) / 256u <= cus ? 2 : 0);
+    if (const char* f = getenv("Q1ENV_RESIDENT_TP")) { if (f[0] == '2' && tp == 1) tp = 2; }      // measurement knob
     if (!tp)
-        return fail(Q1ENV_ERR_INVALID_ARG, "q1env_sample_resident: too many envs for one resident grid (" +
-                                           std::to_string((unsigned)h->num_cus / 2u / 8u * 8u * 512u) + " at most on this device)");
-    NearBufs near;
-    if (int rc = near_bufs(h, a->tag0, a->ticks, &near)) return rc;
+        return fail(Q1ENV_ERR_INVALID_ARG, "q1env_sample_resident: too many envs for one resident grid (" + std::to_string(cus * 256u) +
+                                           " at most on this device)");
     ResidentArgs k{};
-    k.ticks = a->ticks; k.tag0 = a->tag0; k.env_blocks = be;
+    k.ticks = a->ticks;
     k.pi = q1pol::Net{m->w1, m->b1, m->w23_image, m->b2, m->b3, m->out, m->out_dim};
     k.seed = a->seed; k.counter_offset = a->counter_offset + (a->counter_dev ? 0 : h->tick_count); k.counter_dev = a->counter_dev;
     k.deterministic = a->deterministic;
     k.keys = a->keys_dev; k.mouse = a->mouse_dev; k.logp = a->logp_dev; k.obs = a->obs_dev; k.reward = a->reward_dev; k.done = a->done_dev;
     k.zero_start = a->zero_start_dev; k.ep_return = a->ep_return_dev; k.partials = a->partials_dev;
-    k.mailbox = a->mailbox_dev; k.results = a->results_dev; k.near = near; k.status = a->status_dev;
+    k.status = a->status_dev;
     k.timeout_ticks = (uint64_t)(a->timeout_s * 1.0e8);
-    const dim3 g(be + (tp == 1 ? 2u * be : be)), b(512);
-#define Q1_LAUNCH_RS(SP, TP) hipLaunchKernelGGL((sampler_resident_kernel<SP, TP>), g, b, q1pol::LDS_TOTAL, h->stream, h->p, h->st, k)
+    const unsigned per_block = 128u * (unsigned)tp;
+    const dim3 g((n + per_block - 1u) / per_block), b(512);
+#define Q1_LAUNCH_RS(SP, TP) hipLaunchKernelGGL((sampler_resident_kernel<SP, TP>), g, b, q1res::LDS_BYTES, h->stream, h->p, h->st, k)
     if (is_spec(h->p)) { if (tp == 1) Q1_LAUNCH_RS(true, 1); else Q1_LAUNCH_RS(true, 2); }
     else { if (tp == 1) Q1_LAUNCH_RS(false, 1); else Q1_LAUNCH_RS(false, 2); }
 #undef Q1_LAUNCH_RS

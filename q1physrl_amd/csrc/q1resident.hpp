@@ -1,32 +1,37 @@
 // q1resident.hpp - the resident sampler of libq1env (q1env_sample_resident, include/q1env.h): a whole sampling horizon as ONE
-// dispatch.  Included by q1env.hip after q1server.hpp (hand-off protocol) and q1policy.hpp (matrix-core forward).
+// dispatch.  Included by q1env.hip after q1policy.hpp (matrix-core forward).
 //
-// The two-launch sampler tick (q1env_policy_value_forward + q1env_sample_step) costs ~26 us at 32 768 envs - two dispatch
-// boundaries, 157 KB of weights staged into every CU's LDS again, ~4 us of arithmetic.  Here the policy network's weights are
-// staged ONCE, the env state lives in registers for the whole horizon, and the two halves talk through the tick server's tagged
-// granules (q1server.hpp): XCD-local when a pair of waves found each other on one XCD, agent-scope otherwise.
+// The two-launch sampler tick (q1env_policy_value_forward + q1env_sample_step) costs ~25 us at 32 768 envs - two dispatch
+// boundaries, 157 KB of weights staged into every CU's LDS again, a few us of arithmetic.  Here the policy network's weights are
+// staged ONCE per workgroup, the env state lives in registers for the whole horizon, and a workgroup is self-contained:
 //
-//   blocks [0, Be)            ENV blocks: 8 waves x 64 envs.  Per tick: wait for the action granule, tick (+ in-kernel reset of
-//                             finished episodes, Philox exactly as q1env_sample_step), publish the observation as result granules,
-//                             write reward / done / next observation into the tick-major trajectory, episode statistics in registers
-//   blocks [Be, Be + Bp)      POLICY blocks: 8 waves, the policy network in LDS.  Per tick and 32-env tile: wait for the tile's
-//                             observation granules (tick 0: the trajectory's row 0), forward (q1pol::mlp_tile), gather the logits
-//                             of an env into one lane, sample the action + log-probability (sample_action_regs: same Philox
-//                             draws as q1env_sample_step), write logits / action / log-probability into the trajectory, publish
-//                             the action granule
-// TP = tiles per policy wave per tick: 1 (two policy blocks per env block: the policy's forward of a tick is one tile deep) or
-// 2 (one policy block per env block).  The value network is NOT in the loop: its forward over the (T + 1) N stored observations
-// runs afterwards as one batched launch at full efficiency (q1env_policy_forward_rows) - nothing in the loop depends on it.
+//   waves 0..3                POLICY waves, ONE per SIMD (a tile of 32 envs through the three layers is latency-bound on one wave;
+//                             a second policy wave on the SIMD would double every tick's latency).  Per tick and tile: wait for
+//                             the tile's observations (tick 0: the trajectory's row 0), forward (q1pol::mlp_tile), gather the
+//                             logits of an env into one lane, sample the action + log-probability (sample_action_regs: the same
+//                             Philox draws as q1env_sample_step), write logits / action / log-probability into the trajectory,
+//                             hand the action over
+//   waves 4..4 + 2 TP - 1     ENV waves, 64 envs each (two tiles).  Per tick: wait for the two tiles' actions, tick (+ in-kernel reset
+//                             of finished episodes, Philox exactly as q1env_sample_step), hand the observations over, write
+//                             reward / done / next observation into the tick-major trajectory, episode statistics in registers.
+//                             Their float64 arithmetic runs while the policy wave of their SIMD waits.
+//   remaining waves           exit at once (the workgroup has 512 threads so that it owns its CU's register file and LDS)
+// TP = tiles per policy wave per tick (1 or 2): a workgroup serves 128 TP envs, the grid is ceil(N / (128 TP)) workgroups, one per CU.
+// Both sides of every hand-off are waves of ONE workgroup, so the hand-offs go through LDS: the data (observation rows / packed
+// actions), a workgroup-scope release, then ONE tag word per env wave (observations) or per tile (actions) that carries the tick
+// number; the reader spins on the tag (a broadcast ds_read, ~0.1 us per look - an L2 granule costs ~0.45 us per look), acquires, reads.
+// LDS room: only 16 of the 32 rows of the W3 tile are kept (rows >= out_dim are zero anyway; lanes 16..31 re-read rows 0..15
+// and produce output rows nobody looks at), which frees 8.4 KB next to the weights.
+// The value network is NOT in the loop: its forward over the (T + 1) N stored observations runs afterwards as one batched launch
+// at full efficiency (q1env_policy_forward_rows) - nothing in the loop depends on it.
 // Bit-identical trajectories to the two-launch sampler (same forward arithmetic per tile, same draws, same env arithmetic).
-// Every wait is bounded exactly like the tick server's; status words as there ([0..2] env side, [3..4] policy side).
+// Every wait is bounded (waves of one workgroup are co-resident by construction; the bound guards against a wave that died);
+// status words as the tick server's: [0..2] env side, [3..4] policy side, written on failure only.
 #pragma once
 #include "q1policy.hpp"
-#include "q1server.hpp"
 
 struct ResidentArgs {
     int ticks;
-    uint32_t tag0;
-    uint32_t env_blocks;            // Be (a multiple of 8 when the grid was padded for XCD affinity)
     q1pol::Net pi;                  // policy network; pi.out = logits trajectory float[T][N][width] (may be null), pi.out_dim = width
     uint64_t seed;
     uint64_t counter_offset;
@@ -41,29 +46,53 @@ struct ResidentArgs {
     uint8_t* zero_start;            // [N]: flag of the episode the LAST step belonged to
     double* ep_return;              // [N]
     double* partials;               // [ceil(N/64)][4]
-    uint64_t* mailbox;              // agent-scope copies: uint64[N], uint64[4][N][2]
-    uint64_t* results;
-    NearBufs near;                  // XCD-local copies (null = agent-scope only)
     uint32_t* status;
     uint64_t timeout_ticks;
 };
 
-// place bits ride in bits 36..39 of EVERY result granule here (the policy reads the observation pairs only)
-__device__ __forceinline__ uint64_t result_granule(uint64_t tag, uint32_t place, uint32_t low_bits, uint32_t flags) {
-    return (tag << 40) | ((uint64_t)place << 36) | ((uint64_t)flags << 32) | (uint64_t)low_bits;
-}
+namespace q1res {
+// LDS map of a workgroup: the network (W3 trimmed to 16 rows) and the hand-off area (sized for TP = 2: 256 envs)
+constexpr size_t L_W2 = 0;
+constexpr size_t L_W3 = q1pol::LDS_W2;                                       // 135168
+constexpr size_t W3_BYTES = (size_t)16 * q1pol::ROW_BYTES;                    // 8448
+constexpr size_t L_B2 = L_W3 + W3_BYTES;                                      // 143616
+constexpr size_t L_W1 = L_B2 + q1pol::LDS_B2;                                 // 144640
+constexpr size_t L_TAGS = L_W1 + q1pol::LDS_W1;                               // 152832: uint32 obs_tag[4], act_tag[8] (+ pad)
+constexpr size_t L_ACT = L_TAGS + 64;                                         // uint64 act[256]
+constexpr size_t L_OBS = L_ACT + 256 * 8;                                     // float obs[256][6]
+constexpr size_t LDS_BYTES = L_OBS + 256 * 6 * 4;                             // 161088 <= 163840
+constexpr uint32_t IMG_VEC16 = (uint32_t)((q1pol::LDS_W2 + W3_BYTES) / 16);   // W2 rows + the first 16 W3 rows of the host's image
 
+__device__ __forceinline__ uint32_t tag_load(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ void tag_store(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+
+// spin (bounded) until *tag == want; wave-uniform (every lane reads the same word)
+__device__ __forceinline__ bool wait_tag(const uint32_t* tag, uint32_t want, uint64_t timeout_ticks) {
+    uint32_t polls = 0;
+    uint64_t t_wait = 0;
+    while (tag_load(tag) != want) {
+        if ((++polls & 1023u) == 0u) {                           // (the 100 MHz clock is only looked at every 1024 failed looks)
+            const uint64_t now = wall_clock64();
+            if (t_wait == 0) t_wait = now;
+            else if (now - t_wait > timeout_ticks) return false;
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    return true;
+}
+}  // namespace q1res
+
+// u = env wave of the workgroup (0 .. 2 TP - 1): envs i = block_env0 + 64 u + lane
 template <bool SPEC>
-__device__ __forceinline__ void resident_env_wave(const Params& p, const StatePtrs& s, const ResidentArgs& a, uint32_t i, float* slab) {
+__device__ __forceinline__ void resident_env_wave(const Params& p, const StatePtrs& s, const ResidentArgs& a, uint32_t i, uint32_t u, unsigned char* lds) {
     const uint32_t lane = threadIdx.x & 63u, n = (uint32_t)p.n;
     const bool live = i < n;
-    const uint32_t wave_first = i - lane;
-    const bool full = wave_first + 64u <= n;
-    const uint32_t my_xcc = xcc_id();
-    const bool has_near = a.near.mailbox != nullptr;
     const uint64_t genv = (uint64_t)p.env_index_base + (uint64_t)i;
     const uint64_t counter0 = a.counter_offset + (a.counter_dev ? *a.counter_dev : 0ull);
-    const Backoff bo{0, 0, 0, 0};
+    uint32_t* obs_tag = reinterpret_cast<uint32_t*>(lds + q1res::L_TAGS) + u;
+    const uint32_t* act_tag = reinterpret_cast<const uint32_t*>(lds + q1res::L_TAGS) + 4u + 2u * u;       // this wave's two tiles
+    const uint64_t* act = reinterpret_cast<const uint64_t*>(lds + q1res::L_ACT) + 64u * u + lane;
+    float* obs_row = reinterpret_cast<float*>(lds + q1res::L_OBS) + (size_t)(64u * u + lane) * 6u;
     Env env{};
     double ep_ret = 0.0;
     if (live) { load_env(s, n, i, env); ep_ret = a.ep_return[i]; }
@@ -72,25 +101,18 @@ __device__ __forceinline__ void resident_env_wave(const Params& p, const StatePt
 #pragma unroll
         for (int k = 0; k < 4; ++k) slot[k] = a.partials[(size_t)(i >> 6) * 4 + k];
     }
-    bool near_peer = false, peer_known = false, timed_out = false, last_zs = false;
+    bool timed_out = false, last_zs = false;
     int completed = 0;
     for (int t = 0; t < a.ticks; ++t) {
-        const uint64_t tag = tick_tag(a.tag0, (uint32_t)t);
-        uint64_t g = 0;
-        // until the policy wave's place is known (tick 0) both copies are polled: near-first, the agent-scope copy every eighth poll
-        const bool near_first = has_near && (!peer_known || near_peer);
-        if (!wait_for(live, a.timeout_ticks, bo, [&](uint32_t polls) {
-                const bool far = !near_first || (polls % NEAR_POLL_PERIOD) == NEAR_POLL_PERIOD - 1u;
-                g = granule_load((far ? a.mailbox : a.near.mailbox) + i);
-                return (g >> 40) == tag;
-            })) {
+        if (!q1res::wait_tag(act_tag, (uint32_t)t + 1u, a.timeout_ticks) || !q1res::wait_tag(act_tag + 1, (uint32_t)t + 1u, a.timeout_ticks)) {
             timed_out = true;
             break;
         }
-        near_peer = has_near && __all(!live || peer_is_near((uint32_t)(g >> 36) & 0xFu, my_xcc));
-        peer_known = true;
+        const uint64_t g = *act;
         TickOut<float> o;
         o.reward = 0.0f; o.done = false;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) o.obs[k] = 0.0f;
         bool zs = false;
         if (live) {
             const uint32_t keys = (uint32_t)(g >> 32) & ((1u << cfg_num_keys<SPEC>(p)) - 1u);
@@ -101,24 +123,20 @@ __device__ __forceinline__ void resident_env_wave(const Params& p, const StatePt
                 reset_philox(p, env, a.seed, genv, counter0 + (uint64_t)t + 1);
                 observe<float>(p, env, o.obs);
             }
-            if (t + 1 < a.ticks) {                                               // (nobody reads the last tick's granules)
-                const uint32_t place = PEER_VALID | my_xcc;
-                uint64_t* r = near_peer ? a.near.results : a.results;
-#pragma unroll
-                for (uint32_t q = 0; q < 3u; ++q) {
-                    const uint64_t g0 = result_granule(tag, place, __float_as_uint(o.obs[2 * q]), 0u);
-                    const uint64_t g1 = result_granule(tag, place, __float_as_uint(o.obs[2 * q + 1]), 0u);
-                    if (near_peer) granule_pair_store_near(pair_ptr(r, n, q, i), g0, g1);
-                    else granule_pair_store(pair_ptr(r, n, q, i), g0, g1);
-                }
-            }
             last_zs = zs;
+        }
+        // hand the observations over: rows, release, tag = number of ticks served
+        {
+            float2* w = reinterpret_cast<float2*>(obs_row);
+            w[0] = make_float2(o.obs[0], o.obs[1]);
+            w[1] = make_float2(o.obs[2], o.obs[3]);
+            w[2] = make_float2(o.obs[4], o.obs[5]);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            if (lane == 0) q1res::tag_store(obs_tag, (uint32_t)t + 1u);
         }
         // the trajectory (plain stores: read after the kernel) and the episode bookkeeping of q1env_episode_stats
         if (live) {
-            float* obs_next = a.obs + (size_t)(t + 1) * n * 6u;
-            if (full) write_obs_wave_f32(obs_next, wave_first, lane, o.obs, slab);
-            else write_obs<float>(obs_next, (size_t)i, o.obs);
+            write_obs<float>(a.obs + (size_t)(t + 1) * n * 6u, (size_t)i, o.obs);
             a.reward[(size_t)t * n + i] = o.reward;
             a.done[(size_t)t * n + i] = o.done ? 1 : 0;
         }
@@ -155,73 +173,51 @@ __device__ __forceinline__ void resident_env_wave(const Params& p, const StatePt
     }
 }
 
-// one policy wave: TP tiles of 32 envs (tile j at env index env0 + 32 j)
+// v = policy wave of the workgroup (0..3): tiles v TP + j, j < TP (tile = 32 envs; tile k of the workgroup belongs to env wave k / 2)
 template <int TP>
-__device__ __forceinline__ void resident_policy_wave(const Params& p, const ResidentArgs& a, uint32_t env0, const q1pol::LdsNet& l) {
+__device__ __forceinline__ void resident_policy_wave(const Params& p, const ResidentArgs& a, uint32_t block_env0, uint32_t v, unsigned char* lds) {
     const uint32_t lane = threadIdx.x & 63u, n = (uint32_t)p.n;
     const uint32_t col = lane & 31u, half = lane >> 5;
-    const uint32_t my_xcc = xcc_id();
-    const bool has_near = a.near.mailbox != nullptr;
     const int W = a.pi.out_dim;
     const uint64_t counter0 = a.counter_offset + (a.counter_dev ? *a.counter_dev : 0ull);
-    const uint32_t result_bytes = n * 64u;
-    const __amdgpu_buffer_rsrc_t far_rsrc = granule_rsrc(a.results, result_bytes);
-    const __amdgpu_buffer_rsrc_t near_rsrc = granule_rsrc(has_near ? a.near.results : a.results, result_bytes);
-    const unsigned char* w1row = l.w1 + (size_t)col * 32u + half * 16u;
-    const unsigned char* wrow = l.w2 + (size_t)col * q1pol::ROW_BYTES + half * 16u;
-    const unsigned char* w3row = l.w3 + (size_t)col * q1pol::ROW_BYTES + half * 16u;
-    uint32_t env[TP];
-    bool live[TP], near_peer[TP], peer_known[TP];
+    const unsigned char* w1row = lds + q1res::L_W1 + (size_t)col * 32u + half * 16u;
+    const unsigned char* wrow = lds + q1res::L_W2 + (size_t)col * q1pol::ROW_BYTES + half * 16u;
+    const unsigned char* w3row = lds + q1res::L_W3 + (size_t)(col & 15u) * q1pol::ROW_BYTES + half * 16u;      // rows 16..31 alias 0..15
+    const float* l_b2 = reinterpret_cast<const float*>(lds + q1res::L_B2);
+    const uint32_t* obs_tags = reinterpret_cast<const uint32_t*>(lds + q1res::L_TAGS);
+    uint32_t* act_tags = reinterpret_cast<uint32_t*>(lds + q1res::L_TAGS) + 4u;
+    uint64_t* act = reinterpret_cast<uint64_t*>(lds + q1res::L_ACT);
+    const float* obs_lds = reinterpret_cast<const float*>(lds + q1res::L_OBS);
+    uint32_t tile[TP], loc[TP], env[TP];
+    bool live[TP];
 #pragma unroll
     for (int j = 0; j < TP; ++j) {
-        env[j] = env0 + 32u * (uint32_t)j + col;
+        tile[j] = v * (uint32_t)TP + (uint32_t)j;
+        loc[j] = tile[j] * 32u + col;                           // env index within the workgroup
+        env[j] = block_env0 + loc[j];
         live[j] = env[j] < n;
-        near_peer[j] = false; peer_known[j] = false;
     }
+    float b3[10];                                                 // the output bias: fetched once
+#pragma unroll
+    for (int k = 0; k < 10; ++k) b3[k] = k < W ? a.pi.b3[k] : 0.0f;
     bool timed_out = false;
     int handed = 0;
     for (int t = 0; t < a.ticks && !timed_out; ++t) {
-        const uint64_t tag = tick_tag(a.tag0, (uint32_t)t);
-        const uint64_t want = tick_tag(a.tag0, t > 0 ? (uint32_t)t - 1u : 0u);
 #pragma unroll
         for (int j = 0; j < TP; ++j) {
             // ---- the tile's observations: lane (col, half) needs columns half, 2 + half, 4 + half of env `col`
-            float x[3] = {0.0f, 0.0f, 0.0f};
+            float x[3];
             if (t == 0) {
 #pragma unroll
                 for (int sx = 0; sx < 3; ++sx) x[sx] = live[j] ? a.obs[(size_t)env[j] * 6u + 2u * (uint32_t)sx + half] : 0.0f;
             } else {
-                u32x4v v[3];
-                uint32_t polls = 0;
-                uint64_t t_wait = 0;
-                const bool near_first = has_near && (!peer_known[j] || near_peer[j]);
-                for (;;) {
-                    const bool far = !near_first || (polls % NEAR_POLL_PERIOD) == NEAR_POLL_PERIOD - 1u;
-                    const __amdgpu_buffer_rsrc_t r = far ? far_rsrc : near_rsrc;
-                    bool ok = true;
-                    if (live[j]) {
+                if (!q1res::wait_tag(obs_tags + (tile[j] >> 1), (uint32_t)t, a.timeout_ticks)) { timed_out = true; break; }
 #pragma unroll
-                        for (uint32_t q = 0; q < 3u; ++q) v[q] = granule_pair_load_sc1(r, (q * n + env[j]) * 16u);
-#pragma unroll
-                        for (uint32_t q = 0; q < 3u; ++q) ok = ok && ((uint64_t)(v[q][1] >> 8) == want) && ((uint64_t)(v[q][3] >> 8) == want);
-                    }
-                    if (__all(ok)) break;
-                    if ((++polls & 255u) == 0u) {
-                        const uint64_t now = wall_clock64();
-                        if (t_wait == 0) t_wait = now;
-                        else if (now - t_wait > a.timeout_ticks) { timed_out = true; break; }
-                        __builtin_amdgcn_s_sleep(8);
-                    }
-                }
-                if (timed_out) break;
-                near_peer[j] = has_near && __all(!live[j] || peer_is_near((v[0][1] >> 4) & 0xFu, my_xcc));       // bits 36..39 of granule 0
-                peer_known[j] = true;
-#pragma unroll
-                for (int sx = 0; sx < 3; ++sx) x[sx] = live[j] ? __uint_as_float(v[sx][2u * half]) : 0.0f;          // low word of granule 2 sx + half
+                for (int sx = 0; sx < 3; ++sx) x[sx] = obs_lds[(size_t)loc[j] * 6u + 2u * (uint32_t)sx + half];
             }
             // ---- forward: Y^T of the tile, then all of an env's logits into its half-0 lane
             const q1pol::f16x8 xb = q1pol::split_inputs(x, half);
-            const q1pol::f32x16 y = q1pol::mlp_tile(xb, w1row, wrow, w3row, l.b2, half, nullptr);
+            const q1pol::f32x16 y = q1pol::mlp_tile(xb, w1row, wrow, w3row, l_b2, half, nullptr);
             // lane (col, half) holds rows r + 8 g + 4 half; rows 0..3, 8..9 are half 0's, rows 4..7 come over from lane + 32
             float lg[10];
 #pragma unroll
@@ -232,29 +228,29 @@ __device__ __forceinline__ void resident_policy_wave(const Params& p, const Resi
             }
             lg[8] = y[4]; lg[9] = y[5];
 #pragma unroll
-            for (int k = 0; k < 10; ++k) lg[k] = k < W ? lg[k] + a.pi.b3[k] : 0.0f;
-            const bool actor = live[j] && half == 0u;
-            if (actor) {
-                const uint32_t i = env[j];
-                if (a.pi.out) {
-                    float* row = a.pi.out + ((size_t)t * n + i) * (uint32_t)W;
+            for (int k = 0; k < 10; ++k) lg[k] = k < W ? lg[k] + b3[k] : 0.0f;
+            if (half == 0u) {
+                uint32_t keys = 0;
+                float mouse = 0.0f, logp = 0.0f;
+                if (live[j]) {
+                    const uint32_t i = env[j];
+                    if (a.pi.out) {
+                        float* row = a.pi.out + ((size_t)t * n + i) * (uint32_t)W;
 #pragma unroll
-                    for (int k = 0; k < 10; ++k)
-                        if (k < W) row[k] = lg[k];
+                        for (int k = 0; k < 10; ++k)
+                            if (k < W) row[k] = lg[k];
+                    }
+                    sample_action_regs(p, lg, nullptr, a.seed, (uint64_t)p.env_index_base + (uint64_t)i, counter0 + (uint64_t)t, a.deterministic,
+                                       keys, mouse, logp);
+                    a.keys[(size_t)t * n + i] = (uint8_t)keys;
+                    if (a.mouse) a.mouse[(size_t)t * n + i] = mouse;
+                    if (a.logp) a.logp[(size_t)t * n + i] = logp;
                 }
-                uint32_t keys;
-                float mouse, logp;
-                sample_action_regs(p, lg, nullptr, a.seed, (uint64_t)p.env_index_base + (uint64_t)i, counter0 + (uint64_t)t, a.deterministic,
-                                   keys, mouse, logp);
-                a.keys[(size_t)t * n + i] = (uint8_t)keys;
-                if (a.mouse) a.mouse[(size_t)t * n + i] = mouse;
-                if (a.logp) a.logp[(size_t)t * n + i] = logp;
-                const uint64_t act = (tag << 40) | ((uint64_t)(has_near ? (PEER_VALID | my_xcc) : 0u) << 36) | ((uint64_t)(keys & 0xFu) << 32) |
-                                     (uint64_t)__float_as_uint(mouse);
-                // (near_peer is wave-uniform: both halves of the tile waited on the same env wave)
-                if (has_near && (!peer_known[j] || near_peer[j])) granule_store_near(a.near.mailbox + i, act);
-                if (!peer_known[j] || !near_peer[j]) granule_store(a.mailbox + i, act);
+                act[loc[j]] = ((uint64_t)(keys & 0xFu) << 32) | (uint64_t)__float_as_uint(mouse);
             }
+            // hand the tile's actions over: data, release, tag = number of ticks handed over
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            if (lane == 0) q1res::tag_store(act_tags + tile[j], (uint32_t)t + 1u);
         }
         if (!timed_out) handed = t + 1;
     }
@@ -269,24 +265,34 @@ __global__ void __launch_bounds__(512, 1)
 sampler_resident_kernel(Params p, StatePtrs s, ResidentArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const uint32_t tid = threadIdx.x, wave = tid >> 6;
-    if (blockIdx.x < a.env_blocks) {
-        // env block: 8 waves x 64 envs; the (unused) weight area of LDS lends each wave its observation slab
-        float* slab = reinterpret_cast<float*>(lds) + wave * 384u;
-        resident_env_wave<SPEC>(p, s, a, (blockIdx.x * 8u + wave) * 64u + (tid & 63u), slab);
-        return;
+    const uint32_t block_env0 = blockIdx.x * (128u * (uint32_t)TP);
+    // stage the network: W2 and the first 16 rows of W3 (one contiguous piece of the host's image), b2 (pre-scaled), the layer-1 image
+    {
+        const uint4* src = reinterpret_cast<const uint4*>(a.pi.w23);
+        uint4* d = reinterpret_cast<uint4*>(lds);
+        constexpr uint32_t PER = (q1res::IMG_VEC16 + 511u) / 512u;
+        uint4 v[PER];
+#pragma unroll
+        for (uint32_t k = 0; k < PER; ++k) {
+            const uint32_t c = k * 512u + tid;
+            v[k] = c < q1res::IMG_VEC16 ? src[c] : make_uint4(0, 0, 0, 0);
+        }
+#pragma unroll
+        for (uint32_t k = 0; k < PER; ++k) {
+            const uint32_t c = k * 512u + tid;
+            if (c < q1res::IMG_VEC16) d[c] = v[k];
+        }
+        if (tid < (uint32_t)q1pol::HID) {
+            reinterpret_cast<float*>(lds + q1res::L_B2)[tid] = q1pol::TANH_PRESCALE * a.pi.b2[tid];
+            q1pol::stage_w1_row(lds + q1res::L_W1, tid, a.pi.w1, a.pi.b1);
+        }
+        if (tid < 16u) reinterpret_cast<uint32_t*>(lds + q1res::L_TAGS)[tid] = 0u;
     }
-    const uint32_t q = blockIdx.x - a.env_blocks;
-    q1pol::stage_net<512>(lds, a.pi.w1, a.pi.b1, a.pi.w23, a.pi.b2, tid);
-    __syncthreads();
-    const q1pol::LdsNet l = q1pol::lds_net(lds);
-    uint32_t env0;
-    if (TP == 2) {
-        env0 = q * 512u + wave * 64u;                                  // policy block q <-> env block q, wave <-> wave
-    } else {
-        // two policy blocks per env block.  Blocks go round-robin over the XCDs (observed; speed only), so the two policy blocks of
-        // env block b = 8 k + x are q = 16 k + x and 16 k + 8 + x: all three on XCD x when Be is a multiple of 8
-        const uint32_t b = 8u * (q >> 4) + (q & 7u), sh = (q >> 3) & 1u;
-        env0 = b * 512u + (8u * sh + wave) * 32u;
+    __syncthreads();                                                       // (the only barrier: before any wave leaves or loops)
+    if (wave < 4u) {
+        resident_policy_wave<TP>(p, a, block_env0, wave, lds);
+    } else if (wave < 4u + 2u * (uint32_t)TP) {
+        const uint32_t u = wave - 4u;
+        resident_env_wave<SPEC>(p, s, a, block_env0 + u * 64u + (tid & 63u), u, lds);
     }
-    resident_policy_wave<TP>(p, a, env0, l);
 }

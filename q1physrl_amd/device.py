@@ -225,12 +225,12 @@ class DeviceEnv:
         """One network over `rows` observation rows of any buffer (q1env_policy_forward_rows)."""
         _lib.check(self._lib.q1env_policy_forward_rows(self._h, int(rows), obs, C.byref(net)))
 
-    def sample_resident_dev(self, ticks, tag0, pi: "_lib.Q1Mlp", seed, counter_dev, counter_offset, deterministic, keys, mouse, logp, obs,
-                            reward, done, zero_start, ep_return, partials, mailbox, results, status, timeout_s=2.0):
+    def sample_resident_dev(self, ticks, pi: "_lib.Q1Mlp", seed, counter_dev, counter_offset, deterministic, keys, mouse, logp, obs,
+                            reward, done, zero_start, ep_return, partials, status, timeout_s=2.0):
         """A whole sampling horizon as one dispatch (q1env_sample_resident); all arguments are device addresses."""
-        a = _lib.Q1ResidentArgs(int(ticks), int(tag0) & 0xFFFFFFFF, C.pointer(pi), int(seed) & 0xFFFFFFFFFFFFFFFF, counter_dev or None,
-                                int(counter_offset), int(bool(deterministic)), keys, mouse or None, logp, obs, reward, done, zero_start or None,
-                                ep_return, partials, mailbox, results, status, float(timeout_s))
+        a = _lib.Q1ResidentArgs(int(ticks), int(bool(deterministic)), C.pointer(pi), int(seed) & 0xFFFFFFFFFFFFFFFF, counter_dev or None,
+                                int(counter_offset), keys, mouse or None, logp, obs, reward, done, zero_start or None,
+                                ep_return, partials, status, float(timeout_s))
         _lib.check(self._lib.q1env_sample_resident(self._h, C.byref(a)))
 
     def policy_value_forward_dev(self, obs, pi: "_lib.Q1Mlp", vf: "_lib.Q1Mlp"):

@@ -52,9 +52,8 @@ class GpuSampler:
         self._stats = torch.zeros(((n + 63) // 64, 4), dtype=torch.float64, device=d)
         self.use_graph = bool(use_graph) and not self.resident
         self._graphs = {}
-        if self.resident:               # scratch of the hand-off protocol (tags continue from launch to launch)
-            self._srv = {"mailbox": torch.zeros((n,), dtype=torch.int64, device=d), "results": torch.zeros((4, n, 2), dtype=torch.int64, device=d),
-                         "status": torch.zeros((5,), dtype=torch.int32, device=d), "tag": 0}
+        if self.resident:
+            self._status = torch.zeros((5,), dtype=torch.int32, device=d)       # written by the resident dispatch on failure only
         self.obs[0].copy_(env.reset())
 
     def _forward(self, obs):
@@ -104,20 +103,19 @@ class GpuSampler:
 
     def _horizon_resident(self, deterministic, timeout_s=5.0):
         """T ticks as one dispatch + the value network over the T + 1 stored observation rows as one batched launch."""
-        env, dev, sv = self.env, self.env._dev, self._srv
+        env, dev = self.env, self.env._dev
         n, t = env.num_envs, self.T
         pi = self.policy._mlp("pi", self.logits.view(t * n, -1))
-        dev.sample_resident_dev(t, sv["tag"], pi, env.seed, self.tick.data_ptr(), 0, deterministic, self.keys.data_ptr(),
+        dev.sample_resident_dev(t, pi, env.seed, self.tick.data_ptr(), 0, deterministic, self.keys.data_ptr(),
                                 self.mouse.data_ptr(), self.logp.data_ptr(), self.obs.data_ptr(),
                                 self.reward.data_ptr(), self.done.data_ptr(), env.zero_start.data_ptr(), self.ep_return.data_ptr(),
-                                self._stats.data_ptr(), sv["mailbox"].data_ptr(), sv["results"].data_ptr(), sv["status"].data_ptr(), timeout_s)
-        sv["tag"] = (sv["tag"] + t) % 0xFFFFFF
+                                self._stats.data_ptr(), self._status.data_ptr(), timeout_s)
         self.tick.add_(t)
         dev.policy_forward_rows_dev((t + 1) * n, self.obs.data_ptr(), self.policy._mlp("vf", self.value.view((t + 1) * n, 1)))
 
     def resident_status(self):
         """uint32[5] as q1env_step_persistent_*: all zero = every wave served / handed over every tick of every horizon so far."""
-        return self._srv["status"].cpu().numpy().astype("uint32")
+        return self._status.cpu().numpy().astype("uint32")
 
     def _scratch_logits(self):
         if not hasattr(self, "_scratch"):
