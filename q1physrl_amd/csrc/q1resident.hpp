@@ -229,28 +229,29 @@ __device__ __forceinline__ void resident_policy_wave(const Params& p, const Resi
             lg[8] = y[4]; lg[9] = y[5];
 #pragma unroll
             for (int k = 0; k < 10; ++k) lg[k] = k < W ? lg[k] + b3[k] : 0.0f;
-            if (half == 0u) {
-                uint32_t keys = 0;
-                float mouse = 0.0f, logp = 0.0f;
-                if (live[j]) {
-                    const uint32_t i = env[j];
-                    if (a.pi.out) {
-                        float* row = a.pi.out + ((size_t)t * n + i) * (uint32_t)W;
-#pragma unroll
-                        for (int k = 0; k < 10; ++k)
-                            if (k < W) row[k] = lg[k];
-                    }
-                    sample_action_regs(p, lg, nullptr, a.seed, (uint64_t)p.env_index_base + (uint64_t)i, counter0 + (uint64_t)t, a.deterministic,
-                                       keys, mouse, logp);
-                    a.keys[(size_t)t * n + i] = (uint8_t)keys;
-                    if (a.mouse) a.mouse[(size_t)t * n + i] = mouse;
-                    if (a.logp) a.logp[(size_t)t * n + i] = logp;
-                }
-                act[loc[j]] = ((uint64_t)(keys & 0xFu) << 32) | (uint64_t)__float_as_uint(mouse);
-            }
-            // hand the tile's actions over: data, release, tag = number of ticks handed over
+            // sample in the half-0 lanes, hand the tile's actions over (data, release, tag = number of ticks handed over), and only
+            // THEN write the trajectory: a release waits for every store issued before it, and these go all the way to HBM
+            uint32_t keys = 0;
+            float mouse = 0.0f, logp = 0.0f;
+            const bool actor = half == 0u && live[j];
+            if (actor)
+                sample_action_regs(p, lg, nullptr, a.seed, (uint64_t)p.env_index_base + (uint64_t)env[j], counter0 + (uint64_t)t, a.deterministic,
+                                   keys, mouse, logp);
+            if (half == 0u) act[loc[j]] = ((uint64_t)(keys & 0xFu) << 32) | (uint64_t)__float_as_uint(mouse);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             if (lane == 0) q1res::tag_store(act_tags + tile[j], (uint32_t)t + 1u);
+            if (actor) {
+                const uint32_t i = env[j];
+                if (a.pi.out) {
+                    float* row = a.pi.out + ((size_t)t * n + i) * (uint32_t)W;
+#pragma unroll
+                    for (int k = 0; k < 10; ++k)
+                        if (k < W) row[k] = lg[k];
+                }
+                a.keys[(size_t)t * n + i] = (uint8_t)keys;
+                if (a.mouse) a.mouse[(size_t)t * n + i] = mouse;
+                if (a.logp) a.logp[(size_t)t * n + i] = logp;
+            }
         }
         if (!timed_out) handed = t + 1;
     }

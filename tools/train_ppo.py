@@ -34,6 +34,7 @@ ap.add_argument("--seed", type=int, default=0)
 ap.add_argument("--out", default="")
 ap.add_argument("--no-graph", action="store_true")
 ap.add_argument("--fused-policy", action="store_true", help="sample with the fused MFMA forward kernel (bf16 hidden layer)")
+ap.add_argument("--resident", action="store_true", help="sample every horizon as ONE dispatch (q1env_sample_resident) + one batched value forward; needs --fused-policy")
 ap.add_argument("--fused-loss", action="store_true", help="PPO loss + gradient from the q1env_ppo_loss_grad kernel")
 ap.add_argument("--save", default="", help="write the final policy weights (npz, RLlib fcnet naming) here")
 ap.add_argument("--discrete-yaw-steps", type=int, default=-1, help="Config.discrete_yaw_steps: the mouse becomes Discrete(2S+1) (a Categorical policy head)")
@@ -51,7 +52,7 @@ cfg = Config(**{**Config.get_default().__dict__, "num_envs": count, "zero_start_
 env = TensorVectorEnv(cfg, device=local, seed=args.seed + 1, env_index_base=start)
 pol = P.Q1Policy(discrete_yaw_steps=args.discrete_yaw_steps).cuda()
 fused = P.FusedPolicyForward(pol, env) if args.fused_policy else None
-smp = GpuSampler(env, fused if fused is not None else pol, horizon=args.horizon, use_graph=not args.no_graph)
+smp = GpuSampler(env, fused if fused is not None else pol, horizon=args.horizon, use_graph=not args.no_graph, resident=args.resident)
 lrn = ppo.PPOLearner(pol, float(cfg.action_range), lr=args.lr, num_sgd_iter=args.epochs, minibatch_size=args.minibatch,
                      entropy_coeff=args.entropy, kl_target=args.kl_target, seed=args.seed + rank, use_graph=not args.no_graph, fused_loss=args.fused_loss, env=env,
                      discrete_yaw_steps=args.discrete_yaw_steps)
