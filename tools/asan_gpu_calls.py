@@ -52,5 +52,17 @@ for n in (130, 4096 + 37, 70001):
     assert not tv.serve_ticks(keys, mouse)["status"].any()
     tv.close()
     print("ok server", n, flush=True)
+# the resident sampler's host side (argument struct, shape selection, batched value forward)
+from q1physrl_amd import policy as PL
+from q1physrl_amd.sampler import GpuSampler
+for n in (130, 4096 + 37):
+    tv = TensorVectorEnv(E.Config(**dict(E.Config.get_default().__dict__, num_envs=n, time_limit=0.3)), device=0, seed=3)
+    sm = GpuSampler(tv, PL.FusedPolicyForward(PL.Q1Policy().cuda(), tv), horizon=12, resident=True)
+    for _ in range(3):
+        sm.collect()
+    torch.cuda.synchronize()
+    assert not sm.resident_status().any()
+    tv.close()
+    print("ok resident", n, flush=True)
 _lib.pinned_pool().trim()
 print("ASAN_GPU_CALLS_OK")
