@@ -64,7 +64,7 @@ class PPOLearner:
     def __init__(self, policy, action_range, lr=5e-6, gamma=0.99, lam=0.95, clip_param=0.3, vf_clip_param=100.0,
                  vf_loss_coeff=1.0, entropy_coeff=0.01, kl_coeff=0.2, kl_target=0.0036, num_sgd_iter=30,
                  minibatch_size=128, num_keys=4, seed=0, use_graph=False, fused_loss=False, env=None, discrete_yaw_steps=-1,
-                 allow_yaw=True):
+                 allow_yaw=True, autocast_dtype=None, fused_adam=False):
         self.policy = policy
         self.action_range = float(action_range)
         self.gamma, self.lam = gamma, lam
@@ -78,7 +78,10 @@ class PPOLearner:
         self.fused_loss, self.env = bool(fused_loss), env
         if self.fused_loss and env is None:
             raise ValueError("fused_loss=True needs env= (the TensorVectorEnv whose handle runs q1env_ppo_loss_grad)")
-        self.opt = torch.optim.Adam(policy.parameters(), lr=lr, capturable=self.use_graph)
+        # autocast_dtype (e.g. torch.bfloat16): the two MLPs' matrix products run on reduced-precision operands with float32
+        # accumulation (master weights, loss, its gradient and Adam stay float32); fused_adam: one multi-tensor Adam launch
+        self.autocast_dtype = autocast_dtype
+        self.opt = torch.optim.Adam(policy.parameters(), lr=lr, capturable=self.use_graph, **({"fused": True} if fused_adam else {}))
         self._graph = None
         self._klc = None                        # device scalar: the KL coefficient as the captured graph / the kernel reads it
         self._work = None
@@ -95,7 +98,12 @@ class PPOLearner:
     def _sgd_step(self, mb):
         """One minibatch: forward, loss, backward, (gradient all-reduce,) Adam.  Returns the stats vector (STAT_KEYS order)."""
         if self.fused_loss:
-            logits, value = self.policy(mb["obs"])
+            if self.autocast_dtype is not None:
+                with torch.autocast("cuda", dtype=self.autocast_dtype):
+                    logits, value = self.policy(mb["obs"])
+                logits, value = logits.float().contiguous(), value.float().contiguous()
+            else:
+                logits, value = self.policy(mb["obs"])
             bsz, width = logits.shape
             if self._work is None or self._work[0].shape != logits.shape:
                 dev = logits.device
