@@ -309,12 +309,16 @@ constexpr float LOG_SQUASH_SCALE = -0.097778246f;     // float32(log(float32(0.9
 
 // The arithmetic of one env's action from its (up to ten) policy outputs in registers; `row` is only read by the discrete-mouse
 // branch (2S+1 logits behind the key pairs).
-__device__ __forceinline__ void sample_action_regs(const Params& p, const float (&lg)[10], const float* __restrict__ row, uint64_t seed,
-                                                   uint64_t genv, uint64_t counter, int deterministic, uint32_t& keys, float& mouse,
-                                                   float& logp) {
-    uint32_t r[4], r2[4];
+// (the two Philox words of the (env, counter) pair: they do not depend on the policy's outputs, so a caller with idle time before
+// the logits arrive - the resident sampler - draws them ahead)
+__device__ __forceinline__ void sample_action_draws(uint64_t seed, uint64_t genv, uint64_t counter, uint32_t (&r)[4], uint32_t (&r2)[4]) {
     philox_draw(seed, genv, counter, STREAM_POLICY, 0, r);
     philox_draw(seed, genv, counter, STREAM_POLICY, 1, r2);
+}
+
+__device__ __forceinline__ void sample_action_from_draws(const Params& p, const float (&lg)[10], const float* __restrict__ row,
+                                                         const uint32_t (&r)[4], const uint32_t (&r2)[4], int deterministic, uint32_t& keys,
+                                                         float& mouse, float& logp) {
     logp = 0.0f;
     keys = 0;
     const uint32_t ku[4] = {r[0], r[1], r2[0], r2[1]};
@@ -368,6 +372,14 @@ __device__ __forceinline__ void sample_action_regs(const Params& p, const float 
         mouse = (float)choice;
         logp += lpc;
     }
+}
+
+__device__ __forceinline__ void sample_action_regs(const Params& p, const float (&lg)[10], const float* __restrict__ row, uint64_t seed,
+                                                   uint64_t genv, uint64_t counter, int deterministic, uint32_t& keys, float& mouse,
+                                                   float& logp) {
+    uint32_t r[4], r2[4];
+    sample_action_draws(seed, genv, counter, r, r2);
+    sample_action_from_draws(p, lg, row, r, r2, deterministic, keys, mouse, logp);
 }
 
 __device__ __forceinline__ void sample_action(const Params& p, const float* __restrict__ row, uint64_t seed, uint64_t genv,

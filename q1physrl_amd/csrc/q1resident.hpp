@@ -205,6 +205,9 @@ __device__ __forceinline__ void resident_policy_wave(const Params& p, const Resi
     for (int t = 0; t < a.ticks && !timed_out; ++t) {
 #pragma unroll
         for (int j = 0; j < TP; ++j) {
+            // the tick's Philox draws need no logits: drawn before the wait for the env wave, i.e. in time that is idle anyway
+            uint32_t r[4] = {0u, 0u, 0u, 0u}, r2[4] = {0u, 0u, 0u, 0u};
+            if (half == 0u && live[j]) sample_action_draws(a.seed, (uint64_t)p.env_index_base + (uint64_t)env[j], counter0 + (uint64_t)t, r, r2);
             // ---- the tile's observations: lane (col, half) needs columns half, 2 + half, 4 + half of env `col`
             float x[3];
             if (t == 0) {
@@ -234,9 +237,7 @@ __device__ __forceinline__ void resident_policy_wave(const Params& p, const Resi
             uint32_t keys = 0;
             float mouse = 0.0f, logp = 0.0f;
             const bool actor = half == 0u && live[j];
-            if (actor)
-                sample_action_regs(p, lg, nullptr, a.seed, (uint64_t)p.env_index_base + (uint64_t)env[j], counter0 + (uint64_t)t, a.deterministic,
-                                   keys, mouse, logp);
+            if (actor) sample_action_from_draws(p, lg, nullptr, r, r2, a.deterministic, keys, mouse, logp);
             if (half == 0u) act[loc[j]] = ((uint64_t)(keys & 0xFu) << 32) | (uint64_t)__float_as_uint(mouse);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             if (lane == 0) q1res::tag_store(act_tags + tile[j], (uint32_t)t + 1u);
