@@ -356,14 +356,9 @@ int q1env_sample_resident(q1env_t* env, const q1env_resident_args* args);
  * != 0; Philox counter as there) or q1env_step calls with the packed action layout.  Everything that crosses is an 8-byte
  * data-tagged granule, written by ONE agent-scope (sc1) store and polled with sc1 loads (MI355X_MICROARCH.md, persistent-kernel
  * price list) - no flags, fences or drains, one hop per direction:
- *   mailbox[i]    = (tag << 40) | (place << 36) | (key bits << 32) | float32 bits of the mouse action   producer -> server, uint64[N]
+ *   mailbox[i]    = (tag << 40) | (key bits << 32) | float32 bits of the mouse action          producer -> server, uint64[N]
  *   G[k][i], k = 0..5 = (tag << 40) | float32 bits of observation column k                   server -> consumer
- *   G[6][i] = (tag << 40) | (zero_start << 33) | (done << 32) | float32 bits of reward;  G[7][i] = (tag << 40) | place (padding)
- *   place (4 bits) = 0 ("unknown": what an external producer writes - keep bits 36..39 of an action granule zero) or 8 | XCC id of
- *   the writing wave.  The library's own resident driver (_drive / _pair) sets it: a server wave and a driver wave that find each
- *   other on ONE XCD hand over through that XCD's L2 (plain stores into copies owned by the handle) instead of these agent-scope
- *   buffers, from tick 1 of a launch on; tick 0 and the last tick of every launch always travel through mailbox / results, and an
- *   external producer sees nothing but them.  Placement is verified per wave pair at run time, never assumed.
+ *   G[6][i] = (tag << 40) | (zero_start << 33) | (done << 32) | float32 bits of reward;  G[7][i] = tag << 40 (padding)
  *   results = uint64[4][N][2]: pair q of env i = {G[2q][i], G[2q+1][i]}, written as ONE 16-byte sc1 store (an sc1 store is one
  *   fabric write per lane whatever its width); every 8-byte half carries its own tag and can be read and validated alone.
  *   tag of tick t (0-based) of the launch = (tag0 + t) mod (2^24 - 1) + 1, i.e. 1 .. 0xFFFFFF and never 0: zero the mailbox before the
@@ -397,10 +392,15 @@ int q1env_step_persistent_publish(q1env_t* env, void* producer_stream, uint32_t 
 int q1env_step_persistent_collect(q1env_t* env, void* producer_stream, uint32_t tag0, uint32_t tick, const uint64_t* results_dev,
                                   float* obs_dev, float* reward_dev, uint8_t* done_dev, uint8_t* zero_start_dev, uint32_t* status_dev,
                                   double timeout_s);
-/* _start + _drive as ONE dispatch on the handle's stream (server waves and driver waves are blocks of the same grid, same protocol,
- * same results): two streams are only concurrent when the runtime maps them to different hardware queues, which HIP does not
- * promise - a producer queued behind the server it feeds can only time out.  Give an external producer a stream of another
- * PRIORITY (hipStreamCreateWithPriority: separate queue pool) or use this entry point.  num_envs <= half the resident capacity.
+/* The server and the reference dependent producer as ONE dispatch on the handle's stream: a workgroup = one server wave + one driver
+ * wave serving 1, 2 or 3 sub-batches of 64 envs (the smallest count whose grid is resident: up to 131 072 / 262 144 / 294 912 envs
+ * on an MI355X; more is refused).  Both sides of every hand-off then sit on one CU, so the per-tick hand-offs go through LDS (data,
+ * then one tag word per sub-batch carrying the tick count) instead of the granules above - the arrangement the resident sampler has
+ * with a real policy - and a server wave with several sub-batches keeps one env state in registers and rotates the others through LDS.
+ * Same results as _start + _drive: the state, obs_final, status and checksum; `results` receives the LAST tick's granules (tag of tick
+ * ticks - 1), mailbox_dev is not touched.  (Two streams are only concurrent when the runtime maps them to different hardware
+ * queues, which HIP does not promise - a producer queued behind the server it feeds can only time out: give an external producer
+ * a stream of another PRIORITY, hipStreamCreateWithPriority, or use this entry point.)
  * auto_reset: bit 0 = in-kernel reset of finished episodes; Q1ENV_TIMER_START (4) / Q1ENV_TIMER_STOP (8) may be added to record the
  * handle's timer events right around the launch, as in q1env_step_many. */
 int q1env_step_persistent_pair(q1env_t* env, int ticks, uint32_t tag0, const uint8_t* keys_dev, const float* mouse_dev,

@@ -807,9 +807,6 @@ struct q1env {
     int num_cus = 256;                // compute units of the device (MI355X in SPX mode: 256)
     int server_blocks_per_cu[3] = {-1, -1, -1};   // occupancy of the resident tick server at 1/2/4 envs per lane (queried once)
     int pair_blocks_per_cu[3] = {-1, -1, -1};     // ... and of the server + driver pair kernel, per shape (PAIR_SHAPES)
-    uint64_t* near_buf = nullptr;     // XCD-local copies of the tick server's hand-off buffers (mailbox uint64[N] + results uint64[4][N][2])
-    uint32_t near_next_tag = 0;       // the tag0 that continues the last launch (the copies hold no tag a continuing launch could match)
-    bool near_stale = false;          // a launch ran without the copies: wipe them before the next use
     bool resident_attr_set = false;   // the resident sampler's dynamic-LDS attribute
     bool mlp_attr_set = false;        // dynamic-LDS attribute of the policy kernels (a per-device setting: kept per handle)
     // cached hipGraphs of step_many, keyed by (ticks, formats, pointers); a handful of entries, oldest evicted
@@ -1057,7 +1054,6 @@ int q1env_destroy(q1env_t* h) {
     if (h->stage) (void)hipFree(h->stage);
     if (h->pin) (void)hipHostFree(h->pin);
     if (h->snap) (void)hipFree(h->snap);
-    if (h->near_buf) (void)hipFree(h->near_buf);
     if (h->arena) (void)hipFree(h->arena);
     if (h->own_stream) (void)hipStreamDestroy(h->stream);
     delete h;
@@ -1773,47 +1769,13 @@ int q1env_policy_forward_rows(q1env_t* h, uint64_t rows, const float* obs, const
 // the defaults (measurement knob).
 static Backoff server_backoff() {
     static const Backoff bo = [] {
-        Backoff b{0, 0, 0, 0};
+        Backoff b{0, 0, 0};
         if (const char* e = getenv("Q1ENV_SERVER_BACKOFF")) (void)sscanf(e, "%d,%d,%d", &b.first_server, &b.first_driver, &b.between);
         auto clamp = [](int v) { return v < 0 ? 0 : (v > 4096 ? 4096 : v); };
         b.first_server = clamp(b.first_server); b.first_driver = clamp(b.first_driver); b.between = clamp(b.between);
-        if (const char* d = getenv("Q1ENV_SERVER_DIAG")) b.diag = d[0] == '1';
         return b;
     }();
     return bo;
-}
-
-// The XCD-local copies of mailbox / results (q1server.hpp): owned by the handle, handed to the server and to the library's own driver
-// only.  They must never hold a tag the coming launch could match: fresh buffers are zeroed, and so are they whenever tag0 does not
-// continue the previous launch's sequence (a synchronising memset on that rare path; launches that continue pay nothing).
-// Measurement / test knobs, read at every launch: Q1ENV_SERVER_NEAR=0 turns the fast path off (everything travels agent-scope);
-// Q1ENV_SERVER_PAD=0 leaves the pair grid unpadded (an odd block count then puts every pair on two XCDs: the verified-far path).
-static bool knob_on(const char* name) { const char* e = getenv(name); return !(e && e[0] == '0'); }
-
-static int near_bufs(q1env_t* h, uint32_t tag0, int ticks, NearBufs* out) {
-    *out = NearBufs{nullptr, nullptr};
-    if (!knob_on("Q1ENV_SERVER_NEAR")) {
-        h->near_stale = true;                   // (no launch continues this one: the copies are wiped before they are used again)
-        return Q1ENV_OK;
-    }
-    const size_t n = (size_t)h->p.n, bytes = n * 9 * sizeof(uint64_t);
-    bool wipe = h->near_stale || tag0 != h->near_next_tag;
-    h->near_stale = false;
-    if (!h->near_buf) {
-        HIP_TRY(hipMalloc((void**)&h->near_buf, bytes));
-        wipe = true;
-    }
-    if (wipe) {
-        HIP_TRY(hipMemsetAsync(h->near_buf, 0, bytes, h->stream));
-        HIP_TRY(hipStreamSynchronize(h->stream));
-    }
-    h->near_next_tag = (uint32_t)(((uint64_t)tag0 + (uint64_t)ticks) % 0xFFFFFFull);
-    *out = NearBufs{h->near_buf, h->near_buf + n};
-    return Q1ENV_OK;
-}
-// (for the driver of the two-stream form: whatever q1env_step_persistent_start set up - call that first)
-static NearBufs near_bufs_of(const q1env_t* h) {
-    return h->near_buf && knob_on("Q1ENV_SERVER_NEAR") ? NearBufs{h->near_buf, h->near_buf + (size_t)h->p.n} : NearBufs{nullptr, nullptr};
 }
 
 // Envs per lane of the resident grid (E in {1, 2, 4}, index e = log2 E): the smallest that makes the whole grid resident (at 8 the
@@ -1830,19 +1792,14 @@ extern "C++" {
 template <int E> static const void* server_fn(bool spec) { return spec ? (const void*)tick_server_kernel<true, E> : (const void*)tick_server_kernel<false, E>; }
 }
 
-// Shapes of the pair dispatch: a server / driver wave pair serves ES sub-batches of 64 envs; "dense" is the same code compiled for
-// four waves per SIMD (q1server.hpp).  Tried in this order; the first whose grid is resident wins (Q1ENV_SERVER_SHAPE="<index>"
-// forces one: measurement knob).  Measured on an MI355X (tools/time_persistent.py): dense ES = 1 up to 131 072 envs, ES = 2 up to
-// 196 608, ES = 4 up to 262 144; a dense ES = 2 spills (28 registers) and is slower than ES = 4.
-struct PairShape { int es; bool dense; };
-static constexpr int N_PAIR_SHAPES = 3;
-static constexpr PairShape PAIR_SHAPES[N_PAIR_SHAPES] = {{1, true}, {2, false}, {4, false}};
-
-#define Q1_FOR_SHAPE(idx, CALL)                              \
-    switch (idx) {                                           \
-        case 0: { CALL(tick_pair_kernel_dense, 1); } break;  \
-        case 1: { CALL(tick_pair_kernel, 2); } break;        \
-        default: { CALL(tick_pair_kernel, 4); } break;       \
+// q1env_step_persistent_pair: ES = sub-batches of 64 envs per (server wave, driver wave) workgroup (q1server.hpp, tick_pair_lds_kernel).
+// The smallest ES whose grid is resident wins (Q1ENV_SERVER_SHAPE="<ES>" forces one: measurement knob).
+static constexpr int MAX_PAIR_ES = 3;
+#define Q1_FOR_PAIR_ES(es, CALL)       \
+    switch (es) {                      \
+        case 1: { CALL(1); } break;    \
+        case 2: { CALL(2); } break;    \
+        default: { CALL(3); } break;   \
     }
 
 static int server_blocks_per_cu_of(q1env_t* h, int e_idx, int* out) {
@@ -1861,16 +1818,16 @@ static int server_blocks_per_cu_of(q1env_t* h, int e_idx, int* out) {
     return Q1ENV_OK;
 }
 
-static int pair_blocks_per_cu_of(q1env_t* h, int shape, int* out) {
-    int& slot = h->pair_blocks_per_cu[shape];
+static int pair_blocks_per_cu_of(q1env_t* h, int es, int* out) {
+    int& slot = h->pair_blocks_per_cu[es - 1];
     if (slot < 0) {
         const void* fn = nullptr;
         const bool spec = is_spec(h->p);
-#define Q1_FN(K, ES) fn = spec ? (const void*)K<true, ES> : (const void*)K<false, ES>
-        Q1_FOR_SHAPE(shape, Q1_FN)
+#define Q1_FN(ES) fn = spec ? (const void*)tick_pair_lds_kernel<true, ES> : (const void*)tick_pair_lds_kernel<false, ES>
+        Q1_FOR_PAIR_ES(es, Q1_FN)
 #undef Q1_FN
         int per_cu = 0;
-        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 64, 0));
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 128, q1pair::lds_bytes(es)));
         slot = per_cu;
     }
     *out = slot;
@@ -1905,14 +1862,12 @@ int q1env_step_persistent_start(q1env_t* h, int ticks, uint32_t tag0, const uint
     const unsigned per_block = 64u << e_idx;
     const dim3 g(((unsigned)h->p.n + per_block - 1u) / per_block), b(64);
     const uint64_t timeout_ticks = (uint64_t)(timeout_s * 1.0e8);          // wall_clock64: 100 MHz
-    NearBufs near;
-    if (int rc = near_bufs(h, tag0, ticks, &near)) return rc;
 #define Q1_LAUNCH(E)                                                                                                                    \
     if (is_spec(h->p))                                                                                                                  \
-        hipLaunchKernelGGL((tick_server_kernel<true, E>), g, b, 0, h->stream, h->p, h->st, ticks, tag0, mailbox_dev, results_dev, near, \
+        hipLaunchKernelGGL((tick_server_kernel<true, E>), g, b, 0, h->stream, h->p, h->st, ticks, tag0, mailbox_dev, results_dev,       \
                            obs_final_dev, seed, h->tick_count, auto_reset, status_dev, timeout_ticks, server_backoff());                \
     else                                                                                                                                \
-        hipLaunchKernelGGL((tick_server_kernel<false, E>), g, b, 0, h->stream, h->p, h->st, ticks, tag0, mailbox_dev, results_dev, near,\
+        hipLaunchKernelGGL((tick_server_kernel<false, E>), g, b, 0, h->stream, h->p, h->st, ticks, tag0, mailbox_dev, results_dev,      \
                            obs_final_dev, seed, h->tick_count, auto_reset, status_dev, timeout_ticks, server_backoff())
     Q1_FOR_E(e_idx, Q1_LAUNCH)
 #undef Q1_LAUNCH
@@ -1935,7 +1890,7 @@ int q1env_step_persistent_drive(q1env_t* h, void* producer_stream, int ticks, ui
     const dim3 g(((unsigned)h->p.n + per_block - 1u) / per_block), b(64);
 #define Q1_LAUNCH(E)                                                                                                                 \
     hipLaunchKernelGGL((tick_driver_kernel<E>), g, b, 0, (hipStream_t)producer_stream, h->p.n, ticks, tag0, keys_dev, mouse_dev,     \
-                       mailbox_dev, results_dev, near_bufs_of(h), checksum_dev, status_dev, (uint64_t)(timeout_s * 1.0e8), server_backoff())
+                       mailbox_dev, results_dev, checksum_dev, status_dev, (uint64_t)(timeout_s * 1.0e8), server_backoff())
     Q1_FOR_E(e_idx, Q1_LAUNCH)
 #undef Q1_LAUNCH
     HIP_TRY(hipGetLastError());
@@ -1974,47 +1929,36 @@ int q1env_step_persistent_pair(q1env_t* h, int ticks, uint32_t tag0, const uint8
         return fail(Q1ENV_ERR_INVALID_ARG, "q1env_step_persistent_pair: null argument");
     if (ticks <= 0 || !(timeout_s > 0.0) || timeout_s > 30.0) return fail(Q1ENV_ERR_INVALID_ARG, "q1env_step_persistent_pair: bad ticks / timeout_s");
     DeviceGuard guard(h->device);
-    // one dispatch of server + driver waves: co-resident iff the grid fits the device (first shape that does)
-    int shape = -1;
-    unsigned server_blocks = 0, driver_blocks = 0;
+    // one dispatch of (server wave, driver wave) workgroups: every wait in it is between waves of one workgroup, but the grid is
+    // still required to be resident (a workgroup that waits for a slot holds its envs' ticks back, and the launch's time with them)
+    int es = 0;
     long best = 0;
     const char* forced = getenv("Q1ENV_SERVER_SHAPE");
-    const bool pad = knob_on("Q1ENV_SERVER_PAD");
-    for (int k = 0; k < N_PAIR_SHAPES && shape < 0; ++k) {
-        if (forced && forced[0] >= '0' && forced[0] < '0' + N_PAIR_SHAPES && k != forced[0] - '0') continue;
-        const int es = PAIR_SHAPES[k].es;
+    for (int k = 1; k <= MAX_PAIR_ES && !es; ++k) {
+        if (forced && forced[0] >= '1' && forced[0] <= '0' + MAX_PAIR_ES && k != forced[0] - '0') continue;
         int per_cu = 0;
         if (int rc = pair_blocks_per_cu_of(h, k, &per_cu)) return rc;
-        const long resident = (long)h->num_cus * per_cu;
-        const unsigned per_block = 64u * (unsigned)es;
-        // speed only: with B a multiple of 8, block b and block B + b meet on one XCD under round-robin placement (q1server.hpp)
-        unsigned bs = ((unsigned)h->p.n + per_block - 1u) / per_block;
-        const unsigned padded = (bs + 7u) & ~7u;
-        if (pad && 2L * padded <= resident) bs = padded;
-        const long max_envs = resident / 2 * per_block;
+        const long max_envs = (long)h->num_cus * per_cu * 64 * k;
         if (max_envs > best) best = max_envs;
-        if (2L * bs <= resident) { shape = k; server_blocks = bs; driver_blocks = bs; }
+        if ((long)h->p.n <= max_envs) es = k;
     }
-    if (shape < 0)
+    if (!es)
         return fail(Q1ENV_ERR_INVALID_ARG, "q1env_step_persistent_pair: too many envs for one resident grid (" + std::to_string(best) +
                                            " at most on this device)");
     const uint64_t timeout_ticks = (uint64_t)(timeout_s * 1.0e8);
-    const dim3 g(server_blocks + driver_blocks), b(64);
-    NearBufs near;
-    if (int rc = near_bufs(h, tag0, ticks, &near)) return rc;
+    const unsigned per_block = 64u * (unsigned)es;
+    const dim3 g(((unsigned)h->p.n + per_block - 1u) / per_block), b(128);
     const bool t_start = (auto_reset & Q1ENV_TIMER_START) != 0, t_stop = (auto_reset & Q1ENV_TIMER_STOP) != 0;
     auto_reset &= 1;
     if (t_start) HIP_TRY(hipEventRecord(h->ev0, h->stream));
-#define Q1_LAUNCH(K, ES)                                                                                                                   \
-    if (is_spec(h->p))                                                                                                                     \
-        hipLaunchKernelGGL((K<true, ES>), g, b, 0, h->stream, h->p, h->st, ticks, tag0, mailbox_dev, results_dev, near,                 \
-                           obs_final_dev, seed, h->tick_count, auto_reset, keys_dev, mouse_dev, checksum_dev, status_dev, timeout_ticks,   \
-                           server_backoff(), server_blocks);                                                                               \
-    else                                                                                                                                   \
-        hipLaunchKernelGGL((K<false, ES>), g, b, 0, h->stream, h->p, h->st, ticks, tag0, mailbox_dev, results_dev, near,                \
-                           obs_final_dev, seed, h->tick_count, auto_reset, keys_dev, mouse_dev, checksum_dev, status_dev, timeout_ticks,   \
-                           server_backoff(), server_blocks)
-    Q1_FOR_SHAPE(shape, Q1_LAUNCH)
+#define Q1_LAUNCH(ES)                                                                                                                     \
+    if (is_spec(h->p))                                                                                                                    \
+        hipLaunchKernelGGL((tick_pair_lds_kernel<true, ES>), g, b, q1pair::lds_bytes(ES), h->stream, h->p, h->st, ticks, tag0, results_dev, \
+                           obs_final_dev, seed, h->tick_count, auto_reset, keys_dev, mouse_dev, checksum_dev, status_dev, timeout_ticks); \
+    else                                                                                                                                  \
+        hipLaunchKernelGGL((tick_pair_lds_kernel<false, ES>), g, b, q1pair::lds_bytes(ES), h->stream, h->p, h->st, ticks, tag0, results_dev, \
+                           obs_final_dev, seed, h->tick_count, auto_reset, keys_dev, mouse_dev, checksum_dev, status_dev, timeout_ticks)
+    Q1_FOR_PAIR_ES(es, Q1_LAUNCH)
 #undef Q1_LAUNCH
     HIP_TRY(hipGetLastError());
     if (t_stop) HIP_TRY(hipEventRecord(h->ev1, h->stream));

@@ -24,30 +24,18 @@ using namespace q1;
 // state as of the last completed tick and reports status[1] != 0 - a missing or stalled producer ends the launch, not the GPU.
 // Bit-identical to `ticks` q1env_step_autoreset / q1env_step calls with the packed action layout.
 //
-// XCD-local fast path (the library's own resident driver only).  An sc1 store DROPS its line from the writer's L2 and an sc1 load
-// of it is served over the fabric - ~0.9 us per hop wherever the two waves sit.  A PLAIN store stays in the XCD's L2, where an
-// L1-bypassing (sc1) load of ANOTHER CU OF THE SAME XCD finds it in ~0.4 us (tools/ubench_handoff.hip: round trip 1.78 -> 0.79 us);
-// a reader on another XCD never sees it.  So placement is not assumed but EXCHANGED: every wave reads HW_REG_XCC_ID and puts it
-// into its granules (action bits 36..39, result granule 7 bits 0..3: 8 | xcc; 0 = "unknown", what an external producer writes).
-// Tick 0 of a launch travels agent-scope (the driver stores both copies; it polls both for the results).  From then on a side
-// whose partner is verified on its own XCD stores the XCD-local copy ONLY (buffers owned by the handle, never seen by an
-// external producer) and polls it, looking at the agent-scope copy every eighth poll; every other pair keeps the sc1 protocol.
-// Nothing is assumed about block -> XCD placement (the pair grid is merely padded so that block b and block B + b meet on
-// one XCD when the dispatcher goes round-robin): a pair on two XCDs is slower, not wrong.  The last tick of a launch is also
-// stored agent-scope, so `results` always holds it.
+// These granules serve the TWO-STREAM form (q1env_step_persistent_start + _drive / _publish / _collect: the producer is another
+// dispatch, possibly an external one).  q1env_step_persistent_pair puts a server wave and its driver wave into ONE workgroup and
+// hands over through LDS instead (tick_pair_lds_kernel, end of this file).  In between the round tried granules through the shared
+// L2 of an XCD for wave pairs that had verified - by exchanging HW_REG_XCC_ID - that they sit on one XCD (plain stores, L1-bypassing
+// loads: round trip 0.79 us against 1.78 us agent-scope, tools/ubench_handoff.hip): 2.7 -> 1.8 us per tick at 65 536 envs, then
+// superseded by the LDS form (1.3 us) and removed - two separate dispatches were never observed to land pairwise on one XCD.
 constexpr int RESULT_GRANULES = 7;
-constexpr uint32_t PEER_VALID = 8u;            // granule bit: "the low three bits are my XCC id"
-constexpr uint32_t NEAR_POLL_PERIOD = 8u;      // near-first polling: polls 0..6 of every 8 read the XCD-local copy, poll 7 the agent-scope copy
-
-struct NearBufs { uint64_t* mailbox; uint64_t* results; };      // XCD-local copies (uint64[N], uint64[4][N][2]); null = sc1 protocol only
-
-__device__ __forceinline__ uint32_t xcc_id() { return (uint32_t)__builtin_amdgcn_s_getreg(20 | (3 << 11)) & 7u; }      // HW_REG_XCC_ID[3:0]
-__device__ __forceinline__ bool peer_is_near(uint32_t bits, uint32_t my_xcc) { return (bits & PEER_VALID) != 0u && (bits & 7u) == my_xcc; }
 
 // Poll pacing, in units of s_sleep(1) (64 clocks): `first_*` before the first poll of a tick - the other side needs at least a hop
 // plus its own work before anything new can be there, and thousands of waves polling early only load the fabric the hand-offs
 // travel through - and `between` after every failed poll.
-struct Backoff { int first_server, first_driver, between, diag; };     // diag != 0: driver waves count their XCD-local sub-batches into status[5..6] (status must then have 8 words)
+struct Backoff { int first_server, first_driver, between; };
 
 __device__ __forceinline__ void nap(int units) {
     for (int k = 0; k < units; ++k) __builtin_amdgcn_s_sleep(1);
@@ -75,15 +63,6 @@ __device__ __forceinline__ void granule_pair_store(uint64_t* p, uint64_t a, uint
     // (the s_nop covers the "VALU overwrites the data registers of a > 64-bit VMEM store" hazard: the compiler's hazard recognizer
     // does not look inside inline assembly, and without it lanes 12-15 of every 16 stored the NEXT pair's first word)
     asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 2" ::"v"(p), "v"(v) : "memory");
-}
-
-// the XCD-local flavours: plain stores (the line stays in this XCD's L2)
-__device__ __forceinline__ void granule_store_near(uint64_t* p, uint64_t v) {
-    asm volatile("global_store_dwordx2 %0, %1, off" ::"v"(p), "v"(v) : "memory");
-}
-__device__ __forceinline__ void granule_pair_store_near(uint64_t* p, uint64_t a, uint64_t b) {
-    const u32x4 v = {(uint32_t)a, (uint32_t)(a >> 32), (uint32_t)b, (uint32_t)(b >> 32)};
-    asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 2" ::"v"(p), "v"(v) : "memory");
 }
 
 // four pairs (eight granules) with all four loads in flight together
@@ -137,20 +116,17 @@ __device__ __forceinline__ bool wait_for(bool live, uint64_t timeout_ticks, cons
 // producer) still runs as ONE resident grid, at E x the arithmetic per wave and the same two hops per tick.
 template <bool SPEC, int E>
 __device__ __forceinline__ void tick_server_body(const Params& p, const StatePtrs& s, uint32_t block, int ticks, uint32_t tag0,
-                                                 const uint64_t* mailbox, uint64_t* results, NearBufs near, float* obs_final,
-                                                 uint64_t seed, uint64_t counter0, int auto_reset, uint32_t* status,
-                                                 uint64_t timeout_ticks, Backoff bo) {
+                                                 const uint64_t* mailbox, uint64_t* results, float* obs_final, uint64_t seed,
+                                                 uint64_t counter0, int auto_reset, uint32_t* status, uint64_t timeout_ticks,
+                                                 Backoff bo) {
     const uint32_t lane = threadIdx.x, n = (uint32_t)p.n;
-    const uint32_t my_xcc = xcc_id();
     uint32_t idx[E];
     bool live[E];
-    bool near_peer[E];                   // the producer of this sub-batch said (last tick) that it sits on this XCD
     Env env[E];
 #pragma unroll
     for (int e = 0; e < E; ++e) {
         idx[e] = (block * (uint32_t)E + (uint32_t)e) * 64u + lane;
         live[e] = idx[e] < n;
-        near_peer[e] = false;
         env[e] = Env{};
         if (live[e]) load_env(s, n, idx[e], env[e]);
     }
@@ -163,20 +139,11 @@ __device__ __forceinline__ void tick_server_body(const Params& p, const StatePtr
         for (int e = 0; e < E; ++e) {
             const uint32_t i = idx[e];
             uint64_t g = 0;
-            // every lane polls its own granule: one contiguous 512-B sc1 read per wave (of the XCD-local copy while the producer is near)
-            const bool near_first = near_peer[e];
-            if (!wait_for(live[e], timeout_ticks, bo, [&](uint32_t polls) {
-                    const bool far = !near_first || (polls % NEAR_POLL_PERIOD) == NEAR_POLL_PERIOD - 1u;
-                    g = granule_load((far ? mailbox : near.mailbox) + i);
-                    return (g >> 40) == tag;
-                })) {
+            // every lane polls its own granule: one contiguous 512-B sc1 read per wave
+            if (!wait_for(live[e], timeout_ticks, bo, [&](uint32_t) { g = granule_load(mailbox + i); return (g >> 40) == tag; })) {
                 timed_out = true;
                 break;
             }
-            // where this tick's results go is decided by the action granule itself (wave-uniform: one producer wave per sub-batch)
-            const bool peer_near = near.results != nullptr && __all(!live[e] || peer_is_near((uint32_t)(g >> 36) & 0xFu, my_xcc));
-            near_peer[e] = peer_near;
-            const bool store_far = !peer_near || t == ticks - 1, store_near = peer_near;
             if (live[e]) {
                 const uint32_t keys = (uint32_t)(g >> 32) & ((1u << cfg_num_keys<SPEC>(p)) - 1u);
                 const double yaw_act = cfg_yaw_mode<SPEC>(p) ? (double)__uint_as_float((uint32_t)g) : 0.0;
@@ -189,21 +156,11 @@ __device__ __forceinline__ void tick_server_body(const Params& p, const StatePtr
                 }
                 const uint64_t hi = tag << 40;
                 const uint64_t last = hi | ((uint64_t)(zs ? 1u : 0u) << 33) | ((uint64_t)(o.done ? 1u : 0u) << 32) | (uint64_t)__float_as_uint(o.reward);
-                const uint64_t pad = hi | (uint64_t)(PEER_VALID | my_xcc);                // granule 7: tag + where the server wave sits
-                if (store_near) {
 #pragma unroll
-                    for (uint32_t q = 0; q < 3u; ++q)
-                        granule_pair_store_near(pair_ptr(near.results, n, q, i), hi | (uint64_t)__float_as_uint(o.obs[2 * q]),
-                                                hi | (uint64_t)__float_as_uint(o.obs[2 * q + 1]));
-                    granule_pair_store_near(pair_ptr(near.results, n, 3u, i), last, pad);
-                }
-                if (store_far) {
-#pragma unroll
-                    for (uint32_t q = 0; q < 3u; ++q)
-                        granule_pair_store(pair_ptr(results, n, q, i), hi | (uint64_t)__float_as_uint(o.obs[2 * q]),
-                                           hi | (uint64_t)__float_as_uint(o.obs[2 * q + 1]));
-                    granule_pair_store(pair_ptr(results, n, 3u, i), last, pad);
-                }
+                for (uint32_t q = 0; q < 3u; ++q)
+                    granule_pair_store(pair_ptr(results, n, q, i), hi | (uint64_t)__float_as_uint(o.obs[2 * q]),
+                                       hi | (uint64_t)__float_as_uint(o.obs[2 * q + 1]));
+                granule_pair_store(pair_ptr(results, n, 3u, i), last, hi);      // granule 7 is padding: tag only
             }
         }
         if (!timed_out) completed = t + 1;
@@ -231,11 +188,9 @@ __device__ __forceinline__ void tick_server_body(const Params& p, const StatePtr
 // over only after ALL result granules of tick t of the same env have arrived.  Actions come from a resident tick-major packed
 // episode (keys uint8[T][N], mouse float[T][N]); checksum (optional, double[2][N]) accumulates the rewards and the first
 // observation column it received, so the data really makes the round trip.
-// A driver wave feeds the server wave of the same block index (ED = ES sub-batches of 64 envs; block d and server block d meet on
-// one XCD when the dispatcher places blocks round-robin and the server half is a multiple of 8 blocks - speed only, verified per
-// pair).  The result polls of up to four sub-batches are in flight TOGETHER (a poll is an L2 round trip of ~0.4 us even when the
-// granule is there): each round requests the pending sub-batches of the group, then consumes those that have arrived and hands
-// their next action over at once.
+// A driver wave feeds the server wave of the same block index (ED sub-batches of 64 envs).  The result polls of up to four
+// sub-batches are in flight TOGETHER (a poll is a fabric round trip even when the granule is there): each round requests the
+// pending sub-batches of the group, then consumes those that have arrived and hands their next action over at once.
 typedef uint32_t u32x4v __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t granule_rsrc(const uint64_t* base, uint32_t bytes) {
@@ -249,25 +204,19 @@ __device__ __forceinline__ u32x4v granule_pair_load_sc1(__amdgpu_buffer_rsrc_t r
 
 template <int ED>
 __device__ __forceinline__ void tick_driver_body(int n_, uint32_t dblock, int ticks, uint32_t tag0, const uint8_t* keys, const float* mouse,
-                                                 uint64_t* mailbox, const uint64_t* results, NearBufs near, double* checksum,
-                                                 uint32_t* status, uint64_t timeout_ticks, Backoff bo) {
+                                                 uint64_t* mailbox, const uint64_t* results, double* checksum, uint32_t* status,
+                                                 uint64_t timeout_ticks, Backoff bo) {
     constexpr int GROUP = ED < 4 ? ED : 4;
     static_assert(ED % GROUP == 0, "sub-batches are polled in full groups");
     const uint32_t lane = threadIdx.x, n = (uint32_t)n_;
-    const uint32_t my_xcc = xcc_id();
-    const bool has_near = near.mailbox != nullptr;
-    const uint32_t result_bytes = n * 64u;                                 // uint64[4][N][2]
-    const __amdgpu_buffer_rsrc_t far_rsrc = granule_rsrc(results, result_bytes);
-    const __amdgpu_buffer_rsrc_t near_rsrc = granule_rsrc(has_near ? near.results : results, result_bytes);
+    const __amdgpu_buffer_rsrc_t rsrc = granule_rsrc(results, n * 64u);    // uint64[4][N][2]
     uint32_t idx[ED];
     bool live[ED];
-    bool near_peer[ED];                  // the server wave of this sub-batch is known to sit on this XCD (from its last results)
     double acc_r[ED], acc_o[ED];
 #pragma unroll
     for (int e = 0; e < ED; ++e) {
         idx[e] = (dblock * (uint32_t)ED + (uint32_t)e) * 64u + lane;
         live[e] = idx[e] < n;
-        near_peer[e] = false;
         acc_r[e] = 0.0; acc_o[e] = 0.0;
     }
     bool timed_out = false;
@@ -290,20 +239,15 @@ __device__ __forceinline__ void tick_driver_body(int n_, uint32_t dblock, int ti
             uint32_t polls = 0;
             uint64_t t_wait = 0;
             while (pending != 0u) {
-                // tick 0's results may be in either copy (the server knows by then where this wave sits, this wave does not know the
-                // server's place yet): near-first polling covers both; afterwards only a near server is polled near-first
-                const bool far_round = (polls % NEAR_POLL_PERIOD) == NEAR_POLL_PERIOD - 1u;
                 u32x4v v[GROUP][4];
 #pragma unroll
                 for (int q = 0; q < GROUP; ++q) {
                     const int e = base + q;
-                    const bool near_first = has_near && (t == 1 || near_peer[e]);
-                    const __amdgpu_buffer_rsrc_t r = (!near_first || far_round) ? far_rsrc : near_rsrc;
 #pragma unroll
                     for (uint32_t w = 0; w < 4u; ++w) v[q][w] = u32x4v{0u, 0u, 0u, 0u};
                     if (((pending >> q) & 1u) != 0u && live[e]) {
 #pragma unroll
-                        for (uint32_t w = 0; w < 4u; ++w) v[q][w] = granule_pair_load_sc1(r, (w * n + idx[e]) * 16u);
+                        for (uint32_t w = 0; w < 4u; ++w) v[q][w] = granule_pair_load_sc1(rsrc, (w * n + idx[e]) * 16u);
                     }
                 }
 #pragma unroll
@@ -316,14 +260,10 @@ __device__ __forceinline__ void tick_driver_body(int n_, uint32_t dblock, int ti
                         ok = ok && ((uint64_t)(v[q][w][1] >> 8) == want) && ((uint64_t)(v[q][w][3] >> 8) == want);      // tag = bits 40..63 of each granule
                     if (!__all(!live[e] || ok)) continue;
                     pending &= ~(1u << q);
-                    near_peer[e] = has_near && __all(!live[e] || peer_is_near(v[q][3][2] & 0xFu, my_xcc));               // granule 7's payload
                     if (live[e]) {
                         acc_r[e] += (double)__uint_as_float(v[q][3][0]);                                                  // granule 6: reward
                         acc_o[e] += (double)__uint_as_float(v[q][0][0]);                                                  // granule 0: obs[0]
-                        const uint64_t a = (tag << 40) | ((uint64_t)(has_near ? (PEER_VALID | my_xcc) : 0u) << 36) | ((uint64_t)(k[e] & 0xFu) << 32) |
-                                           (uint64_t)__float_as_uint(m[e]);
-                        if (near_peer[e]) granule_store_near(near.mailbox + idx[e], a);
-                        else granule_store(mailbox + idx[e], a);
+                        granule_store(mailbox + idx[e], (tag << 40) | ((uint64_t)(k[e] & 0xFu) << 32) | (uint64_t)__float_as_uint(m[e]));
                     }
                 }
                 if (pending != 0u) {
@@ -340,28 +280,15 @@ __device__ __forceinline__ void tick_driver_body(int n_, uint32_t dblock, int ti
         }
         if (timed_out) break;
         if (t == 0) {
-            // the first tick of a launch travels agent-scope AND XCD-local: neither side knows the other's place yet
 #pragma unroll
             for (int e = 0; e < ED; ++e)
-                if (live[e]) {
-                    const uint64_t a = (tag << 40) | ((uint64_t)(has_near ? (PEER_VALID | my_xcc) : 0u) << 36) | ((uint64_t)(k[e] & 0xFu) << 32) |
-                                       (uint64_t)__float_as_uint(m[e]);
-                    if (has_near) granule_store_near(near.mailbox + idx[e], a);
-                    granule_store(mailbox + idx[e], a);
-                }
+                if (live[e]) granule_store(mailbox + idx[e], (tag << 40) | ((uint64_t)(k[e] & 0xFu) << 32) | (uint64_t)__float_as_uint(m[e]));
         }
         handed = t + 1;
     }
 #pragma unroll
     for (int e = 0; e < ED; ++e)
         if (live[e] && checksum) { checksum[idx[e]] += acc_r[e]; checksum[(size_t)n + idx[e]] += acc_o[e]; }
-    if (bo.diag != 0 && lane == 0) {                             // measurement knob (Q1ENV_SERVER_DIAG): how many sub-batches ended XCD-local
-        uint32_t near_count = 0, total = 0;
-#pragma unroll
-        for (int e = 0; e < ED; ++e) { near_count += near_peer[e] ? 1u : 0u; total += (idx[e] - lane) < n ? 1u : 0u; }
-        atomicAdd(&status[5], near_count);
-        atomicAdd(&status[6], total);
-    }
     if (lane == 0 && handed != ticks) {
         if (timed_out) atomicOr(&status[3], 1u);
         atomicMax(&status[4], (uint32_t)(ticks - handed));       // actions the slowest wave did not hand over
@@ -421,50 +348,232 @@ tick_collect_kernel(int n, uint32_t tag0, uint32_t t, const uint64_t* results, f
 
 template <bool SPEC, int E>
 __global__ void __launch_bounds__(64)
-tick_server_kernel(Params p, StatePtrs s, int ticks, uint32_t tag0, const uint64_t* mailbox, uint64_t* results, NearBufs near, float* obs_final,
+tick_server_kernel(Params p, StatePtrs s, int ticks, uint32_t tag0, const uint64_t* mailbox, uint64_t* results, float* obs_final,
                    uint64_t seed, uint64_t counter0, int auto_reset, uint32_t* status, uint64_t timeout_ticks, Backoff bo) {
-    tick_server_body<SPEC, E>(p, s, blockIdx.x, ticks, tag0, mailbox, results, near, obs_final, seed, counter0, auto_reset, status, timeout_ticks, bo);
+    tick_server_body<SPEC, E>(p, s, blockIdx.x, ticks, tag0, mailbox, results, obs_final, seed, counter0, auto_reset, status, timeout_ticks, bo);
 }
 
 template <int E>
 __global__ void __launch_bounds__(64)
 tick_driver_kernel(int n, int ticks, uint32_t tag0, const uint8_t* keys, const float* mouse, uint64_t* mailbox,
-                   const uint64_t* results, NearBufs near, double* checksum, uint32_t* status, uint64_t timeout_ticks, Backoff bo) {
-    tick_driver_body<E>(n, blockIdx.x, ticks, tag0, keys, mouse, mailbox, results, near, checksum, status, timeout_ticks, bo);
+                   const uint64_t* results, double* checksum, uint32_t* status, uint64_t timeout_ticks, Backoff bo) {
+    tick_driver_body<E>(n, blockIdx.x, ticks, tag0, keys, mouse, mailbox, results, checksum, status, timeout_ticks, bo);
 }
 
-// Server and reference driver in ONE dispatch (q1env_step_persistent_pair): blocks [0, B) are the server's waves (ES sub-batches of 64
-// envs each), blocks [B, 2B) the driver's.  Two streams are only concurrent when the runtime maps them to different hardware
-// queues, which HIP does not promise (a process that has created many streams re-uses queues: the producer then queues BEHIND the
-// server it feeds and both sides can only time out).  One grid that fits the device is co-resident by construction - this is what
-// the benchmark and most tests use; the two-stream entry points remain for an external producer.  The host pads B to a multiple of
-// 8 (blocks whose envs are all beyond n idle through the loop), so that with the round-robin block -> XCD placement the dispatcher
-// is observed to use, server block b and its driver block B + b share an XCD and take the XCD-local path (verified per wave pair at
-// run time, never assumed).
-#define Q1_PAIR_KERNEL_BODY                                                                                                                   \
-    if (blockIdx.x < server_blocks)                                                                                                           \
-        tick_server_body<SPEC, ES>(p, s, blockIdx.x, ticks, tag0, mailbox, results, near, obs_final, seed, counter0, auto_reset, status,     \
-                                   timeout_ticks, bo);                                                                                        \
-    else                                                                                                                                      \
-        tick_driver_body<ES>(p.n, blockIdx.x - server_blocks, ticks, tag0, keys, mouse, mailbox, results, near, checksum, status,            \
-                             timeout_ticks, bo)
+// ============================================================================ server + driver as ONE WORKGROUP (hand-offs through LDS)
+// q1env_step_persistent_pair's kernel: a workgroup = one SERVER wave + one DRIVER wave (128 threads) serving ES sub-batches of 64
+// envs.  Both sides of every hand-off sit on one CU, so it goes through LDS - the data words, a workgroup-scope release, then ONE
+// tag word per sub-batch that counts the ticks handed over; the reader spins on the tag (a broadcast ds_read, ~0.1 us per look
+// against ~0.45 us for an L2 granule and ~0.9 us agent-scope), acquires, reads.  This is the arrangement the resident sampler has
+// (q1resident.hpp: the policy waves sit in the env waves' workgroup); the driver is its stand-in - a DEPENDENT producer that hands
+// tick t + 1's action over only after it has read all eight result words of tick t.  With ES > 1 the server keeps ONE env state in
+// registers and rotates the sub-batches' states through LDS (11 x 8 bytes per env): one copy of the tick code for any ES, 128
+// registers, four waves per SIMD - two server waves per SIMD overlap their float64 chains.  The LAST tick of a launch is also
+// stored as agent-scope granules into `results` (and obs_final), exactly as the two-stream form leaves it.
+namespace q1pair {
+constexpr uint32_t STATE_WORDS = 11;        // uint64 words of one Env: {vx,vy} {vz,flags} px py z yaw trem lk[4]
+constexpr size_t lds_bytes(int es) {          // tags | act[ES][64] u64 | res[ES][8][64] u32 | state[ES][11][64] u64 (ES > 1 only)
+    return (size_t)es * 64u * (8u + 32u + (es > 1 ? STATE_WORDS * 8u : 0u)) + 64u;
+}
+__device__ __forceinline__ void env_to_lds(uint64_t* w, uint32_t lane, const Env& e) {          // w = this sub-batch's [11][64] words
+    w[0 * 64 + lane] = (uint64_t)__float_as_uint(e.vx) | ((uint64_t)__float_as_uint(e.vy) << 32);
+    w[1 * 64 + lane] = (uint64_t)__float_as_uint(e.vz) | ((uint64_t)e.flags << 32);
+    w[2 * 64 + lane] = (uint64_t)__double_as_longlong(e.px); w[3 * 64 + lane] = (uint64_t)__double_as_longlong(e.py);
+    w[4 * 64 + lane] = (uint64_t)__double_as_longlong(e.z); w[5 * 64 + lane] = (uint64_t)__double_as_longlong(e.yaw);
+    w[6 * 64 + lane] = (uint64_t)__double_as_longlong(e.trem);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) w[(7 + k) * 64 + lane] = (uint64_t)__double_as_longlong(e.lk[k]);
+}
+__device__ __forceinline__ void env_from_lds(const uint64_t* w, uint32_t lane, Env& e) {
+    const uint64_t a = w[0 * 64 + lane], b = w[1 * 64 + lane];
+    e.vx = __uint_as_float((uint32_t)a); e.vy = __uint_as_float((uint32_t)(a >> 32));
+    e.vz = __uint_as_float((uint32_t)b); e.flags = (uint32_t)(b >> 32);
+    e.px = __longlong_as_double((long long)w[2 * 64 + lane]); e.py = __longlong_as_double((long long)w[3 * 64 + lane]);
+    e.z = __longlong_as_double((long long)w[4 * 64 + lane]); e.yaw = __longlong_as_double((long long)w[5 * 64 + lane]);
+    e.trem = __longlong_as_double((long long)w[6 * 64 + lane]);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) e.lk[k] = __longlong_as_double((long long)w[(7 + k) * 64 + lane]);
+}
+__device__ __forceinline__ uint32_t tag_load(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ void tag_store(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+// spin (bounded) until *tag == want; wave-uniform
+__device__ __forceinline__ bool wait_tag(const uint32_t* tag, uint32_t want, uint64_t timeout_ticks) {
+    uint32_t polls = 0;
+    uint64_t t_wait = 0;
+    while (tag_load(tag) != want) {
+        if ((++polls & 1023u) == 0u) {
+            const uint64_t now = wall_clock64();
+            if (t_wait == 0) t_wait = now;
+            else if (now - t_wait > timeout_ticks) return false;
+        }
+    }
+    asm volatile("" ::: "memory");                                // (LDS only: a wave's DS operations execute in order; no cache to invalidate)
+    return true;
+}
+// publish: everything this wave wrote to LDS before is in LDS before the tag is.  NOT a workgroup-scope release fence: that one also
+// waits for the wave's outstanding GLOBAL loads (vmcnt(0)) - the driver's prefetched actions, 1 - 2 us of HBM latency per tick.
+__device__ __forceinline__ void publish_tag(uint32_t* tag, uint32_t v, bool lane0) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (lane0) tag_store(tag, v);
+}
+}  // namespace q1pair
 
 template <bool SPEC, int ES>
-__global__ void __launch_bounds__(64)
-tick_pair_kernel(Params p, StatePtrs s, int ticks, uint32_t tag0, uint64_t* mailbox, uint64_t* results, NearBufs near, float* obs_final,
-                 uint64_t seed, uint64_t counter0, int auto_reset, const uint8_t* keys, const float* mouse, double* checksum,
-                 uint32_t* status, uint64_t timeout_ticks, Backoff bo, uint32_t server_blocks) {
-    Q1_PAIR_KERNEL_BODY;
-}
+__global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(4, 4)))
+tick_pair_lds_kernel(Params p, StatePtrs s, int ticks, uint32_t tag0, uint64_t* results, float* obs_final, uint64_t seed, uint64_t counter0,
+                     int auto_reset, const uint8_t* keys, const float* mouse, double* checksum, uint32_t* status, uint64_t timeout_ticks) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const uint32_t lane = threadIdx.x & 63u, n = (uint32_t)p.n;
+    const bool is_server = threadIdx.x < 64u;
+    // LDS map: tags (act_tag[ES], res_tag[ES]) | act[ES][64] u64 | res[ES][8][64] u32 | state[ES][11][64] u64 (ES > 1 only)
+    uint32_t* act_tag = reinterpret_cast<uint32_t*>(lds);
+    uint32_t* res_tag = act_tag + ES;
+    uint64_t* act = reinterpret_cast<uint64_t*>(lds + 64);
+    uint32_t* res = reinterpret_cast<uint32_t*>(lds + 64 + (size_t)ES * 64u * 8u);
+    uint64_t* state = reinterpret_cast<uint64_t*>(lds + 64 + (size_t)ES * 64u * 40u);
+    if (threadIdx.x < 2u * ES) act_tag[threadIdx.x] = 0u;
+    __syncthreads();                                                      // (the only barrier)
+    const uint32_t base = blockIdx.x * (64u * (uint32_t)ES) + lane;     // env of sub-batch e: base + 64 e
 
-// The same dispatch compiled for FOUR waves per SIMD (at most 128 VGPRs; no spills at ES = 1): 131 072 envs are resident at one env
-// per lane, with two server waves per SIMD overlapping their float64 chains (3.3 -> 2.6 us per tick against two envs per lane), and
-// smaller batches are no slower than with the 142 registers the compiler takes when left alone.
-template <bool SPEC, int ES>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
-tick_pair_kernel_dense(Params p, StatePtrs s, int ticks, uint32_t tag0, uint64_t* mailbox, uint64_t* results, NearBufs near, float* obs_final,
-                       uint64_t seed, uint64_t counter0, int auto_reset, const uint8_t* keys, const float* mouse, double* checksum,
-                       uint32_t* status, uint64_t timeout_ticks, Backoff bo, uint32_t server_blocks) {
-    Q1_PAIR_KERNEL_BODY;
+    if (is_server) {
+        Env env{};
+        if (ES == 1) {
+            if (base < n) load_env(s, n, base, env);
+        } else {
+#pragma unroll 1
+            for (int e = 0; e < ES; ++e) {
+                Env tmp{};
+                if (base + 64u * e < n) load_env(s, n, base + 64u * e, tmp);
+                q1pair::env_to_lds(state + (size_t)e * q1pair::STATE_WORDS * 64u, lane, tmp);
+            }
+        }
+        int completed = 0;
+        bool timed_out = false;
+        for (int t = 0; t < ticks && !timed_out; ++t) {
+            const uint64_t tag = tick_tag(tag0, (uint32_t)t);
+#pragma unroll 1
+            for (int e = 0; e < ES; ++e) {
+                const uint32_t i = base + 64u * (uint32_t)e;
+                const bool live = i < n;
+                if (!q1pair::wait_tag(act_tag + e, (uint32_t)t + 1u, timeout_ticks)) { timed_out = true; break; }
+                const uint64_t g = act[e * 64 + lane];
+                if (ES > 1) q1pair::env_from_lds(state + (size_t)e * q1pair::STATE_WORDS * 64u, lane, env);
+                TickOut<float> o;
+                o.reward = 0.0f; o.done = false;
+#pragma unroll
+                for (int k = 0; k < 6; ++k) o.obs[k] = 0.0f;
+                bool zs = false;
+                if (live) {
+                    const uint32_t kb = (uint32_t)(g >> 32) & ((1u << cfg_num_keys<SPEC>(p)) - 1u);
+                    const double yaw_act = cfg_yaw_mode<SPEC>(p) ? (double)__uint_as_float((uint32_t)g) : 0.0;
+                    tick<float, SPEC>(p, env, kb, yaw_act, o);
+                    zs = (env.flags & FLAG_ZERO_START) != 0;                       // of the episode the step belonged to
+                    if (auto_reset && o.done) {
+                        // (the counter passes through an empty asm INSIDE the branch: the reset's arithmetic - Philox rounds, sincos -
+                        // is pure and, with one sub-batch, invariant in the e loop, and the compiler otherwise hoists ALL of it in
+                        // front of the loop, i.e. executes it on every tick: 1.1 us per tick, measured)
+                        uint64_t ctr = counter0 + (uint64_t)t + 1;
+                        asm volatile("" : "+v"(ctr));
+                        reset_philox(p, env, seed, (uint64_t)p.env_index_base + (uint64_t)i, ctr);
+                        observe<float>(p, env, o.obs);
+                    }
+                }
+                const uint32_t fl = (zs ? 2u : 0u) | (o.done ? 1u : 0u);
+                uint32_t* r = res + (size_t)e * 8u * 64u;
+#pragma unroll
+                for (int k = 0; k < 6; ++k) r[k * 64 + lane] = __float_as_uint(o.obs[k]);
+                r[6 * 64 + lane] = __float_as_uint(o.reward);
+                r[7 * 64 + lane] = fl;
+                if (ES > 1) q1pair::env_to_lds(state + (size_t)e * q1pair::STATE_WORDS * 64u, lane, env);
+                q1pair::publish_tag(res_tag + e, (uint32_t)t + 1u, lane == 0);
+                if (t == ticks - 1 && live) {
+                    // what a launch leaves behind for its caller: the last tick as agent-scope granules, and its observation row
+                    const uint64_t hi = tag << 40;
+#pragma unroll
+                    for (uint32_t q = 0; q < 3u; ++q)
+                        granule_pair_store(pair_ptr(results, n, q, i), hi | (uint64_t)__float_as_uint(o.obs[2 * q]),
+                                           hi | (uint64_t)__float_as_uint(o.obs[2 * q + 1]));
+                    granule_pair_store(pair_ptr(results, n, 3u, i), hi | ((uint64_t)fl << 32) | (uint64_t)__float_as_uint(o.reward), hi);
+                    if (obs_final) write_obs<float>(obs_final, (size_t)i, o.obs);
+                }
+            }
+            if (!timed_out) completed = t + 1;
+        }
+        // (a wave that timed out in the middle of a tick has served that tick for its first sub-batches only - reported through status)
+        if (ES == 1) {
+            if (base < n) store_env(s, n, base, env);
+        } else {
+#pragma unroll 1
+            for (int e = 0; e < ES; ++e) {
+                q1pair::env_from_lds(state + (size_t)e * q1pair::STATE_WORDS * 64u, lane, env);
+                if (base + 64u * e < n) store_env(s, n, base + 64u * e, env);
+            }
+        }
+        if (lane == 0 && completed != ticks) {
+            atomicAdd(&status[0], 1u);
+            if (timed_out) atomicOr(&status[1], 1u);
+            atomicMax(&status[2], (uint32_t)(ticks - completed));
+        }
+    } else {
+        // the dependent reference producer: tick t + 1's action only after all eight result words of tick t were read
+        double acc_r[ES], acc_o[ES];
+        uint32_t k_cur[ES];                                      // the packed actions of the tick about to be handed over ...
+        float m_cur[ES];
+#pragma unroll
+        for (int e = 0; e < ES; ++e) {
+            const uint32_t i = base + 64u * (uint32_t)e;
+            acc_r[e] = 0.0; acc_o[e] = 0.0;
+            k_cur[e] = i < n ? keys[i] : 0u;
+            m_cur[e] = i < n ? mouse[i] : 0.0f;
+        }
+        int handed = 0;
+        bool timed_out = false;
+        for (int t = 0; t < ticks && !timed_out; ++t) {
+            // ... and the NEXT tick's are requested a whole tick ahead: an HBM load (1 - 2 us) is longer than the tick it would otherwise
+            // have to hide under
+            uint32_t k_nxt[ES];
+            float m_nxt[ES];
+#pragma unroll
+            for (int e = 0; e < ES; ++e) {
+                const uint32_t i = base + 64u * (uint32_t)e;
+                const bool more = t + 1 < ticks && i < n;
+                k_nxt[e] = more ? keys[(size_t)(t + 1) * n + i] : 0u;
+                m_nxt[e] = more ? mouse[(size_t)(t + 1) * n + i] : 0.0f;
+            }
+#pragma unroll
+            for (int e = 0; e < ES; ++e) {
+                const uint32_t i = base + 64u * (uint32_t)e;
+                const bool live = i < n;
+                if (t > 0) {
+                    if (!q1pair::wait_tag(res_tag + e, (uint32_t)t, timeout_ticks)) { timed_out = true; break; }
+                    const uint32_t* r = res + (size_t)e * 8u * 64u;
+                    uint32_t w[8];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) w[q] = r[q * 64 + lane];
+                    uint32_t sink = 0;                                   // every word is read (a policy would consume them all)
+#pragma unroll
+                    for (int q = 1; q < 6; ++q) sink |= w[q];
+                    if (live) {
+                        acc_r[e] += (double)__uint_as_float(w[6]);
+                        acc_o[e] += (double)__uint_as_float(w[0]);
+                    }
+                    asm volatile("" ::"v"(sink), "v"(w[7]));
+                }
+                act[e * 64 + lane] = ((uint64_t)(k_cur[e] & 0xFu) << 32) | (uint64_t)__float_as_uint(m_cur[e]);
+                q1pair::publish_tag(act_tag + e, (uint32_t)t + 1u, lane == 0);
+            }
+#pragma unroll
+            for (int e = 0; e < ES; ++e) { k_cur[e] = k_nxt[e]; m_cur[e] = m_nxt[e]; }
+            if (!timed_out) handed = t + 1;
+        }
+#pragma unroll
+        for (int e = 0; e < ES; ++e) {
+            const uint32_t i = base + 64u * (uint32_t)e;
+            if (i < n && checksum) { checksum[i] += acc_r[e]; checksum[(size_t)n + i] += acc_o[e]; }
+        }
+        if (lane == 0 && handed != ticks) {
+            if (timed_out) atomicOr(&status[3], 1u);
+            atomicMax(&status[4], (uint32_t)(ticks - handed));
+        }
+    }
 }
-#undef Q1_PAIR_KERNEL_BODY

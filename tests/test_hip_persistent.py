@@ -65,10 +65,10 @@ def test_tick_server_equals_per_tick_kernels(n, ticks, over, two_streams):
     a.close(); b.close()
 
 
-@pytest.mark.parametrize("n,two_streams", [(131072 + 77, False),        # 2 envs per lane (pair), ragged last wave
-                                           (131072 + 77, True),         # ... and on two streams
+@pytest.mark.parametrize("n,two_streams", [(131072 + 77, False),        # two sub-batches per workgroup (pair), ragged last wave
+                                           (131072 + 77, True),         # ... and 2 envs per lane on two streams
                                            (200000, True),              # 4 envs per lane next to an external producer
-                                           (262144, False)])            # 4 envs per lane: BASELINE configs[2]'s batch as ONE resident grid
+                                           (262144, False)])            # BASELINE configs[2]'s batch as ONE resident grid
 def test_tick_server_several_envs_per_lane(n, two_streams):
     """Batches above one env per lane of the resident grid: each wave serves 2 or 4 sub-batches of 64 envs in order.  Same bits as
     the per-tick kernels (state, last results, the producer's float64 sums), with in-kernel resets on."""
@@ -98,13 +98,12 @@ def test_tick_server_several_envs_per_lane(n, two_streams):
     a.close(); b.close()
 
 
-@pytest.mark.parametrize("knobs", [{}, {"Q1ENV_SERVER_NEAR": "0"}, {"Q1ENV_SERVER_PAD": "0"}])
-@pytest.mark.parametrize("n", [4096 + 37, 65536 + 64])            # 65 and 1025 blocks: odd, so unpadded pairs sit on two XCDs
-def test_tick_server_hand_off_paths(n, knobs, monkeypatch):
-    """The hand-offs travel XCD-local (plain stores, found in the shared L2) between wave pairs that verified - by exchanging
-    their XCC ids - that they share an XCD, agent-scope (sc1) otherwise.  Same bits on every path: default (padded grid: pairs
-    meet on one XCD), fast path off, and an unpadded odd grid (every pair verified to sit on two XCDs); launches alternate
-    between the knobs' setting and the default, with continuing tags, so stale XCD-local copies would show."""
+@pytest.mark.parametrize("shape", ["1", "2", "3"])
+@pytest.mark.parametrize("n", [4096 + 37, 65536 + 64])
+def test_tick_server_pair_shapes(n, shape, monkeypatch):
+    """q1env_step_persistent_pair: a (server wave, driver wave) workgroup serves 1, 2 or 3 sub-batches of 64 envs (the smallest count
+    whose grid is resident; forced here through the measurement knob).  With more than one, the server rotates the sub-batches' states
+    through LDS.  Same bits in every shape, over launches that alternate between the forced shape and the default."""
     import torch
     ticks = 90
     over = dict(time_limit=0.4, zero_start_prob=0.3)
@@ -121,13 +120,12 @@ def test_tick_server_hand_off_paths(n, knobs, monkeypatch):
                 sums[1] += obs_b[:, 0].double()
         with monkeypatch.context() as m:
             if launch != 1:
-                for k, v in knobs.items():
-                    m.setenv(k, v)
+                m.setenv("Q1ENV_SERVER_SHAPE", shape)
             res = a.serve_ticks(keys, mouse)
         assert not res["status"].any(), (launch, res["status"])
         assert torch.equal(res["checksum"], sums), launch
         assert torch.equal(res["obs"], obs_b) and torch.equal(res["obs_from_granules"], obs_b)
-        assert torch.equal(res["reward"], rew_b) and torch.equal(res["done"], done_b)
+        assert torch.equal(res["reward"], rew_b) and torch.equal(res["done"], done_b) and torch.equal(res["zero_start"], b.zero_start)
     sa, sb = a.get_state(), b.get_state()
     for k in sa:
         assert np.array_equal(sa[k], sb[k]), k
