@@ -46,6 +46,6 @@ def test_bench_prints_one_contract_json_line():
     # per-tick kernels are then reported next to it, and the steady-state block carries both
     assert d["mode"] in ("server", "step") and (d["mode"] == "server" or d["mode_fallback"])
     if d["mode"] == "server":
-        assert d["mode_fallback"] is None and d["per_tick_step"]["value"] > 1e8 and "tick_pair_kernel" in rf["kernel"]
+        assert d["mode_fallback"] is None and d["per_tick_step"]["value"] > 1e8 and "tick_pair_lds_kernel" in rf["kernel"]
     ss = d["steady_state_720_ticks"]
     assert ss["step"]["us_per_tick"] > 0 and ss["server"]["us_per_tick"] > 0
