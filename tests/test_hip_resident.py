@@ -86,3 +86,62 @@ def test_resident_sampler_refuses_what_it_cannot_run():
     with pytest.raises(ValueError, match="FusedPolicyForward"):
         cfg, env = make_env(512, seed=1)
         GpuSampler(env, P.Q1Policy().cuda(), horizon=4, resident=True)
+
+
+def test_policy_forward_rows_equals_the_per_batch_forward():
+    """q1env_policy_forward_rows over T stacked observation batches == T q1env_policy_value_forward calls, bit for bit (what the
+    resident sampler's batched value forward relies on)."""
+    import torch
+    from q1physrl_amd import policy as P
+    n, T = 3000, 5
+    cfg, env = make_env(n, seed=2)
+    torch.manual_seed(1)
+    pol = P.Q1Policy().cuda()
+    with torch.no_grad():
+        for p_ in pol.parameters():
+            p_.mul_(2.0)
+    fused = P.FusedPolicyForward(pol, env)
+    obs = (torch.rand((T, n, 6), device="cuda") * 2 - 1).contiguous()
+    per_batch_l, per_batch_v = [], []
+    for t in range(T):
+        lg, v = fused(obs[t])
+        per_batch_l.append(lg.clone()); per_batch_v.append(v.clone())
+    value = torch.empty((T * n, 1), device="cuda")
+    logits = torch.empty((T * n, 10), device="cuda")
+    env._dev.policy_forward_rows_dev(T * n, obs.data_ptr(), fused._mlp("vf", value))
+    env._dev.policy_forward_rows_dev(T * n, obs.data_ptr(), fused._mlp("pi", logits))
+    torch.cuda.synchronize()
+    assert torch.equal(value.view(T, n), torch.stack(per_batch_v)) and torch.equal(logits.view(T, n, 10), torch.stack(per_batch_l))
+    env.close()
+
+
+def test_resident_sampler_shard_equals_the_slice_of_the_whole_batch():
+    """Multi-GPU is a batch split: the trajectories a shard (env_index_base = first global env) samples are the corresponding slice
+    of the whole batch's - the Philox draws of sampling and resets are keyed by the GLOBAL env index, the workgroup boundaries are not."""
+    import torch
+    from q1physrl_amd import policy as P
+    from q1physrl_amd.env import Config
+    from q1physrl_amd.sampler import GpuSampler
+    from q1physrl_amd.tensor_env import TensorVectorEnv
+    n, T, base, count = 6000, 20, 2100, 1700                       # a shard that starts and ends inside workgroups of the whole batch
+    over = dict(time_limit=0.2, zero_start_prob=1.0)               # (zero starts: the initial state is the same everywhere)
+    outs = []
+    for num, b in ((n, 0), (count, base)):
+        cfg = O.OracleConfig.get_default(num_envs=num, **over)
+        env = TensorVectorEnv(Config(**cfg.__dict__), device=0, seed=4, env_index_base=b)
+        torch.manual_seed(3)
+        pol = P.Q1Policy().cuda()
+        with torch.no_grad():
+            for p_ in pol.parameters():
+                p_.mul_(3.0)
+        s = GpuSampler(env, P.FusedPolicyForward(pol, env), horizon=T, resident=True)
+        runs = [{k: v.clone() for k, v in s.collect().items()} for _ in range(2)]
+        torch.cuda.synchronize()
+        assert not s.resident_status().any()
+        outs.append(runs)
+        env.close()
+    whole, shard = outs
+    for h in range(2):
+        for k in ("obs", "keys", "mouse", "logp", "logits", "value", "reward", "done"):
+            assert torch.equal(whole[h][k][:, base:base + count], shard[h][k]), (h, k)
+    assert int(whole[1]["done"].sum()) > 0

@@ -29,7 +29,7 @@ def main():
     env = TensorVectorEnv(Config(num_envs=n, **PARAMS_YML), seed=3)
     env.reset()
     keys = torch.randint(0, 16, (T, n), dtype=torch.uint8, device="cuda")
-    mouse = (torch.rand((T, n), device="cuda") * 20 - 10)
+    mouse = (torch.rand((T, n), device="cuda") * 20 - 10).contiguous()
     def step_reset():
         for t in range(T):
             env.step_tensor((keys[t], mouse[t]))
@@ -60,6 +60,11 @@ def main():
     print(f"C3 {n} envs full Config: step with in-kernel reset, 1 launch/tick (+1 counter op), graph replay: {ms*1e3/T:8.2f} us/tick  {n*T/ms/1e6:8.2f} G env-steps/s")
     ms = timed(env, lambda: env.step_many((keys, mouse), T, auto_reset=True), 3)
     print(f"C3 {n} envs full Config: q1env_step_autoreset_many (1 launch/tick, one counter node per {T} ticks), graph replay: {ms*1e3/T:8.2f} us/tick  {n*T/ms/1e6:8.2f} G env-steps/s")
+    def served():
+        env.serve_ticks(keys, mouse, sync=False)
+    ms = timed(env, served, 3)
+    assert not env._srv["status"].cpu().numpy().any()
+    print(f"C3 {n} envs full Config: resident tick server + dependent producer (q1env_step_persistent_pair, in-kernel reset): {ms*1e3/T:8.2f} us/tick  {n*T/ms/1e6:8.2f} G env-steps/s")
     obs = torch.empty((T, n, 6), dtype=torch.float32, device="cuda"); rew = torch.empty((T, n), device="cuda"); done = torch.empty((T, n), dtype=torch.uint8, device="cuda")
     def fused():
         env._dev.rollout_dev(T, _lib.ACT_PACKED, keys.data_ptr(), mouse.data_ptr(), 3, _lib.OBS_F32, obs.data_ptr(), rew.data_ptr(), done.data_ptr(), True, 0)
@@ -75,6 +80,7 @@ def main():
     mouse = (torch.rand((T, n), device="cuda") * 20 - 10)
     obs = torch.empty((T, n, 6), dtype=torch.float32, device="cuda"); rew = torch.empty((T, n), device="cuda"); done = torch.empty((T, n), dtype=torch.uint8, device="cuda")
     variants = {
+        "resident tick server + dependent producer (q1env_step_persistent_pair)": lambda: env.serve_ticks(keys.contiguous(), mouse.contiguous(), sync=False),
         "per-tick step kernel (hipGraph), packed actions from HBM": lambda: env._dev.step_many_dev(T, _lib.ACT_PACKED, keys.data_ptr(), mouse.data_ptr(), _lib.OBS_F32, env.obs.data_ptr(), env.reward.data_ptr(), env.done.data_ptr(), 0, True),
         "fused rollout, packed actions from HBM, per-tick outputs": lambda: env._dev.rollout_dev(T, _lib.ACT_PACKED, keys.data_ptr(), mouse.data_ptr(), 0, _lib.OBS_F32, obs.data_ptr(), rew.data_ptr(), done.data_ptr(), False, 0),
         "fused rollout, on-device Philox actions, per-tick outputs": lambda: env._dev.rollout_dev(T, _lib.ACT_RANDOM, 0, 0, 7, _lib.OBS_F32, obs.data_ptr(), rew.data_ptr(), done.data_ptr(), False, 0),
