@@ -46,6 +46,11 @@ def build_lib(force=False, verbose=False):
     if r.returncode != 0:
         raise RuntimeError("hipcc failed:\n" + r.stdout + r.stderr)
     os.replace(OUT + ".tmp", OUT)
+    for stray in glob.glob(OUT + ".*"):            # the offload bundler's per-target intermediates (libq1env.so.0.hipv4-..., ...)
+        try:
+            os.remove(stray)
+        except OSError:
+            pass
     return OUT
 
 
