@@ -178,6 +178,38 @@ def size_sweep(dev_index, sizes=(262144, 1048576, 4194304), ticks=72, reps=4):
     return rows
 
 
+def sampler_block(dev_index, n=32768, horizon=64, reps=3):
+    """BASELINE configs[4]'s per-GPU shard next to the contract fields: the env inside a sampler loop with the policy in it (params.yml
+    Config, random-init policy of the reference's shape) - the two-launch tick (fused matrix-core forward + fused sample/step/reset,
+    the horizon captured in a hipGraph) and the resident sampler (one dispatch per horizon + one batched value forward); HIP events."""
+    import torch
+    from q1physrl_amd import policy as P
+    from q1physrl_amd.env import Config
+    from q1physrl_amd.sampler import GpuSampler
+    from q1physrl_amd.tensor_env import TensorVectorEnv
+    params_yml = dict(action_range=10, allow_jump=True, allow_yaw=True, auto_jump=False, discrete_yaw_steps=-1, fmove_max=800, smove_max=1060,
+                      hover=False, initial_yaw_range=(0, 360), key_press_delay=0.3, max_initial_speed=700, smooth_keys=True, speed_reward=False,
+                      time_delta=0.013888888888888, time_limit=10, zero_start_prob=0.01)
+    row = {"envs": n, "horizon": horizon, "workload": "BASELINE configs[4] shard: sampler loop with the policy forward in it, params.yml Config"}
+    for label, kw in (("two_launch", dict(use_graph=True)), ("resident", dict(resident=True))):
+        env = TensorVectorEnv(Config(num_envs=n, **params_yml), device=dev_index, seed=1)
+        s = GpuSampler(env, P.FusedPolicyForward(P.Q1Policy().cuda(), env), horizon=horizon, **kw)
+        s.collect(); s.collect()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        best = 1e30
+        for _ in range(reps):
+            env.use_current_stream()
+            e0.record(); s.collect(); e1.record(); torch.cuda.synchronize()
+            best = min(best, e0.elapsed_time(e1) * 1e3 / horizon)
+        if label == "resident" and s.resident_status().any():
+            raise RuntimeError(f"resident sampler timed out: status {s.resident_status()}")
+        row[label + "_us_per_tick"] = best
+        row[label + "_env_steps_per_s"] = n / (best * 1e-6)
+        env.close()
+    return row
+
+
 def load_profiled_traffic(mode, n, env_steps_per_launch=None):
     """HBM bytes per launch measured with rocprofv3 PMC passes (tools/profile_round.sh -> profiles/traffic.json); None if absent.
     A tick-server launch serves as many ticks as it is asked to, so its entry is per env-step and scaled to the launch."""
@@ -592,6 +624,11 @@ def main(argv=None):
                 steady[m] = {"error": repr(ex)}
         out["steady_state_720_ticks"] = steady
         out["step_kernel_size_sweep"] = size_sweep(dev_index)
+        if rank == 0 and not injected:
+            try:
+                out["sampler_configs4_shard"] = sampler_block(dev_index)
+            except Exception as ex:   # noqa: BLE001 - extra information must not take the contract line down
+                out["sampler_configs4_shard"] = {"error": repr(ex)}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         def gpu_check(acts, k):
             """The GPU env on the oracle's own actions (float64 rows) for k ticks from a fresh zero start."""
