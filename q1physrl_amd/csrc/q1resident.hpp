@@ -21,7 +21,8 @@
 // actions), a workgroup-scope release, then ONE tag word per env wave (observations) or per tile (actions) that carries the tick
 // number; the reader spins on the tag (a broadcast ds_read, ~0.1 us per look - an L2 granule costs ~0.45 us per look), acquires, reads.
 // LDS room: only 16 of the 32 rows of the W3 tile are kept (rows >= out_dim are zero anyway; lanes 16..31 re-read rows 0..15
-// and produce output rows nobody looks at), which frees 8.4 KB next to the weights.
+// and produce output rows nobody looks at), which frees 8.4 KB next to the weights; a discrete-mouse head with up to 24 outputs
+// keeps 24 rows and runs at one tile per policy wave.
 // The value network is NOT in the loop: its forward over the (T + 1) N stored observations runs afterwards as one batched launch
 // at full efficiency (q1env_policy_forward_rows) - nothing in the loop depends on it.
 // Bit-identical trajectories to the two-launch sampler (same forward arithmetic per tile, same draws, same env arithmetic).
@@ -51,17 +52,21 @@ struct ResidentArgs {
 };
 
 namespace q1res {
-// LDS map of a workgroup: the network (W3 trimmed to 16 rows) and the hand-off area (sized for TP = 2: 256 envs)
+// LDS map of a workgroup: the network with W3 trimmed to R3 rows (16 for the continuous head's out_dim <= 10, 24 for a discrete-mouse
+// head of up to 24 outputs) and the hand-off area for 128 TP envs.  (R3, TP) = (16, 1), (16, 2), (24, 1) fit the CU's 160 KB; (24, 2) does not.
 constexpr size_t L_W2 = 0;
-constexpr size_t L_W3 = q1pol::LDS_W2;                                       // 135168
-constexpr size_t W3_BYTES = (size_t)16 * q1pol::ROW_BYTES;                    // 8448
-constexpr size_t L_B2 = L_W3 + W3_BYTES;                                      // 143616
-constexpr size_t L_W1 = L_B2 + q1pol::LDS_B2;                                 // 144640
-constexpr size_t L_TAGS = L_W1 + q1pol::LDS_W1;                               // 152832: uint32 obs_tag[4], act_tag[8] (+ pad)
-constexpr size_t L_ACT = L_TAGS + 64;                                         // uint64 act[256]
-constexpr size_t L_OBS = L_ACT + 256 * 8;                                     // float obs[256][6]
-constexpr size_t LDS_BYTES = L_OBS + 256 * 6 * 4;                             // 161088 <= 163840
-constexpr uint32_t IMG_VEC16 = (uint32_t)((q1pol::LDS_W2 + W3_BYTES) / 16);   // W2 rows + the first 16 W3 rows of the host's image
+constexpr size_t L_W3 = q1pol::LDS_W2;                                                 // 135168
+template <int R3> struct Map {
+    static constexpr size_t W3_BYTES = (size_t)R3 * q1pol::ROW_BYTES;
+    static constexpr size_t L_B2 = L_W3 + W3_BYTES;
+    static constexpr size_t L_W1 = L_B2 + q1pol::LDS_B2;
+    static constexpr size_t L_TAGS = L_W1 + q1pol::LDS_W1;                             // uint32 obs_tag[4], act_tag[8] (+ pad)
+    static constexpr size_t L_ACT = L_TAGS + 64;                                       // uint64 act[128 TP]
+    static constexpr uint32_t IMG_VEC16 = (uint32_t)((q1pol::LDS_W2 + W3_BYTES) / 16); // W2 rows + the first R3 W3 rows of the host's image
+    static constexpr size_t l_obs(int tp) { return L_ACT + (size_t)128 * tp * 8; }     // float obs[128 TP][6]
+    static constexpr size_t bytes(int tp) { return l_obs(tp) + (size_t)128 * tp * 24; }
+};
+static_assert(Map<16>::bytes(2) <= 163840 && Map<24>::bytes(1) <= 163840, "the resident sampler's LDS map must fit one CU");
 
 __device__ __forceinline__ uint32_t tag_load(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 __device__ __forceinline__ void tag_store(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
@@ -83,16 +88,17 @@ __device__ __forceinline__ bool wait_tag(const uint32_t* tag, uint32_t want, uin
 }  // namespace q1res
 
 // u = env wave of the workgroup (0 .. 2 TP - 1): envs i = block_env0 + 64 u + lane
-template <bool SPEC>
+template <bool SPEC, int TP, int R3>
 __device__ __forceinline__ void resident_env_wave(const Params& p, const StatePtrs& s, const ResidentArgs& a, uint32_t i, uint32_t u, unsigned char* lds) {
+    using M = q1res::Map<R3>;
     const uint32_t lane = threadIdx.x & 63u, n = (uint32_t)p.n;
     const bool live = i < n;
     const uint64_t genv = (uint64_t)p.env_index_base + (uint64_t)i;
     const uint64_t counter0 = a.counter_offset + (a.counter_dev ? *a.counter_dev : 0ull);
-    uint32_t* obs_tag = reinterpret_cast<uint32_t*>(lds + q1res::L_TAGS) + u;
-    const uint32_t* act_tag = reinterpret_cast<const uint32_t*>(lds + q1res::L_TAGS) + 4u + 2u * u;       // this wave's two tiles
-    const uint64_t* act = reinterpret_cast<const uint64_t*>(lds + q1res::L_ACT) + 64u * u + lane;
-    float* obs_row = reinterpret_cast<float*>(lds + q1res::L_OBS) + (size_t)(64u * u + lane) * 6u;
+    uint32_t* obs_tag = reinterpret_cast<uint32_t*>(lds + M::L_TAGS) + u;
+    const uint32_t* act_tag = reinterpret_cast<const uint32_t*>(lds + M::L_TAGS) + 4u + 2u * u;       // this wave's two tiles
+    const uint64_t* act = reinterpret_cast<const uint64_t*>(lds + M::L_ACT) + 64u * u + lane;
+    float* obs_row = reinterpret_cast<float*>(lds + M::l_obs(TP)) + (size_t)(64u * u + lane) * 6u;
     Env env{};
     double ep_ret = 0.0;
     if (live) { load_env(s, n, i, env); ep_ret = a.ep_return[i]; }
@@ -174,20 +180,22 @@ __device__ __forceinline__ void resident_env_wave(const Params& p, const StatePt
 }
 
 // v = policy wave of the workgroup (0..3): tiles v TP + j, j < TP (tile = 32 envs; tile k of the workgroup belongs to env wave k / 2)
-template <int TP>
+template <int TP, int R3>
 __device__ __forceinline__ void resident_policy_wave(const Params& p, const ResidentArgs& a, uint32_t block_env0, uint32_t v, unsigned char* lds) {
+    using M = q1res::Map<R3>;
+    constexpr int NLG = R3 == 16 ? 10 : 24;                      // logits an env's lane gathers (rows 0..9, or all 24)
     const uint32_t lane = threadIdx.x & 63u, n = (uint32_t)p.n;
     const uint32_t col = lane & 31u, half = lane >> 5;
     const int W = a.pi.out_dim;
     const uint64_t counter0 = a.counter_offset + (a.counter_dev ? *a.counter_dev : 0ull);
-    const unsigned char* w1row = lds + q1res::L_W1 + (size_t)col * 32u + half * 16u;
+    const unsigned char* w1row = lds + M::L_W1 + (size_t)col * 32u + half * 16u;
     const unsigned char* wrow = lds + q1res::L_W2 + (size_t)col * q1pol::ROW_BYTES + half * 16u;
-    const unsigned char* w3row = lds + q1res::L_W3 + (size_t)(col & 15u) * q1pol::ROW_BYTES + half * 16u;      // rows 16..31 alias 0..15
-    const float* l_b2 = reinterpret_cast<const float*>(lds + q1res::L_B2);
-    const uint32_t* obs_tags = reinterpret_cast<const uint32_t*>(lds + q1res::L_TAGS);
-    uint32_t* act_tags = reinterpret_cast<uint32_t*>(lds + q1res::L_TAGS) + 4u;
-    uint64_t* act = reinterpret_cast<uint64_t*>(lds + q1res::L_ACT);
-    const float* obs_lds = reinterpret_cast<const float*>(lds + q1res::L_OBS);
+    const unsigned char* w3row = lds + q1res::L_W3 + (size_t)(col % (uint32_t)R3) * q1pol::ROW_BYTES + half * 16u;   // rows R3..31 alias 0..
+    const float* l_b2 = reinterpret_cast<const float*>(lds + M::L_B2);
+    const uint32_t* obs_tags = reinterpret_cast<const uint32_t*>(lds + M::L_TAGS);
+    uint32_t* act_tags = reinterpret_cast<uint32_t*>(lds + M::L_TAGS) + 4u;
+    uint64_t* act = reinterpret_cast<uint64_t*>(lds + M::L_ACT);
+    const float* obs_lds = reinterpret_cast<const float*>(lds + M::l_obs(TP));
     uint32_t tile[TP], loc[TP], env[TP];
     bool live[TP];
 #pragma unroll
@@ -197,9 +205,9 @@ __device__ __forceinline__ void resident_policy_wave(const Params& p, const Resi
         env[j] = block_env0 + loc[j];
         live[j] = env[j] < n;
     }
-    float b3[10];                                                 // the output bias: fetched once
+    float b3[NLG];                                                // the output bias: fetched once
 #pragma unroll
-    for (int k = 0; k < 10; ++k) b3[k] = k < W ? a.pi.b3[k] : 0.0f;
+    for (int k = 0; k < NLG; ++k) b3[k] = k < W ? a.pi.b3[k] : 0.0f;
     bool timed_out = false;
     int handed = 0;
     for (int t = 0; t < a.ticks && !timed_out; ++t) {
@@ -221,30 +229,45 @@ __device__ __forceinline__ void resident_policy_wave(const Params& p, const Resi
             // ---- forward: Y^T of the tile, then all of an env's logits into its half-0 lane
             const q1pol::f16x8 xb = q1pol::split_inputs(x, half);
             const q1pol::f32x16 y = q1pol::mlp_tile(xb, w1row, wrow, w3row, l_b2, half, nullptr);
-            // lane (col, half) holds rows r + 8 g + 4 half; rows 0..3, 8..9 are half 0's, rows 4..7 come over from lane + 32
-            float lg[10];
+            // lane (col, half) holds rows r + 8 g + 4 half in y[4 g + r]: half 0 owns rows 0..3, 8..11, 16..19 of its column, rows 4..7,
+            // 12..15, 20..23 come over from lane + 32
+            float lg[NLG];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float other = __shfl_xor(y[r], 32, 64);               // half 0 receives rows 4 + r of its column
-                lg[r] = y[r];
-                lg[4 + r] = other;
-            }
-            lg[8] = y[4]; lg[9] = y[5];
+            for (int g = 0; g < (NLG == 10 ? 1 : 3); ++g)
 #pragma unroll
-            for (int k = 0; k < 10; ++k) lg[k] = k < W ? lg[k] + b3[k] : 0.0f;
+                for (int r = 0; r < 4; ++r) {
+                    const float other = __shfl_xor(y[4 * g + r], 32, 64);
+                    lg[8 * g + r] = y[4 * g + r];
+                    lg[8 * g + 4 + r] = other;
+                }
+            if (NLG == 10) { lg[8] = y[4]; lg[9] = y[5]; }
+#pragma unroll
+            for (int k = 0; k < NLG; ++k) lg[k] = k < W ? lg[k] + b3[k] : 0.0f;
             // sample in the half-0 lanes, hand the tile's actions over (data, release, tag = number of ticks handed over), and only
             // THEN write the trajectory: a release waits for every store issued before it, and these go all the way to HBM
             uint32_t keys = 0;
             float mouse = 0.0f, logp = 0.0f;
             const bool actor = half == 0u && live[j];
-            if (actor) sample_action_from_draws(p, lg, nullptr, r, r2, a.deterministic, keys, mouse, logp);
+            float* row = a.pi.out ? a.pi.out + ((size_t)t * n + env[j]) * (uint32_t)W : nullptr;
+            if (actor) {
+                float lg10[10];
+#pragma unroll
+                for (int k = 0; k < 10; ++k) lg10[k] = lg[k];
+                if (NLG > 10) {
+                    // a discrete mouse: the categorical part of the sampling walks the row in memory (as q1env_sample_step does), so the
+                    // logits row of the trajectory is written BEFORE the sampling here (a thread reads its own stores)
+#pragma unroll
+                    for (int k = 0; k < NLG; ++k)
+                        if (k < W) row[k] = lg[k];
+                }
+                sample_action_from_draws(p, lg10, row, r, r2, a.deterministic, keys, mouse, logp);
+            }
             if (half == 0u) act[loc[j]] = ((uint64_t)(keys & 0xFu) << 32) | (uint64_t)__float_as_uint(mouse);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             if (lane == 0) q1res::tag_store(act_tags + tile[j], (uint32_t)t + 1u);
             if (actor) {
                 const uint32_t i = env[j];
-                if (a.pi.out) {
-                    float* row = a.pi.out + ((size_t)t * n + i) * (uint32_t)W;
+                if (NLG == 10 && row) {
 #pragma unroll
                     for (int k = 0; k < 10; ++k)
                         if (k < W) row[k] = lg[k];
@@ -262,9 +285,10 @@ __device__ __forceinline__ void resident_policy_wave(const Params& p, const Resi
     }
 }
 
-template <bool SPEC, int TP>
+template <bool SPEC, int TP, int R3>
 __global__ void __launch_bounds__(512, 1)
 sampler_resident_kernel(Params p, StatePtrs s, ResidentArgs a) {
+    using M = q1res::Map<R3>;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const uint32_t tid = threadIdx.x, wave = tid >> 6;
     const uint32_t block_env0 = blockIdx.x * (128u * (uint32_t)TP);
@@ -272,29 +296,29 @@ sampler_resident_kernel(Params p, StatePtrs s, ResidentArgs a) {
     {
         const uint4* src = reinterpret_cast<const uint4*>(a.pi.w23);
         uint4* d = reinterpret_cast<uint4*>(lds);
-        constexpr uint32_t PER = (q1res::IMG_VEC16 + 511u) / 512u;
+        constexpr uint32_t PER = (M::IMG_VEC16 + 511u) / 512u;
         uint4 v[PER];
 #pragma unroll
         for (uint32_t k = 0; k < PER; ++k) {
             const uint32_t c = k * 512u + tid;
-            v[k] = c < q1res::IMG_VEC16 ? src[c] : make_uint4(0, 0, 0, 0);
+            v[k] = c < M::IMG_VEC16 ? src[c] : make_uint4(0, 0, 0, 0);
         }
 #pragma unroll
         for (uint32_t k = 0; k < PER; ++k) {
             const uint32_t c = k * 512u + tid;
-            if (c < q1res::IMG_VEC16) d[c] = v[k];
+            if (c < M::IMG_VEC16) d[c] = v[k];
         }
         if (tid < (uint32_t)q1pol::HID) {
-            reinterpret_cast<float*>(lds + q1res::L_B2)[tid] = q1pol::TANH_PRESCALE * a.pi.b2[tid];
-            q1pol::stage_w1_row(lds + q1res::L_W1, tid, a.pi.w1, a.pi.b1);
+            reinterpret_cast<float*>(lds + M::L_B2)[tid] = q1pol::TANH_PRESCALE * a.pi.b2[tid];
+            q1pol::stage_w1_row(lds + M::L_W1, tid, a.pi.w1, a.pi.b1);
         }
-        if (tid < 16u) reinterpret_cast<uint32_t*>(lds + q1res::L_TAGS)[tid] = 0u;
+        if (tid < 16u) reinterpret_cast<uint32_t*>(lds + M::L_TAGS)[tid] = 0u;
     }
     __syncthreads();                                                       // (the only barrier: before any wave leaves or loops)
     if (wave < 4u) {
-        resident_policy_wave<TP>(p, a, block_env0, wave, lds);
+        resident_policy_wave<TP, R3>(p, a, block_env0, wave, lds);
     } else if (wave < 4u + 2u * (uint32_t)TP) {
         const uint32_t u = wave - 4u;
-        resident_env_wave<SPEC>(p, s, a, block_env0 + u * 64u + (tid & 63u), u, lds);
+        resident_env_wave<SPEC, TP, R3>(p, s, a, block_env0 + u * 64u + (tid & 63u), u, lds);
     }
 }

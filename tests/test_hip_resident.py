@@ -23,7 +23,7 @@ def run_sampler(n, horizons, T, resident, over, deterministic=False, policy_seed
     from q1physrl_amd.sampler import GpuSampler
     torch.manual_seed(policy_seed)
     cfg, env = make_env(n, seed=9, **over)
-    pol = P.Q1Policy(num_keys=env.num_keys, allow_yaw=cfg.allow_yaw).cuda() if (env.num_keys != 4 or not cfg.allow_yaw) else P.Q1Policy().cuda()
+    pol = P.Q1Policy(num_keys=env.num_keys, allow_yaw=cfg.allow_yaw, discrete_yaw_steps=cfg.discrete_yaw_steps).cuda()
     with torch.no_grad():                                          # (weights large enough for the actions to depend on the observation)
         for p_ in pol.parameters():
             p_.mul_(3.0)
@@ -49,6 +49,10 @@ def run_sampler(n, horizons, T, resident, over, deterministic=False, policy_seed
     (1500, 30, dict(time_limit=0.25, allow_yaw=False), False),                          # no mouse
     (777, 30, dict(time_limit=0.25, auto_jump=True, speed_reward=True), False),         # generic (SPEC = false) kernels
     (2048, 30, dict(zero_start_prob=0.5, time_limit=0.3), True),                        # deterministic actions
+    (3000, 30, dict(time_limit=0.25, zero_start_prob=0.4, discrete_yaw_steps=5), False),        # discrete mouse: 19 logits, categorical head
+    (900, 30, dict(time_limit=0.25, discrete_yaw_steps=7, hover=True), False),                  # 23 logits, generic kernels
+    (1300, 24, dict(time_limit=0.25, discrete_yaw_steps=1, allow_jump=False), True),            # 3 keys + a 3-way mouse: 9 logits, still the discrete variant
+    (32768, 8, dict(zero_start_prob=0.3, time_limit=0.1, discrete_yaw_steps=5), False),         # the wide variant's capacity
 ])
 def test_resident_sampler_equals_the_two_launch_sampler(n, T, over, det):
     import torch
@@ -72,10 +76,15 @@ def test_resident_sampler_refuses_what_it_cannot_run():
     import torch
     from q1physrl_amd import _lib, policy as P
     from q1physrl_amd.sampler import GpuSampler
-    cfg, env = make_env(512, seed=1, discrete_yaw_steps=5)
-    pol = P.Q1Policy(discrete_yaw_steps=5).cuda()
+    cfg, env = make_env(512, seed=1, discrete_yaw_steps=10)
+    pol = P.Q1Policy(discrete_yaw_steps=10).cuda()                  # 8 + 21 = 29 outputs: more than the resident workgroup's LDS holds
     s = GpuSampler(env, P.FusedPolicyForward(pol, env), horizon=4, resident=True)
-    with pytest.raises(_lib.Q1EnvError, match="discrete-mouse"):
+    with pytest.raises(_lib.Q1EnvError, match="more than 24"):
+        s.collect()
+    env.close()
+    cfg, env = make_env(40000, seed=1, discrete_yaw_steps=5)       # a discrete-mouse head runs at one tile per policy wave: 32 768 envs at most
+    s = GpuSampler(env, P.FusedPolicyForward(P.Q1Policy(discrete_yaw_steps=5).cuda(), env), horizon=4, resident=True)
+    with pytest.raises(_lib.Q1EnvError, match="too many envs"):
         s.collect()
     env.close()
     cfg, env = make_env(1 << 17, seed=1)
