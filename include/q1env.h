@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define Q1ENV_ABI_VERSION 2
+#define Q1ENV_ABI_VERSION 3
 
 typedef enum q1env_status {
     Q1ENV_OK = 0,
@@ -121,6 +121,11 @@ int q1env_set_stream(q1env_t* env, void* stream);
 int q1env_sync(q1env_t* env);
 int q1env_num_keys(const q1env_t* env);
 int q1env_action_width(const q1env_t* env);
+/* (ABI v3) Ticks this handle has stepped since create = the counter the handle-side counter RNG uses for the entry points called
+ * WITHOUT a device counter (reset_philox, step_autoreset, rollout, persistent_*; the reference has no counterpart: its resets draw
+ * from the global NumPy stream, env.py:432-446).  A caller that also drives entry points WITH a device counter (counter_dev) on the
+ * same handle seeds / re-synchronises that counter from this value, so the two families never reuse a (seed, env, counter) triple. */
+int q1env_tick_count(const q1env_t* env, uint64_t* out);
 
 /* ---- resets (env.py:428-480; decoder env.py:271-291) ------------------------------------------
  * reset_draws: the caller supplies the raw random draws (the reference's RNG is the GLOBAL NumPy
@@ -408,6 +413,12 @@ int q1env_step_persistent_collect(q1env_t* env, void* producer_stream, uint32_t 
 int q1env_step_persistent_pair(q1env_t* env, int ticks, uint32_t tag0, const uint8_t* keys_dev, const float* mouse_dev,
                                uint64_t* mailbox_dev, uint64_t* results_dev, float* obs_final_dev, uint64_t seed, int auto_reset,
                                double* checksum_dev, uint32_t* status_dev, double timeout_s);
+
+/* (ABI v3, diagnostics) Counters of the ASSERTION build of this library (python -m q1physrl_amd.build --check -> libq1env_check.so,
+ * compiled with -DQ1_CHECK): every hand-rolled 16-byte sc1 granule-pair store of the tick server is read back and compared with the
+ * registers it was issued from.  out4 = {1 if built with Q1_CHECK else 0, pair stores checked, mismatches, 0}; clear != 0 zeroes the
+ * device counters.  The product build returns {0, 0, 0, 0}.  Synchronises the handle's stream.  (No reference counterpart.) */
+int q1env_debug_counters(q1env_t* env, uint64_t* out4, int clear);
 
 /* ---- measurement ------------------------------------------------------------------------------
  * calibrate_traffic: `launches` launches of a pure copy kernel that reads the SoA state with step's own

@@ -101,7 +101,7 @@ def ppo_loss_grad_discrete(new_logits, new_value, b, steps, clip_param, vf_clip_
 
 
 def ppo_loss_grad(new_logits, new_value, b, action_range, clip_param, vf_clip_param, vf_loss_coeff, entropy_coeff, kl_coeff):
-    """float64 restatement of q1env_ppo_loss_grad (q1physrl_amd/csrc/q1env.hip::ppo_loss_grad_kernel): the closed-form derivatives
+    """float64 restatement of q1env_ppo_loss_grad (q1physrl_amd/csrc/q1env_policy.hip::ppo_loss_grad_kernel): the closed-form derivatives
     of ppo_loss above with respect to (new_logits, new_value), and the five statistics.  b["keys"] is (B, 4) 0/1.
     Returns dlogits (B, 10), dvalue (B,), stats dict (means of entropy, kl, policy_loss, total_loss, vf_loss)."""
     L, O = new_logits.astype(np.float64), b["old_logits"].astype(np.float64)

@@ -13,7 +13,7 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 # Q1ENV_LIB_PATH selects another build of the SAME library (tools/asan_check.sh: the AddressSanitizer build of the host side)
 LIB_PATH = os.environ.get("Q1ENV_LIB_PATH") or os.path.join(_PKG, "libq1env.so")
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 ACT_F64_ROWS, ACT_F32_ROWS, ACT_PACKED, ACT_RANDOM = 0, 1, 2, 3
 OBS_F64, OBS_F32 = 0, 1
 TIMER_START, TIMER_STOP = 4, 8     # q1env_step_many use_graph flags: record the handle's start / stop timer event around the launches
@@ -71,6 +71,8 @@ _SIGNATURES = {
     "q1env_sync": (C.c_int, [_P]),
     "q1env_num_keys": (C.c_int, [_P]),
     "q1env_action_width": (C.c_int, [_P]),
+    "q1env_tick_count": (C.c_int, [_P, C.POINTER(C.c_uint64)]),
+    "q1env_debug_counters": (C.c_int, [_P, C.POINTER(C.c_uint64), C.c_int]),
     "q1env_reset_draws_host": (C.c_int, [_P, C.c_int64, _P, _P, _P, _P, _P, _P, C.c_int, _P]),
     "q1env_reset_philox": (C.c_int, [_P, C.c_uint64, _P, _P, C.c_int, C.c_int, _P]),
     "q1env_step": (C.c_int, [_P, C.c_int, _P, _P, C.c_int, _P, _P, _P, _P]),
@@ -173,7 +175,7 @@ def ptr(a):
 
 
 # ---- page-locked host arrays -------------------------------------------------------------------------------------------------
-PACK_MAX_ENVS = 16384      # q1env.hip: batches up to this size are packed through the handle's own pinned staging
+PACK_MAX_ENVS = 16384      # q1env_core.hip: batches up to this size are packed through the handle's own pinned staging
 
 
 class _PinnedBlock:

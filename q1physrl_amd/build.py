@@ -1,25 +1,38 @@
 """Build libq1env.so (the HIP kernels + C ABI) in-tree with hipcc for gfx950.
 
-    python -m q1physrl_amd.build            # or __graft_entry__.build()
+    python -m q1physrl_amd.build [--force] [--check]      # or __graft_entry__.build()
 
-hipcc cross-compiles gfx950 without a GPU.  The .so is git-ignored but travels to the GPU box with
-the repo snapshot.  -ffp-contract=off is part of the numerics contract (the reference never fuses a
-multiply-add), not an optimisation knob.
+The library is several translation units (csrc/q1env_*.hip: env core, policy glue, tick server, resident sampler, learner,
+diagnostics), each compiled to an object file (in parallel; only the stale ones) and linked into ONE shared library.  hipcc
+cross-compiles gfx950 without a GPU.  The .so is git-ignored but travels to the GPU box with the repo snapshot.
+-ffp-contract=off is part of the numerics contract (the reference never fuses a multiply-add), not an optimisation knob.
+-fvisibility=hidden: only the functions include/q1env.h declares are exported (tests/test_abi_symbols.py).
+
+--check builds a second library, libq1env_check.so, with -DQ1_CHECK: device-side assertions of the hand-rolled hand-off protocols
+(the inline-assembly 16-byte sc1 granule stores are read back and compared with the registers they were issued from); used by the
+soak tools through Q1ENV_LIB_PATH, never by the product path.
 """
-import os
+import concurrent.futures
 import glob
+import os
 import shutil
 import subprocess
 import sys
 
 PKG = os.path.dirname(os.path.abspath(__file__))
-SRC = os.path.join(PKG, "csrc", "q1env.hip")
-DEPS = [SRC] + sorted(glob.glob(os.path.join(PKG, "csrc", "*.hpp"))) + [os.path.join(os.path.dirname(PKG), "include", "q1env.h")]
+CSRC = os.path.join(PKG, "csrc")
+SOURCES = sorted(glob.glob(os.path.join(CSRC, "q1env_*.hip")))
+HEADERS = sorted(glob.glob(os.path.join(CSRC, "*.hpp"))) + [os.path.join(os.path.dirname(PKG), "include", "q1env.h")]
+DEPS = SOURCES + HEADERS
+OBJ_DIR = os.path.join(PKG, "build")
 OUT = os.path.join(PKG, "libq1env.so")
+OUT_CHECK = os.path.join(PKG, "libq1env_check.so")
 
-HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
-               "-Wall", "-Wno-unused-function",
-               "-mllvm", "-amdgpu-kernarg-preload-count=16"]   # leading scalar kernel arguments arrive in SGPRs (step_kernel's state pointers)
+COMPILE_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-fvisibility=hidden",
+                 "-Wall", "-Wno-unused-function",
+                 "-mllvm", "-amdgpu-kernarg-preload-count=16"]   # leading scalar kernel arguments arrive in SGPRs (step_kernel's state pointers)
+LINK_FLAGS = ["--offload-arch=gfx950", "-shared", "-fPIC"]
+HIPCC_FLAGS = COMPILE_FLAGS + ["-shared"]     # (kept for tools that compile a single file the old way, e.g. tools/asan_check.sh)
 
 
 def hipcc_path():
@@ -29,30 +42,56 @@ def hipcc_path():
     raise RuntimeError("hipcc not found (set HIPCC or install ROCm); libq1env.so cannot be built")
 
 
-def is_stale():
-    if not os.path.exists(OUT):
+def _obj_of(src, tag):
+    return os.path.join(OBJ_DIR, os.path.splitext(os.path.basename(src))[0] + tag + ".o")
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
         return True
-    t = os.path.getmtime(OUT)
-    return any(os.path.getmtime(d) > t for d in DEPS)
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build_lib(force=False, verbose=False):
-    if not force and not is_stale():
-        return OUT
-    cmd = [hipcc_path()] + HIPCC_FLAGS + [SRC, "-o", OUT + ".tmp"]
+def is_stale(out=OUT):
+    return _stale(out, DEPS)
+
+
+def _run(cmd, verbose):
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
-        raise RuntimeError("hipcc failed:\n" + r.stdout + r.stderr)
-    os.replace(OUT + ".tmp", OUT)
-    for stray in glob.glob(OUT + ".*"):            # the offload bundler's per-target intermediates (libq1env.so.0.hipv4-..., ...)
+        raise RuntimeError("hipcc failed: " + " ".join(cmd) + "\n" + r.stdout + r.stderr)
+    if verbose and r.stderr.strip():
+        print(r.stderr, file=sys.stderr)
+
+
+def build_lib(force=False, verbose=False, check=False, extra_flags=()):
+    """Compile the stale translation units (in parallel) and link.  check=True: the -DQ1_CHECK assertion build (libq1env_check.so)."""
+    out = OUT_CHECK if check else OUT
+    tag = "_check" if check else ""
+    if not force and not is_stale(out):
+        return out
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    hipcc = hipcc_path()
+    flags = COMPILE_FLAGS + (["-DQ1_CHECK=1"] if check else []) + list(extra_flags)
+    jobs = []
+    for src in SOURCES:
+        obj = _obj_of(src, tag)
+        if force or _stale(obj, [src] + HEADERS):
+            jobs.append([hipcc] + flags + ["-c", src, "-o", obj])
+    with concurrent.futures.ThreadPoolExecutor(max_workers=max(1, min(len(jobs), os.cpu_count() or 1))) as ex:
+        list(ex.map(lambda c: _run(c, verbose), jobs))
+    _run([hipcc] + LINK_FLAGS + [_obj_of(s, tag) for s in SOURCES] + ["-o", out + ".tmp"], verbose)
+    os.replace(out + ".tmp", out)
+    for stray in glob.glob(out + ".*"):            # the offload bundler's per-target intermediates (libq1env.so.0.hipv4-..., ...)
         try:
             os.remove(stray)
         except OSError:
             pass
-    return OUT
+    return out
 
 
 if __name__ == "__main__":
-    print(build_lib(force="--force" in sys.argv, verbose=True))
+    print(build_lib(force="--force" in sys.argv, verbose=True, check="--check" in sys.argv))

@@ -1,0 +1,125 @@
+// q1env_host.hpp - host-side internals shared by the translation units of libq1env.so (NOT part of the C ABI: everything here has
+// hidden visibility; the exported surface is include/q1env.h and nothing else).
+//
+//   q1env_core.hip      env kernels (step / autoreset / rollout / reset / observe / decode / phys.apply), the handle, the core ABI
+//   q1env_policy.hip    policy-side glue kernels (action sampling, fused sampler tick, episode statistics, GAE, PPO loss gradient)
+//                       and the launchers of the matrix-core forward (q1policy.hpp)
+//   q1env_server.hip    the resident tick server (q1server.hpp)
+//   q1env_resident.hip  the resident sampler (q1resident.hpp)
+//   q1env_diag.hip      timers, PMC traffic calibration, division self-test
+//
+// Kernels live in the translation unit that launches them (no relocatable device code: each TU carries its own code object).
+#pragma once
+#include "q1env_device.hpp"
+#pragma GCC visibility push(default)
+#include "../../include/q1env.h"
+#pragma GCC visibility pop
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#define Q1_HIDDEN __attribute__((visibility("hidden")))
+
+// thread-local last-error message (q1env_last_error) + status code pass-through
+Q1_HIDDEN int q1_fail(int code, const std::string& msg);
+Q1_HIDDEN const char* q1_last_error_cstr();
+static inline int fail(int code, const std::string& msg) { return q1_fail(code, msg); }
+
+#define HIP_TRY(expr)                                                                         \
+    do {                                                                                      \
+        hipError_t _e = (expr);                                                               \
+        if (_e != hipSuccess)                                                                 \
+            return fail(Q1ENV_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e));    \
+    } while (0)
+
+// Makes the handle's device current for the duration of an entry point and restores the caller's device afterwards
+// (a host framework such as torch tracks the thread's current device itself; the library must not change it under it).
+struct DeviceGuard {
+    int prev = -1;
+    bool switched = false;
+    explicit DeviceGuard(int dev) {
+        if (hipGetDevice(&prev) == hipSuccess && prev != dev) switched = (hipSetDevice(dev) == hipSuccess);
+    }
+    ~DeviceGuard() {
+        if (switched) (void)hipSetDevice(prev);
+    }
+    DeviceGuard(const DeviceGuard&) = delete;
+    DeviceGuard& operator=(const DeviceGuard&) = delete;
+};
+
+using q1::Params;
+using q1::StatePtrs;
+
+struct q1env {
+    q1env_config cfg{};
+    Params p{};
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    void* arena = nullptr;            // one allocation holding the whole SoA state
+    StatePtrs st{};
+    // staging for the *_host entry points (grown on demand)
+    void* snap = nullptr;             // q1env_snapshot_state: a second arena holding a copy of the whole SoA state
+    void* stage = nullptr;
+    size_t stage_bytes = 0;
+    void* pin = nullptr;              // pinned (page-locked) host staging of the *_host entry points: one DMA each way instead of
+    size_t pin_bytes = 0;             // one staged pageable copy per array
+    uint64_t tick_count = 0;          // ticks since create: the counter of the counter-based RNG
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    int num_cus = 256;                // compute units of the device (MI355X in SPX mode: 256)
+    int server_blocks_per_cu[3] = {-1, -1, -1};   // occupancy of the resident tick server at 1/2/4 envs per lane (queried once)
+    int pair_blocks_per_cu[3] = {-1, -1, -1};     // ... and of the server + driver pair kernel, per shape (PAIR_SHAPES)
+    bool resident_attr_set = false;   // the resident sampler's dynamic-LDS attribute
+    bool mlp_attr_set = false;        // dynamic-LDS attribute of the policy kernels (a per-device setting: kept per handle)
+    // cached hipGraphs of step_many, keyed by (ticks, formats, pointers); a handful of entries, oldest evicted
+    struct GraphEntry { std::vector<uint64_t> key; hipGraphExec_t exec; };
+    std::vector<GraphEntry> graphs;
+    hipStream_t cap_stream = nullptr;  // private stream used only to CAPTURE (the null stream cannot be captured)
+};
+
+static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+static inline dim3 grid_for(int n, int block) { return dim3((unsigned)((n + block - 1) / block)); }
+
+// Small batches are latency bound: 64-lane workgroups spread 64 k envs over all 256 CUs (1024 waves).
+// Large batches are bandwidth bound: 256-lane workgroups cut dispatch overhead.
+static inline int block_for(int n) {
+    static const int forced = [] { const char* e = getenv("Q1ENV_BLOCK"); return e ? atoi(e) : 0; }();   // tuning knob
+    if (forced == 64 || forced == 128 || forced == 256) return forced;
+    return n >= (1 << 19) ? 256 : 64;
+}
+
+Q1_HIDDEN int ensure_stage(q1env* h, size_t bytes);
+Q1_HIDDEN int ensure_pin(q1env* h, size_t bytes);
+Q1_HIDDEN void carve_into(void* arena, size_t n, q1::StatePtrs& st);
+Q1_HIDDEN size_t arena_bytes(size_t n);
+
+static inline int check_act(const q1env* h, int fmt, const void* a, const void* b, bool allow_random) {
+    if (fmt == Q1ENV_ACT_RANDOM) return allow_random ? 0 : fail(Q1ENV_ERR_INVALID_ARG, "Q1ENV_ACT_RANDOM is rollout-only");
+    if (fmt < 0 || fmt > 2) return fail(Q1ENV_ERR_INVALID_ARG, "unknown action_format");
+    if (!a) return fail(Q1ENV_ERR_INVALID_ARG, "act_a is NULL");
+    if (fmt == Q1ENV_ACT_PACKED && h->p.yaw_mode && !b) return fail(Q1ENV_ERR_INVALID_ARG, "packed actions need act_b (mouse)");
+    return 0;
+}
+
+static inline size_t act_bytes_a(const q1env* h, int fmt) {
+    const size_t n = (size_t)h->p.n;
+    if (fmt == Q1ENV_ACT_F64_ROWS) return n * h->p.act_width * 8;
+    if (fmt == Q1ENV_ACT_F32_ROWS) return n * h->p.act_width * 4;
+    return n;
+}
+
+// Width of one row of policy-network outputs (Q1PhysActionDist.required_model_output_shape, action_dist.py:236-241): two logits per
+// key, then (mean, log_std) of the continuous mouse or the 2S+1 logits of the discrete one.
+static inline int policy_row_width(const Params& p) {
+    return 2 * p.num_keys + (p.yaw_mode == 1 ? 2 : (p.yaw_mode == 2 ? 2 * (int)p.yaw_steps + 1 : 0));
+}
+
+// The default action/episode structure (4 keys, continuous mouse, jump key, no hover, y reward) runs the SPEC kernels.
+static inline bool is_spec(const Params& p) {
+    return p.num_keys == 4 && p.yaw_mode == 1 && p.jump_mode == 1 && !p.hover && !p.speed_reward;
+}

@@ -1,5 +1,5 @@
 // q1resident.hpp - the resident sampler of libq1env (q1env_sample_resident, include/q1env.h): a whole sampling horizon as ONE
-// dispatch.  Included by q1env.hip after q1policy.hpp (matrix-core forward).
+// dispatch.  Included by q1env_resident.hip after q1policy.hpp (matrix-core forward) and q1policy_glue.hpp (action sampling).
 //
 // The two-launch sampler tick (q1env_policy_value_forward + q1env_sample_step) costs ~25 us at 32 768 envs - two dispatch
 // boundaries, 157 KB of weights staged into every CU's LDS again, a few us of arithmetic.  Here the policy network's weights are

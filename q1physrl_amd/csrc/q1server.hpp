@@ -1,5 +1,5 @@
 // q1server.hpp - the resident tick server of libq1env (q1env_step_persistent_start / _drive / _pair, include/q1env.h): device code.
-// Included by q1env.hip after q1env_device.hpp; uses tick<>, reset_philox, observe<>, load_env / store_env from there.
+// Included by q1env_server.hip after q1env_device.hpp; uses tick<>, reset_philox, observe<>, load_env / store_env from there.
 #pragma once
 #include "q1env_device.hpp"
 
@@ -58,11 +58,29 @@ __device__ __forceinline__ void granule_store(uint64_t* p, uint64_t v) {
 // and a 16-byte access torn at the 8-byte boundary (never observed on gfx950) would be detected, not consumed.
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
+#ifdef Q1_CHECK
+// Assertion build (python -m q1physrl_amd.build --check -> libq1env_check.so; tools/soak_check.py): every hand-rolled 16-byte sc1
+// store is read back (sc1: from L2, past this CU's L1) and compared with the operands it was issued from.  Nobody else writes a
+// result pair between two ticks of its own lane, so a mismatch can only be this store (a data hazard behind the inline assembly,
+// as round 2 once had) - counted, never fatal.  q1env_debug_counters reads the two words.
+__device__ unsigned long long q1_check_pair_stores = 0ull, q1_check_pair_mismatches = 0ull;
+#endif
+
 __device__ __forceinline__ void granule_pair_store(uint64_t* p, uint64_t a, uint64_t b) {
     const u32x4 v = {(uint32_t)a, (uint32_t)(a >> 32), (uint32_t)b, (uint32_t)(b >> 32)};
     // (the s_nop covers the "VALU overwrites the data registers of a > 64-bit VMEM store" hazard: the compiler's hazard recognizer
     // does not look inside inline assembly, and without it lanes 12-15 of every 16 stored the NEXT pair's first word)
     asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 2" ::"v"(p), "v"(v) : "memory");
+#ifdef Q1_CHECK
+    u32x4 r;
+    asm volatile("s_waitcnt vmcnt(0)\n\tglobal_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(r) : "v"(p) : "memory");
+    const bool bad = r[0] != (uint32_t)a || r[1] != (uint32_t)(a >> 32) || r[2] != (uint32_t)b || r[3] != (uint32_t)(b >> 32);
+    const unsigned long long act = __ballot(true), wrong = __ballot(bad);
+    if (__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == (unsigned)__builtin_ctzll(act)) {   // first active lane
+        atomicAdd(&q1_check_pair_stores, (unsigned long long)__builtin_popcountll(act));
+        if (wrong) atomicAdd(&q1_check_pair_mismatches, (unsigned long long)__builtin_popcountll(wrong));
+    }
+#endif
 }
 
 // four pairs (eight granules) with all four loads in flight together

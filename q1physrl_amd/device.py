@@ -274,6 +274,18 @@ class DeviceEnv:
     def sync(self):
         _lib.check(self._lib.q1env_sync(self._h))
 
+    def debug_counters(self, clear=False):
+        """(built_with_Q1_CHECK, granule-pair stores checked, mismatches) of the assertion build (q1env_debug_counters)."""
+        out = (C.c_uint64 * 4)()
+        _lib.check(self._lib.q1env_debug_counters(self._h, out, int(bool(clear))))
+        return int(out[0]), int(out[1]), int(out[2])
+
+    def tick_count(self):
+        """Ticks stepped since create: the handle-side Philox counter (q1env_tick_count)."""
+        out = C.c_uint64()
+        _lib.check(self._lib.q1env_tick_count(self._h, C.byref(out)))
+        return int(out.value)
+
     def calibrate_traffic(self, launches=10):
         _lib.check(self._lib.q1env_calibrate_traffic(self._h, int(launches)))
 

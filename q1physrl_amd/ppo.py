@@ -18,8 +18,15 @@ from .policy import Q1PhysActionDist
 
 
 def ppo_loss(policy, batch, action_range, clip_param, vf_clip_param, vf_loss_coeff, entropy_coeff, kl_coeff, num_keys=4,
-             discrete_yaw_steps=-1, allow_yaw=True):
-    logits, value = policy(batch["obs"])
+             discrete_yaw_steps=-1, allow_yaw=True, autocast_dtype=None):
+    """autocast_dtype: reduced-precision operands for the two MLPs' matrix products only; the distribution / loss arithmetic below
+    always runs in float32 (the same split as the fused-loss path of PPOLearner._sgd_step)."""
+    if autocast_dtype is not None and batch["obs"].is_cuda:
+        with torch.autocast("cuda", dtype=autocast_dtype):
+            logits, value = policy(batch["obs"])
+        logits, value = logits.float(), value.float()
+    else:
+        logits, value = policy(batch["obs"])
     new = Q1PhysActionDist(logits, action_range, num_keys, discrete_yaw_steps, allow_yaw)
     old = Q1PhysActionDist(batch["old_logits"], action_range, num_keys, discrete_yaw_steps, allow_yaw)
     logp = new.logp(batch["keys"], batch["mouse"])
@@ -81,12 +88,24 @@ class PPOLearner:
         # autocast_dtype (e.g. torch.bfloat16): the two MLPs' matrix products run on reduced-precision operands with float32
         # accumulation (master weights, loss, its gradient and Adam stay float32); fused_adam: one multi-tensor Adam launch
         self.autocast_dtype = autocast_dtype
-        self.opt = torch.optim.Adam(policy.parameters(), lr=lr, capturable=self.use_graph, **({"fused": True} if fused_adam else {}))
+        self.opt = self._make_adam(policy, lr, self.use_graph, fused_adam)
         self._graph = None
         self._klc = None                        # device scalar: the KL coefficient as the captured graph / the kernel reads it
         self._work = None
         self.gen = None
         self.seed = seed
+
+    @staticmethod
+    def _make_adam(policy, lr, capturable, fused_adam):
+        """Adam, multi-tensor fused when asked for and supported: older torch versions reject fused=True together with
+        capturable=True (or on CPU parameters) at construction - fall back to the plain implementation instead of failing."""
+        if fused_adam:
+            try:
+                return torch.optim.Adam(policy.parameters(), lr=lr, capturable=capturable, fused=True)
+            except (RuntimeError, ValueError, TypeError) as ex:
+                import warnings
+                warnings.warn(f"PPOLearner: fused Adam unavailable here ({ex}); using the unfused optimizer", RuntimeWarning, stacklevel=3)
+        return torch.optim.Adam(policy.parameters(), lr=lr, capturable=capturable)
 
     def _flatten(self, traj, adv, vtarg, old_logits):
         t, n = traj["reward"].shape
@@ -121,7 +140,8 @@ class PPOLearner:
             stats = partials.sum(dim=0) / bsz
         else:
             loss, st = ppo_loss(self.policy, mb, self.action_range, self.clip_param, self.vf_clip_param, self.vf_loss_coeff,
-                                self.entropy_coeff, self._klc, self.num_keys, self.discrete_yaw_steps, self.allow_yaw)
+                                self.entropy_coeff, self._klc, self.num_keys, self.discrete_yaw_steps, self.allow_yaw,
+                                autocast_dtype=self.autocast_dtype)
             self.opt.zero_grad(set_to_none=True)
             loss.backward()
             stats = torch.stack([st[k].float() for k in STAT_KEYS])

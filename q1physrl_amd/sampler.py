@@ -27,7 +27,10 @@ class GpuSampler:
         """resident=True: the whole horizon is ONE dispatch (q1env_sample_resident: policy blocks with the network's weights in LDS
         and env blocks with the state in registers, talking through tagged granules) followed by one batched value-network
         forward over the stored observations - bit-identical trajectories, no per-tick launches.  Needs a FusedPolicyForward
-        policy, a continuous (or no) mouse and a batch whose grid is resident (q1env.h); use_graph is ignored."""
+        policy (continuous, discrete - up to 24 outputs - or no mouse) and a batch whose grid is resident (q1env.h); use_graph is
+        ignored.  Every wait inside the dispatch is bounded; a wave that gives up sets the status words and the rows after its last
+        completed tick are NOT written, so collect() checks the status after every horizon (check_status=True; one 20-byte D2H copy
+        at a point where the caller synchronises anyway) and raises instead of handing stale memory to the learner."""
         self.env, self.policy, self.T = env, policy, int(horizon)
         self.fused_tick = bool(fused_tick)
         self.resident = bool(resident)
@@ -117,20 +120,33 @@ class GpuSampler:
         """uint32[5] as q1env_step_persistent_*: all zero = every wave served / handed over every tick of every horizon so far."""
         return self._status.cpu().numpy().astype("uint32")
 
+    def check_resident_status(self):
+        """Raise if any env / policy wave of a resident horizon gave up (time-out): trajectory rows after its last completed tick
+        are stale memory.  Synchronises with the dispatch (a 20-byte copy)."""
+        if self.resident:
+            st = self.resident_status()
+            if st.any():
+                raise RuntimeError(f"resident sampler: a wave timed out, the trajectory of the last horizon is incomplete "
+                                   f"(status words {st.tolist()}; see q1env_sample_resident in include/q1env.h)")
+
     def _scratch_logits(self):
         if not hasattr(self, "_scratch"):
             self._scratch = torch.empty_like(self.logits[0])
         return self._scratch
 
     @torch.no_grad()
-    def collect(self, deterministic=False):
+    def collect(self, deterministic=False, check_status=True):
         """One horizon; returns the trajectory buffers (views, valid until the next collect).  obs[T] is carried over
-        to obs[0] at the START of the next collect, so the returned buffers are complete (T+1 observation rows)."""
+        to obs[0] at the START of the next collect, so the returned buffers are complete (T+1 observation rows).
+        resident=True: check_status=True (default) reads the dispatch's status words back and raises on a time-out;
+        pass False in latency-critical loops and call check_resident_status() before the trajectory is consumed."""
         if getattr(self, "_carry", False):
             self.obs[0].copy_(self.obs[self.T])
         self._carry = True
         if self.resident:
             self._horizon_resident(deterministic)
+            if check_status:
+                self.check_resident_status()
         elif not self.use_graph:
             self._horizon(deterministic)
         else:

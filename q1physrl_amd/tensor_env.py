@@ -99,8 +99,14 @@ class TensorVectorEnv:
         lives in self.reset_counter, a device int64 advanced by the graph itself)."""
         fmt, a, b = self._act_ptrs(actions, (ticks, self.num_envs))
         if auto_reset:
+            # ONE logical Philox counter per handle: the device-resident count the replayable graph reads is re-synchronised from
+            # the handle's tick count before every call (a 8-byte fill on the stream), so this path, reset(), step_autoreset() and
+            # the serve_* / rollout paths - which read the handle's own count - never reuse a (seed, env, counter) triple, in any
+            # interleaving.  (q1env_step_autoreset_many advances both by `ticks`.)  The GpuSampler keeps its OWN counter (sampler.tick)
+            # for its trajectory's draws: do not step a sampler's env through other entry points between its horizons.
             if not hasattr(self, "reset_counter"):
                 self.reset_counter = torch.zeros((1,), dtype=torch.int64, device=self.device)
+            self.reset_counter.fill_(self._dev.tick_count())
             n = self.num_envs
             if outputs:
                 obs = torch.empty((ticks, n, 6), dtype=torch.float32, device=self.device)

@@ -1,6 +1,7 @@
 """GPU: the resident tick server (q1env_step_persistent_start / _drive) - bit-identical to per-tick q1env_step_autoreset calls and
 to the NumPy oracle, across launches, with ragged sizes and in-kernel resets; and its failure mode: without a producer the
 server times out, reports it, stores the state it had and the device stays usable (it must never hang)."""
+import os
 import time
 
 import numpy as np
@@ -292,3 +293,26 @@ def test_tick_server_with_a_torch_producer_in_the_policy_seat():
     for k_ in sa:
         assert np.array_equal(sa[k_], sb[k_]), k_
     a.close(); b.close()
+
+
+def test_assertion_build_reads_every_granule_pair_store_back():
+    """The -DQ1_CHECK build of the SAME sources (libq1env_check.so, built by __graft_entry__.build()) reads every inline-assembly
+    16-byte sc1 granule-pair store back on the device and compares it with the registers it was issued from - the guard against a
+    data hazard behind the inline assembly (round 2 had one: lanes 12-15 stored the next pair's first word).  Runs in a subprocess:
+    the assertion library is selected through Q1ENV_LIB_PATH before the binding loads, the product library stays what this process
+    uses.  The product build must report "not an assertion build"."""
+    import subprocess
+    import sys
+    from q1physrl_amd import build
+    from q1physrl_amd.env import Config
+    from q1physrl_amd.tensor_env import TensorVectorEnv
+    e = TensorVectorEnv(Config(**dict(Config.get_default().__dict__, num_envs=256)), device=0)
+    assert e._dev.debug_counters() == (0, 0, 0)
+    e.close()
+    so = build.build_lib(check=True)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "soak_check.py"), "--envs", "3000", "65536", "--launches", "2", "--ticks", "120"],
+                       capture_output=True, text=True, timeout=600, cwd=root, env=dict(os.environ, Q1ENV_LIB_PATH=so))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    last = r.stdout.strip().splitlines()[-1]
+    assert last.startswith("soak_check total") and last.endswith(" 0 mismatches"), last

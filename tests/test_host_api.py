@@ -204,7 +204,8 @@ sys.modules.update({"gym": gym, "gym.error": err, "gym.envs": envs, "gym.envs.re
 def test_physenv_is_a_gym_env_and_registers_when_gym_is_importable():
     """With a gym on the path PhysEnv must BE a gym.Env (gym 0.17's EnvSpec.make does `env.unwrapped.spec = spec`; RLlib and
     wrappers test isinstance) and importing the module must register Q1PhysEnv-v0 exactly as env.py:516-521 does; importing it
-    twice (the drop-in namespace re-exports it) must not fail, any other registration error must surface."""
+    twice (the drop-in namespace re-exports it) must not fail; any other registration error is reported as a RuntimeWarning
+    (the import itself must not fail: the reference's registration never raises on import, and the package's own registry entry works)."""
     import subprocess
     import sys
     code = _STUB_GYM + '''
@@ -224,12 +225,13 @@ assert D.PhysEnv is E.PhysEnv or issubclass(D.PhysEnv, gym.Env)
 def boom(id, **kw):
     raise RuntimeError("registry is broken")
 gym.envs.registration.register = boom
-try:
+import warnings
+with warnings.catch_warnings(record=True) as w:      # any OTHER registration failure: import still works, but it is reported
+    warnings.simplefilter("always")
     importlib.reload(E)
-except RuntimeError as ex:
-    assert "broken" in str(ex)
-else:
-    raise SystemExit("a failing registration was swallowed")
+assert any("registry is broken" in str(x.message) and issubclass(x.category, RuntimeWarning) for x in w), [str(x.message) for x in w]
+from q1physrl_amd import registry
+assert "Q1PhysEnv-v0" in registry._REGISTRY if hasattr(registry, "_REGISTRY") else True
 print("OK")
 '''
     import os

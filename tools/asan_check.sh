@@ -17,7 +17,7 @@ SO=q1physrl_amd/libq1env_asan.so
 gcc -O1 -fPIC -shared tools/asan_shim.c -o $OUT/libasan_shim.so > $OUT/build.log 2>&1 || { echo "ASAN SHIM BUILD FAILED"; exit 2; }
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O1 -g -std=c++17 -ffp-contract=off -fPIC -shared -Wall -Wno-unused-function \
     -mllvm -amdgpu-kernarg-preload-count=16 -fsanitize=address -fno-gpu-sanitize \
-    q1physrl_amd/csrc/q1env.hip -o $SO >> $OUT/build.log 2>&1 || { echo "ASAN BUILD FAILED"; tail -5 $OUT/build.log | cut -c1-300; exit 2; }
+    q1physrl_amd/csrc/q1env_*.hip -o $SO >> $OUT/build.log 2>&1 || { echo "ASAN BUILD FAILED"; tail -5 $OUT/build.log | cut -c1-300; exit 2; }
 # (libstdc++ rides along so that the runtime finds the real __cxa_throw when it initialises: torch's lazy device initialisation throws
 # and catches a C++ exception, and GCC's ASan aborts with a CHECK if it had no libstdc++ to resolve the interceptor's target in)
 RT="$(readlink -f "$(gcc -print-file-name=libasan.so)") $(readlink -f "$(gcc -print-file-name=libstdc++.so.6)") $ROOT/$OUT/libasan_shim.so"

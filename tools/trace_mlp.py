@@ -1,5 +1,5 @@
 """Phase times inside q1pol::mlp_forward_kernel (wave 0 of workgroup 0), from a -DQ1POL_TRACE build of libq1env.so:
-    hipcc <flags of q1physrl_amd/build.py> -DQ1POL_TRACE q1physrl_amd/csrc/q1env.hip -o q1physrl_amd/libq1env.so
+    python -c "from q1physrl_amd import build as b; b.build_lib(force=True, extra_flags=['-DQ1POL_TRACE'])"
 (rebuild without the flag afterwards: the trace overwrites the first outputs)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
