@@ -1,30 +1,36 @@
 #!/usr/bin/env python3
 """bench.py - env-steps/s of the q1physrl hot path on MI355X (BASELINE.json metric).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--envs E] [--mode step|rollout]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--envs E] [--mode auto|rollout|step|server]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 `python bench.py --gpus N` with N > 1 and no RANK / WORLD_SIZE in the environment launches its own N workers (one process
-per GPU, LOCAL_RANK = device index, rendezvous on 127.0.0.1) and rank 0 prints the JSON line; under torch.distributed.run the
-launcher's environment is used as is.  BASELINE configs[3] (1 048 576 envs on 8 GPUs) is `--gpus 8 --envs 131072`.
+per GPU, LOCAL_RANK = device index, rendezvous on 127.0.0.1, every rank pinned to the CPU cores of its GPU's NUMA node) and rank 0
+prints the JSON line; under torch.distributed.run the launcher's environment is used as is.  BASELINE configs[3] (1 048 576 envs on
+8 GPUs) is `--gpus 8 --envs 131072`.
 
 A "step" is one tick (one VectorPhysEnv.vector_step, reference env.py:482-510) of the whole batch.
 Workload at N=1 = BASELINE.json configs[1]: 65 536 envs, zero-start 100 m run (zero_start_prob = 1,
 get_default Config, dt = 1/72, 720-tick episodes), random actions (keys flip with p = 0.05 per tick,
 mouse ~ U(-action_range, action_range) float32).  Inputs (the packed 5 B/env action tensor of a whole
-720-tick episode) are resident in HBM before the timed region; every tick writes obs float32 (N,6),
-reward float32, done uint8; all envs are reset on device at each episode end (inside the timed region).
+720-tick episode) are resident in HBM before the timed region.  In EVERY primary-capable mode each tick's obs float32 (N,6),
+reward float32 and done uint8 are written to HBM where any later kernel / the host can read them (what vector_step returns,
+env.py:507-510); all envs are reset on device at each episode end (inside the timed region).
 
-  --mode auto     (default) = server, falling back to step (and saying so in "mode_fallback") if the server cannot run.
+  --mode auto     (default) = rollout.
+  --mode rollout  q1env_rollout: the K ticks as ONE launch per episode chunk (an episode boundary splits a launch), env state in
+                  registers between ticks, tick t's packed action read from the resident action tensor, tick t's obs / reward / done
+                  written TICK-MAJOR to HBM ((T,N,6) / (T,N) / (T,N) tensors).  This is configs[1] as stated - "random actions" are
+                  known in advance - and the boundary's multi-tick entry point (include/q1env.h q1env_rollout).  Bound: float64-heavy
+                  VALU issue of one wave per SIMD, not HBM: `roofline` reports VALU-busy cycles against the chip's VALU cycles and the
+                  measured HBM bytes next to it.
   --mode step     ONE step_kernel launch per tick, 720 launches replayed from one hipGraph.  The granularity the drop-in API has
-                  (a policy can sit between ticks); reported as "per_tick_step" when it is not the primary mode.
-  --mode rollout  the fused kernel: 720 ticks per launch, state in registers, same per-tick outputs.
-                  Reported in the same JSON line under "fused_rollout" (secondary; it needs the actions in advance).
-  --mode server   the resident tick server (q1env_step_persistent_pair): ONE dispatch serves all K ticks with the env state in
-                  registers; half of its waves are the server, the other half a DEPENDENT producer that hands tick t+1's action over
-                  only after all of tick t's results arrived (a policy's place) - every tick is a real round trip through 8-byte
-                  data-tagged words, no kernel boundary per tick.  Bit-identical to the per-tick kernels
-                  (tests/test_hip_persistent.py).  Q1_BENCH_SERVER_TWO_STREAMS=1 puts the producer on its own stream instead.
+                  (a policy can sit between ticks); HBM-bound formulation (reads + writes the whole SoA state every tick); reported as
+                  "per_tick_step" when it is not the primary mode.
+  --mode server   the resident tick server (q1env_step_persistent_pair): ONE dispatch serves all K ticks; a server wave and a
+                  DEPENDENT stand-in producer wave per workgroup hand actions / results over through LDS every tick.  Per-tick outputs
+                  do NOT reach HBM in this mode (only the last tick's do) - it measures the tick-to-tick round trip a resident policy
+                  would see, and is therefore never the primary mode; reported as "persistent_server".
 
 Multi-GPU: one process per GPU, the batch is split (65 536 envs per GPU, weak scaling), no collective on
 the data path; ranks only meet in the barriers around the timed region and in the MAX of the elapsed time.
@@ -50,10 +56,13 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-B_ALG = 204.0            # algorithmic bytes per env-step (SURVEY.md 8d / DESIGN.md section 3)
-B_FUSED = 34.0           # real bytes per env-step of the fused rollout kernel (5 B action + 29 B outputs), + 170 B/env/launch
+B_ALG = 204.0            # algorithmic bytes per env-step of the PER-TICK formulation: 2 x 85 B state + 5 B action + 29 B outputs
+B_FUSED = 34.0           # algorithmic bytes per env-step of a register-resident multi-tick kernel: 5 B action in + 29 B outputs out ...
+B_STATE = 170.0          # ... + the 85 B state read and written ONCE per launch, per env
 HBM_PEAK_GBPS = 8000.0   # MI355X_MICROARCH.md: 8 TB/s spec
+PEAK_CLOCK_GHZ = 2.4     # MI355X_MICROARCH.md: max shader clock
 EPISODE_TICKS = 720
+PRIMARY_AUTO = "rollout"  # what --mode auto measures: every tick's obs / reward / done reach HBM
 
 
 def make_actions(n, ticks, action_range, seed):
@@ -210,19 +219,107 @@ def sampler_block(dev_index, n=32768, horizon=64, reps=3):
     return row
 
 
-def load_profiled_traffic(mode, n, env_steps_per_launch=None):
-    """HBM bytes per launch measured with rocprofv3 PMC passes (tools/profile_round.sh -> profiles/traffic.json); None if absent.
-    A tick-server launch serves as many ticks as it is asked to, so its entry is per env-step and scaled to the launch."""
-    path = os.path.join(ROOT, "profiles", "traffic.json")
+def load_pmc(mode, n):
+    """Hardware-counter figures of this mode's kernel at this batch size from the round's rocprofv3 PMC passes
+    (tools/profile_round3.sh -> tools/summarize_pmc.py -> profiles/pmc.json), or None if that size was not profiled.
+    Entry: {"kernel": exact name, "ticks_per_launch": T the passes ran at, "fetch_x2_B", "write_B": HBM bytes per launch (FETCH_SIZE x 2
+    per MI355X_MICROARCH.md's gfx950 correction, calibrated on calib_copy_kernel), "valu_busy_cycles": 4 x SQ_ACTIVE_INST_VALU per launch
+    (cycles in which a SIMD's VALU executes an instruction, summed over SIMDs), "insts_valu": SQ_INSTS_VALU per launch, "waves"}."""
     try:
-        with open(path) as f:
-            d = json.load(f)
-        if mode == "server":
-            per = d.get(f"server_{n}_per_env_step")
-            return None if per is None or env_steps_per_launch is None else per * env_steps_per_launch
-        return d.get(f"{mode}_{n}")
+        with open(os.path.join(ROOT, "profiles", "pmc.json")) as f:
+            return json.load(f).get(f"{mode}_{n}")
     except Exception:   # noqa: BLE001
         return None
+
+
+def traffic_per_launch(pmc, n, ticks_per_launch, resident_state):
+    """Measured HBM bytes of one launch of `ticks_per_launch` ticks, from a PMC entry taken at pmc["ticks_per_launch"] ticks: a
+    register-resident kernel moves the 170 B/env state once per launch and the rest per tick, so its per-tick part is scaled."""
+    if pmc is None or pmc.get("fetch_x2_B") is None or pmc.get("write_B") is None:
+        return None
+    total = float(pmc["fetch_x2_B"]) + float(pmc["write_B"])
+    t0 = float(pmc.get("ticks_per_launch", 1))
+    if not resident_state:
+        return total * ticks_per_launch / t0
+    per_tick = max(total - B_STATE * n, 0.0) / t0
+    return B_STATE * n + per_tick * ticks_per_launch
+
+
+# ---- CPU placement of a rank (VERDICT r2 item 2): the cores of its GPU's NUMA node -----------------------------------------------
+def _parse_cpulist(text):
+    cpus = set()
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        lo, _, hi = part.partition("-")
+        cpus.update(range(int(lo), int(hi or lo) + 1))
+    return cpus
+
+
+def numa_cpus_of_pci(pci_bus_id, sysfs="/sys"):
+    """(numa_node, set of CPUs) of the PCI device `dddd:bb:dd.f` from sysfs; (-1, None) when the platform does not say."""
+    try:
+        with open(os.path.join(sysfs, "bus", "pci", "devices", pci_bus_id.lower(), "numa_node")) as f:
+            node = int(f.read().strip())
+        if node < 0:
+            return -1, None
+        with open(os.path.join(sysfs, "devices", "system", "node", f"node{node}", "cpulist")) as f:
+            cpus = _parse_cpulist(f.read())
+        return node, (cpus or None)
+    except (OSError, ValueError):
+        return -1, None
+
+
+def pin_rank(pci_bus_id, local_rank, local_world, sysfs="/sys", apply=True):
+    """Pin this process to the cores of its GPU's NUMA node, split among the ranks that share the node so that no two ranks compete
+    for a core (a 20-tick timed region is ~50 us of host work: one rank on the wrong socket, or two on one core, sets the MAX over
+    ranks).  Without NUMA information the allowed CPUs are split evenly by local rank.  Returns what was done (for `per_rank`)."""
+    try:
+        allowed = sorted(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        return {"pinned": False, "reason": "sched_getaffinity unavailable"}
+    node, cpus = numa_cpus_of_pci(pci_bus_id, sysfs) if pci_bus_id else (-1, None)
+    pool = sorted(set(allowed) & cpus) if cpus else []
+    how = f"numa node {node}"
+    if not pool:
+        pool, how = allowed, "no NUMA information: even split of the allowed CPUs"
+    share = max(1, len(pool) // max(1, local_world))
+    mine = pool[(local_rank % max(1, local_world)) * share:][:share] or pool
+    info = {"pinned": False, "numa_node": node, "how": how, "cpus": f"{mine[0]}-{mine[-1]}" if mine else "", "n_cpus": len(mine)}
+    if apply and os.environ.get("Q1_BENCH_NO_PIN") != "1":
+        try:
+            os.sched_setaffinity(0, mine)
+            info["pinned"] = True
+        except OSError as ex:
+            info["reason"] = repr(ex)
+    return info
+
+
+def device_pci_bus_id(dev_index):
+    """PCI bus id of HIP device `dev_index` ("0000:05:00.0"), through torch's device properties or the HIP runtime torch loaded."""
+    try:
+        import torch
+        pr = torch.cuda.get_device_properties(dev_index)
+        if hasattr(pr, "pci_bus_id") and hasattr(pr, "pci_device_id") and hasattr(pr, "pci_domain_id"):
+            return f"{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0"
+    except Exception:   # noqa: BLE001
+        pass
+    try:
+        import ctypes
+        for name in ("libamdhip64.so", "libamdhip64.so.7", "libamdhip64.so.6"):
+            try:
+                hip = ctypes.CDLL(name)
+                break
+            except OSError:
+                hip = None
+        if hip is None:
+            return None
+        buf = ctypes.create_string_buffer(64)
+        if hip.hipDeviceGetPCIBusId(buf, 64, int(dev_index)) == 0:
+            return buf.value.decode().lower()
+    except Exception:   # noqa: BLE001
+        pass
+    return None
 
 
 SERVER_AUTO_MAX_ENVS = 294912      # auto mode: resident tick server up to its resident capacity on an MI355X, per-tick kernels above
@@ -235,7 +332,7 @@ def parse_args(argv=None):
     ap.add_argument("--warmup", type=int, default=720)
     ap.add_argument("--envs", type=int, default=65536, help="envs per GPU (131072 = BASELINE configs[3]'s shard)")
     ap.add_argument("--mode", choices=("auto", "step", "rollout", "server"), default="auto",
-                    help="auto = server (the resident tick server), falling back to step - and saying so in the JSON - if it cannot run")
+                    help="auto = rollout (one launch per episode chunk, every tick's obs / reward / done written to HBM)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary (other-mode) measurement")
@@ -282,15 +379,20 @@ def launch_workers(args, argv):
 
 
 def load_env_class():
-    """The per-GPU env handle.  Q1_BENCH_ENV_FACTORY = "module:attr" exists for tests/test_bench_launcher.py only: this
-    container has no GPU, so the world-size-2 launcher test substitutes an oracle-backed stand-in with DeviceEnv's methods and
-    runs every other line of this file (launcher, rendezvous, timed region, rank reduction, JSON) on CPU over gloo."""
+    """The per-GPU env handle and its import path (printed as `env_impl`).  Q1_BENCH_ENV_FACTORY = "module:attr" exists for
+    tests/test_bench_launcher.py only: this container has no GPU, so the world-size-2 launcher test substitutes an oracle-backed
+    stand-in with DeviceEnv's methods and runs every other line of this file (launcher, rendezvous, timed region, rank reduction,
+    JSON) on CPU over gloo.  A bench whose timed region could silently execute the oracle would be worthless, so the variable is
+    REFUSED unless Q1_BENCH_ALLOW_FAKE=1 is set as well, and the JSON line names the class that ran either way."""
     spec = os.environ.get("Q1_BENCH_ENV_FACTORY")
     if spec:
+        if os.environ.get("Q1_BENCH_ALLOW_FAKE") != "1":
+            raise SystemExit("bench.py: Q1_BENCH_ENV_FACTORY is set but Q1_BENCH_ALLOW_FAKE=1 is not - refusing to time anything but "
+                             "q1physrl_amd.device.DeviceEnv (the variable exists for the CPU launcher tests only)")
         mod, attr = spec.split(":")
-        return getattr(importlib.import_module(mod), attr), True
+        return getattr(importlib.import_module(mod), attr), True, f"{mod}.{attr} (INJECTED through Q1_BENCH_ENV_FACTORY: not the HIP path)"
     from q1physrl_amd.device import DeviceEnv
-    return DeviceEnv, False
+    return DeviceEnv, False, "q1physrl_amd.device.DeviceEnv"
 
 
 def main(argv=None):
@@ -302,7 +404,7 @@ def main(argv=None):
     import torch
     import torch.distributed as dist
     from q1physrl_amd import _lib, env as E, sharding
-    DeviceEnv, injected = load_env_class()
+    DeviceEnv, injected, env_impl = load_env_class()
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -324,6 +426,12 @@ def main(argv=None):
         torch.cuda.set_device(dev_index)
         d = torch.device("cuda", dev_index)
         dsync = torch.cuda.synchronize
+    # CPU placement: this rank's host thread (launch calls, the one synchronisation) on the cores next to its GPU
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+    pci = None if injected else device_pci_bus_id(dev_index)
+    placement = pin_rank(pci, local_rank, local_world) if world > 1 or os.environ.get("Q1_BENCH_PIN") == "1" else {"pinned": False, "how": "single rank: not pinned"}
+    placement["device"] = dev_index
+    placement["pci_bus_id"] = pci
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         # the env path has no collective: ranks only meet in barriers and one MAX of a scalar, which gloo serves from the host
@@ -513,122 +621,171 @@ def main(argv=None):
         wall = sharding.max_over_ranks(own, device=d)
         return wall, ev_ms, launches, own
 
-    def per_rank(own, ev_ms):
-        """Every rank's own wall / event time of the region it timed, gathered on all ranks (host objects, after the timing)."""
-        mine = {"rank": rank, "wall_ms": own * 1e3, "event_ms": ev_ms, "env_steps_per_s": float(n) * args.steps / own}
+    def per_rank(own, ev_ms, steps, mode):
+        """Every rank's own wall / event time of the region it timed, its host-side split, device and CPU placement, gathered on all
+        ranks (host objects, after the timing)."""
+        mine = {"rank": rank, "wall_ms": own * 1e3, "event_ms": ev_ms, "env_steps_per_s": float(n) * steps / own, "mode": mode,
+                "env_index_base": int(start), "envs": int(n), "host_split_us": host_split.get(mode), "placement": placement,
+                "env_impl": env_impl}
         if world == 1:
             return [mine]
         rows = [None] * world
         dist.all_gather_object(rows, mine)
         return rows
 
-    fallback, measured = None, False
+    fallback = None
     if args.mode == "auto":
-        try_server = not injected or bool(os.environ.get("Q1_BENCH_FORCE_AUTO_SERVER"))     # (the test stand-in has no tick server)
-        if try_server and n > SERVER_AUTO_MAX_ENVS:
-            try_server = False
-            sys.stderr.write(f"bench.py: {n} envs per GPU > {SERVER_AUTO_MAX_ENVS}: auto mode = per-tick step kernels\n")
-        args.mode = "server" if try_server else "step"
-        if try_server:
-            try:
-                wall, ev_ms, launches, own = measure("server", args.steps, args.warmup)
-                measured = True
-            except Exception as ex:   # noqa: BLE001 - e.g. the pair grid is not resident on this device: measure the per-tick kernels instead
-                fallback = f"server mode failed ({ex!r}); measured with per-tick launches instead"
-                sys.stderr.write("bench.py: " + fallback + "\n")
-                args.mode = "step"
-        # (measure() reaches its verdict collectively, so every rank is in the same mode here)
-    if not measured:
+        args.mode = PRIMARY_AUTO
+        try:
+            wall, ev_ms, launches, own = measure(args.mode, args.steps, args.warmup)
+        except Exception as ex:   # noqa: BLE001 - measure() reaches its verdict collectively: every rank falls back at the same point
+            fallback = f"{args.mode} mode failed ({ex!r}); measured with per-tick launches instead"
+            sys.stderr.write("bench.py: " + fallback + "\n")
+            args.mode = "step"
+            wall, ev_ms, launches, own = measure(args.mode, args.steps, args.warmup)
+    else:
         wall, ev_ms, launches, own = measure(args.mode, args.steps, args.warmup)
-    ranks = per_rank(own, ev_ms)
+    ranks = per_rank(own, ev_ms, args.steps, args.mode)
     value = float(n) * args.steps * world / wall
-    ticks_per_launch = args.steps / launches
-    kern_us = ev_ms * 1e3 / launches
-    achieved = B_ALG * n * ticks_per_launch / (kern_us * 1e-6) / 1e9
-    kernel = {"step": "step_kernel<float,SPEC,PACKED>", "rollout": "rollout_kernel<float,SPEC,PACKED,no-reset,all-outputs>",
-              "server": "tick_pair_lds_kernel<SPEC, ES> (tick server wave + dependent producer wave per workgroup)"}[args.mode]
-    roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-            "traffic": load_profiled_traffic(args.mode, n, n * ticks_per_launch), "kernel": kernel, "avg_launch_us": kern_us,
-            "event_ms_per_step": ev_ms / args.steps, "wall_over_event": wall * 1e3 / ev_ms if ev_ms > 0 else None,
-            "host_split_us": host_split.get(args.mode),
-            "alg_bytes_per_env_step": B_ALG, "env_steps_per_launch": n * ticks_per_launch,
-            "note": "achieved = 204 B x env-steps per launch / (HIP-event time of the timed region / launches). "
-                    "traffic = HBM bytes per launch from the rocprofv3 FETCH_SIZE(x2, gfx950)/WRITE_SIZE passes in profiles/ "
-                    "(null if that size was not profiled)."}
-    if args.mode == "server":
-        roof["note"] += (" The resident tick server keeps the env state in registers between ticks; a server wave and its dependent "
-                         "producer wave share a workgroup and hand actions / results over through LDS (a real round trip per tick), so the "
-                         "kernel's measured HBM traffic is 6.4 B per env-step (the producer's packed actions; state once per launch).  SURVEY "
-                         "8(d) fixes the accounting for this case: 'a multi-tick fused kernel moves fewer real bytes than B_alg per step; "
-                         "still report against B_alg and state real bytes from rocprof alongside' - so `frac` is a NOMINAL figure that "
-                         "passes 1 (the per-tick formulation's roofline ceiling is 39 G env-steps/s per GPU), `traffic` is what the kernel "
-                         "really moves, and the bound is the latency of one tick's dependent float64 chain (~0.8 us) plus two LDS hand-offs.")
-        roof["frac_is_nominal"] = True
-        roof["us_per_tick"] = ev_ms * 1e3 / args.steps
-    if args.mode == "rollout":
-        real = (B_FUSED * n * ticks_per_launch + 170.0 * n) / (kern_us * 1e-6) / 1e9
-        roof["real_bytes_achieved_GBps"] = real
-        roof["note"] += (" The fused kernel keeps state in registers: its real traffic is 34 B/env-step + 170 B/env/launch, "
-                         "so the 204-B figure overstates its HBM use; it is bound by float64 VALU issue.")
+    spec_cfg = True                                   # get_default's action / episode structure: the SPEC = true instantiations
+
+    def pair_es(n_envs):
+        """sub-batches of 64 envs per workgroup the pair kernel runs with at this size (q1env_step_persistent_pair picks the
+        smallest whose grid is resident: 256 CUs x 8 workgroups x 64 x ES on an MI355X)"""
+        return 1 if n_envs <= 131072 else (2 if n_envs <= 262144 else 3)
+
+    def kernel_name(mode):
+        sp = "true" if spec_cfg else "false"
+        return {"step": f"step_kernel<float, {sp}, 2>  (OBS_T = float, SPEC, FMT_PACKED)",
+                "rollout": f"rollout_kernel<float, {sp}, 2, false, 1>  (OBS_T = float, SPEC, FMT_PACKED, HAS_RESET = false, OUT_MODE = 1: obs, reward, done every tick)",
+                "server": f"tick_pair_lds_kernel<{sp}, {pair_es(n)}>  (SPEC, ES = sub-batches per workgroup; server wave + dependent stand-in producer wave)"}[mode]
+
+    def workload(mode):
+        head = (f"BASELINE configs[1]: {n} envs/GPU" if n != 131072 else
+                f"BASELINE configs[3] shard: 131072 envs/GPU ({131072 * world} envs on {world} GPU(s))")
+        head += ", zero-start 100 m run, random actions (packed, resident in HBM), get_default Config, 720-tick episodes with on-device reset of all envs at each episode end; "
+        return head + {
+            "rollout": "mode=rollout: q1env_rollout, one launch per episode chunk, env state in registers between ticks, EVERY tick's obs "
+                       "f32 (N,6) / reward f32 / done u8 written tick-major to HBM",
+            "step": "mode=step" + ("+hipGraph" if not args.no_graph else "") + ": one step_kernel launch per tick (reads + writes the SoA state in HBM "
+                    "every tick), every tick's obs f32 (N,6) / reward f32 / done u8 written to HBM",
+            "server": "mode=server: resident tick server + dependent stand-in producer as ONE dispatch, hand-offs through LDS every tick; "
+                      "per-tick obs / reward / done are consumed by the producer wave and NOT written to HBM (only the last tick's are)"
+                      if not os.environ.get("Q1_BENCH_SERVER_TWO_STREAMS") else
+                      "mode=server (two streams): resident tick server + dependent producer kernel on a second stream, every tick's results cross "
+                      "as 8-byte tagged granules through L2 / HBM"}[mode]
+
+    def roofline(mode, steps, launches_, ev_ms_, wall_):
+        """The roofline statement of `mode`'s kernel for a region of `steps` ticks in `launches_` launches and ev_ms_ of HIP-event time.
+        step:             HBM-bound formulation.  achieved = MEASURED HBM bytes per launch (rocprofv3 PMC, profiles/pmc.json) / launch
+                          time when this size was profiled, else the algorithmic 204 B/env-step; frac_nominal_204B always on the 204 B.
+        rollout / server: register-resident state: the tick is bound by VALU issue (one wave per SIMD at 65 536 envs issues its ~340
+                          float64-heavy VALU instructions per tick at one per ~5.2 cycles: tools/ubench_f64.hip).  achieved = VALU-busy
+                          SIMD-cycles per second (4 x SQ_ACTIVE_INST_VALU per env-step from the PMC pass x env-steps per launch / launch
+                          time), peak = SIMDs x 2.4 GHz; the measured HBM side is in `hbm`."""
+        tpl = steps / launches_
+        kern_us = ev_ms_ * 1e3 / launches_
+        pmc = load_pmc(mode, n)
+        resident = mode != "step"
+        traffic = traffic_per_launch(pmc, n, tpl, resident)
+        alg_bytes = (B_ALG * n * tpl) if not resident else (B_FUSED * n * tpl + B_STATE * n)
+        nominal = B_ALG * n * tpl / (kern_us * 1e-6) / 1e9
+        hbm_bytes = traffic if traffic is not None else alg_bytes
+        hbm = {"achieved_GBps": hbm_bytes / (kern_us * 1e-6) / 1e9, "peak_GBps": HBM_PEAK_GBPS,
+               "frac": hbm_bytes / (kern_us * 1e-6) / 1e9 / HBM_PEAK_GBPS, "bytes_per_launch": hbm_bytes,
+               "bytes_source": "rocprofv3 PMC (FETCH_SIZE x2 + WRITE_SIZE), profiles/pmc.json" if traffic is not None else
+                               "algorithmic (this size / mode is not in profiles/pmc.json)",
+               "algorithmic_bytes_per_launch": alg_bytes}
+        base = {"traffic": traffic, "kernel": kernel_name(mode), "avg_launch_us": kern_us, "ticks_per_launch": tpl,
+                "event_ms_per_step": ev_ms_ / steps, "us_per_tick": ev_ms_ * 1e3 / steps,
+                "wall_over_event": wall_ * 1e3 / ev_ms_ if ev_ms_ > 0 else None, "host_split_us": host_split.get(mode),
+                "env_steps_per_launch": n * tpl, "frac_nominal_204B": nominal / HBM_PEAK_GBPS,
+                "profile": (pmc or {}).get("source")}
+        if not resident:
+            r = {"bound": "hbm", "achieved": hbm["achieved_GBps"], "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": hbm["frac"], **base,
+                 "alg_bytes_per_env_step": B_ALG, "achieved_algorithmic_GBps": nominal,
+                 "note": "per-tick formulation: every launch reads and writes the whole SoA state.  achieved = measured HBM bytes per launch "
+                         "(PMC) / (HIP-event time of the timed region / launches) - below the algorithmic 204 B because the write-back skips "
+                         "unchanged state words; frac_nominal_204B = the same time on the algorithmic bytes.  At 65 536 envs a launch moves "
+                         "13 MB (1.7 us at 8 TB/s) behind a ~1.8 us dependent-dispatch boundary: latency-bound by construction (DESIGN.md 6.1)."}
+            return r
+        simds = 1024.0                                  # 256 CUs x 4 SIMDs
+        peak = simds * PEAK_CLOCK_GHZ                  # G VALU-cycles per second the chip has
+        r = {"bound": "valu", "peak": peak, "unit": "Gcycle/s (VALU-busy SIMD cycles)", **base, "hbm": hbm,
+             "alg_bytes_per_env_step": B_FUSED, "alg_bytes_per_env_per_launch": B_STATE}
+        if pmc is not None and pmc.get("valu_busy_cycles"):
+            busy = float(pmc["valu_busy_cycles"]) * tpl / float(pmc.get("ticks_per_launch", 1))          # per launch of tpl ticks
+            r["achieved"] = busy / (kern_us * 1e-6) / 1e9
+            r["frac"] = r["achieved"] / peak
+            insts = float(pmc.get("insts_valu", 0.0)) / max(float(pmc.get("waves", 1.0)), 1.0) / float(pmc.get("ticks_per_launch", 1))
+            r["valu_insts_per_tick_per_wave"] = insts
+            # the issue limit of a LONE wave on its SIMD (what 65 536 envs on 1 024 SIMDs are): one VALU instruction per 5.17 cycles
+            # whatever its type (tools/ubench_f64.hip, profiles/r3_ubench_f64.txt), 16.8 for a float64 transcendental
+            waves_per_simd = max(1.0, n / 64.0 / simds)
+            if waves_per_simd <= 1.0 and insts > 0:
+                floor_us = insts * 5.17 / (PEAK_CLOCK_GHZ * 1e3)
+                r["lone_wave_issue_floor_us_per_tick"] = floor_us
+                r["frac_of_lone_wave_issue_floor"] = floor_us / (ev_ms_ * 1e3 / steps)
+        else:
+            r["achieved"] = None
+            r["frac"] = None
+        r["note"] = ("register-resident kernel: the env state stays in registers between ticks, so HBM sees 34 B per env-step (5 B action in, "
+                     "29 B obs / reward / done out) + the 170 B state once per launch - `hbm` holds the MEASURED bytes and their fraction of 8 TB/s. "
+                     "What bounds it is VALU issue: achieved = VALU-busy SIMD cycles per second = 4 x SQ_ACTIVE_INST_VALU (rocprofv3 PMC pass of this "
+                     "kernel at this size, profiles/pmc.json) scaled to the launch / HIP-event launch time; peak = 1 024 SIMDs x 2.4 GHz.  "
+                     "frac_nominal_204B (the per-tick formulation's 204 B on this kernel's time) passes 1 by construction and is NOT a roofline fraction.")
+        if mode == "server":
+            r["note"] += ("  server mode: per-tick outputs go to the stand-in producer wave through LDS and are not written to HBM; the tick-to-tick "
+                          "latency additionally contains two LDS hand-offs.")
+        return r
+
+    roof = roofline(args.mode, args.steps, launches, ev_ms, wall)
     out = {
         "metric": "env-steps/sec @ 64k envs, 1/2/4/8 MI355X; max |pos - NumPy ref| over 10 s",
         "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": wall * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
-        "config": {"workload": (f"BASELINE configs[1]: {n} envs/GPU" if n != 131072 else
-                                f"BASELINE configs[3] shard: 131072 envs/GPU ({131072 * world} envs on {world} GPU(s))")
-                               + ", zero-start 100 m run, random actions, get_default Config, "
-                               f"720-tick episodes with on-device reset, per-tick obs f32/reward/done written; mode={args.mode}"
-                               + ("+hipGraph" if args.mode == "step" and not args.no_graph else "")
-                               + (" (resident tick server + dependent producer as ONE dispatch, hand-offs as 8-byte tagged granules)"
-                                  if args.mode == "server" and not os.environ.get("Q1_BENCH_SERVER_TWO_STREAMS") else
-                                  " (resident tick server + dependent producer kernel on a second stream, hand-offs as 8-byte tagged granules)"
-                                  if args.mode == "server" else ""),
-                   "total_envs": n * world,
+        "config": {"workload": workload(args.mode), "total_envs": n * world,
                    "envs_per_gpu": n, "parallelism": f"batch-split x{world}, no collective",
                    "arithmetic": "float64 (float32 storage of vel/obs/reward), bit-identical to the NumPy reference"},
         "roofline": roof,
-        "mode": args.mode, "mode_fallback": fallback,
+        "mode": args.mode, "mode_fallback": fallback, "env_impl": env_impl,
         "per_rank": ranks,
         "parity": "max |pos - NumPy ref| over the 10 s rollout: measured live in cpu_baseline.parity_vs_gpu_after_719_ticks (N=1 runs); "
                   "tests/test_hip_fastpath.py::test_full_size_rollout_parity_65536_envs_720_ticks checks all 65 536 x 720 env-steps bit-exactly",
     }
     if not args.no_secondary:
         names = {"rollout": "fused_rollout", "step": "per_tick_step", "server": "persistent_server"}
-        notes = {"rollout": "one rollout_kernel launch per 720-tick episode, identical inputs / per-tick outputs (needs the actions in advance)",
-                 "step": "one step_kernel launch per tick (hipGraph)",
-                 "server": "resident tick server + dependent producer kernel (q1env_step_persistent_*): no kernel boundary per tick, "
-                           "a producer sits between ticks; bit-identical to the per-tick kernels"}
-        for other in ("step", "server", "rollout"):
-            if other == args.mode or (other == "server" and injected):
+        for other in ("step", "rollout", "server"):
+            if other == args.mode or (other == "server" and (injected or n > SERVER_AUTO_MAX_ENVS)):
                 continue
             try:
-                w2, ev2, l2, _own2 = measure(other, args.steps, args.warmup)
+                w2, ev2, l2, own2 = measure(other, args.steps, args.warmup)
             except Exception as ex:   # noqa: BLE001 - a secondary measurement must not take the contract line down
                 out[names[other]] = {"error": repr(ex)}
                 continue
             out[names[other]] = {"value": float(n) * args.steps * world / w2, "unit": "env-steps/s", "ms_per_step": w2 * 1e3 / args.steps,
-                                 "launches": l2, "avg_launch_us": ev2 * 1e3 / l2, "event_us_per_tick": ev2 * 1e3 / args.steps,
-                                 "frac_of_8TBps_at_204B": B_ALG * n / (ev2 * 1e-3 / args.steps) / 1e9 / HBM_PEAK_GBPS,
-                                 "note": notes[other]}
-    if rank == 0 and world == 1 and not args.no_secondary and not injected:
-        # steady state of the two "a policy can sit between ticks" modes: one whole 720-tick episode per measurement, HIP events
-        # only (what a --steps 20 region cannot show: launch / start-up latency amortised)
+                                 "launches": l2, "workload": workload(other), "roofline": roofline(other, args.steps, l2, ev2, w2)}
+        # steady state (one whole 720-tick episode per measurement, HIP events: what a --steps 20 region cannot show - launch and
+        # start-up latency amortised), on every rank: the multi-GPU line carries it too (slowest rank's event time)
         steady = {}
-        for m in ("step", "server"):
+        for m in ("rollout", "step") + (() if injected or n > SERVER_AUTO_MAX_ENVS else ("server",)):
+            if injected and world > 1 and m != args.mode:
+                continue                                 # (the CPU stand-in is slow: the launcher tests keep to the primary mode)
             try:
-                _w, ev, _l, _o = measure(m, EPISODE_TICKS, 0)
-                steady[m] = {"us_per_tick": ev * 1e3 / EPISODE_TICKS, "env_steps_per_s": n / (ev * 1e-3 / EPISODE_TICKS),
-                             "frac_of_8TBps_at_204B": B_ALG * n / (ev * 1e-3 / EPISODE_TICKS) / 1e9 / HBM_PEAK_GBPS}
+                w3, ev3, l3, _o = measure(m, EPISODE_TICKS, 0)
+                ev_max = sharding.max_over_ranks(ev3 * 1e-3, device=d) * 1e3 if world > 1 else ev3
+                steady[m] = {"us_per_tick": ev_max * 1e3 / EPISODE_TICKS, "env_steps_per_s": n * world / (ev_max * 1e-3 / EPISODE_TICKS),
+                             "launches": l3, "roofline": roofline(m, EPISODE_TICKS, l3, ev_max, w3)}
             except Exception as ex:   # noqa: BLE001
                 steady[m] = {"error": repr(ex)}
         out["steady_state_720_ticks"] = steady
+    if rank == 0 and world == 1 and not args.no_secondary and not injected:
         out["step_kernel_size_sweep"] = size_sweep(dev_index)
-        if rank == 0 and not injected:
-            try:
-                out["sampler_configs4_shard"] = sampler_block(dev_index)
-            except Exception as ex:   # noqa: BLE001 - extra information must not take the contract line down
-                out["sampler_configs4_shard"] = {"error": repr(ex)}
+        try:
+            out["sampler_configs4_shard"] = sampler_block(dev_index)
+        except Exception as ex:   # noqa: BLE001 - extra information must not take the contract line down
+            out["sampler_configs4_shard"] = {"error": repr(ex)}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         def gpu_check(acts, k):
             """The GPU env on the oracle's own actions (float64 rows) for k ticks from a fresh zero start."""
@@ -641,6 +798,11 @@ def main(argv=None):
             chk.close()
             return st
         out["cpu_baseline"] = cpu_baseline(n, ar, gpu_check=gpu_check)
+    elif world > 1:
+        # the CPU baseline is timed on rank 0 at N = 1 only (it would otherwise run next to other ranks' host threads): pointer, not a number
+        out["cpu_baseline"] = {"value": None, "unit": "env-steps/s", "cores": 1, "kind": "port",
+                               "sample": "not timed in a multi-rank run: see the cpu_baseline of the N=1 run of this command "
+                                         "(`python bench.py --gpus 1 ...`, same workload per GPU; BENCH_rNN.json next to SCALE_rNN.json)"}
     else:
         out["cpu_baseline"] = None
     if rank == 0:

@@ -96,3 +96,10 @@ class FakeDeviceEnv:
 
     def close(self):
         pass
+
+
+class FakeNoRollout(FakeDeviceEnv):
+    """A stand-in whose multi-tick entry point is missing: bench.py's default mode must then fall back - on EVERY rank, at the
+    same point - to per-tick launches and say so in the JSON line."""
+    def rollout_dev(self, *a, **k):
+        raise RuntimeError("this stand-in has no fused rollout")

@@ -15,7 +15,7 @@ FAKE = "tests._bench_fake:FakeDeviceEnv"
 
 
 def _run(cmd, extra_env=None, timeout=300):
-    env = dict(os.environ, Q1_BENCH_ENV_FACTORY=FAKE, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    env = dict(os.environ, Q1_BENCH_ENV_FACTORY=FAKE, Q1_BENCH_ALLOW_FAKE="1", PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
     env.update(extra_env or {})
@@ -37,7 +37,12 @@ def _check_line(d, world, envs, steps, warmup):
     slowest = max(r["wall_ms"] for r in rows)
     assert abs(d["ms_per_step"] * steps - slowest) <= 1e-6 * slowest            # MAX over ranks is what `value` is built on
     assert abs(d["value"] - envs * world * steps / (slowest * 1e-3)) <= 1e-6 * d["value"]
-    assert d["cpu_baseline"] is None or world == 1
+    assert d["cpu_baseline"] is None or world == 1 or d["cpu_baseline"]["value"] is None      # multi-rank: a pointer to the N=1 run
+    # the line names what ran: the injected stand-in here, q1physrl_amd.device.DeviceEnv on the GPU box
+    assert "INJECTED" in d["env_impl"] and "tests._bench_fake" in d["env_impl"]
+    bases = [r["env_index_base"] for r in rows]
+    assert bases == [envs * r for r in range(world)] and all(r["envs"] == envs and r["mode"] == d["mode"] for r in rows)
+    assert all("placement" in r and "host_split_us" in r for r in rows)
 
 
 def test_self_launch_two_ranks_without_torchrun():
@@ -78,17 +83,70 @@ def test_failed_rank_fails_the_launch():
 
 def test_server_mode_failure_is_collective_and_auto_falls_back():
     """The oracle stand-in has no tick server.  Explicit `--mode server` must fail on BOTH ranks at the same point (nobody is left
-    waiting in a barrier: the run ends in seconds, non-zero); the default `auto` mode must fall back to per-tick launches on every
-    rank and say so in the JSON line."""
+    waiting in a barrier: the run ends in seconds, non-zero); the default `auto` mode (= rollout) on a stand-in WITHOUT the fused
+    rollout must fall back to per-tick launches on every rank and say so in the JSON line."""
     r = _run([sys.executable, "bench.py", "--gpus", "2", "--steps", "6", "--warmup", "2", "--envs", "16", "--mode", "server", "--no-secondary"],
              timeout=120)
     assert r.returncode != 0 and "server mode failed in the dry run" in r.stderr
     r = _run([sys.executable, "bench.py", "--gpus", "2", "--steps", "6", "--warmup", "2", "--envs", "16", "--no-secondary"],
-             extra_env={"Q1_BENCH_FORCE_AUTO_SERVER": "1"}, timeout=120)
+             extra_env={"Q1_BENCH_ENV_FACTORY": "tests._bench_fake:FakeNoRollout"}, timeout=120)
     assert r.returncode == 0, r.stderr[-3000:]
     d = _one_json(r.stdout)
-    _check_line(d, 2, 16, 6, 2)
-    assert d["mode"] == "step" and "server mode failed" in d["mode_fallback"] and "step_kernel" in d["roofline"]["kernel"]
+    assert d["mode"] == "step" and "rollout mode failed" in d["mode_fallback"] and "step_kernel" in d["roofline"]["kernel"]
+    assert d["roofline"]["bound"] == "hbm" and "mode=step" in d["config"]["workload"]
+
+
+def test_default_mode_writes_per_tick_outputs_and_says_what_bounds_it():
+    """the default mode times a kernel whose per-tick obs / reward / done reach memory (the fused rollout: the
+    stand-in's tick-major output tensors are really written), the workload string is the mode's own, the kernel name carries its
+    template arguments, and the roofline object names the bound of a register-resident kernel (VALU issue) with the HBM side next
+    to it; the 204-B figure survives only as frac_nominal_204B."""
+    r = _run([sys.executable, "bench.py", "--gpus", "1", "--steps", "20", "--warmup", "5", "--envs", "32", "--no-cpu-baseline"], timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = _one_json(r.stdout)
+    assert d["mode"] == "rollout" and d["mode_fallback"] is None
+    assert "mode=rollout" in d["config"]["workload"] and "written tick-major to HBM" in d["config"]["workload"]
+    ro = d["roofline"]
+    assert ro["bound"] == "valu" and ro["kernel"].startswith("rollout_kernel<float, true, 2, false, 1>") and "SPEC, ES" not in ro["kernel"]
+    assert set(("hbm", "frac_nominal_204B", "traffic", "peak", "unit", "ticks_per_launch")) <= set(ro)
+    assert ro["hbm"]["peak_GBps"] == 8000.0 and ro["ticks_per_launch"] == 20
+    # secondaries: the per-tick kernels (HBM-bound formulation), each with its own workload string and roofline
+    st = d["per_tick_step"]
+    assert st["roofline"]["bound"] == "hbm" and "mode=step" in st["workload"] and st["roofline"]["kernel"].startswith("step_kernel<float, true, 2>")
+    assert "persistent_server" not in d                                      # (the stand-in has no tick server)
+    assert set(d["steady_state_720_ticks"]) == {"rollout", "step"}
+
+
+def test_fake_env_is_refused_without_the_explicit_switch():
+    r = _run([sys.executable, "bench.py", "--gpus", "1", "--steps", "2", "--warmup", "1", "--envs", "8"], extra_env={"Q1_BENCH_ALLOW_FAKE": "0"})
+    assert r.returncode != 0 and "Q1_BENCH_ALLOW_FAKE" in r.stderr and not r.stdout.strip()
+
+
+def test_numa_pinning_plan(tmp_path):
+    """pin_rank: the cores of the GPU's NUMA node, split among the ranks that share it; even split of the allowed CPUs when sysfs
+    has no answer.  (apply=False: the test process keeps its own affinity.)"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    allowed = sorted(os.sched_getaffinity(0))
+    sysfs = tmp_path / "sys"
+    dev = sysfs / "bus" / "pci" / "devices" / "0000:05:00.0"
+    dev.mkdir(parents=True)
+    (dev / "numa_node").write_text("1\n")
+    node = sysfs / "devices" / "system" / "node" / "node1"
+    node.mkdir(parents=True)
+    (node / "cpulist").write_text(f"{allowed[0]}-{allowed[-1]}\n")
+    assert bench._parse_cpulist("0-3,8,10-11") == {0, 1, 2, 3, 8, 10, 11}
+    assert bench.numa_cpus_of_pci("0000:05:00.0", str(sysfs))[0] == 1
+    a = bench.pin_rank("0000:05:00.0", 0, 2, sysfs=str(sysfs), apply=False)
+    b = bench.pin_rank("0000:05:00.0", 1, 2, sysfs=str(sysfs), apply=False)
+    assert a["numa_node"] == 1 and b["numa_node"] == 1 and not a["pinned"]
+    if len(allowed) >= 2:
+        assert a["cpus"] != b["cpus"] and a["n_cpus"] == len(allowed) // 2
+    c = bench.pin_rank("0000:99:00.0", 3, 4, sysfs=str(sysfs), apply=False)          # unknown device: even split
+    assert c["numa_node"] == -1 and "even split" in c["how"] and c["n_cpus"] >= 1
+    assert bench.pin_rank(None, 0, 1, sysfs=str(sysfs), apply=False)["n_cpus"] == len(allowed)
 
 
 def test_self_launch_eight_ranks():
