@@ -1,11 +1,14 @@
 """NumPy / SciPy ORACLE for the policy-side action distribution (reference q1physrl/action_dist.py:46-243).
 TEST INFRASTRUCTURE.  float64 restatement of the formulas with scipy.special.ndtr / ndtri.
 
-PARITY UNPINNED by the reference: action_dist.py is TensorFlow 2.1 + tensorflow-probability 0.9 + RLlib 0.8.4 code
-and none of them is installable here (no network), so no golden vector can be produced from it; the reference's own
-tests do not cover it either.  The pin is the published closed forms: log-density by change of variables, Gaussian KL,
-entropy = -KL(N(mean,std) || N(0,S)) + log(high-low), cross-checked numerically in tests/test_policy_dist.py
-(Monte-Carlo entropy, numerical integration of exp(logp) to 1, finite-difference Jacobian).
+PIN.  action_dist.py is TensorFlow 2.1 + tensorflow-probability 0.9 + RLlib 0.8.4 code, none of them installable here (no network),
+and the reference's own tests do not cover it, so no golden vector can be produced BY RUNNING it.  The pin is instead
+tests/golden/dist_known_answers.json: the closed forms of action_dist.py:91-96 (logp), :153-165 (kl), :167-178 (entropy), :186-196
+(squash / unsquash) and of the key Categoricals, evaluated BY HAND at parameter points where they collapse to ln 2, ln 3, ln 20, Phi(1),
+Phi(2) - written by oracle/gen_dist_known_answers.py, which imports nothing from this repository and nothing numerical but `math`.
+This module, q1physrl_amd/policy.py and the HIP kernels (q1env_policy_sample, q1env_ppo_loss_grad) are all checked against it
+(tests/test_policy_dist.py, tests/test_hip_policy.py), next to the first-principles checks (density integrates to 1, closed-form entropy
+= numerical differential entropy, finite-difference Jacobian) and the published WR checkpoint scoring ~5700.
 """
 import numpy as np
 from scipy import special

@@ -1,0 +1,61 @@
+"""GPU: bench.py as the driver runs it.  (a) the N=1 contract line: default mode, HIP path (env_impl), roofline object of the default
+(register-resident) kernel and of the per-tick kernel; (b) VERDICT r2 item 2: `bench.py --gpus 2` self-launched and OVERSUBSCRIBED
+on the one device of this box - both ranks run the same (default) mode on the HIP path, own distinct env_index_base, report their own
+host split and placement, nobody falls back."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(args, extra_env=None, timeout=900):
+    env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "Q1_BENCH_ENV_FACTORY", "Q1_BENCH_ALLOW_FAKE"):
+        env.pop(k, None)
+    env.update(extra_env or {})
+    r = subprocess.run([sys.executable, "bench.py"] + args, capture_output=True, text=True, timeout=timeout, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_driver_line_single_gpu():
+    d = _run(["--gpus", "1", "--steps", "20", "--warmup", "5", "--no-cpu-baseline"])
+    assert d["env_impl"] == "q1physrl_amd.device.DeviceEnv" and d["mode"] == "rollout" and d["mode_fallback"] is None
+    assert d["n_gpus"] == 1 and d["steps"] == 20 and d["config"]["envs_per_gpu"] == 65536 and "written tick-major to HBM" in d["config"]["workload"]
+    ro = d["roofline"]
+    assert ro["bound"] == "valu" and ro["kernel"].startswith("rollout_kernel<float, true, 2, false, 1>")
+    # a roofline fraction is a fraction: whatever axis it is on, it cannot pass 1 (the 204-B nominal figure may, and is kept aside)
+    assert ro["frac"] is None or 0.0 < ro["frac"] <= 1.0
+    assert 0.0 < ro["hbm"]["frac"] <= 1.0
+    st = d["per_tick_step"]["roofline"]
+    assert st["bound"] == "hbm" and 0.0 < st["frac"] <= 1.0
+    sv = d["persistent_server"]
+    assert "NOT written to HBM" in sv["workload"] and sv["roofline"]["kernel"].startswith("tick_pair_lds_kernel<true, 1>")
+    # the event time of the timed region fits inside its wall time, and 20 ticks of 65 536 envs in well under a millisecond
+    assert ro["avg_launch_us"] * 1e-3 <= d["ms_per_step"] * 20 <= 1.0
+    assert set(d["steady_state_720_ticks"]) == {"rollout", "step", "server"}
+
+
+def test_two_ranks_oversubscribed_on_one_device():
+    d = _run(["--gpus", "2", "--steps", "20", "--warmup", "5"], extra_env={"Q1_BENCH_OVERSUBSCRIBE": "1"})
+    assert d["n_gpus"] == 2 and d["mode"] == "rollout" and d["mode_fallback"] is None and d["env_impl"] == "q1physrl_amd.device.DeviceEnv"
+    rows = d["per_rank"]
+    assert [r["rank"] for r in rows] == [0, 1]
+    assert [r["env_index_base"] for r in rows] == [0, 65536] and all(r["envs"] == 65536 for r in rows)
+    assert all(r["mode"] == "rollout" and r["env_impl"] == "q1physrl_amd.device.DeviceEnv" for r in rows)
+    assert all(r["host_split_us"] and r["host_split_us"]["enqueue_us"] > 0 for r in rows)
+    assert all("placement" in r and r["placement"]["device"] == 0 for r in rows)
+    if all(r["placement"].get("pinned") for r in rows) and rows[0]["placement"]["n_cpus"] < os.cpu_count():
+        assert rows[0]["placement"]["cpus"] != rows[1]["placement"]["cpus"]          # the two ranks do not share cores
+    slowest = max(r["wall_ms"] for r in rows)
+    assert abs(d["ms_per_step"] * 20 - slowest) <= 1e-6 * slowest
+    # the --steps-independent figures ride along in the multi-rank line too (slowest rank's event time)
+    assert set(d["steady_state_720_ticks"]) == {"rollout", "step", "server"} and all("us_per_tick" in v for v in d["steady_state_720_ticks"].values())
+    assert d["config"]["total_envs"] == 131072 and d["cpu_baseline"]["value"] is None and "N=1" in d["cpu_baseline"]["sample"]

@@ -1,5 +1,7 @@
 """GPU: the fused policy-sampling kernel (q1env_policy_sample) against the float64 NumPy/SciPy restatement fed with the
 same Philox draws, the torch distribution, and an end-to-end sampler loop."""
+import os
+
 import numpy as np
 import pytest
 
@@ -659,3 +661,64 @@ def test_graph_recapture_keeps_adam_state():
     assert se == sg and se[0] == 3 * (512 * 32 // 2048) + 3 * (512 * 32 // 4096)       # Adam's step count survived the re-capture
     for a, b in zip(pe, pg):
         assert torch.allclose(a, b, rtol=0, atol=5e-5), (a - b).abs().max().item()
+
+
+def test_policy_kernels_reproduce_hand_derived_known_answers():
+    """The policy-side HIP kernels against the hand-derived known answers of the reference's action distribution
+    (tests/golden/dist_known_answers.json <- oracle/gen_dist_known_answers.py: closed forms of action_dist.py:91-96, 153-196 evaluated by
+    hand, independent of oracle/dist_oracle.py and of TensorFlow): (a) q1env_policy_sample in deterministic mode returns arg-max keys, the
+    squashed CLIPPED mean and that action's log-probability; (b) q1env_ppo_loss_grad: with logp_old = the known log-probability and
+    advantage 1 the probability ratio is 1 (policy_loss = -1), and its entropy / KL statistics are the known sums over the five
+    children.  float32 kernels: 2e-5 absolute on O(1..20) quantities."""
+    import json
+    import torch
+    k = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "dist_known_answers.json")))
+    assert k["low"] == -10.0 and k["high"] == 10.0
+    # ---- (a) deterministic sampling
+    det = [c for c in k["cases"] if c["kind"] == "tuple_deterministic"][0]
+    rows, want_x = [det["row"]], [det["expect_x"]]
+    for c in k["cases"]:
+        if c["kind"] == "deterministic":
+            rows.append([0.0, 1.0] * 4 + c["self_in"]); want_x.append(c["expect"])
+        if c["kind"] == "squash" and abs(c["raw"]) <= 3.0:                       # (beyond 3 the mean clip acts first)
+            rows.append([0.0, 1.0] * 4 + [c["raw"], -0.3]); want_x.append(c["expect"])
+    n = len(rows)
+    cfg, env = make_env(n, seed=1, action_range=10.0)
+    lt = torch.tensor(rows, dtype=torch.float32, device="cuda")
+    keys = torch.empty(n, dtype=torch.uint8, device="cuda")
+    mouse = torch.empty(n, dtype=torch.float32, device="cuda")
+    logp = torch.empty(n, dtype=torch.float32, device="cuda")
+    env._dev.policy_sample_dev(lt.data_ptr(), 10, 5, 0, keys.data_ptr(), mouse.data_ptr(), logp.data_ptr(), True)
+    torch.cuda.synchronize()
+    assert keys.cpu().tolist() == [15] * n
+    assert np.max(np.abs(mouse.cpu().numpy().astype(np.float64) - np.array(want_x))) < 2e-5
+    assert abs(float(logp[0]) - det["expect_logp"]) < 2e-5
+    env.close()
+    # ---- (b) loss kernel statistics on the known minibatch
+    b = k["batch"]
+    bsz = len(b)
+    cfg, env = make_env(bsz, seed=1, action_range=10.0)
+    new = torch.tensor([r["row"] for r in b], dtype=torch.float32, device="cuda")
+    old = torch.tensor([r["old_row"] for r in b], dtype=torch.float32, device="cuda")
+    packed = torch.tensor([sum(bit << j for j, bit in enumerate(r["keys"])) for r in b], dtype=torch.uint8, device="cuda")
+    x = torch.tensor([r["x"] for r in b], dtype=torch.float32, device="cuda")
+    logp_old = torch.tensor([r["expect_logp"] for r in b], dtype=torch.float32, device="cuda")
+    adv = torch.ones(bsz, device="cuda")
+    value = torch.zeros(bsz, device="cuda")
+    dl, dv = torch.empty_like(new), torch.empty_like(value)
+    partials = torch.zeros(((bsz + 255) // 256, 5), device="cuda")
+    klc = torch.tensor(0.2, device="cuda")
+    env._dev.ppo_loss_grad_dev(bsz, new.data_ptr(), old.data_ptr(), 10, packed.data_ptr(), x.data_ptr(), logp_old.data_ptr(), adv.data_ptr(),
+                               value.data_ptr(), value.data_ptr(), value.data_ptr(), 0.3, 100.0, 1.0, 0.01, klc.data_ptr(), dl.data_ptr(),
+                               dv.data_ptr(), partials.data_ptr())
+    torch.cuda.synchronize()
+    from q1physrl_amd import ppo
+    stats = dict(zip(ppo.STAT_KEYS, (partials.double().sum(0) / bsz).tolist()))
+    want_h = float(np.mean([r["expect_entropy"] for r in b]))
+    want_kl = float(np.mean([r["expect_kl_old_new"] for r in b]))
+    # the float32 mouse action x carries ~1e-6 of rounding, which ndtri amplifies in the tails (z = 2): 1e-4 on the ratio
+    assert abs(stats["policy_loss"] + 1.0) < 1e-4, stats
+    assert abs(stats["entropy"] - want_h) < 2e-5 * max(1.0, abs(want_h)), (stats["entropy"], want_h)
+    assert abs(stats["kl"] - want_kl) < 2e-5 * max(1.0, abs(want_kl)), (stats["kl"], want_kl)
+    assert abs(stats["vf_loss"]) == 0.0
+    env.close()

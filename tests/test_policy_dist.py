@@ -107,3 +107,96 @@ def test_wr_policy_scores_published_reward_in_the_oracle_env():
             obs, r, d, _ = env.vector_step(a)
             total += float(r[0]); done = bool(d[0]); ticks += 1
     assert ticks == 720 and 5600.0 < total < 5900.0, (ticks, total)
+
+
+# ---- the pin TensorFlow's absence left open: hand-derived known answers (oracle/gen_dist_known_answers.py) --------------------------
+def _known():
+    import json
+    import os
+    return json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "dist_known_answers.json")))
+
+
+def test_known_answers_fixture_is_what_its_generator_writes(tmp_path):
+    """The fixture is reproducible from its generator (pure `math`, no repository imports) - nobody edits expected values by hand."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = open(os.path.join(root, "oracle", "gen_dist_known_answers.py")).read()
+    assert "import numpy" not in src and "from oracle" not in src and "q1physrl_amd" not in src.split('"""')[2]
+    patched = tmp_path / "gen.py"
+    patched.write_text(src.replace('os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "dist_known_answers.json")',
+                                   repr(str(tmp_path / "out.json"))))
+    subprocess.run([sys.executable, str(patched)], check=True, capture_output=True)
+    import json
+    assert json.load(open(tmp_path / "out.json")) == _known()
+
+
+def test_oracle_and_torch_distribution_reproduce_the_hand_derived_known_answers():
+    """oracle/dist_oracle.py (the checker of the HIP kernels) and q1physrl_amd/policy.py (the learner's distribution) against closed
+    forms of action_dist.py:91-96, 153-196 evaluated by hand at points where they collapse to ln 2, ln 3, ln 20, Phi(1), Phi(2):
+    with TensorFlow absent, THIS is what pins the restatements to the reference's formulas.  float64: 1e-12 (1e-9 through ndtri)."""
+    k = _known()
+    low, high = k["low"], k["high"]
+    f64 = lambda v: torch.tensor([v], dtype=torch.float64)          # noqa: E731
+    seen = set()
+    for c in k["cases"]:
+        kind = c["kind"]
+        seen.add(kind)
+        if kind == "kl":
+            (m, ls), (m2, ls2) = c["self_in"], c["other_in"]
+            assert abs(float(DO.mouse_kl(m, ls, m2, ls2)) - c["expect"]) < 1e-12, c["name"]
+            d1, d2 = P.GaussianSquashedGaussian(f64([m, ls]), low, high), P.GaussianSquashedGaussian(f64([m2, ls2]), low, high)
+            assert abs(float(d1.kl(d2)) - c["expect"]) < 1e-12, c["name"]
+        elif kind == "entropy":
+            m, ls = c["self_in"]
+            assert abs(float(DO.mouse_entropy(m, ls, low, high)) - c["expect"]) < 1e-12, c["name"]
+            assert abs(float(P.GaussianSquashedGaussian(f64([m, ls]), low, high).entropy()) - c["expect"]) < 1e-12, c["name"]
+        elif kind == "logp":
+            m, ls = c["self_in"]
+            assert abs(float(DO.mouse_logp(np.array([c["x"]]), m, ls, low, high)[0]) - c["expect"]) < 1e-9, c["name"]
+            assert abs(float(P.GaussianSquashedGaussian(f64([m, ls]), low, high).logp(f64([c["x"]]))) - c["expect"]) < 1e-9, c["name"]
+        elif kind == "squash":
+            assert abs(float(DO.squash(c["raw"], low, high)) - c["expect"]) < 1e-12, c["name"]
+            d0 = P.GaussianSquashedGaussian(f64([0.0, 0.0]), low, high)
+            assert abs(float(d0._squash(f64([c["raw"]]))) - c["expect"]) < 1e-12, c["name"]
+        elif kind == "deterministic":
+            m, ls = c["self_in"]
+            assert abs(float(P.GaussianSquashedGaussian(f64([m, ls]), low, high).deterministic_sample()) - c["expect"]) < 1e-12, c["name"]
+            assert abs(float(DO.squash(DO.clip_params(m, ls)[0], low, high)) - c["expect"]) < 1e-12, c["name"]
+        elif kind == "key":
+            l0, l1 = c["logits"]
+            lp0, lp1 = DO.key_logprobs(np.array([l0]), np.array([l1]))
+            assert abs(lp0[0] - c["expect_logp"][0]) < 1e-12 and abs(lp1[0] - c["expect_logp"][1]) < 1e-12, c["name"]
+            cat = P.Categorical2(f64([l0, l1]))
+            assert abs(float(cat.logp(torch.tensor([0]))) - c["expect_logp"][0]) < 1e-12 and abs(float(cat.logp(torch.tensor([1]))) - c["expect_logp"][1]) < 1e-12
+            assert abs(float(cat.entropy()) - c["expect_entropy"]) < 1e-12, c["name"]
+            _, ent, _ = DO.categorical_terms(np.array([[l0, l1]]))
+            assert abs(ent[0] - c["expect_entropy"]) < 1e-12
+        elif kind == "key_kl":
+            a, b = P.Categorical2(f64(c["logits"])), P.Categorical2(f64(c["other"]))
+            assert abs(float(a.kl(b)) - c["expect"]) < 1e-12 and abs(float(b.kl(a)) - c["expect_reverse"]) < 1e-12, c["name"]
+            _, _, klv = DO.categorical_terms(np.array([c["other"]]), np.array([c["logits"]]))          # KL(old = logits || new = other)
+            assert abs(klv[0] - c["expect"]) < 1e-12
+        elif kind == "tuple":
+            dist = P.Q1PhysActionDist(f64(c["row"]), high, num_keys=4)
+            assert abs(float(dist.logp(torch.tensor([c["keys"]]), f64([c["x"]]))) - c["expect_logp"]) < 1e-9, c["name"]
+            assert abs(float(dist.entropy()) - c["expect_entropy"]) < 1e-12, c["name"]
+        elif kind == "tuple_deterministic":
+            dist = P.Q1PhysActionDist(f64(c["row"]), high, num_keys=4)
+            kk, mm = dist.deterministic_sample()
+            assert kk[0].tolist() == c["expect_keys"] and abs(float(mm) - c["expect_x"]) < 1e-12
+            assert abs(float(dist.logp(kk, mm)) - c["expect_logp"]) < 1e-9, c["name"]
+    assert seen == {"kl", "entropy", "logp", "squash", "deterministic", "key", "key_kl", "tuple", "tuple_deterministic"}
+    # the minibatch rows (sums over the five children): the torch distribution and the loss oracle
+    from oracle import ppo_oracle as PO
+    rows = k["batch"]
+    new = torch.tensor([r["row"] for r in rows], dtype=torch.float64)
+    old = torch.tensor([r["old_row"] for r in rows], dtype=torch.float64)
+    keys = torch.tensor([r["keys"] for r in rows])
+    x = torch.tensor([[r["x"]] for r in rows], dtype=torch.float64)
+    dn, do = P.Q1PhysActionDist(new, high, num_keys=4), P.Q1PhysActionDist(old, high, num_keys=4)
+    assert np.allclose(dn.logp(keys, x).numpy(), [r["expect_logp"] for r in rows], rtol=0, atol=1e-9)
+    assert np.allclose(dn.entropy().numpy(), [r["expect_entropy"] for r in rows], rtol=0, atol=1e-11)
+    assert np.allclose(do.kl(dn).numpy(), [r["expect_kl_old_new"] for r in rows], rtol=1e-12, atol=1e-11)
+    assert hasattr(PO, "ppo_loss_grad")
