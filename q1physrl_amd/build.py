@@ -67,10 +67,13 @@ def _run(cmd, verbose):
         print(r.stderr, file=sys.stderr)
 
 
-def build_lib(force=False, verbose=False, check=False, extra_flags=()):
-    """Compile the stale translation units (in parallel) and link.  check=True: the -DQ1_CHECK assertion build (libq1env_check.so)."""
-    out = OUT_CHECK if check else OUT
-    tag = "_check" if check else ""
+def build_lib(force=False, verbose=False, check=False, extra_flags=(), out=None, tag=None):
+    """Compile the stale translation units (in parallel) and link.  check=True: the -DQ1_CHECK assertion build (libq1env_check.so).
+    out / tag: an experimental variant (extra_flags) built next to the product library, e.g. tools/exp_step_large.py."""
+    if out is None:
+        out = OUT_CHECK if check else OUT
+    if tag is None:
+        tag = "_check" if check else ""
     if not force and not is_stale(out):
         return out
     os.makedirs(OBJ_DIR, exist_ok=True)

@@ -15,8 +15,11 @@ using namespace q1;
 // LDS is used for one thing only: transposing the wave's 64 float32 observation rows so they leave as 16-B-per-lane
 // coalesced stores (write_obs_wave_f32).
 //   SPEC: default Config structure baked in (straight-line tick);  FMT: action layout, or FMT_RUNTIME.
+#ifndef Q1_STEP_MINWAVES            // (measurement knobs: minimum waves per SIMD the register allocation must leave room for)
+#define Q1_STEP_MINWAVES 1
+#endif
 template <typename OBS_T, bool SPEC, int FMT>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, Q1_STEP_MINWAVES)
 step_kernel(float* pvx, float* pvy, float* pvz, double* ppx, double* ppy, double* pz, double* pyaw, double* ptrem,   // preloaded into SGPRs
             Params p, StatePtrs s, int fmt, const void* act_a, const void* act_b,
             OBS_T* obs, float* reward, uint8_t* done, uint8_t* zero_start) {

@@ -85,12 +85,16 @@ static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; 
 
 static inline dim3 grid_for(int n, int block) { return dim3((unsigned)((n + block - 1) / block)); }
 
-// Small batches are latency bound: 64-lane workgroups spread 64 k envs over all 256 CUs (1024 waves).
-// Large batches are bandwidth bound: 256-lane workgroups cut dispatch overhead.
+// 64-lane workgroups at every batch size: small batches are latency bound and 64-lane workgroups spread 64 k envs over all 256 CUs
+// (1024 waves); for the bandwidth-bound batches round 3 re-measured 64 against 256 lanes three times each (tools/exp_step_large.py,
+// profiles/r3_step_large.txt): 512 k envs 15.9 vs 17.0 us per tick, 1 M 33.5-35.7 vs 34.7-37.8, 2 M and 4 M equal within the 5 %
+// run-to-run spread - the dispatcher is not the limit, and smaller workgroups retire (and refill their SIMD slots) sooner.
+// Q1ENV_BLOCK = 64 / 128 / 256 overrides (measurement knob).
 static inline int block_for(int n) {
-    static const int forced = [] { const char* e = getenv("Q1ENV_BLOCK"); return e ? atoi(e) : 0; }();   // tuning knob
+    static const int forced = [] { const char* e = getenv("Q1ENV_BLOCK"); return e ? atoi(e) : 0; }();
+    (void)n;
     if (forced == 64 || forced == 128 || forced == 256) return forced;
-    return n >= (1 << 19) ? 256 : 64;
+    return 64;
 }
 
 Q1_HIDDEN int ensure_stage(q1env* h, size_t bytes);
