@@ -307,6 +307,50 @@ typedef struct q1env_mlp {
 } q1env_mlp;
 int q1env_policy_value_forward(q1env_t* env, const float* obs_dev, const q1env_mlp* pi, const q1env_mlp* vf);
 
+/* ---- native PPO learner step (ABI v3) ---------------------------------------------------------------------------------------
+ * Counterpart of the RLlib PPOTrainer's SGD step the reference configures (q1physrl/train.py:60-64, data/params.yml:4-13) for the two
+ * fcnet networks of the published checkpoint's shape (obs 6 -> 256 tanh -> 256 tanh -> out; policy and value network separate):
+ * forward, PPO loss gradient (q1env_ppo_loss_grad's closed forms), backward and weight gradients as hand-written gfx950 kernels -
+ * float16 matrix-core operands, float32 accumulation; the float32 master weights, the gradients and the optimizer state stay with the
+ * caller (torch Linear layouts: w1 float[256][6], b1 float[256], w2 float[256][256], b2 float[256], w3 float[out][256], b3 float[out]).
+ *   q1env_learner_workspace_bytes   size of the device scratch one (minibatch, splits) shape needs (weight images, float16 activations
+ *                                   of the minibatch in two layouts, split-K partial sums); the caller allocates it once
+ *   q1env_learner_images            float32 masters -> the float16 weight images of both directions (call after every optimizer step)
+ *   q1env_learner_forward           logits float[B][out_pi] / value float[B] of rows idx[0..B) of obs (idx NULL: rows 0..B-1);
+ *                                   bit-identical to q1env_policy_value_forward on the gathered rows; keeps the activations
+ *   q1env_learner_backward          gradients of sum_i <dlogits_i, logits_i> + dvalue_i value_i w.r.t. all twelve tensors, divided by
+ *                                   grad_scale (pass dlogits / dvalue PRE-MULTIPLIED by grad_scale, e.g. B: they travel as float16)
+ *   q1env_learner_step              forward + PPO loss gradient + backward of one minibatch: gw* / gb* = d mean-loss / d parameter,
+ *                                   stats_partials as q1env_ppo_loss_grad; then run the optimizer and q1env_learner_images
+ * `splits` = workgroups per network of the split-K weight-gradient kernel (64 is a good value on an MI355X); it fixes the workspace
+ * size, so the same value goes into every call.  All launches are asynchronous on the handle's stream; nothing is allocated. */
+typedef struct q1env_learner_net {
+    const float* w1; const float* b1; const float* w2; const float* b2; const float* w3; const float* b3;   /* device, float32 masters */
+    float* gw1; float* gb1; float* gw2; float* gb2; float* gw3; float* gb3;                                  /* device, gradients out  */
+    int out_dim;
+} q1env_learner_net;
+typedef struct q1env_learner_batch {
+    int64_t minibatch;                 /* B */
+    const int64_t* idx_dev;            /* int64[B]: rows of the arrays below that form the minibatch (NULL: rows 0..B-1) */
+    const float* obs_dev;              /* float[total][6] */
+    const float* old_logits_dev;       /* float[total][old_stride]: the behaviour policy's outputs */
+    int old_stride;
+    const uint8_t* keys_dev;           /* uint8[total] packed key actions */
+    const float* mouse_dev;            /* float[total] mouse actions (NULL without a mouse) */
+    const float* logp_old_dev; const float* adv_dev; const float* value_old_dev; const float* vtarg_dev;   /* float[total] each */
+    float clip_param, vf_clip_param, vf_loss_coeff, entropy_coeff;
+    const float* kl_coeff_dev;         /* device scalar */
+    float* stats_partials_dev;         /* float[ceil(B/256)][5]: sums of (entropy, kl, -surrogate, total, vf) per block of 256 samples */
+} q1env_learner_batch;
+uint64_t q1env_learner_workspace_bytes(int64_t minibatch, int out_dim_pi, int splits);
+int q1env_learner_images(q1env_t* env, const q1env_learner_net* pi, const q1env_learner_net* vf, void* ws_dev, int64_t minibatch, int splits);
+int q1env_learner_forward(q1env_t* env, const q1env_learner_net* pi, const q1env_learner_net* vf, void* ws_dev, int64_t minibatch, int splits,
+                          const float* obs_dev, const int64_t* idx_dev, float* logits_out_dev, float* value_out_dev);
+int q1env_learner_backward(q1env_t* env, const q1env_learner_net* pi, const q1env_learner_net* vf, void* ws_dev, int64_t minibatch, int splits,
+                           const float* obs_dev, const int64_t* idx_dev, const float* dlogits_dev, const float* dvalue_dev, float grad_scale);
+int q1env_learner_step(q1env_t* env, const q1env_learner_net* pi, const q1env_learner_net* vf, void* ws_dev, int splits,
+                       const q1env_learner_batch* batch);
+
 /* Episode bookkeeping of one sampler tick (the reference's on_episode_end metric hook, q1physrl/train.py:54-57):
  * ep_return double[N] += reward; for envs with done != 0 the finished return is added to this wave's slot of
  * partials (double[ceil(N/64)][4] = episodes, zero-start episodes, return sum, zero-start return sum) and ep_return is

@@ -55,6 +55,18 @@ class Q1ResidentArgs(C.Structure):   # q1env_resident_args
                 ("timeout_s", C.c_double)]
 
 
+class Q1LearnerNet(C.Structure):     # q1env_learner_net
+    _fields_ = [(k, C.c_void_p) for k in ("w1", "b1", "w2", "b2", "w3", "b3", "gw1", "gb1", "gw2", "gb2", "gw3", "gb3")] + [("out_dim", C.c_int)]
+
+
+class Q1LearnerBatch(C.Structure):   # q1env_learner_batch
+    _fields_ = [("minibatch", C.c_int64), ("idx_dev", C.c_void_p), ("obs_dev", C.c_void_p), ("old_logits_dev", C.c_void_p), ("old_stride", C.c_int),
+                ("keys_dev", C.c_void_p), ("mouse_dev", C.c_void_p), ("logp_old_dev", C.c_void_p), ("adv_dev", C.c_void_p),
+                ("value_old_dev", C.c_void_p), ("vtarg_dev", C.c_void_p),
+                ("clip_param", C.c_float), ("vf_clip_param", C.c_float), ("vf_loss_coeff", C.c_float), ("entropy_coeff", C.c_float),
+                ("kl_coeff_dev", C.c_void_p), ("stats_partials_dev", C.c_void_p)]
+
+
 STATE_FIELDS = (("vel_x", np.float32, 1), ("vel_y", np.float32, 1), ("vel_z", np.float32, 1),
                 ("pos_x", np.float64, 1), ("pos_y", np.float64, 1), ("z_pos", np.float64, 1),
                 ("yaw", np.float64, 1), ("time_remaining", np.float64, 1),
@@ -99,6 +111,11 @@ _SIGNATURES = {
     "q1env_policy_forward": (C.c_int, [_P] * 7 + [C.c_int, _P]),
     "q1env_policy_value_forward": (C.c_int, [_P, _P, _P, _P]),
     "q1env_ppo_loss_grad": (C.c_int, [_P, C.c_int64, _P, _P, C.c_int] + [_P] * 7 + [C.c_float] * 4 + [_P] * 4),
+    "q1env_learner_workspace_bytes": (C.c_uint64, [C.c_int64, C.c_int, C.c_int]),
+    "q1env_learner_images": (C.c_int, [_P, C.POINTER(Q1LearnerNet), C.POINTER(Q1LearnerNet), _P, C.c_int64, C.c_int]),
+    "q1env_learner_forward": (C.c_int, [_P, C.POINTER(Q1LearnerNet), C.POINTER(Q1LearnerNet), _P, C.c_int64, C.c_int, _P, _P, _P, _P]),
+    "q1env_learner_backward": (C.c_int, [_P, C.POINTER(Q1LearnerNet), C.POINTER(Q1LearnerNet), _P, C.c_int64, C.c_int, _P, _P, _P, _P, C.c_float]),
+    "q1env_learner_step": (C.c_int, [_P, C.POINTER(Q1LearnerNet), C.POINTER(Q1LearnerNet), _P, C.c_int, C.POINTER(Q1LearnerBatch)]),
     "q1env_sample_step": (C.c_int, [_P, _P, C.c_int, C.c_uint64, _P, C.c_uint64, C.c_int] + [_P] * 9),
     "q1env_episode_stats": (C.c_int, [_P, _P, _P, _P, _P, _P]),
     "q1env_step_persistent_start": (C.c_int, [_P, C.c_int, C.c_uint32, _P, _P, _P, C.c_uint64, C.c_int, _P, C.c_double]),

@@ -6,6 +6,7 @@
 //                       and the launchers of the matrix-core forward (q1policy.hpp)
 //   q1env_server.hip    the resident tick server (q1server.hpp)
 //   q1env_resident.hip  the resident sampler (q1resident.hpp)
+//   q1env_learner.hip   the native PPO learner step (q1learner.hpp, q1ppo_loss.hpp)
 //   q1env_diag.hip      timers, PMC traffic calibration, division self-test
 //
 // Kernels live in the translation unit that launches them (no relocatable device code: each TU carries its own code object).
@@ -75,6 +76,7 @@ struct q1env {
     int pair_blocks_per_cu[3] = {-1, -1, -1};     // ... and of the server + driver pair kernel, per shape (PAIR_SHAPES)
     bool resident_attr_set = false;   // the resident sampler's dynamic-LDS attribute
     bool mlp_attr_set = false;        // dynamic-LDS attribute of the policy kernels (a per-device setting: kept per handle)
+    bool learner_attr_set = false;    // ... and of the native learner's forward / backward kernels
     // cached hipGraphs of step_many, keyed by (ticks, formats, pointers); a handful of entries, oldest evicted
     struct GraphEntry { std::vector<uint64_t> key; hipGraphExec_t exec; };
     std::vector<GraphEntry> graphs;

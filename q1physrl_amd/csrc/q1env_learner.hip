@@ -1,0 +1,188 @@
+// q1env_learner.hip - the native PPO learner step of libq1env.so (q1env_learner_*; device code in q1learner.hpp and q1ppo_loss.hpp):
+// forward + loss gradient + backward + weight gradients of the policy and the value network on the matrix cores, float32 master
+// weights and gradients in torch layouts.  Counterpart of the torch modules + autograd in q1physrl_amd/ppo.py (reference: RLlib's
+// PPOTrainer as configured by q1physrl/train.py:60-64 and data/params.yml:4-13).
+#include "q1env_host.hpp"
+#include "q1policy.hpp"
+#include "q1policy_glue.hpp"
+#include "q1ppo_loss.hpp"
+#include "q1learner.hpp"
+
+using namespace q1;
+
+namespace {
+
+constexpr size_t IMG_FWD_BYTES = (q1pol::LDS_W2 + q1pol::LDS_W3);           // 152064: float16[288][264]
+constexpr size_t IMG_W2T_BYTES = q1learn::LDS_W2T;                          // 135168
+constexpr size_t IMG_W3T_BYTES = q1learn::LDS_W3T;                          // 20480
+
+struct NetWs {
+    uint16_t* w23; uint16_t* w2t; uint16_t* w3t;
+    q1learn::f16x8* h1T; q1learn::f16x8* h2T; q1learn::f16x8* dz2N; q1learn::f16x8* dz1N; q1learn::f16x8* h1N; q1learn::f16x8* h2N;
+    float* partial;
+};
+struct Ws {
+    NetWs net[2];
+    float* logits; float* value; float* dlogits; float* dvalue;
+    size_t bytes;
+};
+
+// carve the caller's workspace (256-byte aligned pieces); base may be NULL to size it
+Ws carve_ws(void* base, int64_t mb, int out_pi, int splits) {
+    Ws w{};
+    char* b = (char*)base;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { void* q = b ? b + off : nullptr; off += align_up(bytes, 256); return q; };
+    const size_t tiles = (size_t)((mb + 31) / 32), act = tiles * q1learn::TILE_VECS * 16u;
+    for (int k = 0; k < 2; ++k) {
+        NetWs& n = w.net[k];
+        n.w23 = (uint16_t*)take(IMG_FWD_BYTES); n.w2t = (uint16_t*)take(IMG_W2T_BYTES); n.w3t = (uint16_t*)take(IMG_W3T_BYTES);
+        n.h1T = (q1learn::f16x8*)take(act); n.h2T = (q1learn::f16x8*)take(act);
+        n.dz2N = (q1learn::f16x8*)take(act); n.dz1N = (q1learn::f16x8*)take(act); n.h1N = (q1learn::f16x8*)take(act); n.h2N = (q1learn::f16x8*)take(act);
+        n.partial = (float*)take((size_t)splits * q1learn::PARTIAL_FLOATS * 4u);
+    }
+    w.logits = (float*)take((size_t)mb * out_pi * 4u); w.value = (float*)take((size_t)mb * 4u);
+    w.dlogits = (float*)take((size_t)mb * out_pi * 4u); w.dvalue = (float*)take((size_t)mb * 4u);
+    w.bytes = off;
+    return w;
+}
+
+int check_nets(const char* who, const q1env_learner_net* pi, const q1env_learner_net* vf, bool need_grads) {
+    for (const q1env_learner_net* m : {pi, vf}) {
+        if (!m || !m->w1 || !m->b1 || !m->w2 || !m->b2 || !m->w3 || !m->b3) return fail(Q1ENV_ERR_INVALID_ARG, std::string(who) + ": null weight pointer");
+        if (need_grads && (!m->gw1 || !m->gb1 || !m->gw2 || !m->gb2 || !m->gw3 || !m->gb3)) return fail(Q1ENV_ERR_INVALID_ARG, std::string(who) + ": null gradient pointer");
+        if (m->out_dim < 1 || m->out_dim > 32) return fail(Q1ENV_ERR_INVALID_ARG, std::string(who) + ": out_dim must be in 1..32");
+    }
+    return 0;
+}
+
+int check_shape(const char* who, int64_t mb, int splits) {
+    if (mb <= 0 || mb > ((int64_t)1 << 24)) return fail(Q1ENV_ERR_INVALID_ARG, std::string(who) + ": minibatch out of range");
+    if (splits < 1 || splits > 512) return fail(Q1ENV_ERR_INVALID_ARG, std::string(who) + ": splits must be in 1..512");
+    return 0;
+}
+
+int ensure_learner_attrs(q1env* h) {
+    if (!h->learner_attr_set) {
+        HIP_TRY(hipFuncSetAttribute((const void*)q1learn::learner_forward_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)q1pol::LDS_TOTAL));
+        HIP_TRY(hipFuncSetAttribute((const void*)q1learn::learner_backward_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)q1learn::LDS_BWD));
+        h->learner_attr_set = true;
+    }
+    return 0;
+}
+
+int launch_forward(q1env* h, const Ws& w, int64_t mb, const q1env_learner_net* pi, const q1env_learner_net* vf, const float* obs, const int64_t* idx,
+                   float* logits, float* value) {
+    if (int r = ensure_learner_attrs(h)) return r;
+    const q1learn::FwdNet na{pi->w1, pi->b1, w.net[0].w23, pi->b2, pi->b3, logits, pi->out_dim, w.net[0].h1T, w.net[0].h2T};
+    const q1learn::FwdNet nb{vf->w1, vf->b1, w.net[1].w23, vf->b2, vf->b3, value, vf->out_dim, w.net[1].h1T, w.net[1].h2T};
+    const unsigned cus = (unsigned)(h->num_cus > 1 ? h->num_cus / 2 : 1);                  // CUs per network, one workgroup each
+    const unsigned tiles = (unsigned)((mb + 31) / 32);
+    unsigned blocks = (tiles + 7u) / 8u;
+    if (blocks > cus) blocks = cus;
+    hipLaunchKernelGGL(q1learn::learner_forward_kernel, dim3(blocks * 2u), dim3(512), q1pol::LDS_TOTAL, h->stream, (int)mb, obs, idx, na, nb, 2);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int launch_backward(q1env* h, const Ws& w, int64_t mb, int splits, const q1env_learner_net* pi, const q1env_learner_net* vf, const float* obs,
+                    const int64_t* idx, const float* dlogits, const float* dvalue, float grad_scale) {
+    if (int r = ensure_learner_attrs(h)) return r;
+    const q1learn::BwdNet ba{w.net[0].w2t, w.net[0].w3t, dlogits, pi->out_dim, pi->out_dim, w.net[0].h1T, w.net[0].h2T,
+                             w.net[0].dz2N, w.net[0].dz1N, w.net[0].h1N, w.net[0].h2N};
+    const q1learn::BwdNet bb{w.net[1].w2t, w.net[1].w3t, dvalue, vf->out_dim, vf->out_dim, w.net[1].h1T, w.net[1].h2T,
+                             w.net[1].dz2N, w.net[1].dz1N, w.net[1].h1N, w.net[1].h2N};
+    const unsigned cus = (unsigned)(h->num_cus > 1 ? h->num_cus / 2 : 1);
+    const unsigned tiles = (unsigned)((mb + 31) / 32);
+    unsigned blocks = (tiles + 3u) / 4u;
+    if (blocks > cus) blocks = cus;
+    hipLaunchKernelGGL(q1learn::learner_backward_kernel, dim3(blocks * 2u), dim3(256), q1learn::LDS_BWD, h->stream, (int)mb, ba, bb, 2);
+    const q1learn::WgNet wa{w.net[0].dz2N, w.net[0].dz1N, w.net[0].h1N, w.net[0].h2N, dlogits, pi->out_dim, pi->out_dim, w.net[0].partial};
+    const q1learn::WgNet wb{w.net[1].dz2N, w.net[1].dz1N, w.net[1].h1N, w.net[1].h2N, dvalue, vf->out_dim, vf->out_dim, w.net[1].partial};
+    hipLaunchKernelGGL(q1learn::learner_wgrad_kernel, dim3(2u * (unsigned)splits, 2), dim3(512), 0, h->stream, (int)mb, obs, idx, wa, wb, splits);
+    const q1learn::Grads ga{pi->gw1, pi->gb1, pi->gw2, pi->gb2, pi->gw3, pi->gb3, pi->out_dim};
+    const q1learn::Grads gb{vf->gw1, vf->gb1, vf->gw2, vf->gb2, vf->gw3, vf->gb3, vf->out_dim};
+    const unsigned max_out = (unsigned)(pi->out_dim > vf->out_dim ? pi->out_dim : vf->out_dim);
+    const unsigned elems = 65536u + 256u + 256u * 6u + 256u + max_out * 256u + max_out;
+    hipLaunchKernelGGL(q1learn::learner_reduce_kernel, dim3((elems + 255u) / 256u, 2), dim3(256), 0, h->stream, (const float*)w.net[0].partial,
+                       (const float*)w.net[1].partial, ga, gb, splits, 1.0f / grad_scale);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+uint64_t q1env_learner_workspace_bytes(int64_t minibatch, int out_dim_pi, int splits) {
+    if (minibatch <= 0 || out_dim_pi < 1 || out_dim_pi > 32 || splits < 1 || splits > 512) return 0;
+    return (uint64_t)carve_ws(nullptr, minibatch, out_dim_pi, splits).bytes;
+}
+
+int q1env_learner_images(q1env_t* h, const q1env_learner_net* pi, const q1env_learner_net* vf, void* ws_dev, int64_t minibatch, int splits) {
+    if (!h || !ws_dev) return fail(Q1ENV_ERR_INVALID_ARG, "q1env_learner_images: null argument");
+    if (int r = check_nets("q1env_learner_images", pi, vf, false)) return r;
+    if (int r = check_shape("q1env_learner_images", minibatch, splits)) return r;
+    DeviceGuard guard(h->device);
+    const Ws w = carve_ws(ws_dev, minibatch, pi->out_dim, splits);
+    const q1learn::ImgNet na{pi->w2, pi->w3, pi->out_dim, w.net[0].w23, w.net[0].w2t, w.net[0].w3t};
+    const q1learn::ImgNet nb{vf->w2, vf->w3, vf->out_dim, w.net[1].w23, w.net[1].w2t, w.net[1].w3t};
+    const unsigned elems = 288u * 264u + 256u * 264u + 256u * 40u;
+    hipLaunchKernelGGL(q1learn::learner_images_kernel, dim3((elems + 255u) / 256u, 2), dim3(256), 0, h->stream, na, nb);
+    HIP_TRY(hipGetLastError());
+    return Q1ENV_OK;
+}
+
+int q1env_learner_forward(q1env_t* h, const q1env_learner_net* pi, const q1env_learner_net* vf, void* ws_dev, int64_t minibatch, int splits,
+                          const float* obs_dev, const int64_t* idx_dev, float* logits_out, float* value_out) {
+    if (!h || !ws_dev || !obs_dev) return fail(Q1ENV_ERR_INVALID_ARG, "q1env_learner_forward: null argument");
+    if (int r = check_nets("q1env_learner_forward", pi, vf, false)) return r;
+    if (int r = check_shape("q1env_learner_forward", minibatch, splits)) return r;
+    DeviceGuard guard(h->device);
+    const Ws w = carve_ws(ws_dev, minibatch, pi->out_dim, splits);
+    if (int r = launch_forward(h, w, minibatch, pi, vf, obs_dev, idx_dev, logits_out ? logits_out : w.logits, value_out ? value_out : w.value)) return r;
+    return Q1ENV_OK;
+}
+
+int q1env_learner_backward(q1env_t* h, const q1env_learner_net* pi, const q1env_learner_net* vf, void* ws_dev, int64_t minibatch, int splits,
+                           const float* obs_dev, const int64_t* idx_dev, const float* dlogits_dev, const float* dvalue_dev, float grad_scale) {
+    if (!h || !ws_dev || !obs_dev || !dlogits_dev || !dvalue_dev) return fail(Q1ENV_ERR_INVALID_ARG, "q1env_learner_backward: null argument");
+    if (!(grad_scale > 0.0f)) return fail(Q1ENV_ERR_INVALID_ARG, "q1env_learner_backward: grad_scale must be > 0");
+    if (int r = check_nets("q1env_learner_backward", pi, vf, true)) return r;
+    if (int r = check_shape("q1env_learner_backward", minibatch, splits)) return r;
+    DeviceGuard guard(h->device);
+    const Ws w = carve_ws(ws_dev, minibatch, pi->out_dim, splits);
+    return launch_backward(h, w, minibatch, splits, pi, vf, obs_dev, idx_dev, dlogits_dev, dvalue_dev, grad_scale);
+}
+
+int q1env_learner_step(q1env_t* h, const q1env_learner_net* pi, const q1env_learner_net* vf, void* ws_dev, int splits, const q1env_learner_batch* b) {
+    if (!h || !ws_dev || !b) return fail(Q1ENV_ERR_INVALID_ARG, "q1env_learner_step: null argument");
+    if (!b->obs_dev || !b->old_logits_dev || !b->keys_dev || !b->logp_old_dev || !b->adv_dev || !b->value_old_dev || !b->vtarg_dev || !b->kl_coeff_dev ||
+        !b->stats_partials_dev)
+        return fail(Q1ENV_ERR_INVALID_ARG, "q1env_learner_step: null pointer in q1env_learner_batch");
+    if (int r = check_nets("q1env_learner_step", pi, vf, true)) return r;
+    if (int r = check_shape("q1env_learner_step", b->minibatch, splits)) return r;
+    if (h->p.yaw_mode != 0 && !b->mouse_dev) return fail(Q1ENV_ERR_INVALID_ARG, "q1env_learner_step: mouse actions required");
+    if (pi->out_dim != policy_row_width(h->p)) return fail(Q1ENV_ERR_INVALID_ARG, "q1env_learner_step: pi->out_dim must be " + std::to_string(policy_row_width(h->p)));
+    if (vf->out_dim != 1) return fail(Q1ENV_ERR_INVALID_ARG, "q1env_learner_step: vf->out_dim must be 1");
+    if (b->old_stride < pi->out_dim) return fail(Q1ENV_ERR_INVALID_ARG, "q1env_learner_step: old_stride smaller than the policy row");
+    DeviceGuard guard(h->device);
+    const int64_t mb = b->minibatch;
+    const Ws w = carve_ws(ws_dev, mb, pi->out_dim, splits);
+    if (int r = launch_forward(h, w, mb, pi, vf, b->obs_dev, b->idx_dev, w.logits, w.value)) return r;
+    const float scale = (float)mb;                                 // per-sample (un-averaged) gradients: float16's normal range
+    if (b->idx_dev)
+        hipLaunchKernelGGL(ppo_loss_grad_kernel<true>, grid_for((int)mb, 256), dim3(256), 0, h->stream, h->p, (int)mb, (const float*)w.logits,
+                           b->old_logits_dev, pi->out_dim, b->old_stride, b->keys_dev, b->mouse_dev, b->logp_old_dev, b->adv_dev, (const float*)w.value,
+                           b->value_old_dev, b->vtarg_dev, b->idx_dev, b->clip_param, b->vf_clip_param, b->vf_loss_coeff, b->entropy_coeff,
+                           b->kl_coeff_dev, scale, w.dlogits, w.dvalue, b->stats_partials_dev);
+    else
+        hipLaunchKernelGGL(ppo_loss_grad_kernel<false>, grid_for((int)mb, 256), dim3(256), 0, h->stream, h->p, (int)mb, (const float*)w.logits,
+                           b->old_logits_dev, pi->out_dim, b->old_stride, b->keys_dev, b->mouse_dev, b->logp_old_dev, b->adv_dev, (const float*)w.value,
+                           b->value_old_dev, b->vtarg_dev, (const int64_t*)nullptr, b->clip_param, b->vf_clip_param, b->vf_loss_coeff, b->entropy_coeff,
+                           b->kl_coeff_dev, scale, w.dlogits, w.dvalue, b->stats_partials_dev);
+    HIP_TRY(hipGetLastError());
+    return launch_backward(h, w, mb, splits, pi, vf, b->obs_dev, b->idx_dev, w.dlogits, w.dvalue, scale);
+}
+
+}  // extern "C"

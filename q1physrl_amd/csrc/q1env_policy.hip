@@ -3,6 +3,7 @@
 #include "q1env_host.hpp"
 #include "q1policy.hpp"
 #include "q1policy_glue.hpp"
+#include "q1ppo_loss.hpp"
 
 using namespace q1;
 
@@ -42,142 +43,6 @@ gae_kernel(int n, int ticks, const float* __restrict__ reward, const float* __re
         vtarg[o] = a + v;
         v_next = v;
     }
-}
-
-// PPO loss of one minibatch and its gradient with respect to the policy outputs (learner-side glue): the
-// closed forms of q1physrl_amd/ppo.py::ppo_loss (RLlib 0.8.4 PPOLoss over the reference's Q1PhysActionDist, action_dist.py:46-243)
-// differentiated by hand, one lane per sample - replaces ~100 elementwise launches + their autograd twins per SGD step:
-//   keys k:  d = l1 - l0, p = sigmoid(d), a = action bit:  logp -= softplus(a ? -d : d)            d logp / dd = a - p
-//            H += softplus(d) - d p                                                                   dH / dd = -d p (1 - p)
-//            KL(old || new) += p_o (logp_o1 - logp_n1) + (1 - p_o)(logp_o0 - logp_n0)                dKL / dd = p - p_o
-//   mouse:   u = S ndtri((x - low) / (high - low)), z = (u - mean) / std  (mean, log_std clamped; the clamp gates the gradient)
-//            logp += N(mean, std).logpdf(u) - N(0, S).logpdf(u) - log(high - low)                    d/dmean = z / std, d/dlog_std = z^2 - 1
-//            H  += log(high - low) - (log S - log_std + (std^2 + mean^2) / (2 S^2) - 1/2)
-//            KL += log_std - log_std_o + (std_o^2 + (mean_o - mean)^2) / (2 std^2) - 1/2
-//   ratio = exp(logp - logp_old), surrogate = min(adv ratio, adv clip(ratio, 1 -+ c))              d/dlogp = adv ratio if adv ratio <= adv clip(..)
-//   vf = max((v - vt)^2, (v_old + clip(v - v_old, +-vc) - vt)^2)
-//   total = mean(-surrogate + kl_coeff KL + vf_coeff vf - ent_coeff H);  dlogits / dvalue are d total / d(logits, value).
-// partials[block][5] = sums of (entropy, kl, -surrogate, total, vf) over the block's samples (no atomics; add them up and divide by B).
-__global__ void __launch_bounds__(256)
-ppo_loss_grad_kernel(Params p, int batch, const float* __restrict__ logits, const float* __restrict__ old_logits, int row_stride,
-                     const uint8_t* __restrict__ keys, const float* __restrict__ mouse, const float* __restrict__ logp_old,
-                     const float* __restrict__ adv, const float* __restrict__ value, const float* __restrict__ value_old,
-                     const float* __restrict__ vtarg, float clip, float vf_clip, float vf_coeff, float ent_coeff,
-                     const float* __restrict__ kl_coeff_dev, float* __restrict__ dlogits, float* __restrict__ dvalue,
-                     float* __restrict__ partials) {
-    __shared__ float red[4][5];
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    const bool live = i < (uint32_t)batch;
-    const float klc = *kl_coeff_dev;
-    const float inv_b = 1.0f / (float)batch;
-    float st[5] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
-    if (live) {
-        const float* row = logits + (size_t)i * row_stride;
-        const float* old = old_logits + (size_t)i * row_stride;
-        float* g = dlogits + (size_t)i * row_stride;
-        const int nk = p.num_keys;
-        const uint32_t kb = keys[i];
-        float logp = 0.0f, ent = 0.0f, kl = 0.0f;
-        float dlp[4], dh[4], dk[4];
-        auto softplus = [](float z) { return (z > 0.0f ? z : 0.0f) + log1pf(expf(-fabsf(z))); };
-        for (int k = 0; k < 4; ++k) {
-            if (k >= nk) break;
-            const float d = row[2 * k + 1] - row[2 * k], d_o = old[2 * k + 1] - old[2 * k];
-            const float pn = 1.0f / (1.0f + expf(-d)), po = 1.0f / (1.0f + expf(-d_o));
-            const float a = (float)((kb >> k) & 1u);
-            const float sp_pos = softplus(d), sp_neg = softplus(-d);            // -log p(0), -log p(1)
-            logp -= a != 0.0f ? sp_neg : sp_pos;
-            ent += sp_pos - d * pn;
-            kl += po * (sp_neg - softplus(-d_o)) + (1.0f - po) * (sp_pos - softplus(d_o));
-            dlp[k] = a - pn; dh[k] = -d * pn * (1.0f - pn); dk[k] = pn - po;
-        }
-        float dlp_m = 0.0f, dlp_s = 0.0f, dh_m = 0.0f, dh_s = 0.0f, dk_m = 0.0f, dk_s = 0.0f;
-        bool in_m = false, in_s = false;
-        // discrete mouse: Categorical over M = 2S+1 logits (see sample_categorical):
-        //   logp += l_a - lse;  H_c = -sum p_j log p_j;  KL_c = sum po_j (log po_j - log p_j)
-        //   d logp / d l_j = [j == a] - p_j;  d H_c / d l_j = -p_j (log p_j + H_c);  d KL_c / d l_j = p_j - po_j
-        const int cat_m = p.yaw_mode == 2 ? 2 * (int)p.yaw_steps + 1 : 0;
-        float cat_lse = 0.0f, cat_lse_o = 0.0f, cat_h = 0.0f;
-        int cat_a = 0;
-        if (p.yaw_mode == 2) {
-            const float* l = row + 2 * nk;
-            const float* lo = old + 2 * nk;
-            float mx = l[0], mxo = lo[0];
-            for (int j = 1; j < cat_m; ++j) { mx = fmaxf(mx, l[j]); mxo = fmaxf(mxo, lo[j]); }
-            float sn = 0.0f, so = 0.0f;
-            for (int j = 0; j < cat_m; ++j) { sn += expf(l[j] - mx); so += expf(lo[j] - mxo); }
-            cat_lse = mx + logf(sn);
-            cat_lse_o = mxo + logf(so);
-            cat_a = min(max((int)mouse[i], 0), cat_m - 1);
-            logp += l[cat_a] - cat_lse;
-            float kc = 0.0f;
-            for (int j = 0; j < cat_m; ++j) {
-                const float lpn = l[j] - cat_lse, lpo = lo[j] - cat_lse_o;
-                cat_h -= expf(lpn) * lpn;
-                kc += expf(lpo) * (lpo - lpn);
-            }
-            ent += cat_h;
-            kl += kc;
-        }
-        if (p.yaw_mode == 1) {
-            const float S = SQUASH_SCALE, low = -p.action_range_f32, high = p.action_range_f32;
-            const float m_raw = row[2 * nk], s_raw = row[2 * nk + 1];
-            in_m = m_raw >= -3.0f && m_raw <= 3.0f;
-            in_s = s_raw >= -20.0f && s_raw <= 2.0f;
-            const float mean = fminf(fmaxf(m_raw, -3.0f), 3.0f), ls = fminf(fmaxf(s_raw, -20.0f), 2.0f);
-            const float mean_o = fminf(fmaxf(old[2 * nk], -3.0f), 3.0f), ls_o = fminf(fmaxf(old[2 * nk + 1], -20.0f), 2.0f);
-            const float inv_std = expf(-ls), std = expf(ls), std_o = expf(ls_o);
-            const float u = S * normcdfinvf((mouse[i] - low) / (high - low));
-            const float z = (u - mean) * inv_std, zq = u / S;
-            logp += (-0.5f * z * z - ls - 0.9189385332046727f) - ((-0.5f * zq * zq - LOG_SQUASH_SCALE - 0.9189385332046727f) + p.log_range_f32);
-            dlp_m = z * inv_std; dlp_s = z * z - 1.0f;
-            ent += p.log_range_f32 - (LOG_SQUASH_SCALE - ls + (std * std + mean * mean) / (2.0f * S * S) - 0.5f);
-            dh_m = -mean / (S * S); dh_s = 1.0f - std * std / (S * S);
-            const float dm = mean_o - mean, q = (std_o * std_o + dm * dm) * inv_std * inv_std;
-            kl += ls - ls_o + 0.5f * q - 0.5f;
-            dk_m = -dm * inv_std * inv_std; dk_s = 1.0f - q;
-        }
-        const float ratio = expf(logp - logp_old[i]), ad = adv[i];
-        const float s1 = ad * ratio, s2 = ad * fminf(fmaxf(ratio, 1.0f - clip), 1.0f + clip);
-        const float surr = fminf(s1, s2);
-        const float c_lp = s1 <= s2 ? -s1 : 0.0f;                                    // d(-surrogate) / dlogp
-        const float v = value[i], vo = value_old[i], vt = vtarg[i];
-        const float dv = v - vo, vc = vo + fminf(fmaxf(dv, -vf_clip), vf_clip);
-        const float e1 = (v - vt) * (v - vt), e2 = (vc - vt) * (vc - vt);
-        const float vf = fmaxf(e1, e2);
-        const float dvf = e1 >= e2 ? 2.0f * (v - vt) : ((dv >= -vf_clip && dv <= vf_clip) ? 2.0f * (vc - vt) : 0.0f);
-        for (int k = 0; k < 4; ++k) {
-            if (k >= nk) break;
-            const float gd = (c_lp * dlp[k] + klc * dk[k] - ent_coeff * dh[k]) * inv_b;
-            g[2 * k] = -gd; g[2 * k + 1] = gd;
-        }
-        if (p.yaw_mode == 1) {
-            g[2 * nk] = in_m ? (c_lp * dlp_m + klc * dk_m - ent_coeff * dh_m) * inv_b : 0.0f;
-            g[2 * nk + 1] = in_s ? (c_lp * dlp_s + klc * dk_s - ent_coeff * dh_s) * inv_b : 0.0f;
-        }
-        if (p.yaw_mode == 2) {
-            const float* l = row + 2 * nk;
-            const float* lo = old + 2 * nk;
-            for (int j = 0; j < cat_m; ++j) {
-                const float lpn = l[j] - cat_lse, pn = expf(lpn), po = expf(lo[j] - cat_lse_o);
-                const float dlp_j = (j == cat_a ? 1.0f : 0.0f) - pn, dh_j = -pn * (lpn + cat_h), dk_j = pn - po;
-                g[2 * nk + j] = (c_lp * dlp_j + klc * dk_j - ent_coeff * dh_j) * inv_b;
-            }
-        }
-        for (int c = 2 * nk + (p.yaw_mode == 1 ? 2 : cat_m); c < row_stride; ++c) g[c] = 0.0f;
-        dvalue[i] = vf_coeff * dvf * inv_b;
-        st[0] = ent; st[1] = kl; st[2] = -surr; st[3] = -surr + klc * kl + vf_coeff * vf - ent_coeff * ent; st[4] = vf;
-    }
-#pragma unroll
-    for (int k = 0; k < 5; ++k)
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) st[k] += __shfl_down(st[k], off, 64);
-    if ((threadIdx.x & 63u) == 0) {
-#pragma unroll
-        for (int k = 0; k < 5; ++k) red[threadIdx.x >> 6][k] = st[k];
-    }
-    __syncthreads();
-    if (threadIdx.x < 5) partials[(size_t)blockIdx.x * 5 + threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
 }
 
 __global__ void __launch_bounds__(256)
@@ -275,9 +140,9 @@ int q1env_ppo_loss_grad(q1env_t* h, int64_t batch, const float* logits, const fl
     if (h->p.yaw_mode != 0 && !mouse) return fail(Q1ENV_ERR_INVALID_ARG, "q1env_ppo_loss_grad: mouse actions required");
     if (row_stride < policy_row_width(h->p)) return fail(Q1ENV_ERR_INVALID_ARG, "q1env_ppo_loss_grad: row_stride too small");
     DeviceGuard guard(h->device);
-    hipLaunchKernelGGL(ppo_loss_grad_kernel, grid_for((int)batch, 256), dim3(256), 0, h->stream, h->p, (int)batch, logits, old_logits,
-                       row_stride, keys, mouse, logp_old, adv, value, value_old, vtarg, clip_param, vf_clip_param, vf_loss_coeff,
-                       entropy_coeff, kl_coeff_dev, dlogits, dvalue, partials);
+    hipLaunchKernelGGL(ppo_loss_grad_kernel<false>, grid_for((int)batch, 256), dim3(256), 0, h->stream, h->p, (int)batch, logits, old_logits,
+                       row_stride, row_stride, keys, mouse, logp_old, adv, value, value_old, vtarg, (const int64_t*)nullptr, clip_param,
+                       vf_clip_param, vf_loss_coeff, entropy_coeff, kl_coeff_dev, 1.0f, dlogits, dvalue, partials);
     HIP_TRY(hipGetLastError());
     return Q1ENV_OK;
 }

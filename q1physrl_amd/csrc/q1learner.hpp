@@ -1,0 +1,449 @@
+// q1learner.hpp - the native PPO learner step of libq1env (device code): forward, backward and weight gradients of the policy and the
+// value network of the reference's shape (RLlib fcnet of train.py:60-64 / params.yml: obs 6 -> 256 tanh -> 256 tanh -> OUT, two
+// separate networks) on the gfx950 matrix cores - float16 operands, float32 accumulation, master weights and the optimizer float32.
+// Counterpart of the torch modules + autograd of q1physrl_amd/ppo.py; included by q1env_learner.hip.
+//
+// One SGD step on a minibatch of B samples is five launches (+ the optimizer):
+//   learner_forward_kernel    gathers the minibatch's observations through idx, runs both networks exactly like the sampler's
+//                             q1pol::mlp_forward_kernel (same mlp_tile: bit-identical outputs) and additionally stores tanh(H1), tanh(H2)
+//                             as float16 "T-format" tiles (lane = sample, registers = hidden units: the next layer's B operands as is)
+//   ppo_loss_grad_kernel      (q1env_policy.hip) d loss / d(logits, value) per sample, closed form, gathered through the same idx
+//   learner_backward_kernel   dH2 = W3^T dY, dZ2 = dH2 (1 - h2^2), dH1 = W2^T dZ2, dZ1 = dH1 (1 - h1^2) per 32-sample tile with the
+//                             TRANSPOSED weight images in LDS, then transposes dZ2, dZ1, h1, h2 to "N-format" (lane = hidden unit,
+//                             registers = samples) with two identity-operand MFMAs per 32x32 tile and stores them
+//   learner_wgrad_kernel      dW2 = dZ2^T h1, dW3 = dY^T h2, dW1 = dZ1^T x and the three bias gradients as matrix products whose
+//                             contraction runs over the SAMPLES (N-format operands, split over workgroups); partial sums per workgroup
+//   learner_reduce_kernel     sums the partials, undoes the tile permutation, scales and writes the gradients in torch layout
+//   learner_images_kernel     (after the optimizer) rebuilds the float16 weight images of both directions from the float32 masters
+//
+// Why two activation formats: a 32x32x16 MFMA contracts the index its operands hold eight-at-a-time per lane.  The forward and the
+// data-gradient chain contract over hidden units (the C/D layout of one layer - lane = sample - is already the next B operand), the
+// weight gradients contract over samples, so every activation is needed once with lane = sample and once with lane = unit.  The
+// transposition costs two MFMAs per 32x32 tile: D = A E with E a 0/1 selection matrix delivers A^T in the C/D layout, exactly (float16
+// values times 1.0, float32 accumulation).
+//
+// T-format (per network, per layer): f16x8[tile][t = 0..7][u = 0..1][lane 64]; element e of lane (c, h) = hidden unit
+//          32 t + 16 u + (e & 3) + 8 (e >> 2) + 4 h of sample 32 tile + c (the B operand of K-step 2 t + u, see q1policy.hpp).
+// N-format (per network, per array): f16x8[tile][t = 0..7][ks = 0..1][lane 64]; lane (c, h) = hidden unit 32 t + sigma(c), sigma = swap
+//          bits 2 and 3; element e = sample 32 tile + (e & 3) + 16 ks + 8 (e >> 2) + 4 h.  Both MFMA operands of a weight-gradient
+//          product use the same sample order, so it never has to be undone; sigma is undone by learner_reduce_kernel.
+// Gradient scaling: d loss / d(logits, value) arrive multiplied by `grad_scale` (= B: the per-sample, un-averaged gradient) so that they
+// sit in float16's normal range; learner_reduce_kernel divides the sums by it again.
+#pragma once
+#include "q1policy.hpp"
+
+namespace q1learn {
+
+using q1pol::f16x8;
+using q1pol::f32x16;
+using q1pol::HID;
+using q1pol::OBS;
+using q1pol::ROW_BYTES;
+
+constexpr uint32_t TILE_VECS = 8u * 2u * 64u;                 // f16x8 vectors of one activation array of one 32-sample tile (16 KiB)
+constexpr int W3T_ROW_BYTES = 32 * 2 + 16;                    // row of the W3^T image: 32 outputs (K) + 16 B pad
+constexpr size_t LDS_W2T = (size_t)HID * ROW_BYTES;           // 135168
+constexpr size_t LDS_W3T = (size_t)HID * W3T_ROW_BYTES;       // 20480
+constexpr size_t LDS_BWD = LDS_W2T + LDS_W3T;                 // 155648 <= 163840
+
+// weight-gradient products of one network, 32x32 float32 tiles: [p][reg 16][lane 64]
+//   p = 8 jt + kt   dW2 tile (rows: units of dZ2 tile jt, cols: units of h1 tile kt)          0 .. 63
+//   p = 64 + jt     dZ2 tile jt x [x | 1]: column 6 = db2                                      64 .. 71
+//   p = 72 + kt     dZ1 tile kt x [x | 1]: columns 0..5 = dW1, column 6 = db1                  72 .. 79
+//   p = 80 + jt     dY x h2 tile jt: rows = outputs, cols = units -> dW3                       80 .. 87
+//   p = 88          dY x [x | 1]: column 6 = db3
+constexpr int WG_PRODUCTS = 89;
+constexpr size_t PARTIAL_FLOATS = (size_t)WG_PRODUCTS * 1024u;
+
+__device__ __forceinline__ uint32_t sigma(uint32_t c) { return (c & ~0xCu) | ((c & 4u) << 1) | ((c & 8u) >> 1); }   // swap bits 2 and 3
+
+__device__ __forceinline__ f16x8 cvt8(const f32x16& a, int u) {
+    union { f16x8 v; q1pol::f16x2 p[4]; } o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const q1pol::f32x2 t = {a[8 * u + 2 * j], a[8 * u + 2 * j + 1]};
+        o.p[j] = __builtin_convertvector(t, q1pol::f16x2);
+    }
+    return o.v;
+}
+
+// ------------------------------------------------------------------------------------------------------------------ forward
+struct FwdNet {
+    const float* w1; const float* b1; const uint16_t* w23; const float* b2; const float* b3;
+    float* out; int out_dim;
+    f16x8* h1T; f16x8* h2T;
+};
+
+// The sampler's forward kernel (q1pol::mlp_forward_kernel<512>) with a gather in front and the activation stores inside; outputs are
+// bit-identical to q1env_policy_value_forward on the gathered rows.
+__global__ void __launch_bounds__(512, 1)
+learner_forward_kernel(int n, const float* __restrict__ obs, const int64_t* __restrict__ idx, FwdNet net_a, FwdNet net_b, int nets) {
+    using namespace q1pol;
+    const uint32_t bgrid = nets == 2 ? gridDim.x / 2u : gridDim.x;
+    const bool second = nets == 2 && blockIdx.x >= bgrid;
+    const uint32_t bid = second ? blockIdx.x - bgrid : blockIdx.x;
+    const FwdNet net = second ? net_b : net_a;
+    const float* __restrict__ b3 = net.b3;
+    float* __restrict__ out = net.out;
+    const int OUT = net.out_dim;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    unsigned char* l_w2 = lds;
+    unsigned char* l_w3 = lds + LDS_W2;
+    float* l_b2 = reinterpret_cast<float*>(lds + LDS_W2 + LDS_W3);
+    unsigned char* l_w1 = lds + LDS_W2 + LDS_W3 + LDS_B2;
+    const uint32_t tid = threadIdx.x;
+    stage_image<512>(lds, net.w23, tid);
+    if (tid < (uint32_t)HID) {
+        l_b2[tid] = TANH_PRESCALE * net.b2[tid];
+        stage_w1_row(l_w1, tid, net.w1, net.b1);
+    }
+    const uint32_t lane = tid & 63u, wave = tid >> 6;
+    const uint32_t col = lane & 31u, half = lane >> 5;
+    __syncthreads();
+    const uint32_t ntiles = ((uint32_t)n + 31u) / 32u;
+    const uint32_t tstride = bgrid * 8u;
+    const unsigned char* w1row = l_w1 + (size_t)col * 32u + half * 16u;
+    const unsigned char* wrow = l_w2 + (size_t)col * ROW_BYTES + half * 16u;
+    const unsigned char* w3row = l_w3 + (size_t)col * ROW_BYTES + half * 16u;
+    for (uint32_t tile = bid * 8u + wave; tile < ntiles; tile += tstride) {
+        const uint32_t s = tile * 32u + col;
+        const bool live = s < (uint32_t)n;
+        float x[3];
+        {
+            const size_t src = live ? (idx ? (size_t)idx[s] : (size_t)s) : 0;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) x[k] = live ? obs[src * OBS + 2u * k + half] : 0.0f;
+        }
+        const f16x8 xb = split_inputs(x, half);
+        f16x8* h1 = net.h1T + (size_t)tile * TILE_VECS + lane;
+        f16x8* h2 = net.h2T + (size_t)tile * TILE_VECS + lane;
+        const f32x16 y = mlp_tile_t<true>(xb, w1row, wrow, w3row, l_b2, half, nullptr, h1, h2);
+        if (live) {
+            float* dst = out + (size_t)s * (uint32_t)OUT;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                if (8 * g < OUT) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int row = r + 8 * g + 4 * (int)half;
+                        if (row < OUT) dst[row] = y[4 * g + r] + b3[row];
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------ backward
+struct BwdNet {
+    const uint16_t* w2t;      // float16[256][264]: row k = W2[perm(p)][k], the forward image's column permutation applied to the K index j
+    const uint16_t* w3t;      // float16[256][40]:  row j = W3[o][j], o = 0..31 (zero beyond out_dim), natural order
+    const float* dy;          // float[n][dy_stride]: d loss / d output x grad_scale (dlogits rows, or dvalue with stride 1)
+    int dy_stride; int out_dim;
+    const f16x8* h1T; const f16x8* h2T;
+    f16x8* dz2N; f16x8* dz1N; f16x8* h1N; f16x8* h2N;
+};
+
+// 32x32 transposition on the matrix pipe: x0 / x1 = the T-format vectors (u = 0 / 1) of one 32-unit tile; returns the tile with
+// lane = unit sigma(c), registers = samples, as float32 (exact), to be packed with cvt8.
+__device__ __forceinline__ f32x16 transpose_tile(const f16x8 x0, const f16x8 x1, const f16x8 e0, const f16x8 e1) {
+    const f32x16 zero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    f32x16 d = __builtin_amdgcn_mfma_f32_32x32x16_f16(x0, e0, zero16, 0, 0, 0);
+    d = __builtin_amdgcn_mfma_f32_32x32x16_f16(x1, e1, d, 0, 0, 0);
+    return d;
+}
+
+__device__ __forceinline__ void store_n(f16x8* dstN, uint32_t t, const f32x16& d) {      // dstN already points at (tile, lane)
+    dstN[(2u * t) * 64u] = cvt8(d, 0);
+    dstN[(2u * t + 1u) * 64u] = cvt8(d, 1);
+}
+
+// acc (float32, C/D layout) *= 1 - h^2 with h the matching T-format vectors; returns nothing, acc updated in place
+__device__ __forceinline__ void times_dtanh(f32x16& acc, const f16x8 h0, const f16x8 h1) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const float a = (float)h0[e], b = (float)h1[e];
+        acc[e] *= 1.0f - a * a;
+        acc[8 + e] *= 1.0f - b * b;
+    }
+}
+
+__global__ void __launch_bounds__(256, 1)
+learner_backward_kernel(int n, BwdNet net_a, BwdNet net_b, int nets) {
+    const uint32_t bgrid = nets == 2 ? gridDim.x / 2u : gridDim.x;
+    const bool second = nets == 2 && blockIdx.x >= bgrid;
+    const uint32_t bid = second ? blockIdx.x - bgrid : blockIdx.x;
+    const BwdNet net = second ? net_b : net_a;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    unsigned char* l_w2t = lds;
+    unsigned char* l_w3t = lds + LDS_W2T;
+    const uint32_t tid = threadIdx.x;
+    {   // stage both images: straight 16-byte copies (135168 + 20480 bytes)
+        const uint4* s2 = reinterpret_cast<const uint4*>(net.w2t);
+        uint4* d2 = reinterpret_cast<uint4*>(l_w2t);
+        for (uint32_t v = tid; v < (uint32_t)(LDS_W2T / 16); v += 256u) d2[v] = s2[v];
+        const uint4* s3 = reinterpret_cast<const uint4*>(net.w3t);
+        uint4* d3 = reinterpret_cast<uint4*>(l_w3t);
+        for (uint32_t v = tid; v < (uint32_t)(LDS_W3T / 16); v += 256u) d3[v] = s3[v];
+    }
+    const uint32_t lane = tid & 63u, wave = tid >> 6;
+    const uint32_t col = lane & 31u, half = lane >> 5;
+    __syncthreads();
+    // selection operands of the transposition: E0[K][c] = [K == c], E1[K][c] = [K == c - 16]; a lane (c, h) holds K = 8 h + e
+    f16x8 e0, e1;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        e0[e] = (8u * half + (uint32_t)e == col) ? (_Float16)1.0f : (_Float16)0.0f;
+        e1[e] = (8u * half + (uint32_t)e + 16u == col) ? (_Float16)1.0f : (_Float16)0.0f;
+    }
+    const f32x16 zero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    const int OUT = net.out_dim;
+    const uint32_t ntiles = ((uint32_t)n + 31u) / 32u;
+    const uint32_t tstride = bgrid * 4u;
+    const unsigned char* w2trow = l_w2t + (size_t)col * ROW_BYTES + half * 16u;           // + 32 t1 rows, + K-step q * 32 B
+    const unsigned char* w3trow = l_w3t + (size_t)col * W3T_ROW_BYTES + half * 16u;       // + 32 t2 rows, + ks * 32 B
+    for (uint32_t tile = bid * 4u + wave; tile < ntiles; tile += tstride) {
+        const uint32_t s = tile * 32u + col;
+        const bool live = s < (uint32_t)n;
+        // ---- dY as B operand(s): K = output index o = 16 ks + 8 h + e
+        f16x8 dyb0, dyb1;
+        {
+            const float* row = net.dy + (size_t)(live ? s : 0) * (uint32_t)net.dy_stride;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int o0 = 8 * (int)half + e, o1 = 16 + o0;
+                // (saturating: a per-sample gradient beyond float16's 65504 - a value error of tens of thousands - must not become inf)
+                dyb0[e] = (_Float16)fminf(fmaxf((live && o0 < OUT) ? row[o0] : 0.0f, -65504.0f), 65504.0f);
+                dyb1[e] = (_Float16)fminf(fmaxf((live && o1 < OUT) ? row[o1] : 0.0f, -65504.0f), 65504.0f);
+            }
+        }
+        const size_t tbase = (size_t)tile * TILE_VECS + lane;
+        // ---- dH2^T = W3^T dY^T, dZ2 = dH2 (1 - h2^2); h2 and dZ2 leave in N-format
+        f16x8 dzb[8][2];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const f16x8 a0 = *reinterpret_cast<const f16x8*>(w3trow + (size_t)t * 32u * W3T_ROW_BYTES);
+            f32x16 acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, dyb0, zero16, 0, 0, 0);
+            if (OUT > 16) {
+                const f16x8 a1 = *reinterpret_cast<const f16x8*>(w3trow + (size_t)t * 32u * W3T_ROW_BYTES + 32u);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, dyb1, acc, 0, 0, 0);
+            }
+            const f16x8 h0 = net.h2T[tbase + (2u * t) * 64u], h1 = net.h2T[tbase + (2u * t + 1u) * 64u];
+            times_dtanh(acc, h0, h1);
+            dzb[t][0] = cvt8(acc, 0);
+            dzb[t][1] = cvt8(acc, 1);
+            store_n(net.h2N + tbase, (uint32_t)t, transpose_tile(h0, h1, e0, e1));
+            store_n(net.dz2N + tbase, (uint32_t)t, transpose_tile(dzb[t][0], dzb[t][1], e0, e1));
+            __builtin_amdgcn_sched_barrier(0);       // one row tile at a time: keeps 16 float32 + a few operand registers live, not 8 x that
+        }
+        // ---- dH1^T = W2^T dZ2^T: 16 K-steps (j) x 8 row tiles (k)
+        f32x16 acc1[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) acc1[t] = zero16;
+        {
+            f16x8 a[8];
+#pragma unroll
+            for (int t = 0; t < 8; ++t) a[t] = *reinterpret_cast<const f16x8*>(w2trow + (size_t)t * 32u * ROW_BYTES);
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                // every W2^T operand register is re-requested for the next K-step right after the MFMA that consumed it was issued
+                // (operands are read at issue), i.e. eight MFMAs ahead of its next use - the forward kernel's pipeline
+#pragma unroll
+                for (int t = 0; t < 8; ++t) {
+                    acc1[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[t], dzb[q >> 1][q & 1], acc1[t], 0, 0, 0);
+                    if (q < 15) a[t] = *reinterpret_cast<const f16x8*>(w2trow + (size_t)t * 32u * ROW_BYTES + (uint32_t)(q + 1) * 32u);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        // ---- dZ1 = dH1 (1 - h1^2); h1 and dZ1 leave in N-format
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const f16x8 h0 = net.h1T[tbase + (2u * t) * 64u], h1 = net.h1T[tbase + (2u * t + 1u) * 64u];
+            times_dtanh(acc1[t], h0, h1);
+            const f16x8 z0 = cvt8(acc1[t], 0), z1 = cvt8(acc1[t], 1);
+            store_n(net.h1N + tbase, (uint32_t)t, transpose_tile(h0, h1, e0, e1));
+            store_n(net.dz1N + tbase, (uint32_t)t, transpose_tile(z0, z1, e0, e1));
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------ weight gradients
+struct WgNet {
+    const f16x8* dz2N; const f16x8* dz1N; const f16x8* h1N; const f16x8* h2N;
+    const float* dy; int dy_stride; int out_dim;
+    float* partial;           // float[splits][PARTIAL_FLOATS]
+};
+
+// One workgroup = eight waves = the eight 32-unit row tiles of the gradient side; it owns a contiguous range of sample tiles (split-K
+// over workgroups, blockIdx.x) and one half of the products (blockIdx.y): y = 0 the dW2 column tiles 0..3 + the [x | 1] products
+// (dW1, db1, db2), y = 1 the column tiles 4..7 + the dY products (dW3, db3) - six float32 accumulator tiles per wave, so two
+// workgroups fit a CU.  It leaves its float32 partial sums in its split's slot.
+__global__ void __launch_bounds__(512, 1)
+learner_wgrad_kernel(int n, const float* __restrict__ obs, const int64_t* __restrict__ idx, WgNet net_a, WgNet net_b, int splits) {
+    const bool second = blockIdx.x >= (uint32_t)splits;
+    const uint32_t split = second ? blockIdx.x - (uint32_t)splits : blockIdx.x;
+    const uint32_t khalf = blockIdx.y;
+    const WgNet net = second ? net_b : net_a;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, w = tid >> 6;
+    const uint32_t col = lane & 31u, half = lane >> 5;
+    const int OUT = net.out_dim;
+    const uint32_t ntiles = ((uint32_t)n + 31u) / 32u;
+    const uint32_t per = (ntiles + (uint32_t)splits - 1u) / (uint32_t)splits;
+    const uint32_t t_begin = split * per, t_end = min(t_begin + per, ntiles);
+    const f32x16 zero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    f32x16 aW2[4], aX = zero16, aY = zero16;          // y = 0: aX = dZ2 x [x|1], aY = dZ1 x [x|1];  y = 1: aX = dY x h2, aY = dY x [x|1] (wave 0)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) aW2[k] = zero16;
+    for (uint32_t tile = t_begin; tile < t_end; ++tile) {
+        const size_t tb = (size_t)tile * TILE_VECS + lane;
+        f16x8 a2[2], x1[2];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            a2[ks] = net.dz2N[tb + (2u * w + (uint32_t)ks) * 64u];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const uint32_t s = tile * 32u + (uint32_t)(e & 3) + 16u * (uint32_t)ks + 8u * (uint32_t)(e >> 2) + 4u * half;
+                float xv = 0.0f;
+                if (s < (uint32_t)n) {
+                    if (col < (uint32_t)OBS) xv = obs[(idx ? (size_t)idx[s] : (size_t)s) * OBS + col];
+                    else if (col == (uint32_t)OBS) xv = 1.0f;
+                }
+                x1[ks][e] = (_Float16)xv;
+            }
+        }
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const f16x8 b = net.h1N[tb + (2u * (4u * khalf + (uint32_t)kt) + (uint32_t)ks) * 64u];
+                aW2[kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a2[ks], b, aW2[kt], 0, 0, 0);
+            }
+        }
+        if (khalf == 0) {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const f16x8 a1 = net.dz1N[tb + (2u * w + (uint32_t)ks) * 64u];
+                aX = __builtin_amdgcn_mfma_f32_32x32x16_f16(a2[ks], x1[ks], aX, 0, 0, 0);
+                aY = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, x1[ks], aY, 0, 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                f16x8 dya;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const uint32_t s = tile * 32u + (uint32_t)(e & 3) + 16u * (uint32_t)ks + 8u * (uint32_t)(e >> 2) + 4u * half;
+                    dya[e] = (_Float16)fminf(fmaxf((s < (uint32_t)n && (int)col < OUT) ? net.dy[(size_t)s * (uint32_t)net.dy_stride + col] : 0.0f, -65504.0f), 65504.0f);
+                }
+                const f16x8 bh2 = net.h2N[tb + (2u * w + (uint32_t)ks) * 64u];
+                aX = __builtin_amdgcn_mfma_f32_32x32x16_f16(dya, bh2, aX, 0, 0, 0);
+                if (w == 0) aY = __builtin_amdgcn_mfma_f32_32x32x16_f16(dya, x1[ks], aY, 0, 0, 0);
+            }
+        }
+    }
+    float* out = net.partial + (size_t)split * PARTIAL_FLOATS;
+    auto put = [&](uint32_t p, const f32x16& a) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) out[((size_t)p * 16u + (uint32_t)r) * 64u + lane] = a[r];
+    };
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) put(8u * w + 4u * khalf + (uint32_t)kt, aW2[kt]);
+    if (khalf == 0) {
+        put(64u + w, aX);
+        put(72u + w, aY);
+    } else {
+        put(80u + w, aX);
+        if (w == 0) put(88u, aY);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------ reduction
+struct Grads {
+    float* w1; float* b1; float* w2; float* b2; float* w3; float* b3;      // torch layouts: [256][6], [256], [256][256], [256], [out][256], [out]
+    int out_dim;
+};
+
+// value of product p at (A-lane index ia, B-lane index cb), summed over the splits
+__device__ __forceinline__ float partial_sum(const float* __restrict__ partial, int splits, uint32_t p, uint32_t ia, uint32_t cb) {
+    const uint32_t h = (ia >> 2) & 1u, r = (ia & 3u) + 4u * (ia >> 3);
+    const size_t off = ((size_t)p * 16u + r) * 64u + cb + 32u * h;
+    float s = 0.0f;
+    for (int k = 0; k < splits; ++k) s += partial[(size_t)k * PARTIAL_FLOATS + off];
+    return s;
+}
+
+__global__ void __launch_bounds__(256)
+learner_reduce_kernel(const float* __restrict__ pa, const float* __restrict__ pb, Grads ga, Grads gb, int splits, float inv_scale) {
+    const bool second = blockIdx.y == 1;
+    const float* __restrict__ partial = second ? pb : pa;
+    const Grads g = second ? gb : ga;
+    const uint32_t OUT = (uint32_t)g.out_dim;
+    const uint32_t nW2 = 65536u, nB2 = 256u, nW1 = 256u * (uint32_t)OBS, nB1 = 256u, nW3 = OUT * 256u, nB3 = OUT;
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < nW2) {
+        const uint32_t j = i >> 8, k = i & 255u;
+        g.w2[i] = inv_scale * partial_sum(partial, splits, 8u * (j >> 5) + (k >> 5), sigma(j & 31u), sigma(k & 31u));
+        return;
+    }
+    i -= nW2;
+    if (i < nB2) { g.b2[i] = inv_scale * partial_sum(partial, splits, 64u + (i >> 5), sigma(i & 31u), (uint32_t)OBS); return; }
+    i -= nB2;
+    if (i < nW1) {
+        const uint32_t k = i / (uint32_t)OBS, c = i % (uint32_t)OBS;
+        g.w1[i] = inv_scale * partial_sum(partial, splits, 72u + (k >> 5), sigma(k & 31u), c);
+        return;
+    }
+    i -= nW1;
+    if (i < nB1) { g.b1[i] = inv_scale * partial_sum(partial, splits, 72u + (i >> 5), sigma(i & 31u), (uint32_t)OBS); return; }
+    i -= nB1;
+    if (i < nW3) {
+        const uint32_t o = i >> 8, j = i & 255u;
+        g.w3[i] = inv_scale * partial_sum(partial, splits, 80u + (j >> 5), o, sigma(j & 31u));
+        return;
+    }
+    i -= nW3;
+    if (i < nB3) g.b3[i] = inv_scale * partial_sum(partial, splits, 88u, i, (uint32_t)OBS);
+}
+
+// ------------------------------------------------------------------------------------------------------------------ weight images
+struct ImgNet {
+    const float* w2; const float* w3; int out_dim;       // float32 masters, torch layouts
+    uint16_t* w23;            // forward image float16[288][264] (q1policy.hpp): W2 x 2 log2 e, then W3, K index permuted
+    uint16_t* w2t;            // backward image float16[256][264]: W2^T, K index (j) permuted the same way
+    uint16_t* w3t;            // backward image float16[256][40]:  W3^T, natural order
+};
+
+__device__ __forceinline__ uint32_t kperm(uint32_t p) { return (p & ~0xCu) | ((p & 4u) << 1) | ((p & 8u) >> 1); }   // image column -> hidden index
+
+__global__ void __launch_bounds__(256)
+learner_images_kernel(ImgNet na, ImgNet nb) {
+    const ImgNet net = blockIdx.y == 1 ? nb : na;
+    const uint32_t OUT = (uint32_t)net.out_dim;
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t nF = 288u * 264u, nT2 = 256u * 264u, nT3 = 256u * 40u;
+    if (i < nF) {
+        const uint32_t row = i / 264u, p = i % 264u;
+        float v = 0.0f;
+        if (p < 256u) {
+            if (row < 256u) v = q1pol::TANH_PRESCALE * net.w2[row * 256u + kperm(p)];
+            else if (row - 256u < OUT) v = net.w3[(row - 256u) * 256u + kperm(p)];
+        }
+        net.w23[i] = q1pol::f16_bits(v);
+        return;
+    }
+    i -= nF;
+    if (i < nT2) {
+        const uint32_t k = i / 264u, p = i % 264u;
+        net.w2t[i] = q1pol::f16_bits(p < 256u ? net.w2[kperm(p) * 256u + k] : 0.0f);
+        return;
+    }
+    i -= nT2;
+    if (i < nT3) {
+        const uint32_t j = i / 40u, o = i % 40u;
+        net.w3t[i] = q1pol::f16_bits(o < OUT ? net.w3[o * 256u + j] : 0.0f);
+    }
+}
+
+}  // namespace q1learn

@@ -166,8 +166,12 @@ __device__ __forceinline__ void stage_net(unsigned char* lds, const float* __res
 // One 32-env tile through all three layers: xb = the lane's layer-1 B operand (split_inputs of its env's observation), the three
 // row pointers = this lane's operand rows in the LDS images (see the callers).  Returns Y^T without b3: y[r] = output row
 // (r&3) + 8(r>>2) + 4*half of env `col`.  (stamps: diagnostic build only - s_memtime after the prologue and after the main loop.)
-__device__ __forceinline__ f32x16 mlp_tile(const f16x8 xb, const unsigned char* w1row, const unsigned char* wrow, const unsigned char* w3row,
-                                           const float* l_b2, uint32_t half, uint64_t* stamps) {
+// STORE (the learner's forward, q1learner.hpp): the activations leave as they are consumed - h1_dst / h2_dst point at THIS lane's slot
+// of the tile's T-format arrays (f16x8 units; element (t, u) at [(2 t + u) * 64]): tanh(H1) / tanh(H2) as the very B operands the next
+// layer's MFMAs read, 32 fully coalesced 16-byte stores per layer and tile.
+template <bool STORE>
+__device__ __forceinline__ f32x16 mlp_tile_t(const f16x8 xb, const unsigned char* w1row, const unsigned char* wrow, const unsigned char* w3row,
+                                             const float* l_b2, uint32_t half, uint64_t* stamps, f16x8* h1_dst, f16x8* h2_dst) {
     const f32x16 zero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     f32x16 acc[8];                                               // H2^T pre-activations, start at b2
 #pragma unroll
@@ -198,6 +202,7 @@ __device__ __forceinline__ f32x16 mlp_tile(const f16x8 xb, const unsigned char* 
 #pragma unroll 1
     for (int t1 = 0; t1 < 8; ++t1) {
         const uint32_t q0 = 2u * (uint32_t)t1;
+        if constexpr (STORE) { h1_dst[(2 * t1) * 64] = cur0; h1_dst[(2 * t1 + 1) * 64] = cur1; }
         // phase 1: even K-step, first half of tanh(tile t1+1)
 #pragma unroll
         for (int t2 = 0; t2 < 8; ++t2) {
@@ -238,6 +243,7 @@ __device__ __forceinline__ f32x16 mlp_tile(const f16x8 xb, const unsigned char* 
 #pragma unroll
     for (int t2 = 0; t2 < 8; ++t2) {
         const f16x8 f0 = activate(acc[t2], 0), f1 = activate(acc[t2], 1);
+        if constexpr (STORE) { h2_dst[(2 * t2) * 64] = f0; h2_dst[(2 * t2 + 1) * 64] = f1; }
         y = __builtin_amdgcn_mfma_f32_32x32x16_f16(w3a, f0, y, 0, 0, 0);
         y = __builtin_amdgcn_mfma_f32_32x32x16_f16(w3b, f1, y, 0, 0, 0);
         if (t2 < 7) {
@@ -246,6 +252,11 @@ __device__ __forceinline__ f32x16 mlp_tile(const f16x8 xb, const unsigned char* 
         }
     }
     return y;
+}
+
+__device__ __forceinline__ f32x16 mlp_tile(const f16x8 xb, const unsigned char* w1row, const unsigned char* wrow, const unsigned char* w3row,
+                                           const float* l_b2, uint32_t half, uint64_t* stamps) {
+    return mlp_tile_t<false>(xb, w1row, wrow, w3row, l_b2, half, stamps, nullptr, nullptr);
 }
 
 // w1: float[HID][OBS] (torch Linear(6,256).weight), b1: float[HID], w23: the f16 LDS image of W2 (Linear(256,256).weight) and W3

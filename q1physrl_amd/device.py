@@ -214,6 +214,27 @@ class DeviceEnv:
                                                  adv, value, value_old, vtarg, float(clip_param), float(vf_clip_param),
                                                  float(vf_loss_coeff), float(entropy_coeff), kl_coeff_dev, dlogits, dvalue, partials))
 
+    # ---- native learner step (q1env_learner_*): nets are _lib.Q1LearnerNet, ws a device pointer of learner_workspace_bytes() bytes
+    def learner_workspace_bytes(self, minibatch, out_dim_pi, splits):
+        n = int(self._lib.q1env_learner_workspace_bytes(int(minibatch), int(out_dim_pi), int(splits)))
+        if n == 0:
+            raise _lib.Q1EnvError("q1env_learner_workspace_bytes: bad shape")
+        return n
+
+    def learner_images_dev(self, pi, vf, ws, minibatch, splits):
+        _lib.check(self._lib.q1env_learner_images(self._h, C.byref(pi), C.byref(vf), ws, int(minibatch), int(splits)))
+
+    def learner_forward_dev(self, pi, vf, ws, minibatch, splits, obs, idx=0, logits_out=0, value_out=0):
+        _lib.check(self._lib.q1env_learner_forward(self._h, C.byref(pi), C.byref(vf), ws, int(minibatch), int(splits), obs, idx or None,
+                                                   logits_out or None, value_out or None))
+
+    def learner_backward_dev(self, pi, vf, ws, minibatch, splits, obs, idx, dlogits, dvalue, grad_scale):
+        _lib.check(self._lib.q1env_learner_backward(self._h, C.byref(pi), C.byref(vf), ws, int(minibatch), int(splits), obs, idx or None,
+                                                    dlogits, dvalue, float(grad_scale)))
+
+    def learner_step_dev(self, pi, vf, ws, splits, batch):
+        _lib.check(self._lib.q1env_learner_step(self._h, C.byref(pi), C.byref(vf), ws, int(splits), C.byref(batch)))
+
     def sample_step_dev(self, logits, row_stride, seed, counter_dev, counter_offset, deterministic, keys, mouse, logp, obs, reward,
                         done, zero_start, ep_return, partials):
         """policy_sample + step_autoreset + episode_stats of one sampler tick in one launch (q1env_sample_step)."""

@@ -58,6 +58,69 @@ def allreduce_grads_(params, world):
         off += g.numel()
 
 
+class NativeStep:
+    """One PPO SGD step's forward + loss gradient + backward + weight gradients as the library's own gfx950 kernels
+    (q1env_learner_step: float16 matrix-core operands, float32 accumulation; include/q1env.h) on the float32 master weights of a
+    Q1Policy: after step() every parameter's .grad holds d mean-loss / d parameter (the tensors are allocated once and overwritten - do
+    not zero_grad(set_to_none=True)); the caller runs the optimizer and then images() to rebuild the kernels' float16 weight images.
+    The minibatch is rows idx of the FULL trajectory arrays (gathered inside the kernels, nothing is copied)."""
+
+    def __init__(self, policy, env, minibatch, splits=64):
+        from . import _lib
+        self.policy, self.env, self.mb, self.splits = policy, env, int(minibatch), int(splits)
+        self._lib = _lib
+        dev = next(policy.parameters()).device
+        for p in policy.parameters():
+            if p.grad is None:
+                p.grad = torch.zeros_like(p)
+        self.pi = self._net(policy.pi)
+        self.vf = self._net(policy.vf)
+        nbytes = env._dev.learner_workspace_bytes(self.mb, policy.pi[4].out_features, self.splits)
+        self.ws = torch.empty((nbytes,), dtype=torch.uint8, device=dev)
+        self.partials = torch.zeros(((self.mb + 255) // 256, len(STAT_KEYS)), dtype=torch.float32, device=dev)
+        self.images()
+
+    def _net(self, seq):
+        l1, l2, l3 = seq[0], seq[2], seq[4]
+        assert l1.in_features == 6 and l1.out_features == 256 and l2.in_features == 256 and l2.out_features == 256 and l3.in_features == 256
+        for l in (l1, l2, l3):
+            assert l.weight.is_contiguous() and l.weight.dtype == torch.float32 and l.weight.grad.is_contiguous()
+        return self._lib.Q1LearnerNet(l1.weight.data_ptr(), l1.bias.data_ptr(), l2.weight.data_ptr(), l2.bias.data_ptr(), l3.weight.data_ptr(),
+                                      l3.bias.data_ptr(), l1.weight.grad.data_ptr(), l1.bias.grad.data_ptr(), l2.weight.grad.data_ptr(),
+                                      l2.bias.grad.data_ptr(), l3.weight.grad.data_ptr(), l3.bias.grad.data_ptr(), l3.out_features)
+
+    def images(self):
+        self.env._dev.learner_images_dev(self.pi, self.vf, self.ws.data_ptr(), self.mb, self.splits)
+
+    def forward(self, obs, idx=None):
+        """logits (B, out) / value (B,) of rows idx of obs (float32 (total, 6)); bit-identical to FusedPolicyForward on those rows."""
+        out = self.policy.pi[4].out_features
+        logits = torch.empty((self.mb, out), dtype=torch.float32, device=obs.device)
+        value = torch.empty((self.mb,), dtype=torch.float32, device=obs.device)
+        self.env._dev.learner_forward_dev(self.pi, self.vf, self.ws.data_ptr(), self.mb, self.splits, obs.data_ptr(),
+                                          idx.data_ptr() if idx is not None else 0, logits.data_ptr(), value.data_ptr())
+        return logits, value
+
+    def backward(self, obs, idx, dlogits, dvalue, grad_scale):
+        """.grad of all parameters <- d(sum_i <dlogits_i, logits_i> + dvalue_i value_i) / grad_scale after a forward() on the same rows;
+        dlogits (B, out) / dvalue (B,) float32, already multiplied by grad_scale."""
+        self.env._dev.learner_backward_dev(self.pi, self.vf, self.ws.data_ptr(), self.mb, self.splits, obs.data_ptr(),
+                                           idx.data_ptr() if idx is not None else 0, dlogits.data_ptr(), dvalue.data_ptr(), grad_scale)
+
+    def step(self, full, idx, clip_param, vf_clip_param, vf_loss_coeff, entropy_coeff, klc_dev):
+        """full: dict of the whole trajectory batch (obs (total,6), old_logits (total,W), keys_packed, mouse, logp, adv, value, vtarg);
+        idx int64 (B,) or None.  Returns the statistics vector (STAT_KEYS order, means over the minibatch)."""
+        L = self._lib
+        ol = full["old_logits"]
+        assert ol.is_contiguous() and full["obs"].is_contiguous() and (idx is None or (idx.dtype == torch.int64 and idx.numel() == self.mb))
+        b = L.Q1LearnerBatch(self.mb, idx.data_ptr() if idx is not None else None, full["obs"].data_ptr(), ol.data_ptr(), ol.shape[1],
+                             full["keys_packed"].data_ptr(), full["mouse"].data_ptr(), full["logp"].data_ptr(), full["adv"].data_ptr(),
+                             full["value"].data_ptr(), full["vtarg"].data_ptr(), clip_param, vf_clip_param, vf_loss_coeff, entropy_coeff,
+                             klc_dev.data_ptr(), self.partials.data_ptr())
+        self.env._dev.learner_step_dev(self.pi, self.vf, self.ws.data_ptr(), self.splits, b)
+        return self.partials.sum(dim=0) / self.mb
+
+
 class PPOLearner:
     """SGD epochs over trajectory batches.
 
@@ -66,12 +129,15 @@ class PPOLearner:
     fused_loss:  the loss and its gradient w.r.t. (logits, value) come from ONE HIP kernel (q1env_ppo_loss_grad, closed-form
                  derivatives) instead of ~100 elementwise torch launches and their autograd twins; torch autograd only runs the
                  two MLPs.  Needs `env` (a TensorVectorEnv: its handle supplies num_keys / action_range and the stream).
+    native:      the WHOLE step up to the gradients - minibatch gather, both MLPs forward and backward, the loss gradient, the weight
+                 gradients - is the library's own gfx950 kernels (NativeStep / q1env_learner_step: float16 matrix-core operands,
+                 float32 accumulation and master weights); torch only runs the (fused) Adam.  Needs `env`; implies the fused loss.
     """
 
     def __init__(self, policy, action_range, lr=5e-6, gamma=0.99, lam=0.95, clip_param=0.3, vf_clip_param=100.0,
                  vf_loss_coeff=1.0, entropy_coeff=0.01, kl_coeff=0.2, kl_target=0.0036, num_sgd_iter=30,
                  minibatch_size=128, num_keys=4, seed=0, use_graph=False, fused_loss=False, env=None, discrete_yaw_steps=-1,
-                 allow_yaw=True, autocast_dtype=None, fused_adam=False):
+                 allow_yaw=True, autocast_dtype=None, fused_adam=False, native=False, native_splits=64):
         self.policy = policy
         self.action_range = float(action_range)
         self.gamma, self.lam = gamma, lam
@@ -83,8 +149,12 @@ class PPOLearner:
         self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
         self.use_graph = bool(use_graph) and self.world == 1
         self.fused_loss, self.env = bool(fused_loss), env
-        if self.fused_loss and env is None:
-            raise ValueError("fused_loss=True needs env= (the TensorVectorEnv whose handle runs q1env_ppo_loss_grad)")
+        self.native, self.native_splits = bool(native), int(native_splits)
+        if (self.fused_loss or self.native) and env is None:
+            raise ValueError("fused_loss=True / native=True need env= (the TensorVectorEnv whose handle runs the kernels)")
+        self._native = None
+        self._full = None
+        self._idx = None
         # autocast_dtype (e.g. torch.bfloat16): the two MLPs' matrix products run on reduced-precision operands with float32
         # accumulation (master weights, loss, its gradient and Adam stay float32); fused_adam: one multi-tensor Adam launch
         self.autocast_dtype = autocast_dtype
@@ -115,7 +185,15 @@ class PPOLearner:
                 "adv": adv.reshape(-1), "vtarg": vtarg.reshape(-1), "old_logits": old_logits}
 
     def _sgd_step(self, mb):
-        """One minibatch: forward, loss, backward, (gradient all-reduce,) Adam.  Returns the stats vector (STAT_KEYS order)."""
+        """One minibatch: forward, loss, backward, (gradient all-reduce,) Adam.  Returns the stats vector (STAT_KEYS order).
+        native: `mb` is ignored - the minibatch is rows self._idx of the persistent full-batch arrays self._full."""
+        if self.native:
+            stats = self._native.step(self._full, self._idx, self.clip_param, self.vf_clip_param, self.vf_loss_coeff, self.entropy_coeff, self._klc)
+            if self.world > 1:
+                allreduce_grads_([p for p in self.policy.parameters()], self.world)
+            self.opt.step()
+            self._native.images()
+            return stats
         if self.fused_loss:
             if self.autocast_dtype is not None:
                 with torch.autocast("cuda", dtype=self.autocast_dtype):
@@ -153,10 +231,14 @@ class PPOLearner:
     def _capture(self, b, mb, dev):
         """Capture one SGD step on static minibatch buffers into a hipGraph (warm-up on a side stream first; the warm-up and
         capture steps trained on the first minibatch, so parameters and Adam moments are rolled back afterwards)."""
-        self._mb = {k: torch.empty((mb,) + tuple(v.shape[1:]), dtype=v.dtype, device=dev) for k, v in b.items()}
+        if self.native:
+            self._mb = None
+            self._idx.copy_(torch.arange(mb, device=dev))
+        else:
+            self._mb = {k: torch.empty((mb,) + tuple(v.shape[1:]), dtype=v.dtype, device=dev) for k, v in b.items()}
+            for k, v in b.items():
+                self._mb[k].copy_(v[:mb])
         self._acc = torch.zeros((len(STAT_KEYS),), dtype=torch.float32, device=dev)
-        for k, v in b.items():
-            self._mb[k].copy_(v[:mb])
         snapshot = [p.detach().clone() for p in self.policy.parameters()]
         # Adam's moments / step counts as they are NOW (empty before the very first step, accumulated on a re-capture after
         # the minibatch size changed): the warm-up and capture steps below must not leave a trace in them either
@@ -193,6 +275,8 @@ class PPOLearner:
                             v_.copy_(saved[k_])
                         else:
                             v_.zero_()
+        if self.native:
+            self._native.images()                    # the float16 images follow the restored masters
         self._graph = g
 
     def update(self, traj, adv, vtarg):
@@ -219,7 +303,18 @@ class PPOLearner:
         if self._klc is None:
             self._klc = torch.zeros((), dtype=torch.float32, device=dev)
         self._klc.fill_(float(self.kl_coeff))
-        if self.use_graph and (self._graph is None or self._mb["adv"].shape[0] != mb):
+        if self.native:
+            # the kernels gather the minibatch themselves: the whole batch sits in PERSISTENT arrays (a captured graph holds their
+            # addresses), refreshed once per update; the minibatch is the static index vector self._idx
+            keys_ = ("obs", "old_logits", "keys_packed", "mouse", "logp", "adv", "value", "vtarg")
+            if self._full is None or self._full["adv"].shape[0] != total or self._idx.shape[0] != mb:
+                self._full = {k: torch.empty_like(b[k].reshape(total, -1) if k in ("obs", "old_logits") else b[k].reshape(-1)).contiguous() for k in keys_}
+                self._idx = torch.zeros((mb,), dtype=torch.int64, device=dev)
+                self._native = NativeStep(self.policy, self.env, mb, self.native_splits)
+                self._graph = None
+            for k in keys_:
+                self._full[k].copy_(b[k].reshape(self._full[k].shape))
+        if self.use_graph and (self._graph is None or (not self.native and self._mb["adv"].shape[0] != mb)):
             self._capture(b, mb, dev)
         acc, steps = torch.zeros((len(STAT_KEYS),), dtype=torch.float32, device=dev), 0
         if self.use_graph:
@@ -228,7 +323,13 @@ class PPOLearner:
             perm = torch.randperm(total, device=dev, generator=self.gen)
             for s in range(0, total - mb + 1, mb):
                 idx = perm[s:s + mb]
-                if self.use_graph:
+                if self.native:
+                    self._idx.copy_(idx)
+                    if self.use_graph:
+                        self._graph.replay()
+                    else:
+                        acc = acc + self._sgd_step(None)
+                elif self.use_graph:
                     for k, v in b.items():
                         torch.index_select(v, 0, idx, out=self._mb[k])
                     self._graph.replay()

@@ -1,0 +1,191 @@
+"""GPU: the native PPO learner step (q1env_learner_*: q1physrl_amd/csrc/q1learner.hpp) - forward bit-identical to the sampler's fused
+forward, gradients against torch autograd of the float32 modules (relative 1e-3), the whole step against the
+torch learner, eager == graph-captured, a ragged minibatch, and the discrete-mouse head."""
+import copy
+
+import numpy as np
+import pytest
+
+from oracle import np_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def make_env(n, seed=5, **over):
+    from q1physrl_amd.tensor_env import TensorVectorEnv
+    from q1physrl_amd.env import Config
+    cfg = O.OracleConfig.get_default(num_envs=n, **over)
+    return cfg, TensorVectorEnv(Config(**cfg.__dict__), device=0, seed=seed)
+
+
+def _policy(seed=0, scale=1.0, **kw):
+    import torch
+    from q1physrl_amd import policy as P
+    torch.manual_seed(seed)
+    pol = P.Q1Policy(**kw).cuda()
+    with torch.no_grad():
+        for p in pol.parameters():
+            p.mul_(scale)
+    return pol
+
+
+def _rel(a, b):
+    return float((a - b).norm() / b.norm().clamp_min(1e-30))
+
+
+@pytest.mark.parametrize("mb", [4096, 1000])
+def test_native_forward_is_the_samplers_forward_and_gradients_match_autograd(mb):
+    """(a) NativeStep.forward on gathered rows == FusedPolicyForward on the same rows, bit for bit (same mlp_tile).  (b) backward of a
+    random linear functional of (logits, value): every parameter gradient against torch autograd through the float32 modules -
+    float16 operands with float32 accumulation: relative (Frobenius) error <= 3e-3 per tensor, 1.5e-3 over all of them."""
+    import torch
+    from q1physrl_amd import policy as P, ppo
+    total = 3 * mb + 17
+    cfg, env = make_env(mb)
+    pol = _policy(1, 1.5)
+    g = torch.Generator(device="cuda").manual_seed(2)
+    obs = torch.randn((total, 6), device="cuda", generator=g) * torch.tensor([0.5, 3.0, 0.3, 1.5, 1.5, 1.0], device="cuda")
+    idx = torch.randperm(total, device="cuda", generator=g)[:mb].contiguous()
+    nat = ppo.NativeStep(pol, env, mb, splits=16)
+    logits, value = nat.forward(obs, idx)
+    fused = P.FusedPolicyForward(pol, env)
+    rows = obs[idx].contiguous()
+    l2, v2 = fused(rows)
+    torch.cuda.synchronize()
+    assert torch.equal(logits, l2) and torch.equal(value, v2)
+    # (b)
+    # per-sample (un-averaged) gradients, as q1env_learner_step passes them: O(1) for the logits, O(10..1000) for the value
+    scale = float(mb)
+    dl_s = torch.randn((mb, 10), device="cuda", generator=g)
+    dv_s = torch.randn((mb,), device="cuda", generator=g) * 300.0
+    dl, dv = dl_s / scale, dv_s / scale
+    nat.backward(obs, idx, dl_s, dv_s, scale)
+    torch.cuda.synchronize()
+    got = [p.grad.detach().clone() for p in pol.parameters()]
+    ref = copy.deepcopy(pol)
+    for p in ref.parameters():
+        p.grad = None
+    lg, vv = ref(rows)
+    ((lg * dl).sum() + (vv * dv).sum()).backward()
+    want = [p.grad for p in ref.parameters()]
+    names = [n for n, _ in pol.named_parameters()]
+    worst = 0.0
+    for n_, a, b in zip(names, got, want):
+        r = _rel(a, b)
+        worst = max(worst, r)
+        assert r < 3e-3, (n_, r)
+    allg, allw = torch.cat([a.reshape(-1) for a in got]), torch.cat([b.reshape(-1) for b in want])
+    assert _rel(allg, allw) < 1.5e-3, _rel(allg, allw)
+    cos = float(torch.dot(allg, allw) / (allg.norm() * allw.norm()))
+    assert cos > 0.999995, cos
+    env.close()
+
+
+def test_native_backward_no_gather_and_full_rows():
+    """idx = None (rows 0..B-1) gives the same gradients as the identity index vector."""
+    import torch
+    from q1physrl_amd import ppo
+    mb = 2048
+    cfg, env = make_env(mb)
+    pol = _policy(4)
+    g = torch.Generator(device="cuda").manual_seed(5)
+    obs = torch.randn((mb, 6), device="cuda", generator=g)
+    dl = torch.randn((mb, 10), device="cuda", generator=g)
+    dv = torch.randn((mb,), device="cuda", generator=g) * 100.0
+    nat = ppo.NativeStep(pol, env, mb, splits=8)
+    nat.forward(obs, None)
+    nat.backward(obs, None, dl, dv, float(mb))
+    torch.cuda.synchronize()
+    a = [p.grad.clone() for p in pol.parameters()]
+    ident = torch.arange(mb, device="cuda")
+    nat.forward(obs, ident)
+    nat.backward(obs, ident, dl, dv, float(mb))
+    torch.cuda.synchronize()
+    for x, y in zip(a, pol.parameters()):
+        assert torch.equal(x, y.grad)
+    env.close()
+
+
+def test_native_learner_matches_the_torch_learner():
+    """PPOLearner(native=True), eager and graph-captured, against the fused-loss torch learner on the same trajectories: same
+    statistics, same KL-coefficient schedule, parameters after 18 Adam steps equal to within what float16 operands allow."""
+    import torch
+    from q1physrl_amd import policy as P, ppo, sampler as S
+    torch.manual_seed(3)
+    base = P.Q1Policy().cuda()
+    cfg, env = make_env(512, time_limit=1.0)
+    smp = S.GpuSampler(env, P.FusedPolicyForward(base, env), horizon=32)
+    trajs = []
+    for _ in range(2):
+        tr = {k: v.clone() for k, v in smp.collect().items()}
+        adv, vt = smp.advantages(tr, 0.99, 0.95)
+        trajs.append((tr, adv.clone(), vt.clone()))
+    res = []
+    for native, graph in ((False, False), (True, False), (True, True)):
+        pol = copy.deepcopy(base)
+        lr = ppo.PPOLearner(pol, cfg.action_range, lr=1e-3, num_sgd_iter=3, minibatch_size=2048, seed=11, use_graph=graph,
+                            fused_loss=True, env=env, native=native, native_splits=8, fused_adam=True)
+        stats = [lr.update(*t) for t in trajs]
+        res.append(([p.detach().clone() for p in pol.parameters()], stats))
+    env.close()
+    (p0, s0) = res[0]
+    for pk, sk in res[1:]:
+        for a, b in zip(p0, pk):              # 18 Adam steps of lr 1e-3 (each moves a weight by <= lr): sign flips of tiny gradients aside, equal
+            assert float((a - b).abs().mean()) < 2e-4, float((a - b).abs().mean())
+        for a, b in zip(s0, sk):
+            assert a["sgd_steps"] == b["sgd_steps"]
+            for k in ("kl", "entropy", "policy_loss", "vf_loss"):
+                assert abs(a[k] - b[k]) <= 2e-2 * max(1.0, abs(a[k])), (k, a[k], b[k])
+    # eager native == graph-captured native (same kernels, same order)
+    for a, b in zip(res[1][0], res[2][0]):
+        assert float((a - b).abs().max()) < 1e-6, float((a - b).abs().max())
+
+
+def test_native_learner_first_step_sees_ratio_one():
+    """The sampler's logits come from the same float16 forward the learner runs: on the first minibatch of an update the new policy IS
+    the behaviour policy, so the probability ratio is 1 and the KL 0 to float32 rounding - the property that made float16 (not bfloat16)
+    operands necessary for the sampler carries over to the learner."""
+    import torch
+    from q1physrl_amd import policy as P, ppo, sampler as S
+    torch.manual_seed(7)
+    pol = P.Q1Policy().cuda()
+    cfg, env = make_env(1024, time_limit=1.0)
+    smp = S.GpuSampler(env, P.FusedPolicyForward(pol, env), horizon=16)
+    tr = smp.collect()
+    adv, vt = smp.advantages(tr, 0.99, 0.95)
+    lr = ppo.PPOLearner(pol, cfg.action_range, lr=0.0, num_sgd_iter=1, minibatch_size=4096, seed=1, fused_loss=True, env=env, native=True,
+                        native_splits=8)
+    st = lr.update(tr, adv, vt)
+    # (exp(log_std) exp(-log_std) is 1 only to float32 rounding; advantages are standardised, so mean(-adv * ratio) = 0 at ratio 1)
+    assert abs(st["kl"]) < 1e-6 and abs(st["policy_loss"]) < 1e-5, st
+    env.close()
+
+
+def test_native_learner_discrete_mouse_head():
+    """19 policy outputs (4 keys + 11-way categorical): the backward kernel's second K-step over the output index and the wider dW3."""
+    import torch
+    from q1physrl_amd import policy as P, ppo
+    mb = 2048
+    cfg, env = make_env(mb, discrete_yaw_steps=5)
+    pol = _policy(9, 1.2, discrete_yaw_steps=5)
+    width = P.policy_row_width(4, 5)
+    assert width == 19
+    g = torch.Generator(device="cuda").manual_seed(6)
+    obs = torch.randn((mb, 6), device="cuda", generator=g)
+    dl_s = torch.randn((mb, width), device="cuda", generator=g)
+    dv_s = torch.randn((mb,), device="cuda", generator=g) * 50.0
+    dl, dv = dl_s / mb, dv_s / mb
+    nat = ppo.NativeStep(pol, env, mb, splits=4)
+    logits, value = nat.forward(obs, None)
+    nat.backward(obs, None, dl_s, dv_s, float(mb))
+    torch.cuda.synchronize()
+    got = [p.grad.detach().clone() for p in pol.parameters()]
+    ref = copy.deepcopy(pol)
+    for p in ref.parameters():
+        p.grad = None
+    lg, vv = ref(obs)
+    assert float((lg - logits).abs().max()) < 5e-3
+    ((lg * dl).sum() + (vv * dv).sum()).backward()
+    for (n_, _), a, b in zip(pol.named_parameters(), got, [p.grad for p in ref.parameters()]):
+        assert _rel(a, b) < 3e-3, (n_, _rel(a, b))
+    env.close()

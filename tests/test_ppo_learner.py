@@ -108,7 +108,7 @@ def test_fused_loss_needs_an_env_handle():
     import pytest
     import torch
     from q1physrl_amd import policy as P, ppo
-    with pytest.raises(ValueError, match="fused_loss=True needs env"):
+    with pytest.raises(ValueError, match="fused_loss=True / native=True need env"):
         ppo.PPOLearner(P.Q1Policy(), 10.0, fused_loss=True)
 
 
