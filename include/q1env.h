@@ -341,6 +341,7 @@ typedef struct q1env_learner_batch {
     float clip_param, vf_clip_param, vf_loss_coeff, entropy_coeff;
     const float* kl_coeff_dev;         /* device scalar */
     float* stats_partials_dev;         /* float[ceil(B/256)][5]: sums of (entropy, kl, -surrogate, total, vf) per block of 256 samples */
+    int skip_reduce;                   /* != 0: leave the split-K partial sums in the workspace for q1env_learner_adam (gw* / gb* untouched) */
 } q1env_learner_batch;
 uint64_t q1env_learner_workspace_bytes(int64_t minibatch, int out_dim_pi, int splits);
 int q1env_learner_images(q1env_t* env, const q1env_learner_net* pi, const q1env_learner_net* vf, void* ws_dev, int64_t minibatch, int splits);
@@ -350,6 +351,14 @@ int q1env_learner_backward(q1env_t* env, const q1env_learner_net* pi, const q1en
                            const float* obs_dev, const int64_t* idx_dev, const float* dlogits_dev, const float* dvalue_dev, float grad_scale);
 int q1env_learner_step(q1env_t* env, const q1env_learner_net* pi, const q1env_learner_net* vf, void* ws_dev, int splits,
                        const q1env_learner_batch* batch);
+/* The optimizer of a single-process run, fused with the gradient reduction and the weight-image rebuild (one pass over the 138 k
+ * parameters after a q1env_learner_step with skip_reduce): torch.optim.Adam's update (no weight decay, no amsgrad) on the float32
+ * masters IN PLACE, moments and the step count in the caller's adam_state_dev (q1env_learner_adam_state_bytes bytes, zero-initialised;
+ * the step count lives on the device, so the call is replayable from a captured graph); gw* / gb* receive the gradients too.
+ * grad_scale = the one the partial sums carry (q1env_learner_step: the minibatch size). */
+uint64_t q1env_learner_adam_state_bytes(int out_dim_pi);
+int q1env_learner_adam(q1env_t* env, const q1env_learner_net* pi, const q1env_learner_net* vf, void* ws_dev, int64_t minibatch, int splits,
+                       float grad_scale, float lr, float beta1, float beta2, float eps, void* adam_state_dev);
 
 /* Episode bookkeeping of one sampler tick (the reference's on_episode_end metric hook, q1physrl/train.py:54-57):
  * ep_return double[N] += reward; for envs with done != 0 the finished return is added to this wave's slot of

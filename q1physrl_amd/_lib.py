@@ -64,7 +64,7 @@ class Q1LearnerBatch(C.Structure):   # q1env_learner_batch
                 ("keys_dev", C.c_void_p), ("mouse_dev", C.c_void_p), ("logp_old_dev", C.c_void_p), ("adv_dev", C.c_void_p),
                 ("value_old_dev", C.c_void_p), ("vtarg_dev", C.c_void_p),
                 ("clip_param", C.c_float), ("vf_clip_param", C.c_float), ("vf_loss_coeff", C.c_float), ("entropy_coeff", C.c_float),
-                ("kl_coeff_dev", C.c_void_p), ("stats_partials_dev", C.c_void_p)]
+                ("kl_coeff_dev", C.c_void_p), ("stats_partials_dev", C.c_void_p), ("skip_reduce", C.c_int)]
 
 
 STATE_FIELDS = (("vel_x", np.float32, 1), ("vel_y", np.float32, 1), ("vel_z", np.float32, 1),
@@ -116,6 +116,8 @@ _SIGNATURES = {
     "q1env_learner_forward": (C.c_int, [_P, C.POINTER(Q1LearnerNet), C.POINTER(Q1LearnerNet), _P, C.c_int64, C.c_int, _P, _P, _P, _P]),
     "q1env_learner_backward": (C.c_int, [_P, C.POINTER(Q1LearnerNet), C.POINTER(Q1LearnerNet), _P, C.c_int64, C.c_int, _P, _P, _P, _P, C.c_float]),
     "q1env_learner_step": (C.c_int, [_P, C.POINTER(Q1LearnerNet), C.POINTER(Q1LearnerNet), _P, C.c_int, C.POINTER(Q1LearnerBatch)]),
+    "q1env_learner_adam_state_bytes": (C.c_uint64, [C.c_int]),
+    "q1env_learner_adam": (C.c_int, [_P, C.POINTER(Q1LearnerNet), C.POINTER(Q1LearnerNet), _P, C.c_int64, C.c_int] + [C.c_float] * 5 + [_P]),
     "q1env_sample_step": (C.c_int, [_P, _P, C.c_int, C.c_uint64, _P, C.c_uint64, C.c_int] + [_P] * 9),
     "q1env_episode_stats": (C.c_int, [_P, _P, _P, _P, _P, _P]),
     "q1env_step_persistent_start": (C.c_int, [_P, C.c_int, C.c_uint32, _P, _P, _P, C.c_uint64, C.c_int, _P, C.c_double]),

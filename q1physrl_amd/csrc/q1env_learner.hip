@@ -19,6 +19,7 @@ constexpr size_t IMG_W3T_BYTES = q1learn::LDS_W3T;                          // 2
 struct NetWs {
     uint16_t* w23; uint16_t* w2t; uint16_t* w3t;
     q1learn::f16x8* h1T; q1learn::f16x8* h2T; q1learn::f16x8* dz2N; q1learn::f16x8* dz1N; q1learn::f16x8* h1N; q1learn::f16x8* h2N;
+    q1learn::f16x8* xN; q1learn::f16x8* dyN;
     float* partial;
 };
 struct Ws {
@@ -39,6 +40,7 @@ Ws carve_ws(void* base, int64_t mb, int out_pi, int splits) {
         n.w23 = (uint16_t*)take(IMG_FWD_BYTES); n.w2t = (uint16_t*)take(IMG_W2T_BYTES); n.w3t = (uint16_t*)take(IMG_W3T_BYTES);
         n.h1T = (q1learn::f16x8*)take(act); n.h2T = (q1learn::f16x8*)take(act);
         n.dz2N = (q1learn::f16x8*)take(act); n.dz1N = (q1learn::f16x8*)take(act); n.h1N = (q1learn::f16x8*)take(act); n.h2N = (q1learn::f16x8*)take(act);
+        n.xN = (q1learn::f16x8*)take(tiles * 128u * 16u); n.dyN = (q1learn::f16x8*)take(tiles * 128u * 16u);
         n.partial = (float*)take((size_t)splits * q1learn::PARTIAL_FLOATS * 4u);
     }
     w.logits = (float*)take((size_t)mb * out_pi * 4u); w.value = (float*)take((size_t)mb * 4u);
@@ -86,20 +88,21 @@ int launch_forward(q1env* h, const Ws& w, int64_t mb, const q1env_learner_net* p
 }
 
 int launch_backward(q1env* h, const Ws& w, int64_t mb, int splits, const q1env_learner_net* pi, const q1env_learner_net* vf, const float* obs,
-                    const int64_t* idx, const float* dlogits, const float* dvalue, float grad_scale) {
+                    const int64_t* idx, const float* dlogits, const float* dvalue, float grad_scale, bool reduce = true) {
     if (int r = ensure_learner_attrs(h)) return r;
     const q1learn::BwdNet ba{w.net[0].w2t, w.net[0].w3t, dlogits, pi->out_dim, pi->out_dim, w.net[0].h1T, w.net[0].h2T,
-                             w.net[0].dz2N, w.net[0].dz1N, w.net[0].h1N, w.net[0].h2N};
+                             w.net[0].dz2N, w.net[0].dz1N, w.net[0].h1N, w.net[0].h2N, w.net[0].xN, w.net[0].dyN};
     const q1learn::BwdNet bb{w.net[1].w2t, w.net[1].w3t, dvalue, vf->out_dim, vf->out_dim, w.net[1].h1T, w.net[1].h2T,
-                             w.net[1].dz2N, w.net[1].dz1N, w.net[1].h1N, w.net[1].h2N};
+                             w.net[1].dz2N, w.net[1].dz1N, w.net[1].h1N, w.net[1].h2N, w.net[1].xN, w.net[1].dyN};
     const unsigned cus = (unsigned)(h->num_cus > 1 ? h->num_cus / 2 : 1);
     const unsigned tiles = (unsigned)((mb + 31) / 32);
     unsigned blocks = (tiles + 3u) / 4u;
     if (blocks > cus) blocks = cus;
-    hipLaunchKernelGGL(q1learn::learner_backward_kernel, dim3(blocks * 2u), dim3(256), q1learn::LDS_BWD, h->stream, (int)mb, ba, bb, 2);
-    const q1learn::WgNet wa{w.net[0].dz2N, w.net[0].dz1N, w.net[0].h1N, w.net[0].h2N, dlogits, pi->out_dim, pi->out_dim, w.net[0].partial};
-    const q1learn::WgNet wb{w.net[1].dz2N, w.net[1].dz1N, w.net[1].h1N, w.net[1].h2N, dvalue, vf->out_dim, vf->out_dim, w.net[1].partial};
-    hipLaunchKernelGGL(q1learn::learner_wgrad_kernel, dim3(2u * (unsigned)splits, 2), dim3(512), 0, h->stream, (int)mb, obs, idx, wa, wb, splits);
+    hipLaunchKernelGGL(q1learn::learner_backward_kernel, dim3(blocks * 2u), dim3(256), q1learn::LDS_BWD, h->stream, (int)mb, obs, idx, ba, bb, 2);
+    const q1learn::WgNet wa{w.net[0].dz2N, w.net[0].dz1N, w.net[0].h1N, w.net[0].h2N, w.net[0].xN, w.net[0].dyN, w.net[0].partial};
+    const q1learn::WgNet wb{w.net[1].dz2N, w.net[1].dz1N, w.net[1].h1N, w.net[1].h2N, w.net[1].xN, w.net[1].dyN, w.net[1].partial};
+    hipLaunchKernelGGL(q1learn::learner_wgrad_kernel, dim3(2u * (unsigned)splits, 2), dim3(512), 0, h->stream, (int)mb, wa, wb, splits);
+    if (!reduce) { HIP_TRY(hipGetLastError()); return 0; }          // q1env_learner_adam sums the partials itself
     const q1learn::Grads ga{pi->gw1, pi->gb1, pi->gw2, pi->gb2, pi->gw3, pi->gb3, pi->out_dim};
     const q1learn::Grads gb{vf->gw1, vf->gb1, vf->gw2, vf->gb2, vf->gw3, vf->gb3, vf->out_dim};
     const unsigned max_out = (unsigned)(pi->out_dim > vf->out_dim ? pi->out_dim : vf->out_dim);
@@ -182,7 +185,43 @@ int q1env_learner_step(q1env_t* h, const q1env_learner_net* pi, const q1env_lear
                            b->value_old_dev, b->vtarg_dev, (const int64_t*)nullptr, b->clip_param, b->vf_clip_param, b->vf_loss_coeff, b->entropy_coeff,
                            b->kl_coeff_dev, scale, w.dlogits, w.dvalue, b->stats_partials_dev);
     HIP_TRY(hipGetLastError());
-    return launch_backward(h, w, mb, splits, pi, vf, b->obs_dev, b->idx_dev, w.dlogits, w.dvalue, scale);
+    return launch_backward(h, w, mb, splits, pi, vf, b->obs_dev, b->idx_dev, w.dlogits, w.dvalue, scale, b->skip_reduce == 0);
+}
+
+uint64_t q1env_learner_adam_state_bytes(int out_dim_pi) {
+    if (out_dim_pi < 1 || out_dim_pi > 32) return 0;
+    const size_t per_pi = 65536u + 256u + 1536u + 256u + (size_t)out_dim_pi * 257u, per_vf = 65536u + 256u + 1536u + 256u + 257u;
+    return (uint64_t)(256u + align_up(2 * per_pi * 4u, 256) + align_up(2 * per_vf * 4u, 256));
+}
+
+int q1env_learner_adam(q1env_t* h, const q1env_learner_net* pi, const q1env_learner_net* vf, void* ws_dev, int64_t minibatch, int splits,
+                       float grad_scale, float lr, float beta1, float beta2, float eps, void* adam_state_dev) {
+    if (!h || !ws_dev || !adam_state_dev) return fail(Q1ENV_ERR_INVALID_ARG, "q1env_learner_adam: null argument");
+    if (!(grad_scale > 0.0f) || !(lr >= 0.0f) || !(beta1 >= 0.0f && beta1 < 1.0f) || !(beta2 >= 0.0f && beta2 < 1.0f) || !(eps > 0.0f))
+        return fail(Q1ENV_ERR_INVALID_ARG, "q1env_learner_adam: bad hyper-parameter");
+    if (int r = check_nets("q1env_learner_adam", pi, vf, true)) return r;
+    if (int r = check_shape("q1env_learner_adam", minibatch, splits)) return r;
+    DeviceGuard guard(h->device);
+    const Ws w = carve_ws(ws_dev, minibatch, pi->out_dim, splits);
+    char* st = (char*)adam_state_dev;
+    long long* step = (long long*)st;
+    float* bc = (float*)(st + 8);
+    const size_t per_pi = 65536u + 256u + 1536u + 256u + (size_t)pi->out_dim * 257u, per_vf = 65536u + 256u + 1536u + 256u + (size_t)vf->out_dim * 257u;
+    float* m_pi = (float*)(st + 256), *v_pi = m_pi + per_pi;
+    float* m_vf = (float*)(st + 256 + align_up(2 * per_pi * 4u, 256)), *v_vf = m_vf + per_vf;
+    hipLaunchKernelGGL(q1learn::adam_tick_kernel, dim3(1), dim3(64), 0, h->stream, step, bc, beta1, beta2);
+    const q1learn::AdamNet na{const_cast<float*>(pi->w1), const_cast<float*>(pi->b1), const_cast<float*>(pi->w2), const_cast<float*>(pi->b2),
+                              const_cast<float*>(pi->w3), const_cast<float*>(pi->b3),
+                              q1learn::Grads{pi->gw1, pi->gb1, pi->gw2, pi->gb2, pi->gw3, pi->gb3, pi->out_dim}, m_pi, v_pi, w.net[0].w23, w.net[0].w2t, w.net[0].w3t};
+    const q1learn::AdamNet nb{const_cast<float*>(vf->w1), const_cast<float*>(vf->b1), const_cast<float*>(vf->w2), const_cast<float*>(vf->b2),
+                              const_cast<float*>(vf->w3), const_cast<float*>(vf->b3),
+                              q1learn::Grads{vf->gw1, vf->gb1, vf->gw2, vf->gb2, vf->gw3, vf->gb3, vf->out_dim}, m_vf, v_vf, w.net[1].w23, w.net[1].w2t, w.net[1].w3t};
+    const unsigned max_out = (unsigned)(pi->out_dim > vf->out_dim ? pi->out_dim : vf->out_dim);
+    const unsigned elems = 65536u + 256u + 256u * 6u + 256u + max_out * 257u;
+    hipLaunchKernelGGL(q1learn::learner_adam_kernel, dim3((elems + 255u) / 256u, 2), dim3(256), 0, h->stream, (const float*)w.net[0].partial,
+                       (const float*)w.net[1].partial, na, nb, splits, 1.0f / grad_scale, q1learn::AdamHyper{lr, beta1, beta2, eps}, (const float*)bc);
+    HIP_TRY(hipGetLastError());
+    return Q1ENV_OK;
 }
 
 }  // extern "C"

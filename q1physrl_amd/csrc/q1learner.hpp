@@ -48,7 +48,7 @@ constexpr size_t LDS_BWD = LDS_W2T + LDS_W3T;                 // 155648 <= 16384
 
 // weight-gradient products of one network, 32x32 float32 tiles: [p][reg 16][lane 64]
 //   p = 8 jt + kt   dW2 tile (rows: units of dZ2 tile jt, cols: units of h1 tile kt)          0 .. 63
-//   p = 64 + jt     dZ2 tile jt x [x | 1]: column 6 = db2                                      64 .. 71
+//   p = 64 + jt     dZ2 tile jt x [x | 1]: column sigma(6) = db2                                      64 .. 71
 //   p = 72 + kt     dZ1 tile kt x [x | 1]: columns 0..5 = dW1, column 6 = db1                  72 .. 79
 //   p = 80 + jt     dY x h2 tile jt: rows = outputs, cols = units -> dW3                       80 .. 87
 //   p = 88          dY x [x | 1]: column 6 = db3
@@ -142,6 +142,8 @@ struct BwdNet {
     int dy_stride; int out_dim;
     const f16x8* h1T; const f16x8* h2T;
     f16x8* dz2N; f16x8* dz1N; f16x8* h1N; f16x8* h2N;
+    f16x8* xN;                // f16x8[tile][ks][lane]: the gathered observations + the constant 1 (input slot 6), lane = sigma(input index)
+    f16x8* dyN;               // f16x8[tile][ks][lane]: dY, lane = output index (natural)
 };
 
 // 32x32 transposition on the matrix pipe: x0 / x1 = the T-format vectors (u = 0 / 1) of one 32-unit tile; returns the tile with
@@ -169,7 +171,7 @@ __device__ __forceinline__ void times_dtanh(f32x16& acc, const f16x8 h0, const f
 }
 
 __global__ void __launch_bounds__(256, 1)
-learner_backward_kernel(int n, BwdNet net_a, BwdNet net_b, int nets) {
+learner_backward_kernel(int n, const float* __restrict__ obs, const int64_t* __restrict__ idx, BwdNet net_a, BwdNet net_b, int nets) {
     const uint32_t bgrid = nets == 2 ? gridDim.x / 2u : gridDim.x;
     const bool second = nets == 2 && blockIdx.x >= bgrid;
     const uint32_t bid = second ? blockIdx.x - bgrid : blockIdx.x;
@@ -218,6 +220,30 @@ learner_backward_kernel(int n, BwdNet net_a, BwdNet net_b, int nets) {
             }
         }
         const size_t tbase = (size_t)tile * TILE_VECS + lane;
+        // every global operand of the tile is requested up front (one wave per SIMD: nothing else hides an HBM round trip): the 16
+        // h2 vectors now, the 16 h1 vectors before the 128-MFMA data-gradient loop they are needed after
+        f16x8 hv[8][2];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) { hv[t][0] = net.h2T[tbase + (2u * t) * 64u]; hv[t][1] = net.h2T[tbase + (2u * t + 1u) * 64u]; }
+        // ---- the weight-gradient kernel's small operands, transposed here: [x | 1] (inputs as "units" 0..7 of a T-format tile: element e
+        //      < 4 of lane (c, h) = input 4 h + e) and dY (K slot = output index, so the transposition delivers lane = output)
+        {
+            f16x8 x0;
+            const size_t src = live ? (idx ? (size_t)idx[s] : (size_t)s) : 0;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int i = 4 * (int)half + e;
+                float v = 0.0f;
+                if (live && e < 4) v = i < OBS ? obs[src * OBS + (uint32_t)i] : (i == OBS ? 1.0f : 0.0f);
+                x0[e] = (_Float16)fminf(fmaxf(v, -65504.0f), 65504.0f);
+            }
+            const f16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+            const f32x16 dx = transpose_tile(x0, zero8, e0, e1);
+            const size_t sb = (size_t)tile * 128u + lane;
+            net.xN[sb] = cvt8(dx, 0); net.xN[sb + 64u] = cvt8(dx, 1);
+            const f32x16 dd = transpose_tile(dyb0, dyb1, e0, e1);
+            net.dyN[sb] = cvt8(dd, 0); net.dyN[sb + 64u] = cvt8(dd, 1);
+        }
         // ---- dH2^T = W3^T dY^T, dZ2 = dH2 (1 - h2^2); h2 and dZ2 leave in N-format
         f16x8 dzb[8][2];
 #pragma unroll
@@ -228,14 +254,14 @@ learner_backward_kernel(int n, BwdNet net_a, BwdNet net_b, int nets) {
                 const f16x8 a1 = *reinterpret_cast<const f16x8*>(w3trow + (size_t)t * 32u * W3T_ROW_BYTES + 32u);
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, dyb1, acc, 0, 0, 0);
             }
-            const f16x8 h0 = net.h2T[tbase + (2u * t) * 64u], h1 = net.h2T[tbase + (2u * t + 1u) * 64u];
-            times_dtanh(acc, h0, h1);
+            times_dtanh(acc, hv[t][0], hv[t][1]);
             dzb[t][0] = cvt8(acc, 0);
             dzb[t][1] = cvt8(acc, 1);
-            store_n(net.h2N + tbase, (uint32_t)t, transpose_tile(h0, h1, e0, e1));
+            store_n(net.h2N + tbase, (uint32_t)t, transpose_tile(hv[t][0], hv[t][1], e0, e1));
             store_n(net.dz2N + tbase, (uint32_t)t, transpose_tile(dzb[t][0], dzb[t][1], e0, e1));
-            __builtin_amdgcn_sched_barrier(0);       // one row tile at a time: keeps 16 float32 + a few operand registers live, not 8 x that
         }
+#pragma unroll
+        for (int t = 0; t < 8; ++t) { hv[t][0] = net.h1T[tbase + (2u * t) * 64u]; hv[t][1] = net.h1T[tbase + (2u * t + 1u) * 64u]; }
         // ---- dH1^T = W2^T dZ2^T: 16 K-steps (j) x 8 row tiles (k)
         f32x16 acc1[8];
 #pragma unroll
@@ -259,36 +285,47 @@ learner_backward_kernel(int n, BwdNet net_a, BwdNet net_b, int nets) {
         // ---- dZ1 = dH1 (1 - h1^2); h1 and dZ1 leave in N-format
 #pragma unroll
         for (int t = 0; t < 8; ++t) {
-            const f16x8 h0 = net.h1T[tbase + (2u * t) * 64u], h1 = net.h1T[tbase + (2u * t + 1u) * 64u];
-            times_dtanh(acc1[t], h0, h1);
+            times_dtanh(acc1[t], hv[t][0], hv[t][1]);
             const f16x8 z0 = cvt8(acc1[t], 0), z1 = cvt8(acc1[t], 1);
-            store_n(net.h1N + tbase, (uint32_t)t, transpose_tile(h0, h1, e0, e1));
+            store_n(net.h1N + tbase, (uint32_t)t, transpose_tile(hv[t][0], hv[t][1], e0, e1));
             store_n(net.dz1N + tbase, (uint32_t)t, transpose_tile(z0, z1, e0, e1));
-            __builtin_amdgcn_sched_barrier(0);
         }
     }
 }
 
 // ------------------------------------------------------------------------------------------------------------------ weight gradients
 struct WgNet {
-    const f16x8* dz2N; const f16x8* dz1N; const f16x8* h1N; const f16x8* h2N;
-    const float* dy; int dy_stride; int out_dim;
+    const f16x8* dz2N; const f16x8* dz1N; const f16x8* h1N; const f16x8* h2N; const f16x8* xN; const f16x8* dyN;
     float* partial;           // float[splits][PARTIAL_FLOATS]
 };
 
 // One workgroup = eight waves = the eight 32-unit row tiles of the gradient side; it owns a contiguous range of sample tiles (split-K
 // over workgroups, blockIdx.x) and one half of the products (blockIdx.y): y = 0 the dW2 column tiles 0..3 + the [x | 1] products
-// (dW1, db1, db2), y = 1 the column tiles 4..7 + the dY products (dW3, db3) - six float32 accumulator tiles per wave, so two
-// workgroups fit a CU.  It leaves its float32 partial sums in its split's slot.
+// (dW1, db1, db2), y = 1 the column tiles 4..7 + the dY products (dW3, db3) - six float32 accumulator tiles per wave.  Every operand
+// is a plain 16-byte-per-lane streaming load in MFMA layout (the backward kernel has done all gathering and transposing); the next
+// tile's operands are requested before the current tile's MFMAs (register double buffer).  It leaves its float32 partial sums in
+// its split's slot.
+struct WgOps { f16x8 a2[2], s0[2], s1[2], b[4][2]; };     // dZ2 rows | y=0: dZ1 rows, [x|1]  y=1: dY, h2 cols | h1 column tiles
+
+__device__ __forceinline__ void wg_load(WgOps& o, const WgNet& net, uint32_t tile, uint32_t lane, uint32_t w, uint32_t khalf) {
+    const size_t tb = (size_t)tile * TILE_VECS + lane, sb = (size_t)tile * 128u + lane;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        o.a2[ks] = net.dz2N[tb + (2u * w + (uint32_t)ks) * 64u];
+        if (khalf == 0) { o.s0[ks] = net.dz1N[tb + (2u * w + (uint32_t)ks) * 64u]; o.s1[ks] = net.xN[sb + 64u * (uint32_t)ks]; }
+        else { o.s0[ks] = net.dyN[sb + 64u * (uint32_t)ks]; o.s1[ks] = net.h2N[tb + (2u * w + (uint32_t)ks) * 64u]; }
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) o.b[kt][ks] = net.h1N[tb + (2u * (4u * khalf + (uint32_t)kt) + (uint32_t)ks) * 64u];
+    }
+}
+
 __global__ void __launch_bounds__(512, 1)
-learner_wgrad_kernel(int n, const float* __restrict__ obs, const int64_t* __restrict__ idx, WgNet net_a, WgNet net_b, int splits) {
+learner_wgrad_kernel(int n, WgNet net_a, WgNet net_b, int splits) {
     const bool second = blockIdx.x >= (uint32_t)splits;
     const uint32_t split = second ? blockIdx.x - (uint32_t)splits : blockIdx.x;
     const uint32_t khalf = blockIdx.y;
     const WgNet net = second ? net_b : net_a;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, w = tid >> 6;
-    const uint32_t col = lane & 31u, half = lane >> 5;
-    const int OUT = net.out_dim;
     const uint32_t ntiles = ((uint32_t)n + 31u) / 32u;
     const uint32_t per = (ntiles + (uint32_t)splits - 1u) / (uint32_t)splits;
     const uint32_t t_begin = split * per, t_end = min(t_begin + per, ntiles);
@@ -296,52 +333,29 @@ learner_wgrad_kernel(int n, const float* __restrict__ obs, const int64_t* __rest
     f32x16 aW2[4], aX = zero16, aY = zero16;          // y = 0: aX = dZ2 x [x|1], aY = dZ1 x [x|1];  y = 1: aX = dY x h2, aY = dY x [x|1] (wave 0)
 #pragma unroll
     for (int k = 0; k < 4; ++k) aW2[k] = zero16;
+    WgOps cur, nxt;
+    if (t_begin < t_end) wg_load(cur, net, t_begin, lane, w, khalf);
     for (uint32_t tile = t_begin; tile < t_end; ++tile) {
-        const size_t tb = (size_t)tile * TILE_VECS + lane;
-        f16x8 a2[2], x1[2];
+        const uint32_t tn = tile + 1u < t_end ? tile + 1u : tile;           // (the last iteration re-requests its own tile: harmless)
+        wg_load(nxt, net, tn, lane, w, khalf);
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            a2[ks] = net.dz2N[tb + (2u * w + (uint32_t)ks) * 64u];
+        for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const uint32_t s = tile * 32u + (uint32_t)(e & 3) + 16u * (uint32_t)ks + 8u * (uint32_t)(e >> 2) + 4u * half;
-                float xv = 0.0f;
-                if (s < (uint32_t)n) {
-                    if (col < (uint32_t)OBS) xv = obs[(idx ? (size_t)idx[s] : (size_t)s) * OBS + col];
-                    else if (col == (uint32_t)OBS) xv = 1.0f;
-                }
-                x1[ks][e] = (_Float16)xv;
-            }
-        }
-#pragma unroll
-        for (int kt = 0; kt < 4; ++kt) {
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                const f16x8 b = net.h1N[tb + (2u * (4u * khalf + (uint32_t)kt) + (uint32_t)ks) * 64u];
-                aW2[kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a2[ks], b, aW2[kt], 0, 0, 0);
-            }
-        }
+            for (int ks = 0; ks < 2; ++ks) aW2[kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur.a2[ks], cur.b[kt][ks], aW2[kt], 0, 0, 0);
         if (khalf == 0) {
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
-                const f16x8 a1 = net.dz1N[tb + (2u * w + (uint32_t)ks) * 64u];
-                aX = __builtin_amdgcn_mfma_f32_32x32x16_f16(a2[ks], x1[ks], aX, 0, 0, 0);
-                aY = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, x1[ks], aY, 0, 0, 0);
+                aX = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur.a2[ks], cur.s1[ks], aX, 0, 0, 0);
+                aY = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur.s0[ks], cur.s1[ks], aY, 0, 0, 0);
             }
         } else {
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
-                f16x8 dya;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const uint32_t s = tile * 32u + (uint32_t)(e & 3) + 16u * (uint32_t)ks + 8u * (uint32_t)(e >> 2) + 4u * half;
-                    dya[e] = (_Float16)fminf(fmaxf((s < (uint32_t)n && (int)col < OUT) ? net.dy[(size_t)s * (uint32_t)net.dy_stride + col] : 0.0f, -65504.0f), 65504.0f);
-                }
-                const f16x8 bh2 = net.h2N[tb + (2u * w + (uint32_t)ks) * 64u];
-                aX = __builtin_amdgcn_mfma_f32_32x32x16_f16(dya, bh2, aX, 0, 0, 0);
-                if (w == 0) aY = __builtin_amdgcn_mfma_f32_32x32x16_f16(dya, x1[ks], aY, 0, 0, 0);
+                aX = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur.s0[ks], cur.s1[ks], aX, 0, 0, 0);
+                if (w == 0) aY = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur.s0[ks], net.xN[(size_t)tile * 128u + lane + 64u * (uint32_t)ks], aY, 0, 0, 0);
             }
         }
+        cur = nxt;
     }
     float* out = net.partial + (size_t)split * PARTIAL_FLOATS;
     auto put = [&](uint32_t p, const f32x16& a) {
@@ -388,15 +402,15 @@ learner_reduce_kernel(const float* __restrict__ pa, const float* __restrict__ pb
         return;
     }
     i -= nW2;
-    if (i < nB2) { g.b2[i] = inv_scale * partial_sum(partial, splits, 64u + (i >> 5), sigma(i & 31u), (uint32_t)OBS); return; }
+    if (i < nB2) { g.b2[i] = inv_scale * partial_sum(partial, splits, 64u + (i >> 5), sigma(i & 31u), sigma((uint32_t)OBS)); return; }
     i -= nB2;
     if (i < nW1) {
         const uint32_t k = i / (uint32_t)OBS, c = i % (uint32_t)OBS;
-        g.w1[i] = inv_scale * partial_sum(partial, splits, 72u + (k >> 5), sigma(k & 31u), c);
+        g.w1[i] = inv_scale * partial_sum(partial, splits, 72u + (k >> 5), sigma(k & 31u), sigma(c));
         return;
     }
     i -= nW1;
-    if (i < nB1) { g.b1[i] = inv_scale * partial_sum(partial, splits, 72u + (i >> 5), sigma(i & 31u), (uint32_t)OBS); return; }
+    if (i < nB1) { g.b1[i] = inv_scale * partial_sum(partial, splits, 72u + (i >> 5), sigma(i & 31u), sigma((uint32_t)OBS)); return; }
     i -= nB1;
     if (i < nW3) {
         const uint32_t o = i >> 8, j = i & 255u;
@@ -404,7 +418,86 @@ learner_reduce_kernel(const float* __restrict__ pa, const float* __restrict__ pb
         return;
     }
     i -= nW3;
-    if (i < nB3) g.b3[i] = inv_scale * partial_sum(partial, splits, 88u, i, (uint32_t)OBS);
+    if (i < nB3) g.b3[i] = inv_scale * partial_sum(partial, splits, 88u, i, sigma((uint32_t)OBS));
+}
+
+__device__ __forceinline__ uint32_t kperm(uint32_t p) { return (p & ~0xCu) | ((p & 4u) << 1) | ((p & 8u) >> 1); }   // image column <-> hidden index (an involution)
+
+// ------------------------------------------------------------------------------------------------------------------ optimizer
+// Reduction + Adam + weight images in ONE pass over the parameters (single-process training: no gradient all-reduce sits between
+// them): a thread owns one parameter element - sums its split-K partials, writes the gradient (inspection / parity tests), updates the
+// float32 moments and the master weight exactly as torch.optim.Adam does (no weight decay, no amsgrad: exp_avg.lerp_, exp_avg_sq
+// mul_/addcmul_, step_size = lr / bias_correction1, denom = sqrt(v) / sqrt(bias_correction2) + eps), and re-emits the element's float16
+// copies in the forward and backward weight images.  bias corrections come from adam_tick_kernel (device-resident step count: the
+// step is replayable from a captured graph).
+struct AdamNet {
+    float* w1; float* b1; float* w2; float* b2; float* w3; float* b3;          // float32 masters, updated in place
+    Grads g;                                                                       // gradients out (torch layouts)
+    float* m; float* v;                                                            // moments, flat: [w2 | b2 | w1 | b1 | w3 | b3]
+    uint16_t* w23; uint16_t* w2t; uint16_t* w3t;                                   // weight images (ImgNet)
+};
+
+struct AdamHyper { float lr, beta1, beta2, eps; };
+
+__global__ void adam_tick_kernel(long long* step, float* bc, float beta1, float beta2) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        const long long t = *step + 1;
+        *step = t;
+        bc[0] = (float)(1.0 - pow((double)beta1, (double)t));
+        bc[1] = (float)(1.0 - pow((double)beta2, (double)t));
+    }
+}
+
+__device__ __forceinline__ float adam_update(float w, float g, float& m, float& v, const AdamHyper& hp, float bc1, float bc2) {
+    m = m + (g - m) * (1.0f - hp.beta1);
+    v = v * hp.beta2 + (1.0f - hp.beta2) * g * g;
+    const float denom = sqrtf(v) / sqrtf(bc2) + hp.eps;
+    return w - (hp.lr / bc1) * (m / denom);
+}
+
+__global__ void __launch_bounds__(256)
+learner_adam_kernel(const float* __restrict__ pa, const float* __restrict__ pb, AdamNet na, AdamNet nb, int splits, float inv_scale,
+                    AdamHyper hp, const float* __restrict__ bc) {
+    const bool second = blockIdx.y == 1;
+    const float* __restrict__ partial = second ? pb : pa;
+    const AdamNet net = second ? nb : na;
+    const uint32_t OUT = (uint32_t)net.g.out_dim;
+    const uint32_t nW2 = 65536u, nB2 = 256u, nW1 = 256u * (uint32_t)OBS, nB1 = 256u, nW3 = OUT * 256u, nB3 = OUT;
+    const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= nW2 + nB2 + nW1 + nB1 + nW3 + nB3) return;
+    const float bc1 = bc[0], bc2 = bc[1];
+    float m = net.m[e], v = net.v[e];
+    uint32_t i = e;
+    if (i < nW2) {
+        const uint32_t j = i >> 8, k = i & 255u;
+        const float g = inv_scale * partial_sum(partial, splits, 8u * (j >> 5) + (k >> 5), sigma(j & 31u), sigma(k & 31u));
+        const float w = adam_update(net.w2[i], g, m, v, hp, bc1, bc2);
+        net.g.w2[i] = g; net.w2[i] = w;
+        net.w23[j * 264u + kperm(k)] = q1pol::f16_bits(q1pol::TANH_PRESCALE * w);
+        net.w2t[k * 264u + kperm(j)] = q1pol::f16_bits(w);
+    } else if ((i -= nW2) < nB2) {
+        const float g = inv_scale * partial_sum(partial, splits, 64u + (i >> 5), sigma(i & 31u), sigma((uint32_t)OBS));
+        net.g.b2[i] = g; net.b2[i] = adam_update(net.b2[i], g, m, v, hp, bc1, bc2);
+    } else if ((i -= nB2) < nW1) {
+        const uint32_t k = i / (uint32_t)OBS, c = i % (uint32_t)OBS;
+        const float g = inv_scale * partial_sum(partial, splits, 72u + (k >> 5), sigma(k & 31u), sigma(c));
+        net.g.w1[i] = g; net.w1[i] = adam_update(net.w1[i], g, m, v, hp, bc1, bc2);
+    } else if ((i -= nW1) < nB1) {
+        const float g = inv_scale * partial_sum(partial, splits, 72u + (i >> 5), sigma(i & 31u), sigma((uint32_t)OBS));
+        net.g.b1[i] = g; net.b1[i] = adam_update(net.b1[i], g, m, v, hp, bc1, bc2);
+    } else if ((i -= nB1) < nW3) {
+        const uint32_t o = i >> 8, j = i & 255u;
+        const float g = inv_scale * partial_sum(partial, splits, 80u + (j >> 5), o, sigma(j & 31u));
+        const float w = adam_update(net.w3[i], g, m, v, hp, bc1, bc2);
+        net.g.w3[i] = g; net.w3[i] = w;
+        net.w23[(256u + o) * 264u + kperm(j)] = q1pol::f16_bits(w);
+        net.w3t[j * 40u + o] = q1pol::f16_bits(w);
+    } else {
+        i -= nW3;
+        const float g = inv_scale * partial_sum(partial, splits, 88u, i, sigma((uint32_t)OBS));
+        net.g.b3[i] = g; net.b3[i] = adam_update(net.b3[i], g, m, v, hp, bc1, bc2);
+    }
+    net.m[e] = m; net.v[e] = v;
 }
 
 // ------------------------------------------------------------------------------------------------------------------ weight images
@@ -414,8 +507,6 @@ struct ImgNet {
     uint16_t* w2t;            // backward image float16[256][264]: W2^T, K index (j) permuted the same way
     uint16_t* w3t;            // backward image float16[256][40]:  W3^T, natural order
 };
-
-__device__ __forceinline__ uint32_t kperm(uint32_t p) { return (p & ~0xCu) | ((p & 4u) << 1) | ((p & 8u) >> 1); }   // image column -> hidden index
 
 __global__ void __launch_bounds__(256)
 learner_images_kernel(ImgNet na, ImgNet nb) {

@@ -232,6 +232,13 @@ class DeviceEnv:
         _lib.check(self._lib.q1env_learner_backward(self._h, C.byref(pi), C.byref(vf), ws, int(minibatch), int(splits), obs, idx or None,
                                                     dlogits, dvalue, float(grad_scale)))
 
+    def learner_adam_state_bytes(self, out_dim_pi):
+        return int(self._lib.q1env_learner_adam_state_bytes(int(out_dim_pi)))
+
+    def learner_adam_dev(self, pi, vf, ws, minibatch, splits, grad_scale, lr, beta1, beta2, eps, state):
+        _lib.check(self._lib.q1env_learner_adam(self._h, C.byref(pi), C.byref(vf), ws, int(minibatch), int(splits), float(grad_scale), float(lr),
+                                                float(beta1), float(beta2), float(eps), state))
+
     def learner_step_dev(self, pi, vf, ws, splits, batch):
         _lib.check(self._lib.q1env_learner_step(self._h, C.byref(pi), C.byref(vf), ws, int(splits), C.byref(batch)))
 

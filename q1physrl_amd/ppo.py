@@ -65,7 +65,7 @@ class NativeStep:
     not zero_grad(set_to_none=True)); the caller runs the optimizer and then images() to rebuild the kernels' float16 weight images.
     The minibatch is rows idx of the FULL trajectory arrays (gathered inside the kernels, nothing is copied)."""
 
-    def __init__(self, policy, env, minibatch, splits=64):
+    def __init__(self, policy, env, minibatch, splits=32):
         from . import _lib
         self.policy, self.env, self.mb, self.splits = policy, env, int(minibatch), int(splits)
         self._lib = _lib
@@ -78,6 +78,7 @@ class NativeStep:
         nbytes = env._dev.learner_workspace_bytes(self.mb, policy.pi[4].out_features, self.splits)
         self.ws = torch.empty((nbytes,), dtype=torch.uint8, device=dev)
         self.partials = torch.zeros(((self.mb + 255) // 256, len(STAT_KEYS)), dtype=torch.float32, device=dev)
+        self.adam_state = torch.zeros((env._dev.learner_adam_state_bytes(policy.pi[4].out_features),), dtype=torch.uint8, device=dev)
         self.images()
 
     def _net(self, seq):
@@ -107,16 +108,23 @@ class NativeStep:
         self.env._dev.learner_backward_dev(self.pi, self.vf, self.ws.data_ptr(), self.mb, self.splits, obs.data_ptr(),
                                            idx.data_ptr() if idx is not None else 0, dlogits.data_ptr(), dvalue.data_ptr(), grad_scale)
 
-    def step(self, full, idx, clip_param, vf_clip_param, vf_loss_coeff, entropy_coeff, klc_dev):
+    def adam(self, lr, betas=(0.9, 0.999), eps=1e-8):
+        """After step(..., skip_reduce=True): gradient reduction + torch.optim.Adam's update of the masters + weight images, ONE kernel
+        (q1env_learner_adam; moments and step count in self.adam_state)."""
+        self.env._dev.learner_adam_dev(self.pi, self.vf, self.ws.data_ptr(), self.mb, self.splits, float(self.mb), lr, betas[0], betas[1], eps,
+                                       self.adam_state.data_ptr())
+
+    def step(self, full, idx, clip_param, vf_clip_param, vf_loss_coeff, entropy_coeff, klc_dev, skip_reduce=False):
         """full: dict of the whole trajectory batch (obs (total,6), old_logits (total,W), keys_packed, mouse, logp, adv, value, vtarg);
-        idx int64 (B,) or None.  Returns the statistics vector (STAT_KEYS order, means over the minibatch)."""
+        idx int64 (B,) or None.  Returns the statistics vector (STAT_KEYS order, means over the minibatch).
+        skip_reduce: the parameter gradients stay as split-K partial sums for adam() (.grad is then written by adam())."""
         L = self._lib
         ol = full["old_logits"]
         assert ol.is_contiguous() and full["obs"].is_contiguous() and (idx is None or (idx.dtype == torch.int64 and idx.numel() == self.mb))
         b = L.Q1LearnerBatch(self.mb, idx.data_ptr() if idx is not None else None, full["obs"].data_ptr(), ol.data_ptr(), ol.shape[1],
                              full["keys_packed"].data_ptr(), full["mouse"].data_ptr(), full["logp"].data_ptr(), full["adv"].data_ptr(),
                              full["value"].data_ptr(), full["vtarg"].data_ptr(), clip_param, vf_clip_param, vf_loss_coeff, entropy_coeff,
-                             klc_dev.data_ptr(), self.partials.data_ptr())
+                             klc_dev.data_ptr(), self.partials.data_ptr(), int(bool(skip_reduce)))
         self.env._dev.learner_step_dev(self.pi, self.vf, self.ws.data_ptr(), self.splits, b)
         return self.partials.sum(dim=0) / self.mb
 
@@ -137,7 +145,7 @@ class PPOLearner:
     def __init__(self, policy, action_range, lr=5e-6, gamma=0.99, lam=0.95, clip_param=0.3, vf_clip_param=100.0,
                  vf_loss_coeff=1.0, entropy_coeff=0.01, kl_coeff=0.2, kl_target=0.0036, num_sgd_iter=30,
                  minibatch_size=128, num_keys=4, seed=0, use_graph=False, fused_loss=False, env=None, discrete_yaw_steps=-1,
-                 allow_yaw=True, autocast_dtype=None, fused_adam=False, native=False, native_splits=64):
+                 allow_yaw=True, autocast_dtype=None, fused_adam=False, native=False, native_splits=32, native_adam=True):
         self.policy = policy
         self.action_range = float(action_range)
         self.gamma, self.lam = gamma, lam
@@ -149,7 +157,7 @@ class PPOLearner:
         self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
         self.use_graph = bool(use_graph) and self.world == 1
         self.fused_loss, self.env = bool(fused_loss), env
-        self.native, self.native_splits = bool(native), int(native_splits)
+        self.native, self.native_splits, self.native_adam = bool(native), int(native_splits), bool(native_adam)
         if (self.fused_loss or self.native) and env is None:
             raise ValueError("fused_loss=True / native=True need env= (the TensorVectorEnv whose handle runs the kernels)")
         self._native = None
@@ -188,7 +196,13 @@ class PPOLearner:
         """One minibatch: forward, loss, backward, (gradient all-reduce,) Adam.  Returns the stats vector (STAT_KEYS order).
         native: `mb` is ignored - the minibatch is rows self._idx of the persistent full-batch arrays self._full."""
         if self.native:
-            stats = self._native.step(self._full, self._idx, self.clip_param, self.vf_clip_param, self.vf_loss_coeff, self.entropy_coeff, self._klc)
+            own_adam = self.world == 1 and self.native_adam       # no all-reduce between gradients and optimizer: one fused kernel
+            stats = self._native.step(self._full, self._idx, self.clip_param, self.vf_clip_param, self.vf_loss_coeff, self.entropy_coeff, self._klc,
+                                      skip_reduce=own_adam)
+            if own_adam:
+                g = self.opt.param_groups[0]
+                self._native.adam(g["lr"], g["betas"], g["eps"])
+                return stats
             if self.world > 1:
                 allreduce_grads_([p for p in self.policy.parameters()], self.world)
             self.opt.step()
@@ -245,6 +259,8 @@ class PPOLearner:
         opt_snapshot = {id(p): {k: (v.detach().clone() if torch.is_tensor(v) else v) for k, v in st.items()}
                         for p, st in self.opt.state.items()}
 
+        adam_snapshot = self._native.adam_state.clone() if self.native else None      # the native optimizer's moments and step count
+
         def one_step():
             self._acc += self._sgd_step(self._mb)
 
@@ -276,6 +292,7 @@ class PPOLearner:
                         else:
                             v_.zero_()
         if self.native:
+            self._native.adam_state.copy_(adam_snapshot)
             self._native.images()                    # the float16 images follow the restored masters
         self._graph = g
 

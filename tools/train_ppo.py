@@ -38,6 +38,8 @@ ap.add_argument("--resident", action="store_true", help="sample every horizon as
 ap.add_argument("--learner-bf16", action="store_true", help="learner GEMMs under torch.autocast(bfloat16) (float32 master weights, loss and Adam)")
 ap.add_argument("--no-fused-adam", action="store_true", help="plain torch.optim.Adam instead of the multi-tensor fused one (0.48 instead of 0.41 s per iteration)")
 ap.add_argument("--fused-loss", action="store_true", help="PPO loss + gradient from the q1env_ppo_loss_grad kernel")
+ap.add_argument("--native", action="store_true", help="native learner step: gather, both MLPs forward + backward, loss gradient and weight gradients as the library's gfx950 kernels (q1env_learner_step); torch runs only Adam")
+ap.add_argument("--native-splits", type=int, default=32, help="workgroups per network of the split-K weight-gradient kernel")
 ap.add_argument("--save", default="", help="write the final policy weights (npz, RLlib fcnet naming) here")
 ap.add_argument("--discrete-yaw-steps", type=int, default=-1, help="Config.discrete_yaw_steps: the mouse becomes Discrete(2S+1) (a Categorical policy head)")
 args = ap.parse_args()
@@ -57,7 +59,8 @@ fused = P.FusedPolicyForward(pol, env) if args.fused_policy else None
 smp = GpuSampler(env, fused if fused is not None else pol, horizon=args.horizon, use_graph=not args.no_graph, resident=args.resident)
 lrn = ppo.PPOLearner(pol, float(cfg.action_range), lr=args.lr, num_sgd_iter=args.epochs, minibatch_size=args.minibatch,
                      entropy_coeff=args.entropy, kl_target=args.kl_target, seed=args.seed + rank, use_graph=not args.no_graph, fused_loss=args.fused_loss, env=env,
-                     discrete_yaw_steps=args.discrete_yaw_steps, autocast_dtype=torch.bfloat16 if args.learner_bf16 else None, fused_adam=not args.no_fused_adam)
+                     discrete_yaw_steps=args.discrete_yaw_steps, autocast_dtype=torch.bfloat16 if args.learner_bf16 else None, fused_adam=not args.no_fused_adam,
+                     native=args.native, native_splits=args.native_splits)
 log = []
 t0 = time.time()
 prev = smp.stats
