@@ -101,7 +101,7 @@ int launch_backward(q1env* h, const Ws& w, int64_t mb, int splits, const q1env_l
     hipLaunchKernelGGL(q1learn::learner_backward_kernel, dim3(blocks * 2u), dim3(256), q1learn::LDS_BWD, h->stream, (int)mb, obs, idx, ba, bb, 2);
     const q1learn::WgNet wa{w.net[0].dz2N, w.net[0].dz1N, w.net[0].h1N, w.net[0].h2N, w.net[0].xN, w.net[0].dyN, w.net[0].partial};
     const q1learn::WgNet wb{w.net[1].dz2N, w.net[1].dz1N, w.net[1].h1N, w.net[1].h2N, w.net[1].xN, w.net[1].dyN, w.net[1].partial};
-    hipLaunchKernelGGL(q1learn::learner_wgrad_kernel, dim3(2u * (unsigned)splits, 2), dim3(512), 0, h->stream, (int)mb, wa, wb, splits);
+    hipLaunchKernelGGL(q1learn::learner_wgrad_kernel, dim3(2u * (unsigned)splits, 2, 2), dim3(256), 0, h->stream, (int)mb, wa, wb, splits);
     if (!reduce) { HIP_TRY(hipGetLastError()); return 0; }          // q1env_learner_adam sums the partials itself
     const q1learn::Grads ga{pi->gw1, pi->gb1, pi->gw2, pi->gb2, pi->gw3, pi->gb3, pi->out_dim};
     const q1learn::Grads gb{vf->gw1, vf->gb1, vf->gw2, vf->gb2, vf->gw3, vf->gb3, vf->out_dim};
@@ -195,7 +195,7 @@ uint64_t q1env_learner_adam_state_bytes(int out_dim_pi) {
 }
 
 int q1env_learner_adam(q1env_t* h, const q1env_learner_net* pi, const q1env_learner_net* vf, void* ws_dev, int64_t minibatch, int splits,
-                       float grad_scale, float lr, float beta1, float beta2, float eps, void* adam_state_dev) {
+                       float grad_scale, float lr, float beta1, float beta2, float eps, void* adam_state_dev, const float* stats_partials_dev) {
     if (!h || !ws_dev || !adam_state_dev) return fail(Q1ENV_ERR_INVALID_ARG, "q1env_learner_adam: null argument");
     if (!(grad_scale > 0.0f) || !(lr >= 0.0f) || !(beta1 >= 0.0f && beta1 < 1.0f) || !(beta2 >= 0.0f && beta2 < 1.0f) || !(eps > 0.0f))
         return fail(Q1ENV_ERR_INVALID_ARG, "q1env_learner_adam: bad hyper-parameter");
@@ -209,7 +209,8 @@ int q1env_learner_adam(q1env_t* h, const q1env_learner_net* pi, const q1env_lear
     const size_t per_pi = 65536u + 256u + 1536u + 256u + (size_t)pi->out_dim * 257u, per_vf = 65536u + 256u + 1536u + 256u + (size_t)vf->out_dim * 257u;
     float* m_pi = (float*)(st + 256), *v_pi = m_pi + per_pi;
     float* m_vf = (float*)(st + 256 + align_up(2 * per_pi * 4u, 256)), *v_vf = m_vf + per_vf;
-    hipLaunchKernelGGL(q1learn::adam_tick_kernel, dim3(1), dim3(64), 0, h->stream, step, bc, beta1, beta2);
+    hipLaunchKernelGGL(q1learn::adam_tick_kernel, dim3(1), dim3(64), 0, h->stream, step, bc, beta1, beta2, stats_partials_dev,
+                       (int)((minibatch + 255) / 256), 1.0f / (float)minibatch, (float*)(st + 16));
     const q1learn::AdamNet na{const_cast<float*>(pi->w1), const_cast<float*>(pi->b1), const_cast<float*>(pi->w2), const_cast<float*>(pi->b2),
                               const_cast<float*>(pi->w3), const_cast<float*>(pi->b3),
                               q1learn::Grads{pi->gw1, pi->gb1, pi->gw2, pi->gb2, pi->gw3, pi->gb3, pi->out_dim}, m_pi, v_pi, w.net[0].w23, w.net[0].w2t, w.net[0].w3t};

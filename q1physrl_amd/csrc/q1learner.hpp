@@ -146,6 +146,24 @@ struct BwdNet {
     f16x8* dyN;               // f16x8[tile][ks][lane]: dY, lane = output index (natural)
 };
 
+template <uint32_t THREADS, uint32_t NVEC>
+__device__ __forceinline__ void stage_copy(unsigned char* dst, const uint16_t* __restrict__ src_, uint32_t tid) {
+    const uint4* src = reinterpret_cast<const uint4*>(src_);
+    uint4* d = reinterpret_cast<uint4*>(dst);
+    constexpr uint32_t PER = (NVEC + THREADS - 1u) / THREADS;
+    uint4 v[PER];
+#pragma unroll
+    for (uint32_t k = 0; k < PER; ++k) {
+        const uint32_t c = k * THREADS + tid;
+        v[k] = c < NVEC ? src[c] : make_uint4(0, 0, 0, 0);
+    }
+#pragma unroll
+    for (uint32_t k = 0; k < PER; ++k) {
+        const uint32_t c = k * THREADS + tid;
+        if (c < NVEC) d[c] = v[k];
+    }
+}
+
 // 32x32 transposition on the matrix pipe: x0 / x1 = the T-format vectors (u = 0 / 1) of one 32-unit tile; returns the tile with
 // lane = unit sigma(c), registers = samples, as float32 (exact), to be packed with cvt8.
 __device__ __forceinline__ f32x16 transpose_tile(const f16x8 x0, const f16x8 x1, const f16x8 e0, const f16x8 e1) {
@@ -180,14 +198,10 @@ learner_backward_kernel(int n, const float* __restrict__ obs, const int64_t* __r
     unsigned char* l_w2t = lds;
     unsigned char* l_w3t = lds + LDS_W2T;
     const uint32_t tid = threadIdx.x;
-    {   // stage both images: straight 16-byte copies (135168 + 20480 bytes)
-        const uint4* s2 = reinterpret_cast<const uint4*>(net.w2t);
-        uint4* d2 = reinterpret_cast<uint4*>(l_w2t);
-        for (uint32_t v = tid; v < (uint32_t)(LDS_W2T / 16); v += 256u) d2[v] = s2[v];
-        const uint4* s3 = reinterpret_cast<const uint4*>(net.w3t);
-        uint4* d3 = reinterpret_cast<uint4*>(l_w3t);
-        for (uint32_t v = tid; v < (uint32_t)(LDS_W3T / 16); v += 256u) d3[v] = s3[v];
-    }
+    // stage both images: straight 16-byte copies (135168 + 20480 bytes) with ALL of a thread's loads in flight at once (a load -> store
+    // loop would expose one L2 / HBM round trip per 4 KiB: 38 of them)
+    stage_copy<256, (uint32_t)(LDS_W2T / 16)>(l_w2t, net.w2t, tid);
+    stage_copy<256, (uint32_t)(LDS_W3T / 16)>(l_w3t, net.w3t, tid);
     const uint32_t lane = tid & 63u, wave = tid >> 6;
     const uint32_t col = lane & 31u, half = lane >> 5;
     __syncthreads();
@@ -299,8 +313,8 @@ struct WgNet {
     float* partial;           // float[splits][PARTIAL_FLOATS]
 };
 
-// One workgroup = eight waves = the eight 32-unit row tiles of the gradient side; it owns a contiguous range of sample tiles (split-K
-// over workgroups, blockIdx.x) and one half of the products (blockIdx.y): y = 0 the dW2 column tiles 0..3 + the [x | 1] products
+// One workgroup = four waves = four of the eight 32-unit row tiles of the gradient side (blockIdx.z picks the half); it owns a contiguous
+// range of sample tiles (split-K over workgroups, blockIdx.x) and one half of the products (blockIdx.y): y = 0 the dW2 column tiles 0..3 + the [x | 1] products
 // (dW1, db1, db2), y = 1 the column tiles 4..7 + the dY products (dW3, db3) - six float32 accumulator tiles per wave.  Every operand
 // is a plain 16-byte-per-lane streaming load in MFMA layout (the backward kernel has done all gathering and transposing); the next
 // tile's operands are requested before the current tile's MFMAs (register double buffer).  It leaves its float32 partial sums in
@@ -319,13 +333,13 @@ __device__ __forceinline__ void wg_load(WgOps& o, const WgNet& net, uint32_t til
     }
 }
 
-__global__ void __launch_bounds__(512, 1)
+__global__ void __launch_bounds__(256, 2)
 learner_wgrad_kernel(int n, WgNet net_a, WgNet net_b, int splits) {
     const bool second = blockIdx.x >= (uint32_t)splits;
     const uint32_t split = second ? blockIdx.x - (uint32_t)splits : blockIdx.x;
     const uint32_t khalf = blockIdx.y;
     const WgNet net = second ? net_b : net_a;
-    const uint32_t tid = threadIdx.x, lane = tid & 63u, w = tid >> 6;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, w = (tid >> 6) + 4u * blockIdx.z;      // row tile of the gradient side
     const uint32_t ntiles = ((uint32_t)n + 31u) / 32u;
     const uint32_t per = (ntiles + (uint32_t)splits - 1u) / (uint32_t)splits;
     const uint32_t t_begin = split * per, t_end = min(t_begin + per, ntiles);
@@ -439,8 +453,27 @@ struct AdamNet {
 
 struct AdamHyper { float lr, beta1, beta2, eps; };
 
-__global__ void adam_tick_kernel(long long* step, float* bc, float beta1, float beta2) {
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
+// One small block per optimizer step: advances the device-resident step count, publishes the two bias corrections, and folds the loss
+// kernel's per-block statistics (float[nblocks][5] sums over 256 samples each) into the running sums stats_acc[5] += sum / batch -
+// what three torch launches (sum, scale, accumulate) did per SGD step.
+__global__ void __launch_bounds__(64)
+adam_tick_kernel(long long* step, float* bc, float beta1, float beta2, const float* __restrict__ stats_partials, int nblocks, float inv_batch,
+                 float* stats_acc) {
+    const uint32_t lane = threadIdx.x;
+    if (stats_partials) {
+        float s[5] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+        for (int b = (int)lane; b < nblocks; b += 64)
+#pragma unroll
+            for (int k = 0; k < 5; ++k) s[k] += stats_partials[(size_t)b * 5 + k];
+#pragma unroll
+        for (int k = 0; k < 5; ++k)
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) s[k] += __shfl_down(s[k], off, 64);
+        if (lane == 0)
+#pragma unroll
+            for (int k = 0; k < 5; ++k) stats_acc[k] += s[k] * inv_batch;
+    }
+    if (lane == 0) {
         const long long t = *step + 1;
         *step = t;
         bc[0] = (float)(1.0 - pow((double)beta1, (double)t));

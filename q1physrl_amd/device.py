@@ -235,9 +235,9 @@ class DeviceEnv:
     def learner_adam_state_bytes(self, out_dim_pi):
         return int(self._lib.q1env_learner_adam_state_bytes(int(out_dim_pi)))
 
-    def learner_adam_dev(self, pi, vf, ws, minibatch, splits, grad_scale, lr, beta1, beta2, eps, state):
+    def learner_adam_dev(self, pi, vf, ws, minibatch, splits, grad_scale, lr, beta1, beta2, eps, state, stats_partials=0):
         _lib.check(self._lib.q1env_learner_adam(self._h, C.byref(pi), C.byref(vf), ws, int(minibatch), int(splits), float(grad_scale), float(lr),
-                                                float(beta1), float(beta2), float(eps), state))
+                                                float(beta1), float(beta2), float(eps), state, stats_partials or None))
 
     def learner_step_dev(self, pi, vf, ws, splits, batch):
         _lib.check(self._lib.q1env_learner_step(self._h, C.byref(pi), C.byref(vf), ws, int(splits), C.byref(batch)))

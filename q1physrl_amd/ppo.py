@@ -79,6 +79,7 @@ class NativeStep:
         self.ws = torch.empty((nbytes,), dtype=torch.uint8, device=dev)
         self.partials = torch.zeros(((self.mb + 255) // 256, len(STAT_KEYS)), dtype=torch.float32, device=dev)
         self.adam_state = torch.zeros((env._dev.learner_adam_state_bytes(policy.pi[4].out_features),), dtype=torch.uint8, device=dev)
+        self.stats_acc = self.adam_state[16:36].view(torch.float32)      # running sums of the step statistics (q1env_learner_adam)
         self.images()
 
     def _net(self, seq):
@@ -112,7 +113,7 @@ class NativeStep:
         """After step(..., skip_reduce=True): gradient reduction + torch.optim.Adam's update of the masters + weight images, ONE kernel
         (q1env_learner_adam; moments and step count in self.adam_state)."""
         self.env._dev.learner_adam_dev(self.pi, self.vf, self.ws.data_ptr(), self.mb, self.splits, float(self.mb), lr, betas[0], betas[1], eps,
-                                       self.adam_state.data_ptr())
+                                       self.adam_state.data_ptr(), self.partials.data_ptr())
 
     def step(self, full, idx, clip_param, vf_clip_param, vf_loss_coeff, entropy_coeff, klc_dev, skip_reduce=False):
         """full: dict of the whole trajectory batch (obs (total,6), old_logits (total,W), keys_packed, mouse, logp, adv, value, vtarg);
@@ -126,6 +127,8 @@ class NativeStep:
                              full["value"].data_ptr(), full["vtarg"].data_ptr(), clip_param, vf_clip_param, vf_loss_coeff, entropy_coeff,
                              klc_dev.data_ptr(), self.partials.data_ptr(), int(bool(skip_reduce)))
         self.env._dev.learner_step_dev(self.pi, self.vf, self.ws.data_ptr(), self.splits, b)
+        if skip_reduce:
+            return None                              # adam() folds the statistics into self.stats_acc on the device
         return self.partials.sum(dim=0) / self.mb
 
 
@@ -199,10 +202,10 @@ class PPOLearner:
             own_adam = self.world == 1 and self.native_adam       # no all-reduce between gradients and optimizer: one fused kernel
             stats = self._native.step(self._full, self._idx, self.clip_param, self.vf_clip_param, self.vf_loss_coeff, self.entropy_coeff, self._klc,
                                       skip_reduce=own_adam)
-            if own_adam:
+            if own_adam:                              # statistics accumulate in self._native.stats_acc
                 g = self.opt.param_groups[0]
                 self._native.adam(g["lr"], g["betas"], g["eps"])
-                return stats
+                return None
             if self.world > 1:
                 allreduce_grads_([p for p in self.policy.parameters()], self.world)
             self.opt.step()
@@ -262,7 +265,9 @@ class PPOLearner:
         adam_snapshot = self._native.adam_state.clone() if self.native else None      # the native optimizer's moments and step count
 
         def one_step():
-            self._acc += self._sgd_step(self._mb)
+            st = self._sgd_step(self._mb)
+            if st is not None:
+                self._acc += st
 
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
@@ -336,6 +341,8 @@ class PPOLearner:
         acc, steps = torch.zeros((len(STAT_KEYS),), dtype=torch.float32, device=dev), 0
         if self.use_graph:
             self._acc.zero_()
+        if self._native is not None:
+            self._native.stats_acc.zero_()
         for _ in range(self.num_sgd_iter):
             perm = torch.randperm(total, device=dev, generator=self.gen)
             for s in range(0, total - mb + 1, mb):
@@ -345,7 +352,9 @@ class PPOLearner:
                     if self.use_graph:
                         self._graph.replay()
                     else:
-                        acc = acc + self._sgd_step(None)
+                        st = self._sgd_step(None)
+                        if st is not None:
+                            acc = acc + st
                 elif self.use_graph:
                     for k, v in b.items():
                         torch.index_select(v, 0, idx, out=self._mb[k])
@@ -355,6 +364,8 @@ class PPOLearner:
                 steps += 1
         if self.use_graph:
             acc = self._acc.clone()
+        if self.native and self.world == 1 and self.native_adam:
+            acc = self._native.stats_acc.clone()
         acc = acc / steps
         if self.world > 1:
             dist.all_reduce(acc, op=dist.ReduceOp.SUM)
