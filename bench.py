@@ -493,9 +493,6 @@ def main(argv=None):
         calls = []
         t, left, launches = tick0, k, 0
         started = stopped = False
-        if timed and mode == "rollout":
-            calls.append(dev.timer_start)
-            started = True
         o1, r1, d1 = obs1.data_ptr(), rew1.data_ptr(), done1.data_ptr()
         while left > 0:
             ph = t % EPISODE_TICKS
@@ -549,8 +546,16 @@ def main(argv=None):
                 launches += chunk
             else:
                 if not prepare:
+                    # (the timer events are recorded inside the q1env_rollout call of the first / last chunk, next to the launch itself)
+                    rflags = 0
+                    if timed and not started:
+                        rflags |= _lib.TIMER_START
+                        started = True
+                    if timed and left == chunk and not ends_episode:
+                        rflags |= _lib.TIMER_STOP
+                        stopped = True
                     calls.append(functools.partial(dev.rollout_dev, chunk, _lib.ACT_PACKED, ka, ma, 0, _lib.OBS_F32, obsT.data_ptr(),
-                                                   rewT.data_ptr(), doneT.data_ptr(), False))
+                                                   rewT.data_ptr(), doneT.data_ptr(), rflags))
                 launches += 1
             t += chunk
             left -= chunk

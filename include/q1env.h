@@ -181,8 +181,9 @@ int q1env_step_many(q1env_t* env, int ticks, int action_format, const void* act_
                     int out_stride_ticks, int use_graph);
 /* Fused multi-tick kernel: state stays in registers for `ticks` ticks (one launch).  Actions are
  * tick-major device arrays in `action_format`, or Q1ENV_ACT_RANDOM (then rng_seed keys the counter RNG).
- * Per-tick outputs are tick-major and optional (NULL).  auto_reset != 0: an env whose tick set `done`
- * is reset in-kernel with the Philox reset (as q1env_reset_philox) before its next tick.
+ * Per-tick outputs are tick-major and optional (NULL).  auto_reset bit 0: an env whose tick set `done`
+ * is reset in-kernel with the Philox reset (as q1env_reset_philox) before its next tick; (ABI v3) Q1ENV_TIMER_START (4) /
+ * Q1ENV_TIMER_STOP (8) may be added to record the handle's timer events around the launch inside this call (as q1env_step_many).
  * return_sum_dev (optional, double[N]) accumulates reward over the launch in float64. */
 int q1env_rollout(q1env_t* env, int ticks, int action_format, const void* act_a_dev, const void* act_b_dev,
                   uint64_t rng_seed, int obs_format, void* obs_dev, float* reward_dev, uint8_t* done_dev,
@@ -355,7 +356,8 @@ int q1env_learner_step(q1env_t* env, const q1env_learner_net* pi, const q1env_le
  * parameters after a q1env_learner_step with skip_reduce): torch.optim.Adam's update (no weight decay, no amsgrad) on the float32
  * masters IN PLACE, moments and the step count in the caller's adam_state_dev (q1env_learner_adam_state_bytes bytes, zero-initialised;
  * the step count lives on the device, so the call is replayable from a captured graph); gw* / gb* receive the gradients too.
- * grad_scale = the one the partial sums carry (q1env_learner_step: the minibatch size).  adam_state layout: int64 step count at byte 0,
+ * grad_scale = the one the POLICY network's partial sums carry (q1env_learner_step: the minibatch size B; the value network's carry
+ * B / 64, which this call accounts for - it pairs with q1env_learner_step, not with a hand-made q1env_learner_backward).  adam_state layout: int64 step count at byte 0,
  * float bias corrections [2] at byte 8, float running statistics [5] at byte 16 (+= the mean of stats_partials_dev - the step's
  * q1env_learner_batch.stats_partials_dev - per call, if not NULL; the caller zeroes them when it starts a new average), moments from 256. */
 uint64_t q1env_learner_adam_state_bytes(int out_dim_pi);

@@ -800,6 +800,10 @@ int q1env_rollout(q1env_t* h, int ticks, int fmt, const void* a, const void* b, 
     if (ticks <= 0) return fail(Q1ENV_ERR_INVALID_ARG, "ticks must be > 0");
     if (int r = check_act(h, fmt, a, b, true)) return r;
     if (obs_format != Q1ENV_OBS_F32 && obs_format != Q1ENV_OBS_F64) return fail(Q1ENV_ERR_INVALID_ARG, "bad obs_format");
+    // (Q1ENV_TIMER_START / _STOP in auto_reset: record the handle's timer events around the launch, inside this call - as q1env_step_many)
+    const bool t_start = (auto_reset & Q1ENV_TIMER_START) != 0, t_stop = (auto_reset & Q1ENV_TIMER_STOP) != 0;
+    auto_reset &= 1;
+    if (t_start) HIP_TRY(hipEventRecord(h->ev0, h->stream));
     const int blk = block_for(h->p.n);
     const dim3 g = grid_for(h->p.n, blk), bs(blk);
     const bool spec = is_spec(h->p);
@@ -828,6 +832,7 @@ int q1env_rollout(q1env_t* h, int ticks, int fmt, const void* a, const void* b, 
     }
 #undef Q1_LAUNCH_ROLL
     HIP_TRY(hipGetLastError());
+    if (t_stop) HIP_TRY(hipEventRecord(h->ev1, h->stream));
     h->tick_count += (uint64_t)ticks;
     return Q1ENV_OK;
 }

@@ -12,6 +12,7 @@ using namespace q1;
 
 namespace {
 
+constexpr float Q1_LEARNER_VALUE_DOWNSCALE = 64.0f;    // q1env_learner_step scales the value network's gradients by B / 64 (float16 range)
 constexpr size_t IMG_FWD_BYTES = (q1pol::LDS_W2 + q1pol::LDS_W3);           // 152064: float16[288][264]
 constexpr size_t IMG_W2T_BYTES = q1learn::LDS_W2T;                          // 135168
 constexpr size_t IMG_W3T_BYTES = q1learn::LDS_W3T;                          // 20480
@@ -88,7 +89,7 @@ int launch_forward(q1env* h, const Ws& w, int64_t mb, const q1env_learner_net* p
 }
 
 int launch_backward(q1env* h, const Ws& w, int64_t mb, int splits, const q1env_learner_net* pi, const q1env_learner_net* vf, const float* obs,
-                    const int64_t* idx, const float* dlogits, const float* dvalue, float grad_scale, bool reduce = true) {
+                    const int64_t* idx, const float* dlogits, const float* dvalue, float grad_scale, float grad_scale_v, bool reduce = true) {
     if (int r = ensure_learner_attrs(h)) return r;
     const q1learn::BwdNet ba{w.net[0].w2t, w.net[0].w3t, dlogits, pi->out_dim, pi->out_dim, w.net[0].h1T, w.net[0].h2T,
                              w.net[0].dz2N, w.net[0].dz1N, w.net[0].h1N, w.net[0].h2N, w.net[0].xN, w.net[0].dyN};
@@ -108,7 +109,7 @@ int launch_backward(q1env* h, const Ws& w, int64_t mb, int splits, const q1env_l
     const unsigned max_out = (unsigned)(pi->out_dim > vf->out_dim ? pi->out_dim : vf->out_dim);
     const unsigned elems = 65536u + 256u + 256u * 6u + 256u + max_out * 256u + max_out;
     hipLaunchKernelGGL(q1learn::learner_reduce_kernel, dim3((elems + 255u) / 256u, 2), dim3(256), 0, h->stream, (const float*)w.net[0].partial,
-                       (const float*)w.net[1].partial, ga, gb, splits, 1.0f / grad_scale);
+                       (const float*)w.net[1].partial, ga, gb, splits, 1.0f / grad_scale, 1.0f / grad_scale_v);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -155,7 +156,7 @@ int q1env_learner_backward(q1env_t* h, const q1env_learner_net* pi, const q1env_
     if (int r = check_shape("q1env_learner_backward", minibatch, splits)) return r;
     DeviceGuard guard(h->device);
     const Ws w = carve_ws(ws_dev, minibatch, pi->out_dim, splits);
-    return launch_backward(h, w, minibatch, splits, pi, vf, obs_dev, idx_dev, dlogits_dev, dvalue_dev, grad_scale);
+    return launch_backward(h, w, minibatch, splits, pi, vf, obs_dev, idx_dev, dlogits_dev, dvalue_dev, grad_scale, grad_scale);
 }
 
 int q1env_learner_step(q1env_t* h, const q1env_learner_net* pi, const q1env_learner_net* vf, void* ws_dev, int splits, const q1env_learner_batch* b) {
@@ -173,19 +174,20 @@ int q1env_learner_step(q1env_t* h, const q1env_learner_net* pi, const q1env_lear
     const int64_t mb = b->minibatch;
     const Ws w = carve_ws(ws_dev, mb, pi->out_dim, splits);
     if (int r = launch_forward(h, w, mb, pi, vf, b->obs_dev, b->idx_dev, w.logits, w.value)) return r;
-    const float scale = (float)mb;                                 // per-sample (un-averaged) gradients: float16's normal range
+    // per-sample (un-averaged) gradients for the policy, 1/64 of that for the value network: float16's normal range (q1learner.hpp)
+    const float scale = (float)mb, scale_v = (float)mb / Q1_LEARNER_VALUE_DOWNSCALE;
     if (b->idx_dev)
         hipLaunchKernelGGL(ppo_loss_grad_kernel<true>, grid_for((int)mb, 256), dim3(256), 0, h->stream, h->p, (int)mb, (const float*)w.logits,
                            b->old_logits_dev, pi->out_dim, b->old_stride, b->keys_dev, b->mouse_dev, b->logp_old_dev, b->adv_dev, (const float*)w.value,
                            b->value_old_dev, b->vtarg_dev, b->idx_dev, b->clip_param, b->vf_clip_param, b->vf_loss_coeff, b->entropy_coeff,
-                           b->kl_coeff_dev, scale, w.dlogits, w.dvalue, b->stats_partials_dev);
+                           b->kl_coeff_dev, scale, scale_v, w.dlogits, w.dvalue, b->stats_partials_dev);
     else
         hipLaunchKernelGGL(ppo_loss_grad_kernel<false>, grid_for((int)mb, 256), dim3(256), 0, h->stream, h->p, (int)mb, (const float*)w.logits,
                            b->old_logits_dev, pi->out_dim, b->old_stride, b->keys_dev, b->mouse_dev, b->logp_old_dev, b->adv_dev, (const float*)w.value,
                            b->value_old_dev, b->vtarg_dev, (const int64_t*)nullptr, b->clip_param, b->vf_clip_param, b->vf_loss_coeff, b->entropy_coeff,
-                           b->kl_coeff_dev, scale, w.dlogits, w.dvalue, b->stats_partials_dev);
+                           b->kl_coeff_dev, scale, scale_v, w.dlogits, w.dvalue, b->stats_partials_dev);
     HIP_TRY(hipGetLastError());
-    return launch_backward(h, w, mb, splits, pi, vf, b->obs_dev, b->idx_dev, w.dlogits, w.dvalue, scale, b->skip_reduce == 0);
+    return launch_backward(h, w, mb, splits, pi, vf, b->obs_dev, b->idx_dev, w.dlogits, w.dvalue, scale, scale_v, b->skip_reduce == 0);
 }
 
 uint64_t q1env_learner_adam_state_bytes(int out_dim_pi) {
@@ -220,7 +222,8 @@ int q1env_learner_adam(q1env_t* h, const q1env_learner_net* pi, const q1env_lear
     const unsigned max_out = (unsigned)(pi->out_dim > vf->out_dim ? pi->out_dim : vf->out_dim);
     const unsigned elems = 65536u + 256u + 256u * 6u + 256u + max_out * 257u;
     hipLaunchKernelGGL(q1learn::learner_adam_kernel, dim3((elems + 255u) / 256u, 2), dim3(256), 0, h->stream, (const float*)w.net[0].partial,
-                       (const float*)w.net[1].partial, na, nb, splits, 1.0f / grad_scale, q1learn::AdamHyper{lr, beta1, beta2, eps}, (const float*)bc);
+                       (const float*)w.net[1].partial, na, nb, splits, 1.0f / grad_scale, Q1_LEARNER_VALUE_DOWNSCALE / grad_scale,
+                       q1learn::AdamHyper{lr, beta1, beta2, eps}, (const float*)bc);
     HIP_TRY(hipGetLastError());
     return Q1ENV_OK;
 }

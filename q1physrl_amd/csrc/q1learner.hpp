@@ -27,8 +27,11 @@
 // N-format (per network, per array): f16x8[tile][t = 0..7][ks = 0..1][lane 64]; lane (c, h) = hidden unit 32 t + sigma(c), sigma = swap
 //          bits 2 and 3; element e = sample 32 tile + (e & 3) + 16 ks + 8 (e >> 2) + 4 h.  Both MFMA operands of a weight-gradient
 //          product use the same sample order, so it never has to be undone; sigma is undone by learner_reduce_kernel.
-// Gradient scaling: d loss / d(logits, value) arrive multiplied by `grad_scale` (= B: the per-sample, un-averaged gradient) so that they
-// sit in float16's normal range; learner_reduce_kernel divides the sums by it again.
+// Gradient scaling: d loss / d(logits, value) arrive multiplied by a per-network `grad_scale` so that they and everything derived from them
+// sit in float16's normal range: B for the policy (the per-sample, un-averaged gradient, O(1)) and B / 64 for the value network (its
+// per-sample gradient 2 (v - vtarg) reaches the thousands, and W2^T dZ2 sums 256 of them times weights that grow to O(1..10): unscaled,
+// dZ1 passed 65504 in a training run and the resulting inf became NaN weights).  The data gradients are additionally converted with
+// saturation.  learner_reduce_kernel / learner_adam_kernel divide the sums by the scale again.
 #pragma once
 #include "q1policy.hpp"
 
@@ -62,6 +65,18 @@ __device__ __forceinline__ f16x8 cvt8(const f32x16& a, int u) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const q1pol::f32x2 t = {a[8 * u + 2 * j], a[8 * u + 2 * j + 1]};
+        o.p[j] = __builtin_convertvector(t, q1pol::f16x2);
+    }
+    return o.v;
+}
+
+// the same with saturation at float16's largest finite value: for the data gradients, whose magnitude is not bounded by construction -
+// an inf would turn into NaN in the very next transposition (inf x 0 of the selection operand) and from there into every weight
+__device__ __forceinline__ f16x8 cvt8_sat(const f32x16& a, int u) {
+    union { f16x8 v; q1pol::f16x2 p[4]; } o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const q1pol::f32x2 t = {__builtin_amdgcn_fmed3f(a[8 * u + 2 * j], -65504.0f, 65504.0f), __builtin_amdgcn_fmed3f(a[8 * u + 2 * j + 1], -65504.0f, 65504.0f)};
         o.p[j] = __builtin_convertvector(t, q1pol::f16x2);
     }
     return o.v;
@@ -269,8 +284,8 @@ learner_backward_kernel(int n, const float* __restrict__ obs, const int64_t* __r
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, dyb1, acc, 0, 0, 0);
             }
             times_dtanh(acc, hv[t][0], hv[t][1]);
-            dzb[t][0] = cvt8(acc, 0);
-            dzb[t][1] = cvt8(acc, 1);
+            dzb[t][0] = cvt8_sat(acc, 0);
+            dzb[t][1] = cvt8_sat(acc, 1);
             store_n(net.h2N + tbase, (uint32_t)t, transpose_tile(hv[t][0], hv[t][1], e0, e1));
             store_n(net.dz2N + tbase, (uint32_t)t, transpose_tile(dzb[t][0], dzb[t][1], e0, e1));
         }
@@ -300,7 +315,7 @@ learner_backward_kernel(int n, const float* __restrict__ obs, const int64_t* __r
 #pragma unroll
         for (int t = 0; t < 8; ++t) {
             times_dtanh(acc1[t], hv[t][0], hv[t][1]);
-            const f16x8 z0 = cvt8(acc1[t], 0), z1 = cvt8(acc1[t], 1);
+            const f16x8 z0 = cvt8_sat(acc1[t], 0), z1 = cvt8_sat(acc1[t], 1);
             store_n(net.h1N + tbase, (uint32_t)t, transpose_tile(hv[t][0], hv[t][1], e0, e1));
             store_n(net.dz1N + tbase, (uint32_t)t, transpose_tile(z0, z1, e0, e1));
         }
@@ -403,8 +418,9 @@ __device__ __forceinline__ float partial_sum(const float* __restrict__ partial, 
 }
 
 __global__ void __launch_bounds__(256)
-learner_reduce_kernel(const float* __restrict__ pa, const float* __restrict__ pb, Grads ga, Grads gb, int splits, float inv_scale) {
+learner_reduce_kernel(const float* __restrict__ pa, const float* __restrict__ pb, Grads ga, Grads gb, int splits, float inv_scale_a, float inv_scale_b) {
     const bool second = blockIdx.y == 1;
+    const float inv_scale = second ? inv_scale_b : inv_scale_a;
     const float* __restrict__ partial = second ? pb : pa;
     const Grads g = second ? gb : ga;
     const uint32_t OUT = (uint32_t)g.out_dim;
@@ -489,9 +505,10 @@ __device__ __forceinline__ float adam_update(float w, float g, float& m, float& 
 }
 
 __global__ void __launch_bounds__(256)
-learner_adam_kernel(const float* __restrict__ pa, const float* __restrict__ pb, AdamNet na, AdamNet nb, int splits, float inv_scale,
-                    AdamHyper hp, const float* __restrict__ bc) {
+learner_adam_kernel(const float* __restrict__ pa, const float* __restrict__ pb, AdamNet na, AdamNet nb, int splits, float inv_scale_a,
+                    float inv_scale_b, AdamHyper hp, const float* __restrict__ bc) {
     const bool second = blockIdx.y == 1;
+    const float inv_scale = second ? inv_scale_b : inv_scale_a;
     const float* __restrict__ partial = second ? pb : pa;
     const AdamNet net = second ? nb : na;
     const uint32_t OUT = (uint32_t)net.g.out_dim;

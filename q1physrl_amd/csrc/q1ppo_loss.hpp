@@ -20,15 +20,15 @@
 // partials[block][5] = sums of (entropy, kl, -surrogate, total, vf) over the block's samples (no atomics; add them up and divide by B).
 // GATHER (the native learner, q1learner.hpp): sample i of the minibatch is row idx[i] of the per-sample inputs (old_logits with
 // old_stride, keys, mouse, logp_old, adv, value_old, vtarg - the whole trajectory batch, never copied); logits / value / dlogits /
-// dvalue are minibatch-local rows i.  out_scale multiplies both gradients (the learner asks for B x the averaged gradient, i.e. the
-// per-sample one, so that it sits in float16's normal range; 1 otherwise); the statistics are unaffected.
+// dvalue are minibatch-local rows i.  out_scale / out_scale_v multiply dlogits / dvalue (the learner asks for B x / (B / 64) x the averaged
+// gradient so that it sits in float16's normal range; 1 otherwise); the statistics are unaffected.
 template <bool GATHER>
 __global__ void __launch_bounds__(256)
 ppo_loss_grad_kernel(Params p, int batch, const float* __restrict__ logits, const float* __restrict__ old_logits, int row_stride, int old_stride,
                      const uint8_t* __restrict__ keys, const float* __restrict__ mouse, const float* __restrict__ logp_old,
                      const float* __restrict__ adv, const float* __restrict__ value, const float* __restrict__ value_old,
                      const float* __restrict__ vtarg, const int64_t* __restrict__ idx, float clip, float vf_clip, float vf_coeff, float ent_coeff,
-                     const float* __restrict__ kl_coeff_dev, float out_scale, float* __restrict__ dlogits, float* __restrict__ dvalue,
+                     const float* __restrict__ kl_coeff_dev, float out_scale, float out_scale_v, float* __restrict__ dlogits, float* __restrict__ dvalue,
                      float* __restrict__ partials) {
     __shared__ float red[4][5];
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -131,7 +131,7 @@ ppo_loss_grad_kernel(Params p, int batch, const float* __restrict__ logits, cons
             }
         }
         for (int c = 2 * nk + (p.yaw_mode == 1 ? 2 : cat_m); c < row_stride; ++c) g[c] = 0.0f;
-        dvalue[i] = vf_coeff * dvf * inv_b;
+        dvalue[i] = vf_coeff * dvf * (out_scale_v / (float)batch);
         st[0] = ent; st[1] = kl; st[2] = -surr; st[3] = -surr + klc * kl + vf_coeff * vf - ent_coeff * ent; st[4] = vf;
     }
 #pragma unroll

@@ -193,7 +193,8 @@ class DeviceEnv:
     def rollout_dev(self, ticks, action_format, act_a=0, act_b=0, rng_seed=0, obs_format=_lib.OBS_F32, obs=0, reward=0,
                     done=0, auto_reset=False, return_sum=0):
         _lib.check(self._lib.q1env_rollout(self._h, ticks, action_format, act_a or None, act_b or None, rng_seed, obs_format,
-                                           obs or None, reward or None, done or None, int(auto_reset), return_sum or None))
+                                           obs or None, reward or None, done or None, int(auto_reset),     # bit 0 + timer flags
+                                           return_sum or None))
 
     def reset_philox_dev(self, seed, mask=0, done_only=False, obs_format=_lib.OBS_F32, obs=0, counter_dev=0):
         _lib.check(self._lib.q1env_reset_philox(self._h, seed, counter_dev or None, mask or None, int(done_only), obs_format, obs or None))

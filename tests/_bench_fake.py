@@ -70,7 +70,7 @@ class FakeDeviceEnv:
     def rollout_dev(self, ticks, action_format, act_a=0, act_b=0, rng_seed=0, obs_format=1, obs=0, reward=0, done=0,
                     auto_reset=False, return_sum=0):
         self.calls.append(("rollout", ticks))
-        self.step_many_dev(ticks, action_format, act_a, act_b, obs_format, obs, reward, done, out_stride_ticks=1, use_graph=0)
+        self.step_many_dev(ticks, action_format, act_a, act_b, obs_format, obs, reward, done, out_stride_ticks=1, use_graph=int(auto_reset) & 12)
         self.calls.pop()
 
     def reset_philox_dev(self, seed, mask=0, done_only=False, obs_format=1, obs=0, counter_dev=0):

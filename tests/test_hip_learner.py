@@ -186,8 +186,47 @@ def test_native_learner_discrete_mouse_head():
     for p in ref.parameters():
         p.grad = None
     lg, vv = ref(obs)
-    assert float((lg - logits).abs().max()) < 5e-3
+    assert float((lg.detach() - logits).abs().max()) < 5e-3
     ((lg * dl).sum() + (vv * dv).sum()).backward()
     for (n_, _), a, b in zip(pol.named_parameters(), got, [p.grad for p in ref.parameters()]):
         assert _rel(a, b) < 3e-3, (n_, _rel(a, b))
+    env.close()
+
+
+def test_native_step_never_produces_non_finite_gradients():
+    """float16 operands saturate instead of overflowing: a training run once turned value errors of a few thousand into inf in dZ1,
+    NaN in the transposition (inf x 0) and NaN weights.  Value targets of 1e3 (the real range) keep the gradients accurate; absurd
+    ones (1e7) must still leave every gradient finite."""
+    import torch
+    from q1physrl_amd import policy as P, ppo, sampler as S
+    torch.manual_seed(2)
+    pol = _policy(3, 3.0)                                   # large weights: large data gradients
+    cfg, env = make_env(1024, time_limit=1.0)
+    smp = S.GpuSampler(env, P.FusedPolicyForward(pol, env), horizon=8)
+    tr = smp.collect()
+    adv, vt = smp.advantages(tr, 0.99, 0.95)
+    t, n = tr["reward"].shape
+    full = {"obs": tr["obs"][:t].reshape(t * n, 6).contiguous(), "old_logits": tr["logits"].reshape(t * n, -1).contiguous(),
+            "keys_packed": tr["keys"].reshape(-1), "mouse": tr["mouse"].reshape(-1), "logp": tr["logp"].reshape(-1),
+            "adv": ((adv - adv.mean()) / adv.std()).reshape(-1).contiguous(), "value": tr["value"][:t].reshape(-1).contiguous(), "vtarg": None}
+    klc = torch.tensor(0.2, device="cuda")
+    nat = ppo.NativeStep(pol, env, t * n, splits=8)
+    ref = None
+    for big in (1.0e3, 1.0e7):
+        full["vtarg"] = (vt.reshape(-1) + big).contiguous()
+        nat.step(full, None, 0.3, 1.0e9, 1.0, 0.01, klc)
+        torch.cuda.synchronize()
+        for name, p in pol.named_parameters():
+            assert bool(torch.isfinite(p.grad).all()), (big, name)
+        if big == 1.0e3:        # still accurate: against autograd of the float32 modules with the same loss
+            ref = copy.deepcopy(pol)
+            for p in ref.parameters():
+                p.grad = None
+            b = {"obs": full["obs"], "old_logits": full["old_logits"], "keys": ((full["keys_packed"].reshape(-1, 1).long() >> torch.arange(4, device="cuda")) & 1),
+                 "mouse": full["mouse"].reshape(-1, 1), "logp": full["logp"], "adv": full["adv"], "value": full["value"], "vtarg": full["vtarg"]}
+            loss, _ = ppo.ppo_loss(ref, b, cfg.action_range, 0.3, 1.0e9, 1.0, 0.01, klc)
+            loss.backward()
+            for (name, p), q in zip(pol.named_parameters(), ref.parameters()):
+                if name.startswith("vf."):
+                    assert _rel(p.grad, q.grad) < 5e-3, (name, _rel(p.grad, q.grad))
     env.close()
