@@ -187,10 +187,12 @@ def size_sweep(dev_index, sizes=(262144, 1048576, 4194304), ticks=72, reps=4):
     return rows
 
 
-def sampler_block(dev_index, n=32768, horizon=64, reps=3):
-    """BASELINE configs[4]'s per-GPU shard next to the contract fields: the env inside a sampler loop with the policy in it (params.yml
-    Config, random-init policy of the reference's shape) - the two-launch tick (fused matrix-core forward + fused sample/step/reset,
-    the horizon captured in a hipGraph) and the resident sampler (one dispatch per horizon + one batched value forward); HIP events."""
+def sampler_block(dev_index, sizes=(32768, 262144), horizon=128, reps=4):
+    """BASELINE configs[4] next to the contract fields: the env inside a sampler loop with the policy in it (params.yml Config,
+    random-init policy of the reference's shape) at the per-GPU shard (32 768 envs) and at the whole batch on ONE GPU (262 144) - the
+    two-launch tick (fused matrix-core forward + fused sample/step/reset, the horizon captured in a hipGraph) and, where its grid is
+    resident (<= 65 536 envs), the resident sampler (one dispatch per horizon + one batched value forward).  128-tick horizons (the
+    training configuration), two warm-up horizons, best of `reps`, HIP events."""
     import torch
     from q1physrl_amd import policy as P
     from q1physrl_amd.env import Config
@@ -199,24 +201,33 @@ def sampler_block(dev_index, n=32768, horizon=64, reps=3):
     params_yml = dict(action_range=10, allow_jump=True, allow_yaw=True, auto_jump=False, discrete_yaw_steps=-1, fmove_max=800, smove_max=1060,
                       hover=False, initial_yaw_range=(0, 360), key_press_delay=0.3, max_initial_speed=700, smooth_keys=True, speed_reward=False,
                       time_delta=0.013888888888888, time_limit=10, zero_start_prob=0.01)
-    row = {"envs": n, "horizon": horizon, "workload": "BASELINE configs[4] shard: sampler loop with the policy forward in it, params.yml Config"}
-    for label, kw in (("two_launch", dict(use_graph=True)), ("resident", dict(resident=True))):
-        env = TensorVectorEnv(Config(num_envs=n, **params_yml), device=dev_index, seed=1)
-        s = GpuSampler(env, P.FusedPolicyForward(P.Q1Policy().cuda(), env), horizon=horizon, **kw)
-        s.collect(); s.collect()
-        torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        best = 1e30
-        for _ in range(reps):
-            env.use_current_stream()
-            e0.record(); s.collect(check_status=False); e1.record(); torch.cuda.synchronize()
-            best = min(best, e0.elapsed_time(e1) * 1e3 / horizon)
-        if label == "resident" and s.resident_status().any():
-            raise RuntimeError(f"resident sampler timed out: status {s.resident_status()}")
-        row[label + "_us_per_tick"] = best
-        row[label + "_env_steps_per_s"] = n / (best * 1e-6)
-        env.close()
-    return row
+    rows = []
+    for n in sizes:
+        row = {"envs": n, "horizon": horizon, "workload": "BASELINE configs[4]: sampler loop with the policy forward in it, params.yml Config"
+               + (" (per-GPU shard of 8)" if n == 32768 else " (the whole batch on one GPU)")}
+        for label, kw in (("two_launch", dict(use_graph=True)), ("resident", dict(resident=True))):
+            if label == "resident" and n > 65536:
+                row["resident"] = "not resident at this size: a workgroup per CU serves at most 256 envs (DESIGN.md section 8)"
+                continue
+            env = TensorVectorEnv(Config(num_envs=n, **params_yml), device=dev_index, seed=1)
+            s = GpuSampler(env, P.FusedPolicyForward(P.Q1Policy().cuda(), env), horizon=horizon, **kw)
+            s.collect(); s.collect()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            best = 1e30
+            for _ in range(reps):
+                env.use_current_stream()
+                e0.record(); s.collect(check_status=False); e1.record(); torch.cuda.synchronize()
+                best = min(best, e0.elapsed_time(e1) * 1e3 / horizon)
+            if label == "resident" and s.resident_status().any():
+                raise RuntimeError(f"resident sampler timed out: status {s.resident_status()}")
+            row[label + "_us_per_tick"] = best
+            row[label + "_env_steps_per_s"] = n / (best * 1e-6)
+            env.close()
+            del s, env
+            torch.cuda.empty_cache()
+        rows.append(row)
+    return rows
 
 
 def load_pmc(mode, n):

@@ -356,8 +356,7 @@ int q1env_learner_step(q1env_t* env, const q1env_learner_net* pi, const q1env_le
  * parameters after a q1env_learner_step with skip_reduce): torch.optim.Adam's update (no weight decay, no amsgrad) on the float32
  * masters IN PLACE, moments and the step count in the caller's adam_state_dev (q1env_learner_adam_state_bytes bytes, zero-initialised;
  * the step count lives on the device, so the call is replayable from a captured graph); gw* / gb* receive the gradients too.
- * grad_scale = the one the POLICY network's partial sums carry (q1env_learner_step: the minibatch size B; the value network's carry
- * B / 64, which this call accounts for - it pairs with q1env_learner_step, not with a hand-made q1env_learner_backward).  adam_state layout: int64 step count at byte 0,
+ * grad_scale = the one the partial sums carry (q1env_learner_step: the minibatch size B).  adam_state layout: int64 step count at byte 0,
  * float bias corrections [2] at byte 8, float running statistics [5] at byte 16 (+= the mean of stats_partials_dev - the step's
  * q1env_learner_batch.stats_partials_dev - per call, if not NULL; the caller zeroes them when it starts a new average), moments from 256. */
 uint64_t q1env_learner_adam_state_bytes(int out_dim_pi);

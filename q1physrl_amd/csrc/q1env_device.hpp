@@ -277,10 +277,12 @@ __device__ __forceinline__ Cmd decode(const Params& p, Env& e, uint32_t keybits,
             keys |= key << k;
         }
     }
-    double lvl[3];
-#pragma unroll
-    for (int k = 0; k < 3; ++k)                                         // env.py:251-254, branch-free and exact on 0/1
-        lvl[k] = ((double)((keys >> k) & 1u) + p.smooth_prev * (double)((prev >> k) & 1u)) * p.smooth_scale;
+    // env.py:251-254: level_k = (key_k + prev_k) * 0.5 with smoothing, key_k without.  Every level is one of {0, 0.5, 1}, so the
+    // difference right - left and the level itself are formed EXACTLY in integers (units of smooth_scale) and converted once: the two
+    // products below see the same float64 operands as the reference's (strafe_right - strafe_left) and forward levels.
+    const int sp = p.smooth_keys ? 1 : 0;
+    const int lr2 = ((int)((keys >> 1) & 1u) - (int)(keys & 1u)) + sp * ((int)((prev >> 1) & 1u) - (int)(prev & 1u));     // (lvl[1] - lvl[0]) / smooth_scale
+    const int fw2 = (int)((keys >> 2) & 1u) + sp * (int)((prev >> 2) & 1u);                                                  // lvl[2] / smooth_scale
     e.flags = (e.flags & 0x7u) | (keys << FLAG_KEYS_SHIFT);             // env.py:256
 
     double dyaw = 0.0;
@@ -289,8 +291,8 @@ __device__ __forceinline__ Cmd decode(const Params& p, Env& e, uint32_t keybits,
     e.yaw = e.yaw + dyaw;                                               // env.py:258
 
     Cmd c;
-    c.smove = trunc(p.smove_max * (lvl[1] - lvl[0])) + 0.0;             // astype(int): toward zero, +0 (env.py:259-260,269)
-    c.fmove = trunc(p.fmove_max * lvl[2]) + 0.0;                        // env.py:261,269
+    c.smove = trunc(p.smove_max * ((double)lr2 * p.smooth_scale)) + 0.0;   // astype(int): toward zero, +0 (env.py:259-260,269)
+    c.fmove = trunc(p.fmove_max * ((double)fw2 * p.smooth_scale)) + 0.0;   // env.py:261,269
     if (cfg_jump_mode<SPEC>(p) == 2) c.jump = z_vel <= 16.0f;           // env.py:263
     else if (cfg_jump_mode<SPEC>(p) == 1) c.jump = (keys >> 3) & 1u;    // env.py:265
     else c.jump = false;                                                // env.py:267

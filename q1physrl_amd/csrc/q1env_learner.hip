@@ -12,7 +12,17 @@ using namespace q1;
 
 namespace {
 
-constexpr float Q1_LEARNER_VALUE_DOWNSCALE = 64.0f;    // q1env_learner_step scales the value network's gradients by B / 64 (float16 range)
+// q1env_learner_step's float16 loss scales: the policy network's per-sample gradients travel multiplied by B x pi_upscale, the value
+// network's by B / value_downscale (q1learner.hpp "Gradient scaling").  Q1_LEARNER_PI_UPSCALE / Q1_LEARNER_VALUE_DOWNSCALE override the
+// defaults (measurement knobs; read once).
+static float learner_pi_upscale() {
+    static const float v = [] { const char* e = getenv("Q1_LEARNER_PI_UPSCALE"); const float f = e ? (float)atof(e) : 1.0f; return f > 0.0f ? f : 1.0f; }();
+    return v;
+}
+static float learner_value_downscale() {
+    static const float v = [] { const char* e = getenv("Q1_LEARNER_VALUE_DOWNSCALE"); const float f = e ? (float)atof(e) : 1.0f; return f > 0.0f ? f : 1.0f; }();
+    return v;
+}
 constexpr size_t IMG_FWD_BYTES = (q1pol::LDS_W2 + q1pol::LDS_W3);           // 152064: float16[288][264]
 constexpr size_t IMG_W2T_BYTES = q1learn::LDS_W2T;                          // 135168
 constexpr size_t IMG_W3T_BYTES = q1learn::LDS_W3T;                          // 20480
@@ -175,7 +185,7 @@ int q1env_learner_step(q1env_t* h, const q1env_learner_net* pi, const q1env_lear
     const Ws w = carve_ws(ws_dev, mb, pi->out_dim, splits);
     if (int r = launch_forward(h, w, mb, pi, vf, b->obs_dev, b->idx_dev, w.logits, w.value)) return r;
     // per-sample (un-averaged) gradients for the policy, 1/64 of that for the value network: float16's normal range (q1learner.hpp)
-    const float scale = (float)mb, scale_v = (float)mb / Q1_LEARNER_VALUE_DOWNSCALE;
+    const float scale = (float)mb * learner_pi_upscale(), scale_v = (float)mb / learner_value_downscale();
     if (b->idx_dev)
         hipLaunchKernelGGL(ppo_loss_grad_kernel<true>, grid_for((int)mb, 256), dim3(256), 0, h->stream, h->p, (int)mb, (const float*)w.logits,
                            b->old_logits_dev, pi->out_dim, b->old_stride, b->keys_dev, b->mouse_dev, b->logp_old_dev, b->adv_dev, (const float*)w.value,
@@ -222,7 +232,7 @@ int q1env_learner_adam(q1env_t* h, const q1env_learner_net* pi, const q1env_lear
     const unsigned max_out = (unsigned)(pi->out_dim > vf->out_dim ? pi->out_dim : vf->out_dim);
     const unsigned elems = 65536u + 256u + 256u * 6u + 256u + max_out * 257u;
     hipLaunchKernelGGL(q1learn::learner_adam_kernel, dim3((elems + 255u) / 256u, 2), dim3(256), 0, h->stream, (const float*)w.net[0].partial,
-                       (const float*)w.net[1].partial, na, nb, splits, 1.0f / grad_scale, Q1_LEARNER_VALUE_DOWNSCALE / grad_scale,
+                       (const float*)w.net[1].partial, na, nb, splits, 1.0f / (grad_scale * learner_pi_upscale()), learner_value_downscale() / grad_scale,
                        q1learn::AdamHyper{lr, beta1, beta2, eps}, (const float*)bc);
     HIP_TRY(hipGetLastError());
     return Q1ENV_OK;

@@ -154,3 +154,25 @@ def test_resident_sampler_shard_equals_the_slice_of_the_whole_batch():
         for k in ("obs", "keys", "mouse", "logp", "logits", "value", "reward", "done"):
             assert torch.equal(whole[h][k][:, base:base + count], shard[h][k]), (h, k)
     assert int(whole[1]["done"].sum()) > 0
+
+
+def test_collect_raises_when_a_resident_wave_reports_a_time_out():
+    """a resident horizon whose status words are non-zero left trajectory rows unwritten; collect() must raise instead of
+    handing stale memory to the learner.  (The status words are forced here: a real time-out needs a dead wave.)"""
+    import torch
+    from q1physrl_amd import policy as P
+    from q1physrl_amd.env import Config
+    from q1physrl_amd.sampler import GpuSampler
+    from q1physrl_amd.tensor_env import TensorVectorEnv
+    env = TensorVectorEnv(Config(**dict(Config.get_default().__dict__, num_envs=512)), device=0, seed=2)
+    s = GpuSampler(env, P.FusedPolicyForward(P.Q1Policy().cuda(), env), horizon=4, resident=True)
+    s.collect()                                   # a healthy horizon: no exception, status all zero
+    assert not s.resident_status().any()
+    s._status[1] = 1
+    s._status[2] = 3
+    with pytest.raises(RuntimeError, match="timed out"):
+        s.collect()
+    s._status.zero_()
+    s.collect(check_status=False)
+    s.check_resident_status()
+    env.close()
