@@ -13,10 +13,13 @@ using namespace q1;
 namespace {
 
 // q1env_learner_step's float16 loss scales: the policy network's per-sample gradients travel multiplied by B x pi_upscale, the value
-// network's by B / value_downscale (q1learner.hpp "Gradient scaling").  Q1_LEARNER_PI_UPSCALE / Q1_LEARNER_VALUE_DOWNSCALE override the
-// defaults (measurement knobs; read once).
+// network's by B / value_downscale (q1learner.hpp "Gradient scaling").  Defaults from round 3's training regressions (profiles/
+// r3_train_ppo_native_*.json): pi_upscale = 256 - the policy head starts with weights of 1e-2 x (RLlib's
+// normc_initializer(0.01)), so dZ2 = W3^T dY and dZ1 behind it sat at 1e-3 .. 1e-6, partly in float16's subnormal range, and one seed
+// of five plateaued at 5 230 instead of ~5 650 until the scale lifted them; value_downscale = 1 (B / 64 cost two of three seeds the
+// same way from the other side).  Outliers saturate (cvt8_sat).  Q1_LEARNER_PI_UPSCALE / Q1_LEARNER_VALUE_DOWNSCALE override (read once).
 static float learner_pi_upscale() {
-    static const float v = [] { const char* e = getenv("Q1_LEARNER_PI_UPSCALE"); const float f = e ? (float)atof(e) : 1.0f; return f > 0.0f ? f : 1.0f; }();
+    static const float v = [] { const char* e = getenv("Q1_LEARNER_PI_UPSCALE"); const float f = e ? (float)atof(e) : 256.0f; return f > 0.0f ? f : 256.0f; }();
     return v;
 }
 static float learner_value_downscale() {

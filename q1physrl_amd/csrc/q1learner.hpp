@@ -27,13 +27,14 @@
 // N-format (per network, per array): f16x8[tile][t = 0..7][ks = 0..1][lane 64]; lane (c, h) = hidden unit 32 t + sigma(c), sigma = swap
 //          bits 2 and 3; element e = sample 32 tile + (e & 3) + 16 ks + 8 (e >> 2) + 4 h.  Both MFMA operands of a weight-gradient
 //          product use the same sample order, so it never has to be undone; sigma is undone by learner_reduce_kernel.
-// Gradient scaling: d loss / d(logits, value) arrive multiplied by `grad_scale` = B (the per-sample, un-averaged gradient: O(1) for the
-// logits, O(1..1000) for the value) so that they and everything derived from them sit in float16's normal range;
-// learner_reduce_kernel / learner_adam_kernel divide the sums by it again.  Outliers (a probability ratio that explodes for one sample,
-// a value error of tens of thousands) SATURATE at float16's largest finite value in every float32 -> float16 conversion of a gradient:
-// an inf would become NaN in the very next transposition (inf x 0 of the selection operand) and from there every weight - which is
-// what the first long training run of a second seed did before the conversions saturated.  (A per-network scale exists in the
-// interface - a value-network scale of B / 64 was tried and cost precision: q1env_learner.hip.)
+// Gradient scaling (loss scaling): d loss / d(logits, value) arrive multiplied by a per-network scale so that they AND everything derived
+// from them (dZ2 = W3^T dY, dZ1 = W2^T dZ2, each times 1 - h^2) sit in float16's normal range: 256 B for the policy network (B makes the
+// gradient per-sample instead of averaged; 256 because the policy head's weights start at 1e-2 x and dZ would otherwise sit at 1e-3 ..
+// 1e-6, partly subnormal - which cost one training seed of five its final 400 reward units), B for the value network (per-sample value
+// errors are O(1..1000) already).  learner_reduce_kernel / learner_adam_kernel divide the sums by the scale again.  Outliers (a
+// probability ratio that explodes for one sample, a value error of tens of thousands) SATURATE at float16's largest finite value in
+// every float32 -> float16 conversion of a gradient: an inf would become NaN in the very next transposition (inf x 0 of the selection
+// operand) and from there every weight - which is what the first long training run of a second seed did before the conversions saturated.
 #pragma once
 #include "q1policy.hpp"
 
