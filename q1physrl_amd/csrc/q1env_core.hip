@@ -136,12 +136,22 @@ __device__ __forceinline__ void rollout_loop(const Params& p, Env& e, uint32_t i
         TickOut<OBS_T> o;
         tick<OBS_T, SPEC>(p, e, keys, yaw_act, o);
         const size_t base = (size_t)t * n;
+#ifndef Q1_ROLLOUT_OUT_STORES          // measurement knob: 0 = plain, 1 = non-temporal per-tick output stores
+#define Q1_ROLLOUT_OUT_STORES 0
+#endif
         if (OUT_MODE == 1 || (OUT_MODE < 0 && obs)) {
-            if constexpr (sizeof(OBS_T) == 4 && FULL) write_obs_wave_f32(obs, base + wave_first, lane, o.obs, slab);
-            else write_obs<OBS_T>(obs, base + i, o.obs);
+            if constexpr (sizeof(OBS_T) == 4 && FULL) {
+                if constexpr (Q1_ROLLOUT_OUT_STORES == 1) write_obs_wave_f32_nt(obs, base + wave_first, lane, o.obs, slab);
+                else write_obs_wave_f32(obs, base + wave_first, lane, o.obs, slab);
+            } else write_obs<OBS_T>(obs, base + i, o.obs);
         }
-        if (OUT_MODE == 1 || (OUT_MODE < 0 && reward)) (reward + base)[i] = o.reward;
-        if (OUT_MODE == 1 || (OUT_MODE < 0 && done)) (done + base)[i] = o.done ? 1 : 0;
+        if constexpr (Q1_ROLLOUT_OUT_STORES == 1) {
+            if (OUT_MODE == 1 || (OUT_MODE < 0 && reward)) __builtin_nontemporal_store(o.reward, reward + base + i);
+            if (OUT_MODE == 1 || (OUT_MODE < 0 && done)) __builtin_nontemporal_store((uint8_t)(o.done ? 1 : 0), done + base + i);
+        } else {
+            if (OUT_MODE == 1 || (OUT_MODE < 0 && reward)) (reward + base)[i] = o.reward;
+            if (OUT_MODE == 1 || (OUT_MODE < 0 && done)) (done + base)[i] = o.done ? 1 : 0;
+        }
         ret += (double)o.reward;
         if constexpr (HAS_RESET) {
             if (auto_reset && o.done) reset_philox(p, e, seed, genv, tick0 + (uint64_t)t + 1);
