@@ -233,8 +233,8 @@ def test_native_step_never_produces_non_finite_gradients():
 
 
 def test_native_training_learns_strafe_jumping_in_seconds():
-    """End-to-end regression of the whole GPU-resident stack (resident sampler + native learner, round 2's hyper-parameters): 160
-    iterations = 0.34 G env-steps in ~15 s must take the zero-start reward from ~1 700 (plain running) past 4 000 - strafe-jumping
+    """End-to-end regression of the whole GPU-resident stack (resident sampler + native learner, round 2's hyper-parameters): 200
+    iterations = 0.42 G env-steps in ~17 s must take the zero-start reward from ~1 700 (plain running) past 4 200 - strafe-jumping
     discovered - with finite statistics all the way.  (The full 1 300-iteration runs, 5 643-5 686 in 106-108 s for five seeds, are in
     profiles/r3_train_ppo_native_s*.json.)"""
     import json
@@ -242,7 +242,7 @@ def test_native_training_learns_strafe_jumping_in_seconds():
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, os.path.join(root, "tools", "train_ppo.py"), "--iters", "160", "--envs", "16384", "--horizon", "128", "--lr", "3e-5",
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "train_ppo.py"), "--iters", "200", "--envs", "16384", "--horizon", "128", "--lr", "3e-5",
                         "--epochs", "8", "--minibatch", "32768", "--entropy", "0.01", "--kl-target", "0.0036", "--fused-policy", "--resident",
                         "--fused-loss", "--native", "--seed", "0"], capture_output=True, text=True, timeout=600, cwd=root,
                        env=dict(os.environ, Q1_TUNABLEOP="0"))
@@ -250,5 +250,6 @@ def test_native_training_learns_strafe_jumping_in_seconds():
     rows = [json.loads(ln) for ln in r.stdout.splitlines() if ln.startswith("{")]
     its = [x for x in rows if "iter" in x]
     assert its and all(np.isfinite([x["kl"], x["entropy"], x["vf_loss"]]).all() for x in its)
-    assert its[0]["zero_start_total_reward_mean"] < 2500.0 < 4000.0 < its[-1]["zero_start_total_reward_mean"], (its[0], its[-1])
+    zs = [x["zero_start_total_reward_mean"] for x in its if np.isfinite(x["zero_start_total_reward_mean"])]     # (no zero-start episode ends in iteration 0)
+    assert zs[0] < 2500.0 < 4200.0 < zs[-1], (zs[0], zs[-1])
     assert its[-1]["iter_s"] < 0.2                                  # <= 0.2 s per iteration (measured 0.08)
