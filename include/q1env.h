@@ -485,6 +485,13 @@ int q1env_debug_counters(q1env_t* env, uint64_t* out4, int clear);
  * 180, 90, 100, 200, c0, c1; writes 4 mismatch counts (all must be 0).
  * timer_*: HIP events recorded on the handle's stream. */
 int q1env_selftest_division(int device, uint64_t n, uint64_t seed, double c0, double c1, uint64_t* mismatches4);
+/* (ABI v3) selftest_trig: the tick's own sin / cos of a yaw (radians = yaw*pi/180 with the exact constant division, then the in-line
+ * sincos of csrc/q1env_device.hpp that replaces the device library's on the tick: phys.py:56-66) for n HOST yaw values in degrees;
+ * writes sin and cos to the host arrays (the caller compares them with its own libm: <= 1 ulp, a few % of values differ) and
+ * counts[0] = results that differ from the device library's sincos, counts[1] = the largest such difference in ulps,
+ * counts[2] = mismatches of the scaling-free square root (sqrt_normal) against the compiler's sqrt on n random operands in
+ * [2^-700, 2^700] (must be 0), counts[3] = 0. */
+int q1env_selftest_trig(int device, uint64_t n, const double* yaw_deg, double* sin_out, double* cos_out, uint64_t seed, uint64_t* counts4);
 int q1env_calibrate_traffic(q1env_t* env, int launches);
 int q1env_timer_start(q1env_t* env);
 int q1env_timer_stop(q1env_t* env, float* elapsed_ms);   /* = timer_mark + timer_elapsed: synchronises on the stop event */

@@ -128,6 +128,7 @@ _SIGNATURES = {
     "q1env_policy_forward_rows": (C.c_int, [_P, C.c_uint64, _P, _P]),
     "q1env_sample_resident": (C.c_int, [_P, _P]),
     "q1env_selftest_division": (C.c_int, [C.c_int, C.c_uint64, C.c_uint64, C.c_double, C.c_double, C.POINTER(C.c_uint64)]),
+    "q1env_selftest_trig": (C.c_int, [C.c_int, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]),
     "q1env_calibrate_traffic": (C.c_int, [_P, C.c_int]),
     "q1env_timer_start": (C.c_int, [_P]),
     "q1env_timer_stop": (C.c_int, [_P, C.POINTER(C.c_float)]),

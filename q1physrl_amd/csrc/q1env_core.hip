@@ -117,6 +117,7 @@ __device__ __forceinline__ void rollout_loop(const Params& p, Env& e, uint32_t i
         // back edge - it no longer has to cover the preheader's load order and does not drain the tick's stores.
         __builtin_amdgcn_s_waitcnt(0x0F70);    // vmcnt(0), expcnt/lgkmcnt untouched
     }
+    const TickConsts tc = tick_consts();
     for (int t = 0; t < ticks; ++t) {
         double yaw_act;
         uint32_t keys;
@@ -134,7 +135,7 @@ __device__ __forceinline__ void rollout_loop(const Params& p, Env& e, uint32_t i
             keys = fetch_action<SPEC, FMT>(p, fmt, act_a, act_b, (size_t)t * n + i, &yaw_act);
         }
         TickOut<OBS_T> o;
-        tick<OBS_T, SPEC>(p, e, keys, yaw_act, o);
+        tick<OBS_T, SPEC>(p, tc, e, keys, yaw_act, o);
         const size_t base = (size_t)t * n;
         // The per-tick outputs are written once and read by a later kernel / the host: non-temporal stores (no reason to keep 34 B per
         // env-step dirty in L2 until the launch ends and its release writes them back).  A/B on MI355X, 65 536 envs (Q1_ROLLOUT_OUT_STORES
@@ -163,7 +164,7 @@ __device__ __forceinline__ void rollout_loop(const Params& p, Env& e, uint32_t i
 }
 
 template <typename OBS_T, bool SPEC, int FMT, bool HAS_RESET, int OUT_MODE>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4)))
 rollout_kernel(Params p, StatePtrs s, int ticks, int fmt, const void* act_a, const void* act_b,
                uint64_t seed, uint64_t tick0, OBS_T* obs, float* reward, uint8_t* done,
                int auto_reset, double* return_sum) {
@@ -181,8 +182,12 @@ rollout_kernel(Params p, StatePtrs s, int ticks, int fmt, const void* act_a, con
     else
         rollout_loop<OBS_T, SPEC, FMT, HAS_RESET, OUT_MODE, false>(p, e, i, n, ticks, fmt, act_a, act_b, seed, tick0, obs, reward,
                                                                     done, auto_reset, ret, my_slab);
-    store_env(s, n, i, e);
-    if (return_sum) return_sum[i] += ret;
+    // The final stores address the arrays from a laundered copy of the index: the twelve 64-bit addresses of the initial loads
+    // would otherwise stay in registers across the whole tick loop (24 VGPRs on top of the state and the tick's constants).
+    uint32_t i_st = i;
+    asm volatile("" : "+v"(i_st));
+    store_env(s, n, i_st, e);
+    if (return_sum) return_sum[i_st] += ret;
 }
 
 template <typename OBS_T>
@@ -298,7 +303,7 @@ phys_apply_kernel(int n, const double* yaw, const double* pitch, const double* r
     const double m10 = cp * sy;
     const double m11 = ((-1.0 * sr) * sp) * sy + (-1.0 * cr) * cy;
     const double dt = time_delta[i];
-    physics_core<VT>(vx, vy, vz, z, flags, c, m00, m01, m10, m11, dt, 10.0 * dt, 800.0 * dt);
+    physics_core<VT, false>(make_tick_consts<false>(), vx, vy, vz, z, flags, c, m00, m01, m10, m11, dt, 10.0 * dt, 800.0 * dt);
     out_z[i] = z;
     out_vel[3 * (size_t)i] = vx; out_vel[3 * (size_t)i + 1] = vy; out_vel[3 * (size_t)i + 2] = vz;
     out_og[i] = (flags & FLAG_ON_GROUND) ? 1 : 0;

@@ -105,6 +105,46 @@ struct TickOut {
     bool done;
 };
 
+// ---------------------------------------------------------------------------------------- float64 selects
+// `c ? a : b` on float64 compiles to v_cmp -> VCC and two VOP2 v_cndmask_b32 ..., vcc.  On gfx950 the second of two back-to-back
+// VOP2 v_cndmask_b32 on a freshly written VCC stalls for ~13 ns when all four SIMDs of the CU are busy: 20 ns per select against
+// 8-10 ns with the mask in an SGPR pair and the VOP3 encoding (tools/ubench_select.hip, profiles/r3_ubench_select.txt) - and the tick
+// had twelve.  Most became v_max / v_min (see physics_core); the rest go through these helpers.  mask = __ballot(condition), which
+// folds into the v_cmp that computes the condition (combine conditions as masks, with &, not as booleans).  s_nop 1: the two wait states between a VALU write of an SGPR and a VALU read of
+// it, which the compiler cannot see into the assembly to provide.
+// In-place forms (the value that is kept where the mask is clear is the in/out operand: no copies around the assembly; early-clobber,
+// because an input that happens to hold the same value would otherwise be given the same register and be overwritten mid-sequence).
+__device__ __forceinline__ void select_into_f64(uint64_t mask, double a, double& r) {                 // r = mask ? a : r
+    uint32_t lo = (uint32_t)__double2loint(r), hi = (uint32_t)__double2hiint(r);
+    asm("s_nop 1\n\tv_cndmask_b32_e64 %0, %0, %2, %4\n\tv_cndmask_b32_e64 %1, %1, %3, %4"
+        : "+&v"(lo), "+&v"(hi) : "v"(__double2loint(a)), "v"(__double2hiint(a)), "s"(mask));
+    r = __hiloint2double((int)hi, (int)lo);
+}
+__device__ __forceinline__ void select2_into_f64(uint64_t mask, double a0, double& r0, double a1, double& r1) {
+    uint32_t lo0 = (uint32_t)__double2loint(r0), hi0 = (uint32_t)__double2hiint(r0);
+    uint32_t lo1 = (uint32_t)__double2loint(r1), hi1 = (uint32_t)__double2hiint(r1);
+    asm("s_nop 1\n\tv_cndmask_b32_e64 %0, %0, %4, %8\n\tv_cndmask_b32_e64 %1, %1, %5, %8\n\t"
+        "v_cndmask_b32_e64 %2, %2, %6, %8\n\tv_cndmask_b32_e64 %3, %3, %7, %8"
+        : "+&v"(lo0), "+&v"(hi0), "+&v"(lo1), "+&v"(hi1)
+        : "v"(__double2loint(a0)), "v"(__double2hiint(a0)), "v"(__double2loint(a1)), "v"(__double2hiint(a1)), "s"(mask));
+    r0 = __hiloint2double((int)hi0, (int)lo0);
+    r1 = __hiloint2double((int)hi1, (int)lo1);
+}
+// four values, four masks, one replacement (the decoder's key-press timestamps): r[k] = m[k] ? a : r[k]
+__device__ __forceinline__ void select4_into_f64(uint64_t m0, uint64_t m1, uint64_t m2, uint64_t m3, double a, double r[4]) {
+    uint32_t lo[4], hi[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { lo[k] = (uint32_t)__double2loint(r[k]); hi[k] = (uint32_t)__double2hiint(r[k]); }
+    asm("s_nop 1\n\tv_cndmask_b32_e64 %0, %0, %8, %10\n\tv_cndmask_b32_e64 %1, %1, %9, %10\n\t"
+        "v_cndmask_b32_e64 %2, %2, %8, %11\n\tv_cndmask_b32_e64 %3, %3, %9, %11\n\t"
+        "v_cndmask_b32_e64 %4, %4, %8, %12\n\tv_cndmask_b32_e64 %5, %5, %9, %12\n\t"
+        "v_cndmask_b32_e64 %6, %6, %8, %13\n\tv_cndmask_b32_e64 %7, %7, %9, %13"
+        : "+&v"(lo[0]), "+&v"(hi[0]), "+&v"(lo[1]), "+&v"(hi[1]), "+&v"(lo[2]), "+&v"(hi[2]), "+&v"(lo[3]), "+&v"(hi[3])
+        : "v"(__double2loint(a)), "v"(__double2hiint(a)), "s"(m0), "s"(m1), "s"(m2), "s"(m3));
+#pragma unroll
+    for (int k = 0; k < 4; ++k) r[k] = __hiloint2double((int)hi[k], (int)lo[k]);
+}
+
 // ---------------------------------------------------------------------------------------- exact division
 // x / c for a run-time CONSTANT c > 0 whose correctly rounded reciprocal y = RN(1/c) was computed once on the
 // host.  q0 = RN(x*y) is within 1.5 ulp of x/c; one FMA correction step (r = x - q*c exactly, q' = RN(q + r*y))
@@ -144,6 +184,124 @@ __device__ __forceinline__ double div_shared(double a, double b, double y) {
     const double q = a * y;
     const double r = fma(-b, q, a);
     return fma(r, y, q);          // a = +0 -> +0; a is never -0 here (einsum sums start from +0.0)
+}
+
+// sqrt(a) for 2^-767 <= a < inf: the compiler's correctly rounded float64 expansion (v_rsq_f64, one coupled Goldschmidt step,
+// two residual corrections) without the ldexp scaling of tiny inputs and the zero / infinity pass-through around it.
+__device__ __forceinline__ double sqrt_normal(double a) {
+    const double y = __builtin_amdgcn_rsq(a);
+    double g = a * y;
+    double h = y * 0.5;
+    const double r = fma(-h, g, 0.5);
+    g = fma(g, r, g);
+    h = fma(h, r, h);
+    double d = fma(-g, g, a);
+    g = fma(d, h, g);
+    d = fma(-g, g, a);
+    return fma(d, h, g);
+}
+
+// ---------------------------------------------------------------------------------------- sin / cos of the yaw
+// The tick needs sin and cos of rad = yaw*pi/180, |rad| <~ 130 in an episode.  The library's sincos costs ~75 VALU instructions
+// per tick in the fused kernels: a 17-instruction three-constant reduction written without FMA exactness in mind, ten v_mov_b64
+// that re-load polynomial coefficients into the accumulator of a two-address v_fmac_f64, NaN / infinity selects, and a Payne-Hanek
+// branch.  This restatement keeps the library's accuracy (fdlibm's __kernel_sin / __kernel_cos on a hi + lo reduced argument: against
+// glibc - what NumPy calls - 3.1 % of results differ, by 1 ulp, over yaw in +-7500 degrees; tools/sincos_accuracy.c) at 43:
+//   * n = rint(x 2/pi) and its integer come from ONE fma with the 1.5 2^52 bias (low word = n, two's complement)
+//   * r0 = fma(-n, P1, x) is EXACT (P1 = RN(pi/2); n P1 is a multiple of 2^-52 and |r0| < 1), so hi = RN(r0 - n P2) and
+//     lo = ((r0 - hi) - n P2) - n P3 need four more instructions (fdlibm spends three Cody-Waite rounds to get the same)
+//   * the polynomial steps are three-address v_fma_f64 with the coefficient in a register pair (inline assembly: the compiler's own
+//     selection is the two-address v_fmac_f64 + v_mov_b64)
+// Lanes with |x| >= 2^20 (or NaN) send the whole wave to the library's sincos (never in an episode: yaw is unwrapped degrees).
+__device__ __forceinline__ double fma3(double a, double b, double c) {
+    double d;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+// The tick's float64 constants as opaque 64-bit register values: the eleven polynomial coefficients and the six thresholds whose
+// low word is zero.  A kernel with a tick loop makes them ONCE, before the loop: inline assembly is not speculated, so the compiler
+// cannot hoist it itself; without the opaque copy it assembles each coefficient pair from separately kept halves with a v_mov_b32
+// per use, and re-builds each threshold in an SGPR pair with two s_mov_b32 per tick - and on a lone wave a scalar instruction costs
+// the same 2.2 ns issue slot as a vector one (tools/ubench_select.hip).
+struct TickConsts {
+    double s2, s3, s4, s5, s6, c1, c2, c3, c4, c5, c6;
+    double neg_bias, two20, tiny_wish, tiny_speed, max_wish;
+    bool hoisted;                                                       // compile-time after inlining: which tick_consts*() made it
+    // one Horner step z * acc + coefficient: three-address v_fma_f64 on the register-resident coefficient in a loop kernel, the
+    // compiler's own choice in a single-tick kernel (where pinning 32 registers would cost the HBM-bound kernels their occupancy)
+    __device__ __forceinline__ double horner(double z, double acc, double coeff) const {
+        return hoisted ? fma3(z, acc, coeff) : fma(z, acc, coeff);
+    }
+};
+__device__ __forceinline__ double opaque_vgpr(double c) {
+    asm("" : "+v"(c));
+    return c;
+}
+template <bool HOISTED>
+__device__ __forceinline__ double tick_const(double c) { return HOISTED ? opaque_vgpr(c) : c; }
+template <bool HOISTED>
+__device__ __forceinline__ TickConsts make_tick_consts() {
+    TickConsts t;                                                       // fdlibm k_sin.c S2..S6, k_cos.c C1..C6
+    t.s2 = tick_const<HOISTED>(8.33333333332248946124e-03);  t.s3 = tick_const<HOISTED>(-1.98412698298579493134e-04);
+    t.s4 = tick_const<HOISTED>(2.75573137070700676789e-06);  t.s5 = tick_const<HOISTED>(-2.50507602534068634195e-08);
+    t.s6 = tick_const<HOISTED>(1.58969099521155010221e-10);
+    t.c1 = tick_const<HOISTED>(4.16666666666666019037e-02);  t.c2 = tick_const<HOISTED>(-1.38888888888741095749e-03);
+    t.c3 = tick_const<HOISTED>(2.48015872894767294178e-05);  t.c4 = tick_const<HOISTED>(-2.75573143513906633035e-07);
+    t.c5 = tick_const<HOISTED>(2.08757232129817482790e-09);  t.c6 = tick_const<HOISTED>(-1.13596475577881948265e-11);
+    t.neg_bias = tick_const<HOISTED>(-6755399441055744.0);              // -1.5 * 2^52
+    t.two20 = tick_const<HOISTED>(1048576.0);
+    t.tiny_wish = tick_const<HOISTED>(0x1p-600);
+    t.tiny_speed = tick_const<HOISTED>(0x1p-100);
+    t.max_wish = tick_const<HOISTED>(320.0);
+    t.hoisted = HOISTED;
+    return t;
+}
+// before a tick loop: the constants pinned in registers
+__device__ __forceinline__ TickConsts tick_consts() { return make_tick_consts<true>(); }
+
+__device__ __forceinline__ void sincos_yaw(const TickConsts& k, double x, double& sn_out, double& cs_out) {
+    const double nb = fma(x, 0.6366197723675814, -k.neg_bias);          // + 1.5 * 2^52: the low word is n (two's complement)
+    const uint32_t q = (uint32_t)__double2loint(nb);                    // n mod 2^32 (only bits 0 and 1 are used)
+    const double n = nb + k.neg_bias;
+    const double r0 = fma(-n, 1.5707963267948966, x);                   // exact
+    const double hi = fma(-n, 6.123233995736766e-17, r0);
+    double lo = fma(-n, 6.123233995736766e-17, r0 - hi);
+    lo = fma(-n, -1.4973849048591698e-33, lo);
+    const double z = hi * hi;
+    // sin: hi - ((z (lo/2 - v r) - lo) - v S1), r = S2 + z (S3 + z (S4 + z (S5 + z S6)))       cos: w + (((1 - w) - z/2) + (z^2 c - hi lo)),
+    // w = 1 - z/2, c = C1 + z (C2 + z (C3 + z (C4 + z (C5 + z C6))))                           (fdlibm k_sin.c / k_cos.c)
+    double rs = k.horner(z, k.s6, k.s5);
+    double rc = k.horner(z, k.c6, k.c5);
+    const double v = z * hi;
+    const double hz = 0.5 * z;
+    rs = k.horner(z, rs, k.s4);
+    rc = k.horner(z, rc, k.c4);
+    const double w = 1.0 - hz;
+    const double zz = z * z;
+    rs = k.horner(z, rs, k.s3);
+    rc = k.horner(z, rc, k.c3);
+    double e = (1.0 - w) - hz;
+    rs = k.horner(z, rs, k.s2);
+    rc = k.horner(z, rc, k.c2);
+    e = fma(hi, -lo, e);
+    double t = fma(-v, rs, 0.5 * lo);
+    rc = k.horner(z, rc, k.c1);
+    t = fma(z, t, -lo);
+    e = fma(zz, rc, e);
+    t = fma(-v, -1.66666666666666324348e-01, t);
+    const double cs = w + e;
+    const double sn = hi - t;
+    // quadrant: sin(x) = {sn, cs, -sn, -cs}[n & 3], cos(x) = {cs, -sn, -cs, sn}[n & 3]
+    const bool odd = q & 1u;
+    const uint32_t flip = (q << 30) & 0x80000000u;                      // bit 1 of n -> the sign bit
+    double s_sel = sn, c_sel = cs;
+    select2_into_f64(__ballot(odd), cs, s_sel, -sn, c_sel);
+    sn_out = __hiloint2double(__double2hiint(s_sel) ^ (int)flip, __double2loint(s_sel));
+    cs_out = __hiloint2double(__double2hiint(c_sel) ^ (int)flip, __double2loint(c_sel));
+    // |x| >= 2^20 or NaN anywhere in the wave: the library's path for the whole wave.  (The results pass through an empty asm first so
+    // that the compiler cannot sink their last instructions into an else-side of this branch: one untaken s_cbranch per tick, not two.)
+    if (k.hoisted) asm("" : "+v"(sn_out), "+v"(cs_out));
+    if (__builtin_expect(__ballot(!(fabs(x) < k.two20)) != 0ull, 0)) sincos(x, &sn_out, &cs_out);
 }
 
 // ---------------------------------------------------------------------------------------- state I/O
@@ -267,16 +425,18 @@ __device__ __forceinline__ Cmd decode(const Params& p, Env& e, uint32_t keybits,
     const uint32_t prev = (e.flags >> FLAG_KEYS_SHIFT) & 0xFu;
     const int nk = cfg_num_keys<SPEC>(p);
     uint32_t keys = 0;
+    uint64_t rising[4] = {0ull, 0ull, 0ull, 0ull};
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         if (k < nk) {
             const bool may_press = now >= e.lk[k] + p.key_press_delay;  // float64 compare (env.py:241-242)
             const uint32_t pk = (prev >> k) & 1u;
             const uint32_t key = ((keybits >> k) & 1u) & ((may_press ? 1u : 0u) | pk);   // env.py:243
-            e.lk[k] = (key & ~pk & 1u) ? now : e.lk[k];                 // rising edge (env.py:244-248)
+            rising[k] = __ballot((key & ~pk & 1u) != 0u);               // rising edge (env.py:244-248)
             keys |= key << k;
         }
     }
+    select4_into_f64(rising[0], rising[1], rising[2], rising[3], now, e.lk);
     // env.py:251-254: level_k = (key_k + prev_k) * 0.5 with smoothing, key_k without.  Every level is one of {0, 0.5, 1}, so the
     // difference right - left and the level itself are formed EXACTLY in integers (units of smooth_scale) and converted once: the two
     // products below see the same float64 operands as the reference's (strafe_right - strafe_left) and forward levels.
@@ -302,43 +462,53 @@ __device__ __forceinline__ Cmd decode(const Params& p, Env& e, uint32_t keybits,
 // ---------------------------------------------------------------------------------------- physics
 // phys.apply for one env (phys.py:184-197).  The 2x2 basis (forward | right, phys.py:65-66) is passed in:
 // the env always has pitch = roll = 0, i.e. m = [[cos, sin], [sin, -cos]].
-// Per-lane conditions are selects, not branches, so the whole tick stays one basic block; the only branch is the
-// wave-level ballot of the PREVIOUS tick's on_ground: a wave with nobody on the ground skips the friction block
-// (float32 sqrt + float64 divide) through a wave-uniform s_cbranch.
+// Per-lane conditions are selects (or v_max / v_min), not branches; the only branch is the wave-level ballot of the PREVIOUS
+// tick's on_ground: a wave with nobody on the ground skips the friction block (float32 sqrt + float64 divide) through a
+// wave-uniform s_cbranch (an untaken branch costs a lone wave ~10 ns, four instructions' worth: tools/ubench_select.hip).
 // VT = the dtype PlayerState.vel arrives in: float for the env (float32 storage: friction speed / control and the +270 add are
 // float32 islands, the result is rounded to float32 on store, phys.py:190), double for DataFrame-driven callers
 // (PlayerState.from_df yields a float64 vel, phys.py:168-170: then NOTHING on the path is float32).
-template <typename VT>
-__device__ __forceinline__ void physics_core(VT& vx, VT& vy, VT& vz, double& zpos, uint32_t& flags, const Cmd& c,
+// NORMAL = the caller guarantees |wish_vel|^2 is 0 or within [2^-700, 2^700] (the SPEC kernels: fmove_max / smove_max are checked on
+// the host, q1env_host.hpp is_spec): the square root is then the compiler's own correctly rounded expansion minus its input scaling
+// (an identity for 2^-767 <= x).
+template <typename VT, bool NORMAL>
+__device__ __forceinline__ void physics_core(const TickConsts& k_, VT& vx, VT& vy, VT& vz, double& zpos, uint32_t& flags, const Cmd& c,
                                              double m00, double m01, double m10, double m11,
                                              double dt, double accel_dt, double grav_dt) {
     const bool og = flags & FLAG_ON_GROUND;
+    const uint64_t og_mask = __ballot(og);
     // einsum('ijk,ik->ij') accumulates from +0.0 (phys.py:97)
     const double wx = (0.0 + m00 * c.fmove) + m01 * c.smove;
     const double wy = (0.0 + m10 * c.fmove) + m11 * c.smove;
-    const double wlen = sqrt(wx * wx + wy * wy);                        // phys.py:98
-    const bool has_wish = wlen > 0.0;
-    const double wden = has_wish ? wlen : 1.0;                          // keep the unused quotient finite
-    const double yw = rcp_refined(wden);
-    const double dx = has_wish ? div_shared(wx, wden, yw) : wx;         // phys.py:99-101
-    const double dy = has_wish ? div_shared(wy, wden, yw) : wy;
-    const double wish_speed = fmin(320.0, wlen);                        // phys.py:103
+    // |wish_vel| (phys.py:98), with 2^-300 standing in where there is none.  The stand-in changes no result: without a wish
+    // wx = wy = +0 (the einsum sums start from +0.0), so wish_dir = +0 / 2^-300 = +0 = the reference's pass-through (phys.py:99-101),
+    // and the acceleration - some tiny positive number instead of 0 - multiplies +0: vel + (+0) either way.  One v_max_f64 instead of
+    // the selects around the square root, the reciprocal and the two quotients.
+    const double wsq = fmax(wx * wx + wy * wy, k_.tiny_wish);
+    double wlen;
+    if constexpr (NORMAL) wlen = sqrt_normal(wsq);
+    else wlen = sqrt(wsq);
+    const double yw = rcp_refined(wlen);
+    const double dx = div_shared(wx, wlen, yw);                         // phys.py:99-101
+    const double dy = div_shared(wy, wlen, yw);
+    const double wish_speed = fmin(k_.max_wish, wlen);                  // phys.py:103 (320)
 
     double hx = (double)vx, hy = (double)vy;
-    if (__ballot(og)) {                                                 // wave-uniform skip
+    if (og_mask) {                                                      // wave-uniform skip
         VT speed, control;                                              // norm / control in the velocity's own dtype (phys.py:85-86)
         if constexpr (sizeof(VT) == 4) { speed = sqrtf(vx * vx + vy * vy); control = fmaxf(speed, 100.0f); }
         else { speed = sqrt(vx * vx + vy * vy); control = fmax(speed, 100.0); }
-        const bool fr = og && speed > (VT)0;
         const double drop = (dt * (double)control) * 4.0;               // phys.py:87
         const double ns = fmax(0.0, (double)speed - drop);              // phys.py:88
-        const double sd = fr ? (double)speed : 1.0;
+        const double sd = fmax((double)speed, k_.tiny_speed);                // (speed == 0: any divisor, the quotient is not used)
         const double k = div_shared(ns, sd, rcp_refined(sd));           // phys.py:90 (exact: operands in the normal range)
-        hx = fr ? (double)vx * k : hx;
-        hy = fr ? (double)vy * k : hy;
+        select2_into_f64(og_mask & __ballot(speed > (VT)0), (double)vx * k, hx, (double)vy * k, hy);
     }
     const double cur = (0.0 + hx * dx) + hy * dy;                       // phys.py:71
-    const double capped = (wish_speed > 30.0 && !og) ? 30.0 : wish_speed;   // phys.py:73-75
+    // phys.py:73-75: in the air a wish_speed above 30 is clipped to 30.  wish_speed <= 320, so min(wish_speed, og ? 320 : 30) is
+    // the same number, and the two bounds differ in the high word only: one 32-bit select
+    const double cap = __hiloint2double(og ? 0x40740000 : 0x403e0000, 0);                   // 320.0 : 30.0
+    const double capped = fmin(wish_speed, cap);
     const double add = fmax(0.0, capped - cur);                         // phys.py:77
     const double acc = fmin(accel_dt * wish_speed, add);                // phys.py:78 (unclipped wish_speed)
     vx = (VT)(hx + acc * dx);                                           // phys.py:80, RNE to float32 at phys.py:190
@@ -351,22 +521,24 @@ __device__ __forceinline__ void physics_core(VT& vx, VT& vy, VT& vz, double& zpo
     z_vel = (VT)((double)z_vel - grav_dt);                              // float64 subtract, RNE (phys.py:122)
     const double z = zpos + dt * (double)z_vel;                         // phys.py:127
     const bool landed = z < 24.03125;                                   // phys.py:128
-    zpos = landed ? 24.03125 : z;                                       // phys.py:129
+    zpos = fmax(z, 24.03125);                                           // phys.py:129 (landed ? floor : z)
     vz = landed ? (VT)0 : z_vel;                                        // phys.py:130
     flags = (fl & ~FLAG_ON_GROUND) | (landed ? FLAG_ON_GROUND : 0u);
 }
 
-__device__ __forceinline__ void physics(Env& e, const Cmd& c, double m00, double m01, double m10, double m11,
+template <bool NORMAL>
+__device__ __forceinline__ void physics(const TickConsts& k_, Env& e, const Cmd& c, double m00, double m01, double m10, double m11,
                                         double dt, double accel_dt, double grav_dt) {
-    physics_core<float>(e.vx, e.vy, e.vz, e.z, e.flags, c, m00, m01, m10, m11, dt, accel_dt, grav_dt);
+    physics_core<float, NORMAL>(k_, e.vx, e.vy, e.vz, e.z, e.flags, c, m00, m01, m10, m11, dt, accel_dt, grav_dt);
 }
 
 // yaw -> basis with pitch = roll = 0 (phys.py:56-66): radians = yaw*pi/180 (mul THEN div), float64 sincos
-__device__ __forceinline__ void physics_yaw_only(const Params& p, Env& e, const Cmd& c) {
+template <bool SPEC>
+__device__ __forceinline__ void physics_yaw_only(const Params& p, const TickConsts& tc, Env& e, const Cmd& c) {
     const double rad = div_const<double>(e.yaw * 3.141592653589793, 180.0, 1.0 / 180.0);
     double sn, cs;
-    sincos(rad, &sn, &cs);
-    physics(e, c, cs, sn, sn, -cs, p.dt, p.accel_dt, p.grav_dt);
+    sincos_yaw(tc, rad, sn, cs);
+    physics<SPEC>(tc, e, c, cs, sn, sn, -cs, p.dt, p.accel_dt, p.grav_dt);
 }
 
 // env.py:392-400 with _round_origin (385-390), _round_vel (381-383), get_obs_scale (294-296).
@@ -392,11 +564,12 @@ __device__ __forceinline__ void observe(const Params& p, const Env& e, OBS_T o[6
 }
 
 // VectorPhysEnv.vector_step for one env (env.py:482-510)
+// tc: tick_consts(), made before the tick loop by the kernels that have one
 template <typename OBS_T, bool SPEC>
-__device__ __forceinline__ void tick(const Params& p, Env& e, uint32_t keybits, double yaw_act, TickOut<OBS_T>& out) {
+__device__ __forceinline__ void tick(const Params& p, const TickConsts& tc, Env& e, uint32_t keybits, double yaw_act, TickOut<OBS_T>& out) {
     if (cfg_hover<SPEC>(p)) { e.vz = 0.0f; e.z = 100.0; }               // env.py:483-485
     const Cmd c = decode<SPEC>(p, e, keybits, yaw_act, e.vz, e.trem);
-    physics_yaw_only(p, e, c);
+    physics_yaw_only<SPEC>(p, tc, e, c);
     if (cfg_speed_reward<SPEC>(p)) out.reward = p.dt_f32 * sqrtf(e.vx * e.vx + e.vy * e.vy);   // env.py:501 (float32)
     else out.reward = p.dt_f32 * e.vy;                                  // env.py:503 (float32)
     e.px = e.px + p.dt * (double)e.vx;                                  // extension: distance integrals
@@ -404,6 +577,11 @@ __device__ __forceinline__ void tick(const Params& p, Env& e, uint32_t keybits, 
     e.trem = e.trem - p.dt;                                             // env.py:505
     out.done = e.trem < 0.0;                                            // env.py:506
     observe<OBS_T>(p, e, out.obs);
+}
+
+template <typename OBS_T, bool SPEC>
+__device__ __forceinline__ void tick(const Params& p, Env& e, uint32_t keybits, double yaw_act, TickOut<OBS_T>& out) {
+    tick<OBS_T, SPEC>(p, make_tick_consts<false>(), e, keybits, yaw_act, out);
 }
 
 // ---------------------------------------------------------------------------------------- resets

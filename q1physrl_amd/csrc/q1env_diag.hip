@@ -88,6 +88,54 @@ int q1env_selftest_division(int device, uint64_t n, uint64_t seed, double c0, do
     return Q1ENV_OK;
 }
 
+__global__ void __launch_bounds__(256)
+selftest_trig_kernel(uint64_t n, const double* yaw_deg, double* sin_out, double* cos_out, uint64_t seed, unsigned long long* counts) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double rad = div_const<double>(yaw_deg[i] * 3.141592653589793, 180.0, 1.0 / 180.0);   // physics_yaw_only's radians
+    double sn, cs, sl, cl;
+    sincos_yaw(tick_consts(), rad, sn, cs);
+    sincos(rad, &sl, &cl);
+    sin_out[i] = sn;
+    cos_out[i] = cs;
+    const long long ds = llabs(__double_as_longlong(sn) - __double_as_longlong(sl));             // (same sign and binade up to an ulp)
+    const long long dc = llabs(__double_as_longlong(cs) - __double_as_longlong(cl));
+    if (ds) { atomicAdd(&counts[0], 1ull); atomicMax(&counts[1], (unsigned long long)ds); }
+    if (dc) { atomicAdd(&counts[0], 1ull); atomicMax(&counts[1], (unsigned long long)dc); }
+    uint32_t r[4];
+    philox_draw(seed, i, 0, 9, 0, r);
+    const double a = ldexp(1.0 + u53(r[0], r[1]), (int)(r[2] % 1400u) - 700);                  // [2^-700, 2^700)
+    if (__double_as_longlong(sqrt_normal(a)) != __double_as_longlong(sqrt(a))) atomicAdd(&counts[2], 1ull);
+}
+
+int q1env_selftest_trig(int device, uint64_t n, const double* yaw_deg, double* sin_out, double* cos_out, uint64_t seed, uint64_t* counts4) {
+    if (!yaw_deg || !sin_out || !cos_out || !counts4 || n == 0) return fail(Q1ENV_ERR_INVALID_ARG, "q1env_selftest_trig: bad argument");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(Q1ENV_ERR_NO_DEVICE, "q1env_selftest_trig: no HIP device visible");
+    if (device < 0 || device >= ndev) return fail(Q1ENV_ERR_INVALID_ARG, "q1env_selftest_trig: bad device index");
+    DeviceGuard guard(device);
+    double* d = nullptr;
+    unsigned long long* c = nullptr;
+    const size_t bytes = (size_t)n * sizeof(double);
+    HIP_TRY(hipMalloc((void**)&d, 3 * bytes));
+    if (hipMalloc((void**)&c, 4 * sizeof(unsigned long long)) != hipSuccess) { (void)hipFree(d); return fail(Q1ENV_ERR_HIP, "selftest_trig: hipMalloc"); }
+    hipError_t e = hipMemcpy(d, yaw_deg, bytes, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemset(c, 0, 4 * sizeof(unsigned long long));
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(selftest_trig_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, n, d, d + n, d + 2 * n, seed, c);
+        e = hipGetLastError();
+    }
+    unsigned long long hc[4] = {0, 0, 0, 0};
+    if (e == hipSuccess) e = hipMemcpy(sin_out, d + n, bytes, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(cos_out, d + 2 * n, bytes, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(hc, c, sizeof(hc), hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    (void)hipFree(c);
+    if (e != hipSuccess) return fail(Q1ENV_ERR_HIP, std::string("selftest_trig: ") + hipGetErrorString(e));
+    for (int k = 0; k < 4; ++k) counts4[k] = hc[k];
+    return Q1ENV_OK;
+}
+
 int q1env_calibrate_traffic(q1env_t* h, int launches) {
     if (!h || launches <= 0) return fail(Q1ENV_ERR_INVALID_ARG, "q1env_calibrate_traffic: bad argument");
     DeviceGuard guard(h->device);

@@ -126,6 +126,13 @@ static inline int policy_row_width(const Params& p) {
 }
 
 // The default action/episode structure (4 keys, continuous mouse, jump key, no hover, y reward) runs the SPEC kernels.
+// The SPEC tick also takes the square root of |wish_vel|^2 without the scaling of tiny inputs (q1env_device.hpp physics_core
+// NORMAL): the move maxima must be 0 or of ordinary magnitude (the reference's are 800 and 1060).
+static inline bool move_max_ordinary(double m) {
+    const double a = m < 0 ? -m : m;
+    return a == 0.0 || (a >= 0x1p-200 && a <= 0x1p+200);
+}
 static inline bool is_spec(const Params& p) {
-    return p.num_keys == 4 && p.yaw_mode == 1 && p.jump_mode == 1 && !p.hover && !p.speed_reward;
+    return p.num_keys == 4 && p.yaw_mode == 1 && p.jump_mode == 1 && !p.hover && !p.speed_reward &&
+           move_max_ordinary(p.fmove_max) && move_max_ordinary(p.smove_max) && move_max_ordinary(p.smooth_scale);
 }

@@ -109,6 +109,7 @@ __device__ __forceinline__ void resident_env_wave(const Params& p, const StatePt
     }
     bool timed_out = false, last_zs = false;
     int completed = 0;
+    const TickConsts tc = tick_consts();
     for (int t = 0; t < a.ticks; ++t) {
         if (!q1res::wait_tag(act_tag, (uint32_t)t + 1u, a.timeout_ticks) || !q1res::wait_tag(act_tag + 1, (uint32_t)t + 1u, a.timeout_ticks)) {
             timed_out = true;
@@ -123,7 +124,7 @@ __device__ __forceinline__ void resident_env_wave(const Params& p, const StatePt
         if (live) {
             const uint32_t keys = (uint32_t)(g >> 32) & ((1u << cfg_num_keys<SPEC>(p)) - 1u);
             const double yaw_act = cfg_yaw_mode<SPEC>(p) ? (double)__uint_as_float((uint32_t)g) : 0.0;
-            tick<float, SPEC>(p, env, keys, yaw_act, o);
+            tick<float, SPEC>(p, tc, env, keys, yaw_act, o);
             zs = (env.flags & FLAG_ZERO_START) != 0;                              // of the episode the step belonged to
             if (o.done) {
                 reset_philox(p, env, a.seed, genv, counter0 + (uint64_t)t + 1);

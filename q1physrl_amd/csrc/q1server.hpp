@@ -150,6 +150,7 @@ __device__ __forceinline__ void tick_server_body(const Params& p, const StatePtr
     }
     int completed = 0;
     bool timed_out = false;
+    const TickConsts tc = tick_consts();
     for (int t = 0; t < ticks && !timed_out; ++t) {
         const uint64_t tag = tick_tag(tag0, (uint32_t)t);
         if (t > 0) nap(bo.first_server);
@@ -166,7 +167,7 @@ __device__ __forceinline__ void tick_server_body(const Params& p, const StatePtr
                 const uint32_t keys = (uint32_t)(g >> 32) & ((1u << cfg_num_keys<SPEC>(p)) - 1u);
                 const double yaw_act = cfg_yaw_mode<SPEC>(p) ? (double)__uint_as_float((uint32_t)g) : 0.0;
                 TickOut<float> o;
-                tick<float, SPEC>(p, env[e], keys, yaw_act, o);
+                tick<float, SPEC>(p, tc, env[e], keys, yaw_act, o);
                 const bool zs = (env[e].flags & FLAG_ZERO_START) != 0;                  // of the episode the step belonged to
                 if (auto_reset && o.done) {
                     reset_philox(p, env[e], seed, (uint64_t)p.env_index_base + (uint64_t)i, counter0 + (uint64_t)t + 1);
@@ -467,6 +468,7 @@ tick_pair_lds_kernel(Params p, StatePtrs s, int ticks, uint32_t tag0, uint64_t* 
         }
         int completed = 0;
         bool timed_out = false;
+        const TickConsts tc = tick_consts();
         for (int t = 0; t < ticks && !timed_out; ++t) {
             const uint64_t tag = tick_tag(tag0, (uint32_t)t);
 #pragma unroll 1
@@ -484,7 +486,7 @@ tick_pair_lds_kernel(Params p, StatePtrs s, int ticks, uint32_t tag0, uint64_t* 
                 if (live) {
                     const uint32_t kb = (uint32_t)(g >> 32) & ((1u << cfg_num_keys<SPEC>(p)) - 1u);
                     const double yaw_act = cfg_yaw_mode<SPEC>(p) ? (double)__uint_as_float((uint32_t)g) : 0.0;
-                    tick<float, SPEC>(p, env, kb, yaw_act, o);
+                    tick<float, SPEC>(p, tc, env, kb, yaw_act, o);
                     zs = (env.flags & FLAG_ZERO_START) != 0;                       // of the episode the step belonged to
                     if (auto_reset && o.done) {
                         // (the counter passes through an empty asm INSIDE the branch: the reset's arithmetic - Philox rounds, sincos -

@@ -227,6 +227,38 @@ def test_exact_division_shortcuts_selftest():
         assert list(out) == [0, 0, 0, 0], (seed, list(out))
 
 
+def test_inline_sincos_and_sqrt_selftest():
+    """The tick's in-line sin / cos of the yaw (q1env_device.hpp sincos_yaw: exact FMA reduction + fdlibm kernels on hi + lo) and its
+    scaling-free square root.  2^22 yaw values over +-7500 degrees (an episode stays within ~+-7600) plus a sweep up to the 2^20-radian
+    hand-over to the library: against THIS host's libm (what NumPy calls in the reference) at most 1 ulp and < 5 % of values differ -
+    the same class as the device library's own sincos, which it is also compared with; sqrt_normal == sqrt on 2^22 operands."""
+    import ctypes as C
+    from q1physrl_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(5)
+    n = 1 << 22
+    for span, seed in ((7500.0, 11), (5.9e7, 12)):
+        yaw = rng.uniform(-span, span, n)
+        yaw[:8] = [0.0, 90.0, -90.0, 180.0, 270.0, 360.0, 45.0, 1e-300]
+        sn, cs = np.empty(n), np.empty(n)
+        out = (C.c_uint64 * 4)()
+        _lib.check(lib.q1env_selftest_trig(0, n, yaw.ctypes.data, sn.ctypes.data, cs.ctypes.data, seed, out))
+        rad = (yaw * np.pi) / 180.0
+        ds = np.abs(sn.view(np.int64) - np.sin(rad).view(np.int64))
+        dc = np.abs(cs.view(np.int64) - np.cos(rad).view(np.int64))
+        assert ds.max() <= 1 and dc.max() <= 1, (span, int(ds.max()), int(dc.max()))
+        frac = ((ds != 0).sum() + (dc != 0).sum()) / (2.0 * n)
+        assert frac < 0.05, (span, frac)
+        assert out[1] <= 2 and out[0] < 0.1 * 2 * n, list(out)           # vs the device library: <= 2 ulp apart, < 10 % of values
+        assert out[2] == 0, list(out)                                     # the square root is bit-identical to the compiler's
+    # beyond the hand-over the library's path runs: identical to it by construction
+    yaw = rng.uniform(6.1e7, 1e12, 4096) * rng.choice([-1.0, 1.0], 4096)
+    sn, cs = np.empty(4096), np.empty(4096)
+    out = (C.c_uint64 * 4)()
+    _lib.check(lib.q1env_selftest_trig(0, 4096, yaw.ctypes.data, sn.ctypes.data, cs.ctypes.data, 13, out))
+    assert out[0] == 0 and out[2] == 0, list(out)
+
+
 def test_extreme_yaw_and_speed_states_match_oracle():
     """States far outside what an episode reaches (yaw up to 1e9 degrees: the large-argument path of the device sincos;
     speeds of 1e4; tiny and negative-zero-free velocities) injected through set_state: 50 ticks against the oracle."""
