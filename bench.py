@@ -735,11 +735,14 @@ def main(argv=None):
             r["frac"] = r["achieved"] / peak
             insts = float(pmc.get("insts_valu", 0.0)) / max(float(pmc.get("waves", 1.0)), 1.0) / float(pmc.get("ticks_per_launch", 1))
             r["valu_insts_per_tick_per_wave"] = insts
-            # the issue limit of a LONE wave on its SIMD (what 65 536 envs on 1 024 SIMDs are): one VALU instruction per 5.17 cycles
-            # whatever its type (tools/ubench_f64.hip, profiles/r3_ubench_f64.txt), 16.8 for a float64 transcendental
+            # the issue limit of a LONE wave on its SIMD (what 65 536 envs on 1 024 SIMDs are): one instruction per 5.17 cycles whatever
+            # its type - vector, scalar or memory (tools/ubench_f64.hip, tools/ubench_select.hip; 16.8 for a float64 transcendental)
             waves_per_simd = max(1.0, n / 64.0 / simds)
             if waves_per_simd <= 1.0 and insts > 0:
-                floor_us = insts * 5.17 / (PEAK_CLOCK_GHZ * 1e3)
+                per_wave_tick = max(float(pmc.get("waves", 1.0)), 1.0) * float(pmc.get("ticks_per_launch", 1))
+                other = (float(pmc.get("insts_salu", 0.0)) + float(pmc.get("insts_mem", 0.0))) / per_wave_tick
+                r["salu_and_memory_insts_per_tick_per_wave"] = other
+                floor_us = (insts + other) * 5.17 / (PEAK_CLOCK_GHZ * 1e3)
                 r["lone_wave_issue_floor_us_per_tick"] = floor_us
                 r["frac_of_lone_wave_issue_floor"] = floor_us / (ev_ms_ * 1e3 / steps)
         else:

@@ -18,7 +18,8 @@
 //     the reward multiply (env.py:500-503)
 //   * no FMA contraction (this file MUST be compiled with -ffp-contract=off), true division,
 //     correctly rounded sqrt; einsum sums start from +0.0 (sign of zero results)
-//   * sin/cos: float64 ocml sincos (<= 2 ulp; the float32 rounding of vel absorbs it)
+//   * sin/cos: float64, <= 1 ulp from the host libm's (sincos_yaw below; the device library's sincos beyond 2^20 radians and in the
+//     reset / phys.apply paths); the float32 rounding of vel absorbs the difference, see DESIGN.md
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>

@@ -315,7 +315,6 @@ mlp_forward_kernel(int n, const float* __restrict__ obs, Net net_a, Net net_b, i
     const unsigned char* w1row = l_w1 + (size_t)col * 32u + half * 16u;               // + tile * 1024
     const unsigned char* wrow = l_w2 + (size_t)col * ROW_BYTES + half * 16u;          // + t2 * 32 rows, + K-step * 32 B
     const unsigned char* w3row = l_w3 + (size_t)col * ROW_BYTES + half * 16u;         // + K-step * 32 B
-    const f32x16 zero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #ifdef Q1POL_TRACE                                                   // diagnostic build (tools/trace_mlp.py): phase times of wave 0
     uint64_t tr_pro = 0, tr_loop = 0, tr_l3 = 0, tr_chunks = 0;
     const uint64_t tr_real0 = wall_clock64(), tr_mem0 = __builtin_amdgcn_s_memtime();   // 100 MHz reference vs s_memtime

@@ -91,6 +91,9 @@ for d in sorted(glob.glob(os.path.join(out, "*_*"))):
             e["insts_valu"] = sq["SQ_INSTS_VALU"]
         if "SQ_INSTS_SALU" in sq:
             e["insts_salu"] = sq["SQ_INSTS_SALU"]
+        other = [sq[k] for k in ("SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR", "SQ_INSTS_LDS", "SQ_INSTS_SMEM") if k in sq]
+        if other:
+            e["insts_mem"] = sum(other)                                  # vector-memory, LDS and scalar-memory instructions
         if "SQ_ACTIVE_INST_VALU" in sq:
             e["valu_busy_cycles"] = 4 * sq["SQ_ACTIVE_INST_VALU"]
         if "SQ_WAVE_CYCLES" in sq:
@@ -116,7 +119,8 @@ for key, e in res.items():
                   + (f";  / un-profiled period = {(fx + wr) / (e['event_us_per_tick_unprofiled'] * T * 1e3):.1f} GB/s = {(fx + wr) / (e['event_us_per_tick_unprofiled'] * T * 1e3) / 8000:.3f}" if "event_us_per_tick_unprofiled" in e else ""))
     if "insts_valu" in e and "waves" in e:
         wv = e["waves"]
-        print(f"   waves={wv:.0f}  VALU instructions per tick per wave={e['insts_valu'] / wv / T:.1f}  SALU={e.get('insts_salu', 0) / wv / T:.1f}")
+        print(f"   waves={wv:.0f}  VALU instructions per tick per wave={e['insts_valu'] / wv / T:.1f}  SALU={e.get('insts_salu', 0) / wv / T:.1f}"
+              f"  VMEM + LDS + SMEM={e.get('insts_mem', 0) / wv / T:.1f}")
         if "valu_busy_cycles" in e and "wave_cycles" in e:
             print(f"   VALU-busy cycles per tick per wave={e['valu_busy_cycles'] / wv / T:.0f} of {e['wave_cycles'] / wv / T:.0f} wave cycles = {e['valu_busy_cycles'] / e['wave_cycles']:.3f}"
                   f"  (cycles per VALU instruction: busy {e['valu_busy_cycles'] / e['insts_valu']:.2f}, elapsed {e['wave_cycles'] / e['insts_valu']:.2f})")
