@@ -44,6 +44,10 @@ def counters(path, want):
 
 
 res = {}
+try:        # a re-run on a copy whose large per-launch CSVs were deleted (profile_round3.sh does that on the box) keeps those entries
+    previous = json.load(open(os.path.join(out, "pmc.json")))
+except Exception:   # noqa: BLE001
+    previous = {}
 for d in sorted(glob.glob(os.path.join(out, "*_*"))):
     if not os.path.isdir(d) or os.path.basename(d) == "calib":
         continue
@@ -101,6 +105,8 @@ for d in sorted(glob.glob(os.path.join(out, "*_*"))):
         if "GRBM_GUI_ACTIVE" in sq:
             e["grbm_gui_active_sum"] = sq["GRBM_GUI_ACTIVE"]
         e["counters_raw"] = sq
+    if "kernel" not in e and "fetch_x2_B" not in e and key in previous:
+        e = previous[key]
     res[key] = e
 
 print(f"== {out}: primary kernel per bench.py mode / batch size (per launch; PMC passes are separate runs of the same command)")
