@@ -1,0 +1,56 @@
+"""Time the native learner's kernels on one MI355X: `--steps` forward + backward + weight-gradient launches of a `--mb`-sample
+minibatch (32 768 = tools/train_ppo.py's) on synthetic rows, HIP events around each phase; meant to be run under
+`rocprofv3 --kernel-trace --stats` / `--pmc ...` as well (tools/profile_learner.sh).  Prints one JSON line."""
+import argparse
+import json
+import sys
+import os
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--mb", type=int, default=32768)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--splits", type=int, default=32)
+    ap.add_argument("--phase", default="all", choices=["all", "forward", "backward"])
+    args = ap.parse_args()
+    import torch
+    from q1physrl_amd import policy as P, ppo
+    from q1physrl_amd.tensor_env import TensorVectorEnv
+    from q1physrl_amd.env import Config
+    env = TensorVectorEnv(Config(**dict(Config.get_default().__dict__, num_envs=256)), device=0, seed=1)
+    torch.manual_seed(0)
+    pol = P.Q1Policy().cuda()
+    mb = args.mb
+    total = 4 * mb
+    g = torch.Generator(device="cuda").manual_seed(2)
+    obs = torch.randn((total, 6), device="cuda", generator=g) * torch.tensor([0.5, 3.0, 0.3, 1.5, 1.5, 1.0], device="cuda")
+    idx = torch.randperm(total, device="cuda", generator=g)[:mb].contiguous()
+    nat = ppo.NativeStep(pol, env, mb, splits=args.splits)
+    dl = torch.randn((mb, 10), device="cuda", generator=g)
+    dv = torch.randn((mb,), device="cuda", generator=g) * 100.0
+
+    def timed(fn, n):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(n):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) * 1e3 / n
+
+    out = {"mb": mb, "splits": args.splits, "steps": args.steps}
+    if args.phase in ("all", "forward"):
+        out["forward_us"] = timed(lambda: nat.forward(obs, idx), args.steps)
+    if args.phase in ("all", "backward"):
+        out["backward_wgrad_reduce_us"] = timed(lambda: nat.backward(obs, idx, dl, dv, float(mb)), args.steps)
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
