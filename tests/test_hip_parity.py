@@ -193,6 +193,74 @@ def test_against_oracle_random(n, ticks, seed):
     hip.close()
 
 
+def _random_config(rng, n):
+    kw = dict(O.OracleConfig.get_default(num_envs=n).__dict__)
+    kw.update(time_delta=float(rng.choice([1.0 / 72, 0.013888888888888, 0.02, 1.0 / 125, 0.014])),
+              time_limit=float(rng.choice([1.0, 2.5, 10.0])), key_press_delay=float(rng.choice([0.0, 0.05, 0.3])),
+              smooth_keys=bool(rng.integers(2)), fmove_max=float(rng.choice([0.0, 0.4, 127.0, 400.0, 800.0, 1200.0])),
+              smove_max=float(rng.choice([0.0, 350.0, 700.0, 1060.0])), zero_start_prob=float(rng.choice([0.0, 0.3, 1.0])),
+              max_initial_speed=float(rng.choice([0.0, 320.0, 700.0])), hover=bool(rng.random() < 0.15),
+              speed_reward=bool(rng.random() < 0.3), action_range=float(rng.choice([10.0, 10.079999923706055, 3.0])))
+    mode = rng.integers(4)
+    if mode == 1:
+        kw.update(auto_jump=True)
+    elif mode == 2:
+        kw.update(allow_jump=False)
+    ymode = rng.integers(4)
+    if ymode == 1:
+        kw.update(discrete_yaw_steps=int(rng.choice([1, 4, 10])))
+    elif ymode == 2:
+        kw.update(allow_yaw=False)
+    return kw
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_random_configs_against_oracle(seed):
+    """Config fuzz (round 3: the tick's selects, square root and sin / cos were re-written): random Config - time step, key delay,
+    smoothing, move maxima incl. 0 and sub-unit ones (the wish-less stand-in), jump / yaw modes, hover, both rewards - 192 envs (three
+    waves), 150 ticks of sticky random keys with stretches of NO key pressed and of all keys pressed, reset_at on done.  Ints exact,
+    floats within REL_TOL with >= 99.9 % bit-identical (in practice all)."""
+    from q1physrl_amd import env as E
+    rng = np.random.default_rng(1000 + seed)
+    n = 192
+    kw = _random_config(rng, n)
+    np.random.seed(seed)
+    ora = O.OracleVectorEnv(dict(kw))
+    np.random.seed(seed)
+    hip = E.VectorPhysEnv(dict(kw))
+    cfg = O.OracleConfig(**kw)
+    nk = cfg.num_keys
+    keys = rng.random((n, nk)) < 0.5
+    for t in range(150):
+        keys ^= rng.random((n, nk)) < 0.15
+        if 40 <= t < 55:
+            keys[: n // 2] = False                                  # nobody in the first half presses anything: no wish at all
+        if 90 <= t < 100:
+            keys[n // 2:] = True
+        cols = [keys.astype(np.float64)]
+        if cfg.allow_yaw:
+            if cfg.discrete_yaw_steps >= 0:
+                cols.append(rng.integers(0, 2 * cfg.discrete_yaw_steps + 1, (n, 1)).astype(np.float64))
+            else:
+                cols.append(rng.uniform(-cfg.action_range, cfg.action_range, (n, 1)).astype(np.float32).astype(np.float64))
+        a = np.concatenate(cols, axis=1)
+        o1, r1, d1, z1 = ora.vector_step(a)
+        o2, r2, d2, i2 = hip.vector_step(a)
+        assert np.array_equal(d1, d2), (kw, t)
+        assert float(np.max(rel_err(o2, o1))) <= REL_TOL and float(np.max(rel_err(r2, r1))) <= REL_TOL, (kw, t)
+        assert bit_identical_fraction(np.asarray(o2, np.float64), np.asarray(o1, np.float64)) >= 0.999, (kw, t)
+        for i in np.nonzero(d1)[0]:
+            st = np.random.get_state()
+            a1 = ora.reset_at(int(i))
+            np.random.set_state(st)
+            a2 = hip.reset_at(int(i))
+            assert np.max(rel_err(a2, a1)) <= REL_TOL
+    ps = hip.player_state
+    assert np.array_equal(ps.on_ground, ora.st["on_ground"]) and np.array_equal(ps.jump_released, ora.st["jump_released"])
+    assert bit_identical_fraction(ps.vel, ora.st["vel"]) >= 0.999 and bit_identical_fraction(ps.z_pos, ora.st["z_pos"].astype(ps.z_pos.dtype)) >= 0.999
+    hip.close()
+
+
 def test_state_roundtrip_and_error_behaviour():
     from q1physrl_amd import env as E, _lib
     cfg = dict(E.Config.get_default().__dict__, num_envs=8)
