@@ -14,7 +14,7 @@ def main():
     ap.add_argument("--mb", type=int, default=32768)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--splits", type=int, default=32)
-    ap.add_argument("--phase", default="all", choices=["all", "forward", "backward"])
+    ap.add_argument("--phase", default="all", choices=["all", "forward", "backward", "step"])
     args = ap.parse_args()
     import torch
     from q1physrl_amd import policy as P, ppo
@@ -49,6 +49,33 @@ def main():
         out["forward_us"] = timed(lambda: nat.forward(obs, idx), args.steps)
     if args.phase in ("all", "backward"):
         out["backward_wgrad_reduce_us"] = timed(lambda: nat.backward(obs, idx, dl, dv, float(mb)), args.steps)
+    if args.phase in ("all", "step"):
+        # the whole SGD step as PPOLearner runs it: forward, loss gradient, backward, weight gradients, reduction + Adam + images
+        total_rows = total
+        full = {"obs": obs, "old_logits": torch.randn((total_rows, 10), device="cuda", generator=g).contiguous(),
+                "keys_packed": torch.randint(0, 16, (total_rows,), device="cuda", dtype=torch.uint8),
+                "mouse": (torch.rand((total_rows, 1), device="cuda", generator=g) * 20 - 10), "logp": -torch.rand((total_rows,), device="cuda", generator=g) * 5,
+                "adv": torch.randn((total_rows,), device="cuda", generator=g), "value": torch.randn((total_rows,), device="cuda", generator=g) * 50,
+                "vtarg": torch.randn((total_rows,), device="cuda", generator=g) * 50}
+        klc = torch.full((1,), 0.2, device="cuda")
+
+        def one():
+            nat.step(full, idx, 0.1, 7500.0, 1.0, 0.01, klc, skip_reduce=True)
+            nat.adam(3e-5)
+        out["eager_step_us"] = timed(one, args.steps)
+        gph = torch.cuda.CUDAGraph()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            env.use_current_stream()
+            one()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        with torch.cuda.graph(gph):
+            env.use_current_stream()                     # the library's launches must land on the capturing stream
+            one()
+        env.use_current_stream()
+        out["graph_step_us"] = timed(gph.replay, args.steps)
     print(json.dumps(out))
 
 
