@@ -7,9 +7,11 @@
 // Two instantiations of everything below:
 //   SPEC = false  any Config (runtime num_keys / yaw mode / jump mode / hover / speed_reward), wave-uniform branches
 //   SPEC = true   the default action/episode structure baked in at compile time (4 keys, continuous mouse,
-//                 jump key, no hover, y-velocity reward: Config.get_default() and data/params.yml) -> one
-//                 straight-line basic block per tick, which is what lets the scheduler overlap the independent
-//                 float64 chains (decode | sincos | friction | z) of a lone wave on its SIMD.
+//                 jump key, no hover, y-velocity reward: Config.get_default() and data/params.yml; move maxima of
+//                 ordinary magnitude) -> no per-tick branches on the Config.  What a tick costs a lone wave on its
+//                 SIMD is its instruction COUNT (one issue slot of ~5.2 cycles each, vector, scalar or memory;
+//                 a dependent float64 chain issues as fast as independent ones; a branch ~ four slots):
+//                 tools/ubench_f64.hip, tools/ubench_select.hip, DESIGN.md section 6.2.
 //
 // Numerics contract (restated from the reference as executed by NumPy 2.2.6):
 //   * yaw, time_remaining, last_key_press_time, z_pos and all horizontal intermediates: float64
@@ -115,12 +117,6 @@ struct TickOut {
 // it, which the compiler cannot see into the assembly to provide.
 // In-place forms (the value that is kept where the mask is clear is the in/out operand: no copies around the assembly; early-clobber,
 // because an input that happens to hold the same value would otherwise be given the same register and be overwritten mid-sequence).
-__device__ __forceinline__ void select_into_f64(uint64_t mask, double a, double& r) {                 // r = mask ? a : r
-    uint32_t lo = (uint32_t)__double2loint(r), hi = (uint32_t)__double2hiint(r);
-    asm("s_nop 1\n\tv_cndmask_b32_e64 %0, %0, %2, %4\n\tv_cndmask_b32_e64 %1, %1, %3, %4"
-        : "+&v"(lo), "+&v"(hi) : "v"(__double2loint(a)), "v"(__double2hiint(a)), "s"(mask));
-    r = __hiloint2double((int)hi, (int)lo);
-}
 __device__ __forceinline__ void select2_into_f64(uint64_t mask, double a0, double& r0, double a1, double& r1) {
     uint32_t lo0 = (uint32_t)__double2loint(r0), hi0 = (uint32_t)__double2hiint(r0);
     uint32_t lo1 = (uint32_t)__double2loint(r1), hi1 = (uint32_t)__double2hiint(r1);
