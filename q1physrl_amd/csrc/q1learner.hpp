@@ -337,21 +337,64 @@ struct WgNet {
 // is a plain 16-byte-per-lane streaming load in MFMA layout (the backward kernel has done all gathering and transposing); the next
 // tile's operands are requested before the current tile's MFMAs (register double buffer).  It leaves its float32 partial sums in
 // its split's slot.
-struct WgOps { f16x8 a2[2], s0[2], s1[2], b[4][2]; };     // dZ2 rows | y=0: dZ1 rows, [x|1]  y=1: dY, h2 cols | h1 column tiles
+struct WgOps { f16x8 a2[2], s0[2], s1[2], x[2], b[4][2]; };     // dZ2 rows | y=0: dZ1 rows, [x|1]  y=1: dY, h2 cols, [x|1] | h1 column tiles
 
-__device__ __forceinline__ void wg_load(WgOps& o, const WgNet& net, uint32_t tile, uint32_t lane, uint32_t w, uint32_t khalf) {
+template <int KHALF>
+__device__ __forceinline__ void wg_load(WgOps& o, const WgNet& net, uint32_t tile, uint32_t lane, uint32_t w) {
     const size_t tb = (size_t)tile * TILE_VECS + lane, sb = (size_t)tile * 128u + lane;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
         o.a2[ks] = net.dz2N[tb + (2u * w + (uint32_t)ks) * 64u];
-        if (khalf == 0) { o.s0[ks] = net.dz1N[tb + (2u * w + (uint32_t)ks) * 64u]; o.s1[ks] = net.xN[sb + 64u * (uint32_t)ks]; }
-        else { o.s0[ks] = net.dyN[sb + 64u * (uint32_t)ks]; o.s1[ks] = net.h2N[tb + (2u * w + (uint32_t)ks) * 64u]; }
+        if constexpr (KHALF == 0) { o.s0[ks] = net.dz1N[tb + (2u * w + (uint32_t)ks) * 64u]; o.s1[ks] = net.xN[sb + 64u * (uint32_t)ks]; }
+        else { o.s0[ks] = net.dyN[sb + 64u * (uint32_t)ks]; o.s1[ks] = net.h2N[tb + (2u * w + (uint32_t)ks) * 64u]; o.x[ks] = net.xN[sb + 64u * (uint32_t)ks]; }
 #pragma unroll
-        for (int kt = 0; kt < 4; ++kt) o.b[kt][ks] = net.h1N[tb + (2u * (4u * khalf + (uint32_t)kt) + (uint32_t)ks) * 64u];
+        for (int kt = 0; kt < 4; ++kt) o.b[kt][ks] = net.h1N[tb + (2u * (4u * (uint32_t)KHALF + (uint32_t)kt) + (uint32_t)ks) * 64u];
     }
 }
 
-__global__ void __launch_bounds__(256, 2)
+#ifndef Q1_WGRAD_DEPTH                  // operand sets in flight per wave (measurement knob): tiles requested ahead = depth - 1
+#define Q1_WGRAD_DEPTH 2
+#endif
+// The sample-tile loop of one wave.  One workgroup per CU (splits x 2 x 2 = 256 of them at the default 32 splits) = one wave per
+// SIMD: nothing hides a load's latency but the wave's own requests, so the ring keeps DEPTH - 1 tiles in flight (the workgroup owns
+// its CU's register file: 4 x 56..64 operand registers + 96 accumulators), and the body is straight-line - KHALF is a template
+// argument, the db3 product (dY x [x | 1]) is computed by every wave of the y = 1 half and stored by one - so that the compiler's
+// s_waitcnt are counts, not drains (the first version's in-loop direct load for that product drained the queue every tile).
+template <int KHALF>
+__device__ __forceinline__ void wg_loop(const WgNet& net, uint32_t t_begin, uint32_t t_end, uint32_t lane, uint32_t w, f32x16 aW2[4], f32x16& aX, f32x16& aY) {
+    constexpr int D = Q1_WGRAD_DEPTH;
+    WgOps ring[D];
+    if (t_begin >= t_end) return;
+#pragma unroll
+    for (int d = 0; d < D - 1; ++d) wg_load<KHALF>(ring[d], net, min(t_begin + (uint32_t)d, t_end - 1u), lane, w);
+    for (uint32_t tile0 = t_begin; tile0 < t_end; tile0 += (uint32_t)D) {
+#pragma unroll
+        for (int j = 0; j < D; ++j) {
+            const uint32_t tile = tile0 + (uint32_t)j;
+            if (tile >= t_end) return;                                             // wave-uniform
+            wg_load<KHALF>(ring[(j + D - 1) % D], net, min(tile + (uint32_t)(D - 1), t_end - 1u), lane, w);   // (past the end: re-requests the last tile, harmless)
+            __builtin_amdgcn_sched_barrier(0);                                     // the requests go out HERE, not next to their uses
+            const WgOps& cur = ring[j];
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) aW2[kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur.a2[ks], cur.b[kt][ks], aW2[kt], 0, 0, 0);
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                if constexpr (KHALF == 0) {
+                    aX = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur.a2[ks], cur.s1[ks], aX, 0, 0, 0);
+                    aY = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur.s0[ks], cur.s1[ks], aY, 0, 0, 0);
+                } else {
+                    aX = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur.s0[ks], cur.s1[ks], aX, 0, 0, 0);
+                    aY = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur.s0[ks], cur.x[ks], aY, 0, 0, 0);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256, 1)
 learner_wgrad_kernel(int n, WgNet net_a, WgNet net_b, int splits) {
     const bool second = blockIdx.x >= (uint32_t)splits;
     const uint32_t split = second ? blockIdx.x - (uint32_t)splits : blockIdx.x;
@@ -362,33 +405,11 @@ learner_wgrad_kernel(int n, WgNet net_a, WgNet net_b, int splits) {
     const uint32_t per = (ntiles + (uint32_t)splits - 1u) / (uint32_t)splits;
     const uint32_t t_begin = split * per, t_end = min(t_begin + per, ntiles);
     const f32x16 zero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    f32x16 aW2[4], aX = zero16, aY = zero16;          // y = 0: aX = dZ2 x [x|1], aY = dZ1 x [x|1];  y = 1: aX = dY x h2, aY = dY x [x|1] (wave 0)
+    f32x16 aW2[4], aX = zero16, aY = zero16;          // y = 0: aX = dZ2 x [x|1], aY = dZ1 x [x|1];  y = 1: aX = dY x h2, aY = dY x [x|1] (kept by wave 0)
 #pragma unroll
     for (int k = 0; k < 4; ++k) aW2[k] = zero16;
-    WgOps cur, nxt;
-    if (t_begin < t_end) wg_load(cur, net, t_begin, lane, w, khalf);
-    for (uint32_t tile = t_begin; tile < t_end; ++tile) {
-        const uint32_t tn = tile + 1u < t_end ? tile + 1u : tile;           // (the last iteration re-requests its own tile: harmless)
-        wg_load(nxt, net, tn, lane, w, khalf);
-#pragma unroll
-        for (int kt = 0; kt < 4; ++kt)
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) aW2[kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur.a2[ks], cur.b[kt][ks], aW2[kt], 0, 0, 0);
-        if (khalf == 0) {
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                aX = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur.a2[ks], cur.s1[ks], aX, 0, 0, 0);
-                aY = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur.s0[ks], cur.s1[ks], aY, 0, 0, 0);
-            }
-        } else {
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                aX = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur.s0[ks], cur.s1[ks], aX, 0, 0, 0);
-                if (w == 0) aY = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur.s0[ks], net.xN[(size_t)tile * 128u + lane + 64u * (uint32_t)ks], aY, 0, 0, 0);
-            }
-        }
-        cur = nxt;
-    }
+    if (khalf == 0) wg_loop<0>(net, t_begin, t_end, lane, w, aW2, aX, aY);
+    else wg_loop<1>(net, t_begin, t_end, lane, w, aW2, aX, aY);
     float* out = net.partial + (size_t)split * PARTIAL_FLOATS;
     auto put = [&](uint32_t p, const f32x16& a) {
 #pragma unroll
