@@ -421,18 +421,17 @@ __device__ __forceinline__ Cmd decode(const Params& p, Env& e, uint32_t keybits,
     const double now = p.time_limit - trem;                             // env.py:241,246
     const uint32_t prev = (e.flags >> FLAG_KEYS_SHIFT) & 0xFu;
     const int nk = cfg_num_keys<SPEC>(p);
-    uint32_t keys = 0;
-    uint64_t rising[4] = {0ull, 0ull, 0ull, 0ull};
+    // env.py:241-248 for the four keys at once, as bit masks: may_press_k = now >= last_press_k + delay (float64 compare),
+    // keys = key_actions & (may_press | last_keys), rising edge = keys & ~last_keys
+    uint32_t may = 0;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        if (k < nk) {
-            const bool may_press = now >= e.lk[k] + p.key_press_delay;  // float64 compare (env.py:241-242)
-            const uint32_t pk = (prev >> k) & 1u;
-            const uint32_t key = ((keybits >> k) & 1u) & ((may_press ? 1u : 0u) | pk);   // env.py:243
-            rising[k] = __ballot((key & ~pk & 1u) != 0u);               // rising edge (env.py:244-248)
-            keys |= key << k;
-        }
-    }
+    for (int k = 0; k < 4; ++k)
+        if (k < nk) may |= (now >= e.lk[k] + p.key_press_delay) ? (1u << k) : 0u;
+    const uint32_t keys = keybits & ((1u << nk) - 1u) & (may | prev);   // env.py:243
+    const uint32_t rise = keys & ~prev;
+    uint64_t rising[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) rising[k] = __ballot((rise & (1u << k)) != 0u);
     select4_into_f64(rising[0], rising[1], rising[2], rising[3], now, e.lk);
     // env.py:251-254: level_k = (key_k + prev_k) * 0.5 with smoothing, key_k without.  Every level is one of {0, 0.5, 1}, so the
     // difference right - left and the level itself are formed EXACTLY in integers (units of smooth_scale) and converted once: the two
