@@ -74,6 +74,8 @@ def build_lib(force=False, verbose=False, check=False, extra_flags=(), out=None,
         out = OUT_CHECK if check else OUT
     if tag is None:
         tag = "_check" if check else ""
+    if out == OUT:
+        build_rows_helper(force=force, verbose=verbose)       # the host-side CPython helper rides with the product build
     if not force and not is_stale(out):
         return out
     os.makedirs(OBJ_DIR, exist_ok=True)
@@ -94,6 +96,33 @@ def build_lib(force=False, verbose=False, check=False, extra_flags=(), out=None,
         except OSError:
             pass
     return out
+
+
+ROWS_SRC = os.path.join(CSRC, "q1rows.c")
+ROWS_OUT = os.path.join(PKG, "_q1rows.so")
+
+
+def build_rows_helper(force=False, verbose=False):
+    """The CPython helper of the drop-in surface (csrc/q1rows.c: RLlib's list-of-tuples actions -> float64 rows in one C pass), gcc.
+    Optional: env.py falls back to its NumPy formulations without it, so a missing compiler or header only warns."""
+    if not force and os.path.exists(ROWS_OUT) and os.path.getmtime(ROWS_OUT) >= os.path.getmtime(ROWS_SRC):
+        return ROWS_OUT
+    import sysconfig
+    try:
+        import numpy
+        cmd = ["gcc", "-O2", "-shared", "-fPIC", "-Wall", "-I" + sysconfig.get_paths()["include"], "-I" + numpy.get_include(), ROWS_SRC,
+               "-o", ROWS_OUT + ".tmp"]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(r.stdout + r.stderr)
+        os.replace(ROWS_OUT + ".tmp", ROWS_OUT)
+        return ROWS_OUT
+    except Exception as ex:   # noqa: BLE001 - no compiler / no Python headers: the NumPy path stays
+        import warnings
+        warnings.warn(f"q1physrl_amd: the action-row helper was not built ({ex}); list-of-tuples actions take the NumPy path", RuntimeWarning)
+        return None
 
 
 if __name__ == "__main__":

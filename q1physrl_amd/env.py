@@ -110,6 +110,25 @@ def get_obs_scale(config):
     return [config.time_limit, 90., 100, 200, 200, 200]
 
 
+def _load_rows_helper():
+    """csrc/q1rows.c, built by build.py next to the package (optional: None -> the NumPy formulations below)."""
+    import importlib.util
+    import os
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_q1rows.so")
+    if not os.path.exists(path):
+        return None
+    try:
+        spec = importlib.util.spec_from_file_location("q1physrl_amd._q1rows", path)
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        return mod
+    except Exception:   # noqa: BLE001 - built for another interpreter / NumPy: not an error, the NumPy path is equivalent
+        return None
+
+
+_ROWS_HELPER = _load_rows_helper()
+
+
 def _action_rows(actions, width):
     """The job of ActionDecoder._fix_actions (env.py:221-223) without its per-element Python loop.
 
@@ -118,6 +137,10 @@ def _action_rows(actions, width):
     """
     if isinstance(actions, np.ndarray) and actions.ndim == 2 and actions.dtype != object:
         return np.ascontiguousarray(actions, dtype=np.float64)
+    if _ROWS_HELPER is not None and type(actions) in (list, tuple) and len(actions):
+        out = np.empty((len(actions), width), dtype=np.float64)         # RLlib's list of N tuples: one C pass (csrc/q1rows.c)
+        if _ROWS_HELPER.rows(actions, int(width), out):
+            return out
     first = actions[0] if len(actions) else ()
     mixed = isinstance(first, (tuple, list)) and any(isinstance(c, np.ndarray) for c in first) and \
         not all(isinstance(c, np.ndarray) for c in first)  # RLlib's rows: Python ints + a (1,) array - np.asarray can only fail on them

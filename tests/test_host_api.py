@@ -59,6 +59,37 @@ def test_action_rows_all_formats():
         assert got.dtype == np.float64 and got.flags["C_CONTIGUOUS"] and np.array_equal(got, want)
 
 
+def test_action_rows_c_helper_equals_the_numpy_path(monkeypatch):
+    """csrc/q1rows.c (built by build.py with gcc): RLlib's list of N tuples - Python ints / bools / floats, NumPy scalars, arrays of
+    length >= 1 of several dtypes - in one C pass; identical to the NumPy formulations on everything it accepts, and it declines
+    (None -> NumPy path, which raises the reference's errors) on rows of the wrong length, nested lists and empty arrays."""
+    from q1physrl_amd import build, env as E
+    build.build_rows_helper()
+    helper = E._load_rows_helper()
+    if helper is None:
+        pytest.skip("no compiler / Python headers here: the NumPy path is the only one")
+    rng = np.random.default_rng(3)
+    n = 4000
+    rows = []
+    for i in range(n):
+        kind = i % 5
+        keys = [int(rng.integers(2)), bool(rng.integers(2)), np.int64(rng.integers(2)), np.uint8(rng.integers(2))]
+        mouse = [np.array([rng.uniform(-10, 10)], dtype=np.float32), float(rng.uniform(-10, 10)), np.float64(rng.uniform(-10, 10)),
+                 np.array([rng.uniform(-10, 10), 99.0]), np.array([[rng.integers(-5, 5)]], dtype=np.int32)][kind]
+        rows.append(tuple(keys) + (mouse,))
+    monkeypatch.setattr(E, "_ROWS_HELPER", None)
+    want = E._action_rows(rows, 5)
+    monkeypatch.setattr(E, "_ROWS_HELPER", helper)
+    got = E._action_rows(rows, 5)
+    assert got.dtype == np.float64 and got.flags.c_contiguous and np.array_equal(got, want)
+    assert np.array_equal(E._action_rows([list(r) for r in rows], 5), want)           # lists of lists too
+    out = np.empty((1, 3))
+    assert helper.rows([(1, 2)], 3, out) is None and helper.rows([(1, 2, [3])], 3, out) is None
+    assert helper.rows([(1, 2, np.array([], dtype=np.float32))], 3, out) is None and helper.rows("abc", 3, out) is None
+    with pytest.raises(ValueError):
+        E._checked_rows([(1, 0, 1)], 5, 1)                                              # the wrapper's shape check is unchanged
+
+
 def test_lazy_infos_behaves_like_the_list_of_dicts():
     zs = np.array([True, False, True])
     infos = E._LazyInfos(zs)
