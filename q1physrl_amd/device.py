@@ -196,6 +196,22 @@ class DeviceEnv:
                                            obs or None, reward or None, done or None, int(auto_reset),     # bit 0 + timer flags
                                            return_sum or None))
 
+    def prepare_rollout(self, ticks, action_format, act_a=0, act_b=0, rng_seed=0, obs_format=_lib.OBS_F32, obs=0, reward=0, done=0,
+                        auto_reset=False, return_sum=0):
+        """rollout_dev with the arguments converted ONCE: returns a zero-argument callable that issues the same q1env_rollout call.
+        For loops that launch the same rollout repeatedly (a benchmark's timed region, a sampler replaying fixed buffers): ctypes'
+        per-call conversion of twelve Python values is ~1.5 us of a ~9 us enqueue."""
+        fn = self._lib.q1env_rollout
+        p = lambda v: C.c_void_p(v) if v else None                 # noqa: E731
+        args = (self._h, C.c_int(int(ticks)), C.c_int(int(action_format)), p(act_a), p(act_b), C.c_uint64(int(rng_seed)), C.c_int(int(obs_format)),
+                p(obs), p(reward), p(done), C.c_int(int(auto_reset)), p(return_sum))
+
+        def call():
+            r = fn(*args)
+            if r:
+                _lib.check(r)
+        return call
+
     def reset_philox_dev(self, seed, mask=0, done_only=False, obs_format=_lib.OBS_F32, obs=0, counter_dev=0):
         _lib.check(self._lib.q1env_reset_philox(self._h, seed, counter_dev or None, mask or None, int(done_only), obs_format, obs or None))
 

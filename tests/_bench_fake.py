@@ -73,6 +73,10 @@ class FakeDeviceEnv:
         self.step_many_dev(ticks, action_format, act_a, act_b, obs_format, obs, reward, done, out_stride_ticks=1, use_graph=int(auto_reset) & 12)
         self.calls.pop()
 
+    def prepare_rollout(self, *a, **k):
+        import functools
+        return functools.partial(self.rollout_dev, *a, **k)
+
     def reset_philox_dev(self, seed, mask=0, done_only=False, obs_format=1, obs=0, counter_dev=0):
         self.calls.append(("reset", bool(done_only)))
         for i in np.flatnonzero(self._env.t_rem < 0) if done_only else range(self.n):
