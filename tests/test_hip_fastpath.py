@@ -93,7 +93,7 @@ def test_step_tensor_action_layouts(fmt):
     tenv.close()
 
 
-@pytest.mark.parametrize("mode", ["many_graph", "many_eager", "rollout_f32", "rollout_f64"])
+@pytest.mark.parametrize("mode", ["many_graph", "many_eager", "rollout_f32", "rollout_f64", "rollout_prepared"])
 def test_multi_tick_entry_points(mode):
     torch = torch_mod()
     n, ticks = 777, 150            # ragged: 777 = 12 waves + 9 lanes
@@ -108,6 +108,18 @@ def test_multi_tick_entry_points(mode):
     act = (torch.from_numpy(keys).cuda(), torch.from_numpy(mouse).cuda())
     if mode.startswith("many"):
         obs, rew, done = tenv.step_many(act, ticks, outputs=True, use_graph=(mode == "many_graph"))
+    elif mode == "rollout_prepared":                       # DeviceEnv.prepare_rollout: the same call with its arguments converted once
+        from q1physrl_amd import _lib
+        obs = torch.empty((ticks, n, 6), dtype=torch.float32, device="cuda")
+        rew = torch.empty((ticks, n), dtype=torch.float32, device="cuda")
+        done = torch.empty((ticks, n), dtype=torch.uint8, device="cuda")
+        half = ticks // 2
+        calls = [tenv._dev.prepare_rollout(half, _lib.ACT_PACKED, act[0].data_ptr(), act[1].data_ptr(), 0, _lib.OBS_F32, obs.data_ptr(),
+                                           rew.data_ptr(), done.data_ptr()),
+                 tenv._dev.prepare_rollout(ticks - half, _lib.ACT_PACKED, act[0][half:].data_ptr(), act[1][half:].data_ptr(), 0, _lib.OBS_F32,
+                                           obs[half:].data_ptr(), rew[half:].data_ptr(), done[half:].data_ptr())]
+        for c in calls:
+            c()
     else:
         obs, rew, done = tenv.rollout(ticks, act, outputs=True, obs_dtype=torch.float32 if mode == "rollout_f32" else torch.float64)
     torch.cuda.synchronize()
