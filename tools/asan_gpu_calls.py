@@ -64,5 +64,33 @@ for n in (130, 4096 + 37):
     assert not sm.resident_status().any()
     tv.close()
     print("ok resident", n, flush=True)
+# round 3: the native learner's host side (workspace carving, the three launchers, the optimizer state) and the trig self-test
+import ctypes as C
+from q1physrl_amd import ppo
+for mb in (1000, 4096):
+    tv = TensorVectorEnv(E.Config(**dict(E.Config.get_default().__dict__, num_envs=256)), device=0, seed=3)
+    pol = PL.Q1Policy().cuda()
+    nat = ppo.NativeStep(pol, tv, mb, splits=8)
+    total = 3 * mb
+    obs = torch.randn((total, 6), device="cuda")
+    idx = torch.randperm(total, device="cuda")[:mb].contiguous()
+    full = {"obs": obs, "old_logits": torch.randn((total, 10), device="cuda"), "keys_packed": torch.randint(0, 16, (total,), device="cuda", dtype=torch.uint8),
+            "mouse": torch.rand((total, 1), device="cuda") * 20 - 10, "logp": -torch.rand((total,), device="cuda"), "adv": torch.randn((total,), device="cuda"),
+            "value": torch.randn((total,), device="cuda"), "vtarg": torch.randn((total,), device="cuda")}
+    klc = torch.full((1,), 0.2, device="cuda")
+    for _ in range(2):
+        nat.step(full, idx, 0.1, 100.0, 1.0, 0.01, klc, skip_reduce=True)
+        nat.adam(1e-4)
+        nat.step(full, idx, 0.1, 100.0, 1.0, 0.01, klc, skip_reduce=False)
+        nat.images()
+    torch.cuda.synchronize()
+    assert all(torch.isfinite(p_).all() for p_ in pol.parameters())
+    tv.close()
+    print("ok learner", mb, flush=True)
+yaw = np.linspace(-7000.0, 7000.0, 5000)
+sn, cs, cnt = np.empty_like(yaw), np.empty_like(yaw), (C.c_uint64 * 4)()
+_lib.check(_lib.load().q1env_selftest_trig(0, yaw.size, yaw.ctypes.data, sn.ctypes.data, cs.ctypes.data, 5, cnt))
+assert cnt[2] == 0 and np.abs(sn - np.sin(yaw * np.pi / 180.0)).max() < 1e-15
+print("ok selftest_trig", flush=True)
 _lib.pinned_pool().trim()
 print("ASAN_GPU_CALLS_OK")
