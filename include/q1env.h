@@ -333,6 +333,9 @@ typedef struct q1env_learner_net {
 typedef struct q1env_learner_batch {
     int64_t minibatch;                 /* B */
     const int64_t* idx_dev;            /* int64[B]: rows of the arrays below that form the minibatch (NULL: rows 0..B-1) */
+    const int64_t* idx_cursor_dev;     /* optional device scalar: the minibatch is idx_dev[*cursor .. *cursor + B) - a whole epoch's permutation stays in
+                                        * idx_dev and the step replays from a captured graph without a copy per minibatch.  q1env_learner_adam keeps such
+                                        * a cursor at byte 72 of its adam_state (+= B per call; the caller zeroes it when it loads a new permutation) */
     const float* obs_dev;              /* float[total][6] */
     const float* old_logits_dev;       /* float[total][old_stride]: the behaviour policy's outputs */
     int old_stride;
@@ -358,7 +361,8 @@ int q1env_learner_step(q1env_t* env, const q1env_learner_net* pi, const q1env_le
  * the step count lives on the device, so the call is replayable from a captured graph); gw* / gb* receive the gradients too.
  * grad_scale = the one the partial sums carry (q1env_learner_step: the minibatch size B).  adam_state layout: int64 step count at byte 0,
  * float bias corrections [2] at byte 8, float running statistics [5] at byte 16 (+= the mean of stats_partials_dev - the step's
- * q1env_learner_batch.stats_partials_dev - per call, if not NULL; the caller zeroes them when it starts a new average), moments from 256. */
+ * q1env_learner_batch.stats_partials_dev - per call, if not NULL; the caller zeroes them when it starts a new average), an int64 minibatch
+ * cursor at byte 72 (+= minibatch per call: q1env_learner_batch.idx_cursor_dev may point at it), moments from 256. */
 uint64_t q1env_learner_adam_state_bytes(int out_dim_pi);
 int q1env_learner_adam(q1env_t* env, const q1env_learner_net* pi, const q1env_learner_net* vf, void* ws_dev, int64_t minibatch, int splits,
                        float grad_scale, float lr, float beta1, float beta2, float eps, void* adam_state_dev, const float* stats_partials_dev);

@@ -60,7 +60,7 @@ class Q1LearnerNet(C.Structure):     # q1env_learner_net
 
 
 class Q1LearnerBatch(C.Structure):   # q1env_learner_batch
-    _fields_ = [("minibatch", C.c_int64), ("idx_dev", C.c_void_p), ("obs_dev", C.c_void_p), ("old_logits_dev", C.c_void_p), ("old_stride", C.c_int),
+    _fields_ = [("minibatch", C.c_int64), ("idx_dev", C.c_void_p), ("idx_cursor_dev", C.c_void_p), ("obs_dev", C.c_void_p), ("old_logits_dev", C.c_void_p), ("old_stride", C.c_int),
                 ("keys_dev", C.c_void_p), ("mouse_dev", C.c_void_p), ("logp_old_dev", C.c_void_p), ("adv_dev", C.c_void_p),
                 ("value_old_dev", C.c_void_p), ("vtarg_dev", C.c_void_p),
                 ("clip_param", C.c_float), ("vf_clip_param", C.c_float), ("vf_loss_coeff", C.c_float), ("entropy_coeff", C.c_float),

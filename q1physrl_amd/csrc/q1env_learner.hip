@@ -88,6 +88,7 @@ int ensure_learner_attrs(q1env* h) {
 }
 
 int launch_forward(q1env* h, const Ws& w, int64_t mb, const q1env_learner_net* pi, const q1env_learner_net* vf, const float* obs, const int64_t* idx,
+                   const int64_t* idx_cursor,
                    float* logits, float* value) {
     if (int r = ensure_learner_attrs(h)) return r;
     const q1learn::FwdNet na{pi->w1, pi->b1, w.net[0].w23, pi->b2, pi->b3, logits, pi->out_dim, w.net[0].h1T, w.net[0].h2T};
@@ -96,13 +97,14 @@ int launch_forward(q1env* h, const Ws& w, int64_t mb, const q1env_learner_net* p
     const unsigned tiles = (unsigned)((mb + 31) / 32);
     unsigned blocks = (tiles + 7u) / 8u;
     if (blocks > cus) blocks = cus;
-    hipLaunchKernelGGL(q1learn::learner_forward_kernel, dim3(blocks * 2u), dim3(512), q1pol::LDS_TOTAL, h->stream, (int)mb, obs, idx, na, nb, 2);
+    hipLaunchKernelGGL(q1learn::learner_forward_kernel, dim3(blocks * 2u), dim3(512), q1pol::LDS_TOTAL, h->stream, (int)mb, obs, idx, idx_cursor, na, nb, 2);
     HIP_TRY(hipGetLastError());
     return 0;
 }
 
 int launch_backward(q1env* h, const Ws& w, int64_t mb, int splits, const q1env_learner_net* pi, const q1env_learner_net* vf, const float* obs,
-                    const int64_t* idx, const float* dlogits, const float* dvalue, float grad_scale, float grad_scale_v, bool reduce = true) {
+                    const int64_t* idx, const int64_t* idx_cursor, const float* dlogits, const float* dvalue, float grad_scale, float grad_scale_v,
+                    bool reduce = true) {
     if (int r = ensure_learner_attrs(h)) return r;
     const q1learn::BwdNet ba{w.net[0].w2t, w.net[0].w3t, dlogits, pi->out_dim, pi->out_dim, w.net[0].h1T, w.net[0].h2T,
                              w.net[0].dz2N, w.net[0].dz1N, w.net[0].h1N, w.net[0].h2N, w.net[0].xN, w.net[0].dyN};
@@ -112,7 +114,7 @@ int launch_backward(q1env* h, const Ws& w, int64_t mb, int splits, const q1env_l
     const unsigned tiles = (unsigned)((mb + 31) / 32);
     unsigned blocks = (tiles + 3u) / 4u;
     if (blocks > cus) blocks = cus;
-    hipLaunchKernelGGL(q1learn::learner_backward_kernel, dim3(blocks * 2u), dim3(256), q1learn::LDS_BWD, h->stream, (int)mb, obs, idx, ba, bb, 2);
+    hipLaunchKernelGGL(q1learn::learner_backward_kernel, dim3(blocks * 2u), dim3(256), q1learn::LDS_BWD, h->stream, (int)mb, obs, idx, idx_cursor, ba, bb, 2);
     const q1learn::WgNet wa{w.net[0].dz2N, w.net[0].dz1N, w.net[0].h1N, w.net[0].h2N, w.net[0].xN, w.net[0].dyN, w.net[0].partial};
     const q1learn::WgNet wb{w.net[1].dz2N, w.net[1].dz1N, w.net[1].h1N, w.net[1].h2N, w.net[1].xN, w.net[1].dyN, w.net[1].partial};
     hipLaunchKernelGGL(q1learn::learner_wgrad_kernel, dim3(2u * (unsigned)splits, 2, 2), dim3(256), 0, h->stream, (int)mb, wa, wb, splits);
@@ -157,7 +159,7 @@ int q1env_learner_forward(q1env_t* h, const q1env_learner_net* pi, const q1env_l
     if (int r = check_shape("q1env_learner_forward", minibatch, splits)) return r;
     DeviceGuard guard(h->device);
     const Ws w = carve_ws(ws_dev, minibatch, pi->out_dim, splits);
-    if (int r = launch_forward(h, w, minibatch, pi, vf, obs_dev, idx_dev, logits_out ? logits_out : w.logits, value_out ? value_out : w.value)) return r;
+    if (int r = launch_forward(h, w, minibatch, pi, vf, obs_dev, idx_dev, nullptr, logits_out ? logits_out : w.logits, value_out ? value_out : w.value)) return r;
     return Q1ENV_OK;
 }
 
@@ -169,7 +171,7 @@ int q1env_learner_backward(q1env_t* h, const q1env_learner_net* pi, const q1env_
     if (int r = check_shape("q1env_learner_backward", minibatch, splits)) return r;
     DeviceGuard guard(h->device);
     const Ws w = carve_ws(ws_dev, minibatch, pi->out_dim, splits);
-    return launch_backward(h, w, minibatch, splits, pi, vf, obs_dev, idx_dev, dlogits_dev, dvalue_dev, grad_scale, grad_scale);
+    return launch_backward(h, w, minibatch, splits, pi, vf, obs_dev, idx_dev, nullptr, dlogits_dev, dvalue_dev, grad_scale, grad_scale);
 }
 
 int q1env_learner_step(q1env_t* h, const q1env_learner_net* pi, const q1env_learner_net* vf, void* ws_dev, int splits, const q1env_learner_batch* b) {
@@ -186,21 +188,21 @@ int q1env_learner_step(q1env_t* h, const q1env_learner_net* pi, const q1env_lear
     DeviceGuard guard(h->device);
     const int64_t mb = b->minibatch;
     const Ws w = carve_ws(ws_dev, mb, pi->out_dim, splits);
-    if (int r = launch_forward(h, w, mb, pi, vf, b->obs_dev, b->idx_dev, w.logits, w.value)) return r;
+    if (int r = launch_forward(h, w, mb, pi, vf, b->obs_dev, b->idx_dev, b->idx_cursor_dev, w.logits, w.value)) return r;
     // per-sample (un-averaged) gradients for the policy, 1/64 of that for the value network: float16's normal range (q1learner.hpp)
     const float scale = (float)mb * learner_pi_upscale(), scale_v = (float)mb / learner_value_downscale();
     if (b->idx_dev)
         hipLaunchKernelGGL(ppo_loss_grad_kernel<true>, grid_for((int)mb, 256), dim3(256), 0, h->stream, h->p, (int)mb, (const float*)w.logits,
                            b->old_logits_dev, pi->out_dim, b->old_stride, b->keys_dev, b->mouse_dev, b->logp_old_dev, b->adv_dev, (const float*)w.value,
-                           b->value_old_dev, b->vtarg_dev, b->idx_dev, b->clip_param, b->vf_clip_param, b->vf_loss_coeff, b->entropy_coeff,
+                           b->value_old_dev, b->vtarg_dev, b->idx_dev, b->idx_cursor_dev, b->clip_param, b->vf_clip_param, b->vf_loss_coeff, b->entropy_coeff,
                            b->kl_coeff_dev, scale, scale_v, w.dlogits, w.dvalue, b->stats_partials_dev);
     else
         hipLaunchKernelGGL(ppo_loss_grad_kernel<false>, grid_for((int)mb, 256), dim3(256), 0, h->stream, h->p, (int)mb, (const float*)w.logits,
                            b->old_logits_dev, pi->out_dim, b->old_stride, b->keys_dev, b->mouse_dev, b->logp_old_dev, b->adv_dev, (const float*)w.value,
-                           b->value_old_dev, b->vtarg_dev, (const int64_t*)nullptr, b->clip_param, b->vf_clip_param, b->vf_loss_coeff, b->entropy_coeff,
+                           b->value_old_dev, b->vtarg_dev, (const int64_t*)nullptr, (const int64_t*)nullptr, b->clip_param, b->vf_clip_param, b->vf_loss_coeff, b->entropy_coeff,
                            b->kl_coeff_dev, scale, scale_v, w.dlogits, w.dvalue, b->stats_partials_dev);
     HIP_TRY(hipGetLastError());
-    return launch_backward(h, w, mb, splits, pi, vf, b->obs_dev, b->idx_dev, w.dlogits, w.dvalue, scale, scale_v, b->skip_reduce == 0);
+    return launch_backward(h, w, mb, splits, pi, vf, b->obs_dev, b->idx_dev, b->idx_cursor_dev, w.dlogits, w.dvalue, scale, scale_v, b->skip_reduce == 0);
 }
 
 uint64_t q1env_learner_adam_state_bytes(int out_dim_pi) {
@@ -225,7 +227,7 @@ int q1env_learner_adam(q1env_t* h, const q1env_learner_net* pi, const q1env_lear
     float* m_pi = (float*)(st + 256), *v_pi = m_pi + per_pi;
     float* m_vf = (float*)(st + 256 + align_up(2 * per_pi * 4u, 256)), *v_vf = m_vf + per_vf;
     hipLaunchKernelGGL(q1learn::adam_tick_kernel, dim3(1), dim3(64), 0, h->stream, step, bc, beta1, beta2, stats_partials_dev,
-                       (int)((minibatch + 255) / 256), 1.0f / (float)minibatch, (float*)(st + 16));
+                       (int)((minibatch + 255) / 256), 1.0f / (float)minibatch, (float*)(st + 16), (long long*)(st + 72), (long long)minibatch);
     const q1learn::AdamNet na{const_cast<float*>(pi->w1), const_cast<float*>(pi->b1), const_cast<float*>(pi->w2), const_cast<float*>(pi->b2),
                               const_cast<float*>(pi->w3), const_cast<float*>(pi->b3),
                               q1learn::Grads{pi->gw1, pi->gb1, pi->gw2, pi->gb2, pi->gw3, pi->gb3, pi->out_dim}, m_pi, v_pi, w.net[0].w23, w.net[0].w2t, w.net[0].w3t};

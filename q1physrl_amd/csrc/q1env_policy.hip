@@ -141,7 +141,7 @@ int q1env_ppo_loss_grad(q1env_t* h, int64_t batch, const float* logits, const fl
     if (row_stride < policy_row_width(h->p)) return fail(Q1ENV_ERR_INVALID_ARG, "q1env_ppo_loss_grad: row_stride too small");
     DeviceGuard guard(h->device);
     hipLaunchKernelGGL(ppo_loss_grad_kernel<false>, grid_for((int)batch, 256), dim3(256), 0, h->stream, h->p, (int)batch, logits, old_logits,
-                       row_stride, row_stride, keys, mouse, logp_old, adv, value, value_old, vtarg, (const int64_t*)nullptr, clip_param,
+                       row_stride, row_stride, keys, mouse, logp_old, adv, value, value_old, vtarg, (const int64_t*)nullptr, (const int64_t*)nullptr, clip_param,
                        vf_clip_param, vf_loss_coeff, entropy_coeff, kl_coeff_dev, 1.0f, 1.0f, dlogits, dvalue, partials);
     HIP_TRY(hipGetLastError());
     return Q1ENV_OK;

@@ -95,7 +95,9 @@ struct FwdNet {
 // The sampler's forward kernel (q1pol::mlp_forward_kernel<512>) with a gather in front and the activation stores inside; outputs are
 // bit-identical to q1env_policy_value_forward on the gathered rows.
 __global__ void __launch_bounds__(512, 1)
-learner_forward_kernel(int n, const float* __restrict__ obs, const int64_t* __restrict__ idx, FwdNet net_a, FwdNet net_b, int nets) {
+learner_forward_kernel(int n, const float* __restrict__ obs, const int64_t* __restrict__ idx, const int64_t* __restrict__ idx_cursor, FwdNet net_a,
+                       FwdNet net_b, int nets) {
+    if (idx && idx_cursor) idx += *idx_cursor;         // the minibatch = rows idx[cursor .. cursor + n) (q1env_learner_batch.idx_cursor_dev)
     using namespace q1pol;
     const uint32_t bgrid = nets == 2 ? gridDim.x / 2u : gridDim.x;
     const bool second = nets == 2 && blockIdx.x >= bgrid;
@@ -207,7 +209,9 @@ __device__ __forceinline__ void times_dtanh(f32x16& acc, const f16x8 h0, const f
 }
 
 __global__ void __launch_bounds__(256, 1)
-learner_backward_kernel(int n, const float* __restrict__ obs, const int64_t* __restrict__ idx, BwdNet net_a, BwdNet net_b, int nets) {
+learner_backward_kernel(int n, const float* __restrict__ obs, const int64_t* __restrict__ idx, const int64_t* __restrict__ idx_cursor, BwdNet net_a,
+                        BwdNet net_b, int nets) {
+    if (idx && idx_cursor) idx += *idx_cursor;
     const uint32_t bgrid = nets == 2 ? gridDim.x / 2u : gridDim.x;
     const bool second = nets == 2 && blockIdx.x >= bgrid;
     const uint32_t bid = second ? blockIdx.x - bgrid : blockIdx.x;
@@ -493,12 +497,12 @@ struct AdamNet {
 
 struct AdamHyper { float lr, beta1, beta2, eps; };
 
-// One small block per optimizer step: advances the device-resident step count, publishes the two bias corrections, and folds the loss
+// One small block per optimizer step: advances the device-resident step count and the minibatch cursor, publishes the two bias corrections, and folds the loss
 // kernel's per-block statistics (float[nblocks][5] sums over 256 samples each) into the running sums stats_acc[5] += sum / batch -
 // what three torch launches (sum, scale, accumulate) did per SGD step.
 __global__ void __launch_bounds__(64)
 adam_tick_kernel(long long* step, float* bc, float beta1, float beta2, const float* __restrict__ stats_partials, int nblocks, float inv_batch,
-                 float* stats_acc) {
+                 float* stats_acc, long long* idx_cursor, long long minibatch) {
     const uint32_t lane = threadIdx.x;
     if (stats_partials) {
         float s[5] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
@@ -516,6 +520,7 @@ adam_tick_kernel(long long* step, float* bc, float beta1, float beta2, const flo
     if (lane == 0) {
         const long long t = *step + 1;
         *step = t;
+        *idx_cursor += minibatch;                        // the next step's minibatch starts where this one ended (callers that pass no cursor ignore it)
         bc[0] = (float)(1.0 - pow((double)beta1, (double)t));
         bc[1] = (float)(1.0 - pow((double)beta2, (double)t));
     }

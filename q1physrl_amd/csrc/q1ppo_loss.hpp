@@ -27,10 +27,12 @@ __global__ void __launch_bounds__(256)
 ppo_loss_grad_kernel(Params p, int batch, const float* __restrict__ logits, const float* __restrict__ old_logits, int row_stride, int old_stride,
                      const uint8_t* __restrict__ keys, const float* __restrict__ mouse, const float* __restrict__ logp_old,
                      const float* __restrict__ adv, const float* __restrict__ value, const float* __restrict__ value_old,
-                     const float* __restrict__ vtarg, const int64_t* __restrict__ idx, float clip, float vf_clip, float vf_coeff, float ent_coeff,
+                     const float* __restrict__ vtarg, const int64_t* __restrict__ idx, const int64_t* __restrict__ idx_cursor, float clip, float vf_clip,
+                     float vf_coeff, float ent_coeff,
                      const float* __restrict__ kl_coeff_dev, float out_scale, float out_scale_v, float* __restrict__ dlogits, float* __restrict__ dvalue,
                      float* __restrict__ partials) {
     __shared__ float red[4][5];
+    if (GATHER && idx_cursor) idx += *idx_cursor;       // rows idx[cursor .. cursor + batch) (q1env_learner_batch.idx_cursor_dev)
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     const bool live = i < (uint32_t)batch;
     const float klc = *kl_coeff_dev;

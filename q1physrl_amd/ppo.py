@@ -80,6 +80,7 @@ class NativeStep:
         self.partials = torch.zeros(((self.mb + 255) // 256, len(STAT_KEYS)), dtype=torch.float32, device=dev)
         self.adam_state = torch.zeros((env._dev.learner_adam_state_bytes(policy.pi[4].out_features),), dtype=torch.uint8, device=dev)
         self.stats_acc = self.adam_state[16:36].view(torch.float32)      # running sums of the step statistics (q1env_learner_adam)
+        self.cursor = self.adam_state[72:80].view(torch.int64)           # minibatch cursor: += mb per adam() (q1env_learner_batch.idx_cursor_dev)
         self.images()
 
     def _net(self, seq):
@@ -115,14 +116,18 @@ class NativeStep:
         self.env._dev.learner_adam_dev(self.pi, self.vf, self.ws.data_ptr(), self.mb, self.splits, float(self.mb), lr, betas[0], betas[1], eps,
                                        self.adam_state.data_ptr(), self.partials.data_ptr())
 
-    def step(self, full, idx, clip_param, vf_clip_param, vf_loss_coeff, entropy_coeff, klc_dev, skip_reduce=False):
+    def step(self, full, idx, clip_param, vf_clip_param, vf_loss_coeff, entropy_coeff, klc_dev, skip_reduce=False, use_cursor=False):
         """full: dict of the whole trajectory batch (obs (total,6), old_logits (total,W), keys_packed, mouse, logp, adv, value, vtarg);
         idx int64 (B,) or None.  Returns the statistics vector (STAT_KEYS order, means over the minibatch).
         skip_reduce: the parameter gradients stay as split-K partial sums for adam() (.grad is then written by adam())."""
         L = self._lib
         ol = full["old_logits"]
-        assert ol.is_contiguous() and full["obs"].is_contiguous() and (idx is None or (idx.dtype == torch.int64 and idx.numel() == self.mb))
-        b = L.Q1LearnerBatch(self.mb, idx.data_ptr() if idx is not None else None, full["obs"].data_ptr(), ol.data_ptr(), ol.shape[1],
+        # use_cursor: idx is a whole epoch's permutation and the minibatch is idx[cursor : cursor + mb] with the device-resident cursor
+        # that adam() advances - nothing to copy per minibatch, and the step replays from a captured graph as it is
+        assert ol.is_contiguous() and full["obs"].is_contiguous() and (idx is None or idx.dtype == torch.int64)
+        assert idx is None or (idx.numel() >= self.mb if use_cursor else idx.numel() == self.mb)
+        b = L.Q1LearnerBatch(self.mb, idx.data_ptr() if idx is not None else None, self.cursor.data_ptr() if (use_cursor and idx is not None) else None,
+                             full["obs"].data_ptr(), ol.data_ptr(), ol.shape[1],
                              full["keys_packed"].data_ptr(), full["mouse"].data_ptr(), full["logp"].data_ptr(), full["adv"].data_ptr(),
                              full["value"].data_ptr(), full["vtarg"].data_ptr(), clip_param, vf_clip_param, vf_loss_coeff, entropy_coeff,
                              klc_dev.data_ptr(), self.partials.data_ptr(), int(bool(skip_reduce)))
@@ -166,6 +171,7 @@ class PPOLearner:
         self._native = None
         self._full = None
         self._idx = None
+        self._perm = None                       # native + own Adam: the epoch's permutation, read through the device-resident cursor
         # autocast_dtype (e.g. torch.bfloat16): the two MLPs' matrix products run on reduced-precision operands with float32
         # accumulation (master weights, loss, its gradient and Adam stay float32); fused_adam: one multi-tensor Adam launch
         self.autocast_dtype = autocast_dtype
@@ -197,11 +203,13 @@ class PPOLearner:
 
     def _sgd_step(self, mb):
         """One minibatch: forward, loss, backward, (gradient all-reduce,) Adam.  Returns the stats vector (STAT_KEYS order).
-        native: `mb` is ignored - the minibatch is rows self._idx of the persistent full-batch arrays self._full."""
+        native: `mb` is ignored - the minibatch is rows self._idx (or, with the library's own Adam, the window of self._perm at the
+        device-resident cursor) of the persistent full-batch arrays self._full."""
         if self.native:
             own_adam = self.world == 1 and self.native_adam       # no all-reduce between gradients and optimizer: one fused kernel
-            stats = self._native.step(self._full, self._idx, self.clip_param, self.vf_clip_param, self.vf_loss_coeff, self.entropy_coeff, self._klc,
-                                      skip_reduce=own_adam)
+            # own optimizer: the minibatch is a window of the epoch's permutation (self._perm) at the cursor adam() advances
+            stats = self._native.step(self._full, self._perm if own_adam else self._idx, self.clip_param, self.vf_clip_param, self.vf_loss_coeff,
+                                      self.entropy_coeff, self._klc, skip_reduce=own_adam, use_cursor=own_adam)
             if own_adam:                              # statistics accumulate in self._native.stats_acc
                 g = self.opt.param_groups[0]
                 self._native.adam(g["lr"], g["betas"], g["eps"])
@@ -248,9 +256,12 @@ class PPOLearner:
     def _capture(self, b, mb, dev):
         """Capture one SGD step on static minibatch buffers into a hipGraph (warm-up on a side stream first; the warm-up and
         capture steps trained on the first minibatch, so parameters and Adam moments are rolled back afterwards)."""
+        own_adam = self.native and self.world == 1 and self.native_adam
         if self.native:
             self._mb = None
             self._idx.copy_(torch.arange(mb, device=dev))
+            if own_adam:
+                self._perm.copy_(torch.arange(self._perm.numel(), device=dev))
         else:
             self._mb = {k: torch.empty((mb,) + tuple(v.shape[1:]), dtype=v.dtype, device=dev) for k, v in b.items()}
             for k, v in b.items():
@@ -275,7 +286,11 @@ class PPOLearner:
             if self.env is not None:
                 self.env.use_current_stream()
             for _ in range(3):
+                if own_adam:
+                    self._native.cursor.zero_()        # every warm-up step on the first minibatch (adam() advances the cursor)
                 one_step()
+            if own_adam:
+                self._native.cursor.zero_()
         torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize(dev)
         g = torch.cuda.CUDAGraph()
@@ -332,6 +347,7 @@ class PPOLearner:
             if self._full is None or self._full["adv"].shape[0] != total or self._idx.shape[0] != mb:
                 self._full = {k: torch.empty_like(b[k].reshape(total, -1) if k in ("obs", "old_logits") else b[k].reshape(-1)).contiguous() for k in keys_}
                 self._idx = torch.zeros((mb,), dtype=torch.int64, device=dev)
+                self._perm = torch.zeros((total,), dtype=torch.int64, device=dev)
                 self._native = NativeStep(self.policy, self.env, mb, self.native_splits)
                 self._graph = None
             for k in keys_:
@@ -343,12 +359,17 @@ class PPOLearner:
             self._acc.zero_()
         if self._native is not None:
             self._native.stats_acc.zero_()
+        own_adam = self.native and self.world == 1 and self.native_adam
         for _ in range(self.num_sgd_iter):
             perm = torch.randperm(total, device=dev, generator=self.gen)
+            if own_adam:                            # the whole epoch's order once; each step reads its window at the device-resident cursor
+                self._perm.copy_(perm)
+                self._native.cursor.zero_()
             for s in range(0, total - mb + 1, mb):
                 idx = perm[s:s + mb]
                 if self.native:
-                    self._idx.copy_(idx)
+                    if not own_adam:
+                        self._idx.copy_(idx)
                     if self.use_graph:
                         self._graph.replay()
                     else:

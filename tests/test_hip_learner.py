@@ -232,6 +232,44 @@ def test_native_step_never_produces_non_finite_gradients():
     env.close()
 
 
+def test_minibatch_cursor_selects_the_same_rows_as_an_index_copy():
+    """q1env_learner_batch.idx_cursor_dev: with a whole permutation in idx_dev and a device-resident cursor, step k's gradients equal
+    those of a step on a copy of perm[k mb : (k + 1) mb] bit for bit, and q1env_learner_adam advances the cursor by the minibatch."""
+    import torch
+    from q1physrl_amd import policy as P, ppo, sampler as S
+    torch.manual_seed(4)
+    pol = _policy(5, 2.0)
+    cfg, env = make_env(512, time_limit=1.0)
+    smp = S.GpuSampler(env, P.FusedPolicyForward(pol, env), horizon=8)
+    tr = smp.collect()
+    adv, vt = smp.advantages(tr, 0.99, 0.95)
+    t, n = tr["reward"].shape
+    total, mb = t * n, 1024
+    full = {"obs": tr["obs"][:t].reshape(total, 6).contiguous(), "old_logits": tr["logits"].reshape(total, -1).contiguous(),
+            "keys_packed": tr["keys"].reshape(-1), "mouse": tr["mouse"].reshape(-1), "logp": tr["logp"].reshape(-1),
+            "adv": ((adv - adv.mean()) / adv.std()).reshape(-1).contiguous(), "value": tr["value"][:t].reshape(-1).contiguous(),
+            "vtarg": vt.reshape(-1).contiguous()}
+    klc = torch.tensor(0.2, device="cuda")
+    perm = torch.randperm(total, device="cuda")
+    nat = ppo.NativeStep(pol, env, mb, splits=8)
+    for k in (0, 2, total // mb - 1):
+        nat.step(full, perm[k * mb:(k + 1) * mb].contiguous(), 0.3, 10.0, 1.0, 0.01, klc)
+        torch.cuda.synchronize()
+        want = [p.grad.detach().clone() for p in pol.parameters()]
+        nat.cursor.fill_(k * mb)
+        nat.step(full, perm, 0.3, 10.0, 1.0, 0.01, klc, use_cursor=True)
+        torch.cuda.synchronize()
+        for a, b in zip(want, [p.grad for p in pol.parameters()]):
+            assert torch.equal(a, b), k
+    nat.cursor.zero_()
+    w0 = [p.detach().clone() for p in pol.parameters()]
+    nat.step(full, perm, 0.3, 10.0, 1.0, 0.01, klc, skip_reduce=True, use_cursor=True)
+    nat.adam(1e-4)
+    torch.cuda.synchronize()
+    assert int(nat.cursor.item()) == mb and any(not torch.equal(a, p) for a, p in zip(w0, pol.parameters()))
+    env.close()
+
+
 def test_native_training_learns_strafe_jumping_in_seconds():
     """End-to-end regression of the whole GPU-resident stack (resident sampler + native learner, round 2's hyper-parameters): 200
     iterations = 0.42 G env-steps in ~17 s must take the zero-start reward from ~1 700 (plain running) past 4 200 - strafe-jumping
