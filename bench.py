@@ -35,9 +35,17 @@ env.py:507-510); all envs are reset on device at each episode end (inside the ti
 Multi-GPU: one process per GPU, the batch is split (65 536 envs per GPU, weak scaling), no collective on
 the data path; ranks only meet in the barriers around the timed region and in the MAX of the elapsed time.
 
-Timed region (every rank): graphs instantiated and uploaded, warm-up ticks, barrier + torch.cuda.synchronize();
-t0; start event; EXACTLY K ticks enqueued; stop event; ONE torch.cuda.synchronize(); t1; barrier.  `value` uses the MAX over
-ranks of t1 - t0 (host wall clock); `roofline` uses the HIP-event time between the two events on the launch stream.
+Timed region (every rank): graphs instantiated and uploaded, warm-up ticks, barrier + torch.cuda.synchronize(); t0; EXACTLY K ticks
+enqueued; completion; t1; torch.cuda.synchronize(); barrier.  `value` uses the MAX over ranks of t1 - t0 (host wall clock).
+  rollout mode (the default): no marker packets ride with the launch and completion is the kernel's own signal - the last wave to retire
+      its stores writes an end stamp and a sequence number into host-coherent pinned memory, which the host polls (q1env_signal_wait,
+      include/q1env.h "completion signal"; VERDICT r3 item 1: with hipEventRecord x 2 + a runtime synchronisation the driver's 20-tick
+      line was 54 % host latency).  The torch.cuda.synchronize() that follows t1 is the untimed check that nothing else was in flight;
+      its duration is reported (`host_split_us.post_sync_us`), as is `ms_per_step_incl_runtime_sync`, the same region's wall time had t1
+      been taken after it.  Kernel time of the timed region = device wall-clock stamps written by its first and last wave
+      (`roofline.device_stamp_us`); the SAME K ticks are then repeated from the same state between two HIP events on the launch stream
+      (`roofline.avg_launch_us`, what the roofline uses).
+  step / server modes: HIP events around the launches inside the timed region, ONE torch.cuda.synchronize() ends it (t1 after it).
 
 Output: ONE JSON line on rank 0 (contract in the task statement) with `roofline` and `cpu_baseline`.
 """
@@ -230,17 +238,28 @@ def sampler_block(dev_index, sizes=(32768, 262144), horizon=128, reps=4):
     return rows
 
 
-def load_pmc(mode, n):
-    """Hardware-counter figures of this mode's kernel at this batch size from the round's rocprofv3 PMC passes
-    (tools/profile_round3.sh -> tools/summarize_pmc.py -> profiles/pmc.json), or None if that size was not profiled.
+def load_pmc(mode, n, lib_build_id=None):
+    """(entry, stale): hardware-counter figures of this mode's kernel at this batch size from the round's rocprofv3 PMC passes
+    (tools/profile_round.sh -> tools/summarize_pmc.py -> profiles/pmc.json), or (None, False) if that size was not profiled.
     Entry: {"kernel": exact name, "ticks_per_launch": T the passes ran at, "fetch_x2_B", "write_B": HBM bytes per launch (FETCH_SIZE x 2
     per MI355X_MICROARCH.md's gfx950 correction, calibrated on calib_copy_kernel), "valu_busy_cycles": 4 x SQ_ACTIVE_INST_VALU per launch
-    (cycles in which a SIMD's VALU executes an instruction, summed over SIMDs), "insts_valu": SQ_INSTS_VALU per launch, "waves"}."""
+    (cycles in which a SIMD's VALU executes an instruction, summed over SIMDs), "insts_valu": SQ_INSTS_VALU per launch, "waves",
+    "build_id": q1env_build_id() of the library the passes profiled}.
+    Staleness guard: counters describe ONE build of the kernels.  When the entry's build_id (or the file's
+    top-level "_build_id") differs from the library this process loaded, the entry is withheld and stale = True: `traffic` and `valu`
+    become null instead of silently describing other code."""
     try:
         with open(os.path.join(ROOT, "profiles", "pmc.json")) as f:
-            return json.load(f).get(f"{mode}_{n}")
+            doc = json.load(f)
     except Exception:   # noqa: BLE001
-        return None
+        return None, False
+    ent = doc.get(f"{mode}_{n}")
+    if ent is None:
+        return None, False
+    bid = ent.get("build_id") or doc.get("_build_id")
+    if lib_build_id is not None and bid != lib_build_id:
+        return None, True
+    return ent, False
 
 
 def traffic_per_launch(pmc, n, ticks_per_launch, resident_state):
@@ -416,6 +435,13 @@ def main(argv=None):
     import torch.distributed as dist
     from q1physrl_amd import _lib, env as E, sharding
     DeviceEnv, injected, env_impl = load_env_class()
+    # which binary ran: sha256 of the loaded libq1env.so and the source hash compiled into it (q1physrl_amd/build.py sources_sha16)
+    try:
+        lib_sha16, lib_build_id = _lib.lib_sha16(), _lib.build_id()
+    except Exception as ex:   # noqa: BLE001 - only possible with the injected CPU stand-in on a box without the library
+        if not injected:
+            raise
+        lib_sha16, lib_build_id = None, f"unavailable ({ex!r})"
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -558,12 +584,14 @@ def main(argv=None):
             else:
                 if not prepare:
                     # (the timer events are recorded inside the q1env_rollout call of the first / last chunk, next to the launch itself)
+                    # timed = "signal": device stamps + the kernel-written completion signal (the timed region proper);
+                    # timed = "events": HIP events around the same launches (the cross-check pass that follows it)
                     rflags = 0
                     if timed and not started:
-                        rflags |= _lib.TIMER_START
+                        rflags |= _lib.STAMP_START if timed == "signal" else _lib.TIMER_START
                         started = True
                     if timed and left == chunk and not ends_episode:
-                        rflags |= _lib.TIMER_STOP
+                        rflags |= _lib.SIGNAL if timed == "signal" else _lib.TIMER_STOP
                         stopped = True
                     # (arguments converted once, outside the timed region: DeviceEnv.prepare_rollout)
                     calls.append(dev.prepare_rollout(chunk, _lib.ACT_PACKED, ka, ma, 0, _lib.OBS_F32, obsT.data_ptr(), rewT.data_ptr(),
@@ -574,7 +602,7 @@ def main(argv=None):
             if ends_episode and not prepare:
                 calls.append(functools.partial(dev.reset_philox_dev, 99, 0, True))   # zero_start_prob = 1: every env back to the start line
         if timed and not stopped:
-            calls.append(dev.timer_mark)
+            calls.append(dev.signal_mark if timed == "signal" else dev.timer_mark)
         return calls, launches
 
     def run(calls):
@@ -622,15 +650,41 @@ def main(argv=None):
                                " (tick server / producer timed out)" if mode == "server" else ""))
         dev.restore_state()
         run(plan_ticks(mode, warmup, 0)[0])       # the W untimed warm-up ticks
-        timed_calls, launches = plan_ticks(mode, steps, warmup, timed=True)
+        signalled = mode == "rollout" and hasattr(dev, "signal_wait") and os.environ.get("Q1_BENCH_NO_SIGNAL") != "1"
+        timed_calls, launches = plan_ticks(mode, steps, warmup, timed="signal" if signalled else "events")
+        wait = dev.signal_wait if signalled else None
         barrier()
-        t0 = time.perf_counter()
-        run(timed_calls)                          # EXACTLY `steps` ticks; HIP events on the launch stream around them
-        t_enq = time.perf_counter()
-        dsync()                                   # the ONE synchronisation that ends the timed region (device-wide: covers both streams)
-        own = time.perf_counter() - t0
-        host_split[mode] = {"enqueue_us": (t_enq - t0) * 1e6, "enqueue_to_sync_return_us": (t0 + own - t_enq) * 1e6}
-        ev_ms = dev.timer_elapsed()               # both events have completed: no further wait
+        if signalled:
+            t0 = time.perf_counter()
+            run(timed_calls)                      # EXACTLY `steps` ticks: first wave stamps the start, last wave stamps the end + signals
+            t_enq = time.perf_counter()
+            wait()                                # poll the host-coherent sequence word the kernel writes (no runtime synchronisation)
+            t1 = time.perf_counter()
+            dsync()                               # untimed: nothing else may have been in flight (and nothing was: see post_sync_us)
+            t2 = time.perf_counter()
+            own = t1 - t0
+            stamp_ms = dev.signal_elapsed() * 1e3
+            host_split[mode] = {"enqueue_us": (t_enq - t0) * 1e6, "enqueue_to_signal_seen_us": (t1 - t_enq) * 1e6,
+                                "post_sync_us": (t2 - t1) * 1e6, "wall_incl_runtime_sync_us": (t2 - t0) * 1e6,
+                                "device_stamp_us": stamp_ms * 1e3, "completion": "kernel-written signal polled by the host"}
+            # the same K ticks again, from the same state, between two HIP events on the launch stream (what `roofline` uses)
+            dev.restore_state()
+            run(plan_ticks(mode, warmup, 0)[0])
+            ev_calls, _l = plan_ticks(mode, steps, warmup, timed="events")
+            barrier()
+            run(ev_calls)
+            dsync()
+            ev_ms = dev.timer_elapsed()
+            host_split[mode]["hip_event_us"] = ev_ms * 1e3
+        else:
+            t0 = time.perf_counter()
+            run(timed_calls)                      # EXACTLY `steps` ticks; HIP events on the launch stream around them
+            t_enq = time.perf_counter()
+            dsync()                               # the ONE synchronisation that ends the timed region (device-wide: covers both streams)
+            own = time.perf_counter() - t0
+            host_split[mode] = {"enqueue_us": (t_enq - t0) * 1e6, "enqueue_to_sync_return_us": (t0 + own - t_enq) * 1e6,
+                                "completion": "torch.cuda.synchronize()"}
+            ev_ms = dev.timer_elapsed()           # both events have completed: no further wait
         if world > 1:
             dist.barrier()
         if not agree(mode != "server" or server_ok()):
@@ -693,67 +747,70 @@ def main(argv=None):
                       "as 8-byte tagged granules through L2 / HBM"}[mode]
 
     def roofline(mode, steps, launches_, ev_ms_, wall_):
-        """The roofline statement of `mode`'s kernel for a region of `steps` ticks in `launches_` launches and ev_ms_ of HIP-event time.
-        step:             HBM-bound formulation.  achieved = MEASURED HBM bytes per launch (rocprofv3 PMC, profiles/pmc.json) / launch
-                          time when this size was profiled, else the algorithmic 204 B/env-step; frac_nominal_204B always on the 204 B.
-        rollout / server: register-resident state: the tick is bound by VALU issue (one wave per SIMD at 65 536 envs issues its ~340
-                          float64-heavy VALU instructions per tick at one per ~5.2 cycles: tools/ubench_f64.hip).  achieved = VALU-busy
-                          SIMD-cycles per second (4 x SQ_ACTIVE_INST_VALU per env-step from the PMC pass x env-steps per launch / launch
-                          time), peak = SIMDs x 2.4 GHz; the measured HBM side is in `hbm`."""
+        """The roofline statement of `mode`'s dominant kernel for a region of `steps` ticks in `launches_` launches and ev_ms_ of HIP-event
+        time on the launch stream.  Always `bound: hbm` (the path has no dense contraction):
+            achieved = ALGORITHMIC bytes per launch / average launch duration, frac = achieved / 8 TB/s
+            traffic  = MEASURED HBM bytes per launch (rocprofv3 PMC, profiles/pmc.json) - null when that file was taken from another
+                       build of the library (`pmc_stale`) or does not hold this mode / size
+        step:             204 B per env-step (reads + writes the whole SoA state every tick).
+        rollout / server: the state stays in registers between ticks, so a launch of T ticks must move 34 B per env-step (5 B action
+                          in, 29 B obs / reward / done out) + the 170 B state once: that is the algorithmic figure, and `frac` says how
+                          far from the HBM roof the kernel is.  WHY it is that far - float64 VALU issue, one wave per SIMD - is in the
+                          `valu` sub-object (counters from the same PMC file, null when stale); frac_nominal_204B keeps the per-tick
+                          formulation's bytes on this kernel's time (passes 1 by construction: NOT a roofline fraction)."""
         tpl = steps / launches_
         kern_us = ev_ms_ * 1e3 / launches_
-        pmc = load_pmc(mode, n)
+        pmc, pmc_stale = load_pmc(mode, n, lib_build_id)
         resident = mode != "step"
         traffic = traffic_per_launch(pmc, n, tpl, resident)
         alg_bytes = (B_ALG * n * tpl) if not resident else (B_FUSED * n * tpl + B_STATE * n)
+        achieved = alg_bytes / (kern_us * 1e-6) / 1e9
         nominal = B_ALG * n * tpl / (kern_us * 1e-6) / 1e9
-        hbm_bytes = traffic if traffic is not None else alg_bytes
-        hbm = {"achieved_GBps": hbm_bytes / (kern_us * 1e-6) / 1e9, "peak_GBps": HBM_PEAK_GBPS,
-               "frac": hbm_bytes / (kern_us * 1e-6) / 1e9 / HBM_PEAK_GBPS, "bytes_per_launch": hbm_bytes,
-               "bytes_source": "rocprofv3 PMC (FETCH_SIZE x2 + WRITE_SIZE), profiles/pmc.json" if traffic is not None else
-                               "algorithmic (this size / mode is not in profiles/pmc.json)",
-               "algorithmic_bytes_per_launch": alg_bytes}
-        base = {"traffic": traffic, "kernel": kernel_name(mode), "avg_launch_us": kern_us, "ticks_per_launch": tpl,
-                "event_ms_per_step": ev_ms_ / steps, "us_per_tick": ev_ms_ * 1e3 / steps,
-                "wall_over_event": wall_ * 1e3 / ev_ms_ if ev_ms_ > 0 else None, "host_split_us": host_split.get(mode),
-                "env_steps_per_launch": n * tpl, "frac_nominal_204B": nominal / HBM_PEAK_GBPS,
-                "profile": (pmc or {}).get("source")}
+        hs = host_split.get(mode) or {}
+        stamp_us = hs.get("device_stamp_us")
+        r = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+             "kernel": kernel_name(mode), "avg_launch_us": kern_us, "ticks_per_launch": tpl, "launches": launches_,
+             "algorithmic_bytes_per_launch": alg_bytes,
+             "alg_bytes_per_env_step": B_ALG if not resident else B_FUSED, "alg_bytes_per_env_per_launch": 0.0 if not resident else B_STATE,
+             "event_ms_per_step": ev_ms_ / steps, "us_per_tick": ev_ms_ * 1e3 / steps,
+             "launch_duration_source": "HIP events on the launch stream" + (" (the K ticks repeated from the same state right after the timed "
+                                       "region; the timed region itself carries no marker packets - its kernel time is device_stamp_us)" if stamp_us else ""),
+             "device_stamp_us": stamp_us,
+             "wall_over_event": (wall_ * 1e6 / stamp_us) if stamp_us else (wall_ * 1e3 / ev_ms_ if ev_ms_ > 0 else None),
+             "wall_over_event_basis": "device stamps of the timed region" if stamp_us else "HIP events of the timed region",
+             "host_split_us": hs or None, "env_steps_per_launch": n * tpl, "frac_nominal_204B": nominal / HBM_PEAK_GBPS,
+             "traffic_frac_of_peak": (traffic / (kern_us * 1e-6) / 1e9 / HBM_PEAK_GBPS) if traffic is not None else None,
+             "traffic_over_algorithmic": (traffic / alg_bytes) if traffic is not None else None,
+             "pmc_stale": pmc_stale, "pmc_build_id": (pmc or {}).get("build_id"), "lib_build_id": lib_build_id,
+             "profile": (pmc or {}).get("source")}
         if not resident:
-            r = {"bound": "hbm", "achieved": hbm["achieved_GBps"], "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": hbm["frac"], **base,
-                 "alg_bytes_per_env_step": B_ALG, "achieved_algorithmic_GBps": nominal,
-                 "note": "per-tick formulation: every launch reads and writes the whole SoA state.  achieved = measured HBM bytes per launch "
-                         "(PMC) / (HIP-event time of the timed region / launches) - below the algorithmic 204 B because the write-back skips "
-                         "unchanged state words; frac_nominal_204B = the same time on the algorithmic bytes.  At 65 536 envs a launch moves "
-                         "13 MB (1.7 us at 8 TB/s) behind a ~1.8 us dependent-dispatch boundary: latency-bound by construction (DESIGN.md 6.1)."}
+            r["note"] = ("per-tick formulation: every launch reads and writes the whole SoA state (204 B per env-step).  At 65 536 envs a launch "
+                         "moves 13 MB (1.7 us at 8 TB/s) behind a ~1.8 us dependent-dispatch boundary: latency-bound by construction "
+                         "(DESIGN.md 6.1); the size sweep shows the same kernel at large batches.")
             return r
         simds = 1024.0                                  # 256 CUs x 4 SIMDs
-        peak = simds * PEAK_CLOCK_GHZ                  # G VALU-cycles per second the chip has
-        r = {"bound": "valu", "peak": peak, "unit": "Gcycle/s (VALU-busy SIMD cycles)", **base, "hbm": hbm,
-             "alg_bytes_per_env_step": B_FUSED, "alg_bytes_per_env_per_launch": B_STATE}
+        valu = None
         if pmc is not None and pmc.get("valu_busy_cycles"):
-            busy = float(pmc["valu_busy_cycles"]) * tpl / float(pmc.get("ticks_per_launch", 1))          # per launch of tpl ticks
-            r["achieved"] = busy / (kern_us * 1e-6) / 1e9
-            r["frac"] = r["achieved"] / peak
-            insts = float(pmc.get("insts_valu", 0.0)) / max(float(pmc.get("waves", 1.0)), 1.0) / float(pmc.get("ticks_per_launch", 1))
-            r["valu_insts_per_tick_per_wave"] = insts
+            t0_ = float(pmc.get("ticks_per_launch", 1))
+            waves = max(float(pmc.get("waves", 1.0)), 1.0)
+            busy = float(pmc["valu_busy_cycles"]) * tpl / t0_                                            # per launch of tpl ticks
+            insts = float(pmc.get("insts_valu", 0.0)) / waves / t0_
+            other = (float(pmc.get("insts_salu", 0.0)) + float(pmc.get("insts_mem", 0.0))) / waves / t0_
+            valu = {"valu_busy_Gcycles_per_s": busy / (kern_us * 1e-6) / 1e9, "chip_Gcycles_per_s": simds * PEAK_CLOCK_GHZ,
+                    "valu_busy_frac": busy / (kern_us * 1e-6) / 1e9 / (simds * PEAK_CLOCK_GHZ),
+                    "valu_insts_per_tick_per_wave": insts, "salu_and_memory_insts_per_tick_per_wave": other}
             # the issue limit of a LONE wave on its SIMD (what 65 536 envs on 1 024 SIMDs are): one instruction per 5.17 cycles whatever
             # its type - vector, scalar or memory (tools/ubench_f64.hip, tools/ubench_select.hip; 16.8 for a float64 transcendental)
-            waves_per_simd = max(1.0, n / 64.0 / simds)
-            if waves_per_simd <= 1.0 and insts > 0:
-                per_wave_tick = max(float(pmc.get("waves", 1.0)), 1.0) * float(pmc.get("ticks_per_launch", 1))
-                other = (float(pmc.get("insts_salu", 0.0)) + float(pmc.get("insts_mem", 0.0))) / per_wave_tick
-                r["salu_and_memory_insts_per_tick_per_wave"] = other
+            if max(1.0, n / 64.0 / simds) <= 1.0 and insts > 0:
                 floor_us = (insts + other) * 5.17 / (PEAK_CLOCK_GHZ * 1e3)
-                r["lone_wave_issue_floor_us_per_tick"] = floor_us
-                r["frac_of_lone_wave_issue_floor"] = floor_us / (ev_ms_ * 1e3 / steps)
-        else:
-            r["achieved"] = None
-            r["frac"] = None
-        r["note"] = ("register-resident kernel: the env state stays in registers between ticks, so HBM sees 34 B per env-step (5 B action in, "
-                     "29 B obs / reward / done out) + the 170 B state once per launch - `hbm` holds the MEASURED bytes and their fraction of 8 TB/s. "
-                     "What bounds it is VALU issue: achieved = VALU-busy SIMD cycles per second = 4 x SQ_ACTIVE_INST_VALU (rocprofv3 PMC pass of this "
-                     "kernel at this size, profiles/pmc.json) scaled to the launch / HIP-event launch time; peak = 1 024 SIMDs x 2.4 GHz.  "
-                     "frac_nominal_204B (the per-tick formulation's 204 B on this kernel's time) passes 1 by construction and is NOT a roofline fraction.")
+                valu["lone_wave_issue_floor_us_per_tick"] = floor_us
+                valu["frac_of_lone_wave_issue_floor"] = floor_us / (ev_ms_ * 1e3 / steps)
+        r["valu"] = valu
+        r["note"] = ("register-resident kernel: the env state stays in registers between ticks, so a launch must move 34 B per env-step (5 B action "
+                     "in, 29 B obs / reward / done out) + the 170 B state once - `achieved` is that figure over the measured launch time, `frac` "
+                     "its fraction of 8 TB/s, `traffic` the bytes the counters saw.  The kernel is NOT HBM-bound: its limiter is float64 VALU issue "
+                     "with one wave per SIMD (`valu`: busy cycles = 4 x SQ_ACTIVE_INST_VALU, instruction counts per tick and wave, and the "
+                     "lone-wave issue floor of tools/ubench_f64.hip).")
         if mode == "server":
             r["note"] += ("  server mode: per-tick outputs go to the stand-in producer wave through LDS and are not written to HBM; the tick-to-tick "
                           "latency additionally contains two LDS hand-offs.")
@@ -769,7 +826,9 @@ def main(argv=None):
                    "envs_per_gpu": n, "parallelism": f"batch-split x{world}, no collective",
                    "arithmetic": "float64 (float32 storage of vel/obs/reward), bit-identical to the NumPy reference"},
         "roofline": roof,
-        "mode": args.mode, "mode_fallback": fallback, "env_impl": env_impl,
+        "mode": args.mode, "mode_fallback": fallback, "env_impl": env_impl, "lib_sha16": lib_sha16, "lib_build_id": lib_build_id,
+        "ms_per_step_incl_runtime_sync": ((host_split.get(args.mode) or {}).get("wall_incl_runtime_sync_us") or wall * 1e6) / 1e3 / args.steps
+                                         if world == 1 else None,
         "per_rank": ranks,
         "parity": "max |pos - NumPy ref| over the 10 s rollout: measured live in cpu_baseline.parity_vs_gpu_after_719_ticks (N=1 runs); "
                   "tests/test_hip_fastpath.py::test_full_size_rollout_parity_65536_envs_720_ticks checks all 65 536 x 720 env-steps bit-exactly",

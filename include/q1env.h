@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define Q1ENV_ABI_VERSION 3
+#define Q1ENV_ABI_VERSION 4
 
 typedef enum q1env_status {
     Q1ENV_OK = 0,
@@ -184,10 +184,41 @@ int q1env_step_many(q1env_t* env, int ticks, int action_format, const void* act_
  * Per-tick outputs are tick-major and optional (NULL).  auto_reset bit 0: an env whose tick set `done`
  * is reset in-kernel with the Philox reset (as q1env_reset_philox) before its next tick; (ABI v3) Q1ENV_TIMER_START (4) /
  * Q1ENV_TIMER_STOP (8) may be added to record the handle's timer events around the launch inside this call (as q1env_step_many).
- * return_sum_dev (optional, double[N]) accumulates reward over the launch in float64. */
+ * return_sum_dev (optional, double[N]) accumulates reward over the launch in float64.
+ * (ABI v4) Q1ENV_STAMP_START (16) / Q1ENV_SIGNAL (32) / Q1ENV_SIGNAL_WAIT (64) in auto_reset: the completion signal below, written by
+ * this launch's own waves - no marker packets around the kernel and no runtime synchronisation to learn that it has finished. */
+#define Q1ENV_STAMP_START 16
+#define Q1ENV_SIGNAL 32
+#define Q1ENV_SIGNAL_WAIT 64
 int q1env_rollout(q1env_t* env, int ticks, int action_format, const void* act_a_dev, const void* act_b_dev,
                   uint64_t rng_seed, int obs_format, void* obs_dev, float* reward_dev, uint8_t* done_dev,
                   int auto_reset, double* return_sum_dev);
+
+/* ---- completion signal + device time stamps (ABI v4) ---------------------------------------------------------------------------
+ * A 20-tick launch of 65 536 envs is ~20 us of GPU work; hipEventRecord x 2 + a runtime synchronisation around it cost more host
+ * time than that (the driver's line was 54 % host latency).  The handle therefore owns three words of host-coherent
+ * pinned memory the KERNEL writes itself:
+ *   start stamp   the device's constant-rate wall clock (wall_clock64 = s_memrealtime) read by the first wave of a launch made with
+ *                 Q1ENV_STAMP_START
+ *   end stamp     the same clock read by the LAST wave to finish of a launch made with Q1ENV_SIGNAL (every wave, after its final
+ *                 stores and an agent-scope release fence, takes a ticket from a device counter; the wave that draws the last one
+ *                 knows all others have retired their stores)
+ *   sequence      that wave then stores the launch's sequence number with system-scope release: the host thread sees it over PCIe
+ *                 ~1 us later by polling its own cache line - q1env_signal_wait - instead of waiting for the dispatch's completion
+ *                 interrupt to travel through the runtime.
+ * Q1ENV_SIGNAL_WAIT makes the launching call itself poll until the signal arrives (one call across the ABI for launch + wait).
+ * q1env_signal_mark: the same end stamp + sequence from a one-wave kernel enqueued behind whatever the stream holds (for regions that
+ * do not end in a q1env_rollout launch).  q1env_signal_wait: poll (no sleep) until the last signal requested on this handle has
+ * arrived, or timeout_s passes (-> Q1ENV_ERR_HIP, message says so).  q1env_signal_read: the two stamps of the last signalled region
+ * and the clock's rate in Hz (hipDeviceAttributeWallClockRate).  The signal says the region's kernels have finished their work; the
+ * stream's own ordering (a later launch, hipMemcpy or synchronisation) is what makes their results visible to other agents, as
+ * always.  No reference counterpart (the reference is synchronous NumPy). */
+int q1env_signal_mark(q1env_t* env);
+int q1env_signal_wait(q1env_t* env, double timeout_s);
+int q1env_signal_read(q1env_t* env, uint64_t* start_ticks, uint64_t* end_ticks, double* ticks_per_second);
+/* (ABI v4) 16 hex digits identifying the sources this library was built from (sha256 over csrc/ and include/q1env.h and the compile
+ * flags, computed by q1physrl_amd/build.py): profiles/pmc.json records it, bench.py refuses counters taken from another build. */
+const char* q1env_build_id(void);
 
 /* current observation without stepping (env.py:392-400) */
 int q1env_observe(q1env_t* env, int obs_format, void* obs_dev);
@@ -359,7 +390,11 @@ int q1env_learner_step(q1env_t* env, const q1env_learner_net* pi, const q1env_le
  * parameters after a q1env_learner_step with skip_reduce): torch.optim.Adam's update (no weight decay, no amsgrad) on the float32
  * masters IN PLACE, moments and the step count in the caller's adam_state_dev (q1env_learner_adam_state_bytes bytes, zero-initialised;
  * the step count lives on the device, so the call is replayable from a captured graph); gw* / gb* receive the gradients too.
- * grad_scale = the one the partial sums carry (q1env_learner_step: the minibatch size B).  adam_state layout: int64 step count at byte 0,
+ * grad_scale = the minibatch size B of the q1env_learner_step (skip_reduce) that left the partial sums.  The step's float16 loss scales
+ * are applied INTERNALLY on top of it (policy network: x pi_upscale, default 256; value network: / value_downscale, default 1;
+ * csrc/q1env_learner.hip learner_pi_upscale / learner_value_downscale): the partial sums this function consumes are the ones
+ * q1env_learner_step leaves - those of q1env_learner_backward carry grad_scale only and are NOT valid input here.  vf->out_dim must be 1
+ * (the state block is sized for a scalar value head).  adam_state layout: int64 step count at byte 0,
  * float bias corrections [2] at byte 8, float running statistics [5] at byte 16 (+= the mean of stats_partials_dev - the step's
  * q1env_learner_batch.stats_partials_dev - per call, if not NULL; the caller zeroes them when it starts a new average), an int64 minibatch
  * cursor at byte 72 (+= minibatch per call: q1env_learner_batch.idx_cursor_dev may point at it), moments from 256. */

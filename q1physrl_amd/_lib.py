@@ -13,10 +13,11 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 # Q1ENV_LIB_PATH selects another build of the SAME library (tools/asan_check.sh: the AddressSanitizer build of the host side)
 LIB_PATH = os.environ.get("Q1ENV_LIB_PATH") or os.path.join(_PKG, "libq1env.so")
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 ACT_F64_ROWS, ACT_F32_ROWS, ACT_PACKED, ACT_RANDOM = 0, 1, 2, 3
 OBS_F64, OBS_F32 = 0, 1
 TIMER_START, TIMER_STOP = 4, 8     # q1env_step_many use_graph flags: record the handle's start / stop timer event around the launches
+STAMP_START, SIGNAL, SIGNAL_WAIT = 16, 32, 64   # q1env_rollout auto_reset flags: the kernel-written completion signal (include/q1env.h)
 FLAG_ON_GROUND, FLAG_JUMP_RELEASED, FLAG_ZERO_START, FLAG_LAST_KEY0 = 1, 2, 4, 8
 
 
@@ -130,6 +131,10 @@ _SIGNATURES = {
     "q1env_selftest_division": (C.c_int, [C.c_int, C.c_uint64, C.c_uint64, C.c_double, C.c_double, C.POINTER(C.c_uint64)]),
     "q1env_selftest_trig": (C.c_int, [C.c_int, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]),
     "q1env_calibrate_traffic": (C.c_int, [_P, C.c_int]),
+    "q1env_signal_mark": (C.c_int, [_P]),
+    "q1env_signal_wait": (C.c_int, [_P, C.c_double]),
+    "q1env_signal_read": (C.c_int, [_P, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_double)]),
+    "q1env_build_id": (C.c_char_p, []),
     "q1env_timer_start": (C.c_int, [_P]),
     "q1env_timer_stop": (C.c_int, [_P, C.POINTER(C.c_float)]),
     "q1env_timer_mark": (C.c_int, [_P]),
@@ -178,6 +183,18 @@ def load():
         raise Q1EnvError(f"libq1env ABI {lib.q1env_abi_version()} != binding ABI {ABI_VERSION}")
     _lib = lib
     return lib
+
+
+def lib_sha16():
+    """First 16 hex digits of the sha256 of the library file this process loads (bench.py prints it as `lib_sha16`)."""
+    import hashlib
+    with open(LIB_PATH, "rb") as f:
+        return hashlib.sha256(f.read()).hexdigest()[:16]
+
+
+def build_id():
+    """The source hash compiled into the loaded library (q1physrl_amd/build.py sources_sha16)."""
+    return load().q1env_build_id().decode()
 
 
 def check(rc):

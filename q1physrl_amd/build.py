@@ -42,6 +42,24 @@ def hipcc_path():
     raise RuntimeError("hipcc not found (set HIPCC or install ROCm); libq1env.so cannot be built")
 
 
+def sources_sha16(flags=None):
+    """16 hex digits over everything the library is built from: csrc/*.hip, csrc/*.hpp, include/q1env.h (names + contents, sorted)
+    and the compile flags.  Compiled into the library (q1env_build_id) and recorded by the profiling tools next to the counters they
+    take, so that bench.py can tell whether profiles/pmc.json describes the library it is running."""
+    import hashlib
+    h = hashlib.sha256()
+    for path in sorted(DEPS):
+        h.update(os.path.basename(path).encode() + b"\0")
+        with open(path, "rb") as f:
+            h.update(f.read())
+        h.update(b"\0")
+    h.update(" ".join(COMPILE_FLAGS if flags is None else flags).encode())
+    return h.hexdigest()[:16]
+
+
+BUILD_ID_TU = "q1env_core.hip"        # the translation unit that defines q1env_build_id()
+
+
 def _obj_of(src, tag):
     return os.path.join(OBJ_DIR, os.path.splitext(os.path.basename(src))[0] + tag + ".o")
 
@@ -76,16 +94,25 @@ def build_lib(force=False, verbose=False, check=False, extra_flags=(), out=None,
         tag = "_check" if check else ""
     if out == OUT:
         build_rows_helper(force=force, verbose=verbose)       # the host-side CPython helper rides with the product build
-    if not force and not is_stale(out):
-        return out
     os.makedirs(OBJ_DIR, exist_ok=True)
-    hipcc = hipcc_path()
     flags = COMPILE_FLAGS + (["-DQ1_CHECK=1"] if check else []) + list(extra_flags)
+    # the build id (hash of all sources + flags) is compiled into ONE translation unit; its stamp file makes that unit - and the
+    # link - stale whenever any source changed, even one that unit does not include
+    bid = sources_sha16(flags)
+    stamp = os.path.join(OBJ_DIR, "build_id" + tag + ".txt")
+    old = open(stamp).read().strip() if os.path.exists(stamp) else None
+    if old != bid:
+        with open(stamp, "w") as f:
+            f.write(bid + "\n")
+    if not force and not _stale(out, DEPS + [stamp]):
+        return out
+    hipcc = hipcc_path()
     jobs = []
     for src in SOURCES:
         obj = _obj_of(src, tag)
-        if force or _stale(obj, [src] + HEADERS):
-            jobs.append([hipcc] + flags + ["-c", src, "-o", obj])
+        is_id_tu = os.path.basename(src) == BUILD_ID_TU
+        if force or _stale(obj, [src] + HEADERS + ([stamp] if is_id_tu else [])):
+            jobs.append([hipcc] + flags + (['-DQ1_BUILD_ID="' + bid + '"'] if is_id_tu else []) + ["-c", src, "-o", obj])
     with concurrent.futures.ThreadPoolExecutor(max_workers=max(1, min(len(jobs), os.cpu_count() or 1))) as ex:
         list(ex.map(lambda c: _run(c, verbose), jobs))
     _run([hipcc] + LINK_FLAGS + [_obj_of(s, tag) for s in SOURCES] + ["-o", out + ".tmp"], verbose)

@@ -6,6 +6,7 @@
 
 #include <mutex>
 #include <new>
+#include <time.h>
 
 using namespace q1;
 
@@ -167,10 +168,11 @@ template <typename OBS_T, bool SPEC, int FMT, bool HAS_RESET, int OUT_MODE>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4)))
 rollout_kernel(Params p, StatePtrs s, int ticks, int fmt, const void* act_a, const void* act_b,
                uint64_t seed, uint64_t tick0, OBS_T* obs, float* reward, uint8_t* done,
-               int auto_reset, double* return_sum) {
+               int auto_reset, double* return_sum, Signal sg) {
     __shared__ float slab[4][384];
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t n = (uint32_t)p.n;
+    signal_start(sg);
     if (i >= n) return;
     Env e;
     load_env(s, n, i, e);
@@ -188,6 +190,14 @@ rollout_kernel(Params p, StatePtrs s, int ticks, int fmt, const void* act_a, con
     asm volatile("" : "+v"(i_st));
     store_env(s, n, i_st, e);
     if (return_sum) return_sum[i_st] += ret;
+    signal_done(sg);
+}
+
+// the end stamp + sequence number of the completion signal behind whatever the stream holds (q1env_signal_mark)
+__global__ void signal_mark_kernel(Signal sg) {
+    sg.waves = 1;
+    signal_start(sg);
+    signal_done(sg);
 }
 
 template <typename OBS_T>
@@ -336,6 +346,52 @@ int ensure_pin(q1env* h, size_t bytes) {
     HIP_TRY(hipHostMalloc(&h->pin, bytes, hipHostMallocDefault));
     h->pin_bytes = bytes;
     return 0;
+}
+
+// The completion signal's memory: three 64-bit words of host-coherent pinned memory (one cache line of its own) the kernels write
+// over PCIe, and the device-resident ticket counter.
+int ensure_signal(q1env* h) {
+    if (h->sig_host) return 0;
+    void* host = nullptr;
+    HIP_TRY(hipHostMalloc(&host, 256, hipHostMallocCoherent | hipHostMallocMapped));
+    memset(host, 0, 256);
+    void* dev = nullptr;
+    hipError_t e = hipHostGetDevicePointer(&dev, host, 0);
+    if (e == hipSuccess) e = hipMalloc((void**)&h->ticket_dev, 256);
+    if (e == hipSuccess) e = hipMemsetAsync(h->ticket_dev, 0, 256, h->stream);
+    if (e != hipSuccess) {
+        (void)hipHostFree(host);
+        if (h->ticket_dev) { (void)hipFree(h->ticket_dev); h->ticket_dev = nullptr; }
+        return fail(Q1ENV_ERR_HIP, std::string("completion signal set-up: ") + hipGetErrorString(e));
+    }
+    int khz = 0;
+    if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, h->device) == hipSuccess && khz > 0) h->wall_clock_hz = 1e3 * (double)khz;
+    else h->wall_clock_hz = 1e8;                       // gfx9: s_memrealtime counts at 100 MHz
+    h->sig_dev = (uint64_t*)dev;
+    h->sig_host = (volatile uint64_t*)host;
+    return 0;
+}
+
+// Poll the sequence word until the last requested signal has arrived.  No sleep, no yield: the caller asked for latency.
+int signal_wait(q1env* h, double timeout_s) {
+    const uint64_t want = h->sig_seq;
+    volatile uint64_t* seq = h->sig_host + 2;
+    if (*seq >= want) return Q1ENV_OK;
+    struct timespec t0;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    for (;;) {
+        for (int k = 0; k < 256; ++k) {
+            if (*seq >= want) return Q1ENV_OK;
+            __builtin_ia32_pause();
+        }
+        struct timespec t1;
+        clock_gettime(CLOCK_MONOTONIC, &t1);
+        if ((double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec) > timeout_s) {
+            const hipError_t q = hipStreamQuery(h->stream);
+            return fail(Q1ENV_ERR_HIP, std::string("completion signal did not arrive within the timeout (stream state: ") +
+                                       hipGetErrorString(q) + ")");
+        }
+    }
 }
 
 // Batches up to this many envs go through the handle's pinned staging as ONE block each way (the call count dominates there);
@@ -545,6 +601,8 @@ int q1env_destroy(q1env_t* h) {
     if (h->stage) (void)hipFree(h->stage);
     if (h->pin) (void)hipHostFree(h->pin);
     if (h->snap) (void)hipFree(h->snap);
+    if (h->sig_host) (void)hipHostFree((void*)h->sig_host);
+    if (h->ticket_dev) (void)hipFree(h->ticket_dev);
     if (h->arena) (void)hipFree(h->arena);
     if (h->own_stream) (void)hipStreamDestroy(h->stream);
     delete h;
@@ -820,14 +878,26 @@ int q1env_rollout(q1env_t* h, int ticks, int fmt, const void* a, const void* b, 
     if (obs_format != Q1ENV_OBS_F32 && obs_format != Q1ENV_OBS_F64) return fail(Q1ENV_ERR_INVALID_ARG, "bad obs_format");
     // (Q1ENV_TIMER_START / _STOP in auto_reset: record the handle's timer events around the launch, inside this call - as q1env_step_many)
     const bool t_start = (auto_reset & Q1ENV_TIMER_START) != 0, t_stop = (auto_reset & Q1ENV_TIMER_STOP) != 0;
+    // (ABI v4) the completion signal: stamps and sequence number written by the launch's own waves (include/q1env.h)
+    const bool s_start = (auto_reset & Q1ENV_STAMP_START) != 0, s_wait = (auto_reset & Q1ENV_SIGNAL_WAIT) != 0;
+    const bool s_done = (auto_reset & Q1ENV_SIGNAL) != 0 || s_wait;
     auto_reset &= 1;
+    Signal sg{};
+    if (s_start || s_done) {
+        if (int r = ensure_signal(h)) return r;
+        sg.sig = h->sig_dev;
+        sg.ticket = h->ticket_dev;
+        sg.waves = (uint32_t)((h->p.n + 63) / 64);
+        sg.flags = (s_start ? 1u : 0u) | (s_done ? 2u : 0u);
+        if (s_done) sg.seq = ++h->sig_seq;
+    }
     if (t_start) HIP_TRY(hipEventRecord(h->ev0, h->stream));
     const int blk = block_for(h->p.n);
     const dim3 g = grid_for(h->p.n, blk), bs(blk);
     const bool spec = is_spec(h->p);
 #define Q1_LAUNCH_ROLL(OT, SP, FM, HR, OM)                                                                           \
     hipLaunchKernelGGL((rollout_kernel<OT, SP, FM, HR, OM>), g, bs, 0, h->stream, h->p, h->st, ticks, fmt, a, b, seed, \
-                       h->tick_count, (OT*)obs, reward, done, auto_reset, return_sum)
+                       h->tick_count, (OT*)obs, reward, done, auto_reset, return_sum, sg)
     const bool all_out = obs && reward && done, no_out = !obs && !reward && !done;
     if (obs_format == Q1ENV_OBS_F32 && spec && (all_out || no_out) &&
         (fmt == Q1ENV_ACT_PACKED || fmt == Q1ENV_ACT_RANDOM)) {
@@ -852,8 +922,39 @@ int q1env_rollout(q1env_t* h, int ticks, int fmt, const void* a, const void* b, 
     HIP_TRY(hipGetLastError());
     if (t_stop) HIP_TRY(hipEventRecord(h->ev1, h->stream));
     h->tick_count += (uint64_t)ticks;
+    if (s_wait) return signal_wait(h, 30.0);
     return Q1ENV_OK;
 }
+
+int q1env_signal_mark(q1env_t* h) {
+    if (!h) return fail(Q1ENV_ERR_INVALID_ARG, "q1env_signal_mark: null handle");
+    DeviceGuard guard(h->device);
+    if (int r = ensure_signal(h)) return r;
+    Signal sg{h->sig_dev, h->ticket_dev, ++h->sig_seq, 1u, 2u};
+    hipLaunchKernelGGL(signal_mark_kernel, dim3(1), dim3(64), 0, h->stream, sg);
+    HIP_TRY(hipGetLastError());
+    return Q1ENV_OK;
+}
+
+int q1env_signal_wait(q1env_t* h, double timeout_s) {
+    if (!h) return fail(Q1ENV_ERR_INVALID_ARG, "q1env_signal_wait: null handle");
+    if (!h->sig_host) return fail(Q1ENV_ERR_INVALID_ARG, "q1env_signal_wait: no signal was requested on this handle");
+    return signal_wait(h, timeout_s);
+}
+
+int q1env_signal_read(q1env_t* h, uint64_t* start_ticks, uint64_t* end_ticks, double* hz) {
+    if (!h) return fail(Q1ENV_ERR_INVALID_ARG, "q1env_signal_read: null handle");
+    if (!h->sig_host) return fail(Q1ENV_ERR_INVALID_ARG, "q1env_signal_read: no signal was requested on this handle");
+    if (start_ticks) *start_ticks = h->sig_host[0];
+    if (end_ticks) *end_ticks = h->sig_host[1];
+    if (hz) *hz = h->wall_clock_hz;
+    return Q1ENV_OK;
+}
+
+#ifndef Q1_BUILD_ID
+#define Q1_BUILD_ID "unknown"
+#endif
+const char* q1env_build_id(void) { return Q1_BUILD_ID; }
 
 int q1env_observe(q1env_t* h, int obs_format, void* obs) {
     if (!h || !obs) return fail(Q1ENV_ERR_INVALID_ARG, "q1env_observe: null argument");

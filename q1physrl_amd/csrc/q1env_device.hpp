@@ -337,6 +337,34 @@ __device__ __forceinline__ void store_env_delta(const StatePtrs& s, uint32_t n, 
     if ((e.flags & 0xFFu) != (old.flags & 0xFFu)) s.flags[i] = (uint8_t)e.flags;
 }
 
+// ---------------------------------------------------------------------------------------- completion signal
+// include/q1env.h "completion signal": sig = three 64-bit words of host-coherent pinned memory (start stamp, end stamp, sequence).
+struct Signal {
+    uint64_t* sig;          // NULL: no stamps, no signal
+    uint32_t* ticket;       // device counter of waves that have retired their stores (returns to 0 with the last ticket)
+    uint64_t seq;           // the sequence number this launch publishes
+    uint32_t waves;         // waves of this launch that own at least one env
+    uint32_t flags;         // bit 0: stamp the start; bit 1: stamp the end + publish seq
+};
+__device__ __forceinline__ void signal_start(const Signal& g) {
+    if (g.sig && (g.flags & 1u) && blockIdx.x == 0 && threadIdx.x == 0)
+        __hip_atomic_store(g.sig, (uint64_t)wall_clock64(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+// Called by every wave that owns an env, after its last store.  The release fence orders the wave's stores before its ticket; the
+// wave that draws the last ticket has therefore seen every other wave's ticket AFTER that wave's stores were released.
+__device__ __forceinline__ void signal_done(const Signal& g) {
+    if (!g.sig || !(g.flags & 2u)) return;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    if ((threadIdx.x & 63u) == 0u) {
+        const uint32_t prev = __hip_atomic_fetch_add(g.ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        if (prev + 1u == g.waves) {
+            __hip_atomic_store(g.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(g.sig + 1, (uint64_t)wall_clock64(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(g.sig + 2, g.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------- Philox
 __host__ __device__ __forceinline__ void philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1) {
 #pragma unroll

@@ -81,7 +81,16 @@ struct q1env {
     struct GraphEntry { std::vector<uint64_t> key; hipGraphExec_t exec; };
     std::vector<GraphEntry> graphs;
     hipStream_t cap_stream = nullptr;  // private stream used only to CAPTURE (the null stream cannot be captured)
+    // completion signal (include/q1env.h "completion signal"): sig_host[0] = start stamp, [1] = end stamp, [2] = sequence number, written
+    // by the kernels themselves into host-coherent pinned memory; ticket_dev = device counter of retired waves; sig_seq = last requested
+    volatile uint64_t* sig_host = nullptr;
+    uint64_t* sig_dev = nullptr;
+    uint32_t* ticket_dev = nullptr;
+    uint64_t sig_seq = 0;
+    double wall_clock_hz = 0.0;
 };
+Q1_HIDDEN int ensure_signal(q1env* h);
+Q1_HIDDEN int signal_wait(q1env* h, double timeout_s);
 
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 

@@ -189,7 +189,8 @@ int q1env_learner_step(q1env_t* h, const q1env_learner_net* pi, const q1env_lear
     const int64_t mb = b->minibatch;
     const Ws w = carve_ws(ws_dev, mb, pi->out_dim, splits);
     if (int r = launch_forward(h, w, mb, pi, vf, b->obs_dev, b->idx_dev, b->idx_cursor_dev, w.logits, w.value)) return r;
-    // per-sample (un-averaged) gradients for the policy, 1/64 of that for the value network: float16's normal range (q1learner.hpp)
+    // per-sample (un-averaged) gradients x learner_pi_upscale() for the policy, / learner_value_downscale() (default 1) for the value
+    // network: float16's normal range (q1learner.hpp)
     const float scale = (float)mb * learner_pi_upscale(), scale_v = (float)mb / learner_value_downscale();
     if (b->idx_dev)
         hipLaunchKernelGGL(ppo_loss_grad_kernel<true>, grid_for((int)mb, 256), dim3(256), 0, h->stream, h->p, (int)mb, (const float*)w.logits,
@@ -218,6 +219,9 @@ int q1env_learner_adam(q1env_t* h, const q1env_learner_net* pi, const q1env_lear
         return fail(Q1ENV_ERR_INVALID_ARG, "q1env_learner_adam: bad hyper-parameter");
     if (int r = check_nets("q1env_learner_adam", pi, vf, true)) return r;
     if (int r = check_shape("q1env_learner_adam", minibatch, splits)) return r;
+    // the state block is sized by q1env_learner_adam_state_bytes(out_dim_pi), which assumes a scalar value head
+    if (vf->out_dim != 1) return fail(Q1ENV_ERR_INVALID_ARG, "q1env_learner_adam: vf->out_dim must be 1");
+    if (pi->out_dim < 1 || pi->out_dim > 32) return fail(Q1ENV_ERR_INVALID_ARG, "q1env_learner_adam: pi->out_dim must be in 1..32");
     DeviceGuard guard(h->device);
     const Ws w = carve_ws(ws_dev, minibatch, pi->out_dim, splits);
     char* st = (char*)adam_state_dev;

@@ -20,7 +20,7 @@
 // partials[block][5] = sums of (entropy, kl, -surrogate, total, vf) over the block's samples (no atomics; add them up and divide by B).
 // GATHER (the native learner, q1learner.hpp): sample i of the minibatch is row idx[i] of the per-sample inputs (old_logits with
 // old_stride, keys, mouse, logp_old, adv, value_old, vtarg - the whole trajectory batch, never copied); logits / value / dlogits /
-// dvalue are minibatch-local rows i.  out_scale / out_scale_v multiply dlogits / dvalue (the learner asks for B x / (B / 64) x the averaged
+// dvalue are minibatch-local rows i.  out_scale / out_scale_v multiply dlogits / dvalue (the learner asks for B x pi_upscale / (B / value_downscale) x the averaged
 // gradient so that it sits in float16's normal range; 1 otherwise); the statistics are unaffected.
 template <bool GATHER>
 __global__ void __launch_bounds__(256)

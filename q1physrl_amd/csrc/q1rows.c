@@ -72,7 +72,9 @@ static int component(PyObject* x, double* out) {
         const int r = first_of_ndarray(x, out);
         if (r != -2) return r;
     }
-    if (PyObject_CheckBuffer(x)) return first_of_buffer(x, out);         /* other arrays of length >= 1, NumPy scalars */
+    /* other ndarrays of length >= 1 and NumPy scalars ONLY: bytes / bytearray / memoryview also speak the buffer protocol, but the
+     * reference's np.ravel(x)[0] (env.py:223) yields a non-numeric element for them and fails later - they go back to the NumPy path */
+    if ((PyArray_Check(x) || PyArray_IsScalar(x, Generic)) && PyObject_CheckBuffer(x)) return first_of_buffer(x, out);
     if (PyFloat_Check(x) || PyLong_Check(x)) {                           /* subclasses */
         const double d = PyFloat_AsDouble(x);
         if (d == -1.0 && PyErr_Occurred()) { PyErr_Clear(); return -1; }

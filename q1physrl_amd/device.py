@@ -334,6 +334,21 @@ class DeviceEnv:
     def calibrate_traffic(self, launches=10):
         _lib.check(self._lib.q1env_calibrate_traffic(self._h, int(launches)))
 
+    # ---- completion signal (include/q1env.h, ABI v4): stamps + sequence number written by the kernels themselves
+    def signal_mark(self):
+        """End stamp + sequence number behind whatever the stream holds (for regions that do not end in a rollout launch)."""
+        _lib.check(self._lib.q1env_signal_mark(self._h))
+
+    def signal_wait(self, timeout_s=30.0):
+        """Poll the host-coherent sequence word until the last requested signal has arrived."""
+        _lib.check(self._lib.q1env_signal_wait(self._h, float(timeout_s)))
+
+    def signal_elapsed(self):
+        """Seconds between the start stamp and the end stamp of the last signalled region (the device's constant-rate wall clock)."""
+        a, b, hz = C.c_uint64(), C.c_uint64(), C.c_double()
+        _lib.check(self._lib.q1env_signal_read(self._h, C.byref(a), C.byref(b), C.byref(hz)))
+        return (int(b.value) - int(a.value)) / hz.value
+
     def timer_start(self):
         _lib.check(self._lib.q1env_timer_start(self._h))
 

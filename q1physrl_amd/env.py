@@ -599,20 +599,23 @@ def _register():
                      kwargs={'config': Config.get_default()})
     except Exception as ex:                          # noqa: BLE001
         # A duplicate id (gym.error.Error('Cannot re-register id: ...'), e.g. the reference package imported first) is expected
-        # and silent.  Anything else - a gym / gymnasium whose register() has another signature or message - is downgraded to a
-        # warning: the package's own registry entry above already serves q1physrl_amd.make(), and an import-time failure of the
-        # whole module (the reference's registration at env.py:516-521 never raises on import) would be worse than a missing
-        # gym-side entry.
+        # and silent - the only error that is swallowed.
         dup = False
         try:
             import gym.error as _gerr
             dup = isinstance(ex, _gerr.Error) and ('re-register' in str(ex) or 'already registered' in str(ex).lower())
         except Exception:                            # noqa: BLE001 - gym without gym.error: fall back to the message
             dup = 're-register' in str(ex) or 'already registered' in str(ex).lower()
-        if not dup:
-            import warnings
-            warnings.warn(f"q1physrl_amd: gym registration of 'Q1PhysEnv-v0' failed ({ex!r}); "
-                          "q1physrl_amd.make('Q1PhysEnv-v0') still works", RuntimeWarning, stacklevel=2)
+        if dup:
+            return
+        # anything else is genuine breakage (wrong entry_point / kwargs, a gym whose register() changed): fail at import like any
+        # other import-time error, unless the caller explicitly asks for the lenient behaviour
+        import os
+        if os.environ.get("Q1PHYSRL_LENIENT_GYM_REGISTER") != "1":
+            raise
+        import warnings
+        warnings.warn(f"q1physrl_amd: gym registration of 'Q1PhysEnv-v0' failed ({ex!r}); "
+                      "q1physrl_amd.make('Q1PhysEnv-v0') still works", RuntimeWarning, stacklevel=2)
 
 
 _register()

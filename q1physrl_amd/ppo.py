@@ -65,7 +65,7 @@ class NativeStep:
     not zero_grad(set_to_none=True)); the caller runs the optimizer and then images() to rebuild the kernels' float16 weight images.
     The minibatch is rows idx of the FULL trajectory arrays (gathered inside the kernels, nothing is copied)."""
 
-    def __init__(self, policy, env, minibatch, splits=32):
+    def __init__(self, policy, env, minibatch, splits=32, adam_state=None):
         from . import _lib
         self.policy, self.env, self.mb, self.splits = policy, env, int(minibatch), int(splits)
         self._lib = _lib
@@ -78,7 +78,13 @@ class NativeStep:
         nbytes = env._dev.learner_workspace_bytes(self.mb, policy.pi[4].out_features, self.splits)
         self.ws = torch.empty((nbytes,), dtype=torch.uint8, device=dev)
         self.partials = torch.zeros(((self.mb + 255) // 256, len(STAT_KEYS)), dtype=torch.float32, device=dev)
-        self.adam_state = torch.zeros((env._dev.learner_adam_state_bytes(policy.pi[4].out_features),), dtype=torch.uint8, device=dev)
+        # the optimizer's moments and step count: owned by the caller when given (PPOLearner keeps ONE across re-builds of this object -
+        # a different minibatch size must not zero Adam's history; its size depends on the network shape only)
+        nstate = env._dev.learner_adam_state_bytes(policy.pi[4].out_features)
+        if adam_state is None:
+            adam_state = torch.zeros((nstate,), dtype=torch.uint8, device=dev)
+        assert adam_state.numel() == nstate and adam_state.dtype == torch.uint8 and adam_state.device == dev
+        self.adam_state = adam_state
         self.stats_acc = self.adam_state[16:36].view(torch.float32)      # running sums of the step statistics (q1env_learner_adam)
         self.cursor = self.adam_state[72:80].view(torch.int64)           # minibatch cursor: += mb per adam() (q1env_learner_batch.idx_cursor_dev)
         self.images()
@@ -169,6 +175,8 @@ class PPOLearner:
         if (self.fused_loss or self.native) and env is None:
             raise ValueError("fused_loss=True / native=True need env= (the TensorVectorEnv whose handle runs the kernels)")
         self._native = None
+        self._adam_state = None                 # native own-Adam moments + step count: allocated once, survives NativeStep re-builds
+        self._graph_hparams = None              # (lr, betas, eps) baked into the captured graph's kernel arguments
         self._full = None
         self._idx = None
         self._perm = None                       # native + own Adam: the epoch's permutation, read through the device-resident cursor
@@ -316,6 +324,28 @@ class PPOLearner:
             self._native.images()                    # the float16 images follow the restored masters
         self._graph = g
 
+    def _hparams(self):
+        g = self.opt.param_groups[0]
+        return (float(g["lr"]), tuple(float(x) for x in g["betas"]), float(g["eps"]))
+
+    def state_dict(self):
+        """Everything a resume needs: torch Adam's state (the non-native / multi-rank paths), the native optimizer's moments and step
+        count (q1env_learner_adam's state block; self.opt is never stepped on that path, so its state_dict() is empty there), and the
+        adaptive KL coefficient."""
+        return {"opt": self.opt.state_dict(), "kl_coeff": float(self.kl_coeff),
+                "native_adam": None if self._adam_state is None else self._adam_state.detach().cpu().clone()}
+
+    def load_state_dict(self, sd):
+        self.opt.load_state_dict(sd["opt"])
+        self.kl_coeff = float(sd.get("kl_coeff", self.kl_coeff))
+        na = sd.get("native_adam")
+        if na is not None:
+            dev = next(self.policy.parameters()).device
+            if self._adam_state is None:
+                self._adam_state = na.to(dev).clone()
+            else:
+                self._adam_state.copy_(na.to(dev))       # in place: a captured graph / NativeStep hold this address
+
     def update(self, traj, adv, vtarg):
         """SGD epochs over one trajectory batch; adv/vtarg from q1env_gae.  Returns averaged stats (python floats)."""
         dev = adv.device
@@ -348,12 +378,17 @@ class PPOLearner:
                 self._full = {k: torch.empty_like(b[k].reshape(total, -1) if k in ("obs", "old_logits") else b[k].reshape(-1)).contiguous() for k in keys_}
                 self._idx = torch.zeros((mb,), dtype=torch.int64, device=dev)
                 self._perm = torch.zeros((total,), dtype=torch.int64, device=dev)
-                self._native = NativeStep(self.policy, self.env, mb, self.native_splits)
+                self._native = NativeStep(self.policy, self.env, mb, self.native_splits, adam_state=self._adam_state)
+                self._adam_state = self._native.adam_state      # first build allocates it; later builds (other mb / total) reuse it
                 self._graph = None
             for k in keys_:
                 self._full[k].copy_(b[k].reshape(self._full[k].shape))
+        # lr / betas / eps are kernel ARGUMENTS of the native Adam, baked into a captured graph: a changed param_group re-captures
+        if self.use_graph and self._graph is not None and self.native and self._graph_hparams != self._hparams():
+            self._graph = None
         if self.use_graph and (self._graph is None or (not self.native and self._mb["adv"].shape[0] != mb)):
             self._capture(b, mb, dev)
+            self._graph_hparams = self._hparams()
         acc, steps = torch.zeros((len(STAT_KEYS),), dtype=torch.float32, device=dev), 0
         if self.use_graph:
             self._acc.zero_()

@@ -41,11 +41,13 @@ class FakeDeviceEnv:
     def step_many_dev(self, ticks, action_format, act_a, act_b=0, obs_format=1, obs=0, reward=0, done=0, out_stride_ticks=0,
                       use_graph=True):
         self.calls.append(("step_many", ticks, int(use_graph)))
-        flags, use_graph = int(use_graph) & 12, int(use_graph) & 3
+        flags, use_graph = int(use_graph) & 124, int(use_graph) & 3
         if use_graph == 2:                           # prepare only
             return
         if flags & 4:
             self.timer_start()
+        if flags & 16:                               # Q1ENV_STAMP_START: the "device" start stamp
+            self._s0 = time.perf_counter()
         n = self.n
         for t in range(ticks):
             ot = t if out_stride_ticks else 0
@@ -55,6 +57,8 @@ class FakeDeviceEnv:
                        _view(done + ot * n, n, np.uint8) if done else None)
         if flags & 8:
             self.timer_mark()
+        if flags & (32 | 64):                        # Q1ENV_SIGNAL / _WAIT: end stamp + sequence number (synchronous stand-in)
+            self.signal_mark()
 
     def persistent_start(self, *a):
         raise RuntimeError("the oracle stand-in has no tick server")
@@ -70,7 +74,7 @@ class FakeDeviceEnv:
     def rollout_dev(self, ticks, action_format, act_a=0, act_b=0, rng_seed=0, obs_format=1, obs=0, reward=0, done=0,
                     auto_reset=False, return_sum=0):
         self.calls.append(("rollout", ticks))
-        self.step_many_dev(ticks, action_format, act_a, act_b, obs_format, obs, reward, done, out_stride_ticks=1, use_graph=int(auto_reset) & 12)
+        self.step_many_dev(ticks, action_format, act_a, act_b, obs_format, obs, reward, done, out_stride_ticks=1, use_graph=int(auto_reset) & 124)
         self.calls.pop()
 
     def prepare_rollout(self, *a, **k):
@@ -84,6 +88,17 @@ class FakeDeviceEnv:
 
     def sync(self):
         pass
+
+    # completion signal of the real handle (include/q1env.h, ABI v4): the stand-in runs synchronously, so the signal has always arrived
+    def signal_mark(self):
+        self._s1 = time.perf_counter()
+        self._signalled = True
+
+    def signal_wait(self, timeout_s=30.0):
+        assert getattr(self, "_signalled", False), "signal_wait without a signalled launch"
+
+    def signal_elapsed(self):
+        return self._s1 - self._s0
 
     def timer_start(self):
         self._t0 = time.perf_counter()

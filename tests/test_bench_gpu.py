@@ -30,10 +30,19 @@ def test_driver_line_single_gpu():
     assert d["env_impl"] == "q1physrl_amd.device.DeviceEnv" and d["mode"] == "rollout" and d["mode_fallback"] is None
     assert d["n_gpus"] == 1 and d["steps"] == 20 and d["config"]["envs_per_gpu"] == 65536 and "written tick-major to HBM" in d["config"]["workload"]
     ro = d["roofline"]
-    assert ro["bound"] == "valu" and ro["kernel"].startswith("rollout_kernel<float, true, 2, false, 1>")
-    # a roofline fraction is a fraction: whatever axis it is on, it cannot pass 1 (the 204-B nominal figure may, and is kept aside)
-    assert ro["frac"] is None or 0.0 < ro["frac"] <= 1.0
-    assert 0.0 < ro["hbm"]["frac"] <= 1.0
+    assert ro["bound"] == "hbm" and ro["kernel"].startswith("rollout_kernel<float, true, 2, false, 1>")
+    # a roofline fraction is a fraction: it cannot pass 1 (the 204-B nominal figure may, and is kept aside)
+    assert 0.0 < ro["frac"] <= 1.0 and abs(ro["frac"] - ro["achieved"] / 8000.0) < 1e-9
+    # which binary ran and whether the counter file describes it
+    from q1physrl_amd import _lib, build
+    assert d["lib_sha16"] == _lib.lib_sha16() and d["lib_build_id"] == build.sources_sha16() and ro["pmc_stale"] in (True, False)
+    assert (ro["traffic"] is None) or not ro["pmc_stale"]
+    # the timed region ends in the kernel-written completion signal; what the runtime synchronisation would have
+    # added is reported next to it; the device stamps of the timed region fit inside its wall time
+    hs = ro["host_split_us"]
+    assert hs["completion"].startswith("kernel-written signal") and 0 < hs["device_stamp_us"] <= d["ms_per_step"] * 20 * 1e3
+    assert d["ms_per_step_incl_runtime_sync"] >= d["ms_per_step"]
+    assert ro["wall_over_event"] >= 1.0
     st = d["per_tick_step"]["roofline"]
     assert st["bound"] == "hbm" and 0.0 < st["frac"] <= 1.0
     sv = d["persistent_server"]

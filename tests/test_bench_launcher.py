@@ -99,17 +99,25 @@ def test_server_mode_failure_is_collective_and_auto_falls_back():
 def test_default_mode_writes_per_tick_outputs_and_says_what_bounds_it():
     """the default mode times a kernel whose per-tick obs / reward / done reach memory (the fused rollout: the
     stand-in's tick-major output tensors are really written), the workload string is the mode's own, the kernel name carries its
-    template arguments, and the roofline object names the bound of a register-resident kernel (VALU issue) with the HBM side next
-    to it; the 204-B figure survives only as frac_nominal_204B."""
+    template arguments, and the roofline object follows the contract's schema: bound hbm, achieved = ALGORITHMIC bytes of the
+    register-resident kernel (34 B per env-step + 170 B per env per launch) over the launch time, frac a fraction; the VALU analysis
+    sits in `valu`; the 204-B figure survives only as frac_nominal_204B.  VERDICT r3 item 1: the timed region of the default mode ends
+    in the kernel-written completion signal (no runtime synchronisation inside it), the runtime sync after it is reported."""
     r = _run([sys.executable, "bench.py", "--gpus", "1", "--steps", "20", "--warmup", "5", "--envs", "32", "--no-cpu-baseline"], timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]
     d = _one_json(r.stdout)
     assert d["mode"] == "rollout" and d["mode_fallback"] is None
     assert "mode=rollout" in d["config"]["workload"] and "written tick-major to HBM" in d["config"]["workload"]
     ro = d["roofline"]
-    assert ro["bound"] == "valu" and ro["kernel"].startswith("rollout_kernel<float, true, 2, false, 1>") and "SPEC, ES" not in ro["kernel"]
-    assert set(("hbm", "frac_nominal_204B", "traffic", "peak", "unit", "ticks_per_launch")) <= set(ro)
-    assert ro["hbm"]["peak_GBps"] == 8000.0 and ro["ticks_per_launch"] == 20
+    assert ro["bound"] == "hbm" and ro["kernel"].startswith("rollout_kernel<float, true, 2, false, 1>") and "SPEC, ES" not in ro["kernel"]
+    assert set(("valu", "frac_nominal_204B", "traffic", "peak", "unit", "ticks_per_launch", "achieved", "frac", "pmc_stale", "device_stamp_us")) <= set(ro)
+    assert ro["peak"] == 8000.0 and ro["unit"] == "GB/s" and ro["ticks_per_launch"] == 20
+    assert abs(ro["algorithmic_bytes_per_launch"] - (34.0 * 32 * 20 + 170.0 * 32)) < 1e-6
+    assert abs(ro["achieved"] - ro["algorithmic_bytes_per_launch"] / (ro["avg_launch_us"] * 1e-6) / 1e9) <= 1e-9 * ro["achieved"]
+    assert abs(ro["frac"] - ro["achieved"] / ro["peak"]) < 1e-12
+    hs = ro["host_split_us"]
+    assert hs["completion"].startswith("kernel-written signal") and hs["post_sync_us"] >= 0 and hs["device_stamp_us"] > 0 and hs["hip_event_us"] > 0
+    assert d["ms_per_step_incl_runtime_sync"] >= d["ms_per_step"] and "lib_sha16" in d and "lib_build_id" in d
     # secondaries: the per-tick kernels (HBM-bound formulation), each with its own workload string and roofline
     st = d["per_tick_step"]
     assert st["roofline"]["bound"] == "hbm" and "mode=step" in st["workload"] and st["roofline"]["kernel"].startswith("step_kernel<float, true, 2>")

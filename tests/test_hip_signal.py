@@ -1,0 +1,90 @@
+"""GPU: the kernel-written completion signal of q1env_rollout (include/q1env.h "completion signal", ABI v4).
+The signal must (a) change no result, (b) arrive exactly once per signalled launch, in order, with the sequence word the host polls,
+(c) only after every wave of the launch has retired its stores - the outputs copied to the host right after the wait are complete,
+(d) carry device stamps whose difference is a sane kernel duration, and (e) work for ragged batches (a tail wave with inactive lanes)
+and for q1env_signal_mark behind a launch that carries no signal itself."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(n, ticks, seed=3):
+    import torch
+    from q1physrl_amd import _lib, env as E
+    from q1physrl_amd.device import DeviceEnv
+    cfg = E.Config(**{**E.Config.get_default().__dict__, "num_envs": n, "zero_start_prob": 1.0})
+    d = torch.device("cuda", 0)
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    keys = torch.randint(0, 16, (ticks, n), dtype=torch.uint8, generator=g).to(d)
+    mouse = ((torch.rand((ticks, n), generator=g) * 2 - 1) * float(cfg.action_range)).to(d)
+    out = lambda: (torch.zeros((ticks, n, 6), dtype=torch.float32, device=d), torch.zeros((ticks, n), dtype=torch.float32, device=d),   # noqa: E731
+                   torch.full((ticks, n), 7, dtype=torch.uint8, device=d))
+    return torch, _lib, DeviceEnv, cfg, keys, mouse, out
+
+
+@pytest.mark.parametrize("n", [65536, 1000, 64, 1])
+def test_signalled_rollout_equals_plain_rollout_and_outputs_are_complete(n):
+    ticks = 40
+    torch, L, DeviceEnv, cfg, keys, mouse, out = _setup(n, ticks)
+    a, b = DeviceEnv(cfg, device=0), DeviceEnv(cfg, device=0)
+    o1, r1, d1 = out()
+    o2, r2, d2 = out()
+    a.rollout_dev(ticks, L.ACT_PACKED, keys.data_ptr(), mouse.data_ptr(), 0, L.OBS_F32, o1.data_ptr(), r1.data_ptr(), d1.data_ptr())
+    a.sync()
+    b.rollout_dev(ticks, L.ACT_PACKED, keys.data_ptr(), mouse.data_ptr(), 0, L.OBS_F32, o2.data_ptr(), r2.data_ptr(), d2.data_ptr(),
+                  auto_reset=L.STAMP_START | L.SIGNAL)
+    b.signal_wait(10.0)
+    # the signal says every wave has retired its stores; the copies below are ordered behind the launch on the device anyway,
+    # so this checks (a) and that nothing is left behind, not the memory model
+    assert torch.equal(o1.cpu(), o2.cpu()) and torch.equal(r1.cpu(), r2.cpu()) and torch.equal(d1.cpu(), d2.cpu())
+    assert int(d2.max()) <= 1                                  # every done byte was written (initialised to 7)
+    sa, sb = a.get_state(), b.get_state()
+    for k in sa:
+        assert np.array_equal(sa[k], sb[k]), k
+    el = b.signal_elapsed()
+    assert 1e-6 < el < 5e-3, el                                # 40 ticks: tens of microseconds
+    a.close(); b.close()
+
+
+def test_sequence_of_signals_and_signal_mark():
+    n, ticks = 4096, 8
+    torch, L, DeviceEnv, cfg, keys, mouse, out = _setup(n, ticks)
+    dev = DeviceEnv(cfg, device=0)
+    o, r, dn = out()
+    seq = C.c_uint64()
+    last = 0.0
+    for rep in range(50):                                      # back-to-back signalled launches: the ticket counter returns to zero each time
+        dev.rollout_dev(ticks, L.ACT_PACKED, keys.data_ptr(), mouse.data_ptr(), 0, L.OBS_F32, o.data_ptr(), r.data_ptr(), dn.data_ptr(),
+                        auto_reset=L.STAMP_START | L.SIGNAL_WAIT)          # launch + wait in one call
+        el = dev.signal_elapsed()
+        assert 0 < el < 5e-3
+        last = el
+    assert last > 0
+    # a region that ends in a launch without a signal: start stamp on the first rollout, signal_mark behind the reset
+    dev.rollout_dev(ticks, L.ACT_PACKED, keys.data_ptr(), mouse.data_ptr(), 0, L.OBS_F32, o.data_ptr(), r.data_ptr(), dn.data_ptr(),
+                    auto_reset=L.STAMP_START)
+    dev.reset_philox_dev(99, 0, True)
+    dev.signal_mark()
+    dev.signal_wait(10.0)
+    el2 = dev.signal_elapsed()
+    assert el2 > 0 and el2 < 5e-3
+    dev.sync()
+    del seq
+    dev.close()
+
+
+def test_signal_wait_without_a_request_is_an_error_not_a_hang():
+    from q1physrl_amd import _lib
+    torch, L, DeviceEnv, cfg, keys, mouse, out = _setup(64, 2)
+    dev = DeviceEnv(cfg, device=0)
+    with pytest.raises(_lib.Q1EnvError):
+        dev.signal_wait(0.1)
+    dev.close()
+
+
+def test_build_id_matches_the_sources():
+    from q1physrl_amd import _lib, build
+    assert _lib.build_id() == build.sources_sha16() and len(_lib.lib_sha16()) == 16
