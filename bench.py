@@ -590,9 +590,9 @@ def main(argv=None):
                     if timed and not started:
                         rflags |= _lib.STAMP_START if timed == "signal" else _lib.TIMER_START
                         started = True
-                    if timed and left == chunk and not ends_episode:
-                        rflags |= _lib.SIGNAL if timed == "signal" else _lib.TIMER_STOP
-                        stopped = True
+                    if timed and left == chunk and not ends_episode and not (timed == "signal" and os.environ.get("Q1_BENCH_SIGNAL_MARK") == "1"):
+                        rflags |= _lib.SIGNAL if timed == "signal" else _lib.TIMER_STOP     # (Q1_BENCH_SIGNAL_MARK=1: A/B knob - the signal from a
+                        stopped = True                                                       #  one-wave kernel behind the launch instead of its own last wave)
                     # (arguments converted once, outside the timed region: DeviceEnv.prepare_rollout)
                     calls.append(dev.prepare_rollout(chunk, _lib.ACT_PACKED, ka, ma, 0, _lib.OBS_F32, obsT.data_ptr(), rewT.data_ptr(),
                                                      doneT.data_ptr(), rflags))
@@ -653,6 +653,9 @@ def main(argv=None):
         signalled = mode == "rollout" and hasattr(dev, "signal_wait") and os.environ.get("Q1_BENCH_NO_SIGNAL") != "1"
         timed_calls, launches = plan_ticks(mode, steps, warmup, timed="signal" if signalled else "events")
         wait = dev.signal_wait if signalled else None
+        if signalled:                             # the signal's pinned words and ticket counters exist and have been touched before the region
+            dev.signal_mark()
+            dev.signal_wait()
         barrier()
         if signalled:
             t0 = time.perf_counter()

@@ -188,16 +188,20 @@ rollout_kernel(Params p, StatePtrs s, int ticks, int fmt, const void* act_a, con
     // would otherwise stay in registers across the whole tick loop (24 VGPRs on top of the state and the tick's constants).
     uint32_t i_st = i;
     asm volatile("" : "+v"(i_st));
-    store_env(s, n, i_st, e);
+#ifndef Q1_ROLLOUT_STATE_NT
+#define Q1_ROLLOUT_STATE_NT 1
+#endif
+    if constexpr (Q1_ROLLOUT_STATE_NT == 1) store_env_nt(s, n, i_st, e);
+    else store_env(s, n, i_st, e);
     if (return_sum) return_sum[i_st] += ret;
-    signal_done(sg);
+    signal_done(sg, i_st >> 6);
 }
 
 // the end stamp + sequence number of the completion signal behind whatever the stream holds (q1env_signal_mark)
 __global__ void signal_mark_kernel(Signal sg) {
     sg.waves = 1;
     signal_start(sg);
-    signal_done(sg);
+    signal_done(sg, 0u);
 }
 
 template <typename OBS_T>
@@ -357,8 +361,8 @@ int ensure_signal(q1env* h) {
     memset(host, 0, 256);
     void* dev = nullptr;
     hipError_t e = hipHostGetDevicePointer(&dev, host, 0);
-    if (e == hipSuccess) e = hipMalloc((void**)&h->ticket_dev, 256);
-    if (e == hipSuccess) e = hipMemsetAsync(h->ticket_dev, 0, 256, h->stream);
+    if (e == hipSuccess) e = hipMalloc((void**)&h->ticket_dev, 4 * (SIGNAL_LEAVES + 1) * SIGNAL_LEAF_STRIDE);
+    if (e == hipSuccess) e = hipMemsetAsync(h->ticket_dev, 0, 4 * (SIGNAL_LEAVES + 1) * SIGNAL_LEAF_STRIDE, h->stream);
     if (e != hipSuccess) {
         (void)hipHostFree(host);
         if (h->ticket_dev) { (void)hipFree(h->ticket_dev); h->ticket_dev = nullptr; }

@@ -4,13 +4,13 @@ set -u
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 O=gpurun_out/r4_probe1
 mkdir -p $O
-timeout 900 python -m pytest tests/test_hip_signal.py tests/test_bench_gpu.py -x -q > $O/pytest.log 2>&1; echo "pytest rc=$?" >> $O/pytest.log
+timeout 900 python -m pytest tests/test_hip_signal.py -x -q > $O/pytest.log 2>&1; echo "pytest rc=$?" >> $O/pytest.log
 for rep in 1 2 3; do
   timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-secondary > $O/bench_signal_$rep.json 2> $O/bench_signal_$rep.err
 done
 Q1_BENCH_NO_SIGNAL=1 timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-secondary > $O/bench_nosignal.json 2> $O/bench_nosignal.err
 HSA_ENABLE_INTERRUPT=0 timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-secondary > $O/bench_signal_nointr.json 2> $O/bench_signal_nointr.err
-HSA_ENABLE_INTERRUPT=0 Q1_BENCH_NO_SIGNAL=1 timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-secondary > $O/bench_nosignal_nointr.json 2> $O/bench_nosignal_nointr.err
+Q1_BENCH_SIGNAL_MARK=1 timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-secondary > $O/bench_signalmark.json 2> $O/bench_signalmark.err
 HIP_FORCE_DEV_KERNARG=1 timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-secondary > $O/bench_signal_devkernarg.json 2> $O/bench_signal_devkernarg.err
 timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_full.json 2> $O/bench_full.err
 python - <<'P'
