@@ -96,8 +96,8 @@ step_autoreset_kernel(Params p, StatePtrs s, int fmt, const void* act_a, const v
 //             0 = no per-tick output at all, -1 = decided per pointer at run time.
 //   FULL:     every lane of the wave owns an env (the ragged tail wave runs its own copy of the loop, so that the
 //             number of stores per iteration is a compile-time constant in both).
-template <typename OBS_T, bool SPEC, int FMT, bool HAS_RESET, int OUT_MODE, bool FULL>
-__device__ __forceinline__ void rollout_loop(const Params& p, Env& e, uint32_t i, uint32_t n, int ticks, int fmt,
+template <typename OBS_T, bool SPEC, int FMT, bool HAS_RESET, int OUT_MODE, bool RET, bool FULL>
+__device__ __forceinline__ void rollout_loop(const Params& p, const double* move_tab, Env& e, uint32_t i, uint32_t n, int ticks, int fmt,
                                              const void* act_a, const void* act_b, uint64_t seed, uint64_t tick0,
                                              OBS_T* obs, float* reward, uint8_t* done, int auto_reset, double& ret,
                                              float* slab) {
@@ -105,31 +105,40 @@ __device__ __forceinline__ void rollout_loop(const Params& p, Env& e, uint32_t i
     const bool random = (FMT >= 0 ? FMT : fmt) == FMT_RANDOM;
     const uint32_t lane = threadIdx.x & 63u, wave_first = i - lane;
     // Software prefetch for the packed layout: the RAW bytes of tick t+1's action are requested at the top of the
-    // body (unconditionally, index clamped on the last tick, so the loads stay in the body's first basic block),
-    // before tick t is computed, and are only decoded one iteration later; other layouts fetch in place.
+    // body (unconditionally, so the loads stay in the body's first basic block), before tick t is computed, and are only decoded one
+    // iteration later; other layouts fetch in place.  The two action pointers advance by one tick per iteration - by ZERO on the last
+    // one, which re-reads its own action instead of running past the caller's arrays: one scalar select for both strides instead of a
+    // 64-bit multiply-add per array.
     constexpr bool PREFETCH = (FMT == FMT_PACKED);
     uint32_t kraw_next = 0;
     float mraw_next = 0.0f;
+    const uint8_t* ka = (const uint8_t*)act_a + i;
+    const float* ma = (const float*)act_b + i;
     if constexpr (PREFETCH) {
-        kraw_next = ((const uint8_t*)act_a)[i];
-        mraw_next = ((const float*)act_b)[i];
+        kraw_next = *ka;
+        mraw_next = *ma;
         // Drain every outstanding load (state + first action) once, here: the waitcnt scoreboard then enters the
         // loop clean, so inside the loop the wait for a prefetched action is vmcnt(#younger ops) as seen along the
         // back edge - it no longer has to cover the preheader's load order and does not drain the tick's stores.
         __builtin_amdgcn_s_waitcnt(0x0F70);    // vmcnt(0), expcnt/lgkmcnt untouched
     }
-    const TickConsts tc = tick_consts();
+    TickConsts tc = tick_consts();
+    tc.move_tab = move_tab;
+    tc.has_move_tab = true;
     for (int t = 0; t < ticks; ++t) {
         double yaw_act;
         uint32_t keys;
         if constexpr (PREFETCH) {
-            const uint32_t kraw = kraw_next;
-            const float mraw = mraw_next;
-            const size_t nxt = (size_t)(t + 1 < ticks ? t + 1 : t) * n + i;
-            kraw_next = ((const uint8_t*)act_a)[nxt];
-            mraw_next = ((const float*)act_b)[nxt];
-            keys = kraw & 0xFu;
-            yaw_act = (double)mraw;
+            // decode tick t's raw action FIRST, then request tick t+1's into the same two registers (the empty asm keeps the requests
+            // behind the decode: no register copies, and the loop closes with ONE conditional branch)
+            keys = kraw_next & 0xFu;
+            yaw_act = (double)mraw_next;
+            asm volatile("" : "+v"(keys), "+v"(yaw_act) : : "memory");
+            const size_t stride = (t + 1 < ticks) ? (size_t)n : (size_t)0;
+            ka += stride;
+            ma += stride;
+            kraw_next = *ka;
+            mraw_next = *ma;
         } else if (random) {
             keys = random_action<SPEC>(p, seed, genv, tick0 + (uint64_t)t, &yaw_act);
         } else {
@@ -157,33 +166,37 @@ __device__ __forceinline__ void rollout_loop(const Params& p, Env& e, uint32_t i
             if (OUT_MODE == 1 || (OUT_MODE < 0 && reward)) (reward + base)[i] = o.reward;
             if (OUT_MODE == 1 || (OUT_MODE < 0 && done)) (done + base)[i] = o.done ? 1 : 0;
         }
-        ret += (double)o.reward;
+        if constexpr (RET) ret += (double)o.reward;
         if constexpr (HAS_RESET) {
             if (auto_reset && o.done) reset_philox(p, e, seed, genv, tick0 + (uint64_t)t + 1);
         }
     }
 }
 
-template <typename OBS_T, bool SPEC, int FMT, bool HAS_RESET, int OUT_MODE>
+// RET: the launch accumulates each env's reward in float64 for return_sum (a convert and an add per tick that a caller who reads the
+// per-tick rewards anyway - the bench, the sampler - does not pay for).
+template <typename OBS_T, bool SPEC, int FMT, bool HAS_RESET, int OUT_MODE, bool RET>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4)))
 rollout_kernel(Params p, StatePtrs s, int ticks, int fmt, const void* act_a, const void* act_b,
                uint64_t seed, uint64_t tick0, OBS_T* obs, float* reward, uint8_t* done,
                int auto_reset, double* return_sum, Signal sg) {
     __shared__ float slab[4][384];
+    __shared__ double move_tab[128];
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t n = (uint32_t)p.n;
     signal_start(sg);
+    const double* mt = fill_move_table(p, move_tab);       // (every thread, before the early exit: it ends in a workgroup barrier)
     if (i >= n) return;
     Env e;
     load_env(s, n, i, e);
     double ret = 0.0;
     float* my_slab = slab[threadIdx.x >> 6];
     if (i - (threadIdx.x & 63u) + 64u <= n)
-        rollout_loop<OBS_T, SPEC, FMT, HAS_RESET, OUT_MODE, true>(p, e, i, n, ticks, fmt, act_a, act_b, seed, tick0, obs, reward,
-                                                                   done, auto_reset, ret, my_slab);
+        rollout_loop<OBS_T, SPEC, FMT, HAS_RESET, OUT_MODE, RET, true>(p, mt, e, i, n, ticks, fmt, act_a, act_b, seed, tick0, obs, reward,
+                                                                        done, auto_reset, ret, my_slab);
     else
-        rollout_loop<OBS_T, SPEC, FMT, HAS_RESET, OUT_MODE, false>(p, e, i, n, ticks, fmt, act_a, act_b, seed, tick0, obs, reward,
-                                                                    done, auto_reset, ret, my_slab);
+        rollout_loop<OBS_T, SPEC, FMT, HAS_RESET, OUT_MODE, RET, false>(p, mt, e, i, n, ticks, fmt, act_a, act_b, seed, tick0, obs, reward,
+                                                                         done, auto_reset, ret, my_slab);
     // The final stores address the arrays from a laundered copy of the index: the twelve 64-bit addresses of the initial loads
     // would otherwise stay in registers across the whole tick loop (24 VGPRs on top of the state and the tick's constants).
     uint32_t i_st = i;
@@ -193,7 +206,7 @@ rollout_kernel(Params p, StatePtrs s, int ticks, int fmt, const void* act_a, con
 #endif
     if constexpr (Q1_ROLLOUT_STATE_NT == 1) store_env_nt(s, n, i_st, e);
     else store_env(s, n, i_st, e);
-    if (return_sum) return_sum[i_st] += ret;
+    if constexpr (RET) { if (return_sum) return_sum[i_st] += ret; }
     signal_done(sg, i_st >> 6);
 }
 
@@ -265,7 +278,7 @@ decode_kernel(Params p, StatePtrs s, int fmt, const void* act_a, const void* act
     load_env(s, (uint32_t)p.n, i, e);
     double yaw_act;
     const uint32_t keys = fetch_action<false, FMT_RUNTIME>(p, fmt, act_a, act_b, (size_t)i, &yaw_act);
-    const Cmd c = decode<false>(p, e, keys, yaw_act, z_vel[i], trem[i]);
+    const Cmd c = decode<false>(p, make_tick_consts<false>(), e, keys, yaw_act, z_vel[i], trem[i]);
     s.yaw[i] = e.yaw;
 #pragma unroll
     for (int k = 0; k < 4; ++k) s.lk[(size_t)k * p.n + i] = e.lk[k];
@@ -306,7 +319,7 @@ phys_apply_kernel(int n, const double* yaw, const double* pitch, const double* r
     double z = z_pos[i];
     uint32_t flags = (on_ground[i] ? FLAG_ON_GROUND : 0u) | (jump_released[i] ? FLAG_JUMP_RELEASED : 0u);
     Cmd c;
-    c.fmove = fmove[i]; c.smove = smove[i]; c.jump = button2[i] != 0;
+    c.fmove = fmove[i]; c.smove = smove[i]; c.jump = button2[i] != 0 ? 1u : 0u;
     const double k = 3.141592653589793;
     double sy, cy, sp = 0.0, cp = 1.0, sr = 0.0, cr = 1.0;
     sincos((yaw[i] * k) / 180.0, &sy, &cy);
@@ -899,28 +912,31 @@ int q1env_rollout(q1env_t* h, int ticks, int fmt, const void* a, const void* b, 
     const int blk = block_for(h->p.n);
     const dim3 g = grid_for(h->p.n, blk), bs(blk);
     const bool spec = is_spec(h->p);
-#define Q1_LAUNCH_ROLL(OT, SP, FM, HR, OM)                                                                           \
-    hipLaunchKernelGGL((rollout_kernel<OT, SP, FM, HR, OM>), g, bs, 0, h->stream, h->p, h->st, ticks, fmt, a, b, seed, \
+#define Q1_LAUNCH_ROLL(OT, SP, FM, HR, OM, RT)                                                                           \
+    hipLaunchKernelGGL((rollout_kernel<OT, SP, FM, HR, OM, RT>), g, bs, 0, h->stream, h->p, h->st, ticks, fmt, a, b, seed, \
                        h->tick_count, (OT*)obs, reward, done, auto_reset, return_sum, sg)
     const bool all_out = obs && reward && done, no_out = !obs && !reward && !done;
-    if (obs_format == Q1ENV_OBS_F32 && spec && (all_out || no_out) &&
+    if (obs_format == Q1ENV_OBS_F32 && spec && (all_out || no_out) && !return_sum &&
         (fmt == Q1ENV_ACT_PACKED || fmt == Q1ENV_ACT_RANDOM)) {
         const int which = (fmt == Q1ENV_ACT_RANDOM ? 4 : 0) + (auto_reset ? 2 : 0) + (all_out ? 1 : 0);
         switch (which) {
-            case 0: Q1_LAUNCH_ROLL(float, true, FMT_PACKED, false, 0); break;
-            case 1: Q1_LAUNCH_ROLL(float, true, FMT_PACKED, false, 1); break;
-            case 2: Q1_LAUNCH_ROLL(float, true, FMT_PACKED, true, 0); break;
-            case 3: Q1_LAUNCH_ROLL(float, true, FMT_PACKED, true, 1); break;
-            case 4: Q1_LAUNCH_ROLL(float, true, FMT_RANDOM, false, 0); break;
-            case 5: Q1_LAUNCH_ROLL(float, true, FMT_RANDOM, false, 1); break;
-            case 6: Q1_LAUNCH_ROLL(float, true, FMT_RANDOM, true, 0); break;
-            default: Q1_LAUNCH_ROLL(float, true, FMT_RANDOM, true, 1); break;
+            case 0: Q1_LAUNCH_ROLL(float, true, FMT_PACKED, false, 0, false); break;
+            case 1: Q1_LAUNCH_ROLL(float, true, FMT_PACKED, false, 1, false); break;
+            case 2: Q1_LAUNCH_ROLL(float, true, FMT_PACKED, true, 0, false); break;
+            case 3: Q1_LAUNCH_ROLL(float, true, FMT_PACKED, true, 1, false); break;
+            case 4: Q1_LAUNCH_ROLL(float, true, FMT_RANDOM, false, 0, false); break;
+            case 5: Q1_LAUNCH_ROLL(float, true, FMT_RANDOM, false, 1, false); break;
+            case 6: Q1_LAUNCH_ROLL(float, true, FMT_RANDOM, true, 0, false); break;
+            default: Q1_LAUNCH_ROLL(float, true, FMT_RANDOM, true, 1, false); break;
         }
     } else if (obs_format == Q1ENV_OBS_F32) {
-        if (spec && fmt == Q1ENV_ACT_F32_ROWS) Q1_LAUNCH_ROLL(float, true, FMT_F32_ROWS, true, -1);
-        else Q1_LAUNCH_ROLL(float, false, FMT_RUNTIME, true, -1);
+        // (return_sum, partial output sets, row-format actions: the SPEC tick with run-time output pointers, or the generic tick)
+        if (spec && fmt == Q1ENV_ACT_PACKED) Q1_LAUNCH_ROLL(float, true, FMT_PACKED, true, -1, true);
+        else if (spec && fmt == Q1ENV_ACT_RANDOM) Q1_LAUNCH_ROLL(float, true, FMT_RANDOM, true, -1, true);
+        else if (spec && fmt == Q1ENV_ACT_F32_ROWS) Q1_LAUNCH_ROLL(float, true, FMT_F32_ROWS, true, -1, true);
+        else Q1_LAUNCH_ROLL(float, false, FMT_RUNTIME, true, -1, true);
     } else {
-        Q1_LAUNCH_ROLL(double, false, FMT_RUNTIME, true, -1);
+        Q1_LAUNCH_ROLL(double, false, FMT_RUNTIME, true, -1, true);
     }
 #undef Q1_LAUNCH_ROLL
     HIP_TRY(hipGetLastError());

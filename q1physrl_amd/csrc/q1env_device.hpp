@@ -98,7 +98,7 @@ struct Env {               // one env's state in registers
 
 struct Cmd {               // ActionDecoder.map's outputs for one env (env.py:269)
     double fmove, smove;
-    bool jump;
+    uint32_t jump;         // 0 / 1
 };
 
 template <typename OBS_T>
@@ -126,6 +126,43 @@ __device__ __forceinline__ void select2_into_f64(uint64_t mask, double a0, doubl
         : "v"(__double2loint(a0)), "v"(__double2hiint(a0)), "v"(__double2loint(a1)), "v"(__double2hiint(a1)), "s"(mask));
     r0 = __hiloint2double((int)hi0, (int)lo0);
     r1 = __hiloint2double((int)hi1, (int)lo1);
+}
+// out-of-place pair: r0 = mask ? a0 : b0, r1 = mask ? a1 : b1 (no copies of the kept operands first; early-clobber outputs, because the
+// sequence writes its first result while later instructions still read inputs)
+__device__ __forceinline__ void select2_f64(uint64_t mask, double a0, double b0, double& r0, double a1, double b1, double& r1) {
+    uint32_t lo0, hi0, lo1, hi1;
+    asm("s_nop 1\n\tv_cndmask_b32_e64 %0, %4, %8, %12\n\tv_cndmask_b32_e64 %1, %5, %9, %12\n\t"
+        "v_cndmask_b32_e64 %2, %6, %10, %12\n\tv_cndmask_b32_e64 %3, %7, %11, %12"
+        : "=&v"(lo0), "=&v"(hi0), "=&v"(lo1), "=&v"(hi1)
+        : "v"(__double2loint(b0)), "v"(__double2hiint(b0)), "v"(__double2loint(b1)), "v"(__double2hiint(b1)),
+          "v"(__double2loint(a0)), "v"(__double2hiint(a0)), "v"(__double2loint(a1)), "v"(__double2hiint(a1)), "s"(mask));
+    r0 = __hiloint2double((int)hi0, (int)lo0);
+    r1 = __hiloint2double((int)hi1, (int)lo1);
+}
+// v_max_f64 / v_min_f64 on operands the compiler cannot see through (the pinned constants of TickConsts are opaque register values, so
+// its own fmax / fmin first canonicalises them - a v_max_f64 x, x per use): the instruction itself, which under the kernels' IEEE mode
+// already returns the non-NaN operand and quiets a signalling one.
+__device__ __forceinline__ double max_f64_raw(double a, double b) {
+    double d;
+    asm("v_max_f64 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+__device__ __forceinline__ double min_f64_raw(double a, double b) {
+    double d;
+    asm("v_min_f64 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+// (m & a) | (~m & b) and the sign-extended one-bit field, as the instructions themselves: the compiler turns the C forms back into
+// v_cmp + two VOP2 v_cndmask on VCC - the pair that stalls (tools/ubench_select.hip)
+__device__ __forceinline__ uint32_t bfi_b32(uint32_t m, uint32_t a, uint32_t b) {
+    uint32_t d;
+    asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(d) : "v"(m), "v"(a), "v"(b));
+    return d;
+}
+__device__ __forceinline__ uint32_t bit_mask_i32(uint32_t x, uint32_t bit) {   // all ones if bit `bit` of x is set, else zero
+    uint32_t d;
+    asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(d) : "v"(x), "v"(bit));
+    return d;
 }
 // four values, four masks, one replacement (the decoder's key-press timestamps): r[k] = m[k] ? a : r[k]
 __device__ __forceinline__ void select4_into_f64(uint64_t m0, uint64_t m1, uint64_t m2, uint64_t m3, double a, double r[4]) {
@@ -163,6 +200,24 @@ __device__ __forceinline__ T div_const(T x, T c, T y) {
     r = fma_t<T>(-q, c, x);
     q = fma_t<T>(r, y, q);
     return q;
+}
+
+// ONE correction step: q0 = RN(x y) is already FAITHFUL (one of the two neighbours of x / c) when the reciprocal's relative error
+// e = c y - 1 satisfies |e| <= 2^-54: |x y - x/c| = |x/c| |e| < ulp(x/c) / 2 (a significand is < 2), plus half an ulp of rounding, is
+// < 1 ulp.  Markstein's theorem (y = RN(1/c), q faithful, r = x - q c exact => RN(q + r y) = RN(x / c)) then needs no second step:
+// 3 instructions.  |e| 2^54 is 0.6875 for 180 and 90, 1.0 for 10, 0.681 for float32(10.08), 0.375 for 100 and 200
+// (tests/test_division_shortcuts.py: exact rational arithmetic; q1env_selftest_division on the device); for RUN-TIME constants the
+// host checks the bound (q1env_host.hpp div_one_step_ok) and the SPEC kernels require it.  float32: the same with 2^-25.
+template <typename T>
+__device__ __forceinline__ T div_const1(T x, T c, T y) {
+    const T q = x * y;
+    const T r = fma_t<T>(-q, c, x);
+    return fma_t<T>(r, y, q);
+}
+template <bool ONE_STEP, typename T>
+__device__ __forceinline__ T div_const_sel(T x, T c, T y) {
+    if constexpr (ONE_STEP) return div_const1<T>(x, c, y);
+    else return div_const<T>(x, c, y);
 }
 
 // a / b for two numerators sharing one denominator: the refined reciprocal (v_rcp_f64 + two Newton steps, the
@@ -224,6 +279,10 @@ struct TickConsts {
     double s2, s3, s4, s5, s6, c1, c2, c3, c4, c5, c6;
     double neg_bias, two20, tiny_wish, tiny_speed, max_wish;
     bool hoisted;                                                       // compile-time after inlining: which tick_consts*() made it
+    // LDS table of the decoder's move commands (fill_move_table), or NULL: (fmove, smove) for every combination of this tick's and the
+    // previous tick's forward / strafe key bits - 64 entries made once per launch with the reference's own arithmetic
+    const double* move_tab;
+    bool has_move_tab;                                                  // compile-time after inlining (a null test of an LDS pointer is not)
     // one Horner step z * acc + coefficient: three-address v_fma_f64 on the register-resident coefficient in a loop kernel, the
     // compiler's own choice in a single-tick kernel (where pinning 32 registers would cost the HBM-bound kernels their occupancy)
     __device__ __forceinline__ double horner(double z, double acc, double coeff) const {
@@ -251,6 +310,8 @@ __device__ __forceinline__ TickConsts make_tick_consts() {
     t.tiny_speed = tick_const<HOISTED>(0x1p-100);
     t.max_wish = tick_const<HOISTED>(320.0);
     t.hoisted = HOISTED;
+    t.move_tab = nullptr;
+    t.has_move_tab = false;
     return t;
 }
 // before a tick loop: the constants pinned in registers
@@ -288,13 +349,13 @@ __device__ __forceinline__ void sincos_yaw(const TickConsts& k, double x, double
     t = fma(-v, -1.66666666666666324348e-01, t);
     const double cs = w + e;
     const double sn = hi - t;
-    // quadrant: sin(x) = {sn, cs, -sn, -cs}[n & 3], cos(x) = {cs, -sn, -cs, sn}[n & 3]
-    const bool odd = q & 1u;
-    const uint32_t flip = (q << 30) & 0x80000000u;                      // bit 1 of n -> the sign bit
-    double s_sel = sn, c_sel = cs;
-    select2_into_f64(__ballot(odd), cs, s_sel, -sn, c_sel);
-    sn_out = __hiloint2double(__double2hiint(s_sel) ^ (int)flip, __double2loint(s_sel));
-    cs_out = __hiloint2double(__double2hiint(c_sel) ^ (int)flip, __double2loint(c_sel));
+    // quadrant: sin(x) = {sn, cs, -sn, -cs}[n & 3], cos(x) = {cs, -sn, -cs, sn}[n & 3]: odd n swaps the two, bit 1 of n negates the
+    // sine and bit 1 of n + 1 the cosine - so the swap selects plain values and each sign is one three-input bit operation
+    double s_sel, c_sel;
+    select2_f64(__ballot(q & 1u), cs, sn, s_sel, sn, cs, c_sel);
+    const uint32_t flip_s = q << 30, flip_c = (q << 30) + 0x40000000u;   // bit 31 = bit 1 of n / of n + 1
+    sn_out = __hiloint2double(__double2hiint(s_sel) ^ (int)(flip_s & 0x80000000u), __double2loint(s_sel));
+    cs_out = __hiloint2double(__double2hiint(c_sel) ^ (int)(flip_c & 0x80000000u), __double2loint(c_sel));
     // |x| >= 2^20 or NaN anywhere in the wave: the library's path for the whole wave.  (The results pass through an empty asm first so
     // that the compiler cannot sink their last instructions into an else-side of this branch: one untaken s_cbranch per tick, not two.)
     if (k.hoisted) asm("" : "+v"(sn_out), "+v"(cs_out));
@@ -464,45 +525,81 @@ __device__ __forceinline__ uint32_t fetch_action(const Params& p, int fmt_rt, co
 }
 
 // ---------------------------------------------------------------------------------------- decode
+// The move commands of env.py:251-261,269 for given key bits: level_k = (key_k + prev_k) * 0.5 with smoothing, key_k without.  Every
+// level is one of {0, 0.5, 1}, so the difference right - left and the forward level are formed EXACTLY in integers (units of
+// smooth_scale) and converted once: the two products see the same float64 operands as the reference's (strafe_right - strafe_left)
+// and forward levels.  keys / prev: bit 0 = left, 1 = right, 2 = forward.
+__device__ __forceinline__ void move_commands(const Params& p, uint32_t keys, uint32_t prev, double& fmove, double& smove) {
+    const int sp = p.smooth_keys ? 1 : 0;
+    const int lr2 = ((int)((keys >> 1) & 1u) - (int)(keys & 1u)) + sp * ((int)((prev >> 1) & 1u) - (int)(prev & 1u));     // (lvl[1] - lvl[0]) / smooth_scale
+    const int fw2 = (int)((keys >> 2) & 1u) + sp * (int)((prev >> 2) & 1u);                                                  // lvl[2] / smooth_scale
+    smove = trunc(p.smove_max * ((double)lr2 * p.smooth_scale)) + 0.0;     // astype(int): toward zero, +0 (env.py:259-260,269)
+    fmove = trunc(p.fmove_max * ((double)fw2 * p.smooth_scale)) + 0.0;     // env.py:261,269
+}
+// The 64 possible (fmove, smove) pairs of a launch, made once with move_commands itself: entry (keys & 7) | (prev & 7) << 3, which is
+// (keys & 7) | (flags & 0x38) because the previous keys sit at bit 3 of the flag byte.  A multi-tick kernel then spends 4 instructions
+// per tick on the commands (index, address, one 16-byte LDS read) instead of ~22 of bit arithmetic, conversions, products and
+// truncations whose inputs can only take these 64 values.  Call from EVERY thread of the workgroup before any early exit.
+__device__ __forceinline__ const double* fill_move_table(const Params& p, double* tab /* LDS, 128 doubles */) {
+    for (uint32_t idx = threadIdx.x; idx < 64u; idx += blockDim.x) {
+        double f, sm;
+        move_commands(p, idx & 7u, idx >> 3, f, sm);
+        tab[2u * idx] = f;
+        tab[2u * idx + 1u] = sm;
+    }
+    __syncthreads();
+    return tab;
+}
+
 // ActionDecoder.map for one env (env.py:225-269).  z_vel / trem are passed separately because the
 // stand-alone decoder takes them from the caller (mkdemo.py:47-55).
 template <bool SPEC>
-__device__ __forceinline__ Cmd decode(const Params& p, Env& e, uint32_t keybits, double yaw_act,
+__device__ __forceinline__ Cmd decode(const Params& p, const TickConsts& k_, Env& e, uint32_t keybits, double yaw_act,
                                       float z_vel, double trem) {
     const double now = p.time_limit - trem;                             // env.py:241,246
     const uint32_t prev = (e.flags >> FLAG_KEYS_SHIFT) & 0xFu;
     const int nk = cfg_num_keys<SPEC>(p);
-    // env.py:241-248 for the four keys at once, as bit masks: may_press_k = now >= last_press_k + delay (float64 compare),
-    // keys = key_actions & (may_press | last_keys), rising edge = keys & ~last_keys
-    uint32_t may = 0;
+    // env.py:241-248 for the four keys at once, as bit masks: may_press_k = now >= last_press_k + delay, keys = key_actions &
+    // (may_press | last_keys), rising edge = keys & ~last_keys.  The float64 comparison is the SIGN of the float64 difference
+    // now - (last_press_k + delay) - a correctly rounded difference is negative exactly when now < the sum, and +0 when they are equal
+    // (the times are finite) - so the four results are gathered with one v_alignbit each (shift the accumulator left, bring the sign
+    // bit in) instead of a compare, a select and a hazard no-op each.
+    uint32_t neg = 0;
 #pragma unroll
-    for (int k = 0; k < 4; ++k)
-        if (k < nk) may |= (now >= e.lk[k] + p.key_press_delay) ? (1u << k) : 0u;
-    const uint32_t keys = keybits & ((1u << nk) - 1u) & (may | prev);   // env.py:243
+    for (int k = 3; k >= 0; --k) {
+        const double d = now - (e.lk[k] + p.key_press_delay);
+        neg = __builtin_amdgcn_alignbit(neg, (uint32_t)__double2hiint(d), 31);      // (neg << 1) | sign(d): bit k = now < last_press_k + delay
+    }
+    const uint32_t keys = keybits & ((1u << nk) - 1u) & (~neg | prev);  // env.py:243
     const uint32_t rise = keys & ~prev;
-    uint64_t rising[4];
+    // env.py:244-248: last_press_k = now where the key went down.  Per key one sign-extended bit field (all ones / zero) and one bit
+    // select per 32-bit half: no SGPR masks, no hazard
+    const uint32_t now_lo = (uint32_t)__double2loint(now), now_hi = (uint32_t)__double2hiint(now);
 #pragma unroll
-    for (int k = 0; k < 4; ++k) rising[k] = __ballot((rise & (1u << k)) != 0u);
-    select4_into_f64(rising[0], rising[1], rising[2], rising[3], now, e.lk);
-    // env.py:251-254: level_k = (key_k + prev_k) * 0.5 with smoothing, key_k without.  Every level is one of {0, 0.5, 1}, so the
-    // difference right - left and the level itself are formed EXACTLY in integers (units of smooth_scale) and converted once: the two
-    // products below see the same float64 operands as the reference's (strafe_right - strafe_left) and forward levels.
-    const int sp = p.smooth_keys ? 1 : 0;
-    const int lr2 = ((int)((keys >> 1) & 1u) - (int)(keys & 1u)) + sp * ((int)((prev >> 1) & 1u) - (int)(prev & 1u));     // (lvl[1] - lvl[0]) / smooth_scale
-    const int fw2 = (int)((keys >> 2) & 1u) + sp * (int)((prev >> 2) & 1u);                                                  // lvl[2] / smooth_scale
+    for (int k = 0; k < 4; ++k) {
+        const uint32_t m = bit_mask_i32(rise, (uint32_t)k);
+        const uint32_t lo = (uint32_t)__double2loint(e.lk[k]), hi = (uint32_t)__double2hiint(e.lk[k]);
+        e.lk[k] = __hiloint2double((int)bfi_b32(m, now_hi, hi), (int)bfi_b32(m, now_lo, lo));
+    }
+    Cmd c;
+    if (k_.has_move_tab) {                                              // (compile-time after inlining)
+        const uint32_t idx = (keys & 7u) | (e.flags & 0x38u);           // this tick's keys | the previous tick's, already at bit 3
+        const double2 mv = *reinterpret_cast<const double2*>(k_.move_tab + 2u * idx);
+        c.fmove = mv.x;
+        c.smove = mv.y;
+    } else {
+        move_commands(p, keys, prev, c.fmove, c.smove);
+    }
     e.flags = (e.flags & 0x7u) | (keys << FLAG_KEYS_SHIFT);             // env.py:256
 
     double dyaw = 0.0;
-    if (cfg_yaw_mode<SPEC>(p) == 1) dyaw = div_const<double>(yaw_act * p.yaw_num, p.yaw_den, p.yaw_den_rcp);   // env.py:236
+    if (cfg_yaw_mode<SPEC>(p) == 1) dyaw = div_const_sel<SPEC, double>(yaw_act * p.yaw_num, p.yaw_den, p.yaw_den_rcp);   // env.py:236
     else if (cfg_yaw_mode<SPEC>(p) == 2) dyaw = div_const<double>((yaw_act - p.yaw_steps) * p.yaw_num, p.yaw_den, p.yaw_den_rcp);   // env.py:238
     e.yaw = e.yaw + dyaw;                                               // env.py:258
 
-    Cmd c;
-    c.smove = trunc(p.smove_max * ((double)lr2 * p.smooth_scale)) + 0.0;   // astype(int): toward zero, +0 (env.py:259-260,269)
-    c.fmove = trunc(p.fmove_max * ((double)fw2 * p.smooth_scale)) + 0.0;   // env.py:261,269
-    if (cfg_jump_mode<SPEC>(p) == 2) c.jump = z_vel <= 16.0f;           // env.py:263
+    if (cfg_jump_mode<SPEC>(p) == 2) c.jump = z_vel <= 16.0f ? 1u : 0u;   // env.py:263
     else if (cfg_jump_mode<SPEC>(p) == 1) c.jump = (keys >> 3) & 1u;    // env.py:265
-    else c.jump = false;                                                // env.py:267
+    else c.jump = 0u;                                                   // env.py:267
     return c;
 }
 
@@ -531,23 +628,32 @@ __device__ __forceinline__ void physics_core(const TickConsts& k_, VT& vx, VT& v
     // wx = wy = +0 (the einsum sums start from +0.0), so wish_dir = +0 / 2^-300 = +0 = the reference's pass-through (phys.py:99-101),
     // and the acceleration - some tiny positive number instead of 0 - multiplies +0: vel + (+0) either way.  One v_max_f64 instead of
     // the selects around the square root, the reciprocal and the two quotients.
-    const double wsq = fmax(wx * wx + wy * wy, k_.tiny_wish);
+    const double wsq = k_.hoisted ? max_f64_raw(wx * wx + wy * wy, k_.tiny_wish) : fmax(wx * wx + wy * wy, k_.tiny_wish);
     double wlen;
     if constexpr (NORMAL) wlen = sqrt_normal(wsq);
     else wlen = sqrt(wsq);
     const double yw = rcp_refined(wlen);
     const double dx = div_shared(wx, wlen, yw);                         // phys.py:99-101
     const double dy = div_shared(wy, wlen, yw);
-    const double wish_speed = fmin(k_.max_wish, wlen);                  // phys.py:103 (320)
+    const double wish_speed = k_.hoisted ? min_f64_raw(k_.max_wish, wlen) : fmin(k_.max_wish, wlen);   // phys.py:103 (320)
 
     double hx = (double)vx, hy = (double)vy;
-    if (og_mask) {                                                      // wave-uniform skip
+    if (__builtin_expect(og_mask != 0ull, 1)) {                         // wave-uniform skip (somebody stands on the floor in most waves: fall through)
         VT speed, control;                                              // norm / control in the velocity's own dtype (phys.py:85-86)
-        if constexpr (sizeof(VT) == 4) { speed = sqrtf(vx * vx + vy * vy); control = fmaxf(speed, 100.0f); }
-        else { speed = sqrt(vx * vx + vy * vy); control = fmax(speed, 100.0); }
+        if constexpr (sizeof(VT) == 4) {
+            // float32 norm: sum of squares in float32, then the correctly rounded float32 square root.  Through float64: sqrt is one of
+            // the operations whose double rounding is innocuous when the wide format has >= 2 p + 2 bits (53 >= 50), so
+            // RN32(RN64(sqrt(x))) = RN32(sqrt(x)); and sqrt_normal's 10 instructions replace the compiler's float32 expansion (input
+            // scaling, v_sqrt_f32, two residual tests, un-scaling, class test: 17 + 6 hazard no-ops).  x = 0 gives NaN here and is
+            // discarded by the `speed > 0` mask below, like the reference's 0 / 0 (phys.py:90).
+            const float x = vx * vx + vy * vy;
+            if constexpr (NORMAL) speed = (float)sqrt_normal((double)x);
+            else speed = sqrtf(x);
+            control = fmaxf(speed, 100.0f);
+        } else { speed = sqrt(vx * vx + vy * vy); control = fmax(speed, 100.0); }
         const double drop = (dt * (double)control) * 4.0;               // phys.py:87
         const double ns = fmax(0.0, (double)speed - drop);              // phys.py:88
-        const double sd = fmax((double)speed, k_.tiny_speed);                // (speed == 0: any divisor, the quotient is not used)
+        const double sd = k_.hoisted ? max_f64_raw((double)speed, k_.tiny_speed) : fmax((double)speed, k_.tiny_speed);   // (speed == 0: any divisor, the quotient is not used)
         const double k = div_shared(ns, sd, rcp_refined(sd));           // phys.py:90 (exact: operands in the normal range)
         select2_into_f64(og_mask & __ballot(speed > (VT)0), (double)vx * k, hx, (double)vy * k, hy);
     }
@@ -555,22 +661,24 @@ __device__ __forceinline__ void physics_core(const TickConsts& k_, VT& vx, VT& v
     // phys.py:73-75: in the air a wish_speed above 30 is clipped to 30.  wish_speed <= 320, so min(wish_speed, og ? 320 : 30) is
     // the same number, and the two bounds differ in the high word only: one 32-bit select
     const double cap = __hiloint2double(og ? 0x40740000 : 0x403e0000, 0);                   // 320.0 : 30.0
-    const double capped = fmin(wish_speed, cap);
+    const double capped = k_.hoisted ? min_f64_raw(wish_speed, cap) : fmin(wish_speed, cap);
     const double add = fmax(0.0, capped - cur);                         // phys.py:77
     const double acc = fmin(accel_dt * wish_speed, add);                // phys.py:78 (unclipped wish_speed)
     vx = (VT)(hx + acc * dx);                                           // phys.py:80, RNE to float32 at phys.py:190
     vy = (VT)(hy + acc * dy);
 
-    // z (phys.py:112-132)
-    const uint32_t fl = flags | (c.jump ? 0u : FLAG_JUMP_RELEASED);     // phys.py:117
-    const bool do_jump = og && c.jump && (fl & FLAG_JUMP_RELEASED);     // phys.py:118
-    VT z_vel = vz + (do_jump ? (VT)270 : (VT)0);                        // add in vel's dtype (phys.py:119)
+    // z (phys.py:112-132), the flag logic as bit arithmetic on bit 0 = on_ground, bit 1 = jump_released, jump = 0 / 1:
+    // jump_released |= ~jump (117); do_jump = on_ground & jump & jump_released (118) = on_ground & jump & the OLD jump_released
+    const uint32_t dj = flags & (flags >> 1) & c.jump;                  // 0 / 1 (c.jump has no other bits)
+    VT z_vel;
+    if constexpr (sizeof(VT) == 4) z_vel = fmaf((float)dj, 270.0f, vz); // vz + (do_jump ? 270 : 0) in float32 (119): the product is exact
+    else z_vel = vz + (dj ? (VT)270 : (VT)0);
     z_vel = (VT)((double)z_vel - grav_dt);                              // float64 subtract, RNE (phys.py:122)
     const double z = zpos + dt * (double)z_vel;                         // phys.py:127
     const bool landed = z < 24.03125;                                   // phys.py:128
     zpos = fmax(z, 24.03125);                                           // phys.py:129 (landed ? floor : z)
     vz = landed ? (VT)0 : z_vel;                                        // phys.py:130
-    flags = (fl & ~FLAG_ON_GROUND) | (landed ? FLAG_ON_GROUND : 0u);
+    flags = ((flags | ((c.jump ^ 1u) << 1)) & ~FLAG_ON_GROUND) | (landed ? FLAG_ON_GROUND : 0u);
 }
 
 template <bool NORMAL>
@@ -582,31 +690,46 @@ __device__ __forceinline__ void physics(const TickConsts& k_, Env& e, const Cmd&
 // yaw -> basis with pitch = roll = 0 (phys.py:56-66): radians = yaw*pi/180 (mul THEN div), float64 sincos
 template <bool SPEC>
 __device__ __forceinline__ void physics_yaw_only(const Params& p, const TickConsts& tc, Env& e, const Cmd& c) {
-    const double rad = div_const<double>(e.yaw * 3.141592653589793, 180.0, 1.0 / 180.0);
+    const double rad = div_const1<double>(e.yaw * 3.141592653589793, 180.0, 1.0 / 180.0);   // |180 RN(1/180) - 1| = 0.6875 x 2^-54: one step
     double sn, cs;
     sincos_yaw(tc, rad, sn, cs);
     physics<SPEC>(tc, e, c, cs, sn, sn, -cs, p.dt, p.accel_dt, p.grav_dt);
 }
 
 // env.py:392-400 with _round_origin (385-390), _round_vel (381-383), get_obs_scale (294-296).
-// OBS_T = double reproduces the reference's float64 row.  OBS_T = float is DEFINED as that row rounded to float32;
-// for the z and vel columns the rounded-then-scaled numerators (j/8 and 16*m, |j|, |m| < 2^24) are exact in float32
-// and j/800, 2m/25 can never sit within 2^-53 of a float32 rounding boundary (distance >= 2^-29.6 relative), so the
-// float32 division gives RN32(RN64(.)) exactly and those four columns skip float64 entirely.
-template <typename OBS_T>
+// OBS_T = double reproduces the reference's float64 row.  OBS_T = float is DEFINED as that row rounded to float32, computed without
+// the float64 divisions for the four columns whose numerators are small integers:
+//   z:   rint(8 z) = j, the reference's value is RN64(RN64(j / 8) / 100), i.e. j / 800 to within 2^-53; j / 800 = j / (25 * 32) is never
+//        within 2^-29.6 (relative) of a float32 rounding boundary for 0 < |j| < 2^24, and never ON one (that needs j >= 25 * 2^24), so
+//        ANY float64 value within 2^-52 of j / 800 rounds to the same float32: RN32(j * RN64(1 / 800)), one product and one conversion
+//   vel: trunc(v / 16) = m, the reference's value is RN64(16 m / 200) = 2 m / 25 to within 2^-53 and the same argument makes its
+//        float32 rounding equal to the correctly rounded float32 quotient m / 12.5, which one Markstein step on RN32(0.08) delivers
+//        (|12.5 RN32(0.08) - 1| = 0.75 x 2^-25; m = -0 yields +0 like the reference's integer cast)
+// Both are checked EXHAUSTIVELY - every j and every m below 2^24 in magnitude - by tests/test_division_shortcuts.py (NumPy float64
+// emulation, exact for these operand widths) and on the device by q1env_selftest_division.
+// ONE_STEP: time_limit's reciprocal passes the one-step bound (SPEC kernels); 90 always does.
+template <typename OBS_T, bool ONE_STEP = false>
 __device__ __forceinline__ void observe(const Params& p, const Env& e, OBS_T o[6]) {
-    o[0] = (OBS_T)div_const<double>(e.trem, p.time_limit, p.time_limit_rcp);
-    o[1] = (OBS_T)div_const<double>(e.yaw, 90.0, 1.0 / 90.0);
+    o[0] = (OBS_T)div_const_sel<ONE_STEP, double>(e.trem, p.time_limit, p.time_limit_rcp);
+    o[1] = (OBS_T)div_const1<double>(e.yaw, 90.0, 1.0 / 90.0);
     if constexpr (sizeof(OBS_T) == 8) {
         o[2] = div_const<double>(rint(e.z * 8.0) * 0.125, 100.0, 1.0 / 100.0);
         o[3] = div_const<double>(trunc((double)(e.vx * 0.0625f)) * 16.0 + 0.0, 200.0, 1.0 / 200.0);
         o[4] = div_const<double>(trunc((double)(e.vy * 0.0625f)) * 16.0 + 0.0, 200.0, 1.0 / 200.0);
         o[5] = div_const<double>(trunc((double)(e.vz * 0.0625f)) * 16.0 + 0.0, 200.0, 1.0 / 200.0);
     } else {
-        o[2] = div_const<float>((float)(rint(e.z * 8.0) * 0.125), 100.0f, 1.0f / 100.0f);
-        o[3] = div_const<float>(truncf(e.vx * 0.0625f) * 16.0f + 0.0f, 200.0f, 1.0f / 200.0f);
-        o[4] = div_const<float>(truncf(e.vy * 0.0625f) * 16.0f + 0.0f, 200.0f, 1.0f / 200.0f);
-        o[5] = div_const<float>(truncf(e.vz * 0.0625f) * 16.0f + 0.0f, 200.0f, 1.0f / 200.0f);
+        o[2] = (float)(rint(e.z * 8.0) * (1.0 / 800.0));
+        o[3] = div_const1<float>(truncf(e.vx * 0.0625f), 12.5f, 0.08f);
+        // (vel_y, vel_z) as ONE two-wide float32 chain (v_pk_mul / v_pk_fma): columns 4 and 5 are neighbours in the row, so the result
+        // pair is the register pair the row's third 8-byte LDS write takes
+        typedef float f2 __attribute__((ext_vector_type(2)));
+        f2 m = {e.vy, e.vz};
+        m = __builtin_elementwise_trunc(m * 0.0625f);
+        const f2 q = m * 0.08f;
+        const f2 r = __builtin_elementwise_fma(-q, (f2)12.5f, m);
+        const f2 o45 = __builtin_elementwise_fma(r, (f2)0.08f, q);
+        o[4] = o45.x;
+        o[5] = o45.y;
     }
 }
 
@@ -615,7 +738,7 @@ __device__ __forceinline__ void observe(const Params& p, const Env& e, OBS_T o[6
 template <typename OBS_T, bool SPEC>
 __device__ __forceinline__ void tick(const Params& p, const TickConsts& tc, Env& e, uint32_t keybits, double yaw_act, TickOut<OBS_T>& out) {
     if (cfg_hover<SPEC>(p)) { e.vz = 0.0f; e.z = 100.0; }               // env.py:483-485
-    const Cmd c = decode<SPEC>(p, e, keybits, yaw_act, e.vz, e.trem);
+    const Cmd c = decode<SPEC>(p, tc, e, keybits, yaw_act, e.vz, e.trem);
     physics_yaw_only<SPEC>(p, tc, e, c);
     if (cfg_speed_reward<SPEC>(p)) out.reward = p.dt_f32 * sqrtf(e.vx * e.vx + e.vy * e.vy);   // env.py:501 (float32)
     else out.reward = p.dt_f32 * e.vy;                                  // env.py:503 (float32)
@@ -623,7 +746,7 @@ __device__ __forceinline__ void tick(const Params& p, const TickConsts& tc, Env&
     e.py = e.py + p.dt * (double)e.vy;
     e.trem = e.trem - p.dt;                                             // env.py:505
     out.done = e.trem < 0.0;                                            // env.py:506
-    observe<OBS_T>(p, e, out.obs);
+    observe<OBS_T, SPEC>(p, e, out.obs);
 }
 
 template <typename OBS_T, bool SPEC>

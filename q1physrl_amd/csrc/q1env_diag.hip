@@ -36,6 +36,11 @@ selftest_division_kernel(uint64_t n, uint64_t seed, double c_extra0, double c_ex
         const double c = cs[k];
         const double a = div_const<double>(x, c, 1.0 / c), b = x / c;
         bad0 += (__double_as_longlong(a) != __double_as_longlong(b));
+        // the ONE-step form, wherever the host-side bound allows it (the same test q1env_host.hpp div_one_step_ok applies)
+        if (fabs(fma(c, 1.0 / c, -1.0)) <= 0x1p-54) {
+            const double a1 = div_const1<double>(x, c, 1.0 / c);
+            bad0 += (__double_as_longlong(a1) != __double_as_longlong(b));
+        }
     }
     const double den = 0.5 + 4000.0 * u53(r2[0], r2[1]);
     const double num = (2.0 * u53(r2[2], r2[3]) - 1.0) * den;
@@ -54,12 +59,23 @@ selftest_division_kernel(uint64_t n, uint64_t seed, double c_extra0, double c_ex
     {   // vel column: v float32 -> trunc(v/16)*16 / 200, float64 reference vs float32 shortcut
         const float v = (float)((2.0 * u - 1.0) * 40000.0);
         const double ref = (trunc((double)(v / 16.0f)) * 16.0 + 0.0) / 200.0;
-        const float fast = div_const<float>(truncf(v * 0.0625f) * 16.0f + 0.0f, 200.0f, 1.0f / 200.0f);
+        const float fast = div_const1<float>(truncf(v * 0.0625f), 12.5f, 0.08f);                  // observe<float>'s vel columns
         bad2 += (__float_as_uint((float)ref) != __float_as_uint(fast));
         const double z = 24.03125 + 3000.0 * w;
         const double refz = (rint(z * 8.0) / 8.0) / 100.0;
-        const float fastz = div_const<float>((float)(rint(z * 8.0) * 0.125), 100.0f, 1.0f / 100.0f);
+        const float fastz = (float)(rint(z * 8.0) * (1.0 / 800.0));                                // observe<float>'s z column
         bad3 += (__float_as_uint((float)refz) != __float_as_uint(fastz));
+        // EXHAUSTIVE part: thread i < 2^25 checks the integer m = i - 2^24 as trunc(v / 16) and |m| as rint(8 z) - every numerator the
+        // two shortcuts are claimed for (|m|, j < 2^24), against the reference's float64 expressions rounded to float32
+        if (i < (1ull << 25)) {
+            const double md = (double)((long long)i - (1ll << 24));
+            const float mf = (float)md;
+            const double refm = (md * 16.0 + 0.0) / 200.0;
+            bad2 += (__float_as_uint((float)refm) != __float_as_uint(div_const1<float>(mf, 12.5f, 0.08f)));
+            const double jd = fabs(md);
+            const double refj = (jd * 0.125) / 100.0;
+            bad3 += (__float_as_uint((float)refj) != __float_as_uint((float)(jd * (1.0 / 800.0))));
+        }
     }
     if (bad0) atomicAdd(&counts[0], (unsigned long long)bad0);
     if (bad1) atomicAdd(&counts[1], (unsigned long long)bad1);
@@ -92,7 +108,7 @@ __global__ void __launch_bounds__(256)
 selftest_trig_kernel(uint64_t n, const double* yaw_deg, double* sin_out, double* cos_out, uint64_t seed, unsigned long long* counts) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const double rad = div_const<double>(yaw_deg[i] * 3.141592653589793, 180.0, 1.0 / 180.0);   // physics_yaw_only's radians
+    const double rad = div_const1<double>(yaw_deg[i] * 3.141592653589793, 180.0, 1.0 / 180.0);   // physics_yaw_only's radians
     double sn, cs, sl, cl;
     sincos_yaw(tick_consts(), rad, sn, cs);
     sincos(rad, &sl, &cl);

@@ -141,7 +141,16 @@ static inline bool move_max_ordinary(double m) {
     const double a = m < 0 ? -m : m;
     return a == 0.0 || (a >= 0x1p-200 && a <= 0x1p+200);
 }
+// The SPEC tick divides by its two run-time constants (time_limit, yaw_den) with ONE Markstein correction step (q1env_device.hpp
+// div_const1): valid when the correctly rounded reciprocal's relative error is at most 2^-54.  c * y - 1 is exact in one fma (it is a
+// multiple of 2^-105 or so below 2^-52 in magnitude).  10 (time_limit of get_default and params.yml; action_range 10 of params.yml)
+// sits exactly on the bound, float32(10.08) (get_default's action_range) at 0.68 of it; a Config whose constants fail runs the
+// generic kernels (two steps).
+static inline bool div_one_step_ok(double c, double y) {
+    return c > 0.0 && std::fabs(std::fma(c, y, -1.0)) <= 0x1p-54;
+}
 static inline bool is_spec(const Params& p) {
     return p.num_keys == 4 && p.yaw_mode == 1 && p.jump_mode == 1 && !p.hover && !p.speed_reward &&
-           move_max_ordinary(p.fmove_max) && move_max_ordinary(p.smove_max) && move_max_ordinary(p.smooth_scale);
+           move_max_ordinary(p.fmove_max) && move_max_ordinary(p.smove_max) && move_max_ordinary(p.smooth_scale) &&
+           div_one_step_ok(p.time_limit, p.time_limit_rcp) && div_one_step_ok(p.yaw_den, p.yaw_den_rcp);
 }

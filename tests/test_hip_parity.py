@@ -291,7 +291,9 @@ def test_exact_division_shortcuts_selftest():
     lib = _lib.load()
     for seed, c0, c1 in ((1, 10.0, 10.079999923706055), (2, 5.0, 10.0), (3, 0.5, 7.0), (4, 3.0, 5.0)):
         out = (C.c_uint64 * 4)()
-        _lib.check(lib.q1env_selftest_division(0, 1 << 24, seed, c0, c1, out))
+        # 2^25 threads: the first 2^25 also run the EXHAUSTIVE check of the two float32 observation-column shortcuts (every
+        # trunc(v / 16) = m and rint(8 z) = j below 2^24 in magnitude); constants that pass the one-step bound are tested in both forms
+        _lib.check(lib.q1env_selftest_division(0, 1 << 25, seed, c0, c1, out))
         assert list(out) == [0, 0, 0, 0], (seed, list(out))
 
 
