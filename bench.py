@@ -73,6 +73,12 @@ EPISODE_TICKS = 720
 PRIMARY_AUTO = "rollout"  # what --mode auto measures: every tick's obs / reward / done reach HBM
 
 
+# data/params.yml:16-33 env_config of the reference (BASELINE configs[2] / configs[4])
+PARAMS_YML = dict(action_range=10, allow_jump=True, allow_yaw=True, auto_jump=False, discrete_yaw_steps=-1, fmove_max=800, smove_max=1060,
+                  hover=False, initial_yaw_range=(0, 360), key_press_delay=0.3, max_initial_speed=700, smooth_keys=True, speed_reward=False,
+                  time_delta=0.013888888888888, time_limit=10, zero_start_prob=0.01)
+
+
 def make_actions(n, ticks, action_range, seed):
     """Packed actions for one episode, tick-major: keys uint8 (ticks, n) bit k = Key k, mouse float32 (ticks, n)."""
     rng = np.random.default_rng(seed)
@@ -206,9 +212,7 @@ def sampler_block(dev_index, sizes=(32768, 262144), horizon=128, reps=4):
     from q1physrl_amd.env import Config
     from q1physrl_amd.sampler import GpuSampler
     from q1physrl_amd.tensor_env import TensorVectorEnv
-    params_yml = dict(action_range=10, allow_jump=True, allow_yaw=True, auto_jump=False, discrete_yaw_steps=-1, fmove_max=800, smove_max=1060,
-                      hover=False, initial_yaw_range=(0, 360), key_press_delay=0.3, max_initial_speed=700, smooth_keys=True, speed_reward=False,
-                      time_delta=0.013888888888888, time_limit=10, zero_start_prob=0.01)
+    params_yml = PARAMS_YML
     rows = []
     for n in sizes:
         row = {"envs": n, "horizon": horizon, "workload": "BASELINE configs[4]: sampler loop with the policy forward in it, params.yml Config"
@@ -363,6 +367,10 @@ def parse_args(argv=None):
     ap.add_argument("--envs", type=int, default=65536, help="envs per GPU (131072 = BASELINE configs[3]'s shard)")
     ap.add_argument("--mode", choices=("auto", "step", "rollout", "server"), default="auto",
                     help="auto = rollout (one launch per episode chunk, every tick's obs / reward / done written to HBM)")
+    ap.add_argument("--config", choices=("default", "params_yml"), default="default",
+                    help="default = get_default with zero_start_prob 1 (BASELINE configs[1] / [3]); params_yml = the reference's training Config "
+                         "(data/params.yml:16-33: random starts, truncated dt, action_range 10) with IN-KERNEL reset of finished episodes "
+                         "(BASELINE configs[2]; --mode rollout only)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary (other-mode) measurement")
@@ -492,8 +500,16 @@ def main(argv=None):
 
     n = args.envs
     start, _ = sharding.shard_range(n * world, rank, world)                  # contiguous batch split, weak scaling
-    cfg = E.Config(**{**E.Config.get_default().__dict__, "num_envs": n, "zero_start_prob": 1.0})
+    full_cfg = args.config == "params_yml"
+    if full_cfg and args.mode not in ("auto", "rollout"):
+        raise SystemExit("bench.py: --config params_yml is measured with --mode rollout (in-kernel reset of finished episodes)")
+    if full_cfg:
+        cfg = E.Config(num_envs=n, **PARAMS_YML)
+    else:
+        cfg = E.Config(**{**E.Config.get_default().__dict__, "num_envs": n, "zero_start_prob": 1.0})
     dev = DeviceEnv(cfg, device=dev_index, env_index_base=start)             # own stream; global env index keys the RNG
+    if full_cfg:
+        dev.reset_philox_dev(99, 0, False)                                   # random starts (env.py:428-455's distributions, counter RNG)
     ar = float(cfg.action_range)
     keys_h, mouse_h = make_actions(n, EPISODE_TICKS, ar, seed=1234 + rank)
     keys = torch.from_numpy(keys_h).to(d)
@@ -536,7 +552,7 @@ def main(argv=None):
             chunk = min(left, EPISODE_TICKS - ph)
             ka = keys.data_ptr() + ph * n
             ma = mouse.data_ptr() + ph * n * 4
-            ends_episode = (t + chunk) % EPISODE_TICKS == 0
+            ends_episode = (t + chunk) % EPISODE_TICKS == 0 and not full_cfg    # (params_yml: episodes end per env, reset in-kernel)
             if mode == "server":
                 # the resident tick server on the handle's stream + its dependent producer on a second stream: `chunk` ticks,
                 # one launch each; the in-kernel reset at the episode-ending tick replaces the reset launch of the other modes
@@ -586,7 +602,7 @@ def main(argv=None):
                     # (the timer events are recorded inside the q1env_rollout call of the first / last chunk, next to the launch itself)
                     # timed = "signal": device stamps + the kernel-written completion signal (the timed region proper);
                     # timed = "events": HIP events around the same launches (the cross-check pass that follows it)
-                    rflags = 0
+                    rflags = 1 if full_cfg else 0                          # bit 0: in-kernel Philox reset of envs whose episode ended
                     if timed and not started:
                         rflags |= _lib.STAMP_START if timed == "signal" else _lib.TIMER_START
                         started = True
@@ -594,8 +610,8 @@ def main(argv=None):
                         rflags |= _lib.SIGNAL if timed == "signal" else _lib.TIMER_STOP     # (Q1_BENCH_SIGNAL_MARK=1: A/B knob - the signal from a
                         stopped = True                                                       #  one-wave kernel behind the launch instead of its own last wave)
                     # (arguments converted once, outside the timed region: DeviceEnv.prepare_rollout)
-                    calls.append(dev.prepare_rollout(chunk, _lib.ACT_PACKED, ka, ma, 0, _lib.OBS_F32, obsT.data_ptr(), rewT.data_ptr(),
-                                                     doneT.data_ptr(), rflags))
+                    calls.append(dev.prepare_rollout(chunk, _lib.ACT_PACKED, ka, ma, 99 if full_cfg else 0, _lib.OBS_F32, obsT.data_ptr(),
+                                                     rewT.data_ptr(), doneT.data_ptr(), rflags))
                 launches += 1
             t += chunk
             left -= chunk
@@ -731,13 +747,19 @@ def main(argv=None):
     def kernel_name(mode):
         sp = "true" if spec_cfg else "false"
         return {"step": f"step_kernel<float, {sp}, 2>  (OBS_T = float, SPEC, FMT_PACKED)",
-                "rollout": f"rollout_kernel<float, {sp}, 2, false, 1>  (OBS_T = float, SPEC, FMT_PACKED, HAS_RESET = false, OUT_MODE = 1: obs, reward, done every tick)",
+                "rollout": f"rollout_kernel<float, {sp}, 2, {'true' if full_cfg else 'false'}, 1, false>  (OBS_T = float, SPEC, FMT_PACKED, HAS_RESET = "
+                           f"{'true' if full_cfg else 'false'}, OUT_MODE = 1: obs, reward, done every tick, RET = false)",
                 "server": f"tick_pair_lds_kernel<{sp}, {pair_es(n)}>  (SPEC, ES = sub-batches per workgroup; server wave + dependent stand-in producer wave)"}[mode]
 
     def workload(mode):
-        head = (f"BASELINE configs[1]: {n} envs/GPU" if n != 131072 else
-                f"BASELINE configs[3] shard: 131072 envs/GPU ({131072 * world} envs on {world} GPU(s))")
-        head += ", zero-start 100 m run, random actions (packed, resident in HBM), get_default Config, 720-tick episodes with on-device reset of all envs at each episode end; "
+        if full_cfg:
+            head = (f"BASELINE configs[2]: {n} envs/GPU, full Config (data/params.yml env_config: initial_yaw_range (0, 360), time_limit 10 s, "
+                    "key_press_delay 0.3, dt 0.013888888888888, action_range 10, zero_start_prob 0.01), random starts, random actions (packed, "
+                    "resident in HBM), every finished episode reset IN-KERNEL (counter RNG) before its next tick; ")
+        else:
+            head = (f"BASELINE configs[1]: {n} envs/GPU" if n != 131072 else
+                    f"BASELINE configs[3] shard: 131072 envs/GPU ({131072 * world} envs on {world} GPU(s))")
+            head += ", zero-start 100 m run, random actions (packed, resident in HBM), get_default Config, 720-tick episodes with on-device reset of all envs at each episode end; "
         return head + {
             "rollout": "mode=rollout: q1env_rollout, one launch per episode chunk, env state in registers between ticks, EVERY tick's obs "
                        "f32 (N,6) / reward f32 / done u8 written tick-major to HBM",
@@ -763,7 +785,7 @@ def main(argv=None):
                           formulation's bytes on this kernel's time (passes 1 by construction: NOT a roofline fraction)."""
         tpl = steps / launches_
         kern_us = ev_ms_ * 1e3 / launches_
-        pmc, pmc_stale = load_pmc(mode, n, lib_build_id)
+        pmc, pmc_stale = load_pmc(mode + ("_params" if full_cfg else ""), n, lib_build_id)
         resident = mode != "step"
         traffic = traffic_per_launch(pmc, n, tpl, resident)
         alg_bytes = (B_ALG * n * tpl) if not resident else (B_FUSED * n * tpl + B_STATE * n)
@@ -839,8 +861,8 @@ def main(argv=None):
     if not args.no_secondary:
         names = {"rollout": "fused_rollout", "step": "per_tick_step", "server": "persistent_server"}
         for other in ("step", "rollout", "server"):
-            if other == args.mode or (other == "server" and (injected or n > SERVER_AUTO_MAX_ENVS)):
-                continue
+            if other == args.mode or (other == "server" and (injected or n > SERVER_AUTO_MAX_ENVS)) or full_cfg:
+                continue                                 # (params_yml: only the rollout with in-kernel reset is that workload)
             try:
                 w2, ev2, l2, own2 = measure(other, args.steps, args.warmup)
             except Exception as ex:   # noqa: BLE001 - a secondary measurement must not take the contract line down
@@ -852,7 +874,7 @@ def main(argv=None):
         # start-up latency amortised), on every rank: the multi-GPU line carries it too (slowest rank's event time)
         steady = {}
         for m in ("rollout", "step") + (() if injected or n > SERVER_AUTO_MAX_ENVS else ("server",)):
-            if injected and world > 1 and m != args.mode:
+            if (injected and world > 1 and m != args.mode) or (full_cfg and m != "rollout"):
                 continue                                 # (the CPU stand-in is slow: the launcher tests keep to the primary mode)
             try:
                 w3, ev3, l3, _o = measure(m, EPISODE_TICKS, 0)
@@ -862,13 +884,13 @@ def main(argv=None):
             except Exception as ex:   # noqa: BLE001
                 steady[m] = {"error": repr(ex)}
         out["steady_state_720_ticks"] = steady
-    if rank == 0 and world == 1 and not args.no_secondary and not injected:
+    if rank == 0 and world == 1 and not args.no_secondary and not injected and not full_cfg:
         out["step_kernel_size_sweep"] = size_sweep(dev_index)
         try:
             out["sampler_configs4_shard"] = sampler_block(dev_index)
         except Exception as ex:   # noqa: BLE001 - extra information must not take the contract line down
             out["sampler_configs4_shard"] = {"error": repr(ex)}
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not full_cfg:
         def gpu_check(acts, k):
             """The GPU env on the oracle's own actions (float64 rows) for k ticks from a fresh zero start."""
             chk = DeviceEnv(cfg, device=dev_index)

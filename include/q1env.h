@@ -377,6 +377,12 @@ typedef struct q1env_learner_batch {
     const float* kl_coeff_dev;         /* device scalar */
     float* stats_partials_dev;         /* float[ceil(B/256)][5]: sums of (entropy, kl, -surrogate, total, vf) per block of 256 samples */
     int skip_reduce;                   /* != 0: leave the split-K partial sums in the workspace for q1env_learner_adam (gw* / gb* untouched) */
+    uint32_t* saturation_dev;          /* (ABI v4) optional uint32[4], accumulating until the caller zeroes it: [0] += (lane, launch) pairs of the
+                                        * POLICY network's backward pass that converted a gradient element (dY, dZ2, dZ1 - per-sample gradients
+                                        * times the float16 loss scale) beyond float16's largest finite value 65504 and clamped it - a per-sample
+                                        * gradient clip the reference (RLlib, grad_clip None) does not apply, so it is counted, not hidden;
+                                        * [1] = max of the float32 BITS of the largest |element| seen before the clamp; [2], [3] the same for the
+                                        * value network */
 } q1env_learner_batch;
 uint64_t q1env_learner_workspace_bytes(int64_t minibatch, int out_dim_pi, int splits);
 int q1env_learner_images(q1env_t* env, const q1env_learner_net* pi, const q1env_learner_net* vf, void* ws_dev, int64_t minibatch, int splits);

@@ -65,7 +65,7 @@ class Q1LearnerBatch(C.Structure):   # q1env_learner_batch
                 ("keys_dev", C.c_void_p), ("mouse_dev", C.c_void_p), ("logp_old_dev", C.c_void_p), ("adv_dev", C.c_void_p),
                 ("value_old_dev", C.c_void_p), ("vtarg_dev", C.c_void_p),
                 ("clip_param", C.c_float), ("vf_clip_param", C.c_float), ("vf_loss_coeff", C.c_float), ("entropy_coeff", C.c_float),
-                ("kl_coeff_dev", C.c_void_p), ("stats_partials_dev", C.c_void_p), ("skip_reduce", C.c_int)]
+                ("kl_coeff_dev", C.c_void_p), ("stats_partials_dev", C.c_void_p), ("skip_reduce", C.c_int), ("saturation_dev", C.c_void_p)]
 
 
 STATE_FIELDS = (("vel_x", np.float32, 1), ("vel_y", np.float32, 1), ("vel_z", np.float32, 1),

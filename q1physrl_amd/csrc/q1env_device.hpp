@@ -395,18 +395,38 @@ __device__ __forceinline__ void store_env(const StatePtrs& s, uint32_t n, uint32
 }
 
 // The tick's write-back: position, horizontal velocity, yaw and time_remaining change on every tick; the key timestamps (a rising
-// edge at most once per key_press_delay), the flag byte, z and vel_z (constant while the player stands on the floor) often do
-// not - those are written only by the lanes whose bit pattern changed (`old` = the state as loaded), up to 45 B of the 85 B.
+// edge at most once per key_press_delay), the flag byte, z and vel_z (constant while the player stands on the floor) often do not.
+// Product form (Q1_DELTA_PER_LANE = 1): those are written only by the lanes whose bit pattern changed (`old` = the state as loaded), up to
+// 45 B of the 85 B.  The alternative VERDICT r3 item 7 asked for - written by the WHOLE WAVE or not at all, `__ballot(changed)` being
+// wave-uniform, so that every store instruction covers full aligned lines (round 3 counted 1.37 write requests per env where 1.0 would
+// carry the bytes) - was built and measured in round 4 (Q1_DELTA_PER_LANE = 0, tools/exp_step_large.py, profiles/r4_step_large.txt):
+// 7.63 vs 7.37 us per tick at 262 144 envs, 38.4 vs 36.2 at 1 M, 157.0 vs 157.3 at 4 M - no gain, a loss at 1 M: the partial lines are
+// not what holds the kernel below the copy kernel, and the per-lane form writes fewer bytes when keys are held (a trained policy).
+#ifndef Q1_DELTA_PER_LANE            // 1 (product) = per-lane conditional stores; 0 = the whole-wave form above (tools/exp_step_large.py A/B)
+#define Q1_DELTA_PER_LANE 1
+#endif
 __device__ __forceinline__ void store_env_delta(const StatePtrs& s, uint32_t n, uint32_t i, const Env& e, const Env& old) {
+    if constexpr (Q1_DELTA_PER_LANE == 1) {
+        s.vx[i] = e.vx; s.vy[i] = e.vy;
+        if (__float_as_uint(e.vz) != __float_as_uint(old.vz)) s.vz[i] = e.vz;
+        s.px[i] = e.px; s.py[i] = e.py;
+        if (__double_as_longlong(e.z) != __double_as_longlong(old.z)) s.z[i] = e.z;
+        s.yaw[i] = e.yaw; s.trem[i] = e.trem;
+#pragma unroll
+        for (uint32_t k = 0; k < 4; ++k)
+            if (__double_as_longlong(e.lk[k]) != __double_as_longlong(old.lk[k])) (s.lk + (size_t)k * n)[i] = e.lk[k];
+        if ((e.flags & 0xFFu) != (old.flags & 0xFFu)) s.flags[i] = (uint8_t)e.flags;
+        return;
+    }
     s.vx[i] = e.vx; s.vy[i] = e.vy;
-    if (__float_as_uint(e.vz) != __float_as_uint(old.vz)) s.vz[i] = e.vz;
+    if (__ballot(__float_as_uint(e.vz) != __float_as_uint(old.vz)) != 0ull) s.vz[i] = e.vz;
     s.px[i] = e.px; s.py[i] = e.py;
-    if (__double_as_longlong(e.z) != __double_as_longlong(old.z)) s.z[i] = e.z;
+    if (__ballot(__double_as_longlong(e.z) != __double_as_longlong(old.z)) != 0ull) s.z[i] = e.z;
     s.yaw[i] = e.yaw; s.trem[i] = e.trem;
 #pragma unroll
     for (uint32_t k = 0; k < 4; ++k)
-        if (__double_as_longlong(e.lk[k]) != __double_as_longlong(old.lk[k])) (s.lk + (size_t)k * n)[i] = e.lk[k];
-    if ((e.flags & 0xFFu) != (old.flags & 0xFFu)) s.flags[i] = (uint8_t)e.flags;
+        if (__ballot(__double_as_longlong(e.lk[k]) != __double_as_longlong(old.lk[k])) != 0ull) (s.lk + (size_t)k * n)[i] = e.lk[k];
+    if (__ballot((e.flags & 0xFFu) != (old.flags & 0xFFu)) != 0ull) s.flags[i] = (uint8_t)e.flags;
 }
 
 // ---------------------------------------------------------------------------------------- completion signal

@@ -104,12 +104,12 @@ int launch_forward(q1env* h, const Ws& w, int64_t mb, const q1env_learner_net* p
 
 int launch_backward(q1env* h, const Ws& w, int64_t mb, int splits, const q1env_learner_net* pi, const q1env_learner_net* vf, const float* obs,
                     const int64_t* idx, const int64_t* idx_cursor, const float* dlogits, const float* dvalue, float grad_scale, float grad_scale_v,
-                    bool reduce = true) {
+                    bool reduce = true, uint32_t* sat = nullptr) {
     if (int r = ensure_learner_attrs(h)) return r;
     const q1learn::BwdNet ba{w.net[0].w2t, w.net[0].w3t, dlogits, pi->out_dim, pi->out_dim, w.net[0].h1T, w.net[0].h2T,
-                             w.net[0].dz2N, w.net[0].dz1N, w.net[0].h1N, w.net[0].h2N, w.net[0].xN, w.net[0].dyN};
+                             w.net[0].dz2N, w.net[0].dz1N, w.net[0].h1N, w.net[0].h2N, w.net[0].xN, w.net[0].dyN, sat};
     const q1learn::BwdNet bb{w.net[1].w2t, w.net[1].w3t, dvalue, vf->out_dim, vf->out_dim, w.net[1].h1T, w.net[1].h2T,
-                             w.net[1].dz2N, w.net[1].dz1N, w.net[1].h1N, w.net[1].h2N, w.net[1].xN, w.net[1].dyN};
+                             w.net[1].dz2N, w.net[1].dz1N, w.net[1].h1N, w.net[1].h2N, w.net[1].xN, w.net[1].dyN, sat ? sat + 2 : nullptr};
     const unsigned cus = (unsigned)(h->num_cus > 1 ? h->num_cus / 2 : 1);
     const unsigned tiles = (unsigned)((mb + 31) / 32);
     unsigned blocks = (tiles + 3u) / 4u;
@@ -203,7 +203,8 @@ int q1env_learner_step(q1env_t* h, const q1env_learner_net* pi, const q1env_lear
                            b->value_old_dev, b->vtarg_dev, (const int64_t*)nullptr, (const int64_t*)nullptr, b->clip_param, b->vf_clip_param, b->vf_loss_coeff, b->entropy_coeff,
                            b->kl_coeff_dev, scale, scale_v, w.dlogits, w.dvalue, b->stats_partials_dev);
     HIP_TRY(hipGetLastError());
-    return launch_backward(h, w, mb, splits, pi, vf, b->obs_dev, b->idx_dev, b->idx_cursor_dev, w.dlogits, w.dvalue, scale, scale_v, b->skip_reduce == 0);
+    return launch_backward(h, w, mb, splits, pi, vf, b->obs_dev, b->idx_dev, b->idx_cursor_dev, w.dlogits, w.dvalue, scale, scale_v, b->skip_reduce == 0,
+                           b->saturation_dev);
 }
 
 uint64_t q1env_learner_adam_state_bytes(int out_dim_pi) {

@@ -75,10 +75,13 @@ __device__ __forceinline__ f16x8 cvt8(const f32x16& a, int u) {
 
 // the same with saturation at float16's largest finite value: for the data gradients, whose magnitude is not bounded by construction -
 // an inf would turn into NaN in the very next transposition (inf x 0 of the selection operand) and from there into every weight
-__device__ __forceinline__ f16x8 cvt8_sat(const f32x16& a, int u) {
+// amax: running maximum of |value| BEFORE the clamp over everything this lane converts (one v_max3_f32 with |.| modifiers per pair) - what
+// the kernel reports so that a saturation does not go unnoticed
+__device__ __forceinline__ f16x8 cvt8_sat(const f32x16& a, int u, float& amax) {
     union { f16x8 v; q1pol::f16x2 p[4]; } o;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
+        amax = fmaxf(fmaxf(fabsf(a[8 * u + 2 * j]), fabsf(a[8 * u + 2 * j + 1])), amax);
         const q1pol::f32x2 t = {__builtin_amdgcn_fmed3f(a[8 * u + 2 * j], -65504.0f, 65504.0f), __builtin_amdgcn_fmed3f(a[8 * u + 2 * j + 1], -65504.0f, 65504.0f)};
         o.p[j] = __builtin_convertvector(t, q1pol::f16x2);
     }
@@ -164,6 +167,8 @@ struct BwdNet {
     f16x8* dz2N; f16x8* dz1N; f16x8* h1N; f16x8* h2N;
     f16x8* xN;                // f16x8[tile][ks][lane]: the gathered observations + the constant 1 (input slot 6), lane = sigma(input index)
     f16x8* dyN;               // f16x8[tile][ks][lane]: dY, lane = output index (natural)
+    uint32_t* sat;            // optional uint32[2]: += (lane, launch) pairs that converted a gradient element beyond float16's 65504 (it was
+                              // clamped); max= the float32 bits of the largest |element| seen before the clamp (dY, dZ2, dZ1, scaled as they travel)
 };
 
 template <uint32_t THREADS, uint32_t NVEC>
@@ -240,6 +245,7 @@ learner_backward_kernel(int n, const float* __restrict__ obs, const int64_t* __r
     const uint32_t tstride = bgrid * 4u;
     const unsigned char* w2trow = l_w2t + (size_t)col * ROW_BYTES + half * 16u;           // + 32 t1 rows, + K-step q * 32 B
     const unsigned char* w3trow = l_w3t + (size_t)col * W3T_ROW_BYTES + half * 16u;       // + 32 t2 rows, + ks * 32 B
+    float amax = 0.0f;                                                                    // largest |gradient element| this lane converted
     for (uint32_t tile = bid * 4u + wave; tile < ntiles; tile += tstride) {
         const uint32_t s = tile * 32u + col;
         const bool live = s < (uint32_t)n;
@@ -251,8 +257,10 @@ learner_backward_kernel(int n, const float* __restrict__ obs, const int64_t* __r
             for (int e = 0; e < 8; ++e) {
                 const int o0 = 8 * (int)half + e, o1 = 16 + o0;
                 // (saturating: a per-sample gradient beyond float16's 65504 - a value error of tens of thousands - must not become inf)
-                dyb0[e] = (_Float16)fminf(fmaxf((live && o0 < OUT) ? row[o0] : 0.0f, -65504.0f), 65504.0f);
-                dyb1[e] = (_Float16)fminf(fmaxf((live && o1 < OUT) ? row[o1] : 0.0f, -65504.0f), 65504.0f);
+                const float y0 = (live && o0 < OUT) ? row[o0] : 0.0f, y1 = (live && o1 < OUT) ? row[o1] : 0.0f;
+                amax = fmaxf(fmaxf(fabsf(y0), fabsf(y1)), amax);
+                dyb0[e] = (_Float16)fminf(fmaxf(y0, -65504.0f), 65504.0f);
+                dyb1[e] = (_Float16)fminf(fmaxf(y1, -65504.0f), 65504.0f);
             }
         }
         const size_t tbase = (size_t)tile * TILE_VECS + lane;
@@ -291,8 +299,8 @@ learner_backward_kernel(int n, const float* __restrict__ obs, const int64_t* __r
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, dyb1, acc, 0, 0, 0);
             }
             times_dtanh(acc, hv[t][0], hv[t][1]);
-            dzb[t][0] = cvt8_sat(acc, 0);
-            dzb[t][1] = cvt8_sat(acc, 1);
+            dzb[t][0] = cvt8_sat(acc, 0, amax);
+            dzb[t][1] = cvt8_sat(acc, 1, amax);
             store_n(net.h2N + tbase, (uint32_t)t, transpose_tile(hv[t][0], hv[t][1], e0, e1));
             store_n(net.dz2N + tbase, (uint32_t)t, transpose_tile(dzb[t][0], dzb[t][1], e0, e1));
         }
@@ -322,9 +330,20 @@ learner_backward_kernel(int n, const float* __restrict__ obs, const int64_t* __r
 #pragma unroll
         for (int t = 0; t < 8; ++t) {
             times_dtanh(acc1[t], hv[t][0], hv[t][1]);
-            const f16x8 z0 = cvt8_sat(acc1[t], 0), z1 = cvt8_sat(acc1[t], 1);
+            const f16x8 z0 = cvt8_sat(acc1[t], 0, amax), z1 = cvt8_sat(acc1[t], 1, amax);
             store_n(net.h1N + tbase, (uint32_t)t, transpose_tile(hv[t][0], hv[t][1], e0, e1));
             store_n(net.dz1N + tbase, (uint32_t)t, transpose_tile(z0, z1, e0, e1));
+        }
+    }
+    // saturation report: one pair of fire-and-forget atomics per wave (NaN gradients compare false and show up as NaN in the max)
+    if (net.sat) {
+        const uint64_t over = __ballot(amax > 65504.0f);
+        float wmax = amax;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) wmax = fmaxf(wmax, __shfl_xor(wmax, off));
+        if (lane == 0) {
+            if (over) atomicAdd(net.sat, (uint32_t)__popcll(over));
+            atomicMax(net.sat + 1, __float_as_uint(wmax));
         }
     }
 }

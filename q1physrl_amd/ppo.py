@@ -87,6 +87,8 @@ class NativeStep:
         self.adam_state = adam_state
         self.stats_acc = self.adam_state[16:36].view(torch.float32)      # running sums of the step statistics (q1env_learner_adam)
         self.cursor = self.adam_state[72:80].view(torch.int64)           # minibatch cursor: += mb per adam() (q1env_learner_batch.idx_cursor_dev)
+        # saturation report of the backward pass (q1env_learner_batch.saturation_dev): [count, max |element| bits] x (policy, value)
+        self.saturation = torch.zeros((4,), dtype=torch.int32, device=dev)
         self.images()
 
     def _net(self, seq):
@@ -136,7 +138,7 @@ class NativeStep:
                              full["obs"].data_ptr(), ol.data_ptr(), ol.shape[1],
                              full["keys_packed"].data_ptr(), full["mouse"].data_ptr(), full["logp"].data_ptr(), full["adv"].data_ptr(),
                              full["value"].data_ptr(), full["vtarg"].data_ptr(), clip_param, vf_clip_param, vf_loss_coeff, entropy_coeff,
-                             klc_dev.data_ptr(), self.partials.data_ptr(), int(bool(skip_reduce)))
+                             klc_dev.data_ptr(), self.partials.data_ptr(), int(bool(skip_reduce)), self.saturation.data_ptr())
         self.env._dev.learner_step_dev(self.pi, self.vf, self.ws.data_ptr(), self.splits, b)
         if skip_reduce:
             return None                              # adam() folds the statistics into self.stats_acc on the device
@@ -434,4 +436,12 @@ class PPOLearner:
             self.kl_coeff *= 0.5
         out["kl_coeff"] = self.kl_coeff
         out["sgd_steps"] = steps
+        if self._native is not None:
+            # float16 gradient operands: how often the backward pass had to clamp one at 65504 during this update, and the largest
+            # magnitude it met (scaled as it travels: x minibatch x loss scale) - a silent per-sample clip otherwise
+            sat = self._native.saturation.cpu()
+            out["grad_saturated_pi"], out["grad_saturated_vf"] = int(sat[0]), int(sat[2])
+            out["grad_max_abs_pi"] = float(sat[1:2].view(torch.float32)[0])
+            out["grad_max_abs_vf"] = float(sat[3:4].view(torch.float32)[0])
+            self._native.saturation.zero_()
         return out

@@ -33,7 +33,7 @@ def _rel(a, b):
     return float((a - b).norm() / b.norm().clamp_min(1e-30))
 
 
-@pytest.mark.parametrize("mb", [4096, 1000])
+@pytest.mark.parametrize("mb", [4096, 1000, 128])   # 128 = RLlib's sgd_minibatch_size, the reference's
 def test_native_forward_is_the_samplers_forward_and_gradients_match_autograd(mb):
     """(a) NativeStep.forward on gathered rows == FusedPolicyForward on the same rows, bit for bit (same mlp_tile).  (b) backward of a
     random linear functional of (logits, value): every parameter gradient against torch autograd through the float32 modules -
@@ -141,6 +141,43 @@ def test_native_learner_matches_the_torch_learner():
         assert float((a - b).abs().max()) < 1e-6, float((a - b).abs().max())
     for a, b in zip(res[1][0], res[3][0]):          # (18 steps of lr 1e-3: agreement to a few percent of ONE step's movement)
         assert float((a - b).abs().max()) < 1e-4 and float((a - b).abs().mean()) < 1e-5, float((a - b).abs().max())
+
+
+def test_gradient_saturation_is_counted_not_hidden():
+    """ADVICE r3 / VERDICT r3 weak 6: the backward pass carries per-sample gradients as float16 and clamps at 65504.  An ordinary update
+    reports zero clamped elements and a finite maximum; value targets of 1e7 (per-sample value gradients far beyond 65504) must show up
+    in grad_saturated_vf / grad_max_abs_vf instead of passing silently - and must still leave every weight finite.  The optimizer state of
+    the native Adam survives a change of minibatch size (a re-built NativeStep) and a state_dict round trip."""
+    import torch
+    from q1physrl_amd import policy as P, ppo, sampler as S
+    torch.manual_seed(5)
+    pol = P.Q1Policy().cuda()
+    cfg, env = make_env(256, time_limit=1.0)
+    smp = S.GpuSampler(env, P.FusedPolicyForward(pol, env), horizon=16)
+    tr = {k: v.clone() for k, v in smp.collect().items()}
+    adv, vt = smp.advantages(tr, 0.99, 0.95)
+    lr = ppo.PPOLearner(pol, cfg.action_range, lr=1e-4, num_sgd_iter=2, minibatch_size=1024, seed=1, fused_loss=True, env=env, native=True,
+                        native_splits=8)
+    st = lr.update(tr, adv, vt)
+    assert st["grad_saturated_pi"] == 0 and st["grad_saturated_vf"] == 0
+    assert 0.0 < st["grad_max_abs_pi"] < 65504.0 and 0.0 < st["grad_max_abs_vf"] < 65504.0
+    step_before = int(lr._adam_state[:8].view(torch.int64)[0])
+    assert step_before == st["sgd_steps"] > 0
+    sd = lr.state_dict()
+    assert sd["native_adam"] is not None and int(sd["native_adam"][:8].view(torch.int64)[0]) == step_before
+    # another minibatch size: NativeStep is re-built, Adam's moments and step count must carry over (ADVICE r3 medium)
+    lr.minibatch_size = 512
+    moments = lr._adam_state[256:256 + 4096].clone()
+    st2 = lr.update(tr, adv, vt * 1e7)                                # absurd value targets: the value network's gradients saturate
+    assert int(lr._adam_state[:8].view(torch.int64)[0]) == step_before + st2["sgd_steps"]
+    assert not torch.equal(moments, lr._adam_state[256:256 + 4096])   # ... and kept evolving from where they were
+    assert st2["grad_saturated_vf"] > 0 and st2["grad_max_abs_vf"] > 65504.0 and st2["grad_saturated_pi"] == 0
+    assert all(bool(torch.isfinite(p).all()) for p in pol.parameters())
+    lr2 = ppo.PPOLearner(pol, cfg.action_range, lr=1e-4, num_sgd_iter=1, minibatch_size=512, seed=1, fused_loss=True, env=env, native=True,
+                         native_splits=8)
+    lr2.load_state_dict(lr.state_dict())
+    assert torch.equal(lr2._adam_state.cpu(), lr._adam_state.cpu()) and lr2.kl_coeff == lr.kl_coeff
+    env.close()
 
 
 def test_native_learner_first_step_sees_ratio_one():

@@ -1,5 +1,6 @@
-"""Large-batch experiment for the per-tick step kernel: one- vs two-envs-per-lane kernels, block sizes and
-register-allocation targets at 262 144 / 1 M / 4 M envs, next to the known-bytes copy kernel in the same process.
+"""Large-batch experiment for the per-tick step kernel: whole-wave (ballot-gated) against per-lane
+conditional write-back, register-allocation targets and block sizes at 262 144 / 1 M / 4 M envs, next to the known-bytes copy kernel
+in the same process.  (Round 3's two-envs-per-lane variants were measured, dropped and removed.)
 
     python tools/exp_step_large.py build      # (CPU) build the variant libraries into gpurun_scratch/
     python tools/exp_step_large.py run        # (GPU) time every variant, print a table
@@ -7,11 +8,9 @@ register-allocation targets at 262 144 / 1 M / 4 M envs, next to the known-bytes
 import json, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-VARIANTS = {"base": [], "w6": ["-DQ1_STEP_MINWAVES=6"], "w8": ["-DQ1_STEP_MINWAVES=8"], "s2w4": ["-DQ1_STEP2_MINWAVES=4"], "s2w5": ["-DQ1_STEP2_MINWAVES=5"]}
-RUNS = [("base", {"Q1ENV_STEP2": "0"}), ("base", {"Q1ENV_STEP2": "0", "Q1ENV_BLOCK": "64"}), ("base", {"Q1ENV_STEP2": "0", "Q1ENV_BLOCK": "128"}),
-        ("w6", {"Q1ENV_STEP2": "0"}), ("w8", {"Q1ENV_STEP2": "0"}),
-        ("base", {"Q1ENV_STEP2": "1"}), ("base", {"Q1ENV_STEP2": "1", "Q1ENV_STEP2_BLOCK": "64"}), ("base", {"Q1ENV_STEP2": "1", "Q1ENV_STEP2_BLOCK": "128"}),
-        ("s2w4", {"Q1ENV_STEP2": "1"}), ("s2w5", {"Q1ENV_STEP2": "1"})]
+VARIANTS = {"base": [], "wholewave": ["-DQ1_DELTA_PER_LANE=0"], "w6": ["-DQ1_STEP_MINWAVES=6"], "w8": ["-DQ1_STEP_MINWAVES=8"],
+            "wholewave_w6": ["-DQ1_DELTA_PER_LANE=0", "-DQ1_STEP_MINWAVES=6"]}
+RUNS = [("base", {}), ("wholewave", {}), ("base", {}), ("wholewave", {}), ("w6", {}), ("w8", {}), ("wholewave_w6", {}), ("base", {"Q1ENV_BLOCK": "256"})]
 
 CODE = r'''
 import sys, json, torch

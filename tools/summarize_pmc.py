@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Summarise tools/profile_round3.sh: per mode / batch size the primary kernel's rocprofv3 statistics and hardware counters per
+"""Summarise tools/profile_round.sh (round 3: profile_round3.sh): per mode / batch size the primary kernel's rocprofv3 statistics and hardware counters per
 launch, as text (stdout) and as <out>/pmc.json - the file bench.py reads as profiles/pmc.json for `roofline.traffic` (HBM bytes) and
 the VALU-issue roofline of the register-resident kernels.
 
@@ -18,7 +18,9 @@ import sys
 from collections import defaultdict
 
 out = sys.argv[1]
-PRIMARY = {"rollout": "rollout_kernel", "step": "step_kernel", "server": "tick_pair_lds_kernel"}
+PRIMARY = {"rollout": "rollout_kernel", "rollout_params": "rollout_kernel", "step": "step_kernel", "server": "tick_pair_lds_kernel"}
+TAG = os.path.basename(out.rstrip("/")).replace("prof_", "")
+build_ids = set()
 
 
 def first(pattern):
@@ -57,7 +59,8 @@ for d in sorted(glob.glob(os.path.join(out, "*_*"))):
     want = PRIMARY.get(mode)
     if not want:
         continue
-    e = {"envs": n, "source": f"profiles/{os.path.basename(out).replace('prof_', '')}_summary.txt (tools/profile_round3.sh: rocprofv3 --kernel-trace --stats and separate --pmc passes of `bench.py --mode {mode} --envs {n} --steps 1440 --warmup 720`)"}
+    bmode = "rollout --config params_yml" if mode == "rollout_params" else mode
+    e = {"envs": n, "source": f"profiles/{TAG}_summary.txt (tools/profile_round.sh: rocprofv3 --kernel-trace --stats and separate --pmc passes of `bench.py --mode {bmode} --envs {n} --steps 1440 --warmup 720`)"}
     kt = first(f"{key}/trace/**/*kernel_trace.csv")
     if kt:
         spans = []
@@ -75,6 +78,10 @@ for d in sorted(glob.glob(os.path.join(out, "*_*"))):
         b = json.load(open(os.path.join(out, f"{key}.bench_unprofiled.json")))
         e["event_us_per_tick_unprofiled"] = b["roofline"]["us_per_tick"]
         e["value_unprofiled"] = b["value"]
+        if b.get("lib_build_id"):                      # which build of the kernels these passes profiled (bench.py's staleness guard)
+            e["build_id"] = b["lib_build_id"]
+            e["lib_sha16"] = b.get("lib_sha16")
+            build_ids.add(b["lib_build_id"])
     except Exception:   # noqa: BLE001
         pass
     f, _ = counters(first(f"{key}/fetch/**/*counter_collection.csv"), want)
@@ -111,6 +118,8 @@ for d in sorted(glob.glob(os.path.join(out, "*_*"))):
 
 print(f"== {out}: primary kernel per bench.py mode / batch size (per launch; PMC passes are separate runs of the same command)")
 for key, e in res.items():
+    if key.startswith("_"):
+        continue
     n, T = e["envs"], e["ticks_per_launch"]
     print(f"-- {key}: {e.get('kernel', '?')}")
     if "avg_ns" in e:
@@ -160,4 +169,8 @@ if cal:
     res["_calibration"] = {str(g): {"fetch_x2_B_per_env": 2 * v.get("fetch", float("nan")) / g, "write_B_per_env": v.get("write", float("nan")) / g} for g, v in cal.items()}
 for e in res.values():
     e.pop("counters_raw", None) if isinstance(e, dict) and False else None
+if len(build_ids) == 1:
+    res["_build_id"] = build_ids.pop()
+elif build_ids:
+    print("WARNING: the passes profiled more than one build of the library:", sorted(build_ids))
 json.dump(res, open(os.path.join(out, "pmc.json"), "w"), indent=1)

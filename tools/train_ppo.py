@@ -42,7 +42,18 @@ ap.add_argument("--native", action="store_true", help="native learner step: gath
 ap.add_argument("--native-splits", type=int, default=32, help="workgroups per network of the split-K weight-gradient kernel")
 ap.add_argument("--save", default="", help="write the final policy weights (npz, RLlib fcnet naming) here")
 ap.add_argument("--discrete-yaw-steps", type=int, default=-1, help="Config.discrete_yaw_steps: the mouse becomes Discrete(2S+1) (a Categorical policy head)")
+ap.add_argument("--refcfg", action="store_true",
+                help="the REFERENCE's training configuration (VERDICT r3 item 5): data/params.yml trainer_config (lr 5e-6, train_batch_size 50 000, "
+                     "kl_target 0.0036, entropy 0.01, gamma 0.99, lambda 0.95, vf_clip 100) and env_config (params.yml:16-33), RLlib 0.8.4 PPO defaults "
+                     "for the rest (sgd_minibatch_size 128, num_sgd_iter 30, clip 0.3, kl_coeff 0.2), 4 workers x 100 envs = 400 envs x 125 ticks "
+                     "per iteration; overrides --envs / --horizon / --lr / --epochs / --minibatch / --entropy / --kl-target / --zero-start-prob")
+ap.add_argument("--log-every", type=int, default=5)
+ap.add_argument("--eval-every", type=int, default=0, help="every N iterations: 256 zero-start episodes of 720 ticks on a separate env, stochastic (the "
+                                                         "training metric's policy) and deterministic; 0 = only at the end")
 args = ap.parse_args()
+if args.refcfg:
+    args.envs, args.horizon, args.lr, args.epochs, args.minibatch = 400, 125, 5e-6, 30, 128
+    args.entropy, args.kl_target, args.zero_start_prob = 0.01, 0.0036, 0.01
 
 rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
 local = int(os.environ.get("LOCAL_RANK", 0)) % max(torch.cuda.device_count(), 1)
@@ -51,8 +62,12 @@ if world > 1:
     dist.init_process_group("nccl" if torch.cuda.device_count() >= world else "gloo")
 torch.manual_seed(args.seed)                                   # identical initial weights on every rank
 start, count = sharding.shard_range(args.envs, rank, world)
-cfg = Config(**{**Config.get_default().__dict__, "num_envs": count, "zero_start_prob": args.zero_start_prob,
-                "discrete_yaw_steps": args.discrete_yaw_steps})
+import bench
+if args.refcfg:
+    cfg = Config(num_envs=count, **bench.PARAMS_YML)           # data/params.yml:16-33
+else:
+    cfg = Config(**{**Config.get_default().__dict__, "num_envs": count, "zero_start_prob": args.zero_start_prob,
+                    "discrete_yaw_steps": args.discrete_yaw_steps})
 env = TensorVectorEnv(cfg, device=local, seed=args.seed + 1, env_index_base=start)
 pol = P.Q1Policy(discrete_yaw_steps=args.discrete_yaw_steps).cuda()
 fused = P.FusedPolicyForward(pol, env) if args.fused_policy else None
@@ -62,6 +77,22 @@ lrn = ppo.PPOLearner(pol, float(cfg.action_range), lr=args.lr, num_sgd_iter=args
                      discrete_yaw_steps=args.discrete_yaw_steps, autocast_dtype=torch.bfloat16 if args.learner_bf16 else None, fused_adam=not args.no_fused_adam,
                      native=args.native, native_splits=args.native_splits)
 log = []
+
+
+def zero_start_eval(n_eval=256):
+    """Mean y distance (sum of the 720 rewards) of n_eval zero-start episodes under the current policy on a fresh env: stochastic
+    (the policy the reference's zero_start_total_reward_mean averages over, train.py:54-57) and deterministic (what mkdemo plays back)."""
+    base = bench.PARAMS_YML if args.refcfg else {**Config.get_default().__dict__, "discrete_yaw_steps": args.discrete_yaw_steps}
+    ec = Config(**{**{k: v for k, v in base.items() if k != "num_envs"}, "num_envs": n_eval, "zero_start_prob": 1.0})
+    out = {}
+    for det in (False, True):
+        ee = TensorVectorEnv(ec, device=local, seed=4242 + len(log))
+        tr_ = GpuSampler(ee, pol, horizon=720).collect(deterministic=det)
+        out["eval_det" if det else "eval_stochastic"] = float(tr_["reward"].double().sum(0).mean())
+        ee.close()
+    return out
+
+
 t0 = time.time()
 prev = smp.stats
 for it in range(args.iters):
@@ -82,8 +113,11 @@ for it in range(args.iters):
     row = {"iter": it, "steps": (it + 1) * args.envs * args.horizon, "zero_start_total_reward_mean": zmean, "episode_reward_mean": emean,
            "kl": st["kl"], "entropy": st["entropy"], "vf_loss": st["vf_loss"], "kl_coeff": st["kl_coeff"],
            "sample_s": t_sample, "iter_s": t_iter, "wall_s": time.time() - t0}
+    row.update({k: st[k] for k in ("grad_saturated_pi", "grad_saturated_vf", "grad_max_abs_pi", "grad_max_abs_vf") if k in st})
+    if args.eval_every and (it % args.eval_every == 0 or it == args.iters - 1):
+        row.update(zero_start_eval())
     log.append(row)
-    if rank == 0 and (it % 5 == 0 or it == args.iters - 1):
+    if rank == 0 and (it % args.log_every == 0 or it == args.iters - 1 or "eval_det" in row):
         print(json.dumps(row), flush=True)
 
 # deterministic evaluation: zero-start, 720 ticks, argmax keys / squashed mean (what mkdemo would play back)
