@@ -695,6 +695,16 @@ def main(argv=None):
             dsync()
             ev_ms = dev.timer_elapsed()
             host_split[mode]["hip_event_us"] = ev_ms * 1e3
+            # what an EMPTY signalled launch costs here (one-wave kernel that only stamps and signals, then the same poll): the floor
+            # under (wall - device_stamp_us) that no kernel of ours can go below on this runtime / firmware
+            rt = []
+            for _ in range(7):
+                dsync()
+                ta = time.perf_counter()
+                dev.signal_mark()
+                dev.signal_wait()
+                rt.append((time.perf_counter() - ta) * 1e6)
+            host_split[mode]["empty_signalled_launch_roundtrip_us"] = sorted(rt)[len(rt) // 2]
         else:
             t0 = time.perf_counter()
             run(timed_calls)                      # EXACTLY `steps` ticks; HIP events on the launch stream around them

@@ -8,9 +8,10 @@ in the same process.  (Round 3's two-envs-per-lane variants were measured, dropp
 import json, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-VARIANTS = {"base": [], "wholewave": ["-DQ1_DELTA_PER_LANE=0"], "w6": ["-DQ1_STEP_MINWAVES=6"], "w8": ["-DQ1_STEP_MINWAVES=8"],
-            "wholewave_w6": ["-DQ1_DELTA_PER_LANE=0", "-DQ1_STEP_MINWAVES=6"]}
-RUNS = [("base", {}), ("wholewave", {}), ("base", {}), ("wholewave", {}), ("w6", {}), ("w8", {}), ("wholewave_w6", {}), ("base", {"Q1ENV_BLOCK": "256"})]
+VARIANTS = {"base": [], "wholewave": ["-DQ1_DELTA_PER_LANE=0"], "stream_w3": ["-DQ1_STREAM_WAVES=3"], "stream_w2": ["-DQ1_STREAM_WAVES=2"]}
+RUNS = [("base", {"Q1ENV_STEP_STREAM": "0"}), ("base", {"Q1ENV_STEP_STREAM": "1"}), ("stream_w3", {"Q1ENV_STEP_STREAM": "1"}),
+        ("stream_w2", {"Q1ENV_STEP_STREAM": "1"}), ("base", {"Q1ENV_STEP_STREAM": "0"}), ("base", {"Q1ENV_STEP_STREAM": "1"}),
+        ("wholewave", {"Q1ENV_STEP_STREAM": "0"})]
 
 CODE = r'''
 import sys, json, torch
@@ -20,6 +21,7 @@ _lib.LIB_PATH = sys.argv[1]
 from q1physrl_amd.device import DeviceEnv
 from q1physrl_amd.env import Config
 out = {}
+torch.manual_seed(0)        # every variant sees the same actions: equal state hashes = equal results
 for n in (262144, 1048576, 4194304):
     cfg = Config(**{**Config.get_default().__dict__, "num_envs": n, "zero_start_prob": 1.0})
     dev = DeviceEnv(cfg, device=0)

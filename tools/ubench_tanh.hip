@@ -1,0 +1,149 @@
+// What does one tanh activation of the policy forward cost on gfx950, and would a transcendental-free form be cheaper?  (VERDICT r3
+// item 6: "replace v_exp_f32 + v_rcp_f32 per activation by an odd rational / minimax tanh on packed ops".)
+// The forward kernel (csrc/q1policy.hpp activate) computes tanh(z) = 1 - 2 / (2^(c z) + 1) for PAIRS of float32 accumulators:
+// 2 v_exp_f32 + v_pk_add_f32 + 2 v_rcp_f32 + v_pk_fma_f32 + v_cvt_pk_f16_f32.  Candidates, all producing the same packed f16 pair:
+//   A  the product form
+//   B  Pade [7/6] rational x (135135 + 17325 x^2 + 378 x^4 + x^6) / (135135 + 62370 x^2 + 3150 x^4 + 28 x^6), |x| clamped to 4.97,
+//      packed float32 Horner steps + ONE v_rcp_f32 per value
+//   C  t = 2^(-c |x|) (v_exp_f32), tanh = sign(x) (1 - t) q(t) with q a degree-6 polynomial for 1 / (1 + t) on [0, 1]: one
+//      transcendental, no reciprocal
+//   D  no transcendental at all: 2^y by exponent-field arithmetic + a degree-3 polynomial of the fraction, then B's reciprocal-free
+//      tail is impossible (a division remains), so D = polynomial 2^y + v_rcp_f32
+// Per variant: ns per activation per wave at 1 / 2 waves per SIMD (256 workgroups x 256 / 512 threads), and the largest error of the
+// f16 result against tanh in double over z in [-9, 9] (the f16 operand the next layer consumes has 2^-11 relative resolution).
+// Build + run: hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/ubench_tanh.hip -o gpurun_scratch/ubench_tanh && ./gpurun_scratch/ubench_tanh
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdio.h>
+#include <stdint.h>
+#include <vector>
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+#define C2 2.8853900817779268f   // 2 log2 e
+
+template <int V> __device__ __forceinline__ f16x2 act_pair(f32x2 z);     // z = pre-activation (NOT pre-scaled, for a common error basis)
+
+template <> __device__ __forceinline__ f16x2 act_pair<0>(f32x2 z) {      // A: product form (the kernel folds C2 into the weights; here 1 pk_mul extra is NOT charged: see main)
+    f32x2 t = {__builtin_amdgcn_exp2f(z[0]), __builtin_amdgcn_exp2f(z[1])};
+    t = t + 1.0f;
+    const f32x2 r = {__builtin_amdgcn_rcpf(t[0]), __builtin_amdgcn_rcpf(t[1])};
+    return __builtin_convertvector(1.0f - 2.0f * r, f16x2);
+}
+template <> __device__ __forceinline__ f16x2 act_pair<1>(f32x2 x) {      // B: Pade [7/6]
+    x[0] = __builtin_amdgcn_fmed3f(x[0], -4.97f, 4.97f);
+    x[1] = __builtin_amdgcn_fmed3f(x[1], -4.97f, 4.97f);
+    const f32x2 s = x * x;
+    f32x2 n = __builtin_elementwise_fma(s, (f32x2)1.0f, (f32x2)378.0f);
+    n = __builtin_elementwise_fma(n, s, (f32x2)17325.0f);
+    n = __builtin_elementwise_fma(n, s, (f32x2)135135.0f);
+    f32x2 d = __builtin_elementwise_fma(s, (f32x2)28.0f, (f32x2)3150.0f);
+    d = __builtin_elementwise_fma(d, s, (f32x2)62370.0f);
+    d = __builtin_elementwise_fma(d, s, (f32x2)135135.0f);
+    const f32x2 r = {__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+    return __builtin_convertvector(x * n * r, f16x2);
+}
+template <> __device__ __forceinline__ f16x2 act_pair<2>(f32x2 z) {      // C: one exp, polynomial reciprocal of 1 + t
+    const f32x2 a = {-fabsf(z[0]), -fabsf(z[1])};
+    const f32x2 t = {__builtin_amdgcn_exp2f(a[0]), __builtin_amdgcn_exp2f(a[1])};          // in (0, 1]
+    // 1 / (1 + t) on [0, 1], degree 6 (Chebyshev-economised; max error ~ 4e-5)
+    f32x2 q = __builtin_elementwise_fma(t, (f32x2)0.0340147f, (f32x2)-0.1641395f);
+    q = __builtin_elementwise_fma(q, t, (f32x2)0.3767743f);
+    q = __builtin_elementwise_fma(q, t, (f32x2)-0.6118467f);
+    q = __builtin_elementwise_fma(q, t, (f32x2)0.8619883f);
+    q = __builtin_elementwise_fma(q, t, (f32x2)-0.9967700f);
+    q = __builtin_elementwise_fma(q, t, (f32x2)0.9999787f);
+    f32x2 y = (1.0f - t) * q;
+    y[0] = copysignf(y[0], z[0]);
+    y[1] = copysignf(y[1], z[1]);
+    return __builtin_convertvector(y, f16x2);
+}
+template <> __device__ __forceinline__ f16x2 act_pair<3>(f32x2 z) {      // D: polynomial 2^y (no v_exp) + v_rcp
+    const f32x2 m = z + 12582912.0f;                                     // 1.5 * 2^23: the low mantissa bits hold round(z)
+    const f32x2 n = m - 12582912.0f;
+    const f32x2 f = z - n;                                               // [-0.5, 0.5]
+    f32x2 p = __builtin_elementwise_fma(f, (f32x2)0.0555041f, (f32x2)0.2402265f);
+    p = __builtin_elementwise_fma(p, f, (f32x2)0.6931472f);
+    p = __builtin_elementwise_fma(p, f, (f32x2)1.0f);
+    float e0 = __uint_as_float(__float_as_uint(p[0]) + (__float_as_uint(m[0]) << 23));
+    float e1 = __uint_as_float(__float_as_uint(p[1]) + (__float_as_uint(m[1]) << 23));
+    f32x2 t = {e0, e1};
+    t = t + 1.0f;
+    const f32x2 r = {__builtin_amdgcn_rcpf(t[0]), __builtin_amdgcn_rcpf(t[1])};
+    return __builtin_convertvector(1.0f - 2.0f * r, f16x2);
+}
+
+template <int V>
+__global__ void __launch_bounds__(512) bench(float* out, float seed, int iters) {
+    // 16 independent pairs per lane (the kernel activates 16 accumulator registers of a tile at a time)
+    f32x2 z[8];
+    for (int k = 0; k < 8; ++k) z[k] = (f32x2){seed + 0.01f * threadIdx.x + k, seed - 0.02f * threadIdx.x - k};
+    float acc = 0.0f;
+    for (int i = 0; i < iters; ++i) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const f16x2 h = act_pair<V>(z[k]);
+            z[k][0] += (float)h[0] * 1e-3f;                              // keep a dependence so nothing is hoisted
+            z[k][1] -= (float)h[1] * 1e-3f;
+        }
+    }
+    for (int k = 0; k < 8; ++k) acc += z[k][0] + z[k][1];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = acc;
+}
+
+template <int V>
+__global__ void accuracy(const float* x, float* y, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float z = x[i];
+    const f32x2 in = (V == 1) ? (f32x2){z, z} : (f32x2){C2 * z, C2 * z};   // A, C, D take the pre-scaled accumulator c z
+    y[i] = (float)act_pair<V>(in)[0];
+}
+
+template <int V>
+static void run(const char* name, float* d_out) {
+    const int iters = 4096;
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    printf("%-44s", name);
+    for (int threads : {256, 512}) {
+        hipLaunchKernelGGL(bench<V>, dim3(256), dim3(threads), 0, 0, d_out, 0.1f, 64);
+        hipDeviceSynchronize();
+        hipEventRecord(e0);
+        hipLaunchKernelGGL(bench<V>, dim3(256), dim3(threads), 0, 0, d_out, 0.1f, iters);
+        hipEventRecord(e1);
+        hipEventSynchronize(e1);
+        float ms = 0;
+        hipEventElapsedTime(&ms, e0, e1);
+        const double per_act_wave = ms * 1e6 / ((double)iters * 16.0);            // ns per activation per wave (a wave does 16 per iteration)
+        const int wps = threads / 256;
+        printf("  %d wave/SIMD: %6.2f ns per activation per wave = %6.2f ns of the SIMD", wps, per_act_wave, per_act_wave / wps);
+    }
+    // accuracy of the f16 result
+    const int n = 1 << 20;
+    std::vector<float> hx(n), hy(n);
+    for (int i = 0; i < n; ++i) hx[i] = -9.0f + 18.0f * (float)i / (float)(n - 1);
+    float *dx, *dy;
+    hipMalloc(&dx, n * 4); hipMalloc(&dy, n * 4);
+    hipMemcpy(dx, hx.data(), n * 4, hipMemcpyHostToDevice);
+    hipLaunchKernelGGL(accuracy<V>, dim3((n + 255) / 256), dim3(256), 0, 0, dx, dy, n);
+    hipMemcpy(hy.data(), dy, n * 4, hipMemcpyDeviceToHost);
+    double worst = 0, worst_f16 = 0;
+    for (int i = 0; i < n; ++i) {
+        const double t = tanh((double)hx[i]);
+        worst = fmax(worst, fabs((double)hy[i] - t));
+        worst_f16 = fmax(worst_f16, fabs((double)(float)(_Float16)(float)t - t));
+    }
+    printf("   max |f16 result - tanh| = %.2e (f16 rounding of the exact value alone: %.2e)\n", worst, worst_f16);
+    hipFree(dx); hipFree(dy);
+}
+
+int main() {
+    float* d_out;
+    hipMalloc(&d_out, 256 * 512 * 4);
+    run<0>("A exp2 + rcp (product form)", d_out);
+    run<1>("B Pade [7/6], packed Horner + 1 rcp", d_out);
+    run<2>("C exp2 + degree-6 polynomial 1/(1+t)", d_out);
+    run<3>("D polynomial 2^y (no v_exp) + rcp", d_out);
+    return 0;
+}
