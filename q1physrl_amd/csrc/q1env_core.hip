@@ -623,7 +623,16 @@ int q1env_create(const q1env_config* cfg, int device, void* stream, q1env_t** ou
     h->device = device;
     if (stream) { h->stream = (hipStream_t)stream; h->own_stream = false; }
     else {
-        hipError_t e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
+        // (Q1ENV_STREAM_PRIORITY=high: the handle's own stream on a high-priority hardware queue - measurement knob of bench.py's A/B)
+        const char* pr = getenv("Q1ENV_STREAM_PRIORITY");
+        hipError_t e;
+        if (pr && pr[0] == 'h') {
+            int lo = 0, hi = 0;
+            (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+            e = hipStreamCreateWithPriority(&h->stream, hipStreamNonBlocking, hi);
+        } else {
+            e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
+        }
         if (e != hipSuccess) { delete h; return fail(Q1ENV_ERR_HIP, std::string("hipStreamCreate: ") + hipGetErrorString(e)); }
         h->own_stream = true;
     }

@@ -97,6 +97,18 @@ int main(void) {
         const double ey = fabs(yaw[i] - os.yaw[i]) / fmax(fabs(os.yaw[i]), 1.0);
         if (ey > worst) worst = ey;
     }
+    /* ABI v4: the kernel-written completion signal and the build id, from plain C */
+    {
+        uint64_t t_start = 0, t_end = 0;
+        double hz = 0.0;
+        CHECK(q1env_signal_mark(env));
+        CHECK(q1env_signal_wait(env, 5.0));
+        CHECK(q1env_signal_read(env, &t_start, &t_end, &hz));
+        if (!(hz > 0.0) || t_end == 0) { fprintf(stderr, "completion signal: no stamp (hz %g, end %llu)\n", hz, (unsigned long long)t_end); return 1; }
+        const char *bid = q1env_build_id();
+        if (!bid || strlen(bid) != 16) { fprintf(stderr, "q1env_build_id: %s\n", bid ? bid : "(null)"); return 1; }
+        printf("c_abi_client: completion signal ok (device clock %.0f Hz), library build id %s\n", hz, bid);
+    }
     CHECK(q1env_destroy(env));
     const double frac = (double)same / (3.0 * n);
     printf("c_abi_client: %d envs x %d ticks, max rel err %.3e, vel bit-identical %.5f\n", n, ticks, worst, frac);

@@ -68,3 +68,13 @@ def test_two_ranks_oversubscribed_on_one_device():
     # the --steps-independent figures ride along in the multi-rank line too (slowest rank's event time)
     assert set(d["steady_state_720_ticks"]) == {"rollout", "step", "server"} and all("us_per_tick" in v for v in d["steady_state_720_ticks"].values())
     assert d["config"]["total_envs"] == 131072 and d["cpu_baseline"]["value"] is None and "N=1" in d["cpu_baseline"]["sample"]
+
+
+def test_configs2_line_params_yml_with_in_kernel_reset():
+    """BASELINE configs[2] as a bench line: params.yml's Config, random starts, finished episodes reset inside the
+    rollout kernel - the SPEC instantiation with HAS_RESET = true; 2 000 ticks cross the action tensor's wrap and many episode ends."""
+    d = _run(["--gpus", "1", "--steps", "2000", "--warmup", "100", "--envs", "8192", "--config", "params_yml", "--no-secondary"])
+    assert d["mode"] == "rollout" and "configs[2]" in d["config"]["workload"] and "reset IN-KERNEL" in d["config"]["workload"]
+    ro = d["roofline"]
+    assert ro["kernel"].startswith("rollout_kernel<float, true, 2, true, 1, false>") and ro["bound"] == "hbm" and 0 < ro["frac"] <= 1.0
+    assert d["cpu_baseline"] is None and d["value"] > 1e8
