@@ -16,6 +16,10 @@ using namespace q1;
 // LDS is used for one thing only: transposing the wave's 64 float32 observation rows so they leave as 16-B-per-lane
 // coalesced stores (write_obs_wave_f32).
 //   SPEC: default Config structure baked in (straight-line tick);  FMT: action layout, or FMT_RUNTIME.
+// Large batches (round 4, measured and dropped - profiles/r4_step_large.txt): a software-pipelined streaming form of this kernel (a fixed
+// grid of one-wave workgroups walking 64-env tiles grid-stride, the NEXT tile's 85-B state + action requested before the current tile is
+// computed; 128 VGPRs, 4 waves per SIMD) was bit-identical and no faster - 7.8 vs 7.2 us per tick at 262 144 envs, 35.4-35.6 vs 33.6-35.2
+// at 1 M, 135.6-147.7 vs 132.8-143.0 at 4 M: the plain kernel's five resident waves per SIMD already keep the memory system's queues full.
 #ifndef Q1_STEP_MINWAVES            // (measurement knobs: minimum waves per SIMD the register allocation must leave room for)
 #define Q1_STEP_MINWAVES 1
 #endif
@@ -51,52 +55,6 @@ step_kernel(float* pvx, float* pvy, float* pvz, double* ppx, double* ppy, double
     if (reward) __builtin_nontemporal_store(o.reward, reward + i);
     if (done) __builtin_nontemporal_store((uint8_t)(o.done ? 1 : 0), done + i);
     if (zero_start) zero_start[i] = (e.flags & FLAG_ZERO_START) ? 1 : 0;
-}
-
-// The same tick for LARGE batches (>= STREAM_MIN_ENVS), software-pipelined over tiles of 64 envs: a fixed grid of one-wave workgroups
-// walks the batch grid-stride, and the 85-B state + 5-B action of a wave's NEXT tile are requested before the current tile is computed.
-// The per-tick kernel is memory-bound there (profiles/r3_step_large_counters.txt) but keeps only five waves per SIMD resident, each
-// with its loads in flight for ~40 % of its life: this form has every resident wave hold one tile's loads in flight ALL the time
-// (Little's law: 6 TB/s x ~2 us of latency wants ~12 MB in flight; 4 096 waves x 5.4 KB = 22 MB).  Full tiles only (n % 64 == 0).
-#ifndef Q1_STREAM_WAVES              // (measurement knob: waves per SIMD the register allocation of the streaming form leaves room for)
-#define Q1_STREAM_WAVES 4
-#endif
-template <bool SPEC>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(Q1_STREAM_WAVES)))
-step_stream_kernel(Params p, StatePtrs s, const uint8_t* __restrict__ keys_in, const float* __restrict__ mouse_in,
-                   float* __restrict__ obs, float* __restrict__ reward, uint8_t* __restrict__ done) {
-    __shared__ float slab[384];
-    const uint32_t n = (uint32_t)p.n, lane = threadIdx.x;
-    const uint32_t ntiles = n >> 6, stride = gridDim.x;
-    uint32_t tile = blockIdx.x;
-    if (tile >= ntiles) return;
-    Env nxt;
-    uint32_t i = (tile << 6) + lane;
-    load_env(s, n, i, nxt);
-    uint32_t kraw = keys_in[i];
-    float mraw = mouse_in[i];
-    for (;;) {
-        Env e = nxt;
-        const Env loaded = e;
-        const uint32_t keys = kraw & 0xFu;
-        const double yaw_act = (double)mraw;
-        const uint32_t i_cur = i;
-        tile += stride;
-        const bool more = tile < ntiles;                        // wave-uniform
-        if (more) {
-            i = (tile << 6) + lane;
-            load_env(s, n, i, nxt);
-            kraw = keys_in[i];
-            mraw = mouse_in[i];
-        }
-        TickOut<float> o;
-        tick<float, SPEC>(p, e, keys, yaw_act, o);
-        store_env_delta(s, n, i_cur, e, loaded);
-        if (obs) write_obs_wave_f32_nt(obs, i_cur - lane, lane, o.obs, slab);
-        if (reward) __builtin_nontemporal_store(o.reward, reward + i_cur);
-        if (done) __builtin_nontemporal_store((uint8_t)(o.done ? 1 : 0), done + i_cur);
-        if (!more) break;
-    }
 }
 
 // One tick WITH in-kernel reset of the envs whose episode ended on it (the "auto-reset" vector-env convention of
@@ -623,16 +581,8 @@ int q1env_create(const q1env_config* cfg, int device, void* stream, q1env_t** ou
     h->device = device;
     if (stream) { h->stream = (hipStream_t)stream; h->own_stream = false; }
     else {
-        // (Q1ENV_STREAM_PRIORITY=high: the handle's own stream on a high-priority hardware queue - measurement knob of bench.py's A/B)
-        const char* pr = getenv("Q1ENV_STREAM_PRIORITY");
-        hipError_t e;
-        if (pr && pr[0] == 'h') {
-            int lo = 0, hi = 0;
-            (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
-            e = hipStreamCreateWithPriority(&h->stream, hipStreamNonBlocking, hi);
-        } else {
-            e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
-        }
+        // (a high-priority stream was A/B-tested for the 20-tick launch in round 4: no difference, profiles/r4_bench_driver_steps20.json)
+        hipError_t e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
         if (e != hipSuccess) { delete h; return fail(Q1ENV_ERR_HIP, std::string("hipStreamCreate: ") + hipGetErrorString(e)); }
         h->own_stream = true;
     }
@@ -707,7 +657,6 @@ int q1env_tick_count(const q1env_t* h, uint64_t* out) {
     return Q1ENV_OK;
 }
 
-constexpr int STREAM_MIN_ENVS = 524288;          // from here on the per-tick kernel runs in its streaming form (see step_stream_kernel)
 static void launch_step(q1env* h, int fmt, const void* a, const void* b, int obs_format, void* obs,
                         float* reward, uint8_t* done, uint8_t* zs) {
     const int blk = block_for(h->p.n);
@@ -716,20 +665,6 @@ static void launch_step(q1env* h, int fmt, const void* a, const void* b, int obs
 #define Q1_LAUNCH_STEP(OT, SP, FM) \
     hipLaunchKernelGGL((step_kernel<OT, SP, FM>), g, bs, 0, h->stream, h->st.vx, h->st.vy, h->st.vz, h->st.px, h->st.py, h->st.z, h->st.yaw, \
                        h->st.trem, h->p, h->st, fmt, a, b, (OT*)obs, reward, done, zs)
-    // large batches: the software-pipelined streaming form (full 64-env tiles, packed actions, float32 rows; Q1ENV_STEP_STREAM=0 / 1
-    // forces it off / on at any size - measurement knob)
-    const char* stream_env = getenv("Q1ENV_STEP_STREAM");
-    const int stream_knob = stream_env ? atoi(stream_env) : -1;
-    const bool stream_ok = obs_format == Q1ENV_OBS_F32 && fmt == Q1ENV_ACT_PACKED && h->p.yaw_mode && (h->p.n % 64) == 0 && !zs && a && b;
-    if (stream_ok && (stream_knob == 1 || (stream_knob != 0 && h->p.n >= STREAM_MIN_ENVS))) {
-        const unsigned tiles = (unsigned)(h->p.n / 64), cap = (unsigned)h->num_cus * 4u * (unsigned)Q1_STREAM_WAVES;   // the resident waves of the chip
-        const dim3 gs(tiles < cap ? tiles : cap);
-        if (spec) hipLaunchKernelGGL(step_stream_kernel<true>, gs, dim3(64), 0, h->stream, h->p, h->st, (const uint8_t*)a, (const float*)b,
-                                     (float*)obs, reward, done);
-        else hipLaunchKernelGGL(step_stream_kernel<false>, gs, dim3(64), 0, h->stream, h->p, h->st, (const uint8_t*)a, (const float*)b,
-                                (float*)obs, reward, done);
-        return;
-    }
     if (obs_format == Q1ENV_OBS_F32) {
         if (spec && fmt == Q1ENV_ACT_PACKED) Q1_LAUNCH_STEP(float, true, FMT_PACKED);
         else if (spec && fmt == Q1ENV_ACT_F32_ROWS) Q1_LAUNCH_STEP(float, true, FMT_F32_ROWS);

@@ -527,37 +527,3 @@ def test_step_autoreset_many_equals_single_launches(n, use_graph):
         assert np.array_equal(sa[k], sb[k]), k
     assert outs[0][2].sum() > n and not torch.equal(outs[0][0][-1], outs[1][0][-1])     # episodes ended; the replays differ
     a.close(); b.close()
-
-
-@pytest.mark.parametrize("n", [4096, 64 * 1000])
-def test_streaming_step_kernel_equals_the_plain_one(n, monkeypatch):
-    """Large batches run the per-tick kernel in its software-pipelined streaming form (step_stream_kernel: grid-stride over 64-env tiles,
-    the next tile's state requested before the current one is computed).  Forced on at a small size (Q1ENV_STEP_STREAM=1) it must
-    reproduce the plain step_kernel bit for bit: state after 60 ticks, and every tick's obs / reward / done."""
-    import torch
-    from q1physrl_amd import _lib
-    from q1physrl_amd.device import DeviceEnv
-    from q1physrl_amd.env import Config
-    cfg = Config(**{**Config.get_default().__dict__, "num_envs": n, "zero_start_prob": 0.3})
-    d = torch.device("cuda", 0)
-    ticks = 60
-    g = torch.Generator(device="cpu").manual_seed(9)
-    keys = torch.randint(0, 16, (ticks, n), dtype=torch.uint8, generator=g).to(d)
-    mouse = ((torch.rand((ticks, n), generator=g) * 2 - 1) * float(cfg.action_range)).to(d)
-    res = []
-    for knob in ("0", "1"):
-        monkeypatch.setenv("Q1ENV_STEP_STREAM", knob)
-        dev = DeviceEnv(cfg, device=0)
-        dev.reset_philox_dev(5, 0, False)
-        obs = torch.zeros((ticks, n, 6), dtype=torch.float32, device=d)
-        rew = torch.zeros((ticks, n), dtype=torch.float32, device=d)
-        done = torch.full((ticks, n), 9, dtype=torch.uint8, device=d)
-        dev.step_many_dev(ticks, _lib.ACT_PACKED, keys.data_ptr(), mouse.data_ptr(), _lib.OBS_F32, obs.data_ptr(), rew.data_ptr(),
-                          done.data_ptr(), out_stride_ticks=1, use_graph=False)
-        dev.sync()
-        res.append((dev.get_state(), obs.cpu(), rew.cpu(), done.cpu()))
-        dev.close()
-    (s0, o0, r0, d0), (s1, o1, r1, d1) = res
-    for k in s0:
-        assert np.array_equal(s0[k], s1[k]), k
-    assert torch.equal(o0, o1) and torch.equal(r0.view(torch.int32), r1.view(torch.int32)) and torch.equal(d0, d1) and int(d1.max()) <= 1

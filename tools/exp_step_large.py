@@ -8,10 +8,9 @@ in the same process.  (Round 3's two-envs-per-lane variants were measured, dropp
 import json, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-VARIANTS = {"base": [], "wholewave": ["-DQ1_DELTA_PER_LANE=0"], "stream_w3": ["-DQ1_STREAM_WAVES=3"], "stream_w2": ["-DQ1_STREAM_WAVES=2"]}
-RUNS = [("base", {"Q1ENV_STEP_STREAM": "0"}), ("base", {"Q1ENV_STEP_STREAM": "1"}), ("stream_w3", {"Q1ENV_STEP_STREAM": "1"}),
-        ("stream_w2", {"Q1ENV_STEP_STREAM": "1"}), ("base", {"Q1ENV_STEP_STREAM": "0"}), ("base", {"Q1ENV_STEP_STREAM": "1"}),
-        ("wholewave", {"Q1ENV_STEP_STREAM": "0"})]
+VARIANTS = {"base": [], "wholewave": ["-DQ1_DELTA_PER_LANE=0"], "w6": ["-DQ1_STEP_MINWAVES=6"]}
+RUNS = [("base", {}), ("wholewave", {}), ("base", {}), ("wholewave", {}), ("w6", {}), ("base", {"Q1ENV_BLOCK": "256"})]
+# (round 4 also ran a software-pipelined streaming form of the kernel through this tool - profiles/r4_step_large.txt - and removed it)
 
 CODE = r'''
 import sys, json, torch
