@@ -459,8 +459,18 @@ struct Grads {
 __device__ __forceinline__ float partial_sum(const float* __restrict__ partial, int splits, uint32_t p, uint32_t ia, uint32_t cb) {
     const uint32_t h = (ia >> 2) & 1u, r = (ia & 3u) + 4u * (ia >> 3);
     const size_t off = ((size_t)p * 16u + r) * 64u + cb + 32u * h;
+    // eight loads in flight per thread, summed in split order (round 4: the one-load-at-a-time loop spent 22 k of its 23 k cycles per
+    // wave waiting - profiles/r3_learner_counters.txt - in the reduction AND in the fused Adam kernel; the sum's order is unchanged)
     float s = 0.0f;
-    for (int k = 0; k < splits; ++k) s += partial[(size_t)k * PARTIAL_FLOATS + off];
+    int k = 0;
+    for (; k + 8 <= splits; k += 8) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = partial[(size_t)(k + j) * PARTIAL_FLOATS + off];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s += v[j];
+    }
+    for (; k < splits; ++k) s += partial[(size_t)k * PARTIAL_FLOATS + off];
     return s;
 }
 

@@ -54,6 +54,7 @@ args = ap.parse_args()
 if args.refcfg:
     args.envs, args.horizon, args.lr, args.epochs, args.minibatch = 400, 125, 5e-6, 30, 128
     args.entropy, args.kl_target, args.zero_start_prob = 0.01, 0.0036, 0.01
+    args.native_splits = min(args.native_splits, 4)            # a 128-sample minibatch is 4 tiles: more split-K workgroups would only add partial sums
 
 rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
 local = int(os.environ.get("LOCAL_RANK", 0)) % max(torch.cuda.device_count(), 1)
