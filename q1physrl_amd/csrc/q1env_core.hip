@@ -465,6 +465,9 @@ static int make_params(const q1env_config& c, Params& p, std::string& why) {
     return 0;
 }
 
+// (Round 4 measured a skew between consecutive arrays - with power-of-two batch sizes every array starts at the same offset modulo any
+// power of two - of 256 B, 4 352 B and 66 304 B: no effect at 262 144 / 1 M / 4 M envs, profiles/r4_exp_skew.txt; the memory system
+// hashes addresses onto its channels.)
 void carve_into(void* arena, size_t n, StatePtrs& st) {
     char* base = (char*)arena;
     size_t off = 0;

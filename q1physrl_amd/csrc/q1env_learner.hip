@@ -55,7 +55,7 @@ Ws carve_ws(void* base, int64_t mb, int out_pi, int splits) {
         n.h1T = (q1learn::f16x8*)take(act); n.h2T = (q1learn::f16x8*)take(act);
         n.dz2N = (q1learn::f16x8*)take(act); n.dz1N = (q1learn::f16x8*)take(act); n.h1N = (q1learn::f16x8*)take(act); n.h2N = (q1learn::f16x8*)take(act);
         n.xN = (q1learn::f16x8*)take(tiles * 128u * 16u); n.dyN = (q1learn::f16x8*)take(tiles * 128u * 16u);
-        n.partial = (float*)take((size_t)splits * q1learn::PARTIAL_FLOATS * 4u);
+        n.partial = (float*)take((size_t)splits * q1learn::PARTIAL_STRIDE * 4u);
     }
     w.logits = (float*)take((size_t)mb * out_pi * 4u); w.value = (float*)take((size_t)mb * 4u);
     w.dlogits = (float*)take((size_t)mb * out_pi * 4u); w.dvalue = (float*)take((size_t)mb * 4u);

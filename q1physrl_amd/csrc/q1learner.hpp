@@ -60,6 +60,7 @@ constexpr size_t LDS_BWD = LDS_W2T + LDS_W3T;                 // 155648 <= 16384
 //   p = 88          dY x [x | 1]: column 6 = db3
 constexpr int WG_PRODUCTS = 89;
 constexpr size_t PARTIAL_FLOATS = (size_t)WG_PRODUCTS * 1024u;
+constexpr size_t PARTIAL_STRIDE = PARTIAL_FLOATS;    // (round 4: 256 B of padding between the splits - their 356 KB stride is a multiple of 4 KiB - changed nothing)
 
 __device__ __forceinline__ uint32_t sigma(uint32_t c) { return (c & ~0xCu) | ((c & 4u) << 1) | ((c & 8u) >> 1); }   // swap bits 2 and 3
 
@@ -351,7 +352,7 @@ learner_backward_kernel(int n, const float* __restrict__ obs, const int64_t* __r
 // ------------------------------------------------------------------------------------------------------------------ weight gradients
 struct WgNet {
     const f16x8* dz2N; const f16x8* dz1N; const f16x8* h1N; const f16x8* h2N; const f16x8* xN; const f16x8* dyN;
-    float* partial;           // float[splits][PARTIAL_FLOATS]
+    float* partial;           // float[splits][PARTIAL_STRIDE]
 };
 
 // One workgroup = four waves = four of the eight 32-unit row tiles of the gradient side (blockIdx.z picks the half); it owns a contiguous
@@ -433,7 +434,7 @@ learner_wgrad_kernel(int n, WgNet net_a, WgNet net_b, int splits) {
     for (int k = 0; k < 4; ++k) aW2[k] = zero16;
     if (khalf == 0) wg_loop<0>(net, t_begin, t_end, lane, w, aW2, aX, aY);
     else wg_loop<1>(net, t_begin, t_end, lane, w, aW2, aX, aY);
-    float* out = net.partial + (size_t)split * PARTIAL_FLOATS;
+    float* out = net.partial + (size_t)split * PARTIAL_STRIDE;
     auto put = [&](uint32_t p, const f32x16& a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) out[((size_t)p * 16u + (uint32_t)r) * 64u + lane] = a[r];
@@ -459,18 +460,11 @@ struct Grads {
 __device__ __forceinline__ float partial_sum(const float* __restrict__ partial, int splits, uint32_t p, uint32_t ia, uint32_t cb) {
     const uint32_t h = (ia >> 2) & 1u, r = (ia & 3u) + 4u * (ia >> 3);
     const size_t off = ((size_t)p * 16u + r) * 64u + cb + 32u * h;
-    // eight loads in flight per thread, summed in split order (round 4: the one-load-at-a-time loop spent 22 k of its 23 k cycles per
-    // wave waiting - profiles/r3_learner_counters.txt - in the reduction AND in the fused Adam kernel; the sum's order is unchanged)
+    // (round 4: 8 and 32 of these loads in flight per thread instead of one changed neither this kernel's 13 us nor the fused Adam
+    // kernel's 15 us - profiles/r4_learner_step_kernel_stats.txt; the simple loop stays)
     float s = 0.0f;
     int k = 0;
-    for (; k + 8 <= splits; k += 8) {
-        float v[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = partial[(size_t)(k + j) * PARTIAL_FLOATS + off];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) s += v[j];
-    }
-    for (; k < splits; ++k) s += partial[(size_t)k * PARTIAL_FLOATS + off];
+    for (; k < splits; ++k) s += partial[(size_t)k * PARTIAL_STRIDE + off];
     return s;
 }
 

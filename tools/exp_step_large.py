@@ -10,7 +10,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 VARIANTS = {"base": [], "wholewave": ["-DQ1_DELTA_PER_LANE=0"], "w6": ["-DQ1_STEP_MINWAVES=6"]}
 RUNS = [("base", {}), ("wholewave", {}), ("base", {}), ("wholewave", {}), ("w6", {}), ("base", {"Q1ENV_BLOCK": "256"})]
-# (round 4 also ran a software-pipelined streaming form of the kernel through this tool - profiles/r4_step_large.txt - and removed it)
+# (round 4 also ran through this tool, and removed: a software-pipelined streaming form of the kernel - profiles/r4_step_large.txt - and a
+# skew between the SoA state arrays - profiles/r4_exp_skew.txt)
 
 CODE = r'''
 import sys, json, torch
