@@ -164,7 +164,10 @@ int q1env_step_autoreset(q1env_t* env, int action_format, const void* act_a_dev,
 int q1env_step_autoreset_many(q1env_t* env, int ticks, int action_format, const void* act_a_dev, const void* act_b_dev, uint64_t seed,
                               uint64_t* counter_dev, float* obs_dev, float* reward_dev, uint8_t* done_dev, uint8_t* zero_start_dev,
                               int out_stride_ticks, int use_graph);
-/* Same with HOST pointers: stages H2D, steps, copies back, synchronises (the NumPy-compatible path). */
+/* Same with HOST pointers (the NumPy-compatible path): stages H2D, steps, copies back, synchronises.  (ABI v4) Up to 4 096 envs the
+ * staging is host-direct: the kernel reads the actions from and writes the results to host-coherent pinned memory itself and the call
+ * polls the completion signal - one launch, no copy commands, no stream synchronisation (Q1ENV_HOST_DIRECT=0 in the environment selects
+ * the staged form; results are identical).  q1env_reset_draws_host does the same. */
 int q1env_step_host(q1env_t* env, int action_format, const void* act_a, const void* act_b,
                     int obs_format, void* obs, float* reward, uint8_t* done, uint8_t* zero_start);
 /* `ticks` consecutive single-tick launches with tick-major inputs/outputs ([ticks][N]... ; outputs may be

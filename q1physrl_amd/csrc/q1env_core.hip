@@ -27,7 +27,7 @@ template <typename OBS_T, bool SPEC, int FMT>
 __global__ void __launch_bounds__(256, Q1_STEP_MINWAVES)
 step_kernel(float* pvx, float* pvy, float* pvz, double* ppx, double* ppy, double* pz, double* pyaw, double* ptrem,   // preloaded into SGPRs
             Params p, StatePtrs s, int fmt, const void* act_a, const void* act_b,
-            OBS_T* obs, float* reward, uint8_t* done, uint8_t* zero_start) {
+            OBS_T* obs, float* reward, uint8_t* done, uint8_t* zero_start, Signal sg) {
     // The eight leading pointers repeat s.vx .. s.trem: leading scalar kernel arguments are preloaded into SGPRs by the command
     // processor (-mllvm -amdgpu-kernarg-preload-count), so the first state loads do not wait for an s_load of the kernarg segment.
     __shared__ float slab[4][384];
@@ -55,6 +55,7 @@ step_kernel(float* pvx, float* pvy, float* pvz, double* ppx, double* ppy, double
     if (reward) __builtin_nontemporal_store(o.reward, reward + i);
     if (done) __builtin_nontemporal_store((uint8_t)(o.done ? 1 : 0), done + i);
     if (zero_start) zero_start[i] = (e.flags & FLAG_ZERO_START) ? 1 : 0;
+    signal_done_strict(sg);                            // (host-direct launches only: sg.sig is NULL otherwise)
 }
 
 // One tick WITH in-kernel reset of the envs whose episode ended on it (the "auto-reset" vector-env convention of
@@ -236,7 +237,7 @@ __global__ void __launch_bounds__(256) observe_kernel(Params p, StatePtrs s, OBS
 template <typename OBS_T>
 __global__ void __launch_bounds__(256)
 reset_draws_kernel(Params p, StatePtrs s, int count, const int32_t* idx, const uint8_t* zero_start,
-                   const double* yaw, const double* tm, const double* speed, const double* angle, OBS_T* obs) {
+                   const double* yaw, const double* tm, const double* speed, const double* angle, OBS_T* obs, Signal sg) {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= count) return;
     const uint32_t i = idx ? (uint32_t)idx[j] : (uint32_t)j;
@@ -248,6 +249,7 @@ reset_draws_kernel(Params p, StatePtrs s, int count, const int32_t* idx, const u
         observe<OBS_T>(p, e, o);
         write_obs<OBS_T>(obs, (size_t)j, o);
     }
+    signal_done_strict(sg);
 }
 
 template <typename OBS_T>
@@ -391,6 +393,45 @@ int ensure_signal(q1env* h) {
     h->sig_dev = (uint64_t*)dev;
     h->sig_host = (volatile uint64_t*)host;
     return 0;
+}
+
+// Host-direct block (q1env_host.hpp): grown on demand, mapped + coherent so that a kernel's loads / stores reach it over PCIe uncached.
+int ensure_direct(q1env* h, size_t bytes) {
+    if (bytes <= h->direct_bytes) return 0;
+    // the first use sizes the block for the largest host-direct batch (a step of HOST_DIRECT_MAX_ENVS envs needs <= 128 B per env), so that
+    // a reset_at (1 env) followed by a reset_many or a step never re-allocates - a re-allocation is a synchronisation + two runtime calls
+    if (bytes < 4096 * 128 + 8192) bytes = 4096 * 128 + 8192;
+    (void)hipStreamSynchronize(h->stream);            // a launch may still be reading / writing the old block
+    if (h->direct_host) (void)hipHostFree(h->direct_host);
+    h->direct_host = nullptr; h->direct_dev = nullptr; h->direct_bytes = 0;
+    void* host = nullptr;
+    const size_t want = align_up(bytes + bytes / 2, 4096);
+    HIP_TRY(hipHostMalloc(&host, want, hipHostMallocCoherent | hipHostMallocMapped));
+    void* dev = nullptr;
+    const hipError_t e = hipHostGetDevicePointer(&dev, host, 0);
+    if (e != hipSuccess) { (void)hipHostFree(host); return fail(Q1ENV_ERR_HIP, std::string("hipHostGetDevicePointer: ") + hipGetErrorString(e)); }
+    h->direct_host = (char*)host; h->direct_dev = (char*)dev; h->direct_bytes = want;
+    return 0;
+}
+
+// Batches up to this many envs take the host-direct form of q1env_step_host / q1env_reset_draws_host: the kernel reads the caller's
+// actions from, and writes obs / reward / done to, host-coherent pinned memory itself and says so with the completion signal - one
+// launch and a poll (~ 10 us) instead of a copy command each way and a stream synchronisation (~ 30 us; round 3's reset_at 36 us, gym
+// step 33 us).  This is the size RLlib actually runs the reference at (data/params.yml:28 num_envs 100).  Above it the DMA engine's
+// rate wins over PCIe loads issued by waves.  Q1ENV_HOST_DIRECT=0 turns it off (A/B).
+constexpr size_t HOST_DIRECT_MAX_ENVS = 4096;
+static bool host_direct_enabled() {
+    const char* e = getenv("Q1ENV_HOST_DIRECT");
+    return !(e && e[0] == '0');
+}
+static Signal direct_signal(q1env* h, size_t items) {
+    Signal sg{};
+    sg.sig = h->sig_dev;
+    sg.ticket = h->ticket_dev;
+    sg.seq = ++h->sig_seq;
+    sg.waves = (uint32_t)((items + 63) / 64);
+    sg.flags = 3u;
+    return sg;
 }
 
 // Poll the sequence word until the last requested signal has arrived.  No sleep, no yield: the caller asked for latency.
@@ -627,6 +668,7 @@ int q1env_destroy(q1env_t* h) {
     if (h->pin) (void)hipHostFree(h->pin);
     if (h->snap) (void)hipFree(h->snap);
     if (h->sig_host) (void)hipHostFree((void*)h->sig_host);
+    if (h->direct_host) (void)hipHostFree(h->direct_host);
     if (h->ticket_dev) (void)hipFree(h->ticket_dev);
     if (h->arena) (void)hipFree(h->arena);
     if (h->own_stream) (void)hipStreamDestroy(h->stream);
@@ -661,13 +703,13 @@ int q1env_tick_count(const q1env_t* h, uint64_t* out) {
 }
 
 static void launch_step(q1env* h, int fmt, const void* a, const void* b, int obs_format, void* obs,
-                        float* reward, uint8_t* done, uint8_t* zs) {
+                        float* reward, uint8_t* done, uint8_t* zs, const Signal& sg = Signal{}) {
     const int blk = block_for(h->p.n);
     const dim3 g = grid_for(h->p.n, blk), bs(blk);
     const bool spec = is_spec(h->p);
 #define Q1_LAUNCH_STEP(OT, SP, FM) \
     hipLaunchKernelGGL((step_kernel<OT, SP, FM>), g, bs, 0, h->stream, h->st.vx, h->st.vy, h->st.vz, h->st.px, h->st.py, h->st.z, h->st.yaw, \
-                       h->st.trem, h->p, h->st, fmt, a, b, (OT*)obs, reward, done, zs)
+                       h->st.trem, h->p, h->st, fmt, a, b, (OT*)obs, reward, done, zs, sg)
     if (obs_format == Q1ENV_OBS_F32) {
         if (spec && fmt == Q1ENV_ACT_PACKED) Q1_LAUNCH_STEP(float, true, FMT_PACKED);
         else if (spec && fmt == Q1ENV_ACT_F32_ROWS) Q1_LAUNCH_STEP(float, true, FMT_F32_ROWS);
@@ -788,6 +830,27 @@ int q1env_step_host(q1env_t* h, int fmt, const void* a, const void* b, int obs_f
     const size_t ba = align_up(na, 256), bb = align_up(n * 4, 256), bo = align_up(no, 256);
     const size_t br = align_up(n * 4, 256), bd = align_up(n, 256);
     const size_t in_bytes = ba + bb, out_bytes = bo + br + 2 * bd;
+    if (n <= HOST_DIRECT_MAX_ENVS && host_direct_enabled()) {
+        // host-direct: one launch, results written by the kernel into host-coherent memory, completion by signal
+        if (int r = ensure_direct(h, in_bytes + out_bytes)) return r;
+        if (int r = ensure_signal(h)) return r;
+        char* hp = h->direct_host;
+        char* dp = h->direct_dev;
+        memcpy(hp, a, na);
+        if (nb) memcpy(hp + ba, b, nb);
+        const Signal sg = direct_signal(h, n);
+        launch_step(h, fmt, dp, dp + ba, obs_format, obs ? dp + in_bytes : nullptr, reward ? (float*)(dp + in_bytes + bo) : nullptr,
+                    done ? (uint8_t*)(dp + in_bytes + bo + br) : nullptr, zs ? (uint8_t*)(dp + in_bytes + bo + br + bd) : nullptr, sg);
+        HIP_TRY(hipGetLastError());
+        h->tick_count += 1;
+        if (int r = signal_wait(h, 30.0)) return r;
+        const char* po = hp + in_bytes;
+        if (obs) memcpy(obs, po, no);
+        if (reward) memcpy(reward, po + bo, n * 4);
+        if (done) memcpy(done, po + bo + br, n);
+        if (zs) memcpy(zs, po + bo + br + bd, n);
+        return Q1ENV_OK;
+    }
     if (int r = ensure_stage(h, in_bytes + out_bytes)) return r;
     char* d = (char*)h->stage;
     void* d_a = d; void* d_b = d + ba; void* d_o = d + in_bytes;
@@ -1020,6 +1083,32 @@ int q1env_reset_draws_host(q1env_t* h, int64_t count, const int32_t* idx, const 
     const size_t bi = align_up(c * 4, 256), bz = align_up(c, 256), bd = align_up(c * 8, 256);
     const size_t no = c * 6 * (obs_format == Q1ENV_OBS_F32 ? 4 : 8), bo = align_up(no, 256);
     const size_t in_bytes = bi + bz + 4 * bd;
+    if (c <= HOST_DIRECT_MAX_ENVS && host_direct_enabled()) {
+        if (int r = ensure_direct(h, in_bytes + bo)) return r;
+        if (int r = ensure_signal(h)) return r;
+        char* hp = h->direct_host;
+        char* dp = h->direct_dev;
+        if (idx) memcpy(hp, idx, c * 4);
+        memcpy(hp + bi, zero_start, c);
+        memcpy(hp + bi + bz, yaw, c * 8);
+        memcpy(hp + bi + bz + bd, tm, c * 8);
+        memcpy(hp + bi + bz + 2 * bd, speed, c * 8);
+        memcpy(hp + bi + bz + 3 * bd, angle, c * 8);
+        const Signal sg = direct_signal(h, c);
+        const int blk = 64;
+        if (obs_format == Q1ENV_OBS_F32)
+            hipLaunchKernelGGL(reset_draws_kernel<float>, grid_for((int)count, blk), dim3(blk), 0, h->stream, h->p, h->st, (int)count,
+                               idx ? (const int32_t*)dp : nullptr, (const uint8_t*)(dp + bi), (const double*)(dp + bi + bz), (const double*)(dp + bi + bz + bd),
+                               (const double*)(dp + bi + bz + 2 * bd), (const double*)(dp + bi + bz + 3 * bd), obs ? (float*)(dp + in_bytes) : nullptr, sg);
+        else
+            hipLaunchKernelGGL(reset_draws_kernel<double>, grid_for((int)count, blk), dim3(blk), 0, h->stream, h->p, h->st, (int)count,
+                               idx ? (const int32_t*)dp : nullptr, (const uint8_t*)(dp + bi), (const double*)(dp + bi + bz), (const double*)(dp + bi + bz + bd),
+                               (const double*)(dp + bi + bz + 2 * bd), (const double*)(dp + bi + bz + 3 * bd), obs ? (double*)(dp + in_bytes) : nullptr, sg);
+        HIP_TRY(hipGetLastError());
+        if (int r = signal_wait(h, 30.0)) return r;
+        if (obs) memcpy(obs, hp + in_bytes, no);
+        return Q1ENV_OK;
+    }
     if (int r = ensure_stage(h, in_bytes + bo)) return r;
     if (int r = ensure_pin(h, in_bytes + (c <= PACK_MAX_ENVS ? bo : 0))) return r;
     char* d = (char*)h->stage;
@@ -1039,10 +1128,10 @@ int q1env_reset_draws_host(q1env_t* h, int64_t count, const int32_t* idx, const 
     const int blk = 64;
     if (obs_format == Q1ENV_OBS_F32)
         hipLaunchKernelGGL(reset_draws_kernel<float>, grid_for((int)count, blk), dim3(blk), 0, h->stream, h->p, h->st, (int)count,
-                           idx ? d_i : nullptr, d_z, d_y, d_t, d_s, d_a, obs ? (float*)d_o : nullptr);
+                           idx ? d_i : nullptr, d_z, d_y, d_t, d_s, d_a, obs ? (float*)d_o : nullptr, Signal{});
     else
         hipLaunchKernelGGL(reset_draws_kernel<double>, grid_for((int)count, blk), dim3(blk), 0, h->stream, h->p, h->st, (int)count,
-                           idx ? d_i : nullptr, d_z, d_y, d_t, d_s, d_a, obs ? (double*)d_o : nullptr);
+                           idx ? d_i : nullptr, d_z, d_y, d_t, d_s, d_a, obs ? (double*)d_o : nullptr, Signal{});
     HIP_TRY(hipGetLastError());
     if (obs && c <= PACK_MAX_ENVS) {
         HIP_TRY(hipMemcpyAsync(pin + in_bytes, d_o, no, hipMemcpyDeviceToHost, h->stream));

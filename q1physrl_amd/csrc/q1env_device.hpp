@@ -469,6 +469,23 @@ __device__ __forceinline__ void signal_done(const Signal& g, uint32_t wave) {
     }
 }
 
+// The same for a launch whose RESULTS live in host-coherent memory (the host-direct small-batch path of q1env_step_host /
+// q1env_reset_draws_host): the host reads them the moment it sees the sequence number, so every wave releases its stores at SYSTEM
+// scope before its ticket and the ticket is acquire-release - the last wave's system-scope release of the sequence number then
+// carries all of them.  One counter: these launches are a few waves (<= HOST_DIRECT_MAX_ENVS / 64).
+__device__ __forceinline__ void signal_done_strict(const Signal& g) {
+    if (!g.sig || !(g.flags & 2u)) return;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+    if ((threadIdx.x & 63u) == 0u) {
+        uint32_t* root = g.ticket + SIGNAL_LEAVES * SIGNAL_LEAF_STRIDE;
+        if (__hip_atomic_fetch_add(root, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) + 1u == g.waves) {
+            __hip_atomic_store(root, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(g.sig + 1, (uint64_t)wall_clock64(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(g.sig + 2, g.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------- Philox
 __host__ __device__ __forceinline__ void philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1) {
 #pragma unroll

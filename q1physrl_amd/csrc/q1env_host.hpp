@@ -88,8 +88,14 @@ struct q1env {
     uint32_t* ticket_dev = nullptr;
     uint64_t sig_seq = 0;
     double wall_clock_hz = 0.0;
+    // host-direct block of the small-batch *_host paths: host-coherent pinned memory the kernels read their inputs from and write their
+    // results to (no copy commands, no synchronisation: the completion signal says when the results are there)
+    char* direct_host = nullptr;
+    char* direct_dev = nullptr;
+    size_t direct_bytes = 0;
 };
 Q1_HIDDEN int ensure_signal(q1env* h);
+Q1_HIDDEN int ensure_direct(q1env* h, size_t bytes);
 Q1_HIDDEN int signal_wait(q1env* h, double timeout_s);
 
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }

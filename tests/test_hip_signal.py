@@ -88,3 +88,33 @@ def test_signal_wait_without_a_request_is_an_error_not_a_hang():
 def test_build_id_matches_the_sources():
     from q1physrl_amd import _lib, build
     assert _lib.build_id() == build.sources_sha16() and len(_lib.lib_sha16()) == 16
+
+
+@pytest.mark.parametrize("n", [1, 100, 4096])
+def test_host_direct_step_and_reset_equal_the_staged_path(n, monkeypatch):
+    """Small batches (<= 4 096 envs) take the host-direct form of q1env_step_host / q1env_reset_draws_host: the kernel reads the actions
+    from and writes obs / reward / done / zero_start to host-coherent pinned memory itself and says so with the completion signal (one
+    launch + a poll instead of two copy commands + a stream synchronisation).  It must be indistinguishable from the staged path
+    (Q1ENV_HOST_DIRECT=0): same returns on every tick of a seeded trace with RLlib-style reset_at calls, same final state."""
+    from q1physrl_amd import env as E
+    out = []
+    for knob in ("1", "0"):
+        monkeypatch.setenv("Q1ENV_HOST_DIRECT", knob)
+        np.random.seed(11)
+        cfg = E.Config(**{**E.Config.get_default().__dict__, "num_envs": n, "time_limit": 0.5, "zero_start_prob": 0.3})
+        env = E.VectorPhysEnv(cfg, device=0)
+        rng = np.random.default_rng(5)
+        trace = [env.vector_reset().copy()]
+        for t in range(60):
+            a = np.concatenate([(rng.random((n, 4)) < 0.5).astype(np.float64), rng.uniform(-10, 10, (n, 1))], axis=1)
+            obs, rew, done, infos = env.vector_step(a)
+            trace += [obs.copy(), rew.copy(), done.copy(), np.array([infos[i]["zero_start"] for i in range(min(n, 8))])]
+            for i in np.flatnonzero(done)[:16]:
+                trace.append(env.reset_at(int(i)).copy())
+        st = env._dev.get_state()
+        trace += [st[k] for k in sorted(st)]
+        env.close()
+        out.append(trace)
+    assert len(out[0]) == len(out[1])
+    for x, y in zip(*out):
+        assert x.dtype == y.dtype and np.array_equal(x.view(np.uint8), y.view(np.uint8))
