@@ -167,7 +167,7 @@ int q1env_step_autoreset_many(q1env_t* env, int ticks, int action_format, const 
 /* Same with HOST pointers (the NumPy-compatible path): stages H2D, steps, copies back, synchronises.  (ABI v4) Up to 4 096 envs the
  * staging is host-direct: the kernel reads the actions from and writes the results to host-coherent pinned memory itself and the call
  * polls the completion signal - one launch, no copy commands, no stream synchronisation (Q1ENV_HOST_DIRECT=0 in the environment selects
- * the staged form; results are identical).  q1env_reset_draws_host does the same. */
+ * the staged form; results are identical).  q1env_reset_draws_host, q1env_observe_host and q1env_decode_host do the same. */
 int q1env_step_host(q1env_t* env, int action_format, const void* act_a, const void* act_b,
                     int obs_format, void* obs, float* reward, uint8_t* done, uint8_t* zero_start);
 /* `ticks` consecutive single-tick launches with tick-major inputs/outputs ([ticks][N]... ; outputs may be

@@ -223,7 +223,7 @@ __global__ void signal_mark_kernel(Signal sg) {
 }
 
 template <typename OBS_T>
-__global__ void __launch_bounds__(256) observe_kernel(Params p, StatePtrs s, OBS_T* obs) {
+__global__ void __launch_bounds__(256) observe_kernel(Params p, StatePtrs s, OBS_T* obs, Signal sg) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (uint32_t)p.n) return;
     Env e;
@@ -231,6 +231,7 @@ __global__ void __launch_bounds__(256) observe_kernel(Params p, StatePtrs s, OBS
     OBS_T o[6];
     observe<OBS_T>(p, e, o);
     write_obs<OBS_T>(obs, (size_t)i, o);
+    signal_done_strict(sg);                            // (host-direct launches only)
 }
 
 // Reset from host-supplied raw draws (NumPy-compatible RNG stays on the host, the arithmetic is here).
@@ -277,7 +278,7 @@ reset_philox_kernel(Params p, StatePtrs s, uint64_t seed, uint64_t counter, cons
 // Stand-alone ActionDecoder.map (env.py:225-269): decoder state from the handle, z_vel / time from the caller.
 __global__ void __launch_bounds__(256)
 decode_kernel(Params p, StatePtrs s, int fmt, const void* act_a, const void* act_b, const float* z_vel,
-              const double* trem, double* yaw, int64_t* smove, int64_t* fmove, uint8_t* jump) {
+              const double* trem, double* yaw, int64_t* smove, int64_t* fmove, uint8_t* jump, Signal sg) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (uint32_t)p.n) return;
     Env e;
@@ -293,6 +294,7 @@ decode_kernel(Params p, StatePtrs s, int fmt, const void* act_a, const void* act
     smove[i] = (int64_t)c.smove;
     fmove[i] = (int64_t)c.fmove;
     jump[i] = c.jump ? 1 : 0;
+    signal_done_strict(sg);                            // (host-direct launches only)
 }
 
 __global__ void __launch_bounds__(256)
@@ -1052,9 +1054,9 @@ int q1env_observe(q1env_t* h, int obs_format, void* obs) {
     DeviceGuard guard(h->device);
     const int blk = block_for(h->p.n);
     if (obs_format == Q1ENV_OBS_F32)
-        hipLaunchKernelGGL(observe_kernel<float>, grid_for(h->p.n, blk), dim3(blk), 0, h->stream, h->p, h->st, (float*)obs);
+        hipLaunchKernelGGL(observe_kernel<float>, grid_for(h->p.n, blk), dim3(blk), 0, h->stream, h->p, h->st, (float*)obs, Signal{});
     else if (obs_format == Q1ENV_OBS_F64)
-        hipLaunchKernelGGL(observe_kernel<double>, grid_for(h->p.n, blk), dim3(blk), 0, h->stream, h->p, h->st, (double*)obs);
+        hipLaunchKernelGGL(observe_kernel<double>, grid_for(h->p.n, blk), dim3(blk), 0, h->stream, h->p, h->st, (double*)obs, Signal{});
     else return fail(Q1ENV_ERR_INVALID_ARG, "bad obs_format");
     HIP_TRY(hipGetLastError());
     return Q1ENV_OK;
@@ -1063,7 +1065,22 @@ int q1env_observe(q1env_t* h, int obs_format, void* obs) {
 int q1env_observe_host(q1env_t* h, int obs_format, void* obs) {
     if (!h || !obs) return fail(Q1ENV_ERR_INVALID_ARG, "q1env_observe_host: null argument");
     DeviceGuard guard(h->device);
+    if (obs_format != Q1ENV_OBS_F32 && obs_format != Q1ENV_OBS_F64) return fail(Q1ENV_ERR_INVALID_ARG, "bad obs_format");
     const size_t bytes = (size_t)h->p.n * 6 * (obs_format == Q1ENV_OBS_F32 ? 4 : 8);
+    if ((size_t)h->p.n <= HOST_DIRECT_MAX_ENVS && host_direct_enabled()) {      // host-direct: the kernel writes the rows into host memory
+        if (int r = ensure_direct(h, bytes)) return r;
+        if (int r = ensure_signal(h)) return r;
+        const Signal sg = direct_signal(h, (size_t)h->p.n);
+        const int blk = block_for(h->p.n);
+        if (obs_format == Q1ENV_OBS_F32)
+            hipLaunchKernelGGL(observe_kernel<float>, grid_for(h->p.n, blk), dim3(blk), 0, h->stream, h->p, h->st, (float*)h->direct_dev, sg);
+        else
+            hipLaunchKernelGGL(observe_kernel<double>, grid_for(h->p.n, blk), dim3(blk), 0, h->stream, h->p, h->st, (double*)h->direct_dev, sg);
+        HIP_TRY(hipGetLastError());
+        if (int r = signal_wait(h, 30.0)) return r;
+        memcpy(obs, h->direct_host, bytes);
+        return Q1ENV_OK;
+    }
     if (int r = ensure_stage(h, bytes)) return r;
     if (int r = q1env_observe(h, obs_format, h->stage)) return r;
     HIP_TRY(hipMemcpyAsync(obs, h->stage, bytes, hipMemcpyDeviceToHost, h->stream));
@@ -1243,6 +1260,27 @@ int q1env_decode_host(q1env_t* h, int fmt, const void* a, const void* b, const f
     const bool pack = n <= PACK_MAX_ENVS;                  // mkdemo-style per-frame use is n = 1: one copy each way, not eight
     const size_t in_bytes = ba + 2 * b4 + b8, total = ba + 2 * b4 + 4 * b8 + b1;
     const bool has_b = fmt == Q1ENV_ACT_PACKED && h->p.yaw_mode;
+    if (n <= HOST_DIRECT_MAX_ENVS && host_direct_enabled()) {    // host-direct: inputs read from, outputs written to host-coherent memory
+        if (int r = ensure_direct(h, total)) return r;
+        if (int r = ensure_signal(h)) return r;
+        char* hp = h->direct_host;
+        char* dp = h->direct_dev;
+        memcpy(hp, a, act_bytes_a(h, fmt));
+        if (has_b) memcpy(hp + ba, b, n * 4);
+        memcpy(hp + ba + b4, z_vel, n * 4);
+        memcpy(hp + ba + 2 * b4, trem, n * 8);
+        const Signal sg = direct_signal(h, n);
+        const int blk2 = block_for(h->p.n);
+        char* po = dp + in_bytes;
+        hipLaunchKernelGGL(decode_kernel, grid_for(h->p.n, blk2), dim3(blk2), 0, h->stream, h->p, h->st, fmt, (const void*)dp, (const void*)(dp + ba),
+                           (const float*)(dp + ba + b4), (const double*)(dp + ba + 2 * b4), (double*)po, (int64_t*)(po + b8), (int64_t*)(po + 2 * b8),
+                           (uint8_t*)(po + 3 * b8), sg);
+        HIP_TRY(hipGetLastError());
+        if (int r = signal_wait(h, 30.0)) return r;
+        const char* ho = hp + in_bytes;
+        memcpy(yaw, ho, n * 8); memcpy(smove, ho + b8, n * 8); memcpy(fmove, ho + 2 * b8, n * 8); memcpy(jump, ho + 3 * b8, n);
+        return Q1ENV_OK;
+    }
     char* pin = nullptr;
     if (pack) {
         if (int r = ensure_pin(h, total)) return r;
@@ -1260,7 +1298,7 @@ int q1env_decode_host(q1env_t* h, int fmt, const void* a, const void* b, const f
     }
     const int blk = block_for(h->p.n);
     hipLaunchKernelGGL(decode_kernel, grid_for(h->p.n, blk), dim3(blk), 0, h->stream, h->p, h->st, fmt, (const void*)d_a,
-                       (const void*)d_b, (const float*)d_zv, (const double*)d_tr, d_y, d_sm, d_fm, d_j);
+                       (const void*)d_b, (const float*)d_zv, (const double*)d_tr, d_y, d_sm, d_fm, d_j, Signal{});
     HIP_TRY(hipGetLastError());
     if (pack) {
         HIP_TRY(hipMemcpyAsync(pin + in_bytes, d + in_bytes, total - in_bytes, hipMemcpyDeviceToHost, h->stream));

@@ -92,7 +92,8 @@ def test_build_id_matches_the_sources():
 
 @pytest.mark.parametrize("n", [1, 100, 4096])
 def test_host_direct_step_and_reset_equal_the_staged_path(n, monkeypatch):
-    """Small batches (<= 4 096 envs) take the host-direct form of q1env_step_host / q1env_reset_draws_host: the kernel reads the actions
+    """Small batches (<= 4 096 envs) take the host-direct form of q1env_step_host / q1env_reset_draws_host / q1env_observe_host /
+    q1env_decode_host: the kernel reads the actions
     from and writes obs / reward / done / zero_start to host-coherent pinned memory itself and says so with the completion signal (one
     launch + a poll instead of two copy commands + a stream synchronisation).  It must be indistinguishable from the staged path
     (Q1ENV_HOST_DIRECT=0): same returns on every tick of a seeded trace with RLlib-style reset_at calls, same final state."""
@@ -105,10 +106,16 @@ def test_host_direct_step_and_reset_equal_the_staged_path(n, monkeypatch):
         env = E.VectorPhysEnv(cfg, device=0)
         rng = np.random.default_rng(5)
         trace = [env.vector_reset().copy()]
+        dec = E.ActionDecoder(cfg, device=0)                   # the stand-alone decoder (mkdemo.py:47-55): q1env_decode_host
+        dec.vector_reset(np.full(n, 90.0))
         for t in range(60):
             a = np.concatenate([(rng.random((n, 4)) < 0.5).astype(np.float64), rng.uniform(-10, 10, (n, 1))], axis=1)
             obs, rew, done, infos = env.vector_step(a)
             trace += [obs.copy(), rew.copy(), done.copy(), np.array([infos[i]["zero_start"] for i in range(min(n, 8))])]
+            if t % 7 == 0:
+                trace.append(env._get_obs().copy())            # q1env_observe_host
+                yaw, sm, fm, jp = dec.map(a, rng.uniform(-300, 300, n).astype(np.float32), np.full(n, 0.5 - t / 144.0))
+                trace += [np.asarray(yaw).copy(), np.asarray(sm).copy(), np.asarray(fm).copy(), np.asarray(jp).copy()]
             for i in np.flatnonzero(done)[:16]:
                 trace.append(env.reset_at(int(i)).copy())
         st = env._dev.get_state()
