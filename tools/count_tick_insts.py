@@ -38,14 +38,14 @@ def classify(op):
     return "other"
 
 
-def main():
+def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--kernel", default="rollout_kernelIfLb1ELi2ELb0ELi1E")
     ap.add_argument("--src", default=os.path.join(ROOT, "q1physrl_amd", "csrc", "q1env_core.hip"))
     ap.add_argument("--keep", default=None)
     ap.add_argument("--asm", default=None, help="use this assembly file instead of compiling")
     ap.add_argument("-D", action="append", default=[])
-    a = ap.parse_args()
+    a = ap.parse_args(argv)
     from q1physrl_amd import build
     if a.asm:
         text = open(a.asm).read()
@@ -67,25 +67,32 @@ def main():
         if re.search(r"NumVgprs|NumSgprs|Occupancy|ScratchSize", ln):
             print("   ", ln.strip("; ").strip())
     # basic blocks
-    blocks, cur, name, note = [], [], "entry", ""
+    blocks, cur, name, note, targets = [], [], "entry", "", []
+    headers = set(re.findall(r"^(\.LBB\d+_\d+):\s*;.*Loop Header", "\n".join(body), flags=re.M))
+
+    def close():
+        blocks.append((name, note, cur, any(t in headers for t in targets)))
     for ln in body[1:]:
         m = re.match(r"^(\.LBB\d+_\d+):\s*(;.*)?$", ln)
         if m:
-            blocks.append((name, note, cur))
-            name, note, cur = m.group(1), (m.group(2) or ""), []
+            close()
+            name, note, cur, targets = m.group(1), (m.group(2) or ""), [], []
             continue
         m2 = re.match(r"^; %bb\.(\d+):\s*(;.*)?$", ln)
         if m2:
-            blocks.append((name, note, cur))
-            name, note, cur = "%bb." + m2.group(1), (m2.group(2) or ""), []
+            close()
+            name, note, cur, targets = "%bb." + m2.group(1), (m2.group(2) or ""), [], []
             continue
         t = ln.strip()
         if not t or t.startswith((";", ".", "//")):
             continue
         cur.append(t.split()[0])
-    blocks.append((name, note, cur))
+        if t.startswith(("s_cbranch", "s_branch")):
+            targets.append(t.split()[-1])
+    close()
+    hot = hot_path(blocks)
     total = collections.Counter()
-    for name, note, ops in blocks:
+    for name, note, ops, _back in blocks:
         if "in Loop" not in note and "Inner Loop Header" not in note and "Loop Header" not in note:
             continue
         c = collections.Counter(classify(o) for o in ops)
@@ -93,6 +100,43 @@ def main():
         print(f"  {name:12s} {sum(c.values()):4d}  " + "  ".join(f"{k}={c[k]}" for k in ("valu", "salu", "lds", "vmem", "nop", "wait", "branch") if c[k])
               + "   " + note.strip("; ").strip()[:60])
     print("  all loop blocks:", dict(total), "sum", sum(total.values()))
+    if hot:
+        print(f"  hot path of the tick loop ({' '.join(hot['blocks'])}): VALU {hot['valu']}  all issue slots {hot['slots']}")
+    return hot
+
+
+def hot_path(blocks):
+    """The blocks one tick executes: from the header of the LARGEST loop (by instruction count) to the block that holds the back edge,
+    in layout order - the compiler places the blocks a tick normally runs through contiguously and the cold ones (the library sin / cos
+    fallback for |yaw| >= 2^20 rad) behind the latch.  Returns {'blocks', 'valu', 'slots'} or None."""
+    loops = {}
+    for idx, (name, note, ops, _b) in enumerate(blocks):
+        m = re.search(r"Loop Header", note)
+        if m and name.startswith(".LBB"):
+            loops[name] = idx
+    best = None
+    for header, hidx in loops.items():
+        hname = header.replace(".LBB", "BB")
+        members = [i for i, (n, note, ops, _b) in enumerate(blocks) if i == hidx or ("Header=" + hname + " ") in (note + " ")]
+        if not members:
+            continue
+        size = sum(len(blocks[i][2]) for i in members)
+        if best is None or size > best[0]:
+            best = (size, header, hidx, members)
+    if best is None:
+        return None
+    _, header, hidx, members = best
+    # layout order from the header to the first member that branches back to a loop header (the latch)
+    run = [hidx]
+    i = hidx + 1
+    while i < len(blocks) and i in members and len(run) < 16:
+        run.append(i)
+        if blocks[i][3]:                       # this block branches back to the header
+            break
+        i += 1
+    valu = sum(sum(1 for o in blocks[j][2] if classify(o) == "valu") for j in run)
+    slots = sum(len(blocks[j][2]) for j in run)
+    return {"blocks": [blocks[j][0] for j in run], "valu": valu, "slots": slots}
 
 
 if __name__ == "__main__":
