@@ -811,6 +811,11 @@ def main(argv=None):
              "launch_duration_source": "HIP events on the launch stream" + (" (the K ticks repeated from the same state right after the timed "
                                        "region; the timed region itself carries no marker packets - its kernel time is device_stamp_us)" if stamp_us else ""),
              "device_stamp_us": stamp_us,
+             # the same roofline arithmetic on the timed region's OWN kernel time (device stamps; for a launch this short it is what
+             # rocprofv3's kernel-trace reports - profiles/r4_driver_steps20_kernel_trace.txt - while two HIP-event marker packets add ~3.5 us)
+             "avg_launch_us_device_stamps": (stamp_us / launches_) if stamp_us else None,
+             "achieved_device_stamps": (alg_bytes / (stamp_us / launches_ * 1e-6) / 1e9) if stamp_us else None,
+             "frac_device_stamps": (alg_bytes / (stamp_us / launches_ * 1e-6) / 1e9 / HBM_PEAK_GBPS) if stamp_us else None,
              "wall_over_event": (wall_ * 1e6 / stamp_us) if stamp_us else (wall_ * 1e3 / ev_ms_ if ev_ms_ > 0 else None),
              "wall_over_event_basis": "device stamps of the timed region" if stamp_us else "HIP events of the timed region",
              "host_split_us": hs or None, "env_steps_per_launch": n * tpl, "frac_nominal_204B": nominal / HBM_PEAK_GBPS,
