@@ -32,7 +32,7 @@ constexpr size_t IMG_W3T_BYTES = q1learn::LDS_W3T;                          // 2
 
 struct NetWs {
     uint16_t* w23; uint16_t* w2t; uint16_t* w3t;
-    q1learn::f16x8* h1T; q1learn::f16x8* h2T; q1learn::f16x8* dz2N; q1learn::f16x8* dz1N; q1learn::f16x8* h1N; q1learn::f16x8* h2N;
+    q1learn::f16x8* h1T; q1learn::f16x8* h2T; q1learn::f16x8* dz2N; q1learn::f16x8* dz1N;
     q1learn::f16x8* xN; q1learn::f16x8* dyN;
     float* partial;
 };
@@ -53,7 +53,7 @@ Ws carve_ws(void* base, int64_t mb, int out_pi, int splits) {
         NetWs& n = w.net[k];
         n.w23 = (uint16_t*)take(IMG_FWD_BYTES); n.w2t = (uint16_t*)take(IMG_W2T_BYTES); n.w3t = (uint16_t*)take(IMG_W3T_BYTES);
         n.h1T = (q1learn::f16x8*)take(act); n.h2T = (q1learn::f16x8*)take(act);
-        n.dz2N = (q1learn::f16x8*)take(act); n.dz1N = (q1learn::f16x8*)take(act); n.h1N = (q1learn::f16x8*)take(act); n.h2N = (q1learn::f16x8*)take(act);
+        n.dz2N = (q1learn::f16x8*)take(act); n.dz1N = (q1learn::f16x8*)take(act);
         n.xN = (q1learn::f16x8*)take(tiles * 128u * 16u); n.dyN = (q1learn::f16x8*)take(tiles * 128u * 16u);
         n.partial = (float*)take((size_t)splits * q1learn::PARTIAL_STRIDE * 4u);
     }
@@ -107,16 +107,16 @@ int launch_backward(q1env* h, const Ws& w, int64_t mb, int splits, const q1env_l
                     bool reduce = true, uint32_t* sat = nullptr) {
     if (int r = ensure_learner_attrs(h)) return r;
     const q1learn::BwdNet ba{w.net[0].w2t, w.net[0].w3t, dlogits, pi->out_dim, pi->out_dim, w.net[0].h1T, w.net[0].h2T,
-                             w.net[0].dz2N, w.net[0].dz1N, w.net[0].h1N, w.net[0].h2N, w.net[0].xN, w.net[0].dyN, sat};
+                             w.net[0].dz2N, w.net[0].dz1N, w.net[0].xN, w.net[0].dyN, sat};
     const q1learn::BwdNet bb{w.net[1].w2t, w.net[1].w3t, dvalue, vf->out_dim, vf->out_dim, w.net[1].h1T, w.net[1].h2T,
-                             w.net[1].dz2N, w.net[1].dz1N, w.net[1].h1N, w.net[1].h2N, w.net[1].xN, w.net[1].dyN, sat ? sat + 2 : nullptr};
+                             w.net[1].dz2N, w.net[1].dz1N, w.net[1].xN, w.net[1].dyN, sat ? sat + 2 : nullptr};
     const unsigned cus = (unsigned)(h->num_cus > 1 ? h->num_cus / 2 : 1);
     const unsigned tiles = (unsigned)((mb + 31) / 32);
     unsigned blocks = (tiles + 3u) / 4u;
     if (blocks > cus) blocks = cus;
     hipLaunchKernelGGL(q1learn::learner_backward_kernel, dim3(blocks * 2u), dim3(256), q1learn::LDS_BWD, h->stream, (int)mb, obs, idx, idx_cursor, ba, bb, 2);
-    const q1learn::WgNet wa{w.net[0].dz2N, w.net[0].dz1N, w.net[0].h1N, w.net[0].h2N, w.net[0].xN, w.net[0].dyN, w.net[0].partial};
-    const q1learn::WgNet wb{w.net[1].dz2N, w.net[1].dz1N, w.net[1].h1N, w.net[1].h2N, w.net[1].xN, w.net[1].dyN, w.net[1].partial};
+    const q1learn::WgNet wa{w.net[0].dz2N, w.net[0].dz1N, w.net[0].h1T, w.net[0].h2T, w.net[0].xN, w.net[0].dyN, w.net[0].partial};
+    const q1learn::WgNet wb{w.net[1].dz2N, w.net[1].dz1N, w.net[1].h1T, w.net[1].h2T, w.net[1].xN, w.net[1].dyN, w.net[1].partial};
     hipLaunchKernelGGL(q1learn::learner_wgrad_kernel, dim3(2u * (unsigned)splits, 2, 2), dim3(256), 0, h->stream, (int)mb, wa, wb, splits);
     if (!reduce) { HIP_TRY(hipGetLastError()); return 0; }          // q1env_learner_adam sums the partials itself
     const q1learn::Grads ga{pi->gw1, pi->gb1, pi->gw2, pi->gb2, pi->gw3, pi->gb3, pi->out_dim};

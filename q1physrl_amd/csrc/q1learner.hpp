@@ -9,10 +9,13 @@
 //                             as float16 "T-format" tiles (lane = sample, registers = hidden units: the next layer's B operands as is)
 //   ppo_loss_grad_kernel      (q1env_policy.hip) d loss / d(logits, value) per sample, closed form, gathered through the same idx
 //   learner_backward_kernel   dH2 = W3^T dY, dZ2 = dH2 (1 - h2^2), dH1 = W2^T dZ2, dZ1 = dH1 (1 - h1^2) per 32-sample tile with the
-//                             TRANSPOSED weight images in LDS, then transposes dZ2, dZ1, h1, h2 to "N-format" (lane = hidden unit,
+//                             TRANSPOSED weight images in LDS, then transposes dZ2, dZ1 (and [x | 1], dY) to "N-format" (lane = hidden unit,
 //                             registers = samples) with two identity-operand MFMAs per 32x32 tile and stores them
 //   learner_wgrad_kernel      dW2 = dZ2^T h1, dW3 = dY^T h2, dW1 = dZ1^T x and the three bias gradients as matrix products whose
-//                             contraction runs over the SAMPLES (N-format operands, split over workgroups); partial sums per workgroup
+//                             contraction runs over the SAMPLES (N-format operands, split over workgroups); partial sums per workgroup.
+//                             Round 4: h1 / h2 arrive in the forward kernel's T-format and are transposed here (the matrix pipe is idle
+//                             in this memory-bound kernel), so the step no longer materialises N-format copies of them: 519 -> 452 MB
+//                             per 32 768-sample step, same time (profiles/r4_learner_bytes.txt)
 //   learner_reduce_kernel     sums the partials, undoes the tile permutation, scales and writes the gradients in torch layout
 //   learner_images_kernel     (after the optimizer) rebuilds the float16 weight images of both directions from the float32 masters
 //
@@ -165,7 +168,7 @@ struct BwdNet {
     const float* dy;          // float[n][dy_stride]: d loss / d output x grad_scale (dlogits rows, or dvalue with stride 1)
     int dy_stride; int out_dim;
     const f16x8* h1T; const f16x8* h2T;
-    f16x8* dz2N; f16x8* dz1N; f16x8* h1N; f16x8* h2N;
+    f16x8* dz2N; f16x8* dz1N;     // (round 4: h1 / h2 are no longer written in N-format - the weight-gradient kernel transposes the T-format itself)
     f16x8* xN;                // f16x8[tile][ks][lane]: the gathered observations + the constant 1 (input slot 6), lane = sigma(input index)
     f16x8* dyN;               // f16x8[tile][ks][lane]: dY, lane = output index (natural)
     uint32_t* sat;            // optional uint32[2]: += (lane, launch) pairs that converted a gradient element beyond float16's 65504 (it was
@@ -302,7 +305,6 @@ learner_backward_kernel(int n, const float* __restrict__ obs, const int64_t* __r
             times_dtanh(acc, hv[t][0], hv[t][1]);
             dzb[t][0] = cvt8_sat(acc, 0, amax);
             dzb[t][1] = cvt8_sat(acc, 1, amax);
-            store_n(net.h2N + tbase, (uint32_t)t, transpose_tile(hv[t][0], hv[t][1], e0, e1));
             store_n(net.dz2N + tbase, (uint32_t)t, transpose_tile(dzb[t][0], dzb[t][1], e0, e1));
         }
 #pragma unroll
@@ -332,7 +334,6 @@ learner_backward_kernel(int n, const float* __restrict__ obs, const int64_t* __r
         for (int t = 0; t < 8; ++t) {
             times_dtanh(acc1[t], hv[t][0], hv[t][1]);
             const f16x8 z0 = cvt8_sat(acc1[t], 0, amax), z1 = cvt8_sat(acc1[t], 1, amax);
-            store_n(net.h1N + tbase, (uint32_t)t, transpose_tile(hv[t][0], hv[t][1], e0, e1));
             store_n(net.dz1N + tbase, (uint32_t)t, transpose_tile(z0, z1, e0, e1));
         }
     }
@@ -351,7 +352,10 @@ learner_backward_kernel(int n, const float* __restrict__ obs, const int64_t* __r
 
 // ------------------------------------------------------------------------------------------------------------------ weight gradients
 struct WgNet {
-    const f16x8* dz2N; const f16x8* dz1N; const f16x8* h1N; const f16x8* h2N; const f16x8* xN; const f16x8* dyN;
+    // round 4: h1 / h2 are read in the forward kernel's T-format and transposed HERE, on the matrix pipe this kernel leaves idle (it
+    // streams its operands at the memory system's rate: 6.2 TB/s, profiles/r4_learner_bytes.txt) - the backward kernel no longer writes
+    // N-format copies of them (67 MB of the step's 514)
+    const f16x8* dz2N; const f16x8* dz1N; const f16x8* h1T; const f16x8* h2T; const f16x8* xN; const f16x8* dyN;
     float* partial;           // float[splits][PARTIAL_STRIDE]
 };
 
@@ -370,10 +374,18 @@ __device__ __forceinline__ void wg_load(WgOps& o, const WgNet& net, uint32_t til
     for (int ks = 0; ks < 2; ++ks) {
         o.a2[ks] = net.dz2N[tb + (2u * w + (uint32_t)ks) * 64u];
         if constexpr (KHALF == 0) { o.s0[ks] = net.dz1N[tb + (2u * w + (uint32_t)ks) * 64u]; o.s1[ks] = net.xN[sb + 64u * (uint32_t)ks]; }
-        else { o.s0[ks] = net.dyN[sb + 64u * (uint32_t)ks]; o.s1[ks] = net.h2N[tb + (2u * w + (uint32_t)ks) * 64u]; o.x[ks] = net.xN[sb + 64u * (uint32_t)ks]; }
+        // (h2 / h1: T-format vectors u = ks of the unit tile - the same addressing as an N-format array; transposed by wg_transpose)
+        else { o.s0[ks] = net.dyN[sb + 64u * (uint32_t)ks]; o.s1[ks] = net.h2T[tb + (2u * w + (uint32_t)ks) * 64u]; o.x[ks] = net.xN[sb + 64u * (uint32_t)ks]; }
 #pragma unroll
-        for (int kt = 0; kt < 4; ++kt) o.b[kt][ks] = net.h1N[tb + (2u * (4u * (uint32_t)KHALF + (uint32_t)kt) + (uint32_t)ks) * 64u];
+        for (int kt = 0; kt < 4; ++kt) o.b[kt][ks] = net.h1T[tb + (2u * (4u * (uint32_t)KHALF + (uint32_t)kt) + (uint32_t)ks) * 64u];
     }
+}
+
+// T-format pair (u = 0, 1) of one 32-unit tile -> the N-format pair (ks = 0, 1): what learner_backward_kernel's store_n wrote in round 3
+__device__ __forceinline__ void wg_transpose(f16x8 (&v)[2], const f16x8 e0, const f16x8 e1) {
+    const f32x16 d = transpose_tile(v[0], v[1], e0, e1);
+    v[0] = cvt8(d, 0);
+    v[1] = cvt8(d, 1);
 }
 
 #ifndef Q1_WGRAD_DEPTH                  // operand sets in flight per wave (measurement knob): tiles requested ahead = depth - 1
@@ -389,6 +401,16 @@ __device__ __forceinline__ void wg_loop(const WgNet& net, uint32_t t_begin, uint
     constexpr int D = Q1_WGRAD_DEPTH;
     WgOps ring[D];
     if (t_begin >= t_end) return;
+    // selection operands of the transposition (as in learner_backward_kernel): E0[K][c] = [K == c], E1[K][c] = [K == c - 16]
+    f16x8 e0, e1;
+    {
+        const uint32_t col = lane & 31u, half = lane >> 5;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            e0[e] = (8u * half + (uint32_t)e == col) ? (_Float16)1.0f : (_Float16)0.0f;
+            e1[e] = (8u * half + (uint32_t)e + 16u == col) ? (_Float16)1.0f : (_Float16)0.0f;
+        }
+    }
 #pragma unroll
     for (int d = 0; d < D - 1; ++d) wg_load<KHALF>(ring[d], net, min(t_begin + (uint32_t)d, t_end - 1u), lane, w);
     for (uint32_t tile0 = t_begin; tile0 < t_end; tile0 += (uint32_t)D) {
@@ -398,7 +420,10 @@ __device__ __forceinline__ void wg_loop(const WgNet& net, uint32_t t_begin, uint
             if (tile >= t_end) return;                                             // wave-uniform
             wg_load<KHALF>(ring[(j + D - 1) % D], net, min(tile + (uint32_t)(D - 1), t_end - 1u), lane, w);   // (past the end: re-requests the last tile, harmless)
             __builtin_amdgcn_sched_barrier(0);                                     // the requests go out HERE, not next to their uses
-            const WgOps& cur = ring[j];
+            WgOps& cur = ring[j];
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt) wg_transpose(cur.b[kt], e0, e1);          // h1 column tiles: T -> N
+            if constexpr (KHALF == 1) wg_transpose(cur.s1, e0, e1);                  // h2 tile w: T -> N
 #pragma unroll
             for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
