@@ -436,10 +436,11 @@ int q1env_policy_forward_rows(q1env_t* env, uint64_t rows, const float* obs_dev,
  * float[T][N], done uint8[T][N]; zero_start uint8[N], ep_return double[N], partials double[ceil(N/64)][4] as q1env_sample_step /
  * q1env_episode_stats.  RNG counter of tick t = counter_offset + (*counter_dev if given, else the handle's tick count) + t.
  * Limits: out_dim <= 24 (a discrete-mouse head with up to 24 outputs, e.g. 4 keys + discrete_yaw_steps <= 7; pi->out is then
- * required - the categorical part of the sampling reads the row it has just written); N <= 256 x the number of CUs with the
- * continuous / no-mouse head (a workgroup serves 128 envs at one tile per policy wave and tick, 256 at two: 32 768 / 65 536 envs
- * on an MI355X), N <= 128 x CUs with a discrete-mouse head; anything else is refused with Q1ENV_ERR_INVALID_ARG - use the
- * per-tick calls. */
+ * required - the categorical part of the sampling reads the row it has just written); anything else is refused with
+ * Q1ENV_ERR_INVALID_ARG - use the per-tick calls.  A workgroup serves 128 envs at one tile per policy wave and tick (every batch
+ * of a discrete-mouse head, and batches up to 128 x the number of CUs: 32 768 envs on an MI355X) or 256 at two; the workgroups share
+ * nothing, so a batch of more workgroups than the device has CUs (65 536 envs) runs as successive sets of workgroups, each
+ * playing its envs' whole horizon (round 4; before, such a batch was refused). */
 typedef struct q1env_resident_args {
     int ticks;
     int deterministic;

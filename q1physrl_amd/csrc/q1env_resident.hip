@@ -29,15 +29,15 @@ int q1env_sample_resident(q1env_t* h, const q1env_resident_args* a) {
 #undef Q1_ATTR
         h->resident_attr_set = true;
     }
-    // one workgroup per CU (its LDS holds the network): 128 envs per workgroup at one tile per policy wave, 256 at two (heads of up to 10
-    // outputs only: the 24-row W3 tile of a discrete-mouse head leaves no room for the second tile's hand-off area)
+    // a workgroup fills a CU (its LDS holds the network) and serves 128 envs at one tile per policy wave, 256 at two (heads of up to 10
+    // outputs only: the 24-row W3 tile of a discrete-mouse head leaves no room for the second tile's hand-off area).  Workgroups are
+    // self-contained - every wait is on a tag in the workgroup's own LDS - so a grid larger than the device is legal: the dispatcher
+    // starts the next workgroup (its whole horizon) on a CU when one retires.  One tile per wave while that grid is co-resident
+    // (lowest latency per tick), two above (half as many workgroups, half as many weight stagings).
     const unsigned n = (unsigned)h->p.n, cus = (unsigned)h->num_cus;
     const bool wide = h->p.yaw_mode == 2 || width > 10;   // a discrete-mouse head: the 24-row variant (gathers all of an env's logits, writes the row before it samples)
-    int tp = (n + 127u) / 128u <= cus ? 1 : (!wide && (n + 255u) / 256u <= cus ? 2 : 0);
-    if (const char* f = getenv("Q1ENV_RESIDENT_TP")) { if (f[0] == '2' && tp == 1 && !wide) tp = 2; }      // measurement knob
-    if (!tp)
-        return fail(Q1ENV_ERR_INVALID_ARG, "q1env_sample_resident: too many envs for one resident grid (" + std::to_string(cus * (wide ? 128u : 256u)) +
-                                           " at most on this device)");
+    int tp = (wide || (n + 127u) / 128u <= cus) ? 1 : 2;
+    if (const char* f = getenv("Q1ENV_RESIDENT_TP")) { if (f[0] == '2' && !wide) tp = 2; else if (f[0] == '1') tp = 1; }      // measurement knob
     ResidentArgs k{};
     k.ticks = a->ticks;
     k.pi = q1pol::Net{m->w1, m->b1, m->w23_image, m->b2, m->b3, m->out, m->out_dim};

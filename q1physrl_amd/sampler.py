@@ -27,7 +27,7 @@ class GpuSampler:
         """resident=True: the whole horizon is ONE dispatch (q1env_sample_resident: policy blocks with the network's weights in LDS
         and env blocks with the state in registers, talking through tagged granules) followed by one batched value-network
         forward over the stored observations - bit-identical trajectories, no per-tick launches.  Needs a FusedPolicyForward
-        policy (continuous, discrete - up to 24 outputs - or no mouse) and a batch whose grid is resident (q1env.h); use_graph is
+        policy (continuous, discrete - up to 24 outputs - or no mouse); any batch size (q1env.h); use_graph is
         ignored.  Every wait inside the dispatch is bounded; a wave that gives up sets the status words and the rows after its last
         completed tick are NOT written, so collect() checks the status after every horizon (check_status=True; one 20-byte D2H copy
         at a point where the caller synchronises anyway) and raises instead of handing stale memory to the learner."""
