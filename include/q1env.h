@@ -411,6 +411,17 @@ uint64_t q1env_learner_adam_state_bytes(int out_dim_pi);
 int q1env_learner_adam(q1env_t* env, const q1env_learner_net* pi, const q1env_learner_net* vf, void* ws_dev, int64_t minibatch, int splits,
                        float grad_scale, float lr, float beta1, float beta2, float eps, void* adam_state_dev, const float* stats_partials_dev);
 
+/* The whole SGD step of a single-process run as ONE call (round 4): q1env_learner_step with skip_reduce, then q1env_learner_adam with
+ * grad_scale = minibatch = batch->minibatch - the same masters, moments, weight images and gw* / gb* to the last bit - in four launches
+ * instead of six: for the reference's action structure (4 keys + continuous mouse) the backward kernel computes the PPO loss gradient
+ * of its own samples (no loss kernel, no dlogits round trip) and the optimizer's bookkeeping rides in the backward and Adam kernels (no
+ * bookkeeping kernel); other action structures run the two calls as they are.  The step's statistics are folded into adam_state's running
+ * sums (bytes 16..35) as q1env_learner_adam does - summed per workgroup of the backward kernel, i.e. equal to the two-call path's up
+ * to the order of the float32 additions; batch->stats_partials_dev and batch->skip_reduce are not used (stats_partials_dev may be NULL
+ * for the reference's action structure).  Replayable from a captured graph. */
+int q1env_learner_sgd_step(q1env_t* env, const q1env_learner_net* pi, const q1env_learner_net* vf, void* ws_dev, int splits,
+                           const q1env_learner_batch* batch, float lr, float beta1, float beta2, float eps, void* adam_state_dev);
+
 /* Episode bookkeeping of one sampler tick (the reference's on_episode_end metric hook, q1physrl/train.py:54-57):
  * ep_return double[N] += reward; for envs with done != 0 the finished return is added to this wave's slot of
  * partials (double[ceil(N/64)][4] = episodes, zero-start episodes, return sum, zero-start return sum) and ep_return is

@@ -30,6 +30,8 @@ constexpr size_t IMG_FWD_BYTES = (q1pol::LDS_W2 + q1pol::LDS_W3);           // 1
 constexpr size_t IMG_W2T_BYTES = q1learn::LDS_W2T;                          // 135168
 constexpr size_t IMG_W3T_BYTES = q1learn::LDS_W3T;                          // 20480
 
+constexpr size_t STATS_ROWS = 2048;      // >= the backward kernel's workgroups (at most one per CU)
+
 struct NetWs {
     uint16_t* w23; uint16_t* w2t; uint16_t* w3t;
     q1learn::f16x8* h1T; q1learn::f16x8* h2T; q1learn::f16x8* dz2N; q1learn::f16x8* dz1N;
@@ -39,6 +41,7 @@ struct NetWs {
 struct Ws {
     NetWs net[2];
     float* logits; float* value; float* dlogits; float* dvalue;
+    float* stats_rows;            // float[STATS_ROWS][5]: the fused step's statistics rows (one per workgroup of the backward kernel)
     size_t bytes;
 };
 
@@ -59,6 +62,7 @@ Ws carve_ws(void* base, int64_t mb, int out_pi, int splits) {
     }
     w.logits = (float*)take((size_t)mb * out_pi * 4u); w.value = (float*)take((size_t)mb * 4u);
     w.dlogits = (float*)take((size_t)mb * out_pi * 4u); w.dvalue = (float*)take((size_t)mb * 4u);
+    w.stats_rows = (float*)take(STATS_ROWS * 5u * 4u);
     w.bytes = off;
     return w;
 }
@@ -81,7 +85,8 @@ int check_shape(const char* who, int64_t mb, int splits) {
 int ensure_learner_attrs(q1env* h) {
     if (!h->learner_attr_set) {
         HIP_TRY(hipFuncSetAttribute((const void*)q1learn::learner_forward_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)q1pol::LDS_TOTAL));
-        HIP_TRY(hipFuncSetAttribute((const void*)q1learn::learner_backward_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)q1learn::LDS_BWD));
+        HIP_TRY(hipFuncSetAttribute((const void*)q1learn::learner_backward_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)q1learn::LDS_BWD));
+        HIP_TRY(hipFuncSetAttribute((const void*)q1learn::learner_backward_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)q1learn::LDS_BWD));
         h->learner_attr_set = true;
     }
     return 0;
@@ -104,7 +109,8 @@ int launch_forward(q1env* h, const Ws& w, int64_t mb, const q1env_learner_net* p
 
 int launch_backward(q1env* h, const Ws& w, int64_t mb, int splits, const q1env_learner_net* pi, const q1env_learner_net* vf, const float* obs,
                     const int64_t* idx, const int64_t* idx_cursor, const float* dlogits, const float* dvalue, float grad_scale, float grad_scale_v,
-                    bool reduce = true, uint32_t* sat = nullptr) {
+                    bool reduce = true, uint32_t* sat = nullptr, const q1learn::LossArgs* fused = nullptr, const q1learn::BcArgs* bca = nullptr,
+                    unsigned* grid_out = nullptr) {
     if (int r = ensure_learner_attrs(h)) return r;
     const q1learn::BwdNet ba{w.net[0].w2t, w.net[0].w3t, dlogits, pi->out_dim, pi->out_dim, w.net[0].h1T, w.net[0].h2T,
                              w.net[0].dz2N, w.net[0].dz1N, w.net[0].xN, w.net[0].dyN, sat};
@@ -114,7 +120,14 @@ int launch_backward(q1env* h, const Ws& w, int64_t mb, int splits, const q1env_l
     const unsigned tiles = (unsigned)((mb + 31) / 32);
     unsigned blocks = (tiles + 3u) / 4u;
     if (blocks > cus) blocks = cus;
-    hipLaunchKernelGGL(q1learn::learner_backward_kernel, dim3(blocks * 2u), dim3(256), q1learn::LDS_BWD, h->stream, (int)mb, obs, idx, idx_cursor, ba, bb, 2);
+    if (grid_out) *grid_out = blocks * 2u;
+    if (blocks * 2u > STATS_ROWS) return fail(Q1ENV_ERR_INVALID_ARG, "learner: more workgroups than statistics rows");
+    if (fused)          // dY computed in the kernel (q1env_learner_sgd_step; the reference's action structure)
+        hipLaunchKernelGGL(q1learn::learner_backward_kernel<true>, dim3(blocks * 2u), dim3(256), q1learn::LDS_BWD, h->stream, (int)mb, obs, idx, idx_cursor, ba,
+                           bb, 2, *fused, bca ? *bca : q1learn::BcArgs{nullptr, nullptr, 0.0f, 0.0f});
+    else
+        hipLaunchKernelGGL(q1learn::learner_backward_kernel<false>, dim3(blocks * 2u), dim3(256), q1learn::LDS_BWD, h->stream, (int)mb, obs, idx, idx_cursor, ba,
+                           bb, 2, q1learn::LossArgs{}, q1learn::BcArgs{nullptr, nullptr, 0.0f, 0.0f});
     const q1learn::WgNet wa{w.net[0].dz2N, w.net[0].dz1N, w.net[0].h1T, w.net[0].h2T, w.net[0].xN, w.net[0].dyN, w.net[0].partial};
     const q1learn::WgNet wb{w.net[1].dz2N, w.net[1].dz1N, w.net[1].h1T, w.net[1].h2T, w.net[1].xN, w.net[1].dyN, w.net[1].partial};
     hipLaunchKernelGGL(q1learn::learner_wgrad_kernel, dim3(2u * (unsigned)splits, 2, 2), dim3(256), 0, h->stream, (int)mb, wa, wb, splits);
@@ -213,8 +226,16 @@ uint64_t q1env_learner_adam_state_bytes(int out_dim_pi) {
     return (uint64_t)(256u + align_up(2 * per_pi * 4u, 256) + align_up(2 * per_vf * 4u, 256));
 }
 
-int q1env_learner_adam(q1env_t* h, const q1env_learner_net* pi, const q1env_learner_net* vf, void* ws_dev, int64_t minibatch, int splits,
-                       float grad_scale, float lr, float beta1, float beta2, float eps, void* adam_state_dev, const float* stats_partials_dev) {
+}  // extern "C"
+
+namespace {
+
+// q1env_learner_adam (fused_tick = false: the bookkeeping kernel runs in front) and the tail of q1env_learner_sgd_step (fused_tick: the
+// bias corrections were left by the backward kernel, workgroup (0, 0) of the Adam kernel does the rest; stats = the backward kernel's
+// `stat_rows` statistics rows)
+int launch_adam(q1env_t* h, const q1env_learner_net* pi, const q1env_learner_net* vf, void* ws_dev, int64_t minibatch, int splits,
+                float grad_scale, float lr, float beta1, float beta2, float eps, void* adam_state_dev, const float* stats_partials_dev, bool fused_tick,
+                int stat_rows) {
     if (!h || !ws_dev || !adam_state_dev) return fail(Q1ENV_ERR_INVALID_ARG, "q1env_learner_adam: null argument");
     if (!(grad_scale > 0.0f) || !(lr >= 0.0f) || !(beta1 >= 0.0f && beta1 < 1.0f) || !(beta2 >= 0.0f && beta2 < 1.0f) || !(eps > 0.0f))
         return fail(Q1ENV_ERR_INVALID_ARG, "q1env_learner_adam: bad hyper-parameter");
@@ -231,8 +252,12 @@ int q1env_learner_adam(q1env_t* h, const q1env_learner_net* pi, const q1env_lear
     const size_t per_pi = 65536u + 256u + 1536u + 256u + (size_t)pi->out_dim * 257u, per_vf = 65536u + 256u + 1536u + 256u + (size_t)vf->out_dim * 257u;
     float* m_pi = (float*)(st + 256), *v_pi = m_pi + per_pi;
     float* m_vf = (float*)(st + 256 + align_up(2 * per_pi * 4u, 256)), *v_vf = m_vf + per_vf;
-    hipLaunchKernelGGL(q1learn::adam_tick_kernel, dim3(1), dim3(64), 0, h->stream, step, bc, beta1, beta2, stats_partials_dev,
-                       (int)((minibatch + 255) / 256), 1.0f / (float)minibatch, (float*)(st + 16), (long long*)(st + 72), (long long)minibatch);
+    q1learn::AdamTick tick{nullptr, nullptr, 0, nullptr, 0, 0.0f, nullptr};
+    if (fused_tick)
+        tick = q1learn::AdamTick{step, (long long*)(st + 72), (long long)minibatch, stats_partials_dev, stat_rows, 1.0f / (float)minibatch, (float*)(st + 16)};
+    else
+        hipLaunchKernelGGL(q1learn::adam_tick_kernel, dim3(1), dim3(64), 0, h->stream, step, bc, beta1, beta2, stats_partials_dev,
+                           (int)((minibatch + 255) / 256), 1.0f / (float)minibatch, (float*)(st + 16), (long long*)(st + 72), (long long)minibatch);
     const q1learn::AdamNet na{const_cast<float*>(pi->w1), const_cast<float*>(pi->b1), const_cast<float*>(pi->w2), const_cast<float*>(pi->b2),
                               const_cast<float*>(pi->w3), const_cast<float*>(pi->b3),
                               q1learn::Grads{pi->gw1, pi->gb1, pi->gw2, pi->gb2, pi->gw3, pi->gb3, pi->out_dim}, m_pi, v_pi, w.net[0].w23, w.net[0].w2t, w.net[0].w3t};
@@ -243,9 +268,63 @@ int q1env_learner_adam(q1env_t* h, const q1env_learner_net* pi, const q1env_lear
     const unsigned elems = 65536u + 256u + 256u * 6u + 256u + max_out * 257u;
     hipLaunchKernelGGL(q1learn::learner_adam_kernel, dim3((elems + 255u) / 256u, 2), dim3(256), 0, h->stream, (const float*)w.net[0].partial,
                        (const float*)w.net[1].partial, na, nb, splits, 1.0f / (grad_scale * learner_pi_upscale()), learner_value_downscale() / grad_scale,
-                       q1learn::AdamHyper{lr, beta1, beta2, eps}, (const float*)bc);
+                       q1learn::AdamHyper{lr, beta1, beta2, eps}, (const float*)bc, tick);
     HIP_TRY(hipGetLastError());
     return Q1ENV_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int q1env_learner_adam(q1env_t* h, const q1env_learner_net* pi, const q1env_learner_net* vf, void* ws_dev, int64_t minibatch, int splits,
+                       float grad_scale, float lr, float beta1, float beta2, float eps, void* adam_state_dev, const float* stats_partials_dev) {
+    return launch_adam(h, pi, vf, ws_dev, minibatch, splits, grad_scale, lr, beta1, beta2, eps, adam_state_dev, stats_partials_dev, false, 0);
+}
+
+int q1env_learner_sgd_step(q1env_t* h, const q1env_learner_net* pi, const q1env_learner_net* vf, void* ws_dev, int splits, const q1env_learner_batch* b,
+                           float lr, float beta1, float beta2, float eps, void* adam_state_dev) {
+    if (!h || !ws_dev || !b || !adam_state_dev) return fail(Q1ENV_ERR_INVALID_ARG, "q1env_learner_sgd_step: null argument");
+    if (!b->obs_dev || !b->old_logits_dev || !b->keys_dev || !b->logp_old_dev || !b->adv_dev || !b->value_old_dev || !b->vtarg_dev || !b->kl_coeff_dev)
+        return fail(Q1ENV_ERR_INVALID_ARG, "q1env_learner_sgd_step: null pointer in q1env_learner_batch");
+    if (!(lr >= 0.0f) || !(beta1 >= 0.0f && beta1 < 1.0f) || !(beta2 >= 0.0f && beta2 < 1.0f) || !(eps > 0.0f))
+        return fail(Q1ENV_ERR_INVALID_ARG, "q1env_learner_sgd_step: bad hyper-parameter");
+    if (int r = check_nets("q1env_learner_sgd_step", pi, vf, true)) return r;
+    if (int r = check_shape("q1env_learner_sgd_step", b->minibatch, splits)) return r;
+    if (h->p.yaw_mode != 0 && !b->mouse_dev) return fail(Q1ENV_ERR_INVALID_ARG, "q1env_learner_sgd_step: mouse actions required");
+    if (pi->out_dim != policy_row_width(h->p)) return fail(Q1ENV_ERR_INVALID_ARG, "q1env_learner_sgd_step: pi->out_dim must be " + std::to_string(policy_row_width(h->p)));
+    if (vf->out_dim != 1) return fail(Q1ENV_ERR_INVALID_ARG, "q1env_learner_sgd_step: vf->out_dim must be 1");
+    if (b->old_stride < pi->out_dim) return fail(Q1ENV_ERR_INVALID_ARG, "q1env_learner_sgd_step: old_stride smaller than the policy row");
+    // the in-kernel loss gradient is written for the reference's action structure (4 keys + continuous mouse: 10 outputs); any other
+    // Config takes the same path as q1env_learner_step + q1env_learner_adam
+    const bool fixed = h->p.num_keys == 4 && h->p.yaw_mode == 1 && pi->out_dim == 10;
+    if (!fixed) {
+        if (!b->stats_partials_dev) return fail(Q1ENV_ERR_INVALID_ARG, "q1env_learner_sgd_step: stats_partials_dev is required for this action structure");
+        q1env_learner_batch bb = *b;
+        bb.skip_reduce = 1;
+        if (int r = q1env_learner_step(h, pi, vf, ws_dev, splits, &bb)) return r;
+        return q1env_learner_adam(h, pi, vf, ws_dev, b->minibatch, splits, (float)b->minibatch, lr, beta1, beta2, eps, adam_state_dev, b->stats_partials_dev);
+    }
+    DeviceGuard guard(h->device);
+    const int64_t mb = b->minibatch;
+    const Ws w = carve_ws(ws_dev, mb, pi->out_dim, splits);
+    if (int r = launch_forward(h, w, mb, pi, vf, b->obs_dev, b->idx_dev, b->idx_cursor_dev, w.logits, w.value)) return r;
+    const float scale = (float)mb * learner_pi_upscale(), scale_v = (float)mb / learner_value_downscale();
+    q1learn::LossArgs la{};
+    la.p = h->p;
+    la.logits = w.logits; la.value = w.value; la.old_logits = b->old_logits_dev; la.old_stride = b->old_stride;
+    la.keys = b->keys_dev; la.mouse = b->mouse_dev; la.logp_old = b->logp_old_dev; la.adv = b->adv_dev; la.value_old = b->value_old_dev; la.vtarg = b->vtarg_dev;
+    la.kl_coeff_dev = b->kl_coeff_dev;
+    la.clip = b->clip_param; la.vf_clip = b->vf_clip_param; la.vf_coeff = b->vf_loss_coeff; la.ent_coeff = b->entropy_coeff;
+    la.inv_b = scale / (float)mb; la.inv_bv = scale_v / (float)mb;
+    la.stats_rows = w.stats_rows;
+    char* st = (char*)adam_state_dev;
+    const q1learn::BcArgs bca{(const long long*)st, (float*)(st + 8), beta1, beta2};
+    unsigned rows = 0;
+    if (int r = launch_backward(h, w, mb, splits, pi, vf, b->obs_dev, b->idx_dev, b->idx_cursor_dev, nullptr, nullptr, scale, scale_v, false, b->saturation_dev, &la,
+                                &bca, &rows))
+        return r;
+    return launch_adam(h, pi, vf, ws_dev, mb, splits, (float)mb, lr, beta1, beta2, eps, adam_state_dev, w.stats_rows, true, (int)rows);
 }
 
 }  // extern "C"

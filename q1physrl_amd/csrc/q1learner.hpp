@@ -40,6 +40,7 @@
 // operand) and from there every weight - which is what the first long training run of a second seed did before the conversions saturated.
 #pragma once
 #include "q1policy.hpp"
+#include "q1ppo_loss.hpp"
 
 namespace q1learn {
 
@@ -176,22 +177,57 @@ struct BwdNet {
 };
 
 template <uint32_t THREADS, uint32_t NVEC>
-__device__ __forceinline__ void stage_copy(unsigned char* dst, const uint16_t* __restrict__ src_, uint32_t tid) {
+struct StageRegs { uint4 v[(NVEC + THREADS - 1u) / THREADS]; };
+
+// straight 16-byte copies global -> LDS with ALL of a thread's loads in flight at once, in two halves so that a caller may put
+// independent work between the requests and the LDS stores that wait for them
+template <uint32_t THREADS, uint32_t NVEC>
+__device__ __forceinline__ void stage_issue(StageRegs<THREADS, NVEC>& r, const uint16_t* __restrict__ src_, uint32_t tid) {
     const uint4* src = reinterpret_cast<const uint4*>(src_);
-    uint4* d = reinterpret_cast<uint4*>(dst);
     constexpr uint32_t PER = (NVEC + THREADS - 1u) / THREADS;
-    uint4 v[PER];
 #pragma unroll
     for (uint32_t k = 0; k < PER; ++k) {
         const uint32_t c = k * THREADS + tid;
-        v[k] = c < NVEC ? src[c] : make_uint4(0, 0, 0, 0);
-    }
-#pragma unroll
-    for (uint32_t k = 0; k < PER; ++k) {
-        const uint32_t c = k * THREADS + tid;
-        if (c < NVEC) d[c] = v[k];
+        r.v[k] = c < NVEC ? src[c] : make_uint4(0, 0, 0, 0);
     }
 }
+template <uint32_t THREADS, uint32_t NVEC>
+__device__ __forceinline__ void stage_commit(unsigned char* dst, const StageRegs<THREADS, NVEC>& r, uint32_t tid) {
+    uint4* d = reinterpret_cast<uint4*>(dst);
+    constexpr uint32_t PER = (NVEC + THREADS - 1u) / THREADS;
+#pragma unroll
+    for (uint32_t k = 0; k < PER; ++k) {
+        const uint32_t c = k * THREADS + tid;
+        if (c < NVEC) d[c] = r.v[k];
+    }
+}
+template <uint32_t THREADS, uint32_t NVEC>
+__device__ __forceinline__ void stage_copy(unsigned char* dst, const uint16_t* __restrict__ src_, uint32_t tid) {
+    StageRegs<THREADS, NVEC> r;
+    stage_issue<THREADS, NVEC>(r, src_, tid);
+    stage_commit<THREADS, NVEC>(dst, r, tid);
+}
+
+// The fused SGD step (q1env_learner_sgd_step, round 4): the backward kernel computes its own dY - the PPO loss gradient of the tile's
+// samples (q1ppo_loss.hpp, the reference's action structure: 4 keys + continuous mouse) from the forward kernel's logits / value and
+// the trajectory batch - instead of reading rows a separate loss kernel wrote (11.5 us of a 129 us step at 32 768 samples: an
+// elementwise kernel that is three dependent gathers deep), while the tile's h2 vectors are in flight.  Lanes (c, 0) and (c, 1) both
+// evaluate sample c (the same instructions) and each keeps the outputs its operand slots hold.  Statistics: per-lane running sums
+// (half 0 only), one row per workgroup at the end: stats_rows float[gridDim.x][5] = (entropy, kl, -surrogate, total, vf) - the policy
+// network's workgroups fill 0..2 and their part of the total, the value network's the rest.
+struct LossArgs {
+    Params p;
+    const float* logits; const float* value;           // the forward kernel's outputs: minibatch-local rows (10 / 1 floats)
+    const float* old_logits; int old_stride;           // trajectory batch, rows idx[i] (q1env_learner_batch)
+    const uint8_t* keys; const float* mouse; const float* logp_old; const float* adv; const float* value_old; const float* vtarg;
+    const float* kl_coeff_dev;
+    float clip, vf_clip, vf_coeff, ent_coeff;
+    float inv_b, inv_bv;                                // (loss scale) / B of the policy / value network's dY
+    float* stats_rows;
+};
+// ... and thread 0 of workgroup 0 derives the optimizer's bias corrections of step count + 1 (torch: 1 - beta ** step, in double) while
+// the weight image's loads are in flight - the Adam kernel behind reads them (before: a one-wave kernel of its own, 5 us)
+struct BcArgs { const long long* step; float* bc; float beta1, beta2; };
 
 // 32x32 transposition on the matrix pipe: x0 / x1 = the T-format vectors (u = 0 / 1) of one 32-unit tile; returns the tile with
 // lane = unit sigma(c), registers = samples, as float32 (exact), to be packed with cvt8.
@@ -217,9 +253,10 @@ __device__ __forceinline__ void times_dtanh(f32x16& acc, const f16x8 h0, const f
     }
 }
 
+template <bool FUSED>
 __global__ void __launch_bounds__(256, 1)
 learner_backward_kernel(int n, const float* __restrict__ obs, const int64_t* __restrict__ idx, const int64_t* __restrict__ idx_cursor, BwdNet net_a,
-                        BwdNet net_b, int nets) {
+                        BwdNet net_b, int nets, LossArgs la, BcArgs bca) {
     if (idx && idx_cursor) idx += *idx_cursor;
     const uint32_t bgrid = nets == 2 ? gridDim.x / 2u : gridDim.x;
     const bool second = nets == 2 && blockIdx.x >= bgrid;
@@ -231,7 +268,18 @@ learner_backward_kernel(int n, const float* __restrict__ obs, const int64_t* __r
     const uint32_t tid = threadIdx.x;
     // stage both images: straight 16-byte copies (135168 + 20480 bytes) with ALL of a thread's loads in flight at once (a load -> store
     // loop would expose one L2 / HBM round trip per 4 KiB: 38 of them)
-    stage_copy<256, (uint32_t)(LDS_W2T / 16)>(l_w2t, net.w2t, tid);
+    {
+        StageRegs<256, (uint32_t)(LDS_W2T / 16)> r;
+        stage_issue<256, (uint32_t)(LDS_W2T / 16)>(r, net.w2t, tid);
+        if constexpr (FUSED) {
+            if (bca.step && blockIdx.x == 0 && tid == 0) {
+                const long long t = *bca.step + 1;
+                bca.bc[0] = (float)(1.0 - pow((double)bca.beta1, (double)t));
+                bca.bc[1] = (float)(1.0 - pow((double)bca.beta2, (double)t));
+            }
+        }
+        stage_commit<256, (uint32_t)(LDS_W2T / 16)>(l_w2t, r, tid);
+    }
     stage_copy<256, (uint32_t)(LDS_W3T / 16)>(l_w3t, net.w3t, tid);
     const uint32_t lane = tid & 63u, wave = tid >> 6;
     const uint32_t col = lane & 31u, half = lane >> 5;
@@ -250,12 +298,49 @@ learner_backward_kernel(int n, const float* __restrict__ obs, const int64_t* __r
     const unsigned char* w2trow = l_w2t + (size_t)col * ROW_BYTES + half * 16u;           // + 32 t1 rows, + K-step q * 32 B
     const unsigned char* w3trow = l_w3t + (size_t)col * W3T_ROW_BYTES + half * 16u;       // + 32 t2 rows, + ks * 32 B
     float amax = 0.0f;                                                                    // largest |gradient element| this lane converted
+    float st[5] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f};                                         // FUSED: this lane's statistics sums
+    float klc = 0.0f;
+    if constexpr (FUSED) klc = *la.kl_coeff_dev;
     for (uint32_t tile = bid * 4u + wave; tile < ntiles; tile += tstride) {
         const uint32_t s = tile * 32u + col;
         const bool live = s < (uint32_t)n;
+        const size_t tbase = (size_t)tile * TILE_VECS + lane;
+        // every global operand of the tile is requested up front (one wave per SIMD: nothing else hides an HBM round trip): the 16
+        // h2 vectors now, the 16 h1 vectors before the 128-MFMA data-gradient loop they are needed after
+        f16x8 hv[8][2];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) { hv[t][0] = net.h2T[tbase + (2u * t) * 64u]; hv[t][1] = net.h2T[tbase + (2u * t + 1u) * 64u]; }
         // ---- dY as B operand(s): K = output index o = 16 ks + 8 h + e
         f16x8 dyb0, dyb1;
-        {
+        if constexpr (FUSED) {
+            float y0[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) y0[e] = 0.0f;
+            const size_t src = live ? (idx ? (size_t)idx[s] : (size_t)s) : 0;
+            if (!second) {
+                float g[10];
+#pragma unroll
+                for (int c = 0; c < 10; ++c) g[c] = 0.0f;
+                if (live) {
+                    const PpoSample in{la.keys[src], la.mouse[src], la.logp_old[src], la.adv[src]};
+                    const PpoSums ps = ppo_policy_grad<true>(la.p, la.logits + (size_t)s * 10u, la.old_logits + src * (size_t)la.old_stride, in, la.clip,
+                                                             la.ent_coeff, klc, la.inv_b, g, 10);
+                    if (half == 0u) { st[0] += ps.ent; st[1] += ps.kl; st[2] += -ps.surr; st[3] += -ps.surr + klc * ps.kl - la.ent_coeff * ps.ent; }
+                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) y0[e] = half ? (e < 2 ? g[8 + e] : 0.0f) : g[e];
+            } else if (live) {
+                float vf;
+                const float dvf = ppo_value_grad(la.value[s], la.value_old[src], la.vtarg[src], la.vf_clip, vf);
+                if (half == 0u) { y0[0] = la.vf_coeff * dvf * la.inv_bv; st[3] += la.vf_coeff * vf; st[4] += vf; }
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                amax = fmaxf(fabsf(y0[e]), amax);
+                dyb0[e] = (_Float16)fminf(fmaxf(y0[e], -65504.0f), 65504.0f);
+                dyb1[e] = (_Float16)0.0f;
+            }
+        } else {
             const float* row = net.dy + (size_t)(live ? s : 0) * (uint32_t)net.dy_stride;
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
@@ -267,12 +352,6 @@ learner_backward_kernel(int n, const float* __restrict__ obs, const int64_t* __r
                 dyb1[e] = (_Float16)fminf(fmaxf(y1, -65504.0f), 65504.0f);
             }
         }
-        const size_t tbase = (size_t)tile * TILE_VECS + lane;
-        // every global operand of the tile is requested up front (one wave per SIMD: nothing else hides an HBM round trip): the 16
-        // h2 vectors now, the 16 h1 vectors before the 128-MFMA data-gradient loop they are needed after
-        f16x8 hv[8][2];
-#pragma unroll
-        for (int t = 0; t < 8; ++t) { hv[t][0] = net.h2T[tbase + (2u * t) * 64u]; hv[t][1] = net.h2T[tbase + (2u * t + 1u) * 64u]; }
         // ---- the weight-gradient kernel's small operands, transposed here: [x | 1] (inputs as "units" 0..7 of a T-format tile: element e
         //      < 4 of lane (c, h) = input 4 h + e) and dY (K slot = output index, so the transposition delivers lane = output)
         {
@@ -336,6 +415,19 @@ learner_backward_kernel(int n, const float* __restrict__ obs, const int64_t* __r
             const f16x8 z0 = cvt8_sat(acc1[t], 0, amax), z1 = cvt8_sat(acc1[t], 1, amax);
             store_n(net.dz1N + tbase, (uint32_t)t, transpose_tile(z0, z1, e0, e1));
         }
+    }
+    if constexpr (FUSED) {
+        __shared__ float red[4][5];
+#pragma unroll
+        for (int k = 0; k < 5; ++k)
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) st[k] += __shfl_down(st[k], off, 64);
+        if (lane == 0) {
+#pragma unroll
+            for (int k = 0; k < 5; ++k) red[wave][k] = st[k];
+        }
+        __syncthreads();
+        if (tid < 5u) la.stats_rows[(size_t)blockIdx.x * 5u + tid] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
     }
     // saturation report: one pair of fire-and-forget atomics per wave (NaN gradients compare false and show up as NaN in the max)
     if (net.sat) {
@@ -581,9 +673,35 @@ __device__ __forceinline__ float adam_update(float w, float g, float& m, float& 
     return w - (hp.lr / bc1) * (m / denom);
 }
 
+// The fused SGD step's bookkeeping (q1env_learner_sgd_step): the bias corrections were left by the backward kernel (BcArgs), so nothing
+// here depends on the step count - workgroup (0, 0) of the Adam kernel advances it and the minibatch cursor (their readers, the
+// forward / backward kernels of this step, are done) and folds the backward kernel's statistics rows into the running sums:
+// adam_tick_kernel's duties without its launch.  step == NULL: the stand-alone q1env_learner_adam, which runs adam_tick_kernel first.
+struct AdamTick {
+    long long* step; long long* idx_cursor; long long minibatch;
+    const float* stats_rows; int nrows; float inv_batch; float* stats_acc;
+};
+
 __global__ void __launch_bounds__(256)
 learner_adam_kernel(const float* __restrict__ pa, const float* __restrict__ pb, AdamNet na, AdamNet nb, int splits, float inv_scale_a,
-                    float inv_scale_b, AdamHyper hp, const float* __restrict__ bc) {
+                    float inv_scale_b, AdamHyper hp, const float* __restrict__ bc, AdamTick tk) {
+    if (tk.step && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x >= 192u) {           // the workgroup's last wave: after its own element
+        const uint32_t lane = threadIdx.x - 192u;
+        if (tk.stats_rows) {
+            float s[5] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+            for (int b = (int)lane; b < tk.nrows; b += 64)
+#pragma unroll
+                for (int k = 0; k < 5; ++k) s[k] += tk.stats_rows[(size_t)b * 5 + k];
+#pragma unroll
+            for (int k = 0; k < 5; ++k)
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) s[k] += __shfl_down(s[k], off, 64);
+            if (lane == 0)
+#pragma unroll
+                for (int k = 0; k < 5; ++k) tk.stats_acc[k] += s[k] * tk.inv_batch;
+        }
+        if (lane == 0) { *tk.step += 1; *tk.idx_cursor += tk.minibatch; }
+    }
     const bool second = blockIdx.y == 1;
     const float inv_scale = second ? inv_scale_b : inv_scale_a;
     const float* __restrict__ partial = second ? pb : pa;

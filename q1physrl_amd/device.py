@@ -270,6 +270,10 @@ class DeviceEnv:
         _lib.check(self._lib.q1env_learner_adam(self._h, C.byref(pi), C.byref(vf), ws, int(minibatch), int(splits), float(grad_scale), float(lr),
                                                 float(beta1), float(beta2), float(eps), state, stats_partials or None))
 
+    def learner_sgd_step_dev(self, pi, vf, ws, splits, batch, lr, beta1, beta2, eps, state):
+        _lib.check(self._lib.q1env_learner_sgd_step(self._h, C.byref(pi), C.byref(vf), ws, int(splits), C.byref(batch), float(lr), float(beta1),
+                                                    float(beta2), float(eps), state))
+
     def learner_step_dev(self, pi, vf, ws, splits, batch):
         _lib.check(self._lib.q1env_learner_step(self._h, C.byref(pi), C.byref(vf), ws, int(splits), C.byref(batch)))
 

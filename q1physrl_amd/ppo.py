@@ -124,10 +124,11 @@ class NativeStep:
         self.env._dev.learner_adam_dev(self.pi, self.vf, self.ws.data_ptr(), self.mb, self.splits, float(self.mb), lr, betas[0], betas[1], eps,
                                        self.adam_state.data_ptr(), self.partials.data_ptr())
 
-    def step(self, full, idx, clip_param, vf_clip_param, vf_loss_coeff, entropy_coeff, klc_dev, skip_reduce=False, use_cursor=False):
+    def step(self, full, idx, clip_param, vf_clip_param, vf_loss_coeff, entropy_coeff, klc_dev, skip_reduce=False, use_cursor=False, adam=None):
         """full: dict of the whole trajectory batch (obs (total,6), old_logits (total,W), keys_packed, mouse, logp, adv, value, vtarg);
         idx int64 (B,) or None.  Returns the statistics vector (STAT_KEYS order, means over the minibatch).
-        skip_reduce: the parameter gradients stay as split-K partial sums for adam() (.grad is then written by adam())."""
+        skip_reduce: the parameter gradients stay as split-K partial sums for adam() (.grad is then written by adam()).
+        adam = (lr, betas, eps): the optimizer step too, in the same call (same result as step(skip_reduce=True) + adam(lr, betas, eps))."""
         L = self._lib
         ol = full["old_logits"]
         # use_cursor: idx is a whole epoch's permutation and the minibatch is idx[cursor : cursor + mb] with the device-resident cursor
@@ -139,6 +140,10 @@ class NativeStep:
                              full["keys_packed"].data_ptr(), full["mouse"].data_ptr(), full["logp"].data_ptr(), full["adv"].data_ptr(),
                              full["value"].data_ptr(), full["vtarg"].data_ptr(), clip_param, vf_clip_param, vf_loss_coeff, entropy_coeff,
                              klc_dev.data_ptr(), self.partials.data_ptr(), int(bool(skip_reduce)), self.saturation.data_ptr())
+        if adam is not None:                         # the whole SGD step as one call (q1env_learner_sgd_step): step(skip_reduce) + adam() in four launches
+            lr, betas, eps = adam
+            self.env._dev.learner_sgd_step_dev(self.pi, self.vf, self.ws.data_ptr(), self.splits, b, lr, betas[0], betas[1], eps, self.adam_state.data_ptr())
+            return None
         self.env._dev.learner_step_dev(self.pi, self.vf, self.ws.data_ptr(), self.splits, b)
         if skip_reduce:
             return None                              # adam() folds the statistics into self.stats_acc on the device
@@ -218,12 +223,12 @@ class PPOLearner:
         if self.native:
             own_adam = self.world == 1 and self.native_adam       # no all-reduce between gradients and optimizer: one fused kernel
             # own optimizer: the minibatch is a window of the epoch's permutation (self._perm) at the cursor adam() advances
-            stats = self._native.step(self._full, self._perm if own_adam else self._idx, self.clip_param, self.vf_clip_param, self.vf_loss_coeff,
-                                      self.entropy_coeff, self._klc, skip_reduce=own_adam, use_cursor=own_adam)
             if own_adam:                              # statistics accumulate in self._native.stats_acc
                 g = self.opt.param_groups[0]
-                self._native.adam(g["lr"], g["betas"], g["eps"])
+                self._native.step(self._full, self._perm, self.clip_param, self.vf_clip_param, self.vf_loss_coeff, self.entropy_coeff, self._klc,
+                                  skip_reduce=True, use_cursor=True, adam=(g["lr"], g["betas"], g["eps"]))
                 return None
+            stats = self._native.step(self._full, self._idx, self.clip_param, self.vf_clip_param, self.vf_loss_coeff, self.entropy_coeff, self._klc)
             if self.world > 1:
                 allreduce_grads_([p for p in self.policy.parameters()], self.world)
             self.opt.step()

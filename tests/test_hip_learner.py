@@ -307,6 +307,50 @@ def test_minibatch_cursor_selects_the_same_rows_as_an_index_copy():
     env.close()
 
 
+@pytest.mark.parametrize("mb,n_envs,over", [(1024, 512, {}), (1000, 500, {}), (128, 64, {}), (1024, 512, dict(allow_jump=False))])
+def test_sgd_step_equals_step_plus_adam(mb, n_envs, over):
+    """q1env_learner_sgd_step (round 4: the backward kernel computes the PPO loss gradient of its own samples, the optimizer's
+    bookkeeping rides in the backward and Adam kernels - four launches) against q1env_learner_step(skip_reduce) + q1env_learner_adam
+    (six launches): masters, gradients, moments, step count and cursor bit for bit over several steps; the running statistics to float32
+    rounding (summed per workgroup instead of per block of 256 samples).  Ragged minibatches and a three-key Config (which takes the
+    two-call path inside) included."""
+    import copy
+    import torch
+    from q1physrl_amd import policy as P, ppo, sampler as S
+    torch.manual_seed(4)
+    cfg, env = make_env(n_envs, time_limit=1.0, **over)
+    pol_a = _policy(5, 2.0, **({"num_keys": 3} if over else {}))
+    pol_b = copy.deepcopy(pol_a)
+    smp = S.GpuSampler(env, P.FusedPolicyForward(pol_a, env), horizon=8)
+    tr = smp.collect()
+    adv, vt = smp.advantages(tr, 0.99, 0.95)
+    t, n = tr["reward"].shape
+    total = t * n
+    full = {"obs": tr["obs"][:t].reshape(total, 6).contiguous(), "old_logits": tr["logits"].reshape(total, -1).contiguous(),
+            "keys_packed": tr["keys"].reshape(-1), "mouse": tr["mouse"].reshape(-1), "logp": tr["logp"].reshape(-1),
+            "adv": ((adv - adv.mean()) / adv.std()).reshape(-1).contiguous(), "value": tr["value"][:t].reshape(-1).contiguous(),
+            "vtarg": vt.reshape(-1).contiguous()}
+    klc = torch.tensor(0.2, device="cuda")
+    perm = torch.randperm(total, device="cuda")
+    a, b = ppo.NativeStep(pol_a, env, mb, splits=8), ppo.NativeStep(pol_b, env, mb, splits=8)
+    hp = (3e-4, (0.9, 0.999), 1e-8)
+    for k in range(total // mb):
+        a.step(full, perm, 0.3, 10.0, 1.0, 0.01, klc, skip_reduce=True, use_cursor=True)
+        a.adam(*hp)
+        b.step(full, perm, 0.3, 10.0, 1.0, 0.01, klc, skip_reduce=True, use_cursor=True, adam=hp)
+        torch.cuda.synchronize()
+        for (name, p), q in zip(pol_a.named_parameters(), pol_b.parameters()):
+            assert torch.equal(p, q) and torch.equal(p.grad, q.grad), (k, name)
+        for lo, hi in ((0, 16), (72, 80), (256, None)):                         # count + bias corrections, cursor, moments
+            assert torch.equal(a.adam_state[lo:hi], b.adam_state[lo:hi]), (k, lo)
+        assert torch.equal(a.ws[:a.ws.numel() // 2], b.ws[:b.ws.numel() // 2])                                             # the weight images lead the workspace
+        sa, sb = a.stats_acc.cpu().numpy(), b.stats_acc.cpu().numpy()
+        assert np.allclose(sa, sb, rtol=2e-5, atol=1e-6), (k, sa, sb)
+        assert torch.equal(a.saturation, b.saturation)
+    assert int(b.cursor.item()) == (total // mb) * mb and int(b.adam_state[:8].view(torch.int64)[0]) == total // mb
+    env.close()
+
+
 def test_native_training_learns_strafe_jumping_in_seconds():
     """End-to-end regression of the whole GPU-resident stack (resident sampler + native learner, round 2's hyper-parameters): 200
     iterations = 0.42 G env-steps in ~17 s must take the zero-start reward from ~1 700 (plain running) past 4 200 - strafe-jumping

@@ -3,6 +3,7 @@ minibatch (32 768 = tools/train_ppo.py's) on synthetic rows, HIP events around e
 `rocprofv3 --kernel-trace --stats` / `--pmc ...` as well (tools/profile_learner.sh).  Prints one JSON line."""
 import argparse
 import json
+import time
 import sys
 import os
 
@@ -15,6 +16,7 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--splits", type=int, default=32)
     ap.add_argument("--phase", default="all", choices=["all", "forward", "backward", "step"])
+    ap.add_argument("--two-call", action="store_true", help="the step as q1env_learner_step + q1env_learner_adam instead of q1env_learner_sgd_step")
     args = ap.parse_args()
     import torch
     from q1physrl_amd import policy as P, ppo
@@ -38,11 +40,15 @@ def main():
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
+        t0 = time.perf_counter()
         for _ in range(n):
             fn()
+        host_us.append((time.perf_counter() - t0) * 1e6 / n)      # what the host needed to ENQUEUE one call (the queue does not fill at these counts)
         e1.record()
         torch.cuda.synchronize()
         return e0.elapsed_time(e1) * 1e3 / n
+
+    host_us = []
 
     out = {"mb": mb, "splits": args.splits, "steps": args.steps}
     if args.phase in ("all", "forward"):
@@ -60,9 +66,13 @@ def main():
         klc = torch.full((1,), 0.2, device="cuda")
 
         def one():
-            nat.step(full, idx, 0.1, 7500.0, 1.0, 0.01, klc, skip_reduce=True)
-            nat.adam(3e-5)
+            if args.two_call:                            # q1env_learner_step + q1env_learner_adam: six launches
+                nat.step(full, idx, 0.1, 7500.0, 1.0, 0.01, klc, skip_reduce=True)
+                nat.adam(3e-5)
+            else:                                        # q1env_learner_sgd_step: four (round 4; what PPOLearner runs)
+                nat.step(full, idx, 0.1, 7500.0, 1.0, 0.01, klc, skip_reduce=True, adam=(3e-5, (0.9, 0.999), 1e-8))
         out["eager_step_us"] = timed(one, args.steps)
+        out["eager_step_host_enqueue_us"] = host_us[-1]
         gph = torch.cuda.CUDAGraph()
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
