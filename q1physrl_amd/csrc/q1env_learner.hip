@@ -134,8 +134,7 @@ int launch_backward(q1env* h, const Ws& w, int64_t mb, int splits, const q1env_l
     if (!reduce) { HIP_TRY(hipGetLastError()); return 0; }          // q1env_learner_adam sums the partials itself
     const q1learn::Grads ga{pi->gw1, pi->gb1, pi->gw2, pi->gb2, pi->gw3, pi->gb3, pi->out_dim};
     const q1learn::Grads gb{vf->gw1, vf->gb1, vf->gw2, vf->gb2, vf->gw3, vf->gb3, vf->out_dim};
-    const unsigned max_out = (unsigned)(pi->out_dim > vf->out_dim ? pi->out_dim : vf->out_dim);
-    const unsigned elems = 65536u + 256u + 256u * 6u + 256u + max_out * 256u + max_out;
+    const unsigned elems = (unsigned)q1learn::PARTIAL_FLOATS;            // one thread per slot of the partial-sum slab, in the slab's order
     hipLaunchKernelGGL(q1learn::learner_reduce_kernel, dim3((elems + 255u) / 256u, 2), dim3(256), 0, h->stream, (const float*)w.net[0].partial,
                        (const float*)w.net[1].partial, ga, gb, splits, 1.0f / grad_scale, 1.0f / grad_scale_v);
     HIP_TRY(hipGetLastError());
@@ -264,8 +263,7 @@ int launch_adam(q1env_t* h, const q1env_learner_net* pi, const q1env_learner_net
     const q1learn::AdamNet nb{const_cast<float*>(vf->w1), const_cast<float*>(vf->b1), const_cast<float*>(vf->w2), const_cast<float*>(vf->b2),
                               const_cast<float*>(vf->w3), const_cast<float*>(vf->b3),
                               q1learn::Grads{vf->gw1, vf->gb1, vf->gw2, vf->gb2, vf->gw3, vf->gb3, vf->out_dim}, m_vf, v_vf, w.net[1].w23, w.net[1].w2t, w.net[1].w3t};
-    const unsigned max_out = (unsigned)(pi->out_dim > vf->out_dim ? pi->out_dim : vf->out_dim);
-    const unsigned elems = 65536u + 256u + 256u * 6u + 256u + max_out * 257u;
+    const unsigned elems = (unsigned)q1learn::PARTIAL_FLOATS;            // one thread per slot of the partial-sum slab, in the slab's order
     hipLaunchKernelGGL(q1learn::learner_adam_kernel, dim3((elems + 255u) / 256u, 2), dim3(256), 0, h->stream, (const float*)w.net[0].partial,
                        (const float*)w.net[1].partial, na, nb, splits, 1.0f / (grad_scale * learner_pi_upscale()), learner_value_downscale() / grad_scale,
                        q1learn::AdamHyper{lr, beta1, beta2, eps}, (const float*)bc, tick);

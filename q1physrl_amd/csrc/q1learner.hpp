@@ -253,6 +253,41 @@ __device__ __forceinline__ void times_dtanh(f32x16& acc, const f16x8 h0, const f
     }
 }
 
+// FUSED: the per-sample inputs of a tile (everything that hangs on the gathered row index: two dependent round trips) are requested
+// one tile AHEAD - the first tile's before the weight staging, the next tile's in front of the current tile's 128-MFMA loop - so that a
+// lone wave per SIMD never sits on them (round 4: they were the front of every tile's critical path).
+struct TileIn {
+    uint32_t kb; float mouse, logp_old, adv; float lg[10], ol[10];       // policy network's workgroups
+    float v, vo, vt;                                                     // value network's
+    float x[4];                                                          // observation inputs 4 half + e of the lane's sample (both)
+};
+__device__ __forceinline__ size_t tile_src(const int64_t* __restrict__ idx, uint32_t s, bool live) {
+    return live ? (idx ? (size_t)idx[s] : (size_t)s) : 0;
+}
+__device__ __forceinline__ void tile_inputs(TileIn& ti, const LossArgs& la, const float* __restrict__ obs, bool second, bool live, uint32_t s, size_t src,
+                                            uint32_t half) {
+    ti.kb = 0u; ti.mouse = ti.logp_old = ti.adv = ti.v = ti.vo = ti.vt = 0.0f;
+#pragma unroll
+    for (int c = 0; c < 10; ++c) { ti.lg[c] = 0.0f; ti.ol[c] = 0.0f; }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) ti.x[e] = 0.0f;
+    if (!live) return;
+    if (!second) {
+        ti.kb = la.keys[src]; ti.mouse = la.mouse[src]; ti.logp_old = la.logp_old[src]; ti.adv = la.adv[src];
+        const float* row = la.logits + (size_t)s * 10u;
+        const float* old = la.old_logits + src * (size_t)la.old_stride;
+#pragma unroll
+        for (int c = 0; c < 10; ++c) { ti.lg[c] = row[c]; ti.ol[c] = old[c]; }
+    } else {
+        ti.v = la.value[s]; ti.vo = la.value_old[src]; ti.vt = la.vtarg[src];
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int i = 4 * (int)half + e;
+        ti.x[e] = i < OBS ? obs[src * OBS + (uint32_t)i] : (i == OBS ? 1.0f : 0.0f);
+    }
+}
+
 template <bool FUSED>
 __global__ void __launch_bounds__(256, 1)
 learner_backward_kernel(int n, const float* __restrict__ obs, const int64_t* __restrict__ idx, const int64_t* __restrict__ idx_cursor, BwdNet net_a,
@@ -266,12 +301,25 @@ learner_backward_kernel(int n, const float* __restrict__ obs, const int64_t* __r
     unsigned char* l_w2t = lds;
     unsigned char* l_w3t = lds + LDS_W2T;
     const uint32_t tid = threadIdx.x;
+#ifdef Q1_BWD_STAMPS
+    const uint64_t stamp0 = wall_clock64();
+#endif
+    const uint32_t lane = tid & 63u, wave = tid >> 6;
+    const uint32_t col = lane & 31u, half = lane >> 5;
+    const uint32_t ntiles = ((uint32_t)n + 31u) / 32u;
+    const uint32_t tstride = bgrid * 4u;
+    TileIn cur, nxt;
+    size_t src_next = 0;
     // stage both images: straight 16-byte copies (135168 + 20480 bytes) with ALL of a thread's loads in flight at once (a load -> store
     // loop would expose one L2 / HBM round trip per 4 KiB: 38 of them)
     {
+        const uint32_t tile0 = bid * 4u + wave, s0 = tile0 * 32u + col;
+        const bool live0 = tile0 < ntiles && s0 < (uint32_t)n;
+        if constexpr (FUSED) src_next = tile_src(idx, s0, live0);
         StageRegs<256, (uint32_t)(LDS_W2T / 16)> r;
         stage_issue<256, (uint32_t)(LDS_W2T / 16)>(r, net.w2t, tid);
         if constexpr (FUSED) {
+            tile_inputs(cur, la, obs, second, live0, s0, src_next, half);          // the first tile's inputs land under the staging
             if (bca.step && blockIdx.x == 0 && tid == 0) {
                 const long long t = *bca.step + 1;
                 bca.bc[0] = (float)(1.0 - pow((double)bca.beta1, (double)t));
@@ -281,9 +329,15 @@ learner_backward_kernel(int n, const float* __restrict__ obs, const int64_t* __r
         stage_commit<256, (uint32_t)(LDS_W2T / 16)>(l_w2t, r, tid);
     }
     stage_copy<256, (uint32_t)(LDS_W3T / 16)>(l_w3t, net.w3t, tid);
-    const uint32_t lane = tid & 63u, wave = tid >> 6;
-    const uint32_t col = lane & 31u, half = lane >> 5;
+#ifdef Q1_BWD_STAMPS      // diagnostic build (tools/exp_bwd_stamps.py): where does a wave's time go?  100 MHz stamps of wave 0, in statistics rows 1024..
+    float stamps[5] = {0, 0, 0, 0, 0};
+    int stamp_tile = 0;
+#define Q1_STAMP(k) do { if (FUSED && stamp_tile == 0) stamps[k] = (float)(wall_clock64() - stamp0) * 0.01f; } while (0)
+#else
+#define Q1_STAMP(k) do { } while (0)
+#endif
     __syncthreads();
+    Q1_STAMP(0);
     // selection operands of the transposition: E0[K][c] = [K == c], E1[K][c] = [K == c - 16]; a lane (c, h) holds K = 8 h + e
     f16x8 e0, e1;
 #pragma unroll
@@ -293,8 +347,6 @@ learner_backward_kernel(int n, const float* __restrict__ obs, const int64_t* __r
     }
     const f32x16 zero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     const int OUT = net.out_dim;
-    const uint32_t ntiles = ((uint32_t)n + 31u) / 32u;
-    const uint32_t tstride = bgrid * 4u;
     const unsigned char* w2trow = l_w2t + (size_t)col * ROW_BYTES + half * 16u;           // + 32 t1 rows, + K-step q * 32 B
     const unsigned char* w3trow = l_w3t + (size_t)col * W3T_ROW_BYTES + half * 16u;       // + 32 t2 rows, + ks * 32 B
     float amax = 0.0f;                                                                    // largest |gradient element| this lane converted
@@ -306,32 +358,35 @@ learner_backward_kernel(int n, const float* __restrict__ obs, const int64_t* __r
         const bool live = s < (uint32_t)n;
         const size_t tbase = (size_t)tile * TILE_VECS + lane;
         // every global operand of the tile is requested up front (one wave per SIMD: nothing else hides an HBM round trip): the 16
-        // h2 vectors now, the 16 h1 vectors before the 128-MFMA data-gradient loop they are needed after
+        // h2 vectors now, the 16 h1 vectors before the 128-MFMA data-gradient loop they are needed after.  (Round 4 tried requesting
+        // them a phase earlier still - h2 of the next tile after this tile's dZ2 phase, h1 at the tile's start: 506 registers, the
+        // second tile of a wave twice as slow; tools/exp_bwd_stamps.py shows the phases are issue-bound, not waiting for these loads.)
         f16x8 hv[8][2];
 #pragma unroll
         for (int t = 0; t < 8; ++t) { hv[t][0] = net.h2T[tbase + (2u * t) * 64u]; hv[t][1] = net.h2T[tbase + (2u * t + 1u) * 64u]; }
         // ---- dY as B operand(s): K = output index o = 16 ks + 8 h + e
         f16x8 dyb0, dyb1;
+        const uint32_t tile_n = tile + tstride, s_n = tile_n * 32u + col;
+        const bool live_n = tile_n < ntiles && s_n < (uint32_t)n;
         if constexpr (FUSED) {
+            src_next = tile_src(idx, s_n, live_n);                                  // the next tile's row index: requested now, used before the MFMA loop
             float y0[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) y0[e] = 0.0f;
-            const size_t src = live ? (idx ? (size_t)idx[s] : (size_t)s) : 0;
             if (!second) {
                 float g[10];
 #pragma unroll
                 for (int c = 0; c < 10; ++c) g[c] = 0.0f;
                 if (live) {
-                    const PpoSample in{la.keys[src], la.mouse[src], la.logp_old[src], la.adv[src]};
-                    const PpoSums ps = ppo_policy_grad<true>(la.p, la.logits + (size_t)s * 10u, la.old_logits + src * (size_t)la.old_stride, in, la.clip,
-                                                             la.ent_coeff, klc, la.inv_b, g, 10);
+                    const PpoSample in{cur.kb, cur.mouse, cur.logp_old, cur.adv};
+                    const PpoSums ps = ppo_policy_grad<true>(la.p, cur.lg, cur.ol, in, la.clip, la.ent_coeff, klc, la.inv_b, g, 10);
                     if (half == 0u) { st[0] += ps.ent; st[1] += ps.kl; st[2] += -ps.surr; st[3] += -ps.surr + klc * ps.kl - la.ent_coeff * ps.ent; }
                 }
 #pragma unroll
                 for (int e = 0; e < 8; ++e) y0[e] = half ? (e < 2 ? g[8 + e] : 0.0f) : g[e];
             } else if (live) {
                 float vf;
-                const float dvf = ppo_value_grad(la.value[s], la.value_old[src], la.vtarg[src], la.vf_clip, vf);
+                const float dvf = ppo_value_grad(cur.v, cur.vo, cur.vt, la.vf_clip, vf);
                 if (half == 0u) { y0[0] = la.vf_coeff * dvf * la.inv_bv; st[3] += la.vf_coeff * vf; st[4] += vf; }
             }
 #pragma unroll
@@ -356,12 +411,13 @@ learner_backward_kernel(int n, const float* __restrict__ obs, const int64_t* __r
         //      < 4 of lane (c, h) = input 4 h + e) and dY (K slot = output index, so the transposition delivers lane = output)
         {
             f16x8 x0;
-            const size_t src = live ? (idx ? (size_t)idx[s] : (size_t)s) : 0;
+            const size_t src = FUSED ? 0 : tile_src(idx, s, live);
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const int i = 4 * (int)half + e;
                 float v = 0.0f;
-                if (live && e < 4) v = i < OBS ? obs[src * OBS + (uint32_t)i] : (i == OBS ? 1.0f : 0.0f);
+                if constexpr (FUSED) { if (e < 4) v = cur.x[e]; }
+                else if (live && e < 4) v = i < OBS ? obs[src * OBS + (uint32_t)i] : (i == OBS ? 1.0f : 0.0f);
                 x0[e] = (_Float16)fminf(fmaxf(v, -65504.0f), 65504.0f);
             }
             const f16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -371,6 +427,7 @@ learner_backward_kernel(int n, const float* __restrict__ obs, const int64_t* __r
             const f32x16 dd = transpose_tile(dyb0, dyb1, e0, e1);
             net.dyN[sb] = cvt8(dd, 0); net.dyN[sb + 64u] = cvt8(dd, 1);
         }
+        Q1_STAMP(1);
         // ---- dH2^T = W3^T dY^T, dZ2 = dH2 (1 - h2^2); h2 and dZ2 leave in N-format
         f16x8 dzb[8][2];
 #pragma unroll
@@ -388,6 +445,8 @@ learner_backward_kernel(int n, const float* __restrict__ obs, const int64_t* __r
         }
 #pragma unroll
         for (int t = 0; t < 8; ++t) { hv[t][0] = net.h1T[tbase + (2u * t) * 64u]; hv[t][1] = net.h1T[tbase + (2u * t + 1u) * 64u]; }
+        if constexpr (FUSED) tile_inputs(nxt, la, obs, second, live_n, s_n, src_next, half);     // lands under the MFMA loop
+        Q1_STAMP(2);
         // ---- dH1^T = W2^T dZ2^T: 16 K-steps (j) x 8 row tiles (k)
         f32x16 acc1[8];
 #pragma unroll
@@ -408,6 +467,7 @@ learner_backward_kernel(int n, const float* __restrict__ obs, const int64_t* __r
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
+        Q1_STAMP(3);
         // ---- dZ1 = dH1 (1 - h1^2); h1 and dZ1 leave in N-format
 #pragma unroll
         for (int t = 0; t < 8; ++t) {
@@ -415,7 +475,20 @@ learner_backward_kernel(int n, const float* __restrict__ obs, const int64_t* __r
             const f16x8 z0 = cvt8_sat(acc1[t], 0, amax), z1 = cvt8_sat(acc1[t], 1, amax);
             store_n(net.dz1N + tbase, (uint32_t)t, transpose_tile(z0, z1, e0, e1));
         }
+        if constexpr (FUSED) cur = nxt;
+        Q1_STAMP(4);
+#ifdef Q1_BWD_STAMPS
+        ++stamp_tile;
+#endif
     }
+#ifdef Q1_BWD_STAMPS
+    if constexpr (FUSED) {
+        if (tid == 0) {
+            for (int k = 0; k < 5; ++k) la.stats_rows[(size_t)(1024u + blockIdx.x) * 5u + k] = stamps[k];
+            la.stats_rows[(size_t)(1536u + blockIdx.x) * 5u] = (float)(wall_clock64() - stamp0) * 0.01f;
+        }
+    }
+#endif
     if constexpr (FUSED) {
         __shared__ float red[4][5];
 #pragma unroll
@@ -573,16 +646,52 @@ struct Grads {
     int out_dim;
 };
 
-// value of product p at (A-lane index ia, B-lane index cb), summed over the splits
-__device__ __forceinline__ float partial_sum(const float* __restrict__ partial, int splits, uint32_t p, uint32_t ia, uint32_t cb) {
-    const uint32_t h = (ia >> 2) & 1u, r = (ia & 3u) + 4u * (ia >> 3);
-    const size_t off = ((size_t)p * 16u + r) * 64u + cb + 32u * h;
-    // (round 4: 8 and 32 of these loads in flight per thread instead of one changed neither this kernel's 13 us nor the fused Adam
-    // kernel's 15 us - profiles/r4_learner_step_kernel_stats.txt; the simple loop stays)
-    float s = 0.0f;
-    int k = 0;
-    for (; k < splits; ++k) s += partial[(size_t)k * PARTIAL_STRIDE + off];
+// The reduction and the optimizer walk the split-K partial sums in the slab's OWN order: a thread owns slot off = product x 1024 +
+// register row x 64 + lane, so a wave reads 256 contiguous bytes per split and the grid streams every slab front to back, eight
+// splits in flight per thread (round 4; in parameter order - two 128-byte pieces 4 KB apart per wave and split, one load in flight -
+// the fused Adam kernel took 15 us for 23 MB, with eight in flight 25: the more splits open at once, the fewer DRAM pages reused; in slab
+// order 13 us, with eight in flight 7.3).  slot_of() is the inverse of the products' index map (sigma is its own inverse): which
+// parameter a slot holds; slots that belong to none (columns of the [x | 1] products that only the bias gradients use, output rows beyond
+// out_dim) retire.
+struct Slot { int arr; uint32_t i, e, x, y; };     // arr: 0 w2[x][y], 1 b2, 2 w1, 3 b1, 4 w3[x][y], 5 b3, -1 none; i = index in arr, e = flat index [w2|b2|w1|b1|w3|b3]
+__device__ __forceinline__ Slot slot_of(uint32_t off, uint32_t OUT) {
+    const uint32_t nW2 = 65536u, nB2 = 256u, nW1 = 256u * (uint32_t)OBS, nB1 = 256u, nW3 = OUT * 256u;
+    const uint32_t p = off >> 10, r = (off >> 6) & 15u, ln = off & 63u, h = ln >> 5, cb = ln & 31u;
+    const uint32_t ia = (r & 3u) + 4u * h + 8u * (r >> 2);
+    const uint32_t ua = sigma(ia), ub = sigma(cb);                       // the A-side / B-side index within the 32 x 32 tile
+    Slot s{-1, 0, 0, 0, 0};
+    if (p < 64u) {
+        s.x = 32u * (p >> 3) + ua; s.y = 32u * (p & 7u) + ub; s.arr = 0; s.i = s.x * 256u + s.y; s.e = s.i;
+    } else if (p < 72u) {
+        if (ub == (uint32_t)OBS) { s.arr = 1; s.i = 32u * (p - 64u) + ua; s.e = nW2 + s.i; }
+    } else if (p < 80u) {
+        const uint32_t k = 32u * (p - 72u) + ua;
+        if (ub < (uint32_t)OBS) { s.arr = 2; s.i = k * (uint32_t)OBS + ub; s.e = nW2 + nB2 + s.i; }
+        else if (ub == (uint32_t)OBS) { s.arr = 3; s.i = k; s.e = nW2 + nB2 + nW1 + k; }
+    } else if (p < 88u) {
+        if (ia < OUT) { s.x = ia; s.y = 32u * (p - 80u) + ub; s.arr = 4; s.i = s.x * 256u + s.y; s.e = nW2 + nB2 + nW1 + nB1 + s.i; }
+    } else if (p == 88u) {
+        if (ub == (uint32_t)OBS && ia < OUT) { s.arr = 5; s.i = ia; s.e = nW2 + nB2 + nW1 + nB1 + nW3 + ia; }
+    }
     return s;
+}
+__device__ __forceinline__ float slab_sum(const float* __restrict__ partial, int splits, uint32_t off) {
+    constexpr int D = 8;                                                 // loads in flight; added in split order (the bits do not depend on D)
+    float g = 0.0f;
+    int k = 0;
+    for (; k + D <= splits; k += D) {
+        float t[D];
+#pragma unroll
+        for (int u = 0; u < D; ++u) t[u] = partial[(size_t)(k + u) * PARTIAL_STRIDE + off];
+#pragma unroll
+        for (int u = 0; u < D; ++u) g += t[u];
+    }
+    for (; k < splits; ++k) g += partial[(size_t)k * PARTIAL_STRIDE + off];
+    return g;
+}
+__device__ __forceinline__ float* slot_ptr(const Slot& s, float* w2, float* b2, float* w1, float* b1, float* w3, float* b3) {
+    float* const base = s.arr == 0 ? w2 : s.arr == 1 ? b2 : s.arr == 2 ? w1 : s.arr == 3 ? b1 : s.arr == 4 ? w3 : b3;
+    return base + s.i;
 }
 
 __global__ void __launch_bounds__(256)
@@ -591,32 +700,11 @@ learner_reduce_kernel(const float* __restrict__ pa, const float* __restrict__ pb
     const float inv_scale = second ? inv_scale_b : inv_scale_a;
     const float* __restrict__ partial = second ? pb : pa;
     const Grads g = second ? gb : ga;
-    const uint32_t OUT = (uint32_t)g.out_dim;
-    const uint32_t nW2 = 65536u, nB2 = 256u, nW1 = 256u * (uint32_t)OBS, nB1 = 256u, nW3 = OUT * 256u, nB3 = OUT;
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < nW2) {
-        const uint32_t j = i >> 8, k = i & 255u;
-        g.w2[i] = inv_scale * partial_sum(partial, splits, 8u * (j >> 5) + (k >> 5), sigma(j & 31u), sigma(k & 31u));
-        return;
-    }
-    i -= nW2;
-    if (i < nB2) { g.b2[i] = inv_scale * partial_sum(partial, splits, 64u + (i >> 5), sigma(i & 31u), sigma((uint32_t)OBS)); return; }
-    i -= nB2;
-    if (i < nW1) {
-        const uint32_t k = i / (uint32_t)OBS, c = i % (uint32_t)OBS;
-        g.w1[i] = inv_scale * partial_sum(partial, splits, 72u + (k >> 5), sigma(k & 31u), sigma(c));
-        return;
-    }
-    i -= nW1;
-    if (i < nB1) { g.b1[i] = inv_scale * partial_sum(partial, splits, 72u + (i >> 5), sigma(i & 31u), sigma((uint32_t)OBS)); return; }
-    i -= nB1;
-    if (i < nW3) {
-        const uint32_t o = i >> 8, j = i & 255u;
-        g.w3[i] = inv_scale * partial_sum(partial, splits, 80u + (j >> 5), o, sigma(j & 31u));
-        return;
-    }
-    i -= nW3;
-    if (i < nB3) g.b3[i] = inv_scale * partial_sum(partial, splits, 88u, i, sigma((uint32_t)OBS));
+    const uint32_t off = blockIdx.x * blockDim.x + threadIdx.x;
+    if (off >= (uint32_t)PARTIAL_FLOATS) return;
+    const Slot sl = slot_of(off, (uint32_t)g.out_dim);
+    if (sl.arr < 0) return;
+    *slot_ptr(sl, g.w2, g.b2, g.w1, g.b1, g.w3, g.b3) = inv_scale * slab_sum(partial, splits, off);
 }
 
 __device__ __forceinline__ uint32_t kperm(uint32_t p) { return (p & ~0xCu) | ((p & 4u) << 1) | ((p & 8u) >> 1); }   // image column <-> hidden index (an involution)
@@ -702,47 +790,30 @@ learner_adam_kernel(const float* __restrict__ pa, const float* __restrict__ pb, 
         }
         if (lane == 0) { *tk.step += 1; *tk.idx_cursor += tk.minibatch; }
     }
+    // a thread owns one slot of the partial-sum slab (slot_of / slab_sum above)
     const bool second = blockIdx.y == 1;
     const float inv_scale = second ? inv_scale_b : inv_scale_a;
     const float* __restrict__ partial = second ? pb : pa;
     const AdamNet net = second ? nb : na;
-    const uint32_t OUT = (uint32_t)net.g.out_dim;
-    const uint32_t nW2 = 65536u, nB2 = 256u, nW1 = 256u * (uint32_t)OBS, nB1 = 256u, nW3 = OUT * 256u, nB3 = OUT;
-    const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= nW2 + nB2 + nW1 + nB1 + nW3 + nB3) return;
+    const uint32_t off = blockIdx.x * blockDim.x + threadIdx.x;
+    if (off >= (uint32_t)PARTIAL_FLOATS) return;
+    const Slot sl = slot_of(off, (uint32_t)net.g.out_dim);
+    if (sl.arr < 0) return;
+    float* const wp = slot_ptr(sl, net.w2, net.b2, net.w1, net.b1, net.w3, net.b3);
+    float* const gp = slot_ptr(sl, net.g.w2, net.g.b2, net.g.w1, net.g.b1, net.g.w3, net.g.b3);
     const float bc1 = bc[0], bc2 = bc[1];
-    float m = net.m[e], v = net.v[e];
-    uint32_t i = e;
-    if (i < nW2) {
-        const uint32_t j = i >> 8, k = i & 255u;
-        const float g = inv_scale * partial_sum(partial, splits, 8u * (j >> 5) + (k >> 5), sigma(j & 31u), sigma(k & 31u));
-        const float w = adam_update(net.w2[i], g, m, v, hp, bc1, bc2);
-        net.g.w2[i] = g; net.w2[i] = w;
-        net.w23[j * 264u + kperm(k)] = q1pol::f16_bits(q1pol::TANH_PRESCALE * w);
-        net.w2t[k * 264u + kperm(j)] = q1pol::f16_bits(w);
-    } else if ((i -= nW2) < nB2) {
-        const float g = inv_scale * partial_sum(partial, splits, 64u + (i >> 5), sigma(i & 31u), sigma((uint32_t)OBS));
-        net.g.b2[i] = g; net.b2[i] = adam_update(net.b2[i], g, m, v, hp, bc1, bc2);
-    } else if ((i -= nB2) < nW1) {
-        const uint32_t k = i / (uint32_t)OBS, c = i % (uint32_t)OBS;
-        const float g = inv_scale * partial_sum(partial, splits, 72u + (k >> 5), sigma(k & 31u), sigma(c));
-        net.g.w1[i] = g; net.w1[i] = adam_update(net.w1[i], g, m, v, hp, bc1, bc2);
-    } else if ((i -= nW1) < nB1) {
-        const float g = inv_scale * partial_sum(partial, splits, 72u + (i >> 5), sigma(i & 31u), sigma((uint32_t)OBS));
-        net.g.b1[i] = g; net.b1[i] = adam_update(net.b1[i], g, m, v, hp, bc1, bc2);
-    } else if ((i -= nB1) < nW3) {
-        const uint32_t o = i >> 8, j = i & 255u;
-        const float g = inv_scale * partial_sum(partial, splits, 80u + (j >> 5), o, sigma(j & 31u));
-        const float w = adam_update(net.w3[i], g, m, v, hp, bc1, bc2);
-        net.g.w3[i] = g; net.w3[i] = w;
-        net.w23[(256u + o) * 264u + kperm(j)] = q1pol::f16_bits(w);
-        net.w3t[j * 40u + o] = q1pol::f16_bits(w);
-    } else {
-        i -= nW3;
-        const float g = inv_scale * partial_sum(partial, splits, 88u, i, sigma((uint32_t)OBS));
-        net.g.b3[i] = g; net.b3[i] = adam_update(net.b3[i], g, m, v, hp, bc1, bc2);
+    float m = net.m[sl.e], v = net.v[sl.e];
+    const float g = inv_scale * slab_sum(partial, splits, off);
+    const float w = adam_update(*wp, g, m, v, hp, bc1, bc2);
+    *gp = g; *wp = w;
+    net.m[sl.e] = m; net.v[sl.e] = v;
+    if (sl.arr == 0) {
+        net.w23[sl.x * 264u + kperm(sl.y)] = q1pol::f16_bits(q1pol::TANH_PRESCALE * w);
+        net.w2t[sl.y * 264u + kperm(sl.x)] = q1pol::f16_bits(w);
+    } else if (sl.arr == 4) {
+        net.w23[(256u + sl.x) * 264u + kperm(sl.y)] = q1pol::f16_bits(w);
+        net.w3t[sl.y * 40u + sl.x] = q1pol::f16_bits(w);
     }
-    net.m[e] = m; net.v[e] = v;
 }
 
 // ------------------------------------------------------------------------------------------------------------------ weight images
