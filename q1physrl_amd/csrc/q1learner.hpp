@@ -447,7 +447,9 @@ learner_backward_kernel(int n, const float* __restrict__ obs, const int64_t* __r
         for (int t = 0; t < 8; ++t) { hv[t][0] = net.h1T[tbase + (2u * t) * 64u]; hv[t][1] = net.h1T[tbase + (2u * t + 1u) * 64u]; }
         if constexpr (FUSED) tile_inputs(nxt, la, obs, second, live_n, s_n, src_next, half);     // lands under the MFMA loop
         Q1_STAMP(2);
-        // ---- dH1^T = W2^T dZ2^T: 16 K-steps (j) x 8 row tiles (k)
+        // ---- dH1^T = W2^T dZ2^T: 16 K-steps (j) x 8 row tiles (k).  (Round 4 also built this loop over PAIRS of row tiles with the
+        //      previous pair's epilogue - (1 - h^2), conversion, transposition, stores - cut into 16 pieces between the K-steps, so that
+        //      vector and matrix instructions overlap and four accumulators are live instead of eight: same bits, same 105 us step.)
         f32x16 acc1[8];
 #pragma unroll
         for (int t = 0; t < 8; ++t) acc1[t] = zero16;
