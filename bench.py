@@ -204,8 +204,8 @@ def size_sweep(dev_index, sizes=(262144, 1048576, 4194304), ticks=72, reps=4):
 def sampler_block(dev_index, sizes=(32768, 262144), horizon=128, reps=4):
     """BASELINE configs[4] next to the contract fields: the env inside a sampler loop with the policy in it (params.yml Config,
     random-init policy of the reference's shape) at the per-GPU shard (32 768 envs) and at the whole batch on ONE GPU (262 144) - the
-    two-launch tick (fused matrix-core forward + fused sample/step/reset, the horizon captured in a hipGraph) and, where its grid is
-    resident (<= 65 536 envs), the resident sampler (one dispatch per horizon + one batched value forward).  128-tick horizons (the
+    two-launch tick (fused matrix-core forward + fused sample/step/reset, the horizon captured in a hipGraph) and the resident sampler
+    (one dispatch per horizon + one batched value forward; above 65 536 envs its workgroups run as successive sets).  128-tick horizons (the
     training configuration), two warm-up horizons, best of `reps`, HIP events."""
     import torch
     from q1physrl_amd import policy as P
@@ -218,9 +218,6 @@ def sampler_block(dev_index, sizes=(32768, 262144), horizon=128, reps=4):
         row = {"envs": n, "horizon": horizon, "workload": "BASELINE configs[4]: sampler loop with the policy forward in it, params.yml Config"
                + (" (per-GPU shard of 8)" if n == 32768 else " (the whole batch on one GPU)")}
         for label, kw in (("two_launch", dict(use_graph=True)), ("resident", dict(resident=True))):
-            if label == "resident" and n > 65536:
-                row["resident"] = "not resident at this size: a workgroup per CU serves at most 256 envs (DESIGN.md section 8)"
-                continue
             env = TensorVectorEnv(Config(num_envs=n, **params_yml), device=dev_index, seed=1)
             s = GpuSampler(env, P.FusedPolicyForward(P.Q1Policy().cuda(), env), horizon=horizon, **kw)
             s.collect(); s.collect()
