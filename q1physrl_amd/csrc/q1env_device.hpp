@@ -159,9 +159,10 @@ __device__ __forceinline__ uint32_t bfi_b32(uint32_t m, uint32_t a, uint32_t b) 
     asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(d) : "v"(m), "v"(a), "v"(b));
     return d;
 }
-__device__ __forceinline__ uint32_t bit_mask_i32(uint32_t x, uint32_t bit) {   // all ones if bit `bit` of x is set, else zero
+template <int BIT>
+__device__ __forceinline__ uint32_t bit_mask_i32(uint32_t x) {   // all ones if bit BIT of x is set, else zero (the offset as an inline constant: a register operand cost a v_mov per use)
     uint32_t d;
-    asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(d) : "v"(x), "v"(bit));
+    asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(d) : "v"(x), "n"(BIT));
     return d;
 }
 // four values, four masks, one replacement (the decoder's key-press timestamps): r[k] = m[k] ? a : r[k]
@@ -612,11 +613,13 @@ __device__ __forceinline__ Cmd decode(const Params& p, const TickConsts& k_, Env
     // env.py:244-248: last_press_k = now where the key went down.  Per key one sign-extended bit field (all ones / zero) and one bit
     // select per 32-bit half: no SGPR masks, no hazard
     const uint32_t now_lo = (uint32_t)__double2loint(now), now_hi = (uint32_t)__double2hiint(now);
+    {
+        const uint32_t m[4] = {bit_mask_i32<0>(rise), bit_mask_i32<1>(rise), bit_mask_i32<2>(rise), bit_mask_i32<3>(rise)};
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const uint32_t m = bit_mask_i32(rise, (uint32_t)k);
-        const uint32_t lo = (uint32_t)__double2loint(e.lk[k]), hi = (uint32_t)__double2hiint(e.lk[k]);
-        e.lk[k] = __hiloint2double((int)bfi_b32(m, now_hi, hi), (int)bfi_b32(m, now_lo, lo));
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t lo = (uint32_t)__double2loint(e.lk[k]), hi = (uint32_t)__double2hiint(e.lk[k]);
+            e.lk[k] = __hiloint2double((int)bfi_b32(m[k], now_hi, hi), (int)bfi_b32(m[k], now_lo, lo));
+        }
     }
     Cmd c;
     if (k_.has_move_tab) {                                              // (compile-time after inlining)
