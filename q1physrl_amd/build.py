@@ -31,6 +31,12 @@ OUT_CHECK = os.path.join(PKG, "libq1env_check.so")
 COMPILE_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-fvisibility=hidden",
                  "-Wall", "-Wno-unused-function",
                  "-mllvm", "-amdgpu-kernarg-preload-count=16"]   # leading scalar kernel arguments arrive in SGPRs (step_kernel's state pointers)
+# per translation unit, on top of COMPILE_FLAGS.  q1env_learner.hip: matrix instructions take their C / D operands in the ordinary
+# vector registers wherever the allocator can afford it (round 4): the learner's backward kernel spent 19 % of its vector instructions
+# moving values between the two register files - transposition results that the very next instruction converts (558 -> 100 moves per
+# tile, 2 933 -> 2 501 vector instructions; the 32 768-sample SGD step 106 -> 101 us).  The policy / sampler units keep the compiler's
+# default (the resident sampler measured 3 % slower with it).
+TU_FLAGS = {"q1env_learner.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
 LINK_FLAGS = ["--offload-arch=gfx950", "-shared", "-fPIC"]
 HIPCC_FLAGS = COMPILE_FLAGS + ["-shared"]     # (kept for tools that compile a single file the old way, e.g. tools/asan_check.sh)
 
@@ -54,6 +60,7 @@ def sources_sha16(flags=None):
             h.update(f.read())
         h.update(b"\0")
     h.update(" ".join(COMPILE_FLAGS if flags is None else flags).encode())
+    h.update(repr(sorted(TU_FLAGS.items())).encode())
     return h.hexdigest()[:16]
 
 
@@ -112,7 +119,8 @@ def build_lib(force=False, verbose=False, check=False, extra_flags=(), out=None,
         obj = _obj_of(src, tag)
         is_id_tu = os.path.basename(src) == BUILD_ID_TU
         if force or _stale(obj, [src] + HEADERS + ([stamp] if is_id_tu else [])):
-            jobs.append([hipcc] + flags + (['-DQ1_BUILD_ID="' + bid + '"'] if is_id_tu else []) + ["-c", src, "-o", obj])
+            jobs.append([hipcc] + flags + TU_FLAGS.get(os.path.basename(src), []) + (['-DQ1_BUILD_ID="' + bid + '"'] if is_id_tu else []) +
+                        ["-c", src, "-o", obj])
     with concurrent.futures.ThreadPoolExecutor(max_workers=max(1, min(len(jobs), os.cpu_count() or 1))) as ex:
         list(ex.map(lambda c: _run(c, verbose), jobs))
     _run([hipcc] + LINK_FLAGS + [_obj_of(s, tag) for s in SOURCES] + ["-o", out + ".tmp"], verbose)
