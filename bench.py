@@ -541,6 +541,7 @@ def main(argv=None):
             rewT = torch.empty((EPISODE_TICKS, n), dtype=torch.float32, device=d)
             doneT = torch.empty((EPISODE_TICKS, n), dtype=torch.uint8, device=d)
         calls = []
+        waits_itself = False
         t, left, launches = tick0, k, 0
         started = stopped = False
         o1, r1, d1 = obs1.data_ptr(), rew1.data_ptr(), done1.data_ptr()
@@ -600,12 +601,16 @@ def main(argv=None):
                     # timed = "signal": device stamps + the kernel-written completion signal (the timed region proper);
                     # timed = "events": HIP events around the same launches (the cross-check pass that follows it)
                     rflags = 1 if full_cfg else 0                          # bit 0: in-kernel Philox reset of envs whose episode ended
+                    sig = timed in ("signal", "signal_wait")
                     if timed and not started:
-                        rflags |= _lib.STAMP_START if timed == "signal" else _lib.TIMER_START
+                        rflags |= _lib.STAMP_START if sig else _lib.TIMER_START
                         started = True
-                    if timed and left == chunk and not ends_episode and not (timed == "signal" and os.environ.get("Q1_BENCH_SIGNAL_MARK") == "1"):
-                        rflags |= _lib.SIGNAL if timed == "signal" else _lib.TIMER_STOP     # (Q1_BENCH_SIGNAL_MARK=1: A/B knob - the signal from a
-                        stopped = True                                                       #  one-wave kernel behind the launch instead of its own last wave)
+                    if timed and left == chunk and not ends_episode and not (sig and os.environ.get("Q1_BENCH_SIGNAL_MARK") == "1"):
+                        # (Q1_BENCH_SIGNAL_MARK=1: A/B knob - the signal from a one-wave kernel behind the launch instead of its own last wave)
+                        # "signal_wait": the launching call polls for the signal itself (Q1ENV_SIGNAL_WAIT: launch + wait in ONE call across the ABI)
+                        rflags |= (_lib.SIGNAL_WAIT if timed == "signal_wait" else _lib.SIGNAL) if sig else _lib.TIMER_STOP
+                        stopped = True
+                        waits_itself = timed == "signal_wait"
                     # (arguments converted once, outside the timed region: DeviceEnv.prepare_rollout)
                     calls.append(dev.prepare_rollout(chunk, _lib.ACT_PACKED, ka, ma, 99 if full_cfg else 0, _lib.OBS_F32, obsT.data_ptr(),
                                                      rewT.data_ptr(), doneT.data_ptr(), rflags))
@@ -615,7 +620,8 @@ def main(argv=None):
             if ends_episode and not prepare:
                 calls.append(functools.partial(dev.reset_philox_dev, 99, 0, True))   # zero_start_prob = 1: every env back to the start line
         if timed and not stopped:
-            calls.append(dev.signal_mark if timed == "signal" else dev.timer_mark)
+            calls.append(dev.signal_mark if timed in ("signal", "signal_wait") else dev.timer_mark)
+        plan_ticks.waits_itself = waits_itself
         return calls, launches
 
     def run(calls):
@@ -662,36 +668,85 @@ def main(argv=None):
             raise RuntimeError(f"{mode} mode failed in the dry run on at least one rank" + (f": {err!r}" if err is not None else
                                " (tick server / producer timed out)" if mode == "server" else ""))
         dev.restore_state()
-        run(plan_ticks(mode, warmup, 0)[0])       # the W untimed warm-up ticks
         signalled = mode == "rollout" and hasattr(dev, "signal_wait") and os.environ.get("Q1_BENCH_NO_SIGNAL") != "1"
+        if signalled:                             # the signal's pinned words and ticket counters exist and have been touched before the region -
+            dev.signal_mark()                     # and BEFORE the warm-up ticks: the runtime enqueues a kernel 1.5-2 us faster when the
+            dev.signal_wait()                     # previous launch was the same kernel (profiles/r4_bench_probe_host_knobs.txt)
+        # every call of the timed region is resolved BEFORE the warm-up ticks, so that nothing but the synchronisation sits between the
+        # warm-up's last kernel and the timed launch: a queue that has been idle takes longer to start a kernel (Q1_BENCH_SPIN_US: 300 us of
+        # host-only spinning between the synchronisation and t0 cost 5-6 us of the 26; profiles/r4_bench_probe_host_knobs.txt)
         timed_calls, launches = plan_ticks(mode, steps, warmup, timed="signal" if signalled else "events")
         wait = dev.signal_wait if signalled else None
-        if signalled:                             # the signal's pinned words and ticket counters exist and have been touched before the region
-            dev.signal_mark()
-            dev.signal_wait()
+        # a region that is ONE launch (the driver-style 20-tick line) runs as one call across the ABI: launch + poll inside q1env_rollout
+        # (Q1ENV_SIGNAL_WAIT) instead of two calls from Python; the enqueue / wait split is then taken in the cross-check pass below
+        one_call = signalled and launches == 1 and len(timed_calls) == 1 and os.environ.get("Q1_BENCH_TWO_CALLS") != "1"
+        if one_call:
+            timed_calls, launches = plan_ticks(mode, steps, warmup, timed="signal_wait")
+            one_call = plan_ticks.waits_itself and len(timed_calls) == 1
+            if not one_call:
+                timed_calls, launches = plan_ticks(mode, steps, warmup, timed="signal")
+        warm_calls = plan_ticks(mode, warmup, 0)[0]
+        run(warm_calls)                           # the W untimed warm-up ticks
         barrier()
+        spin_us = float(os.environ.get("Q1_BENCH_SPIN_US", "0"))
+        if spin_us > 0:                           # A/B knob: keep the host core busy between the synchronisation and t0 (no GPU work)
+            ts = time.perf_counter()
+            while (time.perf_counter() - ts) * 1e6 < spin_us:
+                pass
         if signalled:
-            t0 = time.perf_counter()
-            run(timed_calls)                      # EXACTLY `steps` ticks: first wave stamps the start, last wave stamps the end + signals
-            t_enq = time.perf_counter()
-            wait()                                # poll the host-coherent sequence word the kernel writes (no runtime synchronisation)
-            t1 = time.perf_counter()
+            if one_call:
+                f = timed_calls[0]
+                t0 = time.perf_counter()
+                f()                               # EXACTLY `steps` ticks in one launch; the call returns when the kernel's signal has arrived
+                t1 = time.perf_counter()
+                t_enq = None
+            else:
+                t0 = time.perf_counter()
+                run(timed_calls)                  # EXACTLY `steps` ticks: first wave stamps the start, last wave stamps the end + signals
+                t_enq = time.perf_counter()
+                wait()                            # poll the host-coherent sequence word the kernel writes (no runtime synchronisation)
+                t1 = time.perf_counter()
             dsync()                               # untimed: nothing else may have been in flight (and nothing was: see post_sync_us)
             t2 = time.perf_counter()
             own = t1 - t0
             stamp_ms = dev.signal_elapsed() * 1e3
-            host_split[mode] = {"enqueue_us": (t_enq - t0) * 1e6, "enqueue_to_signal_seen_us": (t1 - t_enq) * 1e6,
+            host_split[mode] = {"launch_to_signal_seen_us": (t1 - t0) * 1e6,
                                 "post_sync_us": (t2 - t1) * 1e6, "wall_incl_runtime_sync_us": (t2 - t0) * 1e6,
-                                "device_stamp_us": stamp_ms * 1e3, "completion": "kernel-written signal polled by the host"}
+                                "device_stamp_us": stamp_ms * 1e3,
+                                "completion": "kernel-written signal polled by the host" + (" inside the launching call (Q1ENV_SIGNAL_WAIT)" if one_call else "")}
+            if t_enq is not None:
+                host_split[mode]["enqueue_us"] = (t_enq - t0) * 1e6
+                host_split[mode]["enqueue_to_signal_seen_us"] = (t1 - t_enq) * 1e6
             # the same K ticks again, from the same state, between two HIP events on the launch stream (what `roofline` uses)
             dev.restore_state()
             run(plan_ticks(mode, warmup, 0)[0])
             ev_calls, _l = plan_ticks(mode, steps, warmup, timed="events")
             barrier()
+            te0 = time.perf_counter()
             run(ev_calls)
+            te1 = time.perf_counter()
             dsync()
             ev_ms = dev.timer_elapsed()
             host_split[mode]["hip_event_us"] = ev_ms * 1e3
+            if one_call:
+                # the enqueue / wait split of the same launch as TWO calls from Python (q1env_rollout with Q1ENV_SIGNAL, then q1env_signal_wait),
+                # taken here, outside the timed region: what the one-call form saves is two_call_wall_us - launch_to_signal_seen_us
+                host_split[mode]["enqueue_us_events_pass"] = (te1 - te0) * 1e6
+                dev.restore_state()
+                run(plan_ticks(mode, warmup, 0)[0])
+                two_calls, _l = plan_ticks(mode, steps, warmup, timed="signal")
+                barrier()
+                ta = time.perf_counter()
+                run(two_calls)
+                tb = time.perf_counter()
+                wait()
+                tc = time.perf_counter()
+                dsync()
+                host_split[mode]["enqueue_us"] = (tb - ta) * 1e6
+                host_split[mode]["enqueue_to_signal_seen_us"] = (tc - tb) * 1e6
+                host_split[mode]["two_call_wall_us"] = (tc - ta) * 1e6
+                host_split[mode]["two_call_device_stamp_us"] = dev.signal_elapsed() * 1e6
+                host_split[mode]["enqueue_us_source"] = "a repetition of the timed launch as two calls, right after the timed region"
             # what an EMPTY signalled launch costs here (one-wave kernel that only stamps and signals, then the same poll): the floor
             # under (wall - device_stamp_us) that no kernel of ours can go below on this runtime / firmware
             rt = []
