@@ -316,6 +316,7 @@ int q1env_learner_sgd_step(q1env_t* h, const q1env_learner_net* pi, const q1env_
     la.clip = b->clip_param; la.vf_clip = b->vf_clip_param; la.vf_coeff = b->vf_loss_coeff; la.ent_coeff = b->entropy_coeff;
     la.inv_b = scale / (float)mb; la.inv_bv = scale_v / (float)mb;
     la.stats_rows = w.stats_rows;
+    la.wide = ((uintptr_t)b->old_logits_dev % 8u == 0 && b->old_stride % 2 == 0 && (uintptr_t)b->obs_dev % 8u == 0) ? 1 : 0;    // (w.logits is 256-byte aligned, rows of 40 B)
     char* st = (char*)adam_state_dev;
     const q1learn::BcArgs bca{(const long long*)st, (float*)(st + 8), beta1, beta2};
     unsigned rows = 0;

@@ -224,6 +224,7 @@ struct LossArgs {
     float clip, vf_clip, vf_coeff, ent_coeff;
     float inv_b, inv_bv;                                // (loss scale) / B of the policy / value network's dY
     float* stats_rows;
+    int wide;                                           // logits / old_logits / obs rows are 8-byte aligned: 8-byte gathers
 };
 // ... and thread 0 of workgroup 0 derives the optimizer's bias corrections of step count + 1 (torch: 1 - beta ** step, in double) while
 // the weight image's loads are in flight - the Adam kernel behind reads them (before: a one-wave kernel of its own, 5 us)
@@ -239,53 +240,102 @@ __device__ __forceinline__ f32x16 transpose_tile(const f16x8 x0, const f16x8 x1,
 }
 
 __device__ __forceinline__ void store_n(f16x8* dstN, uint32_t t, const f32x16& d) {      // dstN already points at (tile, lane)
+    // (plain stores: with the nt policy the backward kernel ends 1.4 us sooner and the weight-gradient kernel, which reads these back,
+    // takes 8.7 us longer - profiles/r4_learner_bytes.txt)
     dstN[(2u * t) * 64u] = cvt8(d, 0);
     dstN[(2u * t + 1u) * 64u] = cvt8(d, 1);
 }
 
 // acc (float32, C/D layout) *= 1 - h^2 with h the matching T-format vectors; returns nothing, acc updated in place
+// (two elements per instruction - v_pk_mul_f32 / v_pk_add_f32 on register pairs: the same IEEE operations in the same order as the scalar
+// form, RN(acc RN(1 - RN(h h))), so the bits are the same; 1.5 instead of 3 vector instructions per element, and this function was 41 % of
+// the backward kernel's vector instructions)
 __device__ __forceinline__ void times_dtanh(f32x16& acc, const f16x8 h0, const f16x8 h1) {
+    typedef float f32x2_t __attribute__((ext_vector_type(2)));
+    const f32x2_t one = {1.0f, 1.0f};
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        const float a = (float)h0[e], b = (float)h1[e];
-        acc[e] *= 1.0f - a * a;
-        acc[8 + e] *= 1.0f - b * b;
+    for (int e = 0; e < 8; e += 2) {
+        const f32x2_t a = {(float)h0[e], (float)h0[e + 1]}, b = {(float)h1[e], (float)h1[e + 1]};
+        f32x2_t x = {acc[e], acc[e + 1]}, y = {acc[8 + e], acc[8 + e + 1]};
+        x = x * (one - a * a);
+        y = y * (one - b * b);
+        acc[e] = x[0]; acc[e + 1] = x[1];
+        acc[8 + e] = y[0]; acc[8 + e + 1] = y[1];
     }
 }
 
 // FUSED: the per-sample inputs of a tile (everything that hangs on the gathered row index: two dependent round trips) are requested
-// one tile AHEAD - the first tile's before the weight staging, the next tile's in front of the current tile's 128-MFMA loop - so that a
-// lone wave per SIMD never sits on them (round 4: they were the front of every tile's critical path).
+// one tile AHEAD - the first tile's before the weight staging, the next tile's at the current tile's start (the row index a tile earlier
+// still) - so that a lone wave per SIMD never sits on them (round 4: they were the front of every tile's critical path).
+// Lanes (c, 0) and (c, 1) evaluate the same sample, so they SHARE its gathers: every gather instruction costs the address unit one
+// step per active lane whatever the lanes ask for (tools/exp_bwd_stamps.py: 2.6 us per tile for the policy network's sixteen 64-lane
+// gathers), so half 0 fetches the sample's logits row, key bits and mouse action, half 1 its old row, old log-probability and advantage,
+// and the halves swap when the values are used, a tile later (tile_unpack) - 9 gathers' worth of lanes instead of 16, and 16 registers
+// in flight per tile instead of 30.
 struct TileIn {
-    uint32_t kb; float mouse, logp_old, adv; float lg[10], ol[10];       // policy network's workgroups
-    float v, vo, vt;                                                     // value network's
-    float x[4];                                                          // observation inputs 4 half + e of the lane's sample (both)
+    float r[10];              // policy network: half 0 the forward kernel's logits row, half 1 the behaviour policy's
+    float sc[2];              // policy network: half 0 (key bits, mouse), half 1 (logp_old, adv); value network: (value_old, vtarg) in both halves
+    float v;                  // value network: the forward kernel's value
+    float x[4];               // observation inputs 4 half + e of the lane's sample (both networks)
 };
+struct TileVals { uint32_t kb; float mouse, logp_old, adv; float lg[10], ol[10]; };
 __device__ __forceinline__ size_t tile_src(const int64_t* __restrict__ idx, uint32_t s, bool live) {
     return live ? (idx ? (size_t)idx[s] : (size_t)s) : 0;
 }
 __device__ __forceinline__ void tile_inputs(TileIn& ti, const LossArgs& la, const float* __restrict__ obs, bool second, bool live, uint32_t s, size_t src,
                                             uint32_t half) {
-    ti.kb = 0u; ti.mouse = ti.logp_old = ti.adv = ti.v = ti.vo = ti.vt = 0.0f;
 #pragma unroll
-    for (int c = 0; c < 10; ++c) { ti.lg[c] = 0.0f; ti.ol[c] = 0.0f; }
+    for (int c = 0; c < 10; ++c) ti.r[c] = 0.0f;
+    ti.sc[0] = ti.sc[1] = ti.v = 0.0f;
 #pragma unroll
     for (int e = 0; e < 4; ++e) ti.x[e] = 0.0f;
     if (!live) return;
+    // (la.wide: rows are 8-byte aligned - the 10-float rows as five 8-byte loads, the observation as 8-byte loads)
     if (!second) {
-        ti.kb = la.keys[src]; ti.mouse = la.mouse[src]; ti.logp_old = la.logp_old[src]; ti.adv = la.adv[src];
-        const float* row = la.logits + (size_t)s * 10u;
-        const float* old = la.old_logits + src * (size_t)la.old_stride;
+        const float* row = half ? la.old_logits + src * (size_t)la.old_stride : la.logits + (size_t)s * 10u;
+        if (la.wide) {
 #pragma unroll
-        for (int c = 0; c < 10; ++c) { ti.lg[c] = row[c]; ti.ol[c] = old[c]; }
+            for (int c = 0; c < 10; c += 2) {
+                const float2 a = *reinterpret_cast<const float2*>(row + c);
+                ti.r[c] = a.x; ti.r[c + 1] = a.y;
+            }
+        } else {
+#pragma unroll
+            for (int c = 0; c < 10; ++c) ti.r[c] = row[c];
+        }
+        if (half == 0u) ti.sc[0] = __uint_as_float((uint32_t)la.keys[src]);
+        else ti.sc[0] = la.logp_old[src];
+        ti.sc[1] = (half ? la.adv : la.mouse)[src];
     } else {
-        ti.v = la.value[s]; ti.vo = la.value_old[src]; ti.vt = la.vtarg[src];
+        ti.v = la.value[s]; ti.sc[0] = la.value_old[src]; ti.sc[1] = la.vtarg[src];
     }
+    static_assert(OBS == 6, "the observation row is read as 4 + 2 floats");
+    if (la.wide) {
+        const float2* o2 = reinterpret_cast<const float2*>(obs + src * OBS);
+        if (half == 0u) { const float2 a = o2[0], b = o2[1]; ti.x[0] = a.x; ti.x[1] = a.y; ti.x[2] = b.x; ti.x[3] = b.y; }
+        else { const float2 a = o2[2]; ti.x[0] = a.x; ti.x[1] = a.y; ti.x[2] = 1.0f; ti.x[3] = 0.0f; }
+    } else {
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        const int i = 4 * (int)half + e;
-        ti.x[e] = i < OBS ? obs[src * OBS + (uint32_t)i] : (i == OBS ? 1.0f : 0.0f);
+        for (int e = 0; e < 4; ++e) {
+            const int i = 4 * (int)half + e;
+            ti.x[e] = i < OBS ? obs[src * OBS + (uint32_t)i] : (i == OBS ? 1.0f : 0.0f);
+        }
     }
+}
+// the policy network's values of a tile as every lane needs them: its own half's gathers + its partner lane's (lane ^ 32)
+__device__ __forceinline__ TileVals tile_unpack(const TileIn& ti, uint32_t half) {
+    TileVals v;
+    float pr[10], ps[2];
+#pragma unroll
+    for (int c = 0; c < 10; ++c) pr[c] = __shfl_xor(ti.r[c], 32, 64);
+    ps[0] = __shfl_xor(ti.sc[0], 32, 64); ps[1] = __shfl_xor(ti.sc[1], 32, 64);
+#pragma unroll
+    for (int c = 0; c < 10; ++c) { v.lg[c] = half ? pr[c] : ti.r[c]; v.ol[c] = half ? ti.r[c] : pr[c]; }
+    v.kb = __float_as_uint(half ? ps[0] : ti.sc[0]);
+    v.mouse = half ? ps[1] : ti.sc[1];
+    v.logp_old = half ? ti.sc[0] : ps[0];
+    v.adv = half ? ti.sc[1] : ps[1];
+    return v;
 }
 
 template <bool FUSED>
@@ -315,11 +365,16 @@ learner_backward_kernel(int n, const float* __restrict__ obs, const int64_t* __r
     {
         const uint32_t tile0 = bid * 4u + wave, s0 = tile0 * 32u + col;
         const bool live0 = tile0 < ntiles && s0 < (uint32_t)n;
-        if constexpr (FUSED) src_next = tile_src(idx, s0, live0);
+        size_t src0 = 0;
+        if constexpr (FUSED) {
+            src0 = tile_src(idx, s0, live0);
+            const uint32_t s1 = (tile0 + tstride) * 32u + col;                     // the row index of this wave's SECOND tile too: its inputs
+            src_next = tile_src(idx, s1, tile0 + tstride < ntiles && s1 < (uint32_t)n);      // are requested at the first tile's start
+        }
         StageRegs<256, (uint32_t)(LDS_W2T / 16)> r;
         stage_issue<256, (uint32_t)(LDS_W2T / 16)>(r, net.w2t, tid);
         if constexpr (FUSED) {
-            tile_inputs(cur, la, obs, second, live0, s0, src_next, half);          // the first tile's inputs land under the staging
+            tile_inputs(cur, la, obs, second, live0, s0, src0, half);              // the first tile's inputs land under the staging
             if (bca.step && blockIdx.x == 0 && tid == 0) {
                 const long long t = *bca.step + 1;
                 bca.bc[0] = (float)(1.0 - pow((double)bca.beta1, (double)t));
@@ -330,7 +385,7 @@ learner_backward_kernel(int n, const float* __restrict__ obs, const int64_t* __r
     }
     stage_copy<256, (uint32_t)(LDS_W3T / 16)>(l_w3t, net.w3t, tid);
 #ifdef Q1_BWD_STAMPS      // diagnostic build (tools/exp_bwd_stamps.py): where does a wave's time go?  100 MHz stamps of wave 0, in statistics rows 1024..
-    float stamps[5] = {0, 0, 0, 0, 0};
+    float stamps[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     int stamp_tile = 0;
 #define Q1_STAMP(k) do { if (FUSED && stamp_tile == 0) stamps[k] = (float)(wall_clock64() - stamp0) * 0.01f; } while (0)
 #else
@@ -369,7 +424,14 @@ learner_backward_kernel(int n, const float* __restrict__ obs, const int64_t* __r
         const uint32_t tile_n = tile + tstride, s_n = tile_n * 32u + col;
         const bool live_n = tile_n < ntiles && s_n < (uint32_t)n;
         if constexpr (FUSED) {
-            src_next = tile_src(idx, s_n, live_n);                                  // the next tile's row index: requested now, used before the MFMA loop
+            // the NEXT tile's inputs are requested here, a whole tile ahead (their row index came in a tile earlier still): the allocator
+            // parks them in the other register file before the MFMA loop, and a move waits for its load - requested just in front of
+            // the loop (this round's first version) they held the wave for 4 us there (tools/exp_bwd_stamps.py)
+            tile_inputs(nxt, la, obs, second, live_n, s_n, src_next, half);
+            {
+                const uint32_t s_nn = (tile_n + tstride) * 32u + col;
+                src_next = tile_src(idx, s_nn, tile_n + tstride < ntiles && s_nn < (uint32_t)n);
+            }
             float y0[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) y0[e] = 0.0f;
@@ -377,16 +439,17 @@ learner_backward_kernel(int n, const float* __restrict__ obs, const int64_t* __r
                 float g[10];
 #pragma unroll
                 for (int c = 0; c < 10; ++c) g[c] = 0.0f;
+                const TileVals tv = tile_unpack(cur, half);                        // (all 64 lanes: the halves swap their gathers)
                 if (live) {
-                    const PpoSample in{cur.kb, cur.mouse, cur.logp_old, cur.adv};
-                    const PpoSums ps = ppo_policy_grad<true>(la.p, cur.lg, cur.ol, in, la.clip, la.ent_coeff, klc, la.inv_b, g, 10);
+                    const PpoSample in{tv.kb, tv.mouse, tv.logp_old, tv.adv};
+                    const PpoSums ps = ppo_policy_grad<true>(la.p, tv.lg, tv.ol, in, la.clip, la.ent_coeff, klc, la.inv_b, g, 10);
                     if (half == 0u) { st[0] += ps.ent; st[1] += ps.kl; st[2] += -ps.surr; st[3] += -ps.surr + klc * ps.kl - la.ent_coeff * ps.ent; }
                 }
 #pragma unroll
                 for (int e = 0; e < 8; ++e) y0[e] = half ? (e < 2 ? g[8 + e] : 0.0f) : g[e];
             } else if (live) {
                 float vf;
-                const float dvf = ppo_value_grad(cur.v, cur.vo, cur.vt, la.vf_clip, vf);
+                const float dvf = ppo_value_grad(cur.v, cur.sc[0], cur.sc[1], la.vf_clip, vf);
                 if (half == 0u) { y0[0] = la.vf_coeff * dvf * la.inv_bv; st[3] += la.vf_coeff * vf; st[4] += vf; }
             }
 #pragma unroll
@@ -442,40 +505,47 @@ learner_backward_kernel(int n, const float* __restrict__ obs, const int64_t* __r
             dzb[t][0] = cvt8_sat(acc, 0, amax);
             dzb[t][1] = cvt8_sat(acc, 1, amax);
             store_n(net.dz2N + tbase, (uint32_t)t, transpose_tile(dzb[t][0], dzb[t][1], e0, e1));
+            Q1_STAMP(5 + t);
         }
 #pragma unroll
         for (int t = 0; t < 8; ++t) { hv[t][0] = net.h1T[tbase + (2u * t) * 64u]; hv[t][1] = net.h1T[tbase + (2u * t + 1u) * 64u]; }
-        if constexpr (FUSED) tile_inputs(nxt, la, obs, second, live_n, s_n, src_next, half);     // lands under the MFMA loop
         Q1_STAMP(2);
         // ---- dH1^T = W2^T dZ2^T: 16 K-steps (j) x 8 row tiles (k).  (Round 4 also built this loop over PAIRS of row tiles with the
         //      previous pair's epilogue - (1 - h^2), conversion, transposition, stores - cut into 16 pieces between the K-steps, so that
         //      vector and matrix instructions overlap and four accumulators are live instead of eight: same bits, same 105 us step.)
-        f32x16 acc1[8];
+        // Two passes of FOUR row tiles (round 4): with eight accumulators live the loop held 128 + 32 + 64 registers of its own next to the
+        // 64 of the h1 vectors and the 30 of the next tile's inputs that are in flight across it - and the allocator parked those in the
+        // other register file BEFORE the loop, i.e. waited for their loads there (tools/exp_bwd_stamps.py: 1.3 - 5.7 us per tile between
+        // the dZ2 phase and the first MFMA).  Four accumulators leave room for everything; each pass's dZ1 epilogue follows it.
 #pragma unroll
-        for (int t = 0; t < 8; ++t) acc1[t] = zero16;
-        {
-            f16x8 a[8];
+        for (int pass = 0; pass < 2; ++pass) {
+            f32x16 acc1[4];
 #pragma unroll
-            for (int t = 0; t < 8; ++t) a[t] = *reinterpret_cast<const f16x8*>(w2trow + (size_t)t * 32u * ROW_BYTES);
+            for (int t = 0; t < 4; ++t) acc1[t] = zero16;
+            {
+                f16x8 a[4];
 #pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                // every W2^T operand register is re-requested for the next K-step right after the MFMA that consumed it was issued
-                // (operands are read at issue), i.e. eight MFMAs ahead of its next use - the forward kernel's pipeline
+                for (int t = 0; t < 4; ++t) a[t] = *reinterpret_cast<const f16x8*>(w2trow + (size_t)(4 * pass + t) * 32u * ROW_BYTES);
 #pragma unroll
-                for (int t = 0; t < 8; ++t) {
-                    acc1[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[t], dzb[q >> 1][q & 1], acc1[t], 0, 0, 0);
-                    if (q < 15) a[t] = *reinterpret_cast<const f16x8*>(w2trow + (size_t)t * 32u * ROW_BYTES + (uint32_t)(q + 1) * 32u);
+                for (int q = 0; q < 16; ++q) {
+                    // every W2^T operand register is re-requested for the next K-step right after the MFMA that consumed it was issued
+                    // (operands are read at issue), i.e. four MFMAs ahead of its next use
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        acc1[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[t], dzb[q >> 1][q & 1], acc1[t], 0, 0, 0);
+                        if (q < 15) a[t] = *reinterpret_cast<const f16x8*>(w2trow + (size_t)(4 * pass + t) * 32u * ROW_BYTES + (uint32_t)(q + 1) * 32u);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
                 }
-                __builtin_amdgcn_sched_barrier(0);
             }
-        }
-        Q1_STAMP(3);
-        // ---- dZ1 = dH1 (1 - h1^2); h1 and dZ1 leave in N-format
+            if (pass == 1) Q1_STAMP(3);
+            // ---- dZ1 = dH1 (1 - h1^2); dZ1 leaves in N-format
 #pragma unroll
-        for (int t = 0; t < 8; ++t) {
-            times_dtanh(acc1[t], hv[t][0], hv[t][1]);
-            const f16x8 z0 = cvt8_sat(acc1[t], 0, amax), z1 = cvt8_sat(acc1[t], 1, amax);
-            store_n(net.dz1N + tbase, (uint32_t)t, transpose_tile(z0, z1, e0, e1));
+            for (int t = 0; t < 4; ++t) {
+                times_dtanh(acc1[t], hv[4 * pass + t][0], hv[4 * pass + t][1]);
+                const f16x8 z0 = cvt8_sat(acc1[t], 0, amax), z1 = cvt8_sat(acc1[t], 1, amax);
+                store_n(net.dz1N + tbase, (uint32_t)(4 * pass + t), transpose_tile(z0, z1, e0, e1));
+            }
         }
         if constexpr (FUSED) cur = nxt;
         Q1_STAMP(4);
@@ -486,8 +556,8 @@ learner_backward_kernel(int n, const float* __restrict__ obs, const int64_t* __r
 #ifdef Q1_BWD_STAMPS
     if constexpr (FUSED) {
         if (tid == 0) {
-            for (int k = 0; k < 5; ++k) la.stats_rows[(size_t)(1024u + blockIdx.x) * 5u + k] = stamps[k];
-            la.stats_rows[(size_t)(1536u + blockIdx.x) * 5u] = (float)(wall_clock64() - stamp0) * 0.01f;
+            stamps[15] = (float)(wall_clock64() - stamp0) * 0.01f;
+            for (int k = 0; k < 16; ++k) la.stats_rows[5120u + (size_t)blockIdx.x * 16u + k] = stamps[k];
         }
     }
 #endif

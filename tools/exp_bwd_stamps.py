@@ -39,9 +39,13 @@ klc = torch.full((1,), 0.2, device="cuda")
 for _ in range(5):
     nat.step(full, idx, 0.1, 7500.0, 1.0, 0.01, klc, skip_reduce=True, adam=(3e-5, (0.9, 0.999), 1e-8))
 torch.cuda.synchronize()
-rows = nat.ws[-2048 * 20:].view(torch.float32).reshape(2048, 5).cpu()
-st, end = rows[1024:1024 + 256], rows[1536:1536 + 256, 0]
-names = ["after staging + barrier", "tile 0: before the dZ2 phase", "tile 0: before the MFMA loop", "tile 0: after the MFMA loop", "tile 0: end"]
-for k, nm in enumerate(names):
-    print(f"{nm:32s} median {st[:, k].median():7.2f} us   min {st[:, k].min():7.2f}   max {st[:, k].max():7.2f}   (since the wave's start)")
-print(f"{'kernel end (wave 0)':32s} median {end.median():7.2f} us   min {end.min():7.2f}   max {end.max():7.2f}")
+flat = nat.ws[-2048 * 20:].view(torch.float32).cpu()
+st = flat[5120:5120 + 256 * 16].reshape(256, 16)
+for label, sel in (("policy network's workgroups", slice(0, 128)), ("value network's workgroups", slice(128, 256))):
+    g = st[sel]
+    print(label)
+    names = ["after staging + barrier", "tile 0: before the dZ2 phase", "tile 0: before the MFMA loop", "tile 0: after the MFMA loop", "tile 0: end"] + \
+            [f"  dZ2 phase, after row tile {t}" for t in range(8)] + ["", "", "kernel end (wave 0)"]
+    order = [0, 1] + list(range(5, 13)) + [2, 3, 4, 15]
+    for k in order:
+        print(f"  {names[k]:34s} median {g[:, k].median():7.2f} us   min {g[:, k].min():7.2f}   max {g[:, k].max():7.2f}")
