@@ -870,6 +870,8 @@ def main(argv=None):
              "frac_device_stamps": (alg_bytes / (stamp_us / launches_ * 1e-6) / 1e9 / HBM_PEAK_GBPS) if stamp_us else None,
              "wall_over_event": (wall_ * 1e6 / stamp_us) if stamp_us else (wall_ * 1e3 / ev_ms_ if ev_ms_ > 0 else None),
              "wall_over_event_basis": "device stamps of the timed region" if stamp_us else "HIP events of the timed region",
+             # the same ratio on round 3's basis (2.14 then): wall of the timed region over the HIP-event time of the same K ticks (cross-check pass)
+             "wall_over_hip_event": (wall_ * 1e3 / ev_ms_) if ev_ms_ and ev_ms_ > 0 else None,
              "host_split_us": hs or None, "env_steps_per_launch": n * tpl, "frac_nominal_204B": nominal / HBM_PEAK_GBPS,
              "traffic_frac_of_peak": (traffic / (kern_us * 1e-6) / 1e9 / HBM_PEAK_GBPS) if traffic is not None else None,
              "traffic_over_algorithmic": (traffic / alg_bytes) if traffic is not None else None,
