@@ -440,13 +440,14 @@ learner_backward_kernel(int n, const float* __restrict__ obs, const int64_t* __r
 #pragma unroll
                 for (int c = 0; c < 10; ++c) g[c] = 0.0f;
                 const TileVals tv = tile_unpack(cur, half);                        // (all 64 lanes: the halves swap their gathers)
-                if (live) {
+                {
+                    // (all 64 lanes as well: the two lanes of a sample split its four keys - q1ppo_loss.hpp PAIR; a dead lane's inputs are zeros)
                     const PpoSample in{tv.kb, tv.mouse, tv.logp_old, tv.adv};
-                    const PpoSums ps = ppo_policy_grad<true>(la.p, tv.lg, tv.ol, in, la.clip, la.ent_coeff, klc, la.inv_b, g, 10);
-                    if (half == 0u) { st[0] += ps.ent; st[1] += ps.kl; st[2] += -ps.surr; st[3] += -ps.surr + klc * ps.kl - la.ent_coeff * ps.ent; }
+                    const PpoSums ps = ppo_policy_grad<true, true>(la.p, tv.lg, tv.ol, in, la.clip, la.ent_coeff, klc, la.inv_b, g, 10, half);
+                    if (live && half == 0u) { st[0] += ps.ent; st[1] += ps.kl; st[2] += -ps.surr; st[3] += -ps.surr + klc * ps.kl - la.ent_coeff * ps.ent; }
                 }
 #pragma unroll
-                for (int e = 0; e < 8; ++e) y0[e] = half ? (e < 2 ? g[8 + e] : 0.0f) : g[e];
+                for (int e = 0; e < 8; ++e) y0[e] = live ? (half ? (e < 2 ? g[8 + e] : 0.0f) : g[e]) : 0.0f;
             } else if (live) {
                 float vf;
                 const float dvf = ppo_value_grad(cur.v, cur.sc[0], cur.sc[1], la.vf_clip, vf);

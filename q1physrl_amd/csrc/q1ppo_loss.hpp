@@ -31,26 +31,62 @@ struct PpoSums { float ent, kl, surr; };
 // g is then a compile-time constant, so g may live in registers (the native learner's backward kernel computes its own dY with this,
 // q1learner.hpp); FIXED = false reads the structure from Params (the stand-alone kernel below).  Same operations in the same order
 // either way: both users produce the same bits.
-template <bool FIXED>
+// PAIR (with FIXED; the native learner's backward kernel): lanes l and l ^ 32 evaluate the SAME sample, so the four keys' terms - two
+// exponentials, two log1p and two divisions each: half of the function's instructions - are computed once per pair, keys 0, 1 by the
+// lane with half = 0 and keys 2, 3 by its partner, and swapped (six values per key); both lanes then run the accumulations over k = 0..3
+// in the order of the one-lane form, on the same values: the same bits.  All 64 lanes must be active in the call.
+template <bool FIXED, bool PAIR = false>
 __device__ __forceinline__ PpoSums ppo_policy_grad(const Params& p, const float* __restrict__ row, const float* __restrict__ old, const PpoSample& in,
-                                                   float clip, float ent_coeff, float klc, float inv_b, float* __restrict__ g, int row_stride) {
+                                                   float clip, float ent_coeff, float klc, float inv_b, float* __restrict__ g, int row_stride,
+                                                   uint32_t half = 0u) {
+    static_assert(!PAIR || FIXED, "the pair form is written for the fixed action structure");
     const int nk = FIXED ? 4 : p.num_keys;
     const int yaw_mode = FIXED ? 1 : p.yaw_mode;
     const uint32_t kb = in.kb;
     float logp = 0.0f, ent = 0.0f, kl = 0.0f;
     float dlp[4], dh[4], dk[4];
     auto softplus = [](float z) { return (z > 0.0f ? z : 0.0f) + log1pf(expf(-fabsf(z))); };
+    if constexpr (PAIR) {
+        float m[2][6], x[2][6];                                                     // [key of this half][logp term, entropy term, kl term, dlp, dh, dk]
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        if (k >= nk) break;
-        const float d = row[2 * k + 1] - row[2 * k], d_o = old[2 * k + 1] - old[2 * k];
-        const float pn = 1.0f / (1.0f + expf(-d)), po = 1.0f / (1.0f + expf(-d_o));
-        const float a = (float)((kb >> k) & 1u);
-        const float sp_pos = softplus(d), sp_neg = softplus(-d);            // -log p(0), -log p(1)
-        logp -= a != 0.0f ? sp_neg : sp_pos;
-        ent += sp_pos - d * pn;
-        kl += po * (sp_neg - softplus(-d_o)) + (1.0f - po) * (sp_pos - softplus(d_o));
-        dlp[k] = a - pn; dh[k] = -d * pn * (1.0f - pn); dk[k] = pn - po;
+        for (int j = 0; j < 2; ++j) {                                               // this lane's keys: k = 2 half + j
+            const float l0 = half ? row[4 + 2 * j] : row[2 * j], l1 = half ? row[5 + 2 * j] : row[2 * j + 1];
+            const float o0 = half ? old[4 + 2 * j] : old[2 * j], o1 = half ? old[5 + 2 * j] : old[2 * j + 1];
+            const float d = l1 - l0, d_o = o1 - o0;
+            const float pn = 1.0f / (1.0f + expf(-d)), po = 1.0f / (1.0f + expf(-d_o));
+            const float a = (float)((kb >> (2u * half + (uint32_t)j)) & 1u);
+            const float sp_pos = softplus(d), sp_neg = softplus(-d);
+            m[j][0] = a != 0.0f ? sp_neg : sp_pos;
+            m[j][1] = sp_pos - d * pn;
+            m[j][2] = po * (sp_neg - softplus(-d_o)) + (1.0f - po) * (sp_pos - softplus(d_o));
+            m[j][3] = a - pn; m[j][4] = -d * pn * (1.0f - pn); m[j][5] = pn - po;
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int q = 0; q < 6; ++q) x[j][q] = __shfl_xor(m[j][q], 32, 64);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int j = k & 1;
+            const bool mine = (uint32_t)(k >> 1) == half;                           // keys 0, 1 belong to half 0, keys 2, 3 to half 1
+            logp -= mine ? m[j][0] : x[j][0];
+            ent += mine ? m[j][1] : x[j][1];
+            kl += mine ? m[j][2] : x[j][2];
+            dlp[k] = mine ? m[j][3] : x[j][3]; dh[k] = mine ? m[j][4] : x[j][4]; dk[k] = mine ? m[j][5] : x[j][5];
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (k >= nk) break;
+            const float d = row[2 * k + 1] - row[2 * k], d_o = old[2 * k + 1] - old[2 * k];
+            const float pn = 1.0f / (1.0f + expf(-d)), po = 1.0f / (1.0f + expf(-d_o));
+            const float a = (float)((kb >> k) & 1u);
+            const float sp_pos = softplus(d), sp_neg = softplus(-d);            // -log p(0), -log p(1)
+            logp -= a != 0.0f ? sp_neg : sp_pos;
+            ent += sp_pos - d * pn;
+            kl += po * (sp_neg - softplus(-d_o)) + (1.0f - po) * (sp_pos - softplus(d_o));
+            dlp[k] = a - pn; dh[k] = -d * pn * (1.0f - pn); dk[k] = pn - po;
+        }
     }
     float dlp_m = 0.0f, dlp_s = 0.0f, dh_m = 0.0f, dh_s = 0.0f, dk_m = 0.0f, dk_s = 0.0f;
     bool in_m = false, in_s = false;
