@@ -122,8 +122,7 @@ def cpu_baseline(n, action_range, budget_s=10.0, gpu_check=None):
                     "on_ground": env.st["on_ground"].copy(), "t_rem": env.t_rem.copy()}
     dt = spent
     out = {"value": n * ticks / dt, "unit": "env-steps/s", "cores": 1, "kind": "port",
-           "sample": f"{ticks} ticks of {n} envs (ndarray actions, oracle/np_oracle.py, NumPy {np.__version__}) in {dt:.1f} s of oracle time; "
-                     f"host has {os.cpu_count()} logical cores"}
+           "sample": f"{ticks} ticks x {n} envs, oracle/np_oracle.py (NumPy {np.__version__}, ndarray actions), {dt:.1f} s; 1 of {os.cpu_count()} cores"}
     if gpu_check is not None and snap is not None:
         g = gpu_check(acts, EPISODE_TICKS - 1)
         out["parity_vs_gpu_after_719_ticks"] = {
@@ -274,6 +273,86 @@ def traffic_per_launch(pmc, n, ticks_per_launch, resident_state):
         return total * ticks_per_launch / t0
     per_tick = max(total - B_STATE * n, 0.0) / t0
     return B_STATE * n + per_tick * ticks_per_launch
+
+
+# ---- the ONE stdout line ---------------------------------------------------------------------------------------------------------
+LINE_MAX_BYTES = 4096      # the driver keeps the last 8 KB of stdout and parses the line from it (round 4's 20.7 KB line was lost: parsed null)
+
+
+def _sig(x, digits=7):
+    """floats to `digits` significant digits (the line is for reading and for the driver's arithmetic checks: 1e-6 relative is plenty)"""
+    if isinstance(x, float):
+        return float(f"{x:.{digits}g}")
+    if isinstance(x, dict):
+        return {k: _sig(v, digits) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_sig(v, digits) for v in x]
+    return x
+
+
+def extra_path_default():
+    return os.environ.get("Q1_BENCH_EXTRA") or os.path.join(ROOT, "bench_extra.json")
+
+
+def write_extra(out, path=None):
+    """Everything bench.py measured (per-rank rows, host splits, secondary modes, 720-tick steady state, size sweep, sampler block, notes)
+    goes to a side file; the stdout line only names it.  Returns the path written, or None when the directory is not writable."""
+    path = path or extra_path_default()
+    try:
+        tmp = path + ".tmp"
+        with open(tmp, "w") as f:
+            json.dump(out, f, indent=1)
+            f.write("\n")
+        os.replace(tmp, path)
+        return path
+    except OSError as ex:
+        sys.stderr.write(f"bench.py: could not write {path}: {ex!r}\n")
+        return None
+
+
+def contract_line(out, extra_path):
+    """The contract line: the task statement's fields + `roofline` + `cpu_baseline` + one number per steady-state mode, < LINE_MAX_BYTES
+    for any rank count (tests/test_bench_launcher.py, tests/test_bench_gpu.py assert the length at 1, 2 and 8 ranks)."""
+    ro = out.get("roofline") or {}
+    hs = ro.get("host_split_us") or {}
+    line = {k: out.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                                    "vs_baseline", "dtype", "data")}
+    line["config"] = out["config"]
+    line["roofline"] = {k: ro.get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "avg_launch_us",
+                                               "ticks_per_launch", "launches", "pmc_stale")}
+    if isinstance(line["roofline"].get("kernel"), str):
+        line["roofline"]["kernel"] = line["roofline"]["kernel"].split("  (")[0]      # the instantiation; the legend of its arguments is in the side file
+    valu = ro.get("valu") or {}
+    if valu.get("valu_busy_frac") is not None:
+        line["roofline"]["valu_busy_frac"] = valu["valu_busy_frac"]
+    cb = out.get("cpu_baseline")
+    if cb is not None:
+        line["cpu_baseline"] = {k: cb.get(k) for k in ("value", "unit", "cores", "kind", "sample")}
+        par = cb.get("parity_vs_gpu_after_719_ticks")
+        if par:
+            line["cpu_baseline"]["max_abs_pos_diff_vs_gpu_10s"] = max(par["max_abs_pos_xy_diff"], par["max_abs_z_diff"])
+            line["cpu_baseline"]["vel_bit_identical_fraction"] = par["vel_bit_identical_fraction"]
+    else:
+        line["cpu_baseline"] = None
+    for k in ("mode", "mode_fallback", "env_impl", "lib_sha16", "lib_build_id", "ms_per_step_incl_runtime_sync"):
+        line[k] = out.get(k)
+    line["completion"] = out.get("completion")
+    if hs:
+        line["timed_region_us"] = {k: hs.get(k) for k in ("launch_to_signal_seen_us", "device_stamp_us", "hip_event_us", "post_sync_us",
+                                                          "wall_incl_runtime_sync_us") if hs.get(k) is not None}
+    ss = out.get("steady_state_720_ticks")
+    if ss:
+        line["steady_state_us_per_tick"] = {m: v.get("us_per_tick") for m, v in ss.items()}
+    line["extra"] = extra_path
+    text = json.dumps(_sig(line), separators=(",", ":"))
+    if len(text) >= LINE_MAX_BYTES:          # never let prose push the numbers out of the driver's window
+        line["config"] = dict(line["config"], workload=str(line["config"].get("workload"))[:200])
+        if line.get("cpu_baseline"):
+            line["cpu_baseline"]["sample"] = str(line["cpu_baseline"].get("sample"))[:120]
+        line["mode_fallback"] = str(line["mode_fallback"])[:120] if line.get("mode_fallback") else line.get("mode_fallback")
+        text = json.dumps(_sig(line), separators=(",", ":"))
+    assert len(text) < LINE_MAX_BYTES, len(text)
+    return text
 
 
 # ---- CPU placement of a rank (VERDICT r2 item 2): the cores of its GPU's NUMA node -----------------------------------------------
@@ -814,24 +893,22 @@ def main(argv=None):
                 "server": f"tick_pair_lds_kernel<{sp}, {pair_es(n)}>  (SPEC, ES = sub-batches per workgroup; server wave + dependent stand-in producer wave)"}[mode]
 
     def workload(mode):
+        """one clause per item (the full description of each mode is this file's docstring)"""
         if full_cfg:
-            head = (f"BASELINE configs[2]: {n} envs/GPU, full Config (data/params.yml env_config: initial_yaw_range (0, 360), time_limit 10 s, "
-                    "key_press_delay 0.3, dt 0.013888888888888, action_range 10, zero_start_prob 0.01), random starts, random actions (packed, "
-                    "resident in HBM), every finished episode reset IN-KERNEL (counter RNG) before its next tick; ")
+            head = f"BASELINE configs[2]: {n} envs/GPU, params.yml Config, random starts, random packed actions resident in HBM, finished episodes reset IN-KERNEL; "
         else:
             head = (f"BASELINE configs[1]: {n} envs/GPU" if n != 131072 else
                     f"BASELINE configs[3] shard: 131072 envs/GPU ({131072 * world} envs on {world} GPU(s))")
-            head += ", zero-start 100 m run, random actions (packed, resident in HBM), get_default Config, 720-tick episodes with on-device reset of all envs at each episode end; "
+            head += ", zero-start 100 m run, get_default Config, random packed actions resident in HBM, on-device reset at each 720-tick episode end; "
         return head + {
-            "rollout": "mode=rollout: q1env_rollout, one launch per episode chunk, env state in registers between ticks, EVERY tick's obs "
-                       "f32 (N,6) / reward f32 / done u8 written tick-major to HBM",
-            "step": "mode=step" + ("+hipGraph" if not args.no_graph else "") + ": one step_kernel launch per tick (reads + writes the SoA state in HBM "
-                    "every tick), every tick's obs f32 (N,6) / reward f32 / done u8 written to HBM",
-            "server": "mode=server: resident tick server + dependent stand-in producer as ONE dispatch, hand-offs through LDS every tick; "
-                      "per-tick obs / reward / done are consumed by the producer wave and NOT written to HBM (only the last tick's are)"
+            "rollout": "mode=rollout: q1env_rollout, one launch per episode chunk, state in registers, every tick's obs f32 (N,6) / reward f32 / "
+                       "done u8 written tick-major to HBM",
+            "step": "mode=step" + ("+hipGraph" if not args.no_graph else "") + ": one step_kernel launch per tick (SoA state read + written every "
+                    "tick), every tick's obs / reward / done written to HBM",
+            "server": "mode=server: resident tick server + dependent stand-in producer as one dispatch, LDS hand-offs; per-tick outputs are "
+                      "NOT written to HBM (only the last tick's)"
                       if not os.environ.get("Q1_BENCH_SERVER_TWO_STREAMS") else
-                      "mode=server (two streams): resident tick server + dependent producer kernel on a second stream, every tick's results cross "
-                      "as 8-byte tagged granules through L2 / HBM"}[mode]
+                      "mode=server (two streams): tick server + producer kernel on a second stream, results cross as 8-byte tagged granules through L2 / HBM"}[mode]
 
     def roofline(mode, steps, launches_, ev_ms_, wall_):
         """The roofline statement of `mode`'s dominant kernel for a region of `steps` ticks in `launches_` launches and ev_ms_ of HIP-event
@@ -923,6 +1000,7 @@ def main(argv=None):
         "mode": args.mode, "mode_fallback": fallback, "env_impl": env_impl, "lib_sha16": lib_sha16, "lib_build_id": lib_build_id,
         "ms_per_step_incl_runtime_sync": ((host_split.get(args.mode) or {}).get("wall_incl_runtime_sync_us") or wall * 1e6) / 1e3 / args.steps
                                          if world == 1 else None,
+        "completion": (host_split.get(args.mode) or {}).get("completion"),
         "per_rank": ranks,
         "parity": "max |pos - NumPy ref| over the 10 s rollout: measured live in cpu_baseline.parity_vs_gpu_after_719_ticks (N=1 runs); "
                   "tests/test_hip_fastpath.py::test_full_size_rollout_parity_65536_envs_720_ticks checks all 65 536 x 720 env-steps bit-exactly",
@@ -979,7 +1057,8 @@ def main(argv=None):
     else:
         out["cpu_baseline"] = None
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        extra_path = write_extra(out)
+        print(contract_line(out, extra_path), flush=True)
     dev.close()
     if world > 1:
         dist.destroy_process_group()

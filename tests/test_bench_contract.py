@@ -4,6 +4,7 @@ import json
 import os
 import subprocess
 import sys
+import tempfile
 
 import numpy as np
 import pytest
@@ -41,11 +42,18 @@ def test_action_generator_and_traffic_lookup():
 @pytest.mark.gpu
 def test_bench_prints_one_contract_json_line():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "288", "--warmup", "72", "--envs", "8192",
-                        "--no-cpu-baseline"], capture_output=True, text=True, timeout=600)
+                        "--no-cpu-baseline"], capture_output=True, text=True, timeout=600,
+                       env=dict(os.environ, Q1_BENCH_EXTRA=os.path.join(tempfile.gettempdir(), f"q1_bench_extra_contract_{os.getpid()}.json")))
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")]
-    assert len(lines) == 1
-    d = json.loads(lines[0])
+    assert len(lines) == 1 and len(lines[0]) < 4096
+    line = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in line, k
+    with open(line["extra"]) as f:          # the side file: the line's fields + every secondary measurement
+        d = json.load(f)
+    assert abs(d["value"] - line["value"]) <= 1e-6 * d["value"] and set(line["steady_state_us_per_tick"]) == {"rollout", "step", "server"}
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
               "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in d, k

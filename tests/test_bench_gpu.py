@@ -6,6 +6,7 @@ import json
 import os
 import subprocess
 import sys
+import tempfile
 
 import pytest
 
@@ -18,11 +19,25 @@ def _run(args, extra_env=None, timeout=900):
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "Q1_BENCH_ENV_FACTORY", "Q1_BENCH_ALLOW_FAKE"):
         env.pop(k, None)
     env.update(extra_env or {})
+    env["Q1_BENCH_EXTRA"] = os.path.join(tempfile.gettempdir(), f"q1_bench_extra_gpu_{os.getpid()}.json")
     r = subprocess.run([sys.executable, "bench.py"] + args, capture_output=True, text=True, timeout=timeout, env=env, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1, r.stdout[-2000:]
-    return json.loads(lines[0])
+    # the driver parses the line from the last 8 KB of stdout - it must stay small at any rank count; everything
+    # beyond the contract fields lives in the side file the line names.  Returned: the side file (a superset) + the line under "_line".
+    assert len(lines[0]) < 4096, len(lines[0])
+    line = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config", "roofline", "cpu_baseline", "mode", "env_impl", "lib_sha16", "lib_build_id", "extra"):
+        assert k in line, k
+    assert set(("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "avg_launch_us", "ticks_per_launch", "pmc_stale")) <= set(line["roofline"])
+    with open(line["extra"]) as f:
+        full = json.load(f)
+    for k in ("value", "ms_per_step", "n_gpus", "steps", "warmup", "mode"):
+        assert full[k] == line[k] or abs(full[k] - line[k]) <= 1e-6 * abs(full[k]), k
+    full["_line"] = line
+    return full
 
 
 def test_driver_line_single_gpu():

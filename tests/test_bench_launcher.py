@@ -7,6 +7,7 @@ import json
 import os
 import subprocess
 import sys
+import tempfile
 
 import pytest
 
@@ -14,8 +15,16 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 FAKE = "tests._bench_fake:FakeDeviceEnv"
 
 
+CONTRACT_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+                 "data", "config", "roofline", "cpu_baseline")
+_extra_seq = [0]
+
+
 def _run(cmd, extra_env=None, timeout=300):
-    env = dict(os.environ, Q1_BENCH_ENV_FACTORY=FAKE, Q1_BENCH_ALLOW_FAKE="1", PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    _extra_seq[0] += 1
+    extra = os.path.join(tempfile.gettempdir(), f"q1_bench_extra_{os.getpid()}_{_extra_seq[0]}.json")
+    env = dict(os.environ, Q1_BENCH_ENV_FACTORY=FAKE, Q1_BENCH_ALLOW_FAKE="1", Q1_BENCH_EXTRA=extra,
+               PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
     env.update(extra_env or {})
@@ -23,9 +32,24 @@ def _run(cmd, extra_env=None, timeout=300):
 
 
 def _one_json(stdout):
+    """rank 0's stdout is ONE JSON line < 4 KB (the driver parses it from the last 8 KB of stdout) holding the contract
+    fields; everything else bench.py measured is in the side file the line names.  Returns the side file's content (a superset of the
+    line) with the parsed line itself under "_line"."""
     lines = [ln for ln in stdout.splitlines() if ln.strip()]
     assert len(lines) == 1 and lines[0].startswith("{"), stdout          # rank 0's stdout is the JSON line and nothing else
-    return json.loads(lines[0])
+    assert len(lines[0]) < 4096, len(lines[0])
+    line = json.loads(lines[0])
+    for k in CONTRACT_KEYS:
+        assert k in line, k
+    assert set(("workload", "total_envs", "envs_per_gpu", "parallelism", "arithmetic")) <= set(line["config"]) and "model" not in line["config"]
+    assert set(("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "avg_launch_us", "ticks_per_launch", "pmc_stale")) <= set(line["roofline"])
+    with open(line["extra"]) as f:
+        full = json.load(f)
+    os.remove(line["extra"])
+    for k in ("value", "ms_per_step", "n_gpus", "steps", "warmup", "mode"):
+        assert full[k] == line[k] or abs(full[k] - line[k]) <= 1e-6 * abs(full[k]), k
+    full["_line"] = line
+    return full
 
 
 def _check_line(d, world, envs, steps, warmup):
