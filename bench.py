@@ -885,11 +885,13 @@ def main(argv=None):
         smallest whose grid is resident: 256 CUs x 8 workgroups x 64 x ES on an MI355X)"""
         return 1 if n_envs <= 131072 else (2 if n_envs <= 262144 else 3)
 
-    def kernel_name(mode):
+    def kernel_name(mode, ticks_per_launch=None):
         sp = "true" if spec_cfg else "false"
+        # rollout: the action is requested two ticks ahead from 32 ticks per launch (q1env_core.hip ROLLOUT_DEPTH2_MIN_TICKS), one below
+        depth = 2 if (ticks_per_launch or 0) >= 32 else 1
         return {"step": f"step_kernel<float, {sp}, 2>  (OBS_T = float, SPEC, FMT_PACKED)",
-                "rollout": f"rollout_kernel<float, {sp}, 2, {'true' if full_cfg else 'false'}, 1, false>  (OBS_T = float, SPEC, FMT_PACKED, HAS_RESET = "
-                           f"{'true' if full_cfg else 'false'}, OUT_MODE = 1: obs, reward, done every tick, RET = false)",
+                "rollout": f"rollout_kernel<float, {sp}, 2, {'true' if full_cfg else 'false'}, 1, false, {depth}>  (OBS_T = float, SPEC, FMT_PACKED, HAS_RESET = "
+                           f"{'true' if full_cfg else 'false'}, OUT_MODE = 1: obs, reward, done every tick, RET = false, DEPTH = action prefetch distance)",
                 "server": f"tick_pair_lds_kernel<{sp}, {pair_es(n)}>  (SPEC, ES = sub-batches per workgroup; server wave + dependent stand-in producer wave)"}[mode]
 
     def workload(mode):
@@ -933,7 +935,7 @@ def main(argv=None):
         hs = host_split.get(mode) or {}
         stamp_us = hs.get("device_stamp_us")
         r = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-             "kernel": kernel_name(mode), "avg_launch_us": kern_us, "ticks_per_launch": tpl, "launches": launches_,
+             "kernel": kernel_name(mode, tpl), "avg_launch_us": kern_us, "ticks_per_launch": tpl, "launches": launches_,
              "algorithmic_bytes_per_launch": alg_bytes,
              "alg_bytes_per_env_step": B_ALG if not resident else B_FUSED, "alg_bytes_per_env_per_launch": 0.0 if not resident else B_STATE,
              "event_ms_per_step": ev_ms_ / steps, "us_per_tick": ev_ms_ * 1e3 / steps,

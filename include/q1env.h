@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define Q1ENV_ABI_VERSION 4
+#define Q1ENV_ABI_VERSION 5
 
 typedef enum q1env_status {
     Q1ENV_OK = 0,
@@ -203,19 +203,29 @@ int q1env_rollout(q1env_t* env, int ticks, int action_format, const void* act_a_
  * pinned memory the KERNEL writes itself:
  *   start stamp   the device's constant-rate wall clock (wall_clock64 = s_memrealtime) read by the first wave of a launch made with
  *                 Q1ENV_STAMP_START
- *   end stamp     the same clock read by the LAST wave to finish of a launch made with Q1ENV_SIGNAL (every wave, after its final
- *                 stores and an agent-scope release fence, takes a ticket from a device counter; the wave that draws the last one
- *                 knows all others have retired their stores)
+ *   end stamp     the same clock read by the LAST wave to finish of a launch made with Q1ENV_SIGNAL: every wave, after its final
+ *                 stores have been ACKNOWLEDGED (s_waitcnt vmcnt(0)), takes a ticket from a two-level tree of relaxed device
+ *                 counters; the wave that draws the last root ticket knows all others' stores have been acknowledged
  *   sequence      that wave then stores the launch's sequence number with system-scope release: the host thread sees it over PCIe
  *                 ~1 us later by polling its own cache line - q1env_signal_wait - instead of waiting for the dispatch's completion
  *                 interrupt to travel through the runtime.
+ * What the signal GUARANTEES (ABI v5).  q1env_rollout writes every per-tick output (obs / reward / done), the final
+ * env state and return_sum with SYSTEM-scope write-through stores (sc0 sc1 on gfx950): such a store is acknowledged by the memory
+ * side (Infinity Cache / HBM), not by the issuing XCD's private L2, so "every wave's stores are acknowledged" = "every result of the
+ * launch is readable by any agent" - a DMA copy on another stream, the host through a mapped pointer, a kernel on another XCD or
+ * another GPU - with NO further stream synchronisation, event or cache write-back.  The tickets need no release / acquire for this
+ * (it is the acknowledgement that carries the data to memory, not a cache write-back ordered by a fence), which is why they are
+ * relaxed.  tests/test_hip_signal.py::test_signal_carries_visibility_* copy the outputs out through a second, non-blocking stream the
+ * instant q1env_signal_wait returns (no runtime synchronisation in between), 1 000 times at 65 536 envs x 20 ticks, and compare.
+ * q1env_signal_mark's signal sits behind the stream's earlier kernels, whose end-of-kernel release has completed when it runs: the
+ * same guarantee for regions that end in another kernel.  The host-direct small-batch calls use a stricter per-wave system-scope
+ * release before an acquire-release ticket (their results live in host memory).
  * Q1ENV_SIGNAL_WAIT makes the launching call itself poll until the signal arrives (one call across the ABI for launch + wait).
  * q1env_signal_mark: the same end stamp + sequence from a one-wave kernel enqueued behind whatever the stream holds (for regions that
- * do not end in a q1env_rollout launch).  q1env_signal_wait: poll (no sleep) until the last signal requested on this handle has
- * arrived, or timeout_s passes (-> Q1ENV_ERR_HIP, message says so).  q1env_signal_read: the two stamps of the last signalled region
- * and the clock's rate in Hz (hipDeviceAttributeWallClockRate).  The signal says the region's kernels have finished their work; the
- * stream's own ordering (a later launch, hipMemcpy or synchronisation) is what makes their results visible to other agents, as
- * always.  No reference counterpart (the reference is synchronous NumPy). */
+ * do not end in a q1env_rollout launch).  q1env_signal_wait: poll (no sleep; acquire load) until the last signal requested on this
+ * handle has arrived, or timeout_s passes (-> Q1ENV_ERR_HIP after draining the stream, message says so).  q1env_signal_read: the two
+ * stamps of the last signalled region and the clock's rate in Hz (hipDeviceAttributeWallClockRate).  No reference counterpart (the
+ * reference is synchronous NumPy: env.py:507-510 hands the caller arrays it can read - which is what the guarantee above restores). */
 int q1env_signal_mark(q1env_t* env);
 int q1env_signal_wait(q1env_t* env, double timeout_s);
 int q1env_signal_read(q1env_t* env, uint64_t* start_ticks, uint64_t* end_ticks, double* ticks_per_second);
@@ -553,6 +563,14 @@ int q1env_selftest_division(int device, uint64_t n, uint64_t seed, double c0, do
  * [2^-700, 2^700] (must be 0), counts[3] = 0. */
 int q1env_selftest_trig(int device, uint64_t n, const double* yaw_deg, double* sin_out, double* cos_out, uint64_t seed, uint64_t* counts4);
 int q1env_calibrate_traffic(q1env_t* env, int launches);
+/* (ABI v5) visibility check of the completion signal: enqueue, on reader_stream (a hipStream_t other than the handle's), a kernel that
+ * waits for the NEXT signalled launch's sequence number and then compares that launch's tick-major outputs - out_dev: obs f32 [T][N][6]
+ * at offset 0, reward f32 [T][N] at off_reward, done u8 [T][N] at off_done; N % 8 == 0 - with expect_dev (same layout), newest tick
+ * first, using system-scope loads; result_dev = four zeroed 64-bit device words: [0] differing 8-byte words, [1] 1 on timeout, [2] / [3]
+ * device wall clock when the signal was seen / when the newest tick had been checked.  tests/test_hip_signal.py,
+ * tools/visibility_probe.py.  No reference counterpart. */
+int q1env_diag_signal_reader(q1env_t* env, void* reader_stream, const void* out_dev, const void* expect_dev, uint64_t off_reward,
+                             uint64_t off_done, int ticks, int workgroups, double timeout_s, uint64_t* result_dev);
 int q1env_timer_start(q1env_t* env);
 int q1env_timer_stop(q1env_t* env, float* elapsed_ms);   /* = timer_mark + timer_elapsed: synchronises on the stop event */
 /* The two halves of timer_stop, for a timed region that ends in ONE synchronisation of the caller's own: mark records the

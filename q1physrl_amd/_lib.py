@@ -13,7 +13,7 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 # Q1ENV_LIB_PATH selects another build of the SAME library (tools/asan_check.sh: the AddressSanitizer build of the host side)
 LIB_PATH = os.environ.get("Q1ENV_LIB_PATH") or os.path.join(_PKG, "libq1env.so")
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 ACT_F64_ROWS, ACT_F32_ROWS, ACT_PACKED, ACT_RANDOM = 0, 1, 2, 3
 OBS_F64, OBS_F32 = 0, 1
 TIMER_START, TIMER_STOP = 4, 8     # q1env_step_many use_graph flags: record the handle's start / stop timer event around the launches
@@ -132,6 +132,7 @@ _SIGNATURES = {
     "q1env_selftest_division": (C.c_int, [C.c_int, C.c_uint64, C.c_uint64, C.c_double, C.c_double, C.POINTER(C.c_uint64)]),
     "q1env_selftest_trig": (C.c_int, [C.c_int, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]),
     "q1env_calibrate_traffic": (C.c_int, [_P, C.c_int]),
+    "q1env_diag_signal_reader": (C.c_int, [_P, _P, _P, _P, C.c_uint64, C.c_uint64, C.c_int, C.c_int, C.c_double, _P]),
     "q1env_signal_mark": (C.c_int, [_P]),
     "q1env_signal_wait": (C.c_int, [_P, C.c_double]),
     "q1env_signal_read": (C.c_int, [_P, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_double)]),

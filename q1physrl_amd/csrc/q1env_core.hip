@@ -101,7 +101,7 @@ step_autoreset_kernel(Params p, StatePtrs s, int fmt, const void* act_a, const v
 //             0 = no per-tick output at all, -1 = decided per pointer at run time.
 //   FULL:     every lane of the wave owns an env (the ragged tail wave runs its own copy of the loop, so that the
 //             number of stores per iteration is a compile-time constant in both).
-template <typename OBS_T, bool SPEC, int FMT, bool HAS_RESET, int OUT_MODE, bool RET, bool FULL>
+template <typename OBS_T, bool SPEC, int FMT, bool HAS_RESET, int OUT_MODE, bool RET, bool FULL, int DEPTH_>
 __device__ __forceinline__ void rollout_loop(const Params& p, const double* move_tab, Env& e, uint32_t i, uint32_t n, int ticks, int fmt,
                                              const void* act_a, const void* act_b, uint64_t seed, uint64_t tick0,
                                              OBS_T* obs, float* reward, uint8_t* done, int auto_reset, double& ret,
@@ -115,13 +115,25 @@ __device__ __forceinline__ void rollout_loop(const Params& p, const double* move
     // one, which re-reads its own action instead of running past the caller's arrays: one scalar select for both strides instead of a
     // 64-bit multiply-add per array.
     constexpr bool PREFETCH = (FMT == FMT_PACKED);
-    uint32_t kraw_next = 0;
-    float mraw_next = 0.0f;
+    constexpr int DEPTH = PREFETCH ? DEPTH_ : 1;
+    // DEPTH 2: two ticks ahead, in TWO register sets used by alternate ticks (the loop is unrolled by two so that no value has to be
+    // moved between them - a move of a prefetched value would itself have to wait for it): the wait for a prefetched action then only
+    // covers memory operations at least two ticks old.  gfx9's vmcnt retires loads and stores in order, so with depth 1 the wait also
+    // covers the PREVIOUS tick's output stores - and a write-through store's acknowledgement comes from the memory side, not from L2.
+    uint32_t kraw_a = 0, kraw_b = 0;
+    float mraw_a = 0.0f, mraw_b = 0.0f;
     const uint8_t* ka = (const uint8_t*)act_a + i;
     const float* ma = (const float*)act_b + i;
     if constexpr (PREFETCH) {
-        kraw_next = *ka;
-        mraw_next = *ma;
+        kraw_a = *ka;
+        mraw_a = *ma;
+        if constexpr (DEPTH == 2) {
+            const size_t stride = (1 < ticks) ? (size_t)n : (size_t)0;
+            ka += stride;
+            ma += stride;
+            kraw_b = *ka;
+            mraw_b = *ma;
+        }
         // Drain every outstanding load (state + first action) once, here: the waitcnt scoreboard then enters the
         // loop clean, so inside the loop the wait for a prefetched action is vmcnt(#younger ops) as seen along the
         // back edge - it no longer has to cover the preheader's load order and does not drain the tick's stores.
@@ -130,20 +142,20 @@ __device__ __forceinline__ void rollout_loop(const Params& p, const double* move
     TickConsts tc = tick_consts();
     tc.move_tab = move_tab;
     tc.has_move_tab = true;
-    for (int t = 0; t < ticks; ++t) {
+    auto one_tick = [&](const int t, uint32_t& kraw, float& mraw) __attribute__((always_inline)) {
         double yaw_act;
         uint32_t keys;
         if constexpr (PREFETCH) {
-            // decode tick t's raw action FIRST, then request tick t+1's into the same two registers (the empty asm keeps the requests
+            // decode tick t's raw action FIRST, then request tick t+DEPTH's into the same two registers (the empty asm keeps the requests
             // behind the decode: no register copies, and the loop closes with ONE conditional branch)
-            keys = kraw_next & 0xFu;
-            yaw_act = (double)mraw_next;
+            keys = kraw & 0xFu;
+            yaw_act = (double)mraw;
             asm volatile("" : "+v"(keys), "+v"(yaw_act) : : "memory");
-            const size_t stride = (t + 1 < ticks) ? (size_t)n : (size_t)0;
+            const size_t stride = (t + DEPTH < ticks) ? (size_t)n : (size_t)0;
             ka += stride;
             ma += stride;
-            kraw_next = *ka;
-            mraw_next = *ma;
+            kraw = *ka;
+            mraw = *ma;
         } else if (random) {
             keys = random_action<SPEC>(p, seed, genv, tick0 + (uint64_t)t, &yaw_act);
         } else {
@@ -152,19 +164,27 @@ __device__ __forceinline__ void rollout_loop(const Params& p, const double* move
         TickOut<OBS_T> o;
         tick<OBS_T, SPEC>(p, tc, e, keys, yaw_act, o);
         const size_t base = (size_t)t * n;
-        // The per-tick outputs are written once and read by a later kernel / the host: non-temporal stores (no reason to keep 34 B per
-        // env-step dirty in L2 until the launch ends and its release writes them back).  A/B on MI355X, 65 536 envs (Q1_ROLLOUT_OUT_STORES
-        // = 0 builds the plain stores): 20-tick launch 25.6 -> 24.4 us, 720-tick launches 1.09 -> 1.03 us per tick incl. the resets.
+        // The per-tick outputs are written once and read by a later kernel / the host.  Q1_ROLLOUT_OUT_STORES = 2 (product): system-scope
+        // write-through stores (store_sys in q1env_device.hpp) - acknowledged by the memory side, so the launch's completion signal means
+        // "readable by anyone"; the write-through form of the ragged tail's rows included.  1 = non-temporal stores (round 4: acknowledged
+        // by the XCD's L2, written back by the end-of-kernel release), 0 = plain stores.  A/B on MI355X: profiles/r5_visibility.txt.
 #ifndef Q1_ROLLOUT_OUT_STORES
-#define Q1_ROLLOUT_OUT_STORES 1
+#define Q1_ROLLOUT_OUT_STORES 2
 #endif
         if (OUT_MODE == 1 || (OUT_MODE < 0 && obs)) {
             if constexpr (sizeof(OBS_T) == 4 && FULL) {
-                if constexpr (Q1_ROLLOUT_OUT_STORES == 1) write_obs_wave_f32_nt(obs, base + wave_first, lane, o.obs, slab);
+                if constexpr (Q1_ROLLOUT_OUT_STORES == 2) write_obs_wave_f32_sys(obs, base + wave_first, lane, o.obs, slab);
+                else if constexpr (Q1_ROLLOUT_OUT_STORES == 1) write_obs_wave_f32_nt(obs, base + wave_first, lane, o.obs, slab);
                 else write_obs_wave_f32(obs, base + wave_first, lane, o.obs, slab);
+            } else if constexpr (Q1_ROLLOUT_OUT_STORES == 2) {
+#pragma unroll
+                for (int j = 0; j < 6; ++j) store_sys(obs + (base + i) * 6 + j, o.obs[j]);
             } else write_obs<OBS_T>(obs, base + i, o.obs);
         }
-        if constexpr (Q1_ROLLOUT_OUT_STORES == 1) {
+        if constexpr (Q1_ROLLOUT_OUT_STORES == 2) {
+            if (OUT_MODE == 1 || (OUT_MODE < 0 && reward)) store_sys(reward + base + i, o.reward);
+            if (OUT_MODE == 1 || (OUT_MODE < 0 && done)) store_sys(done + base + i, (uint8_t)(o.done ? 1 : 0));
+        } else if constexpr (Q1_ROLLOUT_OUT_STORES == 1) {
             if (OUT_MODE == 1 || (OUT_MODE < 0 && reward)) __builtin_nontemporal_store(o.reward, reward + base + i);
             if (OUT_MODE == 1 || (OUT_MODE < 0 && done)) __builtin_nontemporal_store((uint8_t)(o.done ? 1 : 0), done + base + i);
         } else {
@@ -175,12 +195,23 @@ __device__ __forceinline__ void rollout_loop(const Params& p, const double* move
         if constexpr (HAS_RESET) {
             if (auto_reset && o.done) reset_philox(p, e, seed, genv, tick0 + (uint64_t)t + 1);
         }
+    };
+    if constexpr (DEPTH == 2) {
+        int t = 0;
+        for (; t + 1 < ticks; t += 2) {
+            one_tick(t, kraw_a, mraw_a);
+            one_tick(t + 1, kraw_b, mraw_b);
+        }
+        if (t < ticks) one_tick(t, kraw_a, mraw_a);
+    } else {
+        for (int t = 0; t < ticks; ++t) one_tick(t, kraw_a, mraw_a);
     }
 }
 
 // RET: the launch accumulates each env's reward in float64 for return_sum (a convert and an add per tick that a caller who reads the
 // per-tick rewards anyway - the bench, the sampler - does not pay for).
-template <typename OBS_T, bool SPEC, int FMT, bool HAS_RESET, int OUT_MODE, bool RET>
+// DEPTH: how many ticks ahead the packed action is requested (rollout_loop): 1 for short launches, 2 from ROLLOUT_DEPTH2_MIN_TICKS ticks.
+template <typename OBS_T, bool SPEC, int FMT, bool HAS_RESET, int OUT_MODE, bool RET, int DEPTH = 1>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4)))
 rollout_kernel(Params p, StatePtrs s, int ticks, int fmt, const void* act_a, const void* act_b,
                uint64_t seed, uint64_t tick0, OBS_T* obs, float* reward, uint8_t* done,
@@ -197,21 +228,22 @@ rollout_kernel(Params p, StatePtrs s, int ticks, int fmt, const void* act_a, con
     double ret = 0.0;
     float* my_slab = slab[threadIdx.x >> 6];
     if (i - (threadIdx.x & 63u) + 64u <= n)
-        rollout_loop<OBS_T, SPEC, FMT, HAS_RESET, OUT_MODE, RET, true>(p, mt, e, i, n, ticks, fmt, act_a, act_b, seed, tick0, obs, reward,
+        rollout_loop<OBS_T, SPEC, FMT, HAS_RESET, OUT_MODE, RET, true, DEPTH>(p, mt, e, i, n, ticks, fmt, act_a, act_b, seed, tick0, obs, reward,
                                                                         done, auto_reset, ret, my_slab);
     else
-        rollout_loop<OBS_T, SPEC, FMT, HAS_RESET, OUT_MODE, RET, false>(p, mt, e, i, n, ticks, fmt, act_a, act_b, seed, tick0, obs, reward,
+        rollout_loop<OBS_T, SPEC, FMT, HAS_RESET, OUT_MODE, RET, false, DEPTH>(p, mt, e, i, n, ticks, fmt, act_a, act_b, seed, tick0, obs, reward,
                                                                          done, auto_reset, ret, my_slab);
     // The final stores address the arrays from a laundered copy of the index: the twelve 64-bit addresses of the initial loads
     // would otherwise stay in registers across the whole tick loop (24 VGPRs on top of the state and the tick's constants).
     uint32_t i_st = i;
     asm volatile("" : "+v"(i_st));
-#ifndef Q1_ROLLOUT_STATE_NT
-#define Q1_ROLLOUT_STATE_NT 1
+#ifndef Q1_ROLLOUT_STATE_NT         // 2 (product) = system-scope write-through (store_sys), 1 = non-temporal (round 4), 0 = plain
+#define Q1_ROLLOUT_STATE_NT 2
 #endif
-    if constexpr (Q1_ROLLOUT_STATE_NT == 1) store_env_nt(s, n, i_st, e);
+    if constexpr (Q1_ROLLOUT_STATE_NT == 2) store_env_sys(s, n, i_st, e);
+    else if constexpr (Q1_ROLLOUT_STATE_NT == 1) store_env_nt(s, n, i_st, e);
     else store_env(s, n, i_st, e);
-    if constexpr (RET) { if (return_sum) return_sum[i_st] += ret; }
+    if constexpr (RET) { if (return_sum) store_sys(return_sum + i_st, return_sum[i_st] + ret); }
     signal_done(sg, i_st >> 6);
 }
 
@@ -437,23 +469,34 @@ static Signal direct_signal(q1env* h, size_t items) {
 }
 
 // Poll the sequence word until the last requested signal has arrived.  No sleep, no yield: the caller asked for latency.
+// The load that sees the number is an ACQUIRE: the host's reads of the results that follow it (host-direct block, or the stamps) cannot be
+// taken before it.  On a timeout the launch may still be queued or running and will write the signal words / the host-direct block later:
+// the stream is drained before the error is returned, so that the caller's next call cannot race with it.
+static inline void cpu_relax() {
+#if defined(__x86_64__) || defined(__i386__)
+    __builtin_ia32_pause();
+#elif defined(__aarch64__)
+    asm volatile("yield");
+#endif
+}
 int signal_wait(q1env* h, double timeout_s) {
     const uint64_t want = h->sig_seq;
-    volatile uint64_t* seq = h->sig_host + 2;
-    if (*seq >= want) return Q1ENV_OK;
+    const uint64_t* seq = const_cast<const uint64_t*>(h->sig_host + 2);
+    if (__atomic_load_n(seq, __ATOMIC_ACQUIRE) >= want) return Q1ENV_OK;
     struct timespec t0;
     clock_gettime(CLOCK_MONOTONIC, &t0);
     for (;;) {
         for (int k = 0; k < 256; ++k) {
-            if (*seq >= want) return Q1ENV_OK;
-            __builtin_ia32_pause();
+            if (__atomic_load_n(seq, __ATOMIC_ACQUIRE) >= want) return Q1ENV_OK;
+            cpu_relax();
         }
         struct timespec t1;
         clock_gettime(CLOCK_MONOTONIC, &t1);
         if ((double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec) > timeout_s) {
             const hipError_t q = hipStreamQuery(h->stream);
-            return fail(Q1ENV_ERR_HIP, std::string("completion signal did not arrive within the timeout (stream state: ") +
-                                       hipGetErrorString(q) + ")");
+            const std::string state = hipGetErrorString(q);
+            (void)hipStreamSynchronize(h->stream);         // nothing of this launch is left in flight when the error is returned
+            return fail(Q1ENV_ERR_HIP, "completion signal did not arrive within the timeout (stream state: " + state + "; stream drained)");
         }
     }
 }
@@ -959,6 +1002,7 @@ int q1env_step_many(q1env_t* h, int ticks, int fmt, const void* a, const void* b
     return Q1ENV_OK;
 }
 
+constexpr int ROLLOUT_DEPTH2_MIN_TICKS = 32;
 int q1env_rollout(q1env_t* h, int ticks, int fmt, const void* a, const void* b, uint64_t seed, int obs_format,
                   void* obs, float* reward, uint8_t* done, int auto_reset, double* return_sum) {
     if (!h) return fail(Q1ENV_ERR_INVALID_ARG, "q1env_rollout: null handle");
@@ -985,18 +1029,24 @@ int q1env_rollout(q1env_t* h, int ticks, int fmt, const void* a, const void* b, 
     const int blk = block_for(h->p.n);
     const dim3 g = grid_for(h->p.n, blk), bs(blk);
     const bool spec = is_spec(h->p);
-#define Q1_LAUNCH_ROLL(OT, SP, FM, HR, OM, RT)                                                                           \
-    hipLaunchKernelGGL((rollout_kernel<OT, SP, FM, HR, OM, RT>), g, bs, 0, h->stream, h->p, h->st, ticks, fmt, a, b, seed, \
+#define Q1_LAUNCH_ROLL_D(OT, SP, FM, HR, OM, RT, DP)                                                                         \
+    hipLaunchKernelGGL((rollout_kernel<OT, SP, FM, HR, OM, RT, DP>), g, bs, 0, h->stream, h->p, h->st, ticks, fmt, a, b, seed, \
                        h->tick_count, (OT*)obs, reward, done, auto_reset, return_sum, sg)
+#define Q1_LAUNCH_ROLL(OT, SP, FM, HR, OM, RT) Q1_LAUNCH_ROLL_D(OT, SP, FM, HR, OM, RT, 1)
+    // Packed actions with every output written: from ROLLOUT_DEPTH2_MIN_TICKS ticks per launch the action is requested TWO ticks ahead
+    // (rollout_loop DEPTH 2; + 10 % steady state with the write-through output stores, profiles/r5_visibility.txt); shorter launches
+    // keep the one-tick form (smaller prologue, no gain to amortise).  Q1ENV_ROLLOUT_DEPTH=1|2 in the environment forces one (A/B).
+    static const int depth_forced = [] { const char* e = getenv("Q1ENV_ROLLOUT_DEPTH"); return e ? atoi(e) : 0; }();
+    const bool deep = depth_forced ? depth_forced == 2 : ticks >= ROLLOUT_DEPTH2_MIN_TICKS;
     const bool all_out = obs && reward && done, no_out = !obs && !reward && !done;
     if (obs_format == Q1ENV_OBS_F32 && spec && (all_out || no_out) && !return_sum &&
         (fmt == Q1ENV_ACT_PACKED || fmt == Q1ENV_ACT_RANDOM)) {
         const int which = (fmt == Q1ENV_ACT_RANDOM ? 4 : 0) + (auto_reset ? 2 : 0) + (all_out ? 1 : 0);
         switch (which) {
             case 0: Q1_LAUNCH_ROLL(float, true, FMT_PACKED, false, 0, false); break;
-            case 1: Q1_LAUNCH_ROLL(float, true, FMT_PACKED, false, 1, false); break;
+            case 1: if (deep) Q1_LAUNCH_ROLL_D(float, true, FMT_PACKED, false, 1, false, 2); else Q1_LAUNCH_ROLL(float, true, FMT_PACKED, false, 1, false); break;
             case 2: Q1_LAUNCH_ROLL(float, true, FMT_PACKED, true, 0, false); break;
-            case 3: Q1_LAUNCH_ROLL(float, true, FMT_PACKED, true, 1, false); break;
+            case 3: if (deep) Q1_LAUNCH_ROLL_D(float, true, FMT_PACKED, true, 1, false, 2); else Q1_LAUNCH_ROLL(float, true, FMT_PACKED, true, 1, false); break;
             case 4: Q1_LAUNCH_ROLL(float, true, FMT_RANDOM, false, 0, false); break;
             case 5: Q1_LAUNCH_ROLL(float, true, FMT_RANDOM, false, 1, false); break;
             case 6: Q1_LAUNCH_ROLL(float, true, FMT_RANDOM, true, 0, false); break;
@@ -1012,6 +1062,7 @@ int q1env_rollout(q1env_t* h, int ticks, int fmt, const void* a, const void* b, 
         Q1_LAUNCH_ROLL(double, false, FMT_RUNTIME, true, -1, true);
     }
 #undef Q1_LAUNCH_ROLL
+#undef Q1_LAUNCH_ROLL_D
     HIP_TRY(hipGetLastError());
     if (t_stop) HIP_TRY(hipEventRecord(h->ev1, h->stream));
     h->tick_count += (uint64_t)ticks;

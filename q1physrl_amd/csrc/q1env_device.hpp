@@ -375,8 +375,37 @@ __device__ __forceinline__ void load_env(const StatePtrs& s, uint32_t n, uint32_
     e.flags = s.flags[i];
 }
 
-// the same, write-through (non-temporal): a multi-tick launch's final state is read again by the NEXT launch at the earliest, and lines
-// left dirty in L2 are written back by the dispatch's end-of-kernel release anyway - after the last wave has gone
+// ---- stores that are VISIBLE when they are acknowledged
+// An MI355X has eight XCDs, each with its own write-back L2 that is not coherent with the others: an ordinary (or non-temporal) store is
+// acknowledged by the issuing XCD's L2 and may sit there dirty until the dispatch's end-of-kernel release writes the cache back - after
+// the last wave has gone, behind the runtime's completion path.  A kernel that announces its own completion (signal_done below) would
+// then announce results a DMA engine, the host or another XCD cannot read yet.  A SYSTEM-scope store (sc0 sc1 on gfx942 / gfx950: a
+// relaxed system-scope atomic store is exactly the plain store instruction with those two bits) is written THROUGH the L2 to the
+// memory side (Infinity Cache / HBM, which every agent reads coherently) and its acknowledgement - what s_waitcnt vmcnt(0) waits for -
+// comes from there.  "All my stores are acknowledged" then means "all my results are readable by anyone", with no cache write-back.
+// The outputs and the final state of a multi-tick launch are written once and not read again by the launch: write-through costs nothing
+// a write-back would not have to pay later.  tests/test_hip_signal.py reads them back through a DMA copy on a second stream the
+// instant the signal arrives, 1 000 times, to hold the kernels to this.
+__device__ __forceinline__ void store_sys(float* p, float v) {
+    __hip_atomic_store(reinterpret_cast<uint32_t*>(p), __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ __forceinline__ void store_sys(double* p, double v) {
+    __hip_atomic_store(reinterpret_cast<uint64_t*>(p), (uint64_t)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ __forceinline__ void store_sys(uint8_t* p, uint8_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+__device__ __forceinline__ void store_sys(uint64_t* p, uint64_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+
+__device__ __forceinline__ void store_env_sys(const StatePtrs& s, uint32_t n, uint32_t i, const Env& e) {
+    store_sys(s.vx + i, e.vx); store_sys(s.vy + i, e.vy); store_sys(s.vz + i, e.vz);
+    store_sys(s.px + i, e.px); store_sys(s.py + i, e.py); store_sys(s.z + i, e.z);
+    store_sys(s.yaw + i, e.yaw); store_sys(s.trem + i, e.trem);
+#pragma unroll
+    for (uint32_t k = 0; k < 4; ++k) store_sys(s.lk + (size_t)k * n + i, e.lk[k]);
+    store_sys(s.flags + i, (uint8_t)e.flags);
+}
+
+// the same, non-temporal (the round-4 form, kept as the A/B: Q1_ROLLOUT_STATE_NT = 1): lines left dirty in L2 are written back by
+// the dispatch's end-of-kernel release - after the last wave has gone
 __device__ __forceinline__ void store_env_nt(const StatePtrs& s, uint32_t n, uint32_t i, const Env& e) {
     __builtin_nontemporal_store(e.vx, s.vx + i); __builtin_nontemporal_store(e.vy, s.vy + i); __builtin_nontemporal_store(e.vz, s.vz + i);
     __builtin_nontemporal_store(e.px, s.px + i); __builtin_nontemporal_store(e.py, s.py + i); __builtin_nontemporal_store(e.z, s.z + i);
@@ -445,6 +474,7 @@ struct Signal {
     uint32_t flags;         // bit 0: stamp the start; bit 1: stamp the end + publish seq
 };
 constexpr uint32_t SIGNAL_LEAVES = 64, SIGNAL_LEAF_STRIDE = 64;            // (uint32 units: 256 B)
+constexpr uint32_t SIGNAL_SEQ_DEV_OFFSET = 16;                             // (uint32 units behind the root ticket: the device-resident sequence copy)
 __device__ __forceinline__ void signal_start(const Signal& g) {
     if (g.sig && (g.flags & 1u) && blockIdx.x == 0 && threadIdx.x == 0)
         __hip_atomic_store(g.sig, (uint64_t)wall_clock64(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -464,6 +494,9 @@ __device__ __forceinline__ void signal_done(const Signal& g, uint32_t wave) {
             if (__hip_atomic_fetch_add(root, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u == leaves) {
                 __hip_atomic_store(root, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 __hip_atomic_store(g.sig + 1, (uint64_t)wall_clock64(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                // a device-resident copy of the sequence number (64 B behind the root ticket), for on-device consumers that poll for
+                // this launch (the visibility reader of q1env_diag_signal_reader: polling host memory from the device proved slow)
+                __hip_atomic_store(reinterpret_cast<uint64_t*>(root + SIGNAL_SEQ_DEV_OFFSET), g.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 __hip_atomic_store(g.sig + 2, g.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
             }
         }
@@ -860,6 +893,29 @@ __device__ __forceinline__ void write_obs_wave_f32(float* obs, size_t wave_first
     const float2* src = reinterpret_cast<const float2*>(slab);
 #pragma unroll
     for (uint32_t k = 0; k < 3; ++k) dst[k * 64u + lane] = src[k * 64u + lane];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// Same, with system-scope (write-through) stores: see store_sys.
+__device__ __forceinline__ void write_obs_wave_f32_sys(float* obs, size_t wave_first, uint32_t lane, const float o[6],
+                                                       float* slab) {
+    float2* w = reinterpret_cast<float2*>(slab + lane * 6);
+    w[0] = make_float2(o[0], o[1]);
+    w[1] = make_float2(o[2], o[3]);
+    w[2] = make_float2(o[4], o[5]);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    uint64_t* dst = reinterpret_cast<uint64_t*>(obs + wave_first * 6);
+    const uint64_t* src = reinterpret_cast<const uint64_t*>(slab);
+    // all three LDS reads first, then the stores: the compiler keeps other memory operations in program order around an atomic store,
+    // and would otherwise issue read / wait / store three times (one LDS latency per store instead of one per row)
+    uint64_t v0 = src[lane], v1 = src[64u + lane], v2 = src[128u + lane];
+    asm volatile("" : "+v"(v0), "+v"(v1), "+v"(v2));
+    store_sys(dst + lane, v0);
+    store_sys(dst + 64u + lane, v1);
+    store_sys(dst + 128u + lane, v2);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
 }

@@ -2,6 +2,8 @@
 // kernel (known bytes in step_kernel's own access pattern) and the on-device check of the exact-division shortcuts.
 #include "q1env_host.hpp"
 
+#include <time.h>
+
 using namespace q1;
 
 // Traffic calibration for the PMC counters (MI355X_MICROARCH.md "HBM": FETCH_SIZE / WRITE_SIZE must be calibrated on
@@ -81,6 +83,52 @@ selftest_division_kernel(uint64_t n, uint64_t seed, double c_extra0, double c_ex
     if (bad1) atomicAdd(&counts[1], (unsigned long long)bad1);
     if (bad2) atomicAdd(&counts[2], (unsigned long long)bad2);
     if (bad3) atomicAdd(&counts[3], (unsigned long long)bad3);
+}
+
+// The reader of tests/test_hip_signal.py's visibility check: launched on ANOTHER stream BEFORE a signalled q1env_rollout, it polls the
+// launch's sequence number (its device-resident copy, written just before the word the host polls); the moment it is there it reads the launch's tick-major outputs with
+// system-scope loads (what any other agent effectively does: nothing served from this XCD's own L2) and counts the 8-byte words that
+// differ from `expect` - NEWEST TICK FIRST (done, reward, obs of tick T-1, then T-2, ...): the last ticks' results are the ones that
+// could still sit dirty in another XCD's L2 if the signal were published without visibility, and this reader - on the same device,
+// a microsecond or two behind the signal, its workgroups spread over all eight XCDs - is the consumer most likely to catch it.
+// Arena layout (both out and expect): obs f32 [T][n][6] at 0, reward f32 [T][n] at off_rew, done u8 [T][n] at off_done; n % 8 == 0.
+// result[0] = differing words, result[1] = 1 if the sequence number did not arrive within ~timeout_ticks of the wall clock,
+// result[2] = wall clock when workgroup 0 saw the signal, result[3] = wall clock when workgroup 0 finished the newest tick.
+__global__ void __launch_bounds__(256)
+signal_reader_kernel(uint64_t* sig, const uint64_t* seq_dev, uint64_t want_seq, const char* out, const char* expect, uint64_t off_rew, uint64_t off_done,
+                     uint32_t n, uint32_t ticks, uint64_t timeout_ticks, unsigned long long* result) {
+    __shared__ int ok;
+    if (threadIdx.x == 0) {
+        const uint64_t t0 = wall_clock64();
+        int seen = 0;
+        // "armed": the host side of q1env_diag_signal_reader returns only when workgroup 0 is polling (sig[3] is a spare word of the block)
+        if (blockIdx.x == 0) __hip_atomic_store(sig + 3, want_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        for (;;) {
+            // the DEVICE-resident copy of the sequence number, which the signalling wave writes (write-through) just before the host's
+            if (__hip_atomic_load(seq_dev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) >= want_seq) { seen = 1; break; }
+            if (wall_clock64() - t0 > timeout_ticks) break;
+            __builtin_amdgcn_s_sleep(1);
+        }
+        ok = seen;
+        if (blockIdx.x == 0) result[2] = seen ? (unsigned long long)wall_clock64() : 0ull;
+    }
+    __syncthreads();
+    if (!ok) { if (threadIdx.x == 0) atomicMax(result + 1, 1ull); return; }
+    unsigned long long bad = 0;
+    const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (uint64_t)gridDim.x * blockDim.x;
+    for (int t = (int)ticks - 1; t >= 0; --t) {
+        const uint64_t base[3] = {off_done + (uint64_t)t * n, off_rew + (uint64_t)t * n * 4u, (uint64_t)t * n * 24u};
+        const uint64_t words[3] = {n / 8u, n / 2u, n * 3ull};
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const uint64_t* o = reinterpret_cast<const uint64_t*>(out + base[a]);
+            const uint64_t* e = reinterpret_cast<const uint64_t*>(expect + base[a]);
+            for (uint64_t j = tid; j < words[a]; j += stride)
+                bad += __hip_atomic_load(o + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != e[j] ? 1ull : 0ull;
+        }
+        if (t == (int)ticks - 1 && tid == 0) result[3] = (unsigned long long)wall_clock64();
+    }
+    if (bad) atomicAdd(result, bad);
 }
 
 extern "C" {
@@ -194,6 +242,35 @@ int q1env_timer_stop(q1env_t* h, float* ms) {
     HIP_TRY(hipEventRecord(h->ev1, h->stream));
     HIP_TRY(hipEventSynchronize(h->ev1));
     HIP_TRY(hipEventElapsedTime(ms, h->ev0, h->ev1));
+    return Q1ENV_OK;
+}
+
+// Diagnostics for the completion signal's visibility guarantee (include/q1env.h): enqueue signal_reader_kernel on `reader_stream` for the
+// NEXT signalled launch of this handle.  out / expect: device arenas laid out obs | reward | done (see the kernel); result_dev: four
+// 64-bit words, zeroed by the caller.  The caller then makes the signalled launch and synchronises reader_stream.
+int q1env_diag_signal_reader(q1env_t* h, void* reader_stream, const void* out_dev, const void* expect_dev, uint64_t off_reward,
+                             uint64_t off_done, int ticks, int workgroups, double timeout_s, uint64_t* result_dev) {
+    if (!h || !out_dev || !expect_dev || !result_dev || ticks <= 0 || workgroups <= 0 || (h->p.n & 7) || (off_reward & 7u) || (off_done & 7u))
+        return fail(Q1ENV_ERR_INVALID_ARG, "q1env_diag_signal_reader: bad argument (num_envs and the offsets must be multiples of 8)");
+    DeviceGuard guard(h->device);
+    if (int r = ensure_signal(h)) return r;
+    const uint64_t tmo = (uint64_t)(timeout_s * (h->wall_clock_hz > 0 ? h->wall_clock_hz : 1e8));
+    hipLaunchKernelGGL(signal_reader_kernel, dim3(workgroups), dim3(256), 0, (hipStream_t)reader_stream, h->sig_dev,
+                       reinterpret_cast<const uint64_t*>(h->ticket_dev + SIGNAL_LEAVES * SIGNAL_LEAF_STRIDE + SIGNAL_SEQ_DEV_OFFSET), h->sig_seq + 1,
+                       (const char*)out_dev, (const char*)expect_dev, off_reward, off_done, (uint32_t)h->p.n, (uint32_t)ticks, tmo,
+                       (unsigned long long*)result_dev);
+    HIP_TRY(hipGetLastError());
+    // return when the reader is resident and polling (a kernel launched on a fresh stream can take > 100 us to start: the rollout that
+    // follows would otherwise be over before its reader runs)
+    const uint64_t want = h->sig_seq + 1;
+    struct timespec t0;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    while (__atomic_load_n(const_cast<const uint64_t*>(h->sig_host + 3), __ATOMIC_ACQUIRE) != want) {
+        struct timespec t1;
+        clock_gettime(CLOCK_MONOTONIC, &t1);
+        if ((double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec) > timeout_s)
+            return fail(Q1ENV_ERR_HIP, "q1env_diag_signal_reader: the reader kernel did not start within the timeout");
+    }
     return Q1ENV_OK;
 }
 

@@ -352,6 +352,12 @@ class DeviceEnv:
     def calibrate_traffic(self, launches=10):
         _lib.check(self._lib.q1env_calibrate_traffic(self._h, int(launches)))
 
+    def diag_signal_reader(self, reader_stream, out_dev, expect_dev, off_reward, off_done, ticks, result_dev, workgroups=256, timeout_s=2.0):
+        """Enqueue the visibility reader (include/q1env.h q1env_diag_signal_reader) on reader_stream for the NEXT signalled launch."""
+        _lib.check(self._lib.q1env_diag_signal_reader(self._h, C.c_void_p(int(reader_stream)), C.c_void_p(int(out_dev)), C.c_void_p(int(expect_dev)),
+                                                      int(off_reward), int(off_done), int(ticks), int(workgroups), float(timeout_s),
+                                                      C.c_void_p(int(result_dev))))
+
     # ---- completion signal (include/q1env.h, ABI v4): stamps + sequence number written by the kernels themselves
     def signal_mark(self):
         """End stamp + sequence number behind whatever the stream holds (for regions that do not end in a rollout launch)."""

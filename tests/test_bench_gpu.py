@@ -45,7 +45,7 @@ def test_driver_line_single_gpu():
     assert d["env_impl"] == "q1physrl_amd.device.DeviceEnv" and d["mode"] == "rollout" and d["mode_fallback"] is None
     assert d["n_gpus"] == 1 and d["steps"] == 20 and d["config"]["envs_per_gpu"] == 65536 and "written tick-major to HBM" in d["config"]["workload"]
     ro = d["roofline"]
-    assert ro["bound"] == "hbm" and ro["kernel"].startswith("rollout_kernel<float, true, 2, false, 1, false>")
+    assert ro["bound"] == "hbm" and ro["kernel"].startswith("rollout_kernel<float, true, 2, false, 1, false, 1>")
     # a roofline fraction is a fraction: it cannot pass 1 (the 204-B nominal figure may, and is kept aside)
     assert 0.0 < ro["frac"] <= 1.0 and abs(ro["frac"] - ro["achieved"] / 8000.0) < 1e-9
     # which binary ran and whether the counter file describes it
@@ -91,5 +91,5 @@ def test_configs2_line_params_yml_with_in_kernel_reset():
     d = _run(["--gpus", "1", "--steps", "2000", "--warmup", "100", "--envs", "8192", "--config", "params_yml", "--no-secondary"])
     assert d["mode"] == "rollout" and "configs[2]" in d["config"]["workload"] and "reset IN-KERNEL" in d["config"]["workload"]
     ro = d["roofline"]
-    assert ro["kernel"].startswith("rollout_kernel<float, true, 2, true, 1, false>") and ro["bound"] == "hbm" and 0 < ro["frac"] <= 1.0
+    assert ro["kernel"].startswith("rollout_kernel<float, true, 2, true, 1, false, 2>") and ro["bound"] == "hbm" and 0 < ro["frac"] <= 1.0
     assert d["cpu_baseline"] is None and d["value"] > 1e8

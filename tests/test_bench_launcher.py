@@ -133,7 +133,7 @@ def test_default_mode_writes_per_tick_outputs_and_says_what_bounds_it():
     assert d["mode"] == "rollout" and d["mode_fallback"] is None
     assert "mode=rollout" in d["config"]["workload"] and "written tick-major to HBM" in d["config"]["workload"]
     ro = d["roofline"]
-    assert ro["bound"] == "hbm" and ro["kernel"].startswith("rollout_kernel<float, true, 2, false, 1, false>") and "SPEC, ES" not in ro["kernel"]
+    assert ro["bound"] == "hbm" and ro["kernel"].startswith("rollout_kernel<float, true, 2, false, 1, false, 1>") and "SPEC, ES" not in ro["kernel"]
     assert set(("valu", "frac_nominal_204B", "traffic", "peak", "unit", "ticks_per_launch", "achieved", "frac", "pmc_stale", "device_stamp_us")) <= set(ro)
     assert ro["peak"] == 8000.0 and ro["unit"] == "GB/s" and ro["ticks_per_launch"] == 20
     assert abs(ro["algorithmic_bytes_per_launch"] - (34.0 * 32 * 20 + 170.0 * 32)) < 1e-6

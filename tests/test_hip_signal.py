@@ -37,8 +37,8 @@ def test_signalled_rollout_equals_plain_rollout_and_outputs_are_complete(n):
     b.rollout_dev(ticks, L.ACT_PACKED, keys.data_ptr(), mouse.data_ptr(), 0, L.OBS_F32, o2.data_ptr(), r2.data_ptr(), d2.data_ptr(),
                   auto_reset=L.STAMP_START | L.SIGNAL)
     b.signal_wait(10.0)
-    # the signal says every wave has retired its stores; the copies below are ordered behind the launch on the device anyway,
-    # so this checks (a) and that nothing is left behind, not the memory model
+    # the copies below are ordered behind the launch on the device anyway, so this checks (a) and that nothing is left behind; the
+    # memory model - results readable by another agent the moment the signal is seen - is test_signal_carries_visibility_* below
     assert torch.equal(o1.cpu(), o2.cpu()) and torch.equal(r1.cpu(), r2.cpu()) and torch.equal(d1.cpu(), d2.cpu())
     assert int(d2.max()) <= 1                                  # every done byte was written (initialised to 7)
     sa, sb = a.get_state(), b.get_state()
@@ -47,6 +47,55 @@ def test_signalled_rollout_equals_plain_rollout_and_outputs_are_complete(n):
     el = b.signal_elapsed()
     assert 1e-6 < el < 5e-3, el                                # 40 ticks: tens of microseconds
     a.close(); b.close()
+
+
+def test_signal_carries_visibility_dma_second_stream_and_concurrent_reader_65536_envs_1000_reps():
+    """"done" must mean "consumable".  q1env_rollout writes its outputs with system-scope write-through stores, so the
+    kernel-written signal implies every result is at the memory side.  1 000 repetitions at the bench's driver shape (65 536 envs x 20
+    ticks): outputs poisoned, rollout launched with Q1ENV_SIGNAL_WAIT, and the instant the call returns - with NO runtime
+    synchronisation of the launch stream - (a) a DMA copy on another non-blocking stream brings obs / reward / done to the host, and
+    (b) a reader kernel that was already polling the same sequence word on a third stream has compared them with system-scope loads
+    microseconds after the signal.  Neither may ever see anything but the plain (fully synchronised) rollout's bytes.
+    (tools/visibility_probe.py is the loop; profiles/r5_visibility.txt holds the same probe against the round-4 store forms.)"""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import visibility_probe
+    res = visibility_probe.probe(n=65536, ticks=20, reps=1000)
+    assert res["reader_timeouts"] == 0, res
+    assert res["stale_reps_dma_second_stream"] == 0 and res["stale_reps_reader_kernel"] == 0, res
+    assert res["bytes_checked_per_rep"] >= 65536 * 20 * 29
+
+
+def test_signal_carries_visibility_small_batch_outputs_in_host_coherent_memory():
+    """The same guarantee where the consumer is the HOST THREAD itself: outputs of a 1 024-env x 20-tick rollout live in pinned,
+    host-coherent memory; the moment the launching call (Q1ENV_SIGNAL_WAIT) returns they are read through the host pointer - no stream
+    synchronisation, no copy - and must be complete.  1 000 repetitions from a poisoned buffer."""
+    n, ticks = 1024, 20
+    torch, L, DeviceEnv, cfg, keys, mouse, out = _setup(n, ticks)
+    dev = DeviceEnv(cfg, device=0)
+    dev.snapshot_state()
+    o1, r1, d1 = out()
+    dev.rollout_dev(ticks, L.ACT_PACKED, keys.data_ptr(), mouse.data_ptr(), 0, L.OBS_F32, o1.data_ptr(), r1.data_ptr(), d1.data_ptr())
+    dev.sync()
+    eo, er, ed = o1.cpu().numpy().view(np.uint32), r1.cpu().numpy().view(np.uint32), d1.cpu().numpy()
+    ho = torch.empty((ticks, n, 6), dtype=torch.float32).pin_memory()
+    hr = torch.empty((ticks, n), dtype=torch.float32).pin_memory()
+    hd = torch.empty((ticks, n), dtype=torch.uint8).pin_memory()
+    vo, vr, vd = ho.numpy().view(np.uint32), hr.numpy().view(np.uint32), hd.numpy()
+    call = dev.prepare_rollout(ticks, L.ACT_PACKED, keys.data_ptr(), mouse.data_ptr(), 0, L.OBS_F32, ho.data_ptr(), hr.data_ptr(), hd.data_ptr(),
+                               L.STAMP_START | L.SIGNAL_WAIT)
+    stale = 0
+    for rep in range(1000):
+        dev.restore_state()
+        dev.sync()
+        vo.fill(0xFFFFFFFF); vr.fill(0xFFFFFFFF); vd.fill(0xFF)
+        call()                                                 # returns when the kernel-written sequence word has been seen
+        if not (np.array_equal(vo, eo) and np.array_equal(vr, er) and np.array_equal(vd, ed)):
+            stale += 1
+        dev.sync()
+    assert stale == 0, stale
+    dev.close()
 
 
 def test_sequence_of_signals_and_signal_mark():

@@ -40,7 +40,7 @@ def classify(op):
 
 def main(argv=None):
     ap = argparse.ArgumentParser()
-    ap.add_argument("--kernel", default="rollout_kernelIfLb1ELi2ELb0ELi1E")
+    ap.add_argument("--kernel", default="rollout_kernelIfLb1ELi2ELb0ELi1ELb0ELi1EE")
     ap.add_argument("--src", default=os.path.join(ROOT, "q1physrl_amd", "csrc", "q1env_core.hip"))
     ap.add_argument("--keep", default=None)
     ap.add_argument("--asm", default=None, help="use this assembly file instead of compiling")
