@@ -37,14 +37,17 @@ the data path; ranks only meet in the barriers around the timed region and in th
 
 Timed region (every rank): graphs instantiated and uploaded, warm-up ticks, barrier + torch.cuda.synchronize(); t0; EXACTLY K ticks
 enqueued; completion; t1; torch.cuda.synchronize(); barrier.  `value` uses the MAX over ranks of t1 - t0 (host wall clock).
-  rollout mode (the default): no marker packets ride with the launch and completion is the kernel's own signal - the last wave to retire
-      its stores writes an end stamp and a sequence number into host-coherent pinned memory, which the host polls (q1env_signal_wait,
-      include/q1env.h "completion signal"; VERDICT r3 item 1: with hipEventRecord x 2 + a runtime synchronisation the driver's 20-tick
-      line was 54 % host latency).  The torch.cuda.synchronize() that follows t1 is the untimed check that nothing else was in flight;
-      its duration is reported (`host_split_us.post_sync_us`), as is `ms_per_step_incl_runtime_sync`, the same region's wall time had t1
-      been taken after it.  Kernel time of the timed region = device wall-clock stamps written by its first and last wave
-      (`roofline.device_stamp_us`); the SAME K ticks are then repeated from the same state between two HIP events on the launch stream
-      (`roofline.avg_launch_us`, what the roofline uses).
+  rollout mode (the default): no marker packets ride with the launch and completion is the kernel's own signal - the last wave to have its
+      stores acknowledged writes an end stamp and a sequence number into host-coherent pinned memory, which the host polls (q1env_signal_wait,
+      include/q1env.h "completion signal").  Since round 5 the signal CARRIES VISIBILITY: every per-tick output and the final state are
+      written with system-scope write-through stores, whose acknowledgement comes from the memory side (Infinity Cache / HBM), so t1 is a
+      time after which obs / reward / done need no further wait to be read by the host, a DMA engine or another kernel - held to that by
+      tests/test_hip_signal.py (DMA copy on a second stream + a concurrent reader kernel, 1 000 repetitions; plain stores are caught stale
+      every time, profiles/r5_visibility.txt).  The torch.cuda.synchronize() that follows t1 is then pure runtime cost (the dispatch's
+      completion packet travelling through the runtime); its duration is reported (`timed_region_us.post_sync_us`), as is
+      `ms_per_step_incl_runtime_sync`, the same region's wall time had t1 been taken after it.  Kernel time of the timed region = device
+      wall-clock stamps written by its first and last wave (`device_stamp_us`); the SAME K ticks are then repeated from the same state
+      between two HIP events on the launch stream (`roofline.avg_launch_us`, what the roofline uses).
   step / server modes: HIP events around the launches inside the timed region, ONE torch.cuda.synchronize() ends it (t1 after it).
 
 Output: ONE JSON line on rank 0 (contract in the task statement) with `roofline` and `cpu_baseline`.
@@ -792,7 +795,8 @@ def main(argv=None):
             host_split[mode] = {"launch_to_signal_seen_us": (t1 - t0) * 1e6,
                                 "post_sync_us": (t2 - t1) * 1e6, "wall_incl_runtime_sync_us": (t2 - t0) * 1e6,
                                 "device_stamp_us": stamp_ms * 1e3,
-                                "completion": "kernel-written signal polled by the host" + (" inside the launching call (Q1ENV_SIGNAL_WAIT)" if one_call else "")}
+                                "completion": "kernel-written signal, results written through at system scope (readable by any agent when it arrives: "
+                                              "tests/test_hip_signal.py), polled by the host" + (" inside the launching call" if one_call else "")}
             if t_enq is not None:
                 host_split[mode]["enqueue_us"] = (t_enq - t0) * 1e6
                 host_split[mode]["enqueue_to_signal_seen_us"] = (t1 - t_enq) * 1e6
