@@ -432,6 +432,33 @@ int q1env_learner_adam(q1env_t* env, const q1env_learner_net* pi, const q1env_le
 int q1env_learner_sgd_step(q1env_t* env, const q1env_learner_net* pi, const q1env_learner_net* vf, void* ws_dev, int splits,
                            const q1env_learner_batch* batch, float lr, float beta1, float beta2, float eps, void* adam_state_dev);
 
+/* ---- persistent learner (ABI v5) -------------------------------------------------------------------------------
+ * `steps` SGD steps of 128-sample minibatches - forward, PPO loss gradient, backward, weight gradients, Adam, for both networks - as
+ * ONE dispatch of 2 x 8 co-operating workgroups (csrc/q1learner_persist.hpp): what RLlib's PPO does 11 719 times per training
+ * iteration under the reference's configuration (sgd_minibatch_size 128 x num_sgd_iter 30 over train_batch_size 50 000:
+ * q1physrl/train.py:60-64, data/params.yml:4-13), where a four-launch q1env_learner_sgd_step costs ~43 us per step and a step's
+ * arithmetic is ~0.1 GFLOP.  batch: as for q1env_learner_sgd_step with minibatch == 128 and the reference's action structure (4 keys +
+ * continuous mouse; anything else -> Q1ENV_ERR_INVALID_ARG, use q1env_learner_sgd_step); idx_dev holds the whole schedule: step n
+ * trains on rows idx_dev[(n / steps_per_epoch) * epoch_stride + (n % steps_per_epoch) * 128 + (0..127)] (one permutation of the train
+ * batch per epoch, epoch_stride >= 128 steps_per_epoch apart; NULL = the rows themselves); idx_cursor_dev, stats_partials_dev and
+ * skip_reduce are not used.  Masters, gw* / gb* (the LAST step's gradients) and the moments / step count of adam_state_dev
+ * (q1env_learner_adam's layout) are updated as by `steps` calls of q1env_learner_sgd_step - same float16-operand / float32-accumulate
+ * recipe and loss scales, different summation order: equal to float16 operand rounding, not bit for bit.  adam_state's running
+ * statistics [0], [1], [2], [4] (entropy, kl, policy loss, vf loss) grow by the sum over the steps of the per-step means; [3] (total) is
+ * NOT updated - it is policy + kl_coeff kl + vf_loss_coeff vf - entropy_coeff entropy of the others.  The workspace images of
+ * q1env_learner_images are NOT refreshed: call it (and rebuild any sampler-side weight image) after the launch.
+ * batch_rows = the number of rows of the train batch arrays (every idx value is below it): a first, tiny launch computes the
+ * squashed-Gaussian pre-image of all mouse actions once.  pws_dev: q1env_learner_persistent_bytes(batch_rows) bytes of device memory
+ * (exchange buffers, barrier counters, the W2 slices' optimizer state in owner-lane order, status).  The 16 workgroups spin
+ * on group barriers and must be co-resident (they are whenever 16 CUs are free); every wait is bounded by timeout_s (<= 0: 5 s) and a
+ * timeout is reported by q1env_learner_persistent_status: status4[0] != 0 (1 + index of the barrier within the step), [1] the step.
+ * Asynchronous on the handle's stream like every launch. */
+uint64_t q1env_learner_persistent_bytes(int64_t batch_rows);
+int q1env_learner_sgd_epochs(q1env_t* env, const q1env_learner_net* pi, const q1env_learner_net* vf, void* pws_dev, const q1env_learner_batch* batch,
+                             int64_t batch_rows, int64_t steps, int64_t steps_per_epoch, int64_t epoch_stride, float lr, float beta1, float beta2,
+                             float eps, void* adam_state_dev, double timeout_s);
+int q1env_learner_persistent_status(q1env_t* env, const void* pws_dev, uint32_t* status4_host);   /* synchronises the stream */
+
 /* Episode bookkeeping of one sampler tick (the reference's on_episode_end metric hook, q1physrl/train.py:54-57):
  * ep_return double[N] += reward; for envs with done != 0 the finished return is added to this wave's slot of
  * partials (double[ceil(N/64)][4] = episodes, zero-start episodes, return sum, zero-start return sum) and ep_return is

@@ -77,6 +77,7 @@ struct q1env {
     bool resident_attr_set = false;   // the resident sampler's dynamic-LDS attribute
     bool mlp_attr_set = false;        // dynamic-LDS attribute of the policy kernels (a per-device setting: kept per handle)
     bool learner_attr_set = false;    // ... and of the native learner's forward / backward kernels
+    bool plearner_attr_set = false;   // ... and of the persistent learner (q1learner_persist.hpp)
     // cached hipGraphs of step_many, keyed by (ticks, formats, pointers); a handful of entries, oldest evicted
     struct GraphEntry { std::vector<uint64_t> key; hipGraphExec_t exec; };
     std::vector<GraphEntry> graphs;

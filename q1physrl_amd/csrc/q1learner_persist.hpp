@@ -1,0 +1,680 @@
+// q1learner_persist.hpp - the PERSISTENT PPO learner of libq1env (device code): a whole run of SGD steps at the reference's minibatch
+// size - RLlib's sgd_minibatch_size 128 x num_sgd_iter 30 over a 50 k-sample train batch: 11 719 steps per training iteration
+// (q1physrl/train.py:60-64, data/params.yml:4-13) - as ONE dispatch.  VERDICT r4 item 3: at that size q1env_learner_sgd_step's four
+// launches cost ~43 us for ~0.1 GFLOP, 99 % of the reference-configuration iteration.  Included by q1env_plearner.hip.
+//
+// Decomposition.  The two networks (policy 6-256-256-10, value 6-256-256-1: separate, vf_share_layers = false) never meet inside a
+// step, so each gets its own group of G = 8 workgroups and its own barrier.  Workgroup g of a group OWNS hidden units U = [32 g, 32 g + 32)
+// of both hidden layers: rows U of W1 / b1, rows U of W2 (torch layout [out][in]: all 256 inputs of its 32 units) / b2, columns U of
+// W3 - masters, Adam moments and gradients in their torch layouts in global memory (private to the owner, plain cached accesses), the
+// float16 operand images of its slice in LDS for the whole launch.  A step of 128 samples (four 32-sample tiles, one per wave):
+//   P1   H1[:, U] = tanh(X W1[U]^T + b1[U])                      local; published (both orientations)             -> barrier 1
+//   P2   H2[:, U] = tanh(H1 W2[U]^T + b2[U])                     A/B operands: H1 straight from the exchange buffer, W2[U] from LDS
+//   L3   Yp_g = H2[:, U] W3[:, U]^T  (partial logits)            published                                        -> barrier 2
+//   loss every workgroup sums the G partials in the same order, adds b3 and differentiates the PPO loss of its group's network for all
+//        128 samples (q1ppo_loss.hpp, one thread per sample; redundant across the group, identical bits)
+//   B3   dZ2[:, U] = (dY W3[:, U]) (1 - H2[:, U]^2)              local; published                                -> barrier 3 (arrive)
+//   G2   dW2[U, :] = dZ2[:, U]^T H1, dW3[:, U] = dY^T H2[:, U], db2[U]; Adam on them; new W2[U] image; W2^T slice published
+//   B2   dH1[:, U] = dZ2 W2[:, U]  (after barrier 3: all of dZ2 from the exchange buffer, W2's column block gathered into LDS after barrier 1)
+//        dZ1[:, U] = dH1 (1 - H1[:, U]^2);  dW1[U], db1[U]; Adam; db3 / b3 (workgroup 0)
+// Three group barriers per step (8 arrivals on one counter each), nothing else crosses workgroups.
+//
+// Matrix products: v_mfma_f32_32x32x16_f16, D[i][n] += sum_k A[i][k] B[n][k] with BOTH operands stored "K-contiguous" (row i / n, eight
+// consecutive k per lane: lane (c, h) reads 16 bytes at row c, k = 16 s + 8 h), so swapping the two operand registers yields the
+// transposed product for free.  The accumulator of lane (c, h) holds column n = c, rows i = (r & 3) + 8 (r >> 2) + 4 h - four consecutive
+// i per register quad, which leave as one 8-byte store into a row-major [n][i] array: the layout the NEXT product needs is obtained by
+// choosing which operand plays A.  Where both layouts of a result are needed (H1, H2, dZ2) both orientations are computed from the same
+// operand registers (matrix time is not what bounds this kernel; a transposition through LDS would cost more).
+//
+// Exchange protocol.  Published data are written with agent-scope write-through stores (sc1); "arrive" = s_waitcnt vmcnt(0) (they have
+// reached the memory side), workgroup barrier, one relaxed agent-scope increment; "wait" = spin on the counter, workgroup barrier, agent-scope
+// acquire fence (buffer_inv sc1: this XCD's L2 / the CU's vector cache drop what other XCDs may have rewritten).  Single buffers
+// suffice except for H1 (read by the weight-gradient phase after barrier 3's arrive, while a faster workgroup may already be publishing the
+// next step's): two buffers, by step parity.  Every wait is bounded (status word) - the 16 workgroups must be co-resident.
+//
+// Numerics: float16 operands, float32 accumulation, float32 masters / moments, torch.optim.Adam's update - the same recipe, loss scales and
+// saturating gradient conversions as q1learner.hpp; the summation orders differ, so results agree with q1env_learner_sgd_step to float16
+// operand rounding, not bit for bit (tests/test_hip_learner.py: per-step gradients <= 3e-3 of autograd's, a 391-step epoch against 391
+// calls of q1env_learner_sgd_step).
+#pragma once
+#include "q1policy.hpp"
+#include "q1ppo_loss.hpp"
+
+namespace q1pl {
+
+using q1pol::f16x8;
+using q1pol::f32x16;
+using q1pol::TANH_PRESCALE;
+
+constexpr int G = 8;               // workgroups per network
+constexpr int MB = 128;            // samples per step
+constexpr int HID = 256;
+constexpr uint32_t LD_W = 528;     // bytes per row of a 256-wide float16 row (+ 16 pad)
+constexpr uint32_t LD_B = 272;     // 128-wide (sample-contiguous) row
+constexpr uint32_t LD_16 = 48;     // 16-wide row
+constexpr uint32_t LD_32 = 80;     // 32-wide row
+
+// LDS map (bytes)
+constexpr uint32_t L_W2OWN = 0;                              // [32 u][256 k]  2 log2(e) W2[U]      (P2)
+constexpr uint32_t L_W2COL = L_W2OWN + 32 * LD_W;            // [32 j][256 k]  W2[k][j in U]        (B2)
+constexpr uint32_t L_H2T = L_W2COL + 32 * LD_W;              // [32 u][128 b]
+constexpr uint32_t L_DZ2T = L_H2T + 32 * LD_B;
+constexpr uint32_t L_DZ1T = L_DZ2T + 32 * LD_B;
+constexpr uint32_t L_DYT = L_DZ1T + 32 * LD_B;               // [32 o][128 b]  rows >= OUT stay zero
+constexpr uint32_t L_XT = L_DYT + 32 * LD_B;                 // [32 i][128 b]  rows 0..5 x hi, 6 ones, 8..13 x lo, rest zero
+constexpr uint32_t L_DY = L_XT + 32 * LD_B;                  // [128 b][16 o]
+constexpr uint32_t L_XH = L_DY + MB * LD_16;                 // [128 b][16]    x hi, 1, 0, x lo, 1, 0
+constexpr uint32_t L_W1 = L_XH + MB * LD_16;                 // [32 u][16]     c W1 row, c b1 hi, 0, c W1 row, c b1 lo, 0
+constexpr uint32_t L_W3T = L_W1 + 32 * LD_16;                // [32 u][16 o]   W3[o][u]
+constexpr uint32_t L_W3 = L_W3T + 32 * LD_16;                // [32 o][32 u]   W3[o][U]
+constexpr uint32_t L_H2W = L_W3 + 32 * LD_32;                // [4 waves][32 b][32 u]
+constexpr uint32_t L_FL = L_H2W + 4 * 32 * LD_32;            // floats: b2p[32] | red2[4][32] | red3[2][16] | stat[4][4] | bc[2] | flags
+constexpr uint32_t LDS_BYTES = L_FL + 2048;                  // 108 032
+
+struct Net {
+    float* w1; float* b1; float* w2; float* b2; float* w3; float* b3;          // masters (torch layouts), updated in place
+    float* gw1; float* gb1; float* gw2; float* gb2; float* gw3; float* gb3;    // the LAST step's gradients (inspection / tests)
+    float* m; float* v;                                                          // moments, flat [w2 | b2 | w1 | b1 | w3 | b3] (q1learner.hpp AdamNet)
+    int out_dim;
+    // exchange buffers of this network's group
+    uint16_t* h1x;        // [2 parity][128 b][256 k]
+    uint16_t* h1tx;       // [2 parity][256 k][128 b]
+    uint16_t* dz2x;       // [128 b][256 k]
+    uint16_t* w2tx;       // [256 j][256 k]: W2[k][j]
+    float* yp;            // [G][128 b][16]
+    float* w2st;          // [G][3 (master, m, v)][4 waves][32 slots][64 lanes]: the W2 slice's optimizer state in its OWNER LANE's order
+    uint32_t* bar;        // arrival counter (own 256-byte line)
+    float inv_b;          // d loss / d output travels multiplied by this (loss scale / 1: per-sample, not averaged)
+    float inv_scale;      // gradient = sum over the samples x this
+};
+
+struct Args {
+    q1::Params p;
+    Net net[2];
+    // the train batch (q1env_learner_batch; mouse_u = mouse_u_kernel's output in the workspace) and the minibatch schedule: step n reads rows idx[(n / spe) * epoch_stride + (n % spe) * 128 + b]
+    const int64_t* idx; int64_t spe, epoch_stride;
+    const float* obs; const float* old_logits; int old_stride;
+    const uint8_t* keys; const float* mouse_u; const float* logp_old; const float* adv; const float* value_old; const float* vtarg;
+    float clip, vf_clip, vf_coeff, ent_coeff;
+    const float* klc_dev;
+    float lr, beta1, beta2, eps;
+    int64_t steps;
+    long long* step_count;     // adam_state + 0
+    float* stats_acc;          // adam_state + 16: [entropy, kl, policy_loss, total (left to the host), vf_loss] running sums of per-step means
+    uint32_t* saturation;      // optional uint32[4] (q1env_learner_batch.saturation_dev)
+    uint32_t* status;          // uint32[4]: [0] != 0: a barrier timed out (value = 1 + barrier index), [1] the step it happened in
+    unsigned long long* prof;  // optional uint64[16] (the rest of the status line): 10-ns ticks workgroup (0, 0) spent per phase, summed over the steps
+    uint64_t timeout_ticks;
+};
+
+__device__ __forceinline__ f16x8 lds16(const unsigned char* base, uint32_t off) { return *reinterpret_cast<const f16x8*>(base + off); }
+__device__ __forceinline__ f16x8 glb16(const uint16_t* p) { return *reinterpret_cast<const f16x8*>(p); }
+__device__ __forceinline__ f32x16 mm(f16x8 a, f16x8 b, f32x16 acc) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc, 0, 0, 0); }
+__device__ __forceinline__ uint32_t rrow(int r, uint32_t h) { return (uint32_t)(r & 3) + 8u * (uint32_t)(r >> 2) + 4u * h; }
+
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint64_t pack4(float a, float b, float c, float d) {
+    union { f16x4 v; uint64_t u; } o;
+    o.v = f16x4{(_Float16)a, (_Float16)b, (_Float16)c, (_Float16)d};
+    return o.u;
+}
+__device__ __forceinline__ float sat16(float x, float& amax, uint32_t& nsat) {
+    const float ax = fabsf(x);
+    amax = fmaxf(amax, ax);
+    nsat += ax > 65504.0f ? 1u : 0u;
+    return __builtin_amdgcn_fmed3f(x, -65504.0f, 65504.0f);
+}
+__device__ __forceinline__ float r16(float x) { return (float)(_Float16)x; }                       // the value the float16 operand carries
+__device__ __forceinline__ float act(float z) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(z) + 1.0f); }   // tanh, z prescaled by 2 log2 e
+__device__ __forceinline__ void pub8(uint16_t* p, uint64_t v) {                                     // 8 bytes, write-through at agent scope
+    __hip_atomic_store(reinterpret_cast<uint64_t*>(p), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void pub8f(float* p, float a, float b) {
+    union { float f[2]; uint64_t u; } o;
+    o.f[0] = a; o.f[1] = b;
+    __hip_atomic_store(reinterpret_cast<uint64_t*>(p), o.u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// torch.optim.Adam's update (q1learner.hpp adam_update) with the hardware's 1-ulp square root and reciprocal (v_sqrt_f32, v_rcp_f32) in
+// place of the IEEE expansions: this kernel is bound by its instruction count (one wave per SIMD: ~5 cycles per instruction of any kind),
+// a workgroup updates 8 448 parameters per step, and the gradients already differ from q1env_learner_sgd_step's by float16 rounding.
+// rs_bc2 = 1 / sqrt(bias_correction2), lr_bc1 = lr / bias_correction1 (per step, not per element).
+__device__ __forceinline__ float adam1(float w, float g, float& m, float& v, float b1, float b2, float eps, float lr_bc1, float rs_bc2) {
+    m = m + (g - m) * (1.0f - b1);
+    v = v * b2 + (1.0f - b2) * g * g;
+    const float denom = __builtin_amdgcn_sqrtf(v) * rs_bc2 + eps;
+    return w - lr_bc1 * (m * __builtin_amdgcn_rcpf(denom));
+}
+
+// arrive: this workgroup's published stores are at the memory side; one ticket
+__device__ __forceinline__ void bar_arrive(uint32_t* ctr) {
+    __builtin_amdgcn_s_waitcnt(0);
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// wait until `target` tickets have been drawn; false (for every thread) on timeout / abort
+__device__ __forceinline__ bool bar_wait(uint32_t* ctr, uint32_t target, uint32_t* status, uint32_t which, uint32_t step, uint64_t timeout_ticks, int* s_ok) {
+    if (threadIdx.x == 0) {
+        int ok = 1;
+        uint64_t t0 = 0;
+        uint32_t spins = 0;
+        while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            __builtin_amdgcn_s_sleep(1);
+            if ((++spins & 1023u) == 0u) {
+                const uint64_t now = wall_clock64();
+                if (t0 == 0) t0 = now;
+                if (now - t0 > timeout_ticks || __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+                    if (__hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+                        __hip_atomic_store(status + 1, step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_store(status, which + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                    ok = 0;
+                    break;
+                }
+            }
+        }
+        *s_ok = ok;
+    }
+    __syncthreads();
+    const bool ok = *s_ok != 0;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    return ok;
+}
+
+// The squashed-Gaussian pre-image of every mouse action of the train batch, u = S ndtri((x - low) / (high - low)) (q1ppo_loss.hpp;
+// action_dist.py:186-192): a function of the ACTION alone, so it is computed once per launch for all rows - a float64 polynomial of ~220
+// instructions that each of the 30 epochs x 8 workgroups would otherwise re-evaluate per sample inside the step loop.
+__global__ void __launch_bounds__(256)
+mouse_u_kernel(int64_t rows, const float* __restrict__ mouse, float low, float high, float* __restrict__ u) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < rows) u[i] = SQUASH_SCALE * normcdfinvf((mouse[i] - low) / (high - low));
+}
+
+__global__ void __launch_bounds__(256, 1)
+persistent_learner_kernel(Args a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, w = tid >> 6, c = lane & 31u, h = lane >> 5;
+    const uint32_t ni = blockIdx.x / (uint32_t)G, g = blockIdx.x % (uint32_t)G;
+    const Net net = ni ? a.net[1] : a.net[0];          // (a select on the kernel arguments: no dynamic indexing)
+    const int OUT = net.out_dim;
+    float* const fl = reinterpret_cast<float*>(lds + L_FL);
+    float* const b2p = fl;                 // [32]
+    float* const red2 = fl + 32;           // [4][32]
+    float* const stat = fl + 192;          // [4 waves][4]
+    int* const s_ok = reinterpret_cast<int*>(fl + 212);
+    float* const red3 = fl + 224;          // [4][16]
+    const f32x16 zero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    const float c2 = TANH_PRESCALE;
+    const uint32_t U0 = 32u * g;
+    const uint32_t bsm = 32u * w + c;                           // the sample this lane (and its partner lane ^ 32) differentiates the loss of
+
+    // ---------------------------------------------------------------- prologue: operand images of the owned slice from the masters
+    for (uint32_t off = tid * 16u; off < L_FL; off += 256u * 16u) *reinterpret_cast<uint4*>(lds + off) = uint4{0, 0, 0, 0};
+    __syncthreads();
+    // flat offsets of the moment arrays ([w2 | b2 | w1 | b1 | w3 | b3], q1learner.hpp AdamNet)
+    const size_t E_B2 = 65536, E_W1 = 65536 + 256, E_B1 = E_W1 + 1536, E_W3 = E_B1 + 256, E_B3 = E_W3 + (size_t)OUT * 256;
+    // The W2 slice's masters and moments (8 192 of the 8 448 parameters a workgroup owns) are kept, for the launch, in the order their owner
+    // lanes use them - lane (c, h) of wave w owns inputs k = 64 w + 32 t + c of units U0 + row(r, h): slot 16 t + r - so that a step's 96
+    // loads and 96 stores per lane are fully coalesced and addressed base + immediate; the torch layouts are read here and rewritten
+    // once at the end.
+    float* const st_w = net.w2st + (((size_t)g * 3 + 0) * 4 + w) * 2048 + lane;
+    float* const st_m = net.w2st + (((size_t)g * 3 + 1) * 4 + w) * 2048 + lane;
+    float* const st_v = net.w2st + (((size_t)g * 3 + 2) * 4 + w) * 2048 + lane;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const size_t e = (size_t)(U0 + rrow(r, h)) * HID + 64u * w + 32u * (uint32_t)t + c;
+            st_w[64 * (16 * t + r)] = net.w2[e]; st_m[64 * (16 * t + r)] = net.m[e]; st_v[64 * (16 * t + r)] = net.v[e];
+        }
+    {
+        const uint32_t u = tid >> 3, k0 = (tid & 7u) * 32u;                            // 8 threads per owned unit, 32 inputs each
+        const float* src = net.w2 + (size_t)(U0 + u) * HID + k0;
+        for (uint32_t k = 0; k < 32u; ++k) {
+            const float wv = src[k];
+            *reinterpret_cast<_Float16*>(lds + L_W2OWN + u * LD_W + 2u * (k0 + k)) = (_Float16)(c2 * wv);
+            union { _Float16 hh; uint16_t b; } o; o.hh = (_Float16)wv;
+            __hip_atomic_store(net.w2tx + (size_t)(k0 + k) * HID + U0 + u, o.b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    if (tid < 32u) {
+        const uint32_t u = tid;
+        const float bs = c2 * net.b1[U0 + u];
+        const _Float16 bhi = (_Float16)bs, blo = (_Float16)(bs - (float)bhi);
+        _Float16* row = reinterpret_cast<_Float16*>(lds + L_W1 + u * LD_16);
+        for (int i = 0; i < 6; ++i) { const _Float16 wv = (_Float16)(c2 * net.w1[(size_t)(U0 + u) * 6 + i]); row[i] = wv; row[8 + i] = wv; }
+        row[6] = bhi; row[14] = blo;
+        b2p[u] = c2 * net.b2[U0 + u];
+        for (int o = 0; o < OUT; ++o) {
+            const _Float16 wv = (_Float16)net.w3[(size_t)o * HID + U0 + u];
+            *reinterpret_cast<_Float16*>(lds + L_W3 + (uint32_t)o * LD_32 + 2u * u) = wv;
+            *reinterpret_cast<_Float16*>(lds + L_W3T + u * LD_16 + 2u * (uint32_t)o) = wv;
+        }
+    }
+    if (tid < MB) *reinterpret_cast<_Float16*>(lds + L_XT + 6u * LD_B + 2u * tid) = (_Float16)1.0f;    // the ones row of [x | 1]^T
+    const float klc = *a.klc_dev;
+    const long long step0 = *a.step_count;
+    double pw1 = pow((double)a.beta1, (double)step0), pw2 = pow((double)a.beta2, (double)step0);
+    float st_acc[3] = {0.0f, 0.0f, 0.0f};                       // running sums of the step statistics (thread 0 of workgroup 0 of each group)
+    float amax = 0.0f;
+    uint32_t nsat = 0;
+    uint32_t bar_n = 0;                                         // barriers passed
+    // rows of the FIRST step (every later step's are fetched one step ahead): srcX = the sample whose observation this thread stages
+    // (threads 0..127), srcL = the sample whose loss this lane pair differentiates
+    // (no division in the loop: the position of the next step's window is kept incrementally)
+    int64_t win = 0;                                            // offset of the CURRENT step's 128-row window in idx
+    int64_t in_epoch = 0;                                       // its index within the epoch
+    auto row_at = [&](int64_t window, uint32_t b) -> int64_t { return a.idx ? a.idx[window + (int64_t)b] : window + (int64_t)b; };
+    int64_t srcX = row_at(0, tid & (MB - 1)), srcL = row_at(0, bsm);
+    __syncthreads();
+
+    const bool profiling = a.prof != nullptr && blockIdx.x == 0 && tid == 0;
+    unsigned long long pacc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    uint64_t tprev = profiling ? wall_clock64() : 0;
+#define Q1PL_STAMP(k) do { if (profiling) { const uint64_t now_ = wall_clock64(); pacc[k] += now_ - tprev; tprev = now_; } } while (0)
+    for (int64_t step = 0; step < a.steps; ++step) {
+        const uint32_t par = (uint32_t)(step & 1);
+        const bool last = step + 1 == a.steps;
+        uint16_t* const h1x = net.h1x + (size_t)par * MB * HID;
+        uint16_t* const h1tx = net.h1tx + (size_t)par * MB * HID;
+        // ------------------------------------------------------------ this step's rows: everything that depends only on the row index is
+        // requested NOW (observation for the operand rows; the loss's per-sample inputs, which are not needed before barrier 2)
+        pw1 *= (double)a.beta1;                                   // beta^t, t = step0 + step + 1 (every thread: two float64 multiplies)
+        pw2 *= (double)a.beta2;
+        float ox[6];
+        {
+            const float2* o2 = reinterpret_cast<const float2*>(a.obs + (size_t)srcX * 6);
+            const float2 p0 = o2[0], p1 = o2[1], p2 = o2[2];
+            ox[0] = p0.x; ox[1] = p0.y; ox[2] = p1.x; ox[3] = p1.y; ox[4] = p2.x; ox[5] = p2.y;
+        }
+        if (tid < MB) {
+            _Float16 hi[6], lo[6];
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                const float xs = fminf(fmaxf(ox[i], -65504.0f), 65504.0f);
+                hi[i] = (_Float16)xs;
+                lo[i] = (_Float16)(xs - (float)hi[i]);
+            }
+            _Float16* row = reinterpret_cast<_Float16*>(lds + L_XH + tid * LD_16);
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                row[i] = hi[i]; row[8 + i] = lo[i];
+                *reinterpret_cast<_Float16*>(lds + L_XT + (uint32_t)i * LD_B + 2u * tid) = hi[i];
+                *reinterpret_cast<_Float16*>(lds + L_XT + (uint32_t)(8 + i) * LD_B + 2u * tid) = lo[i];
+            }
+            row[6] = (_Float16)1.0f; row[7] = (_Float16)0.0f; row[14] = (_Float16)1.0f; row[15] = (_Float16)0.0f;
+        }
+        __syncthreads();
+        const float lr_bc1 = a.lr / (float)(1.0 - pw1), rs_bc2 = 1.0f / sqrtf((float)(1.0 - pw2));    // lr / bias_correction1, 1 / sqrt(bias_correction2)
+
+        // ------------------------------------------------------------ P1: layer 1 of the owned units, both orientations
+        float h1B[16];                                          // tanh(H1)[b = 32 w + row(r)][u = c] as the float16 operand carries it
+        {
+            const f16x8 a1 = lds16(lds, L_W1 + c * LD_16 + 16u * h);
+            const f16x8 x1 = lds16(lds, L_XH + (32u * w + c) * LD_16 + 16u * h);
+            const f32x16 dA = mm(a1, x1, zero16);               // [u][b]: lane = sample, registers = units
+            const f32x16 dB = mm(x1, a1, zero16);               // [b][u]: lane = unit, registers = samples
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                pub8(h1x + (size_t)(32u * w + c) * HID + U0 + 8u * q + 4u * h, pack4(act(dA[4 * q]), act(dA[4 * q + 1]), act(dA[4 * q + 2]), act(dA[4 * q + 3])));
+                float t4[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { t4[j] = act(dB[4 * q + j]); h1B[4 * q + j] = r16(t4[j]); }
+                pub8(h1tx + (size_t)(U0 + c) * MB + 32u * w + 8u * q + 4u * h, pack4(t4[0], t4[1], t4[2], t4[3]));
+            }
+        }
+        Q1PL_STAMP(0);                                          // minibatch rows + P1 + publish
+        bar_arrive(net.bar);
+        const int64_t srcL_now = srcL;
+        // the NEXT step's row indices, requested while the barrier is in flight
+        if (!last) {
+            if (++in_epoch == a.spe) { in_epoch = 0; win += a.epoch_stride - (a.spe - 1) * MB; } else { win += MB; }
+            srcX = row_at(win, tid & (MB - 1)); srcL = row_at(win, bsm);
+        }
+        if (!bar_wait(net.bar, (uint32_t)G * ++bar_n, a.status, 0u, (uint32_t)step, a.timeout_ticks, s_ok)) return;
+        Q1PL_STAMP(1);                                          // barrier 1
+
+        // ------------------------------------------------------------ W2's column block (rows j in U of W2^T), then P2 + the partial logits
+        float h2A[16], h2B[16];
+        const size_t sl = (size_t)srcL_now;
+        // the loss's per-sample inputs (not needed before barrier 2), requested with this phase's operands: policy group: keys, logp_old,
+        // adv, old logits row;  value group: value_old, vtarg (in the same registers)
+        const uint32_t in_kb = ni == 0 ? (uint32_t)a.keys[sl] : 0u;
+        const float in_a = ni == 0 ? a.mouse_u[sl] : a.value_old[sl];   // (policy group: the mouse action's pre-image u, mouse_u_kernel)
+        const float in_b = ni == 0 ? a.logp_old[sl] : a.vtarg[sl];
+        const float in_c = ni == 0 ? a.adv[sl] : 0.0f;
+        float oldrow[10];
+#pragma unroll
+        for (int o = 0; o < 10; ++o) oldrow[o] = ni == 0 ? a.old_logits[sl * (size_t)a.old_stride + (size_t)o] : 0.0f;
+        {
+            // every global operand of this phase is requested first: H1 rows of this wave's tile (16 K-steps) and the column block
+            f16x8 bH[16], wc[4];
+            const uint16_t* hrow = h1x + (size_t)(32u * w + c) * HID + 8u * h;
+#pragma unroll
+            for (int s = 0; s < 16; ++s) bH[s] = glb16(hrow + 16 * s);
+            const uint32_t jg = tid >> 3, ch = tid & 7u;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) wc[i] = glb16(net.w2tx + (size_t)(U0 + jg) * HID + 8u * (ch + 8u * (uint32_t)i));
+            f32x16 accA = zero16, accB = zero16;
+#pragma unroll
+            for (int s = 0; s < 16; ++s) {
+                const f16x8 aW = lds16(lds, L_W2OWN + c * LD_W + 32u * (uint32_t)s + 16u * h);
+                accA = mm(aW, bH[s], accA);
+                accB = mm(bH[s], aW, accB);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) *reinterpret_cast<f16x8*>(lds + L_W2COL + jg * LD_W + 16u * (ch + 8u * (uint32_t)i)) = wc[i];
+            const float bB = b2p[c];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 bq = *reinterpret_cast<const float4*>(b2p + 8 * q + 4 * h);
+                const float bb[4] = {bq.x, bq.y, bq.z, bq.w};
+                float tA[4], tB[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    tA[j] = act(accA[4 * q + j] + bb[j]); h2A[4 * q + j] = r16(tA[j]);
+                    tB[j] = act(accB[4 * q + j] + bB); h2B[4 * q + j] = r16(tB[j]);
+                }
+                *reinterpret_cast<uint64_t*>(lds + L_H2W + w * 32u * LD_32 + c * LD_32 + 2u * (8u * q + 4u * h)) = pack4(tA[0], tA[1], tA[2], tA[3]);
+                *reinterpret_cast<uint64_t*>(lds + L_H2T + c * LD_B + 2u * (32u * w + 8u * q + 4u * h)) = pack4(tB[0], tB[1], tB[2], tB[3]);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            f32x16 accY = zero16;                               // [o][b]: lane = sample, registers = outputs
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+                accY = mm(lds16(lds, L_W3 + c * LD_32 + 32u * (uint32_t)s + 16u * h), lds16(lds, L_H2W + w * 32u * LD_32 + c * LD_32 + 32u * (uint32_t)s + 16u * h), accY);
+            float* yrow = net.yp + ((size_t)g * MB + 32u * w + c) * 16u;
+            pub8f(yrow + 4u * h, accY[0], accY[1]); pub8f(yrow + 4u * h + 2u, accY[2], accY[3]);          // outputs 4 h .. 4 h + 3
+            pub8f(yrow + 8u + 4u * h, accY[4], accY[5]); pub8f(yrow + 10u + 4u * h, accY[6], accY[7]);    // outputs 8 + 4 h ..
+        }
+        Q1PL_STAMP(2);                                          // W2 column gather + P2 + partial logits
+        bar_arrive(net.bar);
+        if (!bar_wait(net.bar, (uint32_t)G * ++bar_n, a.status, 1u, (uint32_t)step, a.timeout_ticks, s_ok)) return;
+        Q1PL_STAMP(3);                                          // barrier 2
+
+        // ------------------------------------------------------------ outputs, loss gradient: two lanes per sample (lanes l and l ^ 32 of
+        // wave w: sample 32 w + c; q1ppo_loss.hpp PAIR form - the four keys' terms, half of the function's instructions, are split
+        // between the pair), so all four waves share the work; identical in every workgroup of the group.  Each lane of the pair sums
+        // HALF of the G partial rows (one round of loads), the halves are exchanged: y = b3 + (A + B) in both lanes, the same bits.
+        float s3[3] = {0.0f, 0.0f, 0.0f};
+        float gl[10];
+        {
+            float y[12];
+            {
+                float4 part[4][3];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float4* row = reinterpret_cast<const float4*>(net.yp + ((size_t)(4u * h + (uint32_t)q) * MB + bsm) * 16u);
+                    part[q][0] = row[0];
+                    if (OUT > 4) { part[q][1] = row[1]; part[q][2] = row[2]; } else { part[q][1] = float4{0, 0, 0, 0}; part[q][2] = float4{0, 0, 0, 0}; }
+                }
+                float b3v[12];
+#pragma unroll
+                for (int o = 0; o < 12; ++o) b3v[o] = o < OUT ? net.b3[o] : 0.0f;
+                float half_[12];
+#pragma unroll
+                for (int v = 0; v < 3; ++v) {
+                    half_[4 * v + 0] = ((part[0][v].x + part[1][v].x) + part[2][v].x) + part[3][v].x;
+                    half_[4 * v + 1] = ((part[0][v].y + part[1][v].y) + part[2][v].y) + part[3][v].y;
+                    half_[4 * v + 2] = ((part[0][v].z + part[1][v].z) + part[2][v].z) + part[3][v].z;
+                    half_[4 * v + 3] = ((part[0][v].w + part[1][v].w) + part[2][v].w) + part[3][v].w;
+                }
+#pragma unroll
+                for (int o = 0; o < 12; ++o) {
+                    const float other = __shfl_xor(half_[o], 32, 64);
+                    const float lo_ = h ? other : half_[o], hi_ = h ? half_[o] : other;      // (groups 0..3) + (groups 4..7): the same operand order in both lanes
+                    y[o] = b3v[o] + (lo_ + hi_);
+                }
+            }
+#pragma unroll
+            for (int o = 0; o < 10; ++o) gl[o] = 0.0f;
+            if (ni == 0) {
+                const PpoSample in{in_kb, in_a, in_b, in_c};
+                const PpoSums ps = ppo_policy_grad<true, true, true>(a.p, y, oldrow, in, a.clip, a.ent_coeff, klc, net.inv_b, gl, 10, h);
+                s3[0] = ps.ent; s3[1] = ps.kl; s3[2] = -ps.surr;
+            } else {
+                float vf;
+                const float dvf = ppo_value_grad(y[0], in_a, in_b, a.vf_clip, vf);
+                gl[0] = a.vf_coeff * dvf * net.inv_b;
+                s3[0] = vf;
+            }
+            _Float16 row16[16];
+#pragma unroll
+            for (int o = 0; o < 16; ++o) row16[o] = (_Float16)0.0f;
+#pragma unroll
+            for (int o = 0; o < 10; ++o) {
+                if (o < OUT) {
+                    row16[o] = (_Float16)sat16(gl[o], amax, nsat);
+                    gl[o] = h ? 0.0f : (float)row16[o];         // (the pair computed the same row: lane h = 0 stores it and counts in the sums)
+                    if (!h) *reinterpret_cast<_Float16*>(lds + L_DYT + (uint32_t)o * LD_B + 2u * bsm) = row16[o];
+                }
+            }
+            if (!h) {
+                *reinterpret_cast<f16x8*>(lds + L_DY + bsm * LD_16) = *reinterpret_cast<const f16x8*>(row16);
+                *reinterpret_cast<f16x8*>(lds + L_DY + bsm * LD_16 + 16u) = *reinterpret_cast<const f16x8*>(row16 + 8);
+            } else {
+                s3[0] = 0.0f; s3[1] = 0.0f; s3[2] = 0.0f;
+            }
+        }
+        // sums over the samples: db3 (float16-rounded rows) and the statistics, wave by wave, then in wave order
+#pragma unroll
+        for (int o = 0; o < 10; ++o) {
+            if (o < OUT) {
+                float v = gl[o];
+#pragma unroll
+                for (int off = 16; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+                if (lane == 0) red3[w * 16u + (uint32_t)o] = v;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            float v = s3[k];
+#pragma unroll
+            for (int off = 16; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+            if (lane == 0) stat[w * 4u + (uint32_t)k] = v;
+        }
+        __syncthreads();
+        if (tid == 0 && g == 0) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) st_acc[k] += (((stat[k] + stat[4 + k]) + stat[8 + k]) + stat[12 + k]) * (1.0f / (float)MB);
+        }
+        Q1PL_STAMP(4);                                          // outputs + loss gradient + sums
+
+        // ------------------------------------------------------------ B3: dZ2 of the owned units, both orientations
+        {
+            const f16x8 aT = lds16(lds, L_W3T + c * LD_16 + 16u * h);
+            const f16x8 bY = lds16(lds, L_DY + (32u * w + c) * LD_16 + 16u * h);
+            const f32x16 dA = mm(aT, bY, zero16);               // [u][b]: lane = sample (h2A's layout)
+            const f32x16 dB = mm(bY, aT, zero16);               // [b][u]: lane = unit   (h2B's layout)
+            float sb = 0.0f;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float zA[4], zB[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    zA[j] = sat16(dA[4 * q + j] * (1.0f - h2A[4 * q + j] * h2A[4 * q + j]), amax, nsat);
+                    zB[j] = sat16(dB[4 * q + j] * (1.0f - h2B[4 * q + j] * h2B[4 * q + j]), amax, nsat);
+                    sb += r16(zB[j]);
+                }
+                pub8(net.dz2x + (size_t)(32u * w + c) * HID + U0 + 8u * q + 4u * h, pack4(zA[0], zA[1], zA[2], zA[3]));
+                *reinterpret_cast<uint64_t*>(lds + L_DZ2T + c * LD_B + 2u * (32u * w + 8u * q + 4u * h)) = pack4(zB[0], zB[1], zB[2], zB[3]);
+            }
+            sb += __shfl_xor(sb, 32, 64);
+            if (h == 0) red2[w * 32u + c] = sb;
+        }
+        bar_arrive(net.bar);                                    // (its workgroup barrier also orders dZ2T / H2T / dYT / red2 for the products below)
+        Q1PL_STAMP(5);                                          // B3 + arrive 3
+
+        // ------------------------------------------------------------ G2: dW2 rows U (two 32-input tiles per wave) + Adam + new images
+        // The optimizer state (masters, both moments: torch layouts in global memory, private to the owning lane - lane (c, h) of wave w owns
+        // inputs k = 64 w + 32 t + c of units U0 + row(r, h), the accumulator layout of the product) is REQUESTED before the matrix
+        // products and stored after all of it has been used: every access of one kind is issued together (the compiler must assume that
+        // a store may alias a later load of another array, and would otherwise serialise 32 round trips to L2 per step).
+#pragma unroll 1
+        for (int t = 0; t < 2; ++t) {                           // one 32-input tile at a time (half the registers; the second tile's loads follow the first one's stores)
+            const uint32_t k = 64u * w + 32u * (uint32_t)t + c;
+            float w2v[16], m2v[16], v2v[16];
+            f16x8 hT[8];
+            const uint16_t* r0 = h1tx + (size_t)k * MB + 8u * h;
+#pragma unroll
+            for (int s = 0; s < 8; ++s) hT[s] = glb16(r0 + 16 * s);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { w2v[r] = st_w[64 * (16 * t + r)]; m2v[r] = st_m[64 * (16 * t + r)]; v2v[r] = st_v[64 * (16 * t + r)]; }
+            f32x16 acc = zero16;                                // [u][k]: lane = input k, registers = owned units
+#pragma unroll
+            for (int s = 0; s < 8; ++s) acc = mm(lds16(lds, L_DZ2T + c * LD_B + 32u * (uint32_t)s + 16u * h), hT[s], acc);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int r = 4 * q + j;
+                    const float gr = acc[r] * net.inv_scale;
+                    w2v[r] = adam1(w2v[r], gr, m2v[r], v2v[r], a.beta1, a.beta2, a.eps, lr_bc1, rs_bc2);
+                    *reinterpret_cast<_Float16*>(lds + L_W2OWN + rrow(r, h) * LD_W + 2u * k) = (_Float16)(c2 * w2v[r]);
+                    if (last) net.gw2[(size_t)(U0 + rrow(r, h)) * HID + k] = gr;
+                }
+                pub8(net.w2tx + (size_t)k * HID + U0 + 8u * q + 4u * h, pack4(w2v[4 * q], w2v[4 * q + 1], w2v[4 * q + 2], w2v[4 * q + 3]));
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { st_w[64 * (16 * t + r)] = w2v[r]; st_m[64 * (16 * t + r)] = m2v[r]; st_v[64 * (16 * t + r)] = v2v[r]; }
+        }
+        if (w == 1u) {                                          // dW3[:, U]: lane = owned unit, registers = outputs (o = row(r, h) < OUT <= 10: r < 8)
+            float w3v[8], m3v[8], v3v[8];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const uint32_t o = rrow(r, h);
+                const size_t i3 = (size_t)((int)o < OUT ? o : 0u) * HID + U0 + c;
+                w3v[r] = net.w3[i3]; m3v[r] = net.m[E_W3 + i3]; v3v[r] = net.v[E_W3 + i3];
+            }
+            f32x16 acc = zero16;
+#pragma unroll
+            for (int s = 0; s < 8; ++s)
+                acc = mm(lds16(lds, L_DYT + c * LD_B + 32u * (uint32_t)s + 16u * h), lds16(lds, L_H2T + c * LD_B + 32u * (uint32_t)s + 16u * h), acc);
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const uint32_t o = rrow(r, h);
+                if ((int)o < OUT) {
+                    const float gr = acc[r] * net.inv_scale;
+                    w3v[r] = adam1(w3v[r], gr, m3v[r], v3v[r], a.beta1, a.beta2, a.eps, lr_bc1, rs_bc2);
+                    *reinterpret_cast<_Float16*>(lds + L_W3 + o * LD_32 + 2u * c) = (_Float16)w3v[r];
+                    *reinterpret_cast<_Float16*>(lds + L_W3T + c * LD_16 + 2u * o) = (_Float16)w3v[r];
+                    if (last) net.gw3[(size_t)o * HID + U0 + c] = gr;
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const uint32_t o = rrow(r, h);
+                if ((int)o < OUT) { const size_t i3 = (size_t)o * HID + U0 + c; net.w3[i3] = w3v[r]; net.m[E_W3 + i3] = m3v[r]; net.v[E_W3 + i3] = v3v[r]; }
+            }
+        }
+        if (w == 2u && h == 0u) {                               // db2[U]
+            const size_t u = U0 + c;
+            float b2v = net.b2[u], mv = net.m[E_B2 + u], vv = net.v[E_B2 + u];
+            const float gr = (((red2[c] + red2[32u + c]) + red2[64u + c]) + red2[96u + c]) * net.inv_scale;
+            b2v = adam1(b2v, gr, mv, vv, a.beta1, a.beta2, a.eps, lr_bc1, rs_bc2);
+            b2p[c] = c2 * b2v;
+            net.b2[u] = b2v; net.m[E_B2 + u] = mv; net.v[E_B2 + u] = vv;
+            if (last) net.gb2[u] = gr;
+        }
+        Q1PL_STAMP(6);                                          // dW2 + Adam + images (wave 0's share)
+        if (!bar_wait(net.bar, (uint32_t)G * ++bar_n, a.status, 2u, (uint32_t)step, a.timeout_ticks, s_ok)) return;
+        Q1PL_STAMP(7);                                          // barrier 3 wait (incl. waiting for this workgroup's other waves)
+
+        // ------------------------------------------------------------ B2: dH1 of the owned units from all of dZ2, dZ1, then dW1 / db1, db3
+        {
+            f16x8 zr[16];
+            const uint16_t* zrow = net.dz2x + (size_t)(32u * w + c) * HID + 8u * h;
+#pragma unroll
+            for (int s = 0; s < 16; ++s) zr[s] = glb16(zrow + 16 * s);
+            f32x16 acc = zero16;                                // [b][j]: lane = owned unit j, registers = samples (h1B's layout)
+#pragma unroll
+            for (int s = 0; s < 16; ++s) acc = mm(zr[s], lds16(lds, L_W2COL + c * LD_W + 32u * (uint32_t)s + 16u * h), acc);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float z[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) z[j] = sat16(acc[4 * q + j] * (1.0f - h1B[4 * q + j] * h1B[4 * q + j]), amax, nsat);
+                *reinterpret_cast<uint64_t*>(lds + L_DZ1T + c * LD_B + 2u * (32u * w + 8u * q + 4u * h)) = pack4(z[0], z[1], z[2], z[3]);
+            }
+        }
+        __syncthreads();
+        if (w == 2u) {                                          // dW1[U] / db1[U]: [i'][u]: lane = owned unit, registers = rows of [x hi | 1 | x lo]^T
+            // h = 0: registers 0..3 = inputs 0..3 (hi), 4..7 = the same inputs' lo rows;  h = 1: 0, 1 = inputs 4, 5 (hi), 2 = the ones row, 4, 5 = lo of 4, 5
+            const size_t u = U0 + c;
+            const int base = h ? 4 : 0;
+            float w1v[4], m1v[4], v1v[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const bool isw = h == 0u || j < 2;
+                const size_t i1 = isw ? u * 6 + (size_t)(base + j) : u * 6;
+                w1v[j] = net.w1[i1]; m1v[j] = net.m[E_W1 + i1]; v1v[j] = net.v[E_W1 + i1];
+            }
+            float b1v = net.b1[u], mb1 = net.m[E_B1 + u], vb1 = net.v[E_B1 + u];
+            f32x16 acc = zero16;
+#pragma unroll
+            for (int s = 0; s < 8; ++s)
+                acc = mm(lds16(lds, L_XT + c * LD_B + 32u * (uint32_t)s + 16u * h), lds16(lds, L_DZ1T + c * LD_B + 32u * (uint32_t)s + 16u * h), acc);
+            _Float16* row = reinterpret_cast<_Float16*>(lds + L_W1 + c * LD_16);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (h == 0u || j < 2) {
+                    const float gr = (acc[j] + acc[4 + j]) * net.inv_scale;
+                    w1v[j] = adam1(w1v[j], gr, m1v[j], v1v[j], a.beta1, a.beta2, a.eps, lr_bc1, rs_bc2);
+                    const _Float16 wv = (_Float16)(c2 * w1v[j]);
+                    row[base + j] = wv; row[8 + base + j] = wv;
+                    if (last) net.gw1[u * 6 + (size_t)(base + j)] = gr;
+                }
+            }
+            if (h) {
+                const float gr = acc[2] * net.inv_scale;
+                b1v = adam1(b1v, gr, mb1, vb1, a.beta1, a.beta2, a.eps, lr_bc1, rs_bc2);
+                const float bs = c2 * b1v;
+                const _Float16 bhi = (_Float16)bs;
+                row[6] = bhi; row[14] = (_Float16)(bs - (float)bhi);
+                if (last) net.gb1[u] = gr;
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (h == 0u || j < 2) { const size_t i1 = u * 6 + (size_t)(base + j); net.w1[i1] = w1v[j]; net.m[E_W1 + i1] = m1v[j]; net.v[E_W1 + i1] = v1v[j]; }
+            if (h) { net.b1[u] = b1v; net.m[E_B1 + u] = mb1; net.v[E_B1 + u] = vb1; }
+        }
+        if (g == 0 && w == 3u && (int)lane < OUT) {             // db3 (after barrier 3: every workgroup has read this step's b3)
+            float b3v = net.b3[lane], mv = net.m[E_B3 + lane], vv = net.v[E_B3 + lane];
+            const float gr = (((red3[lane] + red3[16u + lane]) + red3[32u + lane]) + red3[48u + lane]) * net.inv_scale;
+            b3v = adam1(b3v, gr, mv, vv, a.beta1, a.beta2, a.eps, lr_bc1, rs_bc2);
+            net.m[E_B3 + lane] = mv; net.v[E_B3 + lane] = vv;
+            if (last) net.gb3[lane] = gr;
+            __hip_atomic_store(net.b3 + lane, b3v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+        Q1PL_STAMP(8);                                          // B2 + dW1 + end of step
+    }
+#undef Q1PL_STAMP
+    if (profiling)
+        for (int k = 0; k < 10; ++k) a.prof[k] = pacc[k];
+
+    // ---------------------------------------------------------------- epilogue: the W2 slice's optimizer state back to its torch layouts; counters
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const size_t e = (size_t)(U0 + rrow(r, h)) * HID + 64u * w + 32u * (uint32_t)t + c;
+            net.w2[e] = st_w[64 * (16 * t + r)]; net.m[e] = st_m[64 * (16 * t + r)]; net.v[e] = st_v[64 * (16 * t + r)];
+        }
+    if (g == 0 && tid == 0) {
+        if (ni == 0) {
+            a.stats_acc[0] += st_acc[0]; a.stats_acc[1] += st_acc[1]; a.stats_acc[2] += st_acc[2];
+            *a.step_count = step0 + a.steps;
+        } else {
+            a.stats_acc[4] += st_acc[0];
+        }
+    }
+    if (a.saturation) {
+        if (nsat) atomicAdd(a.saturation + 2u * ni, nsat);
+        if (amax > 0.0f) atomicMax(a.saturation + 2u * ni + 1u, __float_as_uint(amax));
+    }
+}
+
+}  // namespace q1pl

@@ -35,7 +35,11 @@ struct PpoSums { float ent, kl, surr; };
 // exponentials, two log1p and two divisions each: half of the function's instructions - are computed once per pair, keys 0, 1 by the
 // lane with half = 0 and keys 2, 3 by its partner, and swapped (six values per key); both lanes then run the accumulations over k = 0..3
 // in the order of the one-lane form, on the same values: the same bits.  All 64 lanes must be active in the call.
-template <bool FIXED, bool PAIR = false>
+// FAST (the persistent learner, q1learner_persist.hpp - a kernel bound by its instruction count): the hardware's exponential and
+// logarithm (v_exp_f32 / v_log_f32 behind __expf / __logf, ~1e-6 relative) in place of the library's expf / log1pf, and in.mouse holds
+// the squashed-Gaussian pre-image u = S ndtri((x - low) / (high - low)) ALREADY (computed by the caller, off its critical path).  The
+// results differ from the exact forms by ~1e-6 relative - three orders below the float16 rounding the gradient row gets next.
+template <bool FIXED, bool PAIR = false, bool FAST = false>
 __device__ __forceinline__ PpoSums ppo_policy_grad(const Params& p, const float* __restrict__ row, const float* __restrict__ old, const PpoSample& in,
                                                    float clip, float ent_coeff, float klc, float inv_b, float* __restrict__ g, int row_stride,
                                                    uint32_t half = 0u) {
@@ -45,7 +49,8 @@ __device__ __forceinline__ PpoSums ppo_policy_grad(const Params& p, const float*
     const uint32_t kb = in.kb;
     float logp = 0.0f, ent = 0.0f, kl = 0.0f;
     float dlp[4], dh[4], dk[4];
-    auto softplus = [](float z) { return (z > 0.0f ? z : 0.0f) + log1pf(expf(-fabsf(z))); };
+    auto expf = [](float z) { return FAST ? __expf(z) : ::expf(z); };                       // (shadows the library function below)
+    auto softplus = [&](float z) { return (z > 0.0f ? z : 0.0f) + (FAST ? __logf(1.0f + __expf(-fabsf(z))) : log1pf(::expf(-fabsf(z)))); };
     if constexpr (PAIR) {
         float m[2][6], x[2][6];                                                     // [key of this half][logp term, entropy term, kl term, dlp, dh, dk]
 #pragma unroll
@@ -124,7 +129,7 @@ __device__ __forceinline__ PpoSums ppo_policy_grad(const Params& p, const float*
         const float mean = fminf(fmaxf(m_raw, -3.0f), 3.0f), ls = fminf(fmaxf(s_raw, -20.0f), 2.0f);
         const float mean_o = fminf(fmaxf(old[2 * nk], -3.0f), 3.0f), ls_o = fminf(fmaxf(old[2 * nk + 1], -20.0f), 2.0f);
         const float inv_std = expf(-ls), std = expf(ls), std_o = expf(ls_o);
-        const float u = S * normcdfinvf((in.mouse - low) / (high - low));
+        const float u = FAST ? in.mouse : S * normcdfinvf((in.mouse - low) / (high - low));
         const float z = (u - mean) * inv_std, zq = u / S;
         logp += (-0.5f * z * z - ls - 0.9189385332046727f) - ((-0.5f * zq * zq - LOG_SQUASH_SCALE - 0.9189385332046727f) + p.log_range_f32);
         dlp_m = z * inv_std; dlp_s = z * z - 1.0f;

@@ -274,6 +274,20 @@ class DeviceEnv:
         _lib.check(self._lib.q1env_learner_sgd_step(self._h, C.byref(pi), C.byref(vf), ws, int(splits), C.byref(batch), float(lr), float(beta1),
                                                     float(beta2), float(eps), state))
 
+    def learner_persistent_bytes(self, batch_rows):
+        return int(self._lib.q1env_learner_persistent_bytes(int(batch_rows)))
+
+    def learner_sgd_epochs_dev(self, pi, vf, pws, batch, batch_rows, steps, steps_per_epoch, epoch_stride, lr, beta1, beta2, eps, state, timeout_s=5.0):
+        """`steps` SGD steps of 128-sample minibatches as ONE dispatch (include/q1env.h q1env_learner_sgd_epochs)."""
+        _lib.check(self._lib.q1env_learner_sgd_epochs(self._h, C.byref(pi), C.byref(vf), C.c_void_p(int(pws)), C.byref(batch), int(batch_rows), int(steps), int(steps_per_epoch),
+                                                      int(epoch_stride), float(lr), float(beta1), float(beta2), float(eps), C.c_void_p(int(state)),
+                                                      float(timeout_s)))
+
+    def learner_persistent_status(self, pws):
+        st = (C.c_uint32 * 4)()
+        _lib.check(self._lib.q1env_learner_persistent_status(self._h, C.c_void_p(int(pws)), st))
+        return [int(x) for x in st]
+
     def learner_step_dev(self, pi, vf, ws, splits, batch):
         _lib.check(self._lib.q1env_learner_step(self._h, C.byref(pi), C.byref(vf), ws, int(splits), C.byref(batch)))
 

@@ -89,6 +89,7 @@ class NativeStep:
         self.cursor = self.adam_state[72:80].view(torch.int64)           # minibatch cursor: += mb per adam() (q1env_learner_batch.idx_cursor_dev)
         # saturation report of the backward pass (q1env_learner_batch.saturation_dev): [count, max |element| bits] x (policy, value)
         self.saturation = torch.zeros((4,), dtype=torch.int32, device=dev)
+        self._pws = None                                         # the persistent learner's exchange buffers (epochs()), made on first use
         self.images()
 
     def _net(self, seq):
@@ -123,6 +124,43 @@ class NativeStep:
         (q1env_learner_adam; moments and step count in self.adam_state)."""
         self.env._dev.learner_adam_dev(self.pi, self.vf, self.ws.data_ptr(), self.mb, self.splits, float(self.mb), lr, betas[0], betas[1], eps,
                                        self.adam_state.data_ptr(), self.partials.data_ptr())
+
+    PERSISTENT_MB = 128                                        # q1env_learner_sgd_epochs is built for RLlib's sgd_minibatch_size
+
+    def persistent_ok(self):
+        """The persistent learner serves the reference's own shape: 128-sample minibatches, 4 keys + continuous mouse (10 policy outputs)."""
+        return self.mb == self.PERSISTENT_MB and self.policy.pi[4].out_features == 10 and self.env._dev.num_keys == 4
+
+    def epochs(self, full, perms, clip_param, vf_clip_param, vf_loss_coeff, entropy_coeff, klc_dev, adam, steps=None, refresh_images=True):
+        """ALL the SGD steps of an update as ONE dispatch (q1env_learner_sgd_epochs, csrc/q1learner_persist.hpp): perms int64
+        (epochs, total) - one permutation of the train batch per epoch; every epoch runs total // 128 steps on consecutive windows of its
+        permutation (what update()'s loop feeds q1env_learner_sgd_step one call at a time).  adam = (lr, betas, eps).  Masters, moments,
+        step count, .grad (the last step's) and the running statistics [0, 1, 2, 4] of self.stats_acc are updated; [3] (total loss) is
+        left to the caller.  Returns the number of steps."""
+        L = self._lib
+        assert self.persistent_ok() and perms.dtype == torch.int64 and perms.is_contiguous() and perms.dim() == 2
+        total = perms.shape[1]
+        spe = total // self.mb
+        n = perms.shape[0] * spe if steps is None else int(steps)
+        rows = full["adv"].shape[0]
+        need = self.env._dev.learner_persistent_bytes(rows)
+        if self._pws is None or self._pws.numel() < need:
+            self._pws = torch.zeros((need,), dtype=torch.uint8, device=perms.device)
+        ol = full["old_logits"]
+        b = L.Q1LearnerBatch(self.mb, perms.data_ptr(), None, full["obs"].data_ptr(), ol.data_ptr(), ol.shape[1],
+                             full["keys_packed"].data_ptr(), full["mouse"].data_ptr(), full["logp"].data_ptr(), full["adv"].data_ptr(),
+                             full["value"].data_ptr(), full["vtarg"].data_ptr(), clip_param, vf_clip_param, vf_loss_coeff, entropy_coeff,
+                             klc_dev.data_ptr(), None, 0, self.saturation.data_ptr())
+        lr, betas, eps = adam
+        self.env._dev.learner_sgd_epochs_dev(self.pi, self.vf, self._pws.data_ptr(), b, rows, n, spe, total, lr, betas[0], betas[1], eps,
+                                             self.adam_state.data_ptr())
+        if refresh_images:
+            self.images()                                      # the four-launch path's float16 weight images follow the new masters
+        return n
+
+    def persistent_status(self):
+        """[0] != 0: a group barrier of the last epochs() launch timed out (1 + its index in the step), [1] = the step.  Synchronises."""
+        return self.env._dev.learner_persistent_status(self._pws.data_ptr()) if self._pws is not None else [0, 0, 0, 0]
 
     def step(self, full, idx, clip_param, vf_clip_param, vf_loss_coeff, entropy_coeff, klc_dev, skip_reduce=False, use_cursor=False, adam=None):
         """full: dict of the whole trajectory batch (obs (total,6), old_logits (total,W), keys_packed, mouse, logp, adv, value, vtarg);
@@ -166,7 +204,7 @@ class PPOLearner:
     def __init__(self, policy, action_range, lr=5e-6, gamma=0.99, lam=0.95, clip_param=0.3, vf_clip_param=100.0,
                  vf_loss_coeff=1.0, entropy_coeff=0.01, kl_coeff=0.2, kl_target=0.0036, num_sgd_iter=30,
                  minibatch_size=128, num_keys=4, seed=0, use_graph=False, fused_loss=False, env=None, discrete_yaw_steps=-1,
-                 allow_yaw=True, autocast_dtype=None, fused_adam=False, native=False, native_splits=32, native_adam=True):
+                 allow_yaw=True, autocast_dtype=None, fused_adam=False, native=False, native_splits=32, native_adam=True, persistent=None):
         self.policy = policy
         self.action_range = float(action_range)
         self.gamma, self.lam = gamma, lam
@@ -179,6 +217,9 @@ class PPOLearner:
         self.use_graph = bool(use_graph) and self.world == 1
         self.fused_loss, self.env = bool(fused_loss), env
         self.native, self.native_splits, self.native_adam = bool(native), int(native_splits), bool(native_adam)
+        # persistent: the whole update (num_sgd_iter epochs of 128-sample minibatches) as ONE dispatch (NativeStep.epochs); None = whenever
+        # the shape allows it (native, own Adam, single process, minibatch 128, the reference's action structure)
+        self.persistent = persistent
         if (self.fused_loss or self.native) and env is None:
             raise ValueError("fused_loss=True / native=True need env= (the TensorVectorEnv whose handle runs the kernels)")
         self._native = None
@@ -187,6 +228,7 @@ class PPOLearner:
         self._full = None
         self._idx = None
         self._perm = None                       # native + own Adam: the epoch's permutation, read through the device-resident cursor
+        self._perms = None                      # persistent learner: all epochs' permutations of one update
         # autocast_dtype (e.g. torch.bfloat16): the two MLPs' matrix products run on reduced-precision operands with float32
         # accumulation (master weights, loss, its gradient and Adam stay float32); fused_adam: one multi-tensor Adam launch
         self.autocast_dtype = autocast_dtype
@@ -390,19 +432,31 @@ class PPOLearner:
                 self._graph = None
             for k in keys_:
                 self._full[k].copy_(b[k].reshape(self._full[k].shape))
+        own_adam = self.native and self.world == 1 and self.native_adam
+        use_persistent = bool(own_adam and self.persistent is not False and self._native.persistent_ok() and total >= mb)
+        if self.persistent is True and not use_persistent:
+            raise ValueError("PPOLearner(persistent=True) needs native=True, native_adam=True, one process, minibatch_size 128 and the reference's action structure")
         # lr / betas / eps are kernel ARGUMENTS of the native Adam, baked into a captured graph: a changed param_group re-captures
         if self.use_graph and self._graph is not None and self.native and self._graph_hparams != self._hparams():
             self._graph = None
-        if self.use_graph and (self._graph is None or (not self.native and self._mb["adv"].shape[0] != mb)):
+        if self.use_graph and not use_persistent and (self._graph is None or (not self.native and self._mb["adv"].shape[0] != mb)):
             self._capture(b, mb, dev)
             self._graph_hparams = self._hparams()
         acc, steps = torch.zeros((len(STAT_KEYS),), dtype=torch.float32, device=dev), 0
-        if self.use_graph:
+        if self.use_graph and not use_persistent:
             self._acc.zero_()
         if self._native is not None:
             self._native.stats_acc.zero_()
-        own_adam = self.native and self.world == 1 and self.native_adam
-        for _ in range(self.num_sgd_iter):
+        if use_persistent:
+            # the same permutations, in the same generator order, as the per-step loop below draws - then one launch for all of them
+            if self._perms is None or self._perms.shape != (self.num_sgd_iter, total):
+                self._perms = torch.empty((self.num_sgd_iter, total), dtype=torch.int64, device=dev)
+            for e in range(self.num_sgd_iter):
+                self._perms[e].copy_(torch.randperm(total, device=dev, generator=self.gen))
+            self.env.use_current_stream()
+            steps = self._native.epochs(self._full, self._perms, self.clip_param, self.vf_clip_param, self.vf_loss_coeff, self.entropy_coeff,
+                                        self._klc, self._hparams())
+        for _ in range(0 if use_persistent else self.num_sgd_iter):
             perm = torch.randperm(total, device=dev, generator=self.gen)
             if own_adam:                            # the whole epoch's order once; each step reads its window at the device-resident cursor
                 self._perm.copy_(perm)
@@ -425,10 +479,17 @@ class PPOLearner:
                 else:
                     acc = acc + self._sgd_step({k: v[idx] for k, v in b.items()})
                 steps += 1
-        if self.use_graph:
+        if self.use_graph and not use_persistent:
             acc = self._acc.clone()
         if self.native and self.world == 1 and self.native_adam:
             acc = self._native.stats_acc.clone()
+            if use_persistent:                        # total = policy + kl_coeff kl + vf_coeff vf - entropy_coeff entropy (all means: linear)
+                i = {k: j for j, k in enumerate(STAT_KEYS)}
+                acc[i["total_loss"]] = (acc[i["policy_loss"]] + float(self.kl_coeff) * acc[i["kl"]] + self.vf_loss_coeff * acc[i["vf_loss"]]
+                                        - self.entropy_coeff * acc[i["entropy"]])
+                st = self._native.persistent_status()
+                if st[0]:
+                    raise RuntimeError(f"persistent learner: group barrier {st[0] - 1} timed out in step {st[1]} (the 16 workgroups were not co-resident?)")
         acc = acc / steps
         if self.world > 1:
             dist.all_reduce(acc, op=dist.ReduceOp.SUM)

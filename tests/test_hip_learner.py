@@ -372,3 +372,132 @@ def test_native_training_learns_strafe_jumping_in_seconds():
     zs = [x["zero_start_total_reward_mean"] for x in its if np.isfinite(x["zero_start_total_reward_mean"])]     # (no zero-start episode ends in iteration 0)
     assert zs[0] < 2500.0 < 4200.0 < zs[-1], (zs[0], zs[-1])
     assert its[-1]["iter_s"] < 0.2                                  # <= 0.2 s per iteration (measured 0.08)
+
+
+# ------------------------------------------------------------------------------------------------ persistent learner (round 5)
+def _train_batch(n_envs, horizon, pol, seed=4):
+    """A real train batch of n_envs x horizon samples from the sampler (the arrays q1env_learner_batch points at)."""
+    import torch
+    from q1physrl_amd import policy as P, sampler as S
+    torch.manual_seed(seed)
+    cfg, env = make_env(n_envs, time_limit=1.0)
+    smp = S.GpuSampler(env, P.FusedPolicyForward(pol, env), horizon=horizon)
+    tr = smp.collect()
+    adv, vt = smp.advantages(tr, 0.99, 0.95)
+    t, n = tr["reward"].shape
+    total = t * n
+    full = {"obs": tr["obs"][:t].reshape(total, 6).contiguous(), "old_logits": tr["logits"].reshape(total, -1).contiguous(),
+            "keys_packed": tr["keys"].reshape(-1), "mouse": tr["mouse"].reshape(-1), "logp": tr["logp"].reshape(-1),
+            "adv": ((adv - adv.mean()) / adv.std()).reshape(-1).contiguous(), "value": tr["value"][:t].reshape(-1).contiguous(),
+            "vtarg": vt.reshape(-1).contiguous()}
+    return env, full, total
+
+
+def test_persistent_learner_one_step_against_the_four_launch_step_and_autograd():
+    """q1env_learner_sgd_epochs with steps = 1 against ONE q1env_learner_sgd_step on the same 128 rows from the same state: every
+    parameter gradient within float16-operand rounding of the four-launch path's (relative Frobenius error <= 3e-3 per tensor - the bound
+    the four-launch path itself is held to against autograd) and, directly, of torch autograd through the float32 modules and
+    ppo.ppo_loss; masters, moments and step count after the Adam update accordingly."""
+    import copy
+    import torch
+    from q1physrl_amd import ppo
+    pol_a = _policy(5, 2.0)
+    pol_b, pol_c = copy.deepcopy(pol_a), copy.deepcopy(pol_a)
+    env, full, total = _train_batch(64, 8, pol_a)
+    klc = torch.tensor(0.2, device="cuda")
+    perm = torch.randperm(total, device="cuda")
+    a, b = ppo.NativeStep(pol_a, env, 128, splits=8), ppo.NativeStep(pol_b, env, 128, splits=8)
+    assert b.persistent_ok()
+    hp = (3e-4, (0.9, 0.999), 1e-8)
+    w0 = [p.detach().clone() for p in pol_a.parameters()]
+    a.step(full, perm, 0.3, 10.0, 1.0, 0.01, klc, skip_reduce=True, use_cursor=True, adam=hp)
+    n = b.epochs(full, perm.reshape(1, -1).contiguous(), 0.3, 10.0, 1.0, 0.01, klc, hp, steps=1)
+    torch.cuda.synchronize()
+    assert n == 1 and b.persistent_status()[0] == 0
+    # autograd reference of the same minibatch
+    idx = perm[:128]
+    mbatch = {"obs": full["obs"][idx], "old_logits": full["old_logits"][idx], "mouse": full["mouse"][idx].reshape(-1, 1), "logp": full["logp"][idx],
+              "adv": full["adv"][idx], "value": full["value"][idx], "vtarg": full["vtarg"][idx],
+              "keys": ((full["keys_packed"][idx].reshape(-1, 1).long() >> torch.arange(4, device="cuda")) & 1)}
+    for p in pol_c.parameters():
+        p.grad = None
+    loss, _st = ppo.ppo_loss(pol_c, mbatch, float(env.config.action_range), 0.3, 10.0, 1.0, 0.01, klc)
+    loss.backward()
+    for (name, pa), pb, pc in zip(pol_a.named_parameters(), pol_b.parameters(), pol_c.parameters()):
+        assert _rel(pb.grad, pa.grad) < 3e-3, (name, "vs four-launch", _rel(pb.grad, pa.grad))
+        assert _rel(pb.grad, pc.grad) < 4e-3, (name, "vs autograd", _rel(pb.grad, pc.grad))
+    for (name, pa), pb, w in zip(pol_a.named_parameters(), pol_b.parameters(), w0):
+        da, db = pa.detach() - w, pb.detach() - w
+        assert float(da.abs().max()) > 0 and _rel(db, da) < 2e-2, (name, _rel(db, da))      # first Adam step: +- lr per element, sign(g) - a flipped sign of a ~0 gradient moves 2 lr
+    assert torch.equal(a.adam_state[:8], b.adam_state[:8])                                     # step count
+    ma, mb_ = a.adam_state[256:].view(torch.float32), b.adam_state[256:].view(torch.float32)
+    assert _rel(mb_, ma) < 3e-3
+    sa, sb = a.stats_acc.cpu().numpy(), b.stats_acc.cpu().numpy()
+    for k in (0, 1, 2, 4):
+        assert abs(sa[k] - sb[k]) <= 2e-3 * max(1.0, abs(sa[k])), (k, sa, sb)
+    env.close()
+
+
+def test_persistent_learner_epoch_of_391_steps_against_391_four_launch_steps():
+    """VERDICT r4 item 3's shape: one epoch of the reference's train batch - 391 minibatches of 128 out of 50 048 samples - as ONE
+    dispatch against 391 calls of q1env_learner_sgd_step (same permutation, same initial state, lr 5e-6 as in data/params.yml).  Not bit
+    for bit (the summation orders differ): the accumulated parameter CHANGE agrees to a few per cent per tensor, the running statistics to
+    1e-3, step counts exactly; then a second launch continues from the first one's state (moments, step count) like two more calls would."""
+    import copy
+    import torch
+    from q1physrl_amd import ppo
+    pol_a = _policy(7, 1.0)
+    pol_b = copy.deepcopy(pol_a)
+    env, full, total = _train_batch(128, 391, pol_a)
+    assert total == 50048
+    klc = torch.tensor(0.2, device="cuda")
+    perm = torch.randperm(total, device="cuda")
+    a, b = ppo.NativeStep(pol_a, env, 128, splits=8), ppo.NativeStep(pol_b, env, 128, splits=8)
+    hp = (5e-6, (0.9, 0.999), 1e-8)
+    w0 = [p.detach().clone() for p in pol_a.parameters()]
+    for _ in range(391):
+        a.step(full, perm, 0.3, 10.0, 1.0, 0.01, klc, skip_reduce=True, use_cursor=True, adam=hp)
+    n = b.epochs(full, perm.reshape(1, -1).contiguous(), 0.3, 10.0, 1.0, 0.01, klc, hp)
+    torch.cuda.synchronize()
+    assert n == 391 and b.persistent_status()[0] == 0
+    assert int(a.adam_state[:8].view(torch.int64)[0]) == 391 == int(b.adam_state[:8].view(torch.int64)[0])
+    for (name, pa), pb, w in zip(pol_a.named_parameters(), pol_b.parameters(), w0):
+        da, db = pa.detach() - w, pb.detach() - w
+        assert torch.isfinite(pb).all() and _rel(db, da) < 5e-2, (name, _rel(db, da))
+    sa, sb = a.stats_acc.cpu().numpy(), b.stats_acc.cpu().numpy()
+    for k in (0, 1, 2, 4):
+        assert abs(sa[k] - sb[k]) <= 1e-3 * max(391.0, abs(sa[k])), (k, sa, sb)
+    # the images of the four-launch path were refreshed: both paths continue from their own state and stay together
+    a.cursor.zero_()
+    for _ in range(5):
+        a.step(full, perm, 0.3, 10.0, 1.0, 0.01, klc, skip_reduce=True, use_cursor=True, adam=hp)
+    b.epochs(full, perm.reshape(1, -1).contiguous(), 0.3, 10.0, 1.0, 0.01, klc, hp, steps=5)
+    torch.cuda.synchronize()
+    assert int(b.adam_state[:8].view(torch.int64)[0]) == 396
+    for (name, pa), pb, w in zip(pol_a.named_parameters(), pol_b.parameters(), w0):
+        assert _rel(pb.detach() - w, pa.detach() - w) < 5e-2, name
+    env.close()
+
+
+def test_ppo_learner_update_persistent_equals_per_step_loop():
+    """PPOLearner.update with the persistent learner (one dispatch per update) against the same learner driving q1env_learner_sgd_step
+    per minibatch: same permutations (same generator), same statistics to 1e-3, same adaptive-KL decision."""
+    import copy
+    import torch
+    from q1physrl_amd import policy as P, ppo, sampler as S
+    pol_a = _policy(9, 1.0)
+    pol_b = copy.deepcopy(pol_a)
+    cfg, env = make_env(128, time_limit=1.0)
+    smp = S.GpuSampler(env, P.FusedPolicyForward(pol_a, env), horizon=16)
+    tr = smp.collect()
+    adv, vt = smp.advantages(tr, 0.99, 0.95)
+    outs = []
+    for pol, persistent in ((pol_a, False), (pol_b, True)):
+        lr_ = ppo.PPOLearner(pol, cfg.action_range, lr=5e-6, num_sgd_iter=3, minibatch_size=128, env=env, native=True, persistent=persistent, seed=3)
+        outs.append(lr_.update(tr, adv, vt))
+    torch.cuda.synchronize()
+    oa, ob = outs
+    assert oa["sgd_steps"] == ob["sgd_steps"] == 3 * 16 and oa["kl_coeff"] == ob["kl_coeff"]
+    for k in ("entropy", "kl", "policy_loss", "total_loss", "vf_loss"):
+        assert abs(oa[k] - ob[k]) <= 2e-3 * max(1.0, abs(oa[k])), (k, oa[k], ob[k])
+    env.close()
