@@ -85,7 +85,10 @@ int q1env_learner_sgd_epochs(q1env_t* h, const q1env_learner_net* pi, const q1en
     uint32_t* status = nullptr;
     float* mouse_u = nullptr;
     carve_pws(pws_dev, batch_rows, pw, &status, &mouse_u);
-    HIP_TRY(hipMemsetAsync(pws_dev, 0, 2 * 256, h->stream));           // status words + the first group's arrival counter
+    // status words and BOTH groups' arrival counters start at zero in every launch (a counter left at its previous final value would
+    // let every wait of the new launch pass at once: no synchronisation at all - found the hard way, by a diverging training run)
+    HIP_TRY(hipMemsetAsync(status, 0, 256, h->stream));
+    HIP_TRY(hipMemsetAsync(pw[0].bar, 0, 256, h->stream));
     HIP_TRY(hipMemsetAsync(pw[1].bar, 0, 256, h->stream));
     char* st = (char*)adam_state_dev;
     const size_t per_pi = 65536u + 256u + 1536u + 256u + (size_t)pi->out_dim * 257u, per_vf = 65536u + 256u + 1536u + 256u + 257u;

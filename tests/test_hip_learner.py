@@ -479,6 +479,37 @@ def test_persistent_learner_epoch_of_391_steps_against_391_four_launch_steps():
     env.close()
 
 
+def test_persistent_learner_consecutive_launches_stay_synchronised():
+    """Regression (round 5): every launch must re-zero BOTH groups' barrier counters - with one left at its previous final value the
+    second launch's waits all pass at once, its workgroups run unsynchronised and training diverges within a few updates (iteration 0 of
+    a run is unaffected, which is why a single-launch test cannot see it).  Six launches of 60 steps each on the same schedule against
+    360 four-launch steps: the parameter change agrees to a few per cent after EVERY launch."""
+    import copy
+    import torch
+    from q1physrl_amd import ppo
+    pol_a = _policy(11, 1.0)
+    pol_b = copy.deepcopy(pol_a)
+    env, full, total = _train_batch(128, 61, pol_a)            # 7 808 rows: NOT the size the workspace was first made for in other tests
+    klc = torch.tensor(0.2, device="cuda")
+    perm = torch.randperm(total, device="cuda")
+    a, b = ppo.NativeStep(pol_a, env, 128, splits=8), ppo.NativeStep(pol_b, env, 128, splits=8)
+    hp = (5e-5, (0.9, 0.999), 1e-8)
+    w0 = [p.detach().clone() for p in pol_a.parameters()]
+    p1 = perm.reshape(1, -1).contiguous()
+    for launch in range(6):
+        a.cursor.zero_()
+        for _ in range(60):
+            a.step(full, perm, 0.3, 10.0, 1.0, 0.01, klc, skip_reduce=True, use_cursor=True, adam=hp)
+        b.epochs(full, p1, 0.3, 10.0, 1.0, 0.01, klc, hp, steps=60)
+        torch.cuda.synchronize()
+        assert b.persistent_status()[0] == 0
+        assert int(b.adam_state[:8].view(torch.int64)[0]) == 60 * (launch + 1)
+        for (name, pa), pb, w in zip(pol_a.named_parameters(), pol_b.parameters(), w0):
+            r = _rel(pb.detach() - w, pa.detach() - w)
+            assert torch.isfinite(pb).all() and r < 5e-2, (launch, name, r)
+    env.close()
+
+
 def test_ppo_learner_update_persistent_equals_per_step_loop():
     """PPOLearner.update with the persistent learner (one dispatch per update) against the same learner driving q1env_learner_sgd_step
     per minibatch: same permutations (same generator), same statistics to 1e-3, same adaptive-KL decision."""
@@ -494,10 +525,10 @@ def test_ppo_learner_update_persistent_equals_per_step_loop():
     outs = []
     for pol, persistent in ((pol_a, False), (pol_b, True)):
         lr_ = ppo.PPOLearner(pol, cfg.action_range, lr=5e-6, num_sgd_iter=3, minibatch_size=128, env=env, native=True, persistent=persistent, seed=3)
-        outs.append(lr_.update(tr, adv, vt))
+        outs.append([lr_.update(tr, adv, vt) for _ in range(4)])          # four updates: the later ones start from the earlier ones' state
     torch.cuda.synchronize()
-    oa, ob = outs
-    assert oa["sgd_steps"] == ob["sgd_steps"] == 3 * 16 and oa["kl_coeff"] == ob["kl_coeff"]
-    for k in ("entropy", "kl", "policy_loss", "total_loss", "vf_loss"):
-        assert abs(oa[k] - ob[k]) <= 2e-3 * max(1.0, abs(oa[k])), (k, oa[k], ob[k])
+    for oa, ob in zip(*outs):
+        assert oa["sgd_steps"] == ob["sgd_steps"] == 3 * 16 and oa["kl_coeff"] == ob["kl_coeff"]
+        for k in ("entropy", "kl", "policy_loss", "total_loss", "vf_loss"):
+            assert abs(oa[k] - ob[k]) <= 2e-3 * max(1.0, abs(oa[k])), (k, oa[k], ob[k])
     env.close()

@@ -31,6 +31,7 @@ ap.add_argument("--entropy", type=float, default=0.003)
 ap.add_argument("--kl-target", type=float, default=0.01)
 ap.add_argument("--zero-start-prob", type=float, default=0.1)
 ap.add_argument("--seed", type=int, default=0)
+ap.add_argument("--time-limit", type=float, default=0.0, help="Config.time_limit in seconds (0 = the Config's own: 10 s = 720-tick episodes)")
 ap.add_argument("--out", default="")
 ap.add_argument("--no-graph", action="store_true")
 ap.add_argument("--fused-policy", action="store_true", help="sample with the fused MFMA forward kernel (bf16 hidden layer)")
@@ -47,6 +48,12 @@ ap.add_argument("--refcfg", action="store_true",
                      "kl_target 0.0036, entropy 0.01, gamma 0.99, lambda 0.95, vf_clip 100) and env_config (params.yml:16-33), RLlib 0.8.4 PPO defaults "
                      "for the rest (sgd_minibatch_size 128, num_sgd_iter 30, clip 0.3, kl_coeff 0.2), 4 workers x 100 envs = 400 envs x 125 ticks "
                      "per iteration; overrides --envs / --horizon / --lr / --epochs / --minibatch / --entropy / --kl-target / --zero-start-prob")
+ap.add_argument("--no-persistent", action="store_true", help="drive q1env_learner_sgd_step per minibatch instead of ONE q1env_learner_sgd_epochs dispatch per update (A/B)")
+ap.add_argument("--checkpoint-dir", default="", help="trainer checkpoints (policy weights, optimizer state incl. the native Adam moments + step count, adaptive KL "
+                                                      "coefficient, iteration, best metric): every --checkpoint-every iterations and whenever "
+                                                      "zero_start_total_reward_mean exceeds its previous best - the reference's schedule (q1physrl/train.py:110-133)")
+ap.add_argument("--checkpoint-every", type=int, default=100)
+ap.add_argument("--restore", default="", help="resume from a checkpoint written by --checkpoint-dir (the reference's params['checkpoint_fname'], train.py:110-111)")
 ap.add_argument("--log-every", type=int, default=5)
 ap.add_argument("--eval-every", type=int, default=0, help="every N iterations: 256 zero-start episodes of 720 ticks on a separate env, stochastic (the "
                                                          "training metric's policy) and deterministic; 0 = only at the end")
@@ -68,7 +75,7 @@ if args.refcfg:
     cfg = Config(num_envs=count, **bench.PARAMS_YML)           # data/params.yml:16-33
 else:
     cfg = Config(**{**Config.get_default().__dict__, "num_envs": count, "zero_start_prob": args.zero_start_prob,
-                    "discrete_yaw_steps": args.discrete_yaw_steps})
+                    "discrete_yaw_steps": args.discrete_yaw_steps, **({"time_limit": args.time_limit} if args.time_limit > 0 else {})})
 env = TensorVectorEnv(cfg, device=local, seed=args.seed + 1, env_index_base=start)
 pol = P.Q1Policy(discrete_yaw_steps=args.discrete_yaw_steps).cuda()
 fused = P.FusedPolicyForward(pol, env) if args.fused_policy else None
@@ -76,8 +83,34 @@ smp = GpuSampler(env, fused if fused is not None else pol, horizon=args.horizon,
 lrn = ppo.PPOLearner(pol, float(cfg.action_range), lr=args.lr, num_sgd_iter=args.epochs, minibatch_size=args.minibatch,
                      entropy_coeff=args.entropy, kl_target=args.kl_target, seed=args.seed + rank, use_graph=not args.no_graph, fused_loss=args.fused_loss, env=env,
                      discrete_yaw_steps=args.discrete_yaw_steps, autocast_dtype=torch.bfloat16 if args.learner_bf16 else None, fused_adam=not args.no_fused_adam,
-                     native=args.native, native_splits=args.native_splits)
+                     native=args.native, native_splits=args.native_splits, persistent=False if args.no_persistent else None)
 log = []
+start_iter, best_metric, best_file = 0, float("-inf"), None
+
+
+def save_checkpoint(it, tag):
+    """One file per checkpoint (torch.save): everything an exact resume needs."""
+    os.makedirs(args.checkpoint_dir, exist_ok=True)
+    fn = os.path.join(args.checkpoint_dir, f"checkpoint_{tag}.pt")
+    torch.save({"iter": it, "policy": pol.state_dict(), "learner": lrn.state_dict(), "best_metric": best_metric, "best_file": best_file,
+                "sampler_stats": smp.stats, "torch_rng": torch.get_rng_state(), "learner_gen": lrn.gen.get_state() if lrn.gen is not None else None,
+                "args": vars(args)}, fn + ".tmp")
+    os.replace(fn + ".tmp", fn)
+    return fn
+
+
+if args.restore:
+    ck = torch.load(args.restore, map_location="cuda", weights_only=False)
+    pol.load_state_dict(ck["policy"])
+    lrn.load_state_dict(ck["learner"])
+    if ck.get("learner_gen") is not None:
+        lrn.gen = torch.Generator(device="cuda").manual_seed(0)
+        lrn.gen.set_state(ck["learner_gen"].cpu())
+    start_iter, best_metric, best_file = int(ck["iter"]) + 1, float(ck["best_metric"]), ck.get("best_file")
+    if fused is not None:
+        fused.refresh()
+    if rank == 0:
+        print(json.dumps({"restored": args.restore, "resume_at_iter": start_iter, "best_metric": best_metric}), flush=True)
 
 
 def zero_start_eval(n_eval=256):
@@ -96,7 +129,7 @@ def zero_start_eval(n_eval=256):
 
 t0 = time.time()
 prev = smp.stats
-for it in range(args.iters):
+for it in range(start_iter, args.iters):
     ts = time.time()
     traj = smp.collect()
     adv, vtarg = smp.advantages(traj, lrn.gamma, lrn.lam)
@@ -117,6 +150,14 @@ for it in range(args.iters):
     row.update({k: st[k] for k in ("grad_saturated_pi", "grad_saturated_vf", "grad_max_abs_pi", "grad_max_abs_vf") if k in st})
     if args.eval_every and (it % args.eval_every == 0 or it == args.iters - 1):
         row.update(zero_start_eval())
+    if args.checkpoint_dir and rank == 0:
+        improved = zmean == zmean and zmean > best_metric                 # (NaN: no zero-start episode finished in this iteration)
+        if improved:
+            best_metric = zmean
+            best_file = save_checkpoint(it, "best")
+            row["checkpoint_best"] = best_file
+        if it % args.checkpoint_every == 0 or it == args.iters - 1:
+            row["checkpoint"] = save_checkpoint(it, f"{it:06d}")
     log.append(row)
     if rank == 0 and (it % args.log_every == 0 or it == args.iters - 1 or "eval_det" in row):
         print(json.dumps(row), flush=True)
