@@ -397,6 +397,14 @@ typedef struct q1env_learner_batch {
                                         * [1] = max of the float32 BITS of the largest |element| seen before the clamp; [2], [3] the same for the
                                         * value network */
 } q1env_learner_batch;
+/* (ABI v5) The float16 loss scales of every q1env_learner_* call made on this handle afterwards: per-sample gradients of the policy network
+ * travel multiplied by pi_upscale, those of the value network divided by value_downscale, and the sums are divided / multiplied back in
+ * float32 (csrc/q1learner.hpp "Gradient scaling") - exact for powers of two, which is all this accepts; 0 = the default (256 and 1, or
+ * Q1_LEARNER_PI_UPSCALE / Q1_LEARNER_VALUE_DOWNSCALE from the environment).  For a caller that adapts the scale to the gradient magnitudes
+ * q1env_learner_batch.saturation_dev reports (q1physrl_amd/ppo.py: chosen per update from the previous update's largest element, so that
+ * nothing saturates: RLlib has grad_clip = None, data/params.yml:2-13).  A q1env_learner_step / q1env_learner_adam pair must run under the
+ * same setting; a captured graph bakes the scales in. */
+int q1env_learner_set_loss_scale(q1env_t* env, float pi_upscale, float value_downscale);
 uint64_t q1env_learner_workspace_bytes(int64_t minibatch, int out_dim_pi, int splits);
 int q1env_learner_images(q1env_t* env, const q1env_learner_net* pi, const q1env_learner_net* vf, void* ws_dev, int64_t minibatch, int splits);
 int q1env_learner_forward(q1env_t* env, const q1env_learner_net* pi, const q1env_learner_net* vf, void* ws_dev, int64_t minibatch, int splits,

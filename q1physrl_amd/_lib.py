@@ -120,6 +120,7 @@ _SIGNATURES = {
     "q1env_learner_adam_state_bytes": (C.c_uint64, [C.c_int]),
     "q1env_learner_adam": (C.c_int, [_P, C.POINTER(Q1LearnerNet), C.POINTER(Q1LearnerNet), _P, C.c_int64, C.c_int] + [C.c_float] * 5 + [_P, _P]),
     "q1env_learner_sgd_step": (C.c_int, [_P, C.POINTER(Q1LearnerNet), C.POINTER(Q1LearnerNet), _P, C.c_int, C.POINTER(Q1LearnerBatch)] + [C.c_float] * 4 + [_P]),
+    "q1env_learner_set_loss_scale": (C.c_int, [_P, C.c_float, C.c_float]),
     "q1env_learner_persistent_bytes": (C.c_uint64, [C.c_int64]),
     "q1env_learner_sgd_epochs": (C.c_int, [_P, C.POINTER(Q1LearnerNet), C.POINTER(Q1LearnerNet), _P, C.POINTER(Q1LearnerBatch), C.c_int64, C.c_int64, C.c_int64, C.c_int64]
                                  + [C.c_float] * 4 + [_P, C.c_double]),

@@ -78,6 +78,7 @@ struct q1env {
     bool mlp_attr_set = false;        // dynamic-LDS attribute of the policy kernels (a per-device setting: kept per handle)
     bool learner_attr_set = false;    // ... and of the native learner's forward / backward kernels
     bool plearner_attr_set = false;   // ... and of the persistent learner (q1learner_persist.hpp)
+    float pi_upscale = 0.0f, value_downscale = 0.0f;   // the learner's float16 loss scales (q1env_learner_set_loss_scale; 0 = the defaults)
     // cached hipGraphs of step_many, keyed by (ticks, formats, pointers); a handful of entries, oldest evicted
     struct GraphEntry { std::vector<uint64_t> key; hipGraphExec_t exec; };
     std::vector<GraphEntry> graphs;

@@ -18,13 +18,13 @@ namespace {
 // normc_initializer(0.01)), so dZ2 = W3^T dY and dZ1 behind it sat at 1e-3 .. 1e-6, partly in float16's subnormal range, and one seed
 // of five plateaued at 5 230 instead of ~5 650 until the scale lifted them; value_downscale = 1 (B / 64 cost two of three seeds the
 // same way from the other side).  Outliers saturate (cvt8_sat).  Q1_LEARNER_PI_UPSCALE / Q1_LEARNER_VALUE_DOWNSCALE override (read once).
-static float learner_pi_upscale() {
+static float learner_pi_upscale(const q1env* h) {
     static const float v = [] { const char* e = getenv("Q1_LEARNER_PI_UPSCALE"); const float f = e ? (float)atof(e) : 256.0f; return f > 0.0f ? f : 256.0f; }();
-    return v;
+    return h->pi_upscale > 0.0f ? h->pi_upscale : v;             // (q1env_learner_set_loss_scale overrides the default / the environment)
 }
-static float learner_value_downscale() {
+static float learner_value_downscale(const q1env* h) {
     static const float v = [] { const char* e = getenv("Q1_LEARNER_VALUE_DOWNSCALE"); const float f = e ? (float)atof(e) : 1.0f; return f > 0.0f ? f : 1.0f; }();
-    return v;
+    return h->value_downscale > 0.0f ? h->value_downscale : v;
 }
 constexpr size_t IMG_FWD_BYTES = (q1pol::LDS_W2 + q1pol::LDS_W3);           // 152064: float16[288][264]
 constexpr size_t IMG_W2T_BYTES = q1learn::LDS_W2T;                          // 135168
@@ -145,6 +145,16 @@ int launch_backward(q1env* h, const Ws& w, int64_t mb, int splits, const q1env_l
 
 extern "C" {
 
+int q1env_learner_set_loss_scale(q1env_t* h, float pi_upscale, float value_downscale) {
+    if (!h) return fail(Q1ENV_ERR_INVALID_ARG, "q1env_learner_set_loss_scale: null handle");
+    auto pow2 = [](float x) { int e = 0; return x > 0.0f && frexpf(x, &e) == 0.5f; };
+    if ((pi_upscale != 0.0f && !pow2(pi_upscale)) || (value_downscale != 0.0f && !pow2(value_downscale)))
+        return fail(Q1ENV_ERR_INVALID_ARG, "q1env_learner_set_loss_scale: scales must be 0 (default) or exact powers of two");
+    h->pi_upscale = pi_upscale;
+    h->value_downscale = value_downscale;
+    return Q1ENV_OK;
+}
+
 uint64_t q1env_learner_workspace_bytes(int64_t minibatch, int out_dim_pi, int splits) {
     if (minibatch <= 0 || out_dim_pi < 1 || out_dim_pi > 32 || splits < 1 || splits > 512) return 0;
     return (uint64_t)carve_ws(nullptr, minibatch, out_dim_pi, splits).bytes;
@@ -201,9 +211,9 @@ int q1env_learner_step(q1env_t* h, const q1env_learner_net* pi, const q1env_lear
     const int64_t mb = b->minibatch;
     const Ws w = carve_ws(ws_dev, mb, pi->out_dim, splits);
     if (int r = launch_forward(h, w, mb, pi, vf, b->obs_dev, b->idx_dev, b->idx_cursor_dev, w.logits, w.value)) return r;
-    // per-sample (un-averaged) gradients x learner_pi_upscale() for the policy, / learner_value_downscale() (default 1) for the value
+    // per-sample (un-averaged) gradients x learner_pi_upscale(h) for the policy, / learner_value_downscale(h) (default 1) for the value
     // network: float16's normal range (q1learner.hpp)
-    const float scale = (float)mb * learner_pi_upscale(), scale_v = (float)mb / learner_value_downscale();
+    const float scale = (float)mb * learner_pi_upscale(h), scale_v = (float)mb / learner_value_downscale(h);
     if (b->idx_dev)
         hipLaunchKernelGGL(ppo_loss_grad_kernel<true>, grid_for((int)mb, 256), dim3(256), 0, h->stream, h->p, (int)mb, (const float*)w.logits,
                            b->old_logits_dev, pi->out_dim, b->old_stride, b->keys_dev, b->mouse_dev, b->logp_old_dev, b->adv_dev, (const float*)w.value,
@@ -265,7 +275,7 @@ int launch_adam(q1env_t* h, const q1env_learner_net* pi, const q1env_learner_net
                               q1learn::Grads{vf->gw1, vf->gb1, vf->gw2, vf->gb2, vf->gw3, vf->gb3, vf->out_dim}, m_vf, v_vf, w.net[1].w23, w.net[1].w2t, w.net[1].w3t};
     const unsigned elems = (unsigned)q1learn::PARTIAL_FLOATS;            // one thread per slot of the partial-sum slab, in the slab's order
     hipLaunchKernelGGL(q1learn::learner_adam_kernel, dim3((elems + 255u) / 256u, 2), dim3(256), 0, h->stream, (const float*)w.net[0].partial,
-                       (const float*)w.net[1].partial, na, nb, splits, 1.0f / (grad_scale * learner_pi_upscale()), learner_value_downscale() / grad_scale,
+                       (const float*)w.net[1].partial, na, nb, splits, 1.0f / (grad_scale * learner_pi_upscale(h)), learner_value_downscale(h) / grad_scale,
                        q1learn::AdamHyper{lr, beta1, beta2, eps}, (const float*)bc, tick);
     HIP_TRY(hipGetLastError());
     return Q1ENV_OK;
@@ -307,7 +317,7 @@ int q1env_learner_sgd_step(q1env_t* h, const q1env_learner_net* pi, const q1env_
     const int64_t mb = b->minibatch;
     const Ws w = carve_ws(ws_dev, mb, pi->out_dim, splits);
     if (int r = launch_forward(h, w, mb, pi, vf, b->obs_dev, b->idx_dev, b->idx_cursor_dev, w.logits, w.value)) return r;
-    const float scale = (float)mb * learner_pi_upscale(), scale_v = (float)mb / learner_value_downscale();
+    const float scale = (float)mb * learner_pi_upscale(h), scale_v = (float)mb / learner_value_downscale(h);
     q1learn::LossArgs la{};
     la.p = h->p;
     la.logits = w.logits; la.value = w.value; la.old_logits = b->old_logits_dev; la.old_stride = b->old_stride;

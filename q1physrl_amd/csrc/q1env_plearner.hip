@@ -12,13 +12,13 @@ using namespace q1;
 
 namespace {
 // the float16 loss scales of q1env_learner_step (q1env_learner.hip: same environment overrides, same defaults)
-static float learner_pi_upscale() {
+static float learner_pi_upscale(const q1env* h) {
     static const float v = [] { const char* e = getenv("Q1_LEARNER_PI_UPSCALE"); const float f = e ? (float)atof(e) : 256.0f; return f > 0.0f ? f : 256.0f; }();
-    return v;
+    return h->pi_upscale > 0.0f ? h->pi_upscale : v;             // (q1env_learner_set_loss_scale overrides the default / the environment)
 }
-static float learner_value_downscale() {
+static float learner_value_downscale(const q1env* h) {
     static const float v = [] { const char* e = getenv("Q1_LEARNER_VALUE_DOWNSCALE"); const float f = e ? (float)atof(e) : 1.0f; return f > 0.0f ? f : 1.0f; }();
-    return v;
+    return h->value_downscale > 0.0f ? h->value_downscale : v;
 }
 int check_nets(const char* who, const q1env_learner_net* pi, const q1env_learner_net* vf, bool need_grads) {
     for (const q1env_learner_net* m : {pi, vf}) {
@@ -33,7 +33,7 @@ int check_nets(const char* who, const q1env_learner_net* pi, const q1env_learner
 // ---- persistent learner (q1learner_persist.hpp): steps x { forward, loss gradient, backward, weight gradients, Adam } of 128-sample
 // minibatches as ONE dispatch of 2 x 8 co-operating workgroups
 namespace {
-struct PWs { uint16_t* h1x; uint16_t* h1tx; uint16_t* dz2x; uint16_t* w2tx; float* yp; float* w2st; uint32_t* bar; };
+struct PWs { uint16_t* h1x; uint16_t* h1tx; uint16_t* dz2x; uint16_t* w2tx; float* yp; float* w2st; float* b3x; uint32_t* bar; };
 size_t carve_pws(void* base, int64_t batch_rows, PWs out[2], uint32_t** status, float** mouse_u) {
     char* b = (char*)base;
     size_t off = 0;
@@ -43,6 +43,7 @@ size_t carve_pws(void* base, int64_t batch_rows, PWs out[2], uint32_t** status, 
     for (int k = 0; k < 2; ++k) {
         PWs w{};
         w.bar = (uint32_t*)take(256);
+        w.b3x = (float*)take(256);
         w.h1x = (uint16_t*)take((size_t)2 * q1pl::MB * q1pl::HID * 2);
         w.h1tx = (uint16_t*)take((size_t)2 * q1pl::MB * q1pl::HID * 2);
         w.dz2x = (uint16_t*)take((size_t)q1pl::MB * q1pl::HID * 2);
@@ -102,12 +103,12 @@ int q1env_learner_sgd_epochs(q1env_t* h, const q1env_learner_net* pi, const q1en
         n.w3 = const_cast<float*>(s->w3); n.b3 = const_cast<float*>(s->b3);
         n.gw1 = s->gw1; n.gb1 = s->gb1; n.gw2 = s->gw2; n.gb2 = s->gb2; n.gw3 = s->gw3; n.gb3 = s->gb3;
         n.m = m; n.v = v; n.out_dim = s->out_dim;
-        n.h1x = w.h1x; n.h1tx = w.h1tx; n.dz2x = w.dz2x; n.w2tx = w.w2tx; n.yp = w.yp; n.w2st = w.w2st; n.bar = w.bar;
+        n.h1x = w.h1x; n.h1tx = w.h1tx; n.dz2x = w.dz2x; n.w2tx = w.w2tx; n.yp = w.yp; n.w2st = w.w2st; n.b3x = w.b3x; n.bar = w.bar;
         n.inv_b = inv_b; n.inv_scale = inv_scale;
     };
     // the float16 loss scales of q1env_learner_step: per-sample gradients x pi_upscale (policy) / value_downscale (value)
-    fill(a.net[0], pi, m_pi, v_pi, pw[0], learner_pi_upscale(), 1.0f / (mbf * learner_pi_upscale()));
-    fill(a.net[1], vf, m_vf, v_vf, pw[1], 1.0f / learner_value_downscale(), learner_value_downscale() / mbf);
+    fill(a.net[0], pi, m_pi, v_pi, pw[0], learner_pi_upscale(h), 1.0f / (mbf * learner_pi_upscale(h)));
+    fill(a.net[1], vf, m_vf, v_vf, pw[1], 1.0f / learner_value_downscale(h), learner_value_downscale(h) / mbf);
     a.idx = b->idx_dev; a.spe = steps_per_epoch; a.epoch_stride = epoch_stride;
     a.obs = b->obs_dev; a.old_logits = b->old_logits_dev; a.old_stride = b->old_stride;
     a.keys = b->keys_dev; a.mouse_u = mouse_u; a.logp_old = b->logp_old_dev; a.adv = b->adv_dev; a.value_old = b->value_old_dev; a.vtarg = b->vtarg_dev;
@@ -119,11 +120,12 @@ int q1env_learner_sgd_epochs(q1env_t* h, const q1env_learner_net* pi, const q1en
     a.stats_acc = (float*)(st + 16);
     a.saturation = b->saturation_dev;
     a.status = status;
+    { const char* e = getenv("Q1_LEARNER_LOCAL"); a.allow_local = (e && e[0] == '0') ? 0 : 1; }
     a.prof = getenv("Q1_LEARNER_PROF") ? reinterpret_cast<unsigned long long*>(status + 4) + 1 : nullptr;      // (bytes 24.. of the status line)
     a.timeout_ticks = (uint64_t)((timeout_s > 0 ? timeout_s : 5.0) * (h->wall_clock_hz > 0 ? h->wall_clock_hz : 1e8));
     hipLaunchKernelGGL(q1pl::mouse_u_kernel, dim3((unsigned)((batch_rows + 255) / 256)), dim3(256), 0, h->stream, batch_rows, b->mouse_dev, -h->p.action_range_f32,
                        h->p.action_range_f32, mouse_u);
-    hipLaunchKernelGGL(q1pl::persistent_learner_kernel, dim3(2 * q1pl::G), dim3(256), q1pl::LDS_BYTES, h->stream, a);
+    hipLaunchKernelGGL(q1pl::persistent_learner_kernel, dim3(8 * q1pl::G), dim3(256), q1pl::LDS_BYTES, h->stream, a);
     HIP_TRY(hipGetLastError());
     return Q1ENV_OK;
 }

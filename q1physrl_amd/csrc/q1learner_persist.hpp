@@ -69,7 +69,7 @@ constexpr uint32_t L_W3T = L_W1 + 32 * LD_16;                // [32 u][16 o]   W
 constexpr uint32_t L_W3 = L_W3T + 32 * LD_16;                // [32 o][32 u]   W3[o][U]
 constexpr uint32_t L_H2W = L_W3 + 32 * LD_32;                // [4 waves][32 b][32 u]
 constexpr uint32_t L_FL = L_H2W + 4 * 32 * LD_32;            // floats: b2p[32] | red2[4][32] | red3[2][16] | stat[4][4] | bc[2] | flags
-constexpr uint32_t LDS_BYTES = L_FL + 2048;                  // 108 032
+constexpr uint32_t LDS_BYTES = L_FL + 4096;                  // 110 080
 
 struct Net {
     float* w1; float* b1; float* w2; float* b2; float* w3; float* b3;          // masters (torch layouts), updated in place
@@ -82,6 +82,7 @@ struct Net {
     uint16_t* dz2x;       // [128 b][256 k]
     uint16_t* w2tx;       // [256 j][256 k]: W2[k][j]
     float* yp;            // [G][128 b][16]
+    float* b3x;           // [16]: the output layer's bias as the group reads it (published by workgroup 0 after every step), zero padded
     float* w2st;          // [G][3 (master, m, v)][4 waves][32 slots][64 lanes]: the W2 slice's optimizer state in its OWNER LANE's order
     uint32_t* bar;        // arrival counter (own 256-byte line)
     float inv_b;          // d loss / d output travels multiplied by this (loss scale / 1: per-sample, not averaged)
@@ -102,13 +103,104 @@ struct Args {
     long long* step_count;     // adam_state + 0
     float* stats_acc;          // adam_state + 16: [entropy, kl, policy_loss, total (left to the host), vf_loss] running sums of per-step means
     uint32_t* saturation;      // optional uint32[4] (q1env_learner_batch.saturation_dev)
-    uint32_t* status;          // uint32[4]: [0] != 0: a barrier timed out (value = 1 + barrier index), [1] the step it happened in
+    uint32_t* status;          // uint32[4]: [0] != 0: a barrier timed out (value = 1 + barrier index), [1] the step it happened in,
+                               // [2], [3]: exchange mode of the policy / value group (1 + the XCD all its workgroups share, 0 = agent scope)
+    int allow_local;           // 0: always the agent-scope exchange mode (A/B)
     unsigned long long* prof;  // optional uint64[16] (the rest of the status line): 10-ns ticks workgroup (0, 0) spent per phase, summed over the steps
     uint64_t timeout_ticks;
 };
 
 __device__ __forceinline__ f16x8 lds16(const unsigned char* base, uint32_t off) { return *reinterpret_cast<const f16x8*>(base + off); }
 __device__ __forceinline__ f16x8 glb16(const uint16_t* p) { return *reinterpret_cast<const f16x8*>(p); }
+// Batched operand loads of EXCHANGED data.  loc = false: ordinary loads (the acquire behind the barrier - buffer_inv sc1 - has emptied the
+// caches of anything another XCD may have rewritten).  loc = true: DEVICE-scope loads (sc1: never served by the CU's vector cache, which
+// is not coherent with another CU's stores; served by the shared L2, where the producers' plain stores sit), all of a phase's requests and
+// their wait in ONE assembly block - the compiler's waitcnt bookkeeping does not see inline loads - so that no cache has to be
+// invalidated behind a local barrier at all (buffer_inv sc1 also empties this XCD's L2 of clean lines: the exchanged operands came back
+// from the memory side at ~2 us per phase, measured).
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+#define Q1PL_LD(i, off) "global_load_dwordx4 %" #i ", %[p], off offset:" #off " sc1\n\t"
+__device__ __forceinline__ void ld16(const uint16_t* p, f16x8 (&o)[16], bool loc) {                 // 16 vectors, 32 bytes apart
+    if (loc) {
+        asm volatile(Q1PL_LD(0, 0) Q1PL_LD(1, 32) Q1PL_LD(2, 64) Q1PL_LD(3, 96) Q1PL_LD(4, 128) Q1PL_LD(5, 160) Q1PL_LD(6, 192) Q1PL_LD(7, 224)
+                     Q1PL_LD(8, 256) Q1PL_LD(9, 288) Q1PL_LD(10, 320) Q1PL_LD(11, 352) Q1PL_LD(12, 384) Q1PL_LD(13, 416) Q1PL_LD(14, 448) Q1PL_LD(15, 480)
+                     "s_waitcnt vmcnt(0)"
+                     : "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3]), "=&v"(o[4]), "=&v"(o[5]), "=&v"(o[6]), "=&v"(o[7]), "=&v"(o[8]), "=&v"(o[9]),
+                       "=&v"(o[10]), "=&v"(o[11]), "=&v"(o[12]), "=&v"(o[13]), "=&v"(o[14]), "=&v"(o[15])
+                     : [p] "v"(p) : "memory");
+    } else {
+#pragma unroll
+        for (int s = 0; s < 16; ++s) o[s] = *reinterpret_cast<const f16x8*>(p + 16 * s);
+    }
+}
+__device__ __forceinline__ void ld8(const uint16_t* p, f16x8 (&o)[8], bool loc) {                   // 8 vectors, 32 bytes apart
+    if (loc) {
+        asm volatile(Q1PL_LD(0, 0) Q1PL_LD(1, 32) Q1PL_LD(2, 64) Q1PL_LD(3, 96) Q1PL_LD(4, 128) Q1PL_LD(5, 160) Q1PL_LD(6, 192) Q1PL_LD(7, 224)
+                     "s_waitcnt vmcnt(0)"
+                     : "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3]), "=&v"(o[4]), "=&v"(o[5]), "=&v"(o[6]), "=&v"(o[7]) : [p] "v"(p) : "memory");
+    } else {
+#pragma unroll
+        for (int s = 0; s < 8; ++s) o[s] = *reinterpret_cast<const f16x8*>(p + 16 * s);
+    }
+}
+__device__ __forceinline__ void ld8x2(const uint16_t* p, const uint16_t* q, f16x8 (&o)[8], f16x8 (&r)[8], bool loc) {   // two rows' 8 vectors each
+    if (loc) {
+        asm volatile(Q1PL_LD(0, 0) Q1PL_LD(1, 32) Q1PL_LD(2, 64) Q1PL_LD(3, 96) Q1PL_LD(4, 128) Q1PL_LD(5, 160) Q1PL_LD(6, 192) Q1PL_LD(7, 224)
+                     "global_load_dwordx4 %8, %[q], off sc1\n\tglobal_load_dwordx4 %9, %[q], off offset:32 sc1\n\t"
+                     "global_load_dwordx4 %10, %[q], off offset:64 sc1\n\tglobal_load_dwordx4 %11, %[q], off offset:96 sc1\n\t"
+                     "global_load_dwordx4 %12, %[q], off offset:128 sc1\n\tglobal_load_dwordx4 %13, %[q], off offset:160 sc1\n\t"
+                     "global_load_dwordx4 %14, %[q], off offset:192 sc1\n\tglobal_load_dwordx4 %15, %[q], off offset:224 sc1\n\t"
+                     "s_waitcnt vmcnt(0)"
+                     : "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3]), "=&v"(o[4]), "=&v"(o[5]), "=&v"(o[6]), "=&v"(o[7]),
+                       "=&v"(r[0]), "=&v"(r[1]), "=&v"(r[2]), "=&v"(r[3]), "=&v"(r[4]), "=&v"(r[5]), "=&v"(r[6]), "=&v"(r[7])
+                     : [p] "v"(p), [q] "v"(q) : "memory");
+    } else {
+#pragma unroll
+        for (int s = 0; s < 8; ++s) { o[s] = *reinterpret_cast<const f16x8*>(p + 16 * s); r[s] = *reinterpret_cast<const f16x8*>(q + 16 * s); }
+    }
+}
+// P2's requests: the 16 operand vectors of this wave's H1 rows + this thread's 4 chunks (128 bytes apart) of W2's column block
+__device__ __forceinline__ void ld16_4(const uint16_t* p, f16x8 (&o)[16], const uint16_t* q, f16x8 (&c)[4], bool loc) {
+    if (loc) {
+        asm volatile(Q1PL_LD(0, 0) Q1PL_LD(1, 32) Q1PL_LD(2, 64) Q1PL_LD(3, 96) Q1PL_LD(4, 128) Q1PL_LD(5, 160) Q1PL_LD(6, 192) Q1PL_LD(7, 224)
+                     Q1PL_LD(8, 256) Q1PL_LD(9, 288) Q1PL_LD(10, 320) Q1PL_LD(11, 352) Q1PL_LD(12, 384) Q1PL_LD(13, 416) Q1PL_LD(14, 448) Q1PL_LD(15, 480)
+                     "global_load_dwordx4 %16, %[q], off sc1\n\tglobal_load_dwordx4 %17, %[q], off offset:128 sc1\n\t"
+                     "global_load_dwordx4 %18, %[q], off offset:256 sc1\n\tglobal_load_dwordx4 %19, %[q], off offset:384 sc1\n\t"
+                     "s_waitcnt vmcnt(0)"
+                     : "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3]), "=&v"(o[4]), "=&v"(o[5]), "=&v"(o[6]), "=&v"(o[7]), "=&v"(o[8]), "=&v"(o[9]),
+                       "=&v"(o[10]), "=&v"(o[11]), "=&v"(o[12]), "=&v"(o[13]), "=&v"(o[14]), "=&v"(o[15]), "=&v"(c[0]), "=&v"(c[1]), "=&v"(c[2]), "=&v"(c[3])
+                     : [p] "v"(p), [q] "v"(q) : "memory");
+    } else {
+#pragma unroll
+        for (int s = 0; s < 16; ++s) o[s] = *reinterpret_cast<const f16x8*>(p + 16 * s);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) c[i] = *reinterpret_cast<const f16x8*>(q + 64 * i);
+    }
+}
+// the loss phase's requests: three float4 (12 outputs) of four partial-logit rows + the bias row
+__device__ __forceinline__ void ld_rows(const float* r0, const float* r1, const float* r2, const float* r3, const float* rb, f32x4 (&o)[5][3], bool loc) {
+    if (loc) {
+#define Q1PL_LR(i, reg) "global_load_dwordx4 %" #i ", %[" #reg "], off sc1\n\tglobal_load_dwordx4 %" #i "+1, %[" #reg "], off offset:16 sc1\n\t"
+        asm volatile("global_load_dwordx4 %0, %[a], off sc1\n\tglobal_load_dwordx4 %1, %[a], off offset:16 sc1\n\tglobal_load_dwordx4 %2, %[a], off offset:32 sc1\n\t"
+                     "global_load_dwordx4 %3, %[b], off sc1\n\tglobal_load_dwordx4 %4, %[b], off offset:16 sc1\n\tglobal_load_dwordx4 %5, %[b], off offset:32 sc1\n\t"
+                     "global_load_dwordx4 %6, %[c], off sc1\n\tglobal_load_dwordx4 %7, %[c], off offset:16 sc1\n\tglobal_load_dwordx4 %8, %[c], off offset:32 sc1\n\t"
+                     "global_load_dwordx4 %9, %[d], off sc1\n\tglobal_load_dwordx4 %10, %[d], off offset:16 sc1\n\tglobal_load_dwordx4 %11, %[d], off offset:32 sc1\n\t"
+                     "global_load_dwordx4 %12, %[e], off sc1\n\tglobal_load_dwordx4 %13, %[e], off offset:16 sc1\n\tglobal_load_dwordx4 %14, %[e], off offset:32 sc1\n\t"
+                     "s_waitcnt vmcnt(0)"
+                     : "=&v"(o[0][0]), "=&v"(o[0][1]), "=&v"(o[0][2]), "=&v"(o[1][0]), "=&v"(o[1][1]), "=&v"(o[1][2]), "=&v"(o[2][0]), "=&v"(o[2][1]), "=&v"(o[2][2]),
+                       "=&v"(o[3][0]), "=&v"(o[3][1]), "=&v"(o[3][2]), "=&v"(o[4][0]), "=&v"(o[4][1]), "=&v"(o[4][2])
+                     : [a] "v"(r0), [b] "v"(r1), [c] "v"(r2), [d] "v"(r3), [e] "v"(rb) : "memory");
+#undef Q1PL_LR
+    } else {
+        const float* rr[5] = {r0, r1, r2, r3, rb};
+#pragma unroll
+        for (int q = 0; q < 5; ++q)
+#pragma unroll
+            for (int v = 0; v < 3; ++v) o[q][v] = *reinterpret_cast<const f32x4*>(rr[q] + 4 * v);
+    }
+}
+#undef Q1PL_LD
+
 __device__ __forceinline__ f32x16 mm(f16x8 a, f16x8 b, f32x16 acc) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc, 0, 0, 0); }
 __device__ __forceinline__ uint32_t rrow(int r, uint32_t h) { return (uint32_t)(r & 3) + 8u * (uint32_t)(r >> 2) + 4u * h; }
 
@@ -126,13 +218,35 @@ __device__ __forceinline__ float sat16(float x, float& amax, uint32_t& nsat) {
 }
 __device__ __forceinline__ float r16(float x) { return (float)(_Float16)x; }                       // the value the float16 operand carries
 __device__ __forceinline__ float act(float z) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(z) + 1.0f); }   // tanh, z prescaled by 2 log2 e
-__device__ __forceinline__ void pub8(uint16_t* p, uint64_t v) {                                     // 8 bytes, write-through at agent scope
-    __hip_atomic_store(reinterpret_cast<uint64_t*>(p), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+// Two exchange modes (wave-uniform `loc`, decided once per launch - see "placement" in the kernel):
+//   loc = false  the group's workgroups may sit on different XCDs: agent-scope write-through stores (sc1), tickets and polls at agent scope
+//                (executed at the memory side), acquire = buffer_inv sc1 - what the language's memory model offers.
+//   loc = true   all workgroups of the group were found on ONE XCD, whose L2 is then the point of coherence: plain stores (the CU's
+//                vector cache is write-through, so an acknowledged store IS in that L2, where it stays dirty - an invalidation does not
+//                drop dirty lines), tickets AND polls as read-modify-write atomics without a scope bit (performed in that L2: a poll is
+//                an atomic add of zero, so that it reads exactly where the tickets are counted - a load, whatever its scope bits, might be
+//                served by the CU's vector cache or sent past the L2), acquire = buffer_inv sc1 (empties the CU's vector cache; the first
+//                version used the sc0 forms of poll and invalidate, which only by-pass the vector cache in threadgroup-split mode: it
+//                dead-locked after ~50 steps on a stale counter line).  Nothing travels to the memory side: a barrier is cheaper and the
+//                exchanged operands come from L2, not HBM / MALL.
+__device__ __forceinline__ void pub8(uint16_t* p, uint64_t v, bool loc) {
+    if (loc) *reinterpret_cast<uint64_t*>(p) = v;
+    else __hip_atomic_store(reinterpret_cast<uint64_t*>(p), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-__device__ __forceinline__ void pub8f(float* p, float a, float b) {
+__device__ __forceinline__ void pub8f(float* p, float a, float b, bool loc) {
     union { float f[2]; uint64_t u; } o;
     o.f[0] = a; o.f[1] = b;
-    __hip_atomic_store(reinterpret_cast<uint64_t*>(p), o.u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (loc) *reinterpret_cast<uint64_t*>(p) = o.u;
+    else __hip_atomic_store(reinterpret_cast<uint64_t*>(p), o.u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void pub4f(float* p, float a, bool loc) {
+    if (loc) *p = a;
+    else __hip_atomic_store(p, a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ uint32_t xcc_id() {                     // which XCD this wave runs on (gfx940+: hardware register XCC_ID, bits 3:0)
+    uint32_t v;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v));
+    return v & 0xFu;
 }
 
 // torch.optim.Adam's update (q1learner.hpp adam_update) with the hardware's 1-ulp square root and reciprocal (v_sqrt_f32, v_rcp_f32) in
@@ -141,24 +255,48 @@ __device__ __forceinline__ void pub8f(float* p, float a, float b) {
 // rs_bc2 = 1 / sqrt(bias_correction2), lr_bc1 = lr / bias_correction1 (per step, not per element).
 __device__ __forceinline__ float adam1(float w, float g, float& m, float& v, float b1, float b2, float eps, float lr_bc1, float rs_bc2) {
     m = m + (g - m) * (1.0f - b1);
-    v = v * b2 + (1.0f - b2) * g * g;
+    v = v * b2 + ((1.0f - b2) * g) * g;
     const float denom = __builtin_amdgcn_sqrtf(v) * rs_bc2 + eps;
     return w - lr_bc1 * (m * __builtin_amdgcn_rcpf(denom));
 }
 
-// arrive: this workgroup's published stores are at the memory side; one ticket
-__device__ __forceinline__ void bar_arrive(uint32_t* ctr) {
+// two elements at a time: the same operations in the same order (packed float32 multiply / add; square root and reciprocal per element)
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 adam2(f32x2 w, f32x2 g, f32x2& m, f32x2& v, float b1, float b2, float eps, float lr_bc1, float rs_bc2) {
+    m = m + (g - m) * (1.0f - b1);
+    v = v * b2 + ((1.0f - b2) * g) * g;
+    const f32x2 sq = {__builtin_amdgcn_sqrtf(v.x), __builtin_amdgcn_sqrtf(v.y)};
+    const f32x2 denom = sq * rs_bc2 + eps;
+    const f32x2 rc = {__builtin_amdgcn_rcpf(denom.x), __builtin_amdgcn_rcpf(denom.y)};
+    return w - lr_bc1 * (m * rc);
+}
+
+// arrive: this workgroup's published stores have been acknowledged (by the memory side / by the XCD's L2); one ticket
+__device__ __forceinline__ void bar_arrive(uint32_t* ctr, bool loc) {
     __builtin_amdgcn_s_waitcnt(0);
     __syncthreads();
-    if (threadIdx.x == 0) __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (threadIdx.x == 0) {
+        if (loc) { const uint32_t one = 1u; asm volatile("global_atomic_add %0, %1, off" :: "v"(ctr), "v"(one) : "memory"); }   // (no scope bits: performed in the L2)
+        else __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+__device__ __forceinline__ uint32_t poll(uint32_t* ctr, bool loc) {
+    if (loc) {
+        uint32_t v;
+        const uint32_t zero = 0u;
+        asm volatile("global_atomic_add %0, %1, %2, off sc0\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(ctr), "v"(zero) : "memory");   // returns the counter as the L2 holds it
+        return v;
+    }
+    return __hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 // wait until `target` tickets have been drawn; false (for every thread) on timeout / abort
-__device__ __forceinline__ bool bar_wait(uint32_t* ctr, uint32_t target, uint32_t* status, uint32_t which, uint32_t step, uint64_t timeout_ticks, int* s_ok) {
+__device__ __forceinline__ bool bar_wait(uint32_t* ctr, uint32_t target, bool loc, uint32_t* status, uint32_t which, uint32_t step, uint64_t timeout_ticks,
+                                         int* s_ok) {
     if (threadIdx.x == 0) {
         int ok = 1;
         uint64_t t0 = 0;
         uint32_t spins = 0;
-        while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+        while (poll(ctr, loc) < target) {
             __builtin_amdgcn_s_sleep(1);
             if ((++spins & 1023u) == 0u) {
                 const uint64_t now = wall_clock64();
@@ -177,7 +315,7 @@ __device__ __forceinline__ bool bar_wait(uint32_t* ctr, uint32_t target, uint32_
     }
     __syncthreads();
     const bool ok = *s_ok != 0;
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    if (!loc) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // buffer_inv sc1; the local mode reads exchanged data with device-scope loads instead (ld16 ...)
     return ok;
 }
 
@@ -190,19 +328,24 @@ mouse_u_kernel(int64_t rows, const float* __restrict__ mouse, float low, float h
     if (i < rows) u[i] = SQUASH_SCALE * normcdfinvf((mouse[i] - low) / (high - low));
 }
 
-__global__ void __launch_bounds__(256, 1)
-persistent_learner_kernel(Args a) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+// NI = 0: a workgroup of the policy group (10 outputs, the PPO policy loss), NI = 1: of the value group (1 output, the value loss): two
+// straight-line specialisations instead of run-time tests on the output count and the network in every loop over the outputs.
+template <int NI>
+__device__ __forceinline__ void persistent_learner_body(const Args& a, unsigned char* lds) {
     const uint32_t tid = threadIdx.x, lane = tid & 63u, w = tid >> 6, c = lane & 31u, h = lane >> 5;
-    const uint32_t ni = blockIdx.x / (uint32_t)G, g = blockIdx.x % (uint32_t)G;
-    const Net net = ni ? a.net[1] : a.net[0];          // (a select on the kernel arguments: no dynamic indexing)
-    const int OUT = net.out_dim;
+    // Placement.  The dispatcher deals workgroups to the eight XCDs round-robin by workgroup id, so of the 64 launched only those with
+    // id % 8 == 0 (policy group) and id % 8 == 1 (value group) take part, g = id / 8: each group's eight workgroups then share an XCD and
+    // its L2.  That is a property of today's dispatcher, not a promise: every workgroup publishes the XCD it actually runs on, and only if
+    // all eight of a group agree does the group use the L2-local exchange mode (loc); otherwise the agent-scope mode, correct anywhere.
+    constexpr uint32_t ni = (uint32_t)NI;
+    const uint32_t g = blockIdx.x >> 3;
+    const Net net = a.net[NI];
+    constexpr int OUT = NI == 0 ? 10 : 1;
     float* const fl = reinterpret_cast<float*>(lds + L_FL);
     float* const b2p = fl;                 // [32]
     float* const red2 = fl + 32;           // [4][32]
-    float* const stat = fl + 192;          // [4 waves][4]
     int* const s_ok = reinterpret_cast<int*>(fl + 212);
-    float* const red3 = fl + 224;          // [4][16]
+    float* const statbuf = fl + 288;       // [3][128]: the per-sample statistics of a step (summed off the critical path)
     const f32x16 zero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     const float c2 = TANH_PRESCALE;
     const uint32_t U0 = 32u * g;
@@ -252,6 +395,19 @@ persistent_learner_kernel(Args a) {
         }
     }
     if (tid < MB) *reinterpret_cast<_Float16*>(lds + L_XT + 6u * LD_B + 2u * tid) = (_Float16)1.0f;    // the ones row of [x | 1]^T
+    if (g == 0 && tid < 16u) __hip_atomic_store(net.b3x + tid, (int)tid < OUT ? net.b3[tid] : 0.0f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // one agent-scope barrier (its own counter) behind the prologue's publications: also carries the XCD census
+    bool loc = false;
+    {
+        if (tid == 0) __hip_atomic_store(net.bar + 16 + g, xcc_id() + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        bar_arrive(net.bar + 8, false);
+        if (!bar_wait(net.bar + 8, (uint32_t)G, false, a.status, 3u, 0u, a.timeout_ticks, s_ok)) return;
+        uint32_t same = 1u;
+        const uint32_t mine = __hip_atomic_load(net.bar + 16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (uint32_t k = 1; k < (uint32_t)G; ++k) same &= __hip_atomic_load(net.bar + 16 + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == mine ? 1u : 0u;
+        loc = a.allow_local != 0 && same != 0u && mine != 0u;
+        if (tid == 0 && g == 0) a.status[2 + ni] = loc ? mine : 0u;          // reported: 1 + the XCD the group shares, or 0 = agent-scope mode
+    }
     const float klc = *a.klc_dev;
     const long long step0 = *a.step_count;
     double pw1 = pow((double)a.beta1, (double)step0), pw2 = pow((double)a.beta2, (double)step0);
@@ -268,8 +424,8 @@ persistent_learner_kernel(Args a) {
     int64_t srcX = row_at(0, tid & (MB - 1)), srcL = row_at(0, bsm);
     __syncthreads();
 
-    const bool profiling = a.prof != nullptr && blockIdx.x == 0 && tid == 0;
-    unsigned long long pacc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    const bool profiling = a.prof != nullptr && blockIdx.x == 0 && tid == 0;      // (workgroup 0 = policy group, g = 0)
+    unsigned long long pacc[14] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     uint64_t tprev = profiling ? wall_clock64() : 0;
 #define Q1PL_STAMP(k) do { if (profiling) { const uint64_t now_ = wall_clock64(); pacc[k] += now_ - tprev; tprev = now_; } } while (0)
     for (int64_t step = 0; step < a.steps; ++step) {
@@ -316,45 +472,44 @@ persistent_learner_kernel(Args a) {
             const f32x16 dB = mm(x1, a1, zero16);               // [b][u]: lane = unit, registers = samples
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                pub8(h1x + (size_t)(32u * w + c) * HID + U0 + 8u * q + 4u * h, pack4(act(dA[4 * q]), act(dA[4 * q + 1]), act(dA[4 * q + 2]), act(dA[4 * q + 3])));
+                pub8(h1x + (size_t)(32u * w + c) * HID + U0 + 8u * q + 4u * h, pack4(act(dA[4 * q]), act(dA[4 * q + 1]), act(dA[4 * q + 2]), act(dA[4 * q + 3])), loc);
                 float t4[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) { t4[j] = act(dB[4 * q + j]); h1B[4 * q + j] = r16(t4[j]); }
-                pub8(h1tx + (size_t)(U0 + c) * MB + 32u * w + 8u * q + 4u * h, pack4(t4[0], t4[1], t4[2], t4[3]));
+                pub8(h1tx + (size_t)(U0 + c) * MB + 32u * w + 8u * q + 4u * h, pack4(t4[0], t4[1], t4[2], t4[3]), loc);
             }
         }
         Q1PL_STAMP(0);                                          // minibatch rows + P1 + publish
-        bar_arrive(net.bar);
+        bar_arrive(net.bar, loc);
         const int64_t srcL_now = srcL;
         // the NEXT step's row indices, requested while the barrier is in flight
         if (!last) {
             if (++in_epoch == a.spe) { in_epoch = 0; win += a.epoch_stride - (a.spe - 1) * MB; } else { win += MB; }
             srcX = row_at(win, tid & (MB - 1)); srcL = row_at(win, bsm);
         }
-        if (!bar_wait(net.bar, (uint32_t)G * ++bar_n, a.status, 0u, (uint32_t)step, a.timeout_ticks, s_ok)) return;
+        if (!bar_wait(net.bar, (uint32_t)G * ++bar_n, loc, a.status, 0u, (uint32_t)step, a.timeout_ticks, s_ok)) return;
         Q1PL_STAMP(1);                                          // barrier 1
 
         // ------------------------------------------------------------ W2's column block (rows j in U of W2^T), then P2 + the partial logits
         float h2A[16], h2B[16];
-        const size_t sl = (size_t)srcL_now;
-        // the loss's per-sample inputs (not needed before barrier 2), requested with this phase's operands: policy group: keys, logp_old,
-        // adv, old logits row;  value group: value_old, vtarg (in the same registers)
-        const uint32_t in_kb = ni == 0 ? (uint32_t)a.keys[sl] : 0u;
-        const float in_a = ni == 0 ? a.mouse_u[sl] : a.value_old[sl];   // (policy group: the mouse action's pre-image u, mouse_u_kernel)
-        const float in_b = ni == 0 ? a.logp_old[sl] : a.vtarg[sl];
-        const float in_c = ni == 0 ? a.adv[sl] : 0.0f;
+        // the loss's per-sample inputs (not needed before barrier 2) are requested BEHIND this phase's operands (the memory counter retires
+        // in order: requested first, their HBM latency would sit in front of the first matrix product): policy group: keys, logp_old, adv,
+        // the mouse pre-image, the old logits row;  value group: value_old, vtarg (in the same registers)
+        uint32_t in_kb = 0u;
+        float in_a = 0.0f, in_b = 0.0f, in_c = 0.0f;
         float oldrow[10];
-#pragma unroll
-        for (int o = 0; o < 10; ++o) oldrow[o] = ni == 0 ? a.old_logits[sl * (size_t)a.old_stride + (size_t)o] : 0.0f;
         {
             // every global operand of this phase is requested first: H1 rows of this wave's tile (16 K-steps) and the column block
             f16x8 bH[16], wc[4];
-            const uint16_t* hrow = h1x + (size_t)(32u * w + c) * HID + 8u * h;
-#pragma unroll
-            for (int s = 0; s < 16; ++s) bH[s] = glb16(hrow + 16 * s);
             const uint32_t jg = tid >> 3, ch = tid & 7u;
+            ld16_4(h1x + (size_t)(32u * w + c) * HID + 8u * h, bH, net.w2tx + (size_t)(U0 + jg) * HID + 8u * ch, wc, loc);
+            {
+                const size_t sl = (size_t)srcL_now;
+                if (ni == 0) { in_kb = (uint32_t)a.keys[sl]; in_a = a.mouse_u[sl]; in_b = a.logp_old[sl]; in_c = a.adv[sl]; }
+                else { in_a = a.value_old[sl]; in_b = a.vtarg[sl]; }
 #pragma unroll
-            for (int i = 0; i < 4; ++i) wc[i] = glb16(net.w2tx + (size_t)(U0 + jg) * HID + 8u * (ch + 8u * (uint32_t)i));
+                for (int o = 0; o < 10; ++o) oldrow[o] = ni == 0 ? a.old_logits[sl * (size_t)a.old_stride + (size_t)o] : 0.0f;
+            }
             f32x16 accA = zero16, accB = zero16;
 #pragma unroll
             for (int s = 0; s < 16; ++s) {
@@ -386,12 +541,12 @@ persistent_learner_kernel(Args a) {
             for (int s = 0; s < 2; ++s)
                 accY = mm(lds16(lds, L_W3 + c * LD_32 + 32u * (uint32_t)s + 16u * h), lds16(lds, L_H2W + w * 32u * LD_32 + c * LD_32 + 32u * (uint32_t)s + 16u * h), accY);
             float* yrow = net.yp + ((size_t)g * MB + 32u * w + c) * 16u;
-            pub8f(yrow + 4u * h, accY[0], accY[1]); pub8f(yrow + 4u * h + 2u, accY[2], accY[3]);          // outputs 4 h .. 4 h + 3
-            pub8f(yrow + 8u + 4u * h, accY[4], accY[5]); pub8f(yrow + 10u + 4u * h, accY[6], accY[7]);    // outputs 8 + 4 h ..
+            pub8f(yrow + 4u * h, accY[0], accY[1], loc); pub8f(yrow + 4u * h + 2u, accY[2], accY[3], loc);          // outputs 4 h .. 4 h + 3
+            pub8f(yrow + 8u + 4u * h, accY[4], accY[5], loc); pub8f(yrow + 10u + 4u * h, accY[6], accY[7], loc);    // outputs 8 + 4 h ..
         }
         Q1PL_STAMP(2);                                          // W2 column gather + P2 + partial logits
-        bar_arrive(net.bar);
-        if (!bar_wait(net.bar, (uint32_t)G * ++bar_n, a.status, 1u, (uint32_t)step, a.timeout_ticks, s_ok)) return;
+        bar_arrive(net.bar, loc);
+        if (!bar_wait(net.bar, (uint32_t)G * ++bar_n, loc, a.status, 1u, (uint32_t)step, a.timeout_ticks, s_ok)) return;
         Q1PL_STAMP(3);                                          // barrier 2
 
         // ------------------------------------------------------------ outputs, loss gradient: two lanes per sample (lanes l and l ^ 32 of
@@ -403,31 +558,22 @@ persistent_learner_kernel(Args a) {
         {
             float y[12];
             {
-                float4 part[4][3];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const float4* row = reinterpret_cast<const float4*>(net.yp + ((size_t)(4u * h + (uint32_t)q) * MB + bsm) * 16u);
-                    part[q][0] = row[0];
-                    if (OUT > 4) { part[q][1] = row[1]; part[q][2] = row[2]; } else { part[q][1] = float4{0, 0, 0, 0}; part[q][2] = float4{0, 0, 0, 0}; }
-                }
-                float b3v[12];
-#pragma unroll
-                for (int o = 0; o < 12; ++o) b3v[o] = o < OUT ? net.b3[o] : 0.0f;
+                f32x4 part[5][3];                               // four partial rows (groups 4 h .. 4 h + 3) + the bias row
+                const float* yb = net.yp + ((size_t)(4u * h) * MB + bsm) * 16u;
+                ld_rows(yb, yb + (size_t)MB * 16, yb + (size_t)2 * MB * 16, yb + (size_t)3 * MB * 16, net.b3x, part, loc);
                 float half_[12];
 #pragma unroll
-                for (int v = 0; v < 3; ++v) {
-                    half_[4 * v + 0] = ((part[0][v].x + part[1][v].x) + part[2][v].x) + part[3][v].x;
-                    half_[4 * v + 1] = ((part[0][v].y + part[1][v].y) + part[2][v].y) + part[3][v].y;
-                    half_[4 * v + 2] = ((part[0][v].z + part[1][v].z) + part[2][v].z) + part[3][v].z;
-                    half_[4 * v + 3] = ((part[0][v].w + part[1][v].w) + part[2][v].w) + part[3][v].w;
-                }
+                for (int v = 0; v < 3; ++v)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) half_[4 * v + e] = ((part[0][v][e] + part[1][v][e]) + part[2][v][e]) + part[3][v][e];
 #pragma unroll
                 for (int o = 0; o < 12; ++o) {
                     const float other = __shfl_xor(half_[o], 32, 64);
                     const float lo_ = h ? other : half_[o], hi_ = h ? half_[o] : other;      // (groups 0..3) + (groups 4..7): the same operand order in both lanes
-                    y[o] = b3v[o] + (lo_ + hi_);
+                    y[o] = part[4][o >> 2][o & 3] + (lo_ + hi_);
                 }
             }
+            Q1PL_STAMP(10);                                     // (loss: the outputs summed)
 #pragma unroll
             for (int o = 0; o < 10; ++o) gl[o] = 0.0f;
             if (ni == 0) {
@@ -440,6 +586,7 @@ persistent_learner_kernel(Args a) {
                 gl[0] = a.vf_coeff * dvf * net.inv_b;
                 s3[0] = vf;
             }
+            Q1PL_STAMP(11);                                     // (loss: differentiated)
             _Float16 row16[16];
 #pragma unroll
             for (int o = 0; o < 16; ++o) row16[o] = (_Float16)0.0f;
@@ -458,28 +605,11 @@ persistent_learner_kernel(Args a) {
                 s3[0] = 0.0f; s3[1] = 0.0f; s3[2] = 0.0f;
             }
         }
-        // sums over the samples: db3 (float16-rounded rows) and the statistics, wave by wave, then in wave order
-#pragma unroll
-        for (int o = 0; o < 10; ++o) {
-            if (o < OUT) {
-                float v = gl[o];
-#pragma unroll
-                for (int off = 16; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-                if (lane == 0) red3[w * 16u + (uint32_t)o] = v;
-            }
-        }
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            float v = s3[k];
-#pragma unroll
-            for (int off = 16; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-            if (lane == 0) stat[w * 4u + (uint32_t)k] = v;
-        }
+        Q1PL_STAMP(12);                                         // (loss: rows converted + stored)
+        // the sums over the samples (db3, the three statistics) are NOT formed here: db3 is a column of one more matrix product (dY^T times
+        // the ones row of [x | 1]^T) and the statistics are summed from LDS, both by workgroup 0's otherwise idle wave 3 during G2
+        if (!h) { statbuf[bsm] = s3[0]; statbuf[MB + bsm] = s3[1]; statbuf[2 * MB + bsm] = s3[2]; }
         __syncthreads();
-        if (tid == 0 && g == 0) {
-#pragma unroll
-            for (int k = 0; k < 3; ++k) st_acc[k] += (((stat[k] + stat[4 + k]) + stat[8 + k]) + stat[12 + k]) * (1.0f / (float)MB);
-        }
         Q1PL_STAMP(4);                                          // outputs + loss gradient + sums
 
         // ------------------------------------------------------------ B3: dZ2 of the owned units, both orientations
@@ -498,13 +628,13 @@ persistent_learner_kernel(Args a) {
                     zB[j] = sat16(dB[4 * q + j] * (1.0f - h2B[4 * q + j] * h2B[4 * q + j]), amax, nsat);
                     sb += r16(zB[j]);
                 }
-                pub8(net.dz2x + (size_t)(32u * w + c) * HID + U0 + 8u * q + 4u * h, pack4(zA[0], zA[1], zA[2], zA[3]));
+                pub8(net.dz2x + (size_t)(32u * w + c) * HID + U0 + 8u * q + 4u * h, pack4(zA[0], zA[1], zA[2], zA[3]), loc);
                 *reinterpret_cast<uint64_t*>(lds + L_DZ2T + c * LD_B + 2u * (32u * w + 8u * q + 4u * h)) = pack4(zB[0], zB[1], zB[2], zB[3]);
             }
             sb += __shfl_xor(sb, 32, 64);
             if (h == 0) red2[w * 32u + c] = sb;
         }
-        bar_arrive(net.bar);                                    // (its workgroup barrier also orders dZ2T / H2T / dYT / red2 for the products below)
+        bar_arrive(net.bar, loc);                                    // (its workgroup barrier also orders dZ2T / H2T / dYT / red2 for the products below)
         Q1PL_STAMP(5);                                          // B3 + arrive 3
 
         // ------------------------------------------------------------ G2: dW2 rows U (two 32-input tiles per wave) + Adam + new images
@@ -513,29 +643,32 @@ persistent_learner_kernel(Args a) {
         // products and stored after all of it has been used: every access of one kind is issued together (the compiler must assume that
         // a store may alias a later load of another array, and would otherwise serialise 32 round trips to L2 per step).
 #pragma unroll 1
-        for (int t = 0; t < 2; ++t) {                           // one 32-input tile at a time (half the registers; the second tile's loads follow the first one's stores)
+        for (int t = 0; t < 2; ++t) {                           // one 32-input tile at a time (both at once - one round of requests - was measured: the
+                                                                // 96 + 64 live registers spill inside the loop, 20.4 -> 23.0 us per step)
             const uint32_t k = 64u * w + 32u * (uint32_t)t + c;
             float w2v[16], m2v[16], v2v[16];
             f16x8 hT[8];
-            const uint16_t* r0 = h1tx + (size_t)k * MB + 8u * h;
-#pragma unroll
-            for (int s = 0; s < 8; ++s) hT[s] = glb16(r0 + 16 * s);
 #pragma unroll
             for (int r = 0; r < 16; ++r) { w2v[r] = st_w[64 * (16 * t + r)]; m2v[r] = st_m[64 * (16 * t + r)]; v2v[r] = st_v[64 * (16 * t + r)]; }
+            ld8(h1tx + (size_t)k * MB + 8u * h, hT, loc);       // (behind the state requests: its wait covers them too - one round trip)
             f32x16 acc = zero16;                                // [u][k]: lane = input k, registers = owned units
 #pragma unroll
             for (int s = 0; s < 8; ++s) acc = mm(lds16(lds, L_DZ2T + c * LD_B + 32u * (uint32_t)s + 16u * h), hT[s], acc);
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
+                for (int j = 0; j < 4; j += 2) {
                     const int r = 4 * q + j;
-                    const float gr = acc[r] * net.inv_scale;
-                    w2v[r] = adam1(w2v[r], gr, m2v[r], v2v[r], a.beta1, a.beta2, a.eps, lr_bc1, rs_bc2);
-                    *reinterpret_cast<_Float16*>(lds + L_W2OWN + rrow(r, h) * LD_W + 2u * k) = (_Float16)(c2 * w2v[r]);
-                    if (last) net.gw2[(size_t)(U0 + rrow(r, h)) * HID + k] = gr;
+                    const f32x2 gr = f32x2{acc[r], acc[r + 1]} * net.inv_scale;
+                    f32x2 mm2 = {m2v[r], m2v[r + 1]}, vv2 = {v2v[r], v2v[r + 1]};
+                    const f32x2 wn = adam2(f32x2{w2v[r], w2v[r + 1]}, gr, mm2, vv2, a.beta1, a.beta2, a.eps, lr_bc1, rs_bc2);
+                    w2v[r] = wn.x; w2v[r + 1] = wn.y; m2v[r] = mm2.x; m2v[r + 1] = mm2.y; v2v[r] = vv2.x; v2v[r + 1] = vv2.y;
+                    const f32x2 wi = c2 * wn;
+                    *reinterpret_cast<_Float16*>(lds + L_W2OWN + rrow(r, h) * LD_W + 2u * k) = (_Float16)wi.x;
+                    *reinterpret_cast<_Float16*>(lds + L_W2OWN + rrow(r + 1, h) * LD_W + 2u * k) = (_Float16)wi.y;
+                    if (last) { net.gw2[(size_t)(U0 + rrow(r, h)) * HID + k] = gr.x; net.gw2[(size_t)(U0 + rrow(r + 1, h)) * HID + k] = gr.y; }
                 }
-                pub8(net.w2tx + (size_t)k * HID + U0 + 8u * q + 4u * h, pack4(w2v[4 * q], w2v[4 * q + 1], w2v[4 * q + 2], w2v[4 * q + 3]));
+                pub8(net.w2tx + (size_t)k * HID + U0 + 8u * q + 4u * h, pack4(w2v[4 * q], w2v[4 * q + 1], w2v[4 * q + 2], w2v[4 * q + 3]), loc);
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) { st_w[64 * (16 * t + r)] = w2v[r]; st_m[64 * (16 * t + r)] = m2v[r]; st_v[64 * (16 * t + r)] = v2v[r]; }
@@ -578,16 +711,29 @@ persistent_learner_kernel(Args a) {
             net.b2[u] = b2v; net.m[E_B2 + u] = mv; net.v[E_B2 + u] = vv;
             if (last) net.gb2[u] = gr;
         }
+        f32x16 acc_b3 = zero16;                                 // [o][i']: lane (c = 6, h) holds db3[o = row(r, h)] (times the loss scale)
+        if (g == 0 && w == 3u) {
+#pragma unroll
+            for (int s = 0; s < 8; ++s)
+                acc_b3 = mm(lds16(lds, L_DYT + c * LD_B + 32u * (uint32_t)s + 16u * h), lds16(lds, L_XT + c * LD_B + 32u * (uint32_t)s + 16u * h), acc_b3);
+            float sv[3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                float v = statbuf[k * MB + lane] + statbuf[k * MB + 64 + lane];
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+                sv[k] = v;
+            }
+            if (lane == 0) { st_acc[0] += sv[0] * (1.0f / (float)MB); st_acc[1] += sv[1] * (1.0f / (float)MB); st_acc[2] += sv[2] * (1.0f / (float)MB); }
+        }
         Q1PL_STAMP(6);                                          // dW2 + Adam + images (wave 0's share)
-        if (!bar_wait(net.bar, (uint32_t)G * ++bar_n, a.status, 2u, (uint32_t)step, a.timeout_ticks, s_ok)) return;
+        if (!bar_wait(net.bar, (uint32_t)G * ++bar_n, loc, a.status, 2u, (uint32_t)step, a.timeout_ticks, s_ok)) return;
         Q1PL_STAMP(7);                                          // barrier 3 wait (incl. waiting for this workgroup's other waves)
 
         // ------------------------------------------------------------ B2: dH1 of the owned units from all of dZ2, dZ1, then dW1 / db1, db3
         {
             f16x8 zr[16];
-            const uint16_t* zrow = net.dz2x + (size_t)(32u * w + c) * HID + 8u * h;
-#pragma unroll
-            for (int s = 0; s < 16; ++s) zr[s] = glb16(zrow + 16 * s);
+            ld16(net.dz2x + (size_t)(32u * w + c) * HID + 8u * h, zr, loc);
             f32x16 acc = zero16;                                // [b][j]: lane = owned unit j, registers = samples (h1B's layout)
 #pragma unroll
             for (int s = 0; s < 16; ++s) acc = mm(zr[s], lds16(lds, L_W2COL + c * LD_W + 32u * (uint32_t)s + 16u * h), acc);
@@ -640,20 +786,31 @@ persistent_learner_kernel(Args a) {
                 if (h == 0u || j < 2) { const size_t i1 = u * 6 + (size_t)(base + j); net.w1[i1] = w1v[j]; net.m[E_W1 + i1] = m1v[j]; net.v[E_W1 + i1] = v1v[j]; }
             if (h) { net.b1[u] = b1v; net.m[E_B1 + u] = mb1; net.v[E_B1 + u] = vb1; }
         }
-        if (g == 0 && w == 3u && (int)lane < OUT) {             // db3 (after barrier 3: every workgroup has read this step's b3)
-            float b3v = net.b3[lane], mv = net.m[E_B3 + lane], vv = net.v[E_B3 + lane];
-            const float gr = (((red3[lane] + red3[16u + lane]) + red3[32u + lane]) + red3[48u + lane]) * net.inv_scale;
-            b3v = adam1(b3v, gr, mv, vv, a.beta1, a.beta2, a.eps, lr_bc1, rs_bc2);
-            net.m[E_B3 + lane] = mv; net.v[E_B3 + lane] = vv;
-            if (last) net.gb3[lane] = gr;
-            __hip_atomic_store(net.b3 + lane, b3v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (g == 0 && w == 3u && c == 6u) {                     // db3 / b3 (after barrier 3: every workgroup has read this step's b3): the ones column of acc_b3
+            float bv[8], mv[8], vv[8];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const uint32_t o = rrow(r, h), oc = (int)o < OUT ? o : 0u;
+                bv[r] = net.b3[oc]; mv[r] = net.m[E_B3 + oc]; vv[r] = net.v[E_B3 + oc];
+            }
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const uint32_t o = rrow(r, h);
+                if ((int)o < OUT) {
+                    const float gr = acc_b3[r] * net.inv_scale;
+                    bv[r] = adam1(bv[r], gr, mv[r], vv[r], a.beta1, a.beta2, a.eps, lr_bc1, rs_bc2);
+                    net.b3[o] = bv[r]; net.m[E_B3 + o] = mv[r]; net.v[E_B3 + o] = vv[r];
+                    if (last) net.gb3[o] = gr;
+                    pub4f(net.b3x + o, bv[r], loc);
+                }
+            }
         }
         __syncthreads();
         Q1PL_STAMP(8);                                          // B2 + dW1 + end of step
     }
 #undef Q1PL_STAMP
     if (profiling)
-        for (int k = 0; k < 10; ++k) a.prof[k] = pacc[k];
+        for (int k = 0; k < 14; ++k) a.prof[k] = pacc[k];
 
     // ---------------------------------------------------------------- epilogue: the W2 slice's optimizer state back to its torch layouts; counters
 #pragma unroll
@@ -663,7 +820,7 @@ persistent_learner_kernel(Args a) {
             const size_t e = (size_t)(U0 + rrow(r, h)) * HID + 64u * w + 32u * (uint32_t)t + c;
             net.w2[e] = st_w[64 * (16 * t + r)]; net.m[e] = st_m[64 * (16 * t + r)]; net.v[e] = st_v[64 * (16 * t + r)];
         }
-    if (g == 0 && tid == 0) {
+    if (g == 0 && tid == 192u) {                                // (wave 3's lane 0 kept the running statistics)
         if (ni == 0) {
             a.stats_acc[0] += st_acc[0]; a.stats_acc[1] += st_acc[1]; a.stats_acc[2] += st_acc[2];
             *a.step_count = step0 + a.steps;
@@ -675,6 +832,15 @@ persistent_learner_kernel(Args a) {
         if (nsat) atomicAdd(a.saturation + 2u * ni, nsat);
         if (amax > 0.0f) atomicMax(a.saturation + 2u * ni + 1u, __float_as_uint(amax));
     }
+}
+
+__global__ void __launch_bounds__(256, 1)
+persistent_learner_kernel(Args a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    // (placement: see persistent_learner_body)
+    const uint32_t role = blockIdx.x & 7u;
+    if (role == 0u) persistent_learner_body<0>(a, lds);
+    else if (role == 1u) persistent_learner_body<1>(a, lds);
 }
 
 }  // namespace q1pl

@@ -274,6 +274,10 @@ class DeviceEnv:
         _lib.check(self._lib.q1env_learner_sgd_step(self._h, C.byref(pi), C.byref(vf), ws, int(splits), C.byref(batch), float(lr), float(beta1),
                                                     float(beta2), float(eps), state))
 
+    def learner_set_loss_scale(self, pi_upscale=0.0, value_downscale=0.0):
+        """float16 loss scales of the learner calls that follow (exact powers of two; 0 = default): include/q1env.h."""
+        _lib.check(self._lib.q1env_learner_set_loss_scale(self._h, float(pi_upscale), float(value_downscale)))
+
     def learner_persistent_bytes(self, batch_rows):
         return int(self._lib.q1env_learner_persistent_bytes(int(batch_rows)))
 

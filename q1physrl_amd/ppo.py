@@ -204,7 +204,8 @@ class PPOLearner:
     def __init__(self, policy, action_range, lr=5e-6, gamma=0.99, lam=0.95, clip_param=0.3, vf_clip_param=100.0,
                  vf_loss_coeff=1.0, entropy_coeff=0.01, kl_coeff=0.2, kl_target=0.0036, num_sgd_iter=30,
                  minibatch_size=128, num_keys=4, seed=0, use_graph=False, fused_loss=False, env=None, discrete_yaw_steps=-1,
-                 allow_yaw=True, autocast_dtype=None, fused_adam=False, native=False, native_splits=32, native_adam=True, persistent=None):
+                 allow_yaw=True, autocast_dtype=None, fused_adam=False, native=False, native_splits=32, native_adam=True, persistent=None,
+                 dynamic_loss_scale=True):
         self.policy = policy
         self.action_range = float(action_range)
         self.gamma, self.lam = gamma, lam
@@ -220,6 +221,12 @@ class PPOLearner:
         # persistent: the whole update (num_sgd_iter epochs of 128-sample minibatches) as ONE dispatch (NativeStep.epochs); None = whenever
         # the shape allows it (native, own Adam, single process, minibatch 128, the reference's action structure)
         self.persistent = persistent
+        # dynamic_loss_scale (native learner): the float16 loss scales of the next update are chosen from THIS update's
+        # largest per-sample gradient element (NativeStep.saturation), as exact powers of two, so that the largest element sits a factor
+        # LOSS_SCALE_HEADROOM below float16's largest finite value: nothing saturates (RLlib: grad_clip = None) unless the gradients grow by
+        # more than that factor from one update to the next, and small gradients keep as many float16 bits as the range allows.
+        self.dynamic_loss_scale = bool(dynamic_loss_scale) and self.native
+        self.pi_upscale, self.value_downscale = 256.0, 1.0      # the library's defaults (csrc/q1env_learner.hip)
         if (self.fused_loss or self.native) and env is None:
             raise ValueError("fused_loss=True / native=True need env= (the TensorVectorEnv whose handle runs the kernels)")
         self._native = None
@@ -370,23 +377,49 @@ class PPOLearner:
                             v_.zero_()
         if self.native:
             self._native.adam_state.copy_(adam_snapshot)
+            self._native.saturation.zero_()          #  the discarded warm-up / capture steps leave no trace in the report either
             self._native.images()                    # the float16 images follow the restored masters
         self._graph = g
+
+    LOSS_SCALE_HEADROOM = 8.0
+    PI_UPSCALE_RANGE = (2.0 ** -6, 2.0 ** 12)
+    VALUE_DOWNSCALE_RANGE = (2.0 ** -8, 2.0 ** 10)
+
+    def _next_loss_scales(self, max_abs_pi, max_abs_vf):
+        """max_abs_*: the largest |element| the backward pass converted to float16 in the update that just ended, AS IT TRAVELLED (i.e.
+        times pi_upscale / divided by value_downscale).  Returns the (pi_upscale, value_downscale) of the next update."""
+        import math
+        target = 65504.0 / self.LOSS_SCALE_HEADROOM
+        up, down = self.pi_upscale, self.value_downscale
+        if max_abs_pi > 0.0 and math.isfinite(max_abs_pi):
+            raw = max_abs_pi / self.pi_upscale                                  # the largest unscaled element
+            up = 2.0 ** math.floor(math.log2(target / raw))
+            up = min(max(up, self.PI_UPSCALE_RANGE[0]), self.PI_UPSCALE_RANGE[1])
+        if max_abs_vf > 0.0 and math.isfinite(max_abs_vf):
+            raw = max_abs_vf * self.value_downscale
+            down = 2.0 ** math.ceil(math.log2(raw / target))
+            down = min(max(down, self.VALUE_DOWNSCALE_RANGE[0]), self.VALUE_DOWNSCALE_RANGE[1])
+        return up, down
 
     def _hparams(self):
         g = self.opt.param_groups[0]
         return (float(g["lr"]), tuple(float(x) for x in g["betas"]), float(g["eps"]))
 
+    def _graph_key(self):
+        """everything a captured graph of the native step bakes into kernel arguments"""
+        return (self._hparams(), self.pi_upscale, self.value_downscale)
+
     def state_dict(self):
         """Everything a resume needs: torch Adam's state (the non-native / multi-rank paths), the native optimizer's moments and step
         count (q1env_learner_adam's state block; self.opt is never stepped on that path, so its state_dict() is empty there), and the
         adaptive KL coefficient."""
-        return {"opt": self.opt.state_dict(), "kl_coeff": float(self.kl_coeff),
+        return {"opt": self.opt.state_dict(), "kl_coeff": float(self.kl_coeff), "pi_upscale": self.pi_upscale, "value_downscale": self.value_downscale,
                 "native_adam": None if self._adam_state is None else self._adam_state.detach().cpu().clone()}
 
     def load_state_dict(self, sd):
         self.opt.load_state_dict(sd["opt"])
         self.kl_coeff = float(sd.get("kl_coeff", self.kl_coeff))
+        self.pi_upscale, self.value_downscale = float(sd.get("pi_upscale", self.pi_upscale)), float(sd.get("value_downscale", self.value_downscale))
         na = sd.get("native_adam")
         if na is not None:
             dev = next(self.policy.parameters()).device
@@ -437,11 +470,13 @@ class PPOLearner:
         if self.persistent is True and not use_persistent:
             raise ValueError("PPOLearner(persistent=True) needs native=True, native_adam=True, one process, minibatch_size 128 and the reference's action structure")
         # lr / betas / eps are kernel ARGUMENTS of the native Adam, baked into a captured graph: a changed param_group re-captures
-        if self.use_graph and self._graph is not None and self.native and self._graph_hparams != self._hparams():
+        if self.native:
+            self.env._dev.learner_set_loss_scale(self.pi_upscale, self.value_downscale)
+        if self.use_graph and self._graph is not None and self.native and self._graph_hparams != self._graph_key():
             self._graph = None
         if self.use_graph and not use_persistent and (self._graph is None or (not self.native and self._mb["adv"].shape[0] != mb)):
             self._capture(b, mb, dev)
-            self._graph_hparams = self._hparams()
+            self._graph_hparams = self._graph_key()
         acc, steps = torch.zeros((len(STAT_KEYS),), dtype=torch.float32, device=dev), 0
         if self.use_graph and not use_persistent:
             self._acc.zero_()
@@ -510,4 +545,7 @@ class PPOLearner:
             out["grad_max_abs_pi"] = float(sat[1:2].view(torch.float32)[0])
             out["grad_max_abs_vf"] = float(sat[3:4].view(torch.float32)[0])
             self._native.saturation.zero_()
+            out["pi_upscale"], out["value_downscale"] = self.pi_upscale, self.value_downscale      # the scales THIS update ran with
+            if self.dynamic_loss_scale:
+                self.pi_upscale, self.value_downscale = self._next_loss_scales(out["grad_max_abs_pi"], out["grad_max_abs_vf"])
         return out

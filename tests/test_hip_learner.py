@@ -532,3 +532,35 @@ def test_ppo_learner_update_persistent_equals_per_step_loop():
         for k in ("entropy", "kl", "policy_loss", "total_loss", "vf_loss"):
             assert abs(oa[k] - ob[k]) <= 2e-3 * max(1.0, abs(oa[k])), (k, oa[k], ob[k])
     env.close()
+
+
+def test_loss_scale_setting_changes_rounding_only_and_insists_on_powers_of_two():
+    """q1env_learner_set_loss_scale (ABI v5): the same step under pi_upscale 256 / 16 / 2048 and value_downscale 1 / 8 gives the same
+    gradients to float16 rounding (the scale is divided out in float32, exactly); anything but a power of two is refused; the persistent
+    learner honours the setting too."""
+    import copy
+    import torch
+    from q1physrl_amd import ppo, _lib
+    pol0 = _policy(5, 2.0)
+    env, full, total = _train_batch(64, 8, pol0)
+    klc = torch.tensor(0.2, device="cuda")
+    perm = torch.randperm(total, device="cuda")
+    hp = (3e-4, (0.9, 0.999), 1e-8)
+    grads = []
+    for up, down, persistent in ((0.0, 0.0, False), (16.0, 8.0, False), (2048.0, 1.0, False), (16.0, 8.0, True)):
+        pol = copy.deepcopy(pol0)
+        env._dev.learner_set_loss_scale(up, down)
+        nat = ppo.NativeStep(pol, env, 128, splits=8)
+        if persistent:
+            nat.epochs(full, perm.reshape(1, -1).contiguous(), 0.3, 10.0, 1.0, 0.01, klc, hp, steps=1)
+        else:
+            nat.step(full, perm, 0.3, 10.0, 1.0, 0.01, klc, skip_reduce=True, use_cursor=True, adam=hp)
+        torch.cuda.synchronize()
+        grads.append([p.grad.detach().clone() for p in pol.parameters()])
+    for other in grads[1:]:
+        for a, b in zip(grads[0], other):
+            assert _rel(b, a) < 3e-3
+    with pytest.raises(_lib.Q1EnvError):
+        env._dev.learner_set_loss_scale(100.0, 0.0)
+    env._dev.learner_set_loss_scale(0.0, 0.0)
+    env.close()

@@ -191,3 +191,25 @@ def test_discrete_mouse_closed_form_gradient_matches_autograd():
     assert np.max(np.abs(freq - p)) < 5e-3
     kd, md = big.deterministic_sample()
     assert int(md[0, 0]) == int(np.argmax(new[0, 8:]))
+
+
+def test_dynamic_loss_scale_choice_is_a_power_of_two_with_headroom():
+    """the next update's float16 loss scales from this update's largest travelled element - exact powers of two,
+    the largest element lands within (1/16, 1/8] of float16's largest finite value, bounded ranges, no change without information."""
+    import math
+    lr = ppo.PPOLearner(P.Q1Policy(), 10.0)                    # (CPU: only the arithmetic of the choice is exercised)
+    lr.native = True
+    assert (lr.pi_upscale, lr.value_downscale) == (256.0, 1.0)
+    for max_pi in (3.0, 94.0 * 256, 12000.0, 3.55e6, 4e7, 1e-3):
+        for max_vf in (237.0, 7100.0, 3.0e5, 0.5):
+            up, down = lr._next_loss_scales(max_pi, max_vf)
+            assert math.frexp(up)[0] == 0.5 and math.frexp(down)[0] == 0.5               # exact powers of two
+            raw_pi, raw_vf = max_pi / lr.pi_upscale, max_vf * lr.value_downscale
+            if lr.PI_UPSCALE_RANGE[0] < up < lr.PI_UPSCALE_RANGE[1]:
+                assert 65504.0 / 16 < raw_pi * up <= 65504.0 / 8
+            if lr.VALUE_DOWNSCALE_RANGE[0] < down < lr.VALUE_DOWNSCALE_RANGE[1]:
+                assert 65504.0 / 16 < raw_vf / down <= 65504.0 / 8
+            assert lr.PI_UPSCALE_RANGE[0] <= up <= lr.PI_UPSCALE_RANGE[1] and lr.VALUE_DOWNSCALE_RANGE[0] <= down <= lr.VALUE_DOWNSCALE_RANGE[1]
+    assert lr._next_loss_scales(0.0, float("nan")) == (256.0, 1.0)
+    # the reference-configuration run of round 4 ended at 3.55 M (x 256) with 1 832 saturated elements: the choice for such an update
+    assert lr._next_loss_scales(3.55e6, 7100.0)[0] == 0.5

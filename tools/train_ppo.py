@@ -49,6 +49,7 @@ ap.add_argument("--refcfg", action="store_true",
                      "for the rest (sgd_minibatch_size 128, num_sgd_iter 30, clip 0.3, kl_coeff 0.2), 4 workers x 100 envs = 400 envs x 125 ticks "
                      "per iteration; overrides --envs / --horizon / --lr / --epochs / --minibatch / --entropy / --kl-target / --zero-start-prob")
 ap.add_argument("--no-persistent", action="store_true", help="drive q1env_learner_sgd_step per minibatch instead of ONE q1env_learner_sgd_epochs dispatch per update (A/B)")
+ap.add_argument("--static-loss-scale", action="store_true", help="keep the native learner's float16 loss scales at their defaults (256, 1) instead of choosing them per update from the previous update's largest gradient element (A/B)")
 ap.add_argument("--checkpoint-dir", default="", help="trainer checkpoints (policy weights, optimizer state incl. the native Adam moments + step count, adaptive KL "
                                                       "coefficient, iteration, best metric): every --checkpoint-every iterations and whenever "
                                                       "zero_start_total_reward_mean exceeds its previous best - the reference's schedule (q1physrl/train.py:110-133)")
@@ -83,7 +84,8 @@ smp = GpuSampler(env, fused if fused is not None else pol, horizon=args.horizon,
 lrn = ppo.PPOLearner(pol, float(cfg.action_range), lr=args.lr, num_sgd_iter=args.epochs, minibatch_size=args.minibatch,
                      entropy_coeff=args.entropy, kl_target=args.kl_target, seed=args.seed + rank, use_graph=not args.no_graph, fused_loss=args.fused_loss, env=env,
                      discrete_yaw_steps=args.discrete_yaw_steps, autocast_dtype=torch.bfloat16 if args.learner_bf16 else None, fused_adam=not args.no_fused_adam,
-                     native=args.native, native_splits=args.native_splits, persistent=False if args.no_persistent else None)
+                     native=args.native, native_splits=args.native_splits, persistent=False if args.no_persistent else None,
+                     dynamic_loss_scale=not args.static_loss_scale)
 log = []
 start_iter, best_metric, best_file = 0, float("-inf"), None
 
@@ -147,7 +149,7 @@ for it in range(start_iter, args.iters):
     row = {"iter": it, "steps": (it + 1) * args.envs * args.horizon, "zero_start_total_reward_mean": zmean, "episode_reward_mean": emean,
            "kl": st["kl"], "entropy": st["entropy"], "vf_loss": st["vf_loss"], "kl_coeff": st["kl_coeff"],
            "sample_s": t_sample, "iter_s": t_iter, "wall_s": time.time() - t0}
-    row.update({k: st[k] for k in ("grad_saturated_pi", "grad_saturated_vf", "grad_max_abs_pi", "grad_max_abs_vf") if k in st})
+    row.update({k: st[k] for k in ("grad_saturated_pi", "grad_saturated_vf", "grad_max_abs_pi", "grad_max_abs_vf", "pi_upscale", "value_downscale") if k in st})
     if args.eval_every and (it % args.eval_every == 0 or it == args.iters - 1):
         row.update(zero_start_eval())
     if args.checkpoint_dir and rank == 0:
