@@ -69,7 +69,9 @@ constexpr uint32_t L_W3T = L_W1 + 32 * LD_16;                // [32 u][16 o]   W
 constexpr uint32_t L_W3 = L_W3T + 32 * LD_16;                // [32 o][32 u]   W3[o][U]
 constexpr uint32_t L_H2W = L_W3 + 32 * LD_32;                // [4 waves][32 b][32 u]
 constexpr uint32_t L_FL = L_H2W + 4 * 32 * LD_32;            // floats: b2p[32] | red2[4][32] | red3[2][16] | stat[4][4] | bc[2] | flags
-constexpr uint32_t LDS_BYTES = L_FL + 4096;                  // 110 080
+constexpr uint32_t L_ST = L_FL + 4096;                       // floats: the optimizer state (master, m, v) of the SMALL owned parameters for the launch:
+                                                             //   sW1[3][32 u][6] | sB1[3][32] | sB2[3][32] | sW3[3][10 o][32 u] | sB3[3][16]
+constexpr uint32_t LDS_BYTES = L_ST + 8192;                  // 118 272
 
 struct Net {
     float* w1; float* b1; float* w2; float* b2; float* w3; float* b3;          // masters (torch layouts), updated in place
@@ -354,8 +356,39 @@ __device__ __forceinline__ void persistent_learner_body(const Args& a, unsigned 
     // ---------------------------------------------------------------- prologue: operand images of the owned slice from the masters
     for (uint32_t off = tid * 16u; off < L_FL; off += 256u * 16u) *reinterpret_cast<uint4*>(lds + off) = uint4{0, 0, 0, 0};
     __syncthreads();
+    // The small owned parameters' optimizer state (W1 / b1 / b2 rows U, W3 columns U, b3 on workgroup 0: ~600 of the 8 448 parameters) lives in
+    // LDS for the launch - their updates sit on the step's critical path (dW1 closes it) and an L2 round trip per array was most of them.
+    float* const sW1 = reinterpret_cast<float*>(lds + L_ST);       // [kind][u * 6 + i]
+    float* const sB1 = sW1 + 3 * 192;                               // [kind][u]
+    float* const sB2 = sB1 + 3 * 32;
+    float* const sW3 = sB2 + 3 * 32;                                // [kind][o * 32 + u]
+    float* const sB3 = sW3 + 3 * 320;                               // [kind][o]
     // flat offsets of the moment arrays ([w2 | b2 | w1 | b1 | w3 | b3], q1learner.hpp AdamNet)
     const size_t E_B2 = 65536, E_W1 = 65536 + 256, E_B1 = E_W1 + 1536, E_W3 = E_B1 + 256, E_B3 = E_W3 + (size_t)OUT * 256;
+    auto small_state = [&](bool to_lds) {                           // LDS <-> the torch layouts (prologue / epilogue)
+        for (uint32_t e = tid; e < 192u; e += 256u) {
+            const size_t i1 = (size_t)U0 * 6 + e;
+            if (to_lds) { sW1[e] = net.w1[i1]; sW1[192 + e] = net.m[E_W1 + i1]; sW1[384 + e] = net.v[E_W1 + i1]; }
+            else { net.w1[i1] = sW1[e]; net.m[E_W1 + i1] = sW1[192 + e]; net.v[E_W1 + i1] = sW1[384 + e]; }
+        }
+        if (tid < 32u) {
+            const size_t u = U0 + tid;
+            if (to_lds) { sB1[tid] = net.b1[u]; sB1[32 + tid] = net.m[E_B1 + u]; sB1[64 + tid] = net.v[E_B1 + u];
+                          sB2[tid] = net.b2[u]; sB2[32 + tid] = net.m[E_B2 + u]; sB2[64 + tid] = net.v[E_B2 + u]; }
+            else { net.b1[u] = sB1[tid]; net.m[E_B1 + u] = sB1[32 + tid]; net.v[E_B1 + u] = sB1[64 + tid];
+                   net.b2[u] = sB2[tid]; net.m[E_B2 + u] = sB2[32 + tid]; net.v[E_B2 + u] = sB2[64 + tid]; }
+        }
+        for (uint32_t e = tid; e < (uint32_t)OUT * 32u; e += 256u) {
+            const size_t i3 = (size_t)(e >> 5) * HID + U0 + (e & 31u);
+            if (to_lds) { sW3[e] = net.w3[i3]; sW3[320 + e] = net.m[E_W3 + i3]; sW3[640 + e] = net.v[E_W3 + i3]; }
+            else { net.w3[i3] = sW3[e]; net.m[E_W3 + i3] = sW3[320 + e]; net.v[E_W3 + i3] = sW3[640 + e]; }
+        }
+        if (g == 0 && tid < (uint32_t)OUT) {
+            if (to_lds) { sB3[tid] = net.b3[tid]; sB3[16 + tid] = net.m[E_B3 + tid]; sB3[32 + tid] = net.v[E_B3 + tid]; }
+            else { net.b3[tid] = sB3[tid]; net.m[E_B3 + tid] = sB3[16 + tid]; net.v[E_B3 + tid] = sB3[32 + tid]; }
+        }
+    };
+    small_state(true);
     // The W2 slice's masters and moments (8 192 of the 8 448 parameters a workgroup owns) are kept, for the launch, in the order their owner
     // lanes use them - lane (c, h) of wave w owns inputs k = 64 w + 32 t + c of units U0 + row(r, h): slot 16 t + r - so that a step's 96
     // loads and 96 stores per lane are fully coalesced and addressed base + immediate; the torch layouts are read here and rewritten
@@ -422,10 +455,18 @@ __device__ __forceinline__ void persistent_learner_body(const Args& a, unsigned 
     int64_t in_epoch = 0;                                       // its index within the epoch
     auto row_at = [&](int64_t window, uint32_t b) -> int64_t { return a.idx ? a.idx[window + (int64_t)b] : window + (int64_t)b; };
     int64_t srcX = row_at(0, tid & (MB - 1)), srcL = row_at(0, bsm);
+    // ... and the observation row itself (24 bytes from HBM at a random row: ~2 us of latency that would otherwise open every step)
+    float oxn[6];
+    auto request_obs = [&]() {
+        const float2* o2 = reinterpret_cast<const float2*>(a.obs + (size_t)srcX * 6);
+        const float2 p0 = o2[0], p1 = o2[1], p2 = o2[2];
+        oxn[0] = p0.x; oxn[1] = p0.y; oxn[2] = p1.x; oxn[3] = p1.y; oxn[4] = p2.x; oxn[5] = p2.y;
+    };
+    request_obs();
     __syncthreads();
 
     const bool profiling = a.prof != nullptr && blockIdx.x == 0 && tid == 0;      // (workgroup 0 = policy group, g = 0)
-    unsigned long long pacc[14] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long pacc[20] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     uint64_t tprev = profiling ? wall_clock64() : 0;
 #define Q1PL_STAMP(k) do { if (profiling) { const uint64_t now_ = wall_clock64(); pacc[k] += now_ - tprev; tprev = now_; } } while (0)
     for (int64_t step = 0; step < a.steps; ++step) {
@@ -438,11 +479,8 @@ __device__ __forceinline__ void persistent_learner_body(const Args& a, unsigned 
         pw1 *= (double)a.beta1;                                   // beta^t, t = step0 + step + 1 (every thread: two float64 multiplies)
         pw2 *= (double)a.beta2;
         float ox[6];
-        {
-            const float2* o2 = reinterpret_cast<const float2*>(a.obs + (size_t)srcX * 6);
-            const float2 p0 = o2[0], p1 = o2[1], p2 = o2[2];
-            ox[0] = p0.x; ox[1] = p0.y; ox[2] = p1.x; ox[3] = p1.y; ox[4] = p2.x; ox[5] = p2.y;
-        }
+#pragma unroll
+        for (int i = 0; i < 6; ++i) ox[i] = oxn[i];              // (requested during the previous step's loss phase)
         if (tid < MB) {
             _Float16 hi[6], lo[6];
 #pragma unroll
@@ -555,6 +593,7 @@ __device__ __forceinline__ void persistent_learner_body(const Args& a, unsigned 
         // HALF of the G partial rows (one round of loads), the halves are exchanged: y = b3 + (A + B) in both lanes, the same bits.
         float s3[3] = {0.0f, 0.0f, 0.0f};
         float gl[10];
+        float wA[16], mA[16], vA[16];                           // (G2's first tile: see below)
         {
             float y[12];
             {
@@ -573,6 +612,11 @@ __device__ __forceinline__ void persistent_learner_body(const Args& a, unsigned 
                     y[o] = part[4][o >> 2][o & 3] + (lo_ + hi_);
                 }
             }
+            // tile 0's optimizer state for G2 (private, coalesced): requested here, two phases early - its L2 round trip was 0.8 us at the head of G2
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { wA[r] = st_w[64 * r]; mA[r] = st_m[64 * r]; vA[r] = st_v[64 * r]; }
+            if (!last) request_obs();                           // the NEXT step's observation rows (srcX was advanced behind barrier 1); behind this
+                                                                // phase's own requests, ~2 us ahead of the next wait on the memory counter
             Q1PL_STAMP(10);                                     // (loss: the outputs summed)
 #pragma unroll
             for (int o = 0; o < 10; ++o) gl[o] = 0.0f;
@@ -642,44 +686,58 @@ __device__ __forceinline__ void persistent_learner_body(const Args& a, unsigned 
         // inputs k = 64 w + 32 t + c of units U0 + row(r, h), the accumulator layout of the product) is REQUESTED before the matrix
         // products and stored after all of it has been used: every access of one kind is issued together (the compiler must assume that
         // a store may alias a later load of another array, and would otherwise serialise 32 round trips to L2 per step).
-#pragma unroll 1
-        for (int t = 0; t < 2; ++t) {                           // one 32-input tile at a time (both at once - one round of requests - was measured: the
-                                                                // 96 + 64 live registers spill inside the loop, 20.4 -> 23.0 us per step)
-            const uint32_t k = 64u * w + 32u * (uint32_t)t + c;
-            float w2v[16], m2v[16], v2v[16];
-            f16x8 hT[8];
+        {
+            // Two 32-input tiles, software-pipelined by hand: tile 0's state + operands, its matrix products; THEN tile 1's state is requested
+            // (in flight under tile 0's optimizer arithmetic), tile 0 is stored, tile 1's operands are requested - one wait covers them, tile 1's
+            // state and tile 0's store acknowledgements.  (Everything of both tiles at once was measured: 96 + 64 live registers spill inside the
+            // loop, 20.4 -> 23.0 us per step.)
+            auto adam_tile = [&](const int t, const f32x16& acc, float (&w2v)[16], float (&m2v)[16], float (&v2v)[16]) __attribute__((always_inline)) {
+                const uint32_t k = 64u * w + 32u * (uint32_t)t + c;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { w2v[r] = st_w[64 * (16 * t + r)]; m2v[r] = st_m[64 * (16 * t + r)]; v2v[r] = st_v[64 * (16 * t + r)]; }
-            ld8(h1tx + (size_t)k * MB + 8u * h, hT, loc);       // (behind the state requests: its wait covers them too - one round trip)
+                for (int q = 0; q < 4; ++q) {
+#pragma unroll
+                    for (int j = 0; j < 4; j += 2) {
+                        const int r = 4 * q + j;
+                        const f32x2 gr = f32x2{acc[r], acc[r + 1]} * net.inv_scale;
+                        f32x2 mm2 = {m2v[r], m2v[r + 1]}, vv2 = {v2v[r], v2v[r + 1]};
+                        const f32x2 wn = adam2(f32x2{w2v[r], w2v[r + 1]}, gr, mm2, vv2, a.beta1, a.beta2, a.eps, lr_bc1, rs_bc2);
+                        w2v[r] = wn.x; w2v[r + 1] = wn.y; m2v[r] = mm2.x; m2v[r + 1] = mm2.y; v2v[r] = vv2.x; v2v[r + 1] = vv2.y;
+                        const f32x2 wi = c2 * wn;
+                        *reinterpret_cast<_Float16*>(lds + L_W2OWN + rrow(r, h) * LD_W + 2u * k) = (_Float16)wi.x;
+                        *reinterpret_cast<_Float16*>(lds + L_W2OWN + rrow(r + 1, h) * LD_W + 2u * k) = (_Float16)wi.y;
+                        if (last) { net.gw2[(size_t)(U0 + rrow(r, h)) * HID + k] = gr.x; net.gw2[(size_t)(U0 + rrow(r + 1, h)) * HID + k] = gr.y; }
+                    }
+                    pub8(net.w2tx + (size_t)k * HID + U0 + 8u * q + 4u * h, pack4(w2v[4 * q], w2v[4 * q + 1], w2v[4 * q + 2], w2v[4 * q + 3]), loc);
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { st_w[64 * (16 * t + r)] = w2v[r]; st_m[64 * (16 * t + r)] = m2v[r]; st_v[64 * (16 * t + r)] = v2v[r]; }
+            };
+            float wB[16], mB[16], vB[16];
+            f16x8 hT[8];
+            ld8(h1tx + (size_t)(64u * w + c) * MB + 8u * h, hT, loc);           // (tile 0's state was requested in the loss phase)
+            Q1PL_STAMP(14);                                     // (G2: tile 0's state + operands arrived)
             f32x16 acc = zero16;                                // [u][k]: lane = input k, registers = owned units
 #pragma unroll
             for (int s = 0; s < 8; ++s) acc = mm(lds16(lds, L_DZ2T + c * LD_B + 32u * (uint32_t)s + 16u * h), hT[s], acc);
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
+            for (int r = 0; r < 16; ++r) { wB[r] = st_w[64 * (16 + r)]; mB[r] = st_m[64 * (16 + r)]; vB[r] = st_v[64 * (16 + r)]; }
+            adam_tile(0, acc, wA, mA, vA);
+            Q1PL_STAMP(15);                                     // (G2: tile 0's products + optimizer + stores issued)
+            ld8(h1tx + (size_t)(64u * w + 32u + c) * MB + 8u * h, hT, loc);
+            Q1PL_STAMP(16);                                     // (G2: tile 1's operands arrived)
+            acc = zero16;
 #pragma unroll
-                for (int j = 0; j < 4; j += 2) {
-                    const int r = 4 * q + j;
-                    const f32x2 gr = f32x2{acc[r], acc[r + 1]} * net.inv_scale;
-                    f32x2 mm2 = {m2v[r], m2v[r + 1]}, vv2 = {v2v[r], v2v[r + 1]};
-                    const f32x2 wn = adam2(f32x2{w2v[r], w2v[r + 1]}, gr, mm2, vv2, a.beta1, a.beta2, a.eps, lr_bc1, rs_bc2);
-                    w2v[r] = wn.x; w2v[r + 1] = wn.y; m2v[r] = mm2.x; m2v[r + 1] = mm2.y; v2v[r] = vv2.x; v2v[r + 1] = vv2.y;
-                    const f32x2 wi = c2 * wn;
-                    *reinterpret_cast<_Float16*>(lds + L_W2OWN + rrow(r, h) * LD_W + 2u * k) = (_Float16)wi.x;
-                    *reinterpret_cast<_Float16*>(lds + L_W2OWN + rrow(r + 1, h) * LD_W + 2u * k) = (_Float16)wi.y;
-                    if (last) { net.gw2[(size_t)(U0 + rrow(r, h)) * HID + k] = gr.x; net.gw2[(size_t)(U0 + rrow(r + 1, h)) * HID + k] = gr.y; }
-                }
-                pub8(net.w2tx + (size_t)k * HID + U0 + 8u * q + 4u * h, pack4(w2v[4 * q], w2v[4 * q + 1], w2v[4 * q + 2], w2v[4 * q + 3]), loc);
-            }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { st_w[64 * (16 * t + r)] = w2v[r]; st_m[64 * (16 * t + r)] = m2v[r]; st_v[64 * (16 * t + r)] = v2v[r]; }
+            for (int s = 0; s < 8; ++s) acc = mm(lds16(lds, L_DZ2T + c * LD_B + 32u * (uint32_t)s + 16u * h), hT[s], acc);
+            adam_tile(1, acc, wB, mB, vB);
+            Q1PL_STAMP(17);                                     // (G2: tile 1 done)
         }
         if (w == 1u) {                                          // dW3[:, U]: lane = owned unit, registers = outputs (o = row(r, h) < OUT <= 10: r < 8)
             float w3v[8], m3v[8], v3v[8];
 #pragma unroll
             for (int r = 0; r < 8; ++r) {
                 const uint32_t o = rrow(r, h);
-                const size_t i3 = (size_t)((int)o < OUT ? o : 0u) * HID + U0 + c;
-                w3v[r] = net.w3[i3]; m3v[r] = net.m[E_W3 + i3]; v3v[r] = net.v[E_W3 + i3];
+                const uint32_t i3 = ((int)o < OUT ? o : 0u) * 32u + c;
+                w3v[r] = sW3[i3]; m3v[r] = sW3[320 + i3]; v3v[r] = sW3[640 + i3];
             }
             f32x16 acc = zero16;
 #pragma unroll
@@ -699,16 +757,16 @@ __device__ __forceinline__ void persistent_learner_body(const Args& a, unsigned 
 #pragma unroll
             for (int r = 0; r < 8; ++r) {
                 const uint32_t o = rrow(r, h);
-                if ((int)o < OUT) { const size_t i3 = (size_t)o * HID + U0 + c; net.w3[i3] = w3v[r]; net.m[E_W3 + i3] = m3v[r]; net.v[E_W3 + i3] = v3v[r]; }
+                if ((int)o < OUT) { const uint32_t i3 = o * 32u + c; sW3[i3] = w3v[r]; sW3[320 + i3] = m3v[r]; sW3[640 + i3] = v3v[r]; }
             }
         }
         if (w == 2u && h == 0u) {                               // db2[U]
             const size_t u = U0 + c;
-            float b2v = net.b2[u], mv = net.m[E_B2 + u], vv = net.v[E_B2 + u];
+            float b2v = sB2[c], mv = sB2[32 + c], vv = sB2[64 + c];
             const float gr = (((red2[c] + red2[32u + c]) + red2[64u + c]) + red2[96u + c]) * net.inv_scale;
             b2v = adam1(b2v, gr, mv, vv, a.beta1, a.beta2, a.eps, lr_bc1, rs_bc2);
             b2p[c] = c2 * b2v;
-            net.b2[u] = b2v; net.m[E_B2 + u] = mv; net.v[E_B2 + u] = vv;
+            sB2[c] = b2v; sB2[32 + c] = mv; sB2[64 + c] = vv;
             if (last) net.gb2[u] = gr;
         }
         f32x16 acc_b3 = zero16;                                 // [o][i']: lane (c = 6, h) holds db3[o = row(r, h)] (times the loss scale)
@@ -754,10 +812,10 @@ __device__ __forceinline__ void persistent_learner_body(const Args& a, unsigned 
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const bool isw = h == 0u || j < 2;
-                const size_t i1 = isw ? u * 6 + (size_t)(base + j) : u * 6;
-                w1v[j] = net.w1[i1]; m1v[j] = net.m[E_W1 + i1]; v1v[j] = net.v[E_W1 + i1];
+                const uint32_t i1 = isw ? c * 6u + (uint32_t)(base + j) : c * 6u;
+                w1v[j] = sW1[i1]; m1v[j] = sW1[192 + i1]; v1v[j] = sW1[384 + i1];
             }
-            float b1v = net.b1[u], mb1 = net.m[E_B1 + u], vb1 = net.v[E_B1 + u];
+            float b1v = sB1[c], mb1 = sB1[32 + c], vb1 = sB1[64 + c];
             f32x16 acc = zero16;
 #pragma unroll
             for (int s = 0; s < 8; ++s)
@@ -783,15 +841,15 @@ __device__ __forceinline__ void persistent_learner_body(const Args& a, unsigned 
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-                if (h == 0u || j < 2) { const size_t i1 = u * 6 + (size_t)(base + j); net.w1[i1] = w1v[j]; net.m[E_W1 + i1] = m1v[j]; net.v[E_W1 + i1] = v1v[j]; }
-            if (h) { net.b1[u] = b1v; net.m[E_B1 + u] = mb1; net.v[E_B1 + u] = vb1; }
+                if (h == 0u || j < 2) { const uint32_t i1 = c * 6u + (uint32_t)(base + j); sW1[i1] = w1v[j]; sW1[192 + i1] = m1v[j]; sW1[384 + i1] = v1v[j]; }
+            if (h) { sB1[c] = b1v; sB1[32 + c] = mb1; sB1[64 + c] = vb1; }
         }
         if (g == 0 && w == 3u && c == 6u) {                     // db3 / b3 (after barrier 3: every workgroup has read this step's b3): the ones column of acc_b3
             float bv[8], mv[8], vv[8];
 #pragma unroll
             for (int r = 0; r < 8; ++r) {
                 const uint32_t o = rrow(r, h), oc = (int)o < OUT ? o : 0u;
-                bv[r] = net.b3[oc]; mv[r] = net.m[E_B3 + oc]; vv[r] = net.v[E_B3 + oc];
+                bv[r] = sB3[oc]; mv[r] = sB3[16 + oc]; vv[r] = sB3[32 + oc];
             }
 #pragma unroll
             for (int r = 0; r < 8; ++r) {
@@ -799,7 +857,7 @@ __device__ __forceinline__ void persistent_learner_body(const Args& a, unsigned 
                 if ((int)o < OUT) {
                     const float gr = acc_b3[r] * net.inv_scale;
                     bv[r] = adam1(bv[r], gr, mv[r], vv[r], a.beta1, a.beta2, a.eps, lr_bc1, rs_bc2);
-                    net.b3[o] = bv[r]; net.m[E_B3 + o] = mv[r]; net.v[E_B3 + o] = vv[r];
+                    sB3[o] = bv[r]; sB3[16 + o] = mv[r]; sB3[32 + o] = vv[r];
                     if (last) net.gb3[o] = gr;
                     pub4f(net.b3x + o, bv[r], loc);
                 }
@@ -810,9 +868,10 @@ __device__ __forceinline__ void persistent_learner_body(const Args& a, unsigned 
     }
 #undef Q1PL_STAMP
     if (profiling)
-        for (int k = 0; k < 14; ++k) a.prof[k] = pacc[k];
+        for (int k = 0; k < 20; ++k) a.prof[k] = pacc[k];
 
     // ---------------------------------------------------------------- epilogue: the W2 slice's optimizer state back to its torch layouts; counters
+    small_state(false);
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll

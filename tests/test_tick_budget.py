@@ -16,6 +16,18 @@ def test_headline_tick_is_within_its_instruction_budget(capsys):
     out = capsys.readouterr().out
     assert hot is not None, out
     assert 4 <= len(hot["blocks"]) <= 6, hot                    # header, physics, friction, output block (+ at most two the compiler may split off)
-    assert 200 <= hot["valu"] <= 255, hot                       # 237 in round 4 (294 in round 3, 337 before)
-    assert hot["slots"] <= 295, hot                             # 276: VALU + SALU + LDS + VMEM + s_nop + s_waitcnt + branches
+    assert 200 <= hot["valu"] <= 240, hot                       # 237 since round 4 (294 in round 3, 337 before); the floor argument per block: profiles/r5_tick_floor.txt
+    assert hot["slots"] <= 272, hot                             # 268: VALU + SALU + LDS + VMEM + s_nop + s_waitcnt + branches (round 5: write-through stores, one wait less)
     assert "Occupancy: 4" in out and "ScratchSize: 0" in out    # <= 128 VGPRs (four waves per SIMD for the 262 144-env configs), no spills
+
+
+def test_two_ahead_instantiation_costs_the_same_tick(capsys):
+    """rollout_kernel<..., DEPTH = 2> (launches of >= 32 ticks: the action is requested two ticks ahead, the loop body is two ticks): per
+    tick within 3 VALU instructions / 3 slots of the one-ahead form, still four waves per SIMD."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import count_tick_insts
+    hot = count_tick_insts.main(["--kernel", "rollout_kernelIfLb1ELi2ELb0ELi1ELb0ELi2EE"])
+    out = capsys.readouterr().out
+    assert hot is not None, out
+    assert 400 <= hot["valu"] <= 2 * 243 and hot["slots"] <= 2 * 275, hot
+    assert "Occupancy: 4" in out

@@ -1,8 +1,8 @@
 #!/bin/bash
 # Run on the GPU box (through gpurun): the round's evidence set for EVERY BASELINE config from the tree as it is.
-#   rollout_65536          configs[1]: bench.py --mode rollout                        (rollout_kernel<float, true, 2, false, 1, false>)
+#   rollout_65536          configs[1]: bench.py --mode rollout                        (rollout_kernel<float, true, 2, false, 1, false, 2>: 720-tick launches)
 #   rollout_131072         configs[3] shard: --mode rollout --envs 131072             (same instantiation, two waves per SIMD)
-#   rollout_params_262144  configs[2]: --config params_yml --envs 262144, in-kernel reset (rollout_kernel<float, true, 2, true, 1, false>)
+#   rollout_params_262144  configs[2]: --config params_yml --envs 262144, in-kernel reset (rollout_kernel<float, true, 2, true, 1, false, 2>)
 #   step_65536 / step_262144 / step_1048576 / step_4194304   the per-tick kernel (HBM-bound formulation), server_65536 the LDS pair
 #   sampler_32768 / sampler_262144   configs[4]: kernel-trace statistics of the sampler loop (mlp_forward_kernel, sample / step / resident)
 # For each bench set: rocprofv3 --kernel-trace --stats, then SEPARATE PMC passes of the SAME command
@@ -11,7 +11,7 @@
 # tools/summarize_pmc.py turns the CSVs into gpurun_out/prof_<tag>/{summary.txt,pmc.json} (each entry carries the build id of the
 # library it profiled); copy those into profiles/.
 set -u
-TAG=${1:-r4}
+TAG=${1:-r5}
 WHAT=${2:-all}
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"

@@ -76,7 +76,8 @@ for d in sorted(glob.glob(os.path.join(out, "*_*"))):
     e["ticks_per_launch"] = 1 if mode == "step" else 720
     try:
         b = json.load(open(os.path.join(out, f"{key}.bench_unprofiled.json")))
-        e["event_us_per_tick_unprofiled"] = b["roofline"]["us_per_tick"]
+        ro = b["roofline"]          # (round 5: the stdout line is the compact one - us_per_tick = avg_launch_us / ticks_per_launch)
+        e["event_us_per_tick_unprofiled"] = ro.get("us_per_tick") or ro["avg_launch_us"] / ro["ticks_per_launch"]
         e["value_unprofiled"] = b["value"]
         if b.get("lib_build_id"):                      # which build of the kernels these passes profiled (bench.py's staleness guard)
             e["build_id"] = b["lib_build_id"]
