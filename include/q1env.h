@@ -188,6 +188,14 @@ int q1env_step_many(q1env_t* env, int ticks, int action_format, const void* act_
  * is reset in-kernel with the Philox reset (as q1env_reset_philox) before its next tick; (ABI v3) Q1ENV_TIMER_START (4) /
  * Q1ENV_TIMER_STOP (8) may be added to record the handle's timer events around the launch inside this call (as q1env_step_many).
  * return_sum_dev (optional, double[N]) accumulates reward over the launch in float64.
+ * Which kernel serves a call (all give identical results; the cost differs): the SPECIALISED instantiations - straight-line
+ * tick, static store count, 237 vector instructions per tick - need (a) the default action / episode structure (4 keys, continuous mouse,
+ * jump key, no hover, y reward: Config.get_default() and data/params.yml) with move maxima and constants that pass the host's exactness
+ * checks (csrc/q1env_host.hpp is_spec: e.g. time_limit and action_range whose reciprocals satisfy the one-step division bound), (b)
+ * float32 observations, (c) packed or on-device random actions, (d) either ALL of obs / reward / done or none of them, (e) no
+ * return_sum_dev.  Anything else runs the same tick through run-time output pointers (return_sum, partial output sets, row actions: ~5 %
+ * slower) or the generic wave-uniform-branch kernels (other Configs: ~1.3 x).  From 32 ticks per launch the specialised all-outputs
+ * kernels request the action two ticks ahead (DEPTH = 2 in the kernel's name; Q1ENV_ROLLOUT_DEPTH=1|2 in the environment forces one).
  * (ABI v4) Q1ENV_STAMP_START (16) / Q1ENV_SIGNAL (32) / Q1ENV_SIGNAL_WAIT (64) in auto_reset: the completion signal below, written by
  * this launch's own waves - no marker packets around the kernel and no runtime synchronisation to learn that it has finished. */
 #define Q1ENV_STAMP_START 16

@@ -121,7 +121,10 @@ __device__ __forceinline__ f16x8 glb16(const uint16_t* p) { return *reinterpret_
 // invalidated behind a local barrier at all (buffer_inv sc1 also empties this XCD's L2 of clean lines: the exchanged operands came back
 // from the memory side at ~2 us per phase, measured).
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-#define Q1PL_LD(i, off) "global_load_dwordx4 %" #i ", %[p], off offset:" #off " sc1\n\t"
+#ifndef Q1PL_SC
+#define Q1PL_SC " sc1"          // scope bits of the local-mode operand loads (measurement knob: "" / " sc0" were timed, profiles/r5_learner_persistent.txt)
+#endif
+#define Q1PL_LD(i, off) "global_load_dwordx4 %" #i ", %[p], off offset:" #off Q1PL_SC "\n\t"
 __device__ __forceinline__ void ld16(const uint16_t* p, f16x8 (&o)[16], bool loc) {                 // 16 vectors, 32 bytes apart
     if (loc) {
         asm volatile(Q1PL_LD(0, 0) Q1PL_LD(1, 32) Q1PL_LD(2, 64) Q1PL_LD(3, 96) Q1PL_LD(4, 128) Q1PL_LD(5, 160) Q1PL_LD(6, 192) Q1PL_LD(7, 224)
@@ -148,10 +151,10 @@ __device__ __forceinline__ void ld8(const uint16_t* p, f16x8 (&o)[8], bool loc) 
 __device__ __forceinline__ void ld8x2(const uint16_t* p, const uint16_t* q, f16x8 (&o)[8], f16x8 (&r)[8], bool loc) {   // two rows' 8 vectors each
     if (loc) {
         asm volatile(Q1PL_LD(0, 0) Q1PL_LD(1, 32) Q1PL_LD(2, 64) Q1PL_LD(3, 96) Q1PL_LD(4, 128) Q1PL_LD(5, 160) Q1PL_LD(6, 192) Q1PL_LD(7, 224)
-                     "global_load_dwordx4 %8, %[q], off sc1\n\tglobal_load_dwordx4 %9, %[q], off offset:32 sc1\n\t"
-                     "global_load_dwordx4 %10, %[q], off offset:64 sc1\n\tglobal_load_dwordx4 %11, %[q], off offset:96 sc1\n\t"
-                     "global_load_dwordx4 %12, %[q], off offset:128 sc1\n\tglobal_load_dwordx4 %13, %[q], off offset:160 sc1\n\t"
-                     "global_load_dwordx4 %14, %[q], off offset:192 sc1\n\tglobal_load_dwordx4 %15, %[q], off offset:224 sc1\n\t"
+                     "global_load_dwordx4 %8, %[q], off" Q1PL_SC "\n\tglobal_load_dwordx4 %9, %[q], off offset:32" Q1PL_SC "\n\t"
+                     "global_load_dwordx4 %10, %[q], off offset:64" Q1PL_SC "\n\tglobal_load_dwordx4 %11, %[q], off offset:96" Q1PL_SC "\n\t"
+                     "global_load_dwordx4 %12, %[q], off offset:128" Q1PL_SC "\n\tglobal_load_dwordx4 %13, %[q], off offset:160" Q1PL_SC "\n\t"
+                     "global_load_dwordx4 %14, %[q], off offset:192" Q1PL_SC "\n\tglobal_load_dwordx4 %15, %[q], off offset:224" Q1PL_SC "\n\t"
                      "s_waitcnt vmcnt(0)"
                      : "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3]), "=&v"(o[4]), "=&v"(o[5]), "=&v"(o[6]), "=&v"(o[7]),
                        "=&v"(r[0]), "=&v"(r[1]), "=&v"(r[2]), "=&v"(r[3]), "=&v"(r[4]), "=&v"(r[5]), "=&v"(r[6]), "=&v"(r[7])
@@ -166,8 +169,8 @@ __device__ __forceinline__ void ld16_4(const uint16_t* p, f16x8 (&o)[16], const 
     if (loc) {
         asm volatile(Q1PL_LD(0, 0) Q1PL_LD(1, 32) Q1PL_LD(2, 64) Q1PL_LD(3, 96) Q1PL_LD(4, 128) Q1PL_LD(5, 160) Q1PL_LD(6, 192) Q1PL_LD(7, 224)
                      Q1PL_LD(8, 256) Q1PL_LD(9, 288) Q1PL_LD(10, 320) Q1PL_LD(11, 352) Q1PL_LD(12, 384) Q1PL_LD(13, 416) Q1PL_LD(14, 448) Q1PL_LD(15, 480)
-                     "global_load_dwordx4 %16, %[q], off sc1\n\tglobal_load_dwordx4 %17, %[q], off offset:128 sc1\n\t"
-                     "global_load_dwordx4 %18, %[q], off offset:256 sc1\n\tglobal_load_dwordx4 %19, %[q], off offset:384 sc1\n\t"
+                     "global_load_dwordx4 %16, %[q], off" Q1PL_SC "\n\tglobal_load_dwordx4 %17, %[q], off offset:128" Q1PL_SC "\n\t"
+                     "global_load_dwordx4 %18, %[q], off offset:256" Q1PL_SC "\n\tglobal_load_dwordx4 %19, %[q], off offset:384" Q1PL_SC "\n\t"
                      "s_waitcnt vmcnt(0)"
                      : "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3]), "=&v"(o[4]), "=&v"(o[5]), "=&v"(o[6]), "=&v"(o[7]), "=&v"(o[8]), "=&v"(o[9]),
                        "=&v"(o[10]), "=&v"(o[11]), "=&v"(o[12]), "=&v"(o[13]), "=&v"(o[14]), "=&v"(o[15]), "=&v"(c[0]), "=&v"(c[1]), "=&v"(c[2]), "=&v"(c[3])
@@ -182,12 +185,12 @@ __device__ __forceinline__ void ld16_4(const uint16_t* p, f16x8 (&o)[16], const 
 // the loss phase's requests: three float4 (12 outputs) of four partial-logit rows + the bias row
 __device__ __forceinline__ void ld_rows(const float* r0, const float* r1, const float* r2, const float* r3, const float* rb, f32x4 (&o)[5][3], bool loc) {
     if (loc) {
-#define Q1PL_LR(i, reg) "global_load_dwordx4 %" #i ", %[" #reg "], off sc1\n\tglobal_load_dwordx4 %" #i "+1, %[" #reg "], off offset:16 sc1\n\t"
-        asm volatile("global_load_dwordx4 %0, %[a], off sc1\n\tglobal_load_dwordx4 %1, %[a], off offset:16 sc1\n\tglobal_load_dwordx4 %2, %[a], off offset:32 sc1\n\t"
-                     "global_load_dwordx4 %3, %[b], off sc1\n\tglobal_load_dwordx4 %4, %[b], off offset:16 sc1\n\tglobal_load_dwordx4 %5, %[b], off offset:32 sc1\n\t"
-                     "global_load_dwordx4 %6, %[c], off sc1\n\tglobal_load_dwordx4 %7, %[c], off offset:16 sc1\n\tglobal_load_dwordx4 %8, %[c], off offset:32 sc1\n\t"
-                     "global_load_dwordx4 %9, %[d], off sc1\n\tglobal_load_dwordx4 %10, %[d], off offset:16 sc1\n\tglobal_load_dwordx4 %11, %[d], off offset:32 sc1\n\t"
-                     "global_load_dwordx4 %12, %[e], off sc1\n\tglobal_load_dwordx4 %13, %[e], off offset:16 sc1\n\tglobal_load_dwordx4 %14, %[e], off offset:32 sc1\n\t"
+#define Q1PL_LR(i, reg) "global_load_dwordx4 %" #i ", %[" #reg "], off" Q1PL_SC "\n\tglobal_load_dwordx4 %" #i "+1, %[" #reg "], off offset:16" Q1PL_SC "\n\t"
+        asm volatile("global_load_dwordx4 %0, %[a], off" Q1PL_SC "\n\tglobal_load_dwordx4 %1, %[a], off offset:16" Q1PL_SC "\n\tglobal_load_dwordx4 %2, %[a], off offset:32" Q1PL_SC "\n\t"
+                     "global_load_dwordx4 %3, %[b], off" Q1PL_SC "\n\tglobal_load_dwordx4 %4, %[b], off offset:16" Q1PL_SC "\n\tglobal_load_dwordx4 %5, %[b], off offset:32" Q1PL_SC "\n\t"
+                     "global_load_dwordx4 %6, %[c], off" Q1PL_SC "\n\tglobal_load_dwordx4 %7, %[c], off offset:16" Q1PL_SC "\n\tglobal_load_dwordx4 %8, %[c], off offset:32" Q1PL_SC "\n\t"
+                     "global_load_dwordx4 %9, %[d], off" Q1PL_SC "\n\tglobal_load_dwordx4 %10, %[d], off offset:16" Q1PL_SC "\n\tglobal_load_dwordx4 %11, %[d], off offset:32" Q1PL_SC "\n\t"
+                     "global_load_dwordx4 %12, %[e], off" Q1PL_SC "\n\tglobal_load_dwordx4 %13, %[e], off offset:16" Q1PL_SC "\n\tglobal_load_dwordx4 %14, %[e], off offset:32" Q1PL_SC "\n\t"
                      "s_waitcnt vmcnt(0)"
                      : "=&v"(o[0][0]), "=&v"(o[0][1]), "=&v"(o[0][2]), "=&v"(o[1][0]), "=&v"(o[1][1]), "=&v"(o[1][2]), "=&v"(o[2][0]), "=&v"(o[2][1]), "=&v"(o[2][2]),
                        "=&v"(o[3][0]), "=&v"(o[3][1]), "=&v"(o[3][2]), "=&v"(o[4][0]), "=&v"(o[4][1]), "=&v"(o[4][2])
