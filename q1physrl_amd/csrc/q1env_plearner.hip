@@ -7,6 +7,7 @@
 #include "q1policy_glue.hpp"
 #include "q1ppo_loss.hpp"
 #include "q1learner_persist.hpp"
+#include "q1learner_persist8.hpp"
 
 using namespace q1;
 
@@ -80,8 +81,13 @@ int q1env_learner_sgd_epochs(q1env_t* h, const q1env_learner_net* pi, const q1en
     DeviceGuard guard(h->device);
     if (!h->plearner_attr_set) {
         HIP_TRY(hipFuncSetAttribute((const void*)q1pl::persistent_learner_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)q1pl::LDS_BYTES));
+        HIP_TRY(hipFuncSetAttribute((const void*)q1pl::persistent_learner_kernel8, hipFuncAttributeMaxDynamicSharedMemorySize, (int)q1pl::LDS_BYTES8));
         h->plearner_attr_set = true;
     }
+    // four waves per workgroup; Q1_LEARNER_WAVES=8 selects the eight-wave kernel (two per SIMD, every phase split over a wave pair:
+    // csrc/q1learner_persist8.hpp) - built, equivalent (same tests), measured SLOWER on MI355X: 21.7 against 20.2 us per step (the weight-
+    // gradient phase gains, 5.3 -> 4.0 us, the operand waits and the partial-sum exchanges through LDS lose more: profiles/r5_learner_persistent.txt)
+    static const int waves = [] { const char* e = getenv("Q1_LEARNER_WAVES"); return (e && atoi(e) == 8) ? 8 : 4; }();
     PWs pw[2];
     uint32_t* status = nullptr;
     float* mouse_u = nullptr;
@@ -125,7 +131,8 @@ int q1env_learner_sgd_epochs(q1env_t* h, const q1env_learner_net* pi, const q1en
     a.timeout_ticks = (uint64_t)((timeout_s > 0 ? timeout_s : 5.0) * (h->wall_clock_hz > 0 ? h->wall_clock_hz : 1e8));
     hipLaunchKernelGGL(q1pl::mouse_u_kernel, dim3((unsigned)((batch_rows + 255) / 256)), dim3(256), 0, h->stream, batch_rows, b->mouse_dev, -h->p.action_range_f32,
                        h->p.action_range_f32, mouse_u);
-    hipLaunchKernelGGL(q1pl::persistent_learner_kernel, dim3(8 * q1pl::G), dim3(256), q1pl::LDS_BYTES, h->stream, a);
+    if (waves == 8) hipLaunchKernelGGL(q1pl::persistent_learner_kernel8, dim3(8 * q1pl::G), dim3(512), q1pl::LDS_BYTES8, h->stream, a);
+    else hipLaunchKernelGGL(q1pl::persistent_learner_kernel, dim3(8 * q1pl::G), dim3(256), q1pl::LDS_BYTES, h->stream, a);
     HIP_TRY(hipGetLastError());
     return Q1ENV_OK;
 }
