@@ -205,7 +205,7 @@ class PPOLearner:
                  vf_loss_coeff=1.0, entropy_coeff=0.01, kl_coeff=0.2, kl_target=0.0036, num_sgd_iter=30,
                  minibatch_size=128, num_keys=4, seed=0, use_graph=False, fused_loss=False, env=None, discrete_yaw_steps=-1,
                  allow_yaw=True, autocast_dtype=None, fused_adam=False, native=False, native_splits=32, native_adam=True, persistent=None,
-                 dynamic_loss_scale=True):
+                 dynamic_loss_scale=False):
         self.policy = policy
         self.action_range = float(action_range)
         self.gamma, self.lam = gamma, lam
@@ -221,10 +221,16 @@ class PPOLearner:
         # persistent: the whole update (num_sgd_iter epochs of 128-sample minibatches) as ONE dispatch (NativeStep.epochs); None = whenever
         # the shape allows it (native, own Adam, single process, minibatch 128, the reference's action structure)
         self.persistent = persistent
-        # dynamic_loss_scale (native learner): the float16 loss scales of the next update are chosen from THIS update's
-        # largest per-sample gradient element (NativeStep.saturation), as exact powers of two, so that the largest element sits a factor
-        # LOSS_SCALE_HEADROOM below float16's largest finite value: nothing saturates (RLlib: grad_clip = None) unless the gradients grow by
-        # more than that factor from one update to the next, and small gradients keep as many float16 bits as the range allows.
+        # dynamic_loss_scale (native learner; OFF by default - measured, see below): the float16 loss scales of the next
+        # update are chosen from THIS update's largest per-sample gradient element (NativeStep.saturation), as exact powers of two, so that
+        # the largest element sits a factor LOSS_SCALE_HEADROOM below float16's largest finite value: (almost) nothing saturates (RLlib:
+        # grad_clip = None).  Measured on MI355X (round 5): under the reference's configuration (minibatch 128, lr 5e-6) the run is unchanged
+        # (5 702 against 5 697 zero-start reward; 176 saturated elements in the run against 1e8), but with large minibatches (32 768, lr 3e-5)
+        # it COSTS the result - 5 290 / 5 240 against 5 652 for two seeds (profiles/r5_train_ppo_largebatch_*.json): the largest element is a
+        # handful of outlier samples (probability ratios that explode), a scale that fits them (down to 2^-6) pushes the bulk of the
+        # gradients into float16's subnormal range, and it is the BULK that carries the learning signal - the same plateau round 3 saw with a
+        # scale of 1.  Saturating the outliers at the static scale (a per-sample clip of a few samples in 10^4) is the better trade; it stays
+        # counted and reported.
         self.dynamic_loss_scale = bool(dynamic_loss_scale) and self.native
         self.pi_upscale, self.value_downscale = 256.0, 1.0      # the library's defaults (csrc/q1env_learner.hip)
         if (self.fused_loss or self.native) and env is None:

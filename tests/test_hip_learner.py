@@ -121,12 +121,12 @@ def test_native_learner_matches_the_torch_learner():
         adv, vt = smp.advantages(tr, 0.99, 0.95)
         trajs.append((tr, adv.clone(), vt.clone()))
     res = []
-    # (static float16 loss scales here: this test is about the KERNELS' equivalence - eager == graph-captured bit for bit; with the dynamic
-    # scale a change of scale re-captures the graph in the second update, and its warm-up / roll-back is equal only to ~1e-5)
+    # (static float16 loss scales - the default: eager == graph-captured bit for bit; with dynamic_loss_scale=True a change of scale re-captures
+    # the graph in the second update, and its warm-up / roll-back is equal only to ~1e-5)
     for native, graph, own_adam in ((False, False, False), (True, False, True), (True, True, True), (True, False, False)):
         pol = copy.deepcopy(base)
         lr = ppo.PPOLearner(pol, cfg.action_range, lr=1e-3, num_sgd_iter=3, minibatch_size=2048, seed=11, use_graph=graph,
-                            fused_loss=True, env=env, native=native, native_splits=8, fused_adam=True, native_adam=own_adam, dynamic_loss_scale=False)
+                            fused_loss=True, env=env, native=native, native_splits=8, fused_adam=True, native_adam=own_adam)
         stats = [lr.update(*t) for t in trajs]
         res.append(([p.detach().clone() for p in pol.parameters()], stats))
     env.close()

@@ -9,6 +9,6 @@ mkdir -p $O
 export Q1_TUNABLEOP=0
 IT=${1:-2989}; TAG=${2:-dynscale}; TMO=${3:-2400}; shift 3 2>/dev/null || true
 timeout $TMO python tools/train_ppo.py --refcfg --native --fused-policy --iters $IT --log-every 50 --eval-every 100 --seed 0 \
-    --checkpoint-dir /tmp/r5_ck_$TAG --out $O/r5_train_ppo_refcfg_$TAG.json --save $O/r5_policy_refcfg_$TAG.npz "$@" > $O/$TAG.log 2>&1
+    --dynamic-loss-scale --checkpoint-dir /tmp/r5_ck_$TAG --out $O/r5_train_ppo_refcfg_$TAG.json --save $O/r5_policy_refcfg_$TAG.npz "$@" > $O/$TAG.log 2>&1
 echo "$TAG rc=$?" >> $O/$TAG.log
 tail -4 $O/$TAG.log | cut -c1-700

@@ -49,7 +49,7 @@ ap.add_argument("--refcfg", action="store_true",
                      "for the rest (sgd_minibatch_size 128, num_sgd_iter 30, clip 0.3, kl_coeff 0.2), 4 workers x 100 envs = 400 envs x 125 ticks "
                      "per iteration; overrides --envs / --horizon / --lr / --epochs / --minibatch / --entropy / --kl-target / --zero-start-prob")
 ap.add_argument("--no-persistent", action="store_true", help="drive q1env_learner_sgd_step per minibatch instead of ONE q1env_learner_sgd_epochs dispatch per update (A/B)")
-ap.add_argument("--static-loss-scale", action="store_true", help="keep the native learner's float16 loss scales at their defaults (256, 1) instead of choosing them per update from the previous update's largest gradient element (A/B)")
+ap.add_argument("--dynamic-loss-scale", action="store_true", help="choose the native learner's float16 loss scales per update from the previous update's largest gradient element instead of the static (256, 1): no saturation, but measured to cost the large-minibatch configuration its result (PPOLearner docstring)")
 ap.add_argument("--checkpoint-dir", default="", help="trainer checkpoints (policy weights, optimizer state incl. the native Adam moments + step count, adaptive KL "
                                                       "coefficient, iteration, best metric): every --checkpoint-every iterations and whenever "
                                                       "zero_start_total_reward_mean exceeds its previous best - the reference's schedule (q1physrl/train.py:110-133)")
@@ -85,7 +85,7 @@ lrn = ppo.PPOLearner(pol, float(cfg.action_range), lr=args.lr, num_sgd_iter=args
                      entropy_coeff=args.entropy, kl_target=args.kl_target, seed=args.seed + rank, use_graph=not args.no_graph, fused_loss=args.fused_loss, env=env,
                      discrete_yaw_steps=args.discrete_yaw_steps, autocast_dtype=torch.bfloat16 if args.learner_bf16 else None, fused_adam=not args.no_fused_adam,
                      native=args.native, native_splits=args.native_splits, persistent=False if args.no_persistent else None,
-                     dynamic_loss_scale=not args.static_loss_scale)
+                     dynamic_loss_scale=args.dynamic_loss_scale)
 log = []
 start_iter, best_metric, best_file = 0, float("-inf"), None
 
