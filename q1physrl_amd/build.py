@@ -36,7 +36,11 @@ COMPILE_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=of
 # moving values between the two register files - transposition results that the very next instruction converts (558 -> 100 moves per
 # tile, 2 933 -> 2 501 vector instructions; the 32 768-sample SGD step 106 -> 101 us).  The policy / sampler units keep the compiler's
 # default (the resident sampler measured 3 % slower with it).
-TU_FLAGS = {"q1env_learner.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
+TU_FLAGS = {"q1env_learner.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"],
+            # the persistent learner: the same register form (its step loop read 220 accumulator registers back per step), and NO atomic
+            # optimizer: that pass rewrites a uniform-address atomic into a wave reduction + s_waitcnt vmcnt(0) + readfirstlane, i.e. it
+            # makes the barrier poll that is requested early and looked at late (q1learner_persist.hpp, barrier 3) synchronous again
+            "q1env_plearner.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form", "-mllvm", "-amdgpu-atomic-optimizer-strategy=None"]}
 LINK_FLAGS = ["--offload-arch=gfx950", "-shared", "-fPIC"]
 HIPCC_FLAGS = COMPILE_FLAGS + ["-shared"]     # (kept for tools that compile a single file the old way, e.g. tools/asan_check.sh)
 

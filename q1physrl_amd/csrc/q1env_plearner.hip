@@ -1,13 +1,11 @@
 // q1env_plearner.hip - the PERSISTENT PPO learner of libq1env.so (q1env_learner_sgd_epochs; device code in q1learner_persist.hpp): a whole
-// update's SGD steps at the reference's minibatch size as ONE dispatch.  Its own translation unit: the four-launch learner's unit is
-// compiled with -amdgpu-mfma-vgpr-form (accumulators in the ordinary vector registers), which this kernel - 512 registers per lane at
-// one wave per SIMD, long-lived accumulators and operand prefetches - must not have.
+// update's SGD steps at the reference's minibatch size as ONE dispatch.  Its own translation unit: it is compiled with its own flags
+// (q1physrl_amd/build.py TU_FLAGS: accumulators in the ordinary vector registers; no atomic optimizer - see there).
 #include "q1env_host.hpp"
 #include "q1policy.hpp"
 #include "q1policy_glue.hpp"
 #include "q1ppo_loss.hpp"
 #include "q1learner_persist.hpp"
-#include "q1learner_persist8.hpp"
 
 using namespace q1;
 
@@ -80,14 +78,10 @@ int q1env_learner_sgd_epochs(q1env_t* h, const q1env_learner_net* pi, const q1en
     if (h->num_cus < 2 * q1pl::G) return fail(Q1ENV_ERR_INVALID_ARG, "q1env_learner_sgd_epochs: needs 16 compute units");
     DeviceGuard guard(h->device);
     if (!h->plearner_attr_set) {
-        HIP_TRY(hipFuncSetAttribute((const void*)q1pl::persistent_learner_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)q1pl::LDS_BYTES));
-        HIP_TRY(hipFuncSetAttribute((const void*)q1pl::persistent_learner_kernel8, hipFuncAttributeMaxDynamicSharedMemorySize, (int)q1pl::LDS_BYTES8));
+        HIP_TRY(hipFuncSetAttribute((const void*)q1pl::persistent_learner_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)q1pl::LDS_BYTES));
+        HIP_TRY(hipFuncSetAttribute((const void*)q1pl::persistent_learner_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)q1pl::LDS_BYTES));
         h->plearner_attr_set = true;
     }
-    // four waves per workgroup; Q1_LEARNER_WAVES=8 selects the eight-wave kernel (two per SIMD, every phase split over a wave pair:
-    // csrc/q1learner_persist8.hpp) - built, equivalent (same tests), measured SLOWER on MI355X: 21.7 against 20.2 us per step (the weight-
-    // gradient phase gains, 5.3 -> 4.0 us, the operand waits and the partial-sum exchanges through LDS lose more: profiles/r5_learner_persistent.txt)
-    static const int waves = [] { const char* e = getenv("Q1_LEARNER_WAVES"); return (e && atoi(e) == 8) ? 8 : 4; }();
     PWs pw[2];
     uint32_t* status = nullptr;
     float* mouse_u = nullptr;
@@ -109,7 +103,7 @@ int q1env_learner_sgd_epochs(q1env_t* h, const q1env_learner_net* pi, const q1en
         n.w3 = const_cast<float*>(s->w3); n.b3 = const_cast<float*>(s->b3);
         n.gw1 = s->gw1; n.gb1 = s->gb1; n.gw2 = s->gw2; n.gb2 = s->gb2; n.gw3 = s->gw3; n.gb3 = s->gb3;
         n.m = m; n.v = v; n.out_dim = s->out_dim;
-        n.h1x = w.h1x; n.h1tx = w.h1tx; n.dz2x = w.dz2x; n.w2tx = w.w2tx; n.yp = w.yp; n.w2st = w.w2st; n.b3x = w.b3x; n.bar = w.bar;
+        n.h1x = w.h1x; n.h1tx = w.h1tx; n.dz2x = w.dz2x; n.w2tx = w.w2tx; n.yp = w.yp; n.w2st = w.w2st; n.b3x = w.b3x; n.bar = w.bar; n.xbase = (const char*)w.bar;
         n.inv_b = inv_b; n.inv_scale = inv_scale;
     };
     // the float16 loss scales of q1env_learner_step: per-sample gradients x pi_upscale (policy) / value_downscale (value)
@@ -128,11 +122,12 @@ int q1env_learner_sgd_epochs(q1env_t* h, const q1env_learner_net* pi, const q1en
     a.status = status;
     { const char* e = getenv("Q1_LEARNER_LOCAL"); a.allow_local = (e && e[0] == '0') ? 0 : 1; }
     a.prof = getenv("Q1_LEARNER_PROF") ? reinterpret_cast<unsigned long long*>(status + 4) + 1 : nullptr;      // (bytes 24.. of the status line)
+    { const char* e = getenv("Q1_LEARNER_PROF"); a.prof_g = e ? (atoi(e) & 7) : 0; }      // (Q1_LEARNER_PROF=<g>: which workgroup of the policy group is stamped)
     a.timeout_ticks = (uint64_t)((timeout_s > 0 ? timeout_s : 5.0) * (h->wall_clock_hz > 0 ? h->wall_clock_hz : 1e8));
     hipLaunchKernelGGL(q1pl::mouse_u_kernel, dim3((unsigned)((batch_rows + 255) / 256)), dim3(256), 0, h->stream, batch_rows, b->mouse_dev, -h->p.action_range_f32,
                        h->p.action_range_f32, mouse_u);
-    if (waves == 8) hipLaunchKernelGGL(q1pl::persistent_learner_kernel8, dim3(8 * q1pl::G), dim3(512), q1pl::LDS_BYTES8, h->stream, a);
-    else hipLaunchKernelGGL(q1pl::persistent_learner_kernel, dim3(8 * q1pl::G), dim3(256), q1pl::LDS_BYTES, h->stream, a);
+    if (a.prof) hipLaunchKernelGGL(q1pl::persistent_learner_kernel<true>, dim3(8 * q1pl::G), dim3(256), q1pl::LDS_BYTES, h->stream, a);
+    else hipLaunchKernelGGL(q1pl::persistent_learner_kernel<false>, dim3(8 * q1pl::G), dim3(256), q1pl::LDS_BYTES, h->stream, a);
     HIP_TRY(hipGetLastError());
     return Q1ENV_OK;
 }

@@ -79,14 +79,18 @@ struct Net {
     float* m; float* v;                                                          // moments, flat [w2 | b2 | w1 | b1 | w3 | b3] (q1learner.hpp AdamNet)
     int out_dim;
     // exchange buffers of this network's group
-    uint16_t* h1x;        // [2 parity][128 b][256 k]
-    uint16_t* h1tx;       // [2 parity][256 k][128 b]
-    uint16_t* dz2x;       // [128 b][256 k]
+    // (H1, H1^T, dZ2 and the partial logits are exchanged in OPERAND-FRAGMENT order: the 16 bytes lane l of consumer wave w reads for K-step s
+    //  sit at ((block * steps + s) * 64 + l) * 16, so that every 64-lane request covers one contiguous KB - 8 cache lines instead of the 32 or 64
+    //  scattered ones of the row-major forms, which made the CU's single request port the bound of every phase that touches exchanged data)
+    uint16_t* h1x;        // [2 parity][4 sample tiles w][16 K-steps s][64 lanes (c = sample, h)][8]: H1[32 w + c][16 s + 8 h ..]
+    uint16_t* h1tx;       // [2 parity][8 unit tiles g][8 K-steps s][64 lanes (c = unit, h)][8]: H1[16 s + 8 h ..][32 g + c]
+    uint16_t* dz2x;       // [4][16][64][8]: dZ2 in H1's form
     uint16_t* w2tx;       // [256 j][256 k]: W2[k][j]
-    float* yp;            // [G][128 b][16]
+    float* yp;            // [G][4 sample tiles w][4 output quads v][32 samples c][4]: partial logits 4 v .. 4 v + 3 of sample 32 w + c
     float* b3x;           // [16]: the output layer's bias as the group reads it (published by workgroup 0 after every step), zero padded
-    float* w2st;          // [G][3 (master, m, v)][4 waves][32 slots][64 lanes]: the W2 slice's optimizer state in its OWNER LANE's order
+    float* w2st;          // [G][3 (master, m, v)][4 waves][8 slot quads][64 lanes][4]: the W2 slice's optimizer state in its OWNER LANE's order
     uint32_t* bar;        // arrival counter (own 256-byte line)
+    const char* xbase;    // lowest address of this group's exchange workspace (the buffer resource of its exchange loads)
     float inv_b;          // d loss / d output travels multiplied by this (loss scale / 1: per-sample, not averaged)
     float inv_scale;      // gradient = sum over the samples x this
 };
@@ -108,105 +112,67 @@ struct Args {
     uint32_t* status;          // uint32[4]: [0] != 0: a barrier timed out (value = 1 + barrier index), [1] the step it happened in,
                                // [2], [3]: exchange mode of the policy / value group (1 + the XCD all its workgroups share, 0 = agent scope)
     int allow_local;           // 0: always the agent-scope exchange mode (A/B)
-    unsigned long long* prof;  // optional uint64[16] (the rest of the status line): 10-ns ticks workgroup (0, 0) spent per phase, summed over the steps
+    unsigned long long* prof;  // optional uint64[20] (the rest of the status line): 10-ns ticks wave 0 of workgroup prof_g of the policy group spent per phase, summed over the steps
+    int prof_g;
     uint64_t timeout_ticks;
 };
 
 __device__ __forceinline__ f16x8 lds16(const unsigned char* base, uint32_t off) { return *reinterpret_cast<const f16x8*>(base + off); }
-__device__ __forceinline__ f16x8 glb16(const uint16_t* p) { return *reinterpret_cast<const f16x8*>(p); }
-// Batched operand loads of EXCHANGED data.  loc = false: ordinary loads (the acquire behind the barrier - buffer_inv sc1 - has emptied the
-// caches of anything another XCD may have rewritten).  loc = true: DEVICE-scope loads (sc1: never served by the CU's vector cache, which
-// is not coherent with another CU's stores; served by the shared L2, where the producers' plain stores sit), all of a phase's requests and
-// their wait in ONE assembly block - the compiler's waitcnt bookkeeping does not see inline loads - so that no cache has to be
-// invalidated behind a local barrier at all (buffer_inv sc1 also empties this XCD's L2 of clean lines: the exchanged operands came back
-// from the memory side at ~2 us per phase, measured).
+// Loads of EXCHANGED data: raw buffer loads over ONE resource per network (base = the group's exchange workspace, Net::xbase), address =
+// base + per-lane byte offset (one 32-bit register, loop invariant) + per-buffer byte offset (scalar) + immediate - no 64-bit per-lane
+// pointers to keep alive across the step - at DEVICE scope (sc1: never served by the CU's vector cache, which is not coherent with
+// another CU's stores; served by the XCD's L2, where - in the L2-local mode - the producers' plain stores sit, so that no cache has to be
+// invalidated behind a local barrier at all: buffer_inv sc1 also empties this XCD's L2 of clean lines and the exchanged operands then came
+// back from the memory side at ~2 us per phase, measured).  They are ordinary compiler-visible loads: the compiler counts them (vmcnt), so
+// a phase's operands can be REQUESTED a phase ahead and waited for where they are used (the first version issued them from inline
+// assembly, request and wait in one block).
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-#ifndef Q1PL_SC
-#define Q1PL_SC " sc1"          // scope bits of the local-mode operand loads (measurement knob: "" / " sc0" were timed, profiles/r5_learner_persistent.txt)
-#endif
-#define Q1PL_LD(i, off) "global_load_dwordx4 %" #i ", %[p], off offset:" #off Q1PL_SC "\n\t"
-__device__ __forceinline__ void ld16(const uint16_t* p, f16x8 (&o)[16], bool loc) {                 // 16 vectors, 32 bytes apart
-    if (loc) {
-        asm volatile(Q1PL_LD(0, 0) Q1PL_LD(1, 32) Q1PL_LD(2, 64) Q1PL_LD(3, 96) Q1PL_LD(4, 128) Q1PL_LD(5, 160) Q1PL_LD(6, 192) Q1PL_LD(7, 224)
-                     Q1PL_LD(8, 256) Q1PL_LD(9, 288) Q1PL_LD(10, 320) Q1PL_LD(11, 352) Q1PL_LD(12, 384) Q1PL_LD(13, 416) Q1PL_LD(14, 448) Q1PL_LD(15, 480)
-                     "s_waitcnt vmcnt(0)"
-                     : "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3]), "=&v"(o[4]), "=&v"(o[5]), "=&v"(o[6]), "=&v"(o[7]), "=&v"(o[8]), "=&v"(o[9]),
-                       "=&v"(o[10]), "=&v"(o[11]), "=&v"(o[12]), "=&v"(o[13]), "=&v"(o[14]), "=&v"(o[15])
-                     : [p] "v"(p) : "memory");
-    } else {
-#pragma unroll
-        for (int s = 0; s < 16; ++s) o[s] = *reinterpret_cast<const f16x8*>(p + 16 * s);
-    }
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+constexpr int XAUX = 16;                                          // cache policy of the exchange loads: sc1 (gfx940+: bit 4 of the aux operand)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t xrsrc(const void* base) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, 0x7FFFFFFF, 0x00020000);      // raw buffer, 32-bit data format, no swizzle
 }
-__device__ __forceinline__ void ld8(const uint16_t* p, f16x8 (&o)[8], bool loc) {                   // 8 vectors, 32 bytes apart
-    if (loc) {
-        asm volatile(Q1PL_LD(0, 0) Q1PL_LD(1, 32) Q1PL_LD(2, 64) Q1PL_LD(3, 96) Q1PL_LD(4, 128) Q1PL_LD(5, 160) Q1PL_LD(6, 192) Q1PL_LD(7, 224)
-                     "s_waitcnt vmcnt(0)"
-                     : "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3]), "=&v"(o[4]), "=&v"(o[5]), "=&v"(o[6]), "=&v"(o[7]) : [p] "v"(p) : "memory");
-    } else {
-#pragma unroll
-        for (int s = 0; s < 8; ++s) o[s] = *reinterpret_cast<const f16x8*>(p + 16 * s);
-    }
+__device__ __forceinline__ f16x8 xld16(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff) {
+    union { u32x4 u; f16x8 v; } o;
+    o.u = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, XAUX);
+    return o.v;
 }
-__device__ __forceinline__ void ld8x2(const uint16_t* p, const uint16_t* q, f16x8 (&o)[8], f16x8 (&r)[8], bool loc) {   // two rows' 8 vectors each
-    if (loc) {
-        asm volatile(Q1PL_LD(0, 0) Q1PL_LD(1, 32) Q1PL_LD(2, 64) Q1PL_LD(3, 96) Q1PL_LD(4, 128) Q1PL_LD(5, 160) Q1PL_LD(6, 192) Q1PL_LD(7, 224)
-                     "global_load_dwordx4 %8, %[q], off" Q1PL_SC "\n\tglobal_load_dwordx4 %9, %[q], off offset:32" Q1PL_SC "\n\t"
-                     "global_load_dwordx4 %10, %[q], off offset:64" Q1PL_SC "\n\tglobal_load_dwordx4 %11, %[q], off offset:96" Q1PL_SC "\n\t"
-                     "global_load_dwordx4 %12, %[q], off offset:128" Q1PL_SC "\n\tglobal_load_dwordx4 %13, %[q], off offset:160" Q1PL_SC "\n\t"
-                     "global_load_dwordx4 %14, %[q], off offset:192" Q1PL_SC "\n\tglobal_load_dwordx4 %15, %[q], off offset:224" Q1PL_SC "\n\t"
-                     "s_waitcnt vmcnt(0)"
-                     : "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3]), "=&v"(o[4]), "=&v"(o[5]), "=&v"(o[6]), "=&v"(o[7]),
-                       "=&v"(r[0]), "=&v"(r[1]), "=&v"(r[2]), "=&v"(r[3]), "=&v"(r[4]), "=&v"(r[5]), "=&v"(r[6]), "=&v"(r[7])
-                     : [p] "v"(p), [q] "v"(q) : "memory");
-    } else {
-#pragma unroll
-        for (int s = 0; s < 8; ++s) { o[s] = *reinterpret_cast<const f16x8*>(p + 16 * s); r[s] = *reinterpret_cast<const f16x8*>(q + 16 * s); }
-    }
+// private data of the owning lane (the W2 slice's optimizer state): the same addressing, ordinary cache policy
+// (four floats per instruction: a wave may have 63 vector-memory instructions in flight, the 64th stalls until the oldest has completed - with
+//  one float per instruction the 96 state loads and 96 state stores of a step ran into that limit behind every batch of operand requests)
+__device__ __forceinline__ void xld4(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff, float* o) {
+    const u32x4 u = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
+    o[0] = __uint_as_float(u.x); o[1] = __uint_as_float(u.y); o[2] = __uint_as_float(u.z); o[3] = __uint_as_float(u.w);
 }
-// P2's requests: the 16 operand vectors of this wave's H1 rows + this thread's 4 chunks (128 bytes apart) of W2's column block
-__device__ __forceinline__ void ld16_4(const uint16_t* p, f16x8 (&o)[16], const uint16_t* q, f16x8 (&c)[4], bool loc) {
-    if (loc) {
-        asm volatile(Q1PL_LD(0, 0) Q1PL_LD(1, 32) Q1PL_LD(2, 64) Q1PL_LD(3, 96) Q1PL_LD(4, 128) Q1PL_LD(5, 160) Q1PL_LD(6, 192) Q1PL_LD(7, 224)
-                     Q1PL_LD(8, 256) Q1PL_LD(9, 288) Q1PL_LD(10, 320) Q1PL_LD(11, 352) Q1PL_LD(12, 384) Q1PL_LD(13, 416) Q1PL_LD(14, 448) Q1PL_LD(15, 480)
-                     "global_load_dwordx4 %16, %[q], off" Q1PL_SC "\n\tglobal_load_dwordx4 %17, %[q], off offset:128" Q1PL_SC "\n\t"
-                     "global_load_dwordx4 %18, %[q], off offset:256" Q1PL_SC "\n\tglobal_load_dwordx4 %19, %[q], off offset:384" Q1PL_SC "\n\t"
-                     "s_waitcnt vmcnt(0)"
-                     : "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3]), "=&v"(o[4]), "=&v"(o[5]), "=&v"(o[6]), "=&v"(o[7]), "=&v"(o[8]), "=&v"(o[9]),
-                       "=&v"(o[10]), "=&v"(o[11]), "=&v"(o[12]), "=&v"(o[13]), "=&v"(o[14]), "=&v"(o[15]), "=&v"(c[0]), "=&v"(c[1]), "=&v"(c[2]), "=&v"(c[3])
-                     : [p] "v"(p), [q] "v"(q) : "memory");
-    } else {
-#pragma unroll
-        for (int s = 0; s < 16; ++s) o[s] = *reinterpret_cast<const f16x8*>(p + 16 * s);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) c[i] = *reinterpret_cast<const f16x8*>(q + 64 * i);
-    }
+__device__ __forceinline__ void xst4(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff, const float* v) {
+    const u32x4 u = {__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])};
+    __builtin_amdgcn_raw_buffer_store_b128(u, r, voff, soff, 0);
 }
-// the loss phase's requests: three float4 (12 outputs) of four partial-logit rows + the bias row
-__device__ __forceinline__ void ld_rows(const float* r0, const float* r1, const float* r2, const float* r3, const float* rb, f32x4 (&o)[5][3], bool loc) {
-    if (loc) {
-#define Q1PL_LR(i, reg) "global_load_dwordx4 %" #i ", %[" #reg "], off" Q1PL_SC "\n\tglobal_load_dwordx4 %" #i "+1, %[" #reg "], off offset:16" Q1PL_SC "\n\t"
-        asm volatile("global_load_dwordx4 %0, %[a], off" Q1PL_SC "\n\tglobal_load_dwordx4 %1, %[a], off offset:16" Q1PL_SC "\n\tglobal_load_dwordx4 %2, %[a], off offset:32" Q1PL_SC "\n\t"
-                     "global_load_dwordx4 %3, %[b], off" Q1PL_SC "\n\tglobal_load_dwordx4 %4, %[b], off offset:16" Q1PL_SC "\n\tglobal_load_dwordx4 %5, %[b], off offset:32" Q1PL_SC "\n\t"
-                     "global_load_dwordx4 %6, %[c], off" Q1PL_SC "\n\tglobal_load_dwordx4 %7, %[c], off offset:16" Q1PL_SC "\n\tglobal_load_dwordx4 %8, %[c], off offset:32" Q1PL_SC "\n\t"
-                     "global_load_dwordx4 %9, %[d], off" Q1PL_SC "\n\tglobal_load_dwordx4 %10, %[d], off offset:16" Q1PL_SC "\n\tglobal_load_dwordx4 %11, %[d], off offset:32" Q1PL_SC "\n\t"
-                     "global_load_dwordx4 %12, %[e], off" Q1PL_SC "\n\tglobal_load_dwordx4 %13, %[e], off offset:16" Q1PL_SC "\n\tglobal_load_dwordx4 %14, %[e], off offset:32" Q1PL_SC "\n\t"
-                     "s_waitcnt vmcnt(0)"
-                     : "=&v"(o[0][0]), "=&v"(o[0][1]), "=&v"(o[0][2]), "=&v"(o[1][0]), "=&v"(o[1][1]), "=&v"(o[1][2]), "=&v"(o[2][0]), "=&v"(o[2][1]), "=&v"(o[2][2]),
-                       "=&v"(o[3][0]), "=&v"(o[3][1]), "=&v"(o[3][2]), "=&v"(o[4][0]), "=&v"(o[4][1]), "=&v"(o[4][2])
-                     : [a] "v"(r0), [b] "v"(r1), [c] "v"(r2), [d] "v"(r3), [e] "v"(rb) : "memory");
-#undef Q1PL_LR
-    } else {
-        const float* rr[5] = {r0, r1, r2, r3, rb};
-#pragma unroll
-        for (int q = 0; q < 5; ++q)
-#pragma unroll
-            for (int v = 0; v < 3; ++v) o[q][v] = *reinterpret_cast<const f32x4*>(rr[q] + 4 * v);
-    }
+// published data (see the exchange modes below): plain stores in the L2-local mode, agent-scope write-through (sc0 sc1) otherwise
+__device__ __forceinline__ void xpub8(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff, uint64_t v, bool loc) {
+    const u32x2 d = {(uint32_t)v, (uint32_t)(v >> 32)};
+    if (loc) __builtin_amdgcn_raw_buffer_store_b64(d, r, voff, soff, 0);
+    else __builtin_amdgcn_raw_buffer_store_b64(d, r, voff, soff, 17);
 }
-#undef Q1PL_LD
+__device__ __forceinline__ void xpub16f(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff, float a, float b, float c, float d, bool loc) {
+    const u32x4 u = {__float_as_uint(a), __float_as_uint(b), __float_as_uint(c), __float_as_uint(d)};
+    if (loc) __builtin_amdgcn_raw_buffer_store_b128(u, r, voff, soff, 0);
+    else __builtin_amdgcn_raw_buffer_store_b128(u, r, voff, soff, 17);
+}
+__device__ __forceinline__ void xpub8f(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff, float a, float b, bool loc) {
+    const u32x2 d = {__float_as_uint(a), __float_as_uint(b)};
+    if (loc) __builtin_amdgcn_raw_buffer_store_b64(d, r, voff, soff, 0);
+    else __builtin_amdgcn_raw_buffer_store_b64(d, r, voff, soff, 17);
+}
+__device__ __forceinline__ f32x4 xld4f(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff) {
+    union { u32x4 u; f32x4 v; } o;
+    o.u = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, XAUX);
+    return o.v;
+}
 
 __device__ __forceinline__ f32x16 mm(f16x8 a, f16x8 b, f32x16 acc) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc, 0, 0, 0); }
+__device__ __forceinline__ constexpr uint32_t fq(int q) { return 512u * (uint32_t)(q & 1) + 1024u * (uint32_t)(q >> 1); }   // piece q of a lane's fragment-order publication
 __device__ __forceinline__ uint32_t rrow(int r, uint32_t h) { return (uint32_t)(r & 3) + 8u * (uint32_t)(r >> 2) + 4u * h; }
 
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
@@ -281,27 +247,33 @@ __device__ __forceinline__ void bar_arrive(uint32_t* ctr, bool loc) {
     __builtin_amdgcn_s_waitcnt(0);
     __syncthreads();
     if (threadIdx.x == 0) {
-        if (loc) { const uint32_t one = 1u; asm volatile("global_atomic_add %0, %1, off" :: "v"(ctr), "v"(one) : "memory"); }   // (no scope bits: performed in the L2)
+        if (loc) __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);      // (no scope bits: performed in the XCD's L2)
         else __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
+// One reading of the counter.  Local mode: a read-modify-write that adds a zero the compiler cannot see through (an atomic add of a literal
+// zero is folded into a workgroup-scope LOAD, which the CU's vector cache may serve: the stale-counter dead-lock of the first version), without
+// scope bits, i.e. performed in the L2 where the tickets are counted.  An ordinary compiler-visible operation: its result can be
+// REQUESTED early and waited for late (vmcnt counts it), which is how barrier 3 is polled from inside the weight-gradient phase.
 __device__ __forceinline__ uint32_t poll(uint32_t* ctr, bool loc) {
     if (loc) {
-        uint32_t v;
-        const uint32_t zero = 0u;
-        asm volatile("global_atomic_add %0, %1, %2, off sc0\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(ctr), "v"(zero) : "memory");   // returns the counter as the L2 holds it
-        return v;
+        uint32_t zero = 0u;
+        asm volatile("" : "+v"(zero));
+        return __hip_atomic_fetch_add(ctr, zero, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
     return __hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-// wait until `target` tickets have been drawn; false (for every thread) on timeout / abort
+// wait until `target` tickets have been drawn; false (for every thread) on timeout / abort.  `first`: a reading thread 0 requested earlier
+// (0 = none: tickets are only ever counted upwards from 0 and target > 0)
 __device__ __forceinline__ bool bar_wait(uint32_t* ctr, uint32_t target, bool loc, uint32_t* status, uint32_t which, uint32_t step, uint64_t timeout_ticks,
-                                         int* s_ok) {
+                                         int* s_ok, uint32_t first = 0u) {
     if (threadIdx.x == 0) {
         int ok = 1;
         uint64_t t0 = 0;
         uint32_t spins = 0;
-        while (poll(ctr, loc) < target) {
+        while (first < target) {
+            first = poll(ctr, loc);
+            if (first >= target) break;
             __builtin_amdgcn_s_sleep(1);
             if ((++spins & 1023u) == 0u) {
                 const uint64_t now = wall_clock64();
@@ -320,7 +292,7 @@ __device__ __forceinline__ bool bar_wait(uint32_t* ctr, uint32_t target, bool lo
     }
     __syncthreads();
     const bool ok = *s_ok != 0;
-    if (!loc) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // buffer_inv sc1; the local mode reads exchanged data with device-scope loads instead (ld16 ...)
+    if (!loc) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // buffer_inv sc1 (the local mode reads exchanged data with device-scope loads instead: xld16)
     return ok;
 }
 
@@ -335,7 +307,7 @@ mouse_u_kernel(int64_t rows, const float* __restrict__ mouse, float low, float h
 
 // NI = 0: a workgroup of the policy group (10 outputs, the PPO policy loss), NI = 1: of the value group (1 output, the value loss): two
 // straight-line specialisations instead of run-time tests on the output count and the network in every loop over the outputs.
-template <int NI>
+template <int NI, bool PROF>
 __device__ __forceinline__ void persistent_learner_body(const Args& a, unsigned char* lds) {
     const uint32_t tid = threadIdx.x, lane = tid & 63u, w = tid >> 6, c = lane & 31u, h = lane >> 5;
     // Placement.  The dispatcher deals workgroups to the eight XCDs round-robin by workgroup id, so of the 64 launched only those with
@@ -355,6 +327,22 @@ __device__ __forceinline__ void persistent_learner_body(const Args& a, unsigned 
     const float c2 = TANH_PRESCALE;
     const uint32_t U0 = 32u * g;
     const uint32_t bsm = 32u * w + c;                           // the sample this lane (and its partner lane ^ 32) differentiates the loss of
+    // exchange loads: one resource, scalar byte offsets of the buffers, per-lane byte offsets (see xld16)
+    const __amdgpu_buffer_rsrc_t xr = xrsrc(net.xbase);
+    auto xoff = [&](const void* q) { return (uint32_t)(reinterpret_cast<const char*>(q) - net.xbase); };
+    const uint32_t o_h1x = xoff(net.h1x), o_h1tx = xoff(net.h1tx), o_dz2x = xoff(net.dz2x), o_w2tx = xoff(net.w2tx), o_yp = xoff(net.yp), o_b3x = xoff(net.b3x);
+    const uint32_t v_col = ((U0 + (tid >> 3)) * (uint32_t)HID + 8u * (tid & 7u)) * 2u;   // this thread's chunks of W2's column block: + 128 i
+    const uint32_t wu = (uint32_t)__builtin_amdgcn_readfirstlane((int)w);        // the wave index as the scalar it is
+    const uint32_t o_w2st = xoff(net.w2st);
+    // ... publishes: (row, 4 h) of a [128 b][256 k] array (+ 2 U0 + 16 q), of H1^T (+ 2 U0 MB + 16 q), of W2^T (+ 2 U0 + 16384 t + 16 q), of the partial logits
+    const uint32_t p_frag = c * 16u + 8u * h;                                    // a 4-element piece of a fragment-order array: + 512 (q & 1) + 1024 (q >> 1), block offset scalar
+    const uint32_t p_w2t = ((64u * w + c) * (uint32_t)HID + 4u * h) * 2u;
+    const uint32_t p_yp = c * 16u + 512u * h;                                    // this lane's output quad h (+ 1024: quad 2 + h) of sample c
+    const uint32_t s_ypg = o_yp + (g * 4u + wu) * 2048u;
+    // ... the W2 slice's optimizer state, [g][kind][wave][8 slot quads][64 lanes][4] floats: lane offset + scalar (kind, wave, tile) + 1024 (r / 4)
+    const uint32_t v_st = lane * 16u;
+    auto s_st = [&](uint32_t kind, uint32_t t) { return o_w2st + ((g * 3u + kind) * 4u + wu) * 8192u + t * 4096u; };
+    const uint32_t v_yp = c * 16u + h * 32768u;                                  // partial logits of sample (w, c), groups 4 h .. 4 h + 3 (8192 bytes apart): + 512 v
 
     // ---------------------------------------------------------------- prologue: operand images of the owned slice from the masters
     for (uint32_t off = tid * 16u; off < L_FL; off += 256u * 16u) *reinterpret_cast<uint4*>(lds + off) = uint4{0, 0, 0, 0};
@@ -396,15 +384,17 @@ __device__ __forceinline__ void persistent_learner_body(const Args& a, unsigned 
     // lanes use them - lane (c, h) of wave w owns inputs k = 64 w + 32 t + c of units U0 + row(r, h): slot 16 t + r - so that a step's 96
     // loads and 96 stores per lane are fully coalesced and addressed base + immediate; the torch layouts are read here and rewritten
     // once at the end.
-    float* const st_w = net.w2st + (((size_t)g * 3 + 0) * 4 + w) * 2048 + lane;
-    float* const st_m = net.w2st + (((size_t)g * 3 + 1) * 4 + w) * 2048 + lane;
-    float* const st_v = net.w2st + (((size_t)g * 3 + 2) * 4 + w) * 2048 + lane;
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const size_t e = (size_t)(U0 + rrow(r, h)) * HID + 64u * w + 32u * (uint32_t)t + c;
-            st_w[64 * (16 * t + r)] = net.w2[e]; st_m[64 * (16 * t + r)] = net.m[e]; st_v[64 * (16 * t + r)] = net.v[e];
+        for (int q = 0; q < 4; ++q) {
+            float w4[4], m4[4], v4[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const size_t e = (size_t)(U0 + rrow(4 * q + j, h)) * HID + 64u * w + 32u * (uint32_t)t + c;
+                w4[j] = net.w2[e]; m4[j] = net.m[e]; v4[j] = net.v[e];
+            }
+            xst4(xr, v_st + 1024u * (uint32_t)q, s_st(0, t), w4); xst4(xr, v_st + 1024u * (uint32_t)q, s_st(1, t), m4); xst4(xr, v_st + 1024u * (uint32_t)q, s_st(2, t), v4);
         }
     {
         const uint32_t u = tid >> 3, k0 = (tid & 7u) * 32u;                            // 8 threads per owned unit, 32 inputs each
@@ -451,6 +441,7 @@ __device__ __forceinline__ void persistent_learner_body(const Args& a, unsigned 
     float amax = 0.0f;
     uint32_t nsat = 0;
     uint32_t bar_n = 0;                                         // barriers passed
+    float lr_prev = 0.0f, rs_prev = 0.0f;                       // the previous step's bias corrections (small_grads)
     // rows of the FIRST step (every later step's are fetched one step ahead): srcX = the sample whose observation this thread stages
     // (threads 0..127), srcL = the sample whose loss this lane pair differentiates
     // (no division in the loop: the position of the next step's window is kept incrementally)
@@ -468,15 +459,111 @@ __device__ __forceinline__ void persistent_learner_body(const Args& a, unsigned 
     request_obs();
     __syncthreads();
 
-    const bool profiling = a.prof != nullptr && blockIdx.x == 0 && tid == 0;      // (workgroup 0 = policy group, g = 0)
-    unsigned long long pacc[20] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    // The SMALL gradients of a step - dW3[:, U] (wave 1), db2[U] (wave 2), db3 and the step's statistics (wave 3 of workgroup 0) -, their
+    // optimizer updates and new operand images.  They need nothing but this workgroup's LDS (dY^T, H2^T, red2, the ones row of [x | 1]^T,
+    // statbuf: all untouched until the next step's barrier 1 has been passed) and nobody needs their results before the next step's P2, so they
+    // are DEFERRED into the window in which the next step waits for barrier 1 (three waves idle there for ~1 us; behind the weight-gradient
+    // tiles they made wave 0 wait for waves 1 .. 3 in front of B2).  b3 is republished there: every workgroup read the old one before it
+    // arrived at barrier 3, the new one is read behind barrier 2.  lr_bc1_ / rs_bc2_: the bias corrections of the step the gradients belong to.
+    // Lane-dependent address parts, made OPAQUE once per step (an empty assembly statement "modifies" them): otherwise every
+    // `base + constant` is a loop invariant, is hoisted out of the step loop and occupies a register of its own for the whole launch (~150
+    // of them, parked in accumulation registers and fetched back with v_accvgpr_read before each use: a quarter of the step's instructions
+    // was such traffic); as values of the current iteration they stay ONE register each and the constants fold into the instructions' offset fields.
+#define Q1PL_OPAQUE(x) asm volatile("" : "+v"(x))
+    uint32_t lW = 0, lB = 0, l16 = 0, lS16 = 0, l32 = 0, lH2W = 0, lwB = 0, lCol = 0, lOwn = 0;            // LDS
+    uint32_t vCol = 0, vYp = 0, pFrag = 0, pW2t = 0, pYp = 0, vSt = 0;                                     // exchange / state buffer offsets
+    auto step_bases = [&]() __attribute__((always_inline)) {
+        lW = c * LD_W + 16u * h; lB = c * LD_B + 16u * h; l16 = c * LD_16 + 16u * h; lS16 = (32u * w + c) * LD_16 + 16u * h; l32 = c * LD_32 + 16u * h;
+        lH2W = w * 32u * LD_32 + c * LD_32 + 16u * h; lwB = c * LD_B + 2u * (32u * w + 4u * h); lCol = (tid >> 3) * LD_W + 16u * (tid & 7u);
+        lOwn = 4u * h * LD_W + 2u * (64u * w + c);
+        vCol = v_col; vYp = v_yp; pFrag = p_frag; pW2t = p_w2t; pYp = p_yp; vSt = v_st;
+        Q1PL_OPAQUE(lW); Q1PL_OPAQUE(lB); Q1PL_OPAQUE(l16); Q1PL_OPAQUE(lS16); Q1PL_OPAQUE(l32); Q1PL_OPAQUE(lH2W); Q1PL_OPAQUE(lwB); Q1PL_OPAQUE(lCol); Q1PL_OPAQUE(lOwn);
+        Q1PL_OPAQUE(vCol); Q1PL_OPAQUE(vYp); Q1PL_OPAQUE(pFrag); Q1PL_OPAQUE(pW2t); Q1PL_OPAQUE(pYp); Q1PL_OPAQUE(vSt);
+    };
+    auto small_grads = [&](const bool store_grads, const float lr_bc1, const float rs_bc2) __attribute__((always_inline)) {
+        if (wu == 1u) {                                          // dW3[:, U]: lane = owned unit, registers = outputs (o = row(r, h) < OUT <= 10: r < 8)
+            float w3v[8], m3v[8], v3v[8];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const uint32_t o = rrow(r, h);
+                const uint32_t i3 = ((int)o < OUT ? o : 0u) * 32u + c;
+                w3v[r] = sW3[i3]; m3v[r] = sW3[320 + i3]; v3v[r] = sW3[640 + i3];
+            }
+            f32x16 acc = zero16;
+#pragma unroll
+            for (int s = 0; s < 8; ++s)
+                acc = mm(lds16(lds, L_DYT + lB + 32u * (uint32_t)s), lds16(lds, L_H2T + lB + 32u * (uint32_t)s), acc);
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const uint32_t o = rrow(r, h);
+                if ((int)o < OUT) {
+                    const float gr = acc[r] * net.inv_scale;
+                    w3v[r] = adam1(w3v[r], gr, m3v[r], v3v[r], a.beta1, a.beta2, a.eps, lr_bc1, rs_bc2);
+                    *reinterpret_cast<_Float16*>(lds + L_W3 + o * LD_32 + 2u * c) = (_Float16)w3v[r];
+                    *reinterpret_cast<_Float16*>(lds + L_W3T + c * LD_16 + 2u * o) = (_Float16)w3v[r];
+                    if (store_grads) net.gw3[(size_t)o * HID + U0 + c] = gr;
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const uint32_t o = rrow(r, h);
+                if ((int)o < OUT) { const uint32_t i3 = o * 32u + c; sW3[i3] = w3v[r]; sW3[320 + i3] = m3v[r]; sW3[640 + i3] = v3v[r]; }
+            }
+        }
+        if (wu == 2u && h == 0u) {                               // db2[U]
+            const size_t u = U0 + c;
+            float b2v = sB2[c], mv = sB2[32 + c], vv = sB2[64 + c];
+            const float gr = (((red2[c] + red2[32u + c]) + red2[64u + c]) + red2[96u + c]) * net.inv_scale;
+            b2v = adam1(b2v, gr, mv, vv, a.beta1, a.beta2, a.eps, lr_bc1, rs_bc2);
+            b2p[c] = c2 * b2v;
+            sB2[c] = b2v; sB2[32 + c] = mv; sB2[64 + c] = vv;
+            if (store_grads) net.gb2[u] = gr;
+        }
+        if (g == 0 && wu == 3u) {
+            f32x16 acc_b3 = zero16;                             // [o][i']: lane (c = 6, h) holds db3[o = row(r, h)] (times the loss scale)
+#pragma unroll
+            for (int s = 0; s < 8; ++s)
+                acc_b3 = mm(lds16(lds, L_DYT + lB + 32u * (uint32_t)s), lds16(lds, L_XT + lB + 32u * (uint32_t)s), acc_b3);
+            float sv[3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                float v = statbuf[k * MB + lane] + statbuf[k * MB + 64 + lane];
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+                sv[k] = v;
+            }
+            if (lane == 0) { st_acc[0] += sv[0] * (1.0f / (float)MB); st_acc[1] += sv[1] * (1.0f / (float)MB); st_acc[2] += sv[2] * (1.0f / (float)MB); }
+            if (c == 6u) {                                      // db3 / b3: the ones column of acc_b3
+                float bv[8], mv[8], vv[8];
+#pragma unroll
+                for (int r = 0; r < 8; ++r) {
+                    const uint32_t o = rrow(r, h), oc = (int)o < OUT ? o : 0u;
+                    bv[r] = sB3[oc]; mv[r] = sB3[16 + oc]; vv[r] = sB3[32 + oc];
+                }
+#pragma unroll
+                for (int r = 0; r < 8; ++r) {
+                    const uint32_t o = rrow(r, h);
+                    if ((int)o < OUT) {
+                        const float gr = acc_b3[r] * net.inv_scale;
+                        bv[r] = adam1(bv[r], gr, mv[r], vv[r], a.beta1, a.beta2, a.eps, lr_bc1, rs_bc2);
+                        sB3[o] = bv[r]; sB3[16 + o] = mv[r]; sB3[32 + o] = vv[r];
+                        if (store_grads) net.gb3[o] = gr;
+                        pub4f(net.b3x + o, bv[r], loc);
+                    }
+                }
+            }
+        }
+    };
+    // (PROF: the instantiation launched under Q1_LEARNER_PROF - the product kernel carries neither the 40 registers nor the clock reads)
+    const bool profiling = PROF && a.prof != nullptr && blockIdx.x == 8u * (uint32_t)a.prof_g && tid == 0;      // (a workgroup of the policy group)
+    unsigned long long pacc[PROF ? 20 : 1] = {};
     uint64_t tprev = profiling ? wall_clock64() : 0;
-#define Q1PL_STAMP(k) do { if (profiling) { const uint64_t now_ = wall_clock64(); pacc[k] += now_ - tprev; tprev = now_; } } while (0)
+#define Q1PL_STAMP(k) do { if constexpr (PROF) { if (profiling) { const uint64_t now_ = wall_clock64(); pacc[k] += now_ - tprev; tprev = now_; } } } while (0)
     for (int64_t step = 0; step < a.steps; ++step) {
         const uint32_t par = (uint32_t)(step & 1);
+        step_bases();
         const bool last = step + 1 == a.steps;
-        uint16_t* const h1x = net.h1x + (size_t)par * MB * HID;
-        uint16_t* const h1tx = net.h1tx + (size_t)par * MB * HID;
+        const uint32_t s_h1x = o_h1x + par * (uint32_t)(MB * HID * 2), s_h1tx = o_h1tx + par * (uint32_t)(MB * HID * 2);
         // ------------------------------------------------------------ this step's rows: everything that depends only on the row index is
         // requested NOW (observation for the operand rows; the loss's per-sample inputs, which are not needed before barrier 2)
         pw1 *= (double)a.beta1;                                   // beta^t, t = step0 + step + 1 (every thread: two float64 multiplies)
@@ -507,21 +594,23 @@ __device__ __forceinline__ void persistent_learner_body(const Args& a, unsigned 
         // ------------------------------------------------------------ P1: layer 1 of the owned units, both orientations
         float h1B[16];                                          // tanh(H1)[b = 32 w + row(r)][u = c] as the float16 operand carries it
         {
-            const f16x8 a1 = lds16(lds, L_W1 + c * LD_16 + 16u * h);
-            const f16x8 x1 = lds16(lds, L_XH + (32u * w + c) * LD_16 + 16u * h);
+            const f16x8 a1 = lds16(lds, L_W1 + l16);
+            const f16x8 x1 = lds16(lds, L_XH + lS16);
             const f32x16 dA = mm(a1, x1, zero16);               // [u][b]: lane = sample, registers = units
             const f32x16 dB = mm(x1, a1, zero16);               // [b][u]: lane = unit, registers = samples
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                pub8(h1x + (size_t)(32u * w + c) * HID + U0 + 8u * q + 4u * h, pack4(act(dA[4 * q]), act(dA[4 * q + 1]), act(dA[4 * q + 2]), act(dA[4 * q + 3])), loc);
+                xpub8(xr, pFrag + fq(q), s_h1x + (wu * 16u + 2u * g) * 1024u, pack4(act(dA[4 * q]), act(dA[4 * q + 1]), act(dA[4 * q + 2]), act(dA[4 * q + 3])), loc);
                 float t4[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) { t4[j] = act(dB[4 * q + j]); h1B[4 * q + j] = r16(t4[j]); }
-                pub8(h1tx + (size_t)(U0 + c) * MB + 32u * w + 8u * q + 4u * h, pack4(t4[0], t4[1], t4[2], t4[3]), loc);
+                xpub8(xr, pFrag + fq(q), s_h1tx + (g * 8u + 2u * wu) * 1024u, pack4(t4[0], t4[1], t4[2], t4[3]), loc);
             }
         }
         Q1PL_STAMP(0);                                          // minibatch rows + P1 + publish
         bar_arrive(net.bar, loc);
+        if (step > 0) small_grads(false, lr_prev, rs_prev);      // (the previous step's: see small_grads)
+        lr_prev = lr_bc1; rs_prev = rs_bc2;
         const int64_t srcL_now = srcL;
         // the NEXT step's row indices, requested while the barrier is in flight
         if (!last) {
@@ -542,8 +631,10 @@ __device__ __forceinline__ void persistent_learner_body(const Args& a, unsigned 
         {
             // every global operand of this phase is requested first: H1 rows of this wave's tile (16 K-steps) and the column block
             f16x8 bH[16], wc[4];
-            const uint32_t jg = tid >> 3, ch = tid & 7u;
-            ld16_4(h1x + (size_t)(32u * w + c) * HID + 8u * h, bH, net.w2tx + (size_t)(U0 + jg) * HID + 8u * ch, wc, loc);
+#pragma unroll
+            for (int s = 0; s < 16; ++s) bH[s] = xld16(xr, vSt + 1024u * (uint32_t)(s & 3), s_h1x + wu * 16384u + 4096u * (uint32_t)(s >> 2));
+#pragma unroll
+            for (int i = 0; i < 4; ++i) wc[i] = xld16(xr, vCol + 128u * (uint32_t)i, o_w2tx);
             {
                 const size_t sl = (size_t)srcL_now;
                 if (ni == 0) { in_kb = (uint32_t)a.keys[sl]; in_a = a.mouse_u[sl]; in_b = a.logp_old[sl]; in_c = a.adv[sl]; }
@@ -551,15 +642,16 @@ __device__ __forceinline__ void persistent_learner_body(const Args& a, unsigned 
 #pragma unroll
                 for (int o = 0; o < 10; ++o) oldrow[o] = ni == 0 ? a.old_logits[sl * (size_t)a.old_stride + (size_t)o] : 0.0f;
             }
+            __builtin_amdgcn_sched_barrier(0);                  // (the requests above are issued HERE, all of them: the scheduler would otherwise sink each to its first use)
             f32x16 accA = zero16, accB = zero16;
 #pragma unroll
             for (int s = 0; s < 16; ++s) {
-                const f16x8 aW = lds16(lds, L_W2OWN + c * LD_W + 32u * (uint32_t)s + 16u * h);
+                const f16x8 aW = lds16(lds, L_W2OWN + lW + 32u * (uint32_t)s);
                 accA = mm(aW, bH[s], accA);
                 accB = mm(bH[s], aW, accB);
             }
 #pragma unroll
-            for (int i = 0; i < 4; ++i) *reinterpret_cast<f16x8*>(lds + L_W2COL + jg * LD_W + 16u * (ch + 8u * (uint32_t)i)) = wc[i];
+            for (int i = 0; i < 4; ++i) *reinterpret_cast<f16x8*>(lds + L_W2COL + lCol + 128u * (uint32_t)i) = wc[i];
             const float bB = b2p[c];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
@@ -571,8 +663,8 @@ __device__ __forceinline__ void persistent_learner_body(const Args& a, unsigned 
                     tA[j] = act(accA[4 * q + j] + bb[j]); h2A[4 * q + j] = r16(tA[j]);
                     tB[j] = act(accB[4 * q + j] + bB); h2B[4 * q + j] = r16(tB[j]);
                 }
-                *reinterpret_cast<uint64_t*>(lds + L_H2W + w * 32u * LD_32 + c * LD_32 + 2u * (8u * q + 4u * h)) = pack4(tA[0], tA[1], tA[2], tA[3]);
-                *reinterpret_cast<uint64_t*>(lds + L_H2T + c * LD_B + 2u * (32u * w + 8u * q + 4u * h)) = pack4(tB[0], tB[1], tB[2], tB[3]);
+                *reinterpret_cast<uint64_t*>(lds + L_H2W + lH2W - 8u * h + 16u * (uint32_t)q) = pack4(tA[0], tA[1], tA[2], tA[3]);
+                *reinterpret_cast<uint64_t*>(lds + L_H2T + lwB + 16u * (uint32_t)q) = pack4(tB[0], tB[1], tB[2], tB[3]);
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
@@ -580,10 +672,9 @@ __device__ __forceinline__ void persistent_learner_body(const Args& a, unsigned 
             f32x16 accY = zero16;                               // [o][b]: lane = sample, registers = outputs
 #pragma unroll
             for (int s = 0; s < 2; ++s)
-                accY = mm(lds16(lds, L_W3 + c * LD_32 + 32u * (uint32_t)s + 16u * h), lds16(lds, L_H2W + w * 32u * LD_32 + c * LD_32 + 32u * (uint32_t)s + 16u * h), accY);
-            float* yrow = net.yp + ((size_t)g * MB + 32u * w + c) * 16u;
-            pub8f(yrow + 4u * h, accY[0], accY[1], loc); pub8f(yrow + 4u * h + 2u, accY[2], accY[3], loc);          // outputs 4 h .. 4 h + 3
-            pub8f(yrow + 8u + 4u * h, accY[4], accY[5], loc); pub8f(yrow + 10u + 4u * h, accY[6], accY[7], loc);    // outputs 8 + 4 h ..
+                accY = mm(lds16(lds, L_W3 + l32 + 32u * (uint32_t)s), lds16(lds, L_H2W + lH2W + 32u * (uint32_t)s), accY);
+            xpub16f(xr, pYp, s_ypg, accY[0], accY[1], accY[2], accY[3], loc);              // outputs 4 h .. 4 h + 3: quad h
+            xpub16f(xr, pYp + 1024u, s_ypg, accY[4], accY[5], accY[6], accY[7], loc);      // outputs 8 + 4 h ..: quad 2 + h
         }
         Q1PL_STAMP(2);                                          // W2 column gather + P2 + partial logits
         bar_arrive(net.bar, loc);
@@ -597,12 +688,19 @@ __device__ __forceinline__ void persistent_learner_body(const Args& a, unsigned 
         float s3[3] = {0.0f, 0.0f, 0.0f};
         float gl[10];
         float wA[16], mA[16], vA[16];                           // (G2's first tile: see below)
+        f16x8 hT[8];                                            // ... and its H1^T operand rows
+        f16x8 zr[16];                                           // B2's operands: this wave's rows of ALL of dZ2 (requested inside G2, behind barrier 3)
         {
             float y[12];
             {
                 f32x4 part[5][3];                               // four partial rows (groups 4 h .. 4 h + 3) + the bias row
-                const float* yb = net.yp + ((size_t)(4u * h) * MB + bsm) * 16u;
-                ld_rows(yb, yb + (size_t)MB * 16, yb + (size_t)2 * MB * 16, yb + (size_t)3 * MB * 16, net.b3x, part, loc);
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int v = 0; v < 3; ++v) part[q][v] = xld4f(xr, vYp + 512u * (uint32_t)v, o_yp + ((uint32_t)q * 4u + wu) * 2048u);
+#pragma unroll
+                for (int v = 0; v < 3; ++v) part[4][v] = xld4f(xr, 16u * (uint32_t)v, o_b3x);
+                __builtin_amdgcn_sched_barrier(0);                  // (the requests above are issued HERE, all of them: the scheduler would otherwise sink each to its first use)
                 float half_[12];
 #pragma unroll
                 for (int v = 0; v < 3; ++v)
@@ -617,9 +715,12 @@ __device__ __forceinline__ void persistent_learner_body(const Args& a, unsigned 
             }
             // tile 0's optimizer state for G2 (private, coalesced): requested here, two phases early - its L2 round trip was 0.8 us at the head of G2
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { wA[r] = st_w[64 * r]; mA[r] = st_m[64 * r]; vA[r] = st_v[64 * r]; }
+            for (int q = 0; q < 4; ++q) { xld4(xr, vSt + 1024u * (uint32_t)q, s_st(0, 0), wA + 4 * q); xld4(xr, vSt + 1024u * (uint32_t)q, s_st(1, 0), mA + 4 * q); xld4(xr, vSt + 1024u * (uint32_t)q, s_st(2, 0), vA + 4 * q); }
+#pragma unroll
+            for (int s = 0; s < 8; ++s) hT[s] = xld16(xr, vSt + 1024u * (uint32_t)(s & 3), s_h1tx + wu * 16384u + 4096u * (uint32_t)(s >> 2));    // (H1^T has been complete since barrier 1)
             if (!last) request_obs();                           // the NEXT step's observation rows (srcX was advanced behind barrier 1); behind this
                                                                 // phase's own requests, ~2 us ahead of the next wait on the memory counter
+            __builtin_amdgcn_sched_barrier(0);                  // (the requests above are issued HERE, all of them: the scheduler would otherwise sink each to its first use)
             Q1PL_STAMP(10);                                     // (loss: the outputs summed)
 #pragma unroll
             for (int o = 0; o < 10; ++o) gl[o] = 0.0f;
@@ -661,8 +762,8 @@ __device__ __forceinline__ void persistent_learner_body(const Args& a, unsigned 
 
         // ------------------------------------------------------------ B3: dZ2 of the owned units, both orientations
         {
-            const f16x8 aT = lds16(lds, L_W3T + c * LD_16 + 16u * h);
-            const f16x8 bY = lds16(lds, L_DY + (32u * w + c) * LD_16 + 16u * h);
+            const f16x8 aT = lds16(lds, L_W3T + l16);
+            const f16x8 bY = lds16(lds, L_DY + lS16);
             const f32x16 dA = mm(aT, bY, zero16);               // [u][b]: lane = sample (h2A's layout)
             const f32x16 dB = mm(bY, aT, zero16);               // [b][u]: lane = unit   (h2B's layout)
             float sb = 0.0f;
@@ -675,8 +776,8 @@ __device__ __forceinline__ void persistent_learner_body(const Args& a, unsigned 
                     zB[j] = sat16(dB[4 * q + j] * (1.0f - h2B[4 * q + j] * h2B[4 * q + j]), amax, nsat);
                     sb += r16(zB[j]);
                 }
-                pub8(net.dz2x + (size_t)(32u * w + c) * HID + U0 + 8u * q + 4u * h, pack4(zA[0], zA[1], zA[2], zA[3]), loc);
-                *reinterpret_cast<uint64_t*>(lds + L_DZ2T + c * LD_B + 2u * (32u * w + 8u * q + 4u * h)) = pack4(zB[0], zB[1], zB[2], zB[3]);
+                xpub8(xr, pFrag + fq(q), o_dz2x + (wu * 16u + 2u * g) * 1024u, pack4(zA[0], zA[1], zA[2], zA[3]), loc);
+                *reinterpret_cast<uint64_t*>(lds + L_DZ2T + lwB + 16u * (uint32_t)q) = pack4(zB[0], zB[1], zB[2], zB[3]);
             }
             sb += __shfl_xor(sb, 32, 64);
             if (h == 0) red2[w * 32u + c] = sb;
@@ -694,10 +795,12 @@ __device__ __forceinline__ void persistent_learner_body(const Args& a, unsigned 
             // (in flight under tile 0's optimizer arithmetic), tile 0 is stored, tile 1's operands are requested - one wait covers them, tile 1's
             // state and tile 0's store acknowledgements.  (Everything of both tiles at once was measured: 96 + 64 live registers spill inside the
             // loop, 20.4 -> 23.0 us per step.)
-            auto adam_tile = [&](const int t, const f32x16& acc, float (&w2v)[16], float (&m2v)[16], float (&v2v)[16]) __attribute__((always_inline)) {
+            // (two parts: the arithmetic + the new float16 image in LDS;  the global stores - state back, the W2^T rows published: the poll of
+            //  barrier 3 sits between them, so that it never queues behind 64 stores)
+            auto adam_tile = [&](const int t, const int q0, const int q1, const f32x16& acc, float (&w2v)[16], float (&m2v)[16], float (&v2v)[16]) __attribute__((always_inline)) {
                 const uint32_t k = 64u * w + 32u * (uint32_t)t + c;
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
+                for (int q = q0; q < q1; ++q) {
 #pragma unroll
                     for (int j = 0; j < 4; j += 2) {
                         const int r = 4 * q + j;
@@ -706,108 +809,74 @@ __device__ __forceinline__ void persistent_learner_body(const Args& a, unsigned 
                         const f32x2 wn = adam2(f32x2{w2v[r], w2v[r + 1]}, gr, mm2, vv2, a.beta1, a.beta2, a.eps, lr_bc1, rs_bc2);
                         w2v[r] = wn.x; w2v[r + 1] = wn.y; m2v[r] = mm2.x; m2v[r + 1] = mm2.y; v2v[r] = vv2.x; v2v[r + 1] = vv2.y;
                         const f32x2 wi = c2 * wn;
-                        *reinterpret_cast<_Float16*>(lds + L_W2OWN + rrow(r, h) * LD_W + 2u * k) = (_Float16)wi.x;
-                        *reinterpret_cast<_Float16*>(lds + L_W2OWN + rrow(r + 1, h) * LD_W + 2u * k) = (_Float16)wi.y;
-                        if (last) { net.gw2[(size_t)(U0 + rrow(r, h)) * HID + k] = gr.x; net.gw2[(size_t)(U0 + rrow(r + 1, h)) * HID + k] = gr.y; }
+                        *reinterpret_cast<_Float16*>(lds + L_W2OWN + (uint32_t)((r & 3) + 8 * (r >> 2)) * LD_W + lOwn + 64u * (uint32_t)t) = (_Float16)wi.x;
+                        *reinterpret_cast<_Float16*>(lds + L_W2OWN + (uint32_t)(((r + 1) & 3) + 8 * ((r + 1) >> 2)) * LD_W + lOwn + 64u * (uint32_t)t) = (_Float16)wi.y;
+                        if (last) {                     // (inspection / tests: a cold block - its 32 addresses must not be hoisted out of the step loop)
+                            uint32_t kk = k;
+                            Q1PL_OPAQUE(kk);
+                            net.gw2[(size_t)(U0 + rrow(r, h)) * HID + kk] = gr.x; net.gw2[(size_t)(U0 + rrow(r + 1, h)) * HID + kk] = gr.y;
+                        }
                     }
-                    pub8(net.w2tx + (size_t)k * HID + U0 + 8u * q + 4u * h, pack4(w2v[4 * q], w2v[4 * q + 1], w2v[4 * q + 2], w2v[4 * q + 3]), loc);
                 }
+            };
+            auto store_tile = [&](const int t, const float (&w2v)[16], const float (&m2v)[16], const float (&v2v)[16]) __attribute__((always_inline)) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) { st_w[64 * (16 * t + r)] = w2v[r]; st_m[64 * (16 * t + r)] = m2v[r]; st_v[64 * (16 * t + r)] = v2v[r]; }
+                for (int q = 0; q < 4; ++q)
+                    xpub8(xr, pW2t + 16u * (uint32_t)q, o_w2tx + 2u * U0 + 16384u * (uint32_t)t, pack4(w2v[4 * q], w2v[4 * q + 1], w2v[4 * q + 2], w2v[4 * q + 3]), loc);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { xst4(xr, vSt + 1024u * (uint32_t)q, s_st(0, (uint32_t)t), w2v + 4 * q); xst4(xr, vSt + 1024u * (uint32_t)q, s_st(1, (uint32_t)t), m2v + 4 * q); xst4(xr, vSt + 1024u * (uint32_t)q, s_st(2, (uint32_t)t), v2v + 4 * q); }
             };
             float wB[16], mB[16], vB[16];
-            f16x8 hT[8];
-            ld8(h1tx + (size_t)(64u * w + c) * MB + 8u * h, hT, loc);           // (tile 0's state was requested in the loss phase)
-            Q1PL_STAMP(14);                                     // (G2: tile 0's state + operands arrived)
+            f16x8 hU[8];
+            Q1PL_STAMP(14);                                     // (G2 entered: tile 0's state + operands were requested in the loss phase)
             f32x16 acc = zero16;                                // [u][k]: lane = input k, registers = owned units
 #pragma unroll
-            for (int s = 0; s < 8; ++s) acc = mm(lds16(lds, L_DZ2T + c * LD_B + 32u * (uint32_t)s + 16u * h), hT[s], acc);
+            for (int s = 0; s < 8; ++s) acc = mm(lds16(lds, L_DZ2T + lB + 32u * (uint32_t)s), hT[s], acc);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { wB[r] = st_w[64 * (16 + r)]; mB[r] = st_m[64 * (16 + r)]; vB[r] = st_v[64 * (16 + r)]; }
-            adam_tile(0, acc, wA, mA, vA);
-            Q1PL_STAMP(15);                                     // (G2: tile 0's products + optimizer + stores issued)
-            ld8(h1tx + (size_t)(64u * w + 32u + c) * MB + 8u * h, hT, loc);
-            Q1PL_STAMP(16);                                     // (G2: tile 1's operands arrived)
+            for (int s = 0; s < 8; ++s) hU[s] = xld16(xr, vSt + 1024u * (uint32_t)(s & 3), s_h1tx + wu * 16384u + 8192u + 4096u * (uint32_t)(s >> 2));
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { xld4(xr, vSt + 1024u * (uint32_t)q, s_st(0, 1), wB + 4 * q); xld4(xr, vSt + 1024u * (uint32_t)q, s_st(1, 1), mB + 4 * q); xld4(xr, vSt + 1024u * (uint32_t)q, s_st(2, 1), vB + 4 * q); }
+            __builtin_amdgcn_sched_barrier(0);                  // (the requests above are issued HERE, all of them: the scheduler would otherwise sink each to its first use)
+            // barrier 3 is polled from HERE: the reading is requested before tile 0's optimizer arithmetic (no store of this wave is in flight:
+            // the counter retires behind nothing but loads) and looked at after it - every workgroup arrived right behind its dZ2, ~1 us ago -,
+            // then B2's operands (all of dZ2: 16 vectors per lane) are requested and travel under tile 0's stores and all of tile 1
+            // (two readings, one before and one in the middle of the arithmetic: the counter is ~1 us away, the later reading is the one that
+            //  usually shows all eight tickets and it has come back by the time the arithmetic ends)
+            const uint32_t seen3a = tid == 0 ? poll(net.bar, loc) : 0u;
+            adam_tile(0, 0, 2, acc, wA, mA, vA);
+            const uint32_t seen3b = tid == 0 ? poll(net.bar, loc) : 0u;
+            adam_tile(0, 2, 4, acc, wA, mA, vA);
+            Q1PL_STAMP(15);                                     // (G2: tile 0's products + optimizer)
+            if (!bar_wait(net.bar, (uint32_t)G * ++bar_n, loc, a.status, 2u, (uint32_t)step, a.timeout_ticks, s_ok, seen3a > seen3b ? seen3a : seen3b)) return;
+            Q1PL_STAMP(7);                                      // (barrier 3 wait)
+#pragma unroll
+            for (int s = 0; s < 16; ++s) zr[s] = xld16(xr, vSt + 1024u * (uint32_t)(s & 3), o_dz2x + wu * 16384u + 4096u * (uint32_t)(s >> 2));
+            __builtin_amdgcn_sched_barrier(0);                  // (the requests above are issued HERE, all of them: the scheduler would otherwise sink each to its first use)
+            store_tile(0, wA, mA, vA);
+            Q1PL_STAMP(16);                                     // (B2's requests + tile 0's stores issued)
             acc = zero16;
 #pragma unroll
-            for (int s = 0; s < 8; ++s) acc = mm(lds16(lds, L_DZ2T + c * LD_B + 32u * (uint32_t)s + 16u * h), hT[s], acc);
-            adam_tile(1, acc, wB, mB, vB);
+            for (int s = 0; s < 8; ++s) acc = mm(lds16(lds, L_DZ2T + lB + 32u * (uint32_t)s), hU[s], acc);
+            adam_tile(1, 0, 4, acc, wB, mB, vB);
+            store_tile(1, wB, mB, vB);
             Q1PL_STAMP(17);                                     // (G2: tile 1 done)
         }
-        if (w == 1u) {                                          // dW3[:, U]: lane = owned unit, registers = outputs (o = row(r, h) < OUT <= 10: r < 8)
-            float w3v[8], m3v[8], v3v[8];
-#pragma unroll
-            for (int r = 0; r < 8; ++r) {
-                const uint32_t o = rrow(r, h);
-                const uint32_t i3 = ((int)o < OUT ? o : 0u) * 32u + c;
-                w3v[r] = sW3[i3]; m3v[r] = sW3[320 + i3]; v3v[r] = sW3[640 + i3];
-            }
-            f32x16 acc = zero16;
-#pragma unroll
-            for (int s = 0; s < 8; ++s)
-                acc = mm(lds16(lds, L_DYT + c * LD_B + 32u * (uint32_t)s + 16u * h), lds16(lds, L_H2T + c * LD_B + 32u * (uint32_t)s + 16u * h), acc);
-#pragma unroll
-            for (int r = 0; r < 8; ++r) {
-                const uint32_t o = rrow(r, h);
-                if ((int)o < OUT) {
-                    const float gr = acc[r] * net.inv_scale;
-                    w3v[r] = adam1(w3v[r], gr, m3v[r], v3v[r], a.beta1, a.beta2, a.eps, lr_bc1, rs_bc2);
-                    *reinterpret_cast<_Float16*>(lds + L_W3 + o * LD_32 + 2u * c) = (_Float16)w3v[r];
-                    *reinterpret_cast<_Float16*>(lds + L_W3T + c * LD_16 + 2u * o) = (_Float16)w3v[r];
-                    if (last) net.gw3[(size_t)o * HID + U0 + c] = gr;
-                }
-            }
-#pragma unroll
-            for (int r = 0; r < 8; ++r) {
-                const uint32_t o = rrow(r, h);
-                if ((int)o < OUT) { const uint32_t i3 = o * 32u + c; sW3[i3] = w3v[r]; sW3[320 + i3] = m3v[r]; sW3[640 + i3] = v3v[r]; }
-            }
-        }
-        if (w == 2u && h == 0u) {                               // db2[U]
-            const size_t u = U0 + c;
-            float b2v = sB2[c], mv = sB2[32 + c], vv = sB2[64 + c];
-            const float gr = (((red2[c] + red2[32u + c]) + red2[64u + c]) + red2[96u + c]) * net.inv_scale;
-            b2v = adam1(b2v, gr, mv, vv, a.beta1, a.beta2, a.eps, lr_bc1, rs_bc2);
-            b2p[c] = c2 * b2v;
-            sB2[c] = b2v; sB2[32 + c] = mv; sB2[64 + c] = vv;
-            if (last) net.gb2[u] = gr;
-        }
-        f32x16 acc_b3 = zero16;                                 // [o][i']: lane (c = 6, h) holds db3[o = row(r, h)] (times the loss scale)
-        if (g == 0 && w == 3u) {
-#pragma unroll
-            for (int s = 0; s < 8; ++s)
-                acc_b3 = mm(lds16(lds, L_DYT + c * LD_B + 32u * (uint32_t)s + 16u * h), lds16(lds, L_XT + c * LD_B + 32u * (uint32_t)s + 16u * h), acc_b3);
-            float sv[3];
-#pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                float v = statbuf[k * MB + lane] + statbuf[k * MB + 64 + lane];
-#pragma unroll
-                for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-                sv[k] = v;
-            }
-            if (lane == 0) { st_acc[0] += sv[0] * (1.0f / (float)MB); st_acc[1] += sv[1] * (1.0f / (float)MB); st_acc[2] += sv[2] * (1.0f / (float)MB); }
-        }
-        Q1PL_STAMP(6);                                          // dW2 + Adam + images (wave 0's share)
-        if (!bar_wait(net.bar, (uint32_t)G * ++bar_n, loc, a.status, 2u, (uint32_t)step, a.timeout_ticks, s_ok)) return;
-        Q1PL_STAMP(7);                                          // barrier 3 wait (incl. waiting for this workgroup's other waves)
 
         // ------------------------------------------------------------ B2: dH1 of the owned units from all of dZ2, dZ1, then dW1 / db1, db3
         {
-            f16x8 zr[16];
-            ld16(net.dz2x + (size_t)(32u * w + c) * HID + 8u * h, zr, loc);
             f32x16 acc = zero16;                                // [b][j]: lane = owned unit j, registers = samples (h1B's layout)
 #pragma unroll
-            for (int s = 0; s < 16; ++s) acc = mm(zr[s], lds16(lds, L_W2COL + c * LD_W + 32u * (uint32_t)s + 16u * h), acc);
+            for (int s = 0; s < 16; ++s) acc = mm(zr[s], lds16(lds, L_W2COL + lW + 32u * (uint32_t)s), acc);
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 float z[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) z[j] = sat16(acc[4 * q + j] * (1.0f - h1B[4 * q + j] * h1B[4 * q + j]), amax, nsat);
-                *reinterpret_cast<uint64_t*>(lds + L_DZ1T + c * LD_B + 2u * (32u * w + 8u * q + 4u * h)) = pack4(z[0], z[1], z[2], z[3]);
+                *reinterpret_cast<uint64_t*>(lds + L_DZ1T + lwB + 16u * (uint32_t)q) = pack4(z[0], z[1], z[2], z[3]);
             }
         }
         __syncthreads();
-        if (w == 2u) {                                          // dW1[U] / db1[U]: [i'][u]: lane = owned unit, registers = rows of [x hi | 1 | x lo]^T
+        if (wu == 2u) {                                         // dW1[U] / db1[U]: [i'][u]: lane = owned unit, registers = rows of [x hi | 1 | x lo]^T
             // h = 0: registers 0..3 = inputs 0..3 (hi), 4..7 = the same inputs' lo rows;  h = 1: 0, 1 = inputs 4, 5 (hi), 2 = the ones row, 4, 5 = lo of 4, 5
             const size_t u = U0 + c;
             const int base = h ? 4 : 0;
@@ -822,7 +891,7 @@ __device__ __forceinline__ void persistent_learner_body(const Args& a, unsigned 
             f32x16 acc = zero16;
 #pragma unroll
             for (int s = 0; s < 8; ++s)
-                acc = mm(lds16(lds, L_XT + c * LD_B + 32u * (uint32_t)s + 16u * h), lds16(lds, L_DZ1T + c * LD_B + 32u * (uint32_t)s + 16u * h), acc);
+                acc = mm(lds16(lds, L_XT + lB + 32u * (uint32_t)s), lds16(lds, L_DZ1T + lB + 32u * (uint32_t)s), acc);
             _Float16* row = reinterpret_cast<_Float16*>(lds + L_W1 + c * LD_16);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -847,40 +916,31 @@ __device__ __forceinline__ void persistent_learner_body(const Args& a, unsigned 
                 if (h == 0u || j < 2) { const uint32_t i1 = c * 6u + (uint32_t)(base + j); sW1[i1] = w1v[j]; sW1[192 + i1] = m1v[j]; sW1[384 + i1] = v1v[j]; }
             if (h) { sB1[c] = b1v; sB1[32 + c] = mb1; sB1[64 + c] = vb1; }
         }
-        if (g == 0 && w == 3u && c == 6u) {                     // db3 / b3 (after barrier 3: every workgroup has read this step's b3): the ones column of acc_b3
-            float bv[8], mv[8], vv[8];
-#pragma unroll
-            for (int r = 0; r < 8; ++r) {
-                const uint32_t o = rrow(r, h), oc = (int)o < OUT ? o : 0u;
-                bv[r] = sB3[oc]; mv[r] = sB3[16 + oc]; vv[r] = sB3[32 + oc];
-            }
-#pragma unroll
-            for (int r = 0; r < 8; ++r) {
-                const uint32_t o = rrow(r, h);
-                if ((int)o < OUT) {
-                    const float gr = acc_b3[r] * net.inv_scale;
-                    bv[r] = adam1(bv[r], gr, mv[r], vv[r], a.beta1, a.beta2, a.eps, lr_bc1, rs_bc2);
-                    sB3[o] = bv[r]; sB3[16 + o] = mv[r]; sB3[32 + o] = vv[r];
-                    if (last) net.gb3[o] = gr;
-                    pub4f(net.b3x + o, bv[r], loc);
-                }
-            }
-        }
         __syncthreads();
         Q1PL_STAMP(8);                                          // B2 + dW1 + end of step
     }
 #undef Q1PL_STAMP
-    if (profiling)
-        for (int k = 0; k < 20; ++k) a.prof[k] = pacc[k];
+    step_bases();
+    small_grads(true, lr_prev, rs_prev);                        // the last step's
+    __syncthreads();
+    if constexpr (PROF) {
+        if (profiling)
+            for (int k = 0; k < 20; ++k) a.prof[k] = pacc[k];
+    }
 
     // ---------------------------------------------------------------- epilogue: the W2 slice's optimizer state back to its torch layouts; counters
     small_state(false);
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const size_t e = (size_t)(U0 + rrow(r, h)) * HID + 64u * w + 32u * (uint32_t)t + c;
-            net.w2[e] = st_w[64 * (16 * t + r)]; net.m[e] = st_m[64 * (16 * t + r)]; net.v[e] = st_v[64 * (16 * t + r)];
+        for (int q = 0; q < 4; ++q) {
+            float w4[4], m4[4], v4[4];
+            xld4(xr, vSt + 1024u * (uint32_t)q, s_st(0, t), w4); xld4(xr, vSt + 1024u * (uint32_t)q, s_st(1, t), m4); xld4(xr, vSt + 1024u * (uint32_t)q, s_st(2, t), v4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const size_t e = (size_t)(U0 + rrow(4 * q + j, h)) * HID + 64u * w + 32u * (uint32_t)t + c;
+                net.w2[e] = w4[j]; net.m[e] = m4[j]; net.v[e] = v4[j];
+            }
         }
     if (g == 0 && tid == 192u) {                                // (wave 3's lane 0 kept the running statistics)
         if (ni == 0) {
@@ -896,13 +956,14 @@ __device__ __forceinline__ void persistent_learner_body(const Args& a, unsigned 
     }
 }
 
+template <bool PROF>
 __global__ void __launch_bounds__(256, 1)
 persistent_learner_kernel(Args a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     // (placement: see persistent_learner_body)
     const uint32_t role = blockIdx.x & 7u;
-    if (role == 0u) persistent_learner_body<0>(a, lds);
-    else if (role == 1u) persistent_learner_body<1>(a, lds);
+    if (role == 0u) persistent_learner_body<0, PROF>(a, lds);
+    else if (role == 1u) persistent_learner_body<1, PROF>(a, lds);
 }
 
 }  // namespace q1pl

@@ -34,7 +34,7 @@ def main():
     out["status"] = nat.persistent_status()
     if os.environ.get("Q1_LEARNER_PROF"):
         ticks = nat._pws[24:24 + 160].view(torch.int64).cpu().tolist()
-        names = ["rows+P1", "barrier1", "gather+P2+L3", "barrier2", "loss", "B3+arrive3", "dW2+Adam", "barrier3", "B2+dW1", "-", "loss:ysum", "loss:ppo", "loss:rows", "-", "G2:wait0", "G2:tile0", "G2:wait1", "G2:tile1", "-", "-"]  # (loss = its three parts + the reductions)
+        names = ["rows+P1", "barrier1", "gather+P2+L3", "barrier2", "loss", "B3+arrive3", "dW2+Adam", "barrier3", "B2+dW1", "-", "loss:ysum", "loss:ppo", "loss:rows", "-", "G2:wait0", "G2:tile0", "G2:zr+stores0", "G2:tile1", "-", "-"]  # (loss = its three parts + the reductions)
         out["prof_us_per_step"] = {nm: t * 0.01 / n for nm, t in zip(names, ticks)}
     nat.images()
     # the four-launch step, eager (no graph): 391 steps
