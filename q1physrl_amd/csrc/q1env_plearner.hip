@@ -111,6 +111,7 @@ int q1env_learner_sgd_epochs(q1env_t* h, const q1env_learner_net* pi, const q1en
     fill(a.net[1], vf, m_vf, v_vf, pw[1], 1.0f / learner_value_downscale(h), learner_value_downscale(h) / mbf);
     a.idx = b->idx_dev; a.spe = steps_per_epoch; a.epoch_stride = epoch_stride;
     a.obs = b->obs_dev; a.old_logits = b->old_logits_dev; a.old_stride = b->old_stride;
+    a.wide_old = (b->old_stride % 2 == 0 && ((uintptr_t)b->old_logits_dev & 7u) == 0) ? 1 : 0;
     a.keys = b->keys_dev; a.mouse_u = mouse_u; a.logp_old = b->logp_old_dev; a.adv = b->adv_dev; a.value_old = b->value_old_dev; a.vtarg = b->vtarg_dev;
     a.clip = b->clip_param; a.vf_clip = b->vf_clip_param; a.vf_coeff = b->vf_loss_coeff; a.ent_coeff = b->entropy_coeff;
     a.klc_dev = b->kl_coeff_dev;

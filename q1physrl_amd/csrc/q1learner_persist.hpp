@@ -85,7 +85,8 @@ struct Net {
     uint16_t* h1x;        // [2 parity][4 sample tiles w][16 K-steps s][64 lanes (c = sample, h)][8]: H1[32 w + c][16 s + 8 h ..]
     uint16_t* h1tx;       // [2 parity][8 unit tiles g][8 K-steps s][64 lanes (c = unit, h)][8]: H1[16 s + 8 h ..][32 g + c]
     uint16_t* dz2x;       // [4][16][64][8]: dZ2 in H1's form
-    uint16_t* w2tx;       // [256 j][256 k]: W2[k][j]
+    uint16_t* w2tx;       // [8 consumers g'][8 producers g][4 q][32 c][2 h][4]: W2[32 g + 8 q + 4 h ..][32 g' + c] - what lane (c, h) of the owner publishes in one
+                          // 8-byte store, so a publishing request is one contiguous 512 B and a consumer's column block one contiguous 16 KB
     float* yp;            // [G][4 sample tiles w][4 output quads v][32 samples c][4]: partial logits 4 v .. 4 v + 3 of sample 32 w + c
     float* b3x;           // [16]: the output layer's bias as the group reads it (published by workgroup 0 after every step), zero padded
     float* w2st;          // [G][3 (master, m, v)][4 waves][8 slot quads][64 lanes][4]: the W2 slice's optimizer state in its OWNER LANE's order
@@ -101,6 +102,7 @@ struct Args {
     // the train batch (q1env_learner_batch; mouse_u = mouse_u_kernel's output in the workspace) and the minibatch schedule: step n reads rows idx[(n / spe) * epoch_stride + (n % spe) * 128 + b]
     const int64_t* idx; int64_t spe, epoch_stride;
     const float* obs; const float* old_logits; int old_stride;
+    int wide_old;              // old_logits rows are 8-byte aligned: read as five 8-byte loads
     const uint8_t* keys; const float* mouse_u; const float* logp_old; const float* adv; const float* value_old; const float* vtarg;
     float clip, vf_clip, vf_coeff, ent_coeff;
     const float* klc_dev;
@@ -331,12 +333,10 @@ __device__ __forceinline__ void persistent_learner_body(const Args& a, unsigned 
     const __amdgpu_buffer_rsrc_t xr = xrsrc(net.xbase);
     auto xoff = [&](const void* q) { return (uint32_t)(reinterpret_cast<const char*>(q) - net.xbase); };
     const uint32_t o_h1x = xoff(net.h1x), o_h1tx = xoff(net.h1tx), o_dz2x = xoff(net.dz2x), o_w2tx = xoff(net.w2tx), o_yp = xoff(net.yp), o_b3x = xoff(net.b3x);
-    const uint32_t v_col = ((U0 + (tid >> 3)) * (uint32_t)HID + 8u * (tid & 7u)) * 2u;   // this thread's chunks of W2's column block: + 128 i
     const uint32_t wu = (uint32_t)__builtin_amdgcn_readfirstlane((int)w);        // the wave index as the scalar it is
     const uint32_t o_w2st = xoff(net.w2st);
     // ... publishes: (row, 4 h) of a [128 b][256 k] array (+ 2 U0 + 16 q), of H1^T (+ 2 U0 MB + 16 q), of W2^T (+ 2 U0 + 16384 t + 16 q), of the partial logits
     const uint32_t p_frag = c * 16u + 8u * h;                                    // a 4-element piece of a fragment-order array: + 512 (q & 1) + 1024 (q >> 1), block offset scalar
-    const uint32_t p_w2t = ((64u * w + c) * (uint32_t)HID + 4u * h) * 2u;
     const uint32_t p_yp = c * 16u + 512u * h;                                    // this lane's output quad h (+ 1024: quad 2 + h) of sample c
     const uint32_t s_ypg = o_yp + (g * 4u + wu) * 2048u;
     // ... the W2 slice's optimizer state, [g][kind][wave][8 slot quads][64 lanes][4] floats: lane offset + scalar (kind, wave, tile) + 1024 (r / 4)
@@ -403,7 +403,8 @@ __device__ __forceinline__ void persistent_learner_body(const Args& a, unsigned 
             const float wv = src[k];
             *reinterpret_cast<_Float16*>(lds + L_W2OWN + u * LD_W + 2u * (k0 + k)) = (_Float16)(c2 * wv);
             union { _Float16 hh; uint16_t b; } o; o.hh = (_Float16)wv;
-            __hip_atomic_store(net.w2tx + (size_t)(k0 + k) * HID + U0 + u, o.b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const uint32_t kk = k0 + k;
+            __hip_atomic_store(net.w2tx + (((size_t)(kk >> 5) * 8 + g) * 4 + (u >> 3)) * 256 + (kk & 31u) * 8u + ((u >> 2) & 1u) * 4u + (u & 3u), o.b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
     if (tid < 32u) {
@@ -471,14 +472,14 @@ __device__ __forceinline__ void persistent_learner_body(const Args& a, unsigned 
     // was such traffic); as values of the current iteration they stay ONE register each and the constants fold into the instructions' offset fields.
 #define Q1PL_OPAQUE(x) asm volatile("" : "+v"(x))
     uint32_t lW = 0, lB = 0, l16 = 0, lS16 = 0, l32 = 0, lH2W = 0, lwB = 0, lCol = 0, lOwn = 0;            // LDS
-    uint32_t vCol = 0, vYp = 0, pFrag = 0, pW2t = 0, pYp = 0, vSt = 0;                                     // exchange / state buffer offsets
+    uint32_t vYp = 0, pFrag = 0, pYp = 0, vSt = 0;                                     // exchange / state buffer offsets
     auto step_bases = [&]() __attribute__((always_inline)) {
         lW = c * LD_W + 16u * h; lB = c * LD_B + 16u * h; l16 = c * LD_16 + 16u * h; lS16 = (32u * w + c) * LD_16 + 16u * h; l32 = c * LD_32 + 16u * h;
-        lH2W = w * 32u * LD_32 + c * LD_32 + 16u * h; lwB = c * LD_B + 2u * (32u * w + 4u * h); lCol = (tid >> 3) * LD_W + 16u * (tid & 7u);
+        lH2W = w * 32u * LD_32 + c * LD_32 + 16u * h; lwB = c * LD_B + 2u * (32u * w + 4u * h); lCol = (tid & 31u) * LD_W + 16u * (tid >> 5);
         lOwn = 4u * h * LD_W + 2u * (64u * w + c);
-        vCol = v_col; vYp = v_yp; pFrag = p_frag; pW2t = p_w2t; pYp = p_yp; vSt = v_st;
+        vYp = v_yp; pFrag = p_frag; pYp = p_yp; vSt = v_st;
         Q1PL_OPAQUE(lW); Q1PL_OPAQUE(lB); Q1PL_OPAQUE(l16); Q1PL_OPAQUE(lS16); Q1PL_OPAQUE(l32); Q1PL_OPAQUE(lH2W); Q1PL_OPAQUE(lwB); Q1PL_OPAQUE(lCol); Q1PL_OPAQUE(lOwn);
-        Q1PL_OPAQUE(vCol); Q1PL_OPAQUE(vYp); Q1PL_OPAQUE(pFrag); Q1PL_OPAQUE(pW2t); Q1PL_OPAQUE(pYp); Q1PL_OPAQUE(vSt);
+        Q1PL_OPAQUE(vYp); Q1PL_OPAQUE(pFrag); Q1PL_OPAQUE(pYp); Q1PL_OPAQUE(vSt);
     };
     auto small_grads = [&](const bool store_grads, const float lr_bc1, const float rs_bc2) __attribute__((always_inline)) {
         if (wu == 1u) {                                          // dW3[:, U]: lane = owned unit, registers = outputs (o = row(r, h) < OUT <= 10: r < 8)
@@ -634,13 +635,19 @@ __device__ __forceinline__ void persistent_learner_body(const Args& a, unsigned 
 #pragma unroll
             for (int s = 0; s < 16; ++s) bH[s] = xld16(xr, vSt + 1024u * (uint32_t)(s & 3), s_h1x + wu * 16384u + 4096u * (uint32_t)(s >> 2));
 #pragma unroll
-            for (int i = 0; i < 4; ++i) wc[i] = xld16(xr, vCol + 128u * (uint32_t)i, o_w2tx);
+            for (int i = 0; i < 4; ++i) wc[i] = xld16(xr, vSt, o_w2tx + g * 16384u + wu * 1024u + 4096u * (uint32_t)i);      // vector tid + 256 i of this workgroup's 16 KB
             {
                 const size_t sl = (size_t)srcL_now;
                 if (ni == 0) { in_kb = (uint32_t)a.keys[sl]; in_a = a.mouse_u[sl]; in_b = a.logp_old[sl]; in_c = a.adv[sl]; }
                 else { in_a = a.value_old[sl]; in_b = a.vtarg[sl]; }
+                if (ni == 0 && a.wide_old) {
+                    const float2* r2 = reinterpret_cast<const float2*>(a.old_logits + sl * (size_t)a.old_stride);
 #pragma unroll
-                for (int o = 0; o < 10; ++o) oldrow[o] = ni == 0 ? a.old_logits[sl * (size_t)a.old_stride + (size_t)o] : 0.0f;
+                    for (int o = 0; o < 10; o += 2) { const float2 p2 = r2[o >> 1]; oldrow[o] = p2.x; oldrow[o + 1] = p2.y; }
+                } else {
+#pragma unroll
+                    for (int o = 0; o < 10; ++o) oldrow[o] = ni == 0 ? a.old_logits[sl * (size_t)a.old_stride + (size_t)o] : 0.0f;
+                }
             }
             __builtin_amdgcn_sched_barrier(0);                  // (the requests above are issued HERE, all of them: the scheduler would otherwise sink each to its first use)
             f32x16 accA = zero16, accB = zero16;
@@ -822,7 +829,7 @@ __device__ __forceinline__ void persistent_learner_body(const Args& a, unsigned 
             auto store_tile = [&](const int t, const float (&w2v)[16], const float (&m2v)[16], const float (&v2v)[16]) __attribute__((always_inline)) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
-                    xpub8(xr, pW2t + 16u * (uint32_t)q, o_w2tx + 2u * U0 + 16384u * (uint32_t)t, pack4(w2v[4 * q], w2v[4 * q + 1], w2v[4 * q + 2], w2v[4 * q + 3]), loc);
+                    xpub8(xr, pFrag + 512u * (uint32_t)q, o_w2tx + ((2u * wu + (uint32_t)t) * 8u + g) * 2048u, pack4(w2v[4 * q], w2v[4 * q + 1], w2v[4 * q + 2], w2v[4 * q + 3]), loc);
 #pragma unroll
                 for (int q = 0; q < 4; ++q) { xst4(xr, vSt + 1024u * (uint32_t)q, s_st(0, (uint32_t)t), w2v + 4 * q); xst4(xr, vSt + 1024u * (uint32_t)q, s_st(1, (uint32_t)t), m2v + 4 * q); xst4(xr, vSt + 1024u * (uint32_t)q, s_st(2, (uint32_t)t), v2v + 4 * q); }
             };
