@@ -66,9 +66,8 @@ constexpr uint32_t L_DY = L_XT + 32 * LD_B;                  // [128 b][16 o]
 constexpr uint32_t L_XH = L_DY + MB * LD_16;                 // [128 b][16]    x hi, 1, 0, x lo, 1, 0
 constexpr uint32_t L_W1 = L_XH + MB * LD_16;                 // [32 u][16]     c W1 row, c b1 hi, 0, c W1 row, c b1 lo, 0
 constexpr uint32_t L_W3T = L_W1 + 32 * LD_16;                // [32 u][16 o]   W3[o][u]
-constexpr uint32_t L_W3 = L_W3T + 32 * LD_16;                // [32 o][32 u]   W3[o][U]
-constexpr uint32_t L_H2W = L_W3 + 32 * LD_32;                // [4 waves][32 b][32 u]
-constexpr uint32_t L_FL = L_H2W + 4 * 32 * LD_32;            // floats: b2p[32] | red2[4][32] | red3[2][16] | stat[4][4] | bc[2] | flags
+constexpr uint32_t L_W3 = L_W3T + 32 * LD_16;                // [32 o][32 slots] W3[o][U], units in K-slot order (w3_slot)
+constexpr uint32_t L_FL = L_W3 + 32 * LD_32;                 // floats: b2p[32] | red2[4][32] | red3[2][16] | stat[4][4] | bc[2] | flags
 constexpr uint32_t L_ST = L_FL + 4096;                       // floats: the optimizer state (master, m, v) of the SMALL owned parameters for the launch:
                                                              //   sW1[3][32 u][6] | sB1[3][32] | sB2[3][32] | sW3[3][10 o][32 u] | sB3[3][16]
 constexpr uint32_t LDS_BYTES = L_ST + 8192;                  // 118 272
@@ -175,9 +174,33 @@ __device__ __forceinline__ f32x4 xld4f(__amdgpu_buffer_rsrc_t r, uint32_t voff, 
 
 __device__ __forceinline__ f32x16 mm(f16x8 a, f16x8 b, f32x16 acc) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc, 0, 0, 0); }
 __device__ __forceinline__ constexpr uint32_t fq(int q) { return 512u * (uint32_t)(q & 1) + 1024u * (uint32_t)(q >> 1); }   // piece q of a lane's fragment-order publication
+__device__ __forceinline__ uint32_t w3_slot(uint32_t u) { return (u & 0x13u) | ((u & 4u) << 1) | ((u & 8u) >> 1); }   // K slot of unit u in transpose32's order (bits 2 and 3 swapped)
 __device__ __forceinline__ uint32_t rrow(int r, uint32_t h) { return (uint32_t)(r & 3) + 8u * (uint32_t)(r >> 2) + 4u * h; }
 
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+// 32x32 transposition on the matrix pipe.  pk[q] = a lane's accumulator registers 4 q .. 4 q + 3 of a [u][b] tile (lane = column b, register r =
+// row u = row(r, h)) converted to float16 - the 8-byte pieces it publishes anyway.  As an A operand, slot e of K-step s of lane (b, h) is then
+// row u(s, h, e) = (e & 3) + 16 s + 8 (e >> 2) + 4 h of column b; against the 0 / 1 operand E_s[n][(h, e)] = [u(s, h, e) == n] the product is
+// D[b][n] = X[n][b]: the tile with lane = row u, registers = columns b, exact (one term per sum).  Replaces computing every both-orientation
+// result twice (the second matrix product AND the second round of activations / derivative factors): 2 instructions instead of ~150.
+struct TrOps { f16x8 e0, e1; };
+__device__ __forceinline__ TrOps transpose_ops(uint32_t c, uint32_t h) {
+    TrOps t;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const uint32_t u0 = (uint32_t)((e & 3) + 8 * (e >> 2)) + 4u * h;
+        t.e0[e] = u0 == c ? (_Float16)1.0f : (_Float16)0.0f;
+        t.e1[e] = u0 + 16u == c ? (_Float16)1.0f : (_Float16)0.0f;
+    }
+    return t;
+}
+__device__ __forceinline__ f32x16 transpose32(const uint64_t (&pk)[4], const TrOps& t) {
+    union { uint64_t u[2]; f16x8 v; } a0, a1;
+    a0.u[0] = pk[0]; a0.u[1] = pk[1]; a1.u[0] = pk[2]; a1.u[1] = pk[3];
+    const f32x16 zero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    f32x16 d = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0.v, t.e0, zero16, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a1.v, t.e1, d, 0, 0, 0);
+}
 __device__ __forceinline__ uint64_t pack4(float a, float b, float c, float d) {
     union { f16x4 v; uint64_t u; } o;
     o.v = f16x4{(_Float16)a, (_Float16)b, (_Float16)c, (_Float16)d};
@@ -328,6 +351,7 @@ __device__ __forceinline__ void persistent_learner_body(const Args& a, unsigned 
     const f32x16 zero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     const float c2 = TANH_PRESCALE;
     const uint32_t U0 = 32u * g;
+    const TrOps tro = transpose_ops(c, h);
     const uint32_t bsm = 32u * w + c;                           // the sample this lane (and its partner lane ^ 32) differentiates the loss of
     // exchange loads: one resource, scalar byte offsets of the buffers, per-lane byte offsets (see xld16)
     const __amdgpu_buffer_rsrc_t xr = xrsrc(net.xbase);
@@ -417,7 +441,7 @@ __device__ __forceinline__ void persistent_learner_body(const Args& a, unsigned 
         b2p[u] = c2 * net.b2[U0 + u];
         for (int o = 0; o < OUT; ++o) {
             const _Float16 wv = (_Float16)net.w3[(size_t)o * HID + U0 + u];
-            *reinterpret_cast<_Float16*>(lds + L_W3 + (uint32_t)o * LD_32 + 2u * u) = wv;
+            *reinterpret_cast<_Float16*>(lds + L_W3 + (uint32_t)o * LD_32 + 2u * w3_slot(u)) = wv;
             *reinterpret_cast<_Float16*>(lds + L_W3T + u * LD_16 + 2u * (uint32_t)o) = wv;
         }
     }
@@ -471,14 +495,14 @@ __device__ __forceinline__ void persistent_learner_body(const Args& a, unsigned 
     // of them, parked in accumulation registers and fetched back with v_accvgpr_read before each use: a quarter of the step's instructions
     // was such traffic); as values of the current iteration they stay ONE register each and the constants fold into the instructions' offset fields.
 #define Q1PL_OPAQUE(x) asm volatile("" : "+v"(x))
-    uint32_t lW = 0, lB = 0, l16 = 0, lS16 = 0, l32 = 0, lH2W = 0, lwB = 0, lCol = 0, lOwn = 0;            // LDS
+    uint32_t lW = 0, lB = 0, l16 = 0, lS16 = 0, l32 = 0, lwB = 0, lCol = 0, lOwn = 0;            // LDS
     uint32_t vYp = 0, pFrag = 0, pYp = 0, vSt = 0;                                     // exchange / state buffer offsets
     auto step_bases = [&]() __attribute__((always_inline)) {
         lW = c * LD_W + 16u * h; lB = c * LD_B + 16u * h; l16 = c * LD_16 + 16u * h; lS16 = (32u * w + c) * LD_16 + 16u * h; l32 = c * LD_32 + 16u * h;
-        lH2W = w * 32u * LD_32 + c * LD_32 + 16u * h; lwB = c * LD_B + 2u * (32u * w + 4u * h); lCol = (tid & 31u) * LD_W + 16u * (tid >> 5);
+        lwB = c * LD_B + 2u * (32u * w + 4u * h); lCol = (tid & 31u) * LD_W + 16u * (tid >> 5);
         lOwn = 4u * h * LD_W + 2u * (64u * w + c);
         vYp = v_yp; pFrag = p_frag; pYp = p_yp; vSt = v_st;
-        Q1PL_OPAQUE(lW); Q1PL_OPAQUE(lB); Q1PL_OPAQUE(l16); Q1PL_OPAQUE(lS16); Q1PL_OPAQUE(l32); Q1PL_OPAQUE(lH2W); Q1PL_OPAQUE(lwB); Q1PL_OPAQUE(lCol); Q1PL_OPAQUE(lOwn);
+        Q1PL_OPAQUE(lW); Q1PL_OPAQUE(lB); Q1PL_OPAQUE(l16); Q1PL_OPAQUE(lS16); Q1PL_OPAQUE(l32); Q1PL_OPAQUE(lwB); Q1PL_OPAQUE(lCol); Q1PL_OPAQUE(lOwn);
         Q1PL_OPAQUE(vYp); Q1PL_OPAQUE(pFrag); Q1PL_OPAQUE(pYp); Q1PL_OPAQUE(vSt);
     };
     auto small_grads = [&](const bool store_grads, const float lr_bc1, const float rs_bc2) __attribute__((always_inline)) {
@@ -500,7 +524,7 @@ __device__ __forceinline__ void persistent_learner_body(const Args& a, unsigned 
                 if ((int)o < OUT) {
                     const float gr = acc[r] * net.inv_scale;
                     w3v[r] = adam1(w3v[r], gr, m3v[r], v3v[r], a.beta1, a.beta2, a.eps, lr_bc1, rs_bc2);
-                    *reinterpret_cast<_Float16*>(lds + L_W3 + o * LD_32 + 2u * c) = (_Float16)w3v[r];
+                    *reinterpret_cast<_Float16*>(lds + L_W3 + o * LD_32 + 2u * w3_slot(c)) = (_Float16)w3v[r];
                     *reinterpret_cast<_Float16*>(lds + L_W3T + c * LD_16 + 2u * o) = (_Float16)w3v[r];
                     if (store_grads) net.gw3[(size_t)o * HID + U0 + c] = gr;
                 }
@@ -598,14 +622,18 @@ __device__ __forceinline__ void persistent_learner_body(const Args& a, unsigned 
             const f16x8 a1 = lds16(lds, L_W1 + l16);
             const f16x8 x1 = lds16(lds, L_XH + lS16);
             const f32x16 dA = mm(a1, x1, zero16);               // [u][b]: lane = sample, registers = units
-            const f32x16 dB = mm(x1, a1, zero16);               // [b][u]: lane = unit, registers = samples
+            uint64_t pk[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                xpub8(xr, pFrag + fq(q), s_h1x + (wu * 16u + 2u * g) * 1024u, pack4(act(dA[4 * q]), act(dA[4 * q + 1]), act(dA[4 * q + 2]), act(dA[4 * q + 3])), loc);
-                float t4[4];
+                pk[q] = pack4(act(dA[4 * q]), act(dA[4 * q + 1]), act(dA[4 * q + 2]), act(dA[4 * q + 3]));
+                xpub8(xr, pFrag + fq(q), s_h1x + (wu * 16u + 2u * g) * 1024u, pk[q], loc);
+            }
+            const f32x16 dT = transpose32(pk, tro);             // [b][u]: lane = unit, registers = samples (the float16 values, exactly)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) { t4[j] = act(dB[4 * q + j]); h1B[4 * q + j] = r16(t4[j]); }
-                xpub8(xr, pFrag + fq(q), s_h1tx + (g * 8u + 2u * wu) * 1024u, pack4(t4[0], t4[1], t4[2], t4[3]), loc);
+            for (int q = 0; q < 4; ++q) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) h1B[4 * q + j] = dT[4 * q + j];
+                xpub8(xr, pFrag + fq(q), s_h1tx + (g * 8u + 2u * wu) * 1024u, pack4(dT[4 * q], dT[4 * q + 1], dT[4 * q + 2], dT[4 * q + 3]), loc);
             }
         }
         Q1PL_STAMP(0);                                          // minibatch rows + P1 + publish
@@ -622,7 +650,7 @@ __device__ __forceinline__ void persistent_learner_body(const Args& a, unsigned 
         Q1PL_STAMP(1);                                          // barrier 1
 
         // ------------------------------------------------------------ W2's column block (rows j in U of W2^T), then P2 + the partial logits
-        float h2A[16], h2B[16];
+        float h2A[16];
         // the loss's per-sample inputs (not needed before barrier 2) are requested BEHIND this phase's operands (the memory counter retires
         // in order: requested first, their HBM latency would sit in front of the first matrix product): policy group: keys, logp_old, adv,
         // the mouse pre-image, the old logits row;  value group: value_old, vtarg (in the same registers)
@@ -650,36 +678,31 @@ __device__ __forceinline__ void persistent_learner_body(const Args& a, unsigned 
                 }
             }
             __builtin_amdgcn_sched_barrier(0);                  // (the requests above are issued HERE, all of them: the scheduler would otherwise sink each to its first use)
-            f32x16 accA = zero16, accB = zero16;
+            f32x16 accA = zero16;                               // [u][b]: lane = sample, registers = owned units
 #pragma unroll
-            for (int s = 0; s < 16; ++s) {
-                const f16x8 aW = lds16(lds, L_W2OWN + lW + 32u * (uint32_t)s);
-                accA = mm(aW, bH[s], accA);
-                accB = mm(bH[s], aW, accB);
-            }
+            for (int s = 0; s < 16; ++s) accA = mm(lds16(lds, L_W2OWN + lW + 32u * (uint32_t)s), bH[s], accA);
 #pragma unroll
             for (int i = 0; i < 4; ++i) *reinterpret_cast<f16x8*>(lds + L_W2COL + lCol + 128u * (uint32_t)i) = wc[i];
-            const float bB = b2p[c];
+            uint64_t pk[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const float4 bq = *reinterpret_cast<const float4*>(b2p + 8 * q + 4 * h);
                 const float bb[4] = {bq.x, bq.y, bq.z, bq.w};
-                float tA[4], tB[4];
+                float tA[4];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    tA[j] = act(accA[4 * q + j] + bb[j]); h2A[4 * q + j] = r16(tA[j]);
-                    tB[j] = act(accB[4 * q + j] + bB); h2B[4 * q + j] = r16(tB[j]);
-                }
-                *reinterpret_cast<uint64_t*>(lds + L_H2W + lH2W - 8u * h + 16u * (uint32_t)q) = pack4(tA[0], tA[1], tA[2], tA[3]);
-                *reinterpret_cast<uint64_t*>(lds + L_H2T + lwB + 16u * (uint32_t)q) = pack4(tB[0], tB[1], tB[2], tB[3]);
+                for (int j = 0; j < 4; ++j) { tA[j] = act(accA[4 * q + j] + bb[j]); h2A[4 * q + j] = r16(tA[j]); }
+                pk[q] = pack4(tA[0], tA[1], tA[2], tA[3]);
             }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            f32x16 accY = zero16;                               // [o][b]: lane = sample, registers = outputs
+            // the partial logits straight from the registers: the lane's pieces ARE a B operand whose K slots run over the units in the order
+            // u(s, h, e) (see transpose32); W3's image in LDS is stored in that order (w3_slot)
+            union { uint64_t u[2]; f16x8 v; } hb0, hb1;
+            hb0.u[0] = pk[0]; hb0.u[1] = pk[1]; hb1.u[0] = pk[2]; hb1.u[1] = pk[3];
+            f32x16 accY = mm(lds16(lds, L_W3 + l32), hb0.v, zero16);                        // [o][b]: lane = sample, registers = outputs
+            accY = mm(lds16(lds, L_W3 + l32 + 32u), hb1.v, accY);
+            const f32x16 hT2 = transpose32(pk, tro);            // H2^T[u][b] (lane = unit, registers = samples) for dW3
 #pragma unroll
-            for (int s = 0; s < 2; ++s)
-                accY = mm(lds16(lds, L_W3 + l32 + 32u * (uint32_t)s), lds16(lds, L_H2W + lH2W + 32u * (uint32_t)s), accY);
+            for (int q = 0; q < 4; ++q)
+                *reinterpret_cast<uint64_t*>(lds + L_H2T + lwB + 16u * (uint32_t)q) = pack4(hT2[4 * q], hT2[4 * q + 1], hT2[4 * q + 2], hT2[4 * q + 3]);
             xpub16f(xr, pYp, s_ypg, accY[0], accY[1], accY[2], accY[3], loc);              // outputs 4 h .. 4 h + 3: quad h
             xpub16f(xr, pYp + 1024u, s_ypg, accY[4], accY[5], accY[6], accY[7], loc);      // outputs 8 + 4 h ..: quad 2 + h
         }
@@ -772,19 +795,22 @@ __device__ __forceinline__ void persistent_learner_body(const Args& a, unsigned 
             const f16x8 aT = lds16(lds, L_W3T + l16);
             const f16x8 bY = lds16(lds, L_DY + lS16);
             const f32x16 dA = mm(aT, bY, zero16);               // [u][b]: lane = sample (h2A's layout)
-            const f32x16 dB = mm(bY, aT, zero16);               // [b][u]: lane = unit   (h2B's layout)
             float sb = 0.0f;
+            uint64_t pk[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                float zA[4], zB[4];
+                float zA[4];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    zA[j] = sat16(dA[4 * q + j] * (1.0f - h2A[4 * q + j] * h2A[4 * q + j]), amax, nsat);
-                    zB[j] = sat16(dB[4 * q + j] * (1.0f - h2B[4 * q + j] * h2B[4 * q + j]), amax, nsat);
-                    sb += r16(zB[j]);
-                }
-                xpub8(xr, pFrag + fq(q), o_dz2x + (wu * 16u + 2u * g) * 1024u, pack4(zA[0], zA[1], zA[2], zA[3]), loc);
-                *reinterpret_cast<uint64_t*>(lds + L_DZ2T + lwB + 16u * (uint32_t)q) = pack4(zB[0], zB[1], zB[2], zB[3]);
+                for (int j = 0; j < 4; ++j) zA[j] = sat16(dA[4 * q + j] * (1.0f - h2A[4 * q + j] * h2A[4 * q + j]), amax, nsat);
+                pk[q] = pack4(zA[0], zA[1], zA[2], zA[3]);
+                xpub8(xr, pFrag + fq(q), o_dz2x + (wu * 16u + 2u * g) * 1024u, pk[q], loc);
+            }
+            const f32x16 zT = transpose32(pk, tro);             // [b][u]: lane = unit, registers = samples (the float16 values)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) sb += zT[4 * q + j];
+                *reinterpret_cast<uint64_t*>(lds + L_DZ2T + lwB + 16u * (uint32_t)q) = pack4(zT[4 * q], zT[4 * q + 1], zT[4 * q + 2], zT[4 * q + 3]);
             }
             sb += __shfl_xor(sb, 32, 64);
             if (h == 0) red2[w * 32u + c] = sb;
