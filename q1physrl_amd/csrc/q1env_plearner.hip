@@ -46,7 +46,7 @@ size_t carve_pws(void* base, int64_t batch_rows, PWs out[2], uint32_t** status, 
         w.h1x = (uint16_t*)take((size_t)2 * q1pl::MB * q1pl::HID * 2);
         w.h1tx = (uint16_t*)take((size_t)2 * q1pl::MB * q1pl::HID * 2);
         w.dz2x = (uint16_t*)take((size_t)q1pl::MB * q1pl::HID * 2);
-        w.w2tx = (uint16_t*)take((size_t)q1pl::HID * q1pl::HID * 2);
+        w.w2tx = (uint16_t*)take((size_t)2 * q1pl::HID * q1pl::HID * 2);
         w.yp = (float*)take((size_t)q1pl::G * q1pl::MB * 16 * 4);
         w.w2st = (float*)take((size_t)q1pl::G * 3 * 4 * 2048 * 4);
         if (out) out[k] = w;
@@ -123,7 +123,7 @@ int q1env_learner_sgd_epochs(q1env_t* h, const q1env_learner_net* pi, const q1en
     a.status = status;
     { const char* e = getenv("Q1_LEARNER_LOCAL"); a.allow_local = (e && e[0] == '0') ? 0 : 1; }
     a.prof = getenv("Q1_LEARNER_PROF") ? reinterpret_cast<unsigned long long*>(status + 4) + 1 : nullptr;      // (bytes 24.. of the status line)
-    { const char* e = getenv("Q1_LEARNER_PROF"); a.prof_g = e ? (atoi(e) & 7) : 0; }      // (Q1_LEARNER_PROF=<g>: which workgroup of the policy group is stamped)
+    { const char* e = getenv("Q1_LEARNER_PROF"); a.prof_g = e ? (atoi(e) & 31) : 0; }      // (Q1_LEARNER_PROF=<g + 8 wave>: which wave of which workgroup of the policy group is stamped)
     a.timeout_ticks = (uint64_t)((timeout_s > 0 ? timeout_s : 5.0) * (h->wall_clock_hz > 0 ? h->wall_clock_hz : 1e8));
     hipLaunchKernelGGL(q1pl::mouse_u_kernel, dim3((unsigned)((batch_rows + 255) / 256)), dim3(256), 0, h->stream, batch_rows, b->mouse_dev, -h->p.action_range_f32,
                        h->p.action_range_f32, mouse_u);

@@ -8,29 +8,44 @@
 // of both hidden layers: rows U of W1 / b1, rows U of W2 (torch layout [out][in]: all 256 inputs of its 32 units) / b2, columns U of
 // W3 - masters, Adam moments and gradients in their torch layouts in global memory (private to the owner, plain cached accesses), the
 // float16 operand images of its slice in LDS for the whole launch.  A step of 128 samples (four 32-sample tiles, one per wave):
-//   P1   H1[:, U] = tanh(X W1[U]^T + b1[U])                      local; published (both orientations)             -> barrier 1
-//   P2   H2[:, U] = tanh(H1 W2[U]^T + b2[U])                     A/B operands: H1 straight from the exchange buffer, W2[U] from LDS
-//   L3   Yp_g = H2[:, U] W3[:, U]^T  (partial logits)            published                                        -> barrier 2
+//   P1   H1[:, U] = tanh(X W1[U]^T + b1[U])                      local; published in both orientations            -> barrier 1
+//   P2   H2[:, U] = tanh(H1 W2[U]^T + b2[U])                     B operands: H1 straight from the exchange buffer, W2[U] from LDS
+//   L3   Yp_g = H2[:, U] W3[:, U]^T  (partial logits)            from the activation registers; published        -> barrier 2
 //   loss every workgroup sums the G partials in the same order, adds b3 and differentiates the PPO loss of its group's network for all
-//        128 samples (q1ppo_loss.hpp, one thread per sample; redundant across the group, identical bits)
+//        128 samples (q1ppo_loss.hpp, two lanes per sample; redundant across the group, identical bits)
 //   B3   dZ2[:, U] = (dY W3[:, U]) (1 - H2[:, U]^2)              local; published                                -> barrier 3 (arrive)
-//   G2   dW2[U, :] = dZ2[:, U]^T H1, dW3[:, U] = dY^T H2[:, U], db2[U]; Adam on them; new W2[U] image; W2^T slice published
-//   B2   dH1[:, U] = dZ2 W2[:, U]  (after barrier 3: all of dZ2 from the exchange buffer, W2's column block gathered into LDS after barrier 1)
-//        dZ1[:, U] = dH1 (1 - H1[:, U]^2);  dW1[U], db1[U]; Adam; db3 / b3 (workgroup 0)
+//   G2   dW2[U, :] = dZ2[:, U]^T H1 in two 32-input tiles per wave, Adam, new W2[U] image, W2^T slice published; dW3[:, U], db2[U], db3
+//   B2   dH1[:, U] = dZ2 W2[:, U]  (all of dZ2 from the exchange buffer; W2's column block gathered into LDS behind barrier 2)
+//        dZ1[:, U] = dH1 (1 - H1[:, U]^2);  dW1[U], db1[U]; Adam
 // Three group barriers per step (8 arrivals on one counter each), nothing else crosses workgroups.
 //
-// Matrix products: v_mfma_f32_32x32x16_f16, D[i][n] += sum_k A[i][k] B[n][k] with BOTH operands stored "K-contiguous" (row i / n, eight
-// consecutive k per lane: lane (c, h) reads 16 bytes at row c, k = 16 s + 8 h), so swapping the two operand registers yields the
-// transposed product for free.  The accumulator of lane (c, h) holds column n = c, rows i = (r & 3) + 8 (r >> 2) + 4 h - four consecutive
-// i per register quad, which leave as one 8-byte store into a row-major [n][i] array: the layout the NEXT product needs is obtained by
-// choosing which operand plays A.  Where both layouts of a result are needed (H1, H2, dZ2) both orientations are computed from the same
-// operand registers (matrix time is not what bounds this kernel; a transposition through LDS would cost more).
+// Schedule.  One wave per SIMD issues in order, so every wait is dead time unless the program itself puts independent work there.  The
+// critical chain of a step is P1 -> b1 -> P2 -> b2 -> loss -> B3 -> b3 -> B2 -> (next) P1; everything else hangs off it and is placed in its
+// waits:  tile 0 of G2 sits between the ARRIVAL at barrier 3 and its wait (the counter is read from inside the tile's optimizer arithmetic -
+// an ordinary compiler-visible atomic, requested early and looked at late - and B2's operands are requested the moment it shows eight
+// tickets, under the tile's stores);  tile 1, db2 and the statistics are DEFERRED into the next step: tile 1 + db2 between the arrival at
+// barrier 1 and its wait (operands requested at the top of that step), dW3 / db3 behind P2's operand requests (under their latency), the
+// statistics in barrier 2's window.  What a deferred piece reads stays valid that long (LDS arrays rewritten only later in the next step; H1^T
+// and W2^T double-buffered by step parity) and what it produces is needed no earlier (W2's image by the next P2, W3's by its L3, b3 behind
+// barrier 2); the last step's deferred work runs behind the loop.
 //
-// Exchange protocol.  Published data are written with agent-scope write-through stores (sc1); "arrive" = s_waitcnt vmcnt(0) (they have
-// reached the memory side), workgroup barrier, one relaxed agent-scope increment; "wait" = spin on the counter, workgroup barrier, agent-scope
-// acquire fence (buffer_inv sc1: this XCD's L2 / the CU's vector cache drop what other XCDs may have rewritten).  Single buffers
-// suffice except for H1 (read by the weight-gradient phase after barrier 3's arrive, while a faster workgroup may already be publishing the
-// next step's): two buffers, by step parity.  Every wait is bounded (status word) - the 16 workgroups must be co-resident.
+// Matrix products: v_mfma_f32_32x32x16_f16, D[i][n] += sum_k A[i][k] B[n][k] with BOTH operands stored "K-contiguous" (row i / n, eight
+// consecutive k per lane: lane (c, h) reads 16 bytes at row c, k = 16 s + 8 h).  The accumulator of lane (c, h) holds column n = c, rows
+// i = (r & 3) + 8 (r >> 2) + 4 h - four consecutive i per register quad, one 8-byte piece.  Where both layouts of a result are needed (H1, H2,
+// dZ2) the second is a transposition on the matrix pipe of the float16 pieces of the first (transpose32: two instructions, exact) - not a
+// second product and a second round of activations.
+//
+// Exchange layouts.  Everything that crosses workgroups is stored in the order its CONSUMER's 64-lane requests read it ("operand-fragment
+// order": Net below), addressed through one buffer resource per group with scalar block offsets: a request covers one contiguous KB (8 cache
+// lines) where the row-major forms touched 32 or 64 scattered lines - the CU's one request per clock, not latency or arithmetic, had been
+// what bounded every phase that touches exchanged data (20.2 -> 14.4 us per step from this alone).
+//
+// Exchange protocol.  Two modes, decided per launch (see "placement" in the kernel).  Agent scope: published data are written through
+// (sc0 sc1), "arrive" = s_waitcnt vmcnt(0), workgroup barrier, one relaxed increment; "wait" = poll, workgroup barrier, buffer_inv sc1.
+// L2-local (all eight workgroups of a group on one XCD - the dispatcher's round-robin placement, verified by a census at every launch):
+// plain stores, device-scope loads (sc1: never the CU's vector cache), no invalidation at all.  H1 / H1^T and W2^T have two buffers, by
+// step parity (both are read by deferred work while a faster workgroup may be publishing the next step's).  Every wait is bounded (status
+// word) - the 16 workgroups must be co-resident.
 //
 // Numerics: float16 operands, float32 accumulation, float32 masters / moments, torch.optim.Adam's update - the same recipe, loss scales and
 // saturating gradient conversions as q1learner.hpp; the summation orders differ, so results agree with q1env_learner_sgd_step to float16
@@ -84,7 +99,7 @@ struct Net {
     uint16_t* h1x;        // [2 parity][4 sample tiles w][16 K-steps s][64 lanes (c = sample, h)][8]: H1[32 w + c][16 s + 8 h ..]
     uint16_t* h1tx;       // [2 parity][8 unit tiles g][8 K-steps s][64 lanes (c = unit, h)][8]: H1[16 s + 8 h ..][32 g + c]
     uint16_t* dz2x;       // [4][16][64][8]: dZ2 in H1's form
-    uint16_t* w2tx;       // [8 consumers g'][8 producers g][4 q][32 c][2 h][4]: W2[32 g + 8 q + 4 h ..][32 g' + c] - what lane (c, h) of the owner publishes in one
+    uint16_t* w2tx;       // [2 update parities][8 consumers g'][8 producers g][4 q][32 c][2 h][4]: W2[32 g + 8 q + 4 h ..][32 g' + c] - what lane (c, h) of the owner publishes in one
                           // 8-byte store, so a publishing request is one contiguous 512 B and a consumer's column block one contiguous 16 KB
     float* yp;            // [G][4 sample tiles w][4 output quads v][32 samples c][4]: partial logits 4 v .. 4 v + 3 of sample 32 w + c
     float* b3x;           // [16]: the output layer's bias as the group reads it (published by workgroup 0 after every step), zero padded
@@ -346,6 +361,7 @@ __device__ __forceinline__ void persistent_learner_body(const Args& a, unsigned 
     float* const fl = reinterpret_cast<float*>(lds + L_FL);
     float* const b2p = fl;                 // [32]
     float* const red2 = fl + 32;           // [4][32]
+    float* const red3 = fl + 160;          // [16]
     int* const s_ok = reinterpret_cast<int*>(fl + 212);
     float* const statbuf = fl + 288;       // [3][128]: the per-sample statistics of a step (summed off the critical path)
     const f32x16 zero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -428,7 +444,7 @@ __device__ __forceinline__ void persistent_learner_body(const Args& a, unsigned 
             *reinterpret_cast<_Float16*>(lds + L_W2OWN + u * LD_W + 2u * (k0 + k)) = (_Float16)(c2 * wv);
             union { _Float16 hh; uint16_t b; } o; o.hh = (_Float16)wv;
             const uint32_t kk = k0 + k;
-            __hip_atomic_store(net.w2tx + (((size_t)(kk >> 5) * 8 + g) * 4 + (u >> 3)) * 256 + (kk & 31u) * 8u + ((u >> 2) & 1u) * 4u + (u & 3u), o.b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(net.w2tx + 65536 + (((size_t)(kk >> 5) * 8 + g) * 4 + (u >> 3)) * 256 + (kk & 31u) * 8u + ((u >> 2) & 1u) * 4u + (u & 3u), o.b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
     if (tid < 32u) {
@@ -466,7 +482,7 @@ __device__ __forceinline__ void persistent_learner_body(const Args& a, unsigned 
     float amax = 0.0f;
     uint32_t nsat = 0;
     uint32_t bar_n = 0;                                         // barriers passed
-    float lr_prev = 0.0f, rs_prev = 0.0f;                       // the previous step's bias corrections (small_grads)
+    float lr_prev = 0.0f, rs_prev = 0.0f;                       // the previous step's bias corrections (its deferred work)
     // rows of the FIRST step (every later step's are fetched one step ahead): srcX = the sample whose observation this thread stages
     // (threads 0..127), srcL = the sample whose loss this lane pair differentiates
     // (no division in the loop: the position of the next step's window is kept incrementally)
@@ -484,12 +500,6 @@ __device__ __forceinline__ void persistent_learner_body(const Args& a, unsigned 
     request_obs();
     __syncthreads();
 
-    // The SMALL gradients of a step - dW3[:, U] (wave 1), db2[U] (wave 2), db3 and the step's statistics (wave 3 of workgroup 0) -, their
-    // optimizer updates and new operand images.  They need nothing but this workgroup's LDS (dY^T, H2^T, red2, the ones row of [x | 1]^T,
-    // statbuf: all untouched until the next step's barrier 1 has been passed) and nobody needs their results before the next step's P2, so they
-    // are DEFERRED into the window in which the next step waits for barrier 1 (three waves idle there for ~1 us; behind the weight-gradient
-    // tiles they made wave 0 wait for waves 1 .. 3 in front of B2).  b3 is republished there: every workgroup read the old one before it
-    // arrived at barrier 3, the new one is read behind barrier 2.  lr_bc1_ / rs_bc2_: the bias corrections of the step the gradients belong to.
     // Lane-dependent address parts, made OPAQUE once per step (an empty assembly statement "modifies" them): otherwise every
     // `base + constant` is a loop invariant, is hoisted out of the step loop and occupies a register of its own for the whole launch (~150
     // of them, parked in accumulation registers and fetched back with v_accvgpr_read before each use: a quarter of the step's instructions
@@ -505,7 +515,81 @@ __device__ __forceinline__ void persistent_learner_body(const Args& a, unsigned 
         Q1PL_OPAQUE(lW); Q1PL_OPAQUE(lB); Q1PL_OPAQUE(l16); Q1PL_OPAQUE(lS16); Q1PL_OPAQUE(l32); Q1PL_OPAQUE(lwB); Q1PL_OPAQUE(lCol); Q1PL_OPAQUE(lOwn);
         Q1PL_OPAQUE(vYp); Q1PL_OPAQUE(pFrag); Q1PL_OPAQUE(pYp); Q1PL_OPAQUE(vSt);
     };
-    auto small_grads = [&](const bool store_grads, const float lr_bc1, const float rs_bc2) __attribute__((always_inline)) {
+    // (two parts: the arithmetic + the new float16 image in LDS;  the global stores - state back, the W2^T rows published: the poll of
+    //  barrier 3 sits between them, so that it never queues behind 64 stores)
+    auto adam_tile = [&](const int t, const int q0, const int q1, const f32x16& acc, float (&w2v)[16], float (&m2v)[16], float (&v2v)[16], const float lr_bc1, const float rs_bc2,
+                         const bool store_grads) __attribute__((always_inline)) {
+        const uint32_t k = 64u * w + 32u * (uint32_t)t + c;
+#pragma unroll
+        for (int q = q0; q < q1; ++q) {
+#pragma unroll
+            for (int j = 0; j < 4; j += 2) {
+                const int r = 4 * q + j;
+                const f32x2 gr = f32x2{acc[r], acc[r + 1]} * net.inv_scale;
+                f32x2 mm2 = {m2v[r], m2v[r + 1]}, vv2 = {v2v[r], v2v[r + 1]};
+                const f32x2 wn = adam2(f32x2{w2v[r], w2v[r + 1]}, gr, mm2, vv2, a.beta1, a.beta2, a.eps, lr_bc1, rs_bc2);
+                w2v[r] = wn.x; w2v[r + 1] = wn.y; m2v[r] = mm2.x; m2v[r + 1] = mm2.y; v2v[r] = vv2.x; v2v[r + 1] = vv2.y;
+                const f32x2 wi = c2 * wn;
+                *reinterpret_cast<_Float16*>(lds + L_W2OWN + (uint32_t)((r & 3) + 8 * (r >> 2)) * LD_W + lOwn + 64u * (uint32_t)t) = (_Float16)wi.x;
+                *reinterpret_cast<_Float16*>(lds + L_W2OWN + (uint32_t)(((r + 1) & 3) + 8 * ((r + 1) >> 2)) * LD_W + lOwn + 64u * (uint32_t)t) = (_Float16)wi.y;
+                if (store_grads) {              // (inspection / tests: a cold block - its 32 addresses must not be hoisted out of the step loop)
+                    uint32_t kk = k;
+                    Q1PL_OPAQUE(kk);
+                    net.gw2[(size_t)(U0 + rrow(r, h)) * HID + kk] = gr.x; net.gw2[(size_t)(U0 + rrow(r + 1, h)) * HID + kk] = gr.y;
+                }
+            }
+        }
+    };
+    // (par2: which of the two W2^T exchange buffers - the parity of the step the update belongs to)
+    auto store_tile = [&](const int t, const uint32_t par2, const float (&w2v)[16], const float (&m2v)[16], const float (&v2v)[16]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            xpub8(xr, pFrag + 512u * (uint32_t)q, o_w2tx + par2 * 131072u + ((2u * wu + (uint32_t)t) * 8u + g) * 2048u, pack4(w2v[4 * q], w2v[4 * q + 1], w2v[4 * q + 2], w2v[4 * q + 3]), loc);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { xst4(xr, vSt + 1024u * (uint32_t)q, s_st(0, (uint32_t)t), w2v + 4 * q); xst4(xr, vSt + 1024u * (uint32_t)q, s_st(1, (uint32_t)t), m2v + 4 * q); xst4(xr, vSt + 1024u * (uint32_t)q, s_st(2, (uint32_t)t), v2v + 4 * q); }
+    };
+    // TILE 1 of a step's W2 gradient (inputs k = 64 w + 32 + c) is DEFERRED like the small gradients: its operands (H1^T of that step: the
+    // exchange buffer of that parity stays intact for two steps; dZ2^T in LDS: rewritten by the next step's B3) and its optimizer state are
+    // requested at the top of the NEXT step and it runs between that step's arrival at barrier 1 and the wait for it - ~1.3 us of work in
+    // a window in which the workgroup would otherwise only wait - instead of between barrier 3 and B2, on the step's critical path.  Its
+    // new weights are needed by the next P2 (LDS image: behind the barrier wait's workgroup barrier) and by the other workgroups' column
+    // gathers, which therefore read W2^T behind barrier 2 and from the buffer of the update's parity (two buffers: a fast workgroup
+    // publishes tile 0 of the NEXT update right behind its arrival at barrier 3, possibly before a slow one has gathered).
+    float wB[16], mB[16], vB[16];
+    f16x8 hU[8];
+    auto tile1_request = [&](const uint32_t parity) __attribute__((always_inline)) {
+        const uint32_t sb = o_h1tx + parity * (uint32_t)(MB * HID * 2) + wu * 16384u + 8192u;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) hU[s] = xld16(xr, vSt + 1024u * (uint32_t)(s & 3), sb + 4096u * (uint32_t)(s >> 2));
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { xld4(xr, vSt + 1024u * (uint32_t)q, s_st(0, 1), wB + 4 * q); xld4(xr, vSt + 1024u * (uint32_t)q, s_st(1, 1), mB + 4 * q); xld4(xr, vSt + 1024u * (uint32_t)q, s_st(2, 1), vB + 4 * q); }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto tile1_run = [&](const uint32_t parity, const float lr_bc1, const float rs_bc2, const bool store_grads) __attribute__((always_inline)) {
+        f32x16 acc = zero16;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) acc = mm(lds16(lds, L_DZ2T + lB + 32u * (uint32_t)s), hU[s], acc);
+        adam_tile(1, 0, 4, acc, wB, mB, vB, lr_bc1, rs_bc2, store_grads);
+    };
+    // The SMALL gradients of a step - db2[U] (wave 2), dW3[:, U] (wave 1), db3 (wave 3 of workgroup 0) and the step's statistics -, their
+    // optimizer updates and new operand images.  They need nothing but this workgroup's LDS (dY^T, H2^T, red2, the ones row of [x | 1]^T,
+    // statbuf) and nobody needs their results before the next step's P2 / L3 / loss, so they are DEFERRED into the next step, each to a
+    // place where its wave would otherwise wait: db2 into the barrier-1 window; dW3 and db3 behind P2's operand requests, under their
+    // latency - one workgroup barrier in P2 then orders the new W3 image before L3 and these reads of H2^T before its rewriting; the
+    // statistics into the barrier-2 window.  b3 is republished by db3: every workgroup read the old one before it arrived at barrier 3,
+    // the new one is read behind barrier 2.  lr_bc1 / rs_bc2: the bias corrections of the step the gradients belong to.
+    auto grads_b2 = [&](const bool store_grads, const float lr_bc1, const float rs_bc2) __attribute__((always_inline)) {
+        if (wu == 2u && h == 0u) {                               // db2[U]
+            const size_t u = U0 + c;
+            float b2v = sB2[c], mv = sB2[32 + c], vv = sB2[64 + c];
+            const float gr = (((red2[c] + red2[32u + c]) + red2[64u + c]) + red2[96u + c]) * net.inv_scale;
+            b2v = adam1(b2v, gr, mv, vv, a.beta1, a.beta2, a.eps, lr_bc1, rs_bc2);
+            b2p[c] = c2 * b2v;
+            sB2[c] = b2v; sB2[32 + c] = mv; sB2[64 + c] = vv;
+            if (store_grads) net.gb2[u] = gr;
+        }
+    };
+    auto grads_w3b3 = [&](const bool store_grads, const float lr_bc1, const float rs_bc2) __attribute__((always_inline)) {
         if (wu == 1u) {                                          // dW3[:, U]: lane = owned unit, registers = outputs (o = row(r, h) < OUT <= 10: r < 8)
             float w3v[8], m3v[8], v3v[8];
 #pragma unroll
@@ -519,36 +603,50 @@ __device__ __forceinline__ void persistent_learner_body(const Args& a, unsigned 
             for (int s = 0; s < 8; ++s)
                 acc = mm(lds16(lds, L_DYT + lB + 32u * (uint32_t)s), lds16(lds, L_H2T + lB + 32u * (uint32_t)s), acc);
 #pragma unroll
-            for (int r = 0; r < 8; ++r) {
+            for (int r = 0; r < 8; r += 2) {                    // (pairs: rows o, o + 1 - the packed optimizer arithmetic; slots beyond OUT are computed and dropped)
                 const uint32_t o = rrow(r, h);
-                if ((int)o < OUT) {
-                    const float gr = acc[r] * net.inv_scale;
-                    w3v[r] = adam1(w3v[r], gr, m3v[r], v3v[r], a.beta1, a.beta2, a.eps, lr_bc1, rs_bc2);
-                    *reinterpret_cast<_Float16*>(lds + L_W3 + o * LD_32 + 2u * w3_slot(c)) = (_Float16)w3v[r];
-                    *reinterpret_cast<_Float16*>(lds + L_W3T + c * LD_16 + 2u * o) = (_Float16)w3v[r];
-                    if (store_grads) net.gw3[(size_t)o * HID + U0 + c] = gr;
+                const f32x2 gr = f32x2{acc[r], acc[r + 1]} * net.inv_scale;
+                f32x2 m2 = {m3v[r], m3v[r + 1]}, v2 = {v3v[r], v3v[r + 1]};
+                const f32x2 wn = adam2(f32x2{w3v[r], w3v[r + 1]}, gr, m2, v2, a.beta1, a.beta2, a.eps, lr_bc1, rs_bc2);
+                const float wq[2] = {wn.x, wn.y}, mq[2] = {m2.x, m2.y}, vq[2] = {v2.x, v2.y}, gq[2] = {gr.x, gr.y};
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    if ((int)(o + (uint32_t)e) < OUT) {
+                        const uint32_t oo = o + (uint32_t)e, i3 = oo * 32u + c;
+                        *reinterpret_cast<_Float16*>(lds + L_W3 + oo * LD_32 + 2u * w3_slot(c)) = (_Float16)wq[e];
+                        *reinterpret_cast<_Float16*>(lds + L_W3T + c * LD_16 + 2u * oo) = (_Float16)wq[e];
+                        sW3[i3] = wq[e]; sW3[320 + i3] = mq[e]; sW3[640 + i3] = vq[e];
+                        if (store_grads) net.gw3[(size_t)oo * HID + U0 + c] = gq[e];
+                    }
                 }
             }
-#pragma unroll
-            for (int r = 0; r < 8; ++r) {
-                const uint32_t o = rrow(r, h);
-                if ((int)o < OUT) { const uint32_t i3 = o * 32u + c; sW3[i3] = w3v[r]; sW3[320 + i3] = m3v[r]; sW3[640 + i3] = v3v[r]; }
-            }
         }
-        if (wu == 2u && h == 0u) {                               // db2[U]
-            const size_t u = U0 + c;
-            float b2v = sB2[c], mv = sB2[32 + c], vv = sB2[64 + c];
-            const float gr = (((red2[c] + red2[32u + c]) + red2[64u + c]) + red2[96u + c]) * net.inv_scale;
-            b2v = adam1(b2v, gr, mv, vv, a.beta1, a.beta2, a.eps, lr_bc1, rs_bc2);
-            b2p[c] = c2 * b2v;
-            sB2[c] = b2v; sB2[32 + c] = mv; sB2[64 + c] = vv;
-            if (store_grads) net.gb2[u] = gr;
-        }
-        if (g == 0 && wu == 3u) {
-            f32x16 acc_b3 = zero16;                             // [o][i']: lane (c = 6, h) holds db3[o = row(r, h)] (times the loss scale)
+        if (g == 0 && wu == 3u) {                               // db3 / b3
+            f32x16 acc_b3 = zero16;                             // [o][i']: lane (c = 6, h) holds db3[o = row(r, h)] (times the loss scale): the ones column
 #pragma unroll
             for (int s = 0; s < 8; ++s)
                 acc_b3 = mm(lds16(lds, L_DYT + lB + 32u * (uint32_t)s), lds16(lds, L_XT + lB + 32u * (uint32_t)s), acc_b3);
+            // one output per lane for the optimizer: the ten sums cross through LDS (red3) instead of eight masked updates in a row on two lanes
+            if (c == 6u) {
+#pragma unroll
+                for (int r = 0; r < 8; ++r) red3[rrow(r, h)] = acc_b3[r];
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            if ((int)lane < OUT) {
+                const uint32_t o = lane;
+                float bv = sB3[o], mv = sB3[16 + o], vv = sB3[32 + o];
+                const float gr = red3[o] * net.inv_scale;
+                bv = adam1(bv, gr, mv, vv, a.beta1, a.beta2, a.eps, lr_bc1, rs_bc2);
+                sB3[o] = bv; sB3[16 + o] = mv; sB3[32 + o] = vv;
+                if (store_grads) net.gb3[o] = gr;
+                pub4f(net.b3x + o, bv, loc);
+            }
+        }
+    };
+    auto grads_stats = [&]() __attribute__((always_inline)) {
+        if (g == 0 && wu == 3u) {
             float sv[3];
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
@@ -558,29 +656,10 @@ __device__ __forceinline__ void persistent_learner_body(const Args& a, unsigned 
                 sv[k] = v;
             }
             if (lane == 0) { st_acc[0] += sv[0] * (1.0f / (float)MB); st_acc[1] += sv[1] * (1.0f / (float)MB); st_acc[2] += sv[2] * (1.0f / (float)MB); }
-            if (c == 6u) {                                      // db3 / b3: the ones column of acc_b3
-                float bv[8], mv[8], vv[8];
-#pragma unroll
-                for (int r = 0; r < 8; ++r) {
-                    const uint32_t o = rrow(r, h), oc = (int)o < OUT ? o : 0u;
-                    bv[r] = sB3[oc]; mv[r] = sB3[16 + oc]; vv[r] = sB3[32 + oc];
-                }
-#pragma unroll
-                for (int r = 0; r < 8; ++r) {
-                    const uint32_t o = rrow(r, h);
-                    if ((int)o < OUT) {
-                        const float gr = acc_b3[r] * net.inv_scale;
-                        bv[r] = adam1(bv[r], gr, mv[r], vv[r], a.beta1, a.beta2, a.eps, lr_bc1, rs_bc2);
-                        sB3[o] = bv[r]; sB3[16 + o] = mv[r]; sB3[32 + o] = vv[r];
-                        if (store_grads) net.gb3[o] = gr;
-                        pub4f(net.b3x + o, bv[r], loc);
-                    }
-                }
-            }
         }
     };
     // (PROF: the instantiation launched under Q1_LEARNER_PROF - the product kernel carries neither the 40 registers nor the clock reads)
-    const bool profiling = PROF && a.prof != nullptr && blockIdx.x == 8u * (uint32_t)a.prof_g && tid == 0;      // (a workgroup of the policy group)
+    const bool profiling = PROF && a.prof != nullptr && blockIdx.x == 8u * (uint32_t)(a.prof_g & 7) && tid == 64u * (uint32_t)(a.prof_g >> 3);      // (lane 0 of one wave of a workgroup of the policy group)
     unsigned long long pacc[PROF ? 20 : 1] = {};
     uint64_t tprev = profiling ? wall_clock64() : 0;
 #define Q1PL_STAMP(k) do { if constexpr (PROF) { if (profiling) { const uint64_t now_ = wall_clock64(); pacc[k] += now_ - tprev; tprev = now_; } } } while (0)
@@ -616,6 +695,7 @@ __device__ __forceinline__ void persistent_learner_body(const Args& a, unsigned 
         __syncthreads();
         const float lr_bc1 = a.lr / (float)(1.0 - pw1), rs_bc2 = 1.0f / sqrtf((float)(1.0 - pw2));    // lr / bias_correction1, 1 / sqrt(bias_correction2)
 
+        if (step > 0) tile1_request(par ^ 1u);                    // (the previous step's deferred tile: see tile1_run)
         // ------------------------------------------------------------ P1: layer 1 of the owned units, both orientations
         float h1B[16];                                          // tanh(H1)[b = 32 w + row(r)][u = c] as the float16 operand carries it
         {
@@ -638,7 +718,15 @@ __device__ __forceinline__ void persistent_learner_body(const Args& a, unsigned 
         }
         Q1PL_STAMP(0);                                          // minibatch rows + P1 + publish
         bar_arrive(net.bar, loc);
-        if (step > 0) small_grads(false, lr_prev, rs_prev);      // (the previous step's: see small_grads)
+        uint32_t seen1 = 0u;
+        if (step > 0) {                                          // the previous step's deferred work: see tile1_run, grads_b2
+            tile1_run(par ^ 1u, lr_prev, rs_prev, false);
+            seen1 = tid == 0 ? poll(net.bar, loc) : 0u;         // (requested ~1 us behind the arrival and IN FRONT of the tile's stores, looked at behind the rest of the window's work)
+            store_tile(1, par ^ 1u, wB, mB, vB);
+            grads_b2(false, lr_prev, rs_prev);
+        }
+        Q1PL_STAMP(17);                                         // (the barrier-1 window's work)
+        const float lr_prev2 = lr_prev, rs_prev2 = rs_prev;
         lr_prev = lr_bc1; rs_prev = rs_bc2;
         const int64_t srcL_now = srcL;
         // the NEXT step's row indices, requested while the barrier is in flight
@@ -646,7 +734,7 @@ __device__ __forceinline__ void persistent_learner_body(const Args& a, unsigned 
             if (++in_epoch == a.spe) { in_epoch = 0; win += a.epoch_stride - (a.spe - 1) * MB; } else { win += MB; }
             srcX = row_at(win, tid & (MB - 1)); srcL = row_at(win, bsm);
         }
-        if (!bar_wait(net.bar, (uint32_t)G * ++bar_n, loc, a.status, 0u, (uint32_t)step, a.timeout_ticks, s_ok)) return;
+        if (!bar_wait(net.bar, (uint32_t)G * ++bar_n, loc, a.status, 0u, (uint32_t)step, a.timeout_ticks, s_ok, seen1)) return;
         Q1PL_STAMP(1);                                          // barrier 1
 
         // ------------------------------------------------------------ W2's column block (rows j in U of W2^T), then P2 + the partial logits
@@ -659,11 +747,9 @@ __device__ __forceinline__ void persistent_learner_body(const Args& a, unsigned 
         float oldrow[10];
         {
             // every global operand of this phase is requested first: H1 rows of this wave's tile (16 K-steps) and the column block
-            f16x8 bH[16], wc[4];
+            f16x8 bH[16];
 #pragma unroll
             for (int s = 0; s < 16; ++s) bH[s] = xld16(xr, vSt + 1024u * (uint32_t)(s & 3), s_h1x + wu * 16384u + 4096u * (uint32_t)(s >> 2));
-#pragma unroll
-            for (int i = 0; i < 4; ++i) wc[i] = xld16(xr, vSt, o_w2tx + g * 16384u + wu * 1024u + 4096u * (uint32_t)i);      // vector tid + 256 i of this workgroup's 16 KB
             {
                 const size_t sl = (size_t)srcL_now;
                 if (ni == 0) { in_kb = (uint32_t)a.keys[sl]; in_a = a.mouse_u[sl]; in_b = a.logp_old[sl]; in_c = a.adv[sl]; }
@@ -678,11 +764,10 @@ __device__ __forceinline__ void persistent_learner_body(const Args& a, unsigned 
                 }
             }
             __builtin_amdgcn_sched_barrier(0);                  // (the requests above are issued HERE, all of them: the scheduler would otherwise sink each to its first use)
+            if (step > 0) grads_w3b3(false, lr_prev2, rs_prev2);      // (the previous step's, under the requests' latency)
             f32x16 accA = zero16;                               // [u][b]: lane = sample, registers = owned units
 #pragma unroll
             for (int s = 0; s < 16; ++s) accA = mm(lds16(lds, L_W2OWN + lW + 32u * (uint32_t)s), bH[s], accA);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) *reinterpret_cast<f16x8*>(lds + L_W2COL + lCol + 128u * (uint32_t)i) = wc[i];
             uint64_t pk[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
@@ -693,6 +778,7 @@ __device__ __forceinline__ void persistent_learner_body(const Args& a, unsigned 
                 for (int j = 0; j < 4; ++j) { tA[j] = act(accA[4 * q + j] + bb[j]); h2A[4 * q + j] = r16(tA[j]); }
                 pk[q] = pack4(tA[0], tA[1], tA[2], tA[3]);
             }
+            __syncthreads();                                    // (W3's new image is complete; nobody reads the previous step's H2^T any more)
             // the partial logits straight from the registers: the lane's pieces ARE a B operand whose K slots run over the units in the order
             // u(s, h, e) (see transpose32); W3's image in LDS is stored in that order (w3_slot)
             union { uint64_t u[2]; f16x8 v; } hb0, hb1;
@@ -708,6 +794,7 @@ __device__ __forceinline__ void persistent_learner_body(const Args& a, unsigned 
         }
         Q1PL_STAMP(2);                                          // W2 column gather + P2 + partial logits
         bar_arrive(net.bar, loc);
+        if (step > 0) grads_stats();                             // (the previous step's statistics: statbuf is rewritten behind this barrier)
         if (!bar_wait(net.bar, (uint32_t)G * ++bar_n, loc, a.status, 1u, (uint32_t)step, a.timeout_ticks, s_ok)) return;
         Q1PL_STAMP(3);                                          // barrier 2
 
@@ -720,6 +807,7 @@ __device__ __forceinline__ void persistent_learner_body(const Args& a, unsigned 
         float wA[16], mA[16], vA[16];                           // (G2's first tile: see below)
         f16x8 hT[8];                                            // ... and its H1^T operand rows
         f16x8 zr[16];                                           // B2's operands: this wave's rows of ALL of dZ2 (requested inside G2, behind barrier 3)
+        f16x8 wc[4];                                            // this thread's share of W2's column block (gathered behind barrier 2: see tile1_run)
         {
             float y[12];
             {
@@ -730,6 +818,8 @@ __device__ __forceinline__ void persistent_learner_body(const Args& a, unsigned 
                     for (int v = 0; v < 3; ++v) part[q][v] = xld4f(xr, vYp + 512u * (uint32_t)v, o_yp + ((uint32_t)q * 4u + wu) * 2048u);
 #pragma unroll
                 for (int v = 0; v < 3; ++v) part[4][v] = xld4f(xr, 16u * (uint32_t)v, o_b3x);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) wc[i] = xld16(xr, vSt, o_w2tx + (par ^ 1u) * 131072u + g * 16384u + wu * 1024u + 4096u * (uint32_t)i);      // vector tid + 256 i of this workgroup's 16 KB
                 __builtin_amdgcn_sched_barrier(0);                  // (the requests above are issued HERE, all of them: the scheduler would otherwise sink each to its first use)
                 float half_[12];
 #pragma unroll
@@ -787,6 +877,8 @@ __device__ __forceinline__ void persistent_learner_body(const Args& a, unsigned 
         // the sums over the samples (db3, the three statistics) are NOT formed here: db3 is a column of one more matrix product (dY^T times
         // the ones row of [x | 1]^T) and the statistics are summed from LDS, both by workgroup 0's otherwise idle wave 3 during G2
         if (!h) { statbuf[bsm] = s3[0]; statbuf[MB + bsm] = s3[1]; statbuf[2 * MB + bsm] = s3[2]; }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) *reinterpret_cast<f16x8*>(lds + L_W2COL + lCol + 128u * (uint32_t)i) = wc[i];
         __syncthreads();
         Q1PL_STAMP(4);                                          // outputs + loss gradient + sums
 
@@ -828,71 +920,27 @@ __device__ __forceinline__ void persistent_learner_body(const Args& a, unsigned 
             // (in flight under tile 0's optimizer arithmetic), tile 0 is stored, tile 1's operands are requested - one wait covers them, tile 1's
             // state and tile 0's store acknowledgements.  (Everything of both tiles at once was measured: 96 + 64 live registers spill inside the
             // loop, 20.4 -> 23.0 us per step.)
-            // (two parts: the arithmetic + the new float16 image in LDS;  the global stores - state back, the W2^T rows published: the poll of
-            //  barrier 3 sits between them, so that it never queues behind 64 stores)
-            auto adam_tile = [&](const int t, const int q0, const int q1, const f32x16& acc, float (&w2v)[16], float (&m2v)[16], float (&v2v)[16]) __attribute__((always_inline)) {
-                const uint32_t k = 64u * w + 32u * (uint32_t)t + c;
-#pragma unroll
-                for (int q = q0; q < q1; ++q) {
-#pragma unroll
-                    for (int j = 0; j < 4; j += 2) {
-                        const int r = 4 * q + j;
-                        const f32x2 gr = f32x2{acc[r], acc[r + 1]} * net.inv_scale;
-                        f32x2 mm2 = {m2v[r], m2v[r + 1]}, vv2 = {v2v[r], v2v[r + 1]};
-                        const f32x2 wn = adam2(f32x2{w2v[r], w2v[r + 1]}, gr, mm2, vv2, a.beta1, a.beta2, a.eps, lr_bc1, rs_bc2);
-                        w2v[r] = wn.x; w2v[r + 1] = wn.y; m2v[r] = mm2.x; m2v[r + 1] = mm2.y; v2v[r] = vv2.x; v2v[r + 1] = vv2.y;
-                        const f32x2 wi = c2 * wn;
-                        *reinterpret_cast<_Float16*>(lds + L_W2OWN + (uint32_t)((r & 3) + 8 * (r >> 2)) * LD_W + lOwn + 64u * (uint32_t)t) = (_Float16)wi.x;
-                        *reinterpret_cast<_Float16*>(lds + L_W2OWN + (uint32_t)(((r + 1) & 3) + 8 * ((r + 1) >> 2)) * LD_W + lOwn + 64u * (uint32_t)t) = (_Float16)wi.y;
-                        if (last) {                     // (inspection / tests: a cold block - its 32 addresses must not be hoisted out of the step loop)
-                            uint32_t kk = k;
-                            Q1PL_OPAQUE(kk);
-                            net.gw2[(size_t)(U0 + rrow(r, h)) * HID + kk] = gr.x; net.gw2[(size_t)(U0 + rrow(r + 1, h)) * HID + kk] = gr.y;
-                        }
-                    }
-                }
-            };
-            auto store_tile = [&](const int t, const float (&w2v)[16], const float (&m2v)[16], const float (&v2v)[16]) __attribute__((always_inline)) {
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    xpub8(xr, pFrag + 512u * (uint32_t)q, o_w2tx + ((2u * wu + (uint32_t)t) * 8u + g) * 2048u, pack4(w2v[4 * q], w2v[4 * q + 1], w2v[4 * q + 2], w2v[4 * q + 3]), loc);
-#pragma unroll
-                for (int q = 0; q < 4; ++q) { xst4(xr, vSt + 1024u * (uint32_t)q, s_st(0, (uint32_t)t), w2v + 4 * q); xst4(xr, vSt + 1024u * (uint32_t)q, s_st(1, (uint32_t)t), m2v + 4 * q); xst4(xr, vSt + 1024u * (uint32_t)q, s_st(2, (uint32_t)t), v2v + 4 * q); }
-            };
-            float wB[16], mB[16], vB[16];
-            f16x8 hU[8];
             Q1PL_STAMP(14);                                     // (G2 entered: tile 0's state + operands were requested in the loss phase)
             f32x16 acc = zero16;                                // [u][k]: lane = input k, registers = owned units
 #pragma unroll
             for (int s = 0; s < 8; ++s) acc = mm(lds16(lds, L_DZ2T + lB + 32u * (uint32_t)s), hT[s], acc);
-#pragma unroll
-            for (int s = 0; s < 8; ++s) hU[s] = xld16(xr, vSt + 1024u * (uint32_t)(s & 3), s_h1tx + wu * 16384u + 8192u + 4096u * (uint32_t)(s >> 2));
-#pragma unroll
-            for (int q = 0; q < 4; ++q) { xld4(xr, vSt + 1024u * (uint32_t)q, s_st(0, 1), wB + 4 * q); xld4(xr, vSt + 1024u * (uint32_t)q, s_st(1, 1), mB + 4 * q); xld4(xr, vSt + 1024u * (uint32_t)q, s_st(2, 1), vB + 4 * q); }
-            __builtin_amdgcn_sched_barrier(0);                  // (the requests above are issued HERE, all of them: the scheduler would otherwise sink each to its first use)
             // barrier 3 is polled from HERE: the reading is requested before tile 0's optimizer arithmetic (no store of this wave is in flight:
             // the counter retires behind nothing but loads) and looked at after it - every workgroup arrived right behind its dZ2, ~1 us ago -,
             // then B2's operands (all of dZ2: 16 vectors per lane) are requested and travel under tile 0's stores and all of tile 1
             // (two readings, one before and one in the middle of the arithmetic: the counter is ~1 us away, the later reading is the one that
             //  usually shows all eight tickets and it has come back by the time the arithmetic ends)
             const uint32_t seen3a = tid == 0 ? poll(net.bar, loc) : 0u;
-            adam_tile(0, 0, 2, acc, wA, mA, vA);
+            adam_tile(0, 0, 2, acc, wA, mA, vA, lr_bc1, rs_bc2, last);
             const uint32_t seen3b = tid == 0 ? poll(net.bar, loc) : 0u;
-            adam_tile(0, 2, 4, acc, wA, mA, vA);
+            adam_tile(0, 2, 4, acc, wA, mA, vA, lr_bc1, rs_bc2, last);
             Q1PL_STAMP(15);                                     // (G2: tile 0's products + optimizer)
             if (!bar_wait(net.bar, (uint32_t)G * ++bar_n, loc, a.status, 2u, (uint32_t)step, a.timeout_ticks, s_ok, seen3a > seen3b ? seen3a : seen3b)) return;
             Q1PL_STAMP(7);                                      // (barrier 3 wait)
 #pragma unroll
             for (int s = 0; s < 16; ++s) zr[s] = xld16(xr, vSt + 1024u * (uint32_t)(s & 3), o_dz2x + wu * 16384u + 4096u * (uint32_t)(s >> 2));
             __builtin_amdgcn_sched_barrier(0);                  // (the requests above are issued HERE, all of them: the scheduler would otherwise sink each to its first use)
-            store_tile(0, wA, mA, vA);
+            store_tile(0, par, wA, mA, vA);
             Q1PL_STAMP(16);                                     // (B2's requests + tile 0's stores issued)
-            acc = zero16;
-#pragma unroll
-            for (int s = 0; s < 8; ++s) acc = mm(lds16(lds, L_DZ2T + lB + 32u * (uint32_t)s), hU[s], acc);
-            adam_tile(1, 0, 4, acc, wB, mB, vB);
-            store_tile(1, wB, mB, vB);
-            Q1PL_STAMP(17);                                     // (G2: tile 1 done)
         }
 
         // ------------------------------------------------------------ B2: dH1 of the owned units from all of dZ2, dZ1, then dW1 / db1, db3
@@ -954,7 +1002,15 @@ __device__ __forceinline__ void persistent_learner_body(const Args& a, unsigned 
     }
 #undef Q1PL_STAMP
     step_bases();
-    small_grads(true, lr_prev, rs_prev);                        // the last step's
+    {                                                           // the last step's deferred work
+        const uint32_t parl = (uint32_t)((a.steps - 1) & 1);
+        tile1_request(parl);
+        tile1_run(parl, lr_prev, rs_prev, true);
+        store_tile(1, parl, wB, mB, vB);
+    }
+    grads_b2(true, lr_prev, rs_prev);
+    grads_w3b3(true, lr_prev, rs_prev);
+    grads_stats();
     __syncthreads();
     if constexpr (PROF) {
         if (profiling)
