@@ -227,6 +227,19 @@ __device__ __forceinline__ float sat16(float x, float& amax, uint32_t& nsat) {
     nsat += ax > 65504.0f ? 1u : 0u;
     return __builtin_amdgcn_fmed3f(x, -65504.0f, 65504.0f);
 }
+// four at a time: the largest magnitude by two v_max3 (operand modifiers take the absolute values), the count of elements beyond float16's
+// range only when that maximum says there is one (a branch the wave almost never takes), one v_med3 per element to clamp - 9 instructions per
+// quad where sat16 costs 20 (and a step converts ~170 gradient elements per lane)
+__device__ __forceinline__ void sat16x4(float (&x)[4], float& amax, uint32_t& nsat) {
+    const float m4 = fmaxf(fmaxf(fabsf(x[0]), fabsf(x[1])), fmaxf(fabsf(x[2]), fabsf(x[3])));
+    amax = fmaxf(amax, m4);
+    if (__builtin_expect(m4 > 65504.0f, 0)) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) nsat += fabsf(x[j]) > 65504.0f ? 1u : 0u;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) x[j] = __builtin_amdgcn_fmed3f(x[j], -65504.0f, 65504.0f);
+}
 __device__ __forceinline__ float r16(float x) { return (float)(_Float16)x; }                       // the value the float16 operand carries
 __device__ __forceinline__ float act(float z) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(z) + 1.0f); }   // tanh, z prescaled by 2 log2 e
 // Two exchange modes (wave-uniform `loc`, decided once per launch - see "placement" in the kernel):
@@ -273,13 +286,17 @@ __device__ __forceinline__ float adam1(float w, float g, float& m, float& v, flo
 
 // two elements at a time: the same operations in the same order (packed float32 multiply / add; square root and reciprocal per element)
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+// (explicitly fused multiply-adds - v_pk_fma_f32 -: the library is compiled with -ffp-contract=off for the ENV's arithmetic, whose contract is
+//  the reference's unfused float64; the optimizer has no such contract - torch's own kernels fuse - and this is 13 instead of 17 instructions per pair)
+__device__ __forceinline__ f32x2 fma2(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
 __device__ __forceinline__ f32x2 adam2(f32x2 w, f32x2 g, f32x2& m, f32x2& v, float b1, float b2, float eps, float lr_bc1, float rs_bc2) {
-    m = m + (g - m) * (1.0f - b1);
-    v = v * b2 + ((1.0f - b2) * g) * g;
+    const f32x2 c1 = {1.0f - b1, 1.0f - b1}, c2v = {1.0f - b2, 1.0f - b2}, b2v = {b2, b2}, rsv = {rs_bc2, rs_bc2}, epsv = {eps, eps}, nlr = {-lr_bc1, -lr_bc1};
+    m = fma2(g - m, c1, m);
+    v = fma2(c2v * g, g, v * b2v);
     const f32x2 sq = {__builtin_amdgcn_sqrtf(v.x), __builtin_amdgcn_sqrtf(v.y)};
-    const f32x2 denom = sq * rs_bc2 + eps;
+    const f32x2 denom = fma2(sq, rsv, epsv);
     const f32x2 rc = {__builtin_amdgcn_rcpf(denom.x), __builtin_amdgcn_rcpf(denom.y)};
-    return w - lr_bc1 * (m * rc);
+    return fma2(nlr, m * rc, w);
 }
 
 // arrive: this workgroup's published stores have been acknowledged (by the memory side / by the XCD's L2); one ticket
@@ -893,7 +910,8 @@ __device__ __forceinline__ void persistent_learner_body(const Args& a, unsigned 
             for (int q = 0; q < 4; ++q) {
                 float zA[4];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) zA[j] = sat16(dA[4 * q + j] * (1.0f - h2A[4 * q + j] * h2A[4 * q + j]), amax, nsat);
+                for (int j = 0; j < 4; ++j) zA[j] = dA[4 * q + j] * (1.0f - h2A[4 * q + j] * h2A[4 * q + j]);
+                sat16x4(zA, amax, nsat);
                 pk[q] = pack4(zA[0], zA[1], zA[2], zA[3]);
                 xpub8(xr, pFrag + fq(q), o_dz2x + (wu * 16u + 2u * g) * 1024u, pk[q], loc);
             }
@@ -952,7 +970,8 @@ __device__ __forceinline__ void persistent_learner_body(const Args& a, unsigned 
             for (int q = 0; q < 4; ++q) {
                 float z[4];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) z[j] = sat16(acc[4 * q + j] * (1.0f - h1B[4 * q + j] * h1B[4 * q + j]), amax, nsat);
+                for (int j = 0; j < 4; ++j) z[j] = acc[4 * q + j] * (1.0f - h1B[4 * q + j] * h1B[4 * q + j]);
+                sat16x4(z, amax, nsat);
                 *reinterpret_cast<uint64_t*>(lds + L_DZ1T + lwB + 16u * (uint32_t)q) = pack4(z[0], z[1], z[2], z[3]);
             }
         }
