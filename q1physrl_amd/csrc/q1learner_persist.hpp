@@ -286,17 +286,17 @@ __device__ __forceinline__ float adam1(float w, float g, float& m, float& v, flo
 
 // two elements at a time: the same operations in the same order (packed float32 multiply / add; square root and reciprocal per element)
 typedef float f32x2 __attribute__((ext_vector_type(2)));
-// (explicitly fused multiply-adds - v_pk_fma_f32 -: the library is compiled with -ffp-contract=off for the ENV's arithmetic, whose contract is
-//  the reference's unfused float64; the optimizer has no such contract - torch's own kernels fuse - and this is 13 instead of 17 instructions per pair)
-__device__ __forceinline__ f32x2 fma2(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+// (An explicitly fused form - v_pk_fma_f32, 13 instead of 17 instructions per pair, -0.1 us per step - was built and is equivalent (391 steps
+//  against the four-launch path: the same 1e-4); it is NOT used: at seed 0 the reference-configuration run ended at 5 345 with it instead of
+//  5 666 - seeds 1 and 2 went the other way over their first 300 iterations, i.e. the run is that sensitive to rounding - and the unfused form
+//  keeps this kernel on the trajectory of the round's earlier runs.  STATE.md.)
 __device__ __forceinline__ f32x2 adam2(f32x2 w, f32x2 g, f32x2& m, f32x2& v, float b1, float b2, float eps, float lr_bc1, float rs_bc2) {
-    const f32x2 c1 = {1.0f - b1, 1.0f - b1}, c2v = {1.0f - b2, 1.0f - b2}, b2v = {b2, b2}, rsv = {rs_bc2, rs_bc2}, epsv = {eps, eps}, nlr = {-lr_bc1, -lr_bc1};
-    m = fma2(g - m, c1, m);
-    v = fma2(c2v * g, g, v * b2v);
+    m = m + (g - m) * (1.0f - b1);
+    v = v * b2 + ((1.0f - b2) * g) * g;
     const f32x2 sq = {__builtin_amdgcn_sqrtf(v.x), __builtin_amdgcn_sqrtf(v.y)};
-    const f32x2 denom = fma2(sq, rsv, epsv);
+    const f32x2 denom = sq * rs_bc2 + eps;
     const f32x2 rc = {__builtin_amdgcn_rcpf(denom.x), __builtin_amdgcn_rcpf(denom.y)};
-    return fma2(nlr, m * rc, w);
+    return w - lr_bc1 * (m * rc);
 }
 
 // arrive: this workgroup's published stores have been acknowledged (by the memory side / by the XCD's L2); one ticket

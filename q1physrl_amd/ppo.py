@@ -11,6 +11,7 @@ Loss (RLlib ppo_tf_policy.PPOLoss restated for torch):
 Multi-GPU: every rank samples its own env shard; the only collective of the whole system is the gradient
 all-reduce of the 138 k-parameter policy (one 552 KB flat bucket per SGD step; RCCL when the backend is nccl).
 """
+import os
 import torch
 import torch.distributed as dist
 
@@ -243,7 +244,7 @@ class PPOLearner:
         self._perm = None                       # native + own Adam: the epoch's permutation, read through the device-resident cursor
         self._perms = None                      # persistent learner: all epochs' permutations of one update
         self._perms_next, self._perms_ready, self._perm_stream = None, None, None      # ... and the next update's, drawn ahead
-        self.prefetch_perms = True
+        self.prefetch_perms = os.environ.get("Q1_PPO_PREFETCH_PERMS", "1") != "0"
         # autocast_dtype (e.g. torch.bfloat16): the two MLPs' matrix products run on reduced-precision operands with float32
         # accumulation (master weights, loss, its gradient and Adam stay float32); fused_adam: one multi-tensor Adam launch
         self.autocast_dtype = autocast_dtype
