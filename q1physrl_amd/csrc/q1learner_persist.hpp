@@ -38,7 +38,8 @@
 // Exchange layouts.  Everything that crosses workgroups is stored in the order its CONSUMER's 64-lane requests read it ("operand-fragment
 // order": Net below), addressed through one buffer resource per group with scalar block offsets: a request covers one contiguous KB (8 cache
 // lines) where the row-major forms touched 32 or 64 scattered lines - the CU's one request per clock, not latency or arithmetic, had been
-// what bounded every phase that touches exchanged data (20.2 -> 14.4 us per step from this alone).
+// what bounded every phase that touches exchanged data (20.2 -> 14.4 us per step from this alone).  For the same reason the W2 slice's
+// optimizer state stays in registers during the loop instead of streaming through L2 every step (12.65 -> 11.7).
 //
 // Exchange protocol.  Two modes, decided per launch (see "placement" in the kernel).  Agent scope: published data are written through
 // (sc0 sc1), "arrive" = s_waitcnt vmcnt(0), workgroup barrier, one relaxed increment; "wait" = poll, workgroup barrier, buffer_inv sc1.
@@ -103,7 +104,8 @@ struct Net {
                           // 8-byte store, so a publishing request is one contiguous 512 B and a consumer's column block one contiguous 16 KB
     float* yp;            // [G][4 sample tiles w][4 output quads v][32 samples c][4]: partial logits 4 v .. 4 v + 3 of sample 32 w + c
     float* b3x;           // [16]: the output layer's bias as the group reads it (published by workgroup 0 after every step), zero padded
-    float* w2st;          // [G][3 (master, m, v)][4 waves][8 slot quads][64 lanes][4]: the W2 slice's optimizer state in its OWNER LANE's order
+    float* w2st;          // [G][3 (master, m, v)][4 waves][8 slot quads][64 lanes][4]: the W2 slice's optimizer state in its OWNER LANE's order (the
+                          // hand-over between the torch layouts and the owner lanes' registers, where it lives during the step loop)
     uint32_t* bar;        // arrival counter (own 256-byte line)
     const char* xbase;    // lowest address of this group's exchange workspace (the buffer resource of its exchange loads)
     float inv_b;          // d loss / d output travels multiplied by this (loss scale / 1: per-sample, not averaged)
@@ -513,13 +515,13 @@ __device__ __forceinline__ void persistent_learner_body(const Args& a, unsigned 
     uint32_t nsat = 0;
     uint32_t bar_n = 0;                                         // barriers passed
     float lr_prev = 0.0f, rs_prev = 0.0f;                       // the previous step's bias corrections (its deferred work)
-    // rows of the FIRST step (every later step's are fetched one step ahead): srcX = the sample whose observation this thread stages
-    // (threads 0..127), srcL = the sample whose loss this lane pair differentiates
+    // rows of the FIRST step (every later step's are fetched one step ahead): srcX = the sample whose observation this lane stages, srcL = the
+    // sample whose loss this lane pair differentiates (the same sample, 32 w + c)
     // (no division in the loop: the position of the next step's window is kept incrementally)
     int64_t win = 0;                                            // offset of the CURRENT step's 128-row window in idx
     int64_t in_epoch = 0;                                       // its index within the epoch
     auto row_at = [&](int64_t window, uint32_t b) -> int64_t { return a.idx ? a.idx[window + (int64_t)b] : window + (int64_t)b; };
-    int64_t srcX = row_at(0, tid & (MB - 1)), srcL = row_at(0, bsm);
+    int64_t srcX = row_at(0, bsm), srcL = row_at(0, bsm);       // (two variables on purpose: with one for both uses the compiled kernel faulted - STATE.md)
     // ... and the observation row itself (24 bytes from HBM at a random row: ~2 us of latency that would otherwise open every step)
     float oxn[6];
     auto request_obs = [&]() {
@@ -572,28 +574,36 @@ __device__ __forceinline__ void persistent_learner_body(const Args& a, unsigned 
         }
     };
     // (par2: which of the two W2^T exchange buffers - the parity of the step the update belongs to)
-    auto store_tile = [&](const int t, const uint32_t par2, const float (&w2v)[16], const float (&m2v)[16], const float (&v2v)[16]) __attribute__((always_inline)) {
+    auto store_tile = [&](const int t, const uint32_t par2, const float (&w2v)[16], const float (&m2v)[16], const float (&v2v)[16], const bool state = true) __attribute__((always_inline)) {
 #pragma unroll
         for (int q = 0; q < 4; ++q)
             xpub8(xr, pFrag + 512u * (uint32_t)q, o_w2tx + par2 * 131072u + ((2u * wu + (uint32_t)t) * 8u + g) * 2048u, pack4(w2v[4 * q], w2v[4 * q + 1], w2v[4 * q + 2], w2v[4 * q + 3]), loc);
+        if (state) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) { xst4(xr, vSt + 1024u * (uint32_t)q, s_st(0, (uint32_t)t), w2v + 4 * q); xst4(xr, vSt + 1024u * (uint32_t)q, s_st(1, (uint32_t)t), m2v + 4 * q); xst4(xr, vSt + 1024u * (uint32_t)q, s_st(2, (uint32_t)t), v2v + 4 * q); }
+            for (int q = 0; q < 4; ++q) { xst4(xr, vSt + 1024u * (uint32_t)q, s_st(0, (uint32_t)t), w2v + 4 * q); xst4(xr, vSt + 1024u * (uint32_t)q, s_st(1, (uint32_t)t), m2v + 4 * q); xst4(xr, vSt + 1024u * (uint32_t)q, s_st(2, (uint32_t)t), v2v + 4 * q); }
+        }
     };
+    // The W2 slice's optimizer state (2 tiles x 48 values per lane) stays in REGISTERS for the whole launch: read here once, written back behind
+    // the loop.  Streamed through L2 every step it was 48 KB of the ~125 KB a wave moved per step, on a CU whose address unit was the bound of
+    // several phases: 12.65 -> 11.7 us per step (the same bits).
+    float wA[16], mA[16], vA[16];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { xld4(xr, v_st + 1024u * (uint32_t)q, s_st(0, 0), wA + 4 * q); xld4(xr, v_st + 1024u * (uint32_t)q, s_st(1, 0), mA + 4 * q); xld4(xr, v_st + 1024u * (uint32_t)q, s_st(2, 0), vA + 4 * q); }
     // TILE 1 of a step's W2 gradient (inputs k = 64 w + 32 + c) is DEFERRED like the small gradients: its operands (H1^T of that step: the
-    // exchange buffer of that parity stays intact for two steps; dZ2^T in LDS: rewritten by the next step's B3) and its optimizer state are
+    // exchange buffer of that parity stays intact for two steps; dZ2^T in LDS: rewritten by the next step's B3) are
     // requested at the top of the NEXT step and it runs between that step's arrival at barrier 1 and the wait for it - ~1.3 us of work in
     // a window in which the workgroup would otherwise only wait - instead of between barrier 3 and B2, on the step's critical path.  Its
     // new weights are needed by the next P2 (LDS image: behind the barrier wait's workgroup barrier) and by the other workgroups' column
     // gathers, which therefore read W2^T behind barrier 2 and from the buffer of the update's parity (two buffers: a fast workgroup
     // publishes tile 0 of the NEXT update right behind its arrival at barrier 3, possibly before a slow one has gathered).
-    float wB[16], mB[16], vB[16];
+    float wB[16], mB[16], vB[16];                                // (tile 1's optimizer state: see wA)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { xld4(xr, v_st + 1024u * (uint32_t)q, s_st(0, 1), wB + 4 * q); xld4(xr, v_st + 1024u * (uint32_t)q, s_st(1, 1), mB + 4 * q); xld4(xr, v_st + 1024u * (uint32_t)q, s_st(2, 1), vB + 4 * q); }
     f16x8 hU[8];
     auto tile1_request = [&](const uint32_t parity) __attribute__((always_inline)) {
         const uint32_t sb = o_h1tx + parity * (uint32_t)(MB * HID * 2) + wu * 16384u + 8192u;
 #pragma unroll
         for (int s = 0; s < 8; ++s) hU[s] = xld16(xr, vSt + 1024u * (uint32_t)(s & 3), sb + 4096u * (uint32_t)(s >> 2));
-#pragma unroll
-        for (int q = 0; q < 4; ++q) { xld4(xr, vSt + 1024u * (uint32_t)q, s_st(0, 1), wB + 4 * q); xld4(xr, vSt + 1024u * (uint32_t)q, s_st(1, 1), mB + 4 * q); xld4(xr, vSt + 1024u * (uint32_t)q, s_st(2, 1), vB + 4 * q); }
         __builtin_amdgcn_sched_barrier(0);
     };
     auto tile1_run = [&](const uint32_t parity, const float lr_bc1, const float rs_bc2, const bool store_grads) __attribute__((always_inline)) {
@@ -706,7 +716,7 @@ __device__ __forceinline__ void persistent_learner_body(const Args& a, unsigned 
         float ox[6];
 #pragma unroll
         for (int i = 0; i < 6; ++i) ox[i] = oxn[i];              // (requested during the previous step's loss phase)
-        if (tid < MB) {
+        if (h == 0u) {                                           // (lanes 0 .. 31 of every wave: sample 32 w + c - the rows this wave's own P1 reads)
             _Float16 hi[6], lo[6];
 #pragma unroll
             for (int i = 0; i < 6; ++i) {
@@ -714,16 +724,19 @@ __device__ __forceinline__ void persistent_learner_body(const Args& a, unsigned 
                 hi[i] = (_Float16)xs;
                 lo[i] = (_Float16)(xs - (float)hi[i]);
             }
-            _Float16* row = reinterpret_cast<_Float16*>(lds + L_XH + tid * LD_16);
+            _Float16* row = reinterpret_cast<_Float16*>(lds + L_XH + bsm * LD_16);
 #pragma unroll
             for (int i = 0; i < 6; ++i) {
                 row[i] = hi[i]; row[8 + i] = lo[i];
-                *reinterpret_cast<_Float16*>(lds + L_XT + (uint32_t)i * LD_B + 2u * tid) = hi[i];
-                *reinterpret_cast<_Float16*>(lds + L_XT + (uint32_t)(8 + i) * LD_B + 2u * tid) = lo[i];
+                *reinterpret_cast<_Float16*>(lds + L_XT + (uint32_t)i * LD_B + 2u * bsm) = hi[i];
+                *reinterpret_cast<_Float16*>(lds + L_XT + (uint32_t)(8 + i) * LD_B + 2u * bsm) = lo[i];
             }
             row[6] = (_Float16)1.0f; row[7] = (_Float16)0.0f; row[14] = (_Float16)1.0f; row[15] = (_Float16)0.0f;
         }
-        __syncthreads();
+        // (wave-level ordering is enough: P1 reads this wave's own rows of L_XH; the transposed image L_XT is read workgroup barriers later)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         const float lr_bc1 = a.lr / (float)(1.0 - pw1), rs_bc2 = 1.0f / sqrtf((float)(1.0 - pw2));    // lr / bias_correction1, 1 / sqrt(bias_correction2)
 
         if (step > 0) tile1_request(par ^ 1u);                    // (the previous step's deferred tile: see tile1_run)
@@ -753,7 +766,7 @@ __device__ __forceinline__ void persistent_learner_body(const Args& a, unsigned 
         if (step > 0) {                                          // the previous step's deferred work: see tile1_run, grads_b2
             tile1_run(par ^ 1u, lr_prev, rs_prev, false);
             seen1 = tid == 0 ? poll(net.bar, loc) : 0u;         // (requested ~1 us behind the arrival and IN FRONT of the tile's stores, looked at behind the rest of the window's work)
-            store_tile(1, par ^ 1u, wB, mB, vB);
+            store_tile(1, par ^ 1u, wB, mB, vB, false);
             grads_b2(false, lr_prev, rs_prev);
         }
         Q1PL_STAMP(17);                                         // (the barrier-1 window's work)
@@ -763,7 +776,7 @@ __device__ __forceinline__ void persistent_learner_body(const Args& a, unsigned 
         // the NEXT step's row indices, requested while the barrier is in flight
         if (!last) {
             if (++in_epoch == a.spe) { in_epoch = 0; win += a.epoch_stride - (a.spe - 1) * MB; } else { win += MB; }
-            srcX = row_at(win, tid & (MB - 1)); srcL = row_at(win, bsm);
+            srcX = row_at(win, bsm); srcL = row_at(win, bsm);
         }
         if (!bar_wait(net.bar, (uint32_t)G * ++bar_n, loc, a.status, 0u, (uint32_t)step, a.timeout_ticks, s_ok, seen1)) return;
         Q1PL_STAMP(1);                                          // barrier 1
@@ -835,7 +848,6 @@ __device__ __forceinline__ void persistent_learner_body(const Args& a, unsigned 
         // HALF of the G partial rows (one round of loads), the halves are exchanged: y = b3 + (A + B) in both lanes, the same bits.
         float s3[3] = {0.0f, 0.0f, 0.0f};
         float gl[10];
-        float wA[16], mA[16], vA[16];                           // (G2's first tile: see below)
         f16x8 hT[8];                                            // ... and its H1^T operand rows
         f16x8 zr[16];                                           // B2's operands: this wave's rows of ALL of dZ2 (requested inside G2, behind barrier 3)
         f16x8 wc[4];                                            // this thread's share of W2's column block (gathered behind barrier 2: see tile1_run)
@@ -864,9 +876,7 @@ __device__ __forceinline__ void persistent_learner_body(const Args& a, unsigned 
                     y[o] = part[4][o >> 2][o & 3] + (lo_ + hi_);
                 }
             }
-            // tile 0's optimizer state for G2 (private, coalesced): requested here, two phases early - its L2 round trip was 0.8 us at the head of G2
-#pragma unroll
-            for (int q = 0; q < 4; ++q) { xld4(xr, vSt + 1024u * (uint32_t)q, s_st(0, 0), wA + 4 * q); xld4(xr, vSt + 1024u * (uint32_t)q, s_st(1, 0), mA + 4 * q); xld4(xr, vSt + 1024u * (uint32_t)q, s_st(2, 0), vA + 4 * q); }
+            // tile 0's H1^T operand rows for G2: requested here, two phases early
 #pragma unroll
             for (int s = 0; s < 8; ++s) hT[s] = xld16(xr, vSt + 1024u * (uint32_t)(s & 3), s_h1tx + wu * 16384u + 4096u * (uint32_t)(s >> 2));    // (H1^T has been complete since barrier 1)
             if (!last) request_obs();                           // the NEXT step's observation rows (srcX was advanced behind barrier 1); behind this
@@ -890,11 +900,20 @@ __device__ __forceinline__ void persistent_learner_body(const Args& a, unsigned 
 #pragma unroll
             for (int o = 0; o < 16; ++o) row16[o] = (_Float16)0.0f;
 #pragma unroll
-            for (int o = 0; o < 10; ++o) {
-                if (o < OUT) {
-                    row16[o] = (_Float16)sat16(gl[o], amax, nsat);
-                    gl[o] = h ? 0.0f : (float)row16[o];         // (the pair computed the same row: lane h = 0 stores it and counts in the sums)
-                    if (!h) *reinterpret_cast<_Float16*>(lds + L_DYT + (uint32_t)o * LD_B + 2u * bsm) = row16[o];
+            for (int k = 0; k < 3; ++k) {                       // (quads of outputs: sat16x4; slots beyond OUT are zeros - they change neither statistic)
+                if (4 * k < OUT) {
+                    float g4[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) g4[j] = (4 * k + j < OUT && 4 * k + j < 10) ? gl[4 * k + j] : 0.0f;
+                    sat16x4(g4, amax, nsat);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int o = 4 * k + j;
+                        if (o < OUT && o < 10) {
+                            row16[o] = (_Float16)g4[j];
+                            if (!h) *reinterpret_cast<_Float16*>(lds + L_DYT + (uint32_t)o * LD_B + 2u * bsm) = row16[o];      // (the pair computed the same row: lane h = 0 stores it)
+                        }
+                    }
                 }
             }
             if (!h) {
@@ -971,7 +990,7 @@ __device__ __forceinline__ void persistent_learner_body(const Args& a, unsigned 
 #pragma unroll
             for (int s = 0; s < 16; ++s) zr[s] = xld16(xr, vSt + 1024u * (uint32_t)(s & 3), o_dz2x + wu * 16384u + 4096u * (uint32_t)(s >> 2));
             __builtin_amdgcn_sched_barrier(0);                  // (the requests above are issued HERE, all of them: the scheduler would otherwise sink each to its first use)
-            store_tile(0, par, wA, mA, vA);
+            store_tile(0, par, wA, mA, vA, false);
             Q1PL_STAMP(16);                                     // (B2's requests + tile 0's stores issued)
         }
 
@@ -1039,8 +1058,10 @@ __device__ __forceinline__ void persistent_learner_body(const Args& a, unsigned 
         const uint32_t parl = (uint32_t)((a.steps - 1) & 1);
         tile1_request(parl);
         tile1_run(parl, lr_prev, rs_prev, true);
-        store_tile(1, parl, wB, mB, vB);
+        store_tile(1, parl, wB, mB, vB, true);
     }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { xst4(xr, vSt + 1024u * (uint32_t)q, s_st(0, 0), wA + 4 * q); xst4(xr, vSt + 1024u * (uint32_t)q, s_st(1, 0), mA + 4 * q); xst4(xr, vSt + 1024u * (uint32_t)q, s_st(2, 0), vA + 4 * q); }
     grads_b2(true, lr_prev, rs_prev);
     grads_w3b3(true, lr_prev, rs_prev);
     grads_stats();

@@ -22,7 +22,7 @@ timeout 1300 python tools/train_ppo.py --refcfg --native --fused-policy --iters 
     --out $O/r5_train_ppo_refcfg_persistent_final2.json --save $O/r5_policy_refcfg_final2.npz > $O/train.log 2>&1
 tail -2 $O/train.log | cut -c1-300 > $O/train_tail.txt
 timeout 3000 bash tools/profile_round.sh r5 all > $O/profile_round.log 2>&1
-for sd in 1 2; do
+for sd in ${SEEDS:-}; do
     timeout 1300 python tools/train_ppo.py --refcfg --native --fused-policy --iters 2989 --log-every 50 --eval-every 100 --seed $sd --checkpoint-dir /tmp/r5_ck_s$sd \
         --out $O/r5_train_ppo_refcfg_persistent_seed$sd.json > $O/train_s$sd.log 2>&1
     tail -1 $O/train_s$sd.log | cut -c1-200 >> $O/train_tail.txt
