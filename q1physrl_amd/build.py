@@ -96,9 +96,12 @@ def _run(cmd, verbose):
         print(r.stderr, file=sys.stderr)
 
 
-def build_lib(force=False, verbose=False, check=False, extra_flags=(), out=None, tag=None):
+def build_lib(force=False, verbose=False, check=False, extra_flags=(), out=None, tag=None, allow_miscompiled=False):
     """Compile the stale translation units (in parallel) and link.  check=True: the -DQ1_CHECK assertion build (libq1env_check.so).
-    out / tag: an experimental variant (extra_flags) built next to the product library, e.g. tools/exp_step_large.py."""
+    out / tag: an experimental variant (extra_flags) built next to the product library, e.g. tools/exp_step_large.py.
+    Every library is disassembled and held to q1physrl_amd/isa_check.py's rule before it replaces the previous one (the compiler bug that made
+    the persistent learner fault in round 5 is visible in the machine code and nowhere else); allow_miscompiled=True only for the diagnostic
+    variant that reproduces it (tools/r6_fault.sh)."""
     if out is None:
         out = OUT_CHECK if check else OUT
     if tag is None:
@@ -128,6 +131,14 @@ def build_lib(force=False, verbose=False, check=False, extra_flags=(), out=None,
     with concurrent.futures.ThreadPoolExecutor(max_workers=max(1, min(len(jobs), os.cpu_count() or 1))) as ex:
         list(ex.map(lambda c: _run(c, verbose), jobs))
     _run([hipcc] + LINK_FLAGS + [_obj_of(s, tag) for s in SOURCES] + ["-o", out + ".tmp"], verbose)
+    if not allow_miscompiled:
+        from . import isa_check
+        try:
+            isa_check.check_objects([out + ".tmp"])
+        except RuntimeError:
+            for stray in glob.glob(out + ".tmp*"):
+                os.remove(stray)
+            raise
     os.replace(out + ".tmp", out)
     for stray in glob.glob(out + ".*"):            # the offload bundler's per-target intermediates (libq1env.so.0.hipv4-..., ...)
         try:

@@ -521,7 +521,12 @@ __device__ __forceinline__ void persistent_learner_body(const Args& a, unsigned 
     int64_t win = 0;                                            // offset of the CURRENT step's 128-row window in idx
     int64_t in_epoch = 0;                                       // its index within the epoch
     auto row_at = [&](int64_t window, uint32_t b) -> int64_t { return a.idx ? a.idx[window + (int64_t)b] : window + (int64_t)b; };
+#ifdef Q1PL_ONE_ROW_VAR
+    int64_t srcX = row_at(0, bsm);
+#define srcL srcX
+#else
     int64_t srcX = row_at(0, bsm), srcL = row_at(0, bsm);       // (two variables on purpose: with one for both uses the compiled kernel faulted - STATE.md)
+#endif
     // ... and the observation row itself (24 bytes from HBM at a random row: ~2 us of latency that would otherwise open every step)
     float oxn[6];
     auto request_obs = [&]() {
@@ -776,7 +781,11 @@ __device__ __forceinline__ void persistent_learner_body(const Args& a, unsigned 
         // the NEXT step's row indices, requested while the barrier is in flight
         if (!last) {
             if (++in_epoch == a.spe) { in_epoch = 0; win += a.epoch_stride - (a.spe - 1) * MB; } else { win += MB; }
+#ifdef Q1PL_ONE_ROW_VAR
+            srcX = row_at(win, bsm);
+#else
             srcX = row_at(win, bsm); srcL = row_at(win, bsm);
+#endif
         }
         if (!bar_wait(net.bar, (uint32_t)G * ++bar_n, loc, a.status, 0u, (uint32_t)step, a.timeout_ticks, s_ok, seen1)) return;
         Q1PL_STAMP(1);                                          // barrier 1
