@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define Q1ENV_ABI_VERSION 5
+#define Q1ENV_ABI_VERSION 6
 
 typedef enum q1env_status {
     Q1ENV_OK = 0,
@@ -448,7 +448,7 @@ int q1env_learner_adam(q1env_t* env, const q1env_learner_net* pi, const q1env_le
 int q1env_learner_sgd_step(q1env_t* env, const q1env_learner_net* pi, const q1env_learner_net* vf, void* ws_dev, int splits,
                            const q1env_learner_batch* batch, float lr, float beta1, float beta2, float eps, void* adam_state_dev);
 
-/* ---- persistent learner (ABI v5) -------------------------------------------------------------------------------
+/* ---- persistent learner (ABI v5, extended in v6) -------------------------------------------------------------------------------
  * `steps` SGD steps of 128-sample minibatches - forward, PPO loss gradient, backward, weight gradients, Adam, for both networks - as
  * ONE dispatch of 2 x 8 co-operating workgroups (csrc/q1learner_persist.hpp): what RLlib's PPO does 11 719 times per training
  * iteration under the reference's configuration (sgd_minibatch_size 128 x num_sgd_iter 30 over train_batch_size 50 000:
@@ -468,12 +468,37 @@ int q1env_learner_sgd_step(q1env_t* env, const q1env_learner_net* pi, const q1en
  * (exchange buffers, barrier counters, the W2 slices' optimizer state in owner-lane order, status).  The 16 workgroups spin
  * on group barriers and must be co-resident (they are whenever 16 CUs are free); every wait is bounded by timeout_s (<= 0: 5 s) and a
  * timeout is reported by q1env_learner_persistent_status: status4[0] != 0 (1 + index of the barrier within the step), [1] the step.
- * Asynchronous on the handle's stream like every launch. */
+ * Asynchronous on the handle's stream like every launch.
+ * (ABI v6) idx_rows = the number of int64 entries of batch->idx_dev (ignored when it is NULL): a schedule that would read past it - or, without
+ * an index list, past batch_rows - is refused with Q1ENV_ERR_INVALID_ARG instead of being read (the VALUES of idx_dev are the caller's
+ * contract; the assertion build of the library, -DQ1_CHECK, compares every one of them with batch_rows on the device).  The step count the
+ * launch starts from is snapshotted by its first kernel, so that the two networks' workgroup groups - which never synchronise with each other -
+ * apply the same Adam bias correction however late one of them starts.
+ *
+ * Exchange mode (ABI v6; csrc/q1learner_persist.hpp "Exchange protocol").  0 = automatic (default): every launch takes a census of the XCD each
+ * of a network's eight workgroups runs on; if all eight share one, they exchange through that XCD's L2 (plain stores, device-scope loads,
+ * barrier tickets counted in the L2: ~11.8 us per step), otherwise through agent-scope write-through stores and invalidations (what the
+ * language's memory model backs on any placement: ~16.7 us).  1 = agent scope always.  2 = automatic with a census that is MADE to disagree
+ * (tests: the fallback is then chosen by the same code path a partitioned device or a different dispatcher would take).  The mode each group
+ * actually ran in is status4[2] (policy) / status4[3] (value): 0 = agent scope, otherwise 1 + the XCD the group shared.
+ * q1env_learner_set_profiling: -1 = off (default); g + 8 w = launch the instantiation that stamps wave w of workgroup g of the policy group
+ * (10-ns ticks per phase, summed over the steps, as uint64[20] at byte 24 of the status line: tools/time_learner_persistent.py).
+ * q1env_learner_persistent_layout: byte offsets, inside pws_dev, of network `net`'s (0 policy, 1 value) exchange buffers - {barrier line, b3,
+ * H1, H1^T, dZ2, W2^T, partial logits, W2 optimizer state} - and, ninth, the bytes of the group's exchange workspace (inspection / tests:
+ * tests/test_hip_learner.py reads back the rows a step actually gathered).
+ * q1env_learner_debug_counters: out5 = {1 if built with -DQ1_CHECK else 0, exchange accesses checked, row indices checked, barrier readings
+ * checked, assertions failed}; an assertion that fails is also reported as status4[0] = 0x100 + code (0x101 exchange offset outside the
+ * group's workspace, 0x102 row index >= batch_rows, 0x103 schedule position outside idx_dev, 0x104 barrier reading outside its range),
+ * status4[1] = the offending value - and the access is skipped: a status word, not a memory fault.  Synchronises the stream. */
 uint64_t q1env_learner_persistent_bytes(int64_t batch_rows);
 int q1env_learner_sgd_epochs(q1env_t* env, const q1env_learner_net* pi, const q1env_learner_net* vf, void* pws_dev, const q1env_learner_batch* batch,
-                             int64_t batch_rows, int64_t steps, int64_t steps_per_epoch, int64_t epoch_stride, float lr, float beta1, float beta2,
-                             float eps, void* adam_state_dev, double timeout_s);
+                             int64_t batch_rows, int64_t idx_rows, int64_t steps, int64_t steps_per_epoch, int64_t epoch_stride, float lr, float beta1,
+                             float beta2, float eps, void* adam_state_dev, double timeout_s);
 int q1env_learner_persistent_status(q1env_t* env, const void* pws_dev, uint32_t* status4_host);   /* synchronises the stream */
+int q1env_learner_set_exchange_mode(q1env_t* env, int mode);
+int q1env_learner_set_profiling(q1env_t* env, int wave_of_group);
+int q1env_learner_persistent_layout(int64_t batch_rows, int net, uint64_t* offsets9_host);
+int q1env_learner_debug_counters(q1env_t* env, uint64_t* out5_host);
 
 /* Episode bookkeeping of one sampler tick (the reference's on_episode_end metric hook, q1physrl/train.py:54-57):
  * ep_return double[N] += reward; for envs with done != 0 the finished return is added to this wave's slot of

@@ -13,7 +13,7 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 # Q1ENV_LIB_PATH selects another build of the SAME library (tools/asan_check.sh: the AddressSanitizer build of the host side)
 LIB_PATH = os.environ.get("Q1ENV_LIB_PATH") or os.path.join(_PKG, "libq1env.so")
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 ACT_F64_ROWS, ACT_F32_ROWS, ACT_PACKED, ACT_RANDOM = 0, 1, 2, 3
 OBS_F64, OBS_F32 = 0, 1
 TIMER_START, TIMER_STOP = 4, 8     # q1env_step_many use_graph flags: record the handle's start / stop timer event around the launches
@@ -122,8 +122,12 @@ _SIGNATURES = {
     "q1env_learner_sgd_step": (C.c_int, [_P, C.POINTER(Q1LearnerNet), C.POINTER(Q1LearnerNet), _P, C.c_int, C.POINTER(Q1LearnerBatch)] + [C.c_float] * 4 + [_P]),
     "q1env_learner_set_loss_scale": (C.c_int, [_P, C.c_float, C.c_float]),
     "q1env_learner_persistent_bytes": (C.c_uint64, [C.c_int64]),
-    "q1env_learner_sgd_epochs": (C.c_int, [_P, C.POINTER(Q1LearnerNet), C.POINTER(Q1LearnerNet), _P, C.POINTER(Q1LearnerBatch), C.c_int64, C.c_int64, C.c_int64, C.c_int64]
+    "q1env_learner_sgd_epochs": (C.c_int, [_P, C.POINTER(Q1LearnerNet), C.POINTER(Q1LearnerNet), _P, C.POINTER(Q1LearnerBatch)] + [C.c_int64] * 5
                                  + [C.c_float] * 4 + [_P, C.c_double]),
+    "q1env_learner_set_exchange_mode": (C.c_int, [_P, C.c_int]),
+    "q1env_learner_set_profiling": (C.c_int, [_P, C.c_int]),
+    "q1env_learner_persistent_layout": (C.c_int, [C.c_int64, C.c_int, C.POINTER(C.c_uint64)]),
+    "q1env_learner_debug_counters": (C.c_int, [_P, C.POINTER(C.c_uint64)]),
     "q1env_learner_persistent_status": (C.c_int, [_P, _P, C.POINTER(C.c_uint32)]),
     "q1env_sample_step": (C.c_int, [_P, _P, C.c_int, C.c_uint64, _P, C.c_uint64, C.c_int] + [_P] * 9),
     "q1env_episode_stats": (C.c_int, [_P, _P, _P, _P, _P, _P]),

@@ -17,15 +17,9 @@ namespace {
 // r3_train_ppo_native_*.json): pi_upscale = 256 - the policy head starts with weights of 1e-2 x (RLlib's
 // normc_initializer(0.01)), so dZ2 = W3^T dY and dZ1 behind it sat at 1e-3 .. 1e-6, partly in float16's subnormal range, and one seed
 // of five plateaued at 5 230 instead of ~5 650 until the scale lifted them; value_downscale = 1 (B / 64 cost two of three seeds the
-// same way from the other side).  Outliers saturate (cvt8_sat).  Q1_LEARNER_PI_UPSCALE / Q1_LEARNER_VALUE_DOWNSCALE override (read once).
-static float learner_pi_upscale(const q1env* h) {
-    static const float v = [] { const char* e = getenv("Q1_LEARNER_PI_UPSCALE"); const float f = e ? (float)atof(e) : 256.0f; return f > 0.0f ? f : 256.0f; }();
-    return h->pi_upscale > 0.0f ? h->pi_upscale : v;             // (q1env_learner_set_loss_scale overrides the default / the environment)
-}
-static float learner_value_downscale(const q1env* h) {
-    static const float v = [] { const char* e = getenv("Q1_LEARNER_VALUE_DOWNSCALE"); const float f = e ? (float)atof(e) : 1.0f; return f > 0.0f ? f : 1.0f; }();
-    return h->value_downscale > 0.0f ? h->value_downscale : v;
-}
+// same way from the other side).  Outliers saturate (cvt8_sat).  Changed per handle by q1env_learner_set_loss_scale, not by the environment.
+static float learner_pi_upscale(const q1env* h) { return h->pi_upscale > 0.0f ? h->pi_upscale : 256.0f; }             // (q1env_learner_set_loss_scale)
+static float learner_value_downscale(const q1env* h) { return h->value_downscale > 0.0f ? h->value_downscale : 1.0f; }
 constexpr size_t IMG_FWD_BYTES = (q1pol::LDS_W2 + q1pol::LDS_W3);           // 152064: float16[288][264]
 constexpr size_t IMG_W2T_BYTES = q1learn::LDS_W2T;                          // 135168
 constexpr size_t IMG_W3T_BYTES = q1learn::LDS_W3T;                          // 20480

@@ -117,6 +117,7 @@ struct Args {
     Net net[2];
     // the train batch (q1env_learner_batch; mouse_u = mouse_u_kernel's output in the workspace) and the minibatch schedule: step n reads rows idx[(n / spe) * epoch_stride + (n % spe) * 128 + b]
     const int64_t* idx; int64_t spe, epoch_stride;
+    int64_t rows, idx_rows;    // rows of the train batch arrays / entries of idx (the host validated the schedule against them; the assertion build re-checks every access)
     const float* obs; const float* old_logits; int old_stride;
     int wide_old;              // old_logits rows are 8-byte aligned: read as five 8-byte loads
     const uint8_t* keys; const float* mouse_u; const float* logp_old; const float* adv; const float* value_old; const float* vtarg;
@@ -124,16 +125,53 @@ struct Args {
     const float* klc_dev;
     float lr, beta1, beta2, eps;
     int64_t steps;
-    long long* step_count;     // adam_state + 0
+    long long* step_count;     // adam_state + 0 (written by the epilogue: the snapshot + steps)
+    const long long* step0_snap;   // its value at the start of the launch, copied by mouse_u_kernel (which runs first on the stream) into the status line: the two
+                               // groups never synchronise with each other, so a late group must not read the count the other's epilogue has already advanced
     float* stats_acc;          // adam_state + 16: [entropy, kl, policy_loss, total (left to the host), vf_loss] running sums of per-step means
     uint32_t* saturation;      // optional uint32[4] (q1env_learner_batch.saturation_dev)
     uint32_t* status;          // uint32[4]: [0] != 0: a barrier timed out (value = 1 + barrier index), [1] the step it happened in,
                                // [2], [3]: exchange mode of the policy / value group (1 + the XCD all its workgroups share, 0 = agent scope)
-    int allow_local;           // 0: always the agent-scope exchange mode (A/B)
+    int allow_local;           // 0: always the agent-scope exchange mode (q1env_learner_set_exchange_mode)
+    int census_skew;           // != 0 (tests): every workgroup reports a different XCD, so that the census fails and the automatic fallback is what runs
     unsigned long long* prof;  // optional uint64[20] (the rest of the status line): 10-ns ticks wave 0 of workgroup prof_g of the policy group spent per phase, summed over the steps
     int prof_g;
     uint64_t timeout_ticks;
 };
+
+// ---- the assertion build (-DQ1_CHECK, libq1env_check.so; tests/test_hip_learner.py runs a whole update of 11 730 steps under it).  Every access
+// to an exchange buffer is compared with the group's workspace size before it is issued (and the buffer resource is BOUNDED, so that a
+// missed case is dropped by the hardware instead of landing in somebody else's memory), every row index is compared with the number of
+// rows before it is used as an address, every position in the schedule with the length of idx, every reading of a barrier counter with the
+// range the protocol allows.  A failed assertion writes 0x100 + its code into status[0] (the step into status[1]) - the words a barrier
+// timeout is reported in - and the access is skipped / the index replaced by 0: a status word, not a memory fault.
+#ifdef Q1_CHECK
+constexpr uint32_t CHK_XOFF = 0x101, CHK_ROW = 0x102, CHK_SCHED = 0x103, CHK_BAR = 0x104;
+__device__ uint32_t* g_chk_status;                 // the launch's status line
+__device__ uint32_t g_chk_xbytes;                  // bytes of one group's exchange workspace
+__device__ unsigned long long g_chk_counts[4];     // exchange accesses / row indices / barrier readings checked (one count per wave and call), failures
+__device__ __forceinline__ void chk_fail(uint32_t code, uint32_t detail) {
+    atomicAdd(&g_chk_counts[3], 1ull);
+    if (__hip_atomic_load(g_chk_status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+        __hip_atomic_store(g_chk_status + 1, detail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(g_chk_status, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+__device__ __forceinline__ bool chk_x(uint32_t voff, uint32_t soff, uint32_t bytes) {
+    if ((threadIdx.x & 63u) == 0u) atomicAdd(&g_chk_counts[0], 1ull);
+    const uint64_t end = (uint64_t)voff + soff + bytes;
+    if (end > g_chk_xbytes || ((voff + soff) & (bytes < 16u ? bytes - 1u : 15u)) != 0u) { chk_fail(CHK_XOFF, voff + soff); return false; }
+    return true;
+}
+__device__ __forceinline__ int64_t chk_row(int64_t r, int64_t rows) {
+    if ((threadIdx.x & 63u) == 0u) atomicAdd(&g_chk_counts[1], 1ull);
+    if ((uint64_t)r >= (uint64_t)rows) { chk_fail(CHK_ROW, (uint32_t)r); return 0; }
+    return r;
+}
+#define Q1PL_XCHK(voff, soff, bytes) chk_x((voff), (soff), (bytes))
+#else
+#define Q1PL_XCHK(voff, soff, bytes) true
+#endif
 
 __device__ __forceinline__ f16x8 lds16(const unsigned char* base, uint32_t off) { return *reinterpret_cast<const f16x8*>(base + off); }
 // Loads of EXCHANGED data: raw buffer loads over ONE resource per network (base = the group's exchange workspace, Net::xbase), address =
@@ -149,10 +187,16 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 constexpr int XAUX = 16;                                          // cache policy of the exchange loads: sc1 (gfx940+: bit 4 of the aux operand)
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t xrsrc(const void* base) {
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, 0x7FFFFFFF, 0x00020000);      // raw buffer, 32-bit data format, no swizzle
+#ifdef Q1_CHECK
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)g_chk_xbytes, 0x00020000);   // ... bounded: out-of-range loads return 0, stores are dropped
+#else
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, 0x7FFFFFFF, 0x00020000);      // raw buffer, 32-bit data format, no swizzle (unbounded: every offset is a
+                                                                                                        // compile-time layout constant + a lane term below 64 KB; the assertion build checks each)
+#endif
 }
 __device__ __forceinline__ f16x8 xld16(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff) {
     union { u32x4 u; f16x8 v; } o;
+    if (!Q1PL_XCHK(voff, soff, 16u)) { o.u = u32x4{0, 0, 0, 0}; return o.v; }
     o.u = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, XAUX);
     return o.v;
 }
@@ -160,31 +204,31 @@ __device__ __forceinline__ f16x8 xld16(__amdgpu_buffer_rsrc_t r, uint32_t voff, 
 // (four floats per instruction: a wave may have 63 vector-memory instructions in flight, the 64th stalls until the oldest has completed - with
 //  one float per instruction the 96 state loads and 96 state stores of a step ran into that limit behind every batch of operand requests)
 __device__ __forceinline__ void xld4(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff, float* o) {
+    if (!Q1PL_XCHK(voff, soff, 16u)) { o[0] = o[1] = o[2] = o[3] = 0.0f; return; }
     const u32x4 u = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
     o[0] = __uint_as_float(u.x); o[1] = __uint_as_float(u.y); o[2] = __uint_as_float(u.z); o[3] = __uint_as_float(u.w);
 }
 __device__ __forceinline__ void xst4(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff, const float* v) {
     const u32x4 u = {__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])};
+    if (!Q1PL_XCHK(voff, soff, 16u)) return;
     __builtin_amdgcn_raw_buffer_store_b128(u, r, voff, soff, 0);
 }
 // published data (see the exchange modes below): plain stores in the L2-local mode, agent-scope write-through (sc0 sc1) otherwise
 __device__ __forceinline__ void xpub8(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff, uint64_t v, bool loc) {
     const u32x2 d = {(uint32_t)v, (uint32_t)(v >> 32)};
+    if (!Q1PL_XCHK(voff, soff, 8u)) return;
     if (loc) __builtin_amdgcn_raw_buffer_store_b64(d, r, voff, soff, 0);
     else __builtin_amdgcn_raw_buffer_store_b64(d, r, voff, soff, 17);
 }
 __device__ __forceinline__ void xpub16f(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff, float a, float b, float c, float d, bool loc) {
     const u32x4 u = {__float_as_uint(a), __float_as_uint(b), __float_as_uint(c), __float_as_uint(d)};
+    if (!Q1PL_XCHK(voff, soff, 16u)) return;
     if (loc) __builtin_amdgcn_raw_buffer_store_b128(u, r, voff, soff, 0);
     else __builtin_amdgcn_raw_buffer_store_b128(u, r, voff, soff, 17);
 }
-__device__ __forceinline__ void xpub8f(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff, float a, float b, bool loc) {
-    const u32x2 d = {__float_as_uint(a), __float_as_uint(b)};
-    if (loc) __builtin_amdgcn_raw_buffer_store_b64(d, r, voff, soff, 0);
-    else __builtin_amdgcn_raw_buffer_store_b64(d, r, voff, soff, 17);
-}
 __device__ __forceinline__ f32x4 xld4f(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff) {
     union { u32x4 u; f32x4 v; } o;
+    if (!Q1PL_XCHK(voff, soff, 16u)) { o.u = u32x4{0, 0, 0, 0}; return o.v; }
     o.u = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, XAUX);
     return o.v;
 }
@@ -223,15 +267,9 @@ __device__ __forceinline__ uint64_t pack4(float a, float b, float c, float d) {
     o.v = f16x4{(_Float16)a, (_Float16)b, (_Float16)c, (_Float16)d};
     return o.u;
 }
-__device__ __forceinline__ float sat16(float x, float& amax, uint32_t& nsat) {
-    const float ax = fabsf(x);
-    amax = fmaxf(amax, ax);
-    nsat += ax > 65504.0f ? 1u : 0u;
-    return __builtin_amdgcn_fmed3f(x, -65504.0f, 65504.0f);
-}
-// four at a time: the largest magnitude by two v_max3 (operand modifiers take the absolute values), the count of elements beyond float16's
-// range only when that maximum says there is one (a branch the wave almost never takes), one v_med3 per element to clamp - 9 instructions per
-// quad where sat16 costs 20 (and a step converts ~170 gradient elements per lane)
+// float32 -> float16 with saturation, four at a time: the largest magnitude by two v_max3 (operand modifiers take the absolute values), the
+// count of elements beyond float16's range only when that maximum says there is one (a branch the wave almost never takes), one v_med3 per
+// element to clamp - 9 instructions per quad (a step converts ~170 gradient elements per lane)
 __device__ __forceinline__ void sat16x4(float (&x)[4], float& amax, uint32_t& nsat) {
     const float m4 = fmaxf(fmaxf(fabsf(x[0]), fabsf(x[1])), fmaxf(fabsf(x[2]), fabsf(x[3])));
     amax = fmaxf(amax, m4);
@@ -255,16 +293,6 @@ __device__ __forceinline__ float act(float z) { return 1.0f - 2.0f * __builtin_a
 //                version used the sc0 forms of poll and invalidate, which only by-pass the vector cache in threadgroup-split mode: it
 //                dead-locked after ~50 steps on a stale counter line).  Nothing travels to the memory side: a barrier is cheaper and the
 //                exchanged operands come from L2, not HBM / MALL.
-__device__ __forceinline__ void pub8(uint16_t* p, uint64_t v, bool loc) {
-    if (loc) *reinterpret_cast<uint64_t*>(p) = v;
-    else __hip_atomic_store(reinterpret_cast<uint64_t*>(p), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ void pub8f(float* p, float a, float b, bool loc) {
-    union { float f[2]; uint64_t u; } o;
-    o.f[0] = a; o.f[1] = b;
-    if (loc) *reinterpret_cast<uint64_t*>(p) = o.u;
-    else __hip_atomic_store(reinterpret_cast<uint64_t*>(p), o.u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
 __device__ __forceinline__ void pub4f(float* p, float a, bool loc) {
     if (loc) *p = a;
     else __hip_atomic_store(p, a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -330,8 +358,21 @@ __device__ __forceinline__ bool bar_wait(uint32_t* ctr, uint32_t target, bool lo
         int ok = 1;
         uint64_t t0 = 0;
         uint32_t spins = 0;
+#ifdef Q1_CHECK
+        // a reading lies in [what was seen before, target + G): a workgroup can be at most one barrier ahead of the slowest (it cannot pass
+        // barrier n + 1 before everybody - this workgroup included - has arrived there)
+        atomicAdd(&g_chk_counts[2], 1ull);
+        if (first >= target + (uint32_t)G) chk_fail(CHK_BAR, first);
+#endif
         while (first < target) {
+#ifdef Q1_CHECK
+            const uint32_t before = first;
+#endif
             first = poll(ctr, loc);
+#ifdef Q1_CHECK
+            atomicAdd(&g_chk_counts[2], 1ull);
+            if (first < before || first >= target + (uint32_t)G) chk_fail(CHK_BAR, first);
+#endif
             if (first >= target) break;
             __builtin_amdgcn_s_sleep(1);
             if ((++spins & 1023u) == 0u) {
@@ -359,8 +400,10 @@ __device__ __forceinline__ bool bar_wait(uint32_t* ctr, uint32_t target, bool lo
 // action_dist.py:186-192): a function of the ACTION alone, so it is computed once per launch for all rows - a float64 polynomial of ~220
 // instructions that each of the 30 epochs x 8 workgroups would otherwise re-evaluate per sample inside the step loop.
 __global__ void __launch_bounds__(256)
-mouse_u_kernel(int64_t rows, const float* __restrict__ mouse, float low, float high, float* __restrict__ u) {
+mouse_u_kernel(int64_t rows, const float* __restrict__ mouse, float low, float high, float* __restrict__ u, const long long* __restrict__ step_count,
+               long long* __restrict__ step0_snap) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) *step0_snap = *step_count;                     // (Args::step0_snap)
     if (i < rows) u[i] = SQUASH_SCALE * normcdfinvf((mouse[i] - low) / (high - low));
 }
 
@@ -498,39 +541,45 @@ __device__ __forceinline__ void persistent_learner_body(const Args& a, unsigned 
     // one agent-scope barrier (its own counter) behind the prologue's publications: also carries the XCD census
     bool loc = false;
     {
-        if (tid == 0) __hip_atomic_store(net.bar + 16 + g, xcc_id() + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid == 0) __hip_atomic_store(net.bar + 16 + g, xcc_id() + 1u + (a.census_skew ? 16u * g : 0u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         bar_arrive(net.bar + 8, false);
         if (!bar_wait(net.bar + 8, (uint32_t)G, false, a.status, 3u, 0u, a.timeout_ticks, s_ok)) return;
         uint32_t same = 1u;
         const uint32_t mine = __hip_atomic_load(net.bar + 16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         for (uint32_t k = 1; k < (uint32_t)G; ++k) same &= __hip_atomic_load(net.bar + 16 + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == mine ? 1u : 0u;
         loc = a.allow_local != 0 && same != 0u && mine != 0u;
-        if (tid == 0 && g == 0) a.status[2 + ni] = loc ? mine : 0u;          // reported: 1 + the XCD the group shares, or 0 = agent-scope mode
+        // (the mode is REPORTED by the epilogue - status[2 + ni] - not here: no one-lane store in front of the step loop)
     }
     const float klc = *a.klc_dev;
-    const long long step0 = *a.step_count;
+    const long long step0 = *a.step0_snap;
     double pw1 = pow((double)a.beta1, (double)step0), pw2 = pow((double)a.beta2, (double)step0);
     float st_acc[3] = {0.0f, 0.0f, 0.0f};                       // running sums of the step statistics (thread 0 of workgroup 0 of each group)
     float amax = 0.0f;
     uint32_t nsat = 0;
     uint32_t bar_n = 0;                                         // barriers passed
     float lr_prev = 0.0f, rs_prev = 0.0f;                       // the previous step's bias corrections (its deferred work)
-    // rows of the FIRST step (every later step's are fetched one step ahead): srcX = the sample whose observation this lane stages, srcL = the
-    // sample whose loss this lane pair differentiates (the same sample, 32 w + c)
+    // the row of the FIRST step (every later step's is fetched one step ahead): the sample whose observation this lane stages and whose loss this
+    // lane pair differentiates, 32 w + c
     // (no division in the loop: the position of the next step's window is kept incrementally)
     int64_t win = 0;                                            // offset of the CURRENT step's 128-row window in idx
     int64_t in_epoch = 0;                                       // its index within the epoch
-    auto row_at = [&](int64_t window, uint32_t b) -> int64_t { return a.idx ? a.idx[window + (int64_t)b] : window + (int64_t)b; };
-#ifdef Q1PL_ONE_ROW_VAR
-    int64_t srcX = row_at(0, bsm);
-#define srcL srcX
+#ifdef Q1_CHECK
+    auto row_at = [&](int64_t window, uint32_t b) -> int64_t {
+        const int64_t at = window + (int64_t)b;
+        if ((uint64_t)at >= (uint64_t)(a.idx ? a.idx_rows : a.rows)) { chk_fail(CHK_SCHED, (uint32_t)at); return 0; }
+        return chk_row(a.idx ? a.idx[at] : at, a.rows);
+    };
 #else
-    int64_t srcX = row_at(0, bsm), srcL = row_at(0, bsm);       // (two variables on purpose: with one for both uses the compiled kernel faulted - STATE.md)
+    auto row_at = [&](int64_t window, uint32_t b) -> int64_t { return a.idx ? a.idx[window + (int64_t)b] : window + (int64_t)b; };
 #endif
+    // (Round 5 kept this index in two variables "because the kernel faulted with one".  The cause was found in round 6 and is not in this code:
+    //  the register allocator had placed copies in front of a join block's exec restore - q1physrl_amd/isa_check.py, which now rejects any
+    //  build that has such a block, whatever the source looks like.)
+    int64_t src = row_at(0, bsm);
     // ... and the observation row itself (24 bytes from HBM at a random row: ~2 us of latency that would otherwise open every step)
     float oxn[6];
     auto request_obs = [&]() {
-        const float2* o2 = reinterpret_cast<const float2*>(a.obs + (size_t)srcX * 6);
+        const float2* o2 = reinterpret_cast<const float2*>(a.obs + (size_t)src * 6);
         const float2 p0 = o2[0], p1 = o2[1], p2 = o2[2];
         oxn[0] = p0.x; oxn[1] = p0.y; oxn[2] = p1.x; oxn[3] = p1.y; oxn[4] = p2.x; oxn[5] = p2.y;
     };
@@ -777,15 +826,11 @@ __device__ __forceinline__ void persistent_learner_body(const Args& a, unsigned 
         Q1PL_STAMP(17);                                         // (the barrier-1 window's work)
         const float lr_prev2 = lr_prev, rs_prev2 = rs_prev;
         lr_prev = lr_bc1; rs_prev = rs_bc2;
-        const int64_t srcL_now = srcL;
+        const int64_t src_now = src;
         // the NEXT step's row indices, requested while the barrier is in flight
         if (!last) {
             if (++in_epoch == a.spe) { in_epoch = 0; win += a.epoch_stride - (a.spe - 1) * MB; } else { win += MB; }
-#ifdef Q1PL_ONE_ROW_VAR
-            srcX = row_at(win, bsm);
-#else
-            srcX = row_at(win, bsm); srcL = row_at(win, bsm);
-#endif
+            src = row_at(win, bsm);
         }
         if (!bar_wait(net.bar, (uint32_t)G * ++bar_n, loc, a.status, 0u, (uint32_t)step, a.timeout_ticks, s_ok, seen1)) return;
         Q1PL_STAMP(1);                                          // barrier 1
@@ -804,7 +849,7 @@ __device__ __forceinline__ void persistent_learner_body(const Args& a, unsigned 
 #pragma unroll
             for (int s = 0; s < 16; ++s) bH[s] = xld16(xr, vSt + 1024u * (uint32_t)(s & 3), s_h1x + wu * 16384u + 4096u * (uint32_t)(s >> 2));
             {
-                const size_t sl = (size_t)srcL_now;
+                const size_t sl = (size_t)src_now;
                 if (ni == 0) { in_kb = (uint32_t)a.keys[sl]; in_a = a.mouse_u[sl]; in_b = a.logp_old[sl]; in_c = a.adv[sl]; }
                 else { in_a = a.value_old[sl]; in_b = a.vtarg[sl]; }
                 if (ni == 0 && a.wide_old) {
@@ -888,7 +933,7 @@ __device__ __forceinline__ void persistent_learner_body(const Args& a, unsigned 
             // tile 0's H1^T operand rows for G2: requested here, two phases early
 #pragma unroll
             for (int s = 0; s < 8; ++s) hT[s] = xld16(xr, vSt + 1024u * (uint32_t)(s & 3), s_h1tx + wu * 16384u + 4096u * (uint32_t)(s >> 2));    // (H1^T has been complete since barrier 1)
-            if (!last) request_obs();                           // the NEXT step's observation rows (srcX was advanced behind barrier 1); behind this
+            if (!last) request_obs();                           // the NEXT step's observation rows (src was advanced behind barrier 1); behind this
                                                                 // phase's own requests, ~2 us ahead of the next wait on the memory counter
             __builtin_amdgcn_sched_barrier(0);                  // (the requests above are issued HERE, all of them: the scheduler would otherwise sink each to its first use)
             Q1PL_STAMP(10);                                     // (loss: the outputs summed)
@@ -1096,6 +1141,8 @@ __device__ __forceinline__ void persistent_learner_body(const Args& a, unsigned 
             }
         }
     if (g == 0 && tid == 192u) {                                // (wave 3's lane 0 kept the running statistics)
+        // the exchange mode this group ran in: 1 + the XCD its eight workgroups share, or 0 = agent scope (the census line is still what it was)
+        cold()->status[2 + ni] = loc ? __hip_atomic_load(cold()->net[NI].bar + 16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
         if (ni == 0) {
             float* const sa = cold()->stats_acc;
             sa[0] += st_acc[0]; sa[1] += st_acc[1]; sa[2] += st_acc[2];

@@ -281,11 +281,33 @@ class DeviceEnv:
     def learner_persistent_bytes(self, batch_rows):
         return int(self._lib.q1env_learner_persistent_bytes(int(batch_rows)))
 
-    def learner_sgd_epochs_dev(self, pi, vf, pws, batch, batch_rows, steps, steps_per_epoch, epoch_stride, lr, beta1, beta2, eps, state, timeout_s=5.0):
+    def learner_sgd_epochs_dev(self, pi, vf, pws, batch, batch_rows, idx_rows, steps, steps_per_epoch, epoch_stride, lr, beta1, beta2, eps, state, timeout_s=5.0):
         """`steps` SGD steps of 128-sample minibatches as ONE dispatch (include/q1env.h q1env_learner_sgd_epochs)."""
-        _lib.check(self._lib.q1env_learner_sgd_epochs(self._h, C.byref(pi), C.byref(vf), C.c_void_p(int(pws)), C.byref(batch), int(batch_rows), int(steps), int(steps_per_epoch),
-                                                      int(epoch_stride), float(lr), float(beta1), float(beta2), float(eps), C.c_void_p(int(state)),
-                                                      float(timeout_s)))
+        _lib.check(self._lib.q1env_learner_sgd_epochs(self._h, C.byref(pi), C.byref(vf), C.c_void_p(int(pws)), C.byref(batch), int(batch_rows), int(idx_rows), int(steps),
+                                                      int(steps_per_epoch), int(epoch_stride), float(lr), float(beta1), float(beta2), float(eps),
+                                                      C.c_void_p(int(state)), float(timeout_s)))
+
+    EXCHANGE_MODES = {"auto": 0, "agent": 1, "census_fail": 2}
+
+    def learner_set_exchange_mode(self, mode):
+        """Exchange mode of the persistent learner on this handle: "auto" (L2-local when the XCD census agrees, else agent scope), "agent",
+        "census_fail" (tests: automatic, with a census made to disagree).  include/q1env.h."""
+        _lib.check(self._lib.q1env_learner_set_exchange_mode(self._h, self.EXCHANGE_MODES[mode] if isinstance(mode, str) else int(mode)))
+
+    def learner_set_profiling(self, wave_of_group=-1):
+        _lib.check(self._lib.q1env_learner_set_profiling(self._h, int(wave_of_group)))
+
+    def learner_persistent_layout(self, batch_rows, net):
+        """{name: byte offset inside the persistent workspace} of network `net`'s exchange buffers + "bytes" (the group's workspace size)."""
+        out = (C.c_uint64 * 9)()
+        _lib.check(self._lib.q1env_learner_persistent_layout(int(batch_rows), int(net), out))
+        return dict(zip(("bar", "b3x", "h1x", "h1tx", "dz2x", "w2tx", "yp", "w2st", "bytes"), (int(x) for x in out)))
+
+    def learner_debug_counters(self):
+        """(built with -DQ1_CHECK, exchange accesses checked, row indices checked, barrier readings checked, assertions failed)."""
+        out = (C.c_uint64 * 5)()
+        _lib.check(self._lib.q1env_learner_debug_counters(self._h, out))
+        return tuple(int(x) for x in out)
 
     def learner_persistent_status(self, pws):
         st = (C.c_uint32 * 4)()

@@ -143,6 +143,8 @@ class NativeStep:
         total = perms.shape[1]
         spe = total // self.mb
         n = perms.shape[0] * spe if steps is None else int(steps)
+        if not 0 < n <= perms.shape[0] * spe:
+            raise ValueError(f"epochs(): {n} steps asked for, the permutations hold {perms.shape[0]} epochs x {spe} minibatches")
         rows = full["adv"].shape[0]
         need = self.env._dev.learner_persistent_bytes(rows)
         if self._pws is None or self._pws.numel() < need:
@@ -153,14 +155,15 @@ class NativeStep:
                              full["value"].data_ptr(), full["vtarg"].data_ptr(), clip_param, vf_clip_param, vf_loss_coeff, entropy_coeff,
                              klc_dev.data_ptr(), None, 0, self.saturation.data_ptr())
         lr, betas, eps = adam
-        self.env._dev.learner_sgd_epochs_dev(self.pi, self.vf, self._pws.data_ptr(), b, rows, n, spe, total, lr, betas[0], betas[1], eps,
+        self.env._dev.learner_sgd_epochs_dev(self.pi, self.vf, self._pws.data_ptr(), b, rows, perms.numel(), n, spe, total, lr, betas[0], betas[1], eps,
                                              self.adam_state.data_ptr())
         if refresh_images:
             self.images()                                      # the four-launch path's float16 weight images follow the new masters
         return n
 
     def persistent_status(self):
-        """[0] != 0: a group barrier of the last epochs() launch timed out (1 + its index in the step), [1] = the step.  Synchronises."""
+        """[0] != 0: a group barrier of the last epochs() launch timed out (1 + its index in the step), [1] = the step; [2], [3]: the exchange mode
+        the policy / value group ran in (0 = agent scope, otherwise 1 + the XCD its eight workgroups shared).  Synchronises."""
         return self.env._dev.learner_persistent_status(self._pws.data_ptr()) if self._pws is not None else [0, 0, 0, 0]
 
     def step(self, full, idx, clip_param, vf_clip_param, vf_loss_coeff, entropy_coeff, klc_dev, skip_reduce=False, use_cursor=False, adam=None):

@@ -395,7 +395,27 @@ def _train_batch(n_envs, horizon, pol, seed=4):
     return env, full, total
 
 
-def test_persistent_learner_one_step_against_the_four_launch_step_and_autograd():
+EXCHANGE_MODES = ["auto", "agent", "census_fail"]
+
+
+def _set_mode(env, mode):
+    env._dev.learner_set_exchange_mode(mode)
+
+
+def _assert_mode(nat, mode):
+    """status[2], [3] = the exchange mode the policy / value group actually ran in (0 agent scope, else 1 + the shared XCD): what was asked
+    for is what ran.  "auto" on an unpartitioned MI355X means L2-local (the dispatcher deals workgroups to the XCDs round-robin; a device on
+    which the census fails would run - correctly - in agent scope, and this assertion is how the suite would learn of it)."""
+    st = nat.persistent_status()
+    assert st[0] == 0, st
+    if mode == "auto":
+        assert 1 <= st[2] <= 8 and 1 <= st[3] <= 8, st
+    else:
+        assert st[2] == 0 and st[3] == 0, st
+
+
+@pytest.mark.parametrize("mode", EXCHANGE_MODES)
+def test_persistent_learner_one_step_against_the_four_launch_step_and_autograd(mode):
     """q1env_learner_sgd_epochs with steps = 1 against ONE q1env_learner_sgd_step on the same 128 rows from the same state: every
     parameter gradient within float16-operand rounding of the four-launch path's (relative Frobenius error <= 3e-3 per tensor - the bound
     the four-launch path itself is held to against autograd) and, directly, of torch autograd through the float32 modules and
@@ -410,12 +430,14 @@ def test_persistent_learner_one_step_against_the_four_launch_step_and_autograd()
     perm = torch.randperm(total, device="cuda")
     a, b = ppo.NativeStep(pol_a, env, 128, splits=8), ppo.NativeStep(pol_b, env, 128, splits=8)
     assert b.persistent_ok()
+    _set_mode(env, mode)
     hp = (3e-4, (0.9, 0.999), 1e-8)
     w0 = [p.detach().clone() for p in pol_a.parameters()]
     a.step(full, perm, 0.3, 10.0, 1.0, 0.01, klc, skip_reduce=True, use_cursor=True, adam=hp)
     n = b.epochs(full, perm.reshape(1, -1).contiguous(), 0.3, 10.0, 1.0, 0.01, klc, hp, steps=1)
     torch.cuda.synchronize()
-    assert n == 1 and b.persistent_status()[0] == 0
+    assert n == 1
+    _assert_mode(b, mode)
     # autograd reference of the same minibatch
     idx = perm[:128]
     mbatch = {"obs": full["obs"][idx], "old_logits": full["old_logits"][idx], "mouse": full["mouse"][idx].reshape(-1, 1), "logp": full["logp"][idx],
@@ -440,7 +462,8 @@ def test_persistent_learner_one_step_against_the_four_launch_step_and_autograd()
     env.close()
 
 
-def test_persistent_learner_epoch_of_391_steps_against_391_four_launch_steps():
+@pytest.mark.parametrize("mode", EXCHANGE_MODES)
+def test_persistent_learner_epoch_of_391_steps_against_391_four_launch_steps(mode):
     """VERDICT r4 item 3's shape: one epoch of the reference's train batch - 391 minibatches of 128 out of 50 048 samples - as ONE
     dispatch against 391 calls of q1env_learner_sgd_step (same permutation, same initial state, lr 5e-6 as in data/params.yml).  Not bit
     for bit (the summation orders differ): the accumulated parameter CHANGE agrees to a few per cent per tensor, the running statistics to
@@ -455,13 +478,15 @@ def test_persistent_learner_epoch_of_391_steps_against_391_four_launch_steps():
     klc = torch.tensor(0.2, device="cuda")
     perm = torch.randperm(total, device="cuda")
     a, b = ppo.NativeStep(pol_a, env, 128, splits=8), ppo.NativeStep(pol_b, env, 128, splits=8)
+    _set_mode(env, mode)
     hp = (5e-6, (0.9, 0.999), 1e-8)
     w0 = [p.detach().clone() for p in pol_a.parameters()]
     for _ in range(391):
         a.step(full, perm, 0.3, 10.0, 1.0, 0.01, klc, skip_reduce=True, use_cursor=True, adam=hp)
     n = b.epochs(full, perm.reshape(1, -1).contiguous(), 0.3, 10.0, 1.0, 0.01, klc, hp)
     torch.cuda.synchronize()
-    assert n == 391 and b.persistent_status()[0] == 0
+    assert n == 391
+    _assert_mode(b, mode)
     assert int(a.adam_state[:8].view(torch.int64)[0]) == 391 == int(b.adam_state[:8].view(torch.int64)[0])
     for (name, pa), pb, w in zip(pol_a.named_parameters(), pol_b.parameters(), w0):
         da, db = pa.detach() - w, pb.detach() - w
@@ -481,7 +506,8 @@ def test_persistent_learner_epoch_of_391_steps_against_391_four_launch_steps():
     env.close()
 
 
-def test_persistent_learner_consecutive_launches_stay_synchronised():
+@pytest.mark.parametrize("mode", EXCHANGE_MODES)
+def test_persistent_learner_consecutive_launches_stay_synchronised(mode):
     """Regression (round 5): every launch must re-zero BOTH groups' barrier counters - with one left at its previous final value the
     second launch's waits all pass at once, its workgroups run unsynchronised and training diverges within a few updates (iteration 0 of
     a run is unaffected, which is why a single-launch test cannot see it).  Six launches of 60 steps each on the same schedule against
@@ -495,6 +521,7 @@ def test_persistent_learner_consecutive_launches_stay_synchronised():
     klc = torch.tensor(0.2, device="cuda")
     perm = torch.randperm(total, device="cuda")
     a, b = ppo.NativeStep(pol_a, env, 128, splits=8), ppo.NativeStep(pol_b, env, 128, splits=8)
+    _set_mode(env, mode)
     hp = (5e-5, (0.9, 0.999), 1e-8)
     w0 = [p.detach().clone() for p in pol_a.parameters()]
     p1 = perm.reshape(1, -1).contiguous()
@@ -504,7 +531,7 @@ def test_persistent_learner_consecutive_launches_stay_synchronised():
             a.step(full, perm, 0.3, 10.0, 1.0, 0.01, klc, skip_reduce=True, use_cursor=True, adam=hp)
         b.epochs(full, p1, 0.3, 10.0, 1.0, 0.01, klc, hp, steps=60)
         torch.cuda.synchronize()
-        assert b.persistent_status()[0] == 0
+        _assert_mode(b, mode)
         assert int(b.adam_state[:8].view(torch.int64)[0]) == 60 * (launch + 1)
         for (name, pa), pb, w in zip(pol_a.named_parameters(), pol_b.parameters(), w0):
             r = _rel(pb.detach() - w, pa.detach() - w)
@@ -512,7 +539,8 @@ def test_persistent_learner_consecutive_launches_stay_synchronised():
     env.close()
 
 
-def test_ppo_learner_update_persistent_equals_per_step_loop():
+@pytest.mark.parametrize("mode", EXCHANGE_MODES)
+def test_ppo_learner_update_persistent_equals_per_step_loop(mode):
     """PPOLearner.update with the persistent learner (one dispatch per update) against the same learner driving q1env_learner_sgd_step
     per minibatch: same permutations (same generator), same statistics to 1e-3, same adaptive-KL decision."""
     import copy
@@ -521,6 +549,7 @@ def test_ppo_learner_update_persistent_equals_per_step_loop():
     pol_a = _policy(9, 1.0)
     pol_b = copy.deepcopy(pol_a)
     cfg, env = make_env(128, time_limit=1.0)
+    _set_mode(env, mode)
     smp = S.GpuSampler(env, P.FusedPolicyForward(pol_a, env), horizon=16)
     tr = smp.collect()
     adv, vt = smp.advantages(tr, 0.99, 0.95)
@@ -528,6 +557,8 @@ def test_ppo_learner_update_persistent_equals_per_step_loop():
     for pol, persistent in ((pol_a, False), (pol_b, True)):
         lr_ = ppo.PPOLearner(pol, cfg.action_range, lr=5e-6, num_sgd_iter=3, minibatch_size=128, env=env, native=True, persistent=persistent, seed=3)
         outs.append([lr_.update(tr, adv, vt) for _ in range(4)])          # four updates: the later ones start from the earlier ones' state
+        if persistent:
+            _assert_mode(lr_._native, mode)
     torch.cuda.synchronize()
     for oa, ob in zip(*outs):
         assert oa["sgd_steps"] == ob["sgd_steps"] == 3 * 16 and oa["kl_coeff"] == ob["kl_coeff"]
@@ -566,3 +597,139 @@ def test_loss_scale_setting_changes_rounding_only_and_insists_on_powers_of_two()
         env._dev.learner_set_loss_scale(100.0, 0.0)
     env._dev.learner_set_loss_scale(0.0, 0.0)
     env.close()
+
+
+def _gather_probe_policy():
+    """A policy through which a step's gathered rows can be read back EXACTLY from the exchange buffers it leaves behind: hidden unit u of
+    layer 1 sees observation feature u % 6 alone (weight 1, no bias), layer 2 is zero (H2 = 0, outputs = b3 = 0), W3 routes ONE output's
+    loss gradient to every unit: dZ2[b][u] = dY[b][1] (policy: logit 1 of key 0) / dY[b][0] (value)."""
+    import torch
+    from q1physrl_amd import policy as P
+    pol = P.Q1Policy().cuda()
+    with torch.no_grad():
+        for p in pol.parameters():
+            p.zero_()
+        for seq, out in ((pol.pi, 1), (pol.vf, 0)):
+            seq[0].weight[torch.arange(256), torch.arange(256) % 6] = 1.0
+            seq[4].weight[out, :] = 1.0
+    return pol
+
+
+def _fragment_rows(buf_u16, torch):
+    """An exchange array in operand-fragment order [4 tiles w][16 K-steps s][64 lanes (h, c)][8] (csrc/q1learner_persist.hpp Net) -> float32
+    [128 samples][256 units]: element (w, s, h, c, e) is sample 32 w + c, unit 16 s + 8 h + e."""
+    t = buf_u16.view(torch.float16).reshape(4, 16, 2, 32, 8).permute(0, 3, 1, 2, 4).reshape(128, 256)
+    return t.float()
+
+
+@pytest.mark.parametrize("mode", ["auto", "agent"])
+def test_persistent_learner_gathers_exactly_the_scheduled_rows(mode):
+    """tolerance tests cannot see one wrong row in 128, so here every row of the train batch ENCODES ITS OWN INDEX -
+    the observation in base 9 over its six features (read back through H1 = tanh(x), which the last step leaves in the exchange buffer),
+    adv and vtarg as index mod 1024 (read back through dZ2 = the loss gradient of one output, exact in float16) - and after launches
+    of k steps (k = 1 .. 9 with 8 minibatches per epoch: every window of an epoch as the last one, then the wrap into the second epoch's
+    permutation; then 40 and 391 x 2 + 5 steps of a 50 048-row batch) the rows the last step consumed must be the scheduled ones, all 128,
+    for the observation request AND for the loss inputs of BOTH networks.  lr = 0: the probe weights stay what they are."""
+    import torch
+    from q1physrl_amd import ppo
+    pol = _gather_probe_policy()
+    cfg, env = make_env(128, time_limit=1.0)
+    _set_mode(env, mode)
+    env._dev.learner_set_loss_scale(256.0, 1.0)
+    levels = torch.tanh(torch.arange(-4, 5, device="cuda", dtype=torch.float32) * 0.25)
+    klc = torch.tensor(0.0, device="cuda")
+    hp = (0.0, (0.9, 0.999), 1e-8)
+    for total, step_counts in ((1024, list(range(1, 10)) + [16]), (50048, [40, 391 * 2 + 5])):
+        r = torch.arange(total, device="cuda")
+        digits = torch.stack([(r // 9 ** i) % 9 for i in range(6)], dim=1)
+        code = (r % 1024).float()
+        full = {"obs": ((digits - 4).float() * 0.25).contiguous(), "old_logits": torch.zeros((total, 10), device="cuda"),
+                "keys_packed": torch.zeros((total,), dtype=torch.uint8, device="cuda"), "mouse": torch.zeros((total,), device="cuda"),
+                "logp": torch.zeros((total,), device="cuda"), "adv": (code / 128.0).contiguous(), "value": torch.zeros((total,), device="cuda"),
+                "vtarg": (code * 0.5).contiguous()}
+        # logp_old = the log-probability of (keys 0, mouse 0) under all-zero outputs, so that ratio = 1: computed by the learner's own forward + loss
+        # is not needed to the last bit - dY = 128 adv ratio is rounded to float16, which absorbs a relative 1e-6
+        from q1physrl_amd.policy import Q1PhysActionDist
+        dist = Q1PhysActionDist(torch.zeros((1, 10), device="cuda"), float(cfg.action_range), 4, -1, True)
+        full["logp"] += float(dist.logp(torch.zeros((1, 4), dtype=torch.long, device="cuda"), torch.zeros((1, 1), device="cuda"))[0])
+        g = torch.Generator(device="cuda").manual_seed(total)
+        perms = torch.stack([torch.randperm(total, device="cuda", generator=g) for _ in range(3)]).contiguous()
+        spe = total // 128
+        nat = ppo.NativeStep(pol, env, 128, splits=8)
+        for k in step_counts:
+            nat.epochs(full, perms, 0.3, 1e9, 1.0, 0.0, klc, hp, steps=k, refresh_images=False)
+            torch.cuda.synchronize()
+            _assert_mode(nat, mode)
+            n = k - 1
+            want = perms[n // spe, (n % spe) * 128:(n % spe) * 128 + 128]
+            for net in (0, 1):
+                lay = env._dev.learner_persistent_layout(total, net)
+                pws = nat._pws
+                h1 = _fragment_rows(pws[lay["h1x"] + (n & 1) * 65536: lay["h1x"] + (n & 1) * 65536 + 65536], torch)
+                dz2 = _fragment_rows(pws[lay["dz2x"]: lay["dz2x"] + 65536], torch)
+                # observation rows: unit i (< 6) of H1 is tanh of feature i -> the digit -> the row
+                dig = (h1[:, :6, None] - levels[None, None, :]).abs().argmin(dim=2)
+                assert float((h1[:, :6] - levels[dig]).abs().max()) < 2e-3
+                got_obs = (dig * (9 ** torch.arange(6, device="cuda"))[None, :]).sum(dim=1)
+                assert torch.equal(got_obs, want), (total, k, net, "observation rows", (got_obs != want).nonzero().flatten().tolist()[:8])
+                # loss rows: policy dY[.][1] = 256 (-adv ratio) (a - p) = 128 adv = code; value dY = 2 (0 - vtarg) = -code: integers below 1 024, exact in float16
+                col = dz2[:, 0]
+                assert float((dz2 - col[:, None]).abs().max()) == 0.0            # every unit carries the same value (W3 row of ones, H2 = 0)
+                sign = 1.0 if net == 0 else -1.0
+                got = (col * sign).round().long()
+                assert float((col * sign - got).abs().max()) < 1e-3
+                assert torch.equal(got, want % 1024), (total, k, net, "loss rows", (got != want % 1024).nonzero().flatten().tolist()[:8])
+        # the weights did not move (lr = 0) and the step count did
+        assert int(nat.adam_state[:8].view(torch.int64)[0]) == sum(step_counts)
+    env._dev.learner_set_loss_scale(0.0, 0.0)
+    env.close()
+
+
+def test_persistent_learner_refuses_a_schedule_that_runs_past_the_index_list():
+    """steps beyond what the permutations hold used to read int64 indices past the end of idx_dev.  NativeStep.epochs raises, and
+    the C ABI itself (idx_rows, ABI v6) refuses with Q1ENV_ERR_INVALID_ARG before anything is launched."""
+    import torch
+    from q1physrl_amd import ppo, _lib
+    pol = _policy(3, 1.0)
+    env, full, total = _train_batch(64, 8, pol)                    # 512 rows: 4 minibatches per epoch
+    klc = torch.tensor(0.2, device="cuda")
+    nat = ppo.NativeStep(pol, env, 128, splits=8)
+    perms = torch.randperm(total, device="cuda").reshape(1, -1).contiguous()
+    hp = (5e-6, (0.9, 0.999), 1e-8)
+    with pytest.raises(ValueError, match="steps"):
+        nat.epochs(full, perms, 0.3, 10.0, 1.0, 0.01, klc, hp, steps=5)
+    assert nat.epochs(full, perms, 0.3, 10.0, 1.0, 0.01, klc, hp, steps=4) == 4
+    torch.cuda.synchronize()
+    assert nat.persistent_status()[0] == 0
+    L = _lib
+    ol = full["old_logits"]
+    b = L.Q1LearnerBatch(128, perms.data_ptr(), None, full["obs"].data_ptr(), ol.data_ptr(), ol.shape[1], full["keys_packed"].data_ptr(),
+                         full["mouse"].data_ptr(), full["logp"].data_ptr(), full["adv"].data_ptr(), full["value"].data_ptr(), full["vtarg"].data_ptr(),
+                         0.3, 10.0, 1.0, 0.01, klc.data_ptr(), None, 0, nat.saturation.data_ptr())
+    for idx_rows, steps, stride in ((total, 5, total), (total - 1, 4, total), (2 * total - 1, 8, total), (0, 1, total)):
+        with pytest.raises(L.Q1EnvError, match="schedule|idx_rows"):
+            env._dev.learner_sgd_epochs_dev(nat.pi, nat.vf, nat._pws.data_ptr(), b, total, idx_rows, steps, 4, stride, 5e-6, 0.9, 0.999, 1e-8, nat.adam_state.data_ptr())
+    env.close()
+
+
+def test_persistent_learner_whole_update_under_the_assertion_build():
+    """VERDICT r5 items 1b / missing 4: the -DQ1_CHECK build of the persistent learner (libq1env_check.so) compares every exchange offset
+    with the group's workspace, every gathered row index with the number of rows, every schedule position with the index list and every
+    barrier reading with its range - a failure is a status word, not a memory fault.  tools/soak_plearner_check.py runs a whole update of
+    the reference's shape (30 epochs x 391 steps = 11 730 steps) in both exchange modes with zero failures, then plants a row index beyond
+    the batch and expects status 0x102 (and a process that is still alive).  Subprocess: the assertion library is chosen before the
+    binding loads; the product library reports "not an assertion build"."""
+    import os
+    import subprocess
+    import sys
+    from q1physrl_amd import build
+    cfg, env = make_env(128)
+    assert env._dev.learner_debug_counters() == (0, 0, 0, 0, 0)
+    env.close()
+    so = build.build_lib(check=True)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "soak_plearner_check.py")], capture_output=True, text=True, timeout=900, cwd=root,
+                       env=dict(os.environ, Q1ENV_LIB_PATH=so))
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    last = r.stdout.strip().splitlines()[-1]
+    assert last.startswith("soak_plearner_check ok: 23460 steps") and " 0 failures" in last and "planted index -> status 0x102" in last, last

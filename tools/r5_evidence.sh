@@ -16,8 +16,8 @@ for n in 2 8; do
         bench.py --gpus $n --steps 20 --warmup 5 --no-cpu-baseline > $O/r5_bench_${n}rank_1gpu.json 2> $O/bench_$n.err
 done
 timeout 300 python tools/time_learner_persistent.py 2>&1 | tail -1 > $O/time_learner_persistent.json
-Q1_LEARNER_PROF=0 timeout 300 python tools/time_learner_persistent.py 2>&1 | tail -1 > $O/time_learner_persistent_prof.json
-Q1_LEARNER_LOCAL=0 timeout 300 python tools/time_learner_persistent.py 2>&1 | tail -1 > $O/time_learner_persistent_agent_scope.json
+PROF=0 timeout 300 python tools/time_learner_persistent.py 2>&1 | tail -1 > $O/time_learner_persistent_prof.json
+MODE=agent timeout 300 python tools/time_learner_persistent.py 2>&1 | tail -1 > $O/time_learner_persistent_agent_scope.json
 timeout 1300 python tools/train_ppo.py --refcfg --native --fused-policy --iters 2989 --log-every 50 --eval-every 100 --seed 0 --checkpoint-dir /tmp/r5_ck_final \
     --out $O/r5_train_ppo_refcfg_persistent_final2.json --save $O/r5_policy_refcfg_final2.npz > $O/train.log 2>&1
 tail -2 $O/train.log | cut -c1-300 > $O/train_tail.txt

@@ -20,6 +20,10 @@ def main():
     env, full, total = T._train_batch(128, 391, pol)
     klc = torch.tensor(0.2, device="cuda")
     nat = ppo.NativeStep(pol, env, 128, splits=8)
+    # MODE=auto|agent|census_fail: the exchange mode (q1env_learner_set_exchange_mode); PROF=<g + 8 wave>: the stamped wave (q1env_learner_set_profiling)
+    env._dev.learner_set_exchange_mode(os.environ.get("MODE", "auto"))
+    if os.environ.get("PROF"):
+        env._dev.learner_set_profiling(int(os.environ["PROF"]))
     hp = (5e-6, (0.9, 0.999), 1e-8)
     perms = torch.stack([torch.randperm(total, device="cuda") for _ in range(epochs)]).contiguous()
     out = {"total": total, "epochs": epochs, "steps": epochs * (total // 128)}
@@ -32,7 +36,7 @@ def main():
         out[f"persistent_rep{rep}_s"] = dt
         out[f"persistent_rep{rep}_us_per_step"] = dt / n * 1e6
     out["status"] = nat.persistent_status()
-    if os.environ.get("Q1_LEARNER_PROF"):
+    if os.environ.get("PROF"):
         ticks = nat._pws[24:24 + 160].view(torch.int64).cpu().tolist()
         names = ["rows+P1", "barrier1", "gather+P2+L3", "barrier2", "loss", "B3+arrive3", "dW2+Adam", "barrier3", "B2+dW1", "-", "loss:ysum", "loss:ppo", "loss:rows", "-", "G2:wait0", "G2:tile0", "G2:zr+stores0", "G2:tile1", "-", "-"]  # (loss = its three parts + the reductions)
         out["prof_us_per_step"] = {nm: t * 0.01 / n for nm, t in zip(names, ticks)}
