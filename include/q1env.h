@@ -494,6 +494,15 @@ uint64_t q1env_learner_persistent_bytes(int64_t batch_rows);
 int q1env_learner_sgd_epochs(q1env_t* env, const q1env_learner_net* pi, const q1env_learner_net* vf, void* pws_dev, const q1env_learner_batch* batch,
                              int64_t batch_rows, int64_t idx_rows, int64_t steps, int64_t steps_per_epoch, int64_t epoch_stride, float lr, float beta1,
                              float beta2, float eps, void* adam_state_dev, double timeout_s);
+/* (ABI v6) The same update in FLOAT32 arithmetic (csrc/q1learner_persist32.hpp): float32 matrix operands (v_mfma_f32_32x32x2_f32) and exchange
+ * buffers, IEEE square root / division in the optimizer, no loss scale, nothing saturates - what RLlib / TF PPO computes (float32 end to end,
+ * grad_clip = None: q1physrl/train.py:60-64, data/params.yml:4-13), up to summation order: gradients within 2e-5 of torch autograd's.  Same
+ * arguments, workspace, status words and exchange modes as q1env_learner_sgd_epochs; q1env_learner_set_loss_scale does not apply and
+ * batch->saturation_dev is not written.  About twice the time per step: the control the float16 learner's training results are compared
+ * with (STATE.md "fp32 control"), and the learner for anyone who wants the reference's arithmetic. */
+int q1env_learner_sgd_epochs_f32(q1env_t* env, const q1env_learner_net* pi, const q1env_learner_net* vf, void* pws_dev, const q1env_learner_batch* batch,
+                                 int64_t batch_rows, int64_t idx_rows, int64_t steps, int64_t steps_per_epoch, int64_t epoch_stride, float lr, float beta1,
+                                 float beta2, float eps, void* adam_state_dev, double timeout_s);
 int q1env_learner_persistent_status(q1env_t* env, const void* pws_dev, uint32_t* status4_host);   /* synchronises the stream */
 int q1env_learner_set_exchange_mode(q1env_t* env, int mode);
 int q1env_learner_set_profiling(q1env_t* env, int wave_of_group);

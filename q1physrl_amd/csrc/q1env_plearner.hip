@@ -6,6 +6,7 @@
 #include "q1policy_glue.hpp"
 #include "q1ppo_loss.hpp"
 #include "q1learner_persist.hpp"
+#include "q1learner_persist32.hpp"
 
 using namespace q1;
 
@@ -39,9 +40,10 @@ size_t carve_pws(void* base, int64_t batch_rows, PWs out[2], uint32_t** status, 
         const size_t start = off;
         w.bar = (uint32_t*)take(256);
         w.b3x = (float*)take(256);
-        w.h1x = (uint16_t*)take((size_t)2 * q1pl::MB * q1pl::HID * 2);
-        w.h1tx = (uint16_t*)take((size_t)2 * q1pl::MB * q1pl::HID * 2);
-        w.dz2x = (uint16_t*)take((size_t)q1pl::MB * q1pl::HID * 2);
+        // (activations are exchanged as float16 by the default kernel and as float32 by q1env_learner_sgd_epochs_f32: sized for the latter)
+        w.h1x = (uint16_t*)take((size_t)2 * q1pl32::XB_ACT);
+        w.h1tx = (uint16_t*)take((size_t)2 * q1pl32::XB_ACT);
+        w.dz2x = (uint16_t*)take((size_t)q1pl32::XB_ACT);
         w.w2tx = (uint16_t*)take((size_t)2 * q1pl::HID * q1pl::HID * 2);
         w.yp = (float*)take((size_t)q1pl::G * q1pl::MB * 16 * 4);
         w.w2st = (float*)take((size_t)q1pl::G * 3 * 4 * 2048 * 4);
@@ -84,9 +86,12 @@ int q1env_learner_set_profiling(q1env_t* h, int wave_of_group) {
     return Q1ENV_OK;
 }
 
-int q1env_learner_sgd_epochs(q1env_t* h, const q1env_learner_net* pi, const q1env_learner_net* vf, void* pws_dev, const q1env_learner_batch* b,
-                             int64_t batch_rows, int64_t idx_rows, int64_t steps, int64_t steps_per_epoch, int64_t epoch_stride, float lr, float beta1,
-                             float beta2, float eps, void* adam_state_dev, double timeout_s) {
+}  // extern "C"
+
+namespace {
+int sgd_epochs_impl(q1env_t* h, const q1env_learner_net* pi, const q1env_learner_net* vf, void* pws_dev, const q1env_learner_batch* b,
+                    int64_t batch_rows, int64_t idx_rows, int64_t steps, int64_t steps_per_epoch, int64_t epoch_stride, float lr, float beta1,
+                    float beta2, float eps, void* adam_state_dev, double timeout_s, bool f32) {
     if (!h || !pws_dev || !b || !adam_state_dev) return fail(Q1ENV_ERR_INVALID_ARG, "q1env_learner_sgd_epochs: null argument");
     if (!b->obs_dev || !b->old_logits_dev || !b->keys_dev || !b->mouse_dev || !b->logp_old_dev || !b->adv_dev || !b->value_old_dev || !b->vtarg_dev ||
         !b->kl_coeff_dev)
@@ -114,6 +119,8 @@ int q1env_learner_sgd_epochs(q1env_t* h, const q1env_learner_net* pi, const q1en
     if (!h->plearner_attr_set) {
         HIP_TRY(hipFuncSetAttribute((const void*)q1pl::persistent_learner_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)q1pl::LDS_BYTES));
         HIP_TRY(hipFuncSetAttribute((const void*)q1pl::persistent_learner_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)q1pl::LDS_BYTES));
+        HIP_TRY(hipFuncSetAttribute((const void*)q1pl32::persistent_learner_f32_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)q1pl32::LDS_BYTES));
+        HIP_TRY(hipFuncSetAttribute((const void*)q1pl32::persistent_learner_f32_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)q1pl32::LDS_BYTES));
         h->plearner_attr_set = true;
     }
     PWs pw[2];
@@ -148,9 +155,9 @@ int q1env_learner_sgd_epochs(q1env_t* h, const q1env_learner_net* pi, const q1en
         n.h1x = w.h1x; n.h1tx = w.h1tx; n.dz2x = w.dz2x; n.w2tx = w.w2tx; n.yp = w.yp; n.w2st = w.w2st; n.b3x = w.b3x; n.bar = w.bar; n.xbase = (const char*)w.bar;
         n.inv_b = inv_b; n.inv_scale = inv_scale;
     };
-    // the float16 loss scales of q1env_learner_step: per-sample gradients x pi_upscale (policy) / value_downscale (value)
-    fill(a.net[0], pi, m_pi, v_pi, pw[0], learner_pi_upscale(h), 1.0f / (mbf * learner_pi_upscale(h)));
-    fill(a.net[1], vf, m_vf, v_vf, pw[1], 1.0f / learner_value_downscale(h), learner_value_downscale(h) / mbf);
+    // the float16 loss scales of q1env_learner_step: per-sample gradients x pi_upscale (policy) / value_downscale (value); none in float32
+    fill(a.net[0], pi, m_pi, v_pi, pw[0], f32 ? 1.0f : learner_pi_upscale(h), 1.0f / (mbf * (f32 ? 1.0f : learner_pi_upscale(h))));
+    fill(a.net[1], vf, m_vf, v_vf, pw[1], f32 ? 1.0f : 1.0f / learner_value_downscale(h), (f32 ? 1.0f : learner_value_downscale(h)) / mbf);
     a.idx = b->idx_dev; a.spe = steps_per_epoch; a.epoch_stride = epoch_stride;
     a.rows = batch_rows; a.idx_rows = idx_rows;
     a.obs = b->obs_dev; a.old_logits = b->old_logits_dev; a.old_stride = b->old_stride;
@@ -173,10 +180,27 @@ int q1env_learner_sgd_epochs(q1env_t* h, const q1env_learner_net* pi, const q1en
     // first on the stream: the mouse pre-images of all rows + the snapshot of the step count both groups start from
     hipLaunchKernelGGL(q1pl::mouse_u_kernel, dim3((unsigned)((batch_rows + 255) / 256)), dim3(256), 0, h->stream, batch_rows, b->mouse_dev, -h->p.action_range_f32,
                        h->p.action_range_f32, mouse_u, (const long long*)st, (long long*)((char*)status + STATUS_SNAP_OFF));
-    if (a.prof) hipLaunchKernelGGL(q1pl::persistent_learner_kernel<true>, dim3(8 * q1pl::G), dim3(256), q1pl::LDS_BYTES, h->stream, a);
+    if (f32 && a.prof) hipLaunchKernelGGL(q1pl32::persistent_learner_f32_kernel<true>, dim3(8 * q1pl::G), dim3(256), q1pl32::LDS_BYTES, h->stream, a);
+    else if (f32) hipLaunchKernelGGL(q1pl32::persistent_learner_f32_kernel<false>, dim3(8 * q1pl::G), dim3(256), q1pl32::LDS_BYTES, h->stream, a);
+    else if (a.prof) hipLaunchKernelGGL(q1pl::persistent_learner_kernel<true>, dim3(8 * q1pl::G), dim3(256), q1pl::LDS_BYTES, h->stream, a);
     else hipLaunchKernelGGL(q1pl::persistent_learner_kernel<false>, dim3(8 * q1pl::G), dim3(256), q1pl::LDS_BYTES, h->stream, a);
     HIP_TRY(hipGetLastError());
     return Q1ENV_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int q1env_learner_sgd_epochs(q1env_t* h, const q1env_learner_net* pi, const q1env_learner_net* vf, void* pws_dev, const q1env_learner_batch* b,
+                             int64_t batch_rows, int64_t idx_rows, int64_t steps, int64_t steps_per_epoch, int64_t epoch_stride, float lr, float beta1,
+                             float beta2, float eps, void* adam_state_dev, double timeout_s) {
+    return sgd_epochs_impl(h, pi, vf, pws_dev, b, batch_rows, idx_rows, steps, steps_per_epoch, epoch_stride, lr, beta1, beta2, eps, adam_state_dev, timeout_s, false);
+}
+
+int q1env_learner_sgd_epochs_f32(q1env_t* h, const q1env_learner_net* pi, const q1env_learner_net* vf, void* pws_dev, const q1env_learner_batch* b,
+                                 int64_t batch_rows, int64_t idx_rows, int64_t steps, int64_t steps_per_epoch, int64_t epoch_stride, float lr, float beta1,
+                                 float beta2, float eps, void* adam_state_dev, double timeout_s) {
+    return sgd_epochs_impl(h, pi, vf, pws_dev, b, batch_rows, idx_rows, steps, steps_per_epoch, epoch_stride, lr, beta1, beta2, eps, adam_state_dev, timeout_s, true);
 }
 
 int q1env_learner_persistent_status(q1env_t* h, const void* pws_dev, uint32_t* status4) {

@@ -281,9 +281,11 @@ class DeviceEnv:
     def learner_persistent_bytes(self, batch_rows):
         return int(self._lib.q1env_learner_persistent_bytes(int(batch_rows)))
 
-    def learner_sgd_epochs_dev(self, pi, vf, pws, batch, batch_rows, idx_rows, steps, steps_per_epoch, epoch_stride, lr, beta1, beta2, eps, state, timeout_s=5.0):
-        """`steps` SGD steps of 128-sample minibatches as ONE dispatch (include/q1env.h q1env_learner_sgd_epochs)."""
-        _lib.check(self._lib.q1env_learner_sgd_epochs(self._h, C.byref(pi), C.byref(vf), C.c_void_p(int(pws)), C.byref(batch), int(batch_rows), int(idx_rows), int(steps),
+    def learner_sgd_epochs_dev(self, pi, vf, pws, batch, batch_rows, idx_rows, steps, steps_per_epoch, epoch_stride, lr, beta1, beta2, eps, state, timeout_s=5.0,
+                               f32=False):
+        """`steps` SGD steps of 128-sample minibatches as ONE dispatch (include/q1env.h q1env_learner_sgd_epochs; f32: ..._f32, float32 arithmetic)."""
+        fn = self._lib.q1env_learner_sgd_epochs_f32 if f32 else self._lib.q1env_learner_sgd_epochs
+        _lib.check(fn(self._h, C.byref(pi), C.byref(vf), C.c_void_p(int(pws)), C.byref(batch), int(batch_rows), int(idx_rows), int(steps),
                                                       int(steps_per_epoch), int(epoch_stride), float(lr), float(beta1), float(beta2), float(eps),
                                                       C.c_void_p(int(state)), float(timeout_s)))
 

@@ -132,12 +132,13 @@ class NativeStep:
         """The persistent learner serves the reference's own shape: 128-sample minibatches, 4 keys + continuous mouse (10 policy outputs)."""
         return self.mb == self.PERSISTENT_MB and self.policy.pi[4].out_features == 10 and self.env._dev.num_keys == 4
 
-    def epochs(self, full, perms, clip_param, vf_clip_param, vf_loss_coeff, entropy_coeff, klc_dev, adam, steps=None, refresh_images=True):
+    def epochs(self, full, perms, clip_param, vf_clip_param, vf_loss_coeff, entropy_coeff, klc_dev, adam, steps=None, refresh_images=True, f32=False):
         """ALL the SGD steps of an update as ONE dispatch (q1env_learner_sgd_epochs, csrc/q1learner_persist.hpp): perms int64
         (epochs, total) - one permutation of the train batch per epoch; every epoch runs total // 128 steps on consecutive windows of its
         permutation (what update()'s loop feeds q1env_learner_sgd_step one call at a time).  adam = (lr, betas, eps).  Masters, moments,
         step count, .grad (the last step's) and the running statistics [0, 1, 2, 4] of self.stats_acc are updated; [3] (total loss) is
-        left to the caller.  Returns the number of steps."""
+        left to the caller.  Returns the number of steps.  f32: the float32-arithmetic kernel (q1env_learner_sgd_epochs_f32: no float16 operand
+        rounding, no loss scale, no saturation - RLlib's own arithmetic; about twice the time per step)."""
         L = self._lib
         assert self.persistent_ok() and perms.dtype == torch.int64 and perms.is_contiguous() and perms.dim() == 2
         total = perms.shape[1]
@@ -156,7 +157,7 @@ class NativeStep:
                              klc_dev.data_ptr(), None, 0, self.saturation.data_ptr())
         lr, betas, eps = adam
         self.env._dev.learner_sgd_epochs_dev(self.pi, self.vf, self._pws.data_ptr(), b, rows, perms.numel(), n, spe, total, lr, betas[0], betas[1], eps,
-                                             self.adam_state.data_ptr())
+                                             self.adam_state.data_ptr(), f32=f32)
         if refresh_images:
             self.images()                                      # the four-launch path's float16 weight images follow the new masters
         return n
@@ -209,7 +210,7 @@ class PPOLearner:
                  vf_loss_coeff=1.0, entropy_coeff=0.01, kl_coeff=0.2, kl_target=0.0036, num_sgd_iter=30,
                  minibatch_size=128, num_keys=4, seed=0, use_graph=False, fused_loss=False, env=None, discrete_yaw_steps=-1,
                  allow_yaw=True, autocast_dtype=None, fused_adam=False, native=False, native_splits=32, native_adam=True, persistent=None,
-                 dynamic_loss_scale=False):
+                 dynamic_loss_scale=False, precision="f16"):
         self.policy = policy
         self.action_range = float(action_range)
         self.gamma, self.lam = gamma, lam
@@ -225,6 +226,12 @@ class PPOLearner:
         # persistent: the whole update (num_sgd_iter epochs of 128-sample minibatches) as ONE dispatch (NativeStep.epochs); None = whenever
         # the shape allows it (native, own Adam, single process, minibatch 128, the reference's action structure)
         self.persistent = persistent
+        # precision of the persistent learner's arithmetic: "f16" = float16 matrix operands, float32 accumulation / masters / optimizer (the fast
+        # default); "f32" = q1env_learner_sgd_epochs_f32: float32 everywhere, no loss scale, no saturation - RLlib's own arithmetic, ~2x the time
+        # per step (the control of STATE.md "fp32 control")
+        if precision not in ("f16", "f32"):
+            raise ValueError("precision must be 'f16' or 'f32'")
+        self.precision = precision
         # dynamic_loss_scale (native learner; OFF by default - measured, see below): the float16 loss scales of the next
         # update are chosen from THIS update's largest per-sample gradient element (NativeStep.saturation), as exact powers of two, so that
         # the largest element sits a factor LOSS_SCALE_HEADROOM below float16's largest finite value: (almost) nothing saturates (RLlib:
@@ -425,8 +432,14 @@ class PPOLearner:
         """Everything a resume needs: torch Adam's state (the non-native / multi-rank paths), the native optimizer's moments and step
         count (q1env_learner_adam's state block; self.opt is never stepped on that path, so its state_dict() is empty there), and the
         adaptive KL coefficient."""
+        if self._perms_ready is not None:
+            self._perms_ready.synchronize()
         return {"opt": self.opt.state_dict(), "kl_coeff": float(self.kl_coeff), "pi_upscale": self.pi_upscale, "value_downscale": self.value_downscale,
-                "native_adam": None if self._adam_state is None else self._adam_state.detach().cpu().clone()}
+                "native_adam": None if self._adam_state is None else self._adam_state.detach().cpu().clone(),
+                # the minibatch permutations: the generator (already advanced past the NEXT update's permutations when those were drawn ahead) and
+                # the prefetched permutations themselves - a resumed run continues with exactly the permutations the uninterrupted one uses
+                "gen": None if self.gen is None else self.gen.get_state().cpu().clone(),
+                "perms_next": None if (self._perms_next is None or self._perms_ready is None) else self._perms_next.detach().cpu().clone()}
 
     def load_state_dict(self, sd):
         self.opt.load_state_dict(sd["opt"])
@@ -439,6 +452,14 @@ class PPOLearner:
                 self._adam_state = na.to(dev).clone()
             else:
                 self._adam_state.copy_(na.to(dev))       # in place: a captured graph / NativeStep hold this address
+        dev = next(self.policy.parameters()).device
+        if sd.get("gen") is not None:
+            self.gen = torch.Generator(device=dev).manual_seed(0)
+            self.gen.set_state(sd["gen"].cpu())
+        if sd.get("perms_next") is not None and dev.type == "cuda":
+            self._perms_next = sd["perms_next"].to(dev).contiguous()
+            self._perms_ready = torch.cuda.Event()
+            self._perms_ready.record(torch.cuda.current_stream(dev))
 
     def update(self, traj, adv, vtarg):
         """SGD epochs over one trajectory batch; adv/vtarg from q1env_gae.  Returns averaged stats (python floats)."""
@@ -479,8 +500,8 @@ class PPOLearner:
                 self._full[k].copy_(b[k].reshape(self._full[k].shape))
         own_adam = self.native and self.world == 1 and self.native_adam
         use_persistent = bool(own_adam and self.persistent is not False and self._native.persistent_ok() and total >= mb)
-        if self.persistent is True and not use_persistent:
-            raise ValueError("PPOLearner(persistent=True) needs native=True, native_adam=True, one process, minibatch_size 128 and the reference's action structure")
+        if (self.persistent is True or self.precision == "f32") and not use_persistent:
+            raise ValueError("PPOLearner(persistent=True / precision='f32') needs native=True, native_adam=True, one process, minibatch_size 128 and the reference's action structure")
         # lr / betas / eps are kernel ARGUMENTS of the native Adam, baked into a captured graph: a changed param_group re-captures
         if self.native:
             self.env._dev.learner_set_loss_scale(self.pi_upscale, self.value_downscale)
@@ -510,7 +531,7 @@ class PPOLearner:
             free_evt = torch.cuda.Event()
             free_evt.record(torch.cuda.current_stream(dev))     # (the buffer about to be refilled was read by the PREVIOUS update's kernel)
             steps = self._native.epochs(self._full, self._perms, self.clip_param, self.vf_clip_param, self.vf_loss_coeff, self.entropy_coeff,
-                                        self._klc, self._hparams())
+                                        self._klc, self._hparams(), f32=self.precision == "f32")
             if self.prefetch_perms:
                 if self._perm_stream is None:
                     self._perm_stream = torch.cuda.Stream(device=dev)

@@ -49,6 +49,8 @@ ap.add_argument("--refcfg", action="store_true",
                      "for the rest (sgd_minibatch_size 128, num_sgd_iter 30, clip 0.3, kl_coeff 0.2), 4 workers x 100 envs = 400 envs x 125 ticks "
                      "per iteration; overrides --envs / --horizon / --lr / --epochs / --minibatch / --entropy / --kl-target / --zero-start-prob")
 ap.add_argument("--no-persistent", action="store_true", help="drive q1env_learner_sgd_step per minibatch instead of ONE q1env_learner_sgd_epochs dispatch per update (A/B)")
+ap.add_argument("--learner-fp32", action="store_true", help="the persistent learner in float32 arithmetic (q1env_learner_sgd_epochs_f32: float32 operands, no loss scale, "
+                                                           "nothing saturates - RLlib's own arithmetic; ~2x the time per step): the control of the float16 learner")
 ap.add_argument("--dynamic-loss-scale", action="store_true", help="choose the native learner's float16 loss scales per update from the previous update's largest gradient element instead of the static (256, 1): no saturation, but measured to cost the large-minibatch configuration its result (PPOLearner docstring)")
 ap.add_argument("--checkpoint-dir", default="", help="trainer checkpoints (policy weights, optimizer state incl. the native Adam moments + step count, adaptive KL "
                                                       "coefficient, iteration, best metric): every --checkpoint-every iterations and whenever "
@@ -56,6 +58,7 @@ ap.add_argument("--checkpoint-dir", default="", help="trainer checkpoints (polic
 ap.add_argument("--checkpoint-every", type=int, default=100)
 ap.add_argument("--restore", default="", help="resume from a checkpoint written by --checkpoint-dir (the reference's params['checkpoint_fname'], train.py:110-111)")
 ap.add_argument("--log-every", type=int, default=5)
+ap.add_argument("--out-stride", type=int, default=1, help="--out keeps every Nth iteration's row (+ every row with an evaluation or a checkpoint, + the last): a 2 989-iteration log is 1.4 MB at stride 1")
 ap.add_argument("--eval-every", type=int, default=0, help="every N iterations: 256 zero-start episodes of 720 ticks on a separate env, stochastic (the "
                                                          "training metric's policy) and deterministic; 0 = only at the end")
 args = ap.parse_args()
@@ -77,7 +80,9 @@ if args.refcfg:
 else:
     cfg = Config(**{**Config.get_default().__dict__, "num_envs": count, "zero_start_prob": args.zero_start_prob,
                     "discrete_yaw_steps": args.discrete_yaw_steps, **({"time_limit": args.time_limit} if args.time_limit > 0 else {})})
-env = TensorVectorEnv(cfg, device=local, seed=args.seed + 1, env_index_base=start)
+# a resumed run does not replay the first run's resets and action noise: its env / sampler seed is offset by the iteration it resumes at
+ck = torch.load(args.restore, map_location="cuda", weights_only=False) if args.restore else None
+env = TensorVectorEnv(cfg, device=local, seed=args.seed + 1 + (1000003 * (int(ck["iter"]) + 1) if ck is not None else 0), env_index_base=start)
 pol = P.Q1Policy(discrete_yaw_steps=args.discrete_yaw_steps).cuda()
 fused = P.FusedPolicyForward(pol, env) if args.fused_policy else None
 smp = GpuSampler(env, fused if fused is not None else pol, horizon=args.horizon, use_graph=not args.no_graph, resident=args.resident)
@@ -85,29 +90,39 @@ lrn = ppo.PPOLearner(pol, float(cfg.action_range), lr=args.lr, num_sgd_iter=args
                      entropy_coeff=args.entropy, kl_target=args.kl_target, seed=args.seed + rank, use_graph=not args.no_graph, fused_loss=args.fused_loss, env=env,
                      discrete_yaw_steps=args.discrete_yaw_steps, autocast_dtype=torch.bfloat16 if args.learner_bf16 else None, fused_adam=not args.no_fused_adam,
                      native=args.native, native_splits=args.native_splits, persistent=False if args.no_persistent else None,
-                     dynamic_loss_scale=args.dynamic_loss_scale)
+                     dynamic_loss_scale=args.dynamic_loss_scale, precision="f32" if args.learner_fp32 else "f16")
 log = []
 start_iter, best_metric, best_file = 0, float("-inf"), None
 
 
 def save_checkpoint(it, tag):
-    """One file per checkpoint (torch.save): everything an exact resume needs."""
+    """One file per checkpoint (torch.save): the policy, the learner (optimizer moments + step count, adaptive KL coefficient, float16 loss scales,
+    the minibatch-permutation generator and the permutations already drawn ahead), torch's generator, the iteration and the best metric: a
+    resumed run continues the LEARNER exactly.  The environment is not checkpointed: a resumed run's sampler starts from a fresh reset with
+    a seed offset by the iteration it resumes at (env state is not part of the reference's RLlib checkpoints either, train.py:110-133), so
+    trajectories after a resume differ from the uninterrupted run's.  Rank 0 writes; each rank's learner generator differs by its rank (seed +
+    rank): the file holds rank 0's, the other ranks re-derive theirs at resume (`lrn.seed`)."""
     os.makedirs(args.checkpoint_dir, exist_ok=True)
     fn = os.path.join(args.checkpoint_dir, f"checkpoint_{tag}.pt")
     torch.save({"iter": it, "policy": pol.state_dict(), "learner": lrn.state_dict(), "best_metric": best_metric, "best_file": best_file,
-                "sampler_stats": smp.stats, "torch_rng": torch.get_rng_state(), "learner_gen": lrn.gen.get_state() if lrn.gen is not None else None,
+                "sampler_stats": smp.stats, "torch_rng": torch.get_rng_state(), "torch_cuda_rng": torch.cuda.get_rng_state(), "rank": rank,
                 "args": vars(args)}, fn + ".tmp")
     os.replace(fn + ".tmp", fn)
     return fn
 
 
 if args.restore:
-    ck = torch.load(args.restore, map_location="cuda", weights_only=False)
     pol.load_state_dict(ck["policy"])
-    lrn.load_state_dict(ck["learner"])
-    if ck.get("learner_gen") is not None:
-        lrn.gen = torch.Generator(device="cuda").manual_seed(0)
-        lrn.gen.set_state(ck["learner_gen"].cpu())
+    lsd = dict(ck["learner"])
+    if ck.get("learner_gen") is not None and lsd.get("gen") is None:       # (checkpoints written before round 6)
+        lsd["gen"] = ck["learner_gen"]
+    if rank != int(ck.get("rank", 0)):                                      # another rank's permutation stream: re-derived from this rank's seed, not collapsed onto rank 0's
+        lsd["gen"], lsd["perms_next"] = None, None
+    lrn.load_state_dict(lsd)
+    if ck.get("torch_rng") is not None:
+        torch.set_rng_state(ck["torch_rng"].cpu())
+    if ck.get("torch_cuda_rng") is not None:
+        torch.cuda.set_rng_state(ck["torch_cuda_rng"].cpu())
     start_iter, best_metric, best_file = int(ck["iter"]) + 1, float(ck["best_metric"]), ck.get("best_file")
     if fused is not None:
         fused.refresh()
@@ -175,7 +190,8 @@ if rank == 0:
              "total_steps": args.iters * args.envs * args.horizon, "wall_s": time.time() - t0}
     print(json.dumps(final), flush=True)
     if args.out:
-        json.dump({"args": vars(args), "log": log, "final": final}, open(args.out, "w"))
+        kept = [r for r in log if r["iter"] % max(1, args.out_stride) == 0 or r["iter"] == args.iters - 1 or "eval_det" in r or "checkpoint" in r]
+        json.dump({"args": vars(args), "log": kept, "final": final}, open(args.out, "w"))
     if args.save:
         import numpy as np
         names = [(pol.pi[0], "fc_1"), (pol.pi[2], "fc_2"), (pol.pi[4], "fc_out"), (pol.vf[0], "fc_value_1"), (pol.vf[2], "fc_value_2"), (pol.vf[4], "value_out")]
