@@ -97,7 +97,7 @@ def make_actions(n, ticks, action_range, seed):
     return keys, mouse
 
 
-def cpu_baseline(n, action_range, budget_s=10.0, gpu_check=None):
+def cpu_baseline(n, action_range, budget_s=10.0, gpu_check=None, extras=True):
     """The NumPy oracle (from-scratch restatement of the reference's NumPy path, bit-pinned to the reference by
     tests/golden) timed on this box's host: 1 process, 1 thread (NumPy elementwise kernels are single-threaded).
     While it runs it also serves as the CHECKER of the metric's second half: after 720 ticks (10 s of game time) its
@@ -139,6 +139,8 @@ def cpu_baseline(n, action_range, budget_s=10.0, gpu_check=None):
             "on_ground_mismatches": int(np.count_nonzero(((g["flags"] & 1) != 0) != snap["on_ground"])),
             "max_abs_time_remaining_diff": float(np.abs(g["time_remaining"] - snap["t_rem"]).max()),
             "max_abs_y_travelled": float(np.abs(snap["dist"][:, 1]).max())}
+    if not extras:
+        return out
     # the reference's verbatim call pattern: RLlib hands vector_step a list of N tuples (scalars + (1,) arrays), which
     # _fix_actions (env.py:221-223) converts with a Python double loop - 86 % of the reference's wall time at this size
     rows = acts[0]
@@ -284,6 +286,7 @@ def traffic_per_launch(pmc, n, ticks_per_launch, resident_state):
 
 
 # ---- the ONE stdout line ---------------------------------------------------------------------------------------------------------
+REGION_REPS = 15           # repetitions of the --steps region reported next to the single-shot `value` (median / min / max: timed_region_us)
 LINE_MAX_BYTES = 4096      # the driver keeps the last 8 KB of stdout and parses the line from it (round 4's 20.7 KB line was lost: parsed null)
 
 
@@ -326,7 +329,7 @@ def contract_line(out, extra_path):
     line = {k: out.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
                                     "vs_baseline", "dtype", "data")}
     line["config"] = out["config"]
-    line["roofline"] = {k: ro.get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "avg_launch_us",
+    line["roofline"] = {k: ro.get(k) for k in ("bound", "frac_axis", "achieved", "peak", "unit", "frac", "frac_8d_204B", "traffic", "kernel", "avg_launch_us",
                                                "ticks_per_launch", "launches", "pmc_stale")}
     if isinstance(line["roofline"].get("kernel"), str):
         line["roofline"]["kernel"] = line["roofline"]["kernel"].split("  (")[0]      # the instantiation; the legend of its arguments is in the side file
@@ -345,9 +348,11 @@ def contract_line(out, extra_path):
     for k in ("mode", "mode_fallback", "env_impl", "lib_sha16", "lib_build_id", "ms_per_step_incl_runtime_sync"):
         line[k] = out.get(k)
     line["completion"] = out.get("completion")
-    if hs:
+    if hs or out.get("timed_region_reps"):
         line["timed_region_us"] = {k: hs.get(k) for k in ("launch_to_signal_seen_us", "device_stamp_us", "hip_event_us", "post_sync_us",
                                                           "wall_incl_runtime_sync_us") if hs.get(k) is not None}
+        rs = out.get("timed_region_reps") or {}
+        line["timed_region_us"].update({k: rs.get(k) for k in ("reps", "median_us", "min_us", "max_us") if rs.get(k) is not None})
     ss = out.get("steady_state_720_ticks")
     if ss:
         line["steady_state_us_per_tick"] = {m: v.get("us_per_tick") for m, v in ss.items()}
@@ -735,7 +740,9 @@ def main(argv=None):
     def server_ok():
         return not server_state()["status"].cpu().numpy().any()      # accumulated since it was zeroed at set-up; written on failure only
 
-    def measure(mode, steps, warmup):
+    region_reps = {}                              # mode -> per-repetition wall seconds of the --steps region (this rank's)
+
+    def measure(mode, steps, warmup, reps=0):
         # Preparation (untimed): instantiate + upload every graph the two sequences replay, and replay them ONCE with the env
         # state saved and restored around it, so that neither the warm-up nor the timed region pays a first-replay cost (kernel
         # code objects, the graph's packets, the TLB entries of the action slabs) - in production a graph is replayed thousands
@@ -854,6 +861,27 @@ def main(argv=None):
             host_split[mode] = {"enqueue_us": (t_enq - t0) * 1e6, "enqueue_to_sync_return_us": (t0 + own - t_enq) * 1e6,
                                 "completion": "torch.cuda.synchronize()"}
             ev_ms = dev.timer_elapsed()           # both events have completed: no further wait
+        # The contract's `value` is the ONE region above.  A 20-tick region is ~28 us: one sample of launch jitter - so the same region is
+        # repeated `reps` times (state restored, the W warm-up ticks, a barrier, the same calls and the same completion criterion) and the
+        # line carries median / min / max next to the single shot.
+        if reps > 0:
+            kind = ("signal_wait" if one_call else "signal") if signalled else "events"
+            times = []
+            for _ in range(reps):
+                dev.restore_state()
+                run(plan_ticks(mode, warmup, 0)[0])
+                calls_r, _l = plan_ticks(mode, steps, warmup, timed=kind)
+                barrier()
+                ta = time.perf_counter()
+                run(calls_r)
+                if signalled and not one_call:
+                    wait()
+                elif not signalled:
+                    dsync()
+                tb = time.perf_counter()
+                dsync()
+                times.append(tb - ta)
+            region_reps[mode] = times
         if world > 1:
             dist.barrier()
         if not agree(mode != "server" or server_ok()):
@@ -877,16 +905,29 @@ def main(argv=None):
     if args.mode == "auto":
         args.mode = PRIMARY_AUTO
         try:
-            wall, ev_ms, launches, own = measure(args.mode, args.steps, args.warmup)
+            wall, ev_ms, launches, own = measure(args.mode, args.steps, args.warmup, reps=REGION_REPS)
         except Exception as ex:   # noqa: BLE001 - measure() reaches its verdict collectively: every rank falls back at the same point
             fallback = f"{args.mode} mode failed ({ex!r}); measured with per-tick launches instead"
             sys.stderr.write("bench.py: " + fallback + "\n")
             args.mode = "step"
-            wall, ev_ms, launches, own = measure(args.mode, args.steps, args.warmup)
+            wall, ev_ms, launches, own = measure(args.mode, args.steps, args.warmup, reps=REGION_REPS)
     else:
-        wall, ev_ms, launches, own = measure(args.mode, args.steps, args.warmup)
+        wall, ev_ms, launches, own = measure(args.mode, args.steps, args.warmup, reps=REGION_REPS)
     ranks = per_rank(own, ev_ms, args.steps, args.mode)
     value = float(n) * args.steps * world / wall
+    # the repetitions of the same region: per repetition the slowest rank (what `value` is built on), then median / min / max over the repetitions
+    reps_stat = None
+    if region_reps.get(args.mode):
+        tt = torch.tensor(region_reps[args.mode], dtype=torch.float64)
+        if world > 1:
+            tt = tt.to(d if dist.get_backend() == "nccl" else "cpu")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            tt = tt.cpu()
+        us = sorted(float(x) * 1e6 for x in tt)
+        reps_stat = {"reps": len(us), "median_us": us[len(us) // 2], "min_us": us[0], "max_us": us[-1],
+                     "median_env_steps_per_s": float(n) * args.steps * world / (us[len(us) // 2] * 1e-6),
+                     "what": f"the --steps region repeated {len(us)} times from the same state (state restored + the W warm-up ticks before each), same calls and "
+                             "completion criterion as the single region `value` is built on; per repetition the slowest rank"}
     spec_cfg = True                                   # get_default's action / episode structure: the SPEC = true instantiations
 
     def pair_es(n_envs):
@@ -943,7 +984,11 @@ def main(argv=None):
         nominal = B_ALG * n * tpl / (kern_us * 1e-6) / 1e9
         hs = host_split.get(mode) or {}
         stamp_us = hs.get("device_stamp_us")
-        r = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+        # `bound`: what limits the kernel.  The per-tick step kernel moves the whole state every launch: memory ("hbm").  The register-resident
+        # kernels are bound by float64 VALU issue at one wave per SIMD (`valu`, profiles/r5_tick_floor.txt) - `frac` is still their distance from
+        # the HBM roof (`frac_axis`), which is the axis SURVEY 8(d) prescribes; frac_8d_204B prices the same launch at 8(d)'s literal 204 B per
+        # env-step (> 1 for a register-resident kernel: the 170 B of state it does not move - not a fraction of anything).
+        r = {"bound": "hbm" if not resident else "valu_f64", "frac_axis": "hbm", "frac_8d_204B": nominal / HBM_PEAK_GBPS, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
              "kernel": kernel_name(mode, tpl), "avg_launch_us": kern_us, "ticks_per_launch": tpl, "launches": launches_,
              "algorithmic_bytes_per_launch": alg_bytes,
              "alg_bytes_per_env_step": B_ALG if not resident else B_FUSED, "alg_bytes_per_env_per_launch": 0.0 if not resident else B_STATE,
@@ -1012,6 +1057,7 @@ def main(argv=None):
         "ms_per_step_incl_runtime_sync": ((host_split.get(args.mode) or {}).get("wall_incl_runtime_sync_us") or wall * 1e6) / 1e3 / args.steps
                                          if world == 1 else None,
         "completion": (host_split.get(args.mode) or {}).get("completion"),
+        "timed_region_reps": reps_stat,
         "per_rank": ranks,
         "parity": "max |pos - NumPy ref| over the 10 s rollout: measured live in cpu_baseline.parity_vs_gpu_after_719_ticks (N=1 runs); "
                   "tests/test_hip_fastpath.py::test_full_size_rollout_parity_65536_envs_720_ticks checks all 65 536 x 720 env-steps bit-exactly",
@@ -1048,7 +1094,7 @@ def main(argv=None):
             out["sampler_configs4_shard"] = sampler_block(dev_index)
         except Exception as ex:   # noqa: BLE001 - extra information must not take the contract line down
             out["sampler_configs4_shard"] = {"error": repr(ex)}
-    if rank == 0 and world == 1 and not args.no_cpu_baseline and not full_cfg:
+    if rank == 0 and not args.no_cpu_baseline and not full_cfg:
         def gpu_check(acts, k):
             """The GPU env on the oracle's own actions (float64 rows) for k ticks from a fresh zero start."""
             chk = DeviceEnv(cfg, device=dev_index)
@@ -1059,14 +1105,15 @@ def main(argv=None):
             st = chk.get_state()
             chk.close()
             return st
-        out["cpu_baseline"] = cpu_baseline(n, ar, gpu_check=gpu_check)
-    elif world > 1:
-        # the CPU baseline is timed on rank 0 at N = 1 only (it would otherwise run next to other ranks' host threads): pointer, not a number
-        out["cpu_baseline"] = {"value": None, "unit": "env-steps/s", "cores": 1, "kind": "port",
-                               "sample": "not timed in a multi-rank run: see the cpu_baseline of the N=1 run of this command "
-                                         "(`python bench.py --gpus 1 ...`, same workload per GPU; BENCH_rNN.json next to SCALE_rNN.json)"}
-    else:
+        # N > 1: timed on rank 0 AFTER every timed region, while the other ranks wait in the barrier below (their host threads sleep in the
+        # collective; nothing of theirs runs on the GPUs) - a shorter sample, without the extras of the N = 1 run
+        out["cpu_baseline"] = cpu_baseline(n, ar, budget_s=10.0 if world == 1 else 4.0, gpu_check=None if injected else gpu_check, extras=world == 1)
+        if world > 1:
+            out["cpu_baseline"]["sample"] += f"; rank 0 of {world}, after the timed regions, the other ranks parked in a barrier"
+    elif args.no_cpu_baseline or full_cfg:
         out["cpu_baseline"] = None
+    if world > 1:
+        dist.barrier()
     if rank == 0:
         extra_path = write_extra(out)
         print(contract_line(out, extra_path), flush=True)

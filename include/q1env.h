@@ -30,6 +30,17 @@ extern "C" {
 
 #define Q1ENV_ABI_VERSION 6
 
+/* Environment variables the library reads (ALL of them; each is an A/B measurement knob read once per process, none changes a result bit):
+ *   Q1ENV_HOST_DIRECT=0           the small-batch *_host paths stage through copy commands instead of the host-coherent block (csrc/q1env_core.hip)
+ *   Q1ENV_ROLLOUT_DEPTH=1|2       how many ticks ahead the rollout kernels request their actions (default: by launch length)
+ *   Q1ENV_BLOCK=64|128|256        workgroup size of the env kernels (default 256)
+ *   Q1ENV_MLP_THREADS=256|512     one or two waves per SIMD in the policy forward (default: by batch size)
+ *   Q1ENV_RESIDENT_TP=1|2         envs per lane pair of the resident sampler
+ *   Q1ENV_SERVER_SHAPE=<ES>, Q1ENV_SERVER_BACKOFF=a,b,c      shape / poll pacing of the resident tick server
+ * Everything that changes WHAT is computed or HOW workgroups communicate is an explicit call: q1env_learner_set_loss_scale,
+ * q1env_learner_set_exchange_mode, q1env_learner_set_profiling (the Q1_LEARNER_* variables of ABI v5 are gone).  The binding additionally
+ * honours Q1ENV_LIB_PATH (which build of this library to load: the -DQ1_CHECK assertion build, the host-side AddressSanitizer build). */
+
 typedef enum q1env_status {
     Q1ENV_OK = 0,
     Q1ENV_ERR_INVALID_ARG = -1,

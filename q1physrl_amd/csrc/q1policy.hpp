@@ -59,6 +59,21 @@ constexpr float TANH_PRESCALE = 2.8853900817779268f;                 // 2 log2(e
 // element; the pair is converted with one v_cvt_pk_f16_f32 (RNE).
 __device__ __forceinline__ f16x8 activate(const f32x16& acc, int u) {
     union { f16x8 v; f16x2 p[4]; } o;
+#ifdef Q1POL_ACT_PK16
+    // EXPERIMENT (round 6; profiles/r6_policy_tanh_experiment.txt): the exponentials stay float32, everything behind them runs
+    // in packed float16 - convert the pair, + 1 (v_pk_add_f16), two v_rcp_f16, 1 - 2 r (v_pk_fma_f16) - so that the result IS the operand pair.
+    // Not the product form: compiled only with -DQ1POL_ACT_PK16 (tools/r6_policy_tanh.sh builds libq1env_pk16.so and times / checks it).
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const f32x2 t = {__builtin_amdgcn_exp2f(acc[8 * u + 2 * j]), __builtin_amdgcn_exp2f(acc[8 * u + 2 * j + 1])};
+        const f32x2 tc = {fminf(t[0], 65504.0f), fminf(t[1], 65504.0f)};      // (2^(c z) overflows float16 from z = 5.5: tanh = 1 - 2 / 65505 there)
+        f16x2 e = __builtin_convertvector(tc, f16x2);
+        e = e + (f16x2){(_Float16)1.0f, (_Float16)1.0f};
+        const f16x2 r = {(_Float16)__builtin_amdgcn_rcph(e[0]), (_Float16)__builtin_amdgcn_rcph(e[1])};
+        o.p[j] = __builtin_elementwise_fma((f16x2){(_Float16)-2.0f, (_Float16)-2.0f}, r, (f16x2){(_Float16)1.0f, (_Float16)1.0f});
+    }
+    return o.v;
+#endif
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         f32x2 t = {__builtin_amdgcn_exp2f(acc[8 * u + 2 * j]), __builtin_amdgcn_exp2f(acc[8 * u + 2 * j + 1])};

@@ -64,7 +64,10 @@ def test_bench_prints_one_contract_json_line():
     # default mode = the fused rollout with every tick's outputs in HBM: a register-resident kernel; the roofline object is on the HBM
     # axis (algorithmic bytes over the launch time) and every fraction is a fraction
     assert d["mode"] == "rollout" and d["mode_fallback"] is None and d["env_impl"] == "q1physrl_amd.device.DeviceEnv"
-    assert rf["bound"] == "hbm" and "rollout_kernel<float, true, 2, false, 1, false, 2>" in rf["kernel"]            # 288 ticks per launch: the two-ahead form
+    # (`bound` names the limiter - float64 VALU issue for the register-resident kernels -, `frac` stays on the HBM axis SURVEY 8(d) prescribes,
+    #  frac_8d_204B prices the launch at 8(d)'s literal 204 B per env-step: not a fraction, may pass 1)
+    assert rf["bound"] == "valu_f64" and rf["frac_axis"] == "hbm" and rf["frac_8d_204B"] > rf["frac"]
+    assert "rollout_kernel<float, true, 2, false, 1, false, 2>" in rf["kernel"]            # 288 ticks per launch: the two-ahead form
     assert 0 < rf["frac"] <= 1.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9 and rf["peak"] == 8000.0
     assert len(d["lib_sha16"]) == 16 and len(d["lib_build_id"]) == 16
     st = d["per_tick_step"]

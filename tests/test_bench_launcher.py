@@ -61,7 +61,14 @@ def _check_line(d, world, envs, steps, warmup):
     slowest = max(r["wall_ms"] for r in rows)
     assert abs(d["ms_per_step"] * steps - slowest) <= 1e-6 * slowest            # MAX over ranks is what `value` is built on
     assert abs(d["value"] - envs * world * steps / (slowest * 1e-3)) <= 1e-6 * d["value"]
-    assert d["cpu_baseline"] is None or world == 1 or d["cpu_baseline"]["value"] is None      # multi-rank: a pointer to the N=1 run
+    # the CPU baseline is a NUMBER at every rank count (timed on rank 0 after the timed regions, the others parked)
+    if d["cpu_baseline"] is not None:
+        assert d["cpu_baseline"]["value"] > 0 and d["cpu_baseline"]["cores"] == 1 and d["cpu_baseline"]["kind"] == "port"
+        assert d["_line"]["cpu_baseline"]["value"] == pytest.approx(d["cpu_baseline"]["value"], rel=1e-5)
+        assert (world == 1) or f"rank 0 of {world}" in d["cpu_baseline"]["sample"]
+    # the --steps region: one shot (`value`) + 15 repetitions (median / min / max over the slowest rank of each)
+    tr = d["_line"]["timed_region_us"]
+    assert tr["reps"] == 15 and 0 < tr["min_us"] <= tr["median_us"] <= tr["max_us"]
     # the line names what ran: the injected stand-in here, q1physrl_amd.device.DeviceEnv on the GPU box
     assert "INJECTED" in d["env_impl"] and "tests._bench_fake" in d["env_impl"]
     bases = [r["env_index_base"] for r in rows]
@@ -133,7 +140,8 @@ def test_default_mode_writes_per_tick_outputs_and_says_what_bounds_it():
     assert d["mode"] == "rollout" and d["mode_fallback"] is None
     assert "mode=rollout" in d["config"]["workload"] and "written tick-major to HBM" in d["config"]["workload"]
     ro = d["roofline"]
-    assert ro["bound"] == "hbm" and ro["kernel"].startswith("rollout_kernel<float, true, 2, false, 1, false, 1>") and "SPEC, ES" not in ro["kernel"]
+    assert ro["bound"] == "valu_f64" and ro["frac_axis"] == "hbm" and ro["kernel"].startswith("rollout_kernel<float, true, 2, false, 1, false, 1>") and "SPEC, ES" not in ro["kernel"]
+    assert abs(ro["frac_8d_204B"] - ro["frac_nominal_204B"]) < 1e-12 and d["_line"]["roofline"]["frac_8d_204B"] == pytest.approx(ro["frac_8d_204B"], rel=1e-5)
     assert set(("valu", "frac_nominal_204B", "traffic", "peak", "unit", "ticks_per_launch", "achieved", "frac", "pmc_stale", "device_stamp_us")) <= set(ro)
     assert ro["peak"] == 8000.0 and ro["unit"] == "GB/s" and ro["ticks_per_launch"] == 20
     assert abs(ro["algorithmic_bytes_per_launch"] - (34.0 * 32 * 20 + 170.0 * 32)) < 1e-6
