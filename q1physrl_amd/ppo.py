@@ -226,9 +226,12 @@ class PPOLearner:
         # persistent: the whole update (num_sgd_iter epochs of 128-sample minibatches) as ONE dispatch (NativeStep.epochs); None = whenever
         # the shape allows it (native, own Adam, single process, minibatch 128, the reference's action structure)
         self.persistent = persistent
-        # precision of the persistent learner's arithmetic: "f16" = float16 matrix operands, float32 accumulation / masters / optimizer (the fast
-        # default); "f32" = q1env_learner_sgd_epochs_f32: float32 everywhere, no loss scale, no saturation - RLlib's own arithmetic, ~2x the time
-        # per step (the control of STATE.md "fp32 control")
+        # precision of the PERSISTENT learner's arithmetic (the reference's shape: minibatch 128; the four-launch path of larger minibatches is float16
+        # only).  "f16" (default) = float16 matrix operands, float32 accumulation / masters / optimizer, 11.8 us per step, per-sample gradients saturating
+        # at 65 504 / loss scale; "f32" = q1env_learner_sgd_epochs_f32: float32 everywhere, no loss scale, nothing saturates - RLlib's own arithmetic (TF
+        # PPO is float32 end to end, grad_clip None), 27 us per step.  Round 6 measured both under the reference's configuration over 8 / 9 seeds
+        # (STATE.md "fp32 control"): 3 of 8 float16 runs and 3 of 9 float32 runs end below 5 500, medians 5 660 / 5 708 - the seed spread belongs to the
+        # configuration, not to the arithmetic -, so the fast kernel stays the default and the float32 one is the explicit choice for the reference's numerics.
         if precision not in ("f16", "f32"):
             raise ValueError("precision must be 'f16' or 'f32'")
         self.precision = precision

@@ -722,7 +722,8 @@ def test_persistent_learner_whole_update_under_the_assertion_build():
     """VERDICT r5 items 1b / missing 4: the -DQ1_CHECK build of the persistent learner (libq1env_check.so) compares every exchange offset
     with the group's workspace, every gathered row index with the number of rows, every schedule position with the index list and every
     barrier reading with its range - a failure is a status word, not a memory fault.  tools/soak_plearner_check.py runs a whole update of
-    the reference's shape (30 epochs x 391 steps = 11 730 steps) in both exchange modes with zero failures, then plants a row index beyond
+    the reference's shape (30 epochs x 391 steps = 11 730 steps) in both exchange modes - and 10 epochs of the float32 kernel in both - with zero
+    failures, then plants a row index beyond
     the batch and expects status 0x102 (and a process that is still alive).  Subprocess: the assertion library is chosen before the
     binding loads; the product library reports "not an assertion build"."""
     import os
@@ -738,7 +739,7 @@ def test_persistent_learner_whole_update_under_the_assertion_build():
                        env=dict(os.environ, Q1ENV_LIB_PATH=so))
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     last = r.stdout.strip().splitlines()[-1]
-    assert last.startswith("soak_plearner_check ok: 23460 steps") and " 0 failures" in last and "planted index -> status 0x102" in last, last
+    assert last.startswith("soak_plearner_check ok: 31280 steps") and " 0 failures" in last and "planted index -> status 0x102" in last, last
 
 
 # ---- the float32-arithmetic persistent learner (q1env_learner_sgd_epochs_f32, csrc/q1learner_persist32.hpp): RLlib's own arithmetic
@@ -864,6 +865,7 @@ def test_ppo_learner_precision_f32_runs_the_float32_kernel():
     tr = smp.collect()
     adv, vt = smp.advantages(tr, 0.99, 0.95)
     outs = []
+    assert ppo.PPOLearner(pol_a, cfg.action_range, env=env, native=True).precision == "f16"       # the default (STATE.md "fp32 control": why it stays)
     for pol, prec in ((pol_a, "f16"), (pol_b, "f32")):
         lr_ = ppo.PPOLearner(pol, cfg.action_range, lr=5e-6, num_sgd_iter=3, minibatch_size=128, env=env, native=True, persistent=True, seed=3, precision=prec)
         outs.append([lr_.update(tr, adv, vt) for _ in range(3)])

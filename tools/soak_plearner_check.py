@@ -28,12 +28,13 @@ def main():
     hp = (5e-6, (0.9, 0.999), 1e-8)
     perms = torch.stack([torch.randperm(total, device="cuda") for _ in range(epochs)]).contiguous()
     steps = 0
-    for mode in ("auto", "agent"):
+    # the float16 kernel: the whole update; the float32 kernel (csrc/q1learner_persist32.hpp: the same accessors, the same assertions): a third of one
+    for f32, mode in ((False, "auto"), (False, "agent"), (True, "auto"), (True, "agent")):
         env._dev.learner_set_exchange_mode(mode)
-        n = nat.epochs(full, perms, 0.3, 10.0, 1.0, 0.01, klc, hp, refresh_images=False)
+        n = nat.epochs(full, perms[:10] if f32 else perms, 0.3, 10.0, 1.0, 0.01, klc, hp, refresh_images=False, f32=f32)
         torch.cuda.synchronize()
         st = nat.persistent_status()
-        print(f"mode {mode}: {n} steps, status {st}, counters {env._dev.learner_debug_counters()}", flush=True)
+        print(f"{'float32' if f32 else 'float16'} kernel, mode {mode}: {n} steps, status {st}, counters {env._dev.learner_debug_counters()}", flush=True)
         if st[0] != 0:
             print("soak_plearner_check FAILED: status", st)
             return 1

@@ -50,7 +50,8 @@ ap.add_argument("--refcfg", action="store_true",
                      "per iteration; overrides --envs / --horizon / --lr / --epochs / --minibatch / --entropy / --kl-target / --zero-start-prob")
 ap.add_argument("--no-persistent", action="store_true", help="drive q1env_learner_sgd_step per minibatch instead of ONE q1env_learner_sgd_epochs dispatch per update (A/B)")
 ap.add_argument("--learner-fp32", action="store_true", help="the persistent learner in float32 arithmetic (q1env_learner_sgd_epochs_f32: float32 operands, no loss scale, "
-                                                           "nothing saturates - RLlib's own arithmetic; ~2x the time per step): the control of the float16 learner")
+                                                           "nothing saturates - RLlib's own arithmetic; 27 instead of 11.8 us per step): the control of the float16 learner "
+                                                           "(STATE.md: same seed spread over 8 / 9 seeds)")
 ap.add_argument("--dynamic-loss-scale", action="store_true", help="choose the native learner's float16 loss scales per update from the previous update's largest gradient element instead of the static (256, 1): no saturation, but measured to cost the large-minibatch configuration its result (PPOLearner docstring)")
 ap.add_argument("--checkpoint-dir", default="", help="trainer checkpoints (policy weights, optimizer state incl. the native Adam moments + step count, adaptive KL "
                                                       "coefficient, iteration, best metric): every --checkpoint-every iterations and whenever "
