@@ -465,6 +465,8 @@ __device__ __forceinline__ void body(const Args& a, unsigned char* lds) {
             *reinterpret_cast<float*>(lds + L_W3T + (u * 20u + o) * 4u) = wn;
             if (last) net.gw3[(size_t)o * HID + U0 + u] = gr;
         }
+        float b3_new = 0.0f;                                    // (workgroup 0: the updated output bias, published BEHIND barrier 3 - see there)
+        bool b3_mine = false;
         {                                                       // db2[U] (8 threads per unit) and, on workgroup 0, db3 (8 threads per output)
             const uint32_t u = tid >> 3, part = tid & 7u;
             float sb = 0.0f, s3o = 0.0f;
@@ -487,7 +489,7 @@ __device__ __forceinline__ void body(const Args& a, unsigned char* lds) {
                     const float b3n = adam32(sB3[u], g3, m3, v3, a.beta1, a.beta2, a.eps, lr_bc1, rs_bc2);
                     sB3[u] = b3n; sB3[16 + u] = m3; sB3[32 + u] = v3;
                     if (last) net.gb3[u] = g3;
-                    q1pl::pub4f(net.b3x + u, b3n, loc);         // (read by every workgroup behind the NEXT step's barrier 2; the old one was read before this barrier 3)
+                    b3_new = b3n; b3_mine = true;
                 }
             }
         }
@@ -531,6 +533,10 @@ __device__ __forceinline__ void body(const Args& a, unsigned char* lds) {
         Q1PL32_STAMP(7);                                        // dW2 + Adam
         if (!q1pl::bar_wait(net.bar, (uint32_t)G * ++bar_n, loc, a.status, 2u, (uint32_t)step, a.timeout_ticks, s_ok)) return;
         Q1PL32_STAMP(8);                                        // barrier 3 wait
+        // the new output bias is published only NOW: every workgroup reads b3 for THIS step's loss right behind barrier 2, and a slow one may still be
+        // there while workgroup 0 is already past its arrival at barrier 3 - behind the wait everybody's reads have completed (the arrival waits for them);
+        // the next reading is behind the next step's barrier 2
+        if (b3_mine) q1pl::pub4f(net.b3x + (tid >> 3), b3_new, loc);
 
         // ------------------------------------------------------------ B2: dH1[:, U] = dZ2 W2[:, U] (all of dZ2), dZ1 = dH1 (1 - H1^2), dW1 / db1
         {
