@@ -127,6 +127,7 @@ _SIGNATURES = {
     "q1env_learner_sgd_epochs_f32": (C.c_int, [_P, C.POINTER(Q1LearnerNet), C.POINTER(Q1LearnerNet), _P, C.POINTER(Q1LearnerBatch)] + [C.c_int64] * 5
                                      + [C.c_float] * 4 + [_P, C.c_double]),
     "q1env_learner_set_exchange_mode": (C.c_int, [_P, C.c_int]),
+    "q1env_learner_set_step_mode": (C.c_int, [_P, C.c_int]),
     "q1env_learner_set_profiling": (C.c_int, [_P, C.c_int]),
     "q1env_learner_persistent_layout": (C.c_int, [C.c_int64, C.c_int, C.POINTER(C.c_uint64)]),
     "q1env_learner_debug_counters": (C.c_int, [_P, C.POINTER(C.c_uint64)]),

@@ -7,6 +7,7 @@
 #include "q1policy_glue.hpp"
 #include "q1ppo_loss.hpp"
 #include "q1learner.hpp"
+#include "q1learner_fused.hpp"
 
 using namespace q1;
 
@@ -24,6 +25,7 @@ constexpr size_t IMG_FWD_BYTES = (q1pol::LDS_W2 + q1pol::LDS_W3);           // 1
 constexpr size_t IMG_W2T_BYTES = q1learn::LDS_W2T;                          // 135168
 constexpr size_t IMG_W3T_BYTES = q1learn::LDS_W3T;                          // 20480
 
+constexpr int64_t FUSED_MIN_BATCH = 2048;      // q1env_learner_sgd_step takes the fused forward + backward kernel from here on (automatic mode)
 constexpr size_t STATS_ROWS = 2048;      // >= the backward kernel's workgroups (at most one per CU)
 
 struct NetWs {
@@ -31,6 +33,7 @@ struct NetWs {
     q1learn::f16x8* h1T; q1learn::f16x8* h2T; q1learn::f16x8* dz2N; q1learn::f16x8* dz1N;
     q1learn::f16x8* xN; q1learn::f16x8* dyN;
     float* partial;
+    float* dw1p;                  // the fused forward + backward kernel's per-tile dW1 / db1 products (q1learner_fused.hpp, DW1)
 };
 struct Ws {
     NetWs net[2];
@@ -57,6 +60,7 @@ Ws carve_ws(void* base, int64_t mb, int out_pi, int splits) {
     w.logits = (float*)take((size_t)mb * out_pi * 4u); w.value = (float*)take((size_t)mb * 4u);
     w.dlogits = (float*)take((size_t)mb * out_pi * 4u); w.dvalue = (float*)take((size_t)mb * 4u);
     w.stats_rows = (float*)take(STATS_ROWS * 5u * 4u);
+    for (int k = 0; k < 2; ++k) w.net[k].dw1p = (float*)take(tiles * q1learn::DW1_TILE_FLOATS * 4u);      // (behind everything round 4 laid out)
     w.bytes = off;
     return w;
 }
@@ -81,6 +85,8 @@ int ensure_learner_attrs(q1env* h) {
         HIP_TRY(hipFuncSetAttribute((const void*)q1learn::learner_forward_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)q1pol::LDS_TOTAL));
         HIP_TRY(hipFuncSetAttribute((const void*)q1learn::learner_backward_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)q1learn::LDS_BWD));
         HIP_TRY(hipFuncSetAttribute((const void*)q1learn::learner_backward_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)q1learn::LDS_BWD));
+        HIP_TRY(hipFuncSetAttribute((const void*)q1learn::learner_fwdbwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)q1learn::LDS_FZ));
+        HIP_TRY(hipFuncSetAttribute((const void*)q1learn::learner_fwdbwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)q1learn::LDS_FZ));
         h->learner_attr_set = true;
     }
     return 0;
@@ -122,15 +128,41 @@ int launch_backward(q1env* h, const Ws& w, int64_t mb, int splits, const q1env_l
     else
         hipLaunchKernelGGL(q1learn::learner_backward_kernel<false>, dim3(blocks * 2u), dim3(256), q1learn::LDS_BWD, h->stream, (int)mb, obs, idx, idx_cursor, ba,
                            bb, 2, q1learn::LossArgs{}, q1learn::BcArgs{nullptr, nullptr, 0.0f, 0.0f});
-    const q1learn::WgNet wa{w.net[0].dz2N, w.net[0].dz1N, w.net[0].h1T, w.net[0].h2T, w.net[0].xN, w.net[0].dyN, w.net[0].partial};
-    const q1learn::WgNet wb{w.net[1].dz2N, w.net[1].dz1N, w.net[1].h1T, w.net[1].h2T, w.net[1].xN, w.net[1].dyN, w.net[1].partial};
-    hipLaunchKernelGGL(q1learn::learner_wgrad_kernel, dim3(2u * (unsigned)splits, 2, 2), dim3(256), 0, h->stream, (int)mb, wa, wb, splits);
+    const q1learn::WgNet wa{w.net[0].dz2N, w.net[0].dz1N, w.net[0].h1T, w.net[0].h2T, w.net[0].xN, w.net[0].dyN, w.net[0].partial, nullptr};
+    const q1learn::WgNet wb{w.net[1].dz2N, w.net[1].dz1N, w.net[1].h1T, w.net[1].h2T, w.net[1].xN, w.net[1].dyN, w.net[1].partial, nullptr};
+    hipLaunchKernelGGL(q1learn::learner_wgrad_kernel<false>, dim3(2u * (unsigned)splits, 2, 2), dim3(256), 0, h->stream, (int)mb, wa, wb, splits);
     if (!reduce) { HIP_TRY(hipGetLastError()); return 0; }          // q1env_learner_adam sums the partials itself
     const q1learn::Grads ga{pi->gw1, pi->gb1, pi->gw2, pi->gb2, pi->gw3, pi->gb3, pi->out_dim};
     const q1learn::Grads gb{vf->gw1, vf->gb1, vf->gw2, vf->gb2, vf->gw3, vf->gb3, vf->out_dim};
     const unsigned elems = (unsigned)q1learn::PARTIAL_FLOATS;            // one thread per slot of the partial-sum slab, in the slab's order
     hipLaunchKernelGGL(q1learn::learner_reduce_kernel, dim3((elems + 255u) / 256u, 2), dim3(256), 0, h->stream, (const float*)w.net[0].partial,
-                       (const float*)w.net[1].partial, ga, gb, splits, 1.0f / grad_scale, 1.0f / grad_scale_v);
+                       (const float*)w.net[1].partial, ga, gb, splits, 1.0f / grad_scale, 1.0f / grad_scale_v, 0);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+// The fused step's first two launches (round 6): forward + loss gradient + data gradients in one kernel (q1learner_fused.hpp), then the
+// weight-gradient kernel.  dw1: dZ1 is replaced by the per-tile dW1 / db1 products.  One workgroup per eight 32-sample tiles and network.
+int launch_fwdbwd(q1env* h, const Ws& w, int64_t mb, int splits, const q1env_learner_net* pi, const q1env_learner_net* vf, const float* obs, const int64_t* idx,
+                  const int64_t* idx_cursor, uint32_t* sat, const q1learn::LossArgs& la, const q1learn::BcArgs& bca, bool dw1, unsigned* grid_out) {
+    if (int r = ensure_learner_attrs(h)) return r;
+    const q1learn::FzNet fa{pi->w1, pi->b1, w.net[0].w23, pi->b2, pi->b3, w.net[0].w2t, w.net[0].w3t, w.net[0].h1T, w.net[0].h2T,
+                            w.net[0].dz2N, w.net[0].dz1N, w.net[0].xN, w.net[0].dyN, w.net[0].dw1p, sat};
+    const q1learn::FzNet fb{vf->w1, vf->b1, w.net[1].w23, vf->b2, vf->b3, w.net[1].w2t, w.net[1].w3t, w.net[1].h1T, w.net[1].h2T,
+                            w.net[1].dz2N, w.net[1].dz1N, w.net[1].xN, w.net[1].dyN, w.net[1].dw1p, sat ? sat + 2 : nullptr};
+    const unsigned tiles = (unsigned)((mb + 31) / 32);
+    const unsigned blocks = (tiles + 7u) / 8u;
+    if (blocks * 2u > STATS_ROWS) return fail(Q1ENV_ERR_INVALID_ARG, "learner: more workgroups than statistics rows");
+    *grid_out = blocks * 2u;
+    const q1learn::WgNet wa{w.net[0].dz2N, w.net[0].dz1N, w.net[0].h1T, w.net[0].h2T, w.net[0].xN, w.net[0].dyN, w.net[0].partial, w.net[0].dw1p};
+    const q1learn::WgNet wb{w.net[1].dz2N, w.net[1].dz1N, w.net[1].h1T, w.net[1].h2T, w.net[1].xN, w.net[1].dyN, w.net[1].partial, w.net[1].dw1p};
+    if (dw1) {
+        hipLaunchKernelGGL(q1learn::learner_fwdbwd_kernel<true>, dim3(blocks * 2u), dim3(512), q1learn::LDS_FZ, h->stream, (int)mb, obs, idx, idx_cursor, fa, fb, la, bca);
+        hipLaunchKernelGGL(q1learn::learner_wgrad_kernel<true>, dim3(2u * (unsigned)splits, 2, 2), dim3(256), 0, h->stream, (int)mb, wa, wb, splits);
+    } else {
+        hipLaunchKernelGGL(q1learn::learner_fwdbwd_kernel<false>, dim3(blocks * 2u), dim3(512), q1learn::LDS_FZ, h->stream, (int)mb, obs, idx, idx_cursor, fa, fb, la, bca);
+        hipLaunchKernelGGL(q1learn::learner_wgrad_kernel<false>, dim3(2u * (unsigned)splits, 2, 2), dim3(256), 0, h->stream, (int)mb, wa, wb, splits);
+    }
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -146,6 +178,14 @@ int q1env_learner_set_loss_scale(q1env_t* h, float pi_upscale, float value_downs
         return fail(Q1ENV_ERR_INVALID_ARG, "q1env_learner_set_loss_scale: scales must be 0 (default) or exact powers of two");
     h->pi_upscale = pi_upscale;
     h->value_downscale = value_downscale;
+    return Q1ENV_OK;
+}
+
+int q1env_learner_set_step_mode(q1env_t* h, int mode) {
+    if (!h) return fail(Q1ENV_ERR_INVALID_ARG, "q1env_learner_set_step_mode: null handle");
+    if (mode < 0 || mode > 3)
+        return fail(Q1ENV_ERR_INVALID_ARG, "q1env_learner_set_step_mode: mode must be 0 (automatic), 1 (four launches), 2 (fused forward + backward) or 3 (fused, dW1 products)");
+    h->learner_step_mode = mode;
     return Q1ENV_OK;
 }
 
@@ -238,7 +278,7 @@ namespace {
 // `stat_rows` statistics rows)
 int launch_adam(q1env_t* h, const q1env_learner_net* pi, const q1env_learner_net* vf, void* ws_dev, int64_t minibatch, int splits,
                 float grad_scale, float lr, float beta1, float beta2, float eps, void* adam_state_dev, const float* stats_partials_dev, bool fused_tick,
-                int stat_rows) {
+                int stat_rows, bool dw1 = false) {
     if (!h || !ws_dev || !adam_state_dev) return fail(Q1ENV_ERR_INVALID_ARG, "q1env_learner_adam: null argument");
     if (!(grad_scale > 0.0f) || !(lr >= 0.0f) || !(beta1 >= 0.0f && beta1 < 1.0f) || !(beta2 >= 0.0f && beta2 < 1.0f) || !(eps > 0.0f))
         return fail(Q1ENV_ERR_INVALID_ARG, "q1env_learner_adam: bad hyper-parameter");
@@ -255,9 +295,9 @@ int launch_adam(q1env_t* h, const q1env_learner_net* pi, const q1env_learner_net
     const size_t per_pi = 65536u + 256u + 1536u + 256u + (size_t)pi->out_dim * 257u, per_vf = 65536u + 256u + 1536u + 256u + (size_t)vf->out_dim * 257u;
     float* m_pi = (float*)(st + 256), *v_pi = m_pi + per_pi;
     float* m_vf = (float*)(st + 256 + align_up(2 * per_pi * 4u, 256)), *v_vf = m_vf + per_vf;
-    q1learn::AdamTick tick{nullptr, nullptr, 0, nullptr, 0, 0.0f, nullptr};
+    q1learn::AdamTick tick{nullptr, nullptr, 0, nullptr, 0, 0.0f, nullptr, 0};
     if (fused_tick)
-        tick = q1learn::AdamTick{step, (long long*)(st + 72), (long long)minibatch, stats_partials_dev, stat_rows, 1.0f / (float)minibatch, (float*)(st + 16)};
+        tick = q1learn::AdamTick{step, (long long*)(st + 72), (long long)minibatch, stats_partials_dev, stat_rows, 1.0f / (float)minibatch, (float*)(st + 16), dw1 ? 1 : 0};
     else
         hipLaunchKernelGGL(q1learn::adam_tick_kernel, dim3(1), dim3(64), 0, h->stream, step, bc, beta1, beta2, stats_partials_dev,
                            (int)((minibatch + 255) / 256), 1.0f / (float)minibatch, (float*)(st + 16), (long long*)(st + 72), (long long)minibatch);
@@ -310,7 +350,11 @@ int q1env_learner_sgd_step(q1env_t* h, const q1env_learner_net* pi, const q1env_
     DeviceGuard guard(h->device);
     const int64_t mb = b->minibatch;
     const Ws w = carve_ws(ws_dev, mb, pi->out_dim, splits);
-    if (int r = launch_forward(h, w, mb, pi, vf, b->obs_dev, b->idx_dev, b->idx_cursor_dev, w.logits, w.value)) return r;
+    // the kernel sequence (q1env_learner_set_step_mode): the fused forward + backward kernel from FUSED_MIN_BATCH samples on
+    int mode = h->learner_step_mode;
+    if (mode == 0) mode = mb >= FUSED_MIN_BATCH ? 3 : 1;
+    if (mode == 1)
+        if (int r = launch_forward(h, w, mb, pi, vf, b->obs_dev, b->idx_dev, b->idx_cursor_dev, w.logits, w.value)) return r;
     const float scale = (float)mb * learner_pi_upscale(h), scale_v = (float)mb / learner_value_downscale(h);
     q1learn::LossArgs la{};
     la.p = h->p;
@@ -324,10 +368,14 @@ int q1env_learner_sgd_step(q1env_t* h, const q1env_learner_net* pi, const q1env_
     char* st = (char*)adam_state_dev;
     const q1learn::BcArgs bca{(const long long*)st, (float*)(st + 8), beta1, beta2};
     unsigned rows = 0;
-    if (int r = launch_backward(h, w, mb, splits, pi, vf, b->obs_dev, b->idx_dev, b->idx_cursor_dev, nullptr, nullptr, scale, scale_v, false, b->saturation_dev, &la,
-                                &bca, &rows))
-        return r;
-    return launch_adam(h, pi, vf, ws_dev, mb, splits, (float)mb, lr, beta1, beta2, eps, adam_state_dev, w.stats_rows, true, (int)rows);
+    if (mode == 1) {
+        if (int r = launch_backward(h, w, mb, splits, pi, vf, b->obs_dev, b->idx_dev, b->idx_cursor_dev, nullptr, nullptr, scale, scale_v, false, b->saturation_dev, &la,
+                                    &bca, &rows))
+            return r;
+    } else {
+        if (int r = launch_fwdbwd(h, w, mb, splits, pi, vf, b->obs_dev, b->idx_dev, b->idx_cursor_dev, b->saturation_dev, la, bca, mode == 3, &rows)) return r;
+    }
+    return launch_adam(h, pi, vf, ws_dev, mb, splits, (float)mb, lr, beta1, beta2, eps, adam_state_dev, w.stats_rows, true, (int)rows, mode == 3);
 }
 
 }  // extern "C"

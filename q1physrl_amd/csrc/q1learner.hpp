@@ -595,6 +595,8 @@ struct WgNet {
     // N-format copies of them (67 MB of the step's 514)
     const f16x8* dz2N; const f16x8* dz1N; const f16x8* h1T; const f16x8* h2T; const f16x8* xN; const f16x8* dyN;
     float* partial;           // float[splits][PARTIAL_STRIDE]
+    const float* dw1p;        // DW1 (round 6, q1learner_fused.hpp): float[tile][unit tile 8][lane 32][reg 8], the per-tile products [x | 1]^T dZ1 the fused
+                              // forward + backward kernel leaves instead of dZ1 itself (dz1N is then never read)
 };
 
 // One workgroup = four waves = four of the eight 32-unit row tiles of the gradient side (blockIdx.z picks the half); it owns a contiguous
@@ -603,15 +605,23 @@ struct WgNet {
 // is a plain 16-byte-per-lane streaming load in MFMA layout (the backward kernel has done all gathering and transposing); the next
 // tile's operands are requested before the current tile's MFMAs (register double buffer).  It leaves its float32 partial sums in
 // its split's slot.
-struct WgOps { f16x8 a2[2], s0[2], s1[2], x[2], b[4][2]; };     // dZ2 rows | y=0: dZ1 rows, [x|1]  y=1: dY, h2 cols, [x|1] | h1 column tiles
+struct WgOps { f16x8 a2[2], s0[2], s1[2], x[2], b[4][2]; float4 p[2]; };     // dZ2 rows | y=0: dZ1 rows (DW1: the tile's dW1 products in p), [x|1]  y=1: dY, h2 cols, [x|1] | h1 column tiles
 
-template <int KHALF>
+template <int KHALF, bool DW1>
 __device__ __forceinline__ void wg_load(WgOps& o, const WgNet& net, uint32_t tile, uint32_t lane, uint32_t w) {
     const size_t tb = (size_t)tile * TILE_VECS + lane, sb = (size_t)tile * 128u + lane;
+    if constexpr (KHALF == 0 && DW1) {
+        // 32 x 7 float32 products of the tile (registers 0..6 of lanes 0..31 in the C / D layout of [x | 1]^T dZ1); the upper lanes re-read the lower lanes' (unused)
+        const float4* q = reinterpret_cast<const float4*>(net.dw1p + ((size_t)tile * 8u + w) * 256u + (size_t)(lane & 31u) * 8u);
+        o.p[0] = q[0]; o.p[1] = q[1];
+    }
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
         o.a2[ks] = net.dz2N[tb + (2u * w + (uint32_t)ks) * 64u];
-        if constexpr (KHALF == 0) { o.s0[ks] = net.dz1N[tb + (2u * w + (uint32_t)ks) * 64u]; o.s1[ks] = net.xN[sb + 64u * (uint32_t)ks]; }
+        if constexpr (KHALF == 0) {
+            if constexpr (!DW1) o.s0[ks] = net.dz1N[tb + (2u * w + (uint32_t)ks) * 64u];
+            o.s1[ks] = net.xN[sb + 64u * (uint32_t)ks];
+        }
         // (h2 / h1: T-format vectors u = ks of the unit tile - the same addressing as an N-format array; transposed by wg_transpose)
         else { o.s0[ks] = net.dyN[sb + 64u * (uint32_t)ks]; o.s1[ks] = net.h2T[tb + (2u * w + (uint32_t)ks) * 64u]; o.x[ks] = net.xN[sb + 64u * (uint32_t)ks]; }
 #pragma unroll
@@ -634,7 +644,7 @@ __device__ __forceinline__ void wg_transpose(f16x8 (&v)[2], const f16x8 e0, cons
 // its CU's register file: 4 x 56..64 operand registers + 96 accumulators), and the body is straight-line - KHALF is a template
 // argument, the db3 product (dY x [x | 1]) is computed by every wave of the y = 1 half and stored by one - so that the compiler's
 // s_waitcnt are counts, not drains (the first version's in-loop direct load for that product drained the queue every tile).
-template <int KHALF>
+template <int KHALF, bool DW1>
 __device__ __forceinline__ void wg_loop(const WgNet& net, uint32_t t_begin, uint32_t t_end, uint32_t lane, uint32_t w, f32x16 aW2[4], f32x16& aX, f32x16& aY) {
     constexpr int D = Q1_WGRAD_DEPTH;
     WgOps ring[D];
@@ -650,13 +660,13 @@ __device__ __forceinline__ void wg_loop(const WgNet& net, uint32_t t_begin, uint
         }
     }
 #pragma unroll
-    for (int d = 0; d < D - 1; ++d) wg_load<KHALF>(ring[d], net, min(t_begin + (uint32_t)d, t_end - 1u), lane, w);
+    for (int d = 0; d < D - 1; ++d) wg_load<KHALF, DW1>(ring[d], net, min(t_begin + (uint32_t)d, t_end - 1u), lane, w);
     for (uint32_t tile0 = t_begin; tile0 < t_end; tile0 += (uint32_t)D) {
 #pragma unroll
         for (int j = 0; j < D; ++j) {
             const uint32_t tile = tile0 + (uint32_t)j;
             if (tile >= t_end) return;                                             // wave-uniform
-            wg_load<KHALF>(ring[(j + D - 1) % D], net, min(tile + (uint32_t)(D - 1), t_end - 1u), lane, w);   // (past the end: re-requests the last tile, harmless)
+            wg_load<KHALF, DW1>(ring[(j + D - 1) % D], net, min(tile + (uint32_t)(D - 1), t_end - 1u), lane, w);   // (past the end: re-requests the last tile, harmless)
             __builtin_amdgcn_sched_barrier(0);                                     // the requests go out HERE, not next to their uses
             WgOps& cur = ring[j];
 #pragma unroll
@@ -670,17 +680,23 @@ __device__ __forceinline__ void wg_loop(const WgNet& net, uint32_t t_begin, uint
             for (int ks = 0; ks < 2; ++ks) {
                 if constexpr (KHALF == 0) {
                     aX = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur.a2[ks], cur.s1[ks], aX, 0, 0, 0);
-                    aY = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur.s0[ks], cur.s1[ks], aY, 0, 0, 0);
+                    if constexpr (!DW1) aY = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur.s0[ks], cur.s1[ks], aY, 0, 0, 0);
                 } else {
                     aX = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur.s0[ks], cur.s1[ks], aX, 0, 0, 0);
                     aY = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur.s0[ks], cur.x[ks], aY, 0, 0, 0);
                 }
+            }
+            if constexpr (KHALF == 0 && DW1) {                                       // the tile's dW1 / db1 products, added in tile order
+                aY[0] += cur.p[0].x; aY[1] += cur.p[0].y; aY[2] += cur.p[0].z; aY[3] += cur.p[0].w;
+                aY[4] += cur.p[1].x; aY[5] += cur.p[1].y; aY[6] += cur.p[1].z; aY[7] += cur.p[1].w;
             }
             __builtin_amdgcn_sched_barrier(0);
         }
     }
 }
 
+// DW1: products 72..79 of the slab hold [x | 1]^T dZ1 (rows = inputs: registers 0..6 of lanes 0..31; slot_of(.., dw1 = true)) instead of dZ1^T [x | 1]
+template <bool DW1>
 __global__ void __launch_bounds__(256, 1)
 learner_wgrad_kernel(int n, WgNet net_a, WgNet net_b, int splits) {
     const bool second = blockIdx.x >= (uint32_t)splits;
@@ -695,8 +711,8 @@ learner_wgrad_kernel(int n, WgNet net_a, WgNet net_b, int splits) {
     f32x16 aW2[4], aX = zero16, aY = zero16;          // y = 0: aX = dZ2 x [x|1], aY = dZ1 x [x|1];  y = 1: aX = dY x h2, aY = dY x [x|1] (kept by wave 0)
 #pragma unroll
     for (int k = 0; k < 4; ++k) aW2[k] = zero16;
-    if (khalf == 0) wg_loop<0>(net, t_begin, t_end, lane, w, aW2, aX, aY);
-    else wg_loop<1>(net, t_begin, t_end, lane, w, aW2, aX, aY);
+    if (khalf == 0) wg_loop<0, DW1>(net, t_begin, t_end, lane, w, aW2, aX, aY);
+    else wg_loop<1, DW1>(net, t_begin, t_end, lane, w, aW2, aX, aY);
     float* out = net.partial + (size_t)split * PARTIAL_STRIDE;
     auto put = [&](uint32_t p, const f32x16& a) {
 #pragma unroll
@@ -727,7 +743,7 @@ struct Grads {
 // parameter a slot holds; slots that belong to none (columns of the [x | 1] products that only the bias gradients use, output rows beyond
 // out_dim) retire.
 struct Slot { int arr; uint32_t i, e, x, y; };     // arr: 0 w2[x][y], 1 b2, 2 w1, 3 b1, 4 w3[x][y], 5 b3, -1 none; i = index in arr, e = flat index [w2|b2|w1|b1|w3|b3]
-__device__ __forceinline__ Slot slot_of(uint32_t off, uint32_t OUT) {
+__device__ __forceinline__ Slot slot_of(uint32_t off, uint32_t OUT, bool dw1 = false) {
     const uint32_t nW2 = 65536u, nB2 = 256u, nW1 = 256u * (uint32_t)OBS, nB1 = 256u, nW3 = OUT * 256u;
     const uint32_t p = off >> 10, r = (off >> 6) & 15u, ln = off & 63u, h = ln >> 5, cb = ln & 31u;
     const uint32_t ia = (r & 3u) + 4u * h + 8u * (r >> 2);
@@ -738,9 +754,11 @@ __device__ __forceinline__ Slot slot_of(uint32_t off, uint32_t OUT) {
     } else if (p < 72u) {
         if (ub == (uint32_t)OBS) { s.arr = 1; s.i = 32u * (p - 64u) + ua; s.e = nW2 + s.i; }
     } else if (p < 80u) {
-        const uint32_t k = 32u * (p - 72u) + ua;
-        if (ub < (uint32_t)OBS) { s.arr = 2; s.i = k * (uint32_t)OBS + ub; s.e = nW2 + nB2 + s.i; }
-        else if (ub == (uint32_t)OBS) { s.arr = 3; s.i = k; s.e = nW2 + nB2 + nW1 + k; }
+        // (dw1: the transposed product of the fused forward + backward kernel - register r of a half-0 lane = input r, lane = unit sigma(cb))
+        const uint32_t k = 32u * (p - 72u) + (dw1 ? ub : ua);
+        const uint32_t in = dw1 ? (h == 0u ? r : 32u) : ub;
+        if (in < (uint32_t)OBS) { s.arr = 2; s.i = k * (uint32_t)OBS + in; s.e = nW2 + nB2 + s.i; }
+        else if (in == (uint32_t)OBS) { s.arr = 3; s.i = k; s.e = nW2 + nB2 + nW1 + k; }
     } else if (p < 88u) {
         if (ia < OUT) { s.x = ia; s.y = 32u * (p - 80u) + ub; s.arr = 4; s.i = s.x * 256u + s.y; s.e = nW2 + nB2 + nW1 + nB1 + s.i; }
     } else if (p == 88u) {
@@ -768,14 +786,15 @@ __device__ __forceinline__ float* slot_ptr(const Slot& s, float* w2, float* b2, 
 }
 
 __global__ void __launch_bounds__(256)
-learner_reduce_kernel(const float* __restrict__ pa, const float* __restrict__ pb, Grads ga, Grads gb, int splits, float inv_scale_a, float inv_scale_b) {
+learner_reduce_kernel(const float* __restrict__ pa, const float* __restrict__ pb, Grads ga, Grads gb, int splits, float inv_scale_a, float inv_scale_b,
+                      int dw1 = 0) {
     const bool second = blockIdx.y == 1;
     const float inv_scale = second ? inv_scale_b : inv_scale_a;
     const float* __restrict__ partial = second ? pb : pa;
     const Grads g = second ? gb : ga;
     const uint32_t off = blockIdx.x * blockDim.x + threadIdx.x;
     if (off >= (uint32_t)PARTIAL_FLOATS) return;
-    const Slot sl = slot_of(off, (uint32_t)g.out_dim);
+    const Slot sl = slot_of(off, (uint32_t)g.out_dim, dw1 != 0);
     if (sl.arr < 0) return;
     *slot_ptr(sl, g.w2, g.b2, g.w1, g.b1, g.w3, g.b3) = inv_scale * slab_sum(partial, splits, off);
 }
@@ -841,6 +860,7 @@ __device__ __forceinline__ float adam_update(float w, float g, float& m, float& 
 struct AdamTick {
     long long* step; long long* idx_cursor; long long minibatch;
     const float* stats_rows; int nrows; float inv_batch; float* stats_acc;
+    int dw1;                  // the slab's products 72..79 are in the fused kernel's orientation (slot_of)
 };
 
 __global__ void __launch_bounds__(256)
@@ -870,7 +890,7 @@ learner_adam_kernel(const float* __restrict__ pa, const float* __restrict__ pb, 
     const AdamNet net = second ? nb : na;
     const uint32_t off = blockIdx.x * blockDim.x + threadIdx.x;
     if (off >= (uint32_t)PARTIAL_FLOATS) return;
-    const Slot sl = slot_of(off, (uint32_t)net.g.out_dim);
+    const Slot sl = slot_of(off, (uint32_t)net.g.out_dim, tk.dw1 != 0);
     if (sl.arr < 0) return;
     float* const wp = slot_ptr(sl, net.w2, net.b2, net.w1, net.b1, net.w3, net.b3);
     float* const gp = slot_ptr(sl, net.g.w2, net.g.b2, net.g.w1, net.g.b1, net.g.w3, net.g.b3);

@@ -184,9 +184,11 @@ __device__ __forceinline__ void stage_net(unsigned char* lds, const float* __res
 // STORE (the learner's forward, q1learner.hpp): the activations leave as they are consumed - h1_dst / h2_dst point at THIS lane's slot
 // of the tile's T-format arrays (f16x8 units; element (t, u) at [(2 t + u) * 64]): tanh(H1) / tanh(H2) as the very B operands the next
 // layer's MFMAs read, 32 fully coalesced 16-byte stores per layer and tile.
-template <bool STORE>
+// KEEP (the fused forward + backward kernel of the learner, q1learner_fused.hpp): tanh(H2) additionally stays with the caller, in h2k[t][u] - the
+// operand vectors the data-gradient phase multiplies by (1 - h2^2) a few microseconds later, without a trip through memory.
+template <bool STORE, bool KEEP = false>
 __device__ __forceinline__ f32x16 mlp_tile_t(const f16x8 xb, const unsigned char* w1row, const unsigned char* wrow, const unsigned char* w3row,
-                                             const float* l_b2, uint32_t half, uint64_t* stamps, f16x8* h1_dst, f16x8* h2_dst) {
+                                             const float* l_b2, uint32_t half, uint64_t* stamps, f16x8* h1_dst, f16x8* h2_dst, f16x8 (*h2k)[2] = nullptr) {
     const f32x16 zero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     f32x16 acc[8];                                               // H2^T pre-activations, start at b2
 #pragma unroll
@@ -259,6 +261,7 @@ __device__ __forceinline__ f32x16 mlp_tile_t(const f16x8 xb, const unsigned char
     for (int t2 = 0; t2 < 8; ++t2) {
         const f16x8 f0 = activate(acc[t2], 0), f1 = activate(acc[t2], 1);
         if constexpr (STORE) { h2_dst[(2 * t2) * 64] = f0; h2_dst[(2 * t2 + 1) * 64] = f1; }
+        if constexpr (KEEP) { h2k[t2][0] = f0; h2k[t2][1] = f1; }
         y = __builtin_amdgcn_mfma_f32_32x32x16_f16(w3a, f0, y, 0, 0, 0);
         y = __builtin_amdgcn_mfma_f32_32x32x16_f16(w3b, f1, y, 0, 0, 0);
         if (t2 < 7) {

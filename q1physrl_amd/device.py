@@ -296,6 +296,13 @@ class DeviceEnv:
         "census_fail" (tests: automatic, with a census made to disagree).  include/q1env.h."""
         _lib.check(self._lib.q1env_learner_set_exchange_mode(self._h, self.EXCHANGE_MODES[mode] if isinstance(mode, str) else int(mode)))
 
+    STEP_MODES = {"auto": 0, "four_launch": 1, "fused": 2, "fused_dw1": 3}
+
+    def learner_set_step_mode(self, mode):
+        """Kernel sequence of q1env_learner_sgd_step on this handle: "auto" (fused forward + backward kernel from 2 048 samples on), "four_launch"
+        (round 4's path), "fused" (bit-identical to it), "fused_dw1" (dZ1 replaced by its per-tile products).  include/q1env.h."""
+        _lib.check(self._lib.q1env_learner_set_step_mode(self._h, self.STEP_MODES[mode] if isinstance(mode, str) else int(mode)))
+
     def learner_set_profiling(self, wave_of_group=-1):
         _lib.check(self._lib.q1env_learner_set_profiling(self._h, int(wave_of_group)))
 

@@ -353,6 +353,70 @@ def test_sgd_step_equals_step_plus_adam(mb, n_envs, over):
     env.close()
 
 
+@pytest.mark.parametrize("mb,n_envs,horizon", [(4096, 2048, 8), (1000, 500, 8), (128, 64, 8), (2048 + 32 * 5 + 7, 1024, 8), (32768, 8192, 8)])
+def test_fused_forward_backward_step_against_the_four_launch_step(mb, n_envs, horizon):
+    """q1env_learner_sgd_step's kernel sequences (round 6, q1env_learner_set_step_mode; csrc/q1learner_fused.hpp): forward + loss gradient + data
+    gradients as ONE kernel.  "fused" must reproduce the four-launch step BIT FOR BIT - masters, gradients, moments, weight images,
+    saturation counters - over several steps (the same arithmetic, only the activations' trip through memory is gone); "fused_dw1" (dZ1 replaced
+    by per-tile products with [x | 1]) the same bits for every tensor but W1 / b1 of both networks, which differ by float32 summation order.
+    Sizes: whole workgroups, a ragged last tile, fewer tiles than one workgroup has waves, a tile count that is no multiple of eight, and the
+    large-minibatch configuration's 32 768."""
+    import torch
+    from q1physrl_amd import policy as P, ppo, sampler as S
+    torch.manual_seed(4)
+    cfg, env = make_env(n_envs, time_limit=1.0)
+    pols = [_policy(5, 2.0)]
+    pols += [copy.deepcopy(pols[0]), copy.deepcopy(pols[0])]
+    smp = S.GpuSampler(env, P.FusedPolicyForward(pols[0], env), horizon=horizon)
+    tr = smp.collect()
+    adv, vt = smp.advantages(tr, 0.99, 0.95)
+    t, n = tr["reward"].shape
+    total = t * n
+    full = {"obs": tr["obs"][:t].reshape(total, 6).contiguous(), "old_logits": tr["logits"].reshape(total, -1).contiguous(),
+            "keys_packed": tr["keys"].reshape(-1), "mouse": tr["mouse"].reshape(-1), "logp": tr["logp"].reshape(-1),
+            "adv": ((adv - adv.mean()) / adv.std()).reshape(-1).contiguous(), "value": tr["value"][:t].reshape(-1).contiguous(),
+            "vtarg": vt.reshape(-1).contiguous()}
+    klc = torch.tensor(0.2, device="cuda")
+    perm = torch.randperm(total, device="cuda")
+    modes = ["four_launch", "fused", "fused_dw1"]
+    nats = [ppo.NativeStep(p, env, mb, splits=8) for p in pols]
+    hp = (3e-4, (0.9, 0.999), 1e-8)
+    n_steps = min(total // mb, 4)
+    assert n_steps >= 1
+    for k in range(n_steps):
+        for mode, nat in zip(modes, nats):
+            env._dev.learner_set_step_mode(mode)
+            nat.step(full, perm, 0.3, 10.0, 1.0, 0.01, klc, skip_reduce=True, use_cursor=True, adam=hp)
+        torch.cuda.synchronize()
+        a, b, c = nats
+        for (name, p), q in zip(pols[0].named_parameters(), pols[1].parameters()):
+            assert torch.equal(p, q) and torch.equal(p.grad, q.grad), (k, name)
+        assert torch.equal(a.adam_state[:16], b.adam_state[:16]) and torch.equal(a.adam_state[72:80], b.adam_state[72:80])
+        assert torch.equal(a.adam_state[256:], b.adam_state[256:]), k
+        assert torch.equal(a.saturation, b.saturation) and torch.equal(a.saturation, c.saturation)
+        sa, sb, sc = (x.stats_acc.cpu().numpy() for x in nats)
+        assert np.allclose(sa, sb, rtol=2e-5, atol=1e-6) and np.array_equal(sb, sc), (k, sa, sb, sc)
+        if k == 0:
+            # the first step starts from identical weights: every gradient but dW1 / db1 is the same bits, those agree to summation order
+            for (name, p), q in zip(pols[0].named_parameters(), pols[2].parameters()):
+                first_layer = name.split(".")[1] == "0"
+                if first_layer:
+                    assert _rel(q.grad, p.grad) < 2e-6, (name, _rel(q.grad, p.grad))
+                    assert not torch.isnan(q.grad).any()
+                else:
+                    assert torch.equal(p.grad, q.grad), name
+        else:
+            for (name, p), q in zip(pols[0].named_parameters(), pols[2].parameters()):
+                # (Adam's first steps move every element by ~lr whatever its gradient's size: an element of dW1 whose last bits differ around
+                # zero may move the other way - bounded by a few lr per element)
+                assert _rel(q, p) < 1e-3 and _rel(q.grad, p.grad) < 1e-2, (k, name, _rel(q, p), _rel(q.grad, p.grad))
+    env._dev.learner_set_step_mode("auto")
+    assert int(nats[1].cursor.item()) == n_steps * mb and int(nats[2].adam_state[:8].view(torch.int64)[0]) == n_steps
+    with pytest.raises(Exception):
+        env._dev.learner_set_step_mode(4)
+    env.close()
+
+
 def test_native_training_learns_strafe_jumping_in_seconds():
     """End-to-end regression of the whole GPU-resident stack (resident sampler + native learner, round 2's hyper-parameters): 200
     iterations = 0.42 G env-steps in ~17 s must take the zero-start reward from ~1 700 (plain running) past 4 200 - strafe-jumping

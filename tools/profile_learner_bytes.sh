@@ -4,11 +4,12 @@
 # calibrated on calib_copy_kernel in tools/profile_round.sh).  VERDICT r3 item 4 asked for bytes per step next to time.
 set -u
 TAG=${1:-r4}
+MODE=${2:-auto}          # q1env_learner_sgd_step's kernel sequence: auto | four_launch | fused | fused_dw1
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
-OUT=gpurun_out/prof_learner_bytes_$TAG
+OUT=gpurun_out/prof_learner_bytes_${TAG}_$MODE
 mkdir -p $OUT
-CMD="python tools/time_learner.py --phase step --steps 40"
+CMD="python tools/time_learner.py --phase step --steps 40 --step-mode $MODE"
 $CMD > $OUT/unprofiled.json 2> $OUT/unprofiled.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o t -- $CMD > /dev/null 2> $OUT/trace.err
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/fetch -o t -- $CMD > /dev/null 2> $OUT/fetch.err

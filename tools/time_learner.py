@@ -16,6 +16,8 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--splits", type=int, default=32)
     ap.add_argument("--phase", default="all", choices=["all", "forward", "backward", "step"])
+    ap.add_argument("--step-mode", default="auto", choices=["auto", "four_launch", "fused", "fused_dw1"],
+                    help="kernel sequence of q1env_learner_sgd_step (include/q1env.h q1env_learner_set_step_mode)")
     ap.add_argument("--two-call", action="store_true", help="the step as q1env_learner_step + q1env_learner_adam instead of q1env_learner_sgd_step")
     args = ap.parse_args()
     import torch
@@ -23,6 +25,7 @@ def main():
     from q1physrl_amd.tensor_env import TensorVectorEnv
     from q1physrl_amd.env import Config
     env = TensorVectorEnv(Config(**dict(Config.get_default().__dict__, num_envs=256)), device=0, seed=1)
+    env._dev.learner_set_step_mode(args.step_mode)
     torch.manual_seed(0)
     pol = P.Q1Policy().cuda()
     mb = args.mb
@@ -50,7 +53,7 @@ def main():
 
     host_us = []
 
-    out = {"mb": mb, "splits": args.splits, "steps": args.steps}
+    out = {"mb": mb, "splits": args.splits, "steps": args.steps, "step_mode": args.step_mode}
     if args.phase in ("all", "forward"):
         out["forward_us"] = timed(lambda: nat.forward(obs, idx), args.steps)
     if args.phase in ("all", "backward"):
