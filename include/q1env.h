@@ -460,10 +460,11 @@ int q1env_learner_sgd_step(q1env_t* env, const q1env_learner_net* pi, const q1en
                            const q1env_learner_batch* batch, float lr, float beta1, float beta2, float eps, void* adam_state_dev);
 /* (ABI v6) The kernel sequence of q1env_learner_sgd_step for the reference's action structure (csrc/q1learner_fused.hpp).  0 = automatic
  * (default): from 2 048 samples on, forward + PPO loss gradient + data gradients run as ONE kernel - the float16 activations are consumed where
- * they are produced instead of travelling through memory between two launches, and dZ1 is replaced by its 256 x 7 product with [x | 1] per
- * 32-sample tile (mode 3); smaller minibatches keep round 4's four launches (mode 1).  2 = the fused kernel with dZ1 stored as before: every
- * result bit-identical to mode 1 (what the tests hold the fused kernel to).  Mode 3 differs from 1 / 2 in dW1 / db1 only, by float32 summation
- * order (per-tile products added in tile order instead of one accumulation chain).  Three launches per step instead of four.  The workspace
+ * they are produced instead of travelling through memory between two launches, and dZ1 and tanh(H2) - which the weight-gradient kernel needs
+ * only for the 256 x 7 and out x 256 products dW1 / db1 and dW3 - are replaced by those products per 32-sample tile (mode 3); smaller minibatches
+ * keep round 4's four launches (mode 1).  2 = the fused kernel with dZ1 and tanh(H2) stored as before: every result bit-identical to mode 1 (what the
+ * tests hold the fused kernel to).  Mode 3 differs from 1 / 2 in dW1, db1 and dW3 only, by float32 summation order (per-tile products added in
+ * tile order instead of one accumulation chain).  Three launches per step instead of four.  The workspace
  * is the same for every mode; a captured graph bakes the mode in. */
 int q1env_learner_set_step_mode(q1env_t* env, int mode);
 

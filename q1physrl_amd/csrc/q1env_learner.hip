@@ -34,6 +34,7 @@ struct NetWs {
     q1learn::f16x8* xN; q1learn::f16x8* dyN;
     float* partial;
     float* dw1p;                  // the fused forward + backward kernel's per-tile dW1 / db1 products (q1learner_fused.hpp, DW1)
+    float4* dw3a; float* dw3b;    // ... and its per-tile dW3 products (dw3a: the policy network only)
 };
 struct Ws {
     NetWs net[2];
@@ -61,6 +62,8 @@ Ws carve_ws(void* base, int64_t mb, int out_pi, int splits) {
     w.dlogits = (float*)take((size_t)mb * out_pi * 4u); w.dvalue = (float*)take((size_t)mb * 4u);
     w.stats_rows = (float*)take(STATS_ROWS * 5u * 4u);
     for (int k = 0; k < 2; ++k) w.net[k].dw1p = (float*)take(tiles * q1learn::DW1_TILE_FLOATS * 4u);      // (behind everything round 4 laid out)
+    w.net[0].dw3a = (float4*)take(tiles * 8u * 64u * 16u); w.net[1].dw3a = (float4*)take(256);      // (value network: a dummy the kernel's branch-free store hits)
+    for (int k = 0; k < 2; ++k) w.net[k].dw3b = (float*)take(tiles * 8u * 64u * 4u);
     w.bytes = off;
     return w;
 }
@@ -128,8 +131,8 @@ int launch_backward(q1env* h, const Ws& w, int64_t mb, int splits, const q1env_l
     else
         hipLaunchKernelGGL(q1learn::learner_backward_kernel<false>, dim3(blocks * 2u), dim3(256), q1learn::LDS_BWD, h->stream, (int)mb, obs, idx, idx_cursor, ba,
                            bb, 2, q1learn::LossArgs{}, q1learn::BcArgs{nullptr, nullptr, 0.0f, 0.0f});
-    const q1learn::WgNet wa{w.net[0].dz2N, w.net[0].dz1N, w.net[0].h1T, w.net[0].h2T, w.net[0].xN, w.net[0].dyN, w.net[0].partial, nullptr};
-    const q1learn::WgNet wb{w.net[1].dz2N, w.net[1].dz1N, w.net[1].h1T, w.net[1].h2T, w.net[1].xN, w.net[1].dyN, w.net[1].partial, nullptr};
+    const q1learn::WgNet wa{w.net[0].dz2N, w.net[0].dz1N, w.net[0].h1T, w.net[0].h2T, w.net[0].xN, w.net[0].dyN, w.net[0].partial, nullptr, nullptr, nullptr};
+    const q1learn::WgNet wb{w.net[1].dz2N, w.net[1].dz1N, w.net[1].h1T, w.net[1].h2T, w.net[1].xN, w.net[1].dyN, w.net[1].partial, nullptr, nullptr, nullptr};
     hipLaunchKernelGGL(q1learn::learner_wgrad_kernel<false>, dim3(2u * (unsigned)splits, 2, 2), dim3(256), 0, h->stream, (int)mb, wa, wb, splits);
     if (!reduce) { HIP_TRY(hipGetLastError()); return 0; }          // q1env_learner_adam sums the partials itself
     const q1learn::Grads ga{pi->gw1, pi->gb1, pi->gw2, pi->gb2, pi->gw3, pi->gb3, pi->out_dim};
@@ -147,17 +150,20 @@ int launch_fwdbwd(q1env* h, const Ws& w, int64_t mb, int splits, const q1env_lea
                   const int64_t* idx_cursor, uint32_t* sat, const q1learn::LossArgs& la, const q1learn::BcArgs& bca, bool dw1, unsigned* grid_out) {
     if (int r = ensure_learner_attrs(h)) return r;
     const q1learn::FzNet fa{pi->w1, pi->b1, w.net[0].w23, pi->b2, pi->b3, w.net[0].w2t, w.net[0].w3t, w.net[0].h1T, w.net[0].h2T,
-                            w.net[0].dz2N, w.net[0].dz1N, w.net[0].xN, w.net[0].dyN, w.net[0].dw1p, sat};
+                            w.net[0].dz2N, w.net[0].dz1N, w.net[0].xN, w.net[0].dyN, w.net[0].dw1p, w.net[0].dw3a, w.net[0].dw3b, sat};
     const q1learn::FzNet fb{vf->w1, vf->b1, w.net[1].w23, vf->b2, vf->b3, w.net[1].w2t, w.net[1].w3t, w.net[1].h1T, w.net[1].h2T,
-                            w.net[1].dz2N, w.net[1].dz1N, w.net[1].xN, w.net[1].dyN, w.net[1].dw1p, sat ? sat + 2 : nullptr};
+                            w.net[1].dz2N, w.net[1].dz1N, w.net[1].xN, w.net[1].dyN, w.net[1].dw1p, w.net[1].dw3a, w.net[1].dw3b, sat ? sat + 2 : nullptr};
     const unsigned tiles = (unsigned)((mb + 31) / 32);
     const unsigned blocks = (tiles + 7u) / 8u;
     if (blocks * 2u > STATS_ROWS) return fail(Q1ENV_ERR_INVALID_ARG, "learner: more workgroups than statistics rows");
     *grid_out = blocks * 2u;
-    const q1learn::WgNet wa{w.net[0].dz2N, w.net[0].dz1N, w.net[0].h1T, w.net[0].h2T, w.net[0].xN, w.net[0].dyN, w.net[0].partial, w.net[0].dw1p};
-    const q1learn::WgNet wb{w.net[1].dz2N, w.net[1].dz1N, w.net[1].h1T, w.net[1].h2T, w.net[1].xN, w.net[1].dyN, w.net[1].partial, w.net[1].dw1p};
+    const q1learn::WgNet wa{w.net[0].dz2N, w.net[0].dz1N, w.net[0].h1T, w.net[0].h2T, w.net[0].xN, w.net[0].dyN, w.net[0].partial, w.net[0].dw1p, w.net[0].dw3a, w.net[0].dw3b};
+    const q1learn::WgNet wb{w.net[1].dz2N, w.net[1].dz1N, w.net[1].h1T, w.net[1].h2T, w.net[1].xN, w.net[1].dyN, w.net[1].partial, w.net[1].dw1p, nullptr, w.net[1].dw3b};
     if (dw1) {
         hipLaunchKernelGGL(q1learn::learner_fwdbwd_kernel<true>, dim3(blocks * 2u), dim3(512), q1learn::LDS_FZ, h->stream, (int)mb, obs, idx, idx_cursor, fa, fb, la, bca);
+#if defined(Q1_FZ_STAMPS) && (Q1_FZ_EXP & 512)       // diagnostic build: the same launch once more (idempotent), so that the second one's stamps see the first one's end
+        hipLaunchKernelGGL(q1learn::learner_fwdbwd_kernel<true>, dim3(blocks * 2u), dim3(512), q1learn::LDS_FZ, h->stream, (int)mb, obs, idx, idx_cursor, fa, fb, la, bca);
+#endif
         hipLaunchKernelGGL(q1learn::learner_wgrad_kernel<true>, dim3(2u * (unsigned)splits, 2, 2), dim3(256), 0, h->stream, (int)mb, wa, wb, splits);
     } else {
         hipLaunchKernelGGL(q1learn::learner_fwdbwd_kernel<false>, dim3(blocks * 2u), dim3(512), q1learn::LDS_FZ, h->stream, (int)mb, obs, idx, idx_cursor, fa, fb, la, bca);

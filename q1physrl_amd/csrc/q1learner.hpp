@@ -176,6 +176,13 @@ struct BwdNet {
                               // clamped); max= the float32 bits of the largest |element| seen before the clamp (dY, dZ2, dZ1, scaled as they travel)
 };
 
+// saturation report of one workgroup (BwdNet::sat): the count is added when there is one, the maximum is published only when it raises the word
+// (the plain read may be stale - the atomic max decides; in the steady state of a training run almost no workgroup issues an atomic at all)
+__device__ __forceinline__ void sat_report(uint32_t* sat, uint32_t count, uint32_t max_bits) {
+    if (count) atomicAdd(sat, count);
+    if (max_bits > *reinterpret_cast<volatile uint32_t*>(sat + 1)) atomicMax(sat + 1, max_bits);
+}
+
 template <uint32_t THREADS, uint32_t NVEC>
 struct StageRegs { uint4 v[(NVEC + THREADS - 1u) / THREADS]; };
 
@@ -575,16 +582,19 @@ learner_backward_kernel(int n, const float* __restrict__ obs, const int64_t* __r
         __syncthreads();
         if (tid < 5u) la.stats_rows[(size_t)blockIdx.x * 5u + tid] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
     }
-    // saturation report: one pair of fire-and-forget atomics per wave (NaN gradients compare false and show up as NaN in the max)
+    // saturation report: one per WORKGROUP (round 6: per wave it was 2 x 1 024 atomics on two words per launch, executed one after the other by the
+    // memory side while the dispatch waited - see q1learner_fused.hpp)
     if (net.sat) {
+        __shared__ uint32_t red_sat[4][2];
         const uint64_t over = __ballot(amax > 65504.0f);
         float wmax = amax;
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) wmax = fmaxf(wmax, __shfl_xor(wmax, off));
-        if (lane == 0) {
-            if (over) atomicAdd(net.sat, (uint32_t)__popcll(over));
-            atomicMax(net.sat + 1, __float_as_uint(wmax));
-        }
+        if (lane == 0) { red_sat[wave][0] = (uint32_t)__popcll(over); red_sat[wave][1] = __float_as_uint(wmax); }
+        __syncthreads();
+        if (tid == 0)
+            sat_report(net.sat, (red_sat[0][0] + red_sat[1][0]) + (red_sat[2][0] + red_sat[3][0]),
+                       max(max(red_sat[0][1], red_sat[1][1]), max(red_sat[2][1], red_sat[3][1])));
     }
 }
 
@@ -597,6 +607,9 @@ struct WgNet {
     float* partial;           // float[splits][PARTIAL_STRIDE]
     const float* dw1p;        // DW1 (round 6, q1learner_fused.hpp): float[tile][unit tile 8][lane 32][reg 8], the per-tile products [x | 1]^T dZ1 the fused
                               // forward + backward kernel leaves instead of dZ1 itself (dz1N is then never read)
+    const float4* dw3a;       // DW1: float4[tile][unit tile 8][lane 64], rows 0..7 of the per-tile products dY^T h2 (policy network; NULL for a one-output network)
+    const float* dw3b;        // DW1: float[tile][unit tile 8][lane 64]: row 8 / 12 (outputs 8, 9) of the same products - or row 0 of a one-output network's
+                              // (h2T is then never read)
 };
 
 // One workgroup = four waves = four of the eight 32-unit row tiles of the gradient side (blockIdx.z picks the half); it owns a contiguous
@@ -605,11 +618,16 @@ struct WgNet {
 // is a plain 16-byte-per-lane streaming load in MFMA layout (the backward kernel has done all gathering and transposing); the next
 // tile's operands are requested before the current tile's MFMAs (register double buffer).  It leaves its float32 partial sums in
 // its split's slot.
-struct WgOps { f16x8 a2[2], s0[2], s1[2], x[2], b[4][2]; float4 p[2]; };     // dZ2 rows | y=0: dZ1 rows (DW1: the tile's dW1 products in p), [x|1]  y=1: dY, h2 cols, [x|1] | h1 column tiles
+struct WgOps { f16x8 a2[2], s0[2], s1[2], x[2], b[4][2]; float4 p[2]; float q; };     // dZ2 rows | y=0: dZ1 rows (DW1: the tile's dW1 products in p), [x|1]  y=1: dY, h2 cols, [x|1] | h1 column tiles
 
 template <int KHALF, bool DW1>
 __device__ __forceinline__ void wg_load(WgOps& o, const WgNet& net, uint32_t tile, uint32_t lane, uint32_t w) {
     const size_t tb = (size_t)tile * TILE_VECS + lane, sb = (size_t)tile * 128u + lane;
+    if constexpr (KHALF == 1 && DW1) {
+        const size_t pb = ((size_t)tile * 8u + w) * 64u + lane;
+        o.p[0] = net.dw3a ? net.dw3a[pb] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);       // (wave-uniform)
+        o.q = net.dw3b[pb];
+    }
     if constexpr (KHALF == 0 && DW1) {
         // 32 x 7 float32 products of the tile (registers 0..6 of lanes 0..31 in the C / D layout of [x | 1]^T dZ1); the upper lanes re-read the lower lanes' (unused)
         const float4* q = reinterpret_cast<const float4*>(net.dw1p + ((size_t)tile * 8u + w) * 256u + (size_t)(lane & 31u) * 8u);
@@ -623,7 +641,10 @@ __device__ __forceinline__ void wg_load(WgOps& o, const WgNet& net, uint32_t til
             o.s1[ks] = net.xN[sb + 64u * (uint32_t)ks];
         }
         // (h2 / h1: T-format vectors u = ks of the unit tile - the same addressing as an N-format array; transposed by wg_transpose)
-        else { o.s0[ks] = net.dyN[sb + 64u * (uint32_t)ks]; o.s1[ks] = net.h2T[tb + (2u * w + (uint32_t)ks) * 64u]; o.x[ks] = net.xN[sb + 64u * (uint32_t)ks]; }
+        else {
+            o.s0[ks] = net.dyN[sb + 64u * (uint32_t)ks]; o.x[ks] = net.xN[sb + 64u * (uint32_t)ks];
+            if constexpr (!DW1) o.s1[ks] = net.h2T[tb + (2u * w + (uint32_t)ks) * 64u];
+        }
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt) o.b[kt][ks] = net.h1T[tb + (2u * (4u * (uint32_t)KHALF + (uint32_t)kt) + (uint32_t)ks) * 64u];
     }
@@ -671,7 +692,7 @@ __device__ __forceinline__ void wg_loop(const WgNet& net, uint32_t t_begin, uint
             WgOps& cur = ring[j];
 #pragma unroll
             for (int kt = 0; kt < 4; ++kt) wg_transpose(cur.b[kt], e0, e1);          // h1 column tiles: T -> N
-            if constexpr (KHALF == 1) wg_transpose(cur.s1, e0, e1);                  // h2 tile w: T -> N
+            if constexpr (KHALF == 1 && !DW1) wg_transpose(cur.s1, e0, e1);          // h2 tile w: T -> N
 #pragma unroll
             for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
@@ -682,9 +703,13 @@ __device__ __forceinline__ void wg_loop(const WgNet& net, uint32_t t_begin, uint
                     aX = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur.a2[ks], cur.s1[ks], aX, 0, 0, 0);
                     if constexpr (!DW1) aY = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur.s0[ks], cur.s1[ks], aY, 0, 0, 0);
                 } else {
-                    aX = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur.s0[ks], cur.s1[ks], aX, 0, 0, 0);
+                    if constexpr (!DW1) aX = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur.s0[ks], cur.s1[ks], aX, 0, 0, 0);
                     aY = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur.s0[ks], cur.x[ks], aY, 0, 0, 0);
                 }
+            }
+            if constexpr (KHALF == 1 && DW1) {                                       // the tile's dW3 products (rows = outputs), added in tile order
+                aX[0] += cur.p[0].x; aX[1] += cur.p[0].y; aX[2] += cur.p[0].z; aX[3] += cur.p[0].w;
+                if (net.dw3a) aX[4] += cur.q; else aX[0] += cur.q;                   // (wave-uniform: ten outputs / one)
             }
             if constexpr (KHALF == 0 && DW1) {                                       // the tile's dW1 / db1 products, added in tile order
                 aY[0] += cur.p[0].x; aY[1] += cur.p[0].y; aY[2] += cur.p[0].z; aY[3] += cur.p[0].w;
@@ -695,7 +720,8 @@ __device__ __forceinline__ void wg_loop(const WgNet& net, uint32_t t_begin, uint
     }
 }
 
-// DW1: products 72..79 of the slab hold [x | 1]^T dZ1 (rows = inputs: registers 0..6 of lanes 0..31; slot_of(.., dw1 = true)) instead of dZ1^T [x | 1]
+// DW1: products 72..79 of the slab hold [x | 1]^T dZ1 (rows = inputs: registers 0..6 of lanes 0..31; slot_of(.., dw1 = true)) instead of dZ1^T [x | 1],
+// and output 9 of products 80..87 sits in row 12 (register 4 of the half-1 lanes) instead of row 9
 template <bool DW1>
 __global__ void __launch_bounds__(256, 1)
 learner_wgrad_kernel(int n, WgNet net_a, WgNet net_b, int splits) {
@@ -760,7 +786,9 @@ __device__ __forceinline__ Slot slot_of(uint32_t off, uint32_t OUT, bool dw1 = f
         if (in < (uint32_t)OBS) { s.arr = 2; s.i = k * (uint32_t)OBS + in; s.e = nW2 + nB2 + s.i; }
         else if (in == (uint32_t)OBS) { s.arr = 3; s.i = k; s.e = nW2 + nB2 + nW1 + k; }
     } else if (p < 88u) {
-        if (ia < OUT) { s.x = ia; s.y = 32u * (p - 80u) + ub; s.arr = 4; s.i = s.x * 256u + s.y; s.e = nW2 + nB2 + nW1 + nB1 + s.i; }
+        // (dw1: the fused kernel's per-tile products keep outputs 0..8 in rows 0..8 and output 9 in row 12 - five registers per lane)
+        const uint32_t o = dw1 ? (ia == 12u ? 9u : (ia <= 8u ? ia : 99u)) : ia;
+        if (o < OUT) { s.x = o; s.y = 32u * (p - 80u) + ub; s.arr = 4; s.i = s.x * 256u + s.y; s.e = nW2 + nB2 + nW1 + nB1 + s.i; }
     } else if (p == 88u) {
         if (ub == (uint32_t)OBS && ia < OUT) { s.arr = 5; s.i = ia; s.e = nW2 + nB2 + nW1 + nB1 + nW3 + ia; }
     }

@@ -39,8 +39,30 @@ struct FzNet {
     const uint16_t* w2t; const uint16_t* w3t;                                                  // backward images (q1learner.hpp BwdNet)
     f16x8* h1T; f16x8* h2T; f16x8* dz2N; f16x8* dz1N; f16x8* xN; f16x8* dyN;
     float* dw1p;              // DW1: float[tile][DW1_TILE_FLOATS]
+    float4* dw3a; float* dw3b;  // DW1: per-tile products dY^T h2 (q1learner.hpp WgNet): float4[tile][8][64] (rows 0..7; policy network only), float[tile][8][64]
     uint32_t* sat;
 };
+
+#ifndef Q1_FZ_EXP         // timing experiments of the diagnostic build (tools/exp_fused_stamps.py; results are WRONG with any bit set): 1 = the forward phase
+#define Q1_FZ_EXP 0       // stores nothing, 4 = hardware exp / log in the loss, 8 = neighbouring XCDs swap their tiles, 16 = the backward phase's stores are
+#endif                    // folded into a checksum instead (the arithmetic that produces them stays), 32 = ... are non-temporal, 64 / 128 / 192 = the forward phase's tanh(H1) stores are sc1 / nt / sc0 sc1,
+                          // 256 = no saturation report, 512 = every wave leaves its end time in one word (atomic max) for the next launch to read
+template <class T>
+__device__ __forceinline__ void fz_store(T* dst, const T& v, uint32_t& chk) {
+    if constexpr ((Q1_FZ_EXP & 16) != 0) {
+        union { T t; uint32_t u[sizeof(T) / 4]; } o;
+        o.t = v;
+#pragma unroll
+        for (unsigned k = 0; k < sizeof(T) / 4; ++k) chk ^= o.u[k];
+    } else if constexpr ((Q1_FZ_EXP & 32) != 0) {
+        typedef uint32_t uvec __attribute__((ext_vector_type(sizeof(T) / 4)));
+        union { T t; uvec u; } o;
+        o.t = v;
+        __builtin_nontemporal_store(o.u, reinterpret_cast<uvec*>(dst));
+    } else {
+        *dst = v;
+    }
+}
 
 template <bool DW1>
 __global__ void __launch_bounds__(512, 1)
@@ -56,11 +78,27 @@ learner_fwdbwd_kernel(int n, const float* __restrict__ obs, const int64_t* __res
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint32_t col = lane & 31u, half = lane >> 5;
     const uint32_t ntiles = ((uint32_t)n + 31u) / 32u;
+#if defined(Q1_FZ_EXP) && (Q1_FZ_EXP & 8)               // timing experiment: the workgroup on XCD x takes the tiles its neighbour on XCD x ^ 1 would have
+    const uint32_t tile = (bid ^ 1u) * 8u + wave;
+#else
     const uint32_t tile = bid * 8u + wave;
+#endif
     const bool tile_live = tile < ntiles;                     // wave-uniform; a wave without a tile still stages and meets the barriers
     const uint32_t s = tile * 32u + col;
     const bool live = tile_live && s < (uint32_t)n;
     const size_t tbase = (size_t)tile * TILE_VECS + lane;
+#ifdef Q1_FZ_STAMPS       // diagnostic build (tools/exp_fused_stamps.py): 100 MHz stamps of every wave, left in the array the mode does not use (dW1 products / dZ1)
+    const uint64_t stamp0 = wall_clock64();
+    float stamps[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    // the latest wave end of the PREVIOUS launch of this kernel (the diagnostic build launches it twice in a row): how long do the end of one dispatch and
+    // the start of the next take?
+    unsigned long long* g_last_end = reinterpret_cast<unsigned long long*>(la.stats_rows + 9000);
+    const float gap_us = (Q1_FZ_EXP & 512) ? (float)(long long)(stamp0 - *g_last_end) * 0.01f : 0.0f;
+#define Q1_FZ_STAMP(k) do { __builtin_amdgcn_sched_barrier(0); stamps[k] = (float)(wall_clock64() - stamp0) * 0.01f; __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define Q1_FZ_STAMP(k) do { } while (0)
+#endif
+    uint32_t chk = 0;
 
     // ---------------------------------------------------------------------------------------------------------------- phase F
     // the sample's observation row (both lanes of a sample's pair read all of it; six named scalars, not an array: indexed by `half` an array
@@ -89,6 +127,7 @@ learner_fwdbwd_kernel(int n, const float* __restrict__ obs, const int64_t* __res
         }
     }
     __syncthreads();
+    Q1_FZ_STAMP(0);
     f16x8 h2k[8][2];
     f32x16 y = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
@@ -100,8 +139,9 @@ learner_fwdbwd_kernel(int n, const float* __restrict__ obs, const int64_t* __res
         const unsigned char* w1row = l.w1 + (size_t)col * 32u + half * 16u;
         const unsigned char* wrow = l.w2 + (size_t)col * ROW_BYTES + half * 16u;
         const unsigned char* w3row = l.w3 + (size_t)col * ROW_BYTES + half * 16u;
-        y = mlp_tile_t<true, true>(xb, w1row, wrow, w3row, l.b2, half, nullptr, net.h1T + tbase, net.h2T + tbase, h2k);
+        y = mlp_tile_t<!(Q1_FZ_EXP & 1), true, !(Q1_FZ_EXP & 1) && !DW1, (Q1_FZ_EXP >> 6) & 3>(xb, w1row, wrow, w3row, l.b2, half, nullptr, net.h1T + tbase, net.h2T + tbase, h2k);
     }
+    Q1_FZ_STAMP(1);
 
     // ---------------------------------------------------------------------------------------------------------------- restage
     // per-sample loss inputs (the gathers that hang on src), requested before the images: half 0 fetches the key bits and the mouse action,
@@ -139,6 +179,7 @@ learner_fwdbwd_kernel(int n, const float* __restrict__ obs, const int64_t* __res
         }
     }
     __syncthreads();                                          // every wave is done with the forward image
+    Q1_FZ_STAMP(2);
     unsigned char* l_w2t = lds;
     unsigned char* l_w3c = lds + LDS_W2T;
     float (*red)[5] = reinterpret_cast<float (*)[5]>(lds + LDS_FZ_RED);
@@ -156,6 +197,7 @@ learner_fwdbwd_kernel(int n, const float* __restrict__ obs, const int64_t* __res
         *reinterpret_cast<uint4*>(l_w3c + (size_t)(tid >> 1) * W3C_ROW_BYTES + (tid & 1u) * 16u) = w3v;
     }
     __syncthreads();
+    Q1_FZ_STAMP(3);
 
     // ---------------------------------------------------------------------------------------------------------------- phase B
     float amax = 0.0f;
@@ -172,6 +214,13 @@ learner_fwdbwd_kernel(int n, const float* __restrict__ obs, const int64_t* __res
         const unsigned char* w2trow = l_w2t + (size_t)col * ROW_BYTES + half * 16u;
         const unsigned char* w3crow = l_w3c + (size_t)col * W3C_ROW_BYTES + half * 16u;
         const float klc = *la.kl_coeff_dev;
+        // ---- the wave's own h1 vectors back, requested FIRST: memory operations of a wave complete in order, so requested behind the dZ2 stores
+        //      (where they are needed) they would wait for those stores' acknowledgements - 5 .. 15 us on the XCDs whose write path is backed up
+        //      (tools/exp_fused_stamps.py)
+        f16x8 hv[8][2];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) { hv[t][0] = net.h1T[tbase + (2u * t) * 64u]; hv[t][1] = net.h1T[tbase + (2u * t + 1u) * 64u]; }
+        __builtin_amdgcn_sched_barrier(0);
         // ---- the outputs as the forward kernel would have stored them (y + b3), and the halves' gathers, swapped
         float v6[6], p6[6];
 #pragma unroll
@@ -203,7 +252,7 @@ learner_fwdbwd_kernel(int n, const float* __restrict__ obs, const int64_t* __res
 #pragma unroll
             for (int c = 0; c < 10; ++c) g[c] = 0.0f;
             const PpoSample in{tv.kb, tv.mouse, tv.logp_old, tv.adv};
-            const PpoSums ps2 = ppo_policy_grad<true, true>(la.p, tv.lg, tv.ol, in, la.clip, la.ent_coeff, klc, la.inv_b, g, 10, half);
+            const PpoSums ps2 = ppo_policy_grad<true, true, (Q1_FZ_EXP & 4) != 0>(la.p, tv.lg, tv.ol, in, la.clip, la.ent_coeff, klc, la.inv_b, g, 10, half);
             if (live && half == 0u) { st[0] += ps2.ent; st[1] += ps2.kl; st[2] += -ps2.surr; st[3] += -ps2.surr + klc * ps2.kl - la.ent_coeff * ps2.ent; }
 #pragma unroll
             for (int e = 0; e < 8; ++e) y0[e] = live ? (half ? (e < 2 ? g[8 + e] : 0.0f) : g[e]) : 0.0f;
@@ -219,6 +268,15 @@ learner_fwdbwd_kernel(int n, const float* __restrict__ obs, const int64_t* __res
             amax = fmaxf(fabsf(y0[e]), amax);
             dyb0[e] = (_Float16)fminf(fmaxf(y0[e], -65504.0f), 65504.0f);
         }
+        Q1_FZ_STAMP(4);
+        // DW1: dY once more as the A operand of the per-tile dW3 products, output 9 moved from slot 9 to slot 12 (see the dZ2 phase)
+        f16x8 dq0 = zero8, dq1 = zero8;
+        if constexpr (DW1) {
+            f16x8 dyq = dyb0;
+            if (half) { dyq[4] = dyb0[1]; dyq[1] = (_Float16)0.0f; }
+            const f32x16 dqt = transpose_tile(dyq, zero8, e0, e1);
+            dq0 = cvt8(dqt, 0); dq1 = cvt8(dqt, 1);
+        }
         // ---- [x | 1] and dY in N-format for the weight-gradient kernel
         f16x8 xd0 = zero8, xd1 = zero8;                      // DW1: [x | 1] once more, inputs 4..6 moved to operand slots 8..10 (see the dZ1 epilogue)
         {
@@ -229,7 +287,7 @@ learner_fwdbwd_kernel(int n, const float* __restrict__ obs, const int64_t* __res
             for (int e = 0; e < 8; ++e) x0[e] = e < 4 ? (_Float16)fminf(fmaxf(xv[e], -65504.0f), 65504.0f) : (_Float16)0.0f;
             const f32x16 dx = transpose_tile(x0, zero8, e0, e1);
             const size_t sb = (size_t)tile * 128u + lane;
-            net.xN[sb] = cvt8(dx, 0); net.xN[sb + 64u] = cvt8(dx, 1);
+            fz_store(net.xN + sb, cvt8(dx, 0), chk); fz_store(net.xN + sb + 64u, cvt8(dx, 1), chk);
             if constexpr (DW1) {
                 // a second transposition with inputs 0..3 in slots 0..3 and inputs 4, 5, the constant 1 in slots 8..10 (all in the half-0 lanes'
                 // vectors): as the A operand of the dW1 product its rows 0..3 (registers 0..3 of the half-0 lanes) are then inputs 0..3 and its
@@ -242,8 +300,9 @@ learner_fwdbwd_kernel(int n, const float* __restrict__ obs, const int64_t* __res
                 xd0 = cvt8(dq, 0); xd1 = cvt8(dq, 1);
             }
             const f32x16 dd = transpose_tile(dyb0, zero8, e0, e1);
-            net.dyN[sb] = cvt8(dd, 0); net.dyN[sb + 64u] = cvt8(dd, 1);
+            fz_store(net.dyN + sb, cvt8(dd, 0), chk); fz_store(net.dyN + sb + 64u, cvt8(dd, 1), chk);
         }
+        Q1_FZ_STAMP(5);
         // ---- dH2^T = W3^T dY^T, dZ2 = dH2 (1 - h2^2)
         f16x8 dzb[8][2];
 #pragma unroll
@@ -253,20 +312,31 @@ learner_fwdbwd_kernel(int n, const float* __restrict__ obs, const int64_t* __res
             times_dtanh(acc, h2k[t][0], h2k[t][1]);
             dzb[t][0] = cvt8_sat(acc, 0, amax);
             dzb[t][1] = cvt8_sat(acc, 1, amax);
-            store_n(net.dz2N + tbase, (uint32_t)t, transpose_tile(dzb[t][0], dzb[t][1], e0, e1));
+            const f32x16 dt = transpose_tile(dzb[t][0], dzb[t][1], e0, e1);
+            fz_store(net.dz2N + tbase + (2u * (uint32_t)t) * 64u, cvt8(dt, 0), chk);                  // (store_n)
+            fz_store(net.dz2N + tbase + (2u * (uint32_t)t + 1u) * 64u, cvt8(dt, 1), chk);
+            if constexpr (DW1) {
+                __builtin_amdgcn_sched_barrier(0);            // (the two halves of the iteration one after the other: their temporaries do not fit side by side)
+                // dW3 of this tile's 32 samples and 32 units: rows = outputs (slots 0..8 and 12 of dyq), columns = units (lane c = unit sigma(c)) - registers
+                // 0..3 of lane (c, h) are outputs 4 h .. 4 h + 3, register 4 is output 8 (h = 0) / 9 (h = 1); a one-output network has its only row in
+                // register 0 of the half-0 lanes.  tanh(H2) itself is stored nowhere.
+                const f32x16 ht = transpose_tile(h2k[t][0], h2k[t][1], e0, e1);
+                f32x16 p3 = __builtin_amdgcn_mfma_f32_32x32x16_f16(dq0, cvt8(ht, 0), zero16, 0, 0, 0);
+                p3 = __builtin_amdgcn_mfma_f32_32x32x16_f16(dq1, cvt8(ht, 1), p3, 0, 0, 0);
+                const size_t pb = ((size_t)tile * 8u + (uint32_t)t) * 64u + lane;
+                // (no branch on the network: a one-output network's dw3a is a 16-byte dummy every lane overwrites - a branch per iteration costs
+                // the register allocator ~80 registers here)
+                fz_store(net.dw3a + (second ? 0 : pb), make_float4(p3[0], p3[1], p3[2], p3[3]), chk);
+                fz_store(net.dw3b + pb, second ? p3[0] : p3[4], chk);
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
+        Q1_FZ_STAMP(6);
         // ---- dH1^T = W2^T dZ2^T in two passes of four row tiles, each followed by its dZ1 epilogue (learner_backward_kernel).  The wave's own
         //      h1 vectors come back four tiles at a time, requested at the head of the pass that ends with them (64 matrix instructions later):
         //      with all eight tiles held the kernel does not fit its 256 registers
 #pragma unroll
         for (int pass = 0; pass < 2; ++pass) {
-            f16x8 hv[4][2];
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                hv[t][0] = net.h1T[tbase + (2u * (uint32_t)(4 * pass + t)) * 64u];
-                hv[t][1] = net.h1T[tbase + (2u * (uint32_t)(4 * pass + t) + 1u) * 64u];
-            }
-            __builtin_amdgcn_sched_barrier(0);
             f32x16 acc1[4];
 #pragma unroll
             for (int t = 0; t < 4; ++t) acc1[t] = zero16;
@@ -284,9 +354,10 @@ learner_fwdbwd_kernel(int n, const float* __restrict__ obs, const int64_t* __res
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
+            Q1_FZ_STAMP(7 + 2 * pass);
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
-                times_dtanh(acc1[t], hv[t][0], hv[t][1]);
+                times_dtanh(acc1[t], hv[4 * pass + t][0], hv[4 * pass + t][1]);
                 const f16x8 z0 = cvt8_sat(acc1[t], 0, amax), z1 = cvt8_sat(acc1[t], 1, amax);
                 const f32x16 d = transpose_tile(z0, z1, e0, e1);
                 if constexpr (DW1) {
@@ -294,16 +365,32 @@ learner_fwdbwd_kernel(int n, const float* __restrict__ obs, const int64_t* __res
                     // 4 h + 3]) of this tile's 32 samples, with "W1[unit][6]" = b1[unit] and slot 7 empty
                     f32x16 p = __builtin_amdgcn_mfma_f32_32x32x16_f16(xd0, cvt8(d, 0), zero16, 0, 0, 0);
                     p = __builtin_amdgcn_mfma_f32_32x32x16_f16(xd1, cvt8(d, 1), p, 0, 0, 0);
-                    *reinterpret_cast<float4*>(net.dw1p + (size_t)tile * DW1_TILE_FLOATS + ((size_t)(4 * pass + t) * 32u + col) * 8u + 4u * half) =
-                        make_float4(p[0], p[1], p[2], p[3]);
+                    fz_store(reinterpret_cast<float4*>(net.dw1p + (size_t)tile * DW1_TILE_FLOATS + ((size_t)(4 * pass + t) * 32u + col) * 8u + 4u * half),
+                             make_float4(p[0], p[1], p[2], p[3]), chk);
                 } else {
-                    store_n(net.dz1N + tbase, (uint32_t)(4 * pass + t), d);
+                    fz_store(net.dz1N + tbase + (2u * (uint32_t)(4 * pass + t)) * 64u, cvt8(d, 0), chk);       // (store_n)
+                    fz_store(net.dz1N + tbase + (2u * (uint32_t)(4 * pass + t) + 1u) * 64u, cvt8(d, 1), chk);
                 }
                 __builtin_amdgcn_sched_barrier(0);            // one tile's epilogue at a time (interleaved, the four of them do not fit the registers)
             }
+            Q1_FZ_STAMP(8 + 2 * pass);
         }
     }
-    // ---- statistics rows and the saturation report (learner_backward_kernel<true>)
+#ifdef Q1_FZ_STAMPS
+    if (tile_live && lane == 0) {                            // (DW1: the dZ1 array is the unused one)
+        stamps[11] = (float)(wall_clock64() - stamp0) * 0.01f;
+        stamps[9] = gap_us;
+        stamps[10] = (float)(stamp0 & 0xFFFFFFull);           // (absolute start, 10-ns ticks modulo 2^24: when did this wave begin, relative to the others?)
+        float* dst = DW1 ? reinterpret_cast<float*>(net.dz1N + (size_t)tile * TILE_VECS) : net.dw1p + (size_t)tile * DW1_TILE_FLOATS;
+        for (int k = 0; k < 12; ++k) dst[k] = stamps[k];
+    }
+    if ((Q1_FZ_EXP & 512) && lane == 0) atomicMax(g_last_end, (unsigned long long)wall_clock64());
+    if (Q1_FZ_EXP & 16) la.stats_rows[2560u * 2u + (size_t)blockIdx.x * 512u / 64u + wave] = __uint_as_float(chk ^ __shfl_xor(chk, 17, 64));
+#endif
+    // ---- statistics rows and the saturation report: ONE row / one pair of atomics per workgroup.  (The first version reported per wave, as
+    //      learner_backward_kernel did: 2 x 2 048 atomics on two words per launch, which the memory side executes one after the other - the dispatch
+    //      lasted 14 us longer than its last wave, profiles/r6_learner_fused.txt.)
+    uint32_t (*red_sat)[2] = reinterpret_cast<uint32_t (*)[2]>(lds + LDS_FZ_RED + 160);
 #pragma unroll
     for (int k = 0; k < 5; ++k)
 #pragma unroll
@@ -312,6 +399,13 @@ learner_fwdbwd_kernel(int n, const float* __restrict__ obs, const int64_t* __res
 #pragma unroll
         for (int k = 0; k < 5; ++k) red[wave][k] = st[k];
     }
+    if (net.sat) {
+        const uint64_t over = __ballot(amax > 65504.0f);
+        float wmax = amax;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) wmax = fmaxf(wmax, __shfl_xor(wmax, off));
+        if (lane == 0) { red_sat[wave][0] = (uint32_t)__popcll(over); red_sat[wave][1] = __float_as_uint(wmax); }
+    }
     __syncthreads();
     if (tid < 5u) {
         float a = 0.0f;
@@ -319,15 +413,11 @@ learner_fwdbwd_kernel(int n, const float* __restrict__ obs, const int64_t* __res
         for (int w = 0; w < 8; ++w) a += red[w][tid];
         la.stats_rows[(size_t)blockIdx.x * 5u + tid] = a;
     }
-    if (net.sat) {
-        const uint64_t over = __ballot(amax > 65504.0f);
-        float wmax = amax;
+    if (!(Q1_FZ_EXP & 256) && net.sat && tid == 64u) {
+        uint32_t cnt = 0, mx = 0;
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) wmax = fmaxf(wmax, __shfl_xor(wmax, off));
-        if (lane == 0) {
-            if (over) atomicAdd(net.sat, (uint32_t)__popcll(over));
-            atomicMax(net.sat + 1, __float_as_uint(wmax));
-        }
+        for (int w = 0; w < 8; ++w) { cnt += red_sat[w][0]; mx = max(mx, red_sat[w][1]); }       // (bits of non-negative floats order like the floats)
+        sat_report(net.sat, cnt, mx);
     }
 }
 

@@ -184,9 +184,25 @@ __device__ __forceinline__ void stage_net(unsigned char* lds, const float* __res
 // STORE (the learner's forward, q1learner.hpp): the activations leave as they are consumed - h1_dst / h2_dst point at THIS lane's slot
 // of the tile's T-format arrays (f16x8 units; element (t, u) at [(2 t + u) * 64]): tanh(H1) / tanh(H2) as the very B operands the next
 // layer's MFMAs read, 32 fully coalesced 16-byte stores per layer and tile.
+// cache policy of an activation store (H1POL of mlp_tile_t): 0 = plain (write-back in the XCD's L2), 1 = sc1, 2 = nt, 3 = sc0 sc1
+template <int POL>
+__device__ __forceinline__ void act_store(f16x8* p, const f16x8 v) {
+    if constexpr (POL == 0) {
+        *p = v;
+    } else {
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+        union { f16x8 h; u32x4 u; } o;
+        o.h = v;
+        if constexpr (POL == 1) asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(o.u) : "memory");
+        else if constexpr (POL == 2) asm volatile("global_store_dwordx4 %0, %1, off nt" ::"v"(p), "v"(o.u) : "memory");
+        else asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(o.u) : "memory");
+    }
+}
+
 // KEEP (the fused forward + backward kernel of the learner, q1learner_fused.hpp): tanh(H2) additionally stays with the caller, in h2k[t][u] - the
 // operand vectors the data-gradient phase multiplies by (1 - h2^2) a few microseconds later, without a trip through memory.
-template <bool STORE, bool KEEP = false>
+// STORE_H2 = false (with STORE): only tanh(H1) is stored - the fused kernel's product mode needs tanh(H2) nowhere else.
+template <bool STORE, bool KEEP = false, bool STORE_H2 = STORE, int H1POL = 0>
 __device__ __forceinline__ f32x16 mlp_tile_t(const f16x8 xb, const unsigned char* w1row, const unsigned char* wrow, const unsigned char* w3row,
                                              const float* l_b2, uint32_t half, uint64_t* stamps, f16x8* h1_dst, f16x8* h2_dst, f16x8 (*h2k)[2] = nullptr) {
     const f32x16 zero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -219,7 +235,7 @@ __device__ __forceinline__ f32x16 mlp_tile_t(const f16x8 xb, const unsigned char
 #pragma unroll 1
     for (int t1 = 0; t1 < 8; ++t1) {
         const uint32_t q0 = 2u * (uint32_t)t1;
-        if constexpr (STORE) { h1_dst[(2 * t1) * 64] = cur0; h1_dst[(2 * t1 + 1) * 64] = cur1; }
+        if constexpr (STORE) { act_store<H1POL>(h1_dst + (2 * t1) * 64, cur0); act_store<H1POL>(h1_dst + (2 * t1 + 1) * 64, cur1); }
         // phase 1: even K-step, first half of tanh(tile t1+1)
 #pragma unroll
         for (int t2 = 0; t2 < 8; ++t2) {
@@ -260,7 +276,7 @@ __device__ __forceinline__ f32x16 mlp_tile_t(const f16x8 xb, const unsigned char
 #pragma unroll
     for (int t2 = 0; t2 < 8; ++t2) {
         const f16x8 f0 = activate(acc[t2], 0), f1 = activate(acc[t2], 1);
-        if constexpr (STORE) { h2_dst[(2 * t2) * 64] = f0; h2_dst[(2 * t2 + 1) * 64] = f1; }
+        if constexpr (STORE_H2) { h2_dst[(2 * t2) * 64] = f0; h2_dst[(2 * t2 + 1) * 64] = f1; }
         if constexpr (KEEP) { h2k[t2][0] = f0; h2k[t2][1] = f1; }
         y = __builtin_amdgcn_mfma_f32_32x32x16_f16(w3a, f0, y, 0, 0, 0);
         y = __builtin_amdgcn_mfma_f32_32x32x16_f16(w3b, f1, y, 0, 0, 0);

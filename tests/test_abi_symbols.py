@@ -70,12 +70,12 @@ def test_learner_workspace_sizes_are_host_arithmetic(lib):
     """q1env_learner_workspace_bytes / _adam_state_bytes need no device: pure layout arithmetic (include/q1env.h, ABI v3).  The workspace
     holds, per network, three float16 weight images, four float16 activation arrays of 16 KiB per 32-sample tile (h1, h2 in the forward
     kernel's layout, dZ1, dZ2 in the weight-gradient kernel's; round 4 dropped the second copies of h1 / h2), two small operand
-    arrays, 8 KiB of dW1 / db1 products per tile (round 6: what the fused forward + backward kernel leaves instead of dZ1) and `splits`
-    partial-sum slabs; it must grow linearly in the tile count and in the splits, and refuse nonsense."""
+    arrays, 8 KiB of dW1 / db1 products per tile and 8 + 2 (policy) / 2 (value network) KiB of dW3 products (round 6: what the fused forward +
+    backward kernel leaves instead of dZ1 and tanh(H2)) and `splits` partial-sum slabs; it must grow linearly in the tile count and in the splits, and refuse nonsense."""
     ws = lib.q1env_learner_workspace_bytes
     b1, b2 = ws(32768, 10, 32), ws(65536, 10, 32)
     tiles = 32768 // 32
-    per_tile = 2 * (4 * 16384 + 2 * 2048 + 8192)                   # both networks
+    per_tile = 2 * (4 * 16384 + 2 * 2048 + 8192 + 2048) + 8192      # both networks
     assert b2 - b1 == tiles * per_tile + 2 * (32768 * 10 * 4) + 2 * (32768 * 4)
     assert ws(32768, 10, 64) - b1 == 2 * 32 * 89 * 1024 * 4         # 89 products of 32x32 float32 per split and network
     assert ws(1000, 19, 4) > 0 and ws(1000, 19, 4) % 256 == 0      # ragged minibatch: whole tiles, 256-byte aligned pieces

@@ -357,8 +357,9 @@ def test_sgd_step_equals_step_plus_adam(mb, n_envs, over):
 def test_fused_forward_backward_step_against_the_four_launch_step(mb, n_envs, horizon):
     """q1env_learner_sgd_step's kernel sequences (round 6, q1env_learner_set_step_mode; csrc/q1learner_fused.hpp): forward + loss gradient + data
     gradients as ONE kernel.  "fused" must reproduce the four-launch step BIT FOR BIT - masters, gradients, moments, weight images,
-    saturation counters - over several steps (the same arithmetic, only the activations' trip through memory is gone); "fused_dw1" (dZ1 replaced
-    by per-tile products with [x | 1]) the same bits for every tensor but W1 / b1 of both networks, which differ by float32 summation order.
+    saturation counters - over several steps (the same arithmetic, only the activations' trip through memory is gone); "fused_dw1" (dZ1 and
+    tanh(H2) replaced by their per-tile products with [x | 1] and dY) the same bits for W2, b2, b3 of both networks; W1, b1, W3 differ by float32
+    summation order (per-tile products added up in tile order instead of one accumulation chain).
     Sizes: whole workgroups, a ragged last tile, fewer tiles than one workgroup has waves, a tile count that is no multiple of eight, and the
     large-minibatch configuration's 32 768."""
     import torch
@@ -395,12 +396,14 @@ def test_fused_forward_backward_step_against_the_four_launch_step(mb, n_envs, ho
         assert torch.equal(a.adam_state[256:], b.adam_state[256:]), k
         assert torch.equal(a.saturation, b.saturation) and torch.equal(a.saturation, c.saturation)
         sa, sb, sc = (x.stats_acc.cpu().numpy() for x in nats)
-        assert np.allclose(sa, sb, rtol=2e-5, atol=1e-6) and np.array_equal(sb, sc), (k, sa, sb, sc)
+        assert np.allclose(sa, sb, rtol=2e-5, atol=1e-6) and np.allclose(sb, sc, rtol=1e-4, atol=1e-6), (k, sa, sb, sc)
         if k == 0:
-            # the first step starts from identical weights: every gradient but dW1 / db1 is the same bits, those agree to summation order
+            assert np.array_equal(sb, sc)              # the same forward, the same loss, the same workgroups: the same sums
+        if k == 0:
+            # the first step starts from identical weights: every gradient but dW1 / db1 / dW3 is the same bits, those agree to summation order
             for (name, p), q in zip(pols[0].named_parameters(), pols[2].parameters()):
-                first_layer = name.split(".")[1] == "0"
-                if first_layer:
+                by_products = name.split(".")[1] == "0" or name.endswith("4.weight")
+                if by_products:
                     assert _rel(q.grad, p.grad) < 2e-6, (name, _rel(q.grad, p.grad))
                     assert not torch.isnan(q.grad).any()
                 else:
