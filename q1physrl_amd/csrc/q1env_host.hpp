@@ -81,6 +81,7 @@ struct q1env {
     float pi_upscale = 0.0f, value_downscale = 0.0f;   // the learner's float16 loss scales (q1env_learner_set_loss_scale; 0 = the defaults)
     int plearner_mode = 0;            // exchange mode of the persistent learner (q1env_learner_set_exchange_mode): 0 auto, 1 agent scope, 2 census made to fail
     int learner_step_mode = 0;        // q1env_learner_sgd_step's kernel sequence (q1env_learner_set_step_mode): 0 auto, 1 four launches, 2 fused forward + backward, 3 ... + dW1 products
+    int wgrad_variant = 0;            // (measurement only) step mode 3 with an earlier weight-gradient kernel: 1 column quarters, 2 round 4's; 0 = the shared-operand kernel
     int plearner_prof = -1;           // >= 0: the profiling instantiation stamps wave (value >> 3) of workgroup (value & 7) of the policy group
     // cached hipGraphs of step_many, keyed by (ticks, formats, pointers); a handful of entries, oldest evicted
     struct GraphEntry { std::vector<uint64_t> key; hipGraphExec_t exec; };

@@ -164,7 +164,12 @@ int launch_fwdbwd(q1env* h, const Ws& w, int64_t mb, int splits, const q1env_lea
 #if defined(Q1_FZ_STAMPS) && (Q1_FZ_EXP & 512)       // diagnostic build: the same launch once more (idempotent), so that the second one's stamps see the first one's end
         hipLaunchKernelGGL(q1learn::learner_fwdbwd_kernel<true>, dim3(blocks * 2u), dim3(512), q1learn::LDS_FZ, h->stream, (int)mb, obs, idx, idx_cursor, fa, fb, la, bca);
 #endif
-        hipLaunchKernelGGL(q1learn::learner_wgrad_kernel<true>, dim3(2u * (unsigned)splits, 2, 2), dim3(256), 0, h->stream, (int)mb, wa, wb, splits);
+        if (h->wgrad_variant == 1)          // (experiment, tools/time_learner.py --step-mode fused_dw1_q: column quarters, two workgroups per CU - 35.2 us against 27.6)
+            hipLaunchKernelGGL((q1learn::learner_wgrad_kernel<true, 2>), dim3(2u * (unsigned)splits, 4, 2), dim3(256), 0, h->stream, (int)mb, wa, wb, splits);
+        else if (h->wgrad_variant == 2)     // (experiment: the round-4 kernel on the product arrays)
+            hipLaunchKernelGGL((q1learn::learner_wgrad_kernel<true, 4>), dim3(2u * (unsigned)splits, 2, 2), dim3(256), 0, h->stream, (int)mb, wa, wb, splits);
+        else
+            hipLaunchKernelGGL(q1learn::learner_wgrad_shared_kernel, dim3(2u * (unsigned)splits, 2, 2), dim3(256), 0, h->stream, (int)mb, wa, wb, splits);
     } else {
         hipLaunchKernelGGL(q1learn::learner_fwdbwd_kernel<false>, dim3(blocks * 2u), dim3(512), q1learn::LDS_FZ, h->stream, (int)mb, obs, idx, idx_cursor, fa, fb, la, bca);
         hipLaunchKernelGGL(q1learn::learner_wgrad_kernel<false>, dim3(2u * (unsigned)splits, 2, 2), dim3(256), 0, h->stream, (int)mb, wa, wb, splits);
@@ -189,6 +194,8 @@ int q1env_learner_set_loss_scale(q1env_t* h, float pi_upscale, float value_downs
 
 int q1env_learner_set_step_mode(q1env_t* h, int mode) {
     if (!h) return fail(Q1ENV_ERR_INVALID_ARG, "q1env_learner_set_step_mode: null handle");
+    if (mode == 4 || mode == 5) { h->learner_step_mode = 3; h->wgrad_variant = mode - 3; return Q1ENV_OK; }      // (measurement only: mode 3 with an older weight-gradient kernel)
+    h->wgrad_variant = 0;
     if (mode < 0 || mode > 3)
         return fail(Q1ENV_ERR_INVALID_ARG, "q1env_learner_set_step_mode: mode must be 0 (automatic), 1 (four launches), 2 (fused forward + backward) or 3 (fused, dW1 products)");
     h->learner_step_mode = mode;

@@ -620,15 +620,18 @@ struct WgNet {
 // its split's slot.
 struct WgOps { f16x8 a2[2], s0[2], s1[2], x[2], b[4][2]; float4 p[2]; float q; };     // dZ2 rows | y=0: dZ1 rows (DW1: the tile's dW1 products in p), [x|1]  y=1: dY, h2 cols, [x|1] | h1 column tiles
 
-template <int KHALF, bool DW1>
+// COL0 / NKT: the wave's dW2 column tiles are COL0 .. COL0 + NKT - 1 (NKT = 4: round 4's two halves per row tile; NKT = 2: four quarters, two
+// workgroups per CU - round 6); the quarter that starts at column 0 also carries the [x | 1] products (EX = 0), the one at column 4 the dY products (EX = 1)
+template <int COL0, int NKT, bool DW1>
 __device__ __forceinline__ void wg_load(WgOps& o, const WgNet& net, uint32_t tile, uint32_t lane, uint32_t w) {
+    constexpr int EX = COL0 == 0 ? 0 : (COL0 == 4 ? 1 : -1);
     const size_t tb = (size_t)tile * TILE_VECS + lane, sb = (size_t)tile * 128u + lane;
-    if constexpr (KHALF == 1 && DW1) {
+    if constexpr (EX == 1 && DW1) {
         const size_t pb = ((size_t)tile * 8u + w) * 64u + lane;
         o.p[0] = net.dw3a ? net.dw3a[pb] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);       // (wave-uniform)
         o.q = net.dw3b[pb];
     }
-    if constexpr (KHALF == 0 && DW1) {
+    if constexpr (EX == 0 && DW1) {
         // 32 x 7 float32 products of the tile (registers 0..6 of lanes 0..31 in the C / D layout of [x | 1]^T dZ1); the upper lanes re-read the lower lanes' (unused)
         const float4* q = reinterpret_cast<const float4*>(net.dw1p + ((size_t)tile * 8u + w) * 256u + (size_t)(lane & 31u) * 8u);
         o.p[0] = q[0]; o.p[1] = q[1];
@@ -636,17 +639,17 @@ __device__ __forceinline__ void wg_load(WgOps& o, const WgNet& net, uint32_t til
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
         o.a2[ks] = net.dz2N[tb + (2u * w + (uint32_t)ks) * 64u];
-        if constexpr (KHALF == 0) {
+        if constexpr (EX == 0) {
             if constexpr (!DW1) o.s0[ks] = net.dz1N[tb + (2u * w + (uint32_t)ks) * 64u];
             o.s1[ks] = net.xN[sb + 64u * (uint32_t)ks];
         }
         // (h2 / h1: T-format vectors u = ks of the unit tile - the same addressing as an N-format array; transposed by wg_transpose)
-        else {
+        else if constexpr (EX == 1) {
             o.s0[ks] = net.dyN[sb + 64u * (uint32_t)ks]; o.x[ks] = net.xN[sb + 64u * (uint32_t)ks];
             if constexpr (!DW1) o.s1[ks] = net.h2T[tb + (2u * w + (uint32_t)ks) * 64u];
         }
 #pragma unroll
-        for (int kt = 0; kt < 4; ++kt) o.b[kt][ks] = net.h1T[tb + (2u * (4u * (uint32_t)KHALF + (uint32_t)kt) + (uint32_t)ks) * 64u];
+        for (int kt = 0; kt < NKT; ++kt) o.b[kt][ks] = net.h1T[tb + (2u * (uint32_t)(COL0 + kt) + (uint32_t)ks) * 64u];
     }
 }
 
@@ -665,8 +668,9 @@ __device__ __forceinline__ void wg_transpose(f16x8 (&v)[2], const f16x8 e0, cons
 // its CU's register file: 4 x 56..64 operand registers + 96 accumulators), and the body is straight-line - KHALF is a template
 // argument, the db3 product (dY x [x | 1]) is computed by every wave of the y = 1 half and stored by one - so that the compiler's
 // s_waitcnt are counts, not drains (the first version's in-loop direct load for that product drained the queue every tile).
-template <int KHALF, bool DW1>
-__device__ __forceinline__ void wg_loop(const WgNet& net, uint32_t t_begin, uint32_t t_end, uint32_t lane, uint32_t w, f32x16 aW2[4], f32x16& aX, f32x16& aY) {
+template <int COL0, int NKT, bool DW1>
+__device__ __forceinline__ void wg_loop(const WgNet& net, uint32_t t_begin, uint32_t t_end, uint32_t lane, uint32_t w, f32x16 (&aW2)[NKT], f32x16& aX, f32x16& aY) {
+    constexpr int EX = COL0 == 0 ? 0 : (COL0 == 4 ? 1 : -1);
     constexpr int D = Q1_WGRAD_DEPTH;
     WgOps ring[D];
     if (t_begin >= t_end) return;
@@ -681,37 +685,37 @@ __device__ __forceinline__ void wg_loop(const WgNet& net, uint32_t t_begin, uint
         }
     }
 #pragma unroll
-    for (int d = 0; d < D - 1; ++d) wg_load<KHALF, DW1>(ring[d], net, min(t_begin + (uint32_t)d, t_end - 1u), lane, w);
+    for (int d = 0; d < D - 1; ++d) wg_load<COL0, NKT, DW1>(ring[d], net, min(t_begin + (uint32_t)d, t_end - 1u), lane, w);
     for (uint32_t tile0 = t_begin; tile0 < t_end; tile0 += (uint32_t)D) {
 #pragma unroll
         for (int j = 0; j < D; ++j) {
             const uint32_t tile = tile0 + (uint32_t)j;
             if (tile >= t_end) return;                                             // wave-uniform
-            wg_load<KHALF, DW1>(ring[(j + D - 1) % D], net, min(tile + (uint32_t)(D - 1), t_end - 1u), lane, w);   // (past the end: re-requests the last tile, harmless)
+            wg_load<COL0, NKT, DW1>(ring[(j + D - 1) % D], net, min(tile + (uint32_t)(D - 1), t_end - 1u), lane, w);   // (past the end: re-requests the last tile, harmless)
             __builtin_amdgcn_sched_barrier(0);                                     // the requests go out HERE, not next to their uses
             WgOps& cur = ring[j];
 #pragma unroll
-            for (int kt = 0; kt < 4; ++kt) wg_transpose(cur.b[kt], e0, e1);          // h1 column tiles: T -> N
-            if constexpr (KHALF == 1 && !DW1) wg_transpose(cur.s1, e0, e1);          // h2 tile w: T -> N
+            for (int kt = 0; kt < NKT; ++kt) wg_transpose(cur.b[kt], e0, e1);        // h1 column tiles: T -> N
+            if constexpr (EX == 1 && !DW1) wg_transpose(cur.s1, e0, e1);          // h2 tile w: T -> N
 #pragma unroll
-            for (int kt = 0; kt < 4; ++kt)
+            for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks) aW2[kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur.a2[ks], cur.b[kt][ks], aW2[kt], 0, 0, 0);
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
-                if constexpr (KHALF == 0) {
+                if constexpr (EX == 0) {
                     aX = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur.a2[ks], cur.s1[ks], aX, 0, 0, 0);
                     if constexpr (!DW1) aY = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur.s0[ks], cur.s1[ks], aY, 0, 0, 0);
-                } else {
+                } else if constexpr (EX == 1) {
                     if constexpr (!DW1) aX = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur.s0[ks], cur.s1[ks], aX, 0, 0, 0);
                     aY = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur.s0[ks], cur.x[ks], aY, 0, 0, 0);
                 }
             }
-            if constexpr (KHALF == 1 && DW1) {                                       // the tile's dW3 products (rows = outputs), added in tile order
+            if constexpr (EX == 1 && DW1) {                                          // the tile's dW3 products (rows = outputs), added in tile order
                 aX[0] += cur.p[0].x; aX[1] += cur.p[0].y; aX[2] += cur.p[0].z; aX[3] += cur.p[0].w;
                 if (net.dw3a) aX[4] += cur.q; else aX[0] += cur.q;                   // (wave-uniform: ten outputs / one)
             }
-            if constexpr (KHALF == 0 && DW1) {                                       // the tile's dW1 / db1 products, added in tile order
+            if constexpr (EX == 0 && DW1) {                                          // the tile's dW1 / db1 products, added in tile order
                 aY[0] += cur.p[0].x; aY[1] += cur.p[0].y; aY[2] += cur.p[0].z; aY[3] += cur.p[0].w;
                 aY[4] += cur.p[1].x; aY[5] += cur.p[1].y; aY[6] += cur.p[1].z; aY[7] += cur.p[1].w;
             }
@@ -722,36 +726,170 @@ __device__ __forceinline__ void wg_loop(const WgNet& net, uint32_t t_begin, uint
 
 // DW1: products 72..79 of the slab hold [x | 1]^T dZ1 (rows = inputs: registers 0..6 of lanes 0..31; slot_of(.., dw1 = true)) instead of dZ1^T [x | 1],
 // and output 9 of products 80..87 sits in row 12 (register 4 of the half-1 lanes) instead of row 9
-template <bool DW1>
-__global__ void __launch_bounds__(256, 1)
+// NKT = 2 (round 6): blockIdx.y = 0..3 picks a QUARTER of the column tiles - 512 workgroups of at most 256 registers per lane, two per CU: eight waves per
+// CU keep twice the loads in flight in a loop that waits for one tile's operands per iteration (the same accumulation chains: the same bits)
+template <bool DW1, int NKT = 4>
+__global__ void __launch_bounds__(256, NKT == 2 ? 2 : 1)
 learner_wgrad_kernel(int n, WgNet net_a, WgNet net_b, int splits) {
     const bool second = blockIdx.x >= (uint32_t)splits;
     const uint32_t split = second ? blockIdx.x - (uint32_t)splits : blockIdx.x;
-    const uint32_t khalf = blockIdx.y;
+    const uint32_t kq = blockIdx.y;                    // column group: tiles NKT kq .. NKT kq + NKT - 1
     const WgNet net = second ? net_b : net_a;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, w = (tid >> 6) + 4u * blockIdx.z;      // row tile of the gradient side
     const uint32_t ntiles = ((uint32_t)n + 31u) / 32u;
     const uint32_t per = (ntiles + (uint32_t)splits - 1u) / (uint32_t)splits;
     const uint32_t t_begin = split * per, t_end = min(t_begin + per, ntiles);
     const f32x16 zero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    f32x16 aW2[4], aX = zero16, aY = zero16;          // y = 0: aX = dZ2 x [x|1], aY = dZ1 x [x|1];  y = 1: aX = dY x h2, aY = dY x [x|1] (kept by wave 0)
+    f32x16 aW2[NKT], aX = zero16, aY = zero16;        // columns 0..: aX = dZ2 x [x|1], aY = dZ1 x [x|1];  columns 4..: aX = dY x h2, aY = dY x [x|1] (kept by wave 0)
 #pragma unroll
-    for (int k = 0; k < 4; ++k) aW2[k] = zero16;
-    if (khalf == 0) wg_loop<0, DW1>(net, t_begin, t_end, lane, w, aW2, aX, aY);
-    else wg_loop<1, DW1>(net, t_begin, t_end, lane, w, aW2, aX, aY);
+    for (int k = 0; k < NKT; ++k) aW2[k] = zero16;
+    if constexpr (NKT == 4) {
+        if (kq == 0) wg_loop<0, 4, DW1>(net, t_begin, t_end, lane, w, aW2, aX, aY);
+        else wg_loop<4, 4, DW1>(net, t_begin, t_end, lane, w, aW2, aX, aY);
+    } else {
+        if (kq == 0) wg_loop<0, 2, DW1>(net, t_begin, t_end, lane, w, aW2, aX, aY);
+        else if (kq == 1) wg_loop<2, 2, DW1>(net, t_begin, t_end, lane, w, aW2, aX, aY);
+        else if (kq == 2) wg_loop<4, 2, DW1>(net, t_begin, t_end, lane, w, aW2, aX, aY);
+        else wg_loop<6, 2, DW1>(net, t_begin, t_end, lane, w, aW2, aX, aY);
+    }
     float* out = net.partial + (size_t)split * PARTIAL_STRIDE;
     auto put = [&](uint32_t p, const f32x16& a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) out[((size_t)p * 16u + (uint32_t)r) * 64u + lane] = a[r];
     };
 #pragma unroll
-    for (int kt = 0; kt < 4; ++kt) put(8u * w + 4u * khalf + (uint32_t)kt, aW2[kt]);
-    if (khalf == 0) {
+    for (int kt = 0; kt < NKT; ++kt) put(8u * w + (uint32_t)NKT * kq + (uint32_t)kt, aW2[kt]);
+    if (kq == 0) {
         put(64u + w, aX);
         put(72u + w, aY);
-    } else {
+    } else if ((uint32_t)NKT * kq == 4u) {
         put(80u + w, aX);
         if (w == 0) put(88u, aY);
+    }
+}
+
+// Round 6: the weight-gradient kernel of the fused step (product arrays: no dZ1, no tanh(H2)) with the h1 column tiles SHARED through LDS.  In
+// learner_wgrad_kernel all four waves of a workgroup load and transpose the same four h1 tiles (8 of the 13 KB a wave requests per sample tile; the
+// CU's vector cache filled at half its rate, and more waves made it worse: the column-quarter form above, 35 us against 27.6) - here wave v loads and
+// transposes ONE of them (column tile COL0 + v) per sample tile, leaves it in LDS (two stages of 4 x 2 KB, one barrier per tile: a stage is
+// rewritten two tiles later, behind the barrier every reader of it has passed) and all four read their B operands from there: 5 - 7 KB of requests
+// per wave and tile, one transposition instead of four, and a ring of three tiles in flight in the registers that frees.  The accumulation chains
+// are learner_wgrad_kernel<true>'s: the same bits.
+constexpr int WGS_DEPTH = 3;
+struct WgsOps { f16x8 a2[2], bo[2], s[2], x[2]; float4 p[2]; float q; };
+
+template <int COL0>
+__device__ __forceinline__ void wgs_load(WgsOps& o, const WgNet& net, uint32_t tile, uint32_t lane, uint32_t v, uint32_t w) {
+    constexpr int EX = COL0 == 0 ? 0 : 1;
+    const size_t tb = (size_t)tile * TILE_VECS + lane, sb = (size_t)tile * 128u + lane;
+    if constexpr (EX == 1) {
+        const size_t pb = ((size_t)tile * 8u + w) * 64u + lane;
+        o.p[0] = net.dw3a ? net.dw3a[pb] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);       // (wave-uniform)
+        o.q = net.dw3b[pb];
+    } else {
+        const float4* q = reinterpret_cast<const float4*>(net.dw1p + ((size_t)tile * 8u + w) * 256u + (size_t)(lane & 31u) * 8u);
+        o.p[0] = q[0]; o.p[1] = q[1];
+    }
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        o.a2[ks] = net.dz2N[tb + (2u * w + (uint32_t)ks) * 64u];
+        o.bo[ks] = net.h1T[tb + (2u * ((uint32_t)COL0 + v) + (uint32_t)ks) * 64u];
+        if constexpr (EX == 0) o.s[ks] = net.xN[sb + 64u * (uint32_t)ks];
+        else { o.s[ks] = net.dyN[sb + 64u * (uint32_t)ks]; o.x[ks] = net.xN[sb + 64u * (uint32_t)ks]; }
+    }
+}
+
+template <int COL0>
+__device__ __forceinline__ void wgs_loop(const WgNet& net, uint32_t t_begin, uint32_t t_end, uint32_t lane, uint32_t v, uint32_t w, f32x16 (&aW2)[4], f32x16& aX,
+                                         f32x16& aY, f16x8* lds) {
+    constexpr int EX = COL0 == 0 ? 0 : 1;
+    constexpr int D = WGS_DEPTH;
+    WgsOps ring[D];
+    if (t_begin >= t_end) return;                                                  // (the same range for the workgroup's four waves: the barriers below are uniform)
+    f16x8 e0, e1;
+    {
+        const uint32_t col = lane & 31u, half = lane >> 5;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            e0[e] = (8u * half + (uint32_t)e == col) ? (_Float16)1.0f : (_Float16)0.0f;
+            e1[e] = (8u * half + (uint32_t)e + 16u == col) ? (_Float16)1.0f : (_Float16)0.0f;
+        }
+    }
+#pragma unroll
+    for (int d = 0; d < D - 1; ++d) wgs_load<COL0>(ring[d], net, min(t_begin + (uint32_t)d, t_end - 1u), lane, v, w);
+    uint32_t stage = 0;
+    for (uint32_t tile0 = t_begin; tile0 < t_end; tile0 += (uint32_t)D) {
+#pragma unroll
+        for (int j = 0; j < D; ++j) {
+            const uint32_t tile = tile0 + (uint32_t)j;
+            if (tile >= t_end) return;                                             // workgroup-uniform
+            wgs_load<COL0>(ring[(j + D - 1) % D], net, min(tile + (uint32_t)(D - 1), t_end - 1u), lane, v, w);
+            __builtin_amdgcn_sched_barrier(0);
+            WgsOps& cur = ring[j];
+            wg_transpose(cur.bo, e0, e1);                                          // this wave's h1 column tile: T -> N
+            f16x8* mine = lds + ((stage * 4u + v) * 2u) * 64u + lane;
+            mine[0] = cur.bo[0]; mine[64] = cur.bo[1];
+            __syncthreads();
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    const f16x8 b = lds[((stage * 4u + (uint32_t)kt) * 2u + (uint32_t)ks) * 64u + lane];
+                    aW2[kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur.a2[ks], b, aW2[kt], 0, 0, 0);
+                }
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                if constexpr (EX == 0) aX = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur.a2[ks], cur.s[ks], aX, 0, 0, 0);
+                else aY = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur.s[ks], cur.x[ks], aY, 0, 0, 0);
+            }
+            if constexpr (EX == 1) {                                               // the tile's dW3 products, added in tile order
+                aX[0] += cur.p[0].x; aX[1] += cur.p[0].y; aX[2] += cur.p[0].z; aX[3] += cur.p[0].w;
+                if (net.dw3a) aX[4] += cur.q; else aX[0] += cur.q;
+            } else {                                                               // the tile's dW1 / db1 products
+                aY[0] += cur.p[0].x; aY[1] += cur.p[0].y; aY[2] += cur.p[0].z; aY[3] += cur.p[0].w;
+                aY[4] += cur.p[1].x; aY[5] += cur.p[1].y; aY[6] += cur.p[1].z; aY[7] += cur.p[1].w;
+            }
+            stage ^= 1u;
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256, 1)
+learner_wgrad_shared_kernel(int n, WgNet net_a, WgNet net_b, int splits) {
+    __shared__ __attribute__((aligned(16))) f16x8 lds[2 * 4 * 2 * 64];            // 16 KB: two stages of four N-format h1 tiles
+    const bool second = blockIdx.x >= (uint32_t)splits;
+    const uint32_t split = second ? blockIdx.x - (uint32_t)splits : blockIdx.x;
+    const uint32_t khalf = blockIdx.y;
+    const WgNet net = second ? net_b : net_a;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, v = tid >> 6, w = v + 4u * blockIdx.z;
+    const uint32_t ntiles = ((uint32_t)n + 31u) / 32u;
+    const uint32_t per = (ntiles + (uint32_t)splits - 1u) / (uint32_t)splits;
+    const uint32_t t_begin = split * per, t_end = min(t_begin + per, ntiles);
+    const f32x16 zero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    f32x16 aW2[4], aX = zero16, aY = zero16;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) aW2[k] = zero16;
+    if (khalf == 0) wgs_loop<0>(net, t_begin, t_end, lane, v, w, aW2, aX, aY, lds);
+    else wgs_loop<4>(net, t_begin, t_end, lane, v, w, aW2, aX, aY, lds);
+    float* out = net.partial + (size_t)split * PARTIAL_STRIDE;
+    // Only the slots slot_of(.., dw1 = true) maps to a parameter are written (nobody reads the others): of the 25 small products' 100 KB per split and
+    // network, 19 KB - 6.5 of the 23 MB this kernel writes in its last microsecond, which no load is left to hide.
+    auto put = [&](uint32_t p, const f32x16& a, int regs, bool lanes) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            if (r < regs && lanes) out[((size_t)p * 16u + (uint32_t)r) * 64u + lane] = a[r];
+    };
+    const uint32_t cb = lane & 31u;
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) put(8u * w + 4u * khalf + (uint32_t)kt, aW2[kt], 16, true);
+    if (khalf == 0) {
+        put(64u + w, aX, 16, cb == sigma((uint32_t)OBS));      // db2: the column of the constant 1
+        put(72u + w, aY, 7, lane < 32u);                       // dW1 / db1: rows = inputs, the half-0 lanes
+    } else {
+        if (net.dw3a) put(80u + w, aX, 5, true);               // dW3, ten outputs: rows 0..8 and 12
+        else put(80u + w, aX, 1, lane < 32u);                  // one output: row 0
+        if (w == 0) put(88u, aY, 16, cb == sigma((uint32_t)OBS));   // db3
     }
 }
 

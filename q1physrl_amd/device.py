@@ -296,7 +296,7 @@ class DeviceEnv:
         "census_fail" (tests: automatic, with a census made to disagree).  include/q1env.h."""
         _lib.check(self._lib.q1env_learner_set_exchange_mode(self._h, self.EXCHANGE_MODES[mode] if isinstance(mode, str) else int(mode)))
 
-    STEP_MODES = {"auto": 0, "four_launch": 1, "fused": 2, "fused_dw1": 3}
+    STEP_MODES = {"auto": 0, "four_launch": 1, "fused": 2, "fused_dw1": 3, "fused_dw1_q": 4, "fused_dw1_r4wgrad": 5}
 
     def learner_set_step_mode(self, mode):
         """Kernel sequence of q1env_learner_sgd_step on this handle: "auto" (fused forward + backward kernel from 2 048 samples on), "four_launch"

@@ -367,7 +367,7 @@ def test_fused_forward_backward_step_against_the_four_launch_step(mb, n_envs, ho
     torch.manual_seed(4)
     cfg, env = make_env(n_envs, time_limit=1.0)
     pols = [_policy(5, 2.0)]
-    pols += [copy.deepcopy(pols[0]), copy.deepcopy(pols[0])]
+    pols += [copy.deepcopy(pols[0]), copy.deepcopy(pols[0]), copy.deepcopy(pols[0])]
     smp = S.GpuSampler(env, P.FusedPolicyForward(pols[0], env), horizon=horizon)
     tr = smp.collect()
     adv, vt = smp.advantages(tr, 0.99, 0.95)
@@ -379,7 +379,7 @@ def test_fused_forward_backward_step_against_the_four_launch_step(mb, n_envs, ho
             "vtarg": vt.reshape(-1).contiguous()}
     klc = torch.tensor(0.2, device="cuda")
     perm = torch.randperm(total, device="cuda")
-    modes = ["four_launch", "fused", "fused_dw1"]
+    modes = ["four_launch", "fused", "fused_dw1", "fused_dw1_q"]
     nats = [ppo.NativeStep(p, env, mb, splits=8) for p in pols]
     hp = (3e-4, (0.9, 0.999), 1e-8)
     n_steps = min(total // mb, 4)
@@ -389,13 +389,17 @@ def test_fused_forward_backward_step_against_the_four_launch_step(mb, n_envs, ho
             env._dev.learner_set_step_mode(mode)
             nat.step(full, perm, 0.3, 10.0, 1.0, 0.01, klc, skip_reduce=True, use_cursor=True, adam=hp)
         torch.cuda.synchronize()
-        a, b, c = nats
+        a, b, c, d = nats
+        # "fused_dw1" runs the shared-operand weight-gradient kernel; the column-quarter form (measurement only) runs the same accumulation chains: equal
+        for (name, p), q in zip(pols[2].named_parameters(), pols[3].parameters()):
+            assert torch.equal(p, q) and torch.equal(p.grad, q.grad), (k, name)
+        assert torch.equal(c.adam_state[256:], d.adam_state[256:]) and torch.equal(c.stats_acc, d.stats_acc), k
         for (name, p), q in zip(pols[0].named_parameters(), pols[1].parameters()):
             assert torch.equal(p, q) and torch.equal(p.grad, q.grad), (k, name)
         assert torch.equal(a.adam_state[:16], b.adam_state[:16]) and torch.equal(a.adam_state[72:80], b.adam_state[72:80])
         assert torch.equal(a.adam_state[256:], b.adam_state[256:]), k
         assert torch.equal(a.saturation, b.saturation) and torch.equal(a.saturation, c.saturation)
-        sa, sb, sc = (x.stats_acc.cpu().numpy() for x in nats)
+        sa, sb, sc = (x.stats_acc.cpu().numpy() for x in nats[:3])
         assert np.allclose(sa, sb, rtol=2e-5, atol=1e-6) and np.allclose(sb, sc, rtol=1e-4, atol=1e-6), (k, sa, sb, sc)
         if k == 0:
             assert np.array_equal(sb, sc)              # the same forward, the same loss, the same workgroups: the same sums
@@ -416,7 +420,7 @@ def test_fused_forward_backward_step_against_the_four_launch_step(mb, n_envs, ho
     env._dev.learner_set_step_mode("auto")
     assert int(nats[1].cursor.item()) == n_steps * mb and int(nats[2].adam_state[:8].view(torch.int64)[0]) == n_steps
     with pytest.raises(Exception):
-        env._dev.learner_set_step_mode(4)
+        env._dev.learner_set_step_mode(7)
     env.close()
 
 

@@ -16,7 +16,7 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--splits", type=int, default=32)
     ap.add_argument("--phase", default="all", choices=["all", "forward", "backward", "step"])
-    ap.add_argument("--step-mode", default="auto", choices=["auto", "four_launch", "fused", "fused_dw1"],
+    ap.add_argument("--step-mode", default="auto", choices=["auto", "four_launch", "fused", "fused_dw1", "fused_dw1_q", "fused_dw1_r4wgrad"],
                     help="kernel sequence of q1env_learner_sgd_step (include/q1env.h q1env_learner_set_step_mode)")
     ap.add_argument("--two-call", action="store_true", help="the step as q1env_learner_step + q1env_learner_adam instead of q1env_learner_sgd_step")
     args = ap.parse_args()
