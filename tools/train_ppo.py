@@ -58,6 +58,9 @@ ap.add_argument("--checkpoint-dir", default="", help="trainer checkpoints (polic
                                                       "zero_start_total_reward_mean exceeds its previous best - the reference's schedule (q1physrl/train.py:110-133)")
 ap.add_argument("--checkpoint-every", type=int, default=100)
 ap.add_argument("--restore", default="", help="resume from a checkpoint written by --checkpoint-dir (the reference's params['checkpoint_fname'], train.py:110-111)")
+ap.add_argument("--step-mode", default="auto", choices=["auto", "four_launch", "fused", "fused_dw1"],
+                help="kernel sequence of q1env_learner_sgd_step (include/q1env.h q1env_learner_set_step_mode): auto = the fused forward + backward kernel with per-tile "
+                     "dW1 / dW3 products from 2 048 samples on; four_launch = round 4's; fused = the fused kernel, bit-identical to four_launch")
 ap.add_argument("--log-every", type=int, default=5)
 ap.add_argument("--out-stride", type=int, default=1, help="--out keeps every Nth iteration's row (+ every row with an evaluation or a checkpoint, + the last): a 2 989-iteration log is 1.4 MB at stride 1")
 ap.add_argument("--eval-every", type=int, default=0, help="every N iterations: 256 zero-start episodes of 720 ticks on a separate env, stochastic (the "
@@ -87,6 +90,7 @@ env = TensorVectorEnv(cfg, device=local, seed=args.seed + 1 + (1000003 * (int(ck
 pol = P.Q1Policy(discrete_yaw_steps=args.discrete_yaw_steps).cuda()
 fused = P.FusedPolicyForward(pol, env) if args.fused_policy else None
 smp = GpuSampler(env, fused if fused is not None else pol, horizon=args.horizon, use_graph=not args.no_graph, resident=args.resident)
+env._dev.learner_set_step_mode(args.step_mode)
 lrn = ppo.PPOLearner(pol, float(cfg.action_range), lr=args.lr, num_sgd_iter=args.epochs, minibatch_size=args.minibatch,
                      entropy_coeff=args.entropy, kl_target=args.kl_target, seed=args.seed + rank, use_graph=not args.no_graph, fused_loss=args.fused_loss, env=env,
                      discrete_yaw_steps=args.discrete_yaw_steps, autocast_dtype=torch.bfloat16 if args.learner_bf16 else None, fused_adam=not args.no_fused_adam,
