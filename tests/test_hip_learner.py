@@ -424,6 +424,43 @@ def test_fused_forward_backward_step_against_the_four_launch_step(mb, n_envs, ho
     env.close()
 
 
+@pytest.mark.parametrize("mb,n_envs", [(4096, 1024), (32768, 8192)])
+def test_every_step_mode_is_as_close_to_float64_autograd(mb, n_envs):
+    """The gradients q1env_learner_sgd_step leaves, per kernel sequence, against torch autograd through the float64 modules and ppo.ppo_loss on the
+    same minibatch: every tensor within the float16-operand bound the step has always been held to (relative Frobenius error <= 3e-3; VERDICT r5
+    item 7), and the fused kernel with per-tile dW1 / dW3 products no further from float64 than the four-launch step is (its three re-ordered tensors
+    W1, b1, W3 within 1.25 x of the four-launch step's own error) - the products change the summation order, not the accuracy."""
+    import torch
+    from q1physrl_amd import ppo
+    pols = [_policy(5, 2.0)]
+    pols += [copy.deepcopy(pols[0]), copy.deepcopy(pols[0])]
+    env, full, total = _train_batch(n_envs, 8, pols[0])
+    assert total >= mb
+    klc = torch.tensor(0.2, device="cuda")
+    perm = torch.randperm(total, device="cuda")
+    ref = copy.deepcopy(pols[0]).double()
+    idx = perm[:mb]
+    mbatch = {"obs": full["obs"][idx].double(), "old_logits": full["old_logits"][idx].double(), "mouse": full["mouse"][idx].reshape(-1, 1).double(),
+              "logp": full["logp"][idx].double(), "adv": full["adv"][idx].double(), "value": full["value"][idx].double(), "vtarg": full["vtarg"][idx].double(),
+              "keys": ((full["keys_packed"][idx].reshape(-1, 1).long() >> torch.arange(4, device="cuda")) & 1)}
+    loss, _st = ppo.ppo_loss(ref, mbatch, float(env.config.action_range), 0.3, 10.0, 1.0, 0.01, klc.double())
+    loss.backward()
+    err = {}
+    for mode, pol in zip(["four_launch", "fused", "fused_dw1"], pols):
+        env._dev.learner_set_step_mode(mode)
+        nat = ppo.NativeStep(pol, env, mb, splits=32)
+        nat.step(full, perm, 0.3, 10.0, 1.0, 0.01, klc, skip_reduce=True, use_cursor=True, adam=(0.0, (0.9, 0.999), 1e-8))      # lr 0: gradients only
+        torch.cuda.synchronize()
+        err[mode] = {name: _rel(p.grad.double(), q.grad) for (name, p), q in zip(pol.named_parameters(), ref.parameters())}
+        for name, e in err[mode].items():
+            assert e < 3e-3, (mode, name, e)
+    env._dev.learner_set_step_mode("auto")
+    assert err["fused"] == err["four_launch"]                                       # bit-identical gradients
+    for name in err["four_launch"]:
+        assert err["fused_dw1"][name] <= 1.25 * err["four_launch"][name] + 1e-7, (name, err["fused_dw1"][name], err["four_launch"][name])
+    env.close()
+
+
 def test_native_training_learns_strafe_jumping_in_seconds():
     """End-to-end regression of the whole GPU-resident stack (resident sampler + native learner, round 2's hyper-parameters): 200
     iterations = 0.42 G env-steps in ~17 s must take the zero-start reward from ~1 700 (plain running) past 4 200 - strafe-jumping

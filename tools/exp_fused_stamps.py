@@ -52,7 +52,7 @@ print("variant", VARIANT or "0", MODE, "step us", e0.elapsed_time(e1) * 10.0)
 tiles = mb // 32
 per = tiles * 8192                                  # bytes of one network's dW1 product array: the workspace's last two pieces
 names = ["forward image staged + barrier", "forward done", "barrier 1 (all waves forward done)", "backward images staged + barrier", "loss gradient done",
-         "[x|1], dY transposed + stored", "dZ2 phase done", "pass 0: 64 MFMAs done", "pass 0: epilogue done", "pass 1: 64 MFMAs done", "(absolute start stamp)",
+         "[x|1], dY transposed + stored", "dZ2 phase done", "pass 0: 64 MFMAs done", "pass 0: epilogue done", "(slot reused: gap to the previous launch's last wave end, -DQ1_FZ_EXP=512 only)", "(slot reused: absolute start stamp, 10-ns ticks mod 2^24)",
          "wave end"]
 import numpy as np
 for label, k in (("policy network", 0), ("value network", 1)):
@@ -71,4 +71,6 @@ for label, k in (("policy network", 0), ("value network", 1)):
     print(label, "wave starts span %.2f us; last wave end - first wave start = %.2f us" % (st.max() * 0.01, (st * 0.01 + a[:, 11].numpy()).max()))
     print(label, "(us since the wave's start: median / min / max over %d waves)" % tiles)
     for j, nm in enumerate(names):
+        if j in (9, 10):
+            continue                                # (pass 1's two stamps gave their slots to the two diagnostics printed above)
         print(f"  {nm:40s} {a[:, j].median():7.2f} {a[:, j].min():7.2f} {a[:, j].max():7.2f}")

@@ -30,9 +30,8 @@ cat $F/times.jsonl 2>/dev/null
 for m in fused_dw1 four_launch; do echo "# ---- HBM bytes per kernel, $m (tools/profile_learner_bytes.sh r6 $m: rocprofv3 kernel-trace + FETCH_SIZE x 2 + WRITE_SIZE, separate passes)"; cat $F/bytes_$m.txt 2>/dev/null; done
 echo "# ---- phase stamps of the fused kernel (tools/exp_fused_stamps.py --dw1: the diagnostic build, every wave of both networks)"
 grep -v "amdgpu.ids" $F/stamps_dw1.txt 2>/dev/null
-echo "# ---- large-minibatch configuration, whole training runs (tools/train_ppo.py --iters 1300 --envs 16384 --horizon 128 --lr 3e-5 --epochs 8 --minibatch 32768 ...: 665 600 SGD steps each)"
-cat $F/largebatch.txt 2>/dev/null | sed 's/^large-minibatch seed/large-minibatch auto (= fused_dw1) seed/'
-sort -t: -k1,1 $F/largebatch_modes.txt 2>/dev/null | sort -k3,3 -k5,5n
+echo "# ---- large-minibatch configuration, whole training runs (665 600 SGD steps each), 16 seeds x {four_launch, fused_dw1} + fused seeds 0, 1: profiles/r6_largebatch_seed_table.md"
+echo "# ---- AddressSanitizer job of the host side (tools/asan_check.sh; learner sections first, tick-server sections opt-in):"
+tail -9 gpurun_out/r6_asan.log 2>/dev/null
 } > $OUT
-for f in $F/r6_train_ppo_largebatch_fused_seed[01].json; do [ -f $f ] && cp $f profiles/; done
 wc -l $OUT
