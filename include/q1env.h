@@ -464,8 +464,9 @@ int q1env_learner_sgd_step(q1env_t* env, const q1env_learner_net* pi, const q1en
  * only for the 256 x 7 and out x 256 products dW1 / db1 and dW3 - are replaced by those products per 32-sample tile (mode 3); smaller minibatches
  * keep round 4's four launches (mode 1).  2 = the fused kernel with dZ1 and tanh(H2) stored as before: every result bit-identical to mode 1 (what the
  * tests hold the fused kernel to).  Mode 3 differs from 1 / 2 in dW1, db1 and dW3 only, by float32 summation order (per-tile products added in
- * tile order instead of one accumulation chain).  Three launches per step instead of four.  The workspace
- * is the same for every mode; a captured graph bakes the mode in. */
+ * tile order instead of one accumulation chain).  Three launches per step instead of four.  The fused kernel serves minibatches of up to
+ * 262 144 samples: beyond, automatic mode keeps the four launches and modes 2 / 3 are refused by q1env_learner_sgd_step.  The workspace is the
+ * same for every mode; a captured graph bakes the mode in. */
 int q1env_learner_set_step_mode(q1env_t* env, int mode);
 
 /* ---- persistent learner (ABI v5, extended in v6) -------------------------------------------------------------------------------

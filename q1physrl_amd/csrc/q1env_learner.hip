@@ -365,7 +365,11 @@ int q1env_learner_sgd_step(q1env_t* h, const q1env_learner_net* pi, const q1env_
     const Ws w = carve_ws(ws_dev, mb, pi->out_dim, splits);
     // the kernel sequence (q1env_learner_set_step_mode): the fused forward + backward kernel from FUSED_MIN_BATCH samples on
     int mode = h->learner_step_mode;
-    if (mode == 0) mode = mb >= FUSED_MIN_BATCH ? 3 : 1;
+    // (one statistics row per workgroup of eight tiles and network: a minibatch beyond STATS_ROWS / 2 such workgroups - 262 144 samples - keeps the
+    // four launches, whose backward kernel walks its tiles grid-stride)
+    const bool fused_fits = ((mb + 31) / 32 + 7) / 8 * 2 <= (int64_t)STATS_ROWS;
+    if (mode == 0) mode = (mb >= FUSED_MIN_BATCH && fused_fits) ? 3 : 1;
+    if (mode != 1 && !fused_fits) return fail(Q1ENV_ERR_INVALID_ARG, "q1env_learner_sgd_step: the fused kernel serves minibatches up to 262 144 samples (step mode 0 or 1 beyond)");
     if (mode == 1)
         if (int r = launch_forward(h, w, mb, pi, vf, b->obs_dev, b->idx_dev, b->idx_cursor_dev, w.logits, w.value)) return r;
     const float scale = (float)mb * learner_pi_upscale(h), scale_v = (float)mb / learner_value_downscale(h);

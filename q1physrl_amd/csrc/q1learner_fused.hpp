@@ -89,7 +89,7 @@ learner_fwdbwd_kernel(int n, const float* __restrict__ obs, const int64_t* __res
     const size_t tbase = (size_t)tile * TILE_VECS + lane;
 #ifdef Q1_FZ_STAMPS       // diagnostic build (tools/exp_fused_stamps.py): 100 MHz stamps of every wave, left in the array the mode does not use (dW1 products / dZ1)
     const uint64_t stamp0 = wall_clock64();
-    float stamps[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    float stamps[14] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     // the latest wave end of the PREVIOUS launch of this kernel (the diagnostic build launches it twice in a row): how long do the end of one dispatch and
     // the start of the next take?
     unsigned long long* g_last_end = reinterpret_cast<unsigned long long*>(la.stats_rows + 9000);
@@ -379,10 +379,10 @@ learner_fwdbwd_kernel(int n, const float* __restrict__ obs, const int64_t* __res
 #ifdef Q1_FZ_STAMPS
     if (tile_live && lane == 0) {                            // (DW1: the dZ1 array is the unused one)
         stamps[11] = (float)(wall_clock64() - stamp0) * 0.01f;
-        stamps[9] = gap_us;
-        stamps[10] = (float)(stamp0 & 0xFFFFFFull);           // (absolute start, 10-ns ticks modulo 2^24: when did this wave begin, relative to the others?)
+        stamps[12] = gap_us;
+        stamps[13] = (float)(stamp0 & 0xFFFFFFull);           // (absolute start, 10-ns ticks modulo 2^24: when did this wave begin, relative to the others?)
         float* dst = DW1 ? reinterpret_cast<float*>(net.dz1N + (size_t)tile * TILE_VECS) : net.dw1p + (size_t)tile * DW1_TILE_FLOATS;
-        for (int k = 0; k < 12; ++k) dst[k] = stamps[k];
+        for (int k = 0; k < 14; ++k) dst[k] = stamps[k];
     }
     if ((Q1_FZ_EXP & 512) && lane == 0) atomicMax(g_last_end, (unsigned long long)wall_clock64());
     if (Q1_FZ_EXP & 16) la.stats_rows[2560u * 2u + (size_t)blockIdx.x * 512u / 64u + wave] = __uint_as_float(chk ^ __shfl_xor(chk, 17, 64));

@@ -461,6 +461,33 @@ def test_every_step_mode_is_as_close_to_float64_autograd(mb, n_envs):
     env.close()
 
 
+def test_step_modes_beyond_the_fused_kernels_largest_minibatch():
+    """The fused kernel leaves one statistics row per workgroup of eight tiles: 2 048 rows = 262 144 samples per minibatch.  One tile more and automatic
+    mode keeps the four launches (same bits as mode "four_launch"), the fused modes are refused - an error code, not a write past the rows."""
+    import torch
+    from q1physrl_amd import _lib, ppo
+    mb = 262144 + 32
+    pols = [_policy(5, 2.0)]
+    pols.append(copy.deepcopy(pols[0]))
+    env, full, total = _train_batch(2048, 8, pols[0])
+    klc = torch.tensor(0.2, device="cuda")
+    idx = torch.randint(0, total, (mb,), device="cuda")                      # (rows repeat: the minibatch is larger than the train batch)
+    hp = (3e-4, (0.9, 0.999), 1e-8)
+    for mode, pol in zip(["auto", "four_launch"], pols):
+        env._dev.learner_set_step_mode(mode)
+        nat = ppo.NativeStep(pol, env, mb, splits=32)
+        nat.step(full, idx, 0.3, 10.0, 1.0, 0.01, klc, skip_reduce=True, adam=hp)
+        torch.cuda.synchronize()
+    for (name, p), q in zip(pols[0].named_parameters(), pols[1].parameters()):
+        assert torch.equal(p, q) and torch.equal(p.grad, q.grad), name
+    for mode in ("fused", "fused_dw1"):
+        env._dev.learner_set_step_mode(mode)
+        with pytest.raises(_lib.Q1EnvError):
+            nat.step(full, idx, 0.3, 10.0, 1.0, 0.01, klc, skip_reduce=True, adam=hp)
+    env._dev.learner_set_step_mode("auto")
+    env.close()
+
+
 def test_native_training_learns_strafe_jumping_in_seconds():
     """End-to-end regression of the whole GPU-resident stack (resident sampler + native learner, round 2's hyper-parameters): 200
     iterations = 0.42 G env-steps in ~17 s must take the zero-start reward from ~1 700 (plain running) past 4 200 - strafe-jumping

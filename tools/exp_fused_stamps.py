@@ -52,25 +52,23 @@ print("variant", VARIANT or "0", MODE, "step us", e0.elapsed_time(e1) * 10.0)
 tiles = mb // 32
 per = tiles * 8192                                  # bytes of one network's dW1 product array: the workspace's last two pieces
 names = ["forward image staged + barrier", "forward done", "barrier 1 (all waves forward done)", "backward images staged + barrier", "loss gradient done",
-         "[x|1], dY transposed + stored", "dZ2 phase done", "pass 0: 64 MFMAs done", "pass 0: epilogue done", "(slot reused: gap to the previous launch's last wave end, -DQ1_FZ_EXP=512 only)", "(slot reused: absolute start stamp, 10-ns ticks mod 2^24)",
+         "[x|1], dY transposed + stored", "dZ2 phase done", "pass 0: 64 MFMAs done", "pass 0: epilogue done", "pass 1: 64 MFMAs done", "pass 1: epilogue done",
          "wave end"]
 import numpy as np
 for label, k in (("policy network", 0), ("value network", 1)):
     if MODE == "fused":
-        a = nat.ws[nat.ws.numel() - (2 - k) * per: nat.ws.numel() - (1 - k) * per].view(torch.float32).reshape(tiles, 2048)[:, :12].cpu()
+        a = nat.ws[nat.ws.numel() - (2 - k) * per: nat.ws.numel() - (1 - k) * per].view(torch.float32).reshape(tiles, 2048)[:, :14].cpu()
     else:                                           # the dZ1 array of network k (csrc/q1env_learner.hip carve_ws: images, h1, h2, dZ2, dZ1, [x|1], dY, partial sums)
         act = tiles * 16384
         per_net = 152064 + 135168 + 20480 + 4 * act + 2 * tiles * 2048 + 32 * 89 * 1024 * 4
         o = k * per_net + 307712 + 3 * act
-        a = nat.ws[o:o + act].view(torch.float32).reshape(tiles, 4096)[:, :12].cpu()
+        a = nat.ws[o:o + act].view(torch.float32).reshape(tiles, 4096)[:, :14].cpu()
     os.makedirs(os.path.join(ROOT, "gpurun_out", "r6_fused"), exist_ok=True)
     np.save(os.path.join(ROOT, "gpurun_out", "r6_fused", "stamps%s%s_net%d.npy" % (VARIANT, "_dw1" if MODE != "fused" else "", k)), a.numpy())
-    print(label, "first wave start - previous launch's last wave end: min %.2f us, median %.2f" % (a[:, 9].min(), a[:, 9].median()))
-    st = a[:, 10].numpy().astype(np.int64)
+    print(label, "first wave start - previous launch's last wave end: min %.2f us, median %.2f" % (a[:, 12].min(), a[:, 12].median()))
+    st = a[:, 13].numpy().astype(np.int64)
     st = (st - st.min()) % (1 << 24)
     print(label, "wave starts span %.2f us; last wave end - first wave start = %.2f us" % (st.max() * 0.01, (st * 0.01 + a[:, 11].numpy()).max()))
     print(label, "(us since the wave's start: median / min / max over %d waves)" % tiles)
     for j, nm in enumerate(names):
-        if j in (9, 10):
-            continue                                # (pass 1's two stamps gave their slots to the two diagnostics printed above)
         print(f"  {nm:40s} {a[:, j].median():7.2f} {a[:, j].min():7.2f} {a[:, j].max():7.2f}")
