@@ -461,6 +461,36 @@ def test_every_step_mode_is_as_close_to_float64_autograd(mb, n_envs):
     env.close()
 
 
+def test_fused_step_with_products_is_deterministic():
+    """Two runs of 48 steps of the default large-minibatch sequence (fused kernel + per-tile products + shared-operand weight gradients) from the same state on
+    the same rows end on the same bits: no atomics on the data path, fixed summation orders - and no race between the waves that share LDS stages (a race
+    would show up as a run-to-run difference long before it showed up in a tolerance)."""
+    import torch
+    from q1physrl_amd import ppo
+    pols = [_policy(5, 2.0)]
+    pols.append(copy.deepcopy(pols[0]))
+    env, full, total = _train_batch(4096, 8, pols[0])
+    mb = 8192 + 32 * 3 + 5
+    klc = torch.tensor(0.2, device="cuda")
+    g = torch.Generator(device="cuda").manual_seed(7)
+    perms = [torch.randperm(total, device="cuda", generator=g) for _ in range(16)]
+    hp = (3e-4, (0.9, 0.999), 1e-8)
+    env._dev.learner_set_step_mode("auto")
+    for pol in pols:
+        nat = ppo.NativeStep(pol, env, mb, splits=32)
+        for perm in perms:
+            nat.cursor.zero_()
+            for _ in range(total // mb):
+                nat.step(full, perm, 0.3, 10.0, 1.0, 0.01, klc, skip_reduce=True, use_cursor=True, adam=hp)
+        torch.cuda.synchronize()
+        pol._moments = nat.adam_state.clone()
+    for (name, p), q in zip(pols[0].named_parameters(), pols[1].parameters()):
+        assert torch.equal(p, q) and torch.equal(p.grad, q.grad), name
+    assert torch.equal(pols[0]._moments, pols[1]._moments)
+    assert all(torch.isfinite(p).all() for p in pols[0].parameters())
+    env.close()
+
+
 def test_step_modes_beyond_the_fused_kernels_largest_minibatch():
     """The fused kernel leaves one statistics row per workgroup of eight tiles: 2 048 rows = 262 144 samples per minibatch.  One tile more and automatic
     mode keeps the four launches (same bits as mode "four_launch"), the fused modes are refused - an error code, not a write past the rows."""
