@@ -18,6 +18,9 @@
 //                             per 32 768-sample step, same time (profiles/r4_learner_bytes.txt)
 //   learner_reduce_kernel     sums the partials, undoes the tile permutation, scales and writes the gradients in torch layout
 //   learner_images_kernel     (after the optimizer) rebuilds the float16 weight images of both directions from the float32 masters
+// Round 6 (large minibatches, q1env_learner_sgd_step from 2 048 samples on): learner_fwdbwd_kernel (q1learner_fused.hpp) does the first three of
+// these in ONE launch, and learner_wgrad_shared_kernel (below) is the weight-gradient kernel with its h1 operands shared through LDS; the kernels
+// listed here remain the path of small minibatches, of q1env_learner_step / _forward / _backward, and the reference the fused ones are tested against.
 //
 // Why two activation formats: a 32x32x16 MFMA contracts the index its operands hold eight-at-a-time per lane.  The forward and the
 // data-gradient chain contract over hidden units (the C/D layout of one layer - lane = sample - is already the next B operand), the

@@ -5,23 +5,26 @@
 //
 // One workgroup = eight waves = eight 32-sample tiles of one network (two waves per SIMD, 256 registers each), exactly one tile per wave:
 //   phase F   the forward image (W2 x 2 log2 e, W3, layer-1 operands, b2: 157.5 KB) is staged into LDS; every wave runs its tile through
-//             q1pol::mlp_tile_t - the sampler's forward, bit for bit - storing tanh(H1), tanh(H2) in T-format for the weight-gradient kernel
-//             and KEEPING tanh(H2) and the outputs in registers;
+//             q1pol::mlp_tile_t - the sampler's forward, bit for bit - storing tanh(H1) (and, without the products below, tanh(H2)) in T-format for
+//             the weight-gradient kernel and KEEPING tanh(H2) and the outputs in registers;
 //   restage   barrier; the per-sample loss inputs are requested; the transposed images (W2^T 132 KB, W3^T one K-step: 12 KB) replace the
 //             forward image in LDS; barrier;
-//   phase B   the tile's PPO loss gradient from the outputs in registers (q1ppo_loss.hpp, the same function and bits as
-//             learner_backward_kernel<true>), dZ2 = W3^T dY (1 - h2^2) with h2 from registers, dZ1 = W2^T dZ2 (1 - h1^2) with the wave's OWN
-//             h1 vectors read back (L2 hits: written by this wave ~10 us earlier), [x | 1], dY, dZ2 (and dZ1) transposed to N-format on the
-//             matrix pipe and stored for learner_wgrad_kernel, as before.
+//   phase B   the wave's OWN h1 vectors are requested back first (a wave's memory operations complete in order: behind the dZ2 stores they
+//             would wait 5 - 15 us for those stores' acknowledgements on the XCDs whose write path is backed up), then the tile's PPO loss
+//             gradient from the outputs in registers (q1ppo_loss.hpp, the same function and bits as learner_backward_kernel<true>),
+//             dZ2 = W3^T dY (1 - h2^2) with h2 from registers, dZ1 = W2^T dZ2 (1 - h1^2); [x | 1], dY, dZ2 (and dZ1) transposed to N-format on
+//             the matrix pipe and stored for the weight-gradient kernel, as before.
 // DW1 = false: every array the weight-gradient kernel reads holds the same bits as after the two-launch sequence, so the whole step is
-//   bit-identical to round 4's four-launch step (tests/test_hip_learner.py holds it to that).
-// DW1 = true: dZ1 is not stored at all (33.5 MB per network written and read back for a 256 x 7 product).  Each wave multiplies its tile's
-//   dZ1^T by [x | 1] right where dZ1 is produced - one more pair of matrix instructions per 32-unit tile, operands already in registers -
-//   and stores the 32 x 7 partial products (float32, 8 KB per tile); learner_wgrad_kernel<true> adds its split's tiles up in tile order
-//   (deterministic; float32 additions per tile instead of one accumulation chain, so dW1 / db1 differ from the four-launch step's in the
-//   last bits - everything else is still identical).
-// Traffic of a 32 768-sample step (profiles/r6_learner_fused.txt): the h1 / h2 re-read (68 MB), the logits / value round trip and, with DW1,
-// dZ1 (67 MB both ways) are gone.
+//   bit-identical to round 4's four-launch step (tests/test_hip_learner.py holds it to that; two whole training runs end on round 5's numbers).
+// DW1 = true ("products"): neither dZ1 nor tanh(H2) is stored at all - 2 x 33.5 MB per network written and read back for a 256 x 7 and an
+//   out x 256 product.  Each wave multiplies its tile's dZ1^T by [x | 1] and its dY^T by tanh(H2) right where the operands sit in registers -
+//   one more pair of matrix instructions per 32-unit tile each - and stores the partial products (float32: 8 KB of dW1 / db1, 10 KB (policy) or
+//   2 KB (value network) of dW3 per tile); learner_wgrad_shared_kernel adds its split's tiles up in tile order (deterministic; float32
+//   additions per tile instead of one accumulation chain, so dW1, db1 and dW3 differ from the four-launch step's in the last bits - everything
+//   else is still identical).  The operand slots of both products are permuted so that every lane stores the same 16-byte piece: a branch
+//   around a store costs the register allocator 80 - 160 registers in these fully unrolled phases (tests/test_fused_learner_isa.py).
+// A 32 768-sample step (profiles/r6_learner_fused.txt): 98.8 -> 81 - 83 us, 442 -> 318 MB.  The saturation report is per WORKGROUP: per wave it
+// was 2 x 2 048 same-address atomics per launch, which kept the dispatch open 14 us after its last wave had ended.
 #pragma once
 #include "q1learner.hpp"
 
