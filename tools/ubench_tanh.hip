@@ -9,6 +9,10 @@
 //      transcendental, no reciprocal
 //   D  no transcendental at all: 2^y by exponent-field arithmetic + a degree-3 polynomial of the fraction, then B's reciprocal-free
 //      tail is impossible (a division remains), so D = polynomial 2^y + v_rcp_f32
+//   E  (round 6) v_exp_f32 kept, the reciprocal WITHOUT v_rcp_f32: integer seed (magic - bits) + two packed Newton steps, the second merged
+//      into the final 1 - 2 r: 2 v_sub_u32 + 3 v_pk_fma_f32 + 2 v_pk_mul_f32 per pair against 2 quarter-rate v_rcp_f32 + 1 v_pk_fma_f32
+//   F  (round 6) ONE v_rcp_f32 per FOUR activations (simultaneous inversion: r = 1 / (d0 d1 d2 d3), 1 / d0 = r d1 (d2 d3), ...); the exponent
+//      is clamped to 30 so that the product of four stays finite
 // Per variant: ns per activation per wave at 1 / 2 waves per SIMD (256 workgroups x 256 / 512 threads), and the largest error of the
 // f16 result against tanh in double over z in [-9, 9] (the f16 operand the next layer consumes has 2^-11 relative resolution).
 // Build + run: hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/ubench_tanh.hip -o gpurun_scratch/ubench_tanh && ./gpurun_scratch/ubench_tanh
@@ -73,6 +77,36 @@ template <> __device__ __forceinline__ f16x2 act_pair<3>(f32x2 z) {      // D: p
     return __builtin_convertvector(1.0f - 2.0f * r, f16x2);
 }
 
+template <> __device__ __forceinline__ f16x2 act_pair<4>(f32x2 z) {      // E: exp2 + integer-seeded packed Newton reciprocal
+    f32x2 d = {__builtin_amdgcn_exp2f(z[0]), __builtin_amdgcn_exp2f(z[1])};
+    d = d + 1.0f;
+    f32x2 r = {__uint_as_float(0x7EF311C7u - __float_as_uint(d[0])), __uint_as_float(0x7EF311C7u - __float_as_uint(d[1]))};   // |r d - 1| <= ~0.06 .. 0.12
+    f32x2 t = __builtin_elementwise_fma(-d, r, (f32x2)2.0f);
+    r = r * t;                                                           // first Newton step
+    t = __builtin_elementwise_fma(-d, r, (f32x2)2.0f);                   // second one, merged: 1 - 2 r t
+    const f32x2 m = r * -2.0f;
+    return __builtin_convertvector(__builtin_elementwise_fma(m, t, (f32x2)1.0f), f16x2);
+}
+// F works on two pairs at a time (act_quad below); the pair form exists for the accuracy kernel only
+__device__ __forceinline__ void act_quad(f32x2 za, f32x2 zb, f16x2& ha, f16x2& hb) {
+    f32x2 da = {__builtin_amdgcn_exp2f(__builtin_amdgcn_fmed3f(za[0], -128.0f, 30.0f)), __builtin_amdgcn_exp2f(__builtin_amdgcn_fmed3f(za[1], -128.0f, 30.0f))};
+    f32x2 db = {__builtin_amdgcn_exp2f(__builtin_amdgcn_fmed3f(zb[0], -128.0f, 30.0f)), __builtin_amdgcn_exp2f(__builtin_amdgcn_fmed3f(zb[1], -128.0f, 30.0f))};
+    da = da + 1.0f; db = db + 1.0f;
+    const f32x2 lo = {da[0], db[0]}, hi = {da[1], db[1]};
+    const f32x2 pp = lo * hi;                                            // (da0 da1, db0 db1)
+    const float r = __builtin_amdgcn_rcpf(pp[0] * pp[1]);
+    const f32x2 rr = (f32x2){pp[1], pp[0]} * r;                          // 1 / (da0 da1), 1 / (db0 db1)
+    const f32x2 qa = __builtin_shufflevector(da, da, 1, 0) * rr[0];      // 1 / da0, 1 / da1
+    const f32x2 qb = __builtin_shufflevector(db, db, 1, 0) * rr[1];
+    ha = __builtin_convertvector(__builtin_elementwise_fma(qa, (f32x2)-2.0f, (f32x2)1.0f), f16x2);
+    hb = __builtin_convertvector(__builtin_elementwise_fma(qb, (f32x2)-2.0f, (f32x2)1.0f), f16x2);
+}
+template <> __device__ __forceinline__ f16x2 act_pair<5>(f32x2 z) {
+    f16x2 ha, hb;
+    act_quad(z, z, ha, hb);
+    return ha;
+}
+
 template <int V>
 __global__ void __launch_bounds__(512) bench(float* out, float seed, int iters) {
     // 16 independent pairs per lane (the kernel activates 16 accumulator registers of a tile at a time)
@@ -82,9 +116,17 @@ __global__ void __launch_bounds__(512) bench(float* out, float seed, int iters) 
     for (int i = 0; i < iters; ++i) {
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-            const f16x2 h = act_pair<V>(z[k]);
-            z[k][0] += (float)h[0] * 1e-3f;                              // keep a dependence so nothing is hoisted
-            z[k][1] -= (float)h[1] * 1e-3f;
+            if constexpr (V == 5) {
+                if (k & 1) continue;
+                f16x2 h, g;
+                act_quad(z[k], z[k + 1], h, g);
+                z[k][0] += (float)h[0] * 1e-3f; z[k][1] -= (float)h[1] * 1e-3f;
+                z[k + 1][0] += (float)g[0] * 1e-3f; z[k + 1][1] -= (float)g[1] * 1e-3f;
+            } else {
+                const f16x2 h = act_pair<V>(z[k]);
+                z[k][0] += (float)h[0] * 1e-3f;                          // keep a dependence so nothing is hoisted
+                z[k][1] -= (float)h[1] * 1e-3f;
+            }
         }
     }
     for (int k = 0; k < 8; ++k) acc += z[k][0] + z[k][1];
@@ -145,5 +187,7 @@ int main() {
     run<1>("B Pade [7/6], packed Horner + 1 rcp", d_out);
     run<2>("C exp2 + degree-6 polynomial 1/(1+t)", d_out);
     run<3>("D polynomial 2^y (no v_exp) + rcp", d_out);
+    run<4>("E exp2 + integer seed + 2 packed Newton steps", d_out);
+    run<5>("F exp2 + ONE rcp per four (simultaneous inv.)", d_out);
     return 0;
 }
